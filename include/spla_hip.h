@@ -1,0 +1,93 @@
+/*
+ * spla_hip.h — the kernel-level C ABI of the MI355X (gfx950) backend: the "thin C-ABI dispatch" a host-side
+ * RegistryAlgo calls once its operands are device-resident.
+ *
+ * Every entry point replaces the body of one reference accelerator algorithm `execute()` (the OpenCL ones,
+ * which are NOT ported; the semantics are those of the CPU algorithms, the parity oracle):
+ *
+ *   splahip_mxv_masked   <- Algo_mxv_masked_cl<T>::execute   reference src/opencl/cl_mxv.hpp:65-74
+ *                           semantics: Algo_mxv_masked_cpu   reference src/cpu/cpu_mxv.hpp:56-106
+ *   splahip_vxm_masked   <- Algo_vxm_masked_cl<T>::execute   reference src/opencl/cl_vxm.hpp:60-173
+ *                           semantics: Algo_vxm_masked_cpu   reference src/cpu/cpu_vxm.hpp:58-128
+ *   splahip_mxm          <- (no accelerated version exists)  reference src/opencl/cl_algo_registry.cpp:82-95
+ *                           semantics: Algo_mxm_cpu          reference src/cpu/cpu_mxm.hpp:58-117
+ *   splahip_mxmT_masked  <- Algo_mxmT_masked_cl<T>::execute  reference src/opencl/cl_mxmT_masked.hpp:60-127
+ *                           semantics: Algo_mxmT_masked_cpu  reference src/cpu/cpu_mxmT_masked.hpp:56-128
+ *   splahip_csr_plan_*   <- cl_csr_init (device CSR upload)  reference src/opencl/cl_format_csr.hpp:40-59
+ *   splahip_malloc/free/memcpy_* <- cl::Buffer create/read   reference src/opencl/cl_format_dense_vec.hpp:40-88
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all `d_` pointers are DEVICE pointers (hipMalloc'ed by anyone: this
+ *     library, PyTorch-ROCm, ...); elements are 4-byte words typed by `splahip_type`; indices are uint32
+ *     (reference include/spla/config.hpp:56); scalars (init) travel as their uint32 bit pattern.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls enqueue work and return;
+ *     the only calls that block are the ones documented as returning a host-side count.
+ *   - every function returns 0 on success or a non-zero splahip_status; splahip_last_error() describes it.
+ *   - there is NO CPU fallback behind this ABI: without a usable gfx950 device every call fails loudly.
+ */
+#ifndef SPLA_HIP_H
+#define SPLA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "spla_hip_ops.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum splahip_status {
+    SPLAHIP_OK               = 0,
+    SPLAHIP_ERROR            = 1, /* HIP runtime error, see splahip_last_error()              */
+    SPLAHIP_NO_DEVICE        = 2, /* no usable gfx950 device                                   */
+    SPLAHIP_INVALID_ARGUMENT = 6, /* bad pointer / size / id (same code as spla Status)        */
+    SPLAHIP_NOT_IMPLEMENTED  = 1024
+} splahip_status;
+
+/* ---- runtime -------------------------------------------------------------------------------------------- */
+int         splahip_device_count(void);
+int         splahip_init(int device);             /* select device, check it is usable; idempotent */
+int         splahip_device_info(char* buffer, int length);
+const char* splahip_last_error(void);
+int         splahip_version(void);
+
+int splahip_malloc(void** d_ptr, size_t bytes);
+int splahip_free(void* d_ptr);
+int splahip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream); /* async on stream      */
+int splahip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream); /* blocks until landed  */
+int splahip_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream); /* async on stream      */
+int splahip_memset32(void* d_dst, uint32_t word, size_t count, void* stream);       /* fill with a 4-byte word */
+int splahip_stream_sync(void* stream);
+
+/* ---- device CSR launch plan ---------------------------------------------------------------------------------
+ * A plan is the row-block decomposition of one device-resident CSR matrix (it is part of the "AccCsr"
+ * decoration, built once per matrix, reused by every mxv/vxm call on it).  Built on the device from d_Ap.
+ * Row blocks are runs of consecutive rows whose entries start inside one 2048-entry window of the nnz
+ * stream and count at most 1024 rows: see DESIGN.md "CSR row blocks".                                        */
+typedef struct splahip_plan_s* splahip_plan;
+
+int splahip_csr_plan_create(splahip_plan* plan, uint32_t n_rows, uint32_t nnz, const uint32_t* d_Ap, void* stream);
+int splahip_csr_plan_destroy(splahip_plan plan);
+/* n_blocks: row blocks; n_long: rows longer than the LDS stage (handled by the long-row path) */
+int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_blocks, uint32_t* n_long);
+
+/* ---- masked SpMV (pull): r[i] = select(mask[i]) ? fold_k add(., mult(Ax[k], v[Aj[k]])) from init : init -----
+ * r, mask: n_rows words; v: n_cols words; all n_rows outputs are written (reference cpu_mxv.hpp:88-103).
+ * early_exit != 0: a row's fold stops at the first partial result != init (reference cpu_mxv.hpp:98).
+ * The matrix may be a row block of a larger matrix (1-D row decomposition): Aj holds GLOBAL column ids and
+ * v is the full gathered vector.                                                                             */
+int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_cols,
+                       const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax,
+                       const void* d_mask, const void* d_v, void* d_r,
+                       int op_mult, int op_add, int op_select, uint32_t init_bits, int early_exit,
+                       void* stream);
+
+/* name of the kernel variant the call above would launch for these arguments (for profiles / DESIGN.md) */
+const char* splahip_mxv_variant(int type, int op_mult, int op_add, int early_exit);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SPLA_HIP_H */

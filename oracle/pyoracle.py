@@ -1,0 +1,332 @@
+"""pyoracle — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+numpy-level drivers for the two CPU checkers:
+
+* ``Oracle``    — oracle/liboracle.so, this repo's plain-C restatement of the reference's sequential algorithms
+                  (oracle/oracle.c; kind "port").
+* ``Reference`` — oracle/_ref/libspla_ref.so, the GENUINE reference CPU backend compiled by oracle/Makefile from
+                  /root/reference (kind "reference"), driven through the reference's own C ABI (include/spla.h of
+                  the reference) plus the few helpers of oracle/ref_shim.cpp.
+
+Both expose the same four calls over plain CSR / dense / COO numpy arrays of 4-byte words, so a test can check
+HIP == Oracle == Reference on the same inputs.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg may import this module; the product package (spla_amd) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ORACLE_SO = HERE / "liboracle.so"
+REF_SO = HERE / "_ref" / "libspla_ref.so"
+
+TYPE = {"INT": 0, "UINT": 1, "FLOAT": 2}
+TYPE_NAME = {0: "INT", 1: "UINT", 2: "FLOAT"}
+TYPE_NP = {0: np.int32, 1: np.uint32, 2: np.float32}
+BINOPS = ["PLUS", "MINUS", "MULT", "DIV", "MINUS_POW2", "FIRST", "SECOND", "BONE", "MIN", "MAX", "LOR", "LAND",
+          "BOR", "BAND", "BXOR"]
+SELOPS = ["EQZERO", "NQZERO", "GTZERO", "GEZERO", "LTZERO", "LEZERO", "ALWAYS", "NEVER"]
+
+_u32p = C.POINTER(C.c_uint32)
+
+
+def build(force: bool = False) -> None:
+    """Compile liboracle.so (and, when /root/reference is present, oracle/_ref/libspla_ref.so)."""
+    if force or not ORACLE_SO.exists() or ORACLE_SO.stat().st_mtime < (HERE / "oracle.c").stat().st_mtime:
+        subprocess.run(["make", "-C", str(HERE), "port"], check=True, capture_output=True)
+    if Path("/root/reference/src/exec.cpp").exists() and (force or not REF_SO.exists()):
+        subprocess.run(["make", "-C", str(HERE), "-j8", "ref"], check=True, capture_output=True)
+
+
+def _tid(t) -> int:
+    return TYPE[t.upper()] if isinstance(t, str) else int(t)
+
+
+def _bid(op) -> int:
+    return BINOPS.index(op.upper()) if isinstance(op, str) else int(op)
+
+
+def _sid(op) -> int:
+    return SELOPS.index(op.upper()) if isinstance(op, str) else int(op)
+
+
+def words(a, t=None) -> np.ndarray:
+    """View/convert an array as contiguous uint32 words (values of element type t keep their bit pattern)."""
+    a = np.asarray(a)
+    if t is not None:
+        a = a.astype(TYPE_NP[_tid(t)], copy=False)
+    assert a.dtype.itemsize == 4, a.dtype
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def bits(value, t) -> int:
+    return int(np.array([value]).astype(TYPE_NP[_tid(t)]).view(np.uint32)[0])
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(_u32p)
+
+
+class Oracle:
+    """Plain-C restatement (oracle/oracle.c)."""
+
+    kind = "port"
+
+    def __init__(self):
+        build()
+        lib = C.CDLL(str(ORACLE_SO))
+        lib.oracle_binop.restype = C.c_uint32
+        lib.oracle_binop.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32]
+        lib.oracle_selop.restype = C.c_int
+        lib.oracle_selop.argtypes = [C.c_int, C.c_int, C.c_uint32]
+        lib.oracle_mxv_masked.restype = None
+        lib.oracle_mxv_masked.argtypes = [C.c_int, C.c_uint32] + [_u32p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int]
+        lib.oracle_vxm_masked.restype = C.c_uint32
+        lib.oracle_vxm_masked.argtypes = [C.c_int, C.c_uint32, C.c_uint32] + [_u32p] * 4 + [C.c_uint32] + [_u32p] * 4 + [C.c_int] * 3
+        lib.oracle_mxm.restype = None
+        lib.oracle_mxm.argtypes = [C.c_int, C.c_uint32, C.c_uint32] + [_u32p] * 7 + [C.POINTER(_u32p)] * 2 + [C.c_int, C.c_int, C.c_uint32]
+        lib.oracle_mxmT_masked.restype = None
+        lib.oracle_mxmT_masked.argtypes = [C.c_int, C.c_uint32] + [_u32p] * 10 + [C.POINTER(_u32p)] * 2 + [C.c_int, C.c_int, C.c_int, C.c_uint32]
+        lib.oracle_free.restype = None
+        lib.oracle_free.argtypes = [C.c_void_p]
+        self.lib = lib
+
+    def binop(self, t, op, a, b):
+        t = _tid(t)
+        return np.array([self.lib.oracle_binop(t, _bid(op), bits(a, t), bits(b, t))], dtype=np.uint32).view(TYPE_NP[t])[0]
+
+    def mxv_masked(self, t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, init, early_exit=False):
+        t = _tid(t)
+        Ap, Aj, Ax, mask, v = words(Ap), words(Aj), words(Ax, t), words(mask, t), words(v, t)
+        assert len(Ap) == n_rows + 1 and len(mask) == n_rows and len(v) == n_cols
+        r = np.empty(n_rows, dtype=np.uint32)
+        self.lib.oracle_mxv_masked(t, n_rows, _p(Ap), _p(Aj), _p(Ax), _p(mask), _p(v), _p(r), _bid(op_mult),
+                                   _bid(op_add), _sid(op_select), bits(init, t), 1 if early_exit else 0)
+        return r.view(TYPE_NP[t])
+
+    def vxm_masked(self, t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, op_mult, op_add, op_select, init=0):
+        t = _tid(t)
+        Ap, Aj, Ax, mask, vi, vx = words(Ap), words(Aj), words(Ax, t), words(mask, t), words(vi), words(vx, t)
+        assert len(mask) == n_cols and len(vi) == len(vx)
+        ri = np.empty(max(n_cols, 1), dtype=np.uint32)
+        rx = np.empty(max(n_cols, 1), dtype=np.uint32)
+        n = self.lib.oracle_vxm_masked(t, n_rows, n_cols, _p(Ap), _p(Aj), _p(Ax), _p(mask), len(vi), _p(vi), _p(vx),
+                                       _p(ri), _p(rx), _bid(op_mult), _bid(op_add), _sid(op_select))
+        return ri[:n].copy(), rx[:n].copy().view(TYPE_NP[t])
+
+    def _take(self, Rp, pj, px, t):
+        n = int(Rp[-1])
+        if n:
+            Rj = np.ctypeslib.as_array(pj, shape=(n,)).copy()
+            Rx = np.ctypeslib.as_array(px, shape=(n,)).copy().view(TYPE_NP[t])
+        else:
+            Rj, Rx = np.empty(0, np.uint32), np.empty(0, TYPE_NP[t])
+        self.lib.oracle_free(pj)
+        self.lib.oracle_free(px)
+        return Rp, Rj, Rx
+
+    def mxm(self, t, a_rows, b_cols, A, B, op_mult, op_add, init):
+        """A, B: (Ap, Aj, Ax) CSR triples.  Returns the CSR triple of R."""
+        t = _tid(t)
+        Ap, Aj, Ax = words(A[0]), words(A[1]), words(A[2], t)
+        Bp, Bj, Bx = words(B[0]), words(B[1]), words(B[2], t)
+        Rp = np.empty(a_rows + 1, dtype=np.uint32)
+        pj, px = _u32p(), _u32p()
+        self.lib.oracle_mxm(t, a_rows, b_cols, _p(Ap), _p(Aj), _p(Ax), _p(Bp), _p(Bj), _p(Bx), _p(Rp), C.byref(pj),
+                            C.byref(px), _bid(op_mult), _bid(op_add), bits(init, t))
+        return self._take(Rp, pj, px, t)
+
+    def mxmT_masked(self, t, n_rows, M, A, B, op_mult, op_add, op_select, init):
+        t = _tid(t)
+        Mp, Mj, Mx = words(M[0]), words(M[1]), words(M[2], t)
+        Ap, Aj, Ax = words(A[0]), words(A[1]), words(A[2], t)
+        Bp, Bj, Bx = words(B[0]), words(B[1]), words(B[2], t)
+        Rp = np.empty(n_rows + 1, dtype=np.uint32)
+        pj, px = _u32p(), _u32p()
+        self.lib.oracle_mxmT_masked(t, n_rows, _p(Mp), _p(Mj), _p(Mx), _p(Ap), _p(Aj), _p(Ax), _p(Bp), _p(Bj), _p(Bx),
+                                    _p(Rp), C.byref(pj), C.byref(px), _bid(op_mult), _bid(op_add), _sid(op_select),
+                                    bits(init, t))
+        return self._take(Rp, pj, px, t)
+
+
+def have_reference() -> bool:
+    return REF_SO.exists()
+
+
+class Reference:
+    """The genuine reference CPU backend (oracle/_ref/libspla_ref.so) behind the same numpy-level calls."""
+
+    kind = "reference"
+
+    def __init__(self):
+        build()
+        if not REF_SO.exists():
+            raise FileNotFoundError(f"{REF_SO} missing (built only where /root/reference exists)")
+        lib = C.CDLL(str(REF_SO))
+        self.lib = lib
+        vp = C.c_void_p
+        for name in ("spla_Type_INT", "spla_Type_UINT", "spla_Type_FLOAT"):
+            getattr(lib, name).restype = vp
+        lib.refshim_descriptor_make.restype = vp
+        lib.refshim_descriptor_make.argtypes = [C.c_int, C.c_int]
+        lib.refshim_matrix_lil_count.restype = C.c_uint64
+        lib.refshim_matrix_lil_count.argtypes = [vp]
+        lib.refshim_matrix_lil_read.argtypes = [vp, _u32p, _u32p, _u32p]
+        lib.refshim_vector_dense_read.argtypes = [vp, _u32p]
+        lib.refshim_vector_dense_write.argtypes = [vp, _u32p]
+        lib.spla_RefCnt_unref.argtypes = [vp]
+        lib.spla_MemView_make.argtypes = [C.POINTER(vp), vp, C.c_size_t, C.c_int]
+        lib.spla_MemView_get_buffer.argtypes = [vp, C.POINTER(vp)]
+        lib.spla_MemView_get_size.argtypes = [vp, C.POINTER(C.c_size_t)]
+        lib.spla_Scalar_make.argtypes = [C.POINTER(vp), vp]
+        lib.spla_Scalar_set_int.argtypes = [vp, C.c_int]
+        lib.spla_Scalar_set_uint.argtypes = [vp, C.c_uint]
+        lib.spla_Scalar_set_float.argtypes = [vp, C.c_float]
+        lib.spla_Vector_make.argtypes = [C.POINTER(vp), C.c_uint, vp]
+        lib.spla_Vector_build.argtypes = [vp, vp, vp]
+        lib.spla_Vector_read.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+        lib.spla_Matrix_make.argtypes = [C.POINTER(vp), C.c_uint, C.c_uint, vp]
+        lib.spla_Matrix_build.argtypes = [vp, vp, vp, vp]
+        lib.spla_Exec_mxv_masked.argtypes = [vp] * 10
+        lib.spla_Exec_vxm_masked.argtypes = [vp] * 10
+        lib.spla_Exec_mxm.argtypes = [vp] * 8
+        lib.spla_Exec_mxmT_masked.argtypes = [vp] * 10
+        lib.refshim_force_cpu()
+        self._types = {0: lib.spla_Type_INT(), 1: lib.spla_Type_UINT(), 2: lib.spla_Type_FLOAT()}
+
+    # ---- object helpers ---------------------------------------------------------------------------------------
+    def _ok(self, status, what):
+        if status != 0:
+            raise RuntimeError(f"reference call {what} returned status {status}")
+
+    def _op(self, kind, name, t):
+        fn = getattr(self.lib, f"spla_Op{kind}_{name}_{TYPE_NAME[t]}")
+        fn.restype = C.c_void_p
+        return fn()
+
+    def _scalar(self, value, t):
+        h = C.c_void_p()
+        self._ok(self.lib.spla_Scalar_make(C.byref(h), self._types[t]), "Scalar_make")
+        if t == 0:
+            self.lib.spla_Scalar_set_int(h, int(np.int32(value)))
+        elif t == 1:
+            self.lib.spla_Scalar_set_uint(h, int(np.uint32(value)))
+        else:
+            self.lib.spla_Scalar_set_float(h, float(np.float32(value)))
+        return h
+
+    def _view(self, arr: np.ndarray):
+        h = C.c_void_p()
+        self._ok(self.lib.spla_MemView_make(C.byref(h), arr.ctypes.data_as(C.c_void_p), arr.nbytes, 0), "MemView_make")
+        return h
+
+    def _unref(self, *handles):
+        for h in handles:
+            if h:
+                self.lib.spla_RefCnt_unref(h)
+
+    def _matrix(self, t, n_rows, n_cols, Ap, Aj, Ax):
+        h = C.c_void_p()
+        self._ok(self.lib.spla_Matrix_make(C.byref(h), n_rows, n_cols, self._types[t]), "Matrix_make")
+        Ap = words(Ap)
+        Ai = np.repeat(np.arange(n_rows, dtype=np.uint32), np.diff(Ap.astype(np.int64)))
+        Aj, Ax = words(Aj), words(Ax, t)
+        v1, v2, v3 = self._view(Ai), self._view(Aj), self._view(Ax)
+        self._ok(self.lib.spla_Matrix_build(h, v1, v2, v3), "Matrix_build")
+        self._unref(v1, v2, v3)
+        return h
+
+    def _dense_vector(self, t, data):
+        data = words(data, t)
+        h = C.c_void_p()
+        self._ok(self.lib.spla_Vector_make(C.byref(h), len(data), self._types[t]), "Vector_make")
+        self._ok(self.lib.refshim_vector_dense_write(h, _p(data)), "dense_write")
+        return h
+
+    def _empty_vector(self, t, n):
+        h = C.c_void_p()
+        self._ok(self.lib.spla_Vector_make(C.byref(h), n, self._types[t]), "Vector_make")
+        return h
+
+    def _read_lil(self, h, n_rows, t):
+        n = int(self.lib.refshim_matrix_lil_count(h))
+        Rp = np.empty(n_rows + 1, np.uint32)
+        Rj = np.empty(max(n, 1), np.uint32)
+        Rx = np.empty(max(n, 1), np.uint32)
+        self._ok(self.lib.refshim_matrix_lil_read(h, _p(Rp), _p(Rj), _p(Rx)), "lil_read")
+        return Rp, Rj[:n].copy(), Rx[:n].copy().view(TYPE_NP[t])
+
+    # ---- the four operations ----------------------------------------------------------------------------------
+    def mxv_masked(self, t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, init, early_exit=False):
+        t = _tid(t)
+        M = self._matrix(t, n_rows, n_cols, Ap, Aj, Ax)
+        hm, hv, hr = self._dense_vector(t, mask), self._dense_vector(t, v), self._empty_vector(t, n_rows)
+        hi = self._scalar(init, t)
+        desc = self.lib.refshim_descriptor_make(1 if early_exit else 0, 0)
+        self._ok(self.lib.spla_Exec_mxv_masked(hr, hm, M, hv, self._op("Binary", BINOPS[_bid(op_mult)], t),
+                                               self._op("Binary", BINOPS[_bid(op_add)], t),
+                                               self._op("Select", SELOPS[_sid(op_select)], t), hi, desc, None), "Exec_mxv_masked")
+        r = np.empty(n_rows, np.uint32)
+        self._ok(self.lib.refshim_vector_dense_read(hr, _p(r)), "dense_read")
+        self._unref(M, hm, hv, hr, hi, desc)
+        return r.view(TYPE_NP[t])
+
+    def vxm_masked(self, t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, op_mult, op_add, op_select, init=0):
+        t = _tid(t)
+        M = self._matrix(t, n_rows, n_cols, Ap, Aj, Ax)
+        hm, hr = self._dense_vector(t, mask), self._empty_vector(t, n_cols)
+        hv = self._empty_vector(t, n_rows)
+        vi, vx = words(vi), words(vx, t)
+        k1, k2 = self._view(vi), self._view(vx)
+        self._ok(self.lib.spla_Vector_build(hv, k1, k2), "Vector_build")
+        hi = self._scalar(init, t)
+        self._ok(self.lib.spla_Exec_vxm_masked(hr, hm, hv, M, self._op("Binary", BINOPS[_bid(op_mult)], t),
+                                               self._op("Binary", BINOPS[_bid(op_add)], t),
+                                               self._op("Select", SELOPS[_sid(op_select)], t), hi, None, None), "Exec_vxm_masked")
+        rk, rv = C.c_void_p(), C.c_void_p()
+        self._ok(self.lib.spla_Vector_read(hr, C.byref(rk), C.byref(rv)), "Vector_read")
+        buf, size = C.c_void_p(), C.c_size_t()
+        self.lib.spla_MemView_get_buffer(rk, C.byref(buf))
+        self.lib.spla_MemView_get_size(rk, C.byref(size))
+        n = size.value // 4
+        ri = np.ctypeslib.as_array(C.cast(buf, _u32p), shape=(n,)).copy() if n else np.empty(0, np.uint32)
+        self.lib.spla_MemView_get_buffer(rv, C.byref(buf))
+        rx = np.ctypeslib.as_array(C.cast(buf, _u32p), shape=(n,)).copy() if n else np.empty(0, np.uint32)
+        self._unref(rk, rv, k1, k2, M, hm, hr, hv, hi)
+        return ri, rx.view(TYPE_NP[t])
+
+    def mxm(self, t, a_rows, b_cols, A, B, op_mult, op_add, init):
+        t = _tid(t)
+        a_cols = len(B[0]) - 1
+        hA = self._matrix(t, a_rows, a_cols, *A)
+        hB = self._matrix(t, a_cols, b_cols, *B)
+        hR = C.c_void_p()
+        self._ok(self.lib.spla_Matrix_make(C.byref(hR), a_rows, b_cols, self._types[t]), "Matrix_make")
+        hi = self._scalar(init, t)
+        self._ok(self.lib.spla_Exec_mxm(hR, hA, hB, self._op("Binary", BINOPS[_bid(op_mult)], t),
+                                        self._op("Binary", BINOPS[_bid(op_add)], t), hi, None, None), "Exec_mxm")
+        out = self._read_lil(hR, a_rows, t)
+        self._unref(hA, hB, hR, hi)
+        return out
+
+    def mxmT_masked(self, t, n_rows, M, A, B, op_mult, op_add, op_select, init, n_cols=None, inner=None):
+        t = _tid(t)
+        b_rows = len(B[0]) - 1
+        n_cols = b_rows if n_cols is None else n_cols
+        inner = int(max(np.max(A[1], initial=0), np.max(B[1], initial=0))) + 1 if inner is None else inner
+        hM = self._matrix(t, n_rows, n_cols, *M)
+        hA = self._matrix(t, n_rows, inner, *A)
+        hB = self._matrix(t, b_rows, inner, *B)
+        hR = C.c_void_p()
+        self._ok(self.lib.spla_Matrix_make(C.byref(hR), n_rows, n_cols, self._types[t]), "Matrix_make")
+        hi = self._scalar(init, t)
+        self._ok(self.lib.spla_Exec_mxmT_masked(hR, hM, hA, hB, self._op("Binary", BINOPS[_bid(op_mult)], t),
+                                                self._op("Binary", BINOPS[_bid(op_add)], t),
+                                                self._op("Select", SELOPS[_sid(op_select)], t), hi, None, None), "Exec_mxmT_masked")
+        out = self._read_lil(hR, n_rows, t)
+        self._unref(hM, hA, hB, hR, hi)
+        return out

@@ -1,0 +1,78 @@
+"""ctypes binding of libspla_amd.so's kernel-level C ABI (include/spla_hip.h).
+
+There is no CPU fallback: if the shared library is missing this module raises at import of the symbols, and every
+call checks the returned status and raises ``SplaHipError`` with the library's own message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libspla_amd.so"
+
+
+class SplaHipError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"splahip status {status}: {message}")
+        self.status = status
+
+
+_u32p = C.POINTER(C.c_uint32)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); restype int == status unless listed in _RAW
+_SIGNATURES = {
+    "splahip_device_count": (C.c_int, []),
+    "splahip_init": (C.c_int, [C.c_int]),
+    "splahip_device_info": (C.c_int, [C.c_char_p, C.c_int]),
+    "splahip_last_error": (C.c_char_p, []),
+    "splahip_version": (C.c_int, []),
+    "splahip_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
+    "splahip_free": (C.c_int, [_vp]),
+    "splahip_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "splahip_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "splahip_memcpy_d2d": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "splahip_memset32": (C.c_int, [_vp, C.c_uint32, C.c_size_t, _vp]),
+    "splahip_stream_sync": (C.c_int, [_vp]),
+    "splahip_csr_plan_create": (C.c_int, [C.POINTER(_vp), C.c_uint32, C.c_uint32, _vp, _vp]),
+    "splahip_csr_plan_destroy": (C.c_int, [_vp]),
+    "splahip_csr_plan_info": (C.c_int, [_vp, _u32p, _u32p]),
+    "splahip_mxv_masked": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, _vp]),
+    "splahip_mxv_variant": (C.c_char_p, [C.c_int, C.c_int, C.c_int, C.c_int]),
+}
+_RAW = {"splahip_device_count", "splahip_last_error", "splahip_version", "splahip_mxv_variant"}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libspla_amd.so (built by `python -m spla_amd.build`); raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: build it with `python -m spla_amd.build` (there is no CPU fallback)")
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def declared_symbols():
+    return sorted(_SIGNATURES)
+
+
+def call(name: str, *args):
+    """Call a status-returning entry point and raise on failure."""
+    lib = load()
+    fn = getattr(lib, name)
+    res = fn(*args)
+    if name in _RAW:
+        return res
+    if res != 0:
+        raise SplaHipError(res, lib.splahip_last_error().decode(errors="replace"))
+    return res

@@ -1,0 +1,74 @@
+// block_utils.hpp — small wavefront / workgroup primitives (64-wide waves, gfx950) shared by the kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace splahip {
+
+    constexpr unsigned kWave = 64;
+
+    __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & (kWave - 1); }
+    __device__ __forceinline__ unsigned wave_id() { return threadIdx.x / kWave; }
+
+    // inclusive prefix sum across the 64 lanes of a wave
+    __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+        const unsigned lane = lane_id();
+#pragma unroll
+        for (unsigned off = 1; off < kWave; off <<= 1) {
+            uint32_t y = __shfl_up(x, off, kWave);
+            if (lane >= off) x += y;
+        }
+        return x;
+    }
+
+    // sum across the 64 lanes of a wave, result valid in every lane
+    __device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
+#pragma unroll
+        for (unsigned off = kWave / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+        return x;
+    }
+
+    // Exclusive prefix sum of one value per thread across a workgroup of NT threads (NT multiple of 64, <= 1024).
+    // `total` receives the workgroup sum.  `s_tmp` must hold NT/64 + 1 words of LDS.  Contains barriers.
+    template<unsigned NT>
+    __device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t x, uint32_t* s_tmp, uint32_t& total) {
+        constexpr unsigned NW   = NT / kWave;
+        const unsigned     lane = lane_id();
+        const unsigned     wave = wave_id();
+        const uint32_t     inc  = wave_inclusive_sum(x);
+        if (lane == kWave - 1) s_tmp[wave] = inc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (unsigned w = 0; w < NW; ++w) {
+                uint32_t t = s_tmp[w];
+                s_tmp[w]   = run;
+                run += t;
+            }
+            s_tmp[NW] = run;
+        }
+        __syncthreads();
+        const uint32_t res = s_tmp[wave] + inc - x;
+        total              = s_tmp[NW];
+        __syncthreads();// s_tmp may be reused by the caller
+        return res;
+    }
+
+    // In-order wave reduction of (valid, value) pairs with an arbitrary associative op: after the call lane 0 holds
+    // x_0 (+) x_1 (+) ... (+) x_63 over the valid lanes, combined in lane order (so non-commutative ops are honoured).
+    template<typename T, class Add>
+    __device__ __forceinline__ void wave_reduce_ordered(T& x, bool& valid, const Add& add) {
+#pragma unroll
+        for (unsigned off = 1; off < kWave; off <<= 1) {
+            const T   y  = __shfl_down(x, off, kWave);
+            const int yv = __shfl_down((int) valid, off, kWave);
+            const bool in_range = (lane_id() + off) < kWave;
+            if (in_range && yv) {
+                x     = valid ? add(x, y) : y;
+                valid = true;
+            }
+        }
+    }
+
+}// namespace splahip

@@ -1,0 +1,37 @@
+// common.hpp — error plumbing shared by the .hip translation units of libspla_amd.so
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../../include/spla_hip.h"
+
+namespace splahip {
+
+    // thread-local last error text, read by splahip_last_error()
+    std::string& last_error();
+    int          fail(int status, const char* fmt, ...);
+
+#define SPLAHIP_TRY(expr)                                                                                       \
+    do {                                                                                                        \
+        hipError_t _e = (expr);                                                                                 \
+        if (_e != hipSuccess)                                                                                   \
+            return ::splahip::fail(SPLAHIP_ERROR, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define SPLAHIP_REQUIRE(cond, msg)                                                                              \
+    do {                                                                                                        \
+        if (!(cond)) return ::splahip::fail(SPLAHIP_INVALID_ARGUMENT, "invalid argument: %s (%s:%d)", msg, __FILE__, __LINE__); \
+    } while (0)
+
+    inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+    // make sure a device has been selected and is a gfx950; returns SPLAHIP_OK or an error status
+    int ensure_device();
+
+    constexpr unsigned WAVE = 64;
+
+}// namespace splahip

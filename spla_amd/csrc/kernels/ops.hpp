@@ -1,0 +1,194 @@
+// ops.hpp — device-side scalar operations of the semirings, as compile-time functors plus a runtime-switched
+// fallback.  Semantics follow reference src/op.cpp:194-266 one to one (ids: include/spla_hip_ops.h).
+//
+// The reference injects an op into its OpenCL kernels as source text and JIT-compiles one program per
+// (kernel, type, ops) combination (reference src/opencl/cl_program_builder.cpp:65-120).  Here the common semirings
+// are ahead-of-time template instantiations and every other combination runs through `DynBin`, a functor that
+// switches on the op id (wave-uniform branch), so any (op_mult, op_add) pair is served on the device.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../../include/spla_hip_ops.h"
+
+namespace splahip {
+
+    using uint = uint32_t;
+
+    template<typename T>
+    struct TypeId;
+    template<>
+    struct TypeId<int32_t> { static constexpr int value = SPLAHIP_INT; };
+    template<>
+    struct TypeId<uint32_t> { static constexpr int value = SPLAHIP_UINT; };
+    template<>
+    struct TypeId<float> { static constexpr int value = SPLAHIP_FLOAT; };
+
+    template<typename T>
+    __host__ __device__ inline T from_bits(uint32_t w) {
+        union {
+            uint32_t u;
+            T        t;
+        } c;
+        c.u = w;
+        return c.t;
+    }
+    template<typename T>
+    __host__ __device__ inline uint32_t to_bits(T t) {
+        union {
+            uint32_t u;
+            T        t;
+        } c;
+        c.t = t;
+        return c.u;
+    }
+
+    // int32 +,-,* wrap (two's complement) instead of the CPU's signed-overflow UB
+    template<typename T>
+    __device__ __forceinline__ T wrap_add(T a, T b) {
+        if constexpr (std::is_same<T, int32_t>::value) return (int32_t) ((uint32_t) a + (uint32_t) b);
+        else
+            return a + b;
+    }
+    template<typename T>
+    __device__ __forceinline__ T wrap_sub(T a, T b) {
+        if constexpr (std::is_same<T, int32_t>::value) return (int32_t) ((uint32_t) a - (uint32_t) b);
+        else
+            return a - b;
+    }
+    template<typename T>
+    __device__ __forceinline__ T wrap_mul(T a, T b) {
+        if constexpr (std::is_same<T, int32_t>::value) return (int32_t) ((uint32_t) a * (uint32_t) b);
+        else
+            return a * b;
+    }
+    template<typename T>
+    __device__ __forceinline__ T safe_div(T a, T b) {
+        if constexpr (std::is_same<T, float>::value) return a / b;
+        else if constexpr (std::is_same<T, int32_t>::value)
+            return b == 0 ? 0 : ((a == INT32_MIN && b == -1) ? a : a / b);// UB on the CPU; defined here
+        else
+            return b == 0 ? 0u : a / b;
+    }
+
+    // Evaluate binary op `OP` (a splahip_binop id, compile-time constant).
+    template<int OP, typename T>
+    __device__ __forceinline__ T eval_bin(T a, T b) {
+        if constexpr (OP == SPLAHIP_PLUS) return wrap_add(a, b);
+        else if constexpr (OP == SPLAHIP_MINUS)
+            return wrap_sub(a, b);
+        else if constexpr (OP == SPLAHIP_MULT)
+            return wrap_mul(a, b);
+        else if constexpr (OP == SPLAHIP_DIV)
+            return safe_div(a, b);
+        else if constexpr (OP == SPLAHIP_MINUS_POW2) {
+            T d = wrap_sub(a, b);
+            return wrap_mul(d, d);
+        } else if constexpr (OP == SPLAHIP_FIRST)
+            return a;
+        else if constexpr (OP == SPLAHIP_SECOND)
+            return b;
+        else if constexpr (OP == SPLAHIP_BONE)
+            return T(1);
+        else if constexpr (OP == SPLAHIP_MIN)
+            return (b < a) ? b : a;// std::min
+        else if constexpr (OP == SPLAHIP_MAX)
+            return (a < b) ? b : a;// std::max
+        else if constexpr (OP == SPLAHIP_LOR)
+            return (a || b) ? T(1) : T(0);
+        else if constexpr (OP == SPLAHIP_LAND)
+            return (a && b) ? T(1) : T(0);
+        else if constexpr (OP == SPLAHIP_BOR || OP == SPLAHIP_BAND || OP == SPLAHIP_BXOR) {
+            if constexpr (std::is_same<T, float>::value) return a;// not defined for F; never dispatched
+            else if constexpr (OP == SPLAHIP_BOR)
+                return a | b;
+            else if constexpr (OP == SPLAHIP_BAND)
+                return a & b;
+            else
+                return a ^ b;
+        } else
+            return a;
+    }
+
+    // compile-time functor
+    template<int OP>
+    struct StaBin {
+        static constexpr bool is_static = true;
+        static constexpr int  op_id     = OP;
+        __host__ __device__ explicit StaBin(int = OP) {}
+        template<typename T>
+        __device__ __forceinline__ T operator()(T a, T b) const { return eval_bin<OP>(a, b); }
+    };
+
+    // runtime-switched functor (any op id)
+    struct DynBin {
+        static constexpr bool is_static = false;
+        int                   op;
+        __host__ __device__ explicit DynBin(int id) : op(id) {}
+        template<typename T>
+        __device__ __forceinline__ T operator()(T a, T b) const {
+            switch (op) {
+                case SPLAHIP_PLUS: return eval_bin<SPLAHIP_PLUS>(a, b);
+                case SPLAHIP_MINUS: return eval_bin<SPLAHIP_MINUS>(a, b);
+                case SPLAHIP_MULT: return eval_bin<SPLAHIP_MULT>(a, b);
+                case SPLAHIP_DIV: return eval_bin<SPLAHIP_DIV>(a, b);
+                case SPLAHIP_MINUS_POW2: return eval_bin<SPLAHIP_MINUS_POW2>(a, b);
+                case SPLAHIP_FIRST: return eval_bin<SPLAHIP_FIRST>(a, b);
+                case SPLAHIP_SECOND: return eval_bin<SPLAHIP_SECOND>(a, b);
+                case SPLAHIP_BONE: return eval_bin<SPLAHIP_BONE>(a, b);
+                case SPLAHIP_MIN: return eval_bin<SPLAHIP_MIN>(a, b);
+                case SPLAHIP_MAX: return eval_bin<SPLAHIP_MAX>(a, b);
+                case SPLAHIP_LOR: return eval_bin<SPLAHIP_LOR>(a, b);
+                case SPLAHIP_LAND: return eval_bin<SPLAHIP_LAND>(a, b);
+                case SPLAHIP_BOR: return eval_bin<SPLAHIP_BOR>(a, b);
+                case SPLAHIP_BAND: return eval_bin<SPLAHIP_BAND>(a, b);
+                case SPLAHIP_BXOR: return eval_bin<SPLAHIP_BXOR>(a, b);
+                default: return a;
+            }
+        }
+    };
+
+    // select op, evaluated once per row: always runtime-switched
+    template<typename T>
+    __device__ __forceinline__ bool eval_sel(int op, T a) {
+        switch (op) {
+            case SPLAHIP_EQZERO: return a == T(0);
+            case SPLAHIP_NQZERO: return a != T(0);
+            case SPLAHIP_GTZERO: return a > T(0);
+            case SPLAHIP_GEZERO: return a >= T(0);
+            case SPLAHIP_LTZERO: return a < T(0);
+            case SPLAHIP_LEZERO: return a <= T(0);
+            case SPLAHIP_ALWAYS: return true;
+            default: return false;// NEVER
+        }
+    }
+
+    // Algebraic traits of an op used as the ADD of a semiring (host side; decide which kernel may be used).
+    //   associative: a tree / segmented reduction gives the left fold's result (bit-exact for I/U; fp32 PLUS and
+    //                MULT are treated as associative under the stated 1e-5 relative tolerance)
+    //   commutative: partial results may be combined in any order
+    inline bool binop_is_associative(int op) {
+        switch (op) {
+            case SPLAHIP_MINUS:
+            case SPLAHIP_DIV:
+            case SPLAHIP_MINUS_POW2: return false;
+            default: return true;
+        }
+    }
+    inline bool binop_is_commutative(int op) {
+        switch (op) {
+            case SPLAHIP_MINUS:
+            case SPLAHIP_DIV:
+            case SPLAHIP_FIRST:
+            case SPLAHIP_SECOND: return false;
+            default: return true;
+        }
+    }
+    inline bool binop_valid_for(int op, int type) {
+        if (op < 0 || op >= SPLAHIP_BINOP_COUNT) return false;
+        if (type == SPLAHIP_FLOAT && (op == SPLAHIP_BOR || op == SPLAHIP_BAND || op == SPLAHIP_BXOR)) return false;
+        return true;
+    }
+
+}// namespace splahip

@@ -1,0 +1,148 @@
+// runtime.hip — device selection, memory helpers and error reporting of the kernel-level C ABI (include/spla_hip.h).
+// Replaces what the reference's OpenCL accelerator object does for its kernels: device pick and buffer
+// create/read/write (reference src/opencl/cl_accelerator.cpp:60-190, src/opencl/cl_format_dense_vec.hpp:40-88).
+#include "common.hpp"
+
+#include <cstring>
+#include <mutex>
+
+namespace splahip {
+
+    std::string& last_error() {
+        static thread_local std::string text;
+        return text;
+    }
+
+    int fail(int status, const char* fmt, ...) {
+        char    buf[1024];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        last_error() = buf;
+        return status;
+    }
+
+    namespace {
+        std::mutex g_lock;
+        int        g_device = -1;// device selected through splahip_init (or adopted from the current HIP context)
+        char       g_arch[256];
+        char       g_name[256];
+    }// namespace
+
+    static int select_device(int device) {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+            (void) hipGetLastError();
+            return fail(SPLAHIP_NO_DEVICE, "no HIP device visible: the MI355X backend has no CPU fallback");
+        }
+        if (device < 0 || device >= count) return fail(SPLAHIP_NO_DEVICE, "device index %d out of range [0,%d)", device, count);
+        hipDeviceProp_t prop;
+        SPLAHIP_TRY(hipGetDeviceProperties(&prop, device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(SPLAHIP_NO_DEVICE, "device %d is %s; this library only carries gfx950 (MI355X) code objects", device, prop.gcnArchName);
+        SPLAHIP_TRY(hipSetDevice(device));
+        g_device = device;
+        std::snprintf(g_arch, sizeof(g_arch), "%s", prop.gcnArchName);
+        std::snprintf(g_name, sizeof(g_name), "%s", prop.name);
+        return SPLAHIP_OK;
+    }
+
+    int ensure_device() {
+        std::lock_guard<std::mutex> guard(g_lock);
+        if (g_device >= 0) return SPLAHIP_OK;
+        // adopt whatever device the process already made current (e.g. torch.cuda.set_device(LOCAL_RANK))
+        int current = 0;
+        if (hipGetDevice(&current) != hipSuccess) {
+            (void) hipGetLastError();
+            return fail(SPLAHIP_NO_DEVICE, "no HIP device visible: the MI355X backend has no CPU fallback");
+        }
+        return select_device(current);
+    }
+
+}// namespace splahip
+
+using namespace splahip;
+
+extern "C" {
+
+int splahip_version(void) { return 100; }
+
+int splahip_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        (void) hipGetLastError();
+        return 0;
+    }
+    return count;
+}
+
+int splahip_init(int device) {
+    std::lock_guard<std::mutex> guard(g_lock);
+    return select_device(device);
+}
+
+int splahip_device_info(char* buffer, int length) {
+    if (!buffer || length <= 0) return fail(SPLAHIP_INVALID_ARGUMENT, "null buffer");
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) {
+        std::snprintf(buffer, (size_t) length, "no device");
+        return st;
+    }
+    std::snprintf(buffer, (size_t) length, "HIP device %d: %s (%s)", g_device, g_name, g_arch);
+    return SPLAHIP_OK;
+}
+
+const char* splahip_last_error(void) { return last_error().c_str(); }
+
+int splahip_malloc(void** d_ptr, size_t bytes) {
+    SPLAHIP_REQUIRE(d_ptr != nullptr, "d_ptr is null");
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    *d_ptr = nullptr;
+    SPLAHIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 4));
+    return SPLAHIP_OK;
+}
+
+int splahip_free(void* d_ptr) {
+    if (!d_ptr) return SPLAHIP_OK;
+    SPLAHIP_TRY(hipFree(d_ptr));
+    return SPLAHIP_OK;
+}
+
+int splahip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream) {
+    if (bytes == 0) return SPLAHIP_OK;
+    SPLAHIP_REQUIRE(d_dst && h_src, "null pointer");
+    SPLAHIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    // pageable host memory may be reused by the caller right after return
+    SPLAHIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return SPLAHIP_OK;
+}
+
+int splahip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream) {
+    if (bytes == 0) return SPLAHIP_OK;
+    SPLAHIP_REQUIRE(h_dst && d_src, "null pointer");
+    SPLAHIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    SPLAHIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return SPLAHIP_OK;
+}
+
+int splahip_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream) {
+    if (bytes == 0) return SPLAHIP_OK;
+    SPLAHIP_REQUIRE(d_dst && d_src, "null pointer");
+    SPLAHIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return SPLAHIP_OK;
+}
+
+int splahip_memset32(void* d_dst, uint32_t word, size_t count, void* stream) {
+    if (count == 0) return SPLAHIP_OK;
+    SPLAHIP_REQUIRE(d_dst, "null pointer");
+    SPLAHIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_dst), (int) word, count, as_stream(stream)));
+    return SPLAHIP_OK;
+}
+
+int splahip_stream_sync(void* stream) {
+    SPLAHIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return SPLAHIP_OK;
+}
+}

@@ -1,0 +1,71 @@
+"""Python face of the kernel-level C ABI for device-resident operands held in torch tensors.
+
+PyTorch-ROCm is plumbing only (device memory, the current HIP stream, torch.distributed); every compute call goes
+through libspla_amd.so.  Tensors are passed as raw device pointers (`tensor.data_ptr()`), int32 tensors stand in
+for uint32 words where torch has no unsigned dtype.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .ops import binop_id, scalar_bits, selop_id, type_id
+
+_TORCH_DTYPE = {0: torch.int32, 1: torch.int32, 2: torch.float32}  # uint32 words travel as int32 bit patterns
+
+
+def torch_dtype(t):
+    return _TORCH_DTYPE[type_id(t)]
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor expected"
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class CsrPlan:
+    """Row-block launch plan of one device CSR matrix (splahip_csr_plan_*)."""
+
+    def __init__(self, n_rows: int, nnz: int, Ap: torch.Tensor):
+        self.n_rows, self.nnz = int(n_rows), int(nnz)
+        self._h = C.c_void_p()
+        _lib.call("splahip_csr_plan_create", C.byref(self._h), self.n_rows, self.nnz, _ptr(Ap), current_stream_ptr())
+        nb, nl = C.c_uint32(), C.c_uint32()
+        _lib.call("splahip_csr_plan_info", self._h, C.byref(nb), C.byref(nl))
+        self.n_blocks, self.n_long = nb.value, nl.value
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            _lib.call("splahip_csr_plan_destroy", self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def mxv_masked(plan: CsrPlan, t, n_cols, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init, early_exit=False):
+    """r = mask-selected rows of (M x v) over (op_mult, op_add), written for every row (splahip_mxv_masked)."""
+    tid = type_id(t)
+    _lib.call("splahip_mxv_masked", plan.handle, tid, plan.n_rows, int(n_cols), _ptr(Ap), _ptr(Aj), _ptr(Ax),
+              _ptr(mask), _ptr(v), _ptr(r), binop_id(op_mult), binop_id(op_add), selop_id(op_select),
+              scalar_bits(init, tid), 1 if early_exit else 0, current_stream_ptr())
+    return r
+
+
+def mxv_variant(t, op_mult, op_add, early_exit=False) -> str:
+    return _lib.call("splahip_mxv_variant", type_id(t), binop_id(op_mult), binop_id(op_add), 1 if early_exit else 0).decode()
