@@ -1,0 +1,387 @@
+#!/usr/bin/env python3
+"""bench.py — masked SpMV (exec_mxv_masked hot path) on MI355X: GTEPS + achieved HBM GB/s vs roofline.
+
+A "step" is ONE pass of the hot path over one batch of synthetic input: one masked SpMV of the BFS-step
+configuration (BASELINE.json configs[1]): R-MAT scale 22 (edge factor 16, self loops + duplicates removed,
+~64 M nnz), int32, op_mult = BAND, op_add = BOR, mask = BFS depth vector at the peak-frontier level with
+EQZERO (selects unvisited rows), v = that level's frontier as a dense 0/1 vector, init 0.  Inputs are resident
+in HBM before the timed region.  With N > 1 ranks (one process per GPU, launched by torch.distributed.run) the
+matrix is the R-MAT of scale 22 + log2(N) split into N nnz-balanced 1-D row blocks (weak scaling: ~64 M nnz per
+GPU) and every step first all-gathers the dense input vector over RCCL, then runs the local SpMV.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` and `cpu_baseline`, and a `variants`
+list with the other measured forms of the same kernel family (early-exit BFS step, all-rows fp32 plus-times).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--scale", type=int, default=22, help="R-MAT scale per GPU (global scale = scale + log2(gpus))")
+    p.add_argument("--edge-factor", type=int, default=16)
+    p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--permute", type=int, default=-1, help="random vertex relabelling: 1/0, default: only when gpus > 1")
+    p.add_argument("--cpu-sample-nnz", type=int, default=8_000_000, help="nnz of the leading row block timed on the CPU")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-variants", action="store_true")
+    p.add_argument("--no-verify", action="store_true")
+    return p.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workload construction (all on the GPU, seeded)
+# ---------------------------------------------------------------------------------------------------------------
+def build_graph(args, rank, world):
+    from spla_amd import graphgen
+    gscale = args.scale + int(round(math.log2(world)))
+    permute = (world > 1) if args.permute < 0 else bool(args.permute)
+    t0 = time.time()
+    n, Ap, Aj = graphgen.rmat_csr(gscale, args.edge_factor, seed=args.seed, device="cuda", permute=permute)
+    torch.cuda.synchronize()
+    stats = graphgen.degree_stats(Ap)
+    bounds = graphgen.nnz_balanced_row_splits(Ap, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    s, e = int(Ap[lo]), int(Ap[hi])
+    Ap_l = (Ap[lo:hi + 1] - Ap[lo]).contiguous()
+    Aj_l = Aj[s:e].clone()
+    nnz_global = int(Ap[-1])
+    del Ap, Aj
+    torch.cuda.empty_cache()
+    if rank == 0:
+        log(f"[bench] R-MAT scale {gscale} permute={permute}: n={n} nnz={nnz_global} deg min/avg/sd/max="
+            f"{stats['min']:.0f}/{stats['avg']:.2f}/{stats['sd']:.1f}/{stats['max']:.0f} empty_rows={stats['empty_rows']} "
+            f"gen {time.time() - t0:.1f}s; row splits {bounds}")
+    return dict(n=n, gscale=gscale, permute=permute, bounds=bounds, lo=lo, hi=hi, Ap=Ap_l, Aj=Aj_l,
+                nnz_local=e - s, nnz_global=nnz_global, stats=stats)
+
+
+class Sharded:
+    """Row block of the matrix owned by this rank + the all-gather of the dense input vector."""
+
+    def __init__(self, g, rank, world):
+        from spla_amd import kernels
+        self.g, self.rank, self.world = g, rank, world
+        self.n = g["n"]
+        self.n_local = g["hi"] - g["lo"]
+        self.plan = kernels.CsrPlan(self.n_local, g["nnz_local"], g["Ap"])
+        self.counts = [g["bounds"][p + 1] - g["bounds"][p] for p in range(world)]
+        self.max_rows = max(self.counts)
+        if world > 1:
+            # v is exchanged as [world][max_rows] padded slices (one RCCL all-gather); remap the global column ids
+            # of the local CSR once so the kernel indexes the padded layout directly
+            b = torch.tensor(g["bounds"], device="cuda", dtype=torch.int64)
+            aj = g["Aj"].to(torch.int64)
+            owner = torch.searchsorted(b[1:].contiguous(), aj, right=True)
+            g["Aj"] = (owner * self.max_rows + (aj - b[owner])).to(torch.int32)
+            self.n_cols_padded = world * self.max_rows
+        else:
+            self.n_cols_padded = self.n
+
+    def gather(self, v_local_padded, v_full):
+        """all-gather(v) of the dense input vector: every rank contributes its (padded) slice."""
+        if self.world > 1:
+            dist.all_gather_into_tensor(v_full, v_local_padded)
+        return v_full
+
+
+def bfs_state(sh: Sharded, Ax):
+    """Run a BFS (pull steps through the HIP kernel) from the highest-degree vertex and return the depth vector
+    and the peak-frontier level: the mid-BFS state the timed step replays.  Not timed."""
+    from spla_amd import kernels
+    g, world = sh.g, sh.world
+    n_local, lo = sh.n_local, g["lo"]
+    deg = (g["Ap"][1:] - g["Ap"][:-1]).to(torch.int64)
+    best = torch.stack([deg.max(), deg.argmax() + lo]).clone()
+    if world > 1:
+        allb = [torch.empty_like(best) for _ in range(world)]
+        dist.all_gather(allb, best)
+        best = max(allb, key=lambda x: (int(x[0]), -int(x[1])))
+    src = int(best[1])
+    depth = torch.zeros(n_local, dtype=torch.int32, device="cuda")
+    front = torch.zeros(sh.max_rows if world > 1 else n_local, dtype=torch.int32, device="cuda")
+    if lo <= src < g["hi"]:
+        depth[src - lo] = 1
+        front[src - lo] = 1
+    v_full = torch.zeros(sh.n_cols_padded, dtype=torch.int32, device="cuda")
+    new = torch.empty(n_local, dtype=torch.int32, device="cuda")
+    sizes = []
+    level = 1
+    while True:
+        sh.gather(front, v_full) if world > 1 else v_full.copy_(front)
+        kernels.mxv_masked(sh.plan, "INT", sh.n_cols_padded, g["Ap"], g["Aj"], Ax, depth, v_full, new,
+                           "BAND", "BOR", "EQZERO", 0, early_exit=False)
+        level += 1
+        hit = new != 0
+        cnt = hit.sum()
+        if world > 1:
+            dist.all_reduce(cnt)
+        cnt = int(cnt)
+        if cnt == 0:
+            break
+        depth[hit] = level
+        front.zero_()
+        front[:n_local] = hit.to(torch.int32)
+        sizes.append(cnt)
+    peak = 1 + int(np.argmax(sizes))  # level whose frontier (depth == peak + 1) is largest ... input level = peak
+    # the timed step consumes frontier = {depth == L} and mask = depth restricted to levels <= L, with L = the level
+    # with the largest frontier
+    L = 1 + peak
+    return depth, L, sizes, src
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from spla_amd import _lib, kernels
+    _lib.load()
+    _lib.call("splahip_init", local_rank)
+
+    g = build_graph(args, rank, world)
+    sh = Sharded(g, rank, world)
+    n_local, nnz_local = sh.n_local, g["nnz_local"]
+    ones_i = torch.ones(nnz_local, dtype=torch.int32, device="cuda")
+
+    depth, L, sizes, src = bfs_state(sh, ones_i)
+    mask = torch.where(depth <= L, depth, torch.zeros_like(depth)).contiguous()      # visited up to level L
+    front = torch.zeros(sh.max_rows if world > 1 else n_local, dtype=torch.int32, device="cuda")
+    front[:n_local] = (depth == L).to(torch.int32)
+    deg = (g["Ap"][1:] - g["Ap"][:-1]).to(torch.int64)
+    sel_rows = mask == 0
+    nnz_sel_local = int(deg[sel_rows].sum())
+    stat = torch.tensor([nnz_sel_local, int(sel_rows.sum()), int((depth == L).sum())], device="cuda", dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(stat)
+    nnz_sel_total, rows_sel_total, front_total = (int(x) for x in stat.tolist())
+    if rank == 0:
+        log(f"[bench] BFS from {src}: frontier sizes per level {sizes}; timed level L={L}: frontier={front_total} "
+            f"rows selected={rows_sel_total} nnz_sel={nnz_sel_total} ({100.0 * nnz_sel_total / g['nnz_global']:.1f}% of nnz)")
+
+    v_full = torch.zeros(sh.n_cols_padded, dtype=torch.int32, device="cuda")
+    r = torch.empty(n_local, dtype=torch.int32, device="cuda")
+    if world == 1:
+        v_full.copy_(front)
+
+    def step(early=False):
+        if world > 1:
+            sh.gather(front, v_full)
+        kernels.mxv_masked(sh.plan, "INT", sh.n_cols_padded, g["Ap"], g["Aj"], ones_i, mask, v_full, r,
+                           "BAND", "BOR", "EQZERO", 0, early_exit=early)
+
+    def timed(fn, steps, warmup):
+        """Contract timing: W untimed steps, then exactly K steps bracketed by barrier + synchronize, max over ranks;
+        per-launch HIP events on the launch stream give the kernel's average duration."""
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        per = [a.elapsed_time(b) for a, b in evs]  # ms
+        if world > 1:
+            w = torch.tensor([wall], device="cuda", dtype=torch.float64)
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            wall = float(w[0])
+        return wall, per
+
+    wall, per = timed(step, args.steps, args.warmup)
+    ms_per_step = wall / args.steps * 1e3
+    gteps = nnz_sel_total / (wall / args.steps) / 1e9
+
+    # roofline of the dominant kernel (this rank's launch): algorithmic bytes per launch / average launch duration.
+    # B_mxv = 8*nnz_sel + 4*(n_rows+1) + 4*n_rows (mask) + 4*n_rows (r) + 4*n_cols (v once)   
+    if world > 1:
+        # kernel-only duration: time the local SpMV without the exchange
+        _, per_k = timed(lambda: kernels.mxv_masked(sh.plan, "INT", sh.n_cols_padded, g["Ap"], g["Aj"], ones_i, mask,
+                                                    v_full, r, "BAND", "BOR", "EQZERO", 0), args.steps, 2)
+    else:
+        per_k = per
+    k_ms = float(np.mean(per_k))
+    alg_bytes = 8 * nnz_sel_local + 4 * (n_local + 1) + 8 * n_local + 4 * sh.n_cols_padded
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": kernels.mxv_variant("INT", "BAND", "BOR", False), "kernel_avg_us": round(k_ms * 1e3, 2),
+                "kernel_median_us": round(float(np.median(per_k)) * 1e3, 2), "algorithmic_bytes": alg_bytes}
+
+    out = {
+        "metric": "masked SpMV GTEPS", "value": round(gteps, 3), "unit": "GTEPS", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "exec_mxv_masked BFS step: R-MAT scale %d (ef %d, %s labels), BAND/BOR int32, mask=depth EQZERO at peak-frontier level, early_exit=false"
+                               % (g["gscale"], args.edge_factor, "permuted" if g["permute"] else "raw"),
+                   "n": g["n"], "nnz": g["nnz_global"], "nnz_selected": nnz_sel_total, "rows_selected": rows_sel_total,
+                   "frontier": front_total, "bfs_level": L, "parallelism": f"1-D nnz-balanced row blocks x{world}" + (" + RCCL all-gather(v)" if world > 1 else ""),
+                   "row_blocks": sh.plan.n_blocks, "long_rows": sh.plan.n_long},
+        "roofline": roofline,
+    }
+
+    # ---- verification of the timed result against the oracle (full local rows), and the CPU baseline ------------
+    if rank == 0 and not args.no_verify:
+        out["verified"] = verify_full(g, sh, mask, v_full, r, ones_i)
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, g, sh, mask, v_full, r)
+
+    if not args.no_variants:
+        out["variants"] = variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total, nnz_sel_local)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def verify_full(g, sh, mask, v_full, r, Ax):
+    """HIP result of the timed step == oracle (plain-C restatement) on every local row, bit-exact (int32)."""
+    from oracle import pyoracle
+    orc = pyoracle.Oracle()
+    want = orc.mxv_masked("INT", sh.n_local, sh.n_cols_padded, g["Ap"].cpu().numpy(), g["Aj"].cpu().numpy(),
+                          Ax.cpu().numpy(), mask.cpu().numpy(), v_full.cpu().numpy(), "BAND", "BOR", "EQZERO", 0)
+    ok = bool(np.array_equal(want, r.cpu().numpy()))
+    log(f"[bench] full-size parity vs oracle: {'OK' if ok else 'MISMATCH'} ({sh.n_local} rows)")
+    if not ok:
+        raise SystemExit("bench: HIP result differs from the oracle")
+    return True
+
+
+def cpu_baseline(args, g, sh, mask, v_full, r):
+    """The reference CPU path timed on this host: the genuine reference build (oracle/_ref) when present, else the
+    plain-C port; on a bounded sample = the leading row block holding ~cpu_sample_nnz entries of the same workload."""
+    from oracle import pyoracle
+    Ap = g["Ap"].cpu().numpy().view(np.uint32)
+    rows = int(np.searchsorted(Ap, min(args.cpu_sample_nnz, int(Ap[-1])), side="left"))
+    rows = max(1, min(rows, sh.n_local))
+    nnz_s = int(Ap[rows])
+    Ap_s = Ap[:rows + 1]
+    Aj_s = g["Aj"][:nnz_s].cpu().numpy()
+    Ax_s = np.ones(nnz_s, np.int32)
+    mask_s = mask[:rows].cpu().numpy()
+    v = v_full.cpu().numpy()
+    deg = np.diff(Ap_s.astype(np.int64))
+    nnz_sel = int(deg[mask_s == 0].sum())
+    impl = pyoracle.Reference() if pyoracle.have_reference() else pyoracle.Oracle()
+    times = []
+    if impl.kind == "reference":
+        # keep the reference objects alive across calls so the timed region is the steady-state exec call only
+        t = 0
+        M = impl._matrix(t, rows, sh.n_cols_padded, Ap_s, Aj_s, Ax_s)
+        hm, hv, hr = impl._dense_vector(t, mask_s), impl._dense_vector(t, v), impl._empty_vector(t, rows)
+        hi = impl._scalar(0, t)
+        opm, opa, ops = impl._op("Binary", "BAND", t), impl._op("Binary", "BOR", t), impl._op("Select", "EQZERO", t)
+        for it in range(4):
+            t0 = time.perf_counter()
+            st = impl.lib.spla_Exec_mxv_masked(hr, hm, M, hv, opm, opa, ops, hi, None, None)
+            dt = time.perf_counter() - t0
+            assert st == 0
+            if it > 0:
+                times.append(dt)
+            else:
+                first = dt
+        got = np.empty(rows, np.uint32)
+        impl.lib.refshim_vector_dense_read(hr, got.ctypes.data_as(pyoracle._u32p))
+        got = got.view(np.int32)
+        impl._unref(M, hm, hv, hr, hi)
+    else:
+        first = None
+        for it in range(4):
+            t0 = time.perf_counter()
+            got = impl.mxv_masked("INT", rows, sh.n_cols_padded, Ap_s, Aj_s, Ax_s, mask_s, v, "BAND", "BOR", "EQZERO", 0)
+            if it > 0:
+                times.append(time.perf_counter() - t0)
+    same = bool(np.array_equal(got, r[:rows].cpu().numpy()))
+    med = float(np.median(times))
+    log(f"[bench] cpu baseline ({impl.kind}): {rows} rows / {nnz_s} nnz / {nnz_sel} selected nnz, median {med * 1e3:.1f} ms, "
+        f"HIP == {impl.kind}: {same}")
+    if not same:
+        raise SystemExit("bench: HIP result differs from the CPU reference on the sample")
+    return {"value": round(nnz_sel / med / 1e9, 4), "unit": "GTEPS", "cores": 1, "kind": impl.kind,
+            "sample": f"leading {rows} rows ({nnz_s} nnz, {nnz_sel} in selected rows) of rank 0's row block, same mask/v; "
+                      f"median of 3 steady-state exec_mxv_masked calls after 1 warm-up"
+                      + (f" (first call incl. format conversion {first * 1e3:.0f} ms)" if first else ""),
+            "host_cpus": os.cpu_count(), "ms": round(med * 1e3, 2), "matches_hip": same}
+
+
+def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total, nnz_sel_local):
+    """Other measured forms of the same kernel family on the same matrix (kernel-only, inputs resident)."""
+    from spla_amd import kernels
+    res = []
+    n_local, nnz_local = sh.n_local, g["nnz_local"]
+    steps = max(10, args.steps // 2)
+
+    def run(name, t, Ax, m, v, r, mul, add, sel, init, early, nnz_sel):
+        fn = lambda: kernels.mxv_masked(sh.plan, t, sh.n_cols_padded, g["Ap"], g["Aj"], Ax, m, v, r, mul, add, sel, init, early_exit=early)
+        _, per = timed(fn, steps, 3)
+        ms = float(np.mean(per))
+        b = 8 * nnz_sel + 4 * (n_local + 1) + 8 * n_local + 4 * sh.n_cols_padded
+        tot = torch.tensor([nnz_sel], device="cuda", dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(tot)
+        res.append({"name": name, "kernel": kernels.mxv_variant(t, mul, add, early), "kernel_avg_us": round(ms * 1e3, 2),
+                    "gteps_local": round(nnz_sel / (ms * 1e-3) / 1e9, 2), "hbm_gbs": round(b / (ms * 1e-3) / 1e9, 1),
+                    "roofline_frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "nnz_selected_local": nnz_sel})
+
+    r_i = torch.empty(n_local, dtype=torch.int32, device="cuda")
+    ones_i = torch.ones(nnz_local, dtype=torch.int32, device="cuda")
+    run("bfs-step early_exit=true (as reference bfs())", "INT", ones_i, mask, v_full, r_i, "BAND", "BOR", "EQZERO", 0, True, nnz_sel_local)
+    zeros_i = torch.zeros(n_local, dtype=torch.int32, device="cuda")
+    run("all rows selected, BAND/BOR int32", "INT", ones_i, zeros_i, v_full, r_i, "BAND", "BOR", "EQZERO", 0, False, nnz_local)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(args.seed + 100 + rank)
+    Ax_f = torch.rand(nnz_local, generator=gen, device="cuda", dtype=torch.float32)
+    v_f = torch.rand(sh.n_cols_padded, generator=gen, device="cuda", dtype=torch.float32)
+    r_f = torch.empty(n_local, dtype=torch.float32, device="cuda")
+    zeros_f = torch.zeros(n_local, dtype=torch.float32, device="cuda")
+    run("all rows selected, MULT/PLUS fp32 (headline bandwidth form)", "FLOAT", Ax_f, zeros_f, v_f, r_f, "MULT", "PLUS", "ALWAYS", 0.0, False, nnz_local)
+    w_i = torch.randint(1, 256, (nnz_local,), generator=gen, device="cuda", dtype=torch.int32)
+    d_i = torch.full((sh.n_cols_padded,), 1 << 30, dtype=torch.int32, device="cuda")
+    d_i[torch.randint(0, sh.n_cols_padded, (sh.n_cols_padded // 8,), generator=gen, device="cuda")] = 1000
+    run("all rows selected, PLUS/MIN int32 (SSSP step)", "INT", w_i, zeros_i, d_i, r_i, "PLUS", "MIN", "ALWAYS", 1 << 30, False, nnz_local)
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,157 @@
+"""Parity of the HIP masked SpMV (through the kernel-level C ABI) against the oracle on seeded inputs.
+Bit-exact for int32 / uint32 and order-free monoids; <= 1e-5 relative for fp32 PLUS / MULT folds (north star)."""
+import numpy as np
+import pytest
+
+from helpers import (NP, SELECTS, SEMIRINGS_COMMON, SEMIRINGS_INT, SEMIRINGS_ORDERED, assert_same, random_csr,
+                     random_mask, random_values)
+
+pytestmark = pytest.mark.gpu
+
+FP32_RTOL = 1e-5
+
+
+def _init_for(add):
+    return {"MIN": 100, "MAX": 0, "MULT": 1, "LAND": 1}.get(add, 0)
+
+
+def test_reference_unit_case_naive(oracle):
+    from gpu_utils import hip_mxv
+    # reference tests/test_mxv.cpp:33-89, r pre-loaded with junk to prove every row is overwritten
+    Ap = np.array([0, 2, 4, 5, 6], np.uint32)
+    Aj = np.array([1, 4, 0, 4, 2, 4], np.uint32)
+    Ax = np.array([2, -9, 2, -8, 3, -1], np.int32)
+    mask = np.array([1, 0, 1, 0], np.int32)
+    v = np.array([3, 0, 3, 0, -1], np.int32)
+    r = hip_mxv("INT", 4, 5, Ap, Aj, Ax, mask, v, "MULT", "PLUS", "EQZERO", 0, junk=77)
+    assert r.tolist() == [0, 14, 0, 1]
+
+
+def test_reference_perf_case_banded(oracle):
+    from gpu_utils import hip_mxv
+    # reference tests/test_mxv.cpp:91-130 at reduced N (banded, 256 nnz/row, every 10th row selected)
+    N, K, S = 20000, 256, 10
+    Ap = (np.arange(N + 1, dtype=np.uint64) * K).astype(np.uint32)
+    Aj = np.sort((np.arange(N)[:, None] + np.arange(K)[None, :]) % N, axis=1).astype(np.uint32).ravel()
+    Ax = np.ones(N * K, np.int32)
+    mask = (np.arange(N) % S != 0).astype(np.int32)
+    v = np.ones(N, np.int32)
+    r = hip_mxv("INT", N, N, Ap, Aj, Ax, mask, v, "MULT", "PLUS", "EQZERO", 0)
+    assert np.array_equal(r, np.where(np.arange(N) % S, 0, K))
+
+
+def _semirings(t):
+    s = SEMIRINGS_COMMON + SEMIRINGS_ORDERED
+    return s + SEMIRINGS_INT if t != "FLOAT" else s
+
+
+@pytest.mark.parametrize("t", ["INT", "UINT", "FLOAT"])
+def test_all_semiring_cells(oracle, t):
+    from gpu_utils import hip_mxv
+    rng = np.random.default_rng(101)
+    n_rows, n_cols = 3000, 2500
+    # skewed degrees, empty rows, rows longer than the lane-per-row limit and two rows longer than the LDS stage
+    Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 9, t, skew=True, long_rows=2, long_len=2400)
+    for k, (mul, add) in enumerate(_semirings(t)):
+        for early in (False, True):
+            sel = SELECTS[(k + early) % len(SELECTS)]
+            mask = random_mask(rng, n_rows, t)
+            v = random_values(rng, n_cols, t, zeros=0.3)
+            init = _init_for(add)
+            want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init, early)
+            got = hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init, early)
+            exact = not (t == "FLOAT" and add in ("PLUS", "MULT") and not early)
+            if exact:
+                np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32), err_msg=f"{t} {mul}/{add} {sel} early={early}")
+            else:
+                np.testing.assert_allclose(got, want, rtol=FP32_RTOL, atol=0, err_msg=f"{t} {mul}/{add} {sel}")
+
+
+@pytest.mark.parametrize("t", ["INT", "FLOAT"])
+def test_long_rows_and_row_caps(oracle, t):
+    from gpu_utils import hip_mxv
+    rng = np.random.default_rng(5)
+    # one 20000-long row (peeled, strided from HBM), >1024 consecutive empty rows (row cap), medium rows 33..2000
+    n_cols = 30000
+    degs = np.concatenate([np.zeros(2500, np.int64), [20000], rng.integers(33, 2000, 40), np.zeros(1500, np.int64),
+                           [4096, 4097, 4095, 1, 0, 2047, 2048, 2049], rng.integers(0, 5, 3000)])
+    n_rows = len(degs)
+    Ap = np.zeros(n_rows + 1, np.uint32)
+    Ap[1:] = np.cumsum(degs)
+    Aj = np.concatenate([np.sort(rng.permutation(n_cols)[:d]) for d in degs]).astype(np.uint32)
+    Ax = random_values(rng, len(Aj), t)
+    v = random_values(rng, n_cols, t, zeros=0.1)
+    for mul, add, sel in [("MULT", "PLUS", "ALWAYS"), ("PLUS", "MIN", "NQZERO"), ("LAND", "LOR", "EQZERO"), ("MIN", "MAX", "GTZERO")]:
+        mask = random_mask(rng, n_rows, t)
+        init = _init_for(add)
+        want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
+        got = hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
+        if t == "FLOAT" and add == "PLUS":
+            np.testing.assert_allclose(got, want, rtol=FP32_RTOL)
+        else:
+            np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32), err_msg=f"{mul}/{add}")
+
+
+def test_edge_shapes(oracle):
+    from gpu_utils import hip_mxv
+    rng = np.random.default_rng(9)
+    t = "INT"
+    # no entries at all: every selected row is init, unselected too
+    Ap = np.zeros(6, np.uint32)
+    r = hip_mxv(t, 5, 4, Ap, np.zeros(0, np.uint32), np.zeros(0, np.int32), np.ones(5, np.int32), np.ones(4, np.int32), "MULT", "PLUS", "ALWAYS", 7, junk=-1)
+    assert r.tolist() == [7] * 5
+    # single row, single entry
+    r = hip_mxv(t, 1, 1, np.array([0, 1], np.uint32), np.array([0], np.uint32), np.array([3], np.int32), np.array([0], np.int32), np.array([5], np.int32), "MULT", "PLUS", "EQZERO", 1)
+    assert r.tolist() == [16]
+    # NEVER selects nothing: r == init everywhere, matrix untouched
+    Ap, Aj, Ax = random_csr(rng, 500, 300, 8, t)
+    r = hip_mxv(t, 500, 300, Ap, Aj, Ax, np.ones(500, np.int32), np.ones(300, np.int32), "MULT", "PLUS", "NEVER", -3)
+    assert np.all(r == -3)
+    # ragged: a 1-row matrix with 10000 entries and a 10000-row matrix with one entry each
+    Aj = np.arange(10000, dtype=np.uint32)
+    v = rng.integers(-3, 4, 10000).astype(np.int32)
+    Ax = rng.integers(-3, 4, 10000).astype(np.int32)
+    r = hip_mxv(t, 1, 10000, np.array([0, 10000], np.uint32), Aj, Ax, np.zeros(1, np.int32), v, "MULT", "PLUS", "EQZERO", 0)
+    assert r[0] == int(np.sum(Ax.astype(np.int64) * v))
+    r = hip_mxv(t, 10000, 10000, np.arange(10001, dtype=np.uint32), Aj, Ax, np.zeros(10000, np.int32), v, "MULT", "PLUS", "EQZERO", 0)
+    assert np.array_equal(r, Ax * v)
+
+
+def test_unaligned_device_arrays(oracle):
+    """Aj / Ax that are not 16-byte aligned (a slice of a larger allocation) take the scalar-load path."""
+    import torch
+    from gpu_utils import dev, host
+    from spla_amd import kernels
+    rng = np.random.default_rng(3)
+    t = "FLOAT"
+    n_rows, n_cols = 2000, 1500
+    Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 12, t, skew=True)
+    mask = random_mask(rng, n_rows, t)
+    v = random_values(rng, n_cols, t)
+    want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, "MULT", "PLUS", "NQZERO", 0.0)
+    dAj = dev(np.concatenate([[0], Aj]).astype(np.uint32))[1:]
+    dAx = dev(np.concatenate([[0], Ax]).astype(np.float32))[1:]
+    assert dAj.data_ptr() % 16 != 0
+    dAp, dm, dv = dev(Ap), dev(mask), dev(v)
+    plan = kernels.CsrPlan(n_rows, len(Aj), dAp)
+    r = torch.empty(n_rows, dtype=torch.float32, device="cuda")
+    kernels.mxv_masked(plan, t, n_cols, dAp, dAj, dAx, dm, dv, r, "MULT", "PLUS", "NQZERO", 0.0)
+    np.testing.assert_allclose(host(r, np.float32), want, rtol=FP32_RTOL)
+
+
+def test_sharded_rows_equal_whole(oracle):
+    """1-D row-block decomposition: running each row block separately (global column ids) gives the same rows."""
+    from gpu_utils import hip_mxv
+    rng = np.random.default_rng(17)
+    t = "INT"
+    n = 4000
+    Ap, Aj, Ax = random_csr(rng, n, n, 10, t, skew=True)
+    mask = random_mask(rng, n, t)
+    v = random_values(rng, n, t)
+    whole = hip_mxv(t, n, n, Ap, Aj, Ax, mask, v, "PLUS", "MIN", "ALWAYS", 1 << 30)
+    parts = []
+    for lo, hi in [(0, 37), (37, 1800), (1800, 4000)]:
+        s, e = int(Ap[lo]), int(Ap[hi])
+        parts.append(hip_mxv(t, hi - lo, n, (Ap[lo:hi + 1] - Ap[lo]).astype(np.uint32), Aj[s:e], Ax[s:e], mask[lo:hi], v, "PLUS", "MIN", "ALWAYS", 1 << 30))
+    assert np.array_equal(np.concatenate(parts), whole)
+    assert np.array_equal(whole, oracle.mxv_masked(t, n, n, Ap, Aj, Ax, mask, v, "PLUS", "MIN", "ALWAYS", 1 << 30))
