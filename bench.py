@@ -147,10 +147,10 @@ def bfs_state(sh: Sharded, Ax):
         front.zero_()
         front[:n_local] = hit.to(torch.int32)
         sizes.append(cnt)
-    peak = 1 + int(np.argmax(sizes))  # level whose frontier (depth == peak + 1) is largest ... input level = peak
-    # the timed step consumes frontier = {depth == L} and mask = depth restricted to levels <= L, with L = the level
-    # with the largest frontier
-    L = 1 + peak
+    # sizes[k] = vertices discovered by the step that consumed the frontier {depth == k + 1}.  The timed step is the
+    # one that PRODUCES the largest frontier (the heaviest pull step of the traversal): it consumes {depth == L}
+    # with the rows visited up to level L masked out.
+    L = 1 + int(np.argmax(sizes))
     return depth, L, sizes, src
 
 
@@ -251,11 +251,11 @@ def main():
         "metric": "masked SpMV GTEPS", "value": round(gteps, 3), "unit": "GTEPS", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "exec_mxv_masked BFS step: R-MAT scale %d (ef %d, %s labels), BAND/BOR int32, mask=depth EQZERO at peak-frontier level, early_exit=false"
+        "config": {"workload": "exec_mxv_masked BFS step: R-MAT scale %d (ef %d, %s labels), BAND/BOR int32, mask=depth EQZERO at the level producing the largest frontier, early_exit=false"
                                % (g["gscale"], args.edge_factor, "permuted" if g["permute"] else "raw"),
                    "n": g["n"], "nnz": g["nnz_global"], "nnz_selected": nnz_sel_total, "rows_selected": rows_sel_total,
                    "frontier": front_total, "bfs_level": L, "parallelism": f"1-D nnz-balanced row blocks x{world}" + (" + RCCL all-gather(v)" if world > 1 else ""),
-                   "row_blocks": sh.plan.n_blocks, "long_rows": sh.plan.n_long},
+                   "work_items": sh.plan.n_items, "long_rows": sh.plan.n_long},
         "roofline": roofline,
     }
 
@@ -290,21 +290,28 @@ def verify_full(g, sh, mask, v_full, r, Ax):
 
 def cpu_baseline(args, g, sh, mask, v_full, r):
     """The reference CPU path timed on this host: the genuine reference build (oracle/_ref) when present, else the
-    plain-C port; on a bounded sample = the leading row block holding ~cpu_sample_nnz entries of the same workload."""
+    plain-C port; on a bounded sample of the same workload = every s-th row of rank 0's row block (s chosen so the
+    sample holds ~cpu_sample_nnz entries; rows are independent, so the sampled rows' results are checked too)."""
     from oracle import pyoracle
-    Ap = g["Ap"].cpu().numpy().view(np.uint32)
-    rows = int(np.searchsorted(Ap, min(args.cpu_sample_nnz, int(Ap[-1])), side="left"))
-    rows = max(1, min(rows, sh.n_local))
-    nnz_s = int(Ap[rows])
-    Ap_s = Ap[:rows + 1]
-    Aj_s = g["Aj"][:nnz_s].cpu().numpy()
+    stride = max(1, int(round(g["nnz_local"] / max(1, args.cpu_sample_nnz))))
+    rows_idx = torch.arange(0, sh.n_local, stride, device="cuda")
+    Ap64 = g["Ap"].to(torch.int64)
+    deg = (Ap64[1:] - Ap64[:-1])[rows_idx]
+    Ap_s = torch.zeros(rows_idx.numel() + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(deg, 0, out=Ap_s[1:])
+    nnz_s = int(Ap_s[-1])
+    # entry k of sampled row i sits at Ap[rows_idx[i]] + (k - Ap_s[i])
+    rep = torch.repeat_interleave(torch.arange(rows_idx.numel(), device="cuda"), deg)
+    src = Ap64[rows_idx][rep] + (torch.arange(nnz_s, device="cuda") - Ap_s[:-1][rep])
+    Aj_s = g["Aj"][src].cpu().numpy()
     Ax_s = np.ones(nnz_s, np.int32)
-    mask_s = mask[:rows].cpu().numpy()
+    rows = int(rows_idx.numel())
+    Ap_s = Ap_s.to(torch.int32).cpu().numpy().view(np.uint32)
+    mask_s = mask[rows_idx].cpu().numpy()
     v = v_full.cpu().numpy()
-    deg = np.diff(Ap_s.astype(np.int64))
-    nnz_sel = int(deg[mask_s == 0].sum())
+    nnz_sel = int(deg[mask[rows_idx] == 0].sum())
     impl = pyoracle.Reference() if pyoracle.have_reference() else pyoracle.Oracle()
-    times = []
+    times, first = [], None
     if impl.kind == "reference":
         # keep the reference objects alive across calls so the timed region is the steady-state exec call only
         t = 0
@@ -326,22 +333,21 @@ def cpu_baseline(args, g, sh, mask, v_full, r):
         got = got.view(np.int32)
         impl._unref(M, hm, hv, hr, hi)
     else:
-        first = None
         for it in range(4):
             t0 = time.perf_counter()
             got = impl.mxv_masked("INT", rows, sh.n_cols_padded, Ap_s, Aj_s, Ax_s, mask_s, v, "BAND", "BOR", "EQZERO", 0)
             if it > 0:
                 times.append(time.perf_counter() - t0)
-    same = bool(np.array_equal(got, r[:rows].cpu().numpy()))
+    same = bool(np.array_equal(got, r[rows_idx].cpu().numpy()))
     med = float(np.median(times))
-    log(f"[bench] cpu baseline ({impl.kind}): {rows} rows / {nnz_s} nnz / {nnz_sel} selected nnz, median {med * 1e3:.1f} ms, "
-        f"HIP == {impl.kind}: {same}")
+    log(f"[bench] cpu baseline ({impl.kind}): every {stride}th row: {rows} rows / {nnz_s} nnz / {nnz_sel} selected nnz, "
+        f"median {med * 1e3:.1f} ms, HIP == {impl.kind}: {same}")
     if not same:
         raise SystemExit("bench: HIP result differs from the CPU reference on the sample")
     return {"value": round(nnz_sel / med / 1e9, 4), "unit": "GTEPS", "cores": 1, "kind": impl.kind,
-            "sample": f"leading {rows} rows ({nnz_s} nnz, {nnz_sel} in selected rows) of rank 0's row block, same mask/v; "
-                      f"median of 3 steady-state exec_mxv_masked calls after 1 warm-up"
-                      + (f" (first call incl. format conversion {first * 1e3:.0f} ms)" if first else ""),
+            "sample": f"every {stride}th row of rank 0's row block: {rows} rows, {nnz_s} nnz, {nnz_sel} in selected rows, same "
+                      f"mask/v; median of 3 steady-state exec_mxv_masked calls after 1 warm-up"
+                      + (f" (first call incl. COO->LIL conversion {first * 1e3:.0f} ms)" if first else ""),
             "host_cpus": os.cpu_count(), "ms": round(med * 1e3, 2), "matches_hip": same}
 
 

@@ -61,16 +61,16 @@ int splahip_memset32(void* d_dst, uint32_t word, size_t count, void* stream);   
 int splahip_stream_sync(void* stream);
 
 /* ---- device CSR launch plan ---------------------------------------------------------------------------------
- * A plan is the row-block decomposition of one device-resident CSR matrix (it is part of the "AccCsr"
- * decoration, built once per matrix, reused by every mxv/vxm call on it).  Built on the device from d_Ap.
- * Row blocks are runs of consecutive rows whose entries start inside one 2048-entry window of the nnz
- * stream and count at most 1024 rows: see DESIGN.md "CSR row blocks".                                        */
+ * A plan is the work decomposition of one device-resident CSR matrix (it is part of the "AccCsr" decoration:
+ * built once per matrix on the device from d_Ap, reused by every call on it).  The nnz stream is cut into work
+ * items of <= ~1 Ki entries, one per wavefront: runs of consecutive short rows, and segments of long rows
+ * (DESIGN.md "wave tiles").                                                                                   */
 typedef struct splahip_plan_s* splahip_plan;
 
 int splahip_csr_plan_create(splahip_plan* plan, uint32_t n_rows, uint32_t nnz, const uint32_t* d_Ap, void* stream);
 int splahip_csr_plan_destroy(splahip_plan plan);
-/* n_blocks: row blocks; n_long: rows longer than the LDS stage (handled by the long-row path) */
-int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_blocks, uint32_t* n_long);
+/* n_items: work items; n_long: rows cut into segment items */
+int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_items, uint32_t* n_long);
 
 /* ---- masked SpMV (pull): r[i] = select(mask[i]) ? fold_k add(., mult(Ax[k], v[Aj[k]])) from init : init -----
  * r, mask: n_rows words; v: n_cols words; all n_rows outputs are written (reference cpu_mxv.hpp:88-103).
@@ -82,6 +82,15 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
                        const void* d_mask, const void* d_v, void* d_r,
                        int op_mult, int op_add, int op_select, uint32_t init_bits, int early_exit,
                        void* stream);
+
+/* ---- accelerator vector formats ------------------------------------------------------------------------------
+ * AccDense <-> AccCoo (reference src/opencl/cl_format_dense_vec.hpp:90-143, cl_format_coo_vec.hpp:149-158).
+ * dense_to_coo keeps the entries != fill in ascending index order (d_idx / d_val need room for n entries) and
+ * returns the count on the host (blocks).  coo_to_dense fills with `fill` then scatters (last write wins).      */
+int splahip_vec_dense_to_coo(int type, uint32_t n, const void* d_dense, uint32_t fill_bits,
+                             uint32_t* d_idx, void* d_val, uint32_t* h_count, void* stream);
+int splahip_vec_coo_to_dense(uint32_t n, uint32_t nvals, const uint32_t* d_idx, const void* d_val, uint32_t fill_bits,
+                             void* d_dense, void* stream);
 
 /* name of the kernel variant the call above would launch for these arguments (for profiles / DESIGN.md) */
 const char* splahip_mxv_variant(int type, int op_mult, int op_add, int early_exit);

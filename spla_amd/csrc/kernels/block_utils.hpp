@@ -71,4 +71,26 @@ namespace splahip {
         }
     }
 
+    // Exclusive scan of `n` per-chunk counts in place by ONE workgroup of NT threads; counts[n] receives the total.
+    // (second pass of the count / scan / write compaction pattern used by the plan builder and the format kernels)
+    template<unsigned NT>
+    __global__ __launch_bounds__(NT) void chunk_scan_kernel(uint32_t* __restrict__ counts, uint32_t n) {
+        __shared__ uint32_t s_tmp[NT / kWave + 1];
+        __shared__ uint32_t s_carry;
+        if (threadIdx.x == 0) s_carry = 0;
+        __syncthreads();
+        for (uint32_t base = 0; base < n; base += NT) {
+            const uint32_t i = base + threadIdx.x;
+            const uint32_t x = i < n ? counts[i] : 0;
+            uint32_t       total;
+            const uint32_t ex    = block_exclusive_sum<NT>(x, s_tmp, total);
+            const uint32_t carry = s_carry;
+            if (i < n) counts[i] = carry + ex;
+            __syncthreads();
+            if (threadIdx.x == 0) s_carry = carry + total;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) counts[n] = s_carry;
+    }
+
 }// namespace splahip

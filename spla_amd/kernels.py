@@ -32,7 +32,7 @@ def current_stream_ptr():
 
 
 class CsrPlan:
-    """Row-block launch plan of one device CSR matrix (splahip_csr_plan_*)."""
+    """Wave-tile work decomposition of one device CSR matrix (splahip_csr_plan_*)."""
 
     def __init__(self, n_rows: int, nnz: int, Ap: torch.Tensor):
         self.n_rows, self.nnz = int(n_rows), int(nnz)
@@ -40,7 +40,8 @@ class CsrPlan:
         _lib.call("splahip_csr_plan_create", C.byref(self._h), self.n_rows, self.nnz, _ptr(Ap), current_stream_ptr())
         nb, nl = C.c_uint32(), C.c_uint32()
         _lib.call("splahip_csr_plan_info", self._h, C.byref(nb), C.byref(nl))
-        self.n_blocks, self.n_long = nb.value, nl.value
+        self.n_items, self.n_long = nb.value, nl.value
+        self.n_blocks = self.n_items  # work items (one per wavefront)
 
     @property
     def handle(self):
