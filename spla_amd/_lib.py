@@ -53,6 +53,12 @@ def load() -> C.CDLL:
         if not LIB_PATH.exists():
             raise FileNotFoundError(
                 f"{LIB_PATH} is missing: build it with `python -m spla_amd.build` (there is no CPU fallback)")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Import
+        # torch first so libspla_amd.so binds to the runtime torch already loaded; two runtimes cannot share the GPU.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(str(LIB_PATH))
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
