@@ -83,6 +83,32 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
                        int op_mult, int op_add, int op_select, uint32_t init_bits, int early_exit,
                        void* stream);
 
+/* ---- masked vxm: r = v^T * M on the columns j with select(mask[j]) (reference cpu_vxm.hpp:92-125) ----------------
+ * v is sparse: nvals (index, value) pairs IN STORED ORDER; r is index-sorted COO written to d_ri / d_rx (room for
+ * n_cols entries), its entry count is returned on the host (these calls block).  `init` is not an input: the
+ * reference never uses it for vxm.
+ *   probe : number of products sum_i nnz(M[v_i,:]) and whether v's indices are strictly ascending — what the host
+ *           needs to choose the form (pull needs ascending indices, an associative + commutative op_add, and pays
+ *           nnz(M) whatever the frontier; push pays ~9x the product count).
+ *   pull  : masked SpMV over the CSR of M^T (d_Tp/d_Tj/d_Tx + its plan, see splahip_csr_transpose); v_is_identity != 0
+ *           says v stores every index 0..n_rows-1 in order, so d_vx is used as the dense vector directly.
+ *   push  : expand / stable sort by column / in-order fold of every column's run / compact.  Exact for every op.      */
+int splahip_vxm_probe(uint32_t nvals, const uint32_t* d_vi, const uint32_t* d_Ap, uint64_t* h_products, int* h_sorted, void* stream);
+int splahip_vxm_pull(splahip_plan plan_T, int type, uint32_t n_rows, uint32_t n_cols,
+                     const uint32_t* d_Tp, const uint32_t* d_Tj, const void* d_Tx, const void* d_mask,
+                     uint32_t nvals, const uint32_t* d_vi, const void* d_vx, int v_is_identity,
+                     uint32_t* d_ri, void* d_rx, uint32_t* h_count,
+                     int op_mult, int op_add, int op_select, void* stream);
+int splahip_vxm_push(int type, uint32_t n_rows, uint32_t n_cols,
+                     const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, const void* d_mask,
+                     uint32_t nvals, const uint32_t* d_vi, const void* d_vx,
+                     uint32_t* d_ri, void* d_rx, uint32_t* h_count,
+                     int op_mult, int op_add, int op_select, void* stream);
+/* CSR of the transpose (n_cols rows): entries of a column keep ascending row order (stable).  d_Tp: n_cols+1 words,
+ * d_Tj / d_Tx: nnz words.  Blocks.  (reference: the CSC slot FormatMatrix::AccCsc, include/spla/config.hpp:102-122) */
+int splahip_csr_transpose(uint32_t n_rows, uint32_t n_cols, uint32_t nnz, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax,
+                          uint32_t* d_Tp, uint32_t* d_Tj, void* d_Tx, void* stream);
+
 /* ---- accelerator vector formats ------------------------------------------------------------------------------
  * AccDense <-> AccCoo (reference src/opencl/cl_format_dense_vec.hpp:90-143, cl_format_coo_vec.hpp:149-158).
  * dense_to_coo keeps the entries != fill in ascending index order (d_idx / d_val need room for n entries) and

@@ -40,6 +40,14 @@ _SIGNATURES = {
     "splahip_mxv_masked": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp,
                                      C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, _vp]),
     "splahip_mxv_variant": (C.c_char_p, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "splahip_vec_dense_to_coo": (C.c_int, [C.c_int, C.c_uint32, _vp, C.c_uint32, _vp, _vp, _u32p, _vp]),
+    "splahip_vec_coo_to_dense": (C.c_int, [C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint32, _vp, _vp]),
+    "splahip_vxm_probe": (C.c_int, [C.c_uint32, _vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int), _vp]),
+    "splahip_vxm_pull": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_int,
+                                   _vp, _vp, _u32p, C.c_int, C.c_int, C.c_int, _vp]),
+    "splahip_vxm_push": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp,
+                                   _vp, _vp, _u32p, C.c_int, C.c_int, C.c_int, _vp]),
+    "splahip_csr_transpose": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 _RAW = {"splahip_device_count", "splahip_last_error", "splahip_version", "splahip_mxv_variant"}
 

@@ -67,6 +67,108 @@ namespace spla {
             }
         };
 
+        inline bool op_assoc_comm(int op) {
+            switch (op) {
+                case SPLAHIP_MINUS:
+                case SPLAHIP_DIV:
+                case SPLAHIP_MINUS_POW2:
+                case SPLAHIP_FIRST:
+                case SPLAHIP_SECOND: return false;
+                default: return true;
+            }
+        }
+
+        // CSR of M^T as the AccCsc decoration: derived on the device from AccCsr, cached until M changes
+        template<typename T>
+        HipCsr<T>* ensure_transpose(TMatrix<T>* M) {
+            constexpr int slot = static_cast<int>(FormatMatrix::AccCsc);
+            M->validate_ctor(FormatMatrix::AccCsc);
+            auto* t = M->acc_csc();
+            if (!M->is_valid(FormatMatrix::AccCsc)) {
+                auto*      a   = M->acc_csr();
+                const uint nnz = a->values;
+                t->drop_plan();
+                t->Ap.reserve(M->get_n_cols() + 1);
+                t->Aj.reserve(nnz);
+                t->Ax.reserve(nnz);
+                hip_check(splahip_csr_transpose(M->get_n_rows(), M->get_n_cols(), nnz, a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(),
+                                                a->Ax.ptr(), t->Ap.template as<uint32_t>(), t->Aj.template as<uint32_t>(), t->Ax.ptr(), nullptr),
+                          "splahip_csr_transpose");
+                t->values = nnz;
+                hip_check(splahip_csr_plan_create(&t->plan, M->get_n_cols(), nnz, t->Ap.template as<uint32_t>(), nullptr), "csr plan (transpose)");
+                M->storage().valid.set(slot);
+            }
+            return t;
+        }
+
+        template<typename T>
+        class Algo_vxm_masked_hip final : public RegistryAlgo {
+        public:
+            std::string get_name() override { return "vxm_masked"; }
+            std::string get_description() override { return "masked vector-matrix product: pull over the transposed CSR or push (expand / stable sort / fold)"; }
+
+            Status execute(const DispatchContext& ctx) override {
+                auto t    = ctx.task.template cast_safe<ScheduleTask_vxm_masked>();
+                auto r    = t->r.template cast_safe<TVector<T>>();
+                auto mask = t->mask.template cast_safe<TVector<T>>();
+                auto v    = t->v.template cast_safe<TVector<T>>();
+                auto M    = t->M.template cast_safe<TMatrix<T>>();
+                (void) t->init.template cast_safe<TScalar<T>>();// read but never used (reference cpu_vxm.hpp:72)
+
+                const int op_mult = device_binop<T>(t->op_multiply);
+                const int op_add  = device_binop<T>(t->op_add);
+                const int op_sel  = device_selop<T>(t->op_select);
+                if (op_mult < 0 || op_add < 0 || op_sel < 0) {
+                    SPLA_LOG(Status::NotImplemented, "user-defined ops have no device code in this build");
+                    return Status::NotImplemented;
+                }
+                if (v->get_n_rows() != M->get_n_rows() || mask->get_n_rows() != M->get_n_cols() || r->get_n_rows() != M->get_n_cols())
+                    return Status::InvalidArgument;
+
+                // sparse in / sparse out, dense mask (reference cpu_vxm.hpp:74-77, cl_vxm.hpp:85-88)
+                r->validate_wd(FormatVector::AccCoo);
+                mask->validate_rw(FormatVector::AccDense);
+                v->validate_rw(FormatVector::AccCoo);
+                M->validate_rw(FormatMatrix::AccCsr);
+
+                auto*      a     = M->acc_csr();
+                auto*      vin   = v->acc_coo();
+                auto*      out   = r->acc_coo();
+                const uint nvals = vin->values;
+                out->Ai.reserve(M->get_n_cols());
+                out->Ax.reserve(M->get_n_cols());
+                out->values = 0;
+                if (nvals == 0 || a->values == 0) return Status::Ok;
+
+                uint64_t products = 0;
+                int      sorted   = 1;
+                hip_check(splahip_vxm_probe(nvals, vin->Ai.template as<uint32_t>(), a->Ap.template as<uint32_t>(), &products, &sorted, nullptr), "splahip_vxm_probe");
+                if (products == 0) return Status::Ok;
+
+                uint32_t   count    = 0;
+                const bool can_pull = sorted && op_assoc_comm(op_add);
+                const bool pull     = can_pull && products * 8ull >= a->values;// push costs ~9x the products, pull costs nnz(M)
+                if (pull) {
+                    auto*     tr       = ensure_transpose<T>(M.get());
+                    const int identity = nvals == M->get_n_rows() ? 1 : 0;
+                    hip_check(splahip_vxm_pull(tr->plan, TypeTraits<T>::id, M->get_n_rows(), M->get_n_cols(), tr->Ap.template as<uint32_t>(),
+                                               tr->Aj.template as<uint32_t>(), tr->Ax.ptr(), mask->acc_dense()->Ax.ptr(), nvals,
+                                               vin->Ai.template as<uint32_t>(), vin->Ax.ptr(), identity, out->Ai.template as<uint32_t>(),
+                                               out->Ax.ptr(), &count, op_mult, op_add, op_sel, nullptr),
+                              "splahip_vxm_pull");
+                } else {
+                    if (products > 0xFFFFFFF0ull) return Status::InvalidArgument;// uint32 product indices
+                    hip_check(splahip_vxm_push(TypeTraits<T>::id, M->get_n_rows(), M->get_n_cols(), a->Ap.template as<uint32_t>(),
+                                               a->Aj.template as<uint32_t>(), a->Ax.ptr(), mask->acc_dense()->Ax.ptr(), nvals,
+                                               vin->Ai.template as<uint32_t>(), vin->Ax.ptr(), out->Ai.template as<uint32_t>(), out->Ax.ptr(),
+                                               &count, op_mult, op_add, op_sel, nullptr),
+                              "splahip_vxm_push");
+                }
+                out->values = count;
+                return Status::Ok;
+            }
+        };
+
         template<template<typename> class Algo>
         void add3(Registry* g, const std::string& name) {
             g->add(name + "_I__hip", std::make_shared<Algo<T_INT>>());
@@ -77,6 +179,7 @@ namespace spla {
 
     void register_algo_hip(Registry* g) {
         add3<Algo_mxv_masked_hip>(g, "mxv_masked");
+        add3<Algo_vxm_masked_hip>(g, "vxm_masked");
     }
 
 }// namespace spla

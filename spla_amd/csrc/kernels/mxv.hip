@@ -17,20 +17,11 @@
 #include "common.hpp"
 #include "mxv_kernels.hpp"
 #include "ops.hpp"
+#include "plan.hpp"
 
 using namespace splahip;
 
 using Cfg = MxvCfg;
-
-struct splahip_plan_s {
-    uint32_t  n_rows  = 0;
-    uint32_t  nnz     = 0;
-    uint32_t  n_items = 0;
-    uint32_t  n_long  = 0;       // rows cut into segment items
-    uint32_t* d_item_row = nullptr;// n_items + 1
-    uint32_t* d_item_k0  = nullptr;// n_items + 1
-    uint32_t* d_partial  = nullptr;// n_items words of scratch (per-segment partial results)
-};
 
 namespace {
 
@@ -59,17 +50,18 @@ namespace {
                         const void* v, void* r, int op_mult, int op_add, int op_select, uint32_t init_bits, hipStream_t st) {
         const bool vec_ok = ((reinterpret_cast<uintptr_t>(Aj) | reinterpret_cast<uintptr_t>(Ax)) & 15u) == 0;
         const uint grid   = (plan->n_items + Cfg::kWaves - 1) / Cfg::kWaves;
-        hipLaunchKernelGGL((mxv_wavetile_kernel<Cfg, T, Mult, Add>), dim3(grid), dim3(Cfg::kTpb), 0, st,
+        hipLaunchKernelGGL((spmv_wavetile_kernel<Cfg, T, Mult, Add, false>), dim3(grid), dim3(Cfg::kTpb), 0, st,
                            plan->d_item_row, plan->d_item_k0, plan->n_items, Ap, Aj, static_cast<const uint32_t*>(Ax),
-                           static_cast<const T*>(mask), static_cast<const T*>(v), static_cast<T*>(r),
-                           reinterpret_cast<T*>(plan->d_partial), Mult(op_mult), Add(op_add), op_select,
+                           static_cast<const T*>(mask), static_cast<const T*>(v), static_cast<const uint32_t*>(nullptr),
+                           static_cast<T*>(r), static_cast<uint32_t*>(nullptr), reinterpret_cast<T*>(plan->d_partial),
+                           static_cast<uint32_t*>(nullptr), Mult(op_mult), Add(op_add), op_select,
                            from_bits<T>(init_bits), plan->nnz, vec_ok ? 1 : 0);
         SPLAHIP_TRY(hipGetLastError());
         if (plan->n_long > 0) {
-            hipLaunchKernelGGL((mxv_combine_kernel<Cfg, T, Add>), dim3((plan->n_items + 255) / 256), dim3(256), 0, st,
+            hipLaunchKernelGGL((spmv_combine_kernel<Cfg, T, Add, false>), dim3((plan->n_items + 255) / 256), dim3(256), 0, st,
                                plan->d_item_row, plan->d_item_k0, plan->n_items, Ap, static_cast<const T*>(mask),
-                               static_cast<T*>(r), reinterpret_cast<const T*>(plan->d_partial), Add(op_add), op_select,
-                               from_bits<T>(init_bits));
+                               static_cast<T*>(r), static_cast<uint32_t*>(nullptr), reinterpret_cast<const T*>(plan->d_partial),
+                               static_cast<const uint32_t*>(nullptr), Add(op_add), op_select, from_bits<T>(init_bits));
             SPLAHIP_TRY(hipGetLastError());
         }
         return SPLAHIP_OK;
@@ -118,6 +110,7 @@ namespace {
         if (plan->d_item_row) (void) hipFree(plan->d_item_row);
         if (plan->d_item_k0) (void) hipFree(plan->d_item_k0);
         if (plan->d_partial) (void) hipFree(plan->d_partial);
+        if (plan->d_partial_ok) (void) hipFree(plan->d_partial_ok);
         delete plan;
     }
 
@@ -165,6 +158,7 @@ int splahip_csr_plan_create(splahip_plan* out, uint32_t n_rows, uint32_t nnz, co
         e                  = hipMalloc(reinterpret_cast<void**>(&plan->d_item_row), bytes);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&plan->d_item_k0), bytes);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&plan->d_partial), bytes);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&plan->d_partial_ok), bytes);
     }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(plan_write_kernel<Cfg>, dim3(n_chunks), dim3(256), 0, s, d_Ap, n_rows, nnz, d_chunk, n_chunks,

@@ -155,22 +155,43 @@ namespace splahip {
         }
     }
 
-    template<class C, typename T, class Mult, class Add>
-    __global__ __launch_bounds__(C::kTpb) void mxv_wavetile_kernel(const uint* __restrict__ item_row,
-                                                                   const uint* __restrict__ item_k0,
-                                                                   uint n_items,
-                                                                   const uint* __restrict__ Ap,
-                                                                   const uint* __restrict__ Aj,
-                                                                   const uint* __restrict__ Ax,
-                                                                   const T* __restrict__ mask,
-                                                                   const T* __restrict__ v,
-                                                                   T* __restrict__ r,
-                                                                   T* __restrict__ partial,
-                                                                   Mult mult, Add add, int op_select, T init,
-                                                                   uint nnz, int vec_ok) {
+    // Operand access of one matrix entry.  MXV: p = mult(Ax[k], v[Aj[k]]), always defined.
+    // VXM (pull form over the transposed matrix): p = mult(v[i], x) and only defined when v stores entry i
+    // (`present` bitmap; nullptr = every entry stored).
+    template<bool VXM, typename T, class Mult>
+    __device__ __forceinline__ T entry_product(const Mult& mult, uint xbits, T vj) {
+        if constexpr (VXM) return mult(vj, from_bits<T>(xbits));
+        else
+            return mult(from_bits<T>(xbits), vj);
+    }
+    __device__ __forceinline__ bool bit_present(const uint* __restrict__ present, uint j) {
+        return present == nullptr || ((present[j >> 5] >> (j & 31u)) & 1u) != 0;
+    }
+
+    // The wave-tile SpMV kernel.  VXM = false: masked mxv (every row written, fold starts at init).
+    // VXM = true: the pull form of vxm on the transposed matrix: "rows" are output columns, entries whose v index is
+    // not stored are skipped, the fold starts at the first product (no init) and touched[row] tells whether the
+    // output entry exists (reference src/cpu/cpu_vxm.hpp:101-107).
+    template<class C, typename T, class Mult, class Add, bool VXM>
+    __global__ __launch_bounds__(C::kTpb) void spmv_wavetile_kernel(const uint* __restrict__ item_row,
+                                                                    const uint* __restrict__ item_k0,
+                                                                    uint n_items,
+                                                                    const uint* __restrict__ Ap,
+                                                                    const uint* __restrict__ Aj,
+                                                                    const uint* __restrict__ Ax,
+                                                                    const T* __restrict__ mask,
+                                                                    const T* __restrict__ v,
+                                                                    const uint* __restrict__ present,
+                                                                    T* __restrict__ r,
+                                                                    uint* __restrict__ touched,
+                                                                    T* __restrict__ partial,
+                                                                    uint* __restrict__ partial_ok,
+                                                                    Mult mult, Add add, int op_select, T init,
+                                                                    uint nnz, int vec_ok) {
         __shared__ uint          s_ap_all[C::kWaves][C::kRowsCap + 1];
         __shared__ T             s_prod_all[C::kWaves][C::kStage + 4];
         __shared__ unsigned char s_sel_all[C::kWaves][C::kRowsCap];
+        __shared__ unsigned char s_ok_all[C::kWaves][VXM ? C::kStage + 4 : 4];
 
         const uint lane = lane_id();
         const uint w    = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -182,7 +203,7 @@ namespace splahip {
         const uint k0  = item_k0[item];
         const uint k1  = item_k0[item + 1];
         const uint row = e0 & ~C::kSegFlag;
-        const uint a0  = k0 & ~3u;                     // 16-byte aligned origin of the entry slice
+        const uint a0  = k0 & ~3u;                        // 16-byte aligned origin of the entry slice
         const uint nq  = k1 > a0 ? (k1 - a0 + 3) >> 2 : 0;// quads in the slice, <= 256
 
         if (e0 & C::kSegFlag) {
@@ -191,7 +212,11 @@ namespace splahip {
             const uint len  = Ap[row + 1] - rs;
             const uint nseg = (len + C::kSeg - 1) / C::kSeg;
             if (!eval_sel(op_select, mask[row])) {
-                if (nseg == 1 && lane == 0) r[row] = init;// multi-segment rows are finished by mxv_combine
+                if (nseg == 1 && lane == 0) {// multi-segment rows are finished by the combine kernel
+                    if constexpr (VXM) touched[row] = 0;
+                    else
+                        r[row] = init;
+                }
                 return;
             }
             uint4 jq[4], xq[4];
@@ -211,12 +236,17 @@ namespace splahip {
                     const uint jj[4] = {jq[u].x, jq[u].y, jq[u].z, jq[u].w};
                     const uint xx[4] = {xq[u].x, xq[u].y, xq[u].z, xq[u].w};
                     T          vv[4];
-#pragma unroll
-                    for (uint e = 0; e < 4; ++e) vv[e] = (kq + e >= k0 && kq + e < k1) ? v[jj[e]] : T(0);
+                    bool       ok[4];
 #pragma unroll
                     for (uint e = 0; e < 4; ++e) {
-                        if (kq + e >= k0 && kq + e < k1) {
-                            const T p = mult(from_bits<T>(xx[e]), vv[e]);
+                        ok[e] = kq + e >= k0 && kq + e < k1;
+                        if (VXM && ok[e]) ok[e] = bit_present(present, jj[e]);
+                        vv[e] = ok[e] ? v[jj[e]] : T(0);
+                    }
+#pragma unroll
+                    for (uint e = 0; e < 4; ++e) {
+                        if (ok[e]) {
+                            const T p = entry_product<VXM>(mult, xx[e], vv[e]);
                             part      = valid ? add(part, p) : p;
                             valid     = true;
                         }
@@ -225,9 +255,17 @@ namespace splahip {
             }
             wave_reduce_ordered(part, valid, add);
             if (lane == 0) {
-                if (nseg == 1) r[row] = valid ? add(init, part) : init;
-                else
-                    partial[item] = part;// every segment holds >= 1 entry, so `part` is valid
+                if (nseg == 1) {
+                    if constexpr (VXM) {
+                        touched[row] = valid ? 1u : 0u;
+                        if (valid) r[row] = part;
+                    } else {
+                        r[row] = valid ? add(init, part) : init;
+                    }
+                } else {
+                    partial[item] = part;
+                    if constexpr (VXM) partial_ok[item] = valid ? 1u : 0u;
+                }
             }
             return;
         }
@@ -237,6 +275,7 @@ namespace splahip {
         uint*          s_ap   = s_ap_all[w];
         T*             s_prod = s_prod_all[w];
         unsigned char* s_sel  = s_sel_all[w];
+        unsigned char* s_ok   = s_ok_all[w];
 
         // 1. row starts and mask -> LDS
         int any = 0, all = 1;
@@ -253,11 +292,15 @@ namespace splahip {
         }
         const bool any_sel = __ballot(any) != 0ull;
         const bool all_sel = __ballot(!all) == 0ull;
-        if (!any_sel) {// nothing selected: every row gets init, no matrix entry is touched
+        if (!any_sel) {// nothing selected: no matrix entry is touched
 #pragma unroll
             for (uint u = 0; u < C::kRowsCap / kWave; ++u) {
                 const uint i = lane + u * kWave;
-                if (i < nr) r[row + i] = init;
+                if (i < nr) {
+                    if constexpr (VXM) touched[row + i] = 0;
+                    else
+                        r[row + i] = init;
+                }
             }
             return;
         }
@@ -284,23 +327,33 @@ namespace splahip {
             }
 #pragma unroll
             for (uint u = 0; u < 4; ++u) {
+                const uint qi = lane + u * kWave;
                 if (act[u]) {
-                    const uint qi    = lane + u * kWave;
                     const uint kq    = a0 + 4 * qi;
                     const uint jj[4] = {jq[u].x, jq[u].y, jq[u].z, jq[u].w};
                     const uint xx[4] = {xq[u].x, xq[u].y, xq[u].z, xq[u].w};
                     T          vv[4];
+                    bool       ok[4];
 #pragma unroll
-                    for (uint e = 0; e < 4; ++e) vv[e] = (kq + e >= k0 && kq + e < k1) ? v[jj[e]] : T(0);
+                    for (uint e = 0; e < 4; ++e) {
+                        ok[e] = kq + e >= k0 && kq + e < k1;
+                        if (VXM && ok[e]) ok[e] = bit_present(present, jj[e]);
+                        vv[e] = ok[e] ? v[jj[e]] : T(0);
+                    }
 #pragma unroll
-                    for (uint e = 0; e < 4; ++e)
-                        if (kq + e >= k0 && kq + e < k1) s_prod[4 * qi + e] = mult(from_bits<T>(xx[e]), vv[e]);
+                    for (uint e = 0; e < 4; ++e) {
+                        if (ok[e]) s_prod[4 * qi + e] = entry_product<VXM>(mult, xx[e], vv[e]);
+                        if constexpr (VXM) s_ok[4 * qi + e] = ok[e] ? 1 : 0;
+                    }
+                } else if (VXM && qi < nq) {
+#pragma unroll
+                    for (uint e = 0; e < 4; ++e) s_ok[4 * qi + e] = 0;
                 }
             }
         }
         wave_lds_fence();
 
-        // 3. fold every row out of LDS: a lane per short row (strict left fold from init = the reference's order);
+        // 3. fold every row out of LDS: a lane per short row (strict left fold in entry order = the reference's order);
         //    rows longer than kShortMax are folded by the whole wave (lane-contiguous odd-length chunks, in-order
         //    segmented shuffle reduction)
 #pragma unroll
@@ -308,16 +361,33 @@ namespace splahip {
             const uint i       = lane + u * kWave;
             bool       is_long = false;
             if (i < nr) {
-                T out = init;
+                T    out = init;
+                bool has = !VXM;
                 if (s_sel[i]) {
                     const uint s = s_ap[i] - a0, e = s_ap[i + 1] - a0;
                     if (e - s <= C::kShortMax) {
-                        for (uint k = s; k < e; ++k) out = add(out, s_prod[k]);
+                        for (uint k = s; k < e; ++k) {
+                            if constexpr (VXM) {
+                                if (s_ok[k]) {
+                                    out = has ? add(out, s_prod[k]) : s_prod[k];
+                                    has = true;
+                                }
+                            } else {
+                                out = add(out, s_prod[k]);
+                            }
+                        }
                     } else {
                         is_long = true;
                     }
                 }
-                if (!is_long) r[row + i] = out;
+                if (!is_long) {
+                    if constexpr (VXM) {
+                        touched[row + i] = has ? 1u : 0u;
+                        if (has) r[row + i] = out;
+                    } else {
+                        r[row + i] = out;
+                    }
+                }
             }
             unsigned long long todo = __ballot(is_long);
             while (todo) {
@@ -328,24 +398,34 @@ namespace splahip {
                 const uint c  = ((e - s + kWave - 1) / kWave) | 1u;
                 const uint ks = s + lane * c;
                 const uint ke = min(ks + c, e);
-                bool       valid = ks < e;
+                bool       valid = false;
                 T          part  = init;
-                if (valid) {
-                    part = s_prod[ks];
-                    for (uint k = ks + 1; k < ke; ++k) part = add(part, s_prod[k]);
+                for (uint k = ks; k < ke; ++k) {
+                    if (!VXM || s_ok[k]) {
+                        part  = valid ? add(part, s_prod[k]) : s_prod[k];
+                        valid = true;
+                    }
                 }
                 wave_reduce_ordered(part, valid, add);
-                if (lane == 0) r[row + li] = valid ? add(init, part) : init;
+                if (lane == 0) {
+                    if constexpr (VXM) {
+                        touched[row + li] = valid ? 1u : 0u;
+                        if (valid) r[row + li] = part;
+                    } else {
+                        r[row + li] = valid ? add(init, part) : init;
+                    }
+                }
             }
         }
     }
 
-    // finish rows made of several segment items: strict in-order fold of their partials from init
-    template<class C, typename T, class Add>
-    __global__ __launch_bounds__(256) void mxv_combine_kernel(const uint* __restrict__ item_row, const uint* __restrict__ item_k0,
-                                                              uint n_items, const uint* __restrict__ Ap,
-                                                              const T* __restrict__ mask, T* __restrict__ r,
-                                                              const T* __restrict__ partial, Add add, int op_select, T init) {
+    // finish rows made of several segment items: strict in-order fold of their partials
+    template<class C, typename T, class Add, bool VXM>
+    __global__ __launch_bounds__(256) void spmv_combine_kernel(const uint* __restrict__ item_row, const uint* __restrict__ item_k0,
+                                                               uint n_items, const uint* __restrict__ Ap,
+                                                               const T* __restrict__ mask, T* __restrict__ r, uint* __restrict__ touched,
+                                                               const T* __restrict__ partial, const uint* __restrict__ partial_ok,
+                                                               Add add, int op_select, T init) {
         const uint i = blockIdx.x * 256 + threadIdx.x;
         if (i >= n_items) return;
         const uint e0 = item_row[i];
@@ -356,10 +436,22 @@ namespace splahip {
         const uint len  = Ap[row + 1] - rs;
         const uint nseg = (len + C::kSeg - 1) / C::kSeg;
         if (nseg == 1) return;// written by the main kernel
-        T out = init;
-        if (eval_sel(op_select, mask[row]))
-            for (uint g = 0; g < nseg; ++g) out = add(out, partial[i + g]);
-        r[row] = out;
+        T    out = init;
+        bool has = !VXM;
+        if (eval_sel(op_select, mask[row])) {
+            for (uint g = 0; g < nseg; ++g) {
+                if (!VXM || partial_ok[i + g]) {
+                    out = has ? add(out, partial[i + g]) : partial[i + g];
+                    has = true;
+                }
+            }
+        }
+        if constexpr (VXM) {
+            touched[row] = has ? 1u : 0u;
+            if (has) r[row] = out;
+        } else {
+            r[row] = out;
+        }
     }
 
     // ------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,558 @@
+// vxm.hip — masked sparse-vector x sparse-matrix, r = v^T * M restricted to columns j with select(mask[j]).
+//
+// Semantics: reference Algo_vxm_masked_cpu<T>::execute, src/cpu/cpu_vxm.hpp:58-128 (the parity oracle): for every
+// stored entry (i, v_i) of v IN STORED ORDER, for every (j, x) of row i: the first hit of column j stores mult(v_i, x),
+// later hits add(r_j, mult(v_i, x)); `init` is not used; output = index-sorted COO with explicit zeros kept.
+// Entry point replaced: Algo_vxm_masked_cl<T>::execute, src/opencl/cl_vxm.hpp:60-173 (count / collect / sort /
+// reduce-by-key) — not ported.  Two forms, chosen by the host algorithm from the product count:
+//
+//   pull  (dense-ish v, e.g. the PageRank step): masked SpMV over the CSR of M^T with the wave-tile kernel in VXM mode
+//         (mxv_kernels.hpp): column j folds its entries in ascending i, which is v's stored order whenever v's COO is
+//         index-sorted (always, unless the caller build()s an unsorted vector with a non-commutative op_add, in which
+//         case the host picks push).  HBM-bound: 8*nnz(M) + 12*n_cols + 4*n_rows bytes.
+//   push  (sparse frontier): expand the products of the frontier rows in (stored order of v, row order), STABLE radix sort
+//         by column (rocPRIM), fold every column's run in order, compact.  Exact for every op, including fp32 PLUS and
+//         non-commutative op_add, because the run order is the reference's fold order.
+#include "block_utils.hpp"
+#include "common.hpp"
+#include "mxv_kernels.hpp"
+#include "ops.hpp"
+#include "plan.hpp"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace splahip {
+
+    using Cfg = MxvCfg;
+
+    // ------------------------------------------------------------------------------------------------------------
+    // small device utilities
+    // ------------------------------------------------------------------------------------------------------------
+    struct DevMem {// scoped hipMalloc
+        void* p = nullptr;
+        ~DevMem() {
+            if (p) (void) hipFree(p);
+        }
+        hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
+        template<typename U>
+        U* as() { return static_cast<U*>(p); }
+    };
+
+    __host__ __device__ inline uint bit_width_u32(uint x) {
+        uint b = 0;
+        while (x) {
+            ++b;
+            x >>= 1;
+        }
+        return b ? b : 1;
+    }
+
+    // per-chunk (1024 elements) sums of x[0..n)
+    __global__ __launch_bounds__(256) void chunk_sum_kernel(const uint* __restrict__ x, uint n, uint* __restrict__ chunk) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        uint            sum   = 0;
+#pragma unroll
+        for (uint u = 0; u < 4; ++u)
+            if (first + u < n) sum += x[first + u];
+        uint total;
+        (void) block_exclusive_sum<256>(sum, s_tmp, total);
+        if (threadIdx.x == 0) chunk[blockIdx.x] = total;
+    }
+    // out[i] = chunk_offset + exclusive prefix inside the chunk; out[n] = total
+    __global__ __launch_bounds__(256) void chunk_scan_apply_kernel(const uint* __restrict__ x, uint n, const uint* __restrict__ chunk,
+                                                                   uint n_chunks, uint* __restrict__ out) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        uint            val[4];
+        uint            sum = 0;
+#pragma unroll
+        for (uint u = 0; u < 4; ++u) {
+            val[u] = first + u < n ? x[first + u] : 0;
+            sum += val[u];
+        }
+        uint total;
+        uint pos = chunk[blockIdx.x] + block_exclusive_sum<256>(sum, s_tmp, total);
+#pragma unroll
+        for (uint u = 0; u < 4; ++u) {
+            if (first + u < n) out[first + u] = pos;
+            pos += val[u];
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = chunk[n_chunks];
+    }
+
+    // exclusive scan of n uint32 into out[n+1] (out[n] = total); x and out may not alias
+    static hipError_t exclusive_scan_u32(const uint* x, uint n, uint* out, hipStream_t s) {
+        const uint n_chunks = (n + 1023u) / 1024u;
+        DevMem     chunk;
+        hipError_t e = chunk.alloc(sizeof(uint) * (size_t) (n_chunks + 1));
+        if (e != hipSuccess) return e;
+        if (n == 0) return hipMemsetAsync(out, 0, sizeof(uint), s);
+        hipLaunchKernelGGL(chunk_sum_kernel, dim3(n_chunks), dim3(256), 0, s, x, n, chunk.as<uint>());
+        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk.as<uint>(), n_chunks);
+        hipLaunchKernelGGL(chunk_scan_apply_kernel, dim3(n_chunks), dim3(256), 0, s, x, n, chunk.as<uint>(), n_chunks, out);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(s);// chunk is freed on return
+        return e;
+    }
+
+    // last i in [0, n) with a[i] <= k, for a[0] <= k < a[n]
+    __device__ __forceinline__ uint upper_row(const uint* __restrict__ a, uint n, uint k) {
+        uint lo = 0, hi = n;
+        while (hi - lo > 1) {
+            const uint mid = (lo + hi) >> 1;
+            if (a[mid] <= k) lo = mid;
+            else
+                hi = mid;
+        }
+        return lo;
+    }
+
+    // ------------------------------------------------------------------------------------------------------------
+    // transpose (CSR of M^T, rows ascending inside every column)
+    // ------------------------------------------------------------------------------------------------------------
+    __global__ __launch_bounds__(256) void iota_kernel(uint* __restrict__ x, uint n) {
+        const uint i = blockIdx.x * 256 + threadIdx.x;
+        if (i < n) x[i] = i;
+    }
+    __global__ __launch_bounds__(256) void transpose_fill_kernel(uint nnz, uint n_rows, const uint* __restrict__ Ap, const uint* __restrict__ Ax,
+                                                                 const uint* __restrict__ perm, uint* __restrict__ Tj, uint* __restrict__ Tx) {
+        const uint t = blockIdx.x * 256 + threadIdx.x;
+        if (t >= nnz) return;
+        const uint k = perm[t];
+        Tj[t]        = upper_row(Ap, n_rows, k);
+        Tx[t]        = Ax[k];
+    }
+    // Tp[c] = first t with sorted_col[t] >= c
+    __global__ __launch_bounds__(256) void transpose_ptr_kernel(uint nnz, uint n_cols, const uint* __restrict__ sorted_col, uint* __restrict__ Tp) {
+        const uint c = blockIdx.x * 256 + threadIdx.x;
+        if (c > n_cols) return;
+        uint lo = 0, hi = nnz;
+        while (lo < hi) {
+            const uint mid = (lo + hi) >> 1;
+            if (sorted_col[mid] < c) lo = mid + 1;
+            else
+                hi = mid;
+        }
+        Tp[c] = lo;
+    }
+
+    // ------------------------------------------------------------------------------------------------------------
+    // probe: number of products of the frontier and whether v's indices are strictly ascending
+    // ------------------------------------------------------------------------------------------------------------
+    __global__ __launch_bounds__(256) void probe_kernel(uint nvals, const uint* __restrict__ vi, const uint* __restrict__ Ap,
+                                                        unsigned long long* __restrict__ products, uint* __restrict__ unsorted) {
+        const uint         idx = blockIdx.x * 256 + threadIdx.x;
+        unsigned long long len = 0;
+        uint               bad = 0;
+        if (idx < nvals) {
+            const uint i = vi[idx];
+            len          = Ap[i + 1] - Ap[i];
+            if (idx > 0 && vi[idx - 1] >= i) bad = 1;
+        }
+        for (uint off = kWave / 2; off > 0; off >>= 1) {
+            len += __shfl_xor(len, off, kWave);
+            bad |= __shfl_xor(bad, off, kWave);
+        }
+        if (lane_id() == 0) {
+            if (len) atomicAdd(products, len);
+            if (bad) atomicOr(unsorted, 1u);
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------------------------
+    // pull helpers
+    // ------------------------------------------------------------------------------------------------------------
+    __global__ __launch_bounds__(256) void scatter_present_kernel(uint nvals, const uint* __restrict__ vi, const uint* __restrict__ vx,
+                                                                  uint* __restrict__ dense, uint* __restrict__ present) {
+        const uint idx = blockIdx.x * 256 + threadIdx.x;
+        if (idx >= nvals) return;
+        const uint i = vi[idx];
+        dense[i]     = vx[idx];
+        atomicOr(&present[i >> 5], 1u << (i & 31u));
+    }
+
+    __global__ __launch_bounds__(256) void flag_count_kernel(const uint* __restrict__ flag, uint n, uint* __restrict__ chunk) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        uint            cnt   = 0;
+#pragma unroll
+        for (uint u = 0; u < 4; ++u)
+            if (first + u < n) cnt += flag[first + u] ? 1u : 0u;
+        uint total;
+        (void) block_exclusive_sum<256>(cnt, s_tmp, total);
+        if (threadIdx.x == 0) chunk[blockIdx.x] = total;
+    }
+    __global__ __launch_bounds__(256) void flag_write_kernel(const uint* __restrict__ flag, const uint* __restrict__ val, uint n,
+                                                             const uint* __restrict__ chunk, uint* __restrict__ out_i, uint* __restrict__ out_x) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        bool            keep[4];
+        uint            cnt = 0;
+#pragma unroll
+        for (uint u = 0; u < 4; ++u) {
+            keep[u] = first + u < n && flag[first + u] != 0;
+            cnt += keep[u] ? 1u : 0u;
+        }
+        uint total;
+        uint pos = chunk[blockIdx.x] + block_exclusive_sum<256>(cnt, s_tmp, total);
+#pragma unroll
+        for (uint u = 0; u < 4; ++u)
+            if (keep[u]) {
+                out_i[pos] = first + u;
+                out_x[pos] = val[first + u];
+                ++pos;
+            }
+    }
+
+    // ------------------------------------------------------------------------------------------------------------
+    // push (expand / stable sort / fold runs / compact)
+    // ------------------------------------------------------------------------------------------------------------
+    __global__ __launch_bounds__(256) void frontier_len_kernel(uint nvals, const uint* __restrict__ vi, const uint* __restrict__ Ap, uint* __restrict__ len) {
+        const uint idx = blockIdx.x * 256 + threadIdx.x;
+        if (idx < nvals) len[idx] = Ap[vi[idx] + 1] - Ap[vi[idx]];
+    }
+
+    template<typename T, class Mult>
+    __global__ __launch_bounds__(256) void expand_kernel(uint n_products, uint nvals, const uint* __restrict__ offs,
+                                                         const uint* __restrict__ vi, const T* __restrict__ vx,
+                                                         const uint* __restrict__ Ap, const uint* __restrict__ Aj, const uint* __restrict__ Ax,
+                                                         const T* __restrict__ mask, uint n_cols, int op_select, Mult mult,
+                                                         uint* __restrict__ key, T* __restrict__ val) {
+        const uint p = blockIdx.x * 256 + threadIdx.x;
+        if (p >= n_products) return;
+        const uint idx = upper_row(offs, nvals, p);
+        const uint k   = Ap[vi[idx]] + (p - offs[idx]);
+        const uint j   = Aj[k];
+        const bool sel = eval_sel(op_select, mask[j]);
+        key[p]         = sel ? j : n_cols;// unselected products sort behind every column
+        val[p]         = mult(vx[idx], from_bits<T>(Ax[k]));
+    }
+
+    __global__ __launch_bounds__(256) void head_count_kernel(const uint* __restrict__ key, uint n, uint n_cols, uint* __restrict__ chunk) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        uint            cnt   = 0;
+#pragma unroll
+        for (uint u = 0; u < 4; ++u) {
+            const uint p = first + u;
+            if (p < n && key[p] < n_cols && (p == 0 || key[p - 1] != key[p])) cnt += 1;
+        }
+        uint total;
+        (void) block_exclusive_sum<256>(cnt, s_tmp, total);
+        if (threadIdx.x == 0) chunk[blockIdx.x] = total;
+    }
+
+    constexpr uint kRunShort = 64;// runs up to this length are folded by the lane that owns their head
+
+    // every run head: write the column id, fold the run in order if it is short, else queue it for the wave kernel
+    template<typename T, class Add>
+    __global__ __launch_bounds__(256) void run_fold_kernel(const uint* __restrict__ key, const T* __restrict__ val, uint n, uint n_cols,
+                                                           const uint* __restrict__ chunk, uint* __restrict__ out_i, T* __restrict__ out_x,
+                                                           uint* __restrict__ long_count, uint* __restrict__ long_pos, uint* __restrict__ long_rank,
+                                                           Add add) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        bool            head[4];
+        uint            cnt = 0;
+#pragma unroll
+        for (uint u = 0; u < 4; ++u) {
+            const uint p = first + u;
+            head[u]      = p < n && key[p] < n_cols && (p == 0 || key[p - 1] != key[p]);
+            cnt += head[u] ? 1u : 0u;
+        }
+        uint total;
+        uint rank = chunk[blockIdx.x] + block_exclusive_sum<256>(cnt, s_tmp, total);
+#pragma unroll
+        for (uint u = 0; u < 4; ++u) {
+            if (!head[u]) continue;
+            const uint p = first + u;
+            const uint j = key[p];
+            out_i[rank]  = j;
+            T    acc     = val[p];
+            uint q       = p + 1;
+            while (q < n && q - p < kRunShort && key[q] == j) {
+                acc = add(acc, val[q]);
+                ++q;
+            }
+            if (q < n && key[q] == j) {// longer than kRunShort: hand over (the whole run is redone in order)
+                const uint slot = atomicAdd(long_count, 1u);
+                long_pos[slot]  = p;
+                long_rank[slot] = rank;
+            } else {
+                out_x[rank] = acc;
+            }
+            ++rank;
+        }
+    }
+
+    // one wavefront per long run: lane-contiguous chunks, in-order segmented shuffle reduction.  ORDERED = false is
+    // only used for non-associative op_add: lane 0 folds the run sequentially.
+    template<typename T, class Add, bool TREE>
+    __global__ __launch_bounds__(256) void long_run_kernel(const uint* __restrict__ key, const T* __restrict__ val, uint n,
+                                                           const uint* __restrict__ long_count, const uint* __restrict__ long_pos,
+                                                           const uint* __restrict__ long_rank, T* __restrict__ out_x, Add add) {
+        const uint w = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+        if (w >= *long_count) return;
+        const uint lane = lane_id();
+        const uint p    = long_pos[w];
+        const uint j    = key[p];
+        // end of the run: first q > p with key[q] != j (keys are sorted)
+        uint lo = p + 1, hi = n;
+        while (lo < hi) {
+            const uint mid = (lo + hi) >> 1;
+            if (key[mid] == j) lo = mid + 1;
+            else
+                hi = mid;
+        }
+        const uint e = lo;
+        if constexpr (TREE) {
+            const uint c  = (e - p + kWave - 1) / kWave;
+            const uint ks = p + lane * c;
+            const uint ke = min(ks + c, e);
+            bool       valid = ks < e;
+            T          part  = T(0);
+            if (valid) {
+                part = val[ks];
+                for (uint q = ks + 1; q < ke; ++q) part = add(part, val[q]);
+            }
+            wave_reduce_ordered(part, valid, add);
+            if (lane == 0) out_x[long_rank[w]] = part;
+        } else {
+            if (lane == 0) {
+                T acc = val[p];
+                for (uint q = p + 1; q < e; ++q) acc = add(acc, val[q]);
+                out_x[long_rank[w]] = acc;
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------------------------
+    // typed drivers
+    // ------------------------------------------------------------------------------------------------------------
+    template<typename T, class Mult, class Add>
+    int pull_typed(splahip_plan plan, uint n_out, uint n_in, const uint* Tp, const uint* Tj, const void* Tx, const void* mask,
+                   uint nvals, const uint* vi, const void* vx, int v_is_identity, uint* ri, void* rx, uint* h_count,
+                   int op_mult, int op_add, int op_select, hipStream_t s) {
+        DevMem dense, present, outv, touched, chunk;
+        const uint* d_present = nullptr;
+        const T*    d_v       = static_cast<const T*>(vx);
+        if (!v_is_identity) {
+            const uint words = (n_in + 31u) / 32u;
+            SPLAHIP_TRY(dense.alloc(sizeof(uint) * (size_t) n_in));
+            SPLAHIP_TRY(present.alloc(sizeof(uint) * (size_t) words));
+            SPLAHIP_TRY(hipMemsetAsync(present.p, 0, sizeof(uint) * (size_t) words, s));
+            if (nvals)
+                hipLaunchKernelGGL(scatter_present_kernel, dim3((nvals + 255) / 256), dim3(256), 0, s, nvals, vi,
+                                   static_cast<const uint*>(vx), dense.as<uint>(), present.as<uint>());
+            d_present = present.as<uint>();
+            d_v       = dense.as<T>();
+        }
+        SPLAHIP_TRY(outv.alloc(sizeof(uint) * (size_t) n_out));
+        SPLAHIP_TRY(touched.alloc(sizeof(uint) * (size_t) n_out));
+        const bool vec_ok = ((reinterpret_cast<uintptr_t>(Tj) | reinterpret_cast<uintptr_t>(Tx)) & 15u) == 0;
+        const uint grid   = (plan->n_items + Cfg::kWaves - 1) / Cfg::kWaves;
+        if (plan->n_items) {
+            hipLaunchKernelGGL((spmv_wavetile_kernel<Cfg, T, Mult, Add, true>), dim3(grid), dim3(Cfg::kTpb), 0, s,
+                               plan->d_item_row, plan->d_item_k0, plan->n_items, Tp, Tj, static_cast<const uint*>(Tx),
+                               static_cast<const T*>(mask), d_v, d_present, outv.as<T>(), touched.as<uint>(),
+                               reinterpret_cast<T*>(plan->d_partial), plan->d_partial_ok, Mult(op_mult), Add(op_add), op_select,
+                               T(0), plan->nnz, vec_ok ? 1 : 0);
+            if (plan->n_long > 0)
+                hipLaunchKernelGGL((spmv_combine_kernel<Cfg, T, Add, true>), dim3((plan->n_items + 255) / 256), dim3(256), 0, s,
+                                   plan->d_item_row, plan->d_item_k0, plan->n_items, Tp, static_cast<const T*>(mask), outv.as<T>(),
+                                   touched.as<uint>(), reinterpret_cast<const T*>(plan->d_partial), plan->d_partial_ok, Add(op_add),
+                                   op_select, T(0));
+        }
+        SPLAHIP_TRY(hipGetLastError());
+        // compaction of the touched columns, ascending
+        const uint n_chunks = (n_out + 1023u) / 1024u;
+        SPLAHIP_TRY(chunk.alloc(sizeof(uint) * (size_t) (n_chunks + 1)));
+        hipLaunchKernelGGL(flag_count_kernel, dim3(n_chunks), dim3(256), 0, s, touched.as<uint>(), n_out, chunk.as<uint>());
+        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk.as<uint>(), n_chunks);
+        hipLaunchKernelGGL(flag_write_kernel, dim3(n_chunks), dim3(256), 0, s, touched.as<uint>(), outv.as<uint>(), n_out, chunk.as<uint>(),
+                           ri, static_cast<uint*>(rx));
+        SPLAHIP_TRY(hipGetLastError());
+        SPLAHIP_TRY(hipMemcpyAsync(h_count, chunk.as<uint>() + n_chunks, sizeof(uint), hipMemcpyDeviceToHost, s));
+        SPLAHIP_TRY(hipStreamSynchronize(s));
+        return SPLAHIP_OK;
+    }
+
+    template<typename T>
+    int push_typed(uint n_rows, uint n_cols, const uint* Ap, const uint* Aj, const void* Ax, const void* mask, uint nvals, const uint* vi,
+                   const void* vx, uint* ri, void* rx, uint* h_count, int op_mult, int op_add, int op_select, hipStream_t s) {
+        (void) n_rows;
+        *h_count = 0;
+        if (nvals == 0) return SPLAHIP_OK;
+        DevMem len, offs;
+        SPLAHIP_TRY(len.alloc(sizeof(uint) * (size_t) nvals));
+        SPLAHIP_TRY(offs.alloc(sizeof(uint) * (size_t) (nvals + 1)));
+        hipLaunchKernelGGL(frontier_len_kernel, dim3((nvals + 255) / 256), dim3(256), 0, s, nvals, vi, Ap, len.as<uint>());
+        SPLAHIP_TRY(exclusive_scan_u32(len.as<uint>(), nvals, offs.as<uint>(), s));
+        uint n_products = 0;
+        SPLAHIP_TRY(hipMemcpyAsync(&n_products, offs.as<uint>() + nvals, sizeof(uint), hipMemcpyDeviceToHost, s));
+        SPLAHIP_TRY(hipStreamSynchronize(s));
+        if (n_products == 0) return SPLAHIP_OK;
+
+        DevMem key_a, key_b, val_a, val_b, tmp, chunk, lcount, lpos, lrank;
+        SPLAHIP_TRY(key_a.alloc(sizeof(uint) * (size_t) n_products));
+        SPLAHIP_TRY(key_b.alloc(sizeof(uint) * (size_t) n_products));
+        SPLAHIP_TRY(val_a.alloc(sizeof(uint) * (size_t) n_products));
+        SPLAHIP_TRY(val_b.alloc(sizeof(uint) * (size_t) n_products));
+        hipLaunchKernelGGL((expand_kernel<T, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, n_products, nvals, offs.as<uint>(), vi,
+                           static_cast<const T*>(vx), Ap, Aj, static_cast<const uint*>(Ax), static_cast<const T*>(mask), n_cols, op_select,
+                           DynBin(op_mult), key_a.as<uint>(), val_a.as<T>());
+        SPLAHIP_TRY(hipGetLastError());
+        // stable LSD radix sort by column: equal columns keep the expand order = the reference's fold order
+        size_t     tmp_bytes = 0;
+        const uint bits      = bit_width_u32(n_cols);
+        SPLAHIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_a.as<uint>(), key_b.as<uint>(), val_a.as<uint>(), val_b.as<uint>(),
+                                              n_products, 0, bits, s));
+        SPLAHIP_TRY(tmp.alloc(tmp_bytes));
+        SPLAHIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, key_a.as<uint>(), key_b.as<uint>(), val_a.as<uint>(), val_b.as<uint>(),
+                                              n_products, 0, bits, s));
+        // run heads -> output slots; short runs folded in place, long runs by a wavefront each
+        const uint n_chunks = (n_products + 1023u) / 1024u;
+        const uint max_long = n_products / kRunShort + 1;
+        SPLAHIP_TRY(chunk.alloc(sizeof(uint) * (size_t) (n_chunks + 1)));
+        SPLAHIP_TRY(lcount.alloc(sizeof(uint)));
+        SPLAHIP_TRY(lpos.alloc(sizeof(uint) * (size_t) max_long));
+        SPLAHIP_TRY(lrank.alloc(sizeof(uint) * (size_t) max_long));
+        SPLAHIP_TRY(hipMemsetAsync(lcount.p, 0, sizeof(uint), s));
+        hipLaunchKernelGGL(head_count_kernel, dim3(n_chunks), dim3(256), 0, s, key_b.as<uint>(), n_products, n_cols, chunk.as<uint>());
+        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk.as<uint>(), n_chunks);
+        hipLaunchKernelGGL((run_fold_kernel<T, DynBin>), dim3(n_chunks), dim3(256), 0, s, key_b.as<uint>(), val_b.as<T>(), n_products, n_cols,
+                           chunk.as<uint>(), ri, static_cast<T*>(rx), lcount.as<uint>(), lpos.as<uint>(), lrank.as<uint>(), DynBin(op_add));
+        SPLAHIP_TRY(hipGetLastError());
+        uint h_tail[1] = {0}, h_long = 0;
+        SPLAHIP_TRY(hipMemcpyAsync(h_tail, chunk.as<uint>() + n_chunks, sizeof(uint), hipMemcpyDeviceToHost, s));
+        SPLAHIP_TRY(hipMemcpyAsync(&h_long, lcount.p, sizeof(uint), hipMemcpyDeviceToHost, s));
+        SPLAHIP_TRY(hipStreamSynchronize(s));
+        if (h_long) {
+            const uint grid = (h_long + 3) / 4;
+            if (binop_is_associative(op_add))
+                hipLaunchKernelGGL((long_run_kernel<T, DynBin, true>), dim3(grid), dim3(256), 0, s, key_b.as<uint>(), val_b.as<T>(), n_products,
+                                   lcount.as<uint>(), lpos.as<uint>(), lrank.as<uint>(), static_cast<T*>(rx), DynBin(op_add));
+            else
+                hipLaunchKernelGGL((long_run_kernel<T, DynBin, false>), dim3(grid), dim3(256), 0, s, key_b.as<uint>(), val_b.as<T>(), n_products,
+                                   lcount.as<uint>(), lpos.as<uint>(), lrank.as<uint>(), static_cast<T*>(rx), DynBin(op_add));
+            SPLAHIP_TRY(hipGetLastError());
+            SPLAHIP_TRY(hipStreamSynchronize(s));
+        }
+        *h_count = h_tail[0];
+        return SPLAHIP_OK;
+    }
+
+#define SPLAHIP_PULL(MUL, ADD) pull_typed<T, StaBin<MUL>, StaBin<ADD>>(plan, n_out, n_in, Tp, Tj, Tx, mask, nvals, vi, vx, ident, ri, rx, h_count, op_mult, op_add, op_select, s)
+    template<typename T>
+    int pull_dispatch(splahip_plan plan, uint n_out, uint n_in, const uint* Tp, const uint* Tj, const void* Tx, const void* mask, uint nvals,
+                      const uint* vi, const void* vx, int ident, uint* ri, void* rx, uint* h_count, int op_mult, int op_add, int op_select,
+                      hipStream_t s) {
+        if (op_mult == SPLAHIP_MULT && op_add == SPLAHIP_PLUS) return SPLAHIP_PULL(SPLAHIP_MULT, SPLAHIP_PLUS);
+        if (op_mult == SPLAHIP_PLUS && op_add == SPLAHIP_MIN) return SPLAHIP_PULL(SPLAHIP_PLUS, SPLAHIP_MIN);
+        if constexpr (!std::is_same<T, float>::value) {
+            if (op_mult == SPLAHIP_BAND && op_add == SPLAHIP_BOR) return SPLAHIP_PULL(SPLAHIP_BAND, SPLAHIP_BOR);
+        }
+        return pull_typed<T, DynBin, DynBin>(plan, n_out, n_in, Tp, Tj, Tx, mask, nvals, vi, vx, ident, ri, rx, h_count, op_mult, op_add, op_select, s);
+    }
+#undef SPLAHIP_PULL
+
+}// namespace splahip
+
+using namespace splahip;
+
+extern "C" {
+
+int splahip_csr_transpose(uint32_t n_rows, uint32_t n_cols, uint32_t nnz, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax,
+                          uint32_t* d_Tp, uint32_t* d_Tj, void* d_Tx, void* stream) {
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    SPLAHIP_REQUIRE(d_Tp != nullptr, "d_Tp is null");
+    hipStream_t s = as_stream(stream);
+    if (nnz == 0) {
+        SPLAHIP_TRY(hipMemsetAsync(d_Tp, 0, sizeof(uint32_t) * ((size_t) n_cols + 1), s));
+        return SPLAHIP_OK;
+    }
+    SPLAHIP_REQUIRE(d_Ap && d_Aj && d_Ax && d_Tj && d_Tx, "null device pointer");
+    DevMem iota, perm, sorted, tmp;
+    SPLAHIP_TRY(iota.alloc(sizeof(uint) * (size_t) nnz));
+    SPLAHIP_TRY(perm.alloc(sizeof(uint) * (size_t) nnz));
+    SPLAHIP_TRY(sorted.alloc(sizeof(uint) * (size_t) nnz));
+    hipLaunchKernelGGL(iota_kernel, dim3((nnz + 255) / 256), dim3(256), 0, s, iota.as<uint>(), nnz);
+    size_t     tmp_bytes = 0;
+    const uint bits      = bit_width_u32(n_cols);
+    SPLAHIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_Aj, sorted.as<uint>(), iota.as<uint>(), perm.as<uint>(), nnz, 0, bits, s));
+    SPLAHIP_TRY(tmp.alloc(tmp_bytes));
+    SPLAHIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, d_Aj, sorted.as<uint>(), iota.as<uint>(), perm.as<uint>(), nnz, 0, bits, s));
+    hipLaunchKernelGGL(transpose_fill_kernel, dim3((nnz + 255) / 256), dim3(256), 0, s, nnz, n_rows, d_Ap, static_cast<const uint*>(d_Ax),
+                       perm.as<uint>(), d_Tj, static_cast<uint*>(d_Tx));
+    hipLaunchKernelGGL(transpose_ptr_kernel, dim3((n_cols + 1 + 255) / 256), dim3(256), 0, s, nnz, n_cols, sorted.as<uint>(), d_Tp);
+    SPLAHIP_TRY(hipGetLastError());
+    SPLAHIP_TRY(hipStreamSynchronize(s));
+    return SPLAHIP_OK;
+}
+
+int splahip_vxm_probe(uint32_t nvals, const uint32_t* d_vi, const uint32_t* d_Ap, uint64_t* h_products, int* h_sorted, void* stream) {
+    SPLAHIP_REQUIRE(h_products && h_sorted, "null output");
+    *h_products = 0;
+    *h_sorted   = 1;
+    if (nvals == 0) return SPLAHIP_OK;
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    hipStream_t s = as_stream(stream);
+    DevMem      acc;
+    SPLAHIP_TRY(acc.alloc(16));
+    SPLAHIP_TRY(hipMemsetAsync(acc.p, 0, 16, s));
+    hipLaunchKernelGGL(probe_kernel, dim3((nvals + 255) / 256), dim3(256), 0, s, nvals, d_vi, d_Ap, acc.as<unsigned long long>(),
+                       reinterpret_cast<uint*>(acc.as<unsigned long long>() + 1));
+    SPLAHIP_TRY(hipGetLastError());
+    unsigned long long h[2] = {0, 0};
+    SPLAHIP_TRY(hipMemcpyAsync(h, acc.p, 16, hipMemcpyDeviceToHost, s));
+    SPLAHIP_TRY(hipStreamSynchronize(s));
+    *h_products = h[0];
+    *h_sorted   = (h[1] & 0xffffffffull) ? 0 : 1;
+    return SPLAHIP_OK;
+}
+
+int splahip_vxm_pull(splahip_plan plan_T, int type, uint32_t n_rows, uint32_t n_cols,
+                     const uint32_t* d_Tp, const uint32_t* d_Tj, const void* d_Tx, const void* d_mask,
+                     uint32_t nvals, const uint32_t* d_vi, const void* d_vx, int v_is_identity,
+                     uint32_t* d_ri, void* d_rx, uint32_t* h_count,
+                     int op_mult, int op_add, int op_select, void* stream) {
+    SPLAHIP_REQUIRE(plan_T != nullptr && h_count != nullptr, "null argument");
+    SPLAHIP_REQUIRE(plan_T->n_rows == n_cols, "plan_T must be the plan of the transposed matrix (n_cols rows)");
+    SPLAHIP_REQUIRE(binop_valid_for(op_mult, type) && binop_valid_for(op_add, type), "op not defined for this type");
+    SPLAHIP_REQUIRE(binop_is_associative(op_add) && binop_is_commutative(op_add),
+                    "the pull form needs an associative and commutative op_add (use splahip_vxm_push)");
+    *h_count = 0;
+    if (n_cols == 0) return SPLAHIP_OK;
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    hipStream_t s = as_stream(stream);
+    switch (type) {
+        case SPLAHIP_INT: return pull_dispatch<int32_t>(plan_T, n_cols, n_rows, d_Tp, d_Tj, d_Tx, d_mask, nvals, d_vi, d_vx, v_is_identity, d_ri, d_rx, h_count, op_mult, op_add, op_select, s);
+        case SPLAHIP_UINT: return pull_dispatch<uint32_t>(plan_T, n_cols, n_rows, d_Tp, d_Tj, d_Tx, d_mask, nvals, d_vi, d_vx, v_is_identity, d_ri, d_rx, h_count, op_mult, op_add, op_select, s);
+        case SPLAHIP_FLOAT: return pull_dispatch<float>(plan_T, n_cols, n_rows, d_Tp, d_Tj, d_Tx, d_mask, nvals, d_vi, d_vx, v_is_identity, d_ri, d_rx, h_count, op_mult, op_add, op_select, s);
+    }
+    return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
+}
+
+int splahip_vxm_push(int type, uint32_t n_rows, uint32_t n_cols,
+                     const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, const void* d_mask,
+                     uint32_t nvals, const uint32_t* d_vi, const void* d_vx,
+                     uint32_t* d_ri, void* d_rx, uint32_t* h_count,
+                     int op_mult, int op_add, int op_select, void* stream) {
+    SPLAHIP_REQUIRE(h_count != nullptr, "null argument");
+    SPLAHIP_REQUIRE(binop_valid_for(op_mult, type) && binop_valid_for(op_add, type), "op not defined for this type");
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    hipStream_t s = as_stream(stream);
+    switch (type) {
+        case SPLAHIP_INT: return push_typed<int32_t>(n_rows, n_cols, d_Ap, d_Aj, d_Ax, d_mask, nvals, d_vi, d_vx, d_ri, d_rx, h_count, op_mult, op_add, op_select, s);
+        case SPLAHIP_UINT: return push_typed<uint32_t>(n_rows, n_cols, d_Ap, d_Aj, d_Ax, d_mask, nvals, d_vi, d_vx, d_ri, d_rx, h_count, op_mult, op_add, op_select, s);
+        case SPLAHIP_FLOAT: return push_typed<float>(n_rows, n_cols, d_Ap, d_Aj, d_Ax, d_mask, nvals, d_vi, d_vx, d_ri, d_rx, h_count, op_mult, op_add, op_select, s);
+    }
+    return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
+}
+}

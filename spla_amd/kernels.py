@@ -70,3 +70,44 @@ def mxv_masked(plan: CsrPlan, t, n_cols, Ap, Aj, Ax, mask, v, r, op_mult, op_add
 
 def mxv_variant(t, op_mult, op_add, early_exit=False) -> str:
     return _lib.call("splahip_mxv_variant", type_id(t), binop_id(op_mult), binop_id(op_add), 1 if early_exit else 0).decode()
+
+
+def csr_transpose(n_rows, n_cols, Ap, Aj, Ax):
+    """Device CSR of the transpose (rows ascending inside every column): returns (Tp, Tj, Tx)."""
+    nnz = int(Aj.numel())
+    Tp = torch.empty(n_cols + 1, dtype=torch.int32, device=Ap.device)
+    Tj = torch.empty(max(nnz, 1), dtype=torch.int32, device=Ap.device)[:nnz]
+    Tx = torch.empty(max(nnz, 1), dtype=Ax.dtype, device=Ap.device)[:nnz]
+    _lib.call("splahip_csr_transpose", int(n_rows), int(n_cols), nnz, _ptr(Ap), _ptr(Aj) if nnz else None, _ptr(Ax) if nnz else None,
+              _ptr(Tp), _ptr(Tj) if nnz else None, _ptr(Tx) if nnz else None, current_stream_ptr())
+    return Tp, Tj, Tx
+
+
+def vxm_probe(vi, Ap):
+    prod, srt = C.c_uint64(), C.c_int()
+    _lib.call("splahip_vxm_probe", int(vi.numel()), _ptr(vi) if vi.numel() else None, _ptr(Ap), C.byref(prod), C.byref(srt), current_stream_ptr())
+    return prod.value, bool(srt.value)
+
+
+def vxm_pull(plan_T: CsrPlan, t, n_rows, n_cols, Tp, Tj, Tx, mask, vi, vx, op_mult, op_add, op_select, identity=False):
+    """Pull form of vxm over the transposed CSR; returns (ri, rx) index-sorted COO tensors."""
+    tid = type_id(t)
+    ri = torch.empty(max(n_cols, 1), dtype=torch.int32, device=mask.device)
+    rx = torch.empty(max(n_cols, 1), dtype=torch_dtype(t), device=mask.device)
+    cnt = C.c_uint32()
+    _lib.call("splahip_vxm_pull", plan_T.handle, tid, int(n_rows), int(n_cols), _ptr(Tp), _ptr(Tj), _ptr(Tx), _ptr(mask),
+              int(vi.numel()), _ptr(vi), _ptr(vx), 1 if identity else 0, _ptr(ri), _ptr(rx), C.byref(cnt),
+              binop_id(op_mult), binop_id(op_add), selop_id(op_select), current_stream_ptr())
+    return ri[:cnt.value], rx[:cnt.value]
+
+
+def vxm_push(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, op_mult, op_add, op_select):
+    """Push form of vxm (expand / stable sort / fold); returns (ri, rx) index-sorted COO tensors."""
+    tid = type_id(t)
+    ri = torch.empty(max(n_cols, 1), dtype=torch.int32, device=mask.device)
+    rx = torch.empty(max(n_cols, 1), dtype=torch_dtype(t), device=mask.device)
+    cnt = C.c_uint32()
+    _lib.call("splahip_vxm_push", tid, int(n_rows), int(n_cols), _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(mask),
+              int(vi.numel()), _ptr(vi) if vi.numel() else None, _ptr(vx) if vi.numel() else None, _ptr(ri), _ptr(rx), C.byref(cnt),
+              binop_id(op_mult), binop_id(op_add), selop_id(op_select), current_stream_ptr())
+    return ri[:cnt.value], rx[:cnt.value]

@@ -1,0 +1,139 @@
+"""Parity of the HIP masked vxm (push and pull forms, and the operator API's automatic choice) against the oracle."""
+import numpy as np
+import pytest
+
+from helpers import (NP, SELECTS, SEMIRINGS_COMMON, SEMIRINGS_INT, SEMIRINGS_ORDERED, assert_same, random_csr,
+                     random_mask, random_values)
+
+pytestmark = pytest.mark.gpu
+FP32_RTOL = 1e-5
+
+
+def _semirings(t):
+    s = SEMIRINGS_COMMON + SEMIRINGS_ORDERED
+    return s + SEMIRINGS_INT if t != "FLOAT" else s
+
+
+def _push(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel):
+    from gpu_utils import dev, host
+    from spla_amd import kernels
+    ri, rx = kernels.vxm_push(t, n_rows, n_cols, dev(Ap), dev(Aj), dev(np.asarray(Ax, NP[t])), dev(np.asarray(mask, NP[t])),
+                              dev(np.asarray(vi, np.uint32)), dev(np.asarray(vx, NP[t])), mul, add, sel)
+    return host(ri, np.uint32), host(rx, NP[t])
+
+
+def _pull(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel, identity=False):
+    from gpu_utils import dev, host
+    from spla_amd import kernels
+    dAp, dAj, dAx = dev(Ap), dev(Aj), dev(np.asarray(Ax, NP[t]))
+    Tp, Tj, Tx = kernels.csr_transpose(n_rows, n_cols, dAp, dAj, dAx)
+    plan = kernels.CsrPlan(n_cols, len(Aj), Tp)
+    ri, rx = kernels.vxm_pull(plan, t, n_rows, n_cols, Tp, Tj, Tx, dev(np.asarray(mask, NP[t])), dev(np.asarray(vi, np.uint32)),
+                              dev(np.asarray(vx, NP[t])), mul, add, sel, identity=identity)
+    return host(ri, np.uint32), host(rx, NP[t])
+
+
+def test_transpose_is_stable_csc():
+    import torch
+    from gpu_utils import dev, host
+    from spla_amd import kernels
+    rng = np.random.default_rng(2)
+    n_rows, n_cols = 900, 700
+    Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 9, "INT", skew=True)
+    Ax = np.arange(len(Aj), dtype=np.int32)  # entry ids: lets us check the exact permutation
+    Tp, Tj, Tx = kernels.csr_transpose(n_rows, n_cols, dev(Ap), dev(Aj), dev(Ax))
+    Tp, Tj, Tx = host(Tp, np.uint32), host(Tj, np.uint32), host(Tx, np.int32)
+    rows = np.repeat(np.arange(n_rows), np.diff(Ap.astype(np.int64)))
+    order = np.lexsort((rows, Aj))  # by column, then row
+    assert np.array_equal(Tx, Ax[order]) and np.array_equal(Tj, rows[order])
+    assert np.array_equal(Tp, np.concatenate([[0], np.cumsum(np.bincount(Aj, minlength=n_cols))]))
+
+
+@pytest.mark.parametrize("t", ["INT", "UINT", "FLOAT"])
+def test_push_all_cells_bit_exact(oracle, t):
+    """The push form folds every column's products in the reference's order: bit-exact for EVERY op, fp32 PLUS included."""
+    rng = np.random.default_rng(31)
+    n_rows, n_cols = 1500, 1100
+    Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 8, t, skew=True, long_rows=2, long_len=900)
+    for k, (mul, add) in enumerate(_semirings(t)):
+        sel = SELECTS[k % len(SELECTS)]
+        mask = random_mask(rng, n_cols, t)
+        nv = int(rng.integers(1, n_rows))
+        vi = np.sort(rng.permutation(n_rows)[:nv]).astype(np.uint32)
+        if k % 3 == 0:
+            vi = rng.permutation(vi).astype(np.uint32)  # caller-ordered COO
+        vx = random_values(rng, nv, t, zeros=0.2)
+        want = oracle.vxm_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel)
+        got = _push(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel)
+        np.testing.assert_array_equal(got[0], want[0], err_msg=f"{t} {mul}/{add} {sel} idx")
+        np.testing.assert_array_equal(got[1].view(np.uint32), want[1].view(np.uint32), err_msg=f"{t} {mul}/{add} {sel} val")
+
+
+@pytest.mark.parametrize("t", ["INT", "UINT", "FLOAT"])
+def test_pull_commutative_cells(oracle, t):
+    rng = np.random.default_rng(37)
+    n_rows, n_cols = 1700, 1300
+    Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 9, t, skew=True, long_rows=2, long_len=1200)
+    sems = [s for s in SEMIRINGS_COMMON + (SEMIRINGS_INT if t != "FLOAT" else [])]
+    for k, (mul, add) in enumerate(sems):
+        sel = SELECTS[k % len(SELECTS)]
+        mask = random_mask(rng, n_cols, t)
+        nv = n_rows if k % 4 == 0 else int(rng.integers(1, n_rows))
+        vi = np.sort(rng.permutation(n_rows)[:nv]).astype(np.uint32)
+        vx = random_values(rng, nv, t, zeros=0.2)
+        want = oracle.vxm_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel)
+        got = _pull(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel, identity=(nv == n_rows))
+        np.testing.assert_array_equal(got[0], want[0], err_msg=f"{t} {mul}/{add} {sel} idx")
+        if t == "FLOAT" and add in ("PLUS", "MULT"):
+            np.testing.assert_allclose(got[1], want[1], rtol=FP32_RTOL, err_msg=f"{t} {mul}/{add}")
+        else:
+            np.testing.assert_array_equal(got[1].view(np.uint32), want[1].view(np.uint32), err_msg=f"{t} {mul}/{add} {sel} val")
+
+
+def test_vxm_naive_reference_case_through_api():
+    # reference tests/test_vxm.cpp:33-89: the mxv numbers through v x M with M 5x4
+    from spla_amd import api
+    M_, N_ = 4, 5
+    ir, imask, iv = api.Vector(M_, api.INT), api.Vector(M_, api.INT), api.Vector(N_, api.INT)
+    iM = api.Matrix((N_, M_), api.INT)
+    for i, x in enumerate([1, 0, 1, 0]):
+        imask.set(i, x)
+    for i, x in enumerate([3, 0, 3, 0, -1]):
+        iv.set(i, x)
+    for (i, j, x) in [(0, 1, 2), (0, 4, -9), (1, 0, 2), (1, 4, -8), (2, 2, 3), (3, 4, -1)]:
+        iM.set(j, i, x)
+    iv.vxm(imask, iM, api.INT.MULT, api.INT.PLUS, api.INT.EQZERO, out=ir, init=api.Scalar(api.INT, 0))
+    assert [ir.get(i) for i in range(M_)] == [0, 14, 0, 1]
+
+
+def test_vxm_explicit_zeros_are_kept_through_api():
+    # SURVEY.md 8c probe (iv): v=[3,2], M=[[0,5],[.,7]] -> ([0,1],[0,29])
+    from spla_amd import api
+    M = api.Matrix.from_lists([0, 0, 1], [0, 1, 1], [0, 5, 7], (2, 2), api.INT)
+    v = api.Vector.from_lists([0, 1], [3, 2], 2, api.INT)
+    mask = api.Vector.from_lists([0, 1], [1, 1], 2, api.INT)
+    r = v.vxm(mask, M, api.INT.MULT, api.INT.PLUS, api.INT.NQZERO)
+    assert r.to_lists() == ([0, 1], [0, 29])
+
+
+@pytest.mark.parametrize("t", ["INT", "FLOAT"])
+def test_vxm_api_auto_form_vs_oracle(oracle, t):
+    """Sparse frontier (push) and full frontier (pull) through spla_Exec_vxm_masked."""
+    from spla_amd import api
+    T = getattr(api, t)
+    rng = np.random.default_rng(41)
+    n_rows, n_cols = 2000, 1500
+    Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 10, t, skew=True)
+    M = api.Matrix.from_csr(Ap, Aj, Ax, (n_rows, n_cols), T)
+    for nv, (mul, add, sel) in [(30, ("MULT", "PLUS", "ALWAYS")), (n_rows, ("MULT", "PLUS", "NQZERO")), (n_rows // 2, ("PLUS", "MIN", "EQZERO")),
+                                (n_rows, ("MULT", "SECOND", "ALWAYS"))]:
+        mask_np = random_mask(rng, n_cols, t)
+        vi = np.sort(rng.permutation(n_rows)[:nv]).astype(np.uint32)
+        vx = random_values(rng, nv, t)
+        mask = api.Vector.from_lists(np.arange(n_cols), mask_np, n_cols, T)
+        v = api.Vector.from_lists(vi, vx, n_rows, T)
+        r = v.vxm(mask, M, getattr(T, mul), getattr(T, add), getattr(T, sel))
+        I, V = r.read()
+        want = oracle.vxm_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask_np, vi, vx, mul, add, sel)
+        np.testing.assert_array_equal(I, want[0])
+        assert_same(V, want[1], t, what=f"{t} nv={nv} {mul}/{add}")
