@@ -109,6 +109,30 @@ int splahip_vxm_push(int type, uint32_t n_rows, uint32_t n_cols,
 int splahip_csr_transpose(uint32_t n_rows, uint32_t n_cols, uint32_t nnz, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax,
                           uint32_t* d_Tp, uint32_t* d_Tj, void* d_Tx, void* stream);
 
+/* ---- SpGEMM ------------------------------------------------------------------------------------------------------
+ * Outputs: d_Rp (rows+1 words) is caller-allocated; the column / value arrays are allocated by the library once the
+ * result size is known and handed to the caller (*d_Rj, *d_Rx; release with splahip_free); *h_nnz = entry count.
+ * These calls block.
+ *
+ * mxmT_masked: R = (A * B^T) .mask — for every stored mask entry (i, j, m) with select(m): the column-sorted rows A[i,:]
+ *   and B[j,:] are intersected, r = fold from init of add(r, mult(a, b)) in ascending column order; entries with
+ *   r == init are dropped (reference cpu_mxmT_masked.hpp:87-125).  mask/A/R have n_rows rows; B has one row per
+ *   column of R.
+ * mxm: R = A * B — R[i,j] folds mult(a_ik, b_kj) over k in the order of A[i,:], starting at init; entries == init are
+ *   dropped; columns ascending (reference cpu_mxm.hpp:85-114).  ESC over row blocks of at most `block_products`
+ *   expanded products (0 = default); *h_products (optional) receives the total number of products.               */
+int splahip_mxmT_masked(int type, uint32_t n_rows, uint32_t mask_nnz,
+                        const uint32_t* d_Mp, const uint32_t* d_Mj, const void* d_Mx,
+                        const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax,
+                        const uint32_t* d_Bp, const uint32_t* d_Bj, const void* d_Bx,
+                        uint32_t* d_Rp, uint32_t** d_Rj, void** d_Rx, uint32_t* h_nnz,
+                        int op_mult, int op_add, int op_select, uint32_t init_bits, void* stream);
+int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols,
+                const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax,
+                const uint32_t* d_Bp, const uint32_t* d_Bj, const void* d_Bx,
+                uint32_t* d_Rp, uint32_t** d_Rj, void** d_Rx, uint32_t* h_nnz, uint64_t* h_products,
+                int op_mult, int op_add, uint32_t init_bits, uint64_t block_products, void* stream);
+
 /* ---- accelerator vector formats ------------------------------------------------------------------------------
  * AccDense <-> AccCoo (reference src/opencl/cl_format_dense_vec.hpp:90-143, cl_format_coo_vec.hpp:149-158).
  * dense_to_coo keeps the entries != fill in ascending index order (d_idx / d_val need room for n entries) and

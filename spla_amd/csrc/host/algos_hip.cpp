@@ -169,6 +169,97 @@ namespace spla {
             }
         };
 
+        template<typename T>
+        class Algo_mxmT_masked_hip final : public RegistryAlgo {
+        public:
+            std::string get_name() override { return "mxmT_masked"; }
+            std::string get_description() override { return "masked matrix x matrix-transposed product: sorted-row intersection per mask entry"; }
+
+            Status execute(const DispatchContext& ctx) override {
+                auto t    = ctx.task.template cast_safe<ScheduleTask_mxmT_masked>();
+                auto R    = t->R.template cast_safe<TMatrix<T>>();
+                auto mask = t->mask.template cast_safe<TMatrix<T>>();
+                auto A    = t->A.template cast_safe<TMatrix<T>>();
+                auto B    = t->B.template cast_safe<TMatrix<T>>();
+                auto init = t->init.template cast_safe<TScalar<T>>();
+
+                const int op_mult = device_binop<T>(t->op_multiply);
+                const int op_add  = device_binop<T>(t->op_add);
+                const int op_sel  = device_selop<T>(t->op_select);
+                if (op_mult < 0 || op_add < 0 || op_sel < 0) {
+                    SPLA_LOG(Status::NotImplemented, "user-defined ops have no device code in this build");
+                    return Status::NotImplemented;
+                }
+                if (R->get_n_rows() != A->get_n_rows() || R->get_n_cols() != B->get_n_rows() || A->get_n_cols() != B->get_n_cols() ||
+                    mask->get_n_rows() != R->get_n_rows() || mask->get_n_cols() != R->get_n_cols())
+                    return Status::InvalidArgument;
+
+                R->validate_wd(FormatMatrix::AccCsr);
+                mask->validate_rw(FormatMatrix::AccCsr);
+                A->validate_rw(FormatMatrix::AccCsr);
+                B->validate_rw(FormatMatrix::AccCsr);
+
+                auto *    r = R->acc_csr(), *m = mask->acc_csr(), *a = A->acc_csr(), *b = B->acc_csr();
+                uint32_t* Rj  = nullptr;
+                void*     Rx  = nullptr;
+                uint32_t  nnz = 0;
+                r->Ap.reserve(R->get_n_rows() + 1);
+                hip_check(splahip_mxmT_masked(TypeTraits<T>::id, R->get_n_rows(), m->values, m->Ap.template as<uint32_t>(), m->Aj.template as<uint32_t>(),
+                                              m->Ax.ptr(), a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(),
+                                              b->Ap.template as<uint32_t>(), b->Aj.template as<uint32_t>(), b->Ax.ptr(), r->Ap.template as<uint32_t>(),
+                                              &Rj, &Rx, &nnz, op_mult, op_add, op_sel, word_of(init->get_value()), nullptr),
+                          "splahip_mxmT_masked");
+                r->drop_plan();
+                r->Aj.adopt(Rj, nnz);
+                r->Ax.adopt(Rx, nnz);
+                r->values = nnz;
+                return Status::Ok;
+            }
+        };
+
+        template<typename T>
+        class Algo_mxm_hip final : public RegistryAlgo {
+        public:
+            std::string get_name() override { return "mxm"; }
+            std::string get_description() override { return "matrix-matrix product: expand / stable sort / in-order compress over row blocks"; }
+
+            Status execute(const DispatchContext& ctx) override {
+                auto t    = ctx.task.template cast_safe<ScheduleTask_mxm>();
+                auto R    = t->R.template cast_safe<TMatrix<T>>();
+                auto A    = t->A.template cast_safe<TMatrix<T>>();
+                auto B    = t->B.template cast_safe<TMatrix<T>>();
+                auto init = t->init.template cast_safe<TScalar<T>>();
+
+                const int op_mult = device_binop<T>(t->op_multiply);
+                const int op_add  = device_binop<T>(t->op_add);
+                if (op_mult < 0 || op_add < 0) {
+                    SPLA_LOG(Status::NotImplemented, "user-defined ops have no device code in this build");
+                    return Status::NotImplemented;
+                }
+                if (R->get_n_rows() != A->get_n_rows() || R->get_n_cols() != B->get_n_cols() || A->get_n_cols() != B->get_n_rows())
+                    return Status::InvalidArgument;
+
+                R->validate_wd(FormatMatrix::AccCsr);
+                A->validate_rw(FormatMatrix::AccCsr);
+                B->validate_rw(FormatMatrix::AccCsr);
+
+                auto *    r = R->acc_csr(), *a = A->acc_csr(), *b = B->acc_csr();
+                uint32_t* Rj  = nullptr;
+                void*     Rx  = nullptr;
+                uint32_t  nnz = 0;
+                r->Ap.reserve(R->get_n_rows() + 1);
+                hip_check(splahip_mxm(TypeTraits<T>::id, A->get_n_rows(), B->get_n_cols(), a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(),
+                                      a->Ax.ptr(), b->Ap.template as<uint32_t>(), b->Aj.template as<uint32_t>(), b->Ax.ptr(),
+                                      r->Ap.template as<uint32_t>(), &Rj, &Rx, &nnz, nullptr, op_mult, op_add, word_of(init->get_value()), 0, nullptr),
+                          "splahip_mxm");
+                r->drop_plan();
+                r->Aj.adopt(Rj, nnz);
+                r->Ax.adopt(Rx, nnz);
+                r->values = nnz;
+                return Status::Ok;
+            }
+        };
+
         template<template<typename> class Algo>
         void add3(Registry* g, const std::string& name) {
             g->add(name + "_I__hip", std::make_shared<Algo<T_INT>>());
@@ -180,6 +271,8 @@ namespace spla {
     void register_algo_hip(Registry* g) {
         add3<Algo_mxv_masked_hip>(g, "mxv_masked");
         add3<Algo_vxm_masked_hip>(g, "vxm_masked");
+        add3<Algo_mxmT_masked_hip>(g, "mxmT_masked");
+        add3<Algo_mxm_hip>(g, "mxm");
     }
 
 }// namespace spla

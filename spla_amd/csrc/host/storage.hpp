@@ -58,6 +58,11 @@ namespace spla {
         void download(void* host, std::size_t words) const {
             if (splahip_memcpy_d2h(host, m_ptr, words * 4, nullptr) != SPLAHIP_OK) throw std::runtime_error(std::string("d2h copy failed: ") + splahip_last_error());
         }
+        void adopt(void* device_ptr, std::size_t words) {// take ownership of a buffer the kernel library allocated
+            release();
+            m_ptr   = device_ptr;
+            m_words = words;
+        }
         void*       ptr() { return m_ptr; }
         const void* ptr() const { return m_ptr; }
         template<typename U>

@@ -1,0 +1,700 @@
+// mxm.hip — the two SpGEMM operators of the hot path on gfx950.
+//
+// splahip_mxmT_masked : R = (A * B^T) .mask
+//   semantics: reference Algo_mxmT_masked_cpu<T>::execute, src/cpu/cpu_mxmT_masked.hpp:87-125 (the parity oracle): for every
+//   STORED mask entry (i, j, m) in row order: r = init; if select(m): two-pointer merge of the column-sorted rows A[i,:] and
+//   B[j,:], r = add(r, mult(a, b)) on equal columns (ascending column); the entry is emitted iff r != init.
+//   entry point replaced: Algo_mxmT_masked_cl<T>::execute, src/opencl/cl_mxmT_masked.hpp:60-127 (one lane per mask entry,
+//   which copies the mask structure and stores init explicitly — a different output structure; parity is with the CPU).
+//   Here: a lane per mask entry does the merge for light entries; heavy entries (long rows) are queued and done by one
+//   wavefront each (lanes take contiguous pieces of the shorter row, binary-search the longer row, in-order shuffle
+//   reduction); then keep-flags -> scan -> compact into CSR.  Work = sum over selected mask entries of the two row lengths.
+//
+// splahip_mxm : R = A * B  (unmasked)
+//   semantics: reference Algo_mxm_cpu<T>::execute, src/cpu/cpu_mxm.hpp:85-114: Gustavson row by row over a dense accumulator
+//   pre-filled with init: R[i,j] = fold over k in the order of A[i,:] of add(., mult(a_ik, b_kj)) starting at init; entries
+//   equal to init are dropped; columns ascending.  No accelerated version exists in the reference.
+//   Here: ESC — expand the products of a block of rows in (A-entry order, B-row order), STABLE radix sort by (row, column)
+//   (rocPRIM), fold every run in order from init, drop == init, compact.  Row blocks bound the expanded size.  The stable
+//   sort keeps every output's products in the reference's fold order, so the result is bit-exact for every op (fp32 PLUS
+//   included) when runs are folded sequentially; runs longer than 64 products use an in-order tree (associative ops).
+#include "block_utils.hpp"
+#include "common.hpp"
+#include "ops.hpp"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <vector>
+
+namespace splahip {
+
+    struct DevBuf {// scoped hipMalloc
+        void* p = nullptr;
+        ~DevBuf() {
+            if (p) (void) hipFree(p);
+        }
+        hipError_t alloc(size_t bytes) {
+            if (p) (void) hipFree(p);
+            p = nullptr;
+            return hipMalloc(&p, bytes ? bytes : 4);
+        }
+        void* release() {
+            void* q = p;
+            p       = nullptr;
+            return q;
+        }
+        template<typename U>
+        U* as() { return static_cast<U*>(p); }
+    };
+
+    static uint bit_width(unsigned long long x) {
+        uint b = 0;
+        while (x) {
+            ++b;
+            x >>= 1;
+        }
+        return b ? b : 1;
+    }
+
+    template<typename T>
+    __device__ __forceinline__ bool differs(T a, T b) { return a != b; }// the reference's `r != I` (float compare for F)
+
+    __device__ __forceinline__ uint row_of_entry(const uint* __restrict__ Ap, uint n_rows, uint k) {
+        uint lo = 0, hi = n_rows;// last row with Ap[row] <= k
+        while (hi - lo > 1) {
+            const uint mid = (lo + hi) >> 1;
+            if (Ap[mid] <= k) lo = mid;
+            else
+                hi = mid;
+        }
+        return lo;
+    }
+
+    // generic flag compaction helpers: count per 1024-chunk, write with ranks
+    __global__ __launch_bounds__(256) void flags_count_kernel(const uint* __restrict__ flag, uint n, uint* __restrict__ chunk) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        uint            cnt   = 0;
+#pragma unroll
+        for (uint u = 0; u < 4; ++u)
+            if (first + u < n) cnt += flag[first + u] ? 1u : 0u;
+        uint total;
+        (void) block_exclusive_sum<256>(cnt, s_tmp, total);
+        if (threadIdx.x == 0) chunk[blockIdx.x] = total;
+    }
+    // rank[i] = number of set flags before i (for every i, plus rank[n] = total)
+    __global__ __launch_bounds__(256) void flags_rank_kernel(const uint* __restrict__ flag, uint n, const uint* __restrict__ chunk, uint n_chunks,
+                                                             uint* __restrict__ rank) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        uint            f[4];
+        uint            cnt = 0;
+#pragma unroll
+        for (uint u = 0; u < 4; ++u) {
+            f[u] = (first + u < n && flag[first + u]) ? 1u : 0u;
+            cnt += f[u];
+        }
+        uint total;
+        uint pos = chunk[blockIdx.x] + block_exclusive_sum<256>(cnt, s_tmp, total);
+#pragma unroll
+        for (uint u = 0; u < 4; ++u) {
+            if (first + u < n) rank[first + u] = pos;
+            pos += f[u];
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) rank[n] = chunk[n_chunks];
+    }
+    static hipError_t flags_exclusive_rank(const uint* flag, uint n, uint* rank, hipStream_t s) {
+        if (n == 0) return hipMemsetAsync(rank, 0, sizeof(uint), s);
+        const uint n_chunks = (n + 1023u) / 1024u;
+        DevBuf     chunk;
+        hipError_t e = chunk.alloc(sizeof(uint) * (size_t) (n_chunks + 1));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(flags_count_kernel, dim3(n_chunks), dim3(256), 0, s, flag, n, chunk.as<uint>());
+        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk.as<uint>(), n_chunks);
+        hipLaunchKernelGGL(flags_rank_kernel, dim3(n_chunks), dim3(256), 0, s, flag, n, chunk.as<uint>(), n_chunks, rank);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        return e;
+    }
+
+    // =============================================================================================================
+    // mxmT_masked
+    // =============================================================================================================
+    constexpr uint kHeavy = 192;// len(A row) + len(B row) above which a mask entry is handled by a wavefront
+
+    template<typename T, class Mult, class Add>
+    __global__ __launch_bounds__(256) void mxmT_entry_kernel(uint n_rows, uint n_entries,
+                                                             const uint* __restrict__ Mp, const uint* __restrict__ Mj, const T* __restrict__ Mx,
+                                                             const uint* __restrict__ Ap, const uint* __restrict__ Aj, const T* __restrict__ Ax,
+                                                             const uint* __restrict__ Bp, const uint* __restrict__ Bj, const T* __restrict__ Bx,
+                                                             T* __restrict__ val, uint* __restrict__ keep,
+                                                             uint* __restrict__ heavy_count, uint* __restrict__ heavy_list,
+                                                             Mult mult, Add add, int op_select, T init) {
+        const uint e = blockIdx.x * 256 + threadIdx.x;
+        if (e >= n_entries) return;
+        T    r    = init;
+        bool done = true;
+        if (eval_sel(op_select, Mx[e])) {
+            const uint i  = row_of_entry(Mp, n_rows, e);
+            const uint j  = Mj[e];
+            uint       ka = Ap[i], ea = Ap[i + 1];
+            uint       kb = Bp[j], eb = Bp[j + 1];
+            if ((ea - ka) + (eb - kb) > kHeavy && ea > ka && eb > kb) {
+                heavy_list[atomicAdd(heavy_count, 1u)] = e;
+                done                                   = false;
+            } else {
+                while (ka < ea && kb < eb) {
+                    const uint ca = Aj[ka], cb = Bj[kb];
+                    if (ca == cb) {
+                        r = add(r, mult(Ax[ka], Bx[kb]));
+                        ++ka;
+                        ++kb;
+                    } else if (ca < cb) {
+                        ++ka;
+                    } else {
+                        ++kb;
+                    }
+                }
+            }
+        }
+        if (done) {
+            val[e]  = r;
+            keep[e] = differs(r, init) ? 1u : 0u;
+        }
+    }
+
+    // one wavefront per heavy mask entry.  TREE: lanes take contiguous pieces of the shorter row (ascending column), look every
+    // column up in the longer row by binary search, fold their matches in order, then an in-order shuffle reduction:
+    // the products are combined in ascending column order = the merge's order (needs an associative op_add).
+    // !TREE: lane 0 runs the plain sequential merge.
+    template<typename T, class Mult, class Add, bool TREE>
+    __global__ __launch_bounds__(256) void mxmT_heavy_kernel(uint n_rows, const uint* __restrict__ heavy_count, const uint* __restrict__ heavy_list,
+                                                             const uint* __restrict__ Mp, const uint* __restrict__ Mj,
+                                                             const uint* __restrict__ Ap, const uint* __restrict__ Aj, const T* __restrict__ Ax,
+                                                             const uint* __restrict__ Bp, const uint* __restrict__ Bj, const T* __restrict__ Bx,
+                                                             T* __restrict__ val, uint* __restrict__ keep, Mult mult, Add add, T init) {
+        const uint w = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+        if (w >= *heavy_count) return;
+        const uint lane = lane_id();
+        const uint e    = heavy_list[w];
+        const uint i    = row_of_entry(Mp, n_rows, e);
+        const uint j    = Mj[e];
+        const uint sa = Ap[i], ea = Ap[i + 1], sb = Bp[j], eb = Bp[j + 1];
+        T          r = init;
+        if constexpr (TREE) {
+            // S = shorter row (scanned), L = longer row (searched); the product keeps mult(a, b) argument order
+            const bool  a_short = (ea - sa) <= (eb - sb);
+            const uint* Sj = a_short ? Aj : Bj;
+            const uint* Lj = a_short ? Bj : Aj;
+            const uint  ss = a_short ? sa : sb, se = a_short ? ea : eb;
+            const uint  ls = a_short ? sb : sa, le = a_short ? eb : ea;
+            const uint  c  = (se - ss + kWave - 1) / kWave;
+            const uint  ks = ss + lane * c;
+            const uint  ke = min(ks + c, se);
+            T           part  = init;
+            bool        valid = false;
+            uint        lo    = ls;// columns ascend, so the search window only moves right
+            for (uint k = ks; k < ke; ++k) {
+                const uint col = Sj[k];
+                uint       hi  = le;
+                while (lo < hi) {
+                    const uint mid = (lo + hi) >> 1;
+                    if (Lj[mid] < col) lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                if (lo < le && Lj[lo] == col) {
+                    const T p = a_short ? mult(Ax[k], Bx[lo]) : mult(Ax[lo], Bx[k]);
+                    part      = valid ? add(part, p) : p;
+                    valid     = true;
+                }
+            }
+            wave_reduce_ordered(part, valid, add);
+            if (valid) r = add(init, part);
+        } else {
+            uint ka = sa, kb = sb;
+            while (ka < ea && kb < eb) {
+                const uint ca = Aj[ka], cb = Bj[kb];
+                if (ca == cb) {
+                    r = add(r, mult(Ax[ka], Bx[kb]));
+                    ++ka;
+                    ++kb;
+                } else if (ca < cb) {
+                    ++ka;
+                } else {
+                    ++kb;
+                }
+            }
+        }
+        if (lane == 0) {
+            val[e]  = r;
+            keep[e] = differs(r, init) ? 1u : 0u;
+        }
+    }
+
+    __global__ __launch_bounds__(256) void mxmT_compact_kernel(uint n_entries, const uint* __restrict__ Mj, const uint* __restrict__ val,
+                                                               const uint* __restrict__ keep, const uint* __restrict__ rank,
+                                                               uint* __restrict__ Rj, uint* __restrict__ Rx) {
+        const uint e = blockIdx.x * 256 + threadIdx.x;
+        if (e < n_entries && keep[e]) {
+            Rj[rank[e]] = Mj[e];
+            Rx[rank[e]] = val[e];
+        }
+    }
+    __global__ __launch_bounds__(256) void rowptr_from_rank_kernel(uint n_rows, const uint* __restrict__ Mp, const uint* __restrict__ rank, uint* __restrict__ Rp) {
+        const uint i = blockIdx.x * 256 + threadIdx.x;
+        if (i <= n_rows) Rp[i] = rank[Mp[i]];
+    }
+
+    template<typename T>
+    int mxmT_typed(uint n_rows, uint n_entries, const uint* Mp, const uint* Mj, const void* Mx, const uint* Ap, const uint* Aj, const void* Ax,
+                   const uint* Bp, const uint* Bj, const void* Bx, uint* Rp, uint** Rj, void** Rx, uint* h_nnz,
+                   int op_mult, int op_add, int op_select, uint32_t init_bits, hipStream_t s) {
+        *Rj = nullptr, *Rx = nullptr, *h_nnz = 0;
+        if (n_entries == 0) {
+            SPLAHIP_TRY(hipMemsetAsync(Rp, 0, sizeof(uint) * ((size_t) n_rows + 1), s));
+            return SPLAHIP_OK;
+        }
+        const T init = from_bits<T>(init_bits);
+        DevBuf  val, keep, rank, hcount, hlist, outj, outx;
+        SPLAHIP_TRY(val.alloc(sizeof(uint) * (size_t) n_entries));
+        SPLAHIP_TRY(keep.alloc(sizeof(uint) * (size_t) n_entries));
+        SPLAHIP_TRY(rank.alloc(sizeof(uint) * ((size_t) n_entries + 1)));
+        SPLAHIP_TRY(hcount.alloc(sizeof(uint)));
+        SPLAHIP_TRY(hlist.alloc(sizeof(uint) * (size_t) n_entries));
+        SPLAHIP_TRY(hipMemsetAsync(hcount.p, 0, sizeof(uint), s));
+        hipLaunchKernelGGL((mxmT_entry_kernel<T, DynBin, DynBin>), dim3((n_entries + 255) / 256), dim3(256), 0, s, n_rows, n_entries, Mp, Mj,
+                           static_cast<const T*>(Mx), Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(),
+                           keep.as<uint>(), hcount.as<uint>(), hlist.as<uint>(), DynBin(op_mult), DynBin(op_add), op_select, init);
+        SPLAHIP_TRY(hipGetLastError());
+        uint h_heavy = 0;
+        SPLAHIP_TRY(hipMemcpyAsync(&h_heavy, hcount.p, sizeof(uint), hipMemcpyDeviceToHost, s));
+        SPLAHIP_TRY(hipStreamSynchronize(s));
+        if (h_heavy) {
+            const uint grid = (h_heavy + 3) / 4;
+            if (binop_is_associative(op_add))
+                hipLaunchKernelGGL((mxmT_heavy_kernel<T, DynBin, DynBin, true>), dim3(grid), dim3(256), 0, s, n_rows, hcount.as<uint>(), hlist.as<uint>(),
+                                   Mp, Mj, Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(), keep.as<uint>(),
+                                   DynBin(op_mult), DynBin(op_add), init);
+            else
+                hipLaunchKernelGGL((mxmT_heavy_kernel<T, DynBin, DynBin, false>), dim3(grid), dim3(256), 0, s, n_rows, hcount.as<uint>(), hlist.as<uint>(),
+                                   Mp, Mj, Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(), keep.as<uint>(),
+                                   DynBin(op_mult), DynBin(op_add), init);
+            SPLAHIP_TRY(hipGetLastError());
+        }
+        SPLAHIP_TRY(flags_exclusive_rank(keep.as<uint>(), n_entries, rank.as<uint>(), s));
+        uint nnz = 0;
+        SPLAHIP_TRY(hipMemcpyAsync(&nnz, rank.as<uint>() + n_entries, sizeof(uint), hipMemcpyDeviceToHost, s));
+        SPLAHIP_TRY(hipStreamSynchronize(s));
+        SPLAHIP_TRY(outj.alloc(sizeof(uint) * (size_t) nnz));
+        SPLAHIP_TRY(outx.alloc(sizeof(uint) * (size_t) nnz));
+        hipLaunchKernelGGL(mxmT_compact_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, s, n_entries, Mj, val.as<uint>(), keep.as<uint>(),
+                           rank.as<uint>(), outj.as<uint>(), outx.as<uint>());
+        hipLaunchKernelGGL(rowptr_from_rank_kernel, dim3((n_rows + 1 + 255) / 256), dim3(256), 0, s, n_rows, Mp, rank.as<uint>(), Rp);
+        SPLAHIP_TRY(hipGetLastError());
+        SPLAHIP_TRY(hipStreamSynchronize(s));
+        *h_nnz = nnz;
+        *Rj    = static_cast<uint*>(outj.release());
+        *Rx    = outx.release();
+        return SPLAHIP_OK;
+    }
+
+    // =============================================================================================================
+    // mxm (ESC)
+    // =============================================================================================================
+    using u64 = unsigned long long;
+
+    // len[e] = nnz(B[Aj[e], :]) for the A entries of a row block
+    __global__ __launch_bounds__(256) void mxm_len_kernel(uint e0, uint n, const uint* __restrict__ Aj, const uint* __restrict__ Bp, uint* __restrict__ len) {
+        const uint t = blockIdx.x * 256 + threadIdx.x;
+        if (t < n) {
+            const uint k = Aj[e0 + t];
+            len[t]       = Bp[k + 1] - Bp[k];
+        }
+    }
+    // products per row of A (for the row blocking): rowprod[i] = sum over entries of row i of nnz(B[k,:])
+    __global__ __launch_bounds__(256) void mxm_rowprod_kernel(uint n_rows, const uint* __restrict__ Ap, const uint* __restrict__ Aj,
+                                                              const uint* __restrict__ Bp, u64* __restrict__ rowprod) {
+        const uint i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= n_rows) return;
+        u64 sum = 0;
+        for (uint e = Ap[i]; e < Ap[i + 1]; ++e) {
+            const uint k = Aj[e];
+            sum += Bp[k + 1] - Bp[k];
+        }
+        rowprod[i] = sum;
+    }
+
+    __global__ __launch_bounds__(256) void len_sum_kernel(const uint* __restrict__ x, uint n, uint* __restrict__ chunk) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        uint            sum   = 0;
+#pragma unroll
+        for (uint u = 0; u < 4; ++u)
+            if (first + u < n) sum += x[first + u];
+        uint total;
+        (void) block_exclusive_sum<256>(sum, s_tmp, total);
+        if (threadIdx.x == 0) chunk[blockIdx.x] = total;
+    }
+    __global__ __launch_bounds__(256) void len_scan_kernel(const uint* __restrict__ x, uint n, const uint* __restrict__ chunk, uint n_chunks, uint* __restrict__ out) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        uint            val[4];
+        uint            sum = 0;
+#pragma unroll
+        for (uint u = 0; u < 4; ++u) {
+            val[u] = first + u < n ? x[first + u] : 0;
+            sum += val[u];
+        }
+        uint total;
+        uint pos = chunk[blockIdx.x] + block_exclusive_sum<256>(sum, s_tmp, total);
+#pragma unroll
+        for (uint u = 0; u < 4; ++u) {
+            if (first + u < n) out[first + u] = pos;
+            pos += val[u];
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = chunk[n_chunks];
+    }
+
+    template<typename T, class Mult>
+    __global__ __launch_bounds__(256) void mxm_expand_kernel(uint n_products, uint e0, uint n_entries, const uint* __restrict__ offs, uint n_rows,
+                                                             const uint* __restrict__ Ap, const uint* __restrict__ Aj, const T* __restrict__ Ax,
+                                                             const uint* __restrict__ Bp, const uint* __restrict__ Bj, const T* __restrict__ Bx,
+                                                             Mult mult, u64* __restrict__ key, T* __restrict__ val) {
+        const uint p = blockIdx.x * 256 + threadIdx.x;
+        if (p >= n_products) return;
+        uint lo = 0, hi = n_entries;// entry t of the block with offs[t] <= p < offs[t+1]
+        while (hi - lo > 1) {
+            const uint mid = (lo + hi) >> 1;
+            if (offs[mid] <= p) lo = mid;
+            else
+                hi = mid;
+        }
+        const uint e  = e0 + lo;
+        const uint i  = row_of_entry(Ap, n_rows, e);
+        const uint k  = Aj[e];
+        const uint kb = Bp[k] + (p - offs[lo]);
+        key[p]        = (u64(i) << 32) | Bj[kb];
+        val[p]        = mult(Ax[e], Bx[kb]);
+    }
+
+    __global__ __launch_bounds__(256) void mxm_head_kernel(const u64* __restrict__ key, uint n, uint* __restrict__ head) {
+        const uint p = blockIdx.x * 256 + threadIdx.x;
+        if (p < n) head[p] = (p == 0 || key[p - 1] != key[p]) ? 1u : 0u;
+    }
+
+    constexpr uint kRunShortMxm = 64;
+
+    // one lane per run head: fold the run in order from init (short runs) or queue it for a wavefront
+    template<typename T, class Add>
+    __global__ __launch_bounds__(256) void mxm_run_kernel(const u64* __restrict__ key, const T* __restrict__ val, uint n, const uint* __restrict__ head,
+                                                          const uint* __restrict__ run_rank, u64* __restrict__ run_key, T* __restrict__ run_val,
+                                                          uint* __restrict__ run_keep, uint* __restrict__ long_count, uint* __restrict__ long_pos,
+                                                          Add add, T init) {
+        const uint p = blockIdx.x * 256 + threadIdx.x;
+        if (p >= n || !head[p]) return;
+        const u64  kk  = key[p];
+        const uint run = run_rank[p];
+        run_key[run]   = kk;
+        T    acc       = add(init, val[p]);
+        uint q         = p + 1;
+        while (q < n && q - p < kRunShortMxm && key[q] == kk) {
+            acc = add(acc, val[q]);
+            ++q;
+        }
+        if (q < n && key[q] == kk) {
+            const uint slot = atomicAdd(long_count, 1u);
+            long_pos[slot]  = p;
+        } else {
+            run_val[run]  = acc;
+            run_keep[run] = differs(acc, init) ? 1u : 0u;
+        }
+    }
+
+    template<typename T, class Add, bool TREE>
+    __global__ __launch_bounds__(256) void mxm_long_run_kernel(const u64* __restrict__ key, const T* __restrict__ val, uint n,
+                                                               const uint* __restrict__ long_count, const uint* __restrict__ long_pos,
+                                                               const uint* __restrict__ run_rank, T* __restrict__ run_val, uint* __restrict__ run_keep,
+                                                               Add add, T init) {
+        const uint w = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+        if (w >= *long_count) return;
+        const uint lane = lane_id();
+        const uint p    = long_pos[w];
+        const u64  kk   = key[p];
+        uint       lo = p + 1, hi = n;
+        while (lo < hi) {
+            const uint mid = (lo + hi) >> 1;
+            if (key[mid] == kk) lo = mid + 1;
+            else
+                hi = mid;
+        }
+        const uint e = lo;
+        T          acc;
+        if constexpr (TREE) {
+            const uint c  = (e - p + kWave - 1) / kWave;
+            const uint ks = p + lane * c;
+            const uint ke = min(ks + c, e);
+            bool       valid = ks < e;
+            T          part  = init;
+            if (valid) {
+                part = val[ks];
+                for (uint q = ks + 1; q < ke; ++q) part = add(part, val[q]);
+            }
+            wave_reduce_ordered(part, valid, add);
+            acc = add(init, part);
+        } else {
+            acc = init;
+            if (lane == 0)
+                for (uint q = p; q < e; ++q) acc = add(acc, val[q]);
+        }
+        if (lane == 0) {
+            run_val[run_rank[p]]  = acc;
+            run_keep[run_rank[p]] = differs(acc, init) ? 1u : 0u;
+        }
+    }
+
+    // kept runs -> (row, col, value) appended at out_base + rank
+    __global__ __launch_bounds__(256) void mxm_emit_kernel(uint n_runs, const u64* __restrict__ run_key, const uint* __restrict__ run_val,
+                                                           const uint* __restrict__ run_keep, const uint* __restrict__ rank,
+                                                           uint* __restrict__ out_row, uint* __restrict__ out_col, uint* __restrict__ out_val) {
+        const uint t = blockIdx.x * 256 + threadIdx.x;
+        if (t < n_runs && run_keep[t]) {
+            const uint o = rank[t];
+            out_row[o]   = uint(run_key[t] >> 32);
+            out_col[o]   = uint(run_key[t] & 0xffffffffull);
+            out_val[o]   = run_val[t];
+        }
+    }
+    // Rp[i] = first output entry whose row >= i (rows ascending)
+    __global__ __launch_bounds__(256) void rowptr_from_rows_kernel(uint n_rows, uint nnz, const uint* __restrict__ rows, uint* __restrict__ Rp) {
+        const uint i = blockIdx.x * 256 + threadIdx.x;
+        if (i > n_rows) return;
+        uint lo = 0, hi = nnz;
+        while (lo < hi) {
+            const uint mid = (lo + hi) >> 1;
+            if (rows[mid] < i) lo = mid + 1;
+            else
+                hi = mid;
+        }
+        Rp[i] = lo;
+    }
+
+    struct Piece {
+        void *row, *col, *val;
+        uint  n;
+    };
+
+    template<typename T>
+    int mxm_typed(uint a_rows, uint b_cols, const uint* Ap, const uint* Aj, const void* Ax, const uint* Bp, const uint* Bj, const void* Bx,
+                  uint* Rp, uint** Rj, void** Rx, uint* h_nnz, u64* h_products, int op_mult, int op_add, uint32_t init_bits,
+                  u64 block_products, hipStream_t s) {
+        *Rj = nullptr, *Rx = nullptr, *h_nnz = 0;
+        if (h_products) *h_products = 0;
+        const T init = from_bits<T>(init_bits);
+        // products per row -> host -> row blocks of at most `block_products` products (a single row may exceed it)
+        std::vector<uint> h_Ap(a_rows + 1);
+        std::vector<u64>  h_rowprod(a_rows);
+        {
+            DevBuf rowprod;
+            SPLAHIP_TRY(rowprod.alloc(sizeof(u64) * (size_t) a_rows));
+            hipLaunchKernelGGL(mxm_rowprod_kernel, dim3((a_rows + 255) / 256), dim3(256), 0, s, a_rows, Ap, Aj, Bp, rowprod.as<u64>());
+            SPLAHIP_TRY(hipGetLastError());
+            SPLAHIP_TRY(hipMemcpyAsync(h_rowprod.data(), rowprod.p, sizeof(u64) * (size_t) a_rows, hipMemcpyDeviceToHost, s));
+            SPLAHIP_TRY(hipMemcpyAsync(h_Ap.data(), Ap, sizeof(uint) * ((size_t) a_rows + 1), hipMemcpyDeviceToHost, s));
+            SPLAHIP_TRY(hipStreamSynchronize(s));
+        }
+        std::vector<Piece> pieces;
+        auto               free_pieces = [&]() {
+            for (auto& pc : pieces) {
+                (void) hipFree(pc.row);
+                (void) hipFree(pc.col);
+                (void) hipFree(pc.val);
+            }
+            pieces.clear();
+        };
+        u64  total_products = 0;
+        uint total_out      = 0;
+        int  status         = SPLAHIP_OK;
+        uint r0             = 0;
+        while (r0 < a_rows && status == SPLAHIP_OK) {
+            u64  prod = 0;
+            uint r1   = r0;
+            while (r1 < a_rows && (r1 == r0 || prod + h_rowprod[r1] <= block_products)) prod += h_rowprod[r1++];
+            total_products += prod;
+            if (prod > 0xFFFFFFF0ull) {
+                status = fail(SPLAHIP_INVALID_ARGUMENT, "a single row expands to %llu products (> 2^32)", prod);
+                break;
+            }
+            const uint e0 = h_Ap[r0], n_entries = h_Ap[r1] - h_Ap[r0], n_products = (uint) prod;
+            r0 = r1;
+            if (n_products == 0) continue;
+
+            auto run_block = [&]() -> int {
+                DevBuf len, offs, chunk, key_a, key_b, val_a, val_b, tmp, head, run_rank, run_key, run_val, run_keep, lcount, lpos, keep_rank;
+                SPLAHIP_TRY(len.alloc(sizeof(uint) * (size_t) n_entries));
+                SPLAHIP_TRY(offs.alloc(sizeof(uint) * ((size_t) n_entries + 1)));
+                const uint n_chunks = (n_entries + 1023u) / 1024u;
+                SPLAHIP_TRY(chunk.alloc(sizeof(uint) * ((size_t) n_chunks + 1)));
+                hipLaunchKernelGGL(mxm_len_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, s, e0, n_entries, Aj, Bp, len.as<uint>());
+                hipLaunchKernelGGL(len_sum_kernel, dim3(n_chunks), dim3(256), 0, s, len.as<uint>(), n_entries, chunk.as<uint>());
+                hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk.as<uint>(), n_chunks);
+                hipLaunchKernelGGL(len_scan_kernel, dim3(n_chunks), dim3(256), 0, s, len.as<uint>(), n_entries, chunk.as<uint>(), n_chunks, offs.as<uint>());
+                SPLAHIP_TRY(hipGetLastError());
+                SPLAHIP_TRY(key_a.alloc(sizeof(u64) * (size_t) n_products));
+                SPLAHIP_TRY(key_b.alloc(sizeof(u64) * (size_t) n_products));
+                SPLAHIP_TRY(val_a.alloc(sizeof(uint) * (size_t) n_products));
+                SPLAHIP_TRY(val_b.alloc(sizeof(uint) * (size_t) n_products));
+                hipLaunchKernelGGL((mxm_expand_kernel<T, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, n_products, e0, n_entries,
+                                   offs.as<uint>(), a_rows, Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), DynBin(op_mult),
+                                   key_a.as<u64>(), val_a.as<T>());
+                SPLAHIP_TRY(hipGetLastError());
+                // stable sort by (row, column): equal keys keep the expand order = the reference's fold order
+                size_t     tmp_bytes = 0;
+                const uint end_bit   = 32 + bit_width(a_rows);
+                const uint col_bits  = bit_width(b_cols);
+                (void) col_bits;
+                SPLAHIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_a.as<u64>(), key_b.as<u64>(), val_a.as<uint>(), val_b.as<uint>(),
+                                                      n_products, 0, end_bit, s));
+                SPLAHIP_TRY(tmp.alloc(tmp_bytes));
+                SPLAHIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, key_a.as<u64>(), key_b.as<u64>(), val_a.as<uint>(), val_b.as<uint>(),
+                                                      n_products, 0, end_bit, s));
+                // runs
+                SPLAHIP_TRY(head.alloc(sizeof(uint) * (size_t) n_products));
+                SPLAHIP_TRY(run_rank.alloc(sizeof(uint) * ((size_t) n_products + 1)));
+                hipLaunchKernelGGL(mxm_head_kernel, dim3((n_products + 255) / 256), dim3(256), 0, s, key_b.as<u64>(), n_products, head.as<uint>());
+                SPLAHIP_TRY(flags_exclusive_rank(head.as<uint>(), n_products, run_rank.as<uint>(), s));
+                uint n_runs = 0;
+                SPLAHIP_TRY(hipMemcpyAsync(&n_runs, run_rank.as<uint>() + n_products, sizeof(uint), hipMemcpyDeviceToHost, s));
+                SPLAHIP_TRY(hipStreamSynchronize(s));
+                SPLAHIP_TRY(run_key.alloc(sizeof(u64) * (size_t) n_runs));
+                SPLAHIP_TRY(run_val.alloc(sizeof(uint) * (size_t) n_runs));
+                SPLAHIP_TRY(run_keep.alloc(sizeof(uint) * (size_t) n_runs));
+                SPLAHIP_TRY(lcount.alloc(sizeof(uint)));
+                SPLAHIP_TRY(lpos.alloc(sizeof(uint) * ((size_t) n_products / kRunShortMxm + 1)));
+                SPLAHIP_TRY(hipMemsetAsync(lcount.p, 0, sizeof(uint), s));
+                hipLaunchKernelGGL((mxm_run_kernel<T, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, key_b.as<u64>(), val_b.as<T>(), n_products,
+                                   head.as<uint>(), run_rank.as<uint>(), run_key.as<u64>(), run_val.as<T>(), run_keep.as<uint>(), lcount.as<uint>(),
+                                   lpos.as<uint>(), DynBin(op_add), init);
+                SPLAHIP_TRY(hipGetLastError());
+                uint h_long = 0;
+                SPLAHIP_TRY(hipMemcpyAsync(&h_long, lcount.p, sizeof(uint), hipMemcpyDeviceToHost, s));
+                SPLAHIP_TRY(hipStreamSynchronize(s));
+                if (h_long) {
+                    const uint grid = (h_long + 3) / 4;
+                    if (binop_is_associative(op_add))
+                        hipLaunchKernelGGL((mxm_long_run_kernel<T, DynBin, true>), dim3(grid), dim3(256), 0, s, key_b.as<u64>(), val_b.as<T>(), n_products,
+                                           lcount.as<uint>(), lpos.as<uint>(), run_rank.as<uint>(), run_val.as<T>(), run_keep.as<uint>(), DynBin(op_add), init);
+                    else
+                        hipLaunchKernelGGL((mxm_long_run_kernel<T, DynBin, false>), dim3(grid), dim3(256), 0, s, key_b.as<u64>(), val_b.as<T>(), n_products,
+                                           lcount.as<uint>(), lpos.as<uint>(), run_rank.as<uint>(), run_val.as<T>(), run_keep.as<uint>(), DynBin(op_add), init);
+                    SPLAHIP_TRY(hipGetLastError());
+                }
+                // drop == init, compact
+                SPLAHIP_TRY(keep_rank.alloc(sizeof(uint) * ((size_t) n_runs + 1)));
+                SPLAHIP_TRY(flags_exclusive_rank(run_keep.as<uint>(), n_runs, keep_rank.as<uint>(), s));
+                uint n_out = 0;
+                SPLAHIP_TRY(hipMemcpyAsync(&n_out, keep_rank.as<uint>() + n_runs, sizeof(uint), hipMemcpyDeviceToHost, s));
+                SPLAHIP_TRY(hipStreamSynchronize(s));
+                if (n_out) {
+                    DevBuf orow, ocol, oval;
+                    SPLAHIP_TRY(orow.alloc(sizeof(uint) * (size_t) n_out));
+                    SPLAHIP_TRY(ocol.alloc(sizeof(uint) * (size_t) n_out));
+                    SPLAHIP_TRY(oval.alloc(sizeof(uint) * (size_t) n_out));
+                    hipLaunchKernelGGL(mxm_emit_kernel, dim3((n_runs + 255) / 256), dim3(256), 0, s, n_runs, run_key.as<u64>(), run_val.as<uint>(),
+                                       run_keep.as<uint>(), keep_rank.as<uint>(), orow.as<uint>(), ocol.as<uint>(), oval.as<uint>());
+                    SPLAHIP_TRY(hipGetLastError());
+                    SPLAHIP_TRY(hipStreamSynchronize(s));
+                    pieces.push_back({orow.release(), ocol.release(), oval.release(), n_out});
+                    total_out += n_out;
+                }
+                return SPLAHIP_OK;
+            };
+            status = run_block();
+        }
+        if (status != SPLAHIP_OK) {
+            free_pieces();
+            return status;
+        }
+        // concatenate the pieces (row blocks are in row order) and derive Rp
+        DevBuf rows, outj, outx;
+        hipError_t e = rows.alloc(sizeof(uint) * (size_t) total_out);
+        if (e == hipSuccess) e = outj.alloc(sizeof(uint) * (size_t) total_out);
+        if (e == hipSuccess) e = outx.alloc(sizeof(uint) * (size_t) total_out);
+        size_t off = 0;
+        for (auto& pc : pieces) {
+            if (e != hipSuccess) break;
+            e = hipMemcpyAsync(rows.as<uint>() + off, pc.row, sizeof(uint) * (size_t) pc.n, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(outj.as<uint>() + off, pc.col, sizeof(uint) * (size_t) pc.n, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(outx.as<uint>() + off, pc.val, sizeof(uint) * (size_t) pc.n, hipMemcpyDeviceToDevice, s);
+            off += pc.n;
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(rowptr_from_rows_kernel, dim3((a_rows + 1 + 255) / 256), dim3(256), 0, s, a_rows, total_out, rows.as<uint>(), Rp);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        free_pieces();
+        if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm assembly failed: %s", hipGetErrorString(e));
+        *h_nnz = total_out;
+        if (h_products) *h_products = total_products;
+        *Rj = static_cast<uint*>(outj.release());
+        *Rx = outx.release();
+        return SPLAHIP_OK;
+    }
+
+}// namespace splahip
+
+using namespace splahip;
+
+extern "C" {
+
+int splahip_mxmT_masked(int type, uint32_t n_rows, uint32_t mask_nnz,
+                        const uint32_t* d_Mp, const uint32_t* d_Mj, const void* d_Mx,
+                        const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax,
+                        const uint32_t* d_Bp, const uint32_t* d_Bj, const void* d_Bx,
+                        uint32_t* d_Rp, uint32_t** d_Rj, void** d_Rx, uint32_t* h_nnz,
+                        int op_mult, int op_add, int op_select, uint32_t init_bits, void* stream) {
+    SPLAHIP_REQUIRE(d_Rp && d_Rj && d_Rx && h_nnz, "null output argument");
+    SPLAHIP_REQUIRE(binop_valid_for(op_mult, type) && binop_valid_for(op_add, type), "op not defined for this type");
+    SPLAHIP_REQUIRE(op_select >= 0 && op_select < SPLAHIP_SELOP_COUNT, "unknown op_select");
+    SPLAHIP_REQUIRE(d_Mp && d_Ap && d_Bp, "null row pointer array");
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    hipStream_t s = as_stream(stream);
+    switch (type) {
+        case SPLAHIP_INT: return mxmT_typed<int32_t>(n_rows, mask_nnz, d_Mp, d_Mj, d_Mx, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, op_mult, op_add, op_select, init_bits, s);
+        case SPLAHIP_UINT: return mxmT_typed<uint32_t>(n_rows, mask_nnz, d_Mp, d_Mj, d_Mx, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, op_mult, op_add, op_select, init_bits, s);
+        case SPLAHIP_FLOAT: return mxmT_typed<float>(n_rows, mask_nnz, d_Mp, d_Mj, d_Mx, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, op_mult, op_add, op_select, init_bits, s);
+    }
+    return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
+}
+
+int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols,
+                const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax,
+                const uint32_t* d_Bp, const uint32_t* d_Bj, const void* d_Bx,
+                uint32_t* d_Rp, uint32_t** d_Rj, void** d_Rx, uint32_t* h_nnz, uint64_t* h_products,
+                int op_mult, int op_add, uint32_t init_bits, uint64_t block_products, void* stream) {
+    SPLAHIP_REQUIRE(d_Rp && d_Rj && d_Rx && h_nnz, "null output argument");
+    SPLAHIP_REQUIRE(binop_valid_for(op_mult, type) && binop_valid_for(op_add, type), "op not defined for this type");
+    SPLAHIP_REQUIRE(d_Ap && d_Bp, "null row pointer array");
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    hipStream_t s = as_stream(stream);
+    if (a_rows == 0) {
+        *d_Rj = nullptr, *d_Rx = nullptr, *h_nnz = 0;
+        return SPLAHIP_OK;
+    }
+    if (block_products == 0) block_products = 1ull << 27;// 128 Mi products per row block (~5 GiB of sort buffers)
+    unsigned long long prod = 0;
+    int                rc;
+    switch (type) {
+        case SPLAHIP_INT: rc = mxm_typed<int32_t>(a_rows, b_cols, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, &prod, op_mult, op_add, init_bits, block_products, s); break;
+        case SPLAHIP_UINT: rc = mxm_typed<uint32_t>(a_rows, b_cols, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, &prod, op_mult, op_add, init_bits, block_products, s); break;
+        case SPLAHIP_FLOAT: rc = mxm_typed<float>(a_rows, b_cols, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, &prod, op_mult, op_add, init_bits, block_products, s); break;
+        default: return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
+    }
+    if (h_products) *h_products = prod;
+    return rc;
+}
+}

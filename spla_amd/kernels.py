@@ -111,3 +111,41 @@ def vxm_push(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, op_mult, op_add, op_se
               int(vi.numel()), _ptr(vi) if vi.numel() else None, _ptr(vx) if vi.numel() else None, _ptr(ri), _ptr(rx), C.byref(cnt),
               binop_id(op_mult), binop_id(op_add), selop_id(op_select), current_stream_ptr())
     return ri[:cnt.value], rx[:cnt.value]
+
+
+def _adopt(ptr, n, dtype):
+    """Copy a library-allocated device array of n words into a torch tensor and release the original."""
+    out = torch.empty(max(n, 1), dtype=dtype, device="cuda")[:n]
+    if n:
+        _lib.call("splahip_memcpy_d2d", _ptr(out), ptr, n * 4, current_stream_ptr())
+        torch.cuda.current_stream().synchronize()
+    if ptr:
+        _lib.call("splahip_free", ptr)
+    return out
+
+
+def mxmT_masked(t, n_rows, M, A, B, op_mult, op_add, op_select, init):
+    """R = (A x B^T) .mask; M, A, B are (Ap, Aj, Ax) device CSR triples; returns the CSR triple of R."""
+    tid = type_id(t)
+    Rp = torch.empty(n_rows + 1, dtype=torch.int32, device="cuda")
+    pj, px, nnz = C.c_void_p(), C.c_void_p(), C.c_uint32()
+    mask_nnz = int(M[1].numel())
+    args = []
+    for (p_, j_, x_) in (M, A, B):
+        args += [_ptr(p_), _ptr(j_) if j_.numel() else None, _ptr(x_) if x_.numel() else None]
+    _lib.call("splahip_mxmT_masked", tid, int(n_rows), mask_nnz, *args, _ptr(Rp), C.byref(pj), C.byref(px), C.byref(nnz),
+              binop_id(op_mult), binop_id(op_add), selop_id(op_select), scalar_bits(init, tid), current_stream_ptr())
+    return Rp, _adopt(pj, nnz.value, torch.int32), _adopt(px, nnz.value, torch_dtype(t))
+
+
+def mxm(t, a_rows, b_cols, A, B, op_mult, op_add, init, block_products=0):
+    """R = A x B (ESC); returns ((Rp, Rj, Rx), products)."""
+    tid = type_id(t)
+    Rp = torch.empty(a_rows + 1, dtype=torch.int32, device="cuda")
+    pj, px, nnz, prod = C.c_void_p(), C.c_void_p(), C.c_uint32(), C.c_uint64()
+    args = []
+    for (p_, j_, x_) in (A, B):
+        args += [_ptr(p_), _ptr(j_) if j_.numel() else None, _ptr(x_) if x_.numel() else None]
+    _lib.call("splahip_mxm", tid, int(a_rows), int(b_cols), *args, _ptr(Rp), C.byref(pj), C.byref(px), C.byref(nnz), C.byref(prod),
+              binop_id(op_mult), binop_id(op_add), scalar_bits(init, tid), int(block_products), current_stream_ptr())
+    return (Rp, _adopt(pj, nnz.value, torch.int32), _adopt(px, nnz.value, torch_dtype(t))), prod.value

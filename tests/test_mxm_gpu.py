@@ -1,0 +1,129 @@
+"""Parity of the HIP SpGEMM operators (mxm: ESC; mxmT_masked: per-mask-entry intersection) against the oracle."""
+import numpy as np
+import pytest
+
+from helpers import NP, assert_same, random_csr, random_mask, random_values
+
+pytestmark = pytest.mark.gpu
+FP32_RTOL = 1e-5
+
+
+def _dev3(A, t):
+    from gpu_utils import dev
+    return dev(A[0]), dev(A[1]), dev(np.asarray(A[2], NP[t]))
+
+
+def _host3(R, t):
+    from gpu_utils import host
+    return host(R[0], np.uint32), host(R[1], np.uint32), host(R[2], NP[t])
+
+
+def _same_csr(got, want, t, exact, what):
+    np.testing.assert_array_equal(got[0], want[0], err_msg=what + " Rp")
+    np.testing.assert_array_equal(got[1], want[1], err_msg=what + " Rj")
+    if exact:
+        np.testing.assert_array_equal(got[2].view(np.uint32), want[2].view(np.uint32), err_msg=what + " Rx")
+    else:
+        np.testing.assert_allclose(got[2], want[2], rtol=FP32_RTOL, err_msg=what + " Rx")
+
+
+CASES = [("MULT", "PLUS", 0), ("PLUS", "MIN", 100), ("MULT", "SECOND", 0), ("MIN", "MAX", 0), ("MULT", "MINUS", 0), ("LAND", "LOR", 0)]
+
+
+@pytest.mark.parametrize("t", ["INT", "UINT", "FLOAT"])
+def test_mxm_vs_oracle(oracle, t):
+    from spla_amd import kernels
+    rng = np.random.default_rng(51)
+    m, k, n = 400, 350, 300
+    A = random_csr(rng, m, k, 6, t, skew=True, long_rows=1, long_len=300)
+    B = random_csr(rng, k, n, 6, t, skew=True, long_rows=1, long_len=280)
+    for mul, add, init in CASES:
+        want = oracle.mxm(t, m, n, A, B, mul, add, init)
+        for block in (0, 2000):  # one row block, and many small row blocks
+            got, products = kernels.mxm(t, m, n, _dev3(A, t), _dev3(B, t), mul, add, init, block_products=block)
+            # runs up to 64 products are folded strictly in order (bit-exact, fp32 PLUS too); longer runs of an
+            # associative op use an in-order tree -> fp32 PLUS/MULT within 1e-5
+            exact = not (t == "FLOAT" and add in ("PLUS", "MULT"))
+            _same_csr(_host3(got, t), want, t, exact, f"mxm {t} {mul}/{add} block={block}")
+            assert products == sum(int(B[0][c + 1]) - int(B[0][c]) for c in A[1])
+
+
+@pytest.mark.parametrize("t", ["INT", "UINT", "FLOAT"])
+def test_mxmT_masked_vs_oracle(oracle, t):
+    from spla_amd import kernels
+    rng = np.random.default_rng(53)
+    m, k, n = 500, 600, 450
+    A = random_csr(rng, m, k, 12, t, skew=True, long_rows=3, long_len=400)
+    B = random_csr(rng, n, k, 12, t, skew=True, long_rows=3, long_len=420)
+    Mk = random_csr(rng, m, n, 20, t)
+    Mk = (Mk[0], Mk[1], random_mask(rng, len(Mk[1]), t))
+    for (mul, add, init), sel in zip(CASES, ["GTZERO", "ALWAYS", "EQZERO", "NQZERO", "ALWAYS", "GEZERO"]):
+        want = oracle.mxmT_masked(t, m, Mk, A, B, mul, add, sel, init)
+        got = kernels.mxmT_masked(t, m, _dev3(Mk, t), _dev3(A, t), _dev3(B, t), mul, add, sel, init)
+        exact = not (t == "FLOAT" and add in ("PLUS", "MULT"))
+        _same_csr(_host3(got, t), want, t, exact, f"mxmT {t} {mul}/{add} {sel}")
+
+
+def test_mxm_naive_reference_case():
+    # reference tests/test_mxm.cpp:33-94: 3x4 . 4x2 fp32 known answer
+    from spla_amd import api
+    A = api.Matrix((3, 4), api.FLOAT)
+    B = api.Matrix((4, 2), api.FLOAT)
+    for (i, j, x) in [(0, 0, 1), (0, 1, 2), (0, 3, 3), (1, 1, 4), (1, 2, 5), (2, 0, 6), (2, 3, 7)]:
+        A.set(i, j, float(x))
+    for (i, j, x) in [(0, 0, 1), (0, 1, 2), (1, 0, 3), (2, 1, 4), (3, 0, 5), (3, 1, 6)]:
+        B.set(i, j, float(x))
+    R = A.mxm(B, api.FLOAT.MULT, api.FLOAT.PLUS, init=api.Scalar(api.FLOAT, 0.0))
+    dense = np.zeros((3, 2), np.float32)
+    for (i, j, x) in [(0, 0, 1), (0, 1, 2), (0, 3, 3), (1, 1, 4), (1, 2, 5), (2, 0, 6), (2, 3, 7)]:
+        for (p, q, y) in [(0, 0, 1), (0, 1, 2), (1, 0, 3), (2, 1, 4), (3, 0, 5), (3, 1, 6)]:
+            if j == p:
+                dense[i, q] += x * y
+    for i in range(3):
+        for j in range(2):
+            assert R.get(i, j) == dense[i, j]
+    I, J, V = R.read()  # Matrix::read() works on results here (the reference crashes)
+    assert len(I) == np.count_nonzero(dense)
+
+
+def test_mxm_cancelled_entry_is_dropped():
+    # SURVEY.md 8c probe (v): [1,-1] . [4,4]^T -> empty
+    from spla_amd import api
+    A = api.Matrix.from_lists([0, 0], [0, 1], [1.0, -1.0], (1, 2), api.FLOAT)
+    B = api.Matrix.from_lists([0, 1], [0, 0], [4.0, 4.0], (2, 1), api.FLOAT)
+    R = A.mxm(B, api.FLOAT.MULT, api.FLOAT.PLUS)
+    assert R.to_lists() == ([], [], [])
+
+
+def test_mxmT_naive_reference_case():
+    # reference tests/test_mxmT.cpp:33-103: 3x4 . (2x4)^T fp32 with a GTZERO mask -> [[23,0],[0,0],[83,0]]
+    from spla_amd import api
+    R = api.Matrix((3, 2), api.FLOAT)
+    mask = api.Matrix((3, 2), api.FLOAT)
+    A = api.Matrix((3, 4), api.FLOAT)
+    B = api.Matrix((2, 4), api.FLOAT)
+    for (i, j) in [(0, 0), (0, 1), (2, 0), (2, 1)]:
+        mask.set(i, j, 1.0)
+    for (i, j, x) in [(0, 0, 1.0), (0, 2, 2.0), (1, 1, 3.0), (1, 3, 4.0), (2, 0, 5.0), (2, 2, 6.0)]:
+        A.set(i, j, x)
+    for (i, j, x) in [(0, 0, 7.0), (0, 2, 8.0), (1, 1, 9.0), (1, 3, 10.0)]:
+        B.set(i, j, x)
+    A.mxmT(mask, B, api.FLOAT.MULT, api.FLOAT.PLUS, api.FLOAT.GTZERO, out=R, init=api.Scalar(api.FLOAT, 0.0))
+    assert [[R.get(i, j) for j in range(2)] for i in range(3)] == [[23.0, 0.0], [0.0, 0.0], [83.0, 0.0]]
+    # entries equal to init are dropped from the structure (CPU backend behaviour)
+    assert R.to_lists() == ([0, 2], [0, 0], [23.0, 83.0])
+
+
+def test_triangle_count_form():
+    # reference src/algorithm.cpp:398-399: B = (L x L^T) .L with MULT/PLUS/GTZERO, triangles = sum of B
+    from spla_amd import api
+    rng = np.random.default_rng(61)
+    n = 300
+    dense = np.triu(rng.random((n, n)) < 0.05, 1)
+    dense = dense | dense.T
+    I, J = np.nonzero(np.tril(dense, -1))
+    L = api.Matrix.from_lists(I, J, np.ones(len(I), np.int32), (n, n), api.INT)
+    Bm = L.mxmT(L, L, api.INT.MULT, api.INT.PLUS, api.INT.GTZERO)
+    _, _, V = Bm.read()
+    a = dense.astype(np.int64)
+    assert int(V.sum()) == int(np.trace(a @ a @ a) // 6)
