@@ -57,18 +57,16 @@ def parse():
 # workload construction (all on the GPU, seeded)
 # ---------------------------------------------------------------------------------------------------------------
 def build_graph(args, rank, world):
-    from spla_amd import graphgen
+    """Seeded R-MAT on the GPU; every rank generates the same global graph and keeps its nnz-balanced row block."""
+    from spla_amd import graphgen, sharding
     gscale = args.scale + int(round(math.log2(world)))
     permute = (world > 1) if args.permute < 0 else bool(args.permute)
     t0 = time.time()
     n, Ap, Aj = graphgen.rmat_csr(gscale, args.edge_factor, seed=args.seed, device="cuda", permute=permute)
     torch.cuda.synchronize()
     stats = graphgen.degree_stats(Ap)
-    bounds = graphgen.nnz_balanced_row_splits(Ap, world)
-    lo, hi = bounds[rank], bounds[rank + 1]
-    s, e = int(Ap[lo]), int(Ap[hi])
-    Ap_l = (Ap[lo:hi + 1] - Ap[lo]).contiguous()
-    Aj_l = Aj[s:e].clone()
+    bounds = sharding.row_splits(Ap, world)
+    blk = sharding.RowBlock(Ap, Aj, None, bounds, rank)
     nnz_global = int(Ap[-1])
     del Ap, Aj
     torch.cuda.empty_cache()
@@ -76,37 +74,27 @@ def build_graph(args, rank, world):
         log(f"[bench] R-MAT scale {gscale} permute={permute}: n={n} nnz={nnz_global} deg min/avg/sd/max="
             f"{stats['min']:.0f}/{stats['avg']:.2f}/{stats['sd']:.1f}/{stats['max']:.0f} empty_rows={stats['empty_rows']} "
             f"gen {time.time() - t0:.1f}s; row splits {bounds}")
-    return dict(n=n, gscale=gscale, permute=permute, bounds=bounds, lo=lo, hi=hi, Ap=Ap_l, Aj=Aj_l,
-                nnz_local=e - s, nnz_global=nnz_global, stats=stats)
+    return dict(n=n, gscale=gscale, permute=permute, bounds=bounds, lo=blk.lo, hi=blk.hi, Ap=blk.Ap, Aj=blk.Aj, blk=blk,
+                nnz_local=blk.nnz_local, nnz_global=nnz_global, stats=stats)
 
 
 class Sharded:
-    """Row block of the matrix owned by this rank + the all-gather of the dense input vector."""
+    """This rank's row block (spla_amd.sharding.RowBlock: column ids already remapped to the padded all-gather layout),
+    its wave-tile plan, and the exchange step."""
 
     def __init__(self, g, rank, world):
         from spla_amd import kernels
         self.g, self.rank, self.world = g, rank, world
+        self.blk = g["blk"]
         self.n = g["n"]
-        self.n_local = g["hi"] - g["lo"]
+        self.n_local = self.blk.n_local
         self.plan = kernels.CsrPlan(self.n_local, g["nnz_local"], g["Ap"])
-        self.counts = [g["bounds"][p + 1] - g["bounds"][p] for p in range(world)]
-        self.max_rows = max(self.counts)
-        if world > 1:
-            # v is exchanged as [world][max_rows] padded slices (one RCCL all-gather); remap the global column ids
-            # of the local CSR once so the kernel indexes the padded layout directly
-            b = torch.tensor(g["bounds"], device="cuda", dtype=torch.int64)
-            aj = g["Aj"].to(torch.int64)
-            owner = torch.searchsorted(b[1:].contiguous(), aj, right=True)
-            g["Aj"] = (owner * self.max_rows + (aj - b[owner])).to(torch.int32)
-            self.n_cols_padded = world * self.max_rows
-        else:
-            self.n_cols_padded = self.n
+        self.max_rows = self.blk.max_rows
+        self.n_cols_padded = self.blk.n_cols_padded
 
     def gather(self, v_local_padded, v_full):
         """all-gather(v) of the dense input vector: every rank contributes its (padded) slice."""
-        if self.world > 1:
-            dist.all_gather_into_tensor(v_full, v_local_padded)
-        return v_full
+        return self.blk.all_gather(v_local_padded, v_full)
 
 
 def bfs_state(sh: Sharded, Ax):

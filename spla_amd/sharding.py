@@ -1,0 +1,70 @@
+"""1-D row-block decomposition of the masked SpMV across the ranks of one node.
+
+* rows are cut into `world` contiguous blocks that balance nnz (prefix sum over Ap), not row count;
+* rank p owns the CSR slice of its rows (column ids stay global), and slice p of every vector under the same cuts;
+* one exchange step per SpMV: the all-gather of the dense input vector.  RCCL has no all-gatherv, so slices are padded
+  to the longest block and exchanged with ONE all_gather_into_tensor; the local CSR's column ids are remapped once,
+  at setup, to index that padded [world][max_rows] layout directly, so the step does no unpacking.
+
+Everything here is device-agnostic torch + torch.distributed (nccl == RCCL on ROCm; gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def row_splits(Ap: torch.Tensor, world: int):
+    """world + 1 row indices that balance nnz across the blocks."""
+    from .graphgen import nnz_balanced_row_splits
+    return nnz_balanced_row_splits(Ap, world)
+
+
+class RowBlock:
+    """This rank's block of an n x n matrix given as global CSR (Ap, Aj[, Ax]) tensors."""
+
+    def __init__(self, Ap, Aj, Ax, bounds, rank):
+        self.bounds, self.rank, self.world = list(bounds), rank, len(bounds) - 1
+        self.n = int(Ap.numel() - 1)
+        self.lo, self.hi = self.bounds[rank], self.bounds[rank + 1]
+        self.n_local = self.hi - self.lo
+        s, e = int(Ap[self.lo]), int(Ap[self.hi])
+        self.Ap = (Ap[self.lo:self.hi + 1] - Ap[self.lo]).contiguous()
+        self.Aj_global = Aj[s:e].clone()
+        self.Ax = Ax[s:e].clone() if Ax is not None else None
+        self.nnz_local = e - s
+        self.counts = [self.bounds[p + 1] - self.bounds[p] for p in range(self.world)]
+        self.max_rows = max(self.counts)
+        self.n_cols_padded = self.world * self.max_rows if self.world > 1 else self.n
+        self.Aj = self.remap_columns(self.Aj_global) if self.world > 1 else self.Aj_global
+
+    def remap_columns(self, cols: torch.Tensor) -> torch.Tensor:
+        """global column id -> index into the padded all-gathered vector (owner * max_rows + offset in the owner's slice)."""
+        b = torch.tensor(self.bounds, device=cols.device, dtype=torch.int64)
+        c = cols.to(torch.int64)
+        owner = torch.searchsorted(b[1:].contiguous(), c, right=True)
+        return (owner * self.max_rows + (c - b[owner])).to(cols.dtype)
+
+    def pad_local(self, x_local: torch.Tensor, fill=0) -> torch.Tensor:
+        """this rank's slice, padded to max_rows (what the all-gather sends)."""
+        if self.world == 1:
+            return x_local
+        out = torch.full((self.max_rows,), fill, dtype=x_local.dtype, device=x_local.device)
+        out[:self.n_local] = x_local
+        return out
+
+    def all_gather(self, x_local_padded: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        """the exchange step: every rank contributes its padded slice, every rank receives [world][max_rows]."""
+        if self.world == 1:
+            return x_local_padded
+        if out is None:
+            out = torch.empty(self.n_cols_padded, dtype=x_local_padded.dtype, device=x_local_padded.device)
+        dist.all_gather_into_tensor(out, x_local_padded)
+        return out
+
+    def unpad(self, x_padded: torch.Tensor) -> torch.Tensor:
+        """padded [world][max_rows] layout -> the global vector (test / host read-back helper)."""
+        if self.world == 1:
+            return x_padded
+        parts = [x_padded[p * self.max_rows: p * self.max_rows + self.counts[p]] for p in range(self.world)]
+        return torch.cat(parts)
