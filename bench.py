@@ -33,6 +33,11 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 
 
+def coll_device():
+    """device for the small control-plane collectives (cpu under the gloo debug backend)"""
+    return "cpu" if dist.is_initialized() and dist.get_backend() == "gloo" else "cuda"
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -104,7 +109,7 @@ def bfs_state(sh: Sharded, Ax):
     g, world = sh.g, sh.world
     n_local, lo = sh.n_local, g["lo"]
     deg = (g["Ap"][1:] - g["Ap"][:-1]).to(torch.int64)
-    best = torch.stack([deg.max(), deg.argmax() + lo]).clone()
+    best = torch.stack([deg.max(), deg.argmax() + lo]).clone().to(coll_device())
     if world > 1:
         allb = [torch.empty_like(best) for _ in range(world)]
         dist.all_gather(allb, best)
@@ -125,7 +130,7 @@ def bfs_state(sh: Sharded, Ax):
                            "BAND", "BOR", "EQZERO", 0, early_exit=False)
         level += 1
         hit = new != 0
-        cnt = hit.sum()
+        cnt = hit.sum().to(coll_device())
         if world > 1:
             dist.all_reduce(cnt)
         cnt = int(cnt)
@@ -149,13 +154,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
-    torch.cuda.set_device(local_rank)
+    backend = os.environ.get("SPLA_DIST_BACKEND", "nccl")  # "gloo": debug mode, ranks may share one GPU
+    device_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     from spla_amd import _lib, kernels
     _lib.load()
-    _lib.call("splahip_init", local_rank)
+    _lib.call("splahip_init", device_index)
 
     g = build_graph(args, rank, world)
     sh = Sharded(g, rank, world)
@@ -169,7 +179,7 @@ def main():
     deg = (g["Ap"][1:] - g["Ap"][:-1]).to(torch.int64)
     sel_rows = mask == 0
     nnz_sel_local = int(deg[sel_rows].sum())
-    stat = torch.tensor([nnz_sel_local, int(sel_rows.sum()), int((depth == L).sum())], device="cuda", dtype=torch.int64)
+    stat = torch.tensor([nnz_sel_local, int(sel_rows.sum()), int((depth == L).sum())], device=coll_device(), dtype=torch.int64)
     if world > 1:
         dist.all_reduce(stat)
     nnz_sel_total, rows_sel_total, front_total = (int(x) for x in stat.tolist())
@@ -210,7 +220,7 @@ def main():
         wall = time.perf_counter() - t0
         per = [a.elapsed_time(b) for a, b in evs]  # ms
         if world > 1:
-            w = torch.tensor([wall], device="cuda", dtype=torch.float64)
+            w = torch.tensor([wall], device=coll_device(), dtype=torch.float64)
             dist.all_reduce(w, op=dist.ReduceOp.MAX)
             wall = float(w[0])
         return wall, per
@@ -351,7 +361,7 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
         _, per = timed(fn, steps, 3)
         ms = float(np.mean(per))
         b = 8 * nnz_sel + 4 * (n_local + 1) + 8 * n_local + 4 * sh.n_cols_padded
-        tot = torch.tensor([nnz_sel], device="cuda", dtype=torch.int64)
+        tot = torch.tensor([nnz_sel], device=coll_device(), dtype=torch.int64)
         if world > 1:
             dist.all_reduce(tot)
         res.append({"name": name, "kernel": kernels.mxv_variant(t, mul, add, early), "kernel_avg_us": round(ms * 1e3, 2),

@@ -59,7 +59,13 @@ class RowBlock:
             return x_local_padded
         if out is None:
             out = torch.empty(self.n_cols_padded, dtype=x_local_padded.dtype, device=x_local_padded.device)
-        dist.all_gather_into_tensor(out, x_local_padded)
+        if x_local_padded.is_cuda and dist.get_backend() == "gloo":
+            # debug path (two ranks sharing one GPU, SPLA_DIST_BACKEND=gloo): stage the exchange through the host
+            parts = [torch.empty(self.max_rows, dtype=out.dtype) for _ in range(self.world)]
+            dist.all_gather(parts, x_local_padded.cpu())
+            out.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(out, x_local_padded)
         return out
 
     def unpad(self, x_padded: torch.Tensor) -> torch.Tensor:
