@@ -38,6 +38,14 @@ def coll_device():
     return "cpu" if dist.is_initialized() and dist.get_backend() == "gloo" else "cuda"
 
 
+def kernel_name(plan, t, mul, add, early):
+    from spla_amd import kernels
+    name = kernels.mxv_variant(t, mul, add, early)
+    if plan.hot and name.startswith("mxv_wavetile") and os.environ.get("SPLAHIP_HOT") == "1":
+        name = name.replace("mxv_wavetile", "spmv_hot (persistent, LDS hot-column cache)")
+    return name
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -93,7 +101,10 @@ class Sharded:
         self.blk = g["blk"]
         self.n = g["n"]
         self.n_local = self.blk.n_local
-        self.plan = kernels.CsrPlan(self.n_local, g["nnz_local"], g["Ap"])
+        # the plan = wave-tile work items (built once per matrix on the device, like the AccCsr upload); the experimental
+        # hot-column cache is attached only for SPLAHIP_HOT=1 A/B runs
+        hot = os.environ.get("SPLAHIP_HOT") == "1"
+        self.plan = kernels.CsrPlan(self.n_local, g["nnz_local"], g["Ap"], self.blk.n_cols_padded if hot else 0, g["Aj"] if hot else None)
         self.max_rows = self.blk.max_rows
         self.n_cols_padded = self.blk.n_cols_padded
 
@@ -242,8 +253,17 @@ def main():
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": kernels.mxv_variant("INT", "BAND", "BOR", False), "kernel_avg_us": round(k_ms * 1e3, 2),
+                "kernel": kernel_name(sh.plan, "INT", "BAND", "BOR", False), "kernel_avg_us": round(k_ms * 1e3, 2),
                 "kernel_median_us": round(float(np.median(per_k)) * 1e3, 2), "algorithmic_bytes": alg_bytes}
+
+    # HBM-side traffic of the same kernel from the rocprofv3 PMC passes (tools/gpu_round.sh -> tools/pmc_traffic.py):
+    # collected by a separate profiler run of this command, so it is read from profiles/ when it matches this workload
+    tf = ROOT / "profiles" / "pmc_traffic.json"
+    if world == 1 and tf.exists():
+        t = json.loads(tf.read_text())
+        if t.get("config", {}).get("nnz_selected") == nnz_sel_total and t.get("config", {}).get("nnz") == g["nnz_global"]:
+            roofline["traffic"] = t["traffic_bytes"]
+            roofline["traffic_source"] = "profiles/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate rocprofv3 --pmc passes"
 
     out = {
         "metric": "masked SpMV GTEPS", "value": round(gteps, 3), "unit": "GTEPS", "n_gpus": world,
@@ -364,7 +384,7 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
         tot = torch.tensor([nnz_sel], device=coll_device(), dtype=torch.int64)
         if world > 1:
             dist.all_reduce(tot)
-        res.append({"name": name, "kernel": kernels.mxv_variant(t, mul, add, early), "kernel_avg_us": round(ms * 1e3, 2),
+        res.append({"name": name, "kernel": kernel_name(sh.plan, t, mul, add, early), "kernel_avg_us": round(ms * 1e3, 2),
                     "gteps_local": round(nnz_sel / (ms * 1e-3) / 1e9, 2), "hbm_gbs": round(b / (ms * 1e-3) / 1e9, 1),
                     "roofline_frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "nnz_selected_local": nnz_sel})
 

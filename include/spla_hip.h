@@ -68,6 +68,10 @@ int splahip_stream_sync(void* stream);
 typedef struct splahip_plan_s* splahip_plan;
 
 int splahip_csr_plan_create(splahip_plan* plan, uint32_t n_rows, uint32_t nnz, const uint32_t* d_Ap, void* stream);
+/* Optional second half of the plan: gives it the matrix's column ids, from which it derives the hot-column cache of the
+ * persistent mxv kernel (the ~28 K most referenced columns get an LDS slot; a re-encoded private copy of Aj is kept with
+ * the plan, +4 bytes per entry).  Without it mxv runs the non-persistent wave-tile kernel.  Blocks.            */
+int splahip_csr_plan_attach_columns(splahip_plan plan, uint32_t n_cols, const uint32_t* d_Aj, void* stream);
 int splahip_csr_plan_destroy(splahip_plan plan);
 /* n_items: work items; n_long: rows cut into segment items */
 int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_items, uint32_t* n_long);

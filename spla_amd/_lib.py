@@ -8,7 +8,11 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+import os
+
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libspla_amd.so"
+if os.environ.get("SPLA_LIB_TAG"):  # experiments only: a side-by-side build made with SPLA_BUILD_TAG
+    LIB_PATH = LIB_PATH.with_name(f"libspla_amd_{os.environ['SPLA_LIB_TAG']}.so")
 
 
 class SplaHipError(RuntimeError):
@@ -35,6 +39,7 @@ _SIGNATURES = {
     "splahip_memset32": (C.c_int, [_vp, C.c_uint32, C.c_size_t, _vp]),
     "splahip_stream_sync": (C.c_int, [_vp]),
     "splahip_csr_plan_create": (C.c_int, [C.POINTER(_vp), C.c_uint32, C.c_uint32, _vp, _vp]),
+    "splahip_csr_plan_attach_columns": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
     "splahip_csr_plan_destroy": (C.c_int, [_vp]),
     "splahip_csr_plan_info": (C.c_int, [_vp, _u32p, _u32p]),
     "splahip_mxv_masked": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp,

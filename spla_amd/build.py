@@ -23,6 +23,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 COMMON = ["-std=c++17", "-O3", "-fPIC", f"-I{REPO / 'include'}", f"-I{CSRC}", "-Wall", "-Wno-unused-function"]
+COMMON += os.environ.get("SPLA_EXTRA_FLAGS", "").split()  # experiments only (e.g. -DSPLAHIP_GATHER_MODE=2)
+if os.environ.get("SPLA_BUILD_TAG"):  # experiments only: side-by-side builds
+    OBJ = ROOT / ("build_" + os.environ["SPLA_BUILD_TAG"])
+    LIB = ROOT / "lib" / f"libspla_amd_{os.environ['SPLA_BUILD_TAG']}.so"
 
 
 def _sources():

@@ -108,6 +108,11 @@ namespace splahip {
 
     // ------------------------------------------------------------------------------------------------------------
     // main kernel
+    //
+    // The kernels are issue-bound as much as memory-bound (profiles/r01_*): the per-entry code below is kept
+    // branch-free.  A work item's slice [k0, k1) is read as whole aligned quads; the up to 3 entries before k0 / after
+    // k1 that ride along belong to neighbouring items: they are real entries (valid column ids), their products are
+    // computed and staged but never folded, so run items need no per-entry predicate at all.
     // ------------------------------------------------------------------------------------------------------------
 
     // last i in [0, nr) with s_ap[i] <= k, for s_ap[0] <= k < s_ap[nr]
@@ -123,55 +128,86 @@ namespace splahip {
     }
 
     __device__ __forceinline__ void wave_lds_fence() {
-        // LDS operations of one wave are executed in order; this only stops the compiler from reordering across it
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // LDS operations of one wave execute in issue order, so a wave's own ds_write -> ds_read needs no hardware wait;
+        // this is only a COMPILER barrier.  (An __builtin_amdgcn_fence here made hipcc emit s_waitcnt vmcnt(0), which
+        // drained the prefetched global loads of the persistent kernel at every use.)
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
 
-    // load up to 4 aligned quads per lane of the entry range [k0, k1) (a0 = k0 & ~3; quad qi covers a0+4qi..+3)
-    struct QuadRegs {
-        uint4 j[4];
-        uint4 x[4];
-        bool  act[4];
+    using u64 = unsigned long long;
+
+    // per-row selected flags of a run item (<= 128 rows) as two ballot masks, uniform across the wave
+    struct SelMask {
+        u64 m0, m1;
+        __device__ __forceinline__ bool row(uint i) const { return ((i < 64 ? m0 >> i : m1 >> (i - 64)) & 1ull) != 0; }
+        __device__ __forceinline__ bool any_in(uint a, uint b) const {// any selected row in [a, b], a <= b < 128
+            u64 r0 = 0, r1 = 0;
+            if (a < 64) r0 = (~0ull << a) & (~0ull >> (63u - min(b, 63u)));
+            if (b >= 64) r1 = (~0ull << (a > 64 ? a - 64 : 0u)) & (~0ull >> (63u - (b - 64)));
+            return ((m0 & r0) | (m1 & r1)) != 0;
+        }
     };
 
-    __device__ __forceinline__ void load_quad(const uint* __restrict__ Aj, const uint* __restrict__ Ax, uint kq, uint k0, uint k1,
-                                              uint nnz, int vec_ok, uint4& jq, uint4& xq) {
-        if (vec_ok && kq + 4 <= nnz) {
+    // One aligned quad of (column, value) pairs.  Only the last quad of the whole matrix can reach past the arrays.
+    __device__ __forceinline__ void load_quad(const uint* __restrict__ Aj, const uint* __restrict__ Ax, uint kq, uint nnz, uint4& jq, uint4& xq) {
+        if (kq + 4 <= nnz) {
+#if !defined(SPLAHIP_STREAM_PLAIN)
+            // non-temporal: the streamed CSR entries are read exactly once and should not evict the gathered vector's lines
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            const u4 a = __builtin_nontemporal_load(reinterpret_cast<const u4*>(Aj + kq));
+            const u4 b = __builtin_nontemporal_load(reinterpret_cast<const u4*>(Ax + kq));
+            jq = make_uint4(a.x, a.y, a.z, a.w);
+            xq = make_uint4(b.x, b.y, b.z, b.w);
+#else
             jq = *reinterpret_cast<const uint4*>(Aj + kq);
             xq = *reinterpret_cast<const uint4*>(Ax + kq);
+#endif
         } else {
             uint jj[4] = {0, 0, 0, 0}, xx[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (uint e = 0; e < 4; ++e) {
-                const uint k = kq + e;
-                if (k >= k0 && k < k1) {
-                    jj[e] = Aj[k];
-                    xx[e] = Ax[k];
+            for (uint e = 0; e < 4; ++e)
+                if (kq + e < nnz) {
+                    jj[e] = Aj[kq + e];
+                    xx[e] = Ax[kq + e];
                 }
-            }
             jq = make_uint4(jj[0], jj[1], jj[2], jj[3]);
             xq = make_uint4(xx[0], xx[1], xx[2], xx[3]);
         }
     }
 
-    // Operand access of one matrix entry.  MXV: p = mult(Ax[k], v[Aj[k]]), always defined.
-    // VXM (pull form over the transposed matrix): p = mult(v[i], x) and only defined when v stores entry i
-    // (`present` bitmap; nullptr = every entry stored).
+    // The gather v[j].  SPLAHIP_GATHER_MODE (experiments): 0 plain load, 1 non-temporal, 2 agent-scope (sc1, L1 bypass);
+    // measured on MI355X: 1 is 2x slower, 2 is no faster than 0 (profiles/r01_notes.md)
+#ifndef SPLAHIP_GATHER_MODE
+#define SPLAHIP_GATHER_MODE 0
+#endif
+    template<typename T>
+    __device__ __forceinline__ T gather_load(const T* p) {
+#if SPLAHIP_GATHER_MODE == 1
+        return __builtin_nontemporal_load(p);
+#elif SPLAHIP_GATHER_MODE == 2
+        return from_bits<T>(__hip_atomic_load(reinterpret_cast<const uint*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#else
+        return *p;
+#endif
+    }
+
+    // product of one entry.  MXV: mult(Ax[k], v[Aj[k]]).  VXM (pull form over the transposed matrix): mult(v[i], x)
     template<bool VXM, typename T, class Mult>
     __device__ __forceinline__ T entry_product(const Mult& mult, uint xbits, T vj) {
         if constexpr (VXM) return mult(vj, from_bits<T>(xbits));
         else
             return mult(from_bits<T>(xbits), vj);
     }
-    __device__ __forceinline__ bool bit_present(const uint* __restrict__ present, uint j) {
-        return present == nullptr || ((present[j >> 5] >> (j & 31u)) & 1u) != 0;
-    }
+
+    template<typename T>
+    struct alignas(16) Quad {
+        T e[4];
+    };
 
     // The wave-tile SpMV kernel.  VXM = false: masked mxv (every row written, fold starts at init).
     // VXM = true: the pull form of vxm on the transposed matrix: "rows" are output columns, entries whose v index is
-    // not stored are skipped, the fold starts at the first product (no init) and touched[row] tells whether the
-    // output entry exists (reference src/cpu/cpu_vxm.hpp:101-107).
+    // not stored (`present` bitmap; nullptr = every index stored) are skipped, the fold starts at the first product (no
+    // init) and touched[row] tells whether the output entry exists (reference src/cpu/cpu_vxm.hpp:101-107).
     template<class C, typename T, class Mult, class Add, bool VXM>
     __global__ __launch_bounds__(C::kTpb) void spmv_wavetile_kernel(const uint* __restrict__ item_row,
                                                                     const uint* __restrict__ item_k0,
@@ -186,12 +222,10 @@ namespace splahip {
                                                                     uint* __restrict__ touched,
                                                                     T* __restrict__ partial,
                                                                     uint* __restrict__ partial_ok,
-                                                                    Mult mult, Add add, int op_select, T init,
-                                                                    uint nnz, int vec_ok) {
-        __shared__ uint          s_ap_all[C::kWaves][C::kRowsCap + 1];
-        __shared__ T             s_prod_all[C::kWaves][C::kStage + 4];
-        __shared__ unsigned char s_sel_all[C::kWaves][C::kRowsCap];
-        __shared__ unsigned char s_ok_all[C::kWaves][VXM ? C::kStage + 4 : 4];
+                                                                    Mult mult, Add add, int op_select, T init, uint nnz) {
+        __shared__ uint    s_ap_all[C::kWaves][C::kRowsCap + 1];
+        __shared__ Quad<T> s_prod_all[C::kWaves][C::kStage / 4 + 1];
+        __shared__ uint    s_ok_all[C::kWaves][VXM ? C::kStage / 4 + 1 : 1];// VXM: 4 "product defined" bytes per quad
 
         const uint lane = lane_id();
         const uint w    = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -220,36 +254,29 @@ namespace splahip {
                 return;
             }
             uint4 jq[4], xq[4];
-            bool  act[4];
 #pragma unroll
-            for (uint u = 0; u < 4; ++u) {
-                const uint qi = lane + u * kWave;
-                act[u]        = qi < nq;
-                if (act[u]) load_quad(Aj, Ax, a0 + 4 * qi, k0, k1, nnz, vec_ok, jq[u], xq[u]);
-            }
+            for (uint u = 0; u < 4; ++u)
+                if (lane + u * kWave < nq) load_quad(Aj, Ax, a0 + 4 * (lane + u * kWave), nnz, jq[u], xq[u]);
             T    part  = init;
             bool valid = false;
 #pragma unroll
             for (uint u = 0; u < 4; ++u) {
-                if (act[u]) {
+                if (lane + u * kWave < nq) {
                     const uint kq    = a0 + 4 * (lane + u * kWave);
                     const uint jj[4] = {jq[u].x, jq[u].y, jq[u].z, jq[u].w};
                     const uint xx[4] = {xq[u].x, xq[u].y, xq[u].z, xq[u].w};
                     T          vv[4];
-                    bool       ok[4];
+#pragma unroll
+                    for (uint e = 0; e < 4; ++e) vv[e] = gather_load(v + jj[e]);
 #pragma unroll
                     for (uint e = 0; e < 4; ++e) {
-                        ok[e] = kq + e >= k0 && kq + e < k1;
-                        if (VXM && ok[e]) ok[e] = bit_present(present, jj[e]);
-                        vv[e] = ok[e] ? v[jj[e]] : T(0);
-                    }
-#pragma unroll
-                    for (uint e = 0; e < 4; ++e) {
-                        if (ok[e]) {
-                            const T p = entry_product<VXM>(mult, xx[e], vv[e]);
-                            part      = valid ? add(part, p) : p;
-                            valid     = true;
-                        }
+                        bool take = kq + e >= k0 && kq + e < k1;// only the first / last quad of a segment are partial
+                        if constexpr (VXM)
+                            if (present != nullptr) take = take && ((present[jj[e] >> 5] >> (jj[e] & 31u)) & 1u) != 0;
+                        const T p    = entry_product<VXM>(mult, xx[e], vv[e]);
+                        const T both = add(part, p);
+                        part         = take ? (valid ? both : p) : part;
+                        valid        = valid || take;
                     }
                 }
             }
@@ -271,83 +298,92 @@ namespace splahip {
         }
 
         // ---------------- run item: rows [row, row + nr), entries [k0, k1)
-        const uint     nr     = (e1 & ~C::kSegFlag) - row;
-        uint*          s_ap   = s_ap_all[w];
-        T*             s_prod = s_prod_all[w];
-        unsigned char* s_sel  = s_sel_all[w];
-        unsigned char* s_ok   = s_ok_all[w];
+        const uint nr     = (e1 & ~C::kSegFlag) - row;
+        uint*      s_ap   = s_ap_all[w];
+        Quad<T>*   s_quad = s_prod_all[w];
+        const T*   s_prod = reinterpret_cast<const T*>(s_quad);
+        uint*      s_okq  = s_ok_all[w];
+        const unsigned char* s_ok = reinterpret_cast<const unsigned char*>(s_okq);
 
-        // 1. row starts and mask -> LDS
-        int any = 0, all = 1;
+        // 1. row starts -> LDS, selected flags -> two ballot masks.  op_select == ALWAYS needs no mask read at all, and then
+        //    the entry stream does not depend on this step: its loads are issued first so both round trips overlap.
+        const bool always = op_select == SPLAHIP_ALWAYS;
+        uint4      jq[4], xq[4];
+        bool       act[4];
+        if (always) {
 #pragma unroll
-        for (uint u = 0; u < (C::kRowsCap + kWave) / kWave; ++u) {
-            const uint i = lane + u * kWave;
-            if (i <= nr) s_ap[i] = Ap[row + i];
-            if (i < nr) {
-                const bool s = eval_sel(op_select, mask[row + i]);
-                s_sel[i]     = s ? 1 : 0;
-                any |= s ? 1 : 0;
-                all &= s ? 1 : 0;
+            for (uint u = 0; u < 4; ++u) {
+                act[u] = lane + u * kWave < nq;
+                if (act[u]) load_quad(Aj, Ax, a0 + 4 * (lane + u * kWave), nnz, jq[u], xq[u]);
             }
         }
-        const bool any_sel = __ballot(any) != 0ull;
-        const bool all_sel = __ballot(!all) == 0ull;
-        if (!any_sel) {// nothing selected: no matrix entry is touched
-#pragma unroll
-            for (uint u = 0; u < C::kRowsCap / kWave; ++u) {
-                const uint i = lane + u * kWave;
-                if (i < nr) {
-                    if constexpr (VXM) touched[row + i] = 0;
-                    else
-                        r[row + i] = init;
-                }
+        bool selA = false, selB = false;
+        {
+            if (lane <= nr) s_ap[lane] = Ap[row + lane];
+            if (lane + kWave <= nr) s_ap[lane + kWave] = Ap[row + lane + kWave];
+            if (lane == 0 && 2 * kWave <= nr) s_ap[2 * kWave] = Ap[row + 2 * kWave];
+            if (lane < nr) selA = always || eval_sel(op_select, mask[row + lane]);
+            if (lane + kWave < nr) selB = always || eval_sel(op_select, mask[row + lane + kWave]);
+        }
+        SelMask sel;
+        sel.m0 = __ballot(selA);
+        sel.m1 = __ballot(selB);
+        const u64 live0 = nr >= 64 ? ~0ull : ((1ull << nr) - 1ull);
+        const u64 live1 = nr <= 64 ? 0ull : (nr >= 128 ? ~0ull : ((1ull << (nr - 64)) - 1ull));
+        if ((sel.m0 | sel.m1) == 0ull) {// nothing selected: no matrix entry is touched
+            if (lane < nr) {
+                if constexpr (VXM) touched[row + lane] = 0;
+                else
+                    r[row + lane] = init;
+            }
+            if (lane + kWave < nr) {
+                if constexpr (VXM) touched[row + lane + kWave] = 0;
+                else
+                    r[row + lane + kWave] = init;
             }
             return;
         }
+        const bool all_sel = sel.m0 == live0 && sel.m1 == live1;
         wave_lds_fence();
 
-        // 2. stream the slice once, stage products in LDS
+        // 2. stream the slice once (16-byte loads), gather, multiply, stage the products in LDS (16-byte stores)
         {
-            uint4 jq[4], xq[4];
-            bool  act[4];
+            if (!always) {
 #pragma unroll
-            for (uint u = 0; u < 4; ++u) {
-                const uint qi = lane + u * kWave;
-                act[u]        = qi < nq;
-                if (act[u] && !all_sel) {// skip quads that only cover unselected rows
-                    bool need = false;
-#pragma unroll
-                    for (uint e = 0; e < 4; ++e) {
-                        const uint k = a0 + 4 * qi + e;
-                        if (k >= k0 && k < k1) need |= s_sel[find_row(s_ap, nr, k)] != 0;
+                for (uint u = 0; u < 4; ++u) {
+                    const uint qi = lane + u * kWave;
+                    act[u]        = qi < nq;
+                    if (act[u] && !all_sel) {// skip quads that only cover unselected rows
+                        const uint ka = max(a0 + 4 * qi, k0), kb = min(a0 + 4 * qi + 3, k1 - 1);
+                        act[u]        = sel.any_in(find_row(s_ap, nr, ka), find_row(s_ap, nr, kb));
                     }
-                    act[u] = need;
+                    if (act[u]) load_quad(Aj, Ax, a0 + 4 * qi, nnz, jq[u], xq[u]);
                 }
-                if (act[u]) load_quad(Aj, Ax, a0 + 4 * qi, k0, k1, nnz, vec_ok, jq[u], xq[u]);
             }
 #pragma unroll
             for (uint u = 0; u < 4; ++u) {
                 const uint qi = lane + u * kWave;
                 if (act[u]) {
-                    const uint kq    = a0 + 4 * qi;
                     const uint jj[4] = {jq[u].x, jq[u].y, jq[u].z, jq[u].w};
                     const uint xx[4] = {xq[u].x, xq[u].y, xq[u].z, xq[u].w};
                     T          vv[4];
-                    bool       ok[4];
 #pragma unroll
-                    for (uint e = 0; e < 4; ++e) {
-                        ok[e] = kq + e >= k0 && kq + e < k1;
-                        if (VXM && ok[e]) ok[e] = bit_present(present, jj[e]);
-                        vv[e] = ok[e] ? v[jj[e]] : T(0);
-                    }
+                    for (uint e = 0; e < 4; ++e) vv[e] = gather_load(v + jj[e]);
+                    Quad<T> p;
 #pragma unroll
-                    for (uint e = 0; e < 4; ++e) {
-                        if (ok[e]) s_prod[4 * qi + e] = entry_product<VXM>(mult, xx[e], vv[e]);
-                        if constexpr (VXM) s_ok[4 * qi + e] = ok[e] ? 1 : 0;
+                    for (uint e = 0; e < 4; ++e) p.e[e] = entry_product<VXM>(mult, xx[e], vv[e]);
+                    s_quad[qi] = p;
+                    if constexpr (VXM) {
+                        uint okw = 0x01010101u;
+                        if (present != nullptr) {
+                            okw = 0;
+#pragma unroll
+                            for (uint e = 0; e < 4; ++e) okw |= ((present[jj[e] >> 5] >> (jj[e] & 31u)) & 1u) << (8 * e);
+                        }
+                        s_okq[qi] = okw;
                     }
                 } else if (VXM && qi < nq) {
-#pragma unroll
-                    for (uint e = 0; e < 4; ++e) s_ok[4 * qi + e] = 0;
+                    s_okq[qi] = 0;
                 }
             }
         }
@@ -363,7 +399,7 @@ namespace splahip {
             if (i < nr) {
                 T    out = init;
                 bool has = !VXM;
-                if (s_sel[i]) {
+                if (sel.row(i)) {
                     const uint s = s_ap[i] - a0, e = s_ap[i + 1] - a0;
                     if (e - s <= C::kShortMax) {
                         for (uint k = s; k < e; ++k) {
@@ -389,7 +425,7 @@ namespace splahip {
                     }
                 }
             }
-            unsigned long long todo = __ballot(is_long);
+            u64 todo = __ballot(is_long);
             while (todo) {
                 const uint l  = __ffsll((long long) todo) - 1;
                 todo &= todo - 1;

@@ -351,14 +351,15 @@ namespace splahip {
         }
         SPLAHIP_TRY(outv.alloc(sizeof(uint) * (size_t) n_out));
         SPLAHIP_TRY(touched.alloc(sizeof(uint) * (size_t) n_out));
-        const bool vec_ok = ((reinterpret_cast<uintptr_t>(Tj) | reinterpret_cast<uintptr_t>(Tx)) & 15u) == 0;
+        if (((reinterpret_cast<uintptr_t>(Tj) | reinterpret_cast<uintptr_t>(Tx)) & 15u) != 0)
+            return fail(SPLAHIP_INVALID_ARGUMENT, "the transposed CSR arrays must be 16-byte aligned");
         const uint grid   = (plan->n_items + Cfg::kWaves - 1) / Cfg::kWaves;
         if (plan->n_items) {
             hipLaunchKernelGGL((spmv_wavetile_kernel<Cfg, T, Mult, Add, true>), dim3(grid), dim3(Cfg::kTpb), 0, s,
                                plan->d_item_row, plan->d_item_k0, plan->n_items, Tp, Tj, static_cast<const uint*>(Tx),
                                static_cast<const T*>(mask), d_v, d_present, outv.as<T>(), touched.as<uint>(),
                                reinterpret_cast<T*>(plan->d_partial), plan->d_partial_ok, Mult(op_mult), Add(op_add), op_select,
-                               T(0), plan->nnz, vec_ok ? 1 : 0);
+                               T(0), plan->nnz);
             if (plan->n_long > 0)
                 hipLaunchKernelGGL((spmv_combine_kernel<Cfg, T, Add, true>), dim3((plan->n_items + 255) / 256), dim3(256), 0, s,
                                    plan->d_item_row, plan->d_item_k0, plan->n_items, Tp, static_cast<const T*>(mask), outv.as<T>(),

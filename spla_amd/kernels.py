@@ -34,14 +34,23 @@ def current_stream_ptr():
 class CsrPlan:
     """Wave-tile work decomposition of one device CSR matrix (splahip_csr_plan_*)."""
 
-    def __init__(self, n_rows: int, nnz: int, Ap: torch.Tensor):
+    def __init__(self, n_rows: int, nnz: int, Ap: torch.Tensor, n_cols: int = 0, Aj: torch.Tensor = None):
+        """Ap alone gives the wave-tile decomposition; with (n_cols, Aj) the plan also builds the hot-column cache that the
+        persistent mxv kernel uses."""
         self.n_rows, self.nnz = int(n_rows), int(nnz)
+        self.hot = False
         self._h = C.c_void_p()
         _lib.call("splahip_csr_plan_create", C.byref(self._h), self.n_rows, self.nnz, _ptr(Ap), current_stream_ptr())
         nb, nl = C.c_uint32(), C.c_uint32()
         _lib.call("splahip_csr_plan_info", self._h, C.byref(nb), C.byref(nl))
         self.n_items, self.n_long = nb.value, nl.value
         self.n_blocks = self.n_items  # work items (one per wavefront)
+        if Aj is not None and n_cols:
+            self.attach_columns(n_cols, Aj)
+
+    def attach_columns(self, n_cols: int, Aj: torch.Tensor):
+        _lib.call("splahip_csr_plan_attach_columns", self._h, int(n_cols), _ptr(Aj) if self.nnz else None, current_stream_ptr())
+        self.hot = self.nnz > 0
 
     @property
     def handle(self):

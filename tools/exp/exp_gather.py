@@ -7,17 +7,23 @@ import numpy as np, torch
 from spla_amd import _lib, graphgen, kernels
 
 torch.cuda.set_device(0); _lib.load(); _lib.call("splahip_init", 0)
-scale = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+scale = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 22
 n, Ap, Aj = graphgen.rmat_csr(scale, 16, seed=1, device="cuda")
 nnz = int(Ap[-1])
 plan = kernels.CsrPlan(n, nnz, Ap)
+HOT = '--hot' in sys.argv
+if HOT:
+    import os
+    os.environ['SPLAHIP_HOT'] = '1'
+SEL = 'EQZERO' if '--eqzero' in sys.argv else 'ALWAYS'
 g = torch.Generator(device="cuda"); g.manual_seed(3)
 Ax = torch.rand(nnz, generator=g, device="cuda")
 v = torch.rand(n, generator=g, device="cuda")
 mask = torch.zeros(n, device="cuda"); r = torch.empty(n, device="cuda")
 
 def bench(name, aj, steps=20):
-    fn = lambda: kernels.mxv_masked(plan, "FLOAT", n, Ap, aj, Ax, mask, v, r, "MULT", "PLUS", "ALWAYS", 0.0)
+    pl = kernels.CsrPlan(n, nnz, Ap, n, aj) if HOT else plan
+    fn = lambda: kernels.mxv_masked(pl, "FLOAT", n, Ap, aj, Ax, mask, v, r, "MULT", "PLUS", SEL, 0.0)
     for _ in range(3): fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
