@@ -9,9 +9,9 @@ cd /tmp; export TMPDIR=/tmp
 echo "== rocprof kernel trace"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -- python3 "$R/bench.py" --steps 30 --warmup 5 --no-cpu-baseline --no-verify > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof_bench.err"; echo "rocprof exit $?"
 echo "== rocprof pmc FETCH_SIZE"
-timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_fetch" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-verify > /dev/null 2> "$R/gpurun_out/pmc_fetch.err"; echo "pmc fetch exit $?"
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_fetch" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-variants > /dev/null 2> "$R/gpurun_out/pmc_fetch.err"; echo "pmc fetch exit $?"
 echo "== rocprof pmc WRITE_SIZE"
-timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_write" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-verify > /dev/null 2> "$R/gpurun_out/pmc_write.err"; echo "pmc write exit $?"
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_write" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-variants > /dev/null 2> "$R/gpurun_out/pmc_write.err"; echo "pmc write exit $?"
 cd "$R"
 python tools/summarize_prof.py gpurun_out/prof > gpurun_out/prof_summary.txt 2>&1
 python tools/summarize_prof.py gpurun_out/pmc_fetch > gpurun_out/pmc_fetch_summary.txt 2>&1

@@ -25,7 +25,8 @@ def main():
     root, out, needle, bench = sys.argv[1:5]
     res = {}
     for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        f = glob.glob(f"{root}/pmc_{kind}/**/*counter_collection.csv", recursive=True)[0]
+        import os
+        f = max(glob.glob(f"{root}/pmc_{kind}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if needle in r["Kernel_Name"] and r["Counter_Name"] == counter]
         res[counter], res[counter + "_dispatches"] = cluster_median(vals)
     b = json.loads(open(bench).read().strip().splitlines()[-1])
@@ -36,7 +37,7 @@ def main():
            "traffic_over_algorithmic": round(traffic / b["roofline"]["algorithmic_bytes"], 3),
            "config": {k: b["config"][k] for k in ("n", "nnz", "nnz_selected")},
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline "
-                     "--no-verify`; traffic = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024 (gfx950 half-count of 128-B read requests; the counter sits on "
+                     "--no-verify --no-variants`; traffic = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024 (gfx950 half-count of 128-B read requests; the counter sits on "
                      "the L2's fabric side, so Infinity-Cache hits — here the gathered vector's lines — are included)"}
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps(doc))
