@@ -63,6 +63,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-variants", action="store_true")
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--workload", default="bfs-step", choices=["bfs-step", "pagerank-vxm", "sssp-step", "tc-mxmT", "mxm"],
+                   help="bfs-step (default, the contract line) or one of the other hot-path operators (bench_workloads.py; N = 1 only)")
     return p.parse_args()
 
 
@@ -177,6 +179,13 @@ def main():
     from spla_amd import _lib, kernels
     _lib.load()
     _lib.call("splahip_init", device_index)
+
+    if args.workload != "bfs-step":
+        if world != 1:
+            raise SystemExit("the operator workloads run on one GPU")
+        import bench_workloads
+        print(json.dumps(bench_workloads.WORKLOADS[args.workload](args)), flush=True)
+        return
 
     g = build_graph(args, rank, world)
     sh = Sharded(g, rank, world)

@@ -1,0 +1,369 @@
+"""The other hot-path operators as bench.py workloads (`python bench.py --workload <name>`): same JSON contract as the default
+BFS-step line (metric / value / roofline / cpu_baseline), one operator each, inputs resident in HBM, results checked against
+the oracle, the genuine reference CPU backend timed beside it on a bounded sample.
+
+    pagerank-vxm : exec_vxm_masked plus-times fp32, every entry of v stored (BASELINE configs[2]; com-Orkut is not on the
+                   box, stand-in: symmetrised R-MAT scale 22 edge factor 28, values 0.85/outdeg)  -> pull form over M^T
+    sssp-step    : exec_mxv_masked min-plus int32 on R-MAT scale 24 (BASELINE configs[3] at N = 1)
+    tc-mxmT      : exec_mxmT_masked(L, L, L) MULT/PLUS/GTZERO int32, L = strict lower triangle of symmetrised R-MAT scale 20
+                   (BASELINE configs[4], triangle-count form)
+    mxm          : exec_mxm plus-times fp32 A x A on R-MAT (BASELINE configs[4]; scale chosen so the expanded products fit)
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _log(*a):
+    import sys
+    print(*a, file=sys.stderr, flush=True)
+
+
+def _time_calls(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return wall, [a.elapsed_time(b) for a, b in evs]
+
+
+def _line(metric, unit, value, args, ms, dtype, config, roofline, extra=None):
+    out = {"metric": metric, "value": round(value, 3), "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+           "data": "synthetic", "config": config, "roofline": roofline}
+    if extra:
+        out.update(extra)
+    return out
+
+
+def _roof(alg_bytes, ms, kernel):
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": None, "kernel": kernel, "kernel_avg_us": round(ms * 1e3, 2), "algorithmic_bytes": int(alg_bytes)}
+
+
+def _sym_rmat(scale, edge_factor, seed):
+    """Symmetrised R-MAT pattern (both directions, self loops and duplicates removed): (n, Ap, Aj) on the GPU."""
+    from spla_amd import graphgen
+    n = 1 << scale
+    key = graphgen.rmat_edge_keys(scale, edge_factor, seed=seed, device="cuda")
+    i, j = torch.div(key, n, rounding_mode="floor"), key % n
+    key = torch.unique(torch.cat([key, j * n + i]), sorted=True)
+    del i, j
+    Ap, Aj = graphgen.keys_to_csr(key, n, n)
+    return n, Ap, Aj
+
+
+# ---------------------------------------------------------------------------------------------------------------- vxm
+def pagerank_vxm(args):
+    from oracle import pyoracle
+    from spla_amd import kernels
+    scale, ef = (args.scale if args.scale != 22 or True else 22), 28
+    n, Ap, Aj = _sym_rmat(scale, ef, args.seed)
+    nnz = int(Ap[-1])
+    deg = (Ap[1:] - Ap[:-1]).to(torch.float32)
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), (Ap[1:] - Ap[:-1]).to(torch.int64))
+    Ax = (0.85 / deg.clamp(min=1.0))[rows].contiguous()  # examples/pr.cpp:81-88: 0.85 / outdeg(row)
+    del rows
+    _log(f"[bench] pagerank-vxm stand-in: symmetrised R-MAT scale {scale} ef {ef}: n={n} nnz={nnz}")
+    Tp, Tj, Tx = kernels.csr_transpose(n, n, Ap, Aj, Ax)
+    plan_T = kernels.CsrPlan(n, nnz, Tp)
+    vi = torch.arange(n, device="cuda", dtype=torch.int32)
+    vx = torch.full((n,), 1.0 / n, device="cuda", dtype=torch.float32)
+    mask = torch.zeros(n, device="cuda", dtype=torch.float32)  # the dummy mask of pr(): ALWAYS ignores it
+    out = {}
+
+    def step():
+        out["r"] = kernels.vxm_pull(plan_T, "FLOAT", n, n, Tp, Tj, Tx, mask, vi, vx, "MULT", "PLUS", "ALWAYS", identity=True)
+
+    wall, per = _time_calls(step, args.steps, args.warmup)
+    ms = float(np.mean(per))
+    ri, rx = out["r"]
+    # B_vxm (dense frontier = mxv over M^T): CSR stream + row pointers + mask + v + (value, touched) + compaction
+    alg = 8 * nnz + 4 * (n + 1) + 4 * n + 4 * n + 8 * n + 8 * n + 8 * int(ri.numel())
+    line = _line("masked vxm GTEPS (PageRank step)", "GTEPS", nnz / (wall / args.steps) / 1e9, args, wall / args.steps * 1e3, "f32",
+                 {"workload": f"exec_vxm_masked MULT/PLUS fp32, ALWAYS mask, every v entry stored; symmetrised R-MAT scale {scale} ef {ef} "
+                              "(stand-in for com-Orkut, which is not on the box)", "n": n, "nnz": nnz, "out_entries": int(ri.numel()),
+                  "form": "pull over the transposed CSR (spmv_wavetile, VXM mode) + order-preserving compaction"},
+                 _roof(alg, ms, "spmv_wavetile<VXM> + compaction"))
+    if not args.no_verify:
+        # structure: identical to the oracle's (same touched columns, index-sorted).  values: the oracle (= the reference) folds
+        # every column sequentially in fp32; columns here have up to ~1e5 products, where that sequential fold itself is ~2e-5 off
+        # the exact sum while the wave-tile tree is ~5e-7 off.  So: (1) HIP within 1e-5 of the fp64 sum for every entry,
+        # (2) HIP within 1e-5 of the oracle for every column of <= 4096 products, (3) within the sequential fold's own error
+        # bound len * 2^-24 for the longer ones (measured: the oracle is up to 1.8e-4 off the fp64 sum on a 239 K-product column).
+        orc = pyoracle.Oracle()
+        wi, wx = orc.vxm_masked("FLOAT", n, n, Ap.cpu().numpy(), Aj.cpu().numpy(), Ax.cpu().numpy(), mask.cpu().numpy(),
+                                vi.cpu().numpy(), vx.cpu().numpy(), "MULT", "PLUS", "ALWAYS")
+        gi, gx = ri.cpu().numpy().view(np.uint32), rx.cpu().numpy()
+        ok = bool(np.array_equal(wi, gi))
+        if ok:
+            exact = torch.zeros(n, dtype=torch.float64, device="cuda")
+            exact.index_add_(0, Aj.to(torch.int64), Ax.to(torch.float64) * (1.0 / n))
+            ex = exact.cpu().numpy()[gi]
+            lens = np.diff(Tp.cpu().numpy().astype(np.int64))[gi]
+            rel_exact = np.abs(gx - ex) / np.abs(ex)
+            rel_orc = np.abs(gx - wx) / np.abs(wx)
+            tol = np.where(lens <= 4096, 1e-5, np.maximum(1e-5, lens * 2.0 ** -24))  # (n-1)*u: the textbook bound of a sequential fp32 sum
+            ok = bool(rel_exact.max() <= 1e-5 and np.all(rel_orc <= tol))
+            line["verify"] = {"max_rel_vs_fp64": float(rel_exact.max()), "max_rel_vs_oracle": float(rel_orc.max()),
+                              "oracle_max_rel_vs_fp64": float((np.abs(wx - ex) / np.abs(ex)).max()), "longest_column": int(lens.max())}
+        _log(f"[bench] vxm full-size parity: structure == oracle, values {line.get('verify')}: {'OK' if ok else 'MISMATCH'}")
+        if not ok:
+            raise SystemExit("bench: vxm result differs from the oracle")
+        line["verified"] = True
+    if not args.no_cpu_baseline and pyoracle.have_reference():
+        ref = pyoracle.Reference()
+        stride = 16
+        svi = np.arange(0, n, stride, dtype=np.uint32)
+        svx = np.full(len(svi), 1.0 / n, np.float32)
+        prod = int((Ap[1:] - Ap[:-1])[::stride].sum())
+        Ap_h, Aj_h, Ax_h, mk = Ap.cpu().numpy(), Aj.cpu().numpy(), Ax.cpu().numpy(), mask.cpu().numpy()
+        t0 = time.perf_counter()
+        ref.vxm_masked("FLOAT", n, n, Ap_h, Aj_h, Ax_h, mk, svi, svx, "MULT", "PLUS", "ALWAYS")
+        first = time.perf_counter() - t0
+        # steady state: exec only (objects rebuilt per call in the driver, so time a second full call minus nothing: report the exec-dominated call)
+        hM = ref._matrix(2, n, n, Ap_h, Aj_h, Ax_h)
+        hm, hr, hv = ref._dense_vector(2, mk), ref._empty_vector(2, n), ref._empty_vector(2, n)
+        k1, k2 = ref._view(svi), ref._view(svx)
+        ref.lib.spla_Vector_build(hv, k1, k2)
+        hi = ref._scalar(0.0, 2)
+        ops = (ref._op("Binary", "MULT", 2), ref._op("Binary", "PLUS", 2), ref._op("Select", "ALWAYS", 2))
+        times = []
+        for it in range(4):
+            t0 = time.perf_counter()
+            st = ref.lib.spla_Exec_vxm_masked(hr, hm, hv, hM, ops[0], ops[1], ops[2], hi, None, None)
+            if it:
+                times.append(time.perf_counter() - t0)
+            assert st == 0
+        med = float(np.median(times))
+        line["cpu_baseline"] = {"value": round(prod / med / 1e9, 4), "unit": "GTEPS", "cores": 1, "kind": "reference",
+                                "sample": f"frontier = every {stride}th vertex ({len(svi)} entries, {prod} products) on the same matrix; median of 3 "
+                                          f"steady-state exec_vxm_masked calls (first full call incl. conversions {first * 1e3:.0f} ms)",
+                                "host_cpus": os.cpu_count(), "ms": round(med * 1e3, 2)}
+        ref._unref(hM, hm, hr, hv, k1, k2, hi)
+    return line
+
+
+# --------------------------------------------------------------------------------------------------------------- sssp
+def sssp_step(args):
+    from oracle import pyoracle
+    from spla_amd import graphgen, kernels
+    scale = 24 if args.scale == 22 else args.scale
+    n, Ap, Aj = graphgen.rmat_csr(scale, args.edge_factor, seed=args.seed, device="cuda")
+    nnz = int(Ap[-1])
+    g = torch.Generator(device="cuda")
+    g.manual_seed(args.seed + 5)
+    Ax = torch.randint(1, 256, (nnz,), generator=g, device="cuda", dtype=torch.int32)
+    INF = 1 << 30
+    v = torch.full((n,), INF, dtype=torch.int32, device="cuda")
+    idx = torch.randint(0, n, (n // 8,), generator=g, device="cuda")
+    v[idx] = torch.randint(0, 5000, (n // 8,), generator=g, device="cuda", dtype=torch.int32)
+    mask = torch.zeros(n, dtype=torch.int32, device="cuda")
+    r = torch.empty(n, dtype=torch.int32, device="cuda")
+    plan = kernels.CsrPlan(n, nnz, Ap)
+    _log(f"[bench] sssp-step: R-MAT scale {scale}: n={n} nnz={nnz} items={plan.n_items}")
+    step = lambda: kernels.mxv_masked(plan, "INT", n, Ap, Aj, Ax, mask, v, r, "PLUS", "MIN", "ALWAYS", INF)
+    wall, per = _time_calls(step, args.steps, args.warmup)
+    ms = float(np.mean(per))
+    alg = 8 * nnz + 4 * (n + 1) + 8 * n + 4 * n
+    line = _line("masked SpMV GTEPS (SSSP step)", "GTEPS", nnz / (wall / args.steps) / 1e9, args, wall / args.steps * 1e3, "int32",
+                 {"workload": f"exec_mxv_masked PLUS/MIN int32 (min-plus), ALWAYS, init 2^30, weights 1..255, 1/8 of v finite; R-MAT scale {scale} "
+                              f"ef {args.edge_factor}, raw labels", "n": n, "nnz": nnz, "work_items": plan.n_items},
+                 _roof(alg, ms, kernels.mxv_variant("INT", "PLUS", "MIN")))
+    if not args.no_verify:
+        orc = pyoracle.Oracle()
+        want = orc.mxv_masked("INT", n, n, Ap.cpu().numpy(), Aj.cpu().numpy(), Ax.cpu().numpy(), mask.cpu().numpy(), v.cpu().numpy(), "PLUS", "MIN", "ALWAYS", INF)
+        ok = bool(np.array_equal(want, r.cpu().numpy()))
+        _log(f"[bench] sssp-step full-size parity vs oracle: {'OK' if ok else 'MISMATCH'}")
+        if not ok:
+            raise SystemExit("bench: HIP result differs from the oracle")
+        line["verified"] = True
+    if not args.no_cpu_baseline and pyoracle.have_reference():
+        ref = pyoracle.Reference()
+        stride = max(1, nnz // args.cpu_sample_nnz)
+        rows = torch.arange(0, n, stride, device="cuda")
+        Ap64 = Ap.to(torch.int64)
+        deg = (Ap64[1:] - Ap64[:-1])[rows]
+        Aps = torch.zeros(rows.numel() + 1, dtype=torch.int64, device="cuda")
+        torch.cumsum(deg, 0, out=Aps[1:])
+        rep = torch.repeat_interleave(torch.arange(rows.numel(), device="cuda"), deg)
+        src = Ap64[rows][rep] + (torch.arange(int(Aps[-1]), device="cuda") - Aps[:-1][rep])
+        Ap_s, Aj_s, Ax_s = Aps.to(torch.int32).cpu().numpy(), Aj[src].cpu().numpy(), Ax[src].cpu().numpy()
+        m = int(rows.numel())
+        M = ref._matrix(0, m, n, Ap_s, Aj_s, Ax_s)
+        hm, hv, hr = ref._dense_vector(0, np.zeros(m, np.int32)), ref._dense_vector(0, v.cpu().numpy()), ref._empty_vector(0, m)
+        hi = ref._scalar(INF, 0)
+        ops = (ref._op("Binary", "PLUS", 0), ref._op("Binary", "MIN", 0), ref._op("Select", "ALWAYS", 0))
+        times = []
+        for it in range(4):
+            t0 = time.perf_counter()
+            assert ref.lib.spla_Exec_mxv_masked(hr, hm, M, hv, ops[0], ops[1], ops[2], hi, None, None) == 0
+            if it:
+                times.append(time.perf_counter() - t0)
+        got = np.empty(m, np.uint32)
+        ref.lib.refshim_vector_dense_read(hr, got.ctypes.data_as(pyoracle._u32p))
+        same = bool(np.array_equal(got.view(np.int32), r[rows].cpu().numpy()))
+        med = float(np.median(times))
+        line["cpu_baseline"] = {"value": round(int(Aps[-1]) / med / 1e9, 4), "unit": "GTEPS", "cores": 1, "kind": "reference",
+                                "sample": f"every {stride}th row: {m} rows, {int(Aps[-1])} nnz, same v; median of 3 steady-state exec_mxv_masked calls",
+                                "host_cpus": os.cpu_count(), "ms": round(med * 1e3, 2), "matches_hip": same}
+        ref._unref(M, hm, hv, hr, hi)
+        if not same:
+            raise SystemExit("bench: HIP result differs from the CPU reference on the sample")
+    return line
+
+
+# --------------------------------------------------------------------------------------------------------------- mxmT
+def _row_sample_csr(Ap, Aj, Ax, rows):
+    """CSR (on the host, numpy) that keeps only the given rows' entries, other rows empty (same shape)."""
+    n = Ap.numel() - 1
+    Ap64 = Ap.to(torch.int64)
+    keep = torch.zeros(n, dtype=torch.bool, device=Ap.device)
+    keep[rows] = True
+    deg = torch.where(keep, Ap64[1:] - Ap64[:-1], torch.zeros_like(Ap64[1:]))
+    Aps = torch.zeros(n + 1, dtype=torch.int64, device=Ap.device)
+    torch.cumsum(deg, 0, out=Aps[1:])
+    ent = torch.repeat_interleave(keep, (Ap64[1:] - Ap64[:-1]))
+    return Aps.to(torch.int32), Aj[ent].contiguous(), Ax[ent].contiguous()
+
+
+def tc_mxmT(args):
+    from oracle import pyoracle
+    from spla_amd import graphgen, kernels
+    scale = 20 if args.scale == 22 else args.scale
+    n, Ap, Aj = _sym_rmat(scale, args.edge_factor, args.seed)
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), (Ap[1:] - Ap[:-1]).to(torch.int64))
+    low = Aj.to(torch.int64) < rows  # strict lower triangle (examples/tc.cpp:82-86)
+    key = rows[low] * n + Aj[low].to(torch.int64)
+    Lp, Lj = graphgen.keys_to_csr(key, n, n)
+    nnz = int(Lp[-1])
+    Lx = torch.ones(nnz, dtype=torch.int32, device="cuda")
+    L = (Lp, Lj, Lx)
+    deg = (Lp[1:] - Lp[:-1]).to(torch.int64)
+    lrows = torch.repeat_interleave(torch.arange(n, device="cuda"), deg)
+    work = int((deg[lrows] + deg[Lj.to(torch.int64)]).sum())
+    _log(f"[bench] tc-mxmT: L = strict lower triangle of symmetrised R-MAT scale {scale}: n={n} nnz(L)={nnz} merge work={work}")
+    out = {}
+
+    def step():
+        out["R"] = kernels.mxmT_masked("INT", n, L, L, L, "MULT", "PLUS", "GTZERO", 0)
+
+    wall, per = _time_calls(step, args.steps, args.warmup)
+    ms = float(np.mean(per))
+    Rp, Rj, Rx = out["R"]
+    nnz_r = int(Rj.numel())
+    triangles = int(Rx.to(torch.int64).sum())
+    alg = 8 * (3 * nnz + nnz_r) + 4 * 4 * (n + 1)  # mask + A + B + R (SURVEY 8d compulsory bytes)
+    line = _line("masked SpGEMM (mxmT) G merge-steps/s", "Gsteps/s", work / (wall / args.steps) / 1e9, args, wall / args.steps * 1e3, "int32",
+                 {"workload": f"exec_mxmT_masked(L, L, L) MULT/PLUS/GTZERO int32 (triangle-count form), L = strict lower triangle of symmetrised R-MAT "
+                              f"scale {scale} ef {args.edge_factor}", "n": n, "nnz_L": nnz, "merge_steps": work, "nnz_R": nnz_r, "triangles": triangles},
+                 _roof(alg, ms, "mxmT_entry + mxmT_heavy + compaction"))
+    if not args.no_verify or not args.no_cpu_baseline:
+        # restrict the mask to every 64th row: the same call on the sample is checked against the oracle and timed on the reference
+        srows = torch.arange(0, n, 64, device="cuda")
+        Mp_s, Mj_s, Mx_s = _row_sample_csr(Lp, Lj, Lx, srows)
+        got = kernels.mxmT_masked("INT", n, (Mp_s, Mj_s, Mx_s), L, L, "MULT", "PLUS", "GTZERO", 0)
+        Lh = tuple(t.cpu().numpy() for t in L)
+        Mh = (Mp_s.cpu().numpy(), Mj_s.cpu().numpy(), Mx_s.cpu().numpy())
+        if not args.no_verify:
+            want = pyoracle.Oracle().mxmT_masked("INT", n, Mh, Lh, Lh, "MULT", "PLUS", "GTZERO", 0)
+            ok = all(np.array_equal(np.asarray(a).view(np.uint32), b.cpu().numpy().view(np.uint32)) for a, b in zip(want, got))
+            _log(f"[bench] tc-mxmT sample parity vs oracle ({int(Mp_s[-1])} mask entries): {'OK' if ok else 'MISMATCH'}")
+            if not ok:
+                raise SystemExit("bench: mxmT result differs from the oracle")
+            line["verified"] = True
+        if not args.no_cpu_baseline and pyoracle.have_reference():
+            ref = pyoracle.Reference()
+            sdeg = (Mp_s[1:] - Mp_s[:-1]).to(torch.int64)
+            srow_of = torch.repeat_interleave(torch.arange(n, device="cuda"), sdeg)
+            swork = int((deg[srow_of] + deg[Mj_s.to(torch.int64)]).sum())
+            t0 = time.perf_counter()
+            ref.mxmT_masked("INT", n, Mh, Lh, Lh, "MULT", "PLUS", "GTZERO", 0, n_cols=n, inner=n)
+            dt = time.perf_counter() - t0
+            line["cpu_baseline"] = {"value": round(swork / dt / 1e9, 4), "unit": "Gsteps/s", "cores": 1, "kind": "reference",
+                                    "sample": f"mask restricted to every 64th row ({int(Mp_s[-1])} entries, {swork} merge steps), one full call incl. "
+                                              "COO->LIL conversion of the three operands", "host_cpus": os.cpu_count(), "ms": round(dt * 1e3, 1)}
+    return line
+
+
+# ---------------------------------------------------------------------------------------------------------------- mxm
+def mxm(args):
+    from oracle import pyoracle
+    from spla_amd import graphgen, kernels
+    scale = 18 if args.scale == 22 else args.scale
+    n, Ap, Aj = graphgen.rmat_csr(scale, args.edge_factor, seed=args.seed, device="cuda")
+    nnz = int(Ap[-1])
+    g = torch.Generator(device="cuda")
+    g.manual_seed(args.seed + 9)
+    Ax = (torch.rand(nnz, generator=g, device="cuda") * 0.5 + 0.25).contiguous()
+    A = (Ap, Aj, Ax)
+    out = {}
+
+    def step():
+        out["R"], out["P"] = kernels.mxm("FLOAT", n, n, A, A, "MULT", "PLUS", 0.0)
+
+    steps, warm = max(1, min(args.steps, 5)), 1
+    wall, per = _time_calls(step, steps, warm)
+    ms = float(np.mean(per))
+    (Rp, Rj, Rx), P = out["R"], out["P"]
+    nnz_c = int(Rj.numel())
+    _log(f"[bench] mxm: R-MAT scale {scale}: n={n} nnz(A)={nnz} products={P} nnz(C)={nnz_c}")
+    alg = 8 * (2 * nnz + nnz_c) + 4 * 3 * (n + 1)
+    args_steps = args.steps
+    args.steps = steps
+    line = _line("SpGEMM (mxm) G products/s", "Gproducts/s", P / (wall / steps) / 1e9, args, wall / steps * 1e3, "f32",
+                 {"workload": f"exec_mxm A x A, MULT/PLUS fp32, init 0; R-MAT scale {scale} ef {args.edge_factor} (scale 20 of BASELINE configs[4] expands to more "
+                              "products than one ESC pass should hold in round 1; stated fallback)", "n": n, "nnz_A": nnz, "products": P, "nnz_C": nnz_c,
+                  "form": "ESC: expand / stable 64-bit radix sort (rocPRIM) / in-order run fold / compact, row blocks of 2^27 products"},
+                 _roof(alg, ms, "mxm ESC pipeline"))
+    args.steps = args_steps
+    if not args.no_verify or not args.no_cpu_baseline:
+        srows = torch.arange(0, n, 256, device="cuda")
+        Sp, Sj, Sx = _row_sample_csr(Ap, Aj, Ax, srows)
+        (gp, gj, gx), sprod = kernels.mxm("FLOAT", n, n, (Sp, Sj, Sx), A, "MULT", "PLUS", 0.0)
+        Ah = tuple(t.cpu().numpy() for t in A)
+        Sh = (Sp.cpu().numpy(), Sj.cpu().numpy(), Sx.cpu().numpy())
+        if not args.no_verify:
+            want = pyoracle.Oracle().mxm("FLOAT", n, n, Sh, Ah, "MULT", "PLUS", 0.0)
+            ok = np.array_equal(want[0], gp.cpu().numpy().view(np.uint32)) and np.array_equal(want[1], gj.cpu().numpy().view(np.uint32)) and \
+                np.allclose(want[2], gx.cpu().numpy(), rtol=1e-5, atol=0)
+            _log(f"[bench] mxm sample parity vs oracle (every 256th row of A, {sprod} products): {'OK' if ok else 'MISMATCH'}")
+            if not ok:
+                raise SystemExit("bench: mxm result differs from the oracle")
+            line["verified"] = True
+        if not args.no_cpu_baseline and pyoracle.have_reference():
+            # the reference's mxm is O(rows x n_cols) per call (cpu_mxm.hpp:93,109): time it on a 2^12-row, 2^12-column corner
+            m = min(n, 4096)
+            keep = Aj[: int(Ap[m])] < m
+            rows = torch.repeat_interleave(torch.arange(m, device="cuda"), (Ap[1:m + 1] - Ap[:m]).to(torch.int64))
+            key = rows[keep] * m + Aj[: int(Ap[m])][keep].to(torch.int64)
+            Cp, Cj = graphgen.keys_to_csr(key, m, m)
+            Cx = Ax[: int(Ap[m])][keep].contiguous()
+            Ch = (Cp.cpu().numpy(), Cj.cpu().numpy(), Cx.cpu().numpy())
+            cprod = int(sum(int(Ch[0][c + 1]) - int(Ch[0][c]) for c in Ch[1]))
+            ref = pyoracle.Reference()
+            t0 = time.perf_counter()
+            ref.mxm("FLOAT", m, m, Ch, Ch, "MULT", "PLUS", 0.0)
+            dt = time.perf_counter() - t0
+            line["cpu_baseline"] = {"value": round(cprod / dt / 1e9, 5), "unit": "Gproducts/s", "cores": 1, "kind": "reference",
+                                    "sample": f"leading {m} x {m} corner of A ({int(Cp[-1])} nnz, {cprod} products): the reference refills and rescans an "
+                                              "n_cols-wide accumulator per row, so it is timed at reduced size; one full call incl. conversions",
+                                    "host_cpus": os.cpu_count(), "ms": round(dt * 1e3, 1)}
+    return line
+
+
+WORKLOADS = {"pagerank-vxm": pagerank_vxm, "sssp-step": sssp_step, "tc-mxmT": tc_mxmT, "mxm": mxm}

@@ -150,6 +150,7 @@ namespace {
         if (plan->d_item_k0) (void) hipFree(plan->d_item_k0);
         if (plan->d_partial) (void) hipFree(plan->d_partial);
         if (plan->d_partial_ok) (void) hipFree(plan->d_partial_ok);
+        if (plan->d_ws) (void) hipFree(plan->d_ws);
         if (plan->d_hot_cols) (void) hipFree(plan->d_hot_cols);
         if (plan->d_hot_values) (void) hipFree(plan->d_hot_values);
         if (plan->d_Aj_enc) (void) hipFree(plan->d_Aj_enc);

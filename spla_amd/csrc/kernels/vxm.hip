@@ -335,47 +335,54 @@ namespace splahip {
     int pull_typed(splahip_plan plan, uint n_out, uint n_in, const uint* Tp, const uint* Tj, const void* Tx, const void* mask,
                    uint nvals, const uint* vi, const void* vx, int v_is_identity, uint* ri, void* rx, uint* h_count,
                    int op_mult, int op_add, int op_select, hipStream_t s) {
-        DevMem dense, present, outv, touched, chunk;
+        // workspace kept with the plan: [dense v | present bitmap | out values | touched flags | chunk counts]
+        const uint   words    = (n_in + 31u) / 32u;
+        const uint   n_chunks = (n_out + 1023u) / 1024u;
+        const size_t need     = sizeof(uint) * ((size_t) n_in + words + 2 * (size_t) n_out + n_chunks + 8);
+        if (plan->ws_bytes < need) {
+            if (plan->d_ws) (void) hipFree(plan->d_ws);
+            plan->d_ws = nullptr, plan->ws_bytes = 0;
+            SPLAHIP_TRY(hipMalloc(&plan->d_ws, need));
+            plan->ws_bytes = need;
+        }
+        uint* ws_dense   = static_cast<uint*>(plan->d_ws);
+        uint* ws_present = ws_dense + n_in;
+        uint* ws_outv    = ws_present + words;
+        uint* ws_touched = ws_outv + n_out;
+        uint* ws_chunk   = ws_touched + n_out;
+
         const uint* d_present = nullptr;
         const T*    d_v       = static_cast<const T*>(vx);
         if (!v_is_identity) {
-            const uint words = (n_in + 31u) / 32u;
-            SPLAHIP_TRY(dense.alloc(sizeof(uint) * (size_t) n_in));
-            SPLAHIP_TRY(present.alloc(sizeof(uint) * (size_t) words));
-            SPLAHIP_TRY(hipMemsetAsync(present.p, 0, sizeof(uint) * (size_t) words, s));
+            SPLAHIP_TRY(hipMemsetAsync(ws_present, 0, sizeof(uint) * (size_t) words, s));
             if (nvals)
                 hipLaunchKernelGGL(scatter_present_kernel, dim3((nvals + 255) / 256), dim3(256), 0, s, nvals, vi,
-                                   static_cast<const uint*>(vx), dense.as<uint>(), present.as<uint>());
-            d_present = present.as<uint>();
-            d_v       = dense.as<T>();
+                                   static_cast<const uint*>(vx), ws_dense, ws_present);
+            d_present = ws_present;
+            d_v       = reinterpret_cast<const T*>(ws_dense);
         }
-        SPLAHIP_TRY(outv.alloc(sizeof(uint) * (size_t) n_out));
-        SPLAHIP_TRY(touched.alloc(sizeof(uint) * (size_t) n_out));
         if (((reinterpret_cast<uintptr_t>(Tj) | reinterpret_cast<uintptr_t>(Tx)) & 15u) != 0)
             return fail(SPLAHIP_INVALID_ARGUMENT, "the transposed CSR arrays must be 16-byte aligned");
         const uint grid   = (plan->n_items + Cfg::kWaves - 1) / Cfg::kWaves;
         if (plan->n_items) {
             hipLaunchKernelGGL((spmv_wavetile_kernel<Cfg, T, Mult, Add, true>), dim3(grid), dim3(Cfg::kTpb), 0, s,
                                plan->d_item_row, plan->d_item_k0, plan->n_items, Tp, Tj, static_cast<const uint*>(Tx),
-                               static_cast<const T*>(mask), d_v, d_present, outv.as<T>(), touched.as<uint>(),
+                               static_cast<const T*>(mask), d_v, d_present, reinterpret_cast<T*>(ws_outv), ws_touched,
                                reinterpret_cast<T*>(plan->d_partial), plan->d_partial_ok, Mult(op_mult), Add(op_add), op_select,
                                T(0), plan->nnz);
             if (plan->n_long > 0)
                 hipLaunchKernelGGL((spmv_combine_kernel<Cfg, T, Add, true>), dim3((plan->n_items + 255) / 256), dim3(256), 0, s,
-                                   plan->d_item_row, plan->d_item_k0, plan->n_items, Tp, static_cast<const T*>(mask), outv.as<T>(),
-                                   touched.as<uint>(), reinterpret_cast<const T*>(plan->d_partial), plan->d_partial_ok, Add(op_add),
+                                   plan->d_item_row, plan->d_item_k0, plan->n_items, Tp, static_cast<const T*>(mask), reinterpret_cast<T*>(ws_outv),
+                                   ws_touched, reinterpret_cast<const T*>(plan->d_partial), plan->d_partial_ok, Add(op_add),
                                    op_select, T(0));
         }
         SPLAHIP_TRY(hipGetLastError());
         // compaction of the touched columns, ascending
-        const uint n_chunks = (n_out + 1023u) / 1024u;
-        SPLAHIP_TRY(chunk.alloc(sizeof(uint) * (size_t) (n_chunks + 1)));
-        hipLaunchKernelGGL(flag_count_kernel, dim3(n_chunks), dim3(256), 0, s, touched.as<uint>(), n_out, chunk.as<uint>());
-        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk.as<uint>(), n_chunks);
-        hipLaunchKernelGGL(flag_write_kernel, dim3(n_chunks), dim3(256), 0, s, touched.as<uint>(), outv.as<uint>(), n_out, chunk.as<uint>(),
-                           ri, static_cast<uint*>(rx));
+        hipLaunchKernelGGL(flag_count_kernel, dim3(n_chunks), dim3(256), 0, s, ws_touched, n_out, ws_chunk);
+        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, ws_chunk, n_chunks);
+        hipLaunchKernelGGL(flag_write_kernel, dim3(n_chunks), dim3(256), 0, s, ws_touched, ws_outv, n_out, ws_chunk, ri, static_cast<uint*>(rx));
         SPLAHIP_TRY(hipGetLastError());
-        SPLAHIP_TRY(hipMemcpyAsync(h_count, chunk.as<uint>() + n_chunks, sizeof(uint), hipMemcpyDeviceToHost, s));
+        SPLAHIP_TRY(hipMemcpyAsync(h_count, ws_chunk + n_chunks, sizeof(uint), hipMemcpyDeviceToHost, s));
         SPLAHIP_TRY(hipStreamSynchronize(s));
         return SPLAHIP_OK;
     }
