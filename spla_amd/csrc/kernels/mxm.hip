@@ -25,6 +25,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <algorithm>
 #include <vector>
 
 namespace splahip {
@@ -513,66 +514,77 @@ namespace splahip {
             }
             pieces.clear();
         };
-        u64  total_products = 0;
-        uint total_out      = 0;
-        int  status         = SPLAHIP_OK;
-        uint r0             = 0;
-        while (r0 < a_rows && status == SPLAHIP_OK) {
+        // row blocks: [r0, r1) with at most block_products products (a single row may exceed it)
+        struct Block {
+            uint r0, r1, e0, n_entries, n_products;
+        };
+        std::vector<Block> blocks;
+        u64                total_products = 0;
+        uint               max_entries = 0, max_products = 0;
+        for (uint r0 = 0; r0 < a_rows;) {
             u64  prod = 0;
             uint r1   = r0;
             while (r1 < a_rows && (r1 == r0 || prod + h_rowprod[r1] <= block_products)) prod += h_rowprod[r1++];
             total_products += prod;
-            if (prod > 0xFFFFFFF0ull) {
-                status = fail(SPLAHIP_INVALID_ARGUMENT, "a single row expands to %llu products (> 2^32)", prod);
-                break;
+            if (prod > 0xFFFFFFF0ull) return fail(SPLAHIP_INVALID_ARGUMENT, "a single row expands to %llu products (> 2^32)", prod);
+            if (prod > 0) {
+                blocks.push_back({r0, r1, h_Ap[r0], h_Ap[r1] - h_Ap[r0], (uint) prod});
+                max_entries  = std::max(max_entries, h_Ap[r1] - h_Ap[r0]);
+                max_products = std::max(max_products, (uint) prod);
             }
-            const uint e0 = h_Ap[r0], n_entries = h_Ap[r1] - h_Ap[r0], n_products = (uint) prod;
             r0 = r1;
-            if (n_products == 0) continue;
-
+        }
+        // one workspace for every block (allocating and freeing GB-sized buffers per block dominated the first version)
+        DevBuf len, offs, chunk, key_a, key_b, val_a, val_b, tmp, head, run_rank, run_key, run_val, run_keep, lcount, lpos, keep_rank;
+        size_t tmp_bytes = 0;
+        const uint end_bit = 32 + bit_width(a_rows);
+        (void) b_cols;
+        if (!blocks.empty()) {
+            const size_t np1 = (size_t) max_products + 1;
+            SPLAHIP_TRY(len.alloc(sizeof(uint) * (size_t) max_entries));
+            SPLAHIP_TRY(offs.alloc(sizeof(uint) * ((size_t) max_entries + 1)));
+            SPLAHIP_TRY(chunk.alloc(sizeof(uint) * ((size_t) (max_entries + 1023u) / 1024u + 2)));
+            SPLAHIP_TRY(key_a.alloc(sizeof(u64) * (size_t) max_products));
+            SPLAHIP_TRY(key_b.alloc(sizeof(u64) * (size_t) max_products));
+            SPLAHIP_TRY(val_a.alloc(sizeof(uint) * (size_t) max_products));
+            SPLAHIP_TRY(val_b.alloc(sizeof(uint) * (size_t) max_products));
+            SPLAHIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_a.as<u64>(), key_b.as<u64>(), val_a.as<uint>(), val_b.as<uint>(),
+                                                  max_products, 0, end_bit, s));
+            SPLAHIP_TRY(tmp.alloc(tmp_bytes));
+            SPLAHIP_TRY(head.alloc(sizeof(uint) * (size_t) max_products));
+            SPLAHIP_TRY(run_rank.alloc(sizeof(uint) * np1));
+            SPLAHIP_TRY(run_key.alloc(sizeof(u64) * (size_t) max_products));
+            SPLAHIP_TRY(run_val.alloc(sizeof(uint) * (size_t) max_products));
+            SPLAHIP_TRY(run_keep.alloc(sizeof(uint) * (size_t) max_products));
+            SPLAHIP_TRY(lcount.alloc(sizeof(uint)));
+            SPLAHIP_TRY(lpos.alloc(sizeof(uint) * ((size_t) max_products / kRunShortMxm + 1)));
+            SPLAHIP_TRY(keep_rank.alloc(sizeof(uint) * np1));
+        }
+        uint total_out = 0;
+        int  status    = SPLAHIP_OK;
+        for (const Block& blk : blocks) {
+            const uint e0 = blk.e0, n_entries = blk.n_entries, n_products = blk.n_products;
             auto run_block = [&]() -> int {
-                DevBuf len, offs, chunk, key_a, key_b, val_a, val_b, tmp, head, run_rank, run_key, run_val, run_keep, lcount, lpos, keep_rank;
-                SPLAHIP_TRY(len.alloc(sizeof(uint) * (size_t) n_entries));
-                SPLAHIP_TRY(offs.alloc(sizeof(uint) * ((size_t) n_entries + 1)));
                 const uint n_chunks = (n_entries + 1023u) / 1024u;
-                SPLAHIP_TRY(chunk.alloc(sizeof(uint) * ((size_t) n_chunks + 1)));
                 hipLaunchKernelGGL(mxm_len_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, s, e0, n_entries, Aj, Bp, len.as<uint>());
                 hipLaunchKernelGGL(len_sum_kernel, dim3(n_chunks), dim3(256), 0, s, len.as<uint>(), n_entries, chunk.as<uint>());
                 hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk.as<uint>(), n_chunks);
                 hipLaunchKernelGGL(len_scan_kernel, dim3(n_chunks), dim3(256), 0, s, len.as<uint>(), n_entries, chunk.as<uint>(), n_chunks, offs.as<uint>());
-                SPLAHIP_TRY(hipGetLastError());
-                SPLAHIP_TRY(key_a.alloc(sizeof(u64) * (size_t) n_products));
-                SPLAHIP_TRY(key_b.alloc(sizeof(u64) * (size_t) n_products));
-                SPLAHIP_TRY(val_a.alloc(sizeof(uint) * (size_t) n_products));
-                SPLAHIP_TRY(val_b.alloc(sizeof(uint) * (size_t) n_products));
                 hipLaunchKernelGGL((mxm_expand_kernel<T, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, n_products, e0, n_entries,
                                    offs.as<uint>(), a_rows, Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), DynBin(op_mult),
                                    key_a.as<u64>(), val_a.as<T>());
                 SPLAHIP_TRY(hipGetLastError());
                 // stable sort by (row, column): equal keys keep the expand order = the reference's fold order
-                size_t     tmp_bytes = 0;
-                const uint end_bit   = 32 + bit_width(a_rows);
-                const uint col_bits  = bit_width(b_cols);
-                (void) col_bits;
-                SPLAHIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_a.as<u64>(), key_b.as<u64>(), val_a.as<uint>(), val_b.as<uint>(),
-                                                      n_products, 0, end_bit, s));
-                SPLAHIP_TRY(tmp.alloc(tmp_bytes));
-                SPLAHIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, key_a.as<u64>(), key_b.as<u64>(), val_a.as<uint>(), val_b.as<uint>(),
+                size_t tb = tmp_bytes;
+                SPLAHIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, key_a.as<u64>(), key_b.as<u64>(), val_a.as<uint>(), val_b.as<uint>(),
                                                       n_products, 0, end_bit, s));
                 // runs
-                SPLAHIP_TRY(head.alloc(sizeof(uint) * (size_t) n_products));
-                SPLAHIP_TRY(run_rank.alloc(sizeof(uint) * ((size_t) n_products + 1)));
                 hipLaunchKernelGGL(mxm_head_kernel, dim3((n_products + 255) / 256), dim3(256), 0, s, key_b.as<u64>(), n_products, head.as<uint>());
                 SPLAHIP_TRY(flags_exclusive_rank(head.as<uint>(), n_products, run_rank.as<uint>(), s));
                 uint n_runs = 0;
                 SPLAHIP_TRY(hipMemcpyAsync(&n_runs, run_rank.as<uint>() + n_products, sizeof(uint), hipMemcpyDeviceToHost, s));
-                SPLAHIP_TRY(hipStreamSynchronize(s));
-                SPLAHIP_TRY(run_key.alloc(sizeof(u64) * (size_t) n_runs));
-                SPLAHIP_TRY(run_val.alloc(sizeof(uint) * (size_t) n_runs));
-                SPLAHIP_TRY(run_keep.alloc(sizeof(uint) * (size_t) n_runs));
-                SPLAHIP_TRY(lcount.alloc(sizeof(uint)));
-                SPLAHIP_TRY(lpos.alloc(sizeof(uint) * ((size_t) n_products / kRunShortMxm + 1)));
                 SPLAHIP_TRY(hipMemsetAsync(lcount.p, 0, sizeof(uint), s));
+                SPLAHIP_TRY(hipStreamSynchronize(s));
                 hipLaunchKernelGGL((mxm_run_kernel<T, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, key_b.as<u64>(), val_b.as<T>(), n_products,
                                    head.as<uint>(), run_rank.as<uint>(), run_key.as<u64>(), run_val.as<T>(), run_keep.as<uint>(), lcount.as<uint>(),
                                    lpos.as<uint>(), DynBin(op_add), init);
@@ -591,7 +603,6 @@ namespace splahip {
                     SPLAHIP_TRY(hipGetLastError());
                 }
                 // drop == init, compact
-                SPLAHIP_TRY(keep_rank.alloc(sizeof(uint) * ((size_t) n_runs + 1)));
                 SPLAHIP_TRY(flags_exclusive_rank(run_keep.as<uint>(), n_runs, keep_rank.as<uint>(), s));
                 uint n_out = 0;
                 SPLAHIP_TRY(hipMemcpyAsync(&n_out, keep_rank.as<uint>() + n_runs, sizeof(uint), hipMemcpyDeviceToHost, s));
@@ -611,6 +622,7 @@ namespace splahip {
                 return SPLAHIP_OK;
             };
             status = run_block();
+            if (status != SPLAHIP_OK) break;
         }
         if (status != SPLAHIP_OK) {
             free_pieces();
