@@ -383,6 +383,13 @@ namespace spla {
                            ref_ptr<OpBinary> op_multiply, ref_ptr<OpBinary> op_add, ref_ptr<OpSelect> op_select, ref_ptr<Scalar> init,
                            ref_ptr<Descriptor> desc = ref_ptr<Descriptor>(), ref_ptr<ScheduleTask>* task_hnd = nullptr);
 
+    // ---- the vector operations of a traversal step (reference include/spla/exec.hpp:423-453,515-519) ----
+    Status exec_v_eadd_fdb(ref_ptr<Vector> r, ref_ptr<Vector> v, ref_ptr<Vector> fdb, ref_ptr<OpBinary> op,
+                           ref_ptr<Descriptor> desc = ref_ptr<Descriptor>(), ref_ptr<ScheduleTask>* task_hnd = nullptr);
+    Status exec_v_assign_masked(ref_ptr<Vector> r, ref_ptr<Vector> mask, ref_ptr<Scalar> value, ref_ptr<OpBinary> op_assign, ref_ptr<OpSelect> op_select,
+                                ref_ptr<Descriptor> desc = ref_ptr<Descriptor>(), ref_ptr<ScheduleTask>* task_hnd = nullptr);
+    Status exec_v_count_mf(ref_ptr<Scalar> r, ref_ptr<Vector> v, ref_ptr<Descriptor> desc = ref_ptr<Descriptor>(), ref_ptr<ScheduleTask>* task_hnd = nullptr);
+
     // ---- library ------------------------------------------------------------------------------------------------------------
     class Library final {
     public:

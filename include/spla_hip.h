@@ -137,6 +137,21 @@ int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols,
                 uint32_t* d_Rp, uint32_t** d_Rj, void** d_Rx, uint32_t* h_nnz, uint64_t* h_products,
                 int op_mult, int op_add, uint32_t init_bits, uint64_t block_products, void* stream);
 
+/* ---- vector operations between two hot-path calls of a traversal --------------------------------
+ * v_assign_masked: r[i] = assign(r[i], value) where select(mask[i]); dense mask (n words) or sparse mask (nvals pairs)
+ *                  (reference src/cpu/cpu_v_assign.hpp:68-132).
+ * v_count_mf     : number of entries != fill of a dense vector, returned on the host (reference cpu_v_count_mf.hpp:99-108).
+ * v_eadd_fdb     : r[i] = op(r[i], v[i]); the feedback vector receives the entries that changed: dense form fdb[i] = changed ?
+ *                  r[i] : fdb_fill; sparse form (v = nvals pairs, each index at most once) appends (i, r[i]) in v's stored
+ *                  order, count returned on the host (reference src/cpu/cpu_v_eadd_fdb.hpp:71-139).                       */
+int splahip_v_assign_masked_dense(int type, uint32_t n, void* d_r, const void* d_mask, uint32_t value_bits, int op_assign, int op_select, void* stream);
+int splahip_v_assign_masked_sparse(int type, uint32_t nvals, void* d_r, const uint32_t* d_mi, const void* d_mx, uint32_t value_bits, int op_assign,
+                                   int op_select, void* stream);
+int splahip_v_count_mf_dense(int type, uint32_t n, const void* d_v, uint32_t fill_bits, uint32_t* h_count, void* stream);
+int splahip_v_eadd_fdb_dense(int type, uint32_t n, void* d_r, const void* d_v, void* d_fdb, uint32_t fdb_fill_bits, int op, void* stream);
+int splahip_v_eadd_fdb_sparse(int type, uint32_t nvals, void* d_r, const uint32_t* d_vi, const void* d_vx, uint32_t* d_fi, void* d_fx,
+                              uint32_t* h_count, int op, void* stream);
+
 /* ---- accelerator vector formats ------------------------------------------------------------------------------
  * AccDense <-> AccCoo (reference src/opencl/cl_format_dense_vec.hpp:90-143, cl_format_coo_vec.hpp:149-158).
  * dense_to_coo keeps the entries != fill in ascending index order (d_idx / d_val need room for n entries) and

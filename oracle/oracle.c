@@ -252,3 +252,50 @@ void oracle_mxmT_masked(int type, uint32_t n_rows,
     *Rj = out.j;
     *Rx = out.x;
 }
+
+/* reference src/cpu/cpu_v_assign.hpp:104-132 (dense mask) and :68-102 (sparse mask, stored order) */
+void oracle_v_assign_dense(int type, uint32_t n, uint32_t* r, const uint32_t* mask, uint32_t value, int op_assign, int op_select) {
+    const binfn assign = k_bin[type][op_assign];
+    const selfn sel    = k_sel[type][op_select];
+    for (uint32_t i = 0; i < n; ++i)
+        if (sel(mask[i])) r[i] = assign(r[i], value);
+}
+void oracle_v_assign_sparse(int type, uint32_t nvals, uint32_t* r, const uint32_t* mi, const uint32_t* mx, uint32_t value, int op_assign, int op_select) {
+    const binfn assign = k_bin[type][op_assign];
+    const selfn sel    = k_sel[type][op_select];
+    for (uint32_t k = 0; k < nvals; ++k)
+        if (sel(mx[k])) r[mi[k]] = assign(r[mi[k]], value);
+}
+
+/* reference src/cpu/cpu_v_eadd_fdb.hpp:107-139 (dense) and :71-105 (sparse) */
+void oracle_v_eadd_fdb_dense(int type, uint32_t n, uint32_t* r, const uint32_t* v, uint32_t* fdb, uint32_t fdb_fill, int op) {
+    const binfn f = k_bin[type][op];
+    for (uint32_t i = 0; i < n; ++i) {
+        const word prev = r[i];
+        r[i]            = f(prev, v[i]);
+        fdb[i]          = neq(type, prev, r[i]) ? r[i] : fdb_fill;
+    }
+}
+uint32_t oracle_v_eadd_fdb_sparse(int type, uint32_t nvals, uint32_t* r, const uint32_t* vi, const uint32_t* vx, uint32_t* fi, uint32_t* fx, int op) {
+    const binfn f     = k_bin[type][op];
+    uint32_t    count = 0;
+    for (uint32_t k = 0; k < nvals; ++k) {
+        const uint32_t i    = vi[k];
+        const word     prev = r[i];
+        r[i]                = f(prev, vx[k]);
+        if (neq(type, prev, r[i])) {
+            fi[count] = i;
+            fx[count] = r[i];
+            ++count;
+        }
+    }
+    return count;
+}
+
+/* reference src/cpu/cpu_v_count_mf.hpp:99-108 */
+uint32_t oracle_v_count_mf_dense(int type, uint32_t n, const uint32_t* v, uint32_t fill) {
+    uint32_t count = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        if (neq(type, v[i], fill)) ++count;
+    return count;
+}

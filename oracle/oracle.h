@@ -72,6 +72,16 @@ void oracle_mxmT_masked(int type, uint32_t n_rows,
                         uint32_t* Rp, uint32_t** Rj, uint32_t** Rx,
                         int op_mult, int op_add, int op_select, uint32_t init);
 
+/* ---- the vector operations of a traversal step ---- */
+/* r[i] = assign(r[i], value) where select(mask[i]): dense mask / sparse mask in stored order.  reference src/cpu/cpu_v_assign.hpp:68-132 */
+void oracle_v_assign_dense(int type, uint32_t n, uint32_t* r, const uint32_t* mask, uint32_t value, int op_assign, int op_select);
+void oracle_v_assign_sparse(int type, uint32_t nvals, uint32_t* r, const uint32_t* mi, const uint32_t* mx, uint32_t value, int op_assign, int op_select);
+/* r[i] = op(r[i], v[i]) with feedback of the changed entries.  reference src/cpu/cpu_v_eadd_fdb.hpp:71-139 */
+void     oracle_v_eadd_fdb_dense(int type, uint32_t n, uint32_t* r, const uint32_t* v, uint32_t* fdb, uint32_t fdb_fill, int op);
+uint32_t oracle_v_eadd_fdb_sparse(int type, uint32_t nvals, uint32_t* r, const uint32_t* vi, const uint32_t* vx, uint32_t* fi, uint32_t* fx, int op);
+/* entries != fill of a dense vector.  reference src/cpu/cpu_v_count_mf.hpp:99-108 */
+uint32_t oracle_v_count_mf_dense(int type, uint32_t n, const uint32_t* v, uint32_t fill);
+
 void oracle_free(void* p);
 
 #ifdef __cplusplus

@@ -93,7 +93,51 @@ class Oracle:
         lib.oracle_mxmT_masked.argtypes = [C.c_int, C.c_uint32] + [_u32p] * 10 + [C.POINTER(_u32p)] * 2 + [C.c_int, C.c_int, C.c_int, C.c_uint32]
         lib.oracle_free.restype = None
         lib.oracle_free.argtypes = [C.c_void_p]
+        lib.oracle_v_assign_dense.restype = None
+        lib.oracle_v_assign_dense.argtypes = [C.c_int, C.c_uint32, _u32p, _u32p, C.c_uint32, C.c_int, C.c_int]
+        lib.oracle_v_assign_sparse.restype = None
+        lib.oracle_v_assign_sparse.argtypes = [C.c_int, C.c_uint32, _u32p, _u32p, _u32p, C.c_uint32, C.c_int, C.c_int]
+        lib.oracle_v_eadd_fdb_dense.restype = None
+        lib.oracle_v_eadd_fdb_dense.argtypes = [C.c_int, C.c_uint32, _u32p, _u32p, _u32p, C.c_uint32, C.c_int]
+        lib.oracle_v_eadd_fdb_sparse.restype = C.c_uint32
+        lib.oracle_v_eadd_fdb_sparse.argtypes = [C.c_int, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, C.c_int]
+        lib.oracle_v_count_mf_dense.restype = C.c_uint32
+        lib.oracle_v_count_mf_dense.argtypes = [C.c_int, C.c_uint32, _u32p, C.c_uint32]
         self.lib = lib
+
+    # ---- vector operations of a traversal step: inputs are numpy arrays, r is returned as a new array
+    def v_assign_masked(self, t, r, mask, value, op_assign, op_select, mask_idx=None):
+        """dense mask (mask = n values) or sparse mask (mask_idx given: mask = the stored values)."""
+        t = _tid(t)
+        r = words(r, t).copy()
+        if mask_idx is None:
+            self.lib.oracle_v_assign_dense(t, len(r), _p(r), _p(words(mask, t)), bits(value, t), _bid(op_assign), _sid(op_select))
+        else:
+            mi = words(mask_idx)
+            self.lib.oracle_v_assign_sparse(t, len(mi), _p(r), _p(mi), _p(words(mask, t)), bits(value, t), _bid(op_assign), _sid(op_select))
+        return r.view(TYPE_NP[t])
+
+    def v_eadd_fdb(self, t, r, v, op, fdb_fill=0, v_idx=None):
+        """returns (r_new, fdb): fdb is a dense array (dense v) or an (indices, values) pair (sparse v: v_idx given)."""
+        t = _tid(t)
+        r = words(r, t).copy()
+        if v_idx is None:
+            fdb = np.empty(len(r), np.uint32)
+            self.lib.oracle_v_eadd_fdb_dense(t, len(r), _p(r), _p(words(v, t)), _p(fdb), bits(fdb_fill, t), _bid(op))
+            return r.view(TYPE_NP[t]), fdb.view(TYPE_NP[t])
+        vi = words(v_idx)
+        fi, fx = np.empty(max(len(vi), 1), np.uint32), np.empty(max(len(vi), 1), np.uint32)
+        n = self.lib.oracle_v_eadd_fdb_sparse(t, len(vi), _p(r), _p(vi), _p(words(v, t)), _p(fi), _p(fx), _bid(op))
+        return r.view(TYPE_NP[t]), (fi[:n].copy(), fx[:n].copy().view(TYPE_NP[t]))
+
+    def v_count_mf(self, t, v, fill=0, idx=None, n=None):
+        """dense vector: entries != fill; sparse vector (idx given): its stored count, explicit zeros included
+        (reference src/cpu/cpu_v_count_mf.hpp:77,88)."""
+        t = _tid(t)
+        if idx is not None:
+            return len(idx)
+        v = words(v, t)
+        return int(self.lib.oracle_v_count_mf_dense(t, len(v), _p(v), bits(fill, t)))
 
     def binop(self, t, op, a, b):
         t = _tid(t)
@@ -259,6 +303,83 @@ class Reference:
         Rx = np.empty(max(n, 1), np.uint32)
         self._ok(self.lib.refshim_matrix_lil_read(h, _p(Rp), _p(Rj), _p(Rx)), "lil_read")
         return Rp, Rj[:n].copy(), Rx[:n].copy().view(TYPE_NP[t])
+
+    # ---- the vector operations of a traversal step (through the reference's own C ABI) -----------------------------
+    def _sparse_vector(self, t, n, idx, val):
+        h = self._empty_vector(t, n)
+        idx, val = words(idx), words(val, t)
+        k1, k2 = self._view(idx), self._view(val)
+        self._ok(self.lib.spla_Vector_build(h, k1, k2), "Vector_build")
+        self._unref(k1, k2)
+        return h
+
+    def _read_coo(self, h, t):
+        rk, rv = C.c_void_p(), C.c_void_p()
+        self._ok(self.lib.spla_Vector_read(h, C.byref(rk), C.byref(rv)), "Vector_read")
+        buf, size = C.c_void_p(), C.c_size_t()
+        self.lib.spla_MemView_get_buffer(rk, C.byref(buf))
+        self.lib.spla_MemView_get_size(rk, C.byref(size))
+        n = size.value // 4
+        ri = np.ctypeslib.as_array(C.cast(buf, _u32p), shape=(n,)).copy() if n else np.empty(0, np.uint32)
+        self.lib.spla_MemView_get_buffer(rv, C.byref(buf))
+        rx = np.ctypeslib.as_array(C.cast(buf, _u32p), shape=(n,)).copy() if n else np.empty(0, np.uint32)
+        self._unref(rk, rv)
+        return ri, rx.view(TYPE_NP[t])
+
+    def _read_dense(self, h, n, t):
+        out = np.empty(n, np.uint32)
+        self._ok(self.lib.refshim_vector_dense_read(h, _p(out)), "dense_read")
+        return out.view(TYPE_NP[t])
+
+    def v_assign_masked(self, t, r, mask, value, op_assign, op_select, mask_idx=None):
+        t = _tid(t)
+        n = len(r)
+        self.lib.spla_Exec_v_assign_masked.argtypes = [C.c_void_p] * 7
+        hr = self._dense_vector(t, r)
+        hm = self._dense_vector(t, mask) if mask_idx is None else self._sparse_vector(t, n, mask_idx, mask)
+        hv = self._scalar(value, t)
+        self._ok(self.lib.spla_Exec_v_assign_masked(hr, hm, hv, self._op("Binary", BINOPS[_bid(op_assign)], t),
+                                                    self._op("Select", SELOPS[_sid(op_select)], t), None, None), "Exec_v_assign_masked")
+        out = self._read_dense(hr, n, t)
+        self._unref(hr, hm, hv)
+        return out
+
+    def v_eadd_fdb(self, t, r, v, op, fdb_fill=0, v_idx=None):
+        t = _tid(t)
+        n = len(r)
+        self.lib.spla_Exec_v_eadd_fdb.argtypes = [C.c_void_p] * 6
+        self.lib.spla_Vector_set_fill_value.argtypes = [C.c_void_p, C.c_void_p]
+        hr = self._dense_vector(t, r)
+        hv = self._dense_vector(t, v) if v_idx is None else self._sparse_vector(t, n, v_idx, v)
+        hf = self._empty_vector(t, n)
+        hs = self._scalar(fdb_fill, t)
+        self.lib.spla_Vector_set_fill_value(hf, hs)
+        self._ok(self.lib.spla_Exec_v_eadd_fdb(hr, hv, hf, self._op("Binary", BINOPS[_bid(op)], t), None, None), "Exec_v_eadd_fdb")
+        r_new = self._read_dense(hr, n, t)
+        fdb = self._read_dense(hf, n, t) if v_idx is None else self._read_coo(hf, t)
+        self._unref(hr, hv, hf, hs)
+        return r_new, fdb
+
+    def v_count_mf(self, t, v, fill=0, idx=None, n=None):
+        """dense vector (v = n values) or sparse (idx given): the reference answers with the stored count for sparse formats."""
+        t = _tid(t)
+        self.lib.spla_Exec_v_count_mf.argtypes = [C.c_void_p] * 4
+        self.lib.spla_Scalar_get_uint.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+        self.lib.spla_Vector_set_fill_value.argtypes = [C.c_void_p, C.c_void_p]
+        if idx is None:
+            hv = self._empty_vector(t, len(v))
+            hs = self._scalar(fill, t)
+            self.lib.spla_Vector_set_fill_value(hv, hs)
+            self._ok(self.lib.refshim_vector_dense_write(hv, _p(words(v, t))), "dense_write")
+            self._unref(hs)
+        else:
+            hv = self._sparse_vector(t, n, idx, v)
+        hr = self._scalar(0, 1)
+        self._ok(self.lib.spla_Exec_v_count_mf(hr, hv, None, None), "Exec_v_count_mf")
+        out = C.c_uint()
+        self.lib.spla_Scalar_get_uint(hr, C.byref(out))
+        self._unref(hr, hv)
+        return int(out.value)
 
     # ---- the four operations ----------------------------------------------------------------------------------
     def mxv_masked(self, t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, init, early_exit=False):

@@ -49,6 +49,7 @@ def c_symbols():
              "spla_Matrix_make", "spla_Matrix_set_format", "spla_Matrix_set_fill_value", "spla_Matrix_set_reduce", "spla_Matrix_set_int", "spla_Matrix_set_uint",
              "spla_Matrix_set_float", "spla_Matrix_get_int", "spla_Matrix_get_uint", "spla_Matrix_get_float", "spla_Matrix_build", "spla_Matrix_read", "spla_Matrix_clear",
              "spla_Exec_mxm", "spla_Exec_mxmT_masked", "spla_Exec_mxv_masked", "spla_Exec_vxm_masked",
+             "spla_Exec_v_eadd_fdb", "spla_Exec_v_assign_masked", "spla_Exec_v_count_mf",
              "spla_Descriptor_make", "spla_Descriptor_set_early_exit", "spla_Descriptor_set_struct_only"]
     for op in BINARY_OPS:
         for t in ("INT", "UINT") + (() if op in BITWISE else ("FLOAT",)):
@@ -119,6 +120,9 @@ def _c():
         lib.spla_Exec_mxmT_masked.argtypes = [_vp] * 9 + [C.POINTER(_vp)]
         lib.spla_Exec_mxv_masked.argtypes = [_vp] * 9 + [C.POINTER(_vp)]
         lib.spla_Exec_vxm_masked.argtypes = [_vp] * 9 + [C.POINTER(_vp)]
+        lib.spla_Exec_v_eadd_fdb.argtypes = [_vp] * 5 + [C.POINTER(_vp)]
+        lib.spla_Exec_v_assign_masked.argtypes = [_vp] * 6 + [C.POINTER(_vp)]
+        lib.spla_Exec_v_count_mf.argtypes = [_vp] * 3 + [C.POINTER(_vp)]
         lib.spla_Descriptor_make.argtypes = [C.POINTER(_vp)]
         lib.spla_Descriptor_set_early_exit.argtypes = [_vp, C.c_int]
         lib.spla_Descriptor_set_struct_only.argtypes = [_vp, C.c_int]
@@ -351,6 +355,26 @@ class Vector(Object):
         for i in range(shape):
             v.set(i, fill_value)
         return v
+
+    def assign(self, mask, value, op_assign, op_select, desc=None):
+        """self[i] = op_assign(self[i], value) where op_select(mask[i]) (reference python/pyspla/vector.py:640-683)."""
+        if not isinstance(value, Scalar):
+            value = Scalar(self.dtype, value)
+        _check(_c().spla_Exec_v_assign_masked(self.hnd, mask.hnd, value.hnd, op_assign.hnd, op_select.hnd, _desc(desc), None), "spla_Exec_v_assign_masked")
+        return self
+
+    def eadd_fdb(self, v, op, fdb=None, desc=None):
+        """self[i] = op(self[i], v[i]); returns the feedback vector holding the entries that changed (reference exec_v_eadd_fdb)."""
+        if fdb is None:
+            fdb = Vector(self.n_rows, self.dtype)
+        _check(_c().spla_Exec_v_eadd_fdb(self.hnd, v.hnd, fdb.hnd, op.hnd, _desc(desc), None), "spla_Exec_v_eadd_fdb")
+        return fdb
+
+    def count_mf(self, desc=None) -> int:
+        """number of stored (sparse formats) / non-fill (dense formats) entries (reference exec_v_count_mf)."""
+        out = Scalar(UINT, 0)
+        _check(_c().spla_Exec_v_count_mf(out.hnd, self.hnd, _desc(desc), None), "spla_Exec_v_count_mf")
+        return int(out.get())
 
     def vxm(self, mask, M, op_mult, op_add, op_select, out=None, init=None, desc=None):
         """r = self^T x M over (op_mult, op_add), columns selected by mask (reference python/pyspla/vector.py:476-546)."""

@@ -269,6 +269,106 @@ namespace spla {
             }
         };
 
+        // ---- vector operations of a traversal step.  Format choice follows the reference's CPU algorithms: a sparse operand is used
+        //      as sparse when it is the valid format, else dense (cpu_v_assign.hpp:59-64, cpu_v_eadd_fdb.hpp:60-67, cpu_v_count_mf.hpp:59-66)
+        template<typename T>
+        bool coo_valid(TVector<T>* v) { return v->is_valid(FormatVector::CpuCoo) || v->is_valid(FormatVector::AccCoo); }
+        template<typename T>
+        bool dense_valid(TVector<T>* v) { return v->is_valid(FormatVector::CpuDense) || v->is_valid(FormatVector::AccDense); }
+
+        template<typename T>
+        class Algo_v_assign_masked_hip final : public RegistryAlgo {
+        public:
+            std::string get_name() override { return "v_assign_masked"; }
+            std::string get_description() override { return "masked scalar assign into a dense vector"; }
+            Status      execute(const DispatchContext& ctx) override {
+                auto t     = ctx.task.template cast_safe<ScheduleTask_v_assign_masked>();
+                auto r     = t->r.template cast_safe<TVector<T>>();
+                auto mask  = t->mask.template cast_safe<TVector<T>>();
+                auto value = t->value.template cast_safe<TScalar<T>>();
+                const int op_assign = device_binop<T>(t->op_assign);
+                const int op_sel    = device_selop<T>(t->op_select);
+                if (op_assign < 0 || op_sel < 0) return Status::NotImplemented;
+                if (r->get_n_rows() != mask->get_n_rows()) return Status::InvalidArgument;
+                // sparse mask when its COO is valid, dense when only its dense image is, sparse otherwise (cpu_v_assign.hpp:59-64):
+                // the two forms differ on absent entries (the dense form applies op_select to the fill value)
+                const bool sparse = coo_valid(mask.get()) || !dense_valid(mask.get());
+                r->validate_rwd(FormatVector::AccDense);
+                if (sparse) {
+                    mask->validate_rw(FormatVector::AccCoo);
+                    auto* m = mask->acc_coo();
+                    hip_check(splahip_v_assign_masked_sparse(TypeTraits<T>::id, m->values, r->acc_dense()->Ax.ptr(), m->Ai.template as<uint32_t>(), m->Ax.ptr(),
+                                                             word_of(value->get_value()), op_assign, op_sel, nullptr),
+                              "splahip_v_assign_masked_sparse");
+                } else {
+                    mask->validate_rw(FormatVector::AccDense);
+                    hip_check(splahip_v_assign_masked_dense(TypeTraits<T>::id, r->get_n_rows(), r->acc_dense()->Ax.ptr(), mask->acc_dense()->Ax.ptr(),
+                                                            word_of(value->get_value()), op_assign, op_sel, nullptr),
+                              "splahip_v_assign_masked_dense");
+                }
+                return Status::Ok;
+            }
+        };
+
+        template<typename T>
+        class Algo_v_eadd_fdb_hip final : public RegistryAlgo {
+        public:
+            std::string get_name() override { return "v_eadd_fdb"; }
+            std::string get_description() override { return "element-wise add into a dense vector with feedback of the changed entries"; }
+            Status      execute(const DispatchContext& ctx) override {
+                auto t   = ctx.task.template cast_safe<ScheduleTask_v_eadd_fdb>();
+                auto r   = t->r.template cast_safe<TVector<T>>();
+                auto v   = t->v.template cast_safe<TVector<T>>();
+                auto fdb = t->fdb.template cast_safe<TVector<T>>();
+                const int op = device_binop<T>(t->op);
+                if (op < 0) return Status::NotImplemented;
+                if (r->get_n_rows() != v->get_n_rows() || r->get_n_rows() != fdb->get_n_rows()) return Status::InvalidArgument;
+                // sp2dn when r is dense and v's COO is valid, dn2dn when both are dense, sp2dn otherwise (cpu_v_eadd_fdb.hpp:60-67)
+                const bool r_dense = dense_valid(r.get());
+                const bool sparse  = (r_dense && coo_valid(v.get())) || !(r_dense && dense_valid(v.get()));
+                r->validate_rwd(FormatVector::AccDense);
+                if (sparse) {
+                    v->validate_rw(FormatVector::AccCoo);
+                    fdb->validate_wd(FormatVector::AccCoo);
+                    auto *   in = v->acc_coo(), *out = fdb->acc_coo();
+                    uint32_t count = 0;
+                    out->Ai.reserve(in->values);
+                    out->Ax.reserve(in->values);
+                    hip_check(splahip_v_eadd_fdb_sparse(TypeTraits<T>::id, in->values, r->acc_dense()->Ax.ptr(), in->Ai.template as<uint32_t>(), in->Ax.ptr(),
+                                                        out->Ai.template as<uint32_t>(), out->Ax.ptr(), &count, op, nullptr),
+                              "splahip_v_eadd_fdb_sparse");
+                    out->values = count;
+                } else {
+                    v->validate_rw(FormatVector::AccDense);
+                    fdb->validate_wd(FormatVector::AccDense);
+                    hip_check(splahip_v_eadd_fdb_dense(TypeTraits<T>::id, r->get_n_rows(), r->acc_dense()->Ax.ptr(), v->acc_dense()->Ax.ptr(),
+                                                       fdb->acc_dense()->Ax.ptr(), word_of(fdb->get_fill_value()), op, nullptr),
+                              "splahip_v_eadd_fdb_dense");
+                }
+                return Status::Ok;
+            }
+        };
+
+        template<typename T>
+        class Algo_v_count_mf_hip final : public RegistryAlgo {
+        public:
+            std::string get_name() override { return "v_count_mf"; }
+            std::string get_description() override { return "count of stored / non-fill entries"; }
+            Status      execute(const DispatchContext& ctx) override {
+                auto t = ctx.task.template cast_safe<ScheduleTask_v_count_mf>();
+                auto v = t->v.template cast_safe<TVector<T>>();
+                // a sparse format that is valid answers with its stored count, explicit zeros included (cpu_v_count_mf.hpp:77,88)
+                if (v->is_valid(FormatVector::CpuDok)) return t->r->set_uint(v->dok()->values);
+                if (v->is_valid(FormatVector::CpuCoo)) return t->r->set_uint(v->coo()->values);
+                if (v->is_valid(FormatVector::AccCoo)) return t->r->set_uint(v->acc_coo()->values);
+                v->validate_rw(FormatVector::AccDense);
+                uint32_t count = 0;
+                hip_check(splahip_v_count_mf_dense(TypeTraits<T>::id, v->get_n_rows(), v->acc_dense()->Ax.ptr(), word_of(v->get_fill_value()), &count, nullptr),
+                          "splahip_v_count_mf_dense");
+                return t->r->set_uint(count);
+            }
+        };
+
         template<template<typename> class Algo>
         void add3(Registry* g, const std::string& name) {
             g->add(name + "_I__hip", std::make_shared<Algo<T_INT>>());
@@ -282,6 +382,9 @@ namespace spla {
         add3<Algo_vxm_masked_hip>(g, "vxm_masked");
         add3<Algo_mxmT_masked_hip>(g, "mxmT_masked");
         add3<Algo_mxm_hip>(g, "mxm");
+        add3<Algo_v_assign_masked_hip>(g, "v_assign_masked");
+        add3<Algo_v_eadd_fdb_hip>(g, "v_eadd_fdb");
+        add3<Algo_v_count_mf_hip>(g, "v_count_mf");
     }
 
 }// namespace spla

@@ -156,6 +156,16 @@ spla_Status spla_Exec_vxm_masked(spla_Vector r, spla_Vector mask, spla_Vector v,
     SPLA_C_EXEC(exec_vxm_masked(as_ref<Vector>(r), as_ref<Vector>(mask), as_ref<Vector>(v), as_ref<Matrix>(M), as_ref<OpBinary>(op_multiply), as_ref<OpBinary>(op_add), as_ref<OpSelect>(op_select), as_ref<Scalar>(init), as_ref<Descriptor>(desc), p_hnd))
 }
 
+spla_Status spla_Exec_v_eadd_fdb(spla_Vector r, spla_Vector v, spla_Vector fdb, spla_OpBinary op, spla_Descriptor desc, spla_ScheduleTask* task) {
+    SPLA_C_EXEC(exec_v_eadd_fdb(as_ref<Vector>(r), as_ref<Vector>(v), as_ref<Vector>(fdb), as_ref<OpBinary>(op), as_ref<Descriptor>(desc), p_hnd))
+}
+spla_Status spla_Exec_v_assign_masked(spla_Vector r, spla_Vector mask, spla_Scalar value, spla_OpBinary op_assign, spla_OpSelect op_select, spla_Descriptor desc, spla_ScheduleTask* task) {
+    SPLA_C_EXEC(exec_v_assign_masked(as_ref<Vector>(r), as_ref<Vector>(mask), as_ref<Scalar>(value), as_ref<OpBinary>(op_assign), as_ref<OpSelect>(op_select), as_ref<Descriptor>(desc), p_hnd))
+}
+spla_Status spla_Exec_v_count_mf(spla_Scalar r, spla_Vector v, spla_Descriptor desc, spla_ScheduleTask* task) {
+    SPLA_C_EXEC(exec_v_count_mf(as_ref<Scalar>(r), as_ref<Vector>(v), as_ref<Descriptor>(desc), p_hnd))
+}
+
 spla_Status spla_Descriptor_make(spla_Descriptor* desc) { return give(desc, Descriptor::make()); }
 spla_Status spla_Descriptor_set_early_exit(spla_Descriptor desc, spla_bool value) {
     if (!desc) return SPLA_STATUS_INVALID_ARGUMENT;

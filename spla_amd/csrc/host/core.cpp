@@ -481,4 +481,38 @@ namespace spla {
         return run_or_return(task.as<ScheduleTask>(), task_hnd);
     }
 
+    Status exec_v_eadd_fdb(ref_ptr<Vector> r, ref_ptr<Vector> v, ref_ptr<Vector> fdb, ref_ptr<OpBinary> op, ref_ptr<Descriptor> desc,
+                           ref_ptr<ScheduleTask>* task_hnd) {
+        if (!r || !v || !fdb || !op) return Status::InvalidArgument;
+        auto task  = ref_ptr<ScheduleTask_v_eadd_fdb>(new ScheduleTask_v_eadd_fdb());
+        task->r    = std::move(r);
+        task->v    = std::move(v);
+        task->fdb  = std::move(fdb);
+        task->op   = std::move(op);
+        task->desc = std::move(desc);
+        return run_or_return(task.as<ScheduleTask>(), task_hnd);
+    }
+
+    Status exec_v_assign_masked(ref_ptr<Vector> r, ref_ptr<Vector> mask, ref_ptr<Scalar> value, ref_ptr<OpBinary> op_assign, ref_ptr<OpSelect> op_select,
+                                ref_ptr<Descriptor> desc, ref_ptr<ScheduleTask>* task_hnd) {
+        if (!r || !mask || !value || !op_assign || !op_select) return Status::InvalidArgument;
+        auto task       = ref_ptr<ScheduleTask_v_assign_masked>(new ScheduleTask_v_assign_masked());
+        task->r         = std::move(r);
+        task->mask      = std::move(mask);
+        task->value     = std::move(value);
+        task->op_assign = std::move(op_assign);
+        task->op_select = std::move(op_select);
+        task->desc      = std::move(desc);
+        return run_or_return(task.as<ScheduleTask>(), task_hnd);
+    }
+
+    Status exec_v_count_mf(ref_ptr<Scalar> r, ref_ptr<Vector> v, ref_ptr<Descriptor> desc, ref_ptr<ScheduleTask>* task_hnd) {
+        if (!r || !v) return Status::InvalidArgument;
+        auto task  = ref_ptr<ScheduleTask_v_count_mf>(new ScheduleTask_v_count_mf());
+        task->r    = std::move(r);
+        task->v    = std::move(v);
+        task->desc = std::move(desc);
+        return run_or_return(task.as<ScheduleTask>(), task_hnd);
+    }
+
 }// namespace spla

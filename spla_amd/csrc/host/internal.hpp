@@ -274,4 +274,32 @@ namespace spla {
         ref_ptr<Scalar>              init;
     };
 
+    // vector operations of a traversal step (reference src/schedule/schedule_tasks.hpp: ScheduleTask_v_eadd_fdb / v_assign_masked / v_count_mf)
+    class ScheduleTask_v_eadd_fdb final : public TaskBase {
+    public:
+        std::string                  get_name() override { return "v_eadd_fdb"; }
+        std::string                  get_key() override { return "v_eadd_fdb_" + r->get_type()->get_code(); }
+        std::vector<ref_ptr<Object>> get_args() override { return {r.as<Object>(), v.as<Object>(), fdb.as<Object>(), op.as<Object>()}; }
+        ref_ptr<Vector>              r, v, fdb;
+        ref_ptr<OpBinary>            op;
+    };
+    class ScheduleTask_v_assign_masked final : public TaskBase {
+    public:
+        std::string                  get_name() override { return "v_assign_masked"; }
+        std::string                  get_key() override { return "v_assign_masked_" + r->get_type()->get_code(); }
+        std::vector<ref_ptr<Object>> get_args() override { return {r.as<Object>(), mask.as<Object>(), value.as<Object>(), op_assign.as<Object>(), op_select.as<Object>()}; }
+        ref_ptr<Vector>              r, mask;
+        ref_ptr<Scalar>              value;
+        ref_ptr<OpBinary>            op_assign;
+        ref_ptr<OpSelect>            op_select;
+    };
+    class ScheduleTask_v_count_mf final : public TaskBase {
+    public:
+        std::string                  get_name() override { return "v_count_mf"; }
+        std::string                  get_key() override { return "v_count_mf_" + v->get_type()->get_code(); }
+        std::vector<ref_ptr<Object>> get_args() override { return {r.as<Object>(), v.as<Object>()}; }
+        ref_ptr<Scalar>              r;
+        ref_ptr<Vector>              v;
+    };
+
 }// namespace spla
