@@ -327,3 +327,15 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
     }
 }
 }
+
+#ifdef SPLAHIP_PHASE_TIMING
+// DIAGNOSTIC BUILD ONLY: copy out (reset != 0: and clear) the per-item phase ticks of mxv_kernels.hpp, 4 x 2^18 words
+extern "C" int splahip_debug_phase(unsigned int* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(splahip::g_phase), sizeof(unsigned int) * 4 * (1 << 18)) != hipSuccess) return SPLAHIP_ERROR;
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(splahip::g_phase)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned int) * 4 * (1 << 18)) != hipSuccess) return SPLAHIP_ERROR;
+    }
+    return SPLAHIP_OK;
+}
+#endif

@@ -16,6 +16,17 @@
 
 namespace splahip {
 
+#ifdef SPLAHIP_PHASE_TIMING
+    // DIAGNOSTIC BUILD ONLY (tools/exp/exp_phase.py): where a run item's wave spends its life.  Summed s_memtime deltas
+    // between fully drained points: [0] header, [1] entry stream + Ap, [2] gathers, [3] LDS stage + fold + stores, [4] items
+    static __device__ unsigned int g_phase[4][1 << 18];// per item, no atomics (contention would dominate)
+#define SPLAHIP_STAMP(t)                                         \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    t = __builtin_amdgcn_s_memtime();
+#else
+#define SPLAHIP_STAMP(t)
+#endif
+
     struct MxvCfg {
         static constexpr uint kWin      = 512; // nnz window that defines a run item
         static constexpr uint kLongT    = 508; // rows longer than this are cut into segment items
@@ -231,6 +242,10 @@ namespace splahip {
         const uint w    = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
         const uint item = blockIdx.x * C::kWaves + w;
         if (item >= n_items) return;
+#ifdef SPLAHIP_PHASE_TIMING
+        unsigned long long t_begin = 0, t_header = 0, t_stream = 0, t_gather = 0, t_end = 0;
+#endif
+        SPLAHIP_STAMP(t_begin)
 
         const uint e0  = item_row[item];
         const uint e1  = item_row[item + 1];
@@ -239,6 +254,7 @@ namespace splahip {
         const uint row = e0 & ~C::kSegFlag;
         const uint a0  = k0 & ~3u;                        // 16-byte aligned origin of the entry slice
         const uint nq  = k1 > a0 ? (k1 - a0 + 3) >> 2 : 0;// quads in the slice, <= 256
+        SPLAHIP_STAMP(t_header)
 
         if (e0 & C::kSegFlag) {
             // ---------------- segment item: a <= kSeg-entry piece of the long row `row`
@@ -360,6 +376,18 @@ namespace splahip {
                     if (act[u]) load_quad(Aj, Ax, a0 + 4 * qi, nnz, jq[u], xq[u]);
                 }
             }
+            SPLAHIP_STAMP(t_stream)
+#ifdef SPLAHIP_PHASE_TIMING
+            T vv_all[4][4];
+#pragma unroll
+            for (uint u = 0; u < 4; ++u)
+                if (act[u]) {
+                    const uint jj[4] = {jq[u].x, jq[u].y, jq[u].z, jq[u].w};
+#pragma unroll
+                    for (uint e = 0; e < 4; ++e) vv_all[u][e] = gather_load(v + jj[e]);
+                }
+            SPLAHIP_STAMP(t_gather)
+#endif
 #pragma unroll
             for (uint u = 0; u < 4; ++u) {
                 const uint qi = lane + u * kWave;
@@ -368,7 +396,11 @@ namespace splahip {
                     const uint xx[4] = {xq[u].x, xq[u].y, xq[u].z, xq[u].w};
                     T          vv[4];
 #pragma unroll
+#ifdef SPLAHIP_PHASE_TIMING
+                    for (uint e = 0; e < 4; ++e) vv[e] = vv_all[u][e];
+#else
                     for (uint e = 0; e < 4; ++e) vv[e] = gather_load(v + jj[e]);
+#endif
                     Quad<T> p;
 #pragma unroll
                     for (uint e = 0; e < 4; ++e) p.e[e] = entry_product<VXM>(mult, xx[e], vv[e]);
@@ -453,6 +485,16 @@ namespace splahip {
                 }
             }
         }
+#ifdef SPLAHIP_PHASE_TIMING
+        SPLAHIP_STAMP(t_end)
+        if (lane == 0) {
+            const uint slot = item & ((1u << 18) - 1u);
+            g_phase[0][slot] = (uint) (t_header - t_begin);
+            g_phase[1][slot] = (uint) (t_stream - t_header);
+            g_phase[2][slot] = (uint) (t_gather - t_stream);
+            g_phase[3][slot] = (uint) (t_end - t_gather);
+        }
+#endif
     }
 
     // finish rows made of several segment items: strict in-order fold of their partials
