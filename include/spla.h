@@ -180,10 +180,23 @@ SPLA_API spla_Status spla_Exec_v_eadd_fdb(spla_Vector r, spla_Vector v, spla_Vec
 SPLA_API spla_Status spla_Exec_v_assign_masked(spla_Vector r, spla_Vector mask, spla_Scalar value, spla_OpBinary op_assign, spla_OpSelect op_select, spla_Descriptor desc, spla_ScheduleTask* task);
 SPLA_API spla_Status spla_Exec_v_count_mf(spla_Scalar r, spla_Vector v, spla_Descriptor desc, spla_ScheduleTask* task);
 
+/* ---- PageRank step remainder and triangle-count tail (reference include/spla.h:378,382,387) ---- */
+SPLA_API spla_Status spla_Exec_m_reduce(spla_Scalar r, spla_Scalar s, spla_Matrix M, spla_OpBinary op_reduce, spla_Descriptor desc, spla_ScheduleTask* task);
+SPLA_API spla_Status spla_Exec_v_eadd(spla_Vector r, spla_Vector u, spla_Vector v, spla_OpBinary op, spla_Descriptor desc, spla_ScheduleTask* task);
+SPLA_API spla_Status spla_Exec_v_reduce(spla_Scalar r, spla_Scalar s, spla_Vector v, spla_OpBinary op_reduce, spla_Descriptor desc, spla_ScheduleTask* task);
+
+/* ---- graph algorithms (reference include/spla.h:360-363); descriptor may be NULL = defaults (push-pull, front factor 0.1) ---- */
+SPLA_API spla_Status spla_Algorithm_bfs(spla_Vector v, spla_Matrix A, spla_uint s, spla_Descriptor descriptor);
+SPLA_API spla_Status spla_Algorithm_sssp(spla_Vector v, spla_Matrix A, spla_uint s, spla_Descriptor descriptor);
+SPLA_API spla_Status spla_Algorithm_pr(spla_Vector* p, spla_Matrix A, float alpha, float eps, spla_Descriptor descriptor);
+SPLA_API spla_Status spla_Algorithm_tc(int* ntrins, spla_Matrix A, spla_Matrix B, spla_Descriptor descriptor);
+
 /* ---- extension: descriptors from C ---- */
 SPLA_API spla_Status spla_Descriptor_make(spla_Descriptor* desc);
 SPLA_API spla_Status spla_Descriptor_set_early_exit(spla_Descriptor desc, spla_bool value);
 SPLA_API spla_Status spla_Descriptor_set_struct_only(spla_Descriptor desc, spla_bool value);
+SPLA_API spla_Status spla_Descriptor_set_traversal_mode(spla_Descriptor desc, int mode); /* 0 push, 1 pull, 2 push-pull */
+SPLA_API spla_Status spla_Descriptor_set_front_factor(spla_Descriptor desc, float value);
 
 #if defined(__cplusplus)
 }

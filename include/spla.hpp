@@ -390,6 +390,20 @@ namespace spla {
                                 ref_ptr<Descriptor> desc = ref_ptr<Descriptor>(), ref_ptr<ScheduleTask>* task_hnd = nullptr);
     Status exec_v_count_mf(ref_ptr<Scalar> r, ref_ptr<Vector> v, ref_ptr<Descriptor> desc = ref_ptr<Descriptor>(), ref_ptr<ScheduleTask>* task_hnd = nullptr);
 
+    // ---- PageRank step remainder and triangle-count tail (reference include/spla/exec.hpp:297-303,381-387,489-495) ----
+    Status exec_v_eadd(ref_ptr<Vector> r, ref_ptr<Vector> u, ref_ptr<Vector> v, ref_ptr<OpBinary> op,
+                       ref_ptr<Descriptor> desc = ref_ptr<Descriptor>(), ref_ptr<ScheduleTask>* task_hnd = nullptr);
+    Status exec_v_reduce(ref_ptr<Scalar> r, ref_ptr<Scalar> s, ref_ptr<Vector> v, ref_ptr<OpBinary> op_reduce,
+                         ref_ptr<Descriptor> desc = ref_ptr<Descriptor>(), ref_ptr<ScheduleTask>* task_hnd = nullptr);
+    Status exec_m_reduce(ref_ptr<Scalar> r, ref_ptr<Scalar> s, ref_ptr<Matrix> M, ref_ptr<OpBinary> op_reduce,
+                         ref_ptr<Descriptor> desc = ref_ptr<Descriptor>(), ref_ptr<ScheduleTask>* task_hnd = nullptr);
+
+    // ---- graph algorithms over exec_* (reference include/spla/algorithm.hpp:54-68,86-101,120-137,157-170) ----
+    Status bfs(const ref_ptr<Vector>& v, const ref_ptr<Matrix>& A, uint s, const ref_ptr<Descriptor>& descriptor);
+    Status sssp(const ref_ptr<Vector>& v, const ref_ptr<Matrix>& A, uint s, const ref_ptr<Descriptor>& descriptor);
+    Status pr(ref_ptr<Vector>& p, const ref_ptr<Matrix>& A, float alpha, float eps, const ref_ptr<Descriptor>& descriptor);
+    Status tc(int& ntrins, const ref_ptr<Matrix>& A, const ref_ptr<Matrix>& B, const ref_ptr<Descriptor>& descriptor);
+
     // ---- library ------------------------------------------------------------------------------------------------------------
     class Library final {
     public:

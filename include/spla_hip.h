@@ -152,6 +152,19 @@ int splahip_v_eadd_fdb_dense(int type, uint32_t n, void* d_r, const void* d_v, v
 int splahip_v_eadd_fdb_sparse(int type, uint32_t nvals, void* d_r, const uint32_t* d_vi, const void* d_vx, uint32_t* d_fi, void* d_fx,
                               uint32_t* h_count, int op, void* stream);
 
+/* ---- the PageRank step remainder and the triangle-count tail -------------------------------
+ * v_eadd: r = op(u, v) element-wise.  dense: every index (reference src/cpu/cpu_v_eadd.hpp:133-155).  sparse: the sorted merge
+ * of two index-sorted COO vectors without duplicate indices; an index held by one side only meets the other side's fill
+ * value (cpu_v_eadd.hpp:96-127); d_ri / d_rx need room for nu + nv entries; the count returns on the host (blocks).
+ * reduce: *h_result_bits = fold of d_x[0..n) from s with op — exec_v_reduce over a vector's stored values
+ * (src/cpu/cpu_v_reduce.hpp:69-117) and exec_m_reduce over a CSR's Ax (src/cpu/cpu_m_reduce.hpp:134-156).  Associative and
+ * commutative ops use a fixed reduction tree (fp32 PLUS / MULT then differ from the sequential fold by rounding only);
+ * every other op is folded strictly left to right.  Blocks until the result is on the host.                          */
+int splahip_v_eadd_dense(int type, uint32_t n, void* d_r, const void* d_u, const void* d_v, int op, void* stream);
+int splahip_v_eadd_sparse(int type, uint32_t nu, const uint32_t* d_ui, const void* d_ux, uint32_t u_fill_bits, uint32_t nv, const uint32_t* d_vi,
+                          const void* d_vx, uint32_t v_fill_bits, uint32_t* d_ri, void* d_rx, uint32_t* h_count, int op, void* stream);
+int splahip_reduce(int type, uint32_t n, const void* d_x, uint32_t s_bits, uint32_t* h_result_bits, int op, void* stream);
+
 /* ---- accelerator vector formats ------------------------------------------------------------------------------
  * AccDense <-> AccCoo (reference src/opencl/cl_format_dense_vec.hpp:90-143, cl_format_coo_vec.hpp:149-158).
  * dense_to_coo keeps the entries != fill in ascending index order (d_idx / d_val need room for n entries) and

@@ -299,3 +299,49 @@ uint32_t oracle_v_count_mf_dense(int type, uint32_t n, const uint32_t* v, uint32
         if (neq(type, v[i], fill)) ++count;
     return count;
 }
+
+/* reference src/cpu/cpu_v_eadd.hpp:133-155 (dense x dense) */
+void oracle_v_eadd_dense(int type, uint32_t n, uint32_t* r, const uint32_t* u, const uint32_t* v, int op) {
+    const binfn f = k_bin[type][op];
+    for (uint32_t i = 0; i < n; ++i) r[i] = f(u[i], v[i]);
+}
+/* reference src/cpu/cpu_v_eadd.hpp:70-131 (sparse x sparse): the two-pointer merge of two index-sorted lists; an index held by
+ * one side only meets the other side's fill value.  ri / rx need room for nu + nv entries; returns the entry count. */
+uint32_t oracle_v_eadd_sparse(int type, uint32_t nu, const uint32_t* ui, const uint32_t* ux, uint32_t u_fill, uint32_t nv, const uint32_t* vi,
+                              const uint32_t* vx, uint32_t v_fill, uint32_t* ri, uint32_t* rx, int op) {
+    const binfn f = k_bin[type][op];
+    uint32_t    a = 0, b = 0, n = 0;
+    while (a < nu && b < nv) {
+        if (ui[a] < vi[b]) {
+            ri[n] = ui[a];
+            rx[n] = f(ux[a], v_fill);
+            ++a;
+        } else if (vi[b] < ui[a]) {
+            ri[n] = vi[b];
+            rx[n] = f(u_fill, vx[b]);
+            ++b;
+        } else {
+            ri[n] = ui[a];
+            rx[n] = f(ux[a], vx[b]);
+            ++a;
+            ++b;
+        }
+        ++n;
+    }
+    for (; a < nu; ++a, ++n) {
+        ri[n] = ui[a];
+        rx[n] = f(ux[a], v_fill);
+    }
+    for (; b < nv; ++b, ++n) {
+        ri[n] = vi[b];
+        rx[n] = f(u_fill, vx[b]);
+    }
+    return n;
+}
+/* reference src/cpu/cpu_v_reduce.hpp:69-117 and src/cpu/cpu_m_reduce.hpp:134-156: strict left fold of the stored values from s */
+uint32_t oracle_reduce(int type, uint32_t n, const uint32_t* x, uint32_t s, int op) {
+    const binfn f   = k_bin[type][op];
+    word        sum = s;
+    for (uint32_t i = 0; i < n; ++i) sum = f(sum, x[i]);
+    return sum;
+}

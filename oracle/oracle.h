@@ -82,6 +82,14 @@ uint32_t oracle_v_eadd_fdb_sparse(int type, uint32_t nvals, uint32_t* r, const u
 /* entries != fill of a dense vector.  reference src/cpu/cpu_v_count_mf.hpp:99-108 */
 uint32_t oracle_v_count_mf_dense(int type, uint32_t n, const uint32_t* v, uint32_t fill);
 
+/* ---- PageRank step remainder and triangle-count tail ---- */
+/* r = op(u, v): dense, and the merge of two index-sorted sparse vectors.  reference src/cpu/cpu_v_eadd.hpp:70-155 */
+void     oracle_v_eadd_dense(int type, uint32_t n, uint32_t* r, const uint32_t* u, const uint32_t* v, int op);
+uint32_t oracle_v_eadd_sparse(int type, uint32_t nu, const uint32_t* ui, const uint32_t* ux, uint32_t u_fill, uint32_t nv, const uint32_t* vi,
+                              const uint32_t* vx, uint32_t v_fill, uint32_t* ri, uint32_t* rx, int op);
+/* strict left fold of x[0..n) from s.  reference src/cpu/cpu_v_reduce.hpp:69-117, src/cpu/cpu_m_reduce.hpp:134-156 */
+uint32_t oracle_reduce(int type, uint32_t n, const uint32_t* x, uint32_t s, int op);
+
 void oracle_free(void* p);
 
 #ifdef __cplusplus

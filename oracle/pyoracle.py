@@ -103,6 +103,12 @@ class Oracle:
         lib.oracle_v_eadd_fdb_sparse.argtypes = [C.c_int, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, C.c_int]
         lib.oracle_v_count_mf_dense.restype = C.c_uint32
         lib.oracle_v_count_mf_dense.argtypes = [C.c_int, C.c_uint32, _u32p, C.c_uint32]
+        lib.oracle_v_eadd_dense.restype = None
+        lib.oracle_v_eadd_dense.argtypes = [C.c_int, C.c_uint32, _u32p, _u32p, _u32p, C.c_int]
+        lib.oracle_v_eadd_sparse.restype = C.c_uint32
+        lib.oracle_v_eadd_sparse.argtypes = [C.c_int, C.c_uint32, _u32p, _u32p, C.c_uint32, C.c_uint32, _u32p, _u32p, C.c_uint32, _u32p, _u32p, C.c_int]
+        lib.oracle_reduce.restype = C.c_uint32
+        lib.oracle_reduce.argtypes = [C.c_int, C.c_uint32, _u32p, C.c_uint32, C.c_int]
         self.lib = lib
 
     # ---- vector operations of a traversal step: inputs are numpy arrays, r is returned as a new array
@@ -138,6 +144,92 @@ class Oracle:
             return len(idx)
         v = words(v, t)
         return int(self.lib.oracle_v_count_mf_dense(t, len(v), _p(v), bits(fill, t)))
+
+    # ---- PageRank step remainder / triangle-count tail
+    def v_eadd(self, t, u, v, op, u_idx=None, v_idx=None, u_fill=0, v_fill=0):
+        """dense x dense (u, v = n values) -> n values; sparse x sparse (u_idx, v_idx given, both index-sorted) -> (indices, values)."""
+        t = _tid(t)
+        if u_idx is None:
+            u, v = words(u, t), words(v, t)
+            r = np.empty(len(u), np.uint32)
+            self.lib.oracle_v_eadd_dense(t, len(u), _p(r), _p(u), _p(v), _bid(op))
+            return r.view(TYPE_NP[t])
+        ui, vi = words(u_idx), words(v_idx)
+        cap = max(len(ui) + len(vi), 1)
+        ri, rx = np.empty(cap, np.uint32), np.empty(cap, np.uint32)
+        n = self.lib.oracle_v_eadd_sparse(t, len(ui), _p(ui), _p(words(u, t)), bits(u_fill, t), len(vi), _p(vi), _p(words(v, t)), bits(v_fill, t),
+                                          _p(ri), _p(rx), _bid(op))
+        return ri[:n].copy(), rx[:n].copy().view(TYPE_NP[t])
+
+    def reduce(self, t, x, op, s=0):
+        """strict left fold of x from s: exec_v_reduce over a vector's stored values, exec_m_reduce over a CSR's values."""
+        t = _tid(t)
+        x = words(x, t)
+        out = self.lib.oracle_reduce(t, len(x), _p(x), bits(s, t), _bid(op))
+        return np.array([out], np.uint32).view(TYPE_NP[t])[0]
+
+    # ---- the graph algorithms, restated over the oracle's own operations (reference src/algorithm.cpp:45-120,158-229,278-335,380-414)
+    def bfs(self, n, Ap, Aj, s, pull=False):
+        """levels from 1 at the source, 0 = unreached.  push walks rows of the frontier (edge i -> j at A[i, j]); pull tests, per
+        unvisited row i, whether any A[i, j] has j in the frontier (the reference's mxv form: edge j -> i)."""
+        Ap, Aj = np.asarray(Ap, np.int64), np.asarray(Aj, np.int64)
+        depth = np.zeros(n, np.int32)
+        front = np.zeros(n, bool)
+        front[s] = True
+        level = 1
+        rows = np.repeat(np.arange(n), np.diff(Ap))
+        while front.any():
+            depth[front] = level
+            if pull:
+                hit = np.zeros(n, bool)
+                hit[rows[front[Aj]]] = True
+            else:
+                hit = np.zeros(n, bool)
+                hit[Aj[front[rows]]] = True
+            front = hit & (depth == 0)
+            level += 1
+        return depth
+
+    def sssp(self, n, Ap, Aj, Ax, s):
+        """fp32 Bellman-Ford to the fixed point, unreachable = FLT_MAX; every candidate is fl(dist[i] + w) as in the reference's min-plus."""
+        Ap, Aj, Ax = np.asarray(Ap, np.int64), np.asarray(Aj, np.int64), np.asarray(Ax, np.float32)
+        inf = np.float32(np.finfo(np.float32).max)
+        dist = np.full(n, inf, np.float32)
+        dist[s] = 0
+        rows = np.repeat(np.arange(n), np.diff(Ap))
+        changed = np.zeros(n, bool)
+        changed[s] = True
+        while changed.any():
+            act = changed[rows]
+            with np.errstate(over="ignore"):
+                cand = (dist[rows[act]] + Ax[act]).astype(np.float32)
+            relaxed = np.full(n, inf, np.float32)
+            np.minimum.at(relaxed, Aj[act], cand)
+            new = np.minimum(dist, relaxed)
+            changed = new != dist
+            dist = new
+        return dist
+
+    def pr(self, n, Ap, Aj, Ax, alpha, eps):
+        """the reference's power iteration step for step, every step through the oracle's own operations"""
+        zeros = np.zeros(n, np.float32)
+        prev = np.full(n, np.float32(1.0) / np.float32(n), np.float32)
+        tele = np.full(n, (np.float32(1.0) - np.float32(alpha)) / np.float32(n), np.float32)
+        p = zeros
+        err = np.float32(eps) + np.float32(0.1)
+        while err > np.float32(eps):
+            prod = self.mxv_masked("FLOAT", n, n, Ap, Aj, Ax, zeros, prev, "MULT", "PLUS", "ALWAYS", 0.0)
+            p = self.v_eadd("FLOAT", prod, tele, "PLUS")
+            d2 = self.v_eadd("FLOAT", p, prev, "MINUS_POW2")
+            err = np.sqrt(self.reduce("FLOAT", d2, "PLUS", 0.0))
+            p, prev = prev, p
+        return prev
+
+    def tc(self, n, Lp, Lj):
+        ones = np.ones(len(Lj), np.int32)
+        L = (Lp, Lj, ones)
+        Bp, Bj, Bx = self.mxmT_masked("INT", n, L, L, L, "MULT", "PLUS", "GTZERO", 0)
+        return int(self.reduce("INT", Bx, "PLUS", 0)), (Bp, Bj, Bx)
 
     def binop(self, t, op, a, b):
         t = _tid(t)
@@ -305,8 +397,13 @@ class Reference:
         return Rp, Rj[:n].copy(), Rx[:n].copy().view(TYPE_NP[t])
 
     # ---- the vector operations of a traversal step (through the reference's own C ABI) -----------------------------
-    def _sparse_vector(self, t, n, idx, val):
+    def _sparse_vector(self, t, n, idx, val, fill=None):
         h = self._empty_vector(t, n)
+        if fill is not None:  # before build: set_fill_value drops the content (reference src/core/tvector.hpp:131-140)
+            self.lib.spla_Vector_set_fill_value.argtypes = [C.c_void_p, C.c_void_p]
+            hs = self._scalar(fill, t)
+            self.lib.spla_Vector_set_fill_value(h, hs)
+            self._unref(hs)
         idx, val = words(idx), words(val, t)
         k1, k2 = self._view(idx), self._view(val)
         self._ok(self.lib.spla_Vector_build(h, k1, k2), "Vector_build")
@@ -380,6 +477,105 @@ class Reference:
         self.lib.spla_Scalar_get_uint(hr, C.byref(out))
         self._unref(hr, hv)
         return int(out.value)
+
+    # ---- PageRank step remainder / triangle-count tail and the graph algorithms (through the reference's own C ABI)
+    def _scalar_value(self, h, t):
+        if t == 0:
+            out = C.c_int()
+            self.lib.spla_Scalar_get_int.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+            self.lib.spla_Scalar_get_int(h, C.byref(out))
+            return np.int32(out.value)
+        if t == 1:
+            out = C.c_uint()
+            self.lib.spla_Scalar_get_uint.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+            self.lib.spla_Scalar_get_uint(h, C.byref(out))
+            return np.uint32(out.value)
+        out = C.c_float()
+        self.lib.spla_Scalar_get_float.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        self.lib.spla_Scalar_get_float(h, C.byref(out))
+        return np.float32(out.value)
+
+    def v_eadd(self, t, u, v, op, u_idx=None, v_idx=None, u_fill=0, v_fill=0):
+        t = _tid(t)
+        self.lib.spla_Exec_v_eadd.argtypes = [C.c_void_p] * 6
+        self.lib.spla_Vector_set_fill_value.argtypes = [C.c_void_p, C.c_void_p]
+        if u_idx is None:
+            n = len(u)
+            hu, hv = self._dense_vector(t, u), self._dense_vector(t, v)
+        else:
+            n = int(max(list(u_idx) + list(v_idx) + [0])) + 1
+            hu, hv = self._sparse_vector(t, n, u_idx, u, fill=u_fill), self._sparse_vector(t, n, v_idx, v, fill=v_fill)
+        hr = self._empty_vector(t, n)
+        self._ok(self.lib.spla_Exec_v_eadd(hr, hu, hv, self._op("Binary", BINOPS[_bid(op)], t), None, None), "Exec_v_eadd")
+        out = self._read_dense(hr, n, t) if u_idx is None else self._read_coo(hr, t)
+        self._unref(hr, hu, hv)
+        return out
+
+    def reduce(self, t, x, op, s=0, idx=None, n=None):
+        """exec_v_reduce over a dense vector (x = n values) or a sparse one (idx given: x = its stored values)."""
+        t = _tid(t)
+        self.lib.spla_Exec_v_reduce.argtypes = [C.c_void_p] * 6
+        hv = self._dense_vector(t, x) if idx is None else self._sparse_vector(t, n, idx, x)
+        hs, hr = self._scalar(s, t), self._scalar(0, t)
+        self._ok(self.lib.spla_Exec_v_reduce(hr, hs, hv, self._op("Binary", BINOPS[_bid(op)], t), None, None), "Exec_v_reduce")
+        out = self._scalar_value(hr, t)
+        self._unref(hv, hs, hr)
+        return out
+
+    def m_reduce(self, t, n_rows, n_cols, Ap, Aj, Ax, op, s=0):
+        t = _tid(t)
+        self.lib.spla_Exec_m_reduce.argtypes = [C.c_void_p] * 6
+        M = self._matrix(t, n_rows, n_cols, Ap, Aj, Ax)
+        hs, hr = self._scalar(s, t), self._scalar(0, t)
+        self._ok(self.lib.spla_Exec_m_reduce(hr, hs, M, self._op("Binary", BINOPS[_bid(op)], t), None, None), "Exec_m_reduce")
+        out = self._scalar_value(hr, t)
+        self._unref(M, hs, hr)
+        return out
+
+    def _traversal(self, mode, front_factor):
+        self.lib.refshim_descriptor_make_traversal.restype = C.c_void_p
+        self.lib.refshim_descriptor_make_traversal.argtypes = [C.c_int, C.c_float]
+        return self.lib.refshim_descriptor_make_traversal({"push": 0, "pull": 1, "push_pull": 2}[mode], float(front_factor))
+
+    def bfs(self, n, Ap, Aj, s, mode="push_pull", front_factor=0.1):
+        """spla_Algorithm_bfs on the INT adjacency matrix (values 1); returns the n levels."""
+        self.lib.spla_Algorithm_bfs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
+        A = self._matrix(0, n, n, Ap, Aj, np.ones(len(Aj), np.int32))
+        hv, d = self._empty_vector(0, n), self._traversal(mode, front_factor)
+        self._ok(self.lib.spla_Algorithm_bfs(hv, A, int(s), d), "Algorithm_bfs")
+        out = self._read_dense(hv, n, 0)
+        self._unref(A, hv, d)
+        return out
+
+    def sssp(self, n, Ap, Aj, Ax, s, mode="push_pull", front_factor=0.1):
+        self.lib.spla_Algorithm_sssp.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
+        A = self._matrix(2, n, n, Ap, Aj, Ax)
+        hv, d = self._empty_vector(2, n), self._traversal(mode, front_factor)
+        self._ok(self.lib.spla_Algorithm_sssp(hv, A, int(s), d), "Algorithm_sssp")
+        out = self._read_dense(hv, n, 2)
+        self._unref(A, hv, d)
+        return out
+
+    def pr(self, n, Ap, Aj, Ax, alpha, eps):
+        self.lib.spla_Algorithm_pr.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        A = self._matrix(2, n, n, Ap, Aj, Ax)
+        hp, d = self._empty_vector(2, n), self._traversal("push_pull", 0.1)
+        self._ok(self.lib.spla_Algorithm_pr(C.byref(hp), A, float(alpha), float(eps), d), "Algorithm_pr")
+        out = self._read_dense(hp, n, 2)
+        self._unref(A, hp, d)
+        return out
+
+    def tc(self, n, Lp, Lj):
+        """spla_Algorithm_tc on the strict lower triangle L (INT ones): returns (ntrins, (Bp, Bj, Bx))."""
+        self.lib.spla_Algorithm_tc.argtypes = [C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p]
+        L = self._matrix(0, n, n, Lp, Lj, np.ones(len(Lj), np.int32))
+        B = C.c_void_p()
+        self._ok(self.lib.spla_Matrix_make(C.byref(B), n, n, self._types[0]), "Matrix_make")
+        d, count = self._traversal("push_pull", 0.1), C.c_int(0)
+        self._ok(self.lib.spla_Algorithm_tc(C.byref(count), L, B, d), "Algorithm_tc")
+        out = self._read_lil(B, n, 0)
+        self._unref(L, B, d)
+        return int(count.value), out
 
     # ---- the four operations ----------------------------------------------------------------------------------
     def mxv_masked(self, t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, init, early_exit=False):

@@ -79,6 +79,14 @@ void* refshim_descriptor_make(int early_exit, int struct_only) {
     return d.release();
 }
 
+// Descriptor for the graph algorithms: traversal mode (0 push, 1 pull, 2 push-pull) and the push/pull switch density.
+void* refshim_descriptor_make_traversal(int mode, float front_factor) {
+    auto d = Descriptor::make();
+    d->set_traversal_mode(static_cast<Descriptor::TraversalMode>(mode));
+    d->set_front_factor(front_factor);
+    return d.release();
+}
+
 // Stored entries of a matrix as seen through its LIL rows (robust to the `values` counter bug above).
 uint64_t refshim_matrix_lil_count(void* m) {
     auto*    M = static_cast<Matrix*>(m);

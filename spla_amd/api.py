@@ -50,7 +50,10 @@ def c_symbols():
              "spla_Matrix_set_float", "spla_Matrix_get_int", "spla_Matrix_get_uint", "spla_Matrix_get_float", "spla_Matrix_build", "spla_Matrix_read", "spla_Matrix_clear",
              "spla_Exec_mxm", "spla_Exec_mxmT_masked", "spla_Exec_mxv_masked", "spla_Exec_vxm_masked",
              "spla_Exec_v_eadd_fdb", "spla_Exec_v_assign_masked", "spla_Exec_v_count_mf",
-             "spla_Descriptor_make", "spla_Descriptor_set_early_exit", "spla_Descriptor_set_struct_only"]
+             "spla_Exec_v_eadd", "spla_Exec_v_reduce", "spla_Exec_m_reduce",
+             "spla_Algorithm_bfs", "spla_Algorithm_sssp", "spla_Algorithm_pr", "spla_Algorithm_tc",
+             "spla_Descriptor_make", "spla_Descriptor_set_early_exit", "spla_Descriptor_set_struct_only",
+             "spla_Descriptor_set_traversal_mode", "spla_Descriptor_set_front_factor"]
     for op in BINARY_OPS:
         for t in ("INT", "UINT") + (() if op in BITWISE else ("FLOAT",)):
             names.append(f"spla_OpBinary_{op}_{t}")
@@ -123,6 +126,15 @@ def _c():
         lib.spla_Exec_v_eadd_fdb.argtypes = [_vp] * 5 + [C.POINTER(_vp)]
         lib.spla_Exec_v_assign_masked.argtypes = [_vp] * 6 + [C.POINTER(_vp)]
         lib.spla_Exec_v_count_mf.argtypes = [_vp] * 3 + [C.POINTER(_vp)]
+        lib.spla_Exec_v_eadd.argtypes = [_vp] * 5 + [C.POINTER(_vp)]
+        lib.spla_Exec_v_reduce.argtypes = [_vp] * 5 + [C.POINTER(_vp)]
+        lib.spla_Exec_m_reduce.argtypes = [_vp] * 5 + [C.POINTER(_vp)]
+        lib.spla_Algorithm_bfs.argtypes = [_vp, _vp, C.c_uint, _vp]
+        lib.spla_Algorithm_sssp.argtypes = [_vp, _vp, C.c_uint, _vp]
+        lib.spla_Algorithm_pr.argtypes = [C.POINTER(_vp), _vp, C.c_float, C.c_float, _vp]
+        lib.spla_Algorithm_tc.argtypes = [C.POINTER(C.c_int), _vp, _vp, _vp]
+        lib.spla_Descriptor_set_traversal_mode.argtypes = [_vp, C.c_int]
+        lib.spla_Descriptor_set_front_factor.argtypes = [_vp, C.c_float]
         lib.spla_Descriptor_make.argtypes = [C.POINTER(_vp)]
         lib.spla_Descriptor_set_early_exit.argtypes = [_vp, C.c_int]
         lib.spla_Descriptor_set_struct_only.argtypes = [_vp, C.c_int]
@@ -265,12 +277,18 @@ class Scalar(Object):
 
 
 class Descriptor(Object):
-    def __init__(self, early_exit=False, struct_only=False):
+    PUSH, PULL, PUSH_PULL = 0, 1, 2
+
+    def __init__(self, early_exit=False, struct_only=False, traversal_mode=None, front_factor=None):
         h = _vp()
         _check(_c().spla_Descriptor_make(C.byref(h)), "spla_Descriptor_make")
         super().__init__(h)
         _c().spla_Descriptor_set_early_exit(h, 1 if early_exit else 0)
         _c().spla_Descriptor_set_struct_only(h, 1 if struct_only else 0)
+        if traversal_mode is not None:
+            _check(_c().spla_Descriptor_set_traversal_mode(h, int(traversal_mode)), "spla_Descriptor_set_traversal_mode")
+        if front_factor is not None:
+            _check(_c().spla_Descriptor_set_front_factor(h, float(front_factor)), "spla_Descriptor_set_front_factor")
 
 
 def _desc(desc):
@@ -375,6 +393,23 @@ class Vector(Object):
         out = Scalar(UINT, 0)
         _check(_c().spla_Exec_v_count_mf(out.hnd, self.hnd, _desc(desc), None), "spla_Exec_v_count_mf")
         return int(out.get())
+
+    def eadd(self, v, op, out=None, desc=None):
+        """out = op(self, v) element-wise (reference python/pyspla/vector.py eadd / exec_v_eadd)."""
+        if out is None:
+            out = Vector(self.n_rows, self.dtype)
+        _check(_c().spla_Exec_v_eadd(out.hnd, self.hnd, v.hnd, op.hnd, _desc(desc), None), "spla_Exec_v_eadd")
+        return out
+
+    def reduce(self, op, init=None, desc=None):
+        """fold of the stored values from init (reference python/pyspla/vector.py reduce / exec_v_reduce)."""
+        out = Scalar(self.dtype, 0)
+        if init is None:
+            init = Scalar(self.dtype, 0)
+        elif not isinstance(init, Scalar):
+            init = Scalar(self.dtype, init)
+        _check(_c().spla_Exec_v_reduce(out.hnd, init.hnd, self.hnd, op.hnd, _desc(desc), None), "spla_Exec_v_reduce")
+        return out.get()
 
     def vxm(self, mask, M, op_mult, op_add, op_select, out=None, init=None, desc=None):
         """r = self^T x M over (op_mult, op_add), columns selected by mask (reference python/pyspla/vector.py:476-546)."""
@@ -486,3 +521,45 @@ class Matrix(Object):
         _check(_c().spla_Exec_mxmT_masked(out.hnd, mask.hnd, self.hnd, M.hnd, op_mult.hnd, op_add.hnd, op_select.hnd, init.hnd,
                                           _desc(desc), None), "spla_Exec_mxmT_masked")
         return out
+
+    def reduce(self, op, init=None, desc=None):
+        """fold of the stored values from init (reference python/pyspla/matrix.py reduce / exec_m_reduce)."""
+        out = Scalar(self.dtype, 0)
+        if init is None:
+            init = Scalar(self.dtype, 0)
+        elif not isinstance(init, Scalar):
+            init = Scalar(self.dtype, init)
+        _check(_c().spla_Exec_m_reduce(out.hnd, init.hnd, self.hnd, op.hnd, _desc(desc), None), "spla_Exec_m_reduce")
+        return out.get()
+
+
+# ---- graph algorithms (reference C API include/spla.h:360-363) ----
+def bfs(A: Matrix, s: int, desc=None) -> Vector:
+    """levels from 1 at the source, 0 = unreached; A is the INT adjacency matrix, edges i -> j at A[i, j]."""
+    v = Vector(A.n_rows, INT)
+    _check(_c().spla_Algorithm_bfs(v.hnd, A.hnd, int(s), _desc(desc)), "spla_Algorithm_bfs")
+    return v
+
+
+def sssp(A: Matrix, s: int, desc=None) -> Vector:
+    """shortest path lengths over FLOAT weights; unreachable = FLT_MAX (the result's fill value)."""
+    v = Vector(A.n_rows, FLOAT)
+    _check(_c().spla_Algorithm_sssp(v.hnd, A.hnd, int(s), _desc(desc)), "spla_Algorithm_sssp")
+    return v
+
+
+def pr(A: Matrix, alpha=0.85, eps=1e-6, desc=None) -> Vector:
+    """PageRank by power iteration; A must already hold alpha / outdeg(j) at [i, j] for every edge j -> i."""
+    p = Vector(A.n_rows, FLOAT)
+    h = _vp(p.hnd.value if isinstance(p.hnd, _vp) else p.hnd)
+    _check(_c().spla_Algorithm_pr(C.byref(h), A.hnd, float(alpha), float(eps), _desc(desc)), "spla_Algorithm_pr")
+    p.hnd = h  # the C call consumed the old handle's reference and handed one to the result
+    return p
+
+
+def tc(L: Matrix, desc=None):
+    """triangle count of the graph whose strict lower triangle is L (INT); returns (count, B = (L x L^T) .* L)."""
+    B = Matrix((L.n_rows, L.n_cols), INT)
+    n = C.c_int(0)
+    _check(_c().spla_Algorithm_tc(C.byref(n), L.hnd, B.hnd, _desc(desc)), "spla_Algorithm_tc")
+    return int(n.value), B

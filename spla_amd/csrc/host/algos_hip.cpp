@@ -4,6 +4,8 @@
 // the launches going through the kernel-level C ABI (include/spla_hip.h) instead of JIT-built OpenCL programs.
 #include "storage.hpp"
 
+#include <cstring>
+
 namespace spla {
 
     namespace {
@@ -369,6 +371,107 @@ namespace spla {
             }
         };
 
+        // ---- PageRank step remainder and triangle-count tail
+        template<typename T>
+        T value_of_word(uint32_t w) {
+            T v;
+            std::memcpy(&v, &w, sizeof(T));
+            return v;
+        }
+
+        template<typename T>
+        class Algo_v_eadd_hip final : public RegistryAlgo {
+        public:
+            std::string get_name() override { return "v_eadd"; }
+            std::string get_description() override { return "element-wise add of two vectors (dense x dense, or the sorted merge of two sparse vectors)"; }
+            Status      execute(const DispatchContext& ctx) override {
+                auto t = ctx.task.template cast_safe<ScheduleTask_v_eadd>();
+                auto r = t->r.template cast_safe<TVector<T>>();
+                auto u = t->u.template cast_safe<TVector<T>>();
+                auto v = t->v.template cast_safe<TVector<T>>();
+                const int op = device_binop<T>(t->op);
+                if (op < 0) return Status::NotImplemented;
+                if (r->get_n_rows() != u->get_n_rows() || r->get_n_rows() != v->get_n_rows()) return Status::InvalidArgument;
+                // sparse x sparse when both COO images are valid, dense x dense when both dense images are, sparse otherwise (cpu_v_eadd.hpp:59-66)
+                const bool dense = !(coo_valid(u.get()) && coo_valid(v.get())) && dense_valid(u.get()) && dense_valid(v.get());
+                if (dense) {
+                    u->validate_rw(FormatVector::AccDense);
+                    v->validate_rw(FormatVector::AccDense);
+                    if (r.get() != u.get() && r.get() != v.get()) r->validate_wd(FormatVector::AccDense);
+                    else
+                        r->validate_rwd(FormatVector::AccDense);// in place: keep the operand's image, drop its other formats
+                    hip_check(splahip_v_eadd_dense(TypeTraits<T>::id, r->get_n_rows(), r->acc_dense()->Ax.ptr(), u->acc_dense()->Ax.ptr(), v->acc_dense()->Ax.ptr(), op, nullptr),
+                              "splahip_v_eadd_dense");
+                    return Status::Ok;
+                }
+                if (r.get() == u.get() || r.get() == v.get()) return Status::InvalidArgument;// the merge cannot run in place
+                u->validate_rw(FormatVector::AccCoo);
+                v->validate_rw(FormatVector::AccCoo);
+                r->validate_wd(FormatVector::AccCoo);
+                auto *   a = u->acc_coo(), *b = v->acc_coo(), *out = r->acc_coo();
+                uint32_t count = 0;
+                out->Ai.reserve(a->values + b->values);
+                out->Ax.reserve(a->values + b->values);
+                hip_check(splahip_v_eadd_sparse(TypeTraits<T>::id, a->values, a->Ai.template as<uint32_t>(), a->Ax.ptr(), word_of(u->get_fill_value()), b->values,
+                                                b->Ai.template as<uint32_t>(), b->Ax.ptr(), word_of(v->get_fill_value()), out->Ai.template as<uint32_t>(),
+                                                out->Ax.ptr(), &count, op, nullptr),
+                          "splahip_v_eadd_sparse");
+                out->values = count;
+                return Status::Ok;
+            }
+        };
+
+        template<typename T>
+        class Algo_v_reduce_hip final : public RegistryAlgo {
+        public:
+            std::string get_name() override { return "v_reduce"; }
+            std::string get_description() override { return "fold of a vector's stored values into a scalar"; }
+            Status      execute(const DispatchContext& ctx) override {
+                auto t = ctx.task.template cast_safe<ScheduleTask_v_reduce>();
+                auto r = t->r.template cast_safe<TScalar<T>>();
+                auto s = t->s.template cast_safe<TScalar<T>>();
+                auto v = t->v.template cast_safe<TVector<T>>();
+                const int op = device_binop<T>(t->op_reduce);
+                if (op < 0) return Status::NotImplemented;
+                // the stored values of the sparse image when it is valid, every entry of the dense image when only that is (cpu_v_reduce.hpp:58-67)
+                const bool  sparse = coo_valid(v.get()) || !dense_valid(v.get());
+                uint32_t    bits   = 0, n;
+                const void* x;
+                if (sparse) {
+                    v->validate_rw(FormatVector::AccCoo);
+                    n = v->acc_coo()->values;
+                    x = v->acc_coo()->Ax.ptr();
+                } else {
+                    v->validate_rw(FormatVector::AccDense);
+                    n = v->get_n_rows();
+                    x = v->acc_dense()->Ax.ptr();
+                }
+                hip_check(splahip_reduce(TypeTraits<T>::id, n, x, word_of(s->get_value()), &bits, op, nullptr), "splahip_reduce");
+                r->set_value(value_of_word<T>(bits));
+                return Status::Ok;
+            }
+        };
+
+        template<typename T>
+        class Algo_m_reduce_hip final : public RegistryAlgo {
+        public:
+            std::string get_name() override { return "m_reduce"; }
+            std::string get_description() override { return "fold of a matrix's stored values into a scalar"; }
+            Status      execute(const DispatchContext& ctx) override {
+                auto t = ctx.task.template cast_safe<ScheduleTask_m_reduce>();
+                auto r = t->r.template cast_safe<TScalar<T>>();
+                auto s = t->s.template cast_safe<TScalar<T>>();
+                auto M = t->M.template cast_safe<TMatrix<T>>();
+                const int op = device_binop<T>(t->op_reduce);
+                if (op < 0) return Status::NotImplemented;
+                M->validate_rw(FormatMatrix::AccCsr);// values in row-major order (cpu_m_reduce.hpp:134-156)
+                uint32_t bits = 0;
+                hip_check(splahip_reduce(TypeTraits<T>::id, M->acc_csr()->values, M->acc_csr()->Ax.ptr(), word_of(s->get_value()), &bits, op, nullptr), "splahip_reduce");
+                r->set_value(value_of_word<T>(bits));
+                return Status::Ok;
+            }
+        };
+
         template<template<typename> class Algo>
         void add3(Registry* g, const std::string& name) {
             g->add(name + "_I__hip", std::make_shared<Algo<T_INT>>());
@@ -385,6 +488,9 @@ namespace spla {
         add3<Algo_v_assign_masked_hip>(g, "v_assign_masked");
         add3<Algo_v_eadd_fdb_hip>(g, "v_eadd_fdb");
         add3<Algo_v_count_mf_hip>(g, "v_count_mf");
+        add3<Algo_v_eadd_hip>(g, "v_eadd");
+        add3<Algo_v_reduce_hip>(g, "v_reduce");
+        add3<Algo_m_reduce_hip>(g, "m_reduce");
     }
 
 }// namespace spla

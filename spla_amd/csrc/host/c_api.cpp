@@ -166,6 +166,38 @@ spla_Status spla_Exec_v_count_mf(spla_Scalar r, spla_Vector v, spla_Descriptor d
     SPLA_C_EXEC(exec_v_count_mf(as_ref<Scalar>(r), as_ref<Vector>(v), as_ref<Descriptor>(desc), p_hnd))
 }
 
+spla_Status spla_Exec_m_reduce(spla_Scalar r, spla_Scalar s, spla_Matrix M, spla_OpBinary op_reduce, spla_Descriptor desc, spla_ScheduleTask* task) {
+    SPLA_C_EXEC(exec_m_reduce(as_ref<Scalar>(r), as_ref<Scalar>(s), as_ref<Matrix>(M), as_ref<OpBinary>(op_reduce), as_ref<Descriptor>(desc), p_hnd))
+}
+spla_Status spla_Exec_v_eadd(spla_Vector r, spla_Vector u, spla_Vector v, spla_OpBinary op, spla_Descriptor desc, spla_ScheduleTask* task) {
+    SPLA_C_EXEC(exec_v_eadd(as_ref<Vector>(r), as_ref<Vector>(u), as_ref<Vector>(v), as_ref<OpBinary>(op), as_ref<Descriptor>(desc), p_hnd))
+}
+spla_Status spla_Exec_v_reduce(spla_Scalar r, spla_Scalar s, spla_Vector v, spla_OpBinary op_reduce, spla_Descriptor desc, spla_ScheduleTask* task) {
+    SPLA_C_EXEC(exec_v_reduce(as_ref<Scalar>(r), as_ref<Scalar>(s), as_ref<Vector>(v), as_ref<OpBinary>(op_reduce), as_ref<Descriptor>(desc), p_hnd))
+}
+
+spla_Status spla_Algorithm_bfs(spla_Vector v, spla_Matrix A, spla_uint s, spla_Descriptor descriptor) {
+    return to_c(bfs(as_ref<Vector>(v), as_ref<Matrix>(A), s, as_ref<Descriptor>(descriptor)));
+}
+spla_Status spla_Algorithm_sssp(spla_Vector v, spla_Matrix A, spla_uint s, spla_Descriptor descriptor) {
+    return to_c(sssp(as_ref<Vector>(v), as_ref<Matrix>(A), s, as_ref<Descriptor>(descriptor)));
+}
+// *p is consumed and replaced: the result may live in a different Vector object than the one passed in (reference src/binding/c_algorithm.cpp:36-48)
+spla_Status spla_Algorithm_pr(spla_Vector* p, spla_Matrix A, float alpha, float eps, spla_Descriptor descriptor) {
+    if (!p || !*p) return SPLA_STATUS_INVALID_ARGUMENT;
+    ref_ptr<Vector> inout = as_ref<Vector>(*p);
+    const Status    st    = pr(inout, as_ref<Matrix>(A), alpha, eps, as_ref<Descriptor>(descriptor));
+    if (st != Status::Ok) return to_c(st);
+    Vector* out = inout.release();// one reference handed to the caller ...
+    as_ptr<Vector>(*p)->rel_ref();   // ... in exchange for the caller's reference to the vector passed in
+    *p = reinterpret_cast<spla_Vector>(out);
+    return SPLA_STATUS_OK;
+}
+spla_Status spla_Algorithm_tc(int* ntrins, spla_Matrix A, spla_Matrix B, spla_Descriptor descriptor) {
+    if (!ntrins) return SPLA_STATUS_INVALID_ARGUMENT;
+    return to_c(tc(*ntrins, as_ref<Matrix>(A), as_ref<Matrix>(B), as_ref<Descriptor>(descriptor)));
+}
+
 spla_Status spla_Descriptor_make(spla_Descriptor* desc) { return give(desc, Descriptor::make()); }
 spla_Status spla_Descriptor_set_early_exit(spla_Descriptor desc, spla_bool value) {
     if (!desc) return SPLA_STATUS_INVALID_ARGUMENT;
@@ -175,6 +207,16 @@ spla_Status spla_Descriptor_set_early_exit(spla_Descriptor desc, spla_bool value
 spla_Status spla_Descriptor_set_struct_only(spla_Descriptor desc, spla_bool value) {
     if (!desc) return SPLA_STATUS_INVALID_ARGUMENT;
     as_ptr<Descriptor>(desc)->set_struct_only(value != 0);
+    return SPLA_STATUS_OK;
+}
+spla_Status spla_Descriptor_set_traversal_mode(spla_Descriptor desc, int mode) {
+    if (!desc || mode < 0 || mode > 2) return SPLA_STATUS_INVALID_ARGUMENT;
+    as_ptr<Descriptor>(desc)->set_traversal_mode(static_cast<Descriptor::TraversalMode>(mode));
+    return SPLA_STATUS_OK;
+}
+spla_Status spla_Descriptor_set_front_factor(spla_Descriptor desc, float value) {
+    if (!desc) return SPLA_STATUS_INVALID_ARGUMENT;
+    as_ptr<Descriptor>(desc)->set_front_factor(value);
     return SPLA_STATUS_OK;
 }
 }

@@ -515,4 +515,39 @@ namespace spla {
         return run_or_return(task.as<ScheduleTask>(), task_hnd);
     }
 
+    Status exec_v_eadd(ref_ptr<Vector> r, ref_ptr<Vector> u, ref_ptr<Vector> v, ref_ptr<OpBinary> op, ref_ptr<Descriptor> desc, ref_ptr<ScheduleTask>* task_hnd) {
+        if (!r || !u || !v || !op) return Status::InvalidArgument;
+        auto task  = ref_ptr<ScheduleTask_v_eadd>(new ScheduleTask_v_eadd());
+        task->r    = std::move(r);
+        task->u    = std::move(u);
+        task->v    = std::move(v);
+        task->op   = std::move(op);
+        task->desc = std::move(desc);
+        return run_or_return(task.as<ScheduleTask>(), task_hnd);
+    }
+
+    Status exec_v_reduce(ref_ptr<Scalar> r, ref_ptr<Scalar> s, ref_ptr<Vector> v, ref_ptr<OpBinary> op_reduce, ref_ptr<Descriptor> desc,
+                         ref_ptr<ScheduleTask>* task_hnd) {
+        if (!r || !s || !v || !op_reduce) return Status::InvalidArgument;
+        auto task       = ref_ptr<ScheduleTask_v_reduce>(new ScheduleTask_v_reduce());
+        task->r         = std::move(r);
+        task->s         = std::move(s);
+        task->v         = std::move(v);
+        task->op_reduce = std::move(op_reduce);
+        task->desc      = std::move(desc);
+        return run_or_return(task.as<ScheduleTask>(), task_hnd);
+    }
+
+    Status exec_m_reduce(ref_ptr<Scalar> r, ref_ptr<Scalar> s, ref_ptr<Matrix> M, ref_ptr<OpBinary> op_reduce, ref_ptr<Descriptor> desc,
+                         ref_ptr<ScheduleTask>* task_hnd) {
+        if (!r || !s || !M || !op_reduce) return Status::InvalidArgument;
+        auto task       = ref_ptr<ScheduleTask_m_reduce>(new ScheduleTask_m_reduce());
+        task->r         = std::move(r);
+        task->s         = std::move(s);
+        task->M         = std::move(M);
+        task->op_reduce = std::move(op_reduce);
+        task->desc      = std::move(desc);
+        return run_or_return(task.as<ScheduleTask>(), task_hnd);
+    }
+
 }// namespace spla

@@ -167,6 +167,7 @@ namespace spla {
         T_UINT             as_uint() override { return static_cast<T_UINT>(m_value); }
         T_FLOAT            as_float() override { return static_cast<T_FLOAT>(m_value); }
         T                  get_value() const { return m_value; }
+        void               set_value(T v) { m_value = v; }
 
     private:
         T           m_value = T();
@@ -300,6 +301,34 @@ namespace spla {
         std::vector<ref_ptr<Object>> get_args() override { return {r.as<Object>(), v.as<Object>()}; }
         ref_ptr<Scalar>              r;
         ref_ptr<Vector>              v;
+    };
+    // PageRank step remainder and triangle-count tail (reference src/schedule/schedule_tasks.hpp: ScheduleTask_v_eadd / v_reduce / m_reduce;
+    // keys by the RESULT's type, schedule_tasks.cpp:264-270,348-354,454-460)
+    class ScheduleTask_v_eadd final : public TaskBase {
+    public:
+        std::string                  get_name() override { return "v_eadd"; }
+        std::string                  get_key() override { return "v_eadd_" + r->get_type()->get_code(); }
+        std::vector<ref_ptr<Object>> get_args() override { return {r.as<Object>(), u.as<Object>(), v.as<Object>(), op.as<Object>()}; }
+        ref_ptr<Vector>              r, u, v;
+        ref_ptr<OpBinary>            op;
+    };
+    class ScheduleTask_v_reduce final : public TaskBase {
+    public:
+        std::string                  get_name() override { return "v_reduce"; }
+        std::string                  get_key() override { return "v_reduce_" + r->get_type()->get_code(); }
+        std::vector<ref_ptr<Object>> get_args() override { return {r.as<Object>(), s.as<Object>(), v.as<Object>(), op_reduce.as<Object>()}; }
+        ref_ptr<Scalar>              r, s;
+        ref_ptr<Vector>              v;
+        ref_ptr<OpBinary>            op_reduce;
+    };
+    class ScheduleTask_m_reduce final : public TaskBase {
+    public:
+        std::string                  get_name() override { return "m_reduce"; }
+        std::string                  get_key() override { return "m_reduce_" + r->get_type()->get_code(); }
+        std::vector<ref_ptr<Object>> get_args() override { return {r.as<Object>(), s.as<Object>(), M.as<Object>(), op_reduce.as<Object>()}; }
+        ref_ptr<Scalar>              r, s;
+        ref_ptr<Matrix>              M;
+        ref_ptr<OpBinary>            op_reduce;
     };
 
 }// namespace spla

@@ -8,6 +8,12 @@
 //   splahip_v_count_mf_dense   semantics: reference Algo_v_count_mf_cpu::execute_dense, src/cpu/cpu_v_count_mf.hpp:99-108
 //                              (replaces Algo_v_count_mf_cl, src/opencl/cl_v_count_mf.hpp:99-108)
 //
+// and the remainder of the PageRank step and the triangle-count tail:
+//
+//   splahip_v_eadd_dense/_sparse  semantics: reference Algo_v_eadd_cpu, src/cpu/cpu_v_eadd.hpp:70-157
+//   splahip_reduce                semantics: reference Algo_v_reduce_cpu / Algo_m_reduce_cpu: a fold of the stored values from
+//                                 the scalar s (src/cpu/cpu_v_reduce.hpp:69-117, src/cpu/cpu_m_reduce.hpp:134-156)
+//
 // All are element-wise, HBM-bound streaming kernels (4-16 bytes per element).  The sparse forms assume the COO operand
 // holds every index at most once (always true for vectors produced by this library and by Dok->Coo / Dense->Coo
 // conversions; the reference's sequential loop would apply a duplicate twice).  The sparse feedback of v_eadd_fdb is
@@ -122,7 +128,238 @@ namespace splahip {
         return SPLAHIP_OK;
     }
 
+    // ---- v_eadd -------------------------------------------------------------------------------------------------------
+    template<typename T>
+    __global__ __launch_bounds__(256) void eadd_dense_kernel(uint n, T* __restrict__ r, const T* __restrict__ u, const T* __restrict__ v, DynBin op) {
+        const uint i = blockIdx.x * 256 + threadIdx.x;
+        if (i < n) r[i] = op(u[i], v[i]);
+    }
+
+    // first position in the ascending list a[0..n) whose value is >= key
+    __device__ __forceinline__ uint lower_bound_u32(const uint* __restrict__ a, uint n, uint key) {
+        uint lo = 0, hi = n;
+        while (lo < hi) {
+            const uint mid = (lo + hi) >> 1;
+            if (a[mid] < key) lo = mid + 1;
+            else
+                hi = mid;
+        }
+        return lo;
+    }
+    // sparse (+) sparse, both index-sorted without duplicates: the merge of the reference (cpu_v_eadd.hpp:96-127) as a
+    // rank computation.  Pass 1: per entry its rank in the other list and whether the index is shared.
+    __global__ __launch_bounds__(256) void eadd_rank_kernel(uint na, const uint* __restrict__ ai, uint nb, const uint* __restrict__ bi,
+                                                            uint* __restrict__ rank, uint* __restrict__ shared_flag) {
+        const uint k = blockIdx.x * 256 + threadIdx.x;
+        if (k >= na) return;
+        const uint key = ai[k];
+        const uint lb  = lower_bound_u32(bi, nb, key);
+        rank[k]        = lb;
+        shared_flag[k] = (lb < nb && bi[lb] == key) ? 1u : 0u;
+    }
+    // exclusive prefix sums of the shared flags, in place (flag[k] -> shared entries before k), count/scan/write style
+    __global__ __launch_bounds__(256) void flag_chunk_count_kernel(const uint* __restrict__ flag, uint n, uint* __restrict__ chunk) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        uint            cnt   = 0;
+#pragma unroll
+        for (uint e = 0; e < 4; ++e)
+            if (first + e < n) cnt += flag[first + e];
+        uint total;
+        (void) block_exclusive_sum<256>(cnt, s_tmp, total);
+        if (threadIdx.x == 0) chunk[blockIdx.x] = total;
+    }
+    // pass 2 for the u side: every u entry is emitted; position = k + (v entries before it) - (shared entries before it)
+    template<typename T>
+    __global__ __launch_bounds__(256) void eadd_emit_u_kernel(uint nu, const uint* __restrict__ ui, const T* __restrict__ ux, const T* __restrict__ vx, T v_fill,
+                                                              const uint* __restrict__ rank, const uint* __restrict__ flag, const uint* __restrict__ chunk,
+                                                              uint* __restrict__ ri, T* __restrict__ rx, DynBin op) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        uint            f[4], cnt = 0;
+#pragma unroll
+        for (uint e = 0; e < 4; ++e) {
+            f[e] = first + e < nu ? flag[first + e] : 0u;
+            cnt += f[e];
+        }
+        uint total;
+        uint before = chunk[blockIdx.x] + block_exclusive_sum<256>(cnt, s_tmp, total);
+#pragma unroll
+        for (uint e = 0; e < 4; ++e) {
+            const uint k = first + e;
+            if (k < nu) {
+                const uint pos = k + rank[k] - before;
+                ri[pos]        = ui[k];
+                rx[pos]        = op(ux[k], f[e] ? vx[rank[k]] : v_fill);
+            }
+            before += f[e];
+        }
+    }
+    // pass 2 for the v side: only entries whose index u does not hold
+    template<typename T>
+    __global__ __launch_bounds__(256) void eadd_emit_v_kernel(uint nv, const uint* __restrict__ vi, const T* __restrict__ vx, T u_fill,
+                                                              const uint* __restrict__ rank, const uint* __restrict__ flag, const uint* __restrict__ chunk,
+                                                              uint* __restrict__ ri, T* __restrict__ rx, DynBin op) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        uint            f[4], cnt = 0;
+#pragma unroll
+        for (uint e = 0; e < 4; ++e) {
+            f[e] = first + e < nv ? flag[first + e] : 0u;
+            cnt += f[e];
+        }
+        uint total;
+        uint before = chunk[blockIdx.x] + block_exclusive_sum<256>(cnt, s_tmp, total);
+#pragma unroll
+        for (uint e = 0; e < 4; ++e) {
+            const uint k = first + e;
+            if (k < nv && !f[e]) {
+                const uint pos = k + rank[k] - before;
+                ri[pos]        = vi[k];
+                rx[pos]        = op(u_fill, vx[k]);
+            }
+            before += f[e];
+        }
+    }
+
+    template<typename T>
+    int eadd_sparse(uint nu, const uint* ui, const void* ux, uint32_t u_fill, uint nv, const uint* vi, const void* vx, uint32_t v_fill, uint* ri, void* rx,
+                    uint* h_count, int op, hipStream_t s) {
+        const uint cu = (nu + 1023u) / 1024u, cv = (nv + 1023u) / 1024u;
+        uint*      scratch = nullptr;// rank_u[nu] flag_u[nu] chunk_u[cu+1] rank_v[nv] flag_v[nv] chunk_v[cv+1]
+        SPLAHIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), sizeof(uint) * (2 * (size_t) nu + 2 * (size_t) nv + cu + cv + 2)));
+        uint *rank_u = scratch, *flag_u = rank_u + nu, *chunk_u = flag_u + nu, *rank_v = chunk_u + cu + 1, *flag_v = rank_v + nv, *chunk_v = flag_v + nv;
+        if (nu) {
+            hipLaunchKernelGGL(eadd_rank_kernel, dim3((nu + 255) / 256), dim3(256), 0, s, nu, ui, nv, vi, rank_u, flag_u);
+            hipLaunchKernelGGL(flag_chunk_count_kernel, dim3(cu), dim3(256), 0, s, flag_u, nu, chunk_u);
+            hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk_u, cu);
+            hipLaunchKernelGGL(eadd_emit_u_kernel<T>, dim3(cu), dim3(256), 0, s, nu, ui, static_cast<const T*>(ux), static_cast<const T*>(vx), from_bits<T>(v_fill),
+                               rank_u, flag_u, chunk_u, ri, static_cast<T*>(rx), DynBin(op));
+        }
+        if (nv) {
+            hipLaunchKernelGGL(eadd_rank_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, nv, vi, nu, ui, rank_v, flag_v);
+            hipLaunchKernelGGL(flag_chunk_count_kernel, dim3(cv), dim3(256), 0, s, flag_v, nv, chunk_v);
+            hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk_v, cv);
+            hipLaunchKernelGGL(eadd_emit_v_kernel<T>, dim3(cv), dim3(256), 0, s, nv, vi, static_cast<const T*>(vx), from_bits<T>(u_fill), rank_v, flag_v, chunk_v, ri,
+                               static_cast<T*>(rx), DynBin(op));
+        }
+        hipError_t e      = hipGetLastError();
+        uint       shared = 0;
+        if (e == hipSuccess && nv) e = hipMemcpyAsync(&shared, chunk_v + cv, sizeof(uint), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void) hipFree(scratch);
+        if (e != hipSuccess) return fail(SPLAHIP_ERROR, "v_eadd (sparse) failed: %s", hipGetErrorString(e));
+        *h_count = nu + nv - shared;
+        return SPLAHIP_OK;
+    }
+
+    // ---- reduce ---------------------------------------------------------------------------------------------------------
+    // Fold of x[0..n) from s.  Associative + commutative ops: every workgroup folds a grid-strided share (16-byte loads),
+    // one more workgroup folds the partials in block order and applies s on the left — a fixed tree, so results repeat
+    // bit for bit from run to run.  Other ops (MINUS, DIV, MINUS_POW2, FIRST, SECOND): the reference's strict left fold by one lane.
+    constexpr uint kReduceBlocks = 1024;
+
+    template<typename T>
+    __device__ __forceinline__ void block_fold(T& acc, bool& valid, const DynBin& op, T* s_val, int* s_ok) {
+        wave_reduce_ordered(acc, valid, op);
+        if (lane_id() == 0) {
+            s_val[wave_id()] = acc;
+            s_ok[wave_id()]  = valid ? 1 : 0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            bool ok = false;
+            T    a  = acc;
+            for (uint w = 0; w < 256 / kWave; ++w)
+                if (s_ok[w]) {
+                    a  = ok ? op(a, s_val[w]) : s_val[w];
+                    ok = true;
+                }
+            acc   = a;
+            valid = ok;
+        }
+    }
+    template<typename T>
+    __global__ __launch_bounds__(256) void reduce_partial_kernel(uint n, const T* __restrict__ x, T* __restrict__ partial, uint* __restrict__ partial_ok, DynBin op) {
+        __shared__ T   s_val[256 / kWave];
+        __shared__ int s_ok[256 / kWave];
+        T              acc   = T();
+        bool           valid = false;
+        const uint     nq    = n / 4;
+        for (uint q = blockIdx.x * 256 + threadIdx.x; q < nq; q += gridDim.x * 256) {
+            const uint4 w = *reinterpret_cast<const uint4*>(x + 4 * (size_t) q);
+            const T     e[4] = {from_bits<T>(w.x), from_bits<T>(w.y), from_bits<T>(w.z), from_bits<T>(w.w)};
+            T           g    = op(op(op(e[0], e[1]), e[2]), e[3]);
+            acc              = valid ? op(acc, g) : g;
+            valid            = true;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3u)) {// the up to 3 trailing elements
+            const T g = x[4 * (size_t) nq + threadIdx.x];
+            acc       = valid ? op(acc, g) : g;
+            valid     = true;
+        }
+        block_fold(acc, valid, op, s_val, s_ok);
+        if (threadIdx.x == 0) {
+            partial[blockIdx.x]    = acc;
+            partial_ok[blockIdx.x] = valid ? 1u : 0u;
+        }
+    }
+    template<typename T>
+    __global__ __launch_bounds__(256) void reduce_final_kernel(uint n_partial, const T* __restrict__ partial, const uint* __restrict__ partial_ok, T s, T* __restrict__ out, DynBin op) {
+        __shared__ T   s_val[256 / kWave];
+        __shared__ int s_ok[256 / kWave];
+        T              acc   = T();
+        bool           valid = false;
+        // thread t folds the contiguous partials [t*per, (t+1)*per): block order is kept
+        const uint per = (n_partial + 255u) / 256u;
+        for (uint k = threadIdx.x * per; k < min((threadIdx.x + 1) * per, n_partial); ++k)
+            if (partial_ok[k]) {
+                acc   = valid ? op(acc, partial[k]) : partial[k];
+                valid = true;
+            }
+        block_fold(acc, valid, op, s_val, s_ok);
+        if (threadIdx.x == 0) out[0] = valid ? op(s, acc) : s;
+    }
+    // one wave: 64 lanes fetch a 1024-element chunk (coalesced), lane 0 folds it in order out of LDS
+    template<typename T>
+    __global__ __launch_bounds__(64) void reduce_sequential_kernel(uint n, const T* __restrict__ x, T s, T* __restrict__ out, DynBin op) {
+        __shared__ T s_buf[1024];
+        T            sum = s;
+        for (uint base = 0; base < n; base += 1024) {
+            const uint len = min(1024u, n - base);
+            for (uint k = threadIdx.x; k < len; k += 64) s_buf[k] = x[base + k];
+            __syncthreads();
+            if (threadIdx.x == 0)
+                for (uint k = 0; k < len; ++k) sum = op(sum, s_buf[k]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[0] = sum;
+    }
+
+    template<typename T>
+    int reduce_typed(uint n, const void* x, uint32_t s_bits, uint32_t* h_result, int op, hipStream_t s) {
+        const uint blocks  = std::max(1u, std::min(kReduceBlocks, (n / 4 + 255u) / 256u));
+        char*      scratch = nullptr;// out[1] | partial[blocks] | ok[blocks]
+        SPLAHIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), sizeof(uint32_t) * (1 + 2 * (size_t) blocks)));
+        T*    out     = reinterpret_cast<T*>(scratch);
+        T*    partial = out + 1;
+        uint* ok      = reinterpret_cast<uint*>(partial + blocks);
+        if (binop_is_associative(op) && binop_is_commutative(op)) {
+            hipLaunchKernelGGL(reduce_partial_kernel<T>, dim3(blocks), dim3(256), 0, s, n, static_cast<const T*>(x), partial, ok, DynBin(op));
+            hipLaunchKernelGGL(reduce_final_kernel<T>, dim3(1), dim3(256), 0, s, blocks, partial, ok, from_bits<T>(s_bits), out, DynBin(op));
+        } else {
+            hipLaunchKernelGGL(reduce_sequential_kernel<T>, dim3(1), dim3(64), 0, s, n, static_cast<const T*>(x), from_bits<T>(s_bits), out, DynBin(op));
+        }
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(h_result, out, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void) hipFree(scratch);
+        if (e != hipSuccess) return fail(SPLAHIP_ERROR, "reduce failed: %s", hipGetErrorString(e));
+        return SPLAHIP_OK;
+    }
+
 }// namespace splahip
+
 
 using namespace splahip;
 
@@ -228,6 +465,57 @@ int splahip_v_eadd_fdb_sparse(int type, uint32_t nvals, void* d_r, const uint32_
         case SPLAHIP_INT: return eadd_fdb_sparse<int32_t>(nvals, d_r, d_vi, d_vx, d_fi, d_fx, h_count, op, s);
         case SPLAHIP_UINT: return eadd_fdb_sparse<uint32_t>(nvals, d_r, d_vi, d_vx, d_fi, d_fx, h_count, op, s);
         case SPLAHIP_FLOAT: return eadd_fdb_sparse<float>(nvals, d_r, d_vi, d_vx, d_fi, d_fx, h_count, op, s);
+    }
+    return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
+}
+
+int splahip_v_eadd_dense(int type, uint32_t n, void* d_r, const void* d_u, const void* d_v, int op, void* stream) {
+    SPLAHIP_REQUIRE(binop_valid_for(op, type), "op not defined for this type");
+    if (n == 0) return SPLAHIP_OK;
+    SPLAHIP_REQUIRE(d_r && d_u && d_v, "null device pointer");
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    const dim3 grid((n + 255) / 256), block(256);
+    hipStream_t s = as_stream(stream);
+    SPLAHIP_BY_TYPE(type,
+                    hipLaunchKernelGGL(eadd_dense_kernel<int32_t>, grid, block, 0, s, n, static_cast<int32_t*>(d_r), static_cast<const int32_t*>(d_u), static_cast<const int32_t*>(d_v), DynBin(op)),
+                    hipLaunchKernelGGL(eadd_dense_kernel<uint32_t>, grid, block, 0, s, n, static_cast<uint32_t*>(d_r), static_cast<const uint32_t*>(d_u), static_cast<const uint32_t*>(d_v), DynBin(op)),
+                    hipLaunchKernelGGL(eadd_dense_kernel<float>, grid, block, 0, s, n, static_cast<float*>(d_r), static_cast<const float*>(d_u), static_cast<const float*>(d_v), DynBin(op)))
+    SPLAHIP_TRY(hipGetLastError());
+    return SPLAHIP_OK;
+}
+
+int splahip_v_eadd_sparse(int type, uint32_t nu, const uint32_t* d_ui, const void* d_ux, uint32_t u_fill_bits, uint32_t nv, const uint32_t* d_vi,
+                          const void* d_vx, uint32_t v_fill_bits, uint32_t* d_ri, void* d_rx, uint32_t* h_count, int op, void* stream) {
+    SPLAHIP_REQUIRE(h_count != nullptr, "h_count is null");
+    SPLAHIP_REQUIRE(binop_valid_for(op, type), "op not defined for this type");
+    *h_count = 0;
+    if (nu == 0 && nv == 0) return SPLAHIP_OK;
+    SPLAHIP_REQUIRE((nu == 0 || (d_ui && d_ux)) && (nv == 0 || (d_vi && d_vx)) && d_ri && d_rx, "null device pointer");
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    hipStream_t s = as_stream(stream);
+    switch (type) {
+        case SPLAHIP_INT: return eadd_sparse<int32_t>(nu, d_ui, d_ux, u_fill_bits, nv, d_vi, d_vx, v_fill_bits, d_ri, d_rx, h_count, op, s);
+        case SPLAHIP_UINT: return eadd_sparse<uint32_t>(nu, d_ui, d_ux, u_fill_bits, nv, d_vi, d_vx, v_fill_bits, d_ri, d_rx, h_count, op, s);
+        case SPLAHIP_FLOAT: return eadd_sparse<float>(nu, d_ui, d_ux, u_fill_bits, nv, d_vi, d_vx, v_fill_bits, d_ri, d_rx, h_count, op, s);
+    }
+    return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
+}
+
+int splahip_reduce(int type, uint32_t n, const void* d_x, uint32_t s_bits, uint32_t* h_result_bits, int op, void* stream) {
+    SPLAHIP_REQUIRE(h_result_bits != nullptr, "h_result_bits is null");
+    SPLAHIP_REQUIRE(binop_valid_for(op, type), "op not defined for this type");
+    *h_result_bits = s_bits;
+    if (n == 0) return SPLAHIP_OK;
+    SPLAHIP_REQUIRE(d_x != nullptr && (reinterpret_cast<uintptr_t>(d_x) & 15u) == 0, "d_x must be a 16-byte aligned device pointer");
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    hipStream_t s = as_stream(stream);
+    switch (type) {
+        case SPLAHIP_INT: return reduce_typed<int32_t>(n, d_x, s_bits, h_result_bits, op, s);
+        case SPLAHIP_UINT: return reduce_typed<uint32_t>(n, d_x, s_bits, h_result_bits, op, s);
+        case SPLAHIP_FLOAT: return reduce_typed<float>(n, d_x, s_bits, h_result_bits, op, s);
     }
     return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
 }
