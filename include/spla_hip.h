@@ -72,6 +72,13 @@ int splahip_csr_plan_create(splahip_plan* plan, uint32_t n_rows, uint32_t nnz, c
  * persistent mxv kernel (the ~28 K most referenced columns get an LDS slot; a re-encoded private copy of Aj is kept with
  * the plan, +4 bytes per entry).  Without it mxv runs the non-persistent wave-tile kernel.  Blocks.            */
 int splahip_csr_plan_attach_columns(splahip_plan plan, uint32_t n_cols, const uint32_t* d_Aj, void* stream);
+/* Optional: a sliced-ELL copy of the matrix with hot-column encoding, kept with the plan (+8 bytes per entry; DESIGN.md 4.1,
+ * spla_amd/csrc/kernels/mxv_sell.hpp).  With it splahip_mxv_masked serves every associative op_add (no early exit) from the
+ * copy: rows are cut into chunks of <= 256 entries, chunks sorted by length and laid out 64 to a slice, one lane per chunk,
+ * the 40,000 most referenced columns of v served from LDS.  The copy holds the VALUES too: rebuild it when Aj or Ax change.
+ * Blocks.  sell_info: slices, stored entries incl. padding, LDS-resident columns, rows longer than one chunk.            */
+int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, void* stream);
+int splahip_csr_plan_sell_info(splahip_plan plan, uint32_t* n_slices, uint32_t* n_slots, uint32_t* n_hot, uint32_t* n_long_rows);
 int splahip_csr_plan_destroy(splahip_plan plan);
 /* n_items: work items; n_long: rows cut into segment items */
 int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_items, uint32_t* n_long);
@@ -176,6 +183,7 @@ int splahip_vec_coo_to_dense(uint32_t n, uint32_t nvals, const uint32_t* d_idx, 
 
 /* name of the kernel variant the call above would launch for these arguments (for profiles / DESIGN.md) */
 const char* splahip_mxv_variant(int type, int op_mult, int op_add, int early_exit);
+const char* splahip_mxv_variant_of(splahip_plan plan, int type, int op_mult, int op_add, int early_exit); /* with the plan's sliced-ELL copy taken into account */
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,9 @@ _SIGNATURES = {
     "splahip_stream_sync": (C.c_int, [_vp]),
     "splahip_csr_plan_create": (C.c_int, [C.POINTER(_vp), C.c_uint32, C.c_uint32, _vp, _vp]),
     "splahip_csr_plan_attach_columns": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
+    "splahip_csr_plan_attach_sell": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "splahip_csr_plan_sell_info": (C.c_int, [_vp, _u32p, _u32p, _u32p, _u32p]),
+    "splahip_mxv_variant_of": (C.c_char_p, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "splahip_csr_plan_destroy": (C.c_int, [_vp]),
     "splahip_csr_plan_info": (C.c_int, [_vp, _u32p, _u32p]),
     "splahip_mxv_masked": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -63,7 +66,7 @@ _SIGNATURES = {
                               C.c_int, C.c_int, C.c_uint32, C.c_uint64, _vp]),
     "splahip_csr_transpose": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
-_RAW = {"splahip_device_count", "splahip_last_error", "splahip_version", "splahip_mxv_variant"}
+_RAW = {"splahip_device_count", "splahip_last_error", "splahip_version", "splahip_mxv_variant", "splahip_mxv_variant_of"}
 
 _lib = None
 

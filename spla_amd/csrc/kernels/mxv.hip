@@ -67,6 +67,11 @@ namespace {
         return !(e && e[0] == '1');
     }
 
+    bool sell_disabled() {
+        const char* e = std::getenv("SPLAHIP_SELL");
+        return e && e[0] == '0';
+    }
+
     template<typename T, class Mult, class Add>
     int launch_wavetile(splahip_plan plan, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const void* mask,
                         const void* v, void* r, int op_mult, int op_add, int op_select, uint32_t init_bits, hipStream_t st) {
@@ -154,6 +159,7 @@ namespace {
         if (plan->d_hot_cols) (void) hipFree(plan->d_hot_cols);
         if (plan->d_hot_values) (void) hipFree(plan->d_hot_values);
         if (plan->d_Aj_enc) (void) hipFree(plan->d_Aj_enc);
+        sell_release(plan->sell);
         delete plan;
     }
 
@@ -290,6 +296,12 @@ int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_items, uint32_t* n_long
     return SPLAHIP_OK;
 }
 
+const char* splahip_mxv_variant_of(splahip_plan plan, int type, int op_mult, int op_add, int early_exit) {
+    if (plan && plan->sell && !early_exit && binop_is_associative(op_add) && !sell_disabled())
+        return static_semiring(type, op_mult, op_add) ? "mxv_sell<static semiring>" : "mxv_sell<runtime ops>";
+    return splahip_mxv_variant(type, op_mult, op_add, early_exit);
+}
+
 const char* splahip_mxv_variant(int type, int op_mult, int op_add, int early_exit) {
     switch (pick_variant(type, op_mult, op_add, early_exit)) {
         case Variant::WaveTileStatic: return "mxv_wavetile<static semiring>";
@@ -310,13 +322,17 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
     SPLAHIP_REQUIRE(binop_valid_for(op_mult, type), "op_multiply not defined for this type");
     SPLAHIP_REQUIRE(binop_valid_for(op_add, type), "op_add not defined for this type");
     SPLAHIP_REQUIRE(op_select >= 0 && op_select < SPLAHIP_SELOP_COUNT, "unknown op_select");
-    (void) n_cols;
     if (n_rows == 0) return SPLAHIP_OK;
     SPLAHIP_REQUIRE(d_Ap && d_mask && d_r, "null device pointer");
     SPLAHIP_REQUIRE(plan->nnz == 0 || (d_Aj && d_Ax && d_v), "null device pointer");
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
     hipStream_t s = as_stream(stream);
+    // the sliced-ELL copy (splahip_csr_plan_attach_sell) serves every associative op_add without early exit; its lanes fold in
+    // entry order, so op_add need not be commutative.  SPLAHIP_SELL=0 keeps the CSR kernels (A/B runs, tests).
+    if (plan->sell && !early_exit && binop_is_associative(op_add) && plan->sell->n_cols == n_cols && !sell_disabled() &&
+        ((reinterpret_cast<uintptr_t>(d_Ap) | reinterpret_cast<uintptr_t>(d_mask)) & 15u) == 0)// its row pass reads Ap / mask 16 bytes at a time
+        return sell_mxv(plan, type, d_Ap, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, stream);
     switch (type) {
         case SPLAHIP_INT:
             return dispatch_typed<int32_t>(plan, n_rows, d_Ap, d_Aj, d_Ax, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, early_exit, s);

@@ -3,6 +3,28 @@
 
 #include <stdint.h>
 
+// sliced-ELL copy of the matrix + hot-column table (sell.hip / mxv_sell.hpp); owned by the plan
+struct splahip_sell_s {
+    uint32_t  n_cols     = 0;
+    uint32_t  n_vrows    = 0;// virtual rows (chunks), padded to a multiple of 64
+    uint32_t  n_slices   = 0;
+    uint32_t  n_slots    = 0;// entries of Aj2 / Ax2 incl. in-slice padding (the allocation adds a read-ahead tail)
+    uint32_t  n_hot      = 0;
+    uint32_t  n_lrows    = 0;// rows longer than one chunk
+    uint32_t  n_partials = 0;
+    uint32_t* d_vrow     = nullptr;// n_vrows: row id | bit 31 "chunk of a long row"
+    uint32_t* d_vlen     = nullptr;// n_vrows: entries of the chunk (0 = padding lane)
+    uint32_t* d_vslot    = nullptr;// n_vrows: partial slot of a long row's chunk
+    uint32_t* d_off      = nullptr;// n_slices + 1: first entry of every slice
+    uint32_t* d_Aj2      = nullptr;
+    uint32_t* d_Ax2      = nullptr;
+    uint32_t* d_hot_cols = nullptr;// n_hot column ids in LDS-slot order
+    uint32_t* d_hot_vals = nullptr;// n_hot words, packed per launch
+    uint32_t* d_lr_row   = nullptr;// n_lrows
+    uint32_t* d_lr_first = nullptr;// n_lrows + 1
+    uint32_t* d_partial  = nullptr;// n_partials
+};
+
 struct splahip_plan_s {
     uint32_t  n_rows  = 0;
     uint32_t  nnz     = 0;
@@ -20,4 +42,12 @@ struct splahip_plan_s {
     uint32_t* d_hot_cols   = nullptr;// n_hot column ids, in LDS-slot order
     uint32_t* d_hot_values = nullptr;// n_hot words of scratch, gathered per launch
     uint32_t* d_Aj_enc     = nullptr;// nnz words: bit 31 set -> low bits are the LDS slot, else the column id
+    splahip_sell_s* sell   = nullptr;// splahip_csr_plan_attach_sell
 };
+
+namespace splahip {
+    void sell_release(splahip_sell_s* sell);
+    // the sliced-ELL masked SpMV (associative op_add, no early exit); returns a SPLAHIP status
+    int sell_mxv(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
+                 uint32_t init_bits, void* stream);
+}// namespace splahip

@@ -1,0 +1,372 @@
+// sell.hip — construction of the sliced-ELL + hot-column copy of a device CSR matrix and the launch of the masked SpMV over
+// it (kernels and the rationale: mxv_sell.hpp).  Everything is built on the device: a matrix that lives in HBM never
+// visits the host.  The copy belongs to the plan (splahip_csr_plan_attach_sell) and must be rebuilt when the matrix changes.
+#include "block_utils.hpp"
+#include "common.hpp"
+#include "mxv_sell.hpp"
+#include "ops.hpp"
+#include "plan.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+using namespace splahip;
+using SC = SellCfg;
+
+namespace {
+
+    // ---- plan-time kernels ----------------------------------------------------------------------------------------------
+    // per row: chunks it contributes, chunks that need a partial slot (rows longer than one chunk), "is long" flag
+    __global__ __launch_bounds__(256) void sell_rowinfo_kernel(const uint* __restrict__ Ap, uint n_rows, uint* __restrict__ vcount, uint* __restrict__ pcount,
+                                                               uint* __restrict__ lflag) {
+        const uint row = blockIdx.x * 256 + threadIdx.x;
+        if (row > n_rows) return;
+        uint c = 0, l = 0;
+        if (row < n_rows) {
+            const uint len = Ap[row + 1] - Ap[row];
+            c              = (len + SC::kC - 1) / SC::kC;
+            l              = len > SC::kC ? 1u : 0u;
+        }
+        vcount[row] = c;// entry n_rows = 0: the scans run over n_rows + 1 values so their last output is the total
+        pcount[row] = l ? c : 0u;
+        lflag[row]  = l;
+    }
+    // per row: its chunks in row order (the stable sort below keeps a long row's chunks adjacent and ascending)
+    __global__ __launch_bounds__(256) void sell_emit_kernel(const uint* __restrict__ Ap, uint n_rows, const uint* __restrict__ vfirst, const uint* __restrict__ pfirst,
+                                                            const uint* __restrict__ lfirst, uint* __restrict__ q_key, uint* __restrict__ q_id, uint* __restrict__ q_row,
+                                                            uint* __restrict__ q_len, uint* __restrict__ q_k0, uint* __restrict__ q_slot, uint* __restrict__ lr_row,
+                                                            uint* __restrict__ lr_first) {
+        const uint row = blockIdx.x * 256 + threadIdx.x;
+        if (row >= n_rows) return;
+        const uint k0  = Ap[row];
+        const uint len = Ap[row + 1] - k0;
+        if (len == 0) return;
+        const bool is_long = len > SC::kC;
+        const uint nch     = (len + SC::kC - 1) / SC::kC;
+        const uint q0      = vfirst[row];
+        const uint p0      = pfirst[row];
+        for (uint c = 0; c < nch; ++c) {
+            const uint clen = min(SC::kC, len - c * SC::kC);
+            const uint q    = q0 + c;
+            q_key[q]        = SC::kC - clen;// ascending key = descending length
+            q_id[q]         = q;
+            q_row[q]        = row | (is_long ? SC::kPartial : 0u);
+            q_len[q]        = clen;
+            q_k0[q]         = k0 + c * SC::kC;
+            q_slot[q]       = is_long ? p0 + c : 0u;
+        }
+        if (is_long) {
+            lr_row[lfirst[row]]   = row;
+            lr_first[lfirst[row]] = p0;
+        }
+    }
+    __global__ __launch_bounds__(256) void sell_permute_kernel(uint n_chunks, uint n_vrows, const uint* __restrict__ order, const uint* __restrict__ q_row,
+                                                               const uint* __restrict__ q_len, const uint* __restrict__ q_k0, const uint* __restrict__ q_slot,
+                                                               uint* __restrict__ vrow, uint* __restrict__ vlen, uint* __restrict__ vk0, uint* __restrict__ vslot) {
+        const uint p = blockIdx.x * 256 + threadIdx.x;
+        if (p >= n_vrows) return;
+        if (p < n_chunks) {
+            const uint q = order[p];
+            vrow[p]      = q_row[q];
+            vlen[p]      = q_len[q];
+            vk0[p]       = q_k0[q];
+            vslot[p]     = q_slot[q];
+        } else {// padding lanes of the last slice
+            vrow[p] = 0x7FFFFFFFu;
+            vlen[p] = vk0[p] = vslot[p] = 0;
+        }
+    }
+    __global__ __launch_bounds__(256) void sell_width_kernel(const uint* __restrict__ vlen, uint n_slices, uint* __restrict__ slots) {
+        const uint s = blockIdx.x * 256 + threadIdx.x;
+        if (s <= n_slices) slots[s] = s < n_slices ? vlen[s * kWave] * kWave : 0u;// sorted descending: lane 0 holds the slice's width
+    }
+    // column reference counts -> the n_hot most referenced columns get an LDS slot
+    __global__ __launch_bounds__(256) void sell_col_count_kernel(const uint* __restrict__ Aj, uint nnz, uint* __restrict__ count) {
+        const uint k = blockIdx.x * 256 + threadIdx.x;
+        if (k < nnz) atomicAdd(&count[Aj[k]], 1u);
+    }
+    __global__ __launch_bounds__(256) void sell_col_key_kernel(const uint* __restrict__ count, uint n_cols, uint* __restrict__ key, uint* __restrict__ col) {
+        const uint j = blockIdx.x * 256 + threadIdx.x;
+        if (j < n_cols) {
+            key[j] = ~count[j];// ascending ~count = descending count; the stable sort keeps ascending column order among ties
+            col[j] = j;
+        }
+    }
+    __global__ __launch_bounds__(256) void sell_slot_kernel(const uint* __restrict__ sorted_col, uint n_hot, uint* __restrict__ slot_of, uint* __restrict__ hot_cols) {
+        const uint s = blockIdx.x * 256 + threadIdx.x;
+        if (s < n_hot) {
+            hot_cols[s]            = sorted_col[s];
+            slot_of[sorted_col[s]] = s;
+        }
+    }
+    // one wave per slice: lane l copies chunk l into the slice's column-major block, re-encoding hot columns; the rest of the
+    // lane's column is padding that reads slot 0 of the hot table and multiplies by a zero word (never folded)
+    __global__ __launch_bounds__(256) void sell_fill_kernel(uint n_slices, const uint* __restrict__ off, const uint* __restrict__ vlen, const uint* __restrict__ vk0,
+                                                            const uint* __restrict__ Aj, const uint* __restrict__ Ax, const uint* __restrict__ slot_of,
+                                                            uint* __restrict__ Aj2, uint* __restrict__ Ax2) {
+        const uint s = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+        if (s >= n_slices) return;
+        const uint lane  = lane_id();
+        const uint base  = off[s];
+        const uint width = (off[s + 1] - base) / kWave;
+        const uint len   = vlen[s * kWave + lane];
+        const uint k0    = vk0[s * kWave + lane];
+        for (uint e = 0; e < width; ++e) {
+            uint j = SC::kHotFlag, x = 0;
+            if (e < len) {
+                const uint col  = Aj[k0 + e];
+                const uint slot = slot_of[col];
+                j               = slot != 0xFFFFFFFFu ? (slot | SC::kHotFlag) : col;
+                x               = Ax[k0 + e];
+            }
+            Aj2[base + e * kWave + lane] = j;
+            Ax2[base + e * kWave + lane] = x;
+        }
+    }
+    __global__ __launch_bounds__(256) void sell_tail_kernel(uint first, uint count, uint* __restrict__ Aj2, uint* __restrict__ Ax2) {
+        const uint k = blockIdx.x * 256 + threadIdx.x;
+        if (k < count) {
+            Aj2[first + k] = SC::kHotFlag;
+            Ax2[first + k] = 0;
+        }
+    }
+
+    constexpr uint kTail = 2 * SC::kU * kWave;// read-ahead of the last slice's group prefetch
+
+    struct Scratch {
+        std::vector<void*> ptrs;
+        ~Scratch() {
+            for (void* p : ptrs)
+                if (p) (void) hipFree(p);
+        }
+        hipError_t alloc(uint32_t** out, size_t words) {
+            void*      p = nullptr;
+            hipError_t e = hipMalloc(&p, sizeof(uint32_t) * (words ? words : 1));
+            if (e == hipSuccess) ptrs.push_back(p);
+            *out = static_cast<uint32_t*>(p);
+            return e;
+        }
+    };
+
+    hipError_t exclusive_scan_u32(uint32_t* in, uint32_t* out, size_t n, hipStream_t s) {
+        size_t     bytes = 0;
+        hipError_t e     = rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), s);
+        if (e != hipSuccess) return e;
+        void* tmp = nullptr;
+        e         = hipMalloc(&tmp, bytes ? bytes : 4);
+        if (e != hipSuccess) return e;
+        e = rocprim::exclusive_scan(tmp, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void) hipFree(tmp);
+        return e;
+    }
+    hipError_t stable_sort_pairs(uint32_t* key, uint32_t* key_s, uint32_t* val, uint32_t* val_s, size_t n, unsigned bits, hipStream_t s) {
+        size_t     bytes = 0;
+        hipError_t e     = rocprim::radix_sort_pairs(nullptr, bytes, key, key_s, val, val_s, n, 0, bits, s);
+        if (e != hipSuccess) return e;
+        void* tmp = nullptr;
+        e         = hipMalloc(&tmp, bytes ? bytes : 4);
+        if (e != hipSuccess) return e;
+        e = rocprim::radix_sort_pairs(tmp, bytes, key, key_s, val, val_s, n, 0, bits, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void) hipFree(tmp);
+        return e;
+    }
+
+    uint compute_units() {
+        static uint cus = 0;
+        if (!cus) {
+            int             dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = (uint) prop.multiProcessorCount;
+            if (!cus) cus = 256;
+        }
+        return cus;
+    }
+
+    template<typename T, class Mult, class Add>
+    int launch_sell(const splahip_plan_s* plan, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
+                    uint32_t init_bits, hipStream_t st) {
+        const splahip_sell_s* g = plan->sell;
+        if (g->n_hot)
+            hipLaunchKernelGGL((sell_hot_pack_kernel<T>), dim3((g->n_hot + 255) / 256), dim3(256), 0, st, g->d_hot_cols, g->n_hot, static_cast<const T*>(v),
+                               reinterpret_cast<T*>(g->d_hot_vals));
+        const uint grid = compute_units();
+        hipLaunchKernelGGL((sell_mxv_kernel<T, Mult, Add>), dim3(grid), dim3(SC::kTpb), 0, st, plan->n_rows, Ap, g->n_slices, g->d_vrow, g->d_vlen, g->d_vslot,
+                           g->d_off, g->d_Aj2, g->d_Ax2, reinterpret_cast<const T*>(g->d_hot_vals), g->n_hot, static_cast<const T*>(mask),
+                           static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(g->d_partial), Mult(op_mult), Add(op_add), op_select,
+                           from_bits<T>(init_bits));
+        SPLAHIP_TRY(hipGetLastError());
+        if (g->n_lrows) {
+            hipLaunchKernelGGL((sell_combine_kernel<T, Add>), dim3((g->n_lrows + 255) / 256), dim3(256), 0, st, g->n_lrows, g->d_lr_row, g->d_lr_first,
+                               reinterpret_cast<const T*>(g->d_partial), static_cast<const T*>(mask), static_cast<T*>(r), Add(op_add), op_select,
+                               from_bits<T>(init_bits));
+            SPLAHIP_TRY(hipGetLastError());
+        }
+        return SPLAHIP_OK;
+    }
+
+#define SPLAHIP_SELL(MUL, ADD) launch_sell<T, StaBin<MUL>, StaBin<ADD>>(plan, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st)
+    template<typename T>
+    int sell_typed(const splahip_plan_s* plan, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
+                   uint32_t init_bits, hipStream_t st) {
+        constexpr int type = TypeId<T>::value;
+        if (op_mult == SPLAHIP_MULT && op_add == SPLAHIP_PLUS) return SPLAHIP_SELL(SPLAHIP_MULT, SPLAHIP_PLUS);
+        if (op_mult == SPLAHIP_PLUS && op_add == SPLAHIP_MIN) return SPLAHIP_SELL(SPLAHIP_PLUS, SPLAHIP_MIN);
+        if (op_mult == SPLAHIP_LAND && op_add == SPLAHIP_LOR) return SPLAHIP_SELL(SPLAHIP_LAND, SPLAHIP_LOR);
+        if constexpr (type != SPLAHIP_FLOAT) {
+            if (op_mult == SPLAHIP_BAND && op_add == SPLAHIP_BOR) return SPLAHIP_SELL(SPLAHIP_BAND, SPLAHIP_BOR);
+        }
+        return launch_sell<T, DynBin, DynBin>(plan, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+    }
+#undef SPLAHIP_SELL
+
+}// namespace
+
+namespace splahip {
+
+    void sell_release(splahip_sell_s* g) {
+        if (!g) return;
+        for (uint32_t* p : {g->d_vrow, g->d_vlen, g->d_vslot, g->d_off, g->d_Aj2, g->d_Ax2, g->d_hot_cols, g->d_hot_vals, g->d_lr_row, g->d_lr_first, g->d_partial})
+            if (p) (void) hipFree(p);
+        delete g;
+    }
+
+    int sell_mxv(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
+                 uint32_t init_bits, void* stream) {
+        hipStream_t st = as_stream(stream);
+        switch (type) {
+            case SPLAHIP_INT: return sell_typed<int32_t>(plan, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+            case SPLAHIP_UINT: return sell_typed<uint32_t>(plan, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+            case SPLAHIP_FLOAT: return sell_typed<float>(plan, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+        }
+        return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
+    }
+
+}// namespace splahip
+
+extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, void* stream) {
+    SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
+    SPLAHIP_REQUIRE(n_cols < SC::kHotFlag, "n_cols must be < 2^31");
+    if (plan->sell) {
+        sell_release(plan->sell);
+        plan->sell = nullptr;
+    }
+    if (plan->nnz == 0 || plan->n_rows == 0 || n_cols == 0) return SPLAHIP_OK;// nothing to lay out: mxv keeps the CSR kernels
+    SPLAHIP_REQUIRE(d_Ap && d_Aj && d_Ax, "null device pointer");
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    hipStream_t    s      = as_stream(stream);
+    const uint32_t n_rows = plan->n_rows, nnz = plan->nnz;
+
+    Scratch   tmp;
+    auto*     g = new splahip_sell_s();
+    g->n_cols   = n_cols;
+    hipError_t e = hipSuccess;
+    auto       bail = [&](const char* what) {
+        sell_release(g);
+        return fail(SPLAHIP_ERROR, "sliced-ELL plan failed (%s): %s", what, hipGetErrorString(e));
+    };
+
+    // 1. chunks per row, partial slots per long row, long-row index: three exclusive scans over n_rows + 1 counters
+    uint32_t *vcount, *pcount, *lflag, *vfirst, *pfirst, *lfirst;
+    for (uint32_t** q : {&vcount, &pcount, &lflag, &vfirst, &pfirst, &lfirst})
+        if (e == hipSuccess) e = tmp.alloc(q, (size_t) n_rows + 1);
+    if (e != hipSuccess) return bail("scratch");
+    hipLaunchKernelGGL(sell_rowinfo_kernel, dim3((n_rows + 256) / 256), dim3(256), 0, s, d_Ap, n_rows, vcount, pcount, lflag);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = exclusive_scan_u32(vcount, vfirst, (size_t) n_rows + 1, s);
+    if (e == hipSuccess) e = exclusive_scan_u32(pcount, pfirst, (size_t) n_rows + 1, s);
+    if (e == hipSuccess) e = exclusive_scan_u32(lflag, lfirst, (size_t) n_rows + 1, s);
+    uint32_t n_chunks = 0;
+    if (e == hipSuccess) e = hipMemcpy(&n_chunks, vfirst + n_rows, 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&g->n_partials, pfirst + n_rows, 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&g->n_lrows, lfirst + n_rows, 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return bail("row scan");
+    g->n_vrows  = (n_chunks + kWave - 1) / kWave * kWave;
+    g->n_slices = g->n_vrows / kWave;
+
+    // 2. chunks in row order -> stable sort by descending length
+    uint32_t *q_key, *q_id, *q_row, *q_len, *q_k0, *q_slot, *key_s, *order, *vk0;
+    for (uint32_t** q : {&q_key, &q_id, &q_row, &q_len, &q_k0, &q_slot, &key_s, &order})
+        if (e == hipSuccess) e = tmp.alloc(q, n_chunks);
+    if (e == hipSuccess) e = tmp.alloc(&vk0, g->n_vrows);
+    auto own = [&](uint32_t** q, size_t words) {
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(q), sizeof(uint32_t) * (words ? words : 1));
+    };
+    own(&g->d_vrow, g->n_vrows);
+    own(&g->d_vlen, g->n_vrows);
+    own(&g->d_vslot, g->n_vrows);
+    own(&g->d_off, (size_t) g->n_slices + 1);
+    own(&g->d_lr_row, g->n_lrows);
+    own(&g->d_lr_first, (size_t) g->n_lrows + 1);
+    own(&g->d_partial, g->n_partials);
+    if (e != hipSuccess) return bail("chunk arrays");
+    hipLaunchKernelGGL(sell_emit_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, d_Ap, n_rows, vfirst, pfirst, lfirst, q_key, q_id, q_row, q_len, q_k0, q_slot,
+                       g->d_lr_row, g->d_lr_first);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(g->d_lr_first + g->n_lrows, &g->n_partials, 4, hipMemcpyHostToDevice, s);
+    unsigned key_bits = 1;
+    while ((1u << key_bits) < SC::kC) ++key_bits;// keys are kC - len in [0, kC)
+    if (e == hipSuccess) e = stable_sort_pairs(q_key, key_s, q_id, order, n_chunks, key_bits, s);
+    if (e != hipSuccess) return bail("chunk sort");
+    hipLaunchKernelGGL(sell_permute_kernel, dim3((g->n_vrows + 255) / 256), dim3(256), 0, s, n_chunks, g->n_vrows, order, q_row, q_len, q_k0, q_slot, g->d_vrow,
+                       g->d_vlen, vk0, g->d_vslot);
+
+    // 3. slice offsets
+    uint32_t* slots = nullptr;
+    e               = tmp.alloc(&slots, (size_t) g->n_slices + 1);
+    if (e != hipSuccess) return bail("slice scratch");
+    hipLaunchKernelGGL(sell_width_kernel, dim3((g->n_slices + 256) / 256), dim3(256), 0, s, g->d_vlen, g->n_slices, slots);
+    e = hipGetLastError();
+    // the padded entry count must stay below 2^32 (offsets are 32-bit); padding is < 1 % after a global sort, so check the bound up front
+    if (e == hipSuccess && (uint64_t) nnz + (uint64_t) g->n_slices * kWave * 2 >= 0xF0000000ull) {
+        sell_release(g);
+        return fail(SPLAHIP_NOT_IMPLEMENTED, "matrix too large for 32-bit slice offsets");
+    }
+    if (e == hipSuccess) e = exclusive_scan_u32(slots, g->d_off, (size_t) g->n_slices + 1, s);
+    if (e == hipSuccess) e = hipMemcpy(&g->n_slots, g->d_off + g->n_slices, 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return bail("slice scan");
+    own(&g->d_Aj2, (size_t) g->n_slots + kTail);
+    own(&g->d_Ax2, (size_t) g->n_slots + kTail);
+
+    // 4. hot columns: the n_hot most referenced ones (stable: ties keep ascending column order)
+    g->n_hot = n_cols < SC::kHot ? n_cols : SC::kHot;
+    uint32_t *count, *ckey, *ccol, *ckey_s, *ccol_s, *slot_of;
+    for (uint32_t** q : {&count, &ckey, &ccol, &ckey_s, &ccol_s, &slot_of})
+        if (e == hipSuccess) e = tmp.alloc(q, n_cols);
+    own(&g->d_hot_cols, g->n_hot);
+    own(&g->d_hot_vals, (size_t) g->n_hot + 4);// whole 16-byte quads: the kernel copies the table with uint4 loads
+    if (e == hipSuccess) e = hipMemsetAsync(count, 0, sizeof(uint32_t) * (size_t) n_cols, s);
+    if (e == hipSuccess) e = hipMemsetAsync(slot_of, 0xFF, sizeof(uint32_t) * (size_t) n_cols, s);
+    if (e != hipSuccess) return bail("hot-column arrays");
+    hipLaunchKernelGGL(sell_col_count_kernel, dim3((nnz + 255) / 256), dim3(256), 0, s, d_Aj, nnz, count);
+    hipLaunchKernelGGL(sell_col_key_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, s, count, n_cols, ckey, ccol);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = stable_sort_pairs(ckey, ckey_s, ccol, ccol_s, n_cols, 32, s);
+    if (e != hipSuccess) return bail("hot-column sort");
+    hipLaunchKernelGGL(sell_slot_kernel, dim3((g->n_hot + 255) / 256), dim3(256), 0, s, ccol_s, g->n_hot, slot_of, g->d_hot_cols);
+
+    // 5. the entries
+    hipLaunchKernelGGL(sell_fill_kernel, dim3((g->n_slices + 3) / 4), dim3(256), 0, s, g->n_slices, g->d_off, g->d_vlen, vk0, d_Aj,
+                       static_cast<const uint32_t*>(d_Ax), slot_of, g->d_Aj2, g->d_Ax2);
+    hipLaunchKernelGGL(sell_tail_kernel, dim3((kTail + 255) / 256), dim3(256), 0, s, g->n_slots, kTail, g->d_Aj2, g->d_Ax2);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return bail("fill");
+    plan->sell = g;
+    return SPLAHIP_OK;
+}
+
+extern "C" int splahip_csr_plan_sell_info(splahip_plan plan, uint32_t* n_slices, uint32_t* n_slots, uint32_t* n_hot, uint32_t* n_long_rows) {
+    SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
+    const splahip_sell_s* g = plan->sell;
+    if (n_slices) *n_slices = g ? g->n_slices : 0;
+    if (n_slots) *n_slots = g ? g->n_slots : 0;
+    if (n_hot) *n_hot = g ? g->n_hot : 0;
+    if (n_long_rows) *n_long_rows = g ? g->n_lrows : 0;
+    return SPLAHIP_OK;
+}

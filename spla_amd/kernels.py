@@ -34,19 +34,31 @@ def current_stream_ptr():
 class CsrPlan:
     """Wave-tile work decomposition of one device CSR matrix (splahip_csr_plan_*)."""
 
-    def __init__(self, n_rows: int, nnz: int, Ap: torch.Tensor, n_cols: int = 0, Aj: torch.Tensor = None):
-        """Ap alone gives the wave-tile decomposition; with (n_cols, Aj) the plan also builds the hot-column cache that the
-        persistent mxv kernel uses."""
+    def __init__(self, n_rows: int, nnz: int, Ap: torch.Tensor, n_cols: int = 0, Aj: torch.Tensor = None, Ax: torch.Tensor = None):
+        """Ap alone gives the wave-tile decomposition of the CSR kernels.  With (n_cols, Aj, Ax) the plan also builds the
+        sliced-ELL + hot-column copy that mxv uses for associative op_add (attach_sell).  With (n_cols, Aj) only: the
+        experimental persistent CSR kernel's hot-column table (attach_columns, SPLAHIP_HOT=1)."""
         self.n_rows, self.nnz = int(n_rows), int(nnz)
         self.hot = False
+        self.sell = None
         self._h = C.c_void_p()
         _lib.call("splahip_csr_plan_create", C.byref(self._h), self.n_rows, self.nnz, _ptr(Ap), current_stream_ptr())
         nb, nl = C.c_uint32(), C.c_uint32()
         _lib.call("splahip_csr_plan_info", self._h, C.byref(nb), C.byref(nl))
         self.n_items, self.n_long = nb.value, nl.value
         self.n_blocks = self.n_items  # work items (one per wavefront)
-        if Aj is not None and n_cols:
+        if Aj is not None and Ax is not None and n_cols:
+            self.attach_sell(n_cols, Ap, Aj, Ax)
+        elif Aj is not None and n_cols:
             self.attach_columns(n_cols, Aj)
+
+    def attach_sell(self, n_cols: int, Ap: torch.Tensor, Aj: torch.Tensor, Ax: torch.Tensor):
+        """sliced-ELL + hot-column copy of the matrix (values included: rebuild when the matrix changes)"""
+        _lib.call("splahip_csr_plan_attach_sell", self._h, int(n_cols), _ptr(Ap), _ptr(Aj) if self.nnz else None, _ptr(Ax) if self.nnz else None,
+                  current_stream_ptr())
+        a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _lib.call("splahip_csr_plan_sell_info", self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        self.sell = {"slices": a.value, "slots": b.value, "hot_columns": c.value, "long_rows": d.value} if a.value else None
 
     def attach_columns(self, n_cols: int, Aj: torch.Tensor):
         _lib.call("splahip_csr_plan_attach_columns", self._h, int(n_cols), _ptr(Aj) if self.nnz else None, current_stream_ptr())
@@ -77,7 +89,10 @@ def mxv_masked(plan: CsrPlan, t, n_cols, Ap, Aj, Ax, mask, v, r, op_mult, op_add
     return r
 
 
-def mxv_variant(t, op_mult, op_add, early_exit=False) -> str:
+def mxv_variant(t, op_mult, op_add, early_exit=False, plan: CsrPlan = None) -> str:
+    """name of the kernel splahip_mxv_masked picks (with `plan`: its sliced-ELL copy taken into account)"""
+    if plan is not None:
+        return _lib.call("splahip_mxv_variant_of", plan.handle, type_id(t), binop_id(op_mult), binop_id(op_add), 1 if early_exit else 0).decode()
     return _lib.call("splahip_mxv_variant", type_id(t), binop_id(op_mult), binop_id(op_add), 1 if early_exit else 0).decode()
 
 

@@ -21,25 +21,37 @@ def host(t: torch.Tensor, np_dtype) -> np.ndarray:
 
 
 def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, init, early_exit=False, junk=None):
-    """Run the masked SpMV twice — the product path (non-persistent wave-tile kernel) and the experimental persistent
-    LDS-hot-cache kernel (SPLAHIP_HOT=1) — assert both give bit-identical results (same work items, same fold order) and
-    return the product path's result."""
+    """Run the masked SpMV three times — the CSR wave-tile / row kernels (SPLAHIP_SELL=0), the experimental persistent
+    LDS-hot-cache CSR kernel (SPLAHIP_HOT=1) and the product path (sliced-ELL copy attached) — and cross-check them: the two CSR
+    forms are bit-identical (same work items, same fold order); the sliced-ELL form is bit-identical for int / uint and within
+    1e-5 for fp32 (it folds every row <= 256 entries strictly in entry order, the CSR form uses an in-order tree for rows > 32).
+    Returns the product path's result."""
     from helpers import NP
     dAp, dAj, dAx, dm, dv = dev(Ap), dev(Aj), dev(np.asarray(Ax, NP[t])), dev(np.asarray(mask, NP[t])), dev(np.asarray(v, NP[t]))
     import os
-    outs = []
-    for hot in (False, True):
-        plan = kernels.CsrPlan(n_rows, len(Aj), dAp, n_cols if hot else 0, dAj if hot else None)
+    outs = {}
+    for form in ("csr", "hot", "sell"):
+        if form == "sell":
+            plan = kernels.CsrPlan(n_rows, len(Aj), dAp, n_cols, dAj, dAx)
+        else:
+            plan = kernels.CsrPlan(n_rows, len(Aj), dAp, n_cols if form == "hot" else 0, dAj if form == "hot" else None)
         r = torch.empty(n_rows, dtype=kernels.torch_dtype(t), device="cuda")
         if junk is not None:
             r.fill_(junk)
-        os.environ["SPLAHIP_HOT"] = "1" if hot else "0"  # the persistent kernel is experimental: switched on per call here
+        os.environ["SPLAHIP_HOT"] = "1" if form == "hot" else "0"  # the persistent CSR kernel is experimental: switched on per call here
         try:
             kernels.mxv_masked(plan, t, n_cols, dAp, dAj, dAx, dm, dv, r, op_mult, op_add, op_select, init, early_exit)
             torch.cuda.synchronize()
         finally:
             os.environ["SPLAHIP_HOT"] = "0"
-        outs.append(host(r, NP[t]))
+        outs[form] = host(r, NP[t])
         plan.close()
-    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), "hot-cache kernel differs from the wave-tile kernel"
-    return outs[0]
+    assert np.array_equal(outs["csr"].view(np.uint32), outs["hot"].view(np.uint32)), "hot-cache kernel differs from the wave-tile kernel"
+    if t == "FLOAT":
+        a, b = outs["sell"].astype(np.float64), outs["csr"].astype(np.float64)
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isinf(a), np.isinf(b)), "sliced-ELL kernel differs from the CSR kernels"
+        fin = np.isfinite(a) & np.isfinite(b)
+        assert np.all(np.abs(a[fin] - b[fin]) <= 1e-5 * np.maximum(np.abs(b[fin]), 1e-30) + 1e-30), "sliced-ELL kernel differs from the CSR kernels"
+    else:
+        assert np.array_equal(outs["sell"], outs["csr"]), "sliced-ELL kernel differs from the CSR kernels"
+    return outs["sell"]
