@@ -63,7 +63,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-variants", action="store_true")
     p.add_argument("--no-verify", action="store_true")
-    p.add_argument("--workload", default="bfs-step", choices=["bfs-step", "pagerank-vxm", "sssp-step", "tc-mxmT", "mxm"],
+    p.add_argument("--workload", default="bfs-step", choices=["bfs-step", "pagerank-vxm", "sssp-step", "tc-mxmT", "mxm", "algorithms"],
                    help="bfs-step (default, the contract line) or one of the other hot-path operators (bench_workloads.py; N = 1 only)")
     return p.parse_args()
 
@@ -385,15 +385,16 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
     n_local, nnz_local = sh.n_local, g["nnz_local"]
     steps = max(10, args.steps // 2)
 
-    def run(name, t, Ax, m, v, r, mul, add, sel, init, early, nnz_sel):
-        fn = lambda: kernels.mxv_masked(sh.plan, t, sh.n_cols_padded, g["Ap"], g["Aj"], Ax, m, v, r, mul, add, sel, init, early_exit=early)
+    def run(name, t, Ax, m, v, r, mul, add, sel, init, early, nnz_sel, plan=None):
+        plan = plan or sh.plan
+        fn = lambda: kernels.mxv_masked(plan, t, sh.n_cols_padded, g["Ap"], g["Aj"], Ax, m, v, r, mul, add, sel, init, early_exit=early)
         _, per = timed(fn, steps, 3)
         ms = float(np.mean(per))
         b = 8 * nnz_sel + 4 * (n_local + 1) + 8 * n_local + 4 * sh.n_cols_padded
         tot = torch.tensor([nnz_sel], device=coll_device(), dtype=torch.int64)
         if world > 1:
             dist.all_reduce(tot)
-        res.append({"name": name, "kernel": kernel_name(sh.plan, t, mul, add, early), "kernel_avg_us": round(ms * 1e3, 2),
+        res.append({"name": name, "kernel": kernels.mxv_variant(t, mul, add, early, plan) if plan is not sh.plan else kernel_name(sh.plan, t, mul, add, early), "kernel_avg_us": round(ms * 1e3, 2),
                     "gteps_local": round(nnz_sel / (ms * 1e-3) / 1e9, 2), "hbm_gbs": round(b / (ms * 1e-3) / 1e9, 1),
                     "roofline_frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "nnz_selected_local": nnz_sel})
 
@@ -413,6 +414,23 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
     d_i = torch.full((sh.n_cols_padded,), 1 << 30, dtype=torch.int32, device="cuda")
     d_i[torch.randint(0, sh.n_cols_padded, (sh.n_cols_padded // 8,), generator=gen, device="cuda")] = 1000
     run("all rows selected, PLUS/MIN int32 (SSSP step)", "INT", w_i, zeros_i, d_i, r_i, "PLUS", "MIN", "ALWAYS", 1 << 30, False, nnz_local)
+    # the opt-in sliced-ELL + LDS hot-column copy of the same matrix (splahip_csr_plan_attach_sell), for the record
+    r_ref = r_f.clone()
+    sell_f = kernels.CsrPlan(n_local, nnz_local, g["Ap"], sh.n_cols_padded, g["Aj"], Ax_f)
+    run("all rows selected, MULT/PLUS fp32, sliced-ELL copy (opt-in)", "FLOAT", Ax_f, zeros_f, v_f, r_f, "MULT", "PLUS", "ALWAYS", 0.0, False, nnz_local, plan=sell_f)
+    run("all rows selected, MULT/PLUS fp32", "FLOAT", Ax_f, zeros_f, v_f, r_ref, "MULT", "PLUS", "ALWAYS", 0.0, False, nnz_local)
+    res.pop()  # (re-run of the CSR form only to have its result at hand for the comparison)
+    rel = ((r_f - r_ref).abs() / r_ref.abs().clamp_min(1e-30)).max().item() if n_local else 0.0
+    res[-1]["max_rel_vs_csr_kernel"] = rel
+    res[-1]["plan"] = sell_f.sell
+    sell_f.close()
+    sell_i = kernels.CsrPlan(n_local, nnz_local, g["Ap"], sh.n_cols_padded, g["Aj"], ones_i)
+    r_chk = torch.empty_like(r_i)
+    run("bfs-step early_exit=false, sliced-ELL copy (opt-in)", "INT", ones_i, mask, v_full, r_chk, "BAND", "BOR", "EQZERO", 0, False, nnz_sel_local, plan=sell_i)
+    kernels.mxv_masked(sh.plan, "INT", sh.n_cols_padded, g["Ap"], g["Aj"], ones_i, mask, v_full, r_i, "BAND", "BOR", "EQZERO", 0)
+    torch.cuda.synchronize()
+    res[-1]["identical_to_csr_kernel"] = bool(torch.equal(r_chk, r_i))
+    sell_i.close()
     return res
 
 

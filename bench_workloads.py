@@ -8,6 +8,9 @@ the oracle, the genuine reference CPU backend timed beside it on a bounded sampl
     tc-mxmT      : exec_mxmT_masked(L, L, L) MULT/PLUS/GTZERO int32, L = strict lower triangle of symmetrised R-MAT scale 20
                    (BASELINE configs[4], triangle-count form)
     mxm          : exec_mxm plus-times fp32 A x A on R-MAT (BASELINE configs[4]; scale chosen so the expanded products fit)
+    algorithms   : bfs / sssp / pr / tc end to end through the operator API (spla_Algorithm_*, every step on the device), on a
+                   symmetrised R-MAT; wall-clock per call including the per-iteration host synchronisations, like the reference's
+                   own whole-algorithm charts
 """
 from __future__ import annotations
 
@@ -366,4 +369,103 @@ def mxm(args):
     return line
 
 
-WORKLOADS = {"pagerank-vxm": pagerank_vxm, "sssp-step": sssp_step, "tc-mxmT": tc_mxmT, "mxm": mxm}
+# ------------------------------------------------------------------------------------------------------- algorithms
+def algorithms(args):
+    """End-to-end graph algorithms over exec_* on the HIP accelerator (spla_amd/csrc/host/algorithms.cpp)."""
+    from oracle import pyoracle
+    from spla_amd import api
+    scale = args.scale if args.scale != 22 else 20
+    n, Ap, Aj = _sym_rmat(scale, args.edge_factor, args.seed)
+    nnz = int(Ap[-1])
+    Ap_h, Aj_h = Ap.cpu().numpy().astype(np.uint32), Aj.cpu().numpy().astype(np.uint32)
+    I_h = np.repeat(np.arange(n, dtype=np.uint32), np.diff(Ap_h.astype(np.int64)))
+    deg = np.diff(Ap_h.astype(np.int64))
+    src = int(np.argmax(deg))
+    rng = np.random.default_rng(args.seed)
+    lo, hi = np.minimum(I_h, Aj_h).astype(np.int64), np.maximum(I_h, Aj_h).astype(np.int64)
+    W_h = (((lo * 2654435761 + hi * 40503) % 255) + 1).astype(np.float32)  # symmetric weights 1..255
+    P_h = (np.float32(0.85) / deg[Aj_h].astype(np.float32)).astype(np.float32)
+    keep = Aj_h < I_h
+    Lp_h = np.zeros(n + 1, np.uint32)
+    np.cumsum(np.bincount(I_h[keep], minlength=n), out=Lp_h[1:])
+    _log(f"[algorithms] symmetrised R-MAT scale {scale}: n={n} nnz={nnz} max degree {int(deg.max())} source {src}")
+    oracle = pyoracle.Oracle()
+    res = {}
+
+    def timed(name, fn, reps):
+        fn()  # first call: host COO -> CSR conversion, upload and plans
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        _log(f"[algorithms] {name}: {1e3 * float(np.median(ts)):.2f} ms (median of {reps})")
+        return out, float(np.median(ts))
+
+    A = api.Matrix.from_lists(I_h, Aj_h, np.ones(nnz, np.int32), (n, n), api.INT)
+    want = oracle.bfs(n, Ap_h, Aj_h, src)
+    reached_edges = int(deg[want > 0].sum())
+    for label, desc in (("push-pull (default)", None), ("pull only", api.Descriptor(traversal_mode=api.Descriptor.PULL)), ("push only", api.Descriptor(traversal_mode=api.Descriptor.PUSH))):
+        lv, dt = timed(f"bfs {label}", lambda d=desc: api.bfs(A, src, d), 5)
+        ok = bool(np.array_equal(lv.to_dense() if n <= (1 << 16) else _dense_i(lv, n), want))
+        res[f"bfs {label}"] = {"ms": round(dt * 1e3, 3), "gteps": round(reached_edges / dt / 1e9, 3), "levels": int(want.max()), "verified": ok}
+    del A
+    Wm = api.Matrix.from_lists(I_h, Aj_h, W_h, (n, n), api.FLOAT)
+    want = oracle.sssp(n, Ap_h, Aj_h, W_h, src)
+    dv, dt = timed("sssp push-pull", lambda: api.sssp(Wm, src), 3)
+    res["sssp push-pull (default)"] = {"ms": round(dt * 1e3, 3), "verified": bool(np.array_equal(_dense_f(dv, n).view(np.uint32), want.view(np.uint32)))}
+    del Wm
+    Pm = api.Matrix.from_lists(I_h, Aj_h, P_h, (n, n), api.FLOAT)
+    pv, dt = timed("pr alpha 0.85 eps 1e-5", lambda: api.pr(Pm, 0.85, 1e-5), 3)
+    want = oracle.pr(n, Ap_h, Aj_h, P_h, 0.85, 1e-5)
+    got = _dense_f(pv, n, fill=0.0)
+    res["pr alpha 0.85 eps 1e-5"] = {"ms": round(dt * 1e3, 3), "max_abs_vs_oracle": float(np.abs(got - want).max()), "verified": bool(np.allclose(got, want, rtol=1e-3, atol=1e-8))}
+    del Pm
+    Lm = api.Matrix.from_lists(I_h[keep], Aj_h[keep], np.ones(int(keep.sum()), np.int32), (n, n), api.INT)
+    (cnt, B), dt = timed("tc", lambda: api.tc(Lm), 3)
+    res["tc"] = {"ms": round(dt * 1e3, 3), "triangles": int(cnt)}
+    if scale <= 16:
+        res["tc"]["verified"] = bool(cnt == oracle.tc(n, Lp_h, Aj_h[keep])[0])
+    del Lm, B
+
+    # reference CPU backend, same graph, bfs only (1 core; bounded: one call)
+    cpu = None
+    try:
+        ref = pyoracle.Reference()
+        t0 = time.perf_counter()
+        lv = ref.bfs(n, Ap_h, Aj_h, src)
+        dt = time.perf_counter() - t0
+        cpu = {"value": round(reached_edges / dt / 1e9, 4), "unit": "GTEPS", "cores": 1, "kind": "reference",
+               "sample": "spla_Algorithm_bfs (push-pull) of the genuine reference on the same graph, one call incl. its format conversions",
+               "host_cpus": os.cpu_count(), "ms": round(dt * 1e3, 1), "matches_hip": bool(np.array_equal(lv, oracle.bfs(n, Ap_h, Aj_h, src)))}
+    except Exception as e:  # oracle/_ref absent
+        _log("[algorithms] reference baseline skipped:", e)
+    main = res["bfs push-pull (default)"]
+    line = _line("BFS end-to-end GTEPS (spla_Algorithm_bfs on the HIP accelerator)", "GTEPS", main["gteps"], args, main["ms"], "int32",
+                 {"workload": f"bfs / sssp / pr / tc through the operator API; symmetrised R-MAT scale {scale} ef {args.edge_factor}", "n": n, "nnz": nnz, "source": src},
+                 {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                  "kernel": "whole algorithm (host-synchronised iterations): no single-kernel byte model applies"},
+                 {"algorithms": res, "verified": all(v.get("verified", True) for v in res.values())})
+    if cpu:
+        line["cpu_baseline"] = cpu
+    return line
+
+
+def _dense_i(vec, n):
+    """dense read-back of an INT vector through the C ABI's bulk read (absent entries = 0)"""
+    I, X = vec.read()
+    out = np.zeros(n, np.int32)
+    out[I] = X
+    return out
+
+
+def _dense_f(vec, n, fill=None):
+    I, X = vec.read()
+    out = np.full(n, np.float32(np.finfo(np.float32).max) if fill is None else np.float32(fill), np.float32)
+    out[I] = X
+    return out
+
+
+WORKLOADS = {"pagerank-vxm": pagerank_vxm, "sssp-step": sssp_step, "tc-mxmT": tc_mxmT, "mxm": mxm, "algorithms": algorithms}
