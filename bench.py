@@ -289,7 +289,7 @@ def main():
     # ---- verification of the timed result against the oracle (full local rows), and the CPU baseline ------------
     if rank == 0 and not args.no_verify:
         out["verified"] = verify_full(g, sh, mask, v_full, r, ones_i)
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU baseline is reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline(args, g, sh, mask, v_full, r)
 
     if not args.no_variants:
@@ -414,7 +414,9 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
     d_i = torch.full((sh.n_cols_padded,), 1 << 30, dtype=torch.int32, device="cuda")
     d_i[torch.randint(0, sh.n_cols_padded, (sh.n_cols_padded // 8,), generator=gen, device="cuda")] = 1000
     run("all rows selected, PLUS/MIN int32 (SSSP step)", "INT", w_i, zeros_i, d_i, r_i, "PLUS", "MIN", "ALWAYS", 1 << 30, False, nnz_local)
-    # the opt-in sliced-ELL + LDS hot-column copy of the same matrix (splahip_csr_plan_attach_sell), for the record
+    if world > 1:
+        return res
+    # the opt-in sliced-ELL + LDS hot-column copy of the same matrix (splahip_csr_plan_attach_sell), for the record (N = 1)
     r_ref = r_f.clone()
     sell_f = kernels.CsrPlan(n_local, nnz_local, g["Ap"], sh.n_cols_padded, g["Aj"], Ax_f)
     run("all rows selected, MULT/PLUS fp32, sliced-ELL copy (opt-in)", "FLOAT", Ax_f, zeros_f, v_f, r_f, "MULT", "PLUS", "ALWAYS", 0.0, False, nnz_local, plan=sell_f)

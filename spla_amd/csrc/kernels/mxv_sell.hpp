@@ -213,18 +213,27 @@ namespace splahip {
         }
     }
 
-    // rows longer than kC: r[row] = init (+) partial[first] (+) partial[first + 1] ... in chunk order
+    // rows longer than kC: r[row] = init (+) partial[first] (+) partial[first + 1] ... in chunk order.  One wave per row: lane l
+    // folds a contiguous run of the row's partials, then an in-order wave reduction joins the runs (associative op_add).
     template<typename T, class Add>
     __global__ __launch_bounds__(256) void sell_combine_kernel(uint n_lrows, const uint* __restrict__ lr_row, const uint* __restrict__ lr_first,
                                                                const T* __restrict__ partial, const T* __restrict__ mask, T* __restrict__ r, Add add,
                                                                int op_select, T init) {
-        const uint i = blockIdx.x * 256 + threadIdx.x;
+        const uint i = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
         if (i >= n_lrows) return;
         const uint row = lr_row[i];
         if (!eval_sel(op_select, mask[row])) return;// the main kernel's row pass wrote init
-        T acc = init;
-        for (uint k = lr_first[i]; k < lr_first[i + 1]; ++k) acc = add(acc, partial[k]);
-        r[row] = acc;
+        const uint k0 = lr_first[i], k1 = lr_first[i + 1];
+        const uint c  = (k1 - k0 + kWave - 1) / kWave;
+        const uint ks = k0 + lane_id() * c, ke = min(k1, ks + c);
+        T          acc   = init;
+        bool       valid = false;
+        for (uint k = ks; k < ke; ++k) {
+            acc   = valid ? add(acc, partial[k]) : partial[k];
+            valid = true;
+        }
+        wave_reduce_ordered(acc, valid, add);
+        if (lane_id() == 0) r[row] = valid ? add(init, acc) : init;
     }
 
 }// namespace splahip

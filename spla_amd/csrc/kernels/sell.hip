@@ -201,7 +201,7 @@ namespace {
                            from_bits<T>(init_bits));
         SPLAHIP_TRY(hipGetLastError());
         if (g->n_lrows) {
-            hipLaunchKernelGGL((sell_combine_kernel<T, Add>), dim3((g->n_lrows + 255) / 256), dim3(256), 0, st, g->n_lrows, g->d_lr_row, g->d_lr_first,
+            hipLaunchKernelGGL((sell_combine_kernel<T, Add>), dim3((g->n_lrows + 3) / 4), dim3(256), 0, st, g->n_lrows, g->d_lr_row, g->d_lr_first,
                                reinterpret_cast<const T*>(g->d_partial), static_cast<const T*>(mask), static_cast<T*>(r), Add(op_add), op_select,
                                from_bits<T>(init_bits));
             SPLAHIP_TRY(hipGetLastError());
