@@ -286,6 +286,19 @@ def main():
         "roofline": roofline,
     }
 
+    # ---- the exchange step on its own (SURVEY.md 8e reporting): all-gather time, per-link rate, overlap -----------
+    if world > 1:
+        _, per_x = timed(lambda: sh.gather(front, v_full), args.steps, 2)
+        x_ms = float(np.mean(per_x))
+        slice_bytes = 4 * sh.max_rows  # what this rank receives from EACH peer (direct all-gather over the xGMI mesh)
+        xm = torch.tensor([x_ms], device=coll_device(), dtype=torch.float64)
+        dist.all_reduce(xm, op=dist.ReduceOp.MAX)
+        out["exchange"] = {"collective": "all_gather_into_tensor (%s), padded slices" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " debug backend"), "avg_us": round(x_ms * 1e3, 2), "max_over_ranks_us": round(float(xm[0]) * 1e3, 2),
+                           "bytes_per_peer": slice_bytes, "bytes_received_per_rank": slice_bytes * (world - 1),
+                           "gbs_per_link_if_direct": round(slice_bytes / (x_ms * 1e-3) / 1e9, 2),
+                           "local_spmv_us": round(k_ms * 1e3, 2), "overlap_fraction": 0.0,
+                           "note": "exchange and local SpMV run back to back on one stream in round 1 (no overlap)"}
+
     # ---- verification of the timed result against the oracle (full local rows), and the CPU baseline ------------
     if rank == 0 and not args.no_verify:
         out["verified"] = verify_full(g, sh, mask, v_full, r, ones_i)

@@ -34,4 +34,27 @@ namespace splahip {
 
     constexpr unsigned WAVE = 64;
 
+    // Scoped, STREAM-ORDERED scratch memory (hipMallocAsync / hipFreeAsync on the call's stream): taken from the device's
+    // default memory pool, whose release threshold runtime.hip raises so that steady-state calls neither reach the driver
+    // nor synchronise the device the way hipMalloc / hipFree do.  Everything that touches the buffer must run on `stream`.
+    struct DevMem {
+        void*       p = nullptr;
+        hipStream_t s = nullptr;
+        DevMem()               = default;
+        DevMem(const DevMem&)  = delete;
+        DevMem& operator=(const DevMem&) = delete;
+        ~DevMem() { release(); }
+        void release() {
+            if (p) (void) hipFreeAsync(p, s);
+            p = nullptr;
+        }
+        hipError_t alloc(hipStream_t stream, size_t bytes) {
+            release();
+            s = stream;
+            return hipMallocAsync(&p, bytes ? bytes : 4, stream);
+        }
+        template<typename U>
+        U* as() { return static_cast<U*>(p); }
+    };
+
 }// namespace splahip

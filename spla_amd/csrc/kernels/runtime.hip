@@ -42,6 +42,15 @@ namespace splahip {
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(SPLAHIP_NO_DEVICE, "device %d is %s; this library only carries gfx950 (MI355X) code objects", device, prop.gcnArchName);
         SPLAHIP_TRY(hipSetDevice(device));
+        {// keep freed scratch (common.hpp DevMem) in the default pool instead of handing it back at every synchronisation
+            hipMemPool_t pool = nullptr;
+            if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
+                uint64_t keep = ~0ull;
+                (void) hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            } else {
+                (void) hipGetLastError();
+            }
+        }
         g_device = device;
         std::snprintf(g_arch, sizeof(g_arch), "%s", prop.gcnArchName);
         std::snprintf(g_name, sizeof(g_name), "%s", prop.name);

@@ -63,8 +63,9 @@ namespace splahip {
     template<typename T>
     int dense_to_coo(uint n, const void* d_dense, uint32_t fill_bits, void* d_idx, void* d_val, uint32_t* h_count, hipStream_t s) {
         const uint n_chunks = (n + 1023u) / 1024u;
-        uint*      d_chunk  = nullptr;
-        SPLAHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_chunk), sizeof(uint) * (size_t) (n_chunks + 1)));
+        DevMem     mem;
+        SPLAHIP_TRY(mem.alloc(s, sizeof(uint) * (size_t) (n_chunks + 1)));
+        uint*      d_chunk = mem.as<uint>();
         const T    fill = from_bits<T>(fill_bits);
         hipLaunchKernelGGL(d2c_count_kernel<T>, dim3(n_chunks), dim3(256), 0, s, static_cast<const T*>(d_dense), n, fill, d_chunk);
         hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, d_chunk, n_chunks);
@@ -73,7 +74,6 @@ namespace splahip {
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(h_count, d_chunk + n_chunks, sizeof(uint), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
-        (void) hipFree(d_chunk);
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "dense_to_coo failed: %s", hipGetErrorString(e));
         return SPLAHIP_OK;
     }

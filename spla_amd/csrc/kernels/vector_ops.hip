@@ -110,8 +110,9 @@ namespace splahip {
         *h_count = 0;
         if (nvals == 0) return SPLAHIP_OK;
         const uint n_chunks = (nvals + 1023u) / 1024u;
-        uint*      scratch  = nullptr;// changed[nvals] | newval[nvals] | chunk[n_chunks + 1]
-        SPLAHIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), sizeof(uint) * (2 * (size_t) nvals + n_chunks + 1)));
+        DevMem     mem;// changed[nvals] | newval[nvals] | chunk[n_chunks + 1]
+        SPLAHIP_TRY(mem.alloc(s, sizeof(uint) * (2 * (size_t) nvals + n_chunks + 1)));
+        uint* scratch = mem.as<uint>();
         uint* changed = scratch;
         uint* newval  = scratch + nvals;
         uint* chunk   = newval + nvals;
@@ -123,7 +124,6 @@ namespace splahip {
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(h_count, chunk + n_chunks, sizeof(uint), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
-        (void) hipFree(scratch);
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "v_eadd_fdb (sparse) failed: %s", hipGetErrorString(e));
         return SPLAHIP_OK;
     }
@@ -226,8 +226,9 @@ namespace splahip {
     int eadd_sparse(uint nu, const uint* ui, const void* ux, uint32_t u_fill, uint nv, const uint* vi, const void* vx, uint32_t v_fill, uint* ri, void* rx,
                     uint* h_count, int op, hipStream_t s) {
         const uint cu = (nu + 1023u) / 1024u, cv = (nv + 1023u) / 1024u;
-        uint*      scratch = nullptr;// rank_u[nu] flag_u[nu] chunk_u[cu+1] rank_v[nv] flag_v[nv] chunk_v[cv+1]
-        SPLAHIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), sizeof(uint) * (2 * (size_t) nu + 2 * (size_t) nv + cu + cv + 2)));
+        DevMem     mem;// rank_u[nu] flag_u[nu] chunk_u[cu+1] rank_v[nv] flag_v[nv] chunk_v[cv+1]
+        SPLAHIP_TRY(mem.alloc(s, sizeof(uint) * (2 * (size_t) nu + 2 * (size_t) nv + cu + cv + 2)));
+        uint* scratch = mem.as<uint>();
         uint *rank_u = scratch, *flag_u = rank_u + nu, *chunk_u = flag_u + nu, *rank_v = chunk_u + cu + 1, *flag_v = rank_v + nv, *chunk_v = flag_v + nv;
         if (nu) {
             hipLaunchKernelGGL(eadd_rank_kernel, dim3((nu + 255) / 256), dim3(256), 0, s, nu, ui, nv, vi, rank_u, flag_u);
@@ -247,7 +248,6 @@ namespace splahip {
         uint       shared = 0;
         if (e == hipSuccess && nv) e = hipMemcpyAsync(&shared, chunk_v + cv, sizeof(uint), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
-        (void) hipFree(scratch);
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "v_eadd (sparse) failed: %s", hipGetErrorString(e));
         *h_count = nu + nv - shared;
         return SPLAHIP_OK;
@@ -339,9 +339,9 @@ namespace splahip {
     template<typename T>
     int reduce_typed(uint n, const void* x, uint32_t s_bits, uint32_t* h_result, int op, hipStream_t s) {
         const uint blocks  = std::max(1u, std::min(kReduceBlocks, (n / 4 + 255u) / 256u));
-        char*      scratch = nullptr;// out[1] | partial[blocks] | ok[blocks]
-        SPLAHIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), sizeof(uint32_t) * (1 + 2 * (size_t) blocks)));
-        T*    out     = reinterpret_cast<T*>(scratch);
+        DevMem     mem;// out[1] | partial[blocks] | ok[blocks]
+        SPLAHIP_TRY(mem.alloc(s, sizeof(uint32_t) * (1 + 2 * (size_t) blocks)));
+        T*    out     = mem.as<T>();
         T*    partial = out + 1;
         uint* ok      = reinterpret_cast<uint*>(partial + blocks);
         if (binop_is_associative(op) && binop_is_commutative(op)) {
@@ -353,7 +353,6 @@ namespace splahip {
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(h_result, out, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
-        (void) hipFree(scratch);
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "reduce failed: %s", hipGetErrorString(e));
         return SPLAHIP_OK;
     }
@@ -414,8 +413,9 @@ int splahip_v_count_mf_dense(int type, uint32_t n, const void* d_v, uint32_t fil
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
     hipStream_t         s = as_stream(stream);
-    unsigned long long* d_count = nullptr;
-    SPLAHIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_count), sizeof(unsigned long long)));
+    DevMem              mem;
+    SPLAHIP_TRY(mem.alloc(s, sizeof(unsigned long long)));
+    unsigned long long* d_count = mem.as<unsigned long long>();
     hipError_t e = hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s);
     const dim3 grid(std::min<uint32_t>((n + 255) / 256, 2048)), block(256);
     if (e == hipSuccess) {
@@ -429,7 +429,6 @@ int splahip_v_count_mf_dense(int type, uint32_t n, const void* d_v, uint32_t fil
     unsigned long long h = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&h, d_count, sizeof(h), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void) hipFree(d_count);
     if (e != hipSuccess) return fail(SPLAHIP_ERROR, "v_count_mf failed: %s", hipGetErrorString(e));
     *h_count = (uint32_t) h;
     return SPLAHIP_OK;

@@ -29,15 +29,6 @@ namespace splahip {
     // ------------------------------------------------------------------------------------------------------------
     // small device utilities
     // ------------------------------------------------------------------------------------------------------------
-    struct DevMem {// scoped hipMalloc
-        void* p = nullptr;
-        ~DevMem() {
-            if (p) (void) hipFree(p);
-        }
-        hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
-        template<typename U>
-        U* as() { return static_cast<U*>(p); }
-    };
 
     __host__ __device__ inline uint bit_width_u32(uint x) {
         uint b = 0;
@@ -86,7 +77,7 @@ namespace splahip {
     static hipError_t exclusive_scan_u32(const uint* x, uint n, uint* out, hipStream_t s) {
         const uint n_chunks = (n + 1023u) / 1024u;
         DevMem     chunk;
-        hipError_t e = chunk.alloc(sizeof(uint) * (size_t) (n_chunks + 1));
+        hipError_t e = chunk.alloc(s, sizeof(uint) * (size_t) (n_chunks + 1));
         if (e != hipSuccess) return e;
         if (n == 0) return hipMemsetAsync(out, 0, sizeof(uint), s);
         hipLaunchKernelGGL(chunk_sum_kernel, dim3(n_chunks), dim3(256), 0, s, x, n, chunk.as<uint>());
@@ -394,8 +385,8 @@ namespace splahip {
         *h_count = 0;
         if (nvals == 0) return SPLAHIP_OK;
         DevMem len, offs;
-        SPLAHIP_TRY(len.alloc(sizeof(uint) * (size_t) nvals));
-        SPLAHIP_TRY(offs.alloc(sizeof(uint) * (size_t) (nvals + 1)));
+        SPLAHIP_TRY(len.alloc(s, sizeof(uint) * (size_t) nvals));
+        SPLAHIP_TRY(offs.alloc(s, sizeof(uint) * (size_t) (nvals + 1)));
         hipLaunchKernelGGL(frontier_len_kernel, dim3((nvals + 255) / 256), dim3(256), 0, s, nvals, vi, Ap, len.as<uint>());
         SPLAHIP_TRY(exclusive_scan_u32(len.as<uint>(), nvals, offs.as<uint>(), s));
         uint n_products = 0;
@@ -404,10 +395,10 @@ namespace splahip {
         if (n_products == 0) return SPLAHIP_OK;
 
         DevMem key_a, key_b, val_a, val_b, tmp, chunk, lcount, lpos, lrank;
-        SPLAHIP_TRY(key_a.alloc(sizeof(uint) * (size_t) n_products));
-        SPLAHIP_TRY(key_b.alloc(sizeof(uint) * (size_t) n_products));
-        SPLAHIP_TRY(val_a.alloc(sizeof(uint) * (size_t) n_products));
-        SPLAHIP_TRY(val_b.alloc(sizeof(uint) * (size_t) n_products));
+        SPLAHIP_TRY(key_a.alloc(s, sizeof(uint) * (size_t) n_products));
+        SPLAHIP_TRY(key_b.alloc(s, sizeof(uint) * (size_t) n_products));
+        SPLAHIP_TRY(val_a.alloc(s, sizeof(uint) * (size_t) n_products));
+        SPLAHIP_TRY(val_b.alloc(s, sizeof(uint) * (size_t) n_products));
         hipLaunchKernelGGL((expand_kernel<T, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, n_products, nvals, offs.as<uint>(), vi,
                            static_cast<const T*>(vx), Ap, Aj, static_cast<const uint*>(Ax), static_cast<const T*>(mask), n_cols, op_select,
                            DynBin(op_mult), key_a.as<uint>(), val_a.as<T>());
@@ -417,16 +408,16 @@ namespace splahip {
         const uint bits      = bit_width_u32(n_cols);
         SPLAHIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_a.as<uint>(), key_b.as<uint>(), val_a.as<uint>(), val_b.as<uint>(),
                                               n_products, 0, bits, s));
-        SPLAHIP_TRY(tmp.alloc(tmp_bytes));
+        SPLAHIP_TRY(tmp.alloc(s, tmp_bytes));
         SPLAHIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, key_a.as<uint>(), key_b.as<uint>(), val_a.as<uint>(), val_b.as<uint>(),
                                               n_products, 0, bits, s));
         // run heads -> output slots; short runs folded in place, long runs by a wavefront each
         const uint n_chunks = (n_products + 1023u) / 1024u;
         const uint max_long = n_products / kRunShort + 1;
-        SPLAHIP_TRY(chunk.alloc(sizeof(uint) * (size_t) (n_chunks + 1)));
-        SPLAHIP_TRY(lcount.alloc(sizeof(uint)));
-        SPLAHIP_TRY(lpos.alloc(sizeof(uint) * (size_t) max_long));
-        SPLAHIP_TRY(lrank.alloc(sizeof(uint) * (size_t) max_long));
+        SPLAHIP_TRY(chunk.alloc(s, sizeof(uint) * (size_t) (n_chunks + 1)));
+        SPLAHIP_TRY(lcount.alloc(s, sizeof(uint)));
+        SPLAHIP_TRY(lpos.alloc(s, sizeof(uint) * (size_t) max_long));
+        SPLAHIP_TRY(lrank.alloc(s, sizeof(uint) * (size_t) max_long));
         SPLAHIP_TRY(hipMemsetAsync(lcount.p, 0, sizeof(uint), s));
         hipLaunchKernelGGL(head_count_kernel, dim3(n_chunks), dim3(256), 0, s, key_b.as<uint>(), n_products, n_cols, chunk.as<uint>());
         hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk.as<uint>(), n_chunks);
@@ -484,14 +475,14 @@ int splahip_csr_transpose(uint32_t n_rows, uint32_t n_cols, uint32_t nnz, const 
     }
     SPLAHIP_REQUIRE(d_Ap && d_Aj && d_Ax && d_Tj && d_Tx, "null device pointer");
     DevMem iota, perm, sorted, tmp;
-    SPLAHIP_TRY(iota.alloc(sizeof(uint) * (size_t) nnz));
-    SPLAHIP_TRY(perm.alloc(sizeof(uint) * (size_t) nnz));
-    SPLAHIP_TRY(sorted.alloc(sizeof(uint) * (size_t) nnz));
+    SPLAHIP_TRY(iota.alloc(s, sizeof(uint) * (size_t) nnz));
+    SPLAHIP_TRY(perm.alloc(s, sizeof(uint) * (size_t) nnz));
+    SPLAHIP_TRY(sorted.alloc(s, sizeof(uint) * (size_t) nnz));
     hipLaunchKernelGGL(iota_kernel, dim3((nnz + 255) / 256), dim3(256), 0, s, iota.as<uint>(), nnz);
     size_t     tmp_bytes = 0;
     const uint bits      = bit_width_u32(n_cols);
     SPLAHIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_Aj, sorted.as<uint>(), iota.as<uint>(), perm.as<uint>(), nnz, 0, bits, s));
-    SPLAHIP_TRY(tmp.alloc(tmp_bytes));
+    SPLAHIP_TRY(tmp.alloc(s, tmp_bytes));
     SPLAHIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, d_Aj, sorted.as<uint>(), iota.as<uint>(), perm.as<uint>(), nnz, 0, bits, s));
     hipLaunchKernelGGL(transpose_fill_kernel, dim3((nnz + 255) / 256), dim3(256), 0, s, nnz, n_rows, d_Ap, static_cast<const uint*>(d_Ax),
                        perm.as<uint>(), d_Tj, static_cast<uint*>(d_Tx));
@@ -510,7 +501,7 @@ int splahip_vxm_probe(uint32_t nvals, const uint32_t* d_vi, const uint32_t* d_Ap
     if (st != SPLAHIP_OK) return st;
     hipStream_t s = as_stream(stream);
     DevMem      acc;
-    SPLAHIP_TRY(acc.alloc(16));
+    SPLAHIP_TRY(acc.alloc(s, 16));
     SPLAHIP_TRY(hipMemsetAsync(acc.p, 0, 16, s));
     hipLaunchKernelGGL(probe_kernel, dim3((nvals + 255) / 256), dim3(256), 0, s, nvals, d_vi, d_Ap, acc.as<unsigned long long>(),
                        reinterpret_cast<uint*>(acc.as<unsigned long long>() + 1));
