@@ -115,6 +115,12 @@ int splahip_vxm_push(int type, uint32_t n_rows, uint32_t n_cols,
                      uint32_t nvals, const uint32_t* d_vi, const void* d_vx,
                      uint32_t* d_ri, void* d_rx, uint32_t* h_count,
                      int op_mult, int op_add, int op_select, void* stream);
+/* same, with the product count splahip_vxm_probe already returned (0 = unknown): saves the call one read-back */
+int splahip_vxm_push_n(int type, uint32_t n_rows, uint32_t n_cols,
+                       const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, const void* d_mask,
+                       uint32_t nvals, const uint32_t* d_vi, const void* d_vx,
+                       uint32_t* d_ri, void* d_rx, uint32_t* h_count,
+                       int op_mult, int op_add, int op_select, uint64_t n_products, void* stream);
 /* CSR of the transpose (n_cols rows): entries of a column keep ascending row order (stable).  d_Tp: n_cols+1 words,
  * d_Tj / d_Tx: nnz words.  Blocks.  (reference: the CSC slot FormatMatrix::AccCsc, include/spla/config.hpp:102-122) */
 int splahip_csr_transpose(uint32_t n_rows, uint32_t n_cols, uint32_t nnz, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax,

@@ -169,10 +169,10 @@ namespace spla {
                               "splahip_vxm_pull");
                 } else {
                     if (products > 0xFFFFFFF0ull) return Status::InvalidArgument;// uint32 product indices
-                    hip_check(splahip_vxm_push(TypeTraits<T>::id, M->get_n_rows(), M->get_n_cols(), a->Ap.template as<uint32_t>(),
-                                               a->Aj.template as<uint32_t>(), a->Ax.ptr(), mask->acc_dense()->Ax.ptr(), nvals,
-                                               vin->Ai.template as<uint32_t>(), vin->Ax.ptr(), out->Ai.template as<uint32_t>(), out->Ax.ptr(),
-                                               &count, op_mult, op_add, op_sel, nullptr),
+                    hip_check(splahip_vxm_push_n(TypeTraits<T>::id, M->get_n_rows(), M->get_n_cols(), a->Ap.template as<uint32_t>(),
+                                                 a->Aj.template as<uint32_t>(), a->Ax.ptr(), mask->acc_dense()->Ax.ptr(), nvals,
+                                                 vin->Ai.template as<uint32_t>(), vin->Ax.ptr(), out->Ai.template as<uint32_t>(), out->Ax.ptr(),
+                                                 &count, op_mult, op_add, op_sel, products, nullptr),
                               "splahip_vxm_push");
                 }
                 out->values = count;

@@ -380,66 +380,66 @@ namespace splahip {
 
     template<typename T>
     int push_typed(uint n_rows, uint n_cols, const uint* Ap, const uint* Aj, const void* Ax, const void* mask, uint nvals, const uint* vi,
-                   const void* vx, uint* ri, void* rx, uint* h_count, int op_mult, int op_add, int op_select, hipStream_t s) {
+                   const void* vx, uint* ri, void* rx, uint* h_count, int op_mult, int op_add, int op_select, uint64_t products_hint, hipStream_t s) {
         (void) n_rows;
         *h_count = 0;
         if (nvals == 0) return SPLAHIP_OK;
-        DevMem len, offs;
-        SPLAHIP_TRY(len.alloc(s, sizeof(uint) * (size_t) nvals));
-        SPLAHIP_TRY(offs.alloc(s, sizeof(uint) * (size_t) (nvals + 1)));
-        hipLaunchKernelGGL(frontier_len_kernel, dim3((nvals + 255) / 256), dim3(256), 0, s, nvals, vi, Ap, len.as<uint>());
-        SPLAHIP_TRY(exclusive_scan_u32(len.as<uint>(), nvals, offs.as<uint>(), s));
-        uint n_products = 0;
-        SPLAHIP_TRY(hipMemcpyAsync(&n_products, offs.as<uint>() + nvals, sizeof(uint), hipMemcpyDeviceToHost, s));
-        SPLAHIP_TRY(hipStreamSynchronize(s));
+        // ONE stream-ordered allocation and ONE host synchronisation per call (two when the caller did not pass the product count
+        // it already got from splahip_vxm_probe): the fixed cost of this form is launches and read-backs, not bytes.
+        DevMem head;// len[nvals] | offs[nvals + 1]
+        SPLAHIP_TRY(head.alloc(s, sizeof(uint) * (2 * (size_t) nvals + 1)));
+        uint* len  = head.as<uint>();
+        uint* offs = len + nvals;
+        hipLaunchKernelGGL(frontier_len_kernel, dim3((nvals + 255) / 256), dim3(256), 0, s, nvals, vi, Ap, len);
+        SPLAHIP_TRY(exclusive_scan_u32(len, nvals, offs, s));
+        uint n_products = (uint) products_hint;
+        if (products_hint == 0) {
+            SPLAHIP_TRY(hipMemcpyAsync(&n_products, offs + nvals, sizeof(uint), hipMemcpyDeviceToHost, s));
+            SPLAHIP_TRY(hipStreamSynchronize(s));
+        }
         if (n_products == 0) return SPLAHIP_OK;
 
-        DevMem key_a, key_b, val_a, val_b, tmp, chunk, lcount, lpos, lrank;
-        SPLAHIP_TRY(key_a.alloc(s, sizeof(uint) * (size_t) n_products));
-        SPLAHIP_TRY(key_b.alloc(s, sizeof(uint) * (size_t) n_products));
-        SPLAHIP_TRY(val_a.alloc(s, sizeof(uint) * (size_t) n_products));
-        SPLAHIP_TRY(val_b.alloc(s, sizeof(uint) * (size_t) n_products));
-        hipLaunchKernelGGL((expand_kernel<T, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, n_products, nvals, offs.as<uint>(), vi,
-                           static_cast<const T*>(vx), Ap, Aj, static_cast<const uint*>(Ax), static_cast<const T*>(mask), n_cols, op_select,
-                           DynBin(op_mult), key_a.as<uint>(), val_a.as<T>());
-        SPLAHIP_TRY(hipGetLastError());
         // stable LSD radix sort by column: equal columns keep the expand order = the reference's fold order
         size_t     tmp_bytes = 0;
         const uint bits      = bit_width_u32(n_cols);
-        SPLAHIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_a.as<uint>(), key_b.as<uint>(), val_a.as<uint>(), val_b.as<uint>(),
-                                              n_products, 0, bits, s));
-        SPLAHIP_TRY(tmp.alloc(s, tmp_bytes));
-        SPLAHIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, key_a.as<uint>(), key_b.as<uint>(), val_a.as<uint>(), val_b.as<uint>(),
-                                              n_products, 0, bits, s));
-        // run heads -> output slots; short runs folded in place, long runs by a wavefront each
-        const uint n_chunks = (n_products + 1023u) / 1024u;
-        const uint max_long = n_products / kRunShort + 1;
-        SPLAHIP_TRY(chunk.alloc(s, sizeof(uint) * (size_t) (n_chunks + 1)));
-        SPLAHIP_TRY(lcount.alloc(s, sizeof(uint)));
-        SPLAHIP_TRY(lpos.alloc(s, sizeof(uint) * (size_t) max_long));
-        SPLAHIP_TRY(lrank.alloc(s, sizeof(uint) * (size_t) max_long));
-        SPLAHIP_TRY(hipMemsetAsync(lcount.p, 0, sizeof(uint), s));
-        hipLaunchKernelGGL(head_count_kernel, dim3(n_chunks), dim3(256), 0, s, key_b.as<uint>(), n_products, n_cols, chunk.as<uint>());
-        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk.as<uint>(), n_chunks);
-        hipLaunchKernelGGL((run_fold_kernel<T, DynBin>), dim3(n_chunks), dim3(256), 0, s, key_b.as<uint>(), val_b.as<T>(), n_products, n_cols,
-                           chunk.as<uint>(), ri, static_cast<T*>(rx), lcount.as<uint>(), lpos.as<uint>(), lrank.as<uint>(), DynBin(op_add));
+        SPLAHIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint*) nullptr, (uint*) nullptr, (uint*) nullptr, (uint*) nullptr, n_products, 0, bits, s));
+        const uint   n_chunks = (n_products + 1023u) / 1024u;
+        const uint   max_long = n_products / kRunShort + 1;
+        const size_t words    = 4 * (size_t) n_products + (n_chunks + 1) + 1 + 2 * (size_t) max_long;
+        const size_t tmp_at   = (sizeof(uint) * words + 255) & ~(size_t) 255;
+        DevMem       body;// key_a | key_b | val_a | val_b | chunk | lcount | lpos | lrank | (aligned) sort scratch
+        SPLAHIP_TRY(body.alloc(s, tmp_at + tmp_bytes));
+        uint* key_a  = body.as<uint>();
+        uint* key_b  = key_a + n_products;
+        uint* val_a  = key_b + n_products;
+        uint* val_b  = val_a + n_products;
+        uint* chunk  = val_b + n_products;
+        uint* lcount = chunk + n_chunks + 1;
+        uint* lpos   = lcount + 1;
+        uint* lrank  = lpos + max_long;
+        void* tmp    = static_cast<char*>(body.p) + tmp_at;
+        hipLaunchKernelGGL((expand_kernel<T, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, n_products, nvals, offs, vi,
+                           static_cast<const T*>(vx), Ap, Aj, static_cast<const uint*>(Ax), static_cast<const T*>(mask), n_cols, op_select,
+                           DynBin(op_mult), key_a, reinterpret_cast<T*>(val_a));
         SPLAHIP_TRY(hipGetLastError());
-        uint h_tail[1] = {0}, h_long = 0;
-        SPLAHIP_TRY(hipMemcpyAsync(h_tail, chunk.as<uint>() + n_chunks, sizeof(uint), hipMemcpyDeviceToHost, s));
-        SPLAHIP_TRY(hipMemcpyAsync(&h_long, lcount.p, sizeof(uint), hipMemcpyDeviceToHost, s));
+        SPLAHIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, key_a, key_b, val_a, val_b, n_products, 0, bits, s));
+        // run heads -> output slots; short runs folded in place, long runs by a wavefront each
+        SPLAHIP_TRY(hipMemsetAsync(lcount, 0, sizeof(uint), s));
+        hipLaunchKernelGGL(head_count_kernel, dim3(n_chunks), dim3(256), 0, s, key_b, n_products, n_cols, chunk);
+        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk, n_chunks);
+        hipLaunchKernelGGL((run_fold_kernel<T, DynBin>), dim3(n_chunks), dim3(256), 0, s, key_b, reinterpret_cast<const T*>(val_b), n_products, n_cols,
+                           chunk, ri, static_cast<T*>(rx), lcount, lpos, lrank, DynBin(op_add));
+        // the long-run pass is launched for the worst case and sizes itself from the device-side counter (no read-back in between)
+        const uint grid = (max_long + 3) / 4;
+        if (binop_is_associative(op_add))
+            hipLaunchKernelGGL((long_run_kernel<T, DynBin, true>), dim3(grid), dim3(256), 0, s, key_b, reinterpret_cast<const T*>(val_b), n_products, lcount, lpos,
+                               lrank, static_cast<T*>(rx), DynBin(op_add));
+        else
+            hipLaunchKernelGGL((long_run_kernel<T, DynBin, false>), dim3(grid), dim3(256), 0, s, key_b, reinterpret_cast<const T*>(val_b), n_products, lcount, lpos,
+                               lrank, static_cast<T*>(rx), DynBin(op_add));
+        SPLAHIP_TRY(hipGetLastError());
+        SPLAHIP_TRY(hipMemcpyAsync(h_count, chunk + n_chunks, sizeof(uint), hipMemcpyDeviceToHost, s));
         SPLAHIP_TRY(hipStreamSynchronize(s));
-        if (h_long) {
-            const uint grid = (h_long + 3) / 4;
-            if (binop_is_associative(op_add))
-                hipLaunchKernelGGL((long_run_kernel<T, DynBin, true>), dim3(grid), dim3(256), 0, s, key_b.as<uint>(), val_b.as<T>(), n_products,
-                                   lcount.as<uint>(), lpos.as<uint>(), lrank.as<uint>(), static_cast<T*>(rx), DynBin(op_add));
-            else
-                hipLaunchKernelGGL((long_run_kernel<T, DynBin, false>), dim3(grid), dim3(256), 0, s, key_b.as<uint>(), val_b.as<T>(), n_products,
-                                   lcount.as<uint>(), lpos.as<uint>(), lrank.as<uint>(), static_cast<T*>(rx), DynBin(op_add));
-            SPLAHIP_TRY(hipGetLastError());
-            SPLAHIP_TRY(hipStreamSynchronize(s));
-        }
-        *h_count = h_tail[0];
         return SPLAHIP_OK;
     }
 
@@ -542,15 +542,24 @@ int splahip_vxm_push(int type, uint32_t n_rows, uint32_t n_cols,
                      uint32_t nvals, const uint32_t* d_vi, const void* d_vx,
                      uint32_t* d_ri, void* d_rx, uint32_t* h_count,
                      int op_mult, int op_add, int op_select, void* stream) {
+    return splahip_vxm_push_n(type, n_rows, n_cols, d_Ap, d_Aj, d_Ax, d_mask, nvals, d_vi, d_vx, d_ri, d_rx, h_count, op_mult, op_add, op_select, 0, stream);
+}
+
+int splahip_vxm_push_n(int type, uint32_t n_rows, uint32_t n_cols,
+                       const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, const void* d_mask,
+                       uint32_t nvals, const uint32_t* d_vi, const void* d_vx,
+                       uint32_t* d_ri, void* d_rx, uint32_t* h_count,
+                       int op_mult, int op_add, int op_select, uint64_t n_products, void* stream) {
     SPLAHIP_REQUIRE(h_count != nullptr, "null argument");
+    SPLAHIP_REQUIRE(n_products <= 0xFFFFFFF0ull, "product count exceeds 32-bit product indices");
     SPLAHIP_REQUIRE(binop_valid_for(op_mult, type) && binop_valid_for(op_add, type), "op not defined for this type");
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
     hipStream_t s = as_stream(stream);
     switch (type) {
-        case SPLAHIP_INT: return push_typed<int32_t>(n_rows, n_cols, d_Ap, d_Aj, d_Ax, d_mask, nvals, d_vi, d_vx, d_ri, d_rx, h_count, op_mult, op_add, op_select, s);
-        case SPLAHIP_UINT: return push_typed<uint32_t>(n_rows, n_cols, d_Ap, d_Aj, d_Ax, d_mask, nvals, d_vi, d_vx, d_ri, d_rx, h_count, op_mult, op_add, op_select, s);
-        case SPLAHIP_FLOAT: return push_typed<float>(n_rows, n_cols, d_Ap, d_Aj, d_Ax, d_mask, nvals, d_vi, d_vx, d_ri, d_rx, h_count, op_mult, op_add, op_select, s);
+        case SPLAHIP_INT: return push_typed<int32_t>(n_rows, n_cols, d_Ap, d_Aj, d_Ax, d_mask, nvals, d_vi, d_vx, d_ri, d_rx, h_count, op_mult, op_add, op_select, n_products, s);
+        case SPLAHIP_UINT: return push_typed<uint32_t>(n_rows, n_cols, d_Ap, d_Aj, d_Ax, d_mask, nvals, d_vi, d_vx, d_ri, d_rx, h_count, op_mult, op_add, op_select, n_products, s);
+        case SPLAHIP_FLOAT: return push_typed<float>(n_rows, n_cols, d_Ap, d_Aj, d_Ax, d_mask, nvals, d_vi, d_vx, d_ri, d_rx, h_count, op_mult, op_add, op_select, n_products, s);
     }
     return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
 }
