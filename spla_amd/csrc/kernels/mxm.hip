@@ -26,18 +26,35 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace splahip {
 
-    struct DevBuf {// scoped hipMalloc
-        void* p = nullptr;
-        ~DevBuf() {
-            if (p) (void) hipFree(p);
+    // Scoped device memory.  alloc(): stream-ordered, from the device's default pool (workspaces and the per-block output pieces:
+    // GB-sized hipMalloc / hipFree pairs per call cost more than the kernels).  alloc_plain(): hipMalloc, for the two arrays
+    // that are handed to the caller and released with splahip_free.
+    static thread_local hipStream_t tl_stream = nullptr;// the stream of the running mxm / mxmT call
+    struct DevBuf {
+        void*       p      = nullptr;
+        hipStream_t s      = nullptr;
+        bool        pooled = false;
+        ~DevBuf() { drop(); }
+        void drop() {
+            if (p) (void) (pooled ? hipFreeAsync(p, s) : hipFree(p));
+            p = nullptr;
         }
         hipError_t alloc(size_t bytes) {
-            if (p) (void) hipFree(p);
-            p = nullptr;
+            drop();
+            s      = tl_stream;
+            pooled = true;
+            return hipMallocAsync(&p, bytes ? bytes : 4, s);
+        }
+        hipError_t alloc_plain(size_t bytes) {
+            drop();
+            pooled = false;
             return hipMalloc(&p, bytes ? bytes : 4);
         }
         void* release() {
@@ -47,6 +64,19 @@ namespace splahip {
         }
         template<typename U>
         U* as() { return static_cast<U*>(p); }
+    };
+
+    // SPLAHIP_MXM_TRACE=1: host-side wall time of the phases of one mxm call on stderr (diagnostic)
+    struct PhaseTrace {
+        bool                                  on = std::getenv("SPLAHIP_MXM_TRACE") != nullptr;
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        void mark(const char* what) {
+            if (!on) return;
+            (void) hipDeviceSynchronize();
+            const auto t1 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[mxm] %-28s %9.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+            t0 = t1;
+        }
     };
 
     static uint bit_width(unsigned long long x) {
@@ -64,7 +94,7 @@ namespace splahip {
     __device__ __forceinline__ uint row_of_entry(const uint* __restrict__ Ap, uint n_rows, uint k) {
         uint lo = 0, hi = n_rows;// last row with Ap[row] <= k
         while (hi - lo > 1) {
-            const uint mid = (lo + hi) >> 1;
+            const uint mid = lo + ((hi - lo) >> 1);
             if (Ap[mid] <= k) lo = mid;
             else
                 hi = mid;
@@ -200,7 +230,7 @@ namespace splahip {
                 const uint col = Sj[k];
                 uint       hi  = le;
                 while (lo < hi) {
-                    const uint mid = (lo + hi) >> 1;
+                    const uint mid = lo + ((hi - lo) >> 1);
                     if (Lj[mid] < col) lo = mid + 1;
                     else
                         hi = mid;
@@ -288,8 +318,8 @@ namespace splahip {
         uint nnz = 0;
         SPLAHIP_TRY(hipMemcpyAsync(&nnz, rank.as<uint>() + n_entries, sizeof(uint), hipMemcpyDeviceToHost, s));
         SPLAHIP_TRY(hipStreamSynchronize(s));
-        SPLAHIP_TRY(outj.alloc(sizeof(uint) * (size_t) nnz));
-        SPLAHIP_TRY(outx.alloc(sizeof(uint) * (size_t) nnz));
+        SPLAHIP_TRY(outj.alloc_plain(sizeof(uint) * (size_t) nnz));
+        SPLAHIP_TRY(outx.alloc_plain(sizeof(uint) * (size_t) nnz));
         hipLaunchKernelGGL(mxmT_compact_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, s, n_entries, Mj, val.as<uint>(), keep.as<uint>(),
                            rank.as<uint>(), outj.as<uint>(), outx.as<uint>());
         hipLaunchKernelGGL(rowptr_from_rank_kernel, dim3((n_rows + 1 + 255) / 256), dim3(256), 0, s, n_rows, Mp, rank.as<uint>(), Rp);
@@ -362,12 +392,12 @@ namespace splahip {
     __global__ __launch_bounds__(256) void mxm_expand_kernel(uint n_products, uint e0, uint n_entries, const uint* __restrict__ offs, uint n_rows,
                                                              const uint* __restrict__ Ap, const uint* __restrict__ Aj, const T* __restrict__ Ax,
                                                              const uint* __restrict__ Bp, const uint* __restrict__ Bj, const T* __restrict__ Bx,
-                                                             Mult mult, u64* __restrict__ key, T* __restrict__ val) {
+                                                             Mult mult, uint r0, uint col_bits, u64* __restrict__ key, T* __restrict__ val) {
         const uint p = blockIdx.x * 256 + threadIdx.x;
         if (p >= n_products) return;
         uint lo = 0, hi = n_entries;// entry t of the block with offs[t] <= p < offs[t+1]
         while (hi - lo > 1) {
-            const uint mid = (lo + hi) >> 1;
+            const uint mid = lo + ((hi - lo) >> 1);
             if (offs[mid] <= p) lo = mid;
             else
                 hi = mid;
@@ -376,7 +406,7 @@ namespace splahip {
         const uint i  = row_of_entry(Ap, n_rows, e);
         const uint k  = Aj[e];
         const uint kb = Bp[k] + (p - offs[lo]);
-        key[p]        = (u64(i) << 32) | Bj[kb];
+        key[p]        = (u64(i - r0) << col_bits) | Bj[kb];// compact (row in block, column): only these bits are sorted
         val[p]        = mult(Ax[e], Bx[kb]);
     }
 
@@ -425,7 +455,7 @@ namespace splahip {
         const u64  kk   = key[p];
         uint       lo = p + 1, hi = n;
         while (lo < hi) {
-            const uint mid = (lo + hi) >> 1;
+            const uint mid = lo + ((hi - lo) >> 1);
             if (key[mid] == kk) lo = mid + 1;
             else
                 hi = mid;
@@ -457,13 +487,13 @@ namespace splahip {
 
     // kept runs -> (row, col, value) appended at out_base + rank
     __global__ __launch_bounds__(256) void mxm_emit_kernel(uint n_runs, const u64* __restrict__ run_key, const uint* __restrict__ run_val,
-                                                           const uint* __restrict__ run_keep, const uint* __restrict__ rank,
+                                                           const uint* __restrict__ run_keep, const uint* __restrict__ rank, uint r0, uint col_bits,
                                                            uint* __restrict__ out_row, uint* __restrict__ out_col, uint* __restrict__ out_val) {
         const uint t = blockIdx.x * 256 + threadIdx.x;
         if (t < n_runs && run_keep[t]) {
             const uint o = rank[t];
-            out_row[o]   = uint(run_key[t] >> 32);
-            out_col[o]   = uint(run_key[t] & 0xffffffffull);
+            out_row[o]   = r0 + uint(run_key[t] >> col_bits);
+            out_col[o]   = uint(run_key[t] & ((1ull << col_bits) - 1ull));
             out_val[o]   = run_val[t];
         }
     }
@@ -473,7 +503,7 @@ namespace splahip {
         if (i > n_rows) return;
         uint lo = 0, hi = nnz;
         while (lo < hi) {
-            const uint mid = (lo + hi) >> 1;
+            const uint mid = lo + ((hi - lo) >> 1);
             if (rows[mid] < i) lo = mid + 1;
             else
                 hi = mid;
@@ -492,7 +522,8 @@ namespace splahip {
                   u64 block_products, hipStream_t s) {
         *Rj = nullptr, *Rx = nullptr, *h_nnz = 0;
         if (h_products) *h_products = 0;
-        const T init = from_bits<T>(init_bits);
+        const T    init = from_bits<T>(init_bits);
+        PhaseTrace trace;
         // products per row -> host -> row blocks of at most `block_products` products (a single row may exceed it)
         std::vector<uint> h_Ap(a_rows + 1);
         std::vector<u64>  h_rowprod(a_rows);
@@ -508,9 +539,9 @@ namespace splahip {
         std::vector<Piece> pieces;
         auto               free_pieces = [&]() {
             for (auto& pc : pieces) {
-                (void) hipFree(pc.row);
-                (void) hipFree(pc.col);
-                (void) hipFree(pc.val);
+                (void) hipFreeAsync(pc.row, s);
+                (void) hipFreeAsync(pc.col, s);
+                (void) hipFreeAsync(pc.val, s);
             }
             pieces.clear();
         };
@@ -534,11 +565,14 @@ namespace splahip {
             }
             r0 = r1;
         }
+        trace.mark("row products + blocking");
         // one workspace for every block (allocating and freeing GB-sized buffers per block dominated the first version)
         DevBuf len, offs, chunk, key_a, key_b, val_a, val_b, tmp, head, run_rank, run_key, run_val, run_keep, lcount, lpos, keep_rank;
         size_t tmp_bytes = 0;
-        const uint end_bit = 32 + bit_width(a_rows);
-        (void) b_cols;
+        const uint col_bits = std::max(1u, bit_width(b_cols ? b_cols - 1 : 0));
+        uint       max_span = 1;
+        for (const Block& b : blocks) max_span = std::max(max_span, b.r1 - b.r0);
+        const uint end_bit_max = col_bits + std::max(1u, bit_width(max_span - 1));
         if (!blocks.empty()) {
             const size_t np1 = (size_t) max_products + 1;
             SPLAHIP_TRY(len.alloc(sizeof(uint) * (size_t) max_entries));
@@ -549,7 +583,7 @@ namespace splahip {
             SPLAHIP_TRY(val_a.alloc(sizeof(uint) * (size_t) max_products));
             SPLAHIP_TRY(val_b.alloc(sizeof(uint) * (size_t) max_products));
             SPLAHIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_a.as<u64>(), key_b.as<u64>(), val_a.as<uint>(), val_b.as<uint>(),
-                                                  max_products, 0, end_bit, s));
+                                                  max_products, 0, end_bit_max, s));
             SPLAHIP_TRY(tmp.alloc(tmp_bytes));
             SPLAHIP_TRY(head.alloc(sizeof(uint) * (size_t) max_products));
             SPLAHIP_TRY(run_rank.alloc(sizeof(uint) * np1));
@@ -560,6 +594,7 @@ namespace splahip {
             SPLAHIP_TRY(lpos.alloc(sizeof(uint) * ((size_t) max_products / kRunShortMxm + 1)));
             SPLAHIP_TRY(keep_rank.alloc(sizeof(uint) * np1));
         }
+        trace.mark("workspace allocation");
         uint total_out = 0;
         int  status    = SPLAHIP_OK;
         for (const Block& blk : blocks) {
@@ -572,10 +607,12 @@ namespace splahip {
                 hipLaunchKernelGGL(len_scan_kernel, dim3(n_chunks), dim3(256), 0, s, len.as<uint>(), n_entries, chunk.as<uint>(), n_chunks, offs.as<uint>());
                 hipLaunchKernelGGL((mxm_expand_kernel<T, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, n_products, e0, n_entries,
                                    offs.as<uint>(), a_rows, Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), DynBin(op_mult),
-                                   key_a.as<u64>(), val_a.as<T>());
+                                   blk.r0, col_bits, key_a.as<u64>(), val_a.as<T>());
                 SPLAHIP_TRY(hipGetLastError());
                 // stable sort by (row, column): equal keys keep the expand order = the reference's fold order
-                size_t tb = tmp_bytes;
+                // only the bits a (row in block, column) key can have are sorted: ~col_bits + log2(rows in the block) instead of 64
+                size_t     tb      = tmp_bytes;
+                const uint end_bit = col_bits + std::max(1u, bit_width(blk.r1 - blk.r0 - 1));
                 SPLAHIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, key_a.as<u64>(), key_b.as<u64>(), val_a.as<uint>(), val_b.as<uint>(),
                                                       n_products, 0, end_bit, s));
                 // runs
@@ -613,7 +650,7 @@ namespace splahip {
                     SPLAHIP_TRY(ocol.alloc(sizeof(uint) * (size_t) n_out));
                     SPLAHIP_TRY(oval.alloc(sizeof(uint) * (size_t) n_out));
                     hipLaunchKernelGGL(mxm_emit_kernel, dim3((n_runs + 255) / 256), dim3(256), 0, s, n_runs, run_key.as<u64>(), run_val.as<uint>(),
-                                       run_keep.as<uint>(), keep_rank.as<uint>(), orow.as<uint>(), ocol.as<uint>(), oval.as<uint>());
+                                       run_keep.as<uint>(), keep_rank.as<uint>(), blk.r0, col_bits, orow.as<uint>(), ocol.as<uint>(), oval.as<uint>());
                     SPLAHIP_TRY(hipGetLastError());
                     SPLAHIP_TRY(hipStreamSynchronize(s));
                     pieces.push_back({orow.release(), ocol.release(), oval.release(), n_out});
@@ -628,11 +665,12 @@ namespace splahip {
             free_pieces();
             return status;
         }
+        trace.mark("all row blocks");
         // concatenate the pieces (row blocks are in row order) and derive Rp
         DevBuf rows, outj, outx;
         hipError_t e = rows.alloc(sizeof(uint) * (size_t) total_out);
-        if (e == hipSuccess) e = outj.alloc(sizeof(uint) * (size_t) total_out);
-        if (e == hipSuccess) e = outx.alloc(sizeof(uint) * (size_t) total_out);
+        if (e == hipSuccess) e = outj.alloc_plain(sizeof(uint) * (size_t) total_out);
+        if (e == hipSuccess) e = outx.alloc_plain(sizeof(uint) * (size_t) total_out);
         size_t off = 0;
         for (auto& pc : pieces) {
             if (e != hipSuccess) break;
@@ -646,7 +684,9 @@ namespace splahip {
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(s);
+        trace.mark("output allocation + assembly");
         free_pieces();
+        trace.mark("free pieces");
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm assembly failed: %s", hipGetErrorString(e));
         *h_nnz = total_out;
         if (h_products) *h_products = total_products;
@@ -674,6 +714,7 @@ int splahip_mxmT_masked(int type, uint32_t n_rows, uint32_t mask_nnz,
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
     hipStream_t s = as_stream(stream);
+    tl_stream     = s;
     switch (type) {
         case SPLAHIP_INT: return mxmT_typed<int32_t>(n_rows, mask_nnz, d_Mp, d_Mj, d_Mx, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, op_mult, op_add, op_select, init_bits, s);
         case SPLAHIP_UINT: return mxmT_typed<uint32_t>(n_rows, mask_nnz, d_Mp, d_Mj, d_Mx, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, op_mult, op_add, op_select, init_bits, s);
@@ -693,6 +734,7 @@ int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols,
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
     hipStream_t s = as_stream(stream);
+    tl_stream     = s;
     if (a_rows == 0) {
         *d_Rj = nullptr, *d_Rx = nullptr, *h_nnz = 0;
         return SPLAHIP_OK;

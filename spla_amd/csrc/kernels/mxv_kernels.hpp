@@ -130,7 +130,7 @@ namespace splahip {
     __device__ __forceinline__ uint find_row(const uint* s_ap, uint nr, uint k) {
         uint lo = 0, hi = nr;
         while (hi - lo > 1) {
-            const uint mid = (lo + hi) >> 1;
+            const uint mid = lo + ((hi - lo) >> 1);
             if (s_ap[mid] <= k) lo = mid;
             else
                 hi = mid;

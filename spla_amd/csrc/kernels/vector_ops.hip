@@ -139,7 +139,7 @@ namespace splahip {
     __device__ __forceinline__ uint lower_bound_u32(const uint* __restrict__ a, uint n, uint key) {
         uint lo = 0, hi = n;
         while (lo < hi) {
-            const uint mid = (lo + hi) >> 1;
+            const uint mid = lo + ((hi - lo) >> 1);
             if (a[mid] < key) lo = mid + 1;
             else
                 hi = mid;

@@ -92,7 +92,7 @@ namespace splahip {
     __device__ __forceinline__ uint upper_row(const uint* __restrict__ a, uint n, uint k) {
         uint lo = 0, hi = n;
         while (hi - lo > 1) {
-            const uint mid = (lo + hi) >> 1;
+            const uint mid = lo + ((hi - lo) >> 1);
             if (a[mid] <= k) lo = mid;
             else
                 hi = mid;
@@ -121,7 +121,7 @@ namespace splahip {
         if (c > n_cols) return;
         uint lo = 0, hi = nnz;
         while (lo < hi) {
-            const uint mid = (lo + hi) >> 1;
+            const uint mid = lo + ((hi - lo) >> 1);
             if (sorted_col[mid] < c) lo = mid + 1;
             else
                 hi = mid;
@@ -292,7 +292,7 @@ namespace splahip {
         // end of the run: first q > p with key[q] != j (keys are sorted)
         uint lo = p + 1, hi = n;
         while (lo < hi) {
-            const uint mid = (lo + hi) >> 1;
+            const uint mid = lo + ((hi - lo) >> 1);
             if (key[mid] == j) lo = mid + 1;
             else
                 hi = mid;

@@ -162,8 +162,28 @@ def mxmT_masked(t, n_rows, M, A, B, op_mult, op_add, op_select, init):
     return Rp, _adopt(pj, nnz.value, torch.int32), _adopt(px, nnz.value, torch_dtype(t))
 
 
-def mxm(t, a_rows, b_cols, A, B, op_mult, op_add, init, block_products=0):
-    """R = A x B (ESC); returns ((Rp, Rj, Rx), products)."""
+class LibraryCsr:
+    """A CSR result whose column / value arrays are still the library's allocations (no copy): `.nnz`, `.Rp` (tensor), raw
+    device pointers `.pj / .px`; `.adopt(t)` copies them into torch tensors, `.free()` releases them (splahip_free)."""
+
+    def __init__(self, Rp, pj, px, nnz):
+        self.Rp, self.pj, self.px, self.nnz = Rp, pj, px, int(nnz)
+
+    def adopt(self, t):
+        out = (self.Rp, _adopt(self.pj, self.nnz, torch.int32), _adopt(self.px, self.nnz, torch_dtype(t)))
+        self.pj = self.px = None
+        return out
+
+    def free(self):
+        for q in (self.pj, self.px):
+            if q:
+                _lib.call("splahip_free", q)
+        self.pj = self.px = None
+
+
+def mxm(t, a_rows, b_cols, A, B, op_mult, op_add, init, block_products=0, adopt=True):
+    """R = A x B (ESC); returns ((Rp, Rj, Rx), products), or (LibraryCsr, products) with adopt=False (what a C host sees:
+    the call itself, without this wrapper's copy of the result into torch tensors)."""
     tid = type_id(t)
     Rp = torch.empty(a_rows + 1, dtype=torch.int32, device="cuda")
     pj, px, nnz, prod = C.c_void_p(), C.c_void_p(), C.c_uint32(), C.c_uint64()
@@ -172,4 +192,5 @@ def mxm(t, a_rows, b_cols, A, B, op_mult, op_add, init, block_products=0):
         args += [_ptr(p_), _ptr(j_) if j_.numel() else None, _ptr(x_) if x_.numel() else None]
     _lib.call("splahip_mxm", tid, int(a_rows), int(b_cols), *args, _ptr(Rp), C.byref(pj), C.byref(px), C.byref(nnz), C.byref(prod),
               binop_id(op_mult), binop_id(op_add), scalar_bits(init, tid), int(block_products), current_stream_ptr())
-    return (Rp, _adopt(pj, nnz.value, torch.int32), _adopt(px, nnz.value, torch_dtype(t))), prod.value
+    raw = LibraryCsr(Rp, pj, px, nnz.value)
+    return (raw.adopt(t) if adopt else raw), prod.value
