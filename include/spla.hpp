@@ -15,9 +15,11 @@
 #pragma once
 
 #include <atomic>
+#include <chrono>
 #include <cstddef>
 #include <cstdint>
 #include <functional>
+#include <iostream>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -403,6 +405,29 @@ namespace spla {
     Status sssp(const ref_ptr<Vector>& v, const ref_ptr<Matrix>& A, uint s, const ref_ptr<Descriptor>& descriptor);
     Status pr(ref_ptr<Vector>& p, const ref_ptr<Matrix>& A, float alpha, float eps, const ref_ptr<Descriptor>& descriptor);
     Status tc(int& ntrins, const ref_ptr<Matrix>& A, const ref_ptr<Matrix>& B, const ref_ptr<Descriptor>& descriptor);
+
+    // ---- wall-clock timer with laps (mirror of reference include/spla/timer.hpp:49-62; used by the reference's perf tests) -----
+    class Timer {
+    public:
+        void start() { m_begin = m_end = clock::now(); }
+        void stop() { m_end = clock::now(); }
+        void lap_begin() { m_lap = clock::now(); }
+        void lap_end() { m_laps.push_back(ms_between(m_lap, clock::now())); }
+        void print(std::ostream& out = std::cout) const {
+            for (double t : m_laps) out << t << ", ";
+        }
+        double                     get_elapsed_ms() const { return ms_between(m_begin, m_end); }
+        double                     get_elapsed_sec() const { return get_elapsed_ms() * 1e-3; }
+        const std::vector<double>& get_laps_ms() const { return m_laps; }
+
+    private:
+        using clock = std::chrono::steady_clock;
+        static double ms_between(clock::time_point a, clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        }
+        clock::time_point   m_begin{}, m_end{}, m_lap{};
+        std::vector<double> m_laps;
+    };
 
     // ---- library ------------------------------------------------------------------------------------------------------------
     class Library final {

@@ -40,6 +40,10 @@ def build(force: bool = False) -> None:
         subprocess.run(["make", "-C", str(HERE), "port"], check=True, capture_output=True)
     if Path("/root/reference/src/exec.cpp").exists() and (force or not REF_SO.exists()):
         subprocess.run(["make", "-C", str(HERE), "-j8", "ref"], check=True, capture_output=True)
+    # the reference's own hot-path unit tests, linked to the product library (make decides what is out of date)
+    product = HERE.parent / "spla_amd" / "lib" / "libspla_amd.so"
+    if Path("/root/reference/tests/test_mxv.cpp").exists() and product.exists():
+        subprocess.run(["make", "-C", str(HERE), "-j4", "reftests"], check=True, capture_output=True)
 
 
 def _tid(t) -> int:
