@@ -10,7 +10,7 @@ from pathlib import Path
 import pytest
 
 REF_DIR = Path(__file__).resolve().parents[1] / "oracle" / "_ref"
-SUITES = ["mxv", "vxm", "mxm", "mxmT"]
+SUITES = ["mxv", "vxm", "mxm", "mxmT", "op", "library"]  # test_op.cpp / test_library.cpp: the op registry and library info through the same API
 
 
 @pytest.mark.gpu
