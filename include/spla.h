@@ -191,6 +191,14 @@ SPLA_API spla_Status spla_Algorithm_sssp(spla_Vector v, spla_Matrix A, spla_uint
 SPLA_API spla_Status spla_Algorithm_pr(spla_Vector* p, spla_Matrix A, float alpha, float eps, spla_Descriptor descriptor);
 SPLA_API spla_Status spla_Algorithm_tc(int* ntrins, spla_Matrix A, spla_Matrix B, spla_Descriptor descriptor);
 
+/* ---- extension: the MatrixMarket loader from C (the reference has MtxLoader in C++ only, include/spla/io.hpp:47-85) ----
+ * load: parse + symmetrise / drop loops / shift indices as asked, sort, de-duplicate; get: sizes and the two index arrays (owned by
+ * the loader, valid until delete). */
+typedef struct spla_MtxLoader_t* spla_MtxLoader;
+SPLA_API spla_Status spla_MtxLoader_load(spla_MtxLoader* loader, const char* file_path, spla_bool offset_indices, spla_bool make_undirected, spla_bool remove_loops);
+SPLA_API spla_Status spla_MtxLoader_get(spla_MtxLoader loader, spla_uint* n_rows, spla_uint* n_cols, spla_size_t* n_values, const spla_uint** Ai, const spla_uint** Aj);
+SPLA_API spla_Status spla_MtxLoader_delete(spla_MtxLoader loader);
+
 /* ---- extension: descriptors from C ---- */
 SPLA_API spla_Status spla_Descriptor_make(spla_Descriptor* desc);
 SPLA_API spla_Status spla_Descriptor_set_early_exit(spla_Descriptor desc, spla_bool value);

@@ -15,9 +15,11 @@
 #pragma once
 
 #include <atomic>
+#include <cassert>
 #include <chrono>
 #include <cstddef>
 #include <cstdint>
+#include <filesystem>
 #include <functional>
 #include <iostream>
 #include <stdexcept>
@@ -401,10 +403,44 @@ namespace spla {
                          ref_ptr<Descriptor> desc = ref_ptr<Descriptor>(), ref_ptr<ScheduleTask>* task_hnd = nullptr);
 
     // ---- graph algorithms over exec_* (reference include/spla/algorithm.hpp:54-68,86-101,120-137,157-170) ----
-    Status bfs(const ref_ptr<Vector>& v, const ref_ptr<Matrix>& A, uint s, const ref_ptr<Descriptor>& descriptor);
-    Status sssp(const ref_ptr<Vector>& v, const ref_ptr<Matrix>& A, uint s, const ref_ptr<Descriptor>& descriptor);
-    Status pr(ref_ptr<Vector>& p, const ref_ptr<Matrix>& A, float alpha, float eps, const ref_ptr<Descriptor>& descriptor);
-    Status tc(int& ntrins, const ref_ptr<Matrix>& A, const ref_ptr<Matrix>& B, const ref_ptr<Descriptor>& descriptor);
+    Status bfs(const ref_ptr<Vector>& v, const ref_ptr<Matrix>& A, uint s, const ref_ptr<Descriptor>& descriptor = ref_ptr<Descriptor>());
+    Status sssp(const ref_ptr<Vector>& v, const ref_ptr<Matrix>& A, uint s, const ref_ptr<Descriptor>& descriptor = ref_ptr<Descriptor>());
+    Status pr(ref_ptr<Vector>& p, const ref_ptr<Matrix>& A, float alpha = 0.85, float eps = 1e-6, const ref_ptr<Descriptor>& descriptor = ref_ptr<Descriptor>());
+    Status tc(int& ntrins, const ref_ptr<Matrix>& A, const ref_ptr<Matrix>& B, const ref_ptr<Descriptor>& descriptor = ref_ptr<Descriptor>());
+    // host-side checkers over std::vector adjacency lists (reference include/spla/algorithm.hpp:70-84,103-118,139-155,172-175): what the
+    // reference's examples verify accelerator results with; never reached from exec_*
+    Status bfs_naive(std::vector<int>& v, std::vector<std::vector<spla::uint>>& A, uint s, const ref_ptr<Descriptor>& descriptor = ref_ptr<Descriptor>());
+    Status sssp_naive(std::vector<float>& v, std::vector<std::vector<uint>>& Ai, std::vector<std::vector<float>>& Ax, uint s,
+                      const ref_ptr<Descriptor>& descriptor = ref_ptr<Descriptor>());
+    Status pr_naive(std::vector<float>& p, std::vector<std::vector<uint>>& Ai, std::vector<std::vector<float>>& Ax, float alpha = 0.85, float eps = 1e-6,
+                    const ref_ptr<Descriptor>& descriptor = ref_ptr<Descriptor>());
+    Status tc_naive(int& ntrins, std::vector<std::vector<spla::uint>>& Ai, const ref_ptr<Descriptor>& descriptor = ref_ptr<Descriptor>());
+
+    // ---- MatrixMarket coordinate loader + degree statistics (reference include/spla/io.hpp:47-85) ------------------
+    class MtxLoader {
+    public:
+        explicit MtxLoader(std::string name = "");
+        bool load(std::filesystem::path file_path, bool offset_indices = true, bool make_undirected = true, bool remove_loops = true);
+        bool save(const std::filesystem::path& file_path, bool stats_only = false);
+        void calc_stats();
+        void output_stats();
+        const std::vector<uint>& get_Ai() const;
+        const std::vector<uint>& get_Aj() const;
+        uint                     get_n_rows() const;
+        uint                     get_n_cols() const;
+        std::size_t              get_n_values() const;
+
+    private:
+        std::string           m_name;
+        std::filesystem::path m_file_path;
+        std::vector<uint>     m_Ai, m_Aj;
+        bool                  m_base_is_zero = false;
+        uint                  m_n_rows = 0, m_n_cols = 0;
+        std::size_t           m_n_values = 0;
+        double                m_deg_avg = -1.0, m_deg_sd = -1.0, m_deg_min = -1.0, m_deg_max = -1.0;
+        std::vector<double>   m_deg_distribution;
+        std::vector<uint>     m_deg_ranges;
+    };
 
     // ---- wall-clock timer with laps (mirror of reference include/spla/timer.hpp:49-62; used by the reference's perf tests) -----
     class Timer {

@@ -43,7 +43,7 @@ def build(force: bool = False) -> None:
     # the reference's own hot-path unit tests, linked to the product library (make decides what is out of date)
     product = HERE.parent / "spla_amd" / "lib" / "libspla_amd.so"
     if Path("/root/reference/tests/test_mxv.cpp").exists() and product.exists():
-        subprocess.run(["make", "-C", str(HERE), "-j4", "reftests"], check=True, capture_output=True)
+        subprocess.run(["make", "-C", str(HERE), "-j4", "reftests", "refexamples"], check=True, capture_output=True)
 
 
 def _tid(t) -> int:
@@ -580,6 +580,24 @@ class Reference:
         out = self._read_lil(B, n, 0)
         self._unref(L, B, d)
         return int(count.value), out
+
+    def load_mtx(self, path, offset_indices=True, make_undirected=True, remove_loops=True):
+        """the reference's MtxLoader::load -> (n_rows, n_cols, Ai, Aj)"""
+        lib = self.lib
+        lib.refshim_mtx_load.restype = C.c_void_p
+        lib.refshim_mtx_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
+        lib.refshim_mtx_get.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(_u32p), C.POINTER(_u32p)]
+        lib.refshim_mtx_free.argtypes = [C.c_void_p]
+        h = lib.refshim_mtx_load(str(path).encode(), int(offset_indices), int(make_undirected), int(remove_loops))
+        if not h:
+            raise RuntimeError("reference MtxLoader failed")
+        nr, nc, nv, pi, pj = C.c_uint32(), C.c_uint32(), C.c_uint64(), _u32p(), _u32p()
+        lib.refshim_mtx_get(h, C.byref(nr), C.byref(nc), C.byref(nv), C.byref(pi), C.byref(pj))
+        n = nv.value
+        Ai = np.ctypeslib.as_array(pi, shape=(n,)).copy() if n else np.empty(0, np.uint32)
+        Aj = np.ctypeslib.as_array(pj, shape=(n,)).copy() if n else np.empty(0, np.uint32)
+        lib.refshim_mtx_free(h)
+        return nr.value, nc.value, Ai, Aj
 
     # ---- the four operations ----------------------------------------------------------------------------------
     def mxv_masked(self, t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, init, early_exit=False):

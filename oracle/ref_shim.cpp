@@ -87,6 +87,25 @@ void* refshim_descriptor_make_traversal(int mode, float front_factor) {
     return d.release();
 }
 
+// The reference's MatrixMarket loader (C++ only): load, hand out sizes + index arrays, free.
+void* refshim_mtx_load(const char* path, int offset_indices, int make_undirected, int remove_loops) {
+    auto* l = new MtxLoader();
+    if (!l->load(path, offset_indices != 0, make_undirected != 0, remove_loops != 0)) {
+        delete l;
+        return nullptr;
+    }
+    return l;
+}
+void refshim_mtx_get(void* loader, uint32_t* n_rows, uint32_t* n_cols, uint64_t* n_values, const uint32_t** Ai, const uint32_t** Aj) {
+    auto* l   = static_cast<MtxLoader*>(loader);
+    *n_rows   = l->get_n_rows();
+    *n_cols   = l->get_n_cols();
+    *n_values = l->get_n_values();
+    *Ai       = l->get_Ai().data();
+    *Aj       = l->get_Aj().data();
+}
+void refshim_mtx_free(void* loader) { delete static_cast<MtxLoader*>(loader); }
+
 // Stored entries of a matrix as seen through its LIL rows (robust to the `values` counter bug above).
 uint64_t refshim_matrix_lil_count(void* m) {
     auto*    M = static_cast<Matrix*>(m);

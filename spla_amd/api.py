@@ -52,6 +52,7 @@ def c_symbols():
              "spla_Exec_v_eadd_fdb", "spla_Exec_v_assign_masked", "spla_Exec_v_count_mf",
              "spla_Exec_v_eadd", "spla_Exec_v_reduce", "spla_Exec_m_reduce",
              "spla_Algorithm_bfs", "spla_Algorithm_sssp", "spla_Algorithm_pr", "spla_Algorithm_tc",
+             "spla_MtxLoader_load", "spla_MtxLoader_get", "spla_MtxLoader_delete",
              "spla_Descriptor_make", "spla_Descriptor_set_early_exit", "spla_Descriptor_set_struct_only",
              "spla_Descriptor_set_traversal_mode", "spla_Descriptor_set_front_factor"]
     for op in BINARY_OPS:
@@ -135,6 +136,9 @@ def _c():
         lib.spla_Algorithm_tc.argtypes = [C.POINTER(C.c_int), _vp, _vp, _vp]
         lib.spla_Descriptor_set_traversal_mode.argtypes = [_vp, C.c_int]
         lib.spla_Descriptor_set_front_factor.argtypes = [_vp, C.c_float]
+        lib.spla_MtxLoader_load.argtypes = [C.POINTER(_vp), C.c_char_p, C.c_int, C.c_int, C.c_int]
+        lib.spla_MtxLoader_get.argtypes = [_vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_size_t), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32))]
+        lib.spla_MtxLoader_delete.argtypes = [_vp]
         lib.spla_Descriptor_make.argtypes = [C.POINTER(_vp)]
         lib.spla_Descriptor_set_early_exit.argtypes = [_vp, C.c_int]
         lib.spla_Descriptor_set_struct_only.argtypes = [_vp, C.c_int]
@@ -563,3 +567,19 @@ def tc(L: Matrix, desc=None):
     n = C.c_int(0)
     _check(_c().spla_Algorithm_tc(C.byref(n), L.hnd, B.hnd, _desc(desc)), "spla_Algorithm_tc")
     return int(n.value), B
+
+
+def load_mtx(path, offset_indices=True, make_undirected=True, remove_loops=True):
+    """MatrixMarket coordinate file -> (n_rows, n_cols, Ai, Aj): sorted, de-duplicated edge list (reference MtxLoader::load semantics)."""
+    h = _vp()
+    _check(_c().spla_MtxLoader_load(C.byref(h), str(path).encode(), int(offset_indices), int(make_undirected), int(remove_loops)), "spla_MtxLoader_load")
+    try:
+        nr, nc, nv = C.c_uint(), C.c_uint(), C.c_size_t()
+        pi, pj = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
+        _check(_c().spla_MtxLoader_get(h, C.byref(nr), C.byref(nc), C.byref(nv), C.byref(pi), C.byref(pj)), "spla_MtxLoader_get")
+        n = nv.value
+        Ai = np.ctypeslib.as_array(pi, shape=(n,)).copy() if n else np.empty(0, np.uint32)
+        Aj = np.ctypeslib.as_array(pj, shape=(n,)).copy() if n else np.empty(0, np.uint32)
+        return nr.value, nc.value, Ai, Aj
+    finally:
+        _c().spla_MtxLoader_delete(h)

@@ -198,6 +198,32 @@ spla_Status spla_Algorithm_tc(int* ntrins, spla_Matrix A, spla_Matrix B, spla_De
     return to_c(tc(*ntrins, as_ref<Matrix>(A), as_ref<Matrix>(B), as_ref<Descriptor>(descriptor)));
 }
 
+spla_Status spla_MtxLoader_load(spla_MtxLoader* loader, const char* file_path, spla_bool offset_indices, spla_bool make_undirected, spla_bool remove_loops) {
+    if (!loader || !file_path) return SPLA_STATUS_INVALID_ARGUMENT;
+    auto* l = new MtxLoader();
+    if (!l->load(file_path, offset_indices != 0, make_undirected != 0, remove_loops != 0)) {
+        delete l;
+        *loader = nullptr;
+        return SPLA_STATUS_ERROR;
+    }
+    *loader = reinterpret_cast<spla_MtxLoader>(l);
+    return SPLA_STATUS_OK;
+}
+spla_Status spla_MtxLoader_get(spla_MtxLoader loader, spla_uint* n_rows, spla_uint* n_cols, spla_size_t* n_values, const spla_uint** Ai, const spla_uint** Aj) {
+    if (!loader) return SPLA_STATUS_INVALID_ARGUMENT;
+    auto* l = reinterpret_cast<MtxLoader*>(loader);
+    if (n_rows) *n_rows = l->get_n_rows();
+    if (n_cols) *n_cols = l->get_n_cols();
+    if (n_values) *n_values = l->get_n_values();
+    if (Ai) *Ai = l->get_Ai().data();
+    if (Aj) *Aj = l->get_Aj().data();
+    return SPLA_STATUS_OK;
+}
+spla_Status spla_MtxLoader_delete(spla_MtxLoader loader) {
+    delete reinterpret_cast<MtxLoader*>(loader);
+    return SPLA_STATUS_OK;
+}
+
 spla_Status spla_Descriptor_make(spla_Descriptor* desc) { return give(desc, Descriptor::make()); }
 spla_Status spla_Descriptor_set_early_exit(spla_Descriptor desc, spla_bool value) {
     if (!desc) return SPLA_STATUS_INVALID_ARGUMENT;
