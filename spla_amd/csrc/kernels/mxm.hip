@@ -33,9 +33,8 @@
 
 namespace splahip {
 
-    // Scoped device memory.  alloc(): stream-ordered, from the device's default pool (workspaces and the per-block output pieces:
-    // GB-sized hipMalloc / hipFree pairs per call cost more than the kernels).  alloc_plain(): hipMalloc, for the two arrays
-    // that are handed to the caller and released with splahip_free.
+    // Scoped device memory: stream-ordered, from the device's default pool (GB-sized hipMalloc / hipFree pairs per call cost more than
+    // the kernels).  The two result arrays are handed to the caller (release()), who returns them with splahip_free.
     static thread_local hipStream_t tl_stream = nullptr;// the stream of the running mxm / mxmT call
     struct DevBuf {
         void*       p      = nullptr;
@@ -52,11 +51,7 @@ namespace splahip {
             pooled = true;
             return hipMallocAsync(&p, bytes ? bytes : 4, s);
         }
-        hipError_t alloc_plain(size_t bytes) {
-            drop();
-            pooled = false;
-            return hipMalloc(&p, bytes ? bytes : 4);
-        }
+        hipError_t alloc_plain(size_t bytes) { return alloc(bytes); }// (results go to the caller, who returns them to the same pool: splahip_free)
         void* release() {
             void* q = p;
             p       = nullptr;

@@ -109,13 +109,15 @@ int splahip_malloc(void** d_ptr, size_t bytes) {
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
     *d_ptr = nullptr;
-    SPLAHIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 4));
+    // from the device's default memory pool, ordered on the default stream: hipMalloc / hipFree pairs synchronise the device and cost
+    // ~0.1 ms each, which dominated short-lived objects (a BFS creates and drops a dozen vectors)
+    SPLAHIP_TRY(hipMallocAsync(d_ptr, bytes ? bytes : 4, nullptr));
     return SPLAHIP_OK;
 }
 
 int splahip_free(void* d_ptr) {
     if (!d_ptr) return SPLAHIP_OK;
-    SPLAHIP_TRY(hipFree(d_ptr));
+    SPLAHIP_TRY(hipFreeAsync(d_ptr, nullptr));// reusable once the work queued on the default stream so far has finished
     return SPLAHIP_OK;
 }
 

@@ -43,10 +43,12 @@ namespace splahip {
 
     template<typename T>
     __global__ __launch_bounds__(256) void count_mf_kernel(uint n, const T* __restrict__ v, T fill, unsigned long long* __restrict__ count) {
-        uint cnt = 0;
+        __shared__ uint s_tmp[256 / kWave + 1];
+        uint            cnt = 0;
         for (uint i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) cnt += v[i] != fill ? 1u : 0u;
-        cnt = wave_sum(cnt);
-        if (lane_id() == 0 && cnt) atomicAdd(count, (unsigned long long) cnt);
+        uint total;
+        (void) block_exclusive_sum<256>(cnt, s_tmp, total);
+        if (threadIdx.x == 0 && total) atomicAdd(count, (unsigned long long) total);// one atomic per workgroup: 8 K same-address atomics cost ~90 us
     }
 
     template<typename T>
@@ -417,7 +419,7 @@ int splahip_v_count_mf_dense(int type, uint32_t n, const void* d_v, uint32_t fil
     SPLAHIP_TRY(mem.alloc(s, sizeof(unsigned long long)));
     unsigned long long* d_count = mem.as<unsigned long long>();
     hipError_t e = hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s);
-    const dim3 grid(std::min<uint32_t>((n + 255) / 256, 2048)), block(256);
+    const dim3 grid(std::min<uint32_t>((n + 255) / 256, 512)), block(256);
     if (e == hipSuccess) {
         switch (type) {
             case SPLAHIP_INT: hipLaunchKernelGGL(count_mf_kernel<int32_t>, grid, block, 0, s, n, static_cast<const int32_t*>(d_v), from_bits<int32_t>(fill_bits), d_count); break;
