@@ -46,6 +46,10 @@ namespace {
 
     Variant pick_variant(int type, int op_mult, int op_add, int early_exit) {
         if (early_exit) return Variant::RowSeqEarly;
+        {// A/B runs only: SPLAHIP_FORCE_ROWSEQ=1 sends everything to the one-lane-per-row kernel
+            const char* e = std::getenv("SPLAHIP_FORCE_ROWSEQ");
+            if (e && e[0] == '1') return Variant::RowSeq;
+        }
         if (!binop_is_associative(op_add) || !binop_is_commutative(op_add)) return Variant::RowSeq;
         return static_semiring(type, op_mult, op_add) ? Variant::WaveTileStatic : Variant::WaveTileDynamic;
     }
