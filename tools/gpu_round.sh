@@ -8,6 +8,10 @@ echo "== bench"; timeout 900 python bench.py > gpurun_out/bench.json 2> gpurun_o
 cd /tmp; export TMPDIR=/tmp
 echo "== rocprof kernel trace"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -- python3 "$R/bench.py" --steps 30 --warmup 5 --no-cpu-baseline --no-verify > "$R/gpurun_out/prof_bench.json" 2> "$R/gpurun_out/prof_bench.err"; echo "rocprof exit $?"
+echo "== rocprof kernel trace of the timed configuration only"
+rm -rf "$R/gpurun_out/prof_timed"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_timed" -- python3 "$R/bench.py" --steps 30 --warmup 5 --no-cpu-baseline --no-verify --no-variants > "$R/gpurun_out/prof_timed_bench.json" 2> /dev/null; echo "rocprof timed exit $?"
+python3 "$R/tools/timed_kernel_from_trace.py" "$R/gpurun_out/prof_timed" 'spmv_wavetile_kernel<splahip::MxvCfg, int, splahip::StaBin<13>' 30 "$R/gpurun_out/prof_timed_bench.json" | tee "$R/gpurun_out/prof_timed_summary.txt"
 echo "== rocprof pmc FETCH_SIZE"
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_fetch" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-variants > /dev/null 2> "$R/gpurun_out/pmc_fetch.err"; echo "pmc fetch exit $?"
 echo "== rocprof pmc WRITE_SIZE"
@@ -18,5 +22,5 @@ python tools/summarize_prof.py gpurun_out/pmc_fetch > gpurun_out/pmc_fetch_summa
 python tools/summarize_prof.py gpurun_out/pmc_write > gpurun_out/pmc_write_summary.txt 2>&1
 cat gpurun_out/prof_summary.txt; grep -E "FETCH|WRITE" gpurun_out/pmc_fetch_summary.txt gpurun_out/pmc_write_summary.txt | head -20
 # keep the merged output small
-find gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*kernel_trace.csv" -size +3M -delete
+find gpurun_out/prof gpurun_out/prof_timed gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*kernel_trace.csv" -size +3M -delete
 find gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*counter_collection.csv" -size +8M -delete
