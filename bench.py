@@ -212,9 +212,27 @@ def main():
     if world == 1:
         v_full.copy_(front)
 
+    # the exchange step (N > 1): dense all-gather of the padded slices, or — when the frontier is sparse and there are enough ranks
+    # for the volume to matter — the sparsity-aware form (positions only; every step does the full exchange of a fresh vector:
+    # local compaction, count exchange, position all-gather, clear + scatter).  SPLA_EXCHANGE=dense|sparse overrides the rule;
+    # the rule depends on global quantities only, so every rank picks the same form.
+    mode = os.environ.get("SPLA_EXCHANGE", "auto")
+    sparse = world > 1 and (mode == "sparse" or (mode == "auto" and world >= 4 and front_total * 16 < g["n"]))
+    sx = None
+    if sparse:
+        from spla_amd import sharding
+        sx = sharding.SparseExchange(sh.blk, torch.int32, "cuda", fill=0)
+        v_full = sx.exchange(front[:n_local], value=1)[:sh.n_cols_padded]
+
+    def exchange():
+        if sparse:
+            sx.exchange(front[:n_local], value=1)
+        else:
+            sh.gather(front, v_full)
+
     def step(early=False):
         if world > 1:
-            sh.gather(front, v_full)
+            exchange()
         kernels.mxv_masked(sh.plan, "INT", sh.n_cols_padded, g["Ap"], g["Aj"], ones_i, mask, v_full, r,
                            "BAND", "BOR", "EQZERO", 0, early_exit=early)
 
@@ -288,15 +306,18 @@ def main():
 
     # ---- the exchange step on its own (SURVEY.md 8e reporting): all-gather time, per-link rate, overlap -----------
     if world > 1:
-        _, per_x = timed(lambda: sh.gather(front, v_full), args.steps, 2)
+        _, per_x = timed(exchange, args.steps, 2)
         x_ms = float(np.mean(per_x))
-        slice_bytes = 4 * sh.max_rows  # what this rank receives from EACH peer (direct all-gather over the xGMI mesh)
+        # what this rank receives from EACH peer (direct all-gather over the xGMI mesh): a padded dense slice, or the longest position list
+        slice_bytes = 4 * sh.max_rows if not sparse else 8 * int(sx.prev.numel() // world)
         xm = torch.tensor([x_ms], device=coll_device(), dtype=torch.float64)
         dist.all_reduce(xm, op=dist.ReduceOp.MAX)
-        out["exchange"] = {"collective": "all_gather_into_tensor (%s), padded slices" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " debug backend"), "avg_us": round(x_ms * 1e3, 2), "max_over_ranks_us": round(float(xm[0]) * 1e3, 2),
+        out["exchange"] = {"mode": "sparse (positions of the non-fill entries)" if sparse else "dense (padded slices)",
+                           "collective": "all_gather_into_tensor (%s)" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " debug backend"), "avg_us": round(x_ms * 1e3, 2), "max_over_ranks_us": round(float(xm[0]) * 1e3, 2),
                            "bytes_per_peer": slice_bytes, "bytes_received_per_rank": slice_bytes * (world - 1),
                            "gbs_per_link_if_direct": round(slice_bytes / (x_ms * 1e-3) / 1e9, 2),
                            "local_spmv_us": round(k_ms * 1e3, 2), "overlap_fraction": 0.0,
+                           "entries_exchanged": int(sx.last_count) if sparse else int(g["n"]),
                            "note": "exchange and local SpMV run back to back on one stream in round 1 (no overlap)"}
 
     # ---- verification of the timed result against the oracle (full local rows), and the CPU baseline ------------

@@ -5,6 +5,10 @@
 * one exchange step per SpMV: the all-gather of the dense input vector.  RCCL has no all-gatherv, so slices are padded
   to the longest block and exchanged with ONE all_gather_into_tensor; the local CSR's column ids are remapped once,
   at setup, to index that padded [world][max_rows] layout directly, so the step does no unpacking.
+* sparsity-aware form of the same step (`SparseExchange`) for vectors that are mostly fill (a BFS frontier, the changed
+  distances of an SSSP round): every rank sends only the positions (and values) of its non-fill entries, padded to the
+  longest list; the receivers clear the previous round's positions and scatter the new ones.  At 8 ranks and a 2 %
+  frontier that is ~1 MB instead of 134 MB per step.
 
 Everything here is device-agnostic torch + torch.distributed (nccl == RCCL on ROCm; gloo in the CPU tests).
 """
@@ -74,3 +78,54 @@ class RowBlock:
             return x_padded
         parts = [x_padded[p * self.max_rows: p * self.max_rows + self.counts[p]] for p in range(self.world)]
         return torch.cat(parts)
+
+
+class SparseExchange:
+    """Sparsity-aware exchange of this rank's slice into the padded gathered vector `v_full` (len n_cols_padded + 1: the last word is
+    a scratch slot that padding positions point to).  One call = one full exchange of a fresh vector: local compaction, a count
+    exchange (lists are padded to the longest), one all-gather of positions (+ one of values unless `value` is given), clearing of
+    the previous round's positions, scatter.  Result: v_full[:n_cols_padded] equals what RowBlock.all_gather would produce."""
+
+    def __init__(self, blk: RowBlock, dtype, device, fill=0):
+        self.blk, self.fill = blk, fill
+        self.trash = blk.n_cols_padded
+        self.v_full = torch.full((blk.n_cols_padded + 1,), fill, dtype=dtype, device=device)
+        self.prev = None  # positions written by the previous exchange
+        self.last_count = 0  # entries exchanged by the last call (all ranks)
+
+    def _all_gather(self, out: torch.Tensor, x: torch.Tensor):
+        if x.is_cuda and dist.get_backend() == "gloo":  # debug path: ranks sharing one GPU, exchange staged through the host
+            parts = [torch.empty(x.numel(), dtype=x.dtype) for _ in range(self.blk.world)]
+            dist.all_gather(parts, x.cpu())
+            out.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(out, x)
+
+    def exchange(self, x_local: torch.Tensor, value=None) -> torch.Tensor:
+        """x_local: this rank's n_local entries.  value: if every non-fill entry holds this value (a 0/1 frontier), values are not sent."""
+        blk, dev = self.blk, x_local.device
+        idx = torch.nonzero(x_local != self.fill).squeeze(1)  # ascending local row ids (host sync: the list length)
+        c = int(idx.numel())
+        cnt = torch.tensor([c], dtype=torch.int64, device=dev)
+        cnts = torch.empty(blk.world, dtype=torch.int64, device=dev)
+        self._all_gather(cnts, cnt)
+        counts = cnts.tolist()
+        m = max(max(counts), 1)
+        send = torch.full((m,), self.trash, dtype=torch.int64, device=dev)
+        send[:c] = idx + blk.rank * blk.max_rows  # position in the padded [world][max_rows] layout
+        recv = torch.empty(blk.world * m, dtype=torch.int64, device=dev)
+        self._all_gather(recv, send)
+        if self.prev is not None:
+            self.v_full.index_fill_(0, self.prev, self.fill)
+        if value is not None:
+            self.v_full.index_fill_(0, recv, value)
+        else:
+            sv = torch.full((m,), self.fill, dtype=x_local.dtype, device=dev)
+            sv[:c] = x_local[idx]
+            rv = torch.empty(blk.world * m, dtype=x_local.dtype, device=dev)
+            self._all_gather(rv, sv)
+            self.v_full.index_put_((recv,), rv)
+        self.v_full[self.trash] = self.fill
+        self.prev = recv
+        self.last_count = sum(counts)
+        return self.v_full

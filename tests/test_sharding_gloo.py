@@ -44,6 +44,23 @@ def _worker(rank, world, port, out_dir):
     # the next iteration's input is the gathered result: results stay sharded, gather again
     r_pad = blk.all_gather(blk.pad_local(torch.from_numpy(r_local)))
     assert np.array_equal(blk.unpad(r_pad).numpy(), r_full)
+    # sparsity-aware exchange == dense exchange, over several rounds (the previous round's positions must be cleared), with and
+    # without the values travelling, including an all-fill round
+    for fill, const in ((0, 1), (7, None)):
+        sx = sharding.SparseExchange(blk, torch.int32, "cpu", fill=fill)
+        for rnd in range(4):
+            gg = torch.Generator().manual_seed(100 + rnd)
+            x = torch.full((n,), fill, dtype=torch.int32)
+            k = [n // 50, n // 7, 0, 3][rnd]
+            pos = torch.randperm(n, generator=gg)[:k]
+            x[pos] = 1 if const is not None else torch.randint(8, 99, (k,), generator=gg, dtype=torch.int32)
+            got = sx.exchange(x[blk.lo:blk.hi], value=const)
+            want = blk.all_gather(blk.pad_local(x[blk.lo:blk.hi], fill=fill))
+            assert got.numel() == blk.n_cols_padded + 1
+            live = torch.zeros(blk.n_cols_padded, dtype=torch.bool)  # padding slots of the dense layout hold `fill` in both forms
+            assert torch.equal(got[:blk.n_cols_padded], want), (fill, rnd)
+            assert torch.equal(got[:blk.n_cols_padded][blk.Aj.to(torch.int64)], x[blk.Aj_global.to(torch.int64)])
+            assert sx.last_count == k
     Path(out_dir, f"ok{rank}").write_text("ok")
     dist.barrier()
     dist.destroy_process_group()
