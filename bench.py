@@ -58,7 +58,9 @@ def parse():
     p.add_argument("--scale", type=int, default=22, help="R-MAT scale per GPU (global scale = scale + log2(gpus))")
     p.add_argument("--edge-factor", type=int, default=16)
     p.add_argument("--seed", type=int, default=1)
-    p.add_argument("--permute", type=int, default=-1, help="random vertex relabelling: 1/0, default: only when gpus > 1")
+    p.add_argument("--permute", type=int, default=-1, help="vertex relabelling: 0 raw, 1 random, 2 owner-sorted (one pseudo-random share of the "
+                   "vertices per row block, original order inside a block); default: raw at 1 GPU, owner-sorted when gpus > 1")
+    p.add_argument("--owners", type=int, default=0, help="blocks of the owner-sorted relabelling (default: the number of GPUs)")
     p.add_argument("--cpu-sample-nnz", type=int, default=8_000_000, help="nnz of the leading row block timed on the CPU")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-variants", action="store_true")
@@ -75,9 +77,10 @@ def build_graph(args, rank, world):
     """Seeded R-MAT on the GPU; every rank generates the same global graph and keeps its nnz-balanced row block."""
     from spla_amd import graphgen, sharding
     gscale = args.scale + int(round(math.log2(world)))
-    permute = (world > 1) if args.permute < 0 else bool(args.permute)
+    pm = (2 if world > 1 else 0) if args.permute < 0 else args.permute
+    permute = {0: False, 1: True, 2: "owner-sorted"}[pm]
     t0 = time.time()
-    n, Ap, Aj = graphgen.rmat_csr(gscale, args.edge_factor, seed=args.seed, device="cuda", permute=permute)
+    n, Ap, Aj = graphgen.rmat_csr(gscale, args.edge_factor, seed=args.seed, device="cuda", permute=permute, owners=args.owners or world)
     torch.cuda.synchronize()
     stats = graphgen.degree_stats(Ap)
     bounds = sharding.row_splits(Ap, world)
@@ -297,7 +300,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": "exec_mxv_masked BFS step: R-MAT scale %d (ef %d, %s labels), BAND/BOR int32, mask=depth EQZERO at the level producing the largest frontier, early_exit=false"
-                               % (g["gscale"], args.edge_factor, "permuted" if g["permute"] else "raw"),
+                               % (g["gscale"], args.edge_factor, {False: "raw", True: "randomly permuted", "owner-sorted": "owner-sorted"}[g["permute"]]),
                    "n": g["n"], "nnz": g["nnz_global"], "nnz_selected": nnz_sel_total, "rows_selected": rows_sel_total,
                    "frontier": front_total, "bfs_level": L, "parallelism": f"1-D nnz-balanced row blocks x{world}" + (" + RCCL all-gather(v)" if world > 1 else ""),
                    "work_items": sh.plan.n_items, "long_rows": sh.plan.n_long},

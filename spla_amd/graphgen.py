@@ -18,15 +18,30 @@ def _gen(device, seed):
     return g
 
 
+def owner_sorted_permutation(n: int, owners: int, seed: int, device="cpu") -> torch.Tensor:
+    """old label -> new label such that every one of `owners` equal blocks of the new id space holds a pseudo-random 1/owners of the
+    vertices IN THEIR ORIGINAL ORDER.  A 1-D row-block split over these labels is balanced like a random relabelling (every block
+    gets its share of the hubs), but inside a block low raw ids — R-MAT's hot vertices — stay clustered at the front, so the
+    gathered vector keeps one hot region per block instead of hot entries scattered over every cache line."""
+    owner = torch.randperm(n, generator=_gen(device, seed + 7919), device=device) % owners
+    order = torch.argsort(owner * n + torch.arange(n, device=device))  # vertices grouped by owner, ascending raw id inside a group
+    perm = torch.empty(n, dtype=torch.int64, device=device)
+    perm[order] = torch.arange(n, device=device)
+    return perm
+
+
 def rmat_edge_keys(scale: int, edge_factor: int = 16, a: float = 0.57, b: float = 0.19, c: float = 0.19,
-                   seed: int = 1, device="cpu", chunk: int = 1 << 25, permute: bool = False) -> torch.Tensor:
-    """Sorted unique int64 keys i * n + j of the R-MAT edges (self loops removed)."""
+                   seed: int = 1, device="cpu", chunk: int = 1 << 25, permute=False, owners: int = 0) -> torch.Tensor:
+    """Sorted unique int64 keys i * n + j of the R-MAT edges (self loops removed).  permute: False = raw labels, True = random
+    relabelling, "owner-sorted" = owner_sorted_permutation(n, owners)."""
     n = 1 << scale
     m = edge_factor << scale
     g = _gen(device, seed)
     ab, abc = a + b, a + b + c
     perm = None
-    if permute:
+    if permute == "owner-sorted":
+        perm = owner_sorted_permutation(n, max(1, owners), seed, device)
+    elif permute:
         perm = torch.randperm(n, generator=_gen(device, seed + 7919), device=device)
     keys = []
     done = 0
@@ -62,10 +77,10 @@ def keys_to_csr(key: torch.Tensor, n_rows: int, n_cols: int):
     return Ap.to(torch.int32), Aj
 
 
-def rmat_csr(scale: int, edge_factor: int = 16, seed: int = 1, device="cpu", permute: bool = False):
+def rmat_csr(scale: int, edge_factor: int = 16, seed: int = 1, device="cpu", permute=False, owners: int = 0):
     """(n, Ap, Aj) of the R-MAT graph; values are attached by the caller."""
     n = 1 << scale
-    key = rmat_edge_keys(scale, edge_factor, seed=seed, device=device, permute=permute)
+    key = rmat_edge_keys(scale, edge_factor, seed=seed, device=device, permute=permute, owners=owners)
     Ap, Aj = keys_to_csr(key, n, n)
     return n, Ap, Aj
 

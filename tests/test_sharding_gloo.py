@@ -82,3 +82,23 @@ def test_splits_balance_nnz():
         assert b[0] == 0 and b[-1] == n and all(b[i] <= b[i + 1] for i in range(parts))
         nnz = [int(Ap[b[i + 1]] - Ap[b[i]]) for i in range(parts)]
         assert max(nnz) <= int(Ap[-1]) // parts + int((Ap[1:] - Ap[:-1]).max())
+
+
+def test_owner_sorted_permutation():
+    """bench.py's relabelling for N > 1: a bijection whose equal blocks each hold a pseudo-random share of the vertices in original order"""
+    sys.path.insert(0, str(ROOT))
+    from spla_amd import graphgen
+    n, owners = 1 << 12, 8
+    perm = graphgen.owner_sorted_permutation(n, owners, seed=3)
+    assert sorted(perm.tolist()) == list(range(n))
+    inv = torch.empty(n, dtype=torch.int64)
+    inv[perm] = torch.arange(n)
+    for b in range(owners):
+        block = inv[b * n // owners:(b + 1) * n // owners]
+        assert torch.all(block[1:] > block[:-1])  # original order inside a block
+        assert abs(float(block.double().mean()) - n / 2) < n / 8  # a spread sample of the id space, not a contiguous range
+    # the relabelled graph is the same graph
+    _, Ap0, Aj0 = graphgen.rmat_csr(10, 8, seed=4, device="cpu")
+    _, Ap1, Aj1 = graphgen.rmat_csr(10, 8, seed=4, device="cpu", permute="owner-sorted", owners=4)
+    assert int(Ap0[-1]) == int(Ap1[-1])
+    assert sorted((Ap0[1:] - Ap0[:-1]).tolist()) == sorted((Ap1[1:] - Ap1[:-1]).tolist())
