@@ -225,11 +225,12 @@ def main():
     if sparse:
         from spla_amd import sharding
         sx = sharding.SparseExchange(sh.blk, torch.int32, "cuda", fill=0)
-        v_full = sx.exchange(front[:n_local], value=1)[:sh.n_cols_padded]
+        v_full = sx.exchange(front[:n_local], value=1, upper_bound=front_total)[:sh.n_cols_padded]
 
     def exchange():
         if sparse:
-            sx.exchange(front[:n_local], value=1)
+            # the global frontier size is what the previous level's count_mf returned in a real traversal: every rank knows it
+            sx.exchange(front[:n_local], value=1, upper_bound=front_total)
         else:
             sh.gather(front, v_full)
 
@@ -320,7 +321,7 @@ def main():
                            "bytes_per_peer": slice_bytes, "bytes_received_per_rank": slice_bytes * (world - 1),
                            "gbs_per_link_if_direct": round(slice_bytes / (x_ms * 1e-3) / 1e9, 2),
                            "local_spmv_us": round(k_ms * 1e3, 2), "overlap_fraction": 0.0,
-                           "entries_exchanged": int(sx.last_count) if sparse else int(g["n"]),
+                           "entries_exchanged": int(front_total) if sparse else int(g["n"]),
                            "note": "exchange and local SpMV run back to back on one stream in round 1 (no overlap)"}
 
     # ---- verification of the timed result against the oracle (full local rows), and the CPU baseline ------------

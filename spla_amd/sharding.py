@@ -101,18 +101,29 @@ class SparseExchange:
         else:
             dist.all_gather_into_tensor(out, x)
 
-    def exchange(self, x_local: torch.Tensor, value=None) -> torch.Tensor:
-        """x_local: this rank's n_local entries.  value: if every non-fill entry holds this value (a 0/1 frontier), values are not sent."""
+    def exchange(self, x_local: torch.Tensor, value=None, upper_bound: int = None) -> torch.Tensor:
+        """x_local: this rank's n_local entries.  value: if every non-fill entry holds this value (a 0/1 frontier), values are not sent.
+        upper_bound: a number every rank knows that bounds each rank's non-fill count (e.g. the global frontier size the previous
+        iteration counted): then lists are padded to it and neither the count exchange nor any host synchronisation is needed."""
         blk, dev = self.blk, x_local.device
-        idx = torch.nonzero(x_local != self.fill).squeeze(1)  # ascending local row ids (host sync: the list length)
-        c = int(idx.numel())
-        cnt = torch.tensor([c], dtype=torch.int64, device=dev)
-        cnts = torch.empty(blk.world, dtype=torch.int64, device=dev)
-        self._all_gather(cnts, cnt)
-        counts = cnts.tolist()
-        m = max(max(counts), 1)
-        send = torch.full((m,), self.trash, dtype=torch.int64, device=dev)
-        send[:c] = idx + blk.rank * blk.max_rows  # position in the padded [world][max_rows] layout
+        live = x_local != self.fill
+        if upper_bound is not None and hasattr(torch, "nonzero_static"):
+            m = max(int(min(upper_bound, blk.max_rows)), 1)
+            idx = torch.nonzero_static(live, size=m, fill_value=-1).squeeze(1)  # ascending local row ids, -1 beyond the count: no sync
+            send = torch.where(idx >= 0, idx + blk.rank * blk.max_rows, torch.full_like(idx, self.trash))
+            total = None
+        else:
+            idx = torch.nonzero(live).squeeze(1)  # (host sync: the list length)
+            c = int(idx.numel())
+            cnt = torch.tensor([c], dtype=torch.int64, device=dev)
+            cnts = torch.empty(blk.world, dtype=torch.int64, device=dev)
+            self._all_gather(cnts, cnt)
+            counts = cnts.tolist()
+            m = max(max(counts), 1)
+            send = torch.full((m,), self.trash, dtype=torch.int64, device=dev)
+            send[:c] = idx + blk.rank * blk.max_rows  # position in the padded [world][max_rows] layout
+            idx = torch.cat([idx, torch.full((m - c,), -1, dtype=torch.int64, device=dev)])
+            total = sum(counts)
         recv = torch.empty(blk.world * m, dtype=torch.int64, device=dev)
         self._all_gather(recv, send)
         if self.prev is not None:
@@ -120,12 +131,11 @@ class SparseExchange:
         if value is not None:
             self.v_full.index_fill_(0, recv, value)
         else:
-            sv = torch.full((m,), self.fill, dtype=x_local.dtype, device=dev)
-            sv[:c] = x_local[idx]
+            sv = torch.where(idx >= 0, x_local[idx.clamp_min(0)], torch.full((m,), self.fill, dtype=x_local.dtype, device=dev))
             rv = torch.empty(blk.world * m, dtype=x_local.dtype, device=dev)
             self._all_gather(rv, sv)
             self.v_full.index_put_((recv,), rv)
         self.v_full[self.trash] = self.fill
         self.prev = recv
-        self.last_count = sum(counts)
+        self.last_count = total  # None when the caller supplied the bound (the count is then the caller's knowledge)
         return self.v_full

@@ -54,13 +54,14 @@ def _worker(rank, world, port, out_dir):
             k = [n // 50, n // 7, 0, 3][rnd]
             pos = torch.randperm(n, generator=gg)[:k]
             x[pos] = 1 if const is not None else torch.randint(8, 99, (k,), generator=gg, dtype=torch.int32)
-            got = sx.exchange(x[blk.lo:blk.hi], value=const)
+            # odd rounds: the caller knows a global bound on the count (no count exchange, no host sync); even rounds: it does not
+            got = sx.exchange(x[blk.lo:blk.hi], value=const, upper_bound=(k if rnd % 2 else None))
             want = blk.all_gather(blk.pad_local(x[blk.lo:blk.hi], fill=fill))
             assert got.numel() == blk.n_cols_padded + 1
             live = torch.zeros(blk.n_cols_padded, dtype=torch.bool)  # padding slots of the dense layout hold `fill` in both forms
             assert torch.equal(got[:blk.n_cols_padded], want), (fill, rnd)
             assert torch.equal(got[:blk.n_cols_padded][blk.Aj.to(torch.int64)], x[blk.Aj_global.to(torch.int64)])
-            assert sx.last_count == k
+            assert sx.last_count == (None if rnd % 2 else k)
     Path(out_dir, f"ok{rank}").write_text("ok")
     dist.barrier()
     dist.destroy_process_group()
