@@ -215,12 +215,11 @@ def main():
     if world == 1:
         v_full.copy_(front)
 
-    # the exchange step (N > 1): dense all-gather of the padded slices, or — when the frontier is sparse and there are enough ranks
-    # for the volume to matter — the sparsity-aware form (positions only; every step does the full exchange of a fresh vector:
+    # the exchange step (N > 1): dense all-gather of the padded slices, or — when the frontier is sparse — the sparsity-aware form (positions only; every step does the full exchange of a fresh vector:
     # local compaction, count exchange, position all-gather, clear + scatter).  SPLA_EXCHANGE=dense|sparse overrides the rule;
     # the rule depends on global quantities only, so every rank picks the same form.
     mode = os.environ.get("SPLA_EXCHANGE", "auto")
-    sparse = world > 1 and (mode == "sparse" or (mode == "auto" and world >= 4 and front_total * 16 < g["n"]))
+    sparse = world > 1 and (mode == "sparse" or (mode == "auto" and front_total * 16 < g["n"]))
     sx = None
     if sparse:
         from spla_amd import sharding
