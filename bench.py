@@ -40,10 +40,7 @@ def coll_device():
 
 def kernel_name(plan, t, mul, add, early):
     from spla_amd import kernels
-    name = kernels.mxv_variant(t, mul, add, early)
-    if plan.hot and name.startswith("mxv_wavetile") and os.environ.get("SPLAHIP_HOT") == "1":
-        name = name.replace("mxv_wavetile", "spmv_hot (persistent, LDS hot-column cache)")
-    return name
+    return kernels.mxv_variant(t, mul, add, early)
 
 
 def log(*a):
@@ -106,10 +103,8 @@ class Sharded:
         self.blk = g["blk"]
         self.n = g["n"]
         self.n_local = self.blk.n_local
-        # the plan = wave-tile work items (built once per matrix on the device, like the AccCsr upload); the experimental
-        # hot-column cache is attached only for SPLAHIP_HOT=1 A/B runs
-        hot = os.environ.get("SPLAHIP_HOT") == "1"
-        self.plan = kernels.CsrPlan(self.n_local, g["nnz_local"], g["Ap"], self.blk.n_cols_padded if hot else 0, g["Aj"] if hot else None)
+        # the plan = wave-tile work items (built once per matrix on the device, like the AccCsr upload)
+        self.plan = kernels.CsrPlan(self.n_local, g["nnz_local"], g["Ap"])
         self.max_rows = self.blk.max_rows
         self.n_cols_padded = self.blk.n_cols_padded
 

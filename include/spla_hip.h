@@ -68,10 +68,6 @@ int splahip_stream_sync(void* stream);
 typedef struct splahip_plan_s* splahip_plan;
 
 int splahip_csr_plan_create(splahip_plan* plan, uint32_t n_rows, uint32_t nnz, const uint32_t* d_Ap, void* stream);
-/* Optional second half of the plan: gives it the matrix's column ids, from which it derives the hot-column cache of the
- * persistent mxv kernel (the ~28 K most referenced columns get an LDS slot; a re-encoded private copy of Aj is kept with
- * the plan, +4 bytes per entry).  Without it mxv runs the non-persistent wave-tile kernel.  Blocks.            */
-int splahip_csr_plan_attach_columns(splahip_plan plan, uint32_t n_cols, const uint32_t* d_Aj, void* stream);
 /* Optional: a sliced-ELL copy of the matrix with hot-column encoding, kept with the plan (+8 bytes per entry; DESIGN.md 4.1,
  * spla_amd/csrc/kernels/mxv_sell.hpp).  With it splahip_mxv_masked serves every associative op_add (no early exit) from the
  * copy: rows are cut into chunks of <= 256 entries, chunks sorted by length and laid out 64 to a slice, one lane per chunk,

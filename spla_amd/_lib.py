@@ -39,7 +39,6 @@ _SIGNATURES = {
     "splahip_memset32": (C.c_int, [_vp, C.c_uint32, C.c_size_t, _vp]),
     "splahip_stream_sync": (C.c_int, [_vp]),
     "splahip_csr_plan_create": (C.c_int, [C.POINTER(_vp), C.c_uint32, C.c_uint32, _vp, _vp]),
-    "splahip_csr_plan_attach_columns": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
     "splahip_csr_plan_attach_sell": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, _vp]),
     "splahip_csr_plan_sell_info": (C.c_int, [_vp, _u32p, _u32p, _u32p, _u32p]),
     "splahip_mxv_variant_of": (C.c_char_p, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -25,16 +25,6 @@ namespace spla {
         void ensure_plan(HipCsr<T>* a, uint n_rows) {
             if (!a->plan) hip_check(splahip_csr_plan_create(&a->plan, n_rows, a->values, a->Ap.template as<uint32_t>(), nullptr), "csr plan");
         }
-        // the hot-column half of the plan, built the first time the matrix is used by mxv (kept until the matrix changes)
-        template<typename T>
-        void ensure_hot_plan(HipCsr<T>* a, uint n_rows, uint n_cols) {
-            ensure_plan(a, n_rows);
-            if (!a->hot_attached) {
-                hip_check(splahip_csr_plan_attach_columns(a->plan, n_cols, a->Aj.template as<uint32_t>(), nullptr), "hot-column plan");
-                a->hot_attached = true;
-            }
-        }
-
         template<typename T>
         class Algo_mxv_masked_hip final : public RegistryAlgo {
         public:
@@ -67,7 +57,7 @@ namespace spla {
                 M->validate_rw(FormatMatrix::AccCsr);
 
                 auto* a = M->acc_csr();
-                ensure_plan(a, M->get_n_rows());// (ensure_hot_plan: experimental persistent kernel)
+                ensure_plan(a, M->get_n_rows());
                 const bool early = t->get_desc_or_default()->get_early_exit();
                 hip_check(splahip_mxv_masked(a->plan, TypeTraits<T>::id, M->get_n_rows(), M->get_n_cols(),
                                              a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(),

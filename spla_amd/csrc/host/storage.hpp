@@ -141,14 +141,12 @@ namespace spla {
     struct HipCsr final : Decoration<T> {
         DeviceBuffer Ap, Aj, Ax;
         splahip_plan plan = nullptr;
-        bool         hot_attached = false;// plan carries the hot-column cache (mxv)
         ~HipCsr() override {
             if (plan) splahip_csr_plan_destroy(plan);
         }
         void drop_plan() {
             if (plan) splahip_csr_plan_destroy(plan);
             plan         = nullptr;
-            hot_attached = false;
         }
     };
 

@@ -15,14 +15,12 @@
 // the reference's early-exit rule.  Exact for non-associative / non-commutative op_add.
 #include "block_utils.hpp"
 #include "common.hpp"
-#include "mxv_hot.hpp"
 #include "mxv_kernels.hpp"
 #include "ops.hpp"
 #include "plan.hpp"
 
 #include <cstdlib>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 using namespace splahip;
 
@@ -54,23 +52,6 @@ namespace {
         return static_semiring(type, op_mult, op_add) ? Variant::WaveTileStatic : Variant::WaveTileDynamic;
     }
 
-    uint compute_units() {
-        static uint cus = 0;
-        if (!cus) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = (uint) prop.multiProcessorCount;
-            if (!cus) cus = 256;
-        }
-        return cus;
-    }
-    // The persistent LDS-hot-cache kernel (mxv_hot.hpp) is EXPERIMENTAL and off by default: on MI355X it is correct but not
-    // faster than the non-persistent wave-tile kernel yet.  SPLAHIP_HOT=1 switches it on for A/B runs.
-    bool hot_disabled() {
-        const char* e = std::getenv("SPLAHIP_HOT");// read per call so a test can A/B both kernels in one process
-        return !(e && e[0] == '1');
-    }
-
     bool sell_disabled() {
         const char* e = std::getenv("SPLAHIP_SELL");
         return e && e[0] == '0';
@@ -79,20 +60,7 @@ namespace {
     template<typename T, class Mult, class Add>
     int launch_wavetile(splahip_plan plan, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const void* mask,
                         const void* v, void* r, int op_mult, int op_add, int op_select, uint32_t init_bits, hipStream_t st) {
-        const bool use_hot = plan->d_Aj_enc != nullptr && !hot_disabled();
-        const uint32_t* Ajk = use_hot ? plan->d_Aj_enc : Aj;
-        const uint grid   = (plan->n_items + Cfg::kWaves - 1) / Cfg::kWaves;
-        if (use_hot) {
-            // persistent form: one 512-thread workgroup per CU, hot columns of v gathered once into LDS
-            if (plan->n_hot)
-                hipLaunchKernelGGL((hot_gather_kernel<T>), dim3((plan->n_hot + 255) / 256), dim3(256), 0, st, plan->d_hot_cols, plan->n_hot,
-                                   static_cast<const T*>(v), reinterpret_cast<T*>(plan->d_hot_values));
-            hipLaunchKernelGGL((spmv_hot_kernel<Cfg, T, Mult, Add>), dim3(compute_units()), dim3(HotCfg::kTpb), 0, st,
-                               plan->d_item_row, plan->d_item_k0, plan->n_items, Ap, Ajk, static_cast<const uint32_t*>(Ax),
-                               static_cast<const T*>(mask), static_cast<const T*>(v), reinterpret_cast<const T*>(plan->d_hot_values), plan->n_hot,
-                               static_cast<T*>(r), reinterpret_cast<T*>(plan->d_partial), Mult(op_mult), Add(op_add), op_select,
-                               from_bits<T>(init_bits), plan->nnz);
-        } else
+        const uint grid = (plan->n_items + Cfg::kWaves - 1) / Cfg::kWaves;
         hipLaunchKernelGGL((spmv_wavetile_kernel<Cfg, T, Mult, Add, false>), dim3(grid), dim3(Cfg::kTpb), 0, st,
                            plan->d_item_row, plan->d_item_k0, plan->n_items, Ap, Aj, static_cast<const uint32_t*>(Ax),
                            static_cast<const T*>(mask), static_cast<const T*>(v), static_cast<const uint32_t*>(nullptr),
@@ -160,9 +128,6 @@ namespace {
         if (plan->d_partial) (void) hipFree(plan->d_partial);
         if (plan->d_partial_ok) (void) hipFree(plan->d_partial_ok);
         if (plan->d_ws) (void) hipFree(plan->d_ws);
-        if (plan->d_hot_cols) (void) hipFree(plan->d_hot_cols);
-        if (plan->d_hot_values) (void) hipFree(plan->d_hot_values);
-        if (plan->d_Aj_enc) (void) hipFree(plan->d_Aj_enc);
         sell_release(plan->sell);
         delete plan;
     }
@@ -225,66 +190,6 @@ int splahip_csr_plan_create(splahip_plan* out, uint32_t n_rows, uint32_t nnz, co
         return fail(SPLAHIP_ERROR, "plan construction failed: %s", hipGetErrorString(e));
     }
     *out = plan;
-    return SPLAHIP_OK;
-}
-
-int splahip_csr_plan_attach_columns(splahip_plan plan, uint32_t n_cols, const uint32_t* d_Aj, void* stream) {
-    SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
-    SPLAHIP_REQUIRE(n_cols < HotCfg::kHotFlag, "n_cols must be < 2^31");
-    if (plan->nnz == 0 || n_cols == 0) return SPLAHIP_OK;
-    SPLAHIP_REQUIRE(d_Aj != nullptr, "d_Aj is null");
-    int st = ensure_device();
-    if (st != SPLAHIP_OK) return st;
-    hipStream_t s = as_stream(stream);
-    if (plan->d_hot_cols) (void) hipFree(plan->d_hot_cols);
-    if (plan->d_hot_values) (void) hipFree(plan->d_hot_values);
-    if (plan->d_Aj_enc) (void) hipFree(plan->d_Aj_enc);
-    plan->d_hot_cols = plan->d_hot_values = plan->d_Aj_enc = nullptr;
-    plan->n_hot = n_cols < HotCfg::kHot ? n_cols : HotCfg::kHot;
-
-    // columns by descending reference count (stable: ties keep ascending column order) -> the first n_hot get an LDS slot
-    uint32_t *count = nullptr, *key = nullptr, *col = nullptr, *key_s = nullptr, *col_s = nullptr, *slot_of = nullptr;
-    void*     tmp   = nullptr;
-    auto      cleanup = [&]() {
-        for (void* q : {(void*) count, (void*) key, (void*) col, (void*) key_s, (void*) col_s, (void*) slot_of, tmp})
-            if (q) (void) hipFree(q);
-    };
-    const size_t cb = sizeof(uint32_t) * (size_t) n_cols;
-    hipError_t   e  = hipMalloc(reinterpret_cast<void**>(&count), cb);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&key), cb);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&col), cb);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&key_s), cb);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&col_s), cb);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&slot_of), cb);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&plan->d_hot_cols), sizeof(uint32_t) * (size_t) plan->n_hot);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&plan->d_hot_values), sizeof(uint32_t) * (size_t) plan->n_hot);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&plan->d_Aj_enc), sizeof(uint32_t) * (size_t) plan->nnz);
-    if (e == hipSuccess) e = hipMemsetAsync(count, 0, cb, s);
-    if (e == hipSuccess) e = hipMemsetAsync(slot_of, 0xFF, cb, s);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(col_count_kernel, dim3((plan->nnz + 255) / 256), dim3(256), 0, s, d_Aj, plan->nnz, count);
-        hipLaunchKernelGGL(col_key_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, s, count, n_cols, key, col);
-        e = hipGetLastError();
-    }
-    size_t tmp_bytes = 0;
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, key, key_s, col, col_s, n_cols, 0, 32, s);
-    if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 4);
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tmp_bytes, key, key_s, col, col_s, n_cols, 0, 32, s);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(slot_fill_kernel, dim3((plan->n_hot + 255) / 256), dim3(256), 0, s, col_s, key_s, plan->n_hot, slot_of, plan->d_hot_cols);
-        hipLaunchKernelGGL(col_encode_kernel, dim3((plan->nnz + 255) / 256), dim3(256), 0, s, d_Aj, plan->nnz, slot_of, plan->d_Aj_enc);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    cleanup();
-    if (e != hipSuccess) {
-        if (plan->d_hot_cols) (void) hipFree(plan->d_hot_cols);
-        if (plan->d_hot_values) (void) hipFree(plan->d_hot_values);
-        if (plan->d_Aj_enc) (void) hipFree(plan->d_Aj_enc);
-        plan->d_hot_cols = plan->d_hot_values = plan->d_Aj_enc = nullptr;
-        plan->n_hot = 0;
-        return fail(SPLAHIP_ERROR, "hot-column plan failed: %s", hipGetErrorString(e));
-    }
     return SPLAHIP_OK;
 }
 

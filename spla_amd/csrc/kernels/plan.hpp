@@ -37,11 +37,6 @@ struct splahip_plan_s {
     // call workspace, grown on demand and kept with the plan so steady-state calls do not allocate (vxm pull form)
     void*     d_ws         = nullptr;
     size_t    ws_bytes     = 0;
-    // hot-column cache (splahip_csr_plan_attach_columns): the matrix's column ids re-encoded for spmv_hot_kernel
-    uint32_t  n_hot        = 0;      // columns whose values are kept in LDS
-    uint32_t* d_hot_cols   = nullptr;// n_hot column ids, in LDS-slot order
-    uint32_t* d_hot_values = nullptr;// n_hot words of scratch, gathered per launch
-    uint32_t* d_Aj_enc     = nullptr;// nnz words: bit 31 set -> low bits are the LDS slot, else the column id
     splahip_sell_s* sell   = nullptr;// splahip_csr_plan_attach_sell
 };
 

@@ -36,10 +36,8 @@ class CsrPlan:
 
     def __init__(self, n_rows: int, nnz: int, Ap: torch.Tensor, n_cols: int = 0, Aj: torch.Tensor = None, Ax: torch.Tensor = None):
         """Ap alone gives the wave-tile decomposition of the CSR kernels.  With (n_cols, Aj, Ax) the plan also builds the
-        sliced-ELL + hot-column copy that mxv uses for associative op_add (attach_sell).  With (n_cols, Aj) only: the
-        experimental persistent CSR kernel's hot-column table (attach_columns, SPLAHIP_HOT=1)."""
+        sliced-ELL + hot-column copy that mxv uses for associative op_add (attach_sell)."""
         self.n_rows, self.nnz = int(n_rows), int(nnz)
-        self.hot = False
         self.sell = None
         self._h = C.c_void_p()
         _lib.call("splahip_csr_plan_create", C.byref(self._h), self.n_rows, self.nnz, _ptr(Ap), current_stream_ptr())
@@ -49,8 +47,6 @@ class CsrPlan:
         self.n_blocks = self.n_items  # work items (one per wavefront)
         if Aj is not None and Ax is not None and n_cols:
             self.attach_sell(n_cols, Ap, Aj, Ax)
-        elif Aj is not None and n_cols:
-            self.attach_columns(n_cols, Aj)
 
     def attach_sell(self, n_cols: int, Ap: torch.Tensor, Aj: torch.Tensor, Ax: torch.Tensor):
         """sliced-ELL + hot-column copy of the matrix (values included: rebuild when the matrix changes)"""
@@ -59,10 +55,6 @@ class CsrPlan:
         a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
         _lib.call("splahip_csr_plan_sell_info", self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
         self.sell = {"slices": a.value, "slots": b.value, "hot_columns": c.value, "long_rows": d.value} if a.value else None
-
-    def attach_columns(self, n_cols: int, Aj: torch.Tensor):
-        _lib.call("splahip_csr_plan_attach_columns", self._h, int(n_cols), _ptr(Aj) if self.nnz else None, current_stream_ptr())
-        self.hot = self.nnz > 0
 
     @property
     def handle(self):

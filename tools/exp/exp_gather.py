@@ -11,10 +11,7 @@ scale = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 22
 n, Ap, Aj = graphgen.rmat_csr(scale, 16, seed=1, device="cuda")
 nnz = int(Ap[-1])
 plan = kernels.CsrPlan(n, nnz, Ap)
-HOT = '--hot' in sys.argv
-if HOT:
-    import os
-    os.environ['SPLAHIP_HOT'] = '1'
+HOT = '--sell' in sys.argv  # run through the sliced-ELL copy (values copied: rebuilt per column pattern)
 SEL = 'EQZERO' if '--eqzero' in sys.argv else 'ALWAYS'
 g = torch.Generator(device="cuda"); g.manual_seed(3)
 Ax = torch.rand(nnz, generator=g, device="cuda")
@@ -22,7 +19,7 @@ v = torch.rand(n, generator=g, device="cuda")
 mask = torch.zeros(n, device="cuda"); r = torch.empty(n, device="cuda")
 
 def bench(name, aj, steps=20):
-    pl = kernels.CsrPlan(n, nnz, Ap, n, aj) if HOT else plan
+    pl = kernels.CsrPlan(n, nnz, Ap, n, aj, Ax) if HOT else plan
     fn = lambda: kernels.mxv_masked(pl, "FLOAT", n, Ap, aj, Ax, mask, v, r, "MULT", "PLUS", SEL, 0.0)
     for _ in range(3): fn()
     torch.cuda.synchronize()
