@@ -61,150 +61,141 @@ typedef uint32_t spla_uint;
 typedef size_t   spla_size_t;
 
 /* opaque handles: raw pointers to intrusively counted objects (reference include/spla.h:119-132) */
-typedef struct spla_RefCnt_t*       spla_RefCnt;
-typedef struct spla_MemView_t*      spla_MemView;
-typedef struct spla_Object_t*       spla_Object;
-typedef struct spla_Type_t*         spla_Type;
-typedef struct spla_Descriptor_t*   spla_Descriptor;
-typedef struct spla_Matrix_t*       spla_Matrix;
-typedef struct spla_Vector_t*       spla_Vector;
-typedef struct spla_Scalar_t*       spla_Scalar;
-typedef struct spla_ScheduleTask_t* spla_ScheduleTask;
-typedef struct spla_OpBinary_t*     spla_OpBinary;
-typedef struct spla_OpSelect_t*     spla_OpSelect;
+#define SPLA_C_HANDLES(X) X(RefCnt) X(MemView) X(Object) X(Type) X(Descriptor) X(Matrix) X(Vector) X(Scalar) X(ScheduleTask) X(OpBinary) X(OpSelect) X(MtxLoader)
+#define SPLA_C_DECL_HANDLE(Name) typedef struct spla_##Name##_t* spla_##Name;
+SPLA_C_HANDLES(SPLA_C_DECL_HANDLE)
+#undef SPLA_C_DECL_HANDLE
 
-typedef void(spla_MessageCallback)(spla_Status, const char* message, const char* file, const char* function, int line, void* p_user_data);
+typedef void(spla_MessageCallback)(spla_Status status, const char* text, const char* file, const char* function, int line, void* user);
+
+/* the three element types of the path, as (accessor suffix, C type): spla_*_set_<suffix> / spla_*_get_<suffix> */
+#define SPLA_C_ELEMENT_TYPES(X, Obj, ...) X(Obj, int, int, __VA_ARGS__) X(Obj, uint, unsigned int, __VA_ARGS__) X(Obj, float, float, __VA_ARGS__)
 
 /* ---- library (reference include/spla.h:136-144) ---- */
 SPLA_API void        spla_Library_finalize(void);
 SPLA_API spla_Status spla_Library_initialize(void);
-SPLA_API spla_Status spla_Library_set_accelerator(spla_AcceleratorType accelerator);
-SPLA_API spla_Status spla_Library_set_platform(int index);
-SPLA_API spla_Status spla_Library_set_device(int index);
-SPLA_API spla_Status spla_Library_set_queues_count(int count);
-SPLA_API spla_Status spla_Library_set_message_callback(spla_MessageCallback callback, void* p_user_data);
+SPLA_API spla_Status spla_Library_set_accelerator(spla_AcceleratorType kind);
+SPLA_API spla_Status spla_Library_set_platform(int platform_index);
+SPLA_API spla_Status spla_Library_set_device(int device_index);
+SPLA_API spla_Status spla_Library_set_queues_count(int n_queues);
+SPLA_API spla_Status spla_Library_set_message_callback(spla_MessageCallback on_message, void* user);
 SPLA_API spla_Status spla_Library_set_default_callback(void);
-SPLA_API spla_Status spla_Library_get_accelerator_info(char* buffer, int length);
+SPLA_API spla_Status spla_Library_get_accelerator_info(char* text, int capacity);
 
 /* ---- element types (reference include/spla.h:150-153) ---- */
-SPLA_API spla_Type spla_Type_BOOL(void);
-SPLA_API spla_Type spla_Type_INT(void);
-SPLA_API spla_Type spla_Type_UINT(void);
-SPLA_API spla_Type spla_Type_FLOAT(void);
+#define SPLA_C_DECL_TYPE(NAME) SPLA_API spla_Type spla_Type_##NAME(void);
+SPLA_C_DECL_TYPE(BOOL) SPLA_C_DECL_TYPE(INT) SPLA_C_DECL_TYPE(UINT) SPLA_C_DECL_TYPE(FLOAT)
+#undef SPLA_C_DECL_TYPE
 
-/* ---- built-in binary ops (reference include/spla.h:197-241): spla_OpBinary_<OP>_{INT,UINT,FLOAT};
- *      the bitwise ops exist for INT and UINT only ---- */
+/* ---- built-in ops (reference include/spla.h:197-267): spla_OpBinary_<OP>_{INT,UINT,FLOAT} (the bitwise ones: INT and UINT only)
+ *      and spla_OpSelect_<OP>_{INT,UINT,FLOAT}; library-owned objects ---- */
 #define SPLA_C_BINARY_OPS_ARITH(X) X(PLUS) X(MINUS) X(MULT) X(DIV) X(MINUS_POW2) X(FIRST) X(SECOND) X(BONE) X(MIN) X(MAX) X(LOR) X(LAND)
 #define SPLA_C_BINARY_OPS_BITWISE(X) X(BOR) X(BAND) X(BXOR)
 #define SPLA_C_SELECT_OPS(X) X(EQZERO) X(NQZERO) X(GTZERO) X(GEZERO) X(LTZERO) X(LEZERO) X(ALWAYS) X(NEVER)
-
-#define SPLA_C_DECL_BIN3(OP)                                \
-    SPLA_API spla_OpBinary spla_OpBinary_##OP##_INT(void);  \
-    SPLA_API spla_OpBinary spla_OpBinary_##OP##_UINT(void); \
-    SPLA_API spla_OpBinary spla_OpBinary_##OP##_FLOAT(void);
-#define SPLA_C_DECL_BIN2(OP)                                \
-    SPLA_API spla_OpBinary spla_OpBinary_##OP##_INT(void);  \
-    SPLA_API spla_OpBinary spla_OpBinary_##OP##_UINT(void);
-#define SPLA_C_DECL_SEL3(OP)                                \
-    SPLA_API spla_OpSelect spla_OpSelect_##OP##_INT(void);  \
-    SPLA_API spla_OpSelect spla_OpSelect_##OP##_UINT(void); \
-    SPLA_API spla_OpSelect spla_OpSelect_##OP##_FLOAT(void);
+#define SPLA_C_GETTER(Kind, OP, T) SPLA_API spla_Op##Kind spla_Op##Kind##_##OP##_##T(void);
+#define SPLA_C_DECL_BIN3(OP) SPLA_C_GETTER(Binary, OP, INT) SPLA_C_GETTER(Binary, OP, UINT) SPLA_C_GETTER(Binary, OP, FLOAT)
+#define SPLA_C_DECL_BIN2(OP) SPLA_C_GETTER(Binary, OP, INT) SPLA_C_GETTER(Binary, OP, UINT)
+#define SPLA_C_DECL_SEL3(OP) SPLA_C_GETTER(Select, OP, INT) SPLA_C_GETTER(Select, OP, UINT) SPLA_C_GETTER(Select, OP, FLOAT)
 SPLA_C_BINARY_OPS_ARITH(SPLA_C_DECL_BIN3)
 SPLA_C_BINARY_OPS_BITWISE(SPLA_C_DECL_BIN2)
-/* ---- built-in select ops (reference include/spla.h:244-267) ---- */
 SPLA_C_SELECT_OPS(SPLA_C_DECL_SEL3)
 #undef SPLA_C_DECL_BIN3
 #undef SPLA_C_DECL_BIN2
 #undef SPLA_C_DECL_SEL3
+#undef SPLA_C_GETTER
 
 /* ---- reference counting (reference include/spla.h:273-274) ---- */
-SPLA_API spla_Status spla_RefCnt_ref(spla_RefCnt object);
-SPLA_API spla_Status spla_RefCnt_unref(spla_RefCnt object);
+SPLA_API spla_Status spla_RefCnt_ref(spla_RefCnt handle);
+SPLA_API spla_Status spla_RefCnt_unref(spla_RefCnt handle);
 
-/* ---- memory views (reference include/spla.h:284-289) ---- */
-SPLA_API spla_Status spla_MemView_make(spla_MemView* view, void* buffer, spla_size_t size, spla_bool is_mutable);
-SPLA_API spla_Status spla_MemView_read(spla_MemView view, spla_size_t offset, spla_size_t size, void* dst);
-SPLA_API spla_Status spla_MemView_write(spla_MemView view, spla_size_t offset, spla_size_t size, const void* src);
-SPLA_API spla_Status spla_MemView_get_buffer(spla_MemView view, void** buffer);
-SPLA_API spla_Status spla_MemView_get_size(spla_MemView view, spla_size_t* size);
-SPLA_API spla_Status spla_MemView_is_mutable(spla_MemView view, spla_bool* is_mutable);
+/* ---- memory views over caller memory (reference include/spla.h:284-289) ---- */
+SPLA_API spla_Status spla_MemView_make(spla_MemView* out, void* memory, spla_size_t n_bytes, spla_bool writable);
+SPLA_API spla_Status spla_MemView_read(spla_MemView view, spla_size_t at, spla_size_t n_bytes, void* into);
+SPLA_API spla_Status spla_MemView_write(spla_MemView view, spla_size_t at, spla_size_t n_bytes, const void* from);
+SPLA_API spla_Status spla_MemView_get_buffer(spla_MemView view, void** memory);
+SPLA_API spla_Status spla_MemView_get_size(spla_MemView view, spla_size_t* n_bytes);
+SPLA_API spla_Status spla_MemView_is_mutable(spla_MemView view, spla_bool* writable);
 
 /* ---- scalars (reference include/spla.h:295-301) ---- */
-SPLA_API spla_Status spla_Scalar_make(spla_Scalar* scalar, spla_Type type);
-SPLA_API spla_Status spla_Scalar_set_int(spla_Scalar s, int value);
-SPLA_API spla_Status spla_Scalar_set_uint(spla_Scalar s, unsigned int value);
-SPLA_API spla_Status spla_Scalar_set_float(spla_Scalar s, float value);
-SPLA_API spla_Status spla_Scalar_get_int(spla_Scalar s, int* value);
-SPLA_API spla_Status spla_Scalar_get_uint(spla_Scalar s, unsigned int* value);
-SPLA_API spla_Status spla_Scalar_get_float(spla_Scalar s, float* value);
+SPLA_API spla_Status spla_Scalar_make(spla_Scalar* out, spla_Type type);
+#define SPLA_C_SCALAR_ACCESS(Obj, sfx, ctype, ...)                          \
+    SPLA_API spla_Status spla_Scalar_set_##sfx(spla_Scalar scalar, ctype x); \
+    SPLA_API spla_Status spla_Scalar_get_##sfx(spla_Scalar scalar, ctype* x);
+SPLA_C_ELEMENT_TYPES(SPLA_C_SCALAR_ACCESS, Scalar, 0)
+#undef SPLA_C_SCALAR_ACCESS
 
 /* ---- vectors (reference include/spla.h:324-336) ---- */
-SPLA_API spla_Status spla_Vector_make(spla_Vector* v, spla_uint n_rows, spla_Type type);
-SPLA_API spla_Status spla_Vector_set_format(spla_Vector v, int format);
-SPLA_API spla_Status spla_Vector_set_fill_value(spla_Vector v, spla_Scalar value);
-SPLA_API spla_Status spla_Vector_set_reduce(spla_Vector v, spla_OpBinary reduce);
-SPLA_API spla_Status spla_Vector_set_int(spla_Vector v, spla_uint row_id, int value);
-SPLA_API spla_Status spla_Vector_set_uint(spla_Vector v, spla_uint row_id, unsigned int value);
-SPLA_API spla_Status spla_Vector_set_float(spla_Vector v, spla_uint row_id, float value);
-SPLA_API spla_Status spla_Vector_get_int(spla_Vector v, spla_uint row_id, int* value);
-SPLA_API spla_Status spla_Vector_get_uint(spla_Vector v, spla_uint row_id, unsigned int* value);
-SPLA_API spla_Status spla_Vector_get_float(spla_Vector v, spla_uint row_id, float* value);
-SPLA_API spla_Status spla_Vector_build(spla_Vector v, spla_MemView keys, spla_MemView values);
-SPLA_API spla_Status spla_Vector_read(spla_Vector v, spla_MemView* keys, spla_MemView* values);
-SPLA_API spla_Status spla_Vector_clear(spla_Vector v);
+SPLA_API spla_Status spla_Vector_make(spla_Vector* out, spla_uint n_rows, spla_Type type);
+SPLA_API spla_Status spla_Vector_set_format(spla_Vector vec, int format /* spla_FormatVector */);
+SPLA_API spla_Status spla_Vector_set_fill_value(spla_Vector vec, spla_Scalar fill);
+SPLA_API spla_Status spla_Vector_set_reduce(spla_Vector vec, spla_OpBinary on_duplicate);
+#define SPLA_C_VECTOR_ACCESS(Obj, sfx, ctype, ...)                                     \
+    SPLA_API spla_Status spla_Vector_set_##sfx(spla_Vector vec, spla_uint i, ctype x);  \
+    SPLA_API spla_Status spla_Vector_get_##sfx(spla_Vector vec, spla_uint i, ctype* x);
+SPLA_C_ELEMENT_TYPES(SPLA_C_VECTOR_ACCESS, Vector, 0)
+#undef SPLA_C_VECTOR_ACCESS
+SPLA_API spla_Status spla_Vector_build(spla_Vector vec, spla_MemView indices, spla_MemView values);
+SPLA_API spla_Status spla_Vector_read(spla_Vector vec, spla_MemView* indices, spla_MemView* values);
+SPLA_API spla_Status spla_Vector_clear(spla_Vector vec);
 
 /* ---- matrices (reference include/spla.h:342-354) ---- */
-SPLA_API spla_Status spla_Matrix_make(spla_Matrix* M, spla_uint n_rows, spla_uint n_cols, spla_Type type);
-SPLA_API spla_Status spla_Matrix_set_format(spla_Matrix M, int format);
-SPLA_API spla_Status spla_Matrix_set_fill_value(spla_Matrix M, spla_Scalar value);
-SPLA_API spla_Status spla_Matrix_set_reduce(spla_Matrix M, spla_OpBinary reduce);
-SPLA_API spla_Status spla_Matrix_set_int(spla_Matrix M, spla_uint row_id, spla_uint col_id, int value);
-SPLA_API spla_Status spla_Matrix_set_uint(spla_Matrix M, spla_uint row_id, spla_uint col_id, unsigned int value);
-SPLA_API spla_Status spla_Matrix_set_float(spla_Matrix M, spla_uint row_id, spla_uint col_id, float value);
-SPLA_API spla_Status spla_Matrix_get_int(spla_Matrix M, spla_uint row_id, spla_uint col_id, int* value);
-SPLA_API spla_Status spla_Matrix_get_uint(spla_Matrix M, spla_uint row_id, spla_uint col_id, unsigned int* value);
-SPLA_API spla_Status spla_Matrix_get_float(spla_Matrix M, spla_uint row_id, spla_uint col_id, float* value);
-SPLA_API spla_Status spla_Matrix_build(spla_Matrix M, spla_MemView keys1, spla_MemView keys2, spla_MemView values);
-SPLA_API spla_Status spla_Matrix_read(spla_Matrix M, spla_MemView* keys1, spla_MemView* keys2, spla_MemView* values);
-SPLA_API spla_Status spla_Matrix_clear(spla_Matrix M);
+SPLA_API spla_Status spla_Matrix_make(spla_Matrix* out, spla_uint n_rows, spla_uint n_cols, spla_Type type);
+SPLA_API spla_Status spla_Matrix_set_format(spla_Matrix mat, int format /* spla_FormatMatrix */);
+SPLA_API spla_Status spla_Matrix_set_fill_value(spla_Matrix mat, spla_Scalar fill);
+SPLA_API spla_Status spla_Matrix_set_reduce(spla_Matrix mat, spla_OpBinary on_duplicate);
+#define SPLA_C_MATRIX_ACCESS(Obj, sfx, ctype, ...)                                                  \
+    SPLA_API spla_Status spla_Matrix_set_##sfx(spla_Matrix mat, spla_uint i, spla_uint j, ctype x);  \
+    SPLA_API spla_Status spla_Matrix_get_##sfx(spla_Matrix mat, spla_uint i, spla_uint j, ctype* x);
+SPLA_C_ELEMENT_TYPES(SPLA_C_MATRIX_ACCESS, Matrix, 0)
+#undef SPLA_C_MATRIX_ACCESS
+SPLA_API spla_Status spla_Matrix_build(spla_Matrix mat, spla_MemView rows, spla_MemView cols, spla_MemView values);
+SPLA_API spla_Status spla_Matrix_read(spla_Matrix mat, spla_MemView* rows, spla_MemView* cols, spla_MemView* values);
+SPLA_API spla_Status spla_Matrix_clear(spla_Matrix mat);
+
+/* Every spla_Exec_* call ends with the same two arguments (reference include/spla.h:369-388): an optional descriptor and, when
+ * `task_out` is not NULL, the request to only create the task object and hand it back. */
+#define SPLA_C_EXEC_TAIL spla_Descriptor options, spla_ScheduleTask* task_out
 
 /* ---- the hot path (reference include/spla.h:369-373) ---- */
-SPLA_API spla_Status spla_Exec_mxm(spla_Matrix R, spla_Matrix A, spla_Matrix B, spla_OpBinary op_multiply, spla_OpBinary op_add, spla_Scalar init, spla_Descriptor desc, spla_ScheduleTask* task);
-SPLA_API spla_Status spla_Exec_mxmT_masked(spla_Matrix R, spla_Matrix mask, spla_Matrix A, spla_Matrix B, spla_OpBinary op_multiply, spla_OpBinary op_add, spla_OpSelect op_select, spla_Scalar init, spla_Descriptor desc, spla_ScheduleTask* task);
-SPLA_API spla_Status spla_Exec_mxv_masked(spla_Vector r, spla_Vector mask, spla_Matrix M, spla_Vector v, spla_OpBinary op_multiply, spla_OpBinary op_add, spla_OpSelect op_select, spla_Scalar init, spla_Descriptor desc, spla_ScheduleTask* task);
-SPLA_API spla_Status spla_Exec_vxm_masked(spla_Vector r, spla_Vector mask, spla_Vector v, spla_Matrix M, spla_OpBinary op_multiply, spla_OpBinary op_add, spla_OpSelect op_select, spla_Scalar init, spla_Descriptor desc, spla_ScheduleTask* task);
+SPLA_API spla_Status spla_Exec_mxm(spla_Matrix out, spla_Matrix lhs, spla_Matrix rhs,
+                                   spla_OpBinary mul, spla_OpBinary add, spla_Scalar init, SPLA_C_EXEC_TAIL);
+SPLA_API spla_Status spla_Exec_mxmT_masked(spla_Matrix out, spla_Matrix mask, spla_Matrix lhs, spla_Matrix rhs_transposed,
+                                           spla_OpBinary mul, spla_OpBinary add, spla_OpSelect keep, spla_Scalar init, SPLA_C_EXEC_TAIL);
+SPLA_API spla_Status spla_Exec_mxv_masked(spla_Vector out, spla_Vector mask, spla_Matrix mat, spla_Vector vec,
+                                          spla_OpBinary mul, spla_OpBinary add, spla_OpSelect keep, spla_Scalar init, SPLA_C_EXEC_TAIL);
+SPLA_API spla_Status spla_Exec_vxm_masked(spla_Vector out, spla_Vector mask, spla_Vector vec, spla_Matrix mat,
+                                          spla_OpBinary mul, spla_OpBinary add, spla_OpSelect keep, spla_Scalar init, SPLA_C_EXEC_TAIL);
 
-/* ---- the vector operations of a traversal step (reference include/spla.h: spla_Exec_v_eadd_fdb, spla_Exec_v_assign_masked,
- *      spla_Exec_v_count_mf) ---- */
-SPLA_API spla_Status spla_Exec_v_eadd_fdb(spla_Vector r, spla_Vector v, spla_Vector fdb, spla_OpBinary op, spla_Descriptor desc, spla_ScheduleTask* task);
-SPLA_API spla_Status spla_Exec_v_assign_masked(spla_Vector r, spla_Vector mask, spla_Scalar value, spla_OpBinary op_assign, spla_OpSelect op_select, spla_Descriptor desc, spla_ScheduleTask* task);
-SPLA_API spla_Status spla_Exec_v_count_mf(spla_Scalar r, spla_Vector v, spla_Descriptor desc, spla_ScheduleTask* task);
+/* ---- the vector operations of a traversal step (reference include/spla.h:384,385,388) ---- */
+SPLA_API spla_Status spla_Exec_v_eadd_fdb(spla_Vector inout, spla_Vector operand, spla_Vector changed, spla_OpBinary op, SPLA_C_EXEC_TAIL);
+SPLA_API spla_Status spla_Exec_v_assign_masked(spla_Vector inout, spla_Vector mask, spla_Scalar x, spla_OpBinary assign, spla_OpSelect keep,
+                                               SPLA_C_EXEC_TAIL);
+SPLA_API spla_Status spla_Exec_v_count_mf(spla_Scalar count, spla_Vector vec, SPLA_C_EXEC_TAIL);
 
 /* ---- PageRank step remainder and triangle-count tail (reference include/spla.h:378,382,387) ---- */
-SPLA_API spla_Status spla_Exec_m_reduce(spla_Scalar r, spla_Scalar s, spla_Matrix M, spla_OpBinary op_reduce, spla_Descriptor desc, spla_ScheduleTask* task);
-SPLA_API spla_Status spla_Exec_v_eadd(spla_Vector r, spla_Vector u, spla_Vector v, spla_OpBinary op, spla_Descriptor desc, spla_ScheduleTask* task);
-SPLA_API spla_Status spla_Exec_v_reduce(spla_Scalar r, spla_Scalar s, spla_Vector v, spla_OpBinary op_reduce, spla_Descriptor desc, spla_ScheduleTask* task);
+SPLA_API spla_Status spla_Exec_m_reduce(spla_Scalar out, spla_Scalar start, spla_Matrix mat, spla_OpBinary op, SPLA_C_EXEC_TAIL);
+SPLA_API spla_Status spla_Exec_v_eadd(spla_Vector out, spla_Vector lhs, spla_Vector rhs, spla_OpBinary op, SPLA_C_EXEC_TAIL);
+SPLA_API spla_Status spla_Exec_v_reduce(spla_Scalar out, spla_Scalar start, spla_Vector vec, spla_OpBinary op, SPLA_C_EXEC_TAIL);
 
-/* ---- graph algorithms (reference include/spla.h:360-363); descriptor may be NULL = defaults (push-pull, front factor 0.1) ---- */
-SPLA_API spla_Status spla_Algorithm_bfs(spla_Vector v, spla_Matrix A, spla_uint s, spla_Descriptor descriptor);
-SPLA_API spla_Status spla_Algorithm_sssp(spla_Vector v, spla_Matrix A, spla_uint s, spla_Descriptor descriptor);
-SPLA_API spla_Status spla_Algorithm_pr(spla_Vector* p, spla_Matrix A, float alpha, float eps, spla_Descriptor descriptor);
-SPLA_API spla_Status spla_Algorithm_tc(int* ntrins, spla_Matrix A, spla_Matrix B, spla_Descriptor descriptor);
+/* ---- graph algorithms (reference include/spla.h:360-363); options may be NULL = defaults (push-pull, front factor 0.1) ---- */
+SPLA_API spla_Status spla_Algorithm_bfs(spla_Vector levels, spla_Matrix adjacency, spla_uint source, spla_Descriptor options);
+SPLA_API spla_Status spla_Algorithm_sssp(spla_Vector distances, spla_Matrix weights, spla_uint source, spla_Descriptor options);
+SPLA_API spla_Status spla_Algorithm_pr(spla_Vector* ranks_inout, spla_Matrix scaled_adjacency, float alpha, float eps, spla_Descriptor options);
+SPLA_API spla_Status spla_Algorithm_tc(int* n_triangles, spla_Matrix lower, spla_Matrix products_out, spla_Descriptor options);
 
 /* ---- extension: the MatrixMarket loader from C (the reference has MtxLoader in C++ only, include/spla/io.hpp:47-85) ----
  * load: parse + symmetrise / drop loops / shift indices as asked, sort, de-duplicate; get: sizes and the two index arrays (owned by
  * the loader, valid until delete). */
-typedef struct spla_MtxLoader_t* spla_MtxLoader;
-SPLA_API spla_Status spla_MtxLoader_load(spla_MtxLoader* loader, const char* file_path, spla_bool offset_indices, spla_bool make_undirected, spla_bool remove_loops);
-SPLA_API spla_Status spla_MtxLoader_get(spla_MtxLoader loader, spla_uint* n_rows, spla_uint* n_cols, spla_size_t* n_values, const spla_uint** Ai, const spla_uint** Aj);
+SPLA_API spla_Status spla_MtxLoader_load(spla_MtxLoader* out, const char* path, spla_bool to_zero_based, spla_bool add_reverse_edges, spla_bool drop_self_loops);
+SPLA_API spla_Status spla_MtxLoader_get(spla_MtxLoader loader, spla_uint* n_rows, spla_uint* n_cols, spla_size_t* n_edges, const spla_uint** rows, const spla_uint** cols);
 SPLA_API spla_Status spla_MtxLoader_delete(spla_MtxLoader loader);
 
 /* ---- extension: descriptors from C ---- */
-SPLA_API spla_Status spla_Descriptor_make(spla_Descriptor* desc);
-SPLA_API spla_Status spla_Descriptor_set_early_exit(spla_Descriptor desc, spla_bool value);
-SPLA_API spla_Status spla_Descriptor_set_struct_only(spla_Descriptor desc, spla_bool value);
-SPLA_API spla_Status spla_Descriptor_set_traversal_mode(spla_Descriptor desc, int mode); /* 0 push, 1 pull, 2 push-pull */
-SPLA_API spla_Status spla_Descriptor_set_front_factor(spla_Descriptor desc, float value);
+SPLA_API spla_Status spla_Descriptor_make(spla_Descriptor* out);
+SPLA_API spla_Status spla_Descriptor_set_early_exit(spla_Descriptor options, spla_bool on);
+SPLA_API spla_Status spla_Descriptor_set_struct_only(spla_Descriptor options, spla_bool on);
+SPLA_API spla_Status spla_Descriptor_set_traversal_mode(spla_Descriptor options, int mode); /* 0 push, 1 pull, 2 push-pull */
+SPLA_API spla_Status spla_Descriptor_set_front_factor(spla_Descriptor options, float fraction);
 
 #if defined(__cplusplus)
 }

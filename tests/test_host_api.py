@@ -124,3 +124,16 @@ def test_scalar_and_ops_and_task_handles():
                                   api.Scalar(api.INT, 0).hnd, None, C.byref(task))
     assert st == 0 and task.value
     lib.spla_RefCnt_unref(task)
+
+
+def test_public_headers_are_valid_c99_and_cxx17(tmp_path):
+    """include/spla.h and include/spla_hip.h are what a C host binds: they must compile as plain C (and as C++)."""
+    import shutil
+    import subprocess
+    src = tmp_path / "use_headers.c"
+    src.write_text('#include "spla.h"\n#include "spla_hip.h"\n#include "spla_hip_ops.h"\nint main(void) { spla_Vector v = 0; splahip_plan p = 0; (void) v; (void) p; return SPLAHIP_PLUS; }\n')
+    inc = str(Path(__file__).resolve().parents[1] / "include")
+    if shutil.which("gcc"):
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I" + inc, str(src)], check=True)
+    if shutil.which("g++"):
+        subprocess.run(["g++", "-std=c++17", "-Wall", "-fsyntax-only", "-I" + inc, "-x", "c++", str(src)], check=True)
