@@ -593,6 +593,7 @@ namespace splahip {
         uint total_out = 0;
         int  status    = SPLAHIP_OK;
         for (const Block& blk : blocks) {
+            if (trace.on && &blk == &blocks.back()) trace.mark("all blocks but the last");
             const uint e0 = blk.e0, n_entries = blk.n_entries, n_products = blk.n_products;
             auto run_block = [&]() -> int {
                 const uint n_chunks = (n_entries + 1023u) / 1024u;
@@ -604,12 +605,14 @@ namespace splahip {
                                    offs.as<uint>(), a_rows, Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), DynBin(op_mult),
                                    blk.r0, col_bits, key_a.as<u64>(), val_a.as<T>());
                 SPLAHIP_TRY(hipGetLastError());
+                if (trace.on && &blk == &blocks.back()) trace.mark("  last block: expand");
                 // stable sort by (row, column): equal keys keep the expand order = the reference's fold order
                 // only the bits a (row in block, column) key can have are sorted: ~col_bits + log2(rows in the block) instead of 64
                 size_t     tb      = tmp_bytes;
                 const uint end_bit = col_bits + std::max(1u, bit_width(blk.r1 - blk.r0 - 1));
                 SPLAHIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, key_a.as<u64>(), key_b.as<u64>(), val_a.as<uint>(), val_b.as<uint>(),
                                                       n_products, 0, end_bit, s));
+                if (trace.on && &blk == &blocks.back()) trace.mark("  last block: sort");
                 // runs
                 hipLaunchKernelGGL(mxm_head_kernel, dim3((n_products + 255) / 256), dim3(256), 0, s, key_b.as<u64>(), n_products, head.as<uint>());
                 SPLAHIP_TRY(flags_exclusive_rank(head.as<uint>(), n_products, run_rank.as<uint>(), s));
@@ -634,6 +637,7 @@ namespace splahip {
                                            lcount.as<uint>(), lpos.as<uint>(), run_rank.as<uint>(), run_val.as<T>(), run_keep.as<uint>(), DynBin(op_add), init);
                     SPLAHIP_TRY(hipGetLastError());
                 }
+                if (trace.on && &blk == &blocks.back()) trace.mark("  last block: runs");
                 // drop == init, compact
                 SPLAHIP_TRY(flags_exclusive_rank(run_keep.as<uint>(), n_runs, keep_rank.as<uint>(), s));
                 uint n_out = 0;
@@ -651,6 +655,7 @@ namespace splahip {
                     pieces.push_back({orow.release(), ocol.release(), oval.release(), n_out});
                     total_out += n_out;
                 }
+                if (trace.on && &blk == &blocks.back()) trace.mark("  last block: compact + emit");
                 return SPLAHIP_OK;
             };
             status = run_block();
