@@ -241,3 +241,45 @@ def test_eadd_and_reduce_through_the_api(oracle):
     r = du.eadd(dv, api.FLOAT.MINUS_POW2)
     assert np.array_equal(r.to_dense(), oracle.v_eadd("FLOAT", u_np, v_np, "MINUS_POW2"))
     assert r.reduce(api.FLOAT.MAX) == float(oracle.reduce("FLOAT", oracle.v_eadd("FLOAT", u_np, v_np, "MINUS_POW2"), "MAX", 0.0))
+
+
+@pytest.mark.gpu
+def test_hip_eadd_reduce_edge_sizes(oracle):
+    """sizes around the kernels' internal granules (4-element quads, 256-thread blocks, 1024-element chunks) and empty operands"""
+    import ctypes as C
+    import torch
+    from gpu_utils import dev, host
+    from spla_amd import _lib
+    from spla_amd.kernels import _ptr, current_stream_ptr
+    from spla_amd.ops import binop_id, scalar_bits, type_id
+    rng = np.random.default_rng(43)
+    t, tid = "INT", type_id("INT")
+    for n in (1, 2, 3, 4, 5, 255, 256, 257, 1023, 1024, 1025, 4099):
+        x = vals(rng, n, t, 1, 4)
+        dx = dev(x)
+        for op in ("PLUS", "MAX", "MINUS", "SECOND"):
+            out = C.c_uint32()
+            _lib.call("splahip_reduce", tid, n, _ptr(dx), scalar_bits(3, tid), C.byref(out), binop_id(op), current_stream_ptr())
+            assert np.array([out.value], np.uint32).view(np.int32)[0] == oracle.reduce(t, x, op, 3), (n, op)
+        cnt = C.c_uint32()
+        _lib.call("splahip_v_count_mf_dense", tid, n, _ptr(dx), scalar_bits(2, tid), C.byref(cnt), current_stream_ptr())
+        assert cnt.value == oracle.v_count_mf(t, x, 2)
+    # reduce over nothing returns the start value
+    out = C.c_uint32()
+    _lib.call("splahip_reduce", tid, 0, None, scalar_bits(7, tid), C.byref(out), binop_id("PLUS"), current_stream_ptr())
+    assert out.value == 7
+    # sparse x sparse with an empty side, disjoint lists, identical lists
+    big = 5000
+    cases = [(np.array([], np.uint32), np.arange(0, big, 7, dtype=np.uint32)), (np.arange(0, big, 7, dtype=np.uint32), np.array([], np.uint32)),
+             (np.arange(0, big, 2, dtype=np.uint32), np.arange(1, big, 2, dtype=np.uint32)), (np.arange(0, big, 3, dtype=np.uint32),) * 2]
+    for ui, vi in cases:
+        ux, vx = vals(rng, len(ui), t), vals(rng, len(vi), t)
+        cap = max(len(ui) + len(vi), 1)
+        ri, rx = torch.empty(cap, dtype=torch.int32, device="cuda"), torch.empty(cap, dtype=torch.int32, device="cuda")
+        dui, dux, dvi, dvx = (dev(a) if len(a) else None for a in (ui, ux, vi, vx))
+        cnt = C.c_uint32()
+        _lib.call("splahip_v_eadd_sparse", tid, len(ui), _ptr(dui) if dui is not None else None, _ptr(dux) if dux is not None else None, scalar_bits(2, tid),
+                  len(vi), _ptr(dvi) if dvi is not None else None, _ptr(dvx) if dvx is not None else None, scalar_bits(3, tid), _ptr(ri), _ptr(rx), C.byref(cnt),
+                  binop_id("MINUS"), current_stream_ptr())
+        wi, wx = oracle.v_eadd(t, ux, vx, "MINUS", u_idx=ui, v_idx=vi, u_fill=2, v_fill=3)
+        assert cnt.value == len(wi) and np.array_equal(host(ri, np.uint32)[:cnt.value], wi) and np.array_equal(host(rx, np.int32)[:cnt.value], wx)
