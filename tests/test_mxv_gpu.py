@@ -155,3 +155,29 @@ def test_sharded_rows_equal_whole(oracle):
         parts.append(hip_mxv(t, hi - lo, n, (Ap[lo:hi + 1] - Ap[lo]).astype(np.uint32), Aj[s:e], Ax[s:e], mask[lo:hi], v, "PLUS", "MIN", "ALWAYS", 1 << 30))
     assert np.array_equal(np.concatenate(parts), whole)
     assert np.array_equal(whole, oracle.mxv_masked(t, n, n, Ap, Aj, Ax, mask, v, "PLUS", "MIN", "ALWAYS", 1 << 30))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", ["INT", "UINT", "FLOAT"])
+def test_more_columns_than_lds_slots(oracle, t):
+    """n_cols beyond the 40,000 LDS-resident columns of the sliced-ELL copy: its lanes then mix LDS reads (hot columns) and global
+    gathers (cold columns) inside one wave instruction; hip_mxv cross-checks that form against the CSR kernels, both against the oracle.
+    Skewed column popularity so that a clear hot set exists; rows of 1..700 entries (chunks of 256 + partials) and empty rows."""
+    from gpu_utils import hip_mxv
+    rng = np.random.default_rng(91)
+    n_rows, n_cols = 6000, 150000
+    degs = rng.integers(0, 40, n_rows)
+    degs[rng.integers(0, n_rows, 30)] = rng.integers(257, 700, 30)
+    degs[::7] = 0
+    Ap = np.zeros(n_rows + 1, np.uint32)
+    np.cumsum(degs, out=Ap[1:])
+    pop = (rng.pareto(1.2, n_cols) + 1e-3)
+    pop /= pop.sum()
+    Aj = np.concatenate([np.sort(rng.choice(n_cols, size=d, replace=False, p=pop)) for d in degs if d]).astype(np.uint32)
+    Ax = random_values(rng, len(Aj), t)
+    v = random_values(rng, n_cols, t, zeros=0.2)
+    for mul, add, sel, init in [("MULT", "PLUS", "ALWAYS", 0), ("PLUS", "MIN", "NQZERO", 1 << 20), ("FIRST", "MAX", "EQZERO", 0)]:
+        mask = random_mask(rng, n_rows, t)
+        want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
+        got = hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
+        assert_same(got, want, t, what=f"{t} {mul}/{add}/{sel}")
