@@ -145,6 +145,8 @@ int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols,
                 const uint32_t* d_Bp, const uint32_t* d_Bj, const void* d_Bx,
                 uint32_t* d_Rp, uint32_t** d_Rj, void** d_Rx, uint32_t* h_nnz, uint64_t* h_products,
                 int op_mult, int op_add, uint32_t init_bits, uint64_t block_products, void* stream);
+/* mxm keeps its GB-sized workspaces between calls (per host thread, grow-only); this returns them to the driver */
+int splahip_mxm_trim(void);
 
 /* ---- vector operations between two hot-path calls of a traversal --------------------------------
  * v_assign_masked: r[i] = assign(r[i], value) where select(mask[i]); dense mask (n words) or sparse mask (nvals pairs)

@@ -34,6 +34,12 @@ namespace splahip {
 
     constexpr unsigned WAVE = 64;
 
+    // Result arrays that a call hands to its caller (mxm / mxmT) are plain hipMalloc allocations — the stream-ordered pool is erratic
+    // for multi-GB buffers — tracked (and cached when returned) in runtime.hip; splahip_free recognises them.
+    hipError_t handoff_alloc(void** p, size_t bytes);
+    bool       handoff_release(void* p);// true: p was a hand-off allocation and has been taken back (cached or freed)
+    void       handoff_trim();          // free the cached hand-off blocks
+
     // Scoped, STREAM-ORDERED scratch memory (hipMallocAsync / hipFreeAsync on the call's stream): taken from the device's
     // default memory pool, whose release threshold runtime.hip raises so that steady-state calls neither reach the driver
     // nor synchronise the device the way hipMalloc / hipFree do.  Everything that touches the buffer must run on `stream`.

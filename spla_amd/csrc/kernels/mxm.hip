@@ -42,8 +42,13 @@ namespace splahip {
         bool        pooled = false;
         ~DevBuf() { drop(); }
         void drop() {
-            if (p) (void) (pooled ? hipFreeAsync(p, s) : hipFree(p));
-            p = nullptr;
+            if (p && !cached) {
+                if (handoff) (void) handoff_release(p);
+                else
+                    (void) (pooled ? hipFreeAsync(p, s) : hipFree(p));
+            }
+            p      = nullptr;
+            cached = handoff = false;
         }
         hipError_t alloc(size_t bytes) {
             drop();
@@ -51,10 +56,48 @@ namespace splahip {
             pooled = true;
             return hipMallocAsync(&p, bytes ? bytes : 4, s);
         }
-        hipError_t alloc_plain(size_t bytes) { return alloc(bytes); }// (results go to the caller, who returns them to the same pool: splahip_free)
+        hipError_t alloc_plain(size_t bytes) {// a result array: handed to the caller with release(), returned with splahip_free
+            drop();
+            pooled = false;
+            handoff = true;
+            return handoff_alloc(&p, bytes);
+        }
+        bool handoff = false;
+        // GB-sized workspaces of mxm: kept between calls in a per-thread, grow-only cache (slot = which buffer) — the stream-ordered
+        // pool's behaviour for buffers of this size is erratic (the same call: 0.2 ms or 2.6 s).  Released by splahip_mxm_trim().
+        hipError_t alloc_cached(unsigned slot, size_t bytes) {
+            drop();
+            auto& c = cache();
+            if (c.size() <= slot) c.resize(slot + 1);
+            if (c[slot].bytes < bytes) {
+                if (c[slot].p) (void) hipFree(c[slot].p);
+                c[slot] = {nullptr, 0};
+                hipError_t e = hipMalloc(&c[slot].p, bytes);
+                if (e != hipSuccess) return e;
+                c[slot].bytes = bytes;
+            }
+            p      = c[slot].p;
+            cached = true;
+            return hipSuccess;
+        }
+        struct Slot {
+            void*  p;
+            size_t bytes;
+        };
+        static std::vector<Slot>& cache() {
+            static thread_local std::vector<Slot> c;
+            return c;
+        }
+        static void trim() {
+            for (auto& sl : cache())
+                if (sl.p) (void) hipFree(sl.p);
+            cache().clear();
+        }
+        bool cached = false;
         void* release() {
             void* q = p;
             p       = nullptr;
+            cached = handoff = false;
             return q;
         }
         template<typename U>
@@ -383,11 +426,11 @@ namespace splahip {
         if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = chunk[n_chunks];
     }
 
-    template<typename T, class Mult>
+    template<typename T, typename K, class Mult>
     __global__ __launch_bounds__(256) void mxm_expand_kernel(uint n_products, uint e0, uint n_entries, const uint* __restrict__ offs, uint n_rows,
                                                              const uint* __restrict__ Ap, const uint* __restrict__ Aj, const T* __restrict__ Ax,
                                                              const uint* __restrict__ Bp, const uint* __restrict__ Bj, const T* __restrict__ Bx,
-                                                             Mult mult, uint r0, uint col_bits, u64* __restrict__ key, T* __restrict__ val) {
+                                                             Mult mult, uint r0, uint col_bits, K* __restrict__ key, T* __restrict__ val) {
         const uint p = blockIdx.x * 256 + threadIdx.x;
         if (p >= n_products) return;
         uint lo = 0, hi = n_entries;// entry t of the block with offs[t] <= p < offs[t+1]
@@ -401,35 +444,66 @@ namespace splahip {
         const uint i  = row_of_entry(Ap, n_rows, e);
         const uint k  = Aj[e];
         const uint kb = Bp[k] + (p - offs[lo]);
-        key[p]        = (u64(i - r0) << col_bits) | Bj[kb];// compact (row in block, column): only these bits are sorted
+        key[p]        = (K(i - r0) << col_bits) | K(Bj[kb]);// compact (row in block, column): only these bits are sorted; K = 32-bit when they fit
         val[p]        = mult(Ax[e], Bx[kb]);
     }
 
-    __global__ __launch_bounds__(256) void mxm_head_kernel(const u64* __restrict__ key, uint n, uint* __restrict__ head) {
+    template<typename K>
+    __global__ __launch_bounds__(256) void mxm_head_kernel(const K* __restrict__ key, uint n, uint* __restrict__ head) {
         const uint p = blockIdx.x * 256 + threadIdx.x;
         if (p < n) head[p] = (p == 0 || key[p - 1] != key[p]) ? 1u : 0u;
     }
 
     constexpr uint kRunShortMxm = 64;
 
-    // one lane per run head: fold the run in order from init (short runs) or queue it for a wavefront
-    template<typename T, class Add>
-    __global__ __launch_bounds__(256) void mxm_run_kernel(const u64* __restrict__ key, const T* __restrict__ val, uint n, const uint* __restrict__ head,
-                                                          const uint* __restrict__ run_rank, u64* __restrict__ run_key, T* __restrict__ run_val,
+    // one lane per product; the lanes that start a run fold it in order from init.  The run's later products sit in the following
+    // lanes of the same wave (avg run length ~2), so they are fetched with shuffles; a run that leaves the wave continues from memory,
+    // a run longer than kRunShortMxm is queued for a wavefront of its own (mxm_long_run_kernel).
+    template<typename T, typename K, class Add>
+    __global__ __launch_bounds__(256) void mxm_run_kernel(const K* __restrict__ key, const T* __restrict__ val, uint n, const uint* __restrict__ head,
+                                                          const uint* __restrict__ run_rank, K* __restrict__ run_key, T* __restrict__ run_val,
                                                           uint* __restrict__ run_keep, uint* __restrict__ long_count, uint* __restrict__ long_pos,
                                                           Add add, T init) {
-        const uint p = blockIdx.x * 256 + threadIdx.x;
-        if (p >= n || !head[p]) return;
-        const u64  kk  = key[p];
+        const uint p      = blockIdx.x * 256 + threadIdx.x;
+        const uint lane   = lane_id();
+        const bool inside = p < n;
+        const K    kk     = inside ? key[p] : K(0);
+        const T    mine   = inside ? val[p] : T();
+        const bool lead   = inside && head[p] != 0;
+        T          acc    = add(init, mine);
+        uint       len    = 1;     // products folded so far
+        bool       open   = lead;  // still extending the run
+        bool       spill  = false; // the run continues beyond this wave
+        for (uint d = 1; d < kWave; ++d) {
+            if (__ballot(open) == 0ull) break;
+            const K    nk   = __shfl_down(kk, d, kWave);
+            const T    nv   = __shfl_down(mine, d, kWave);
+            const bool next = __shfl_down((int) inside, d, kWave) != 0 && lane + d < kWave;
+            if (open) {
+                if (lane + d >= kWave) {// ran off the wave: whether the run continues is decided from memory below
+                    spill = true;
+                    open  = false;
+                } else if (next && nk == kk && len < kRunShortMxm) {
+                    acc = add(acc, nv);
+                    ++len;
+                } else {
+                    open = false;
+                    if (next && nk == kk) spill = true;// hit the length cap inside the wave
+                }
+            }
+        }
+        if (open) spill = true;// (lane 0 with a run covering the whole wave)
+        if (!lead) return;
+        uint q = p + len;
+        if (spill) {
+            while (q < n && q - p < kRunShortMxm && key[q] == kk) {
+                acc = add(acc, val[q]);
+                ++q;
+            }
+        }
         const uint run = run_rank[p];
         run_key[run]   = kk;
-        T    acc       = add(init, val[p]);
-        uint q         = p + 1;
-        while (q < n && q - p < kRunShortMxm && key[q] == kk) {
-            acc = add(acc, val[q]);
-            ++q;
-        }
-        if (q < n && key[q] == kk) {
+        if (q < n && q - p >= kRunShortMxm && key[q] == kk) {
             const uint slot = atomicAdd(long_count, 1u);
             long_pos[slot]  = p;
         } else {
@@ -438,8 +512,8 @@ namespace splahip {
         }
     }
 
-    template<typename T, class Add, bool TREE>
-    __global__ __launch_bounds__(256) void mxm_long_run_kernel(const u64* __restrict__ key, const T* __restrict__ val, uint n,
+    template<typename T, typename K, class Add, bool TREE>
+    __global__ __launch_bounds__(256) void mxm_long_run_kernel(const K* __restrict__ key, const T* __restrict__ val, uint n,
                                                                const uint* __restrict__ long_count, const uint* __restrict__ long_pos,
                                                                const uint* __restrict__ run_rank, T* __restrict__ run_val, uint* __restrict__ run_keep,
                                                                Add add, T init) {
@@ -447,7 +521,7 @@ namespace splahip {
         if (w >= *long_count) return;
         const uint lane = lane_id();
         const uint p    = long_pos[w];
-        const u64  kk   = key[p];
+        const K    kk   = key[p];
         uint       lo = p + 1, hi = n;
         while (lo < hi) {
             const uint mid = lo + ((hi - lo) >> 1);
@@ -481,14 +555,15 @@ namespace splahip {
     }
 
     // kept runs -> (row, col, value) appended at out_base + rank
-    __global__ __launch_bounds__(256) void mxm_emit_kernel(uint n_runs, const u64* __restrict__ run_key, const uint* __restrict__ run_val,
+    template<typename K>
+    __global__ __launch_bounds__(256) void mxm_emit_kernel(uint n_runs, const K* __restrict__ run_key, const uint* __restrict__ run_val,
                                                            const uint* __restrict__ run_keep, const uint* __restrict__ rank, uint r0, uint col_bits,
                                                            uint* __restrict__ out_row, uint* __restrict__ out_col, uint* __restrict__ out_val) {
         const uint t = blockIdx.x * 256 + threadIdx.x;
         if (t < n_runs && run_keep[t]) {
             const uint o = rank[t];
             out_row[o]   = r0 + uint(run_key[t] >> col_bits);
-            out_col[o]   = uint(run_key[t] & ((1ull << col_bits) - 1ull));
+            out_col[o]   = uint(run_key[t] & ((K(1) << col_bits) - K(1)));
             out_val[o]   = run_val[t];
         }
     }
@@ -532,11 +607,13 @@ namespace splahip {
             SPLAHIP_TRY(hipStreamSynchronize(s));
         }
         std::vector<Piece> pieces;
+        std::vector<char>  piece_in_arena;// per piece: carved from the cached arena (not freed) or pool-allocated
         auto               free_pieces = [&]() {
-            for (auto& pc : pieces) {
-                (void) hipFreeAsync(pc.row, s);
-                (void) hipFreeAsync(pc.col, s);
-                (void) hipFreeAsync(pc.val, s);
+            for (size_t k = 0; k < pieces.size(); ++k) {
+                if (k < piece_in_arena.size() && piece_in_arena[k]) continue;// carved from the cached arena
+                (void) hipFreeAsync(pieces[k].row, s);
+                (void) hipFreeAsync(pieces[k].col, s);
+                (void) hipFreeAsync(pieces[k].val, s);
             }
             pieces.clear();
         };
@@ -570,24 +647,33 @@ namespace splahip {
         const uint end_bit_max = col_bits + std::max(1u, bit_width(max_span - 1));
         if (!blocks.empty()) {
             const size_t np1 = (size_t) max_products + 1;
-            SPLAHIP_TRY(len.alloc(sizeof(uint) * (size_t) max_entries));
-            SPLAHIP_TRY(offs.alloc(sizeof(uint) * ((size_t) max_entries + 1)));
-            SPLAHIP_TRY(chunk.alloc(sizeof(uint) * ((size_t) (max_entries + 1023u) / 1024u + 2)));
-            SPLAHIP_TRY(key_a.alloc(sizeof(u64) * (size_t) max_products));
-            SPLAHIP_TRY(key_b.alloc(sizeof(u64) * (size_t) max_products));
-            SPLAHIP_TRY(val_a.alloc(sizeof(uint) * (size_t) max_products));
-            SPLAHIP_TRY(val_b.alloc(sizeof(uint) * (size_t) max_products));
+            SPLAHIP_TRY(len.alloc_cached(0, sizeof(uint) * (size_t) max_entries));
+            SPLAHIP_TRY(offs.alloc_cached(1, sizeof(uint) * ((size_t) max_entries + 1)));
+            SPLAHIP_TRY(chunk.alloc_cached(2, sizeof(uint) * ((size_t) (max_entries + 1023u) / 1024u + 2)));
+            SPLAHIP_TRY(key_a.alloc_cached(3, sizeof(u64) * (size_t) max_products));
+            SPLAHIP_TRY(key_b.alloc_cached(4, sizeof(u64) * (size_t) max_products));
+            SPLAHIP_TRY(val_a.alloc_cached(5, sizeof(uint) * (size_t) max_products));
+            SPLAHIP_TRY(val_b.alloc_cached(6, sizeof(uint) * (size_t) max_products));
             SPLAHIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_a.as<u64>(), key_b.as<u64>(), val_a.as<uint>(), val_b.as<uint>(),
                                                   max_products, 0, end_bit_max, s));
-            SPLAHIP_TRY(tmp.alloc(tmp_bytes));
-            SPLAHIP_TRY(head.alloc(sizeof(uint) * (size_t) max_products));
-            SPLAHIP_TRY(run_rank.alloc(sizeof(uint) * np1));
-            SPLAHIP_TRY(run_key.alloc(sizeof(u64) * (size_t) max_products));
-            SPLAHIP_TRY(run_val.alloc(sizeof(uint) * (size_t) max_products));
-            SPLAHIP_TRY(run_keep.alloc(sizeof(uint) * (size_t) max_products));
-            SPLAHIP_TRY(lcount.alloc(sizeof(uint)));
-            SPLAHIP_TRY(lpos.alloc(sizeof(uint) * ((size_t) max_products / kRunShortMxm + 1)));
-            SPLAHIP_TRY(keep_rank.alloc(sizeof(uint) * np1));
+            SPLAHIP_TRY(tmp.alloc_cached(7, tmp_bytes));
+            SPLAHIP_TRY(head.alloc_cached(8, sizeof(uint) * (size_t) max_products));
+            SPLAHIP_TRY(run_rank.alloc_cached(9, sizeof(uint) * np1));
+            SPLAHIP_TRY(run_key.alloc_cached(10, sizeof(u64) * (size_t) max_products));
+            SPLAHIP_TRY(run_val.alloc_cached(11, sizeof(uint) * (size_t) max_products));
+            SPLAHIP_TRY(run_keep.alloc_cached(12, sizeof(uint) * (size_t) max_products));
+            SPLAHIP_TRY(lcount.alloc_cached(13, sizeof(uint)));
+            SPLAHIP_TRY(lpos.alloc_cached(14, sizeof(uint) * ((size_t) max_products / kRunShortMxm + 1)));
+            SPLAHIP_TRY(keep_rank.alloc_cached(15, sizeof(uint) * np1));
+        }
+        // output pieces of the row blocks are carved from one cached arena (3 words per kept entry); its size follows the largest
+        // result seen so far, a piece that does not fit comes from the pool instead
+        static thread_local size_t arena_want = 0;
+        DevBuf arena;
+        size_t arena_words = 0, arena_used = 0;
+        if (!blocks.empty() && arena_want) {
+            SPLAHIP_TRY(arena.alloc_cached(16, sizeof(uint) * arena_want));
+            arena_words = arena_want;
         }
         trace.mark("workspace allocation");
         uint total_out = 0;
@@ -595,33 +681,34 @@ namespace splahip {
         for (const Block& blk : blocks) {
             if (trace.on && &blk == &blocks.back()) trace.mark("all blocks but the last");
             const uint e0 = blk.e0, n_entries = blk.n_entries, n_products = blk.n_products;
-            auto run_block = [&]() -> int {
+            auto run_block = [&](auto key_tag) -> int {
+                using K = decltype(key_tag);// 32-bit keys when (row in block, column) fits: a third less sort traffic
                 const uint n_chunks = (n_entries + 1023u) / 1024u;
                 hipLaunchKernelGGL(mxm_len_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, s, e0, n_entries, Aj, Bp, len.as<uint>());
                 hipLaunchKernelGGL(len_sum_kernel, dim3(n_chunks), dim3(256), 0, s, len.as<uint>(), n_entries, chunk.as<uint>());
                 hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk.as<uint>(), n_chunks);
                 hipLaunchKernelGGL(len_scan_kernel, dim3(n_chunks), dim3(256), 0, s, len.as<uint>(), n_entries, chunk.as<uint>(), n_chunks, offs.as<uint>());
-                hipLaunchKernelGGL((mxm_expand_kernel<T, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, n_products, e0, n_entries,
+                hipLaunchKernelGGL((mxm_expand_kernel<T, K, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, n_products, e0, n_entries,
                                    offs.as<uint>(), a_rows, Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), DynBin(op_mult),
-                                   blk.r0, col_bits, key_a.as<u64>(), val_a.as<T>());
+                                   blk.r0, col_bits, key_a.as<K>(), val_a.as<T>());
                 SPLAHIP_TRY(hipGetLastError());
                 if (trace.on && &blk == &blocks.back()) trace.mark("  last block: expand");
                 // stable sort by (row, column): equal keys keep the expand order = the reference's fold order
                 // only the bits a (row in block, column) key can have are sorted: ~col_bits + log2(rows in the block) instead of 64
                 size_t     tb      = tmp_bytes;
                 const uint end_bit = col_bits + std::max(1u, bit_width(blk.r1 - blk.r0 - 1));
-                SPLAHIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, key_a.as<u64>(), key_b.as<u64>(), val_a.as<uint>(), val_b.as<uint>(),
+                SPLAHIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, key_a.as<K>(), key_b.as<K>(), val_a.as<uint>(), val_b.as<uint>(),
                                                       n_products, 0, end_bit, s));
                 if (trace.on && &blk == &blocks.back()) trace.mark("  last block: sort");
                 // runs
-                hipLaunchKernelGGL(mxm_head_kernel, dim3((n_products + 255) / 256), dim3(256), 0, s, key_b.as<u64>(), n_products, head.as<uint>());
+                hipLaunchKernelGGL(mxm_head_kernel<K>, dim3((n_products + 255) / 256), dim3(256), 0, s, key_b.as<K>(), n_products, head.as<uint>());
                 SPLAHIP_TRY(flags_exclusive_rank(head.as<uint>(), n_products, run_rank.as<uint>(), s));
                 uint n_runs = 0;
                 SPLAHIP_TRY(hipMemcpyAsync(&n_runs, run_rank.as<uint>() + n_products, sizeof(uint), hipMemcpyDeviceToHost, s));
                 SPLAHIP_TRY(hipMemsetAsync(lcount.p, 0, sizeof(uint), s));
                 SPLAHIP_TRY(hipStreamSynchronize(s));
-                hipLaunchKernelGGL((mxm_run_kernel<T, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, key_b.as<u64>(), val_b.as<T>(), n_products,
-                                   head.as<uint>(), run_rank.as<uint>(), run_key.as<u64>(), run_val.as<T>(), run_keep.as<uint>(), lcount.as<uint>(),
+                hipLaunchKernelGGL((mxm_run_kernel<T, K, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, key_b.as<K>(), val_b.as<T>(), n_products,
+                                   head.as<uint>(), run_rank.as<uint>(), run_key.as<K>(), run_val.as<T>(), run_keep.as<uint>(), lcount.as<uint>(),
                                    lpos.as<uint>(), DynBin(op_add), init);
                 SPLAHIP_TRY(hipGetLastError());
                 uint h_long = 0;
@@ -630,10 +717,10 @@ namespace splahip {
                 if (h_long) {
                     const uint grid = (h_long + 3) / 4;
                     if (binop_is_associative(op_add))
-                        hipLaunchKernelGGL((mxm_long_run_kernel<T, DynBin, true>), dim3(grid), dim3(256), 0, s, key_b.as<u64>(), val_b.as<T>(), n_products,
+                        hipLaunchKernelGGL((mxm_long_run_kernel<T, K, DynBin, true>), dim3(grid), dim3(256), 0, s, key_b.as<K>(), val_b.as<T>(), n_products,
                                            lcount.as<uint>(), lpos.as<uint>(), run_rank.as<uint>(), run_val.as<T>(), run_keep.as<uint>(), DynBin(op_add), init);
                     else
-                        hipLaunchKernelGGL((mxm_long_run_kernel<T, DynBin, false>), dim3(grid), dim3(256), 0, s, key_b.as<u64>(), val_b.as<T>(), n_products,
+                        hipLaunchKernelGGL((mxm_long_run_kernel<T, K, DynBin, false>), dim3(grid), dim3(256), 0, s, key_b.as<K>(), val_b.as<T>(), n_products,
                                            lcount.as<uint>(), lpos.as<uint>(), run_rank.as<uint>(), run_val.as<T>(), run_keep.as<uint>(), DynBin(op_add), init);
                     SPLAHIP_TRY(hipGetLastError());
                 }
@@ -644,11 +731,20 @@ namespace splahip {
                 SPLAHIP_TRY(hipMemcpyAsync(&n_out, keep_rank.as<uint>() + n_runs, sizeof(uint), hipMemcpyDeviceToHost, s));
                 SPLAHIP_TRY(hipStreamSynchronize(s));
                 if (n_out) {
-                    DevBuf orow, ocol, oval;
-                    SPLAHIP_TRY(orow.alloc(sizeof(uint) * (size_t) n_out));
-                    SPLAHIP_TRY(ocol.alloc(sizeof(uint) * (size_t) n_out));
-                    SPLAHIP_TRY(oval.alloc(sizeof(uint) * (size_t) n_out));
-                    hipLaunchKernelGGL(mxm_emit_kernel, dim3((n_runs + 255) / 256), dim3(256), 0, s, n_runs, run_key.as<u64>(), run_val.as<uint>(),
+                    DevBuf     orow, ocol, oval;
+                    const bool fits = arena_used + 3 * (size_t) n_out <= arena_words;
+                    if (fits) {
+                        uint* base = arena.as<uint>() + arena_used;
+                        orow.p = base, ocol.p = base + n_out, oval.p = base + 2 * (size_t) n_out;
+                        orow.cached = ocol.cached = oval.cached = true;// not owned: part of the arena
+                        arena_used += 3 * (size_t) n_out;
+                    } else {
+                        SPLAHIP_TRY(orow.alloc(sizeof(uint) * (size_t) n_out));
+                        SPLAHIP_TRY(ocol.alloc(sizeof(uint) * (size_t) n_out));
+                        SPLAHIP_TRY(oval.alloc(sizeof(uint) * (size_t) n_out));
+                    }
+                    piece_in_arena.push_back(fits ? 1 : 0);
+                    hipLaunchKernelGGL(mxm_emit_kernel<K>, dim3((n_runs + 255) / 256), dim3(256), 0, s, n_runs, run_key.as<K>(), run_val.as<uint>(),
                                        run_keep.as<uint>(), keep_rank.as<uint>(), blk.r0, col_bits, orow.as<uint>(), ocol.as<uint>(), oval.as<uint>());
                     SPLAHIP_TRY(hipGetLastError());
                     SPLAHIP_TRY(hipStreamSynchronize(s));
@@ -658,7 +754,7 @@ namespace splahip {
                 if (trace.on && &blk == &blocks.back()) trace.mark("  last block: compact + emit");
                 return SPLAHIP_OK;
             };
-            status = run_block();
+            status = (col_bits + std::max(1u, bit_width(blk.r1 - blk.r0 - 1)) <= 32u) ? run_block(uint{}) : run_block(u64{});
             if (status != SPLAHIP_OK) break;
         }
         if (status != SPLAHIP_OK) {
@@ -668,7 +764,7 @@ namespace splahip {
         trace.mark("all row blocks");
         // concatenate the pieces (row blocks are in row order) and derive Rp
         DevBuf rows, outj, outx;
-        hipError_t e = rows.alloc(sizeof(uint) * (size_t) total_out);
+        hipError_t e = rows.alloc_cached(17, sizeof(uint) * (size_t) total_out);
         if (e == hipSuccess) e = outj.alloc_plain(sizeof(uint) * (size_t) total_out);
         if (e == hipSuccess) e = outx.alloc_plain(sizeof(uint) * (size_t) total_out);
         size_t off = 0;
@@ -688,7 +784,8 @@ namespace splahip {
         free_pieces();
         trace.mark("free pieces");
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm assembly failed: %s", hipGetErrorString(e));
-        *h_nnz = total_out;
+        arena_want = std::max(arena_want, 3 * (size_t) total_out + 64);
+        *h_nnz     = total_out;
         if (h_products) *h_products = total_products;
         *Rj = static_cast<uint*>(outj.release());
         *Rx = outx.release();
@@ -750,5 +847,11 @@ int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols,
     }
     if (h_products) *h_products = prod;
     return rc;
+}
+
+int splahip_mxm_trim(void) {
+    DevBuf::trim();
+    handoff_trim();
+    return SPLAHIP_OK;
 }
 }

@@ -5,6 +5,9 @@
 
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
+#include <utility>
+#include <vector>
 
 namespace splahip {
 
@@ -55,6 +58,67 @@ namespace splahip {
         std::snprintf(g_arch, sizeof(g_arch), "%s", prop.gcnArchName);
         std::snprintf(g_name, sizeof(g_name), "%s", prop.name);
         return SPLAHIP_OK;
+    }
+
+    // Hand-off allocations (result arrays of mxm / mxmT, multi-GB): plain hipMalloc blocks with a small cache of returned blocks, so
+    // that a steady-state loop (call, consume, splahip_free, call again) neither reaches the driver nor depends on the stream-ordered
+    // pool, whose latency for buffers of this size is erratic.  A returned block is reused for a request of at least half
+    // its size; at most kHandoffCacheBytes stay cached (splahip_mxm_trim() drops them).
+    namespace {
+        constexpr size_t                  kHandoffCacheBytes = size_t(48) << 30;
+        std::mutex                        g_handoff_lock;
+        std::unordered_map<void*, size_t> g_handoff_live;  // handed out: capacity
+        std::vector<std::pair<void*, size_t>> g_handoff_free;// returned, reusable
+        size_t                            g_handoff_free_bytes = 0;
+    }// namespace
+    hipError_t handoff_alloc(void** p, size_t bytes) {
+        if (bytes == 0) bytes = 4;
+        {
+            std::lock_guard<std::mutex> guard(g_handoff_lock);
+            size_t best = g_handoff_free.size();
+            for (size_t k = 0; k < g_handoff_free.size(); ++k) {
+                const size_t cap = g_handoff_free[k].second;
+                if (cap >= bytes && cap / 2 <= bytes && (best == g_handoff_free.size() || cap < g_handoff_free[best].second)) best = k;
+            }
+            if (best != g_handoff_free.size()) {
+                *p = g_handoff_free[best].first;
+                g_handoff_live[*p] = g_handoff_free[best].second;
+                g_handoff_free_bytes -= g_handoff_free[best].second;
+                g_handoff_free.erase(g_handoff_free.begin() + (long) best);
+                return hipSuccess;
+            }
+        }
+        hipError_t e = hipMalloc(p, bytes);
+        if (e == hipSuccess) {
+            std::lock_guard<std::mutex> guard(g_handoff_lock);
+            g_handoff_live[*p] = bytes;
+        }
+        return e;
+    }
+    bool handoff_release(void* p) {
+        size_t cap = 0;
+        {
+            std::lock_guard<std::mutex> guard(g_handoff_lock);
+            auto                        it = g_handoff_live.find(p);
+            if (it == g_handoff_live.end()) return false;
+            cap = it->second;
+            g_handoff_live.erase(it);
+        }
+        (void) hipDeviceSynchronize();// like hipFree: nothing queued may still read the block when it is reused
+        std::lock_guard<std::mutex> guard(g_handoff_lock);
+        if (g_handoff_free_bytes + cap <= kHandoffCacheBytes) {
+            g_handoff_free.emplace_back(p, cap);
+            g_handoff_free_bytes += cap;
+        } else {
+            (void) hipFree(p);
+        }
+        return true;
+    }
+    void handoff_trim() {
+        std::lock_guard<std::mutex> guard(g_handoff_lock);
+        for (auto& b : g_handoff_free) (void) hipFree(b.first);
+        g_handoff_free.clear();
+        g_handoff_free_bytes = 0;
     }
 
     int ensure_device() {
@@ -117,6 +181,7 @@ int splahip_malloc(void** d_ptr, size_t bytes) {
 
 int splahip_free(void* d_ptr) {
     if (!d_ptr) return SPLAHIP_OK;
+    if (handoff_release(d_ptr)) return SPLAHIP_OK;// a result array of mxm / mxmT: plain allocation
     SPLAHIP_TRY(hipFreeAsync(d_ptr, nullptr));// reusable once the work queued on the default stream so far has finished
     return SPLAHIP_OK;
 }
