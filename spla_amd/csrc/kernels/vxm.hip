@@ -19,6 +19,7 @@
 #include "ops.hpp"
 #include "plan.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -221,6 +222,69 @@ namespace splahip {
         val[p]         = mult(vx[idx], from_bits<T>(Ax[k]));
     }
 
+    // ---- push, order-free form ---------------------------------------------------------------------------------------
+    // For an op_add whose result does not depend on the fold order (associative + commutative, and not a rounding fp32 sum / product)
+    // "first hit stores, later hits add" is just a reduction per output column: every product goes straight into a packed
+    // (touched, value) word per column with a compare-and-swap — no expand buffer, no sort.  Used for small product counts, where the
+    // sort form's ~15 launches are the cost (BFS / SSSP levels with small frontiers); hub columns would serialise a large expansion.
+    using u64 = unsigned long long;
+    template<typename T, class Mult, class Add>
+    __global__ __launch_bounds__(256) void push_atomic_kernel(uint n_products, uint nvals, const uint* __restrict__ offs, const uint* __restrict__ vi,
+                                                              const T* __restrict__ vx, const uint* __restrict__ Ap, const uint* __restrict__ Aj,
+                                                              const uint* __restrict__ Ax, const T* __restrict__ mask, int op_select, Mult mult, Add add,
+                                                              u64* __restrict__ acc) {
+        const uint p = blockIdx.x * 256 + threadIdx.x;
+        if (p >= n_products) return;
+        const uint idx = upper_row(offs, nvals, p);
+        const uint k   = Ap[vi[idx]] + (p - offs[idx]);
+        const uint j   = Aj[k];
+        if (!eval_sel(op_select, mask[j])) return;
+        const T prod = mult(vx[idx], from_bits<T>(Ax[k]));
+        u64*    slot = acc + j;
+        u64     seen = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (true) {
+            const bool touched = (seen >> 32) != 0;
+            const T    next    = touched ? add(from_bits<T>((uint) seen), prod) : prod;
+            const u64  want    = (1ull << 32) | (u64) to_bits(next);
+            if (want == seen) break;// nothing to change (e.g. OR-ing a bit that is set, MIN with a larger value)
+            const u64 prev = atomicCAS(slot, seen, want);
+            if (prev == seen) break;
+            seen = prev;
+        }
+    }
+    __global__ __launch_bounds__(256) void acc_count_kernel(const u64* __restrict__ acc, uint n, uint* __restrict__ chunk) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        uint            cnt   = 0;
+#pragma unroll
+        for (uint u = 0; u < 4; ++u)
+            if (first + u < n) cnt += (acc[first + u] >> 32) ? 1u : 0u;
+        uint total;
+        (void) block_exclusive_sum<256>(cnt, s_tmp, total);
+        if (threadIdx.x == 0) chunk[blockIdx.x] = total;
+    }
+    __global__ __launch_bounds__(256) void acc_write_kernel(const u64* __restrict__ acc, uint n, const uint* __restrict__ chunk, uint* __restrict__ out_i,
+                                                            uint* __restrict__ out_x) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        u64             w[4];
+        uint            cnt = 0;
+#pragma unroll
+        for (uint u = 0; u < 4; ++u) {
+            w[u] = first + u < n ? acc[first + u] : 0ull;
+            cnt += (w[u] >> 32) ? 1u : 0u;
+        }
+        uint total;
+        uint pos = chunk[blockIdx.x] + block_exclusive_sum<256>(cnt, s_tmp, total);
+#pragma unroll
+        for (uint u = 0; u < 4; ++u)
+            if (w[u] >> 32) {
+                out_i[pos] = first + u;
+                out_x[pos] = (uint) w[u];
+                ++pos;
+            }
+    }
+
     __global__ __launch_bounds__(256) void head_count_kernel(const uint* __restrict__ key, uint n, uint n_cols, uint* __restrict__ chunk) {
         __shared__ uint s_tmp[256 / kWave + 1];
         const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
@@ -378,6 +442,16 @@ namespace splahip {
         return SPLAHIP_OK;
     }
 
+    constexpr uint kPushAtomicMax = 1u << 22;// products up to which the order-free form is used
+    inline bool    push_order_free(int op_add, int type) {
+        if (!binop_is_associative(op_add) || !binop_is_commutative(op_add)) return false;
+        return !(type == SPLAHIP_FLOAT && (op_add == SPLAHIP_PLUS || op_add == SPLAHIP_MULT));// fp32 sums / products round by order: sort form
+    }
+    inline bool push_atomic_disabled() {
+        const char* e = std::getenv("SPLAHIP_PUSH_ATOMIC");// A/B runs and tests: 0 keeps the sort form
+        return e && e[0] == '0';
+    }
+
     template<typename T>
     int push_typed(uint n_rows, uint n_cols, const uint* Ap, const uint* Aj, const void* Ax, const void* mask, uint nvals, const uint* vi,
                    const void* vx, uint* ri, void* rx, uint* h_count, int op_mult, int op_add, int op_select, uint64_t products_hint, hipStream_t s) {
@@ -398,6 +472,25 @@ namespace splahip {
             SPLAHIP_TRY(hipStreamSynchronize(s));
         }
         if (n_products == 0) return SPLAHIP_OK;
+
+        if (n_products <= kPushAtomicMax && push_order_free(op_add, TypeId<T>::value) && !push_atomic_disabled()) {
+            const uint n_chunks = (n_cols + 1023u) / 1024u;
+            DevMem     body;// acc[n_cols] (8 bytes each) | chunk[n_chunks + 1]
+            SPLAHIP_TRY(body.alloc(s, sizeof(u64) * (size_t) n_cols + sizeof(uint) * ((size_t) n_chunks + 1)));
+            u64*  acc   = body.as<u64>();
+            uint* chunk = reinterpret_cast<uint*>(acc + n_cols);
+            SPLAHIP_TRY(hipMemsetAsync(acc, 0, sizeof(u64) * (size_t) n_cols, s));
+            hipLaunchKernelGGL((push_atomic_kernel<T, DynBin, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, n_products, nvals, offs, vi,
+                               static_cast<const T*>(vx), Ap, Aj, static_cast<const uint*>(Ax), static_cast<const T*>(mask), op_select, DynBin(op_mult),
+                               DynBin(op_add), acc);
+            hipLaunchKernelGGL(acc_count_kernel, dim3(n_chunks), dim3(256), 0, s, acc, n_cols, chunk);
+            hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk, n_chunks);
+            hipLaunchKernelGGL(acc_write_kernel, dim3(n_chunks), dim3(256), 0, s, acc, n_cols, chunk, ri, static_cast<uint*>(rx));
+            SPLAHIP_TRY(hipGetLastError());
+            SPLAHIP_TRY(hipMemcpyAsync(h_count, chunk + n_chunks, sizeof(uint), hipMemcpyDeviceToHost, s));
+            SPLAHIP_TRY(hipStreamSynchronize(s));
+            return SPLAHIP_OK;
+        }
 
         // stable LSD radix sort by column: equal columns keep the expand order = the reference's fold order
         size_t     tmp_bytes = 0;

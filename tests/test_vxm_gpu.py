@@ -49,9 +49,13 @@ def test_transpose_is_stable_csc():
     assert np.array_equal(Tp, np.concatenate([[0], np.cumsum(np.bincount(Aj, minlength=n_cols))]))
 
 
+@pytest.mark.parametrize("form", ["auto", "sort"])
 @pytest.mark.parametrize("t", ["INT", "UINT", "FLOAT"])
-def test_push_all_cells_bit_exact(oracle, t):
-    """The push form folds every column's products in the reference's order: bit-exact for EVERY op, fp32 PLUS included."""
+def test_push_all_cells_bit_exact(oracle, t, form, monkeypatch):
+    """The push form folds every column's products in the reference's order: bit-exact for EVERY op, fp32 PLUS included.  form=auto lets
+    small expansions of order-free op_add take the compare-and-swap form (no sort), form=sort forces the expand / sort / fold form."""
+    if form == "sort":
+        monkeypatch.setenv("SPLAHIP_PUSH_ATOMIC", "0")
     rng = np.random.default_rng(31)
     n_rows, n_cols = 1500, 1100
     Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 8, t, skew=True, long_rows=2, long_len=900)
