@@ -62,7 +62,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-variants", action="store_true")
     p.add_argument("--no-verify", action="store_true")
-    p.add_argument("--workload", default="bfs-step", choices=["bfs-step", "pagerank-vxm", "sssp-step", "tc-mxmT", "mxm", "algorithms"],
+    p.add_argument("--workload", default="bfs-step", choices=["bfs-step", "pagerank-vxm", "sssp-step", "tc-mxmT", "mxm", "algorithms", "transpose"],
                    help="bfs-step (default, the contract line) or one of the other hot-path operators (bench_workloads.py; N = 1 only)")
     return p.parse_args()
 

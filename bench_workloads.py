@@ -8,6 +8,7 @@ the oracle, the genuine reference CPU backend timed beside it on a bounded sampl
     tc-mxmT      : exec_mxmT_masked(L, L, L) MULT/PLUS/GTZERO int32, L = strict lower triangle of symmetrised R-MAT scale 20
                    (BASELINE configs[4], triangle-count form)
     mxm          : exec_mxm plus-times fp32 A x A on R-MAT (BASELINE configs[4]; scale chosen so the expanded products fit)
+    transpose    : exec_m_transpose of the R-MAT scale-22 adjacency matrix (the cached M^T a pull-form vxm wants), int32, AINV on the way
     algorithms   : bfs / sssp / pr / tc end to end through the operator API (spla_Algorithm_*, every step on the device), on a
                    symmetrised R-MAT; wall-clock per call including the per-iteration host synchronisations, like the reference's
                    own whole-algorithm charts
@@ -462,6 +463,54 @@ def algorithms(args):
     return line
 
 
+# ---------------------------------------------------------------------------------------------------------- transpose
+def transpose(args):
+    """R = AINV(M)^T through the kernel-level C ABI; algorithmic bytes = read M + write R = 2 * (8 nnz + 4 (n + 1))."""
+    from oracle import pyoracle
+    from spla_amd import _lib, graphgen
+    from spla_amd.kernels import _ptr, current_stream_ptr
+    from spla_amd.ops import type_id, unop_id
+    scale = int(os.environ.get("SPLA_TRANSPOSE_SCALE", "22"))
+    n, Ap, Aj = graphgen.rmat_csr(scale, 16, seed=1, device="cuda")
+    nnz = int(Aj.numel())
+    Ax = (torch.arange(nnz, device="cuda", dtype=torch.int32) % 1000003)
+    Rp = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    Rj, Rx = torch.empty(nnz, dtype=torch.int32, device="cuda"), torch.empty(nnz, dtype=torch.int32, device="cuda")
+    tid, op = type_id("INT"), unop_id("AINV")
+
+    def step():
+        _lib.call("splahip_m_transpose", tid, n, n, nnz, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(Rp), _ptr(Rj), _ptr(Rx), op, current_stream_ptr())
+
+    wall, ms = _time_calls(step, args.steps, args.warmup)
+    med = float(np.median(ms))
+    # parity on a bounded sample: the first rows of M against the oracle, and (M^T)^T == M in full
+    Bp, Bj, Bx = torch.empty_like(Rp), torch.empty_like(Rj), torch.empty_like(Rx)
+    _lib.call("splahip_m_transpose", tid, n, n, nnz, _ptr(Rp), _ptr(Rj), _ptr(Rx), _ptr(Bp), _ptr(Bj), _ptr(Bx), op, current_stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(Bp, Ap) and torch.equal(Bj, Aj) and torch.equal(Bx, Ax), "transpose twice is not the identity"
+    rows = min(n, 1 << 16)
+    hp = Ap[:rows + 1].cpu().numpy().view(np.uint32)
+    k = int(hp[-1])
+    hj, hx = Aj[:k].cpu().numpy().view(np.uint32), Ax[:k].cpu().numpy()
+    orc = pyoracle.Oracle()
+    t0 = time.perf_counter()
+    want = orc.m_transpose("INT", rows, n, hp, hj, hx, "AINV")
+    cpu_s = time.perf_counter() - t0
+    sp, sj, sx = torch.empty(n + 1, dtype=torch.int32, device="cuda"), torch.empty(max(k, 1), dtype=torch.int32, device="cuda"), torch.empty(max(k, 1), dtype=torch.int32, device="cuda")
+    dp = torch.from_numpy(hp.view(np.int32)).cuda()
+    _lib.call("splahip_m_transpose", tid, rows, n, k, _ptr(dp), _ptr(Aj), _ptr(Ax), _ptr(sp), _ptr(sj), _ptr(sx), op, current_stream_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(sp.cpu().numpy().view(np.uint32), want[0]) and np.array_equal(sj[:k].cpu().numpy().view(np.uint32), want[1]) \
+        and np.array_equal(sx[:k].cpu().numpy(), want[2]), "transpose differs from the oracle"
+    alg = 2 * (8 * nnz + 4 * (n + 1))
+    roof = _roof(alg, med, "rocprim radix sort passes + transpose_payload / emit / offsets")
+    _log(f"[transpose] n={n} nnz={nnz}: {med:.3f} ms per call ({nnz / med / 1e6:.2f} G entries/s), oracle {k / cpu_s / 1e6:.1f} M entries/s on one core")
+    return _line("transpose_gentries_per_s", "Gentries/s", nnz / (med * 1e-3) / 1e9, args, med, "i32",
+                 {"workload": f"exec_m_transpose AINV int32, R-MAT scale {scale} edge factor 16 ({nnz} entries)"}, roof,
+                 {"cpu_baseline": {"value": round(k / cpu_s / 1e9, 4), "unit": "Gentries/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {rows} rows ({k} entries), oracle_m_transpose"}})
+
+
 def _dense_i(vec, n):
     """dense read-back of an INT vector through the C ABI's bulk read (absent entries = 0)"""
     I, X = vec.read()
@@ -477,4 +526,4 @@ def _dense_f(vec, n, fill=None):
     return out
 
 
-WORKLOADS = {"pagerank-vxm": pagerank_vxm, "sssp-step": sssp_step, "tc-mxmT": tc_mxmT, "mxm": mxm, "algorithms": algorithms}
+WORKLOADS = {"pagerank-vxm": pagerank_vxm, "sssp-step": sssp_step, "tc-mxmT": tc_mxmT, "mxm": mxm, "algorithms": algorithms, "transpose": transpose}

@@ -61,7 +61,7 @@ typedef uint32_t spla_uint;
 typedef size_t   spla_size_t;
 
 /* opaque handles: raw pointers to intrusively counted objects (reference include/spla.h:119-132) */
-#define SPLA_C_HANDLES(X) X(RefCnt) X(MemView) X(Object) X(Type) X(Descriptor) X(Matrix) X(Vector) X(Scalar) X(ScheduleTask) X(OpBinary) X(OpSelect) X(MtxLoader)
+#define SPLA_C_HANDLES(X) X(RefCnt) X(MemView) X(Object) X(Type) X(Descriptor) X(Matrix) X(Vector) X(Scalar) X(ScheduleTask) X(OpBinary) X(OpSelect) X(OpUnary) X(MtxLoader)
 #define SPLA_C_DECL_HANDLE(Name) typedef struct spla_##Name##_t* spla_##Name;
 SPLA_C_HANDLES(SPLA_C_DECL_HANDLE)
 #undef SPLA_C_DECL_HANDLE
@@ -96,6 +96,16 @@ SPLA_C_DECL_TYPE(BOOL) SPLA_C_DECL_TYPE(INT) SPLA_C_DECL_TYPE(UINT) SPLA_C_DECL_
 #define SPLA_C_DECL_BIN3(OP) SPLA_C_GETTER(Binary, OP, INT) SPLA_C_GETTER(Binary, OP, UINT) SPLA_C_GETTER(Binary, OP, FLOAT)
 #define SPLA_C_DECL_BIN2(OP) SPLA_C_GETTER(Binary, OP, INT) SPLA_C_GETTER(Binary, OP, UINT)
 #define SPLA_C_DECL_SEL3(OP) SPLA_C_GETTER(Select, OP, INT) SPLA_C_GETTER(Select, OP, UINT) SPLA_C_GETTER(Select, OP, FLOAT)
+/* unary ops (reference include/spla.h:159-191): spla_OpUnary_<OP>_{INT,UINT,FLOAT}; BNOT has no FLOAT form, SQRT .. TRUNC only that */
+#define SPLA_C_UNARY_OPS_ALL(X) X(IDENTITY) X(AINV) X(MINV) X(LNOT) X(UONE) X(ABS)
+#define SPLA_C_UNARY_OPS_FLOAT(X) X(SQRT) X(LOG) X(EXP) X(SIN) X(COS) X(TAN) X(ASIN) X(ACOS) X(ATAN) X(CEIL) X(FLOOR) X(ROUND) X(TRUNC)
+#define SPLA_C_DECL_UN3(OP) SPLA_C_GETTER(Unary, OP, INT) SPLA_C_GETTER(Unary, OP, UINT) SPLA_C_GETTER(Unary, OP, FLOAT)
+#define SPLA_C_DECL_UN1(OP) SPLA_C_GETTER(Unary, OP, FLOAT)
+SPLA_C_UNARY_OPS_ALL(SPLA_C_DECL_UN3)
+SPLA_C_GETTER(Unary, BNOT, INT) SPLA_C_GETTER(Unary, BNOT, UINT)
+SPLA_C_UNARY_OPS_FLOAT(SPLA_C_DECL_UN1)
+#undef SPLA_C_DECL_UN3
+#undef SPLA_C_DECL_UN1
 SPLA_C_BINARY_OPS_ARITH(SPLA_C_DECL_BIN3)
 SPLA_C_BINARY_OPS_BITWISE(SPLA_C_DECL_BIN2)
 SPLA_C_SELECT_OPS(SPLA_C_DECL_SEL3)
@@ -176,6 +186,10 @@ SPLA_API spla_Status spla_Exec_v_count_mf(spla_Scalar count, spla_Vector vec, SP
 SPLA_API spla_Status spla_Exec_m_reduce(spla_Scalar out, spla_Scalar start, spla_Matrix mat, spla_OpBinary op, SPLA_C_EXEC_TAIL);
 SPLA_API spla_Status spla_Exec_v_eadd(spla_Vector out, spla_Vector lhs, spla_Vector rhs, spla_OpBinary op, SPLA_C_EXEC_TAIL);
 SPLA_API spla_Status spla_Exec_v_reduce(spla_Scalar out, spla_Scalar start, spla_Vector vec, spla_OpBinary op, SPLA_C_EXEC_TAIL);
+
+/* ---- transpose and element-wise map (reference include/spla.h:379,386) ---- */
+SPLA_API spla_Status spla_Exec_m_transpose(spla_Matrix out, spla_Matrix mat, spla_OpUnary apply, SPLA_C_EXEC_TAIL);
+SPLA_API spla_Status spla_Exec_v_map(spla_Vector out, spla_Vector vec, spla_OpUnary op, SPLA_C_EXEC_TAIL);
 
 /* ---- graph algorithms (reference include/spla.h:360-363); options may be NULL = defaults (push-pull, front factor 0.1) ---- */
 SPLA_API spla_Status spla_Algorithm_bfs(spla_Vector levels, spla_Matrix adjacency, spla_uint source, spla_Descriptor options);

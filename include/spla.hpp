@@ -278,6 +278,13 @@ namespace spla {
         static ref_ptr<OpBinary> make_uint(std::string name, std::string code, std::function<T_UINT(T_UINT, T_UINT)> function);
         static ref_ptr<OpBinary> make_float(std::string name, std::string code, std::function<T_FLOAT(T_FLOAT, T_FLOAT)> function);
     };
+    class OpUnary : public Op {
+    public:
+        virtual ref_ptr<Type> get_type_arg_0() = 0;
+        static ref_ptr<OpUnary> make_int(std::string name, std::string code, std::function<T_INT(T_INT)> function);
+        static ref_ptr<OpUnary> make_uint(std::string name, std::string code, std::function<T_UINT(T_UINT)> function);
+        static ref_ptr<OpUnary> make_float(std::string name, std::string code, std::function<T_FLOAT(T_FLOAT)> function);
+    };
     class OpSelect : public Op {
     public:
         virtual ref_ptr<Type> get_type_arg_0() = 0;
@@ -292,6 +299,18 @@ namespace spla {
     X(MIN, 1) X(MAX, 1) X(LOR, 1) X(LAND, 1) X(BOR, 0) X(BAND, 0) X(BXOR, 0)
 #define SPLA_SELECT_OPS(X) \
     X(EQZERO) X(NQZERO) X(GTZERO) X(GEZERO) X(LTZERO) X(LEZERO) X(ALWAYS) X(NEVER)
+
+    // built-in unary ops (reference src/op.cpp:99-133); X(name, for INT/UINT, for FLOAT)
+#define SPLA_UNARY_OPS(X) \
+    X(IDENTITY, 1, 1) X(AINV, 1, 1) X(MINV, 1, 1) X(LNOT, 1, 1) X(UONE, 1, 1) X(ABS, 1, 1) X(BNOT, 1, 0) \
+    X(SQRT, 0, 1) X(LOG, 0, 1) X(EXP, 0, 1) X(SIN, 0, 1) X(COS, 0, 1) X(TAN, 0, 1) X(ASIN, 0, 1) X(ACOS, 0, 1) X(ATAN, 0, 1) \
+    X(CEIL, 0, 1) X(FLOOR, 0, 1) X(ROUND, 0, 1) X(TRUNC, 0, 1)
+#define SPLA_DECL_UN(NAME, HASI, HASF)  \
+    extern ref_ptr<OpUnary> NAME##_INT; \
+    extern ref_ptr<OpUnary> NAME##_UINT;\
+    extern ref_ptr<OpUnary> NAME##_FLOAT;/* null where the reference has no such op */
+    SPLA_UNARY_OPS(SPLA_DECL_UN)
+#undef SPLA_DECL_UN
 
 #define SPLA_DECL_BIN(NAME, HASF)             \
     extern ref_ptr<OpBinary> NAME##_INT;      \
@@ -401,6 +420,12 @@ namespace spla {
                          ref_ptr<Descriptor> desc = ref_ptr<Descriptor>(), ref_ptr<ScheduleTask>* task_hnd = nullptr);
     Status exec_m_reduce(ref_ptr<Scalar> r, ref_ptr<Scalar> s, ref_ptr<Matrix> M, ref_ptr<OpBinary> op_reduce,
                          ref_ptr<Descriptor> desc = ref_ptr<Descriptor>(), ref_ptr<ScheduleTask>* task_hnd = nullptr);
+
+    // transpose with a unary op on the way, element-wise map (reference include/spla/exec.hpp:318-323,468-473)
+    Status exec_m_transpose(ref_ptr<Matrix> R, ref_ptr<Matrix> M, ref_ptr<OpUnary> op_apply,
+                            ref_ptr<Descriptor> desc = ref_ptr<Descriptor>(), ref_ptr<ScheduleTask>* task_hnd = nullptr);
+    Status exec_v_map(ref_ptr<Vector> r, ref_ptr<Vector> v, ref_ptr<OpUnary> op,
+                      ref_ptr<Descriptor> desc = ref_ptr<Descriptor>(), ref_ptr<ScheduleTask>* task_hnd = nullptr);
 
     // ---- graph algorithms over exec_* (reference include/spla/algorithm.hpp:54-68,86-101,120-137,157-170) ----
     Status bfs(const ref_ptr<Vector>& v, const ref_ptr<Matrix>& A, uint s, const ref_ptr<Descriptor>& descriptor = ref_ptr<Descriptor>());

@@ -118,7 +118,7 @@ int splahip_vxm_push_n(int type, uint32_t n_rows, uint32_t n_cols,
                        uint32_t* d_ri, void* d_rx, uint32_t* h_count,
                        int op_mult, int op_add, int op_select, uint64_t n_products, void* stream);
 /* CSR of the transpose (n_cols rows): entries of a column keep ascending row order (stable).  d_Tp: n_cols+1 words,
- * d_Tj / d_Tx: nnz words.  Blocks.  (reference: the CSC slot FormatMatrix::AccCsc, include/spla/config.hpp:102-122) */
+ * d_Tj / d_Tx: nnz words.  Blocks; = splahip_m_transpose with the identity.  (reference: the CSC slot FormatMatrix::AccCsc, include/spla/config.hpp:102-122) */
 int splahip_csr_transpose(uint32_t n_rows, uint32_t n_cols, uint32_t nnz, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax,
                           uint32_t* d_Tp, uint32_t* d_Tj, void* d_Tx, void* stream);
 
@@ -175,6 +175,15 @@ int splahip_v_eadd_dense(int type, uint32_t n, void* d_r, const void* d_u, const
 int splahip_v_eadd_sparse(int type, uint32_t nu, const uint32_t* d_ui, const void* d_ux, uint32_t u_fill_bits, uint32_t nv, const uint32_t* d_vi,
                           const void* d_vx, uint32_t v_fill_bits, uint32_t* d_ri, void* d_rx, uint32_t* h_count, int op, void* stream);
 int splahip_reduce(int type, uint32_t n, const void* d_x, uint32_t s_bits, uint32_t* h_result_bits, int op, void* stream);
+
+/* ---- transpose and element-wise map -----------------------------------------------------------
+ * m_transpose: R = op_apply(M)^T, both CSR (reference exec_m_transpose, include/spla/exec.hpp:318-323; semantics of
+ * Algo_m_transpose_cpu::execute_csr, src/cpu/cpu_m_transpose.hpp:141-185): d_Rp has n_cols + 1 entries, d_Rj / d_Rx nnz; inside a
+ * row of R the entries are in ascending source-row order.  op_apply: a splahip_unop id.  Asynchronous on `stream`.
+ * map: d_out[i] = op(d_x[i]), i < n (reference exec_v_map, exec.hpp:468-473; src/cpu/cpu_v_map.hpp:70-121); d_out may equal d_x. */
+int splahip_m_transpose(int type, uint32_t n_rows, uint32_t n_cols, uint32_t nnz, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax,
+                        uint32_t* d_Rp, uint32_t* d_Rj, void* d_Rx, int op_apply, void* stream);
+int splahip_map(int type, uint32_t n, const void* d_x, void* d_out, int op, void* stream);
 
 /* ---- accelerator vector formats ------------------------------------------------------------------------------
  * AccDense <-> AccCoo (reference src/opencl/cl_format_dense_vec.hpp:90-143, cl_format_coo_vec.hpp:149-158).

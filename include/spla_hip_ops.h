@@ -56,6 +56,32 @@ typedef enum splahip_selop {
     SPLAHIP_SELOP_COUNT = 8
 } splahip_selop;
 
+/* unary ops T -> T (reference: src/op.cpp:99-133; BNOT for I,U only, SQRT..TRUNC for F only).  Integer MINV by zero
+ * and ABS(INT_MIN) are undefined in the reference; here 1/0 = 0 and ABS wraps. */
+typedef enum splahip_unop {
+    SPLAHIP_IDENTITY = 0,  /* a          */
+    SPLAHIP_AINV     = 1,  /* -a         */
+    SPLAHIP_MINV     = 2,  /* 1 / a      */
+    SPLAHIP_LNOT     = 3,  /* !(a != 0) -> 0/1 */
+    SPLAHIP_UONE     = 4,  /* 1          */
+    SPLAHIP_ABS      = 5,  /* |a|        */
+    SPLAHIP_BNOT     = 6,  /* ~a  (I,U)  */
+    SPLAHIP_SQRT     = 7,  /* F only from here */
+    SPLAHIP_LOG      = 8,
+    SPLAHIP_EXP      = 9,
+    SPLAHIP_SIN      = 10,
+    SPLAHIP_COS      = 11,
+    SPLAHIP_TAN      = 12,
+    SPLAHIP_ASIN     = 13,
+    SPLAHIP_ACOS     = 14,
+    SPLAHIP_ATAN     = 15,
+    SPLAHIP_CEIL     = 16,
+    SPLAHIP_FLOOR    = 17,
+    SPLAHIP_ROUND    = 18,
+    SPLAHIP_TRUNC    = 19,
+    SPLAHIP_UNOP_COUNT = 20
+} splahip_unop;
+
 #ifdef __cplusplus
 }
 #endif

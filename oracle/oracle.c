@@ -6,6 +6,7 @@
  */
 #include "oracle.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -72,6 +73,31 @@ static inline int neq(int type, word a, word b) {
     return type == SPLAHIP_FLOAT ? (as_f(a) != as_f(b)) : (a != b);
 }
 
+/* ---- unary ops, reference src/op.cpp:99-133.  The reference's integer `1 / a` with a == 0 and abs(INT_MIN) are undefined; the
+ * restatement (and the device) use 1/0 = 0 and a wrapping ABS ---- */
+typedef word (*unfn)(word);
+#define UN_I(name, expr) static word name##_i(word wa) { int32_t a = as_i(wa); (void)a; return from_i((int32_t)(expr)); }
+#define UN_U(name, expr) static word name##_u(word a) { (void)a; return (word)(expr); }
+#define UN_F(name, expr) static word name##_f(word wa) { float a = as_f(wa); (void)a; return from_f((float)(expr)); }
+UN_I(ident, a)                       UN_U(ident, a)                   UN_F(ident, a)
+UN_I(ainv, 0u - (uint32_t)a)         UN_U(ainv, 0u - a)               UN_F(ainv, -a)
+UN_I(minv, a == 0 ? 0 : 1 / a)       UN_U(minv, a == 0 ? 0u : 1u / a) UN_F(minv, 1.0f / a)
+UN_I(lnot, !(a != 0))                UN_U(lnot, !(a != 0))            UN_F(lnot, !(a != 0))
+UN_I(uone, 1)                        UN_U(uone, 1u)                   UN_F(uone, 1.0f)
+UN_I(absv, a < 0 ? 0u - (uint32_t)a : (uint32_t)a)  UN_U(absv, a)     UN_F(absv, fabs((double) a))
+UN_I(bnot, ~a)                       UN_U(bnot, ~a)
+/* the reference calls the unqualified C functions (`sin(a)`, src/op.cpp:121-133): evaluated in DOUBLE, then rounded to float
+ * (pinned against the reference build: 200 000 random arguments per op, bit for bit) */
+UN_F(sqrtv, sqrt((double) a)) UN_F(logv, log((double) a)) UN_F(expv, exp((double) a)) UN_F(sinv, sin((double) a)) UN_F(cosv, cos((double) a))
+UN_F(tanv, tan((double) a)) UN_F(asinv, asin((double) a)) UN_F(acosv, acos((double) a)) UN_F(atanv, atan((double) a))
+UN_F(ceilv, ceil((double) a)) UN_F(floorv, floor((double) a)) UN_F(roundv, round((double) a)) UN_F(truncv, trunc((double) a))
+static const unfn k_un[3][SPLAHIP_UNOP_COUNT] = {
+        {ident_i, ainv_i, minv_i, lnot_i, uone_i, absv_i, bnot_i, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+        {ident_u, ainv_u, minv_u, lnot_u, uone_u, absv_u, bnot_u, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+        {ident_f, ainv_f, minv_f, lnot_f, uone_f, absv_f, NULL, sqrtv_f, logv_f, expv_f, sinv_f, cosv_f, tanv_f, asinv_f, acosv_f, atanv_f,
+         ceilv_f, floorv_f, roundv_f, truncv_f}};
+
+uint32_t oracle_unop(int type, int op, uint32_t a) { return k_un[type][op](a); }
 uint32_t oracle_binop(int type, int op, uint32_t a, uint32_t b) { return k_bin[type][op](a, b); }
 int      oracle_selop(int type, int op, uint32_t a) { return k_sel[type][op](a); }
 void     oracle_free(void* p) { free(p); }
@@ -344,4 +370,33 @@ uint32_t oracle_reduce(int type, uint32_t n, const uint32_t* x, uint32_t s, int 
     word        sum = s;
     for (uint32_t i = 0; i < n; ++i) sum = f(sum, x[i]);
     return sum;
+}
+
+/* reference src/cpu/cpu_m_transpose.hpp:141-185 (execute_csr): count per column, exclusive scan, then a row-major walk that drops
+ * every entry at its column's next free slot — so a row of R lists its entries by ascending source row */
+void oracle_m_transpose(int type, uint32_t n_rows, uint32_t n_cols, const uint32_t* Ap, const uint32_t* Aj, const uint32_t* Ax, uint32_t* Rp,
+                        uint32_t* Rj, uint32_t* Rx, int op_apply) {
+    const unfn f      = k_un[type][op_apply];
+    uint32_t*  offset = (uint32_t*) calloc((size_t) n_cols + 1, sizeof(uint32_t));
+    for (uint32_t i = 0; i < n_rows; ++i)
+        for (uint32_t k = Ap[i]; k < Ap[i + 1]; ++k) offset[Aj[k]] += 1;
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < n_cols; ++j) {
+        Rp[j] = sum;
+        sum += offset[j];
+        offset[j] = 0;
+    }
+    Rp[n_cols] = sum;
+    for (uint32_t i = 0; i < n_rows; ++i)
+        for (uint32_t k = Ap[i]; k < Ap[i + 1]; ++k) {
+            const uint32_t j = Aj[k], at = Rp[j] + offset[j]++;
+            Rj[at] = i;
+            Rx[at] = f(Ax[k]);
+        }
+    free(offset);
+}
+/* reference src/cpu/cpu_v_map.hpp:70-121: out[i] = op(x[i]) over the stored values (sparse) or every index (dense) */
+void oracle_map(int type, uint32_t n, const uint32_t* x, uint32_t* out, int op) {
+    const unfn f = k_un[type][op];
+    for (uint32_t i = 0; i < n; ++i) out[i] = f(x[i]);
 }

@@ -90,6 +90,14 @@ uint32_t oracle_v_eadd_sparse(int type, uint32_t nu, const uint32_t* ui, const u
 /* strict left fold of x[0..n) from s.  reference src/cpu/cpu_v_reduce.hpp:69-117, src/cpu/cpu_m_reduce.hpp:134-156 */
 uint32_t oracle_reduce(int type, uint32_t n, const uint32_t* x, uint32_t s, int op);
 
+/* ---- transpose and element-wise map ---- */
+uint32_t oracle_unop(int type, int op, uint32_t a); /* reference src/op.cpp:99-133 */
+/* R = op(M)^T, CSR to CSR; Rp: n_cols + 1 words, Rj / Rx: nnz words.  reference src/cpu/cpu_m_transpose.hpp:141-185 */
+void oracle_m_transpose(int type, uint32_t n_rows, uint32_t n_cols, const uint32_t* Ap, const uint32_t* Aj, const uint32_t* Ax, uint32_t* Rp,
+                        uint32_t* Rj, uint32_t* Rx, int op_apply);
+/* out[i] = op(x[i]).  reference src/cpu/cpu_v_map.hpp:70-121 */
+void oracle_map(int type, uint32_t n, const uint32_t* x, uint32_t* out, int op);
+
 void oracle_free(void* p);
 
 #ifdef __cplusplus

@@ -29,6 +29,8 @@ TYPE_NAME = {0: "INT", 1: "UINT", 2: "FLOAT"}
 TYPE_NP = {0: np.int32, 1: np.uint32, 2: np.float32}
 BINOPS = ["PLUS", "MINUS", "MULT", "DIV", "MINUS_POW2", "FIRST", "SECOND", "BONE", "MIN", "MAX", "LOR", "LAND",
           "BOR", "BAND", "BXOR"]
+UNOPS = ["IDENTITY", "AINV", "MINV", "LNOT", "UONE", "ABS", "BNOT", "SQRT", "LOG", "EXP", "SIN", "COS", "TAN", "ASIN", "ACOS", "ATAN",
+         "CEIL", "FLOOR", "ROUND", "TRUNC"]
 SELOPS = ["EQZERO", "NQZERO", "GTZERO", "GEZERO", "LTZERO", "LEZERO", "ALWAYS", "NEVER"]
 
 _u32p = C.POINTER(C.c_uint32)
@@ -52,6 +54,10 @@ def _tid(t) -> int:
 
 def _bid(op) -> int:
     return BINOPS.index(op.upper()) if isinstance(op, str) else int(op)
+
+
+def _uid(op) -> int:
+    return UNOPS.index(op.upper()) if isinstance(op, str) else int(op)
 
 
 def _sid(op) -> int:
@@ -113,6 +119,12 @@ class Oracle:
         lib.oracle_v_eadd_sparse.argtypes = [C.c_int, C.c_uint32, _u32p, _u32p, C.c_uint32, C.c_uint32, _u32p, _u32p, C.c_uint32, _u32p, _u32p, C.c_int]
         lib.oracle_reduce.restype = C.c_uint32
         lib.oracle_reduce.argtypes = [C.c_int, C.c_uint32, _u32p, C.c_uint32, C.c_int]
+        lib.oracle_unop.restype = C.c_uint32
+        lib.oracle_unop.argtypes = [C.c_int, C.c_int, C.c_uint32]
+        lib.oracle_m_transpose.restype = None
+        lib.oracle_m_transpose.argtypes = [C.c_int, C.c_uint32, C.c_uint32] + [_u32p] * 6 + [C.c_int]
+        lib.oracle_map.restype = None
+        lib.oracle_map.argtypes = [C.c_int, C.c_uint32, _u32p, _u32p, C.c_int]
         self.lib = lib
 
     # ---- vector operations of a traversal step: inputs are numpy arrays, r is returned as a new array
@@ -171,6 +183,23 @@ class Oracle:
         x = words(x, t)
         out = self.lib.oracle_reduce(t, len(x), _p(x), bits(s, t), _bid(op))
         return np.array([out], np.uint32).view(TYPE_NP[t])[0]
+
+    def m_transpose(self, t, n_rows, n_cols, Ap, Aj, Ax, op_apply="IDENTITY"):
+        """R = op(M)^T as CSR (Rp, Rj, Rx)."""
+        t = _tid(t)
+        Ap, Aj, Ax = words(Ap), words(Aj), words(Ax, t)
+        nnz = len(Aj)
+        Rp, Rj, Rx = np.zeros(n_cols + 1, np.uint32), np.zeros(max(nnz, 1), np.uint32), np.zeros(max(nnz, 1), np.uint32)
+        self.lib.oracle_m_transpose(t, n_rows, n_cols, _p(Ap), _p(Aj if nnz else Rj), _p(Ax if nnz else Rx), _p(Rp), _p(Rj), _p(Rx), _uid(op_apply))
+        return Rp, Rj[:nnz], Rx[:nnz].view(TYPE_NP[t])
+
+    def v_map(self, t, x, op):
+        """out[i] = op(x[i]): x is the dense image or the stored values of a sparse vector."""
+        t = _tid(t)
+        x = words(x, t)
+        out = np.zeros(max(len(x), 1), np.uint32)
+        self.lib.oracle_map(t, len(x), _p(x if len(x) else out), _p(out), _uid(op))
+        return out[:len(x)].view(TYPE_NP[t])
 
     # ---- the graph algorithms, restated over the oracle's own operations (reference src/algorithm.cpp:45-120,158-229,278-335,380-414)
     def bfs(self, n, Ap, Aj, s, pull=False):
@@ -534,6 +563,28 @@ class Reference:
         self._ok(self.lib.spla_Exec_m_reduce(hr, hs, M, self._op("Binary", BINOPS[_bid(op)], t), None, None), "Exec_m_reduce")
         out = self._scalar_value(hr, t)
         self._unref(M, hs, hr)
+        return out
+
+    def m_transpose(self, t, n_rows, n_cols, Ap, Aj, Ax, op_apply="IDENTITY"):
+        t = _tid(t)
+        self.lib.spla_Exec_m_transpose.argtypes = [C.c_void_p] * 5
+        M = self._matrix(t, n_rows, n_cols, Ap, Aj, Ax)
+        R = C.c_void_p()
+        self._ok(self.lib.spla_Matrix_make(C.byref(R), n_cols, n_rows, self._types[t]), "Matrix_make")
+        self._ok(self.lib.spla_Exec_m_transpose(R, M, self._op("Unary", UNOPS[_uid(op_apply)], t), None, None), "Exec_m_transpose")
+        out = self._read_lil(R, n_cols, t)
+        self._unref(M, R)
+        return out
+
+    def v_map(self, t, x, op, idx=None, n=None):
+        """exec_v_map over a dense vector, or a sparse one (idx given); returns the dense image / (indices, values)."""
+        t = _tid(t)
+        self.lib.spla_Exec_v_map.argtypes = [C.c_void_p] * 5
+        hv = self._dense_vector(t, x) if idx is None else self._sparse_vector(t, n, idx, x)
+        hr = self._empty_vector(t, len(x) if idx is None else n)
+        self._ok(self.lib.spla_Exec_v_map(hr, hv, self._op("Unary", UNOPS[_uid(op)], t), None, None), "Exec_v_map")
+        out = self._read_dense(hr, len(x), t) if idx is None else self._read_coo(hr, t)
+        self._unref(hv, hr)
         return out
 
     def _traversal(self, mode, front_factor):

@@ -67,6 +67,8 @@ _SIGNATURES = {
     "splahip_mxm": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32] + [_vp] * 6 + [_vp, C.POINTER(_vp), C.POINTER(_vp), _u32p, C.POINTER(C.c_uint64),
                               C.c_int, C.c_int, C.c_uint32, C.c_uint64, _vp]),
     "splahip_csr_transpose": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "splahip_m_transpose": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "splahip_map": (C.c_int, [C.c_int, C.c_uint32, _vp, _vp, C.c_int, _vp]),
 }
 _RAW = {"splahip_device_count", "splahip_last_error", "splahip_version", "splahip_mxv_variant", "splahip_mxv_variant_of"}
 

@@ -17,6 +17,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from .ops import UNOP, unop_valid
 
 _vp = C.c_void_p
 
@@ -27,6 +28,7 @@ ACCELERATOR_NONE, ACCELERATOR_OPENCL, ACCELERATOR_HIP = 0, 1, 2
 BINARY_OPS = ["PLUS", "MINUS", "MULT", "DIV", "MINUS_POW2", "FIRST", "SECOND", "BONE", "MIN", "MAX", "LOR", "LAND", "BOR", "BAND", "BXOR"]
 SELECT_OPS = ["EQZERO", "NQZERO", "GTZERO", "GEZERO", "LTZERO", "LEZERO", "ALWAYS", "NEVER"]
 BITWISE = ("BOR", "BAND", "BXOR")
+UNARY_OPS = list(UNOP)
 
 
 class SplaError(RuntimeError):
@@ -50,7 +52,7 @@ def c_symbols():
              "spla_Matrix_set_float", "spla_Matrix_get_int", "spla_Matrix_get_uint", "spla_Matrix_get_float", "spla_Matrix_build", "spla_Matrix_read", "spla_Matrix_clear",
              "spla_Exec_mxm", "spla_Exec_mxmT_masked", "spla_Exec_mxv_masked", "spla_Exec_vxm_masked",
              "spla_Exec_v_eadd_fdb", "spla_Exec_v_assign_masked", "spla_Exec_v_count_mf",
-             "spla_Exec_v_eadd", "spla_Exec_v_reduce", "spla_Exec_m_reduce",
+             "spla_Exec_v_eadd", "spla_Exec_v_reduce", "spla_Exec_m_reduce", "spla_Exec_m_transpose", "spla_Exec_v_map",
              "spla_Algorithm_bfs", "spla_Algorithm_sssp", "spla_Algorithm_pr", "spla_Algorithm_tc",
              "spla_MtxLoader_load", "spla_MtxLoader_get", "spla_MtxLoader_delete",
              "spla_Descriptor_make", "spla_Descriptor_set_early_exit", "spla_Descriptor_set_struct_only",
@@ -61,6 +63,10 @@ def c_symbols():
     for op in SELECT_OPS:
         for t in ("INT", "UINT", "FLOAT"):
             names.append(f"spla_OpSelect_{op}_{t}")
+    for op in UNARY_OPS:
+        for t in ("INT", "UINT", "FLOAT"):
+            if unop_valid(op, t):
+                names.append(f"spla_OpUnary_{op}_{t}")
     return names
 
 
@@ -73,7 +79,7 @@ def _c():
     if not _bound:
         for name in c_symbols():
             fn = getattr(lib, name)
-            if name.startswith(("spla_Type_", "spla_OpBinary_", "spla_OpSelect_")):
+            if name.startswith(("spla_Type_", "spla_OpBinary_", "spla_OpSelect_", "spla_OpUnary_")):
                 fn.restype, fn.argtypes = _vp, []
             elif name == "spla_Library_finalize":
                 fn.restype, fn.argtypes = None, []
@@ -130,6 +136,8 @@ def _c():
         lib.spla_Exec_v_eadd.argtypes = [_vp] * 5 + [C.POINTER(_vp)]
         lib.spla_Exec_v_reduce.argtypes = [_vp] * 5 + [C.POINTER(_vp)]
         lib.spla_Exec_m_reduce.argtypes = [_vp] * 5 + [C.POINTER(_vp)]
+        lib.spla_Exec_m_transpose.argtypes = [_vp] * 4 + [C.POINTER(_vp)]
+        lib.spla_Exec_v_map.argtypes = [_vp] * 4 + [C.POINTER(_vp)]
         lib.spla_Algorithm_bfs.argtypes = [_vp, _vp, C.c_uint, _vp]
         lib.spla_Algorithm_sssp.argtypes = [_vp, _vp, C.c_uint, _vp]
         lib.spla_Algorithm_pr.argtypes = [C.POINTER(_vp), _vp, C.c_float, C.c_float, _vp]
@@ -210,6 +218,8 @@ for _op in BINARY_OPS:
     setattr(Type, _op, _OpAttr("Binary", _op))
 for _op in SELECT_OPS:
     setattr(Type, _op, _OpAttr("Select", _op))
+for _op in UNARY_OPS:  # e.g. INT.AINV, FLOAT.SQRT; an op the type lacks (FLOAT.BNOT, INT.SQRT) raises AttributeError at lookup
+    setattr(Type, _op, _OpAttr("Unary", _op))
 
 
 class INT(Type):
@@ -415,6 +425,13 @@ class Vector(Object):
         _check(_c().spla_Exec_v_reduce(out.hnd, init.hnd, self.hnd, op.hnd, _desc(desc), None), "spla_Exec_v_reduce")
         return out.get()
 
+    def map(self, op, out=None, desc=None):
+        """out = op(self) element-wise: stored entries of a sparse vector, every index of a dense one (reference python/pyspla/vector.py:690-720)."""
+        if out is None:
+            out = Vector(self.n_rows, self.dtype)
+        _check(_c().spla_Exec_v_map(out.hnd, self.hnd, op.hnd, _desc(desc), None), "spla_Exec_v_map")
+        return out
+
     def vxm(self, mask, M, op_mult, op_add, op_select, out=None, init=None, desc=None):
         """r = self^T x M over (op_mult, op_add), columns selected by mask (reference python/pyspla/vector.py:476-546)."""
         if out is None:
@@ -535,6 +552,15 @@ class Matrix(Object):
             init = Scalar(self.dtype, init)
         _check(_c().spla_Exec_m_reduce(out.hnd, init.hnd, self.hnd, op.hnd, _desc(desc), None), "spla_Exec_m_reduce")
         return out.get()
+
+    def transpose(self, op_apply=None, out=None, desc=None):
+        """out = op_apply(self)^T (reference python/pyspla/matrix.py:1300-1338 / exec_m_transpose); op_apply defaults to IDENTITY."""
+        if out is None:
+            out = Matrix((self.n_cols, self.n_rows), self.dtype)
+        if op_apply is None:
+            op_apply = self.dtype.IDENTITY
+        _check(_c().spla_Exec_m_transpose(out.hnd, self.hnd, op_apply.hnd, _desc(desc), None), "spla_Exec_m_transpose")
+        return out
 
 
 # ---- graph algorithms (reference C API include/spla.h:360-363) ----

@@ -22,6 +22,12 @@ namespace spla {
         }
 
         template<typename T>
+        int device_unop(const ref_ptr<OpUnary>& op) {
+            auto t = op.template cast_safe<TOpUnary<T>>();
+            return t->device_id;
+        }
+
+        template<typename T>
         void ensure_plan(HipCsr<T>* a, uint n_rows) {
             if (!a->plan) hip_check(splahip_csr_plan_create(&a->plan, n_rows, a->values, a->Ap.template as<uint32_t>(), nullptr), "csr plan");
         }
@@ -462,6 +468,81 @@ namespace spla {
             }
         };
 
+        // R = op_apply(M)^T through the accelerator CSR (the reference's CPU algorithm picks csr / lil / dok by what is valid and
+        // produces the same matrix in each, cpu_m_transpose.hpp:57-75; here every format converges on AccCsr first)
+        template<typename T>
+        class Algo_m_transpose_hip final : public RegistryAlgo {
+        public:
+            std::string get_name() override { return "m_transpose"; }
+            std::string get_description() override { return "transpose with a unary op: stable radix sort of the entries by column"; }
+            Status      execute(const DispatchContext& ctx) override {
+                auto t = ctx.task.template cast_safe<ScheduleTask_m_transpose>();
+                auto R = t->R.template cast_safe<TMatrix<T>>();
+                auto M = t->M.template cast_safe<TMatrix<T>>();
+                const int op = device_unop<T>(t->op_apply);
+                if (op < 0) {
+                    SPLA_LOG(Status::NotImplemented, "user-defined ops have no device code in this build");
+                    return Status::NotImplemented;
+                }
+                if (R->get_n_rows() != M->get_n_cols() || R->get_n_cols() != M->get_n_rows() || R.get() == M.get()) return Status::InvalidArgument;
+                R->validate_wd(FormatMatrix::AccCsr);
+                M->validate_rw(FormatMatrix::AccCsr);
+                auto *r = R->acc_csr(), *m = M->acc_csr();
+                r->drop_plan();
+                r->Ap.reserve(R->get_n_rows() + 1);
+                r->Aj.reserve(m->values);
+                r->Ax.reserve(m->values);
+                hip_check(splahip_m_transpose(TypeTraits<T>::id, M->get_n_rows(), M->get_n_cols(), m->values, m->Ap.template as<uint32_t>(),
+                                              m->Aj.template as<uint32_t>(), m->Ax.ptr(), r->Ap.template as<uint32_t>(), r->Aj.template as<uint32_t>(),
+                                              r->Ax.ptr(), op, nullptr),
+                          "splahip_m_transpose");
+                r->values = m->values;
+                return Status::Ok;
+            }
+        };
+
+        // r = op(v): over the stored entries when the sparse image is the valid one, else over every index (cpu_v_map.hpp:57-68)
+        template<typename T>
+        class Algo_v_map_hip final : public RegistryAlgo {
+        public:
+            std::string get_name() override { return "v_map"; }
+            std::string get_description() override { return "element-wise unary op over a vector"; }
+            Status      execute(const DispatchContext& ctx) override {
+                auto t = ctx.task.template cast_safe<ScheduleTask_v_map>();
+                auto r = t->r.template cast_safe<TVector<T>>();
+                auto v = t->v.template cast_safe<TVector<T>>();
+                const int op = device_unop<T>(t->op);
+                if (op < 0) {
+                    SPLA_LOG(Status::NotImplemented, "user-defined ops have no device code in this build");
+                    return Status::NotImplemented;
+                }
+                if (r->get_n_rows() != v->get_n_rows()) return Status::InvalidArgument;
+                const bool sparse = coo_valid(v.get()) || !dense_valid(v.get());
+                if (sparse) {
+                    v->validate_rw(FormatVector::AccCoo);
+                    const uint n = v->acc_coo()->values;
+                    if (r.get() != v.get()) r->validate_wd(FormatVector::AccCoo);
+                    else
+                        r->validate_rwd(FormatVector::AccCoo);
+                    auto *in = v->acc_coo(), *out = r->acc_coo();
+                    if (in != out) {
+                        out->Ai.reserve(n);
+                        out->Ax.reserve(n);
+                        if (n) hip_check(splahip_memcpy_d2d(out->Ai.ptr(), in->Ai.ptr(), std::size_t(n) * 4, nullptr), "index copy");
+                    }
+                    hip_check(splahip_map(TypeTraits<T>::id, n, in->Ax.ptr(), out->Ax.ptr(), op, nullptr), "splahip_map");
+                    out->values = n;
+                } else {
+                    v->validate_rw(FormatVector::AccDense);
+                    if (r.get() != v.get()) r->validate_wd(FormatVector::AccDense);
+                    else
+                        r->validate_rwd(FormatVector::AccDense);
+                    hip_check(splahip_map(TypeTraits<T>::id, v->get_n_rows(), v->acc_dense()->Ax.ptr(), r->acc_dense()->Ax.ptr(), op, nullptr), "splahip_map");
+                }
+                return Status::Ok;
+            }
+        };
+
         template<template<typename> class Algo>
         void add3(Registry* g, const std::string& name) {
             g->add(name + "_I__hip", std::make_shared<Algo<T_INT>>());
@@ -481,6 +562,8 @@ namespace spla {
         add3<Algo_v_eadd_hip>(g, "v_eadd");
         add3<Algo_v_reduce_hip>(g, "v_reduce");
         add3<Algo_m_reduce_hip>(g, "m_reduce");
+        add3<Algo_m_transpose_hip>(g, "m_transpose");
+        add3<Algo_v_map_hip>(g, "v_map");
     }
 
 }// namespace spla

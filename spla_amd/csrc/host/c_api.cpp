@@ -60,6 +60,13 @@ spla_Type spla_Type_FLOAT(void) { return reinterpret_cast<spla_Type>(FLOAT.get()
 #define SPLA_C_DEF_SEL(OP, TY) \
     spla_OpSelect spla_OpSelect_##OP##_##TY(void) { return (Library::get(), reinterpret_cast<spla_OpSelect>(OP##_##TY.get())); }
 #define SPLA_C_DEF_SEL3(OP) SPLA_C_DEF_SEL(OP, INT) SPLA_C_DEF_SEL(OP, UINT) SPLA_C_DEF_SEL(OP, FLOAT)
+#define SPLA_C_DEF_UN(OP, TY) \
+    spla_OpUnary spla_OpUnary_##OP##_##TY(void) { return (Library::get(), reinterpret_cast<spla_OpUnary>(OP##_##TY.get())); }
+#define SPLA_C_DEF_UN3(OP) SPLA_C_DEF_UN(OP, INT) SPLA_C_DEF_UN(OP, UINT) SPLA_C_DEF_UN(OP, FLOAT)
+#define SPLA_C_DEF_UN1(OP) SPLA_C_DEF_UN(OP, FLOAT)
+SPLA_C_UNARY_OPS_ALL(SPLA_C_DEF_UN3)
+SPLA_C_DEF_UN(BNOT, INT) SPLA_C_DEF_UN(BNOT, UINT)
+SPLA_C_UNARY_OPS_FLOAT(SPLA_C_DEF_UN1)
 SPLA_C_BINARY_OPS_ARITH(SPLA_C_DEF_BIN3)
 SPLA_C_BINARY_OPS_BITWISE(SPLA_C_DEF_BIN2)
 SPLA_C_SELECT_OPS(SPLA_C_DEF_SEL3)
@@ -168,6 +175,12 @@ spla_Status spla_Exec_v_count_mf(spla_Scalar r, spla_Vector v, spla_Descriptor d
 
 spla_Status spla_Exec_m_reduce(spla_Scalar r, spla_Scalar s, spla_Matrix M, spla_OpBinary op_reduce, spla_Descriptor desc, spla_ScheduleTask* task) {
     SPLA_C_EXEC(exec_m_reduce(as_ref<Scalar>(r), as_ref<Scalar>(s), as_ref<Matrix>(M), as_ref<OpBinary>(op_reduce), as_ref<Descriptor>(desc), p_hnd))
+}
+spla_Status spla_Exec_m_transpose(spla_Matrix R, spla_Matrix M, spla_OpUnary op_apply, spla_Descriptor desc, spla_ScheduleTask* task) {
+    SPLA_C_EXEC(exec_m_transpose(as_ref<Matrix>(R), as_ref<Matrix>(M), as_ref<OpUnary>(op_apply), as_ref<Descriptor>(desc), p_hnd))
+}
+spla_Status spla_Exec_v_map(spla_Vector r, spla_Vector v, spla_OpUnary op, spla_Descriptor desc, spla_ScheduleTask* task) {
+    SPLA_C_EXEC(exec_v_map(as_ref<Vector>(r), as_ref<Vector>(v), as_ref<OpUnary>(op), as_ref<Descriptor>(desc), p_hnd))
 }
 spla_Status spla_Exec_v_eadd(spla_Vector r, spla_Vector u, spla_Vector v, spla_OpBinary op, spla_Descriptor desc, spla_ScheduleTask* task) {
     SPLA_C_EXEC(exec_v_eadd(as_ref<Vector>(r), as_ref<Vector>(u), as_ref<Vector>(v), as_ref<OpBinary>(op), as_ref<Descriptor>(desc), p_hnd))

@@ -8,6 +8,7 @@
 
 #include <spla_hip.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
@@ -88,6 +89,13 @@ namespace spla {
     SPLA_SELECT_OPS(SPLA_DEF_SEL)
 #undef SPLA_DEF_SEL
 
+#define SPLA_DEF_UN(NAME, HASI, HASF)   \
+    ref_ptr<OpUnary> NAME##_INT;        \
+    ref_ptr<OpUnary> NAME##_UINT;       \
+    ref_ptr<OpUnary> NAME##_FLOAT;
+    SPLA_UNARY_OPS(SPLA_DEF_UN)
+#undef SPLA_DEF_UN
+
     namespace {
         template<typename T>
         const char* type_name() {
@@ -122,6 +130,18 @@ namespace spla {
             op->function  = std::move(fn);
             op->device_id = device_id;
             return op.template as<OpSelect>();
+        }
+
+        template<typename T>
+        ref_ptr<OpUnary> un(const char* prefix, int device_id, const char* body, std::function<T(T)> fn) {
+            auto op       = ref_ptr<TOpUnary<T>>(new TOpUnary<T>());
+            const std::string c = TypeTraits<T>::code;
+            op->name      = std::string(prefix) + "_" + type_name<T>();
+            op->key       = std::string(prefix) + "_" + c + c;
+            op->source    = std::string("(") + type_cl<T>() + " a) { return " + body + "; }";
+            op->function  = std::move(fn);
+            op->device_id = device_id;
+            return op.template as<OpUnary>();
         }
 
         // host-side scalar semantics; int32 +,-,* wrap like the device (the reference's signed overflow is UB)
@@ -189,8 +209,40 @@ namespace spla {
         }
     }// namespace
 
+    namespace {
+        // unary ops every element type has (reference src/op.cpp:99-116); integer 1/0 = 0 and ABS(INT_MIN) wraps, as on the device
+        template<typename T>
+        void register_unary_common(ref_ptr<OpUnary>& identity, ref_ptr<OpUnary>& ainv, ref_ptr<OpUnary>& minv, ref_ptr<OpUnary>& lnot,
+                                   ref_ptr<OpUnary>& uone, ref_ptr<OpUnary>& abs_) {
+            identity = un<T>("IDENTITY", SPLAHIP_IDENTITY, "a", [](T a) { return a; });
+            ainv     = un<T>("AINV", SPLAHIP_AINV, "-a", [](T a) { return w_sub(T(0), a); });
+            minv     = un<T>("MINV", SPLAHIP_MINV, "1 / a", [](T a) { return w_div(T(1), a); });
+            lnot     = un<T>("LNOT", SPLAHIP_LNOT, "!(a != 0)", [](T a) { return a != T(0) ? T(0) : T(1); });
+            uone     = un<T>("UONE", SPLAHIP_UONE, "1", [](T) { return T(1); });
+            abs_     = un<T>("ABS", SPLAHIP_ABS, "abs(a)", [](T a) { return a < T(0) ? w_sub(T(0), a) : a; });
+        }
+    }// namespace
+
     void register_ops() {
         if (PLUS_INT) return;
+        register_unary_common<T_INT>(IDENTITY_INT, AINV_INT, MINV_INT, LNOT_INT, UONE_INT, ABS_INT);
+        register_unary_common<T_UINT>(IDENTITY_UINT, AINV_UINT, MINV_UINT, LNOT_UINT, UONE_UINT, ABS_UINT);
+        register_unary_common<T_FLOAT>(IDENTITY_FLOAT, AINV_FLOAT, MINV_FLOAT, LNOT_FLOAT, UONE_FLOAT, ABS_FLOAT);
+        BNOT_INT    = un<T_INT>("BNOT", SPLAHIP_BNOT, "~a", [](T_INT a) { return ~a; });
+        BNOT_UINT   = un<T_UINT>("BNOT", SPLAHIP_BNOT, "~a", [](T_UINT a) { return ~a; });
+        SQRT_FLOAT  = un<T_FLOAT>("SQRT", SPLAHIP_SQRT, "sqrt(a)", [](T_FLOAT a) { return std::sqrt(a); });
+        LOG_FLOAT   = un<T_FLOAT>("LOG", SPLAHIP_LOG, "log(a)", [](T_FLOAT a) { return static_cast<T_FLOAT>(std::log(static_cast<double>(a))); });
+        EXP_FLOAT   = un<T_FLOAT>("EXP", SPLAHIP_EXP, "exp(a)", [](T_FLOAT a) { return static_cast<T_FLOAT>(std::exp(static_cast<double>(a))); });
+        SIN_FLOAT   = un<T_FLOAT>("SIN", SPLAHIP_SIN, "sin(a)", [](T_FLOAT a) { return static_cast<T_FLOAT>(std::sin(static_cast<double>(a))); });
+        COS_FLOAT   = un<T_FLOAT>("COS", SPLAHIP_COS, "cos(a)", [](T_FLOAT a) { return static_cast<T_FLOAT>(std::cos(static_cast<double>(a))); });
+        TAN_FLOAT   = un<T_FLOAT>("TAN", SPLAHIP_TAN, "tan(a)", [](T_FLOAT a) { return static_cast<T_FLOAT>(std::tan(static_cast<double>(a))); });
+        ASIN_FLOAT  = un<T_FLOAT>("ASIN", SPLAHIP_ASIN, "asin(a)", [](T_FLOAT a) { return static_cast<T_FLOAT>(std::asin(static_cast<double>(a))); });
+        ACOS_FLOAT  = un<T_FLOAT>("ACOS", SPLAHIP_ACOS, "acos(a)", [](T_FLOAT a) { return static_cast<T_FLOAT>(std::acos(static_cast<double>(a))); });
+        ATAN_FLOAT  = un<T_FLOAT>("ATAN", SPLAHIP_ATAN, "atan(a)", [](T_FLOAT a) { return static_cast<T_FLOAT>(std::atan(static_cast<double>(a))); });
+        CEIL_FLOAT  = un<T_FLOAT>("CEIL", SPLAHIP_CEIL, "ceil(a)", [](T_FLOAT a) { return std::ceil(a); });
+        FLOOR_FLOAT = un<T_FLOAT>("FLOOR", SPLAHIP_FLOOR, "floor(a)", [](T_FLOAT a) { return std::floor(a); });
+        ROUND_FLOAT = un<T_FLOAT>("ROUND", SPLAHIP_ROUND, "round(a)", [](T_FLOAT a) { return std::round(a); });
+        TRUNC_FLOAT = un<T_FLOAT>("TRUNC", SPLAHIP_TRUNC, "trunc(a)", [](T_FLOAT a) { return std::trunc(a); });
         register_arith<T_INT>(PLUS_INT, MINUS_INT, MULT_INT, DIV_INT, MINUS_POW2_INT, FIRST_INT, SECOND_INT, BONE_INT, MIN_INT, MAX_INT, LOR_INT, LAND_INT);
         register_arith<T_UINT>(PLUS_UINT, MINUS_UINT, MULT_UINT, DIV_UINT, MINUS_POW2_UINT, FIRST_UINT, SECOND_UINT, BONE_UINT, MIN_UINT, MAX_UINT, LOR_UINT, LAND_UINT);
         register_arith<T_FLOAT>(PLUS_FLOAT, MINUS_FLOAT, MULT_FLOAT, DIV_FLOAT, MINUS_POW2_FLOAT, FIRST_FLOAT, SECOND_FLOAT, BONE_FLOAT, MIN_FLOAT, MAX_FLOAT, LOR_FLOAT, LAND_FLOAT);
@@ -224,6 +276,21 @@ namespace spla {
             return op.template as<OpSelect>();
         }
     }// namespace
+    namespace {
+        template<typename T>
+        ref_ptr<OpUnary> user_un(std::string name, std::string code, std::function<T(T)> fn) {
+            auto op      = ref_ptr<TOpUnary<T>>(new TOpUnary<T>());
+            const std::string c = TypeTraits<T>::code;
+            op->name     = name;
+            op->key      = name + "_" + c + c;
+            op->source   = std::move(code);
+            op->function = std::move(fn);
+            return op.template as<OpUnary>();
+        }
+    }// namespace
+    ref_ptr<OpUnary> OpUnary::make_int(std::string n, std::string c, std::function<T_INT(T_INT)> f) { return user_un<T_INT>(std::move(n), std::move(c), std::move(f)); }
+    ref_ptr<OpUnary> OpUnary::make_uint(std::string n, std::string c, std::function<T_UINT(T_UINT)> f) { return user_un<T_UINT>(std::move(n), std::move(c), std::move(f)); }
+    ref_ptr<OpUnary> OpUnary::make_float(std::string n, std::string c, std::function<T_FLOAT(T_FLOAT)> f) { return user_un<T_FLOAT>(std::move(n), std::move(c), std::move(f)); }
     ref_ptr<OpBinary> OpBinary::make_int(std::string n, std::string c, std::function<T_INT(T_INT, T_INT)> f) { return user_bin<T_INT>(std::move(n), std::move(c), std::move(f)); }
     ref_ptr<OpBinary> OpBinary::make_uint(std::string n, std::string c, std::function<T_UINT(T_UINT, T_UINT)> f) { return user_bin<T_UINT>(std::move(n), std::move(c), std::move(f)); }
     ref_ptr<OpBinary> OpBinary::make_float(std::string n, std::string c, std::function<T_FLOAT(T_FLOAT, T_FLOAT)> f) { return user_bin<T_FLOAT>(std::move(n), std::move(c), std::move(f)); }
@@ -547,6 +614,26 @@ namespace spla {
         task->M         = std::move(M);
         task->op_reduce = std::move(op_reduce);
         task->desc      = std::move(desc);
+        return run_or_return(task.as<ScheduleTask>(), task_hnd);
+    }
+
+    Status exec_m_transpose(ref_ptr<Matrix> R, ref_ptr<Matrix> M, ref_ptr<OpUnary> op_apply, ref_ptr<Descriptor> desc, ref_ptr<ScheduleTask>* task_hnd) {
+        if (!R || !M || !op_apply) return Status::InvalidArgument;
+        auto task      = ref_ptr<ScheduleTask_m_transpose>(new ScheduleTask_m_transpose());
+        task->R        = std::move(R);
+        task->M        = std::move(M);
+        task->op_apply = std::move(op_apply);
+        task->desc     = std::move(desc);
+        return run_or_return(task.as<ScheduleTask>(), task_hnd);
+    }
+
+    Status exec_v_map(ref_ptr<Vector> r, ref_ptr<Vector> v, ref_ptr<OpUnary> op, ref_ptr<Descriptor> desc, ref_ptr<ScheduleTask>* task_hnd) {
+        if (!r || !v || !op) return Status::InvalidArgument;
+        auto task  = ref_ptr<ScheduleTask_v_map>(new ScheduleTask_v_map());
+        task->r    = std::move(r);
+        task->v    = std::move(v);
+        task->op   = std::move(op);
+        task->desc = std::move(desc);
         return run_or_return(task.as<ScheduleTask>(), task_hnd);
     }
 

@@ -214,6 +214,25 @@ namespace spla {
         std::string m_label;
     };
 
+    template<typename T>
+    class TOpUnary final : public OpUnary {
+    public:
+        void               set_label(std::string label) override { m_label = std::move(label); }
+        const std::string& get_label() const override { return m_label; }
+        ref_ptr<Type>      get_type_res() override { return TypeTraits<T>::type(); }
+        ref_ptr<Type>      get_type_arg_0() override { return TypeTraits<T>::type(); }
+        std::string        get_name() override { return name; }
+        std::string        get_key() override { return key; }
+        std::string        get_source_cl() override { return source; }
+
+        std::function<T(T)> function;
+        std::string         name, key, source;
+        int                 device_id = -1;// splahip_unop
+
+    private:
+        std::string m_label;
+    };
+
     void register_ops();// host/core.cpp: fills the global op handles declared in spla.hpp
 
     // ---- schedule tasks -------------------------------------------------------------------------------------------------------
@@ -329,6 +348,23 @@ namespace spla {
         ref_ptr<Scalar>              r, s;
         ref_ptr<Matrix>              M;
         ref_ptr<OpBinary>            op_reduce;
+    };
+    // reference src/schedule/schedule_tasks.hpp:281-300 (m_transpose), ScheduleTask_v_map; keys by the result's type
+    class ScheduleTask_m_transpose final : public TaskBase {
+    public:
+        std::string                  get_name() override { return "m_transpose"; }
+        std::string                  get_key() override { return "m_transpose_" + R->get_type()->get_code(); }
+        std::vector<ref_ptr<Object>> get_args() override { return {R.as<Object>(), M.as<Object>(), op_apply.as<Object>()}; }
+        ref_ptr<Matrix>              R, M;
+        ref_ptr<OpUnary>             op_apply;
+    };
+    class ScheduleTask_v_map final : public TaskBase {
+    public:
+        std::string                  get_name() override { return "v_map"; }
+        std::string                  get_key() override { return "v_map_" + r->get_type()->get_code(); }
+        std::vector<ref_ptr<Object>> get_args() override { return {r.as<Object>(), v.as<Object>(), op.as<Object>()}; }
+        ref_ptr<Vector>              r, v;
+        ref_ptr<OpUnary>             op;
     };
 
 }// namespace spla

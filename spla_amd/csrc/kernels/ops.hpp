@@ -164,6 +164,54 @@ namespace splahip {
         }
     }
 
+    // unary op (m_transpose's op_apply, v_map): evaluated once per stored entry of a streaming pass, runtime-switched
+    template<typename T>
+    __device__ __forceinline__ T eval_un(int op, T a) {
+        if constexpr (std::is_same<T, float>::value) {
+            switch (op) {
+                case SPLAHIP_AINV: return -a;
+                case SPLAHIP_MINV: return 1.0f / a;
+                case SPLAHIP_LNOT: return a != 0.0f ? 0.0f : 1.0f;
+                case SPLAHIP_UONE: return 1.0f;
+                case SPLAHIP_ABS: return fabsf(a);
+                // the reference calls the unqualified C functions on a float (src/op.cpp:121-133): evaluated in double, rounded once
+                case SPLAHIP_SQRT: return sqrtf(a);// correctly rounded either way
+                case SPLAHIP_LOG: return (float) log((double) a);
+                case SPLAHIP_EXP: return (float) exp((double) a);
+                case SPLAHIP_SIN: return (float) sin((double) a);
+                case SPLAHIP_COS: return (float) cos((double) a);
+                case SPLAHIP_TAN: return (float) tan((double) a);
+                case SPLAHIP_ASIN: return (float) asin((double) a);
+                case SPLAHIP_ACOS: return (float) acos((double) a);
+                case SPLAHIP_ATAN: return (float) atan((double) a);
+                case SPLAHIP_CEIL: return ceilf(a);
+                case SPLAHIP_FLOOR: return floorf(a);
+                case SPLAHIP_ROUND: return roundf(a);
+                case SPLAHIP_TRUNC: return truncf(a);
+                default: return a;// IDENTITY
+            }
+        } else {
+            using U = uint32_t;
+            switch (op) {
+                case SPLAHIP_AINV: return T(U(0) - U(a));
+                case SPLAHIP_MINV: return a == T(0) ? T(0) : T(T(1) / a);
+                case SPLAHIP_LNOT: return a != T(0) ? T(0) : T(1);
+                case SPLAHIP_UONE: return T(1);
+                case SPLAHIP_ABS:
+                    if constexpr (std::is_same<T, int32_t>::value) return a < 0 ? T(U(0) - U(a)) : a;
+                    else
+                        return a;
+                case SPLAHIP_BNOT: return T(~U(a));
+                default: return a;// IDENTITY
+            }
+        }
+    }
+    inline bool unop_valid_for(int op, int type) {
+        if (op < 0 || op >= SPLAHIP_UNOP_COUNT) return false;
+        if (type == SPLAHIP_FLOAT) return op != SPLAHIP_BNOT;
+        return op <= SPLAHIP_BNOT;
+    }
+
     // Algebraic traits of an op used as the ADD of a semiring (host side; decide which kernel may be used).
     //   associative: a tree / segmented reduction gives the left fold's result (bit-exact for I/U; fp32 PLUS and
     //                MULT are treated as associative under the stated 1e-5 relative tolerance)

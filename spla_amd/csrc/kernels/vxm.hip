@@ -104,32 +104,6 @@ namespace splahip {
     // ------------------------------------------------------------------------------------------------------------
     // transpose (CSR of M^T, rows ascending inside every column)
     // ------------------------------------------------------------------------------------------------------------
-    __global__ __launch_bounds__(256) void iota_kernel(uint* __restrict__ x, uint n) {
-        const uint i = blockIdx.x * 256 + threadIdx.x;
-        if (i < n) x[i] = i;
-    }
-    __global__ __launch_bounds__(256) void transpose_fill_kernel(uint nnz, uint n_rows, const uint* __restrict__ Ap, const uint* __restrict__ Ax,
-                                                                 const uint* __restrict__ perm, uint* __restrict__ Tj, uint* __restrict__ Tx) {
-        const uint t = blockIdx.x * 256 + threadIdx.x;
-        if (t >= nnz) return;
-        const uint k = perm[t];
-        Tj[t]        = upper_row(Ap, n_rows, k);
-        Tx[t]        = Ax[k];
-    }
-    // Tp[c] = first t with sorted_col[t] >= c
-    __global__ __launch_bounds__(256) void transpose_ptr_kernel(uint nnz, uint n_cols, const uint* __restrict__ sorted_col, uint* __restrict__ Tp) {
-        const uint c = blockIdx.x * 256 + threadIdx.x;
-        if (c > n_cols) return;
-        uint lo = 0, hi = nnz;
-        while (lo < hi) {
-            const uint mid = lo + ((hi - lo) >> 1);
-            if (sorted_col[mid] < c) lo = mid + 1;
-            else
-                hi = mid;
-        }
-        Tp[c] = lo;
-    }
-
     // ------------------------------------------------------------------------------------------------------------
     // probe: number of products of the frontier and whether v's indices are strictly ascending
     // ------------------------------------------------------------------------------------------------------------
@@ -558,30 +532,10 @@ extern "C" {
 
 int splahip_csr_transpose(uint32_t n_rows, uint32_t n_cols, uint32_t nnz, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax,
                           uint32_t* d_Tp, uint32_t* d_Tj, void* d_Tx, void* stream) {
-    int st = ensure_device();
+    // the value words travel untouched: the transpose of matrix_ops.hip with the identity over 4-byte words
+    int st = splahip_m_transpose(SPLAHIP_UINT, n_rows, n_cols, nnz, d_Ap, d_Aj, d_Ax, d_Tp, d_Tj, d_Tx, SPLAHIP_IDENTITY, stream);
     if (st != SPLAHIP_OK) return st;
-    SPLAHIP_REQUIRE(d_Tp != nullptr, "d_Tp is null");
-    hipStream_t s = as_stream(stream);
-    if (nnz == 0) {
-        SPLAHIP_TRY(hipMemsetAsync(d_Tp, 0, sizeof(uint32_t) * ((size_t) n_cols + 1), s));
-        return SPLAHIP_OK;
-    }
-    SPLAHIP_REQUIRE(d_Ap && d_Aj && d_Ax && d_Tj && d_Tx, "null device pointer");
-    DevMem iota, perm, sorted, tmp;
-    SPLAHIP_TRY(iota.alloc(s, sizeof(uint) * (size_t) nnz));
-    SPLAHIP_TRY(perm.alloc(s, sizeof(uint) * (size_t) nnz));
-    SPLAHIP_TRY(sorted.alloc(s, sizeof(uint) * (size_t) nnz));
-    hipLaunchKernelGGL(iota_kernel, dim3((nnz + 255) / 256), dim3(256), 0, s, iota.as<uint>(), nnz);
-    size_t     tmp_bytes = 0;
-    const uint bits      = bit_width_u32(n_cols);
-    SPLAHIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_Aj, sorted.as<uint>(), iota.as<uint>(), perm.as<uint>(), nnz, 0, bits, s));
-    SPLAHIP_TRY(tmp.alloc(s, tmp_bytes));
-    SPLAHIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, d_Aj, sorted.as<uint>(), iota.as<uint>(), perm.as<uint>(), nnz, 0, bits, s));
-    hipLaunchKernelGGL(transpose_fill_kernel, dim3((nnz + 255) / 256), dim3(256), 0, s, nnz, n_rows, d_Ap, static_cast<const uint*>(d_Ax),
-                       perm.as<uint>(), d_Tj, static_cast<uint*>(d_Tx));
-    hipLaunchKernelGGL(transpose_ptr_kernel, dim3((n_cols + 1 + 255) / 256), dim3(256), 0, s, nnz, n_cols, sorted.as<uint>(), d_Tp);
-    SPLAHIP_TRY(hipGetLastError());
-    SPLAHIP_TRY(hipStreamSynchronize(s));
+    SPLAHIP_TRY(hipStreamSynchronize(as_stream(stream)));
     return SPLAHIP_OK;
 }
 

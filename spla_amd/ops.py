@@ -17,6 +17,11 @@ BINOP = {
     "MIN": 8, "MAX": 9, "LOR": 10, "LAND": 11, "BOR": 12, "BAND": 13, "BXOR": 14,
 }
 SELOP = {"EQZERO": 0, "NQZERO": 1, "GTZERO": 2, "GEZERO": 3, "LTZERO": 4, "LEZERO": 5, "ALWAYS": 6, "NEVER": 7}
+UNOP = {
+    "IDENTITY": 0, "AINV": 1, "MINV": 2, "LNOT": 3, "UONE": 4, "ABS": 5, "BNOT": 6, "SQRT": 7, "LOG": 8, "EXP": 9, "SIN": 10,
+    "COS": 11, "TAN": 12, "ASIN": 13, "ACOS": 14, "ATAN": 15, "CEIL": 16, "FLOOR": 17, "ROUND": 18, "TRUNC": 19,
+}
+FLOAT_ONLY_UNOPS = tuple(n for n, i in UNOP.items() if i >= 7)
 
 BITWISE = ("BOR", "BAND", "BXOR")
 NON_ASSOCIATIVE = ("MINUS", "DIV", "MINUS_POW2")
@@ -39,6 +44,16 @@ def binop_id(name) -> int:
 
 def selop_id(name) -> int:
     return SELOP[name.upper()] if isinstance(name, str) else int(name)
+
+
+def unop_id(name) -> int:
+    return UNOP[name.upper()] if isinstance(name, str) else int(name)
+
+
+def unop_valid(name: str, t) -> bool:
+    if type_id(t) == TYPE["FLOAT"]:
+        return name.upper() != "BNOT"
+    return name.upper() not in FLOAT_ONLY_UNOPS
 
 
 def binop_valid(name: str, t) -> bool:
