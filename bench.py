@@ -40,7 +40,7 @@ def coll_device():
 
 def kernel_name(plan, t, mul, add, early):
     from spla_amd import kernels
-    return kernels.mxv_variant(t, mul, add, early)
+    return kernels.mxv_variant(t, mul, add, early, plan)
 
 
 def log(*a):
@@ -59,6 +59,9 @@ def parse():
                    "vertices per row block, original order inside a block); default: raw at 1 GPU, owner-sorted when gpus > 1")
     p.add_argument("--owners", type=int, default=0, help="blocks of the owner-sorted relabelling (default: the number of GPUs)")
     p.add_argument("--cpu-sample-nnz", type=int, default=8_000_000, help="nnz of the leading row block timed on the CPU")
+    p.add_argument("--plan", default="sell", choices=["sell", "csr"],
+                   help="matrix layout of the timed step: sell = CSR + the sliced-ELL copy (splahip_csr_plan_attach_sell, built once per matrix, "
+                        "+12 B per entry); csr = the CSR wave-tile kernels only")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-variants", action="store_true")
     p.add_argument("--no-verify", action="store_true")
@@ -191,6 +194,13 @@ def main():
     ones_i = torch.ones(nnz_local, dtype=torch.int32, device="cuda")
 
     depth, L, sizes, src = bfs_state(sh, ones_i)
+    sh.plan_csr = sh.plan
+    if args.plan == "sell":  # the timed step runs on the sliced-ELL copy (part of the resident matrix, like the plan's work items)
+        t0 = time.perf_counter()
+        sh.plan = kernels.CsrPlan(n_local, nnz_local, g["Ap"], sh.n_cols_padded, g["Aj"], ones_i)
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f"[bench] sliced-ELL copy attached in {(time.perf_counter() - t0) * 1e3:.0f} ms: {sh.plan.sell}")
     mask = torch.where(depth <= L, depth, torch.zeros_like(depth)).contiguous()      # visited up to level L
     front = torch.zeros(sh.max_rows if world > 1 else n_local, dtype=torch.int32, device="cuda")
     front[:n_local] = (depth == L).to(torch.int32)
@@ -418,7 +428,7 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
     steps = max(10, args.steps // 2)
 
     def run(name, t, Ax, m, v, r, mul, add, sel, init, early, nnz_sel, plan=None):
-        plan = plan or sh.plan
+        plan = plan or sh.plan_csr
         fn = lambda: kernels.mxv_masked(plan, t, sh.n_cols_padded, g["Ap"], g["Aj"], Ax, m, v, r, mul, add, sel, init, early_exit=early)
         _, per = timed(fn, steps, 3)
         ms = float(np.mean(per))
@@ -426,7 +436,7 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
         tot = torch.tensor([nnz_sel], device=coll_device(), dtype=torch.int64)
         if world > 1:
             dist.all_reduce(tot)
-        res.append({"name": name, "kernel": kernels.mxv_variant(t, mul, add, early, plan) if plan is not sh.plan else kernel_name(sh.plan, t, mul, add, early), "kernel_avg_us": round(ms * 1e3, 2),
+        res.append({"name": name, "kernel": kernels.mxv_variant(t, mul, add, early, plan), "kernel_avg_us": round(ms * 1e3, 2),
                     "gteps_local": round(nnz_sel / (ms * 1e-3) / 1e9, 2), "hbm_gbs": round(b / (ms * 1e-3) / 1e9, 1),
                     "roofline_frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "nnz_selected_local": nnz_sel})
 
@@ -451,7 +461,7 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
     # the opt-in sliced-ELL + LDS hot-column copy of the same matrix (splahip_csr_plan_attach_sell), for the record (N = 1)
     r_ref = r_f.clone()
     sell_f = kernels.CsrPlan(n_local, nnz_local, g["Ap"], sh.n_cols_padded, g["Aj"], Ax_f)
-    run("all rows selected, MULT/PLUS fp32, sliced-ELL copy (opt-in)", "FLOAT", Ax_f, zeros_f, v_f, r_f, "MULT", "PLUS", "ALWAYS", 0.0, False, nnz_local, plan=sell_f)
+    run("all rows selected, MULT/PLUS fp32, sliced-ELL copy", "FLOAT", Ax_f, zeros_f, v_f, r_f, "MULT", "PLUS", "ALWAYS", 0.0, False, nnz_local, plan=sell_f)
     run("all rows selected, MULT/PLUS fp32", "FLOAT", Ax_f, zeros_f, v_f, r_ref, "MULT", "PLUS", "ALWAYS", 0.0, False, nnz_local)
     res.pop()  # (re-run of the CSR form only to have its result at hand for the comparison)
     rel = ((r_f - r_ref).abs() / r_ref.abs().clamp_min(1e-30)).max().item() if n_local else 0.0
@@ -460,10 +470,15 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
     sell_f.close()
     sell_i = kernels.CsrPlan(n_local, nnz_local, g["Ap"], sh.n_cols_padded, g["Aj"], ones_i)
     r_chk = torch.empty_like(r_i)
-    run("bfs-step early_exit=false, sliced-ELL copy (opt-in)", "INT", ones_i, mask, v_full, r_chk, "BAND", "BOR", "EQZERO", 0, False, nnz_sel_local, plan=sell_i)
-    kernels.mxv_masked(sh.plan, "INT", sh.n_cols_padded, g["Ap"], g["Aj"], ones_i, mask, v_full, r_i, "BAND", "BOR", "EQZERO", 0)
+    run("bfs-step early_exit=false, sliced-ELL copy", "INT", ones_i, mask, v_full, r_chk, "BAND", "BOR", "EQZERO", 0, False, nnz_sel_local, plan=sell_i)
+    r_chk2 = torch.empty_like(r_i)
+    os.environ["SPLAHIP_SELL_BITS"] = "0"
+    run("bfs-step early_exit=false, sliced-ELL copy, value form forced (SPLAHIP_SELL_BITS=0)", "INT", ones_i, mask, v_full, r_chk2, "BAND", "BOR", "EQZERO", 0, False, nnz_sel_local, plan=sell_i)
+    os.environ["SPLAHIP_SELL_BITS"] = "1"
+    run("bfs-step early_exit=false, CSR wave-tile kernel (no sliced-ELL copy)", "INT", ones_i, mask, v_full, r_i, "BAND", "BOR", "EQZERO", 0, False, nnz_sel_local)
     torch.cuda.synchronize()
-    res[-1]["identical_to_csr_kernel"] = bool(torch.equal(r_chk, r_i))
+    res[-3]["identical_to_csr_kernel"] = bool(torch.equal(r_chk, r_i))
+    res[-2]["identical_to_csr_kernel"] = bool(torch.equal(r_chk2, r_i))
     sell_i.close()
     return res
 

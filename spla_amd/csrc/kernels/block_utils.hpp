@@ -29,6 +29,12 @@ namespace splahip {
         return x;
     }
 
+    __device__ __forceinline__ uint32_t wave_max(uint32_t x) {
+#pragma unroll
+        for (unsigned off = kWave / 2; off > 0; off >>= 1) x = max(x, (uint32_t) __shfl_xor(x, off, kWave));
+        return x;
+    }
+
     // Exclusive prefix sum of one value per thread across a workgroup of NT threads (NT multiple of 64, <= 1024).
     // `total` receives the workgroup sum.  `s_tmp` must hold NT/64 + 1 words of LDS.  Contains barriers.
     template<unsigned NT>

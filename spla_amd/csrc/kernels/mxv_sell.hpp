@@ -18,9 +18,25 @@
 //     take ~2/3 of all gathers off the vector-memory pipeline.
 //   * ONE 1024-thread workgroup per CU (LDS is the limiter, 16 waves); memory-level parallelism comes from the loop, not
 //     from occupancy: each lane keeps a group of U = 8 (Aj, Ax) pairs and 8 gathers in flight and prefetches the next
-//     group and the next slice's header, all with static load counts so hipcc can place exact s_waitcnt values.
+//     group and the next slice's header, all with static load counts so hipcc can place exact s_waitcnt values.  A workgroup's waves take its slices widest
+//     first from an LDS counter (dynamic: which slices a mask skips is not known to the plan).
 //   * chunks of rows longer than C write partials; sell_combine folds them in chunk order (associative op_add only).
 //   * rows without entries and unselected rows get `init` from a coalesced pass over the workgroup's share of rows.
+//
+//
+// Sparse input vectors (BITS form).  When 0 annihilates op_mult and is the identity of op_add (int / uint BAND|MULT|LAND x
+// BOR|PLUS|BXOR, uint MAX), an entry whose v value is 0 cannot change its row's fold, so all the kernel needs from v is ONE BIT
+// per column — and 156 KB of LDS hold the bits of the 1.28 M most referenced columns (97 % of the entries of R-MAT scale 22)
+// where they held 40,000 values.  The columns are stored a second time as RANKS (position in the descending reference-count
+// order): rank < 1.28 M reads its bit from LDS; the few entries of colder columns (3 % on R-MAT scale 22) are taken out of the slices
+// into a rank-sorted side list that sell_cold folds into r afterwards with integer atomics (every BITS op_add is commutative), so
+// the main kernel's inner loop issues no vector-memory access besides its two coalesced streams — a conditional global load there
+// forces s_waitcnt vmcnt(0) per entry and with it a full memory latency per entry.  A pass over v in column order
+// (sell_vprep) scatters the bits (atomicOr), the non-zero values in rank order, and min / max / count of the non-zero values;
+// both forms of the kernel are launched and the device-side statistics decide which one runs (no host round trip): BITS when all
+// non-zero values are equal (a BFS frontier: the set bit IS the value) or when at most a quarter of v is non-zero (set bits
+// gather their value from the rank-ordered copy).  With an LDS-resident bit per entry the kernel has no vector-memory gather
+// left: it streams the selected rows' entries once.
 //
 // Semantics: reference Algo_mxv_masked_cpu<T>::execute, src/cpu/cpu_mxv.hpp:56-106.
 #pragma once
@@ -39,10 +55,84 @@ namespace splahip {
         static constexpr uint kHot     = 40000;// LDS-resident values of the gathered vector (156.25 KB of the 160 KB)
         static constexpr uint kTpb     = 1024; // one workgroup per CU
         static constexpr uint kWaves   = kTpb / kWave;
-        static constexpr uint kU       = 8;    // entries per lane and group
+        static constexpr uint kU       = 8;    // entries per lane and group (16: same speed, 98 VGPRs)
         static constexpr uint kHotFlag = 0x80000000u;
         static constexpr uint kPartial = 0x80000000u;// in vrow: this chunk belongs to a row longer than kC
+        // BITS form: ranks [0, kBitsLds) have an LDS-resident bit; bit kBitsLds of the LDS copy is kept 0 and entries of colder columns
+        // are coded with that rank (they live in the cold list).  (80 KB of bits and two workgroups per CU was tried: the 64-VGPR cap
+        // spills inside the slice loop, 165 -> 173 us on the BFS step.)
+        static constexpr uint kBitWords = kHot;
+        static constexpr uint kBitsLds  = kBitWords * 32 - 1;
+        // statistics behind the bitmap, 4 words per sell_vprep workgroup: count of non-zero v entries, max of ~bits (= ~min), max of bits
+        static constexpr uint kPrepBlocks = 1024;
+        static constexpr uint kStatCount = 0, kStatNotMin = 1, kStatMax = 2;
+        static constexpr uint kDecision = 4 * kPrepBlocks;// behind the slots: form (1 = BITS), is_const, const bits — written by the BITS launch
     };
+
+    // which form runs, from the per-workgroup statistics sell_vprep left on the device (every wave of both kernels evaluates the
+    // same predicate: kPrepBlocks x 3 words, no atomics and no host round trip); force: 0 = decide, 1 = BITS (tests / A-B runs)
+    __device__ __forceinline__ bool sell_bits_form(const uint* __restrict__ stats, uint n_cols, int force, bool& is_const, uint& const_bits) {
+        uint count = 0, notmin = 0, mx = 0;
+        for (uint b = lane_id(); b < SellCfg::kPrepBlocks; b += kWave) {
+            count += stats[4 * b + SellCfg::kStatCount];
+            notmin = max(notmin, stats[4 * b + SellCfg::kStatNotMin]);
+            mx     = max(mx, stats[4 * b + SellCfg::kStatMax]);
+        }
+        count      = wave_sum(count);
+        notmin     = wave_max(notmin);
+        mx         = wave_max(mx);
+        is_const   = count == 0 || ~notmin == mx;
+        const_bits = mx;
+        if (force) return force == 1;
+        return is_const || count <= n_cols / 4;
+    }
+
+    // column-order pass over v: hot values for the value form; bits, rank-ordered values and statistics for the BITS form.
+    // kPrepBlocks workgroups, grid-stride; every workgroup writes its own statistics slot (a same-address atomic per wave cost 0.8 ms)
+    template<typename T>
+    __global__ __launch_bounds__(256) void sell_vprep_kernel(uint n_cols, const T* __restrict__ v, const uint* __restrict__ rank_of, uint n_hot,
+                                                             T* __restrict__ hot_values, uint* __restrict__ vbits, uint* __restrict__ vranked,
+                                                             uint* __restrict__ stats) {
+        __shared__ uint s_red[3][256 / kWave];
+        uint            count = 0, notmin = 0, mx = 0;
+        auto            one   = [&](uint rank, uint b) {
+            if (rank < n_hot) hot_values[rank] = from_bits<T>(b);
+            if (b != 0) {
+                atomicOr(&vbits[rank >> 5], 1u << (rank & 31u));
+                vranked[rank] = b;
+                count += 1;
+                notmin = max(notmin, ~b);
+                mx     = max(mx, b);
+            }
+        };
+        // four columns per lane and step (16-byte loads; hipMalloc'ed operands are 256-byte aligned), tail by single columns
+        const uint n4 = n_cols & ~3u;
+        for (uint j = (blockIdx.x * 256 + threadIdx.x) * 4; j < n4; j += gridDim.x * 1024) {
+            const uint4 rk = *reinterpret_cast<const uint4*>(rank_of + j);
+            const uint4 x  = *reinterpret_cast<const uint4*>(v + j);
+            one(rk.x, x.x), one(rk.y, x.y), one(rk.z, x.z), one(rk.w, x.w);
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n_cols & 3u)) one(rank_of[n4 + threadIdx.x], to_bits(v[n4 + threadIdx.x]));
+        count  = wave_sum(count);
+        notmin = wave_max(notmin);
+        mx     = wave_max(mx);
+        if (lane_id() == 0) {
+            s_red[0][wave_id()] = count;
+            s_red[1][wave_id()] = notmin;
+            s_red[2][wave_id()] = mx;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (uint w = 1; w < 256 / kWave; ++w) {
+                count += s_red[0][w];
+                notmin = max(notmin, s_red[1][w]);
+                mx     = max(mx, s_red[2][w]);
+            }
+            stats[4 * blockIdx.x + SellCfg::kStatCount]  = count;
+            stats[4 * blockIdx.x + SellCfg::kStatNotMin] = notmin;
+            stats[4 * blockIdx.x + SellCfg::kStatMax]    = mx;
+        }
+    }
 
     template<typename T>
     __global__ __launch_bounds__(256) void sell_hot_pack_kernel(const uint* __restrict__ hot_cols, uint n_hot, const T* __restrict__ v, T* __restrict__ hot_values) {
@@ -52,7 +142,10 @@ namespace splahip {
 
     __device__ __forceinline__ uint sell_stream_load(const uint* p) { return __builtin_nontemporal_load(p); }
 
-    template<typename T, class Mult, class Add>
+    // BITS = false: Aj2 holds hot-slot / raw column words, s_hot the hot VALUES, cold lanes gather v.
+    // BITS = true : Aj2 holds ranks, s_hot the hot BITS (vbits), cold ranks read the global bitmap, set bits take const_bits or
+    //               gather vranked; `gate` (the statistics) != nullptr makes the launch a no-op unless its form is the chosen one.
+    template<typename T, class Mult, class Add, bool BITS>
     __global__ __launch_bounds__(SellCfg::kTpb) void sell_mxv_kernel(uint n_rows, const uint* __restrict__ Ap, uint n_slices,
                                                                      const uint* __restrict__ vrow, const uint* __restrict__ vlen,
                                                                      const uint* __restrict__ vslot, const uint* __restrict__ off,
@@ -60,11 +153,32 @@ namespace splahip {
                                                                      const T* __restrict__ hot_values, uint n_hot,
                                                                      const T* __restrict__ mask, const T* __restrict__ v,
                                                                      T* __restrict__ r, T* __restrict__ partial,
-                                                                     Mult mult, Add add, int op_select, T init) {
+                                                                     Mult mult, Add add, int op_select, T init,
+                                                                     const uint* __restrict__ gate, uint n_cols, int force,
+                                                                     const uint* __restrict__ vbits, const uint* __restrict__ vranked) {
         using C = SellCfg;
-        __shared__ T s_hot[C::kHot];
+        __shared__ T    s_hot[BITS ? C::kBitWords : C::kHot];
+        __shared__ uint s_next;// next of this workgroup's slices nobody has taken yet (ordinal)
 
-        const bool always = op_select == SPLAHIP_ALWAYS;
+        const bool always   = op_select == SPLAHIP_ALWAYS;
+        if (threadIdx.x == 0) s_next = C::kWaves;// wave w starts with ordinal w
+        bool       is_const = false;
+        uint       cbits    = 0;
+        if (gate != nullptr) {
+            if constexpr (BITS) {// the first launch of a call: decides, and leaves the decision for the launches behind it
+                const bool bits_form = sell_bits_form(gate, n_cols, force, is_const, cbits);
+                if (blockIdx.x == 0 && threadIdx.x == 0) {
+                    const_cast<uint*>(gate)[C::kDecision]     = bits_form ? 1u : 0u;
+                    const_cast<uint*>(gate)[C::kDecision + 1] = is_const ? 1u : 0u;
+                    const_cast<uint*>(gate)[C::kDecision + 2] = cbits;
+                }
+                if (!bits_form) return;
+            } else {
+                if (gate[C::kDecision] != 0u) return;
+            }
+        }
+        const T cval = from_bits<T>(cbits);
+        if constexpr (BITS) hot_values = reinterpret_cast<const T*>(vbits);// the first kHot words of the bitmap go to LDS
 
         // 0. hot values -> LDS, 16 bytes per lane (the table is allocated in whole quads)
         {
@@ -72,6 +186,9 @@ namespace splahip {
             uint4*       dst = reinterpret_cast<uint4*>(s_hot);
             const uint   nq  = (n_hot + 3u) / 4u;
             for (uint q = threadIdx.x; q < nq; q += C::kTpb) dst[q] = src[q];
+        }
+        if constexpr (BITS) {// the reserved "never set" bit (the same thread copied that word)
+            if (threadIdx.x == ((C::kBitWords - 1) / 4) % C::kTpb) s_hot[C::kBitWords - 1] = from_bits<T>(to_bits(s_hot[C::kBitWords - 1]) & 0x7FFFFFFFu);
         }
 
         // 1. rows that no slice lane will write: empty rows and unselected rows.  Four consecutive rows per lane and step: the
@@ -102,15 +219,14 @@ namespace splahip {
 #endif
         __syncthreads();
 
-        // 2. slices.  They are sorted by width, so dealing them out boustrophedon (round k ascending, round k + 1 descending over the
-        //    launch's waves) gives every wave nearly the same number of entries.
-        const uint lane   = lane_id();
-        const uint w      = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-        const uint stride = gridDim.x * C::kWaves;
-        const uint gw     = blockIdx.x * C::kWaves + w;
-        if (gw >= n_slices) return;
-        uint round = 0;
-        uint s     = gw;
+        // 2. slices.  Workgroup b owns slices b, b + grid, b + 2 grid, ... (sorted by width, so every workgroup holds the same mix);
+        //    its 16 waves take them widest first from an LDS counter.  A static deal cannot balance: which slices are skipped
+        //    depends on the mask (a BFS step skips the widest ones, the visited hubs), and a lane walks its chunk sequentially, so
+        //    the wave that starts a 256-wide slice last sets the launch time.
+        const uint lane = lane_id();
+        const uint w    = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+        uint       s    = blockIdx.x + w * gridDim.x;
+        if (s >= n_slices) return;
 
         uint row_n  = vrow[s * kWave + lane];
         uint len_n  = vlen[s * kWave + lane];
@@ -120,8 +236,9 @@ namespace splahip {
             uint       mylen   = len_n;
             const uint base    = __builtin_amdgcn_readfirstlane(base_n);
             const uint s_cur   = s;
-            ++round;
-            s               = round * stride + ((round & 1u) ? stride - 1u - gw : gw);
+            uint       ord     = 0;
+            if (lane == 0) ord = atomicAdd(&s_next, 1u);
+            s               = blockIdx.x + __builtin_amdgcn_readfirstlane(ord) * gridDim.x;
             const bool more = s < n_slices;
             if (more) {// header of this wave's next slice: lands while the current one is processed
                 row_n  = vrow[s * kWave + lane];
@@ -155,6 +272,10 @@ namespace splahip {
                 const uint width = __builtin_amdgcn_readlane(mylen, __ffsll((long long) live) - 1);
                 T          acc   = init;
                 bool       has   = !chunk;// a row's only chunk folds from init; chunks of a long row fold from their first product
+                if constexpr (BITS) {// a chunk may hold no product at all: its partial is then op_add's identity (0 for every BITS semiring)
+                    if (chunk) acc = T(0);
+                    has = true;
+                }
                 for (uint e = 0; e < width; e += C::kU) {
                     uint jc[C::kU], xc[C::kU];
 #pragma unroll
@@ -172,10 +293,23 @@ namespace splahip {
                             xn[u] = sell_stream_load(px + u * kWave);
                         }
                     }
-                    T vv[C::kU];
+                    T    vv[C::kU];
+                    bool on[C::kU];
 #pragma unroll
                     for (uint u = 0; u < C::kU; ++u) {
                         const bool take = e + u < mylen;
+                        on[u]           = take;
+                        if constexpr (BITS) {
+                            const uint rank = jc[u];
+#if SPLAHIP_SELL_EXP == 10
+                            const uint a = 0xFFFFFFFFu;
+#else
+                            const uint a = to_bits(s_hot[rank >> 5]);
+#endif
+                            on[u] = take && ((a >> (rank & 31u)) & 1u) != 0;
+                            vv[u] = cval;
+                            continue;
+                        }
                         const bool hot  = (jc[u] & C::kHotFlag) != 0;
 #if SPLAHIP_SELL_EXP == 1 /* diagnostic: no gather at all */
                         vv[u] = from_bits<T>(jc[u] | (hot ? 1u : 0u) | (take ? 2u : 0u));
@@ -194,22 +328,61 @@ namespace splahip {
                         vv[u] = hot ? a : b;
 #endif
                     }
+                    if constexpr (BITS) {
+                        if (!is_const) {// set bits fetch their value from the rank-ordered copy of v (all of the group's gathers in flight together)
+#pragma unroll
+                            for (uint u = 0; u < C::kU; ++u)
+                                if (on[u]) vv[u] = from_bits<T>(vranked[jc[u]]);
+                        }
+                    }
 #pragma unroll
                     for (uint u = 0; u < C::kU; ++u) {
-                        const bool take = e + u < mylen;
+                        const bool take = on[u];
                         const T    p    = mult(from_bits<T>(xc[u]), vv[u]);
                         const T    both = add(acc, p);
                         acc             = take ? (has ? both : p) : acc;
                         has             = has || take;
                     }
                 }
+#if SPLAHIP_SELL_EXP == 11
+                if (selected && to_bits(acc) == 0x12345u) r[row] = acc;
+#else
                 if (selected) {
                     if (chunk) partial[vslot[s_cur * kWave + lane]] = acc;
                     else
                         r[row] = acc;
                 }
+#endif
             }
             if (!more) break;
+        }
+    }
+
+    // BITS form, entries of columns beyond the LDS-resident ranks (ascending rank: the bitmap reads are sequential): a set bit on a
+    // selected row folds its product into r[row] with the integer atomic of op_add.  Runs after the main kernel and sell_combine.
+    template<typename T, class Mult>
+    __global__ __launch_bounds__(256) void sell_cold_kernel(uint n_cold, const uint* __restrict__ cold_rank, const unsigned long long* __restrict__ cold_entry,
+                                                            const uint* __restrict__ stats, uint n_cols, int force, const uint* __restrict__ vbits,
+                                                            const uint* __restrict__ vranked, const T* __restrict__ mask, T* __restrict__ r, Mult mult,
+                                                            int op_add, int op_select) {
+        if (stats[SellCfg::kDecision] == 0u) return;
+        const bool is_const = stats[SellCfg::kDecision + 1] != 0u;
+        const uint cbits    = stats[SellCfg::kDecision + 2];
+        const uint k        = blockIdx.x * 256 + threadIdx.x;
+        if (k >= n_cold) return;
+        const uint rank = cold_rank[k];
+        if (((vbits[rank >> 5] >> (rank & 31u)) & 1u) == 0) return;
+        const unsigned long long e = cold_entry[k];
+        const uint row = (uint) (e >> 32);
+        if (!eval_sel(op_select, mask[row])) return;
+        const T    x = from_bits<T>(is_const ? cbits : vranked[rank]);
+        const uint p = to_bits(mult(from_bits<T>((uint) e), x));
+        uint*      d = reinterpret_cast<uint*>(r + row);
+        switch (op_add) {
+            case SPLAHIP_BOR: atomicOr(d, p); break;
+            case SPLAHIP_BXOR: atomicXor(d, p); break;
+            case SPLAHIP_MAX: atomicMax(d, p); break;// uint only (zero_skippable)
+            default: atomicAdd(d, p); break;         // PLUS: two's complement, same bits for int and uint
         }
     }
 

@@ -23,6 +23,16 @@ struct splahip_sell_s {
     uint32_t* d_lr_row   = nullptr;// n_lrows
     uint32_t* d_lr_first = nullptr;// n_lrows + 1
     uint32_t* d_partial  = nullptr;// n_partials
+    // "sparse input vector" form (int / uint semirings whose mult has 0 as annihilator and whose add has 0 as identity):
+    uint32_t* d_rank_of  = nullptr;// n_cols: position of a column in the descending reference-count order (slot s < n_hot == rank s)
+    uint32_t* d_Aj2r     = nullptr;// the entries' columns as ranks, same layout as d_Aj2
+    uint32_t* d_vbits    = nullptr;// per launch: bit `rank` = v[column] != 0; followed by sell_vprep's per-workgroup statistics
+    uint32_t* d_vranked  = nullptr;// per launch: v in rank order (written for the non-zero entries only)
+    uint32_t  n_bit_words = 0;     // words of d_vbits before the statistics
+    // entries whose column rank is beyond the LDS-resident bits: out of d_Aj2r (coded as a never-set bit), listed here by ascending rank
+    uint32_t  n_cold       = 0;
+    uint32_t* d_cold_rank  = nullptr;// n_cold
+    uint64_t* d_cold_entry = nullptr;// n_cold: row << 32 | value bits
 };
 
 struct splahip_plan_s {
@@ -42,6 +52,7 @@ struct splahip_plan_s {
 
 namespace splahip {
     void sell_release(splahip_sell_s* sell);
+    bool sell_zero_skippable(int type, int op_mult, int op_add);// may the sparse-vector (BITS) form serve this semiring
     // the sliced-ELL masked SpMV (associative op_add, no early exit); returns a SPLAHIP status
     int sell_mxv(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
                  uint32_t init_bits, void* stream);

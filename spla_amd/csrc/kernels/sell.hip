@@ -7,6 +7,7 @@
 #include "ops.hpp"
 #include "plan.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -95,18 +96,20 @@ namespace {
             col[j] = j;
         }
     }
-    __global__ __launch_bounds__(256) void sell_slot_kernel(const uint* __restrict__ sorted_col, uint n_hot, uint* __restrict__ slot_of, uint* __restrict__ hot_cols) {
+    // rank_of[column] = position in the descending reference-count order; the first n_hot ranks are the LDS value slots
+    __global__ __launch_bounds__(256) void sell_rank_kernel(const uint* __restrict__ sorted_col, uint n_cols, uint n_hot, uint* __restrict__ rank_of,
+                                                            uint* __restrict__ hot_cols) {
         const uint s = blockIdx.x * 256 + threadIdx.x;
-        if (s < n_hot) {
-            hot_cols[s]            = sorted_col[s];
-            slot_of[sorted_col[s]] = s;
+        if (s < n_cols) {
+            rank_of[sorted_col[s]] = s;
+            if (s < n_hot) hot_cols[s] = sorted_col[s];
         }
     }
     // one wave per slice: lane l copies chunk l into the slice's column-major block, re-encoding hot columns; the rest of the
     // lane's column is padding that reads slot 0 of the hot table and multiplies by a zero word (never folded)
     __global__ __launch_bounds__(256) void sell_fill_kernel(uint n_slices, const uint* __restrict__ off, const uint* __restrict__ vlen, const uint* __restrict__ vk0,
-                                                            const uint* __restrict__ Aj, const uint* __restrict__ Ax, const uint* __restrict__ slot_of,
-                                                            uint* __restrict__ Aj2, uint* __restrict__ Ax2) {
+                                                            const uint* __restrict__ Aj, const uint* __restrict__ Ax, const uint* __restrict__ rank_of, uint n_hot,
+                                                            uint* __restrict__ Aj2, uint* __restrict__ Aj2r, uint* __restrict__ Ax2) {
         const uint s = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
         if (s >= n_slices) return;
         const uint lane  = lane_id();
@@ -115,23 +118,48 @@ namespace {
         const uint len   = vlen[s * kWave + lane];
         const uint k0    = vk0[s * kWave + lane];
         for (uint e = 0; e < width; ++e) {
-            uint j = SC::kHotFlag, x = 0;
+            uint j = SC::kHotFlag, rank = SC::kBitsLds, x = 0;
             if (e < len) {
-                const uint col  = Aj[k0 + e];
-                const uint slot = slot_of[col];
-                j               = slot != 0xFFFFFFFFu ? (slot | SC::kHotFlag) : col;
-                x               = Ax[k0 + e];
+                const uint col = Aj[k0 + e];
+                rank           = rank_of[col];
+                j              = rank < n_hot ? (rank | SC::kHotFlag) : col;
+                x              = Ax[k0 + e];
             }
-            Aj2[base + e * kWave + lane] = j;
-            Ax2[base + e * kWave + lane] = x;
+            Aj2[base + e * kWave + lane]  = j;
+            Aj2r[base + e * kWave + lane] = min(rank, SC::kBitsLds);// colder columns: the never-set bit (their entries are in the cold list)
+            Ax2[base + e * kWave + lane]  = x;
         }
     }
-    __global__ __launch_bounds__(256) void sell_tail_kernel(uint first, uint count, uint* __restrict__ Aj2, uint* __restrict__ Ax2) {
+    __global__ __launch_bounds__(256) void sell_tail_kernel(uint first, uint count, uint* __restrict__ Aj2, uint* __restrict__ Aj2r, uint* __restrict__ Ax2) {
         const uint k = blockIdx.x * 256 + threadIdx.x;
         if (k < count) {
-            Aj2[first + k] = SC::kHotFlag;
-            Ax2[first + k] = 0;
+            Aj2[first + k]  = SC::kHotFlag;
+            Aj2r[first + k] = SC::kBitsLds;
+            Ax2[first + k]  = 0;
         }
+    }
+
+    // cold list: entries whose column rank has no LDS-resident bit
+    __global__ __launch_bounds__(256) void sell_cold_flag_kernel(const uint* __restrict__ Aj, uint nnz, const uint* __restrict__ rank_of, uint* __restrict__ flag) {
+        const uint k = blockIdx.x * 256 + threadIdx.x;
+        if (k <= nnz) flag[k] = (k < nnz && rank_of[Aj[k]] >= SC::kBitsLds) ? 1u : 0u;
+    }
+    __global__ __launch_bounds__(256) void sell_cold_emit_kernel(const uint* __restrict__ Ap, uint n_rows, const uint* __restrict__ Aj, const uint* __restrict__ Ax,
+                                                                 uint nnz, const uint* __restrict__ rank_of, const uint* __restrict__ pos,
+                                                                 uint* __restrict__ cold_rank, unsigned long long* __restrict__ cold_entry) {
+        const uint k = blockIdx.x * 256 + threadIdx.x;
+        if (k >= nnz) return;
+        const uint rank = rank_of[Aj[k]];
+        if (rank < SC::kBitsLds) return;
+        uint lo = 0, hi = n_rows;// last row with Ap[row] <= k
+        while (hi - lo > 1) {
+            const uint mid = lo + ((hi - lo) >> 1);
+            if (Ap[mid] <= k) lo = mid;
+            else
+                hi = mid;
+        }
+        cold_rank[pos[k]]  = rank;
+        cold_entry[pos[k]] = ((unsigned long long) lo << 32) | Ax[k];
     }
 
     constexpr uint kTail = 2 * SC::kU * kWave;// read-ahead of the last slice's group prefetch
@@ -187,23 +215,49 @@ namespace {
         return cus;
     }
 
+    // 0 annihilates op_mult and is op_add's identity: an entry whose v value is 0 cannot change the fold (mxv_sell.hpp, BITS form)
+    bool zero_skippable(int type, int op_mult, int op_add) { return sell_zero_skippable(type, op_mult, op_add); }
+    int bits_force() {// SPLAHIP_SELL_BITS: 0 = never, 1 / unset = the device statistics decide, 2 = always (where the semiring allows it)
+        const char* e = std::getenv("SPLAHIP_SELL_BITS");
+        return e ? std::atoi(e) : 1;
+    }
+
     template<typename T, class Mult, class Add>
     int launch_sell(const splahip_plan_s* plan, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
                     uint32_t init_bits, hipStream_t st) {
-        const splahip_sell_s* g = plan->sell;
-        if (g->n_hot)
+        const splahip_sell_s* g    = plan->sell;
+        const uint            grid = compute_units();
+        const int             mode = bits_force();
+        const bool            bits = mode != 0 && zero_skippable(TypeId<T>::value, op_mult, op_add);
+        uint*                 stats = g->d_vbits + g->n_bit_words;
+        if (bits) {
+            SPLAHIP_TRY(hipMemsetAsync(g->d_vbits, 0, sizeof(uint32_t) * (size_t) g->n_bit_words, st));
+            hipLaunchKernelGGL((sell_vprep_kernel<T>), dim3(SC::kPrepBlocks), dim3(256), 0, st, g->n_cols, static_cast<const T*>(v), g->d_rank_of, g->n_hot,
+                               reinterpret_cast<T*>(g->d_hot_vals), g->d_vbits, g->d_vranked, stats);
+            hipLaunchKernelGGL((sell_mxv_kernel<T, Mult, Add, true>), dim3(grid), dim3(SC::kTpb), 0, st, plan->n_rows, Ap, g->n_slices, g->d_vrow, g->d_vlen,
+                               g->d_vslot, g->d_off, g->d_Aj2r, g->d_Ax2, reinterpret_cast<const T*>(g->d_hot_vals), SC::kBitWords, static_cast<const T*>(mask),
+                               static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(g->d_partial), Mult(op_mult), Add(op_add), op_select,
+                               from_bits<T>(init_bits), stats, g->n_cols, mode == 2 ? 1 : 0, g->d_vbits, g->d_vranked);
+        } else {
             hipLaunchKernelGGL((sell_hot_pack_kernel<T>), dim3((g->n_hot + 255) / 256), dim3(256), 0, st, g->d_hot_cols, g->n_hot, static_cast<const T*>(v),
                                reinterpret_cast<T*>(g->d_hot_vals));
-        const uint grid = compute_units();
-        hipLaunchKernelGGL((sell_mxv_kernel<T, Mult, Add>), dim3(grid), dim3(SC::kTpb), 0, st, plan->n_rows, Ap, g->n_slices, g->d_vrow, g->d_vlen, g->d_vslot,
-                           g->d_off, g->d_Aj2, g->d_Ax2, reinterpret_cast<const T*>(g->d_hot_vals), g->n_hot, static_cast<const T*>(mask),
-                           static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(g->d_partial), Mult(op_mult), Add(op_add), op_select,
-                           from_bits<T>(init_bits));
+        }
+        if (!(bits && mode == 2))
+            hipLaunchKernelGGL((sell_mxv_kernel<T, Mult, Add, false>), dim3(grid), dim3(SC::kTpb), 0, st, plan->n_rows, Ap, g->n_slices, g->d_vrow, g->d_vlen,
+                               g->d_vslot, g->d_off, g->d_Aj2, g->d_Ax2, reinterpret_cast<const T*>(g->d_hot_vals), g->n_hot, static_cast<const T*>(mask),
+                               static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(g->d_partial), Mult(op_mult), Add(op_add), op_select,
+                               from_bits<T>(init_bits), bits ? stats : nullptr, g->n_cols, 0, nullptr, nullptr);
         SPLAHIP_TRY(hipGetLastError());
         if (g->n_lrows) {
             hipLaunchKernelGGL((sell_combine_kernel<T, Add>), dim3((g->n_lrows + 3) / 4), dim3(256), 0, st, g->n_lrows, g->d_lr_row, g->d_lr_first,
                                reinterpret_cast<const T*>(g->d_partial), static_cast<const T*>(mask), static_cast<T*>(r), Add(op_add), op_select,
                                from_bits<T>(init_bits));
+            SPLAHIP_TRY(hipGetLastError());
+        }
+        if (bits && g->n_cold) {
+            hipLaunchKernelGGL((sell_cold_kernel<T, Mult>), dim3((g->n_cold + 255) / 256), dim3(256), 0, st, g->n_cold, g->d_cold_rank,
+                               reinterpret_cast<const unsigned long long*>(g->d_cold_entry), stats, g->n_cols, mode == 2 ? 1 : 0, g->d_vbits, g->d_vranked,
+                               static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), op_add, op_select);
             SPLAHIP_TRY(hipGetLastError());
         }
         return SPLAHIP_OK;
@@ -228,10 +282,19 @@ namespace {
 
 namespace splahip {
 
+    bool sell_zero_skippable(int type, int op_mult, int op_add) {
+        if (type == SPLAHIP_FLOAT) return false;// 0 * inf, -0 + 0: not bit-safe
+        if (op_mult != SPLAHIP_BAND && op_mult != SPLAHIP_MULT && op_mult != SPLAHIP_LAND) return false;
+        if (op_add == SPLAHIP_BOR || op_add == SPLAHIP_PLUS || op_add == SPLAHIP_BXOR) return true;
+        return type == SPLAHIP_UINT && op_add == SPLAHIP_MAX;
+    }
+
     void sell_release(splahip_sell_s* g) {
         if (!g) return;
-        for (uint32_t* p : {g->d_vrow, g->d_vlen, g->d_vslot, g->d_off, g->d_Aj2, g->d_Ax2, g->d_hot_cols, g->d_hot_vals, g->d_lr_row, g->d_lr_first, g->d_partial})
+        for (uint32_t* p : {g->d_vrow, g->d_vlen, g->d_vslot, g->d_off, g->d_Aj2, g->d_Ax2, g->d_hot_cols, g->d_hot_vals, g->d_lr_row, g->d_lr_first, g->d_partial,
+                            g->d_rank_of, g->d_Aj2r, g->d_vbits, g->d_vranked, g->d_cold_rank})
             if (p) (void) hipFree(p);
+        if (g->d_cold_entry) (void) hipFree(g->d_cold_entry);
         delete g;
     }
 
@@ -331,29 +394,67 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     if (e == hipSuccess) e = hipMemcpy(&g->n_slots, g->d_off + g->n_slices, 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return bail("slice scan");
     own(&g->d_Aj2, (size_t) g->n_slots + kTail);
+    own(&g->d_Aj2r, (size_t) g->n_slots + kTail);
     own(&g->d_Ax2, (size_t) g->n_slots + kTail);
 
     // 4. hot columns: the n_hot most referenced ones (stable: ties keep ascending column order)
     g->n_hot = n_cols < SC::kHot ? n_cols : SC::kHot;
-    uint32_t *count, *ckey, *ccol, *ckey_s, *ccol_s, *slot_of;
-    for (uint32_t** q : {&count, &ckey, &ccol, &ckey_s, &ccol_s, &slot_of})
+    uint32_t *count, *ckey, *ccol, *ckey_s, *ccol_s;
+    for (uint32_t** q : {&count, &ckey, &ccol, &ckey_s, &ccol_s})
         if (e == hipSuccess) e = tmp.alloc(q, n_cols);
     own(&g->d_hot_cols, g->n_hot);
     own(&g->d_hot_vals, (size_t) g->n_hot + 4);// whole 16-byte quads: the kernel copies the table with uint4 loads
+    own(&g->d_rank_of, n_cols);
+    own(&g->d_vranked, n_cols);
+    // bitmap of v in rank order: at least the kHot words every workgroup copies to LDS, then the statistics (4 words per sell_vprep workgroup)
+    g->n_bit_words = ((std::max<uint32_t>((n_cols + 31) / 32, SC::kHot) + 3u) & ~3u);
+    own(&g->d_vbits, (size_t) g->n_bit_words + 4 * SC::kPrepBlocks + 4);
     if (e == hipSuccess) e = hipMemsetAsync(count, 0, sizeof(uint32_t) * (size_t) n_cols, s);
-    if (e == hipSuccess) e = hipMemsetAsync(slot_of, 0xFF, sizeof(uint32_t) * (size_t) n_cols, s);
     if (e != hipSuccess) return bail("hot-column arrays");
     hipLaunchKernelGGL(sell_col_count_kernel, dim3((nnz + 255) / 256), dim3(256), 0, s, d_Aj, nnz, count);
     hipLaunchKernelGGL(sell_col_key_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, s, count, n_cols, ckey, ccol);
     e = hipGetLastError();
     if (e == hipSuccess) e = stable_sort_pairs(ckey, ckey_s, ccol, ccol_s, n_cols, 32, s);
     if (e != hipSuccess) return bail("hot-column sort");
-    hipLaunchKernelGGL(sell_slot_kernel, dim3((g->n_hot + 255) / 256), dim3(256), 0, s, ccol_s, g->n_hot, slot_of, g->d_hot_cols);
+    hipLaunchKernelGGL(sell_rank_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, s, ccol_s, n_cols, g->n_hot, g->d_rank_of, g->d_hot_cols);
+
+    // 4b. cold list of the sparse-vector form: entries of columns ranked beyond the LDS-resident bits, sorted by rank
+    if (n_cols > SC::kBitsLds) {
+        uint32_t *flag, *pos;
+        if (e == hipSuccess) e = tmp.alloc(&flag, (size_t) nnz + 1);
+        if (e == hipSuccess) e = tmp.alloc(&pos, (size_t) nnz + 1);
+        if (e != hipSuccess) return bail("cold-list scratch");
+        hipLaunchKernelGGL(sell_cold_flag_kernel, dim3((nnz + 256) / 256), dim3(256), 0, s, d_Aj, nnz, g->d_rank_of, flag);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = exclusive_scan_u32(flag, pos, (size_t) nnz + 1, s);
+        if (e == hipSuccess) e = hipMemcpy(&g->n_cold, pos + nnz, 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return bail("cold-list scan");
+        if (g->n_cold) {
+            uint32_t*           rank_u = nullptr;
+            unsigned long long *entry_u = nullptr, *entry_s = nullptr;
+            if (e == hipSuccess) e = tmp.alloc(&rank_u, g->n_cold);
+            if (e == hipSuccess) e = tmp.alloc(reinterpret_cast<uint32_t**>(&entry_u), 2 * (size_t) g->n_cold);
+            own(&g->d_cold_rank, g->n_cold);
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&entry_s), sizeof(unsigned long long) * g->n_cold);
+            g->d_cold_entry = reinterpret_cast<uint64_t*>(entry_s);
+            if (e != hipSuccess) return bail("cold-list arrays");
+            hipLaunchKernelGGL(sell_cold_emit_kernel, dim3((nnz + 255) / 256), dim3(256), 0, s, d_Ap, n_rows, d_Aj, static_cast<const uint32_t*>(d_Ax), nnz,
+                               g->d_rank_of, pos, rank_u, entry_u);
+            size_t bytes = 0;
+            e            = rocprim::radix_sort_pairs(nullptr, bytes, rank_u, g->d_cold_rank, entry_u, entry_s, g->n_cold, 0, 32, s);
+            void* st_tmp = nullptr;
+            if (e == hipSuccess) e = hipMalloc(&st_tmp, bytes ? bytes : 4);
+            if (e == hipSuccess) e = rocprim::radix_sort_pairs(st_tmp, bytes, rank_u, g->d_cold_rank, entry_u, entry_s, g->n_cold, 0, 32, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (st_tmp) (void) hipFree(st_tmp);
+            if (e != hipSuccess) return bail("cold-list sort");
+        }
+    }
 
     // 5. the entries
     hipLaunchKernelGGL(sell_fill_kernel, dim3((g->n_slices + 3) / 4), dim3(256), 0, s, g->n_slices, g->d_off, g->d_vlen, vk0, d_Aj,
-                       static_cast<const uint32_t*>(d_Ax), slot_of, g->d_Aj2, g->d_Ax2);
-    hipLaunchKernelGGL(sell_tail_kernel, dim3((kTail + 255) / 256), dim3(256), 0, s, g->n_slots, kTail, g->d_Aj2, g->d_Ax2);
+                       static_cast<const uint32_t*>(d_Ax), g->d_rank_of, g->n_hot, g->d_Aj2, g->d_Aj2r, g->d_Ax2);
+    hipLaunchKernelGGL(sell_tail_kernel, dim3((kTail + 255) / 256), dim3(256), 0, s, g->n_slots, kTail, g->d_Aj2, g->d_Aj2r, g->d_Ax2);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return bail("fill");

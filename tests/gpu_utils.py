@@ -26,9 +26,13 @@ def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, 
     every row <= 256 entries strictly in entry order, the CSR form uses an in-order tree for rows > 32).  Returns the CSR result."""
     from helpers import NP
     dAp, dAj, dAx, dm, dv = dev(Ap), dev(Aj), dev(np.asarray(Ax, NP[t])), dev(np.asarray(mask, NP[t])), dev(np.asarray(v, NP[t]))
+    import os
     outs = {}
-    for form in ("csr", "sell"):
-        plan = kernels.CsrPlan(n_rows, len(Aj), dAp, n_cols, dAj, dAx) if form == "sell" else kernels.CsrPlan(n_rows, len(Aj), dAp)
+    # sell-bits: the sparse-input-vector form forced on wherever the semiring allows it (SPLAHIP_SELL_BITS=2); plain "sell" lets the
+    # device statistics choose
+    for form in ("csr", "sell", "sell-bits"):
+        os.environ["SPLAHIP_SELL_BITS"] = "2" if form == "sell-bits" else "1"
+        plan = kernels.CsrPlan(n_rows, len(Aj), dAp, n_cols, dAj, dAx) if form != "csr" else kernels.CsrPlan(n_rows, len(Aj), dAp)
         r = torch.empty(n_rows, dtype=kernels.torch_dtype(t), device="cuda")
         if junk is not None:
             r.fill_(junk)
@@ -36,6 +40,8 @@ def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, 
         torch.cuda.synchronize()
         outs[form] = host(r, NP[t])
         plan.close()
+    os.environ["SPLAHIP_SELL_BITS"] = "1"
+    assert np.array_equal(outs["sell-bits"].view(np.uint32), outs["sell"].view(np.uint32)), "sliced-ELL sparse-vector form differs from the value form"
     if t == "FLOAT":
         a, b = outs["sell"].astype(np.float64), outs["csr"].astype(np.float64)
         assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isinf(a), np.isinf(b)), "sliced-ELL kernel differs from the CSR kernels"

@@ -181,3 +181,64 @@ def test_more_columns_than_lds_slots(oracle, t):
         want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
         got = hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
         assert_same(got, want, t, what=f"{t} {mul}/{add}/{sel}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", ["INT", "UINT"])
+def test_sparse_input_vector_form(oracle, t):
+    """The BITS form of the sliced-ELL kernel (one LDS bit per column instead of a value; semirings where 0 annihilates op_mult and is
+    op_add's identity): constant / varying / empty / dense input vectors, non-zero init, chunked long rows whose chunks may hold no
+    product, every select op class.  hip_mxv runs the CSR kernels, the auto-choosing sliced-ELL call and the forced BITS form."""
+    from gpu_utils import hip_mxv
+    rng = np.random.default_rng(101)
+    n_rows, n_cols = 5000, 90000
+    degs = rng.integers(0, 30, n_rows)
+    degs[rng.integers(0, n_rows, 25)] = rng.integers(257, 1500, 25)
+    degs[::9] = 0
+    Ap = np.zeros(n_rows + 1, np.uint32)
+    np.cumsum(degs, out=Ap[1:])
+    pop = rng.pareto(1.1, n_cols) + 1e-3
+    pop /= pop.sum()
+    Aj = np.concatenate([np.sort(rng.choice(n_cols, size=d, replace=False, p=pop)) for d in degs if d]).astype(np.uint32)
+    Ax = random_values(rng, len(Aj), t)
+    Ax[Ax == 0] = 1
+    vectors = {
+        "frontier (3 % ones)": (rng.random(n_cols) < 0.03).astype(NP[t]),
+        "sparse, varying": np.where(rng.random(n_cols) < 0.05, random_values(rng, n_cols, t), 0).astype(NP[t]),
+        "all zero": np.zeros(n_cols, NP[t]),
+        "dense constant": np.full(n_cols, 3, NP[t]),
+        "dense varying": random_values(rng, n_cols, t, zeros=0.1),
+        "one entry": np.eye(1, n_cols, 77, dtype=NP[t])[0] * 5,
+    }
+    cells = [("BAND", "BOR", "EQZERO", 0), ("MULT", "PLUS", "ALWAYS", 5), ("LAND", "BXOR", "NQZERO", 9), ("MULT", "BOR", "GTZERO", 0)]
+    if t == "UINT":
+        cells.append(("BAND", "MAX", "ALWAYS", 2))
+    for name, v in vectors.items():
+        for mul, add, sel, init in cells:
+            mask = random_mask(rng, n_rows, t)
+            want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
+            got = hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init, junk=123)
+            assert_same(got, want, t, what=f"{t} {name} {mul}/{add}/{sel}")
+
+
+@pytest.mark.gpu
+def test_sparse_input_vector_cold_ranks(oracle):
+    """more referenced columns than the 1.28 M LDS-resident bits: the coldest ranks read the global bitmap"""
+    from gpu_utils import hip_mxv
+    rng = np.random.default_rng(102)
+    n_rows, n_cols = 30000, 1_600_000
+    per = 50
+    cols = rng.permutation(n_cols)[:n_rows * per].reshape(n_rows, per)  # 1.5 M distinct columns, each referenced once
+    cols.sort(axis=1)
+    hub = rng.integers(0, 2000, (n_rows, 6))                            # plus a hot set so that the ranking is not degenerate
+    rows = [np.unique(np.concatenate([cols[i], hub[i]])) for i in range(n_rows)]
+    Ap = np.zeros(n_rows + 1, np.uint32)
+    np.cumsum([len(x) for x in rows], out=Ap[1:])
+    Aj = np.concatenate(rows).astype(np.uint32)
+    Ax = np.ones(len(Aj), np.int32)
+    v = (rng.random(n_cols) < 0.2).astype(np.int32)
+    mask = random_mask(rng, n_rows, "INT")
+    for mul, add, sel, init in [("BAND", "BOR", "EQZERO", 0), ("MULT", "PLUS", "ALWAYS", 1)]:
+        want = oracle.mxv_masked("INT", n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
+        got = hip_mxv("INT", n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
+        assert_same(got, want, "INT", what=f"cold ranks {mul}/{add}")
