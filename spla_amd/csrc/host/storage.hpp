@@ -140,13 +140,15 @@ namespace spla {
     template<typename T>
     struct HipCsr final : Decoration<T> {
         DeviceBuffer Ap, Aj, Ax;
-        splahip_plan plan = nullptr;
+        splahip_plan plan      = nullptr;
+        unsigned     mxv_calls = 0;// mxv calls without early exit served by this plan (algos_hip.cpp: when the sliced-ELL copy gets built)
         ~HipCsr() override {
             if (plan) splahip_csr_plan_destroy(plan);
         }
         void drop_plan() {
             if (plan) splahip_csr_plan_destroy(plan);
-            plan         = nullptr;
+            plan      = nullptr;
+            mxv_calls = 0;
         }
     };
 

@@ -64,7 +64,7 @@ namespace splahip {
         static constexpr uint kBitWords = kHot;
         static constexpr uint kBitsLds  = kBitWords * 32 - 1;
         // statistics behind the bitmap, 4 words per sell_vprep workgroup: count of non-zero v entries, max of ~bits (= ~min), max of bits
-        static constexpr uint kPrepBlocks = 1024;
+        static constexpr uint kPrepBlocks = 4096;
         static constexpr uint kStatCount = 0, kStatNotMin = 1, kStatMax = 2;
         static constexpr uint kDecision = 4 * kPrepBlocks;// behind the slots: form (1 = BITS), is_const, const bits — written by the BITS launch
     };
@@ -92,8 +92,15 @@ namespace splahip {
     template<typename T>
     __global__ __launch_bounds__(256) void sell_vprep_kernel(uint n_cols, const T* __restrict__ v, const uint* __restrict__ rank_of, uint n_hot,
                                                              T* __restrict__ hot_values, uint* __restrict__ vbits, uint* __restrict__ vranked,
-                                                             uint* __restrict__ stats) {
+                                                             uint* __restrict__ stats, uint n_rows, const T* __restrict__ mask, int op_select,
+                                                             unsigned long long* __restrict__ selbits) {
         __shared__ uint s_red[3][256 / kWave];
+        // row selection as one bit per row (64 rows per wave and step, one 8-byte store)
+        for (uint row = blockIdx.x * 256 + threadIdx.x; row < ((n_rows + kWave - 1) & ~(kWave - 1)); row += gridDim.x * 256) {
+            const bool               sel = row < n_rows && eval_sel(op_select, mask[row]);
+            const unsigned long long b   = __ballot(sel);
+            if (lane_id() == 0) selbits[row / kWave] = b;
+        }
         uint            count = 0, notmin = 0, mx = 0;
         auto            one   = [&](uint rank, uint b) {
             if (rank < n_hot) hot_values[rank] = from_bits<T>(b);
@@ -155,10 +162,12 @@ namespace splahip {
                                                                      T* __restrict__ r, T* __restrict__ partial,
                                                                      Mult mult, Add add, int op_select, T init,
                                                                      const uint* __restrict__ gate, uint n_cols, int force,
-                                                                     const uint* __restrict__ vbits, const uint* __restrict__ vranked) {
+                                                                     const uint* __restrict__ vbits, const uint* __restrict__ vranked,
+                                                                     const uint* __restrict__ selbits) {
         using C = SellCfg;
         __shared__ T    s_hot[BITS ? C::kBitWords : C::kHot];
         __shared__ uint s_next;// next of this workgroup's slices nobody has taken yet (ordinal)
+        __shared__ uint s_dec[3];
 
         const bool always   = op_select == SPLAHIP_ALWAYS;
         if (threadIdx.x == 0) s_next = C::kWaves;// wave w starts with ordinal w
@@ -166,13 +175,24 @@ namespace splahip {
         uint       cbits    = 0;
         if (gate != nullptr) {
             if constexpr (BITS) {// the first launch of a call: decides, and leaves the decision for the launches behind it
-                const bool bits_form = sell_bits_form(gate, n_cols, force, is_const, cbits);
-                if (blockIdx.x == 0 && threadIdx.x == 0) {
-                    const_cast<uint*>(gate)[C::kDecision]     = bits_form ? 1u : 0u;
-                    const_cast<uint*>(gate)[C::kDecision + 1] = is_const ? 1u : 0u;
-                    const_cast<uint*>(gate)[C::kDecision + 2] = cbits;
+                // (one wave per workgroup reads the 12 KB of statistics; all 4096 waves doing so cost 0.5 M L2 requests)
+                if (threadIdx.x < kWave) {
+                    const bool bits_form = sell_bits_form(gate, n_cols, force, is_const, cbits);
+                    if (threadIdx.x == 0) {
+                        s_dec[0] = bits_form ? 1u : 0u;
+                        s_dec[1] = is_const ? 1u : 0u;
+                        s_dec[2] = cbits;
+                        if (blockIdx.x == 0) {
+                            const_cast<uint*>(gate)[C::kDecision]     = s_dec[0];
+                            const_cast<uint*>(gate)[C::kDecision + 1] = s_dec[1];
+                            const_cast<uint*>(gate)[C::kDecision + 2] = s_dec[2];
+                        }
+                    }
                 }
-                if (!bits_form) return;
+                __syncthreads();
+                is_const = s_dec[1] != 0u;
+                cbits    = s_dec[2];
+                if (s_dec[0] == 0u) return;
             } else {
                 if (gate[C::kDecision] != 0u) return;
             }
@@ -223,49 +243,79 @@ namespace splahip {
         //    its 16 waves take them widest first from an LDS counter.  A static deal cannot balance: which slices are skipped
         //    depends on the mask (a BFS step skips the widest ones, the visited hubs), and a lane walks its chunk sequentially, so
         //    the wave that starts a 256-wide slice last sets the launch time.
+        //    The selection of a slice's rows (a bit of sell_vprep's bitmap in the BITS form, else the mask word) is fetched one slice
+        //    ahead and the header two ahead, so a lane knows whether its row is selected BEFORE it asks for entries: the stream
+        //    loads are predicated per lane, and a 128-byte line whose 32 lanes are all unselected (the chunks of a visited hub)
+        //    is never requested.
         const uint lane = lane_id();
         const uint w    = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-        uint       s    = blockIdx.x + w * gridDim.x;
-        if (s >= n_slices) return;
+        uint       sA   = blockIdx.x + w * gridDim.x;
+        if (sA >= n_slices) return;
 
-        uint row_n  = vrow[s * kWave + lane];
-        uint len_n  = vlen[s * kWave + lane];
-        uint base_n = off[s];
-        while (true) {
-            const uint rowinfo = row_n;
-            uint       mylen   = len_n;
-            const uint base    = __builtin_amdgcn_readfirstlane(base_n);
-            const uint s_cur   = s;
-            uint       ord     = 0;
+        auto take_slice = [&]() -> uint {
+            uint ord = 0;
             if (lane == 0) ord = atomicAdd(&s_next, 1u);
-            s               = blockIdx.x + __builtin_amdgcn_readfirstlane(ord) * gridDim.x;
-            const bool more = s < n_slices;
-            if (more) {// header of this wave's next slice: lands while the current one is processed
-                row_n  = vrow[s * kWave + lane];
-                len_n  = vlen[s * kWave + lane];
-                base_n = off[s];
-            }
-            const uint row   = rowinfo & ~C::kPartial;
-            const bool chunk = (rowinfo & C::kPartial) != 0;
-            // width before selection: lane 0 holds the slice's longest chunk
-            const uint width0 = __builtin_amdgcn_readfirstlane(mylen);
+            return blockIdx.x + __builtin_amdgcn_readfirstlane(ord) * gridDim.x;
+        };
+        // the word that decides a lane's selection: nothing for ALWAYS, the row's bit word (BITS) or its mask value
+        auto sel_word = [&](uint rowinfo, uint len) -> uint {
+            if (always || len == 0) return 0u;
+            const uint row = rowinfo & ~C::kPartial;
+            if constexpr (BITS) return selbits[row >> 5];
+            else
+                return to_bits(mask[row]);
+        };
+        auto is_selected = [&](uint word, uint rowinfo, uint len) -> bool {
+            if (len == 0) return false;
+            if (always) return true;
+            if constexpr (BITS) return ((word >> (rowinfo & 31u)) & 1u) != 0;
+            else
+                return eval_sel(op_select, from_bits<T>(word));
+        };
 
-            // first group + the mask value travel together; rows of the group beyond the slice's width are not fetched
+        uint rowA = vrow[sA * kWave + lane], lenA = vlen[sA * kWave + lane], baseA = off[sA];
+        uint sB   = take_slice();
+        bool moreB = sB < n_slices;
+        uint rowB = 0, lenB = 0, baseB = 0;
+        if (moreB) {
+            rowB  = vrow[sB * kWave + lane];
+            lenB  = vlen[sB * kWave + lane];
+            baseB = off[sB];
+        }
+        uint wordA = sel_word(rowA, lenA);
+        while (true) {
+            // C's header and B's selection word travel while A is folded
+            uint sC = n_slices, rowC = 0, lenC = 0, baseC = 0;
+            if (moreB) sC = take_slice();
+            const bool moreC = moreB && sC < n_slices;
+            if (moreC) {
+                rowC  = vrow[sC * kWave + lane];
+                lenC  = vlen[sC * kWave + lane];
+                baseC = off[sC];
+            }
+            uint wordB = 0;
+            if (moreB) wordB = sel_word(rowB, lenB);
+
+            // ---- slice A
+            const uint rowinfo = rowA;
+            const uint base    = __builtin_amdgcn_readfirstlane(baseA);
+            const uint s_cur   = sA;
+            const uint row     = rowinfo & ~C::kPartial;
+            const bool chunk   = (rowinfo & C::kPartial) != 0;
+            const bool selected = is_selected(wordA, rowinfo, lenA);
+            const uint mylen    = selected ? lenA : 0u;
             const uint* pj = Aj2 + base + lane;
             const uint* px = Ax2 + base + lane;
             uint        jn[C::kU], xn[C::kU];
 #pragma unroll
-            for (uint u = 0; u < C::kU; ++u) {
-                jn[u] = C::kHotFlag;
+            for (uint u = 0; u < C::kU; ++u) {// first group: only lanes that will fold the entry ask for it
+                jn[u] = BITS ? C::kBitsLds : C::kHotFlag;// a lane without an entry reads the never-set bit / hot slot 0 and folds nothing
                 xn[u] = 0;
-                if (u < width0) {
+                if (u < mylen) {
                     jn[u] = sell_stream_load(pj + u * kWave);
                     xn[u] = sell_stream_load(px + u * kWave);
                 }
             }
-            bool selected = mylen > 0;
-            if (!always && selected) selected = eval_sel(op_select, mask[row]);
-            if (!selected) mylen = 0;
             const unsigned long long live = __ballot(selected);
             if (live != 0ull) {
                 // chunks are sorted by length: the first selected lane holds the longest selected chunk
@@ -288,7 +338,7 @@ namespace splahip {
                     // prefetch the next group before this group's gathers are issued (uniform conditions)
 #pragma unroll
                     for (uint u = 0; u < C::kU; ++u) {
-                        if (e + C::kU + u < width) {
+                        if (e + C::kU + u < mylen) {
                             jn[u] = sell_stream_load(pj + u * kWave);
                             xn[u] = sell_stream_load(px + u * kWave);
                         }
@@ -354,7 +404,9 @@ namespace splahip {
                 }
 #endif
             }
-            if (!more) break;
+            if (!moreB) break;
+            sA = sB, rowA = rowB, lenA = lenB, baseA = baseB, wordA = wordB;
+            sB = sC, moreB = moreC, rowB = rowC, lenB = lenC, baseB = baseC;
         }
     }
 

@@ -29,6 +29,8 @@ struct splahip_sell_s {
     uint32_t* d_vbits    = nullptr;// per launch: bit `rank` = v[column] != 0; followed by sell_vprep's per-workgroup statistics
     uint32_t* d_vranked  = nullptr;// per launch: v in rank order (written for the non-zero entries only)
     uint32_t  n_bit_words = 0;     // words of d_vbits before the statistics
+    uint32_t* d_selbits   = nullptr;// per launch: bit `row` = op_select(mask[row]) (the slices' rows are length-sorted: a bit is 32x denser than
+                                    // a mask word, and the popular lengths keep ascending row order, so a slice's 64 tests share a few lines)
     // entries whose column rank is beyond the LDS-resident bits: out of d_Aj2r (coded as a never-set bit), listed here by ascending rank
     uint32_t  n_cold       = 0;
     uint32_t* d_cold_rank  = nullptr;// n_cold

@@ -72,6 +72,30 @@ def test_mxv_api_vs_oracle(oracle, t):
         assert_same(got, want, t, what=f"{t} {mul}/{add} {sel}")
 
 
+@pytest.mark.parametrize("t", ["INT", "FLOAT"])
+def test_mxv_api_builds_sliced_ell_copy_for_a_reused_matrix(oracle, t, monkeypatch):
+    """a matrix multiplied again and again gets the sliced-ELL copy (here after 2 calls instead of the default 256): the calls before
+    and after the switch agree with the oracle, and a matrix that is modified in between drops the copy with its plan"""
+    monkeypatch.setenv("SPLA_HIP_SELL_AFTER", "2")
+    api = _api()
+    T = getattr(api, t)
+    rng = np.random.default_rng(22)
+    n_rows, n_cols = 900, 800
+    Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 6, t, skew=True, long_rows=2, long_len=600)
+    M = api.Matrix.from_csr(Ap, Aj, Ax, (n_rows, n_cols), T)
+    cells = [("MULT", "PLUS", "ALWAYS", 0), ("MULT", "PLUS", "EQZERO", 3), ("PLUS", "MIN", "NQZERO", 1000), ("MULT", "PLUS", "ALWAYS", 0)]
+    if t == "INT":
+        cells.insert(2, ("BAND", "BOR", "EQZERO", 0))
+    for mul, add, sel, init in cells:
+        mask_np = random_mask(rng, n_rows, t)
+        v_np = random_values(rng, n_cols, t, zeros=0.7)
+        mask = api.Vector.from_lists(np.arange(n_rows), mask_np, n_rows, T)
+        v = api.Vector.from_lists(np.arange(n_cols), v_np, n_cols, T)
+        r = M.mxv(mask, v, getattr(T, mul), getattr(T, add), getattr(T, sel), init=api.Scalar(T, init))
+        want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask_np, v_np, mul, add, sel, init)
+        assert_same(r.to_dense(), want, t, what=f"{t} {mul}/{add} {sel}")
+
+
 def test_type_mismatch_is_an_error():
     api = _api()
     M = api.Matrix.from_lists([0], [0], [1], (1, 1), api.INT)

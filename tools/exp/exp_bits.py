@@ -29,8 +29,11 @@ def t(name, mask, vec, sel, form):
     print(f"{sys.argv[1] if len(sys.argv) > 1 else '':8s} form={form} {name:44s} {a.elapsed_time(b) / 20 * 1e3:8.1f} us", flush=True)
 only = os.environ.get("SPLA_EXP_ONLY")
 for form in ("2", "0"):
-    if only:
+    if only == "A":
         t("A bfs step (depth EQZERO, frontier)", depth, v, "EQZERO", form)
+        continue
+    if only == "B":
+        t("B all rows ALWAYS, frontier", depth, v, "ALWAYS", form)
         continue
     t("A bfs step (depth EQZERO, frontier)", depth, v, "EQZERO", form)
     t("B all rows ALWAYS, frontier", depth, v, "ALWAYS", form)

@@ -27,8 +27,20 @@ def main():
     for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         import os
         f = max(glob.glob(f"{root}/pmc_{kind}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if needle in r["Kernel_Name"] and r["Counter_Name"] == counter]
-        res[counter], res[counter + "_dispatches"] = cluster_median(vals)
+        rows = list(csv.DictReader(open(f)))
+        total, disp = 0.0, []
+        for nd in needle.split("|"):  # a step made of several launches: the sum of every kernel's per-launch figure
+            # one row per hardware instance: sum the instances of a dispatch first
+            per = {}
+            for r in rows:
+                if nd in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+            if not per:
+                continue
+            m, n = cluster_median(list(per.values())) if max(per.values()) > 0 else (0.0, len(per))
+            total += m
+            disp.append(n)
+        res[counter], res[counter + "_dispatches"] = total, disp
     b = json.loads(open(bench).read().strip().splitlines()[-1])
     traffic = (2.0 * res["FETCH_SIZE"] + res["WRITE_SIZE"]) * 1024.0
     doc = {"kernel": needle, "fetch_size_kb_reported": res["FETCH_SIZE"], "write_size_kb_reported": res["WRITE_SIZE"],
