@@ -96,11 +96,13 @@ namespace splahip {
                                                              unsigned long long* __restrict__ selbits) {
         __shared__ uint s_red[3][256 / kWave];
         // row selection as one bit per row (64 rows per wave and step, one 8-byte store)
+#if SPLAHIP_SELL_EXP != 21
         for (uint row = blockIdx.x * 256 + threadIdx.x; row < ((n_rows + kWave - 1) & ~(kWave - 1)); row += gridDim.x * 256) {
             const bool               sel = row < n_rows && eval_sel(op_select, mask[row]);
             const unsigned long long b   = __ballot(sel);
             if (lane_id() == 0) selbits[row / kWave] = b;
         }
+#endif
         uint            count = 0, notmin = 0, mx = 0;
         auto            one   = [&](uint rank, uint b) {
             if (rank < n_hot) hot_values[rank] = from_bits<T>(b);
@@ -114,6 +116,9 @@ namespace splahip {
         };
         // four columns per lane and step (16-byte loads; hipMalloc'ed operands are 256-byte aligned), tail by single columns
         const uint n4 = n_cols & ~3u;
+#if SPLAHIP_SELL_EXP == 22
+        if (false)
+#endif
         for (uint j = (blockIdx.x * 256 + threadIdx.x) * 4; j < n4; j += gridDim.x * 1024) {
             const uint4 rk = *reinterpret_cast<const uint4*>(rank_of + j);
             const uint4 x  = *reinterpret_cast<const uint4*>(v + j);
