@@ -33,7 +33,7 @@
 // the main kernel's inner loop issues no vector-memory access besides its two coalesced streams — a conditional global load there
 // forces s_waitcnt vmcnt(0) per entry and with it a full memory latency per entry.  A pass over v in column order
 // (sell_vprep) scatters the bits (atomicOr), the non-zero values in rank order, and min / max / count of the non-zero values;
-// both forms of the kernel are launched and the device-side statistics decide which one runs (no host round trip): BITS when all
+// one launch carries both forms and the device-side statistics decide which one a workgroup runs (no host round trip): BITS when all
 // non-zero values are equal (a BFS frontier: the set bit IS the value) or when at most a quarter of v is non-zero (set bits
 // gather their value from the rank-ordered copy).  With an LDS-resident bit per entry the kernel has no vector-memory gather
 // left: it streams the selected rows' entries once.
@@ -93,8 +93,11 @@ namespace splahip {
     __global__ __launch_bounds__(256) void sell_vprep_kernel(uint n_cols, const T* __restrict__ v, const uint* __restrict__ rank_of, uint n_hot,
                                                              T* __restrict__ hot_values, uint* __restrict__ vbits, uint* __restrict__ vranked,
                                                              uint* __restrict__ stats, uint n_rows, const T* __restrict__ mask, int op_select,
-                                                             unsigned long long* __restrict__ selbits) {
+                                                             unsigned long long* __restrict__ selbits, uint4* __restrict__ next_bits, uint n_bit_quads) {
         __shared__ uint s_red[3][256 / kWave];
+        // the bitmap is double-buffered: this call fills `vbits` (cleared by the previous call) and clears the other one for the next
+        // call — no memset launch per call
+        for (uint q = blockIdx.x * 256 + threadIdx.x; q < n_bit_quads; q += gridDim.x * 256) next_bits[q] = make_uint4(0, 0, 0, 0);
         // row selection as one bit per row (64 rows per wave and step, one 8-byte store)
 #if SPLAHIP_SELL_EXP != 21
         for (uint row = blockIdx.x * 256 + threadIdx.x; row < ((n_rows + kWave - 1) & ~(kWave - 1)); row += gridDim.x * 256) {
@@ -157,53 +160,25 @@ namespace splahip {
     // BITS = false: Aj2 holds hot-slot / raw column words, s_hot the hot VALUES, cold lanes gather v.
     // BITS = true : Aj2 holds ranks, s_hot the hot BITS (vbits), cold ranks read the global bitmap, set bits take const_bits or
     //               gather vranked; `gate` (the statistics) != nullptr makes the launch a no-op unless its form is the chosen one.
+    // The slice walk of one workgroup.  s_hot / s_next live in the calling kernel (the two forms share one LDS allocation).
     template<typename T, class Mult, class Add, bool BITS>
-    __global__ __launch_bounds__(SellCfg::kTpb) void sell_mxv_kernel(uint n_rows, const uint* __restrict__ Ap, uint n_slices,
-                                                                     const uint* __restrict__ vrow, const uint* __restrict__ vlen,
-                                                                     const uint* __restrict__ vslot, const uint* __restrict__ off,
-                                                                     const uint* __restrict__ Aj2, const uint* __restrict__ Ax2,
-                                                                     const T* __restrict__ hot_values, uint n_hot,
-                                                                     const T* __restrict__ mask, const T* __restrict__ v,
-                                                                     T* __restrict__ r, T* __restrict__ partial,
-                                                                     Mult mult, Add add, int op_select, T init,
-                                                                     const uint* __restrict__ gate, uint n_cols, int force,
-                                                                     const uint* __restrict__ vbits, const uint* __restrict__ vranked,
-                                                                     const uint* __restrict__ selbits) {
+    __device__ __forceinline__ void sell_mxv_body(T* s_hot, uint* s_next_p, uint n_rows, const uint* __restrict__ Ap, uint n_slices,
+                                                  const uint* __restrict__ vrow, const uint* __restrict__ vlen,
+                                                  const uint* __restrict__ vslot, const uint* __restrict__ off,
+                                                  const uint* __restrict__ Aj2, const uint* __restrict__ Ax2,
+                                                  const T* __restrict__ hot_values, uint n_hot,
+                                                  const T* __restrict__ mask, const T* __restrict__ v,
+                                                  T* __restrict__ r, T* __restrict__ partial,
+                                                  Mult mult, Add add, int op_select, T init,
+                                                  bool is_const, uint cbits,
+                                                  const uint* __restrict__ vbits, const uint* __restrict__ vranked,
+                                                  const uint* __restrict__ selbits) {
         using C = SellCfg;
-        __shared__ T    s_hot[BITS ? C::kBitWords : C::kHot];
-        __shared__ uint s_next;// next of this workgroup's slices nobody has taken yet (ordinal)
-        __shared__ uint s_dec[3];
+        uint& s_next = *s_next_p;// next of this workgroup's slices nobody has taken yet (ordinal)
 
-        const bool always   = op_select == SPLAHIP_ALWAYS;
+        const bool always = op_select == SPLAHIP_ALWAYS;
         if (threadIdx.x == 0) s_next = C::kWaves;// wave w starts with ordinal w
-        bool       is_const = false;
-        uint       cbits    = 0;
-        if (gate != nullptr) {
-            if constexpr (BITS) {// the first launch of a call: decides, and leaves the decision for the launches behind it
-                // (one wave per workgroup reads the 12 KB of statistics; all 4096 waves doing so cost 0.5 M L2 requests)
-                if (threadIdx.x < kWave) {
-                    const bool bits_form = sell_bits_form(gate, n_cols, force, is_const, cbits);
-                    if (threadIdx.x == 0) {
-                        s_dec[0] = bits_form ? 1u : 0u;
-                        s_dec[1] = is_const ? 1u : 0u;
-                        s_dec[2] = cbits;
-                        if (blockIdx.x == 0) {
-                            const_cast<uint*>(gate)[C::kDecision]     = s_dec[0];
-                            const_cast<uint*>(gate)[C::kDecision + 1] = s_dec[1];
-                            const_cast<uint*>(gate)[C::kDecision + 2] = s_dec[2];
-                        }
-                    }
-                }
-                __syncthreads();
-                is_const = s_dec[1] != 0u;
-                cbits    = s_dec[2];
-                if (s_dec[0] == 0u) return;
-            } else {
-                if (gate[C::kDecision] != 0u) return;
-            }
-        }
         const T cval = from_bits<T>(cbits);
-        if constexpr (BITS) hot_values = reinterpret_cast<const T*>(vbits);// the first kHot words of the bitmap go to LDS
 
         // 0. hot values -> LDS, 16 bytes per lane (the table is allocated in whole quads)
         {
@@ -413,6 +388,60 @@ namespace splahip {
             sA = sB, rowA = rowB, lenA = lenB, baseA = baseB, wordA = wordB;
             sB = sC, moreB = moreC, rowB = rowC, lenB = lenC, baseB = baseC;
         }
+    }
+
+    // value form only (semirings / types the bit form cannot serve, or SPLAHIP_SELL_BITS=0)
+    template<typename T, class Mult, class Add>
+    __global__ __launch_bounds__(SellCfg::kTpb) void sell_mxv_kernel(uint n_rows, const uint* __restrict__ Ap, uint n_slices, const uint* __restrict__ vrow,
+                                                                     const uint* __restrict__ vlen, const uint* __restrict__ vslot, const uint* __restrict__ off,
+                                                                     const uint* __restrict__ Aj2, const uint* __restrict__ Ax2, const T* __restrict__ hot_values,
+                                                                     uint n_hot, const T* __restrict__ mask, const T* __restrict__ v, T* __restrict__ r,
+                                                                     T* __restrict__ partial, Mult mult, Add add, int op_select, T init) {
+        __shared__ T    s_hot[SellCfg::kHot];
+        __shared__ uint s_next;
+        sell_mxv_body<T, Mult, Add, false>(s_hot, &s_next, n_rows, Ap, n_slices, vrow, vlen, vslot, off, Aj2, Ax2, hot_values, n_hot, mask, v, r, partial, mult, add,
+                                           op_select, init, false, 0u, nullptr, nullptr, nullptr);
+    }
+
+    // both forms in one launch: wave 0 of every workgroup reads sell_vprep's statistics (12-48 KB; all 4096 waves doing so cost
+    // 0.5 M L2 requests), the workgroup then walks its slices in the form they choose — no host round trip and no second launch.
+    // Workgroup 0 leaves the decision behind the statistics for sell_cold.  force: 0 = decide, 1 = bit form.
+    template<typename T, class Mult, class Add>
+    __global__ __launch_bounds__(SellCfg::kTpb) void sell_mxv_dual_kernel(uint n_rows, const uint* __restrict__ Ap, uint n_slices, const uint* __restrict__ vrow,
+                                                                          const uint* __restrict__ vlen, const uint* __restrict__ vslot,
+                                                                          const uint* __restrict__ off, const uint* __restrict__ Aj2, const uint* __restrict__ Aj2r,
+                                                                          const uint* __restrict__ Ax2, const T* __restrict__ hot_values, uint n_hot,
+                                                                          const T* __restrict__ mask, const T* __restrict__ v, T* __restrict__ r,
+                                                                          T* __restrict__ partial, Mult mult, Add add, int op_select, T init, uint* __restrict__ stats,
+                                                                          uint n_cols, int force, const uint* __restrict__ vbits, const uint* __restrict__ vranked,
+                                                                          const uint* __restrict__ selbits) {
+        using C = SellCfg;
+        static_assert(C::kBitWords <= C::kHot, "the two forms share one LDS table");
+        __shared__ T    s_hot[C::kHot];
+        __shared__ uint s_next;
+        __shared__ uint s_dec[3];
+        if (threadIdx.x < kWave) {
+            bool       is_const;
+            uint       cbits;
+            const bool bits_form = sell_bits_form(stats, n_cols, force, is_const, cbits);
+            if (threadIdx.x == 0) {
+                s_dec[0] = bits_form ? 1u : 0u;
+                s_dec[1] = is_const ? 1u : 0u;
+                s_dec[2] = cbits;
+                if (blockIdx.x == 0) {
+                    stats[C::kDecision]     = s_dec[0];
+                    stats[C::kDecision + 1] = s_dec[1];
+                    stats[C::kDecision + 2] = s_dec[2];
+                }
+            }
+        }
+        __syncthreads();
+        if (s_dec[0] != 0u)
+            sell_mxv_body<T, Mult, Add, true>(s_hot, &s_next, n_rows, Ap, n_slices, vrow, vlen, vslot, off, Aj2r, Ax2, reinterpret_cast<const T*>(vbits), C::kBitWords,
+                                              mask, v, r, partial, mult, add, op_select, init, s_dec[1] != 0u, s_dec[2], vbits, vranked, selbits);
+        else
+            sell_mxv_body<T, Mult, Add, false>(s_hot, &s_next, n_rows, Ap, n_slices, vrow, vlen, vslot, off, Aj2, Ax2, hot_values, n_hot, mask, v, r, partial, mult,
+                                               add, op_select, init, false, 0u, nullptr, nullptr, nullptr);
     }
 
     // BITS form, entries of columns beyond the LDS-resident ranks (ascending rank: the bitmap reads are sequential): a set bit on a

@@ -28,7 +28,9 @@ struct splahip_sell_s {
     uint32_t* d_Aj2r     = nullptr;// the entries' columns as ranks, same layout as d_Aj2
     uint32_t* d_vbits    = nullptr;// per launch: bit `rank` = v[column] != 0; followed by sell_vprep's per-workgroup statistics
     uint32_t* d_vranked  = nullptr;// per launch: v in rank order (written for the non-zero entries only)
-    uint32_t  n_bit_words = 0;     // words of d_vbits before the statistics
+    uint32_t  n_bit_words = 0;     // words of ONE bitmap; d_vbits = bitmap 0 | bitmap 1 | statistics (double-buffered: a call fills one and
+                                   // clears the other for the next call)
+    mutable uint32_t bit_buffer = 0;// which bitmap the next call fills
     uint32_t* d_selbits   = nullptr;// per launch: bit `row` = op_select(mask[row]) (the slices' rows are length-sorted: a bit is 32x denser than
                                     // a mask word, and the popular lengths keep ascending row order, so a slice's 64 tests share a few lines)
     // entries whose column rank is beyond the LDS-resident bits: out of d_Aj2r (coded as a never-set bit), listed here by ascending rank

@@ -229,25 +229,26 @@ namespace {
         const uint            grid = compute_units();
         const int             mode = bits_force();
         const bool            bits = mode != 0 && zero_skippable(TypeId<T>::value, op_mult, op_add);
-        uint*                 stats = g->d_vbits + g->n_bit_words;
+        uint*                 stats = g->d_vbits + 2 * (size_t) g->n_bit_words;
+        uint*                 vbits = g->d_vbits + (size_t) g->bit_buffer * g->n_bit_words;
+        uint*                 vnext = g->d_vbits + (size_t) (g->bit_buffer ^ 1u) * g->n_bit_words;
         if (bits) {
-            SPLAHIP_TRY(hipMemsetAsync(g->d_vbits, 0, sizeof(uint32_t) * (size_t) g->n_bit_words, st));
+            g->bit_buffer ^= 1u;
             hipLaunchKernelGGL((sell_vprep_kernel<T>), dim3(SC::kPrepBlocks), dim3(256), 0, st, g->n_cols, static_cast<const T*>(v), g->d_rank_of, g->n_hot,
-                               reinterpret_cast<T*>(g->d_hot_vals), g->d_vbits, g->d_vranked, stats, plan->n_rows, static_cast<const T*>(mask), op_select,
-                               reinterpret_cast<unsigned long long*>(g->d_selbits));
-            hipLaunchKernelGGL((sell_mxv_kernel<T, Mult, Add, true>), dim3(grid), dim3(SC::kTpb), 0, st, plan->n_rows, Ap, g->n_slices, g->d_vrow, g->d_vlen,
-                               g->d_vslot, g->d_off, g->d_Aj2r, g->d_Ax2, reinterpret_cast<const T*>(g->d_hot_vals), SC::kBitWords, static_cast<const T*>(mask),
-                               static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(g->d_partial), Mult(op_mult), Add(op_add), op_select,
-                               from_bits<T>(init_bits), stats, g->n_cols, mode == 2 ? 1 : 0, g->d_vbits, g->d_vranked, g->d_selbits);
+                               reinterpret_cast<T*>(g->d_hot_vals), vbits, g->d_vranked, stats, plan->n_rows, static_cast<const T*>(mask), op_select,
+                               reinterpret_cast<unsigned long long*>(g->d_selbits), reinterpret_cast<uint4*>(vnext), g->n_bit_words / 4);
+            hipLaunchKernelGGL((sell_mxv_dual_kernel<T, Mult, Add>), dim3(grid), dim3(SC::kTpb), 0, st, plan->n_rows, Ap, g->n_slices, g->d_vrow, g->d_vlen,
+                               g->d_vslot, g->d_off, g->d_Aj2, g->d_Aj2r, g->d_Ax2, reinterpret_cast<const T*>(g->d_hot_vals), g->n_hot,
+                               static_cast<const T*>(mask), static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(g->d_partial), Mult(op_mult),
+                               Add(op_add), op_select, from_bits<T>(init_bits), stats, g->n_cols, mode == 2 ? 1 : 0, vbits, g->d_vranked, g->d_selbits);
         } else {
             hipLaunchKernelGGL((sell_hot_pack_kernel<T>), dim3((g->n_hot + 255) / 256), dim3(256), 0, st, g->d_hot_cols, g->n_hot, static_cast<const T*>(v),
                                reinterpret_cast<T*>(g->d_hot_vals));
-        }
-        if (!(bits && mode == 2))
-            hipLaunchKernelGGL((sell_mxv_kernel<T, Mult, Add, false>), dim3(grid), dim3(SC::kTpb), 0, st, plan->n_rows, Ap, g->n_slices, g->d_vrow, g->d_vlen,
-                               g->d_vslot, g->d_off, g->d_Aj2, g->d_Ax2, reinterpret_cast<const T*>(g->d_hot_vals), g->n_hot, static_cast<const T*>(mask),
+            hipLaunchKernelGGL((sell_mxv_kernel<T, Mult, Add>), dim3(grid), dim3(SC::kTpb), 0, st, plan->n_rows, Ap, g->n_slices, g->d_vrow, g->d_vlen, g->d_vslot,
+                               g->d_off, g->d_Aj2, g->d_Ax2, reinterpret_cast<const T*>(g->d_hot_vals), g->n_hot, static_cast<const T*>(mask),
                                static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(g->d_partial), Mult(op_mult), Add(op_add), op_select,
-                               from_bits<T>(init_bits), bits ? stats : nullptr, g->n_cols, 0, nullptr, nullptr, nullptr);
+                               from_bits<T>(init_bits));
+        }
         SPLAHIP_TRY(hipGetLastError());
         if (g->n_lrows) {
             hipLaunchKernelGGL((sell_combine_kernel<T, Add>), dim3((g->n_lrows + 3) / 4), dim3(256), 0, st, g->n_lrows, g->d_lr_row, g->d_lr_first,
@@ -257,7 +258,7 @@ namespace {
         }
         if (bits && g->n_cold) {
             hipLaunchKernelGGL((sell_cold_kernel<T, Mult>), dim3((g->n_cold + 255) / 256), dim3(256), 0, st, g->n_cold, g->d_cold_rank,
-                               reinterpret_cast<const unsigned long long*>(g->d_cold_entry), stats, g->n_cols, mode == 2 ? 1 : 0, g->d_vbits, g->d_vranked,
+                               reinterpret_cast<const unsigned long long*>(g->d_cold_entry), stats, g->n_cols, mode == 2 ? 1 : 0, vbits, g->d_vranked,
                                static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), op_add, op_select);
             SPLAHIP_TRY(hipGetLastError());
         }
@@ -409,7 +410,8 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     own(&g->d_vranked, n_cols);
     // bitmap of v in rank order: at least the kHot words every workgroup copies to LDS, then the statistics (4 words per sell_vprep workgroup)
     g->n_bit_words = ((std::max<uint32_t>((n_cols + 31) / 32, SC::kHot) + 3u) & ~3u);
-    own(&g->d_vbits, (size_t) g->n_bit_words + 4 * SC::kPrepBlocks + 4);
+    own(&g->d_vbits, 2 * (size_t) g->n_bit_words + 4 * SC::kPrepBlocks + 4);
+    if (e == hipSuccess) e = hipMemsetAsync(g->d_vbits, 0, sizeof(uint32_t) * 2 * (size_t) g->n_bit_words, s);// both bitmaps start clear
     own(&g->d_selbits, 2 * ((size_t) n_rows / 64 + 2));
     if (e == hipSuccess) e = hipMemsetAsync(count, 0, sizeof(uint32_t) * (size_t) n_cols, s);
     if (e != hipSuccess) return bail("hot-column arrays");
