@@ -117,6 +117,16 @@ int splahip_vxm_push_n(int type, uint32_t n_rows, uint32_t n_cols,
                        uint32_t nvals, const uint32_t* d_vi, const void* d_vx,
                        uint32_t* d_ri, void* d_rx, uint32_t* h_count,
                        int op_mult, int op_add, int op_select, uint64_t n_products, void* stream);
+/* small frontiers: probe, expansion and compaction back to back with ONE host synchronisation.  The product count is taken on the
+ * device; when it is <= max_products the call completes the push (order-free op_add only: associative, commutative and not an fp32
+ * PLUS / MULT) and *h_done = 1; otherwise *h_done = 0, nothing was written, and *h_products / *h_sorted are what splahip_vxm_probe
+ * would have returned, so the caller goes on to splahip_vxm_pull / splahip_vxm_push_n without probing again. */
+int splahip_vxm_push_small(int type, uint32_t n_rows, uint32_t n_cols,
+                           const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, const void* d_mask,
+                           uint32_t nvals, const uint32_t* d_vi, const void* d_vx,
+                           uint32_t* d_ri, void* d_rx, uint32_t max_products, uint32_t* h_count,
+                           uint64_t* h_products, int* h_sorted, int* h_done,
+                           int op_mult, int op_add, int op_select, void* stream);
 /* CSR of the transpose (n_cols rows): entries of a column keep ascending row order (stable).  d_Tp: n_cols+1 words,
  * d_Tj / d_Tx: nnz words.  Blocks; = splahip_m_transpose with the identity.  (reference: the CSC slot FormatMatrix::AccCsc, include/spla/config.hpp:102-122) */
 int splahip_csr_transpose(uint32_t n_rows, uint32_t n_cols, uint32_t nnz, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax,

@@ -5,6 +5,7 @@
 #include "storage.hpp"
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -162,10 +163,29 @@ namespace spla {
 
                 uint64_t products = 0;
                 int      sorted   = 1;
-                hip_check(splahip_vxm_probe(nvals, vin->Ai.template as<uint32_t>(), a->Ap.template as<uint32_t>(), &products, &sorted, nullptr), "splahip_vxm_probe");
+                uint32_t count    = 0;
+                // small frontiers (the many cheap levels of a traversal): probe, expansion and compaction in one go with a single host
+                // synchronisation, for an op_add that does not depend on the fold order; the device-side product count decides whether
+                // the speculative push ran (<= 4 M products and below the pull threshold) or the general forms below take over
+                const bool order_free = op_assoc_comm(op_add) && !(TypeTraits<T>::id == SPLAHIP_FLOAT && (op_add == SPLAHIP_PLUS || op_add == SPLAHIP_MULT));
+                if (order_free && nvals <= (1u << 16)) {
+                    const uint64_t pull_at      = a->values / 8ull;// products * 8 >= nnz(M) -> pull
+                    const uint32_t max_products = static_cast<uint32_t>(std::min<uint64_t>(1ull << 22, pull_at ? pull_at - 1 : 0));
+                    int            done         = 0;
+                    hip_check(splahip_vxm_push_small(TypeTraits<T>::id, M->get_n_rows(), M->get_n_cols(), a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(),
+                                                     a->Ax.ptr(), mask->acc_dense()->Ax.ptr(), nvals, vin->Ai.template as<uint32_t>(), vin->Ax.ptr(),
+                                                     out->Ai.template as<uint32_t>(), out->Ax.ptr(), max_products, &count, &products, &sorted, &done, op_mult, op_add,
+                                                     op_sel, nullptr),
+                              "splahip_vxm_push_small");
+                    if (done) {
+                        out->values = count;
+                        return Status::Ok;
+                    }
+                } else {
+                    hip_check(splahip_vxm_probe(nvals, vin->Ai.template as<uint32_t>(), a->Ap.template as<uint32_t>(), &products, &sorted, nullptr), "splahip_vxm_probe");
+                }
                 if (products == 0) return Status::Ok;
 
-                uint32_t   count    = 0;
                 const bool can_pull = sorted && op_assoc_comm(op_add);
                 const bool pull     = can_pull && products * 8ull >= a->values;// push costs ~9x the products, pull costs nnz(M)
                 if (pull) {

@@ -259,6 +259,82 @@ namespace splahip {
             }
     }
 
+    // ---- push, small frontiers: probe + expansion + compaction back to back, ONE host synchronisation ---------------------------
+    // gate[0..1] = product count (64 bit), gate[2] = "indices not ascending" flag: written by probe_kernel; the kernels behind it
+    // run only when the count is within `max_products` (the host then reads count + gate in one copy).  A workgroup per frontier
+    // entry walks that row of M and folds the products into the packed (touched, value) words with compare-and-swap; the words
+    // live in a cached workspace that is all-zero between calls: the write kernel clears every word it emits.
+    __device__ __forceinline__ bool small_gate_open(const uint* __restrict__ gate, uint max_products) {
+        return gate[1] == 0u && gate[0] != 0u && gate[0] <= max_products;
+    }
+    template<typename T, class Mult, class Add>
+    __global__ __launch_bounds__(256) void push_direct_kernel(const uint* __restrict__ gate, uint max_products, const uint* __restrict__ vi,
+                                                              const T* __restrict__ vx, const uint* __restrict__ Ap, const uint* __restrict__ Aj,
+                                                              const uint* __restrict__ Ax, const T* __restrict__ mask, int op_select, Mult mult, Add add,
+                                                              u64* __restrict__ acc) {
+        if (!small_gate_open(gate, max_products)) return;
+        // blockIdx.y: the row is shared by gridDim.y workgroups (a lone hub of 64 K entries would otherwise be one workgroup's 250 rounds)
+        const uint row = vi[blockIdx.x];
+        const T    x   = vx[blockIdx.x];
+        const uint k1  = Ap[row + 1];
+        for (uint k = Ap[row] + blockIdx.y * 256 + threadIdx.x; k < k1; k += gridDim.y * 256) {
+            const uint j = Aj[k];
+            if (!eval_sel(op_select, mask[j])) continue;
+            const T prod = mult(x, from_bits<T>(Ax[k]));
+            u64*    slot = acc + j;
+            u64     seen = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (true) {
+                const bool touched = (seen >> 32) != 0;
+                const T    next    = touched ? add(from_bits<T>((uint) seen), prod) : prod;
+                const u64  want    = (1ull << 32) | (u64) to_bits(next);
+                if (want == seen) break;
+                const u64 prev = atomicCAS(slot, seen, want);
+                if (prev == seen) break;
+                seen = prev;
+            }
+        }
+    }
+    __global__ __launch_bounds__(256) void acc_count_gated_kernel(const uint* __restrict__ gate, uint max_products, const u64* __restrict__ acc, uint n,
+                                                                  uint* __restrict__ chunk) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        const bool      open  = small_gate_open(gate, max_products);
+        const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        uint            cnt   = 0;
+        if (open) {
+#pragma unroll
+            for (uint u = 0; u < 4; ++u)
+                if (first + u < n) cnt += (acc[first + u] >> 32) ? 1u : 0u;
+        }
+        uint total;
+        (void) block_exclusive_sum<256>(cnt, s_tmp, total);
+        if (threadIdx.x == 0) chunk[blockIdx.x] = total;
+    }
+    // emits the touched columns in ascending order and returns their words to zero
+    __global__ __launch_bounds__(256) void acc_write_reset_kernel(const uint* __restrict__ gate, uint max_products, u64* __restrict__ acc, uint n,
+                                                                  const uint* __restrict__ chunk, uint* __restrict__ out_i, uint* __restrict__ out_x) {
+        __shared__ uint s_tmp[256 / kWave + 1];
+        if (!small_gate_open(gate, max_products)) return;
+        const uint first = blockIdx.x * 1024u + threadIdx.x * 4u;
+        u64        w[4];
+        uint       cnt = 0;
+#pragma unroll
+        for (uint u = 0; u < 4; ++u) {
+            w[u] = first + u < n ? acc[first + u] : 0ull;
+            cnt += (w[u] >> 32) ? 1u : 0u;
+        }
+        uint total;
+        uint pos = chunk[blockIdx.x] + block_exclusive_sum<256>(cnt, s_tmp, total);
+        if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<uint*>(gate)[3] = chunk[gridDim.x];// the total, next to the gate: one read-back
+#pragma unroll
+        for (uint u = 0; u < 4; ++u)
+            if (w[u] >> 32) {
+                out_i[pos]     = first + u;
+                out_x[pos]     = (uint) w[u];
+                acc[first + u] = 0ull;
+                ++pos;
+            }
+    }
+
     __global__ __launch_bounds__(256) void head_count_kernel(const uint* __restrict__ key, uint n, uint n_cols, uint* __restrict__ chunk) {
         __shared__ uint s_tmp[256 / kWave + 1];
         const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
@@ -416,6 +492,55 @@ namespace splahip {
         return SPLAHIP_OK;
     }
 
+    // all-zero accumulator words kept between calls (grow-only, per host thread like the other cached workspaces)
+    struct SmallPushWs {
+        u64*   acc   = nullptr;
+        size_t words = 0;
+        uint*  misc  = nullptr;// gate[4] | chunk[...]
+        size_t misc_words = 0;
+    };
+    inline SmallPushWs& small_push_ws() {
+        static thread_local SmallPushWs ws;
+        return ws;
+    }
+
+    template<typename T>
+    int push_small_typed(uint n_cols, const uint* Ap, const uint* Aj, const void* Ax, const void* mask, uint nvals, const uint* vi, const void* vx, uint* ri,
+                         void* rx, uint max_products, uint* h_out /* count, products lo, products hi, unsorted */, int op_mult, int op_add, int op_select,
+                         hipStream_t s) {
+        SmallPushWs& ws       = small_push_ws();
+        const uint   n_chunks = (n_cols + 1023u) / 1024u;
+        if (ws.words < n_cols) {
+            if (ws.acc) (void) hipFree(ws.acc);
+            ws.acc = nullptr, ws.words = 0;
+            SPLAHIP_TRY(hipMalloc(reinterpret_cast<void**>(&ws.acc), sizeof(u64) * (size_t) n_cols));
+            ws.words = n_cols;
+            SPLAHIP_TRY(hipMemsetAsync(ws.acc, 0, sizeof(u64) * (size_t) n_cols, s));
+        }
+        if (ws.misc_words < (size_t) n_chunks + 8) {
+            if (ws.misc) (void) hipFree(ws.misc);
+            ws.misc = nullptr, ws.misc_words = 0;
+            SPLAHIP_TRY(hipMalloc(reinterpret_cast<void**>(&ws.misc), sizeof(uint) * ((size_t) n_chunks + 8)));
+            ws.misc_words = (size_t) n_chunks + 8;
+        }
+        uint* gate  = ws.misc;// [0..1] products, [2] unsorted
+        uint* chunk = ws.misc + 4;
+        SPLAHIP_TRY(hipMemsetAsync(gate, 0, 16, s));
+        hipLaunchKernelGGL(probe_kernel, dim3((nvals + 255) / 256), dim3(256), 0, s, nvals, vi, Ap, reinterpret_cast<unsigned long long*>(gate), gate + 2);
+        const uint share = std::max(1u, std::min(64u, 16384u / nvals));// workgroups per frontier entry: few entries -> split their rows
+        hipLaunchKernelGGL((push_direct_kernel<T, DynBin, DynBin>), dim3(nvals, share), dim3(256), 0, s, gate, max_products, vi, static_cast<const T*>(vx), Ap, Aj,
+                           static_cast<const uint*>(Ax), static_cast<const T*>(mask), op_select, DynBin(op_mult), DynBin(op_add), ws.acc);
+        hipLaunchKernelGGL(acc_count_gated_kernel, dim3(n_chunks), dim3(256), 0, s, gate, max_products, ws.acc, n_cols, chunk);
+        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk, n_chunks);
+        hipLaunchKernelGGL(acc_write_reset_kernel, dim3(n_chunks), dim3(256), 0, s, gate, max_products, ws.acc, n_cols, chunk, ri, static_cast<uint*>(rx));
+        SPLAHIP_TRY(hipGetLastError());
+        uint h[4] = {0, 0, 0, 0};// products lo, hi, unsorted, count
+        SPLAHIP_TRY(hipMemcpyAsync(h, gate, 4 * sizeof(uint), hipMemcpyDeviceToHost, s));
+        SPLAHIP_TRY(hipStreamSynchronize(s));
+        h_out[0] = h[3], h_out[1] = h[0], h_out[2] = h[1], h_out[3] = h[2];
+        return SPLAHIP_OK;
+    }
+
     constexpr uint kPushAtomicMax = 1u << 22;// products up to which the order-free form is used
     inline bool    push_order_free(int op_add, int type) {
         if (!binop_is_associative(op_add) || !binop_is_commutative(op_add)) return false;
@@ -558,6 +683,33 @@ int splahip_vxm_probe(uint32_t nvals, const uint32_t* d_vi, const uint32_t* d_Ap
     SPLAHIP_TRY(hipStreamSynchronize(s));
     *h_products = h[0];
     *h_sorted   = (h[1] & 0xffffffffull) ? 0 : 1;
+    return SPLAHIP_OK;
+}
+
+int splahip_vxm_push_small(int type, uint32_t n_rows, uint32_t n_cols, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, const void* d_mask,
+                           uint32_t nvals, const uint32_t* d_vi, const void* d_vx, uint32_t* d_ri, void* d_rx, uint32_t max_products, uint32_t* h_count,
+                           uint64_t* h_products, int* h_sorted, int* h_done, int op_mult, int op_add, int op_select, void* stream) {
+    (void) n_rows;
+    SPLAHIP_REQUIRE(h_count && h_products && h_sorted && h_done, "null output");
+    SPLAHIP_REQUIRE(binop_valid_for(op_mult, type) && binop_valid_for(op_add, type), "op not defined for this type");
+    SPLAHIP_REQUIRE(push_order_free(op_add, type), "the small-frontier form needs an op_add whose result does not depend on the fold order");
+    *h_count = 0, *h_products = 0, *h_sorted = 1, *h_done = 1;
+    if (nvals == 0 || n_cols == 0) return SPLAHIP_OK;
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    hipStream_t s = as_stream(stream);
+    uint32_t    out[4] = {0, 0, 0, 0};
+    switch (type) {
+        case SPLAHIP_INT: st = push_small_typed<int32_t>(n_cols, d_Ap, d_Aj, d_Ax, d_mask, nvals, d_vi, d_vx, d_ri, d_rx, max_products, out, op_mult, op_add, op_select, s); break;
+        case SPLAHIP_UINT: st = push_small_typed<uint32_t>(n_cols, d_Ap, d_Aj, d_Ax, d_mask, nvals, d_vi, d_vx, d_ri, d_rx, max_products, out, op_mult, op_add, op_select, s); break;
+        case SPLAHIP_FLOAT: st = push_small_typed<float>(n_cols, d_Ap, d_Aj, d_Ax, d_mask, nvals, d_vi, d_vx, d_ri, d_rx, max_products, out, op_mult, op_add, op_select, s); break;
+        default: return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
+    }
+    if (st != SPLAHIP_OK) return st;
+    *h_products = ((uint64_t) out[2] << 32) | out[1];
+    *h_sorted   = out[3] ? 0 : 1;
+    *h_done     = (*h_products == 0 || *h_products <= max_products) ? 1 : 0;
+    *h_count    = *h_done ? out[0] : 0;
     return SPLAHIP_OK;
 }
 

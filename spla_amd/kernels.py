@@ -129,6 +129,19 @@ def vxm_push(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, op_mult, op_add, op_se
     return ri[:cnt.value], rx[:cnt.value]
 
 
+def vxm_push_small(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, op_mult, op_add, op_select, max_products):
+    """Single-synchronisation push for small frontiers: returns (done, products, sorted, ri, rx); when the device-side product count
+    exceeds max_products nothing is computed (done = False) and the caller falls back to vxm_push / vxm_pull."""
+    tid = type_id(t)
+    ri = torch.empty(max(n_cols, 1), dtype=torch.int32, device=mask.device)
+    rx = torch.empty(max(n_cols, 1), dtype=torch_dtype(t), device=mask.device)
+    cnt, products, srt, done = C.c_uint32(), C.c_uint64(), C.c_int(), C.c_int()
+    _lib.call("splahip_vxm_push_small", tid, int(n_rows), int(n_cols), _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(mask),
+              int(vi.numel()), _ptr(vi) if vi.numel() else None, _ptr(vx) if vi.numel() else None, _ptr(ri), _ptr(rx), int(max_products), C.byref(cnt),
+              C.byref(products), C.byref(srt), C.byref(done), binop_id(op_mult), binop_id(op_add), selop_id(op_select), current_stream_ptr())
+    return bool(done.value), int(products.value), bool(srt.value), ri[:cnt.value], rx[:cnt.value]
+
+
 def _adopt(ptr, n, dtype):
     """Copy a library-allocated device array of n words into a torch tensor and release the original."""
     out = torch.empty(max(n, 1), dtype=dtype, device="cuda")[:n]

@@ -141,3 +141,46 @@ def test_vxm_api_auto_form_vs_oracle(oracle, t):
         want = oracle.vxm_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask_np, vi, vx, mul, add, sel)
         np.testing.assert_array_equal(I, want[0])
         assert_same(V, want[1], t, what=f"{t} nv={nv} {mul}/{add}")
+
+
+@pytest.mark.parametrize("t", ["INT", "UINT", "FLOAT"])
+def test_push_small_frontier_form(oracle, t):
+    """splahip_vxm_push_small: probe + compare-and-swap expansion + compaction with one host synchronisation.  Order-free op_add cells
+    against the oracle over many consecutive calls (the accumulator workspace must come back all-zero every time), unsorted frontiers,
+    explicit zero products, and the hand-over when the device-side product count exceeds the limit."""
+    from gpu_utils import dev, host
+    from spla_amd import kernels
+    rng = np.random.default_rng(77)
+    n_rows, n_cols = 2500, 1900
+    Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 8, t, skew=True, long_rows=2, long_len=1200)
+    dAp, dAj, dAx = dev(Ap), dev(Aj), dev(np.asarray(Ax, NP[t]))
+    cells = [("MULT", "MIN"), ("PLUS", "MAX"), ("FIRST", "MIN"), ("SECOND", "MAX")]
+    if t != "FLOAT":
+        cells += [("BAND", "BOR"), ("MULT", "PLUS"), ("MULT", "BXOR"), ("LAND", "LOR")]
+    for rep in range(3):
+        for mul, add in cells:
+            for sel in ("ALWAYS", "EQZERO"):
+                mask = random_mask(rng, n_cols, t)
+                nv = int(rng.integers(1, 60))
+                vi = rng.permutation(n_rows)[:nv].astype(np.uint32)  # unsorted: an order-free fold does not care
+                vx = random_values(rng, nv, t, zeros=0.3)
+                want_i, want_x = oracle.vxm_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel)
+                done, products, srt, ri, rx = kernels.vxm_push_small(t, n_rows, n_cols, dAp, dAj, dAx, dev(np.asarray(mask, NP[t])), dev(vi),
+                                                                     dev(np.asarray(vx, NP[t])), mul, add, sel, 1 << 20)
+                assert done and products == int(np.diff(Ap.astype(np.int64))[vi].sum())
+                assert srt == bool(np.all(np.diff(vi.astype(np.int64)) > 0))
+                assert np.array_equal(host(ri, np.uint32), want_i), (mul, add, sel)
+                assert np.array_equal(host(rx, NP[t]).view(np.uint32), want_x.view(np.uint32)), (mul, add, sel)
+    # over the limit: nothing computed, the probe's answer handed back
+    vi = np.arange(0, n_rows, 2, dtype=np.uint32)
+    vx = random_values(rng, len(vi), t)
+    done, products, srt, ri, rx = kernels.vxm_push_small(t, n_rows, n_cols, dAp, dAj, dAx, dev(np.zeros(n_cols, NP[t])), dev(vi), dev(np.asarray(vx, NP[t])),
+                                                         "MULT", "MIN", "ALWAYS", 100)
+    assert not done and len(ri) == 0 and srt and products == int(np.diff(Ap.astype(np.int64))[vi].sum())
+    # ... and the next small call still starts from a clean workspace
+    vi = np.array([5], np.uint32)
+    vx = random_values(rng, 1, t)
+    want_i, want_x = oracle.vxm_masked(t, n_rows, n_cols, Ap, Aj, Ax, np.zeros(n_cols, NP[t]), vi, vx, "MULT", "MIN", "ALWAYS")
+    done, _, _, ri, rx = kernels.vxm_push_small(t, n_rows, n_cols, dAp, dAj, dAx, dev(np.zeros(n_cols, NP[t])), dev(vi), dev(np.asarray(vx, NP[t])), "MULT", "MIN",
+                                                "ALWAYS", 1 << 20)
+    assert done and np.array_equal(host(ri, np.uint32), want_i) and np.array_equal(host(rx, NP[t]).view(np.uint32), want_x.view(np.uint32))
