@@ -50,8 +50,26 @@
 
 namespace splahip {
 
+#ifdef SPLAHIP_SELL_TIMING
+    // DIAGNOSTIC BUILD ONLY (tools/exp/exp_sell_timing.py): per wave of the launch (4096), s_memtime ticks summed over its slices:
+    // [0] top of the loop .. loads issued, [1] .. first group landed, [2] .. fold + stores issued, [3] slices, [4] wave total, [5] prologue
+    static __device__ unsigned long long g_sell_t[6][4096];
+#define SELL_STAMP(t)                                            \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    t = __builtin_amdgcn_s_memtime();
+#define SELL_NOW(t) t = __builtin_amdgcn_s_memtime();
+#else
+#define SELL_STAMP(t)
+#define SELL_NOW(t)
+#endif
+
     struct SellCfg {
         static constexpr uint kC       = 256;  // max entries per virtual row (chunk)
+#ifndef SPLAHIP_SELL_XL
+#define SPLAHIP_SELL_XL 256
+#endif
+        static constexpr uint kXL      = SPLAHIP_SELL_XL;// rows longer than this get ROW-EXCLUSIVE slices: 64 lanes x <= kC entries of one row,
+                                               // lane l holding entries l, l + 64, ... of the slice's 16 Ki-entry block (= the row in CSR order)
         static constexpr uint kHot     = 40000;// LDS-resident values of the gathered vector (156.25 KB of the 160 KB)
         static constexpr uint kTpb     = 1024; // one workgroup per CU
         static constexpr uint kWaves   = kTpb / kWave;
@@ -172,7 +190,7 @@ namespace splahip {
                                                   Mult mult, Add add, int op_select, T init,
                                                   bool is_const, uint cbits,
                                                   const uint* __restrict__ vbits, const uint* __restrict__ vranked,
-                                                  const uint* __restrict__ selbits) {
+                                                  const uint* __restrict__ selbits, const uint* __restrict__ sorder) {
         using C = SellCfg;
         uint& s_next = *s_next_p;// next of this workgroup's slices nobody has taken yet (ordinal)
 
@@ -229,13 +247,16 @@ namespace splahip {
         //    is never requested.
         const uint lane = lane_id();
         const uint w    = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-        uint       sA   = blockIdx.x + w * gridDim.x;
+        // position q of the widest-first order -> slice id (the plan's permutation: row-exclusive slices sit ahead of the sorted chunks in
+        // memory but are taken by width like everything else)
+        auto phys = [&](uint q) -> uint { return q < n_slices ? (sorder ? sorder[q] : q) : n_slices; };
+        uint sA   = phys(blockIdx.x + w * gridDim.x);
         if (sA >= n_slices) return;
 
         auto take_slice = [&]() -> uint {
             uint ord = 0;
             if (lane == 0) ord = atomicAdd(&s_next, 1u);
-            return blockIdx.x + __builtin_amdgcn_readfirstlane(ord) * gridDim.x;
+            return phys(blockIdx.x + __builtin_amdgcn_readfirstlane(ord) * gridDim.x);
         };
         // the word that decides a lane's selection: nothing for ALWAYS, the row's bit word (BITS) or its mask value
         auto sel_word = [&](uint rowinfo, uint len) -> uint {
@@ -253,6 +274,10 @@ namespace splahip {
                 return eval_sel(op_select, from_bits<T>(word));
         };
 
+#ifdef SPLAHIP_SELL_TIMING
+        unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, acc0 = 0, acc1 = 0, acc2 = 0, nsl = 0, t_begin = 0;
+        SELL_NOW(t_begin)
+#endif
         uint rowA = vrow[sA * kWave + lane], lenA = vlen[sA * kWave + lane], baseA = off[sA];
         uint sB   = take_slice();
         bool moreB = sB < n_slices;
@@ -264,6 +289,7 @@ namespace splahip {
         }
         uint wordA = sel_word(rowA, lenA);
         while (true) {
+            SELL_NOW(t_a)
             // C's header and B's selection word travel while A is folded
             uint sC = n_slices, rowC = 0, lenC = 0, baseC = 0;
             if (moreB) sC = take_slice();
@@ -296,6 +322,8 @@ namespace splahip {
                     xn[u] = sell_stream_load(px + u * kWave);
                 }
             }
+            SELL_NOW(t_b)
+            SELL_STAMP(t_c)
             const unsigned long long live = __ballot(selected);
             if (live != 0ull) {
                 // chunks are sorted by length: the first selected lane holds the longest selected chunk
@@ -384,6 +412,17 @@ namespace splahip {
                 }
 #endif
             }
+#ifdef SPLAHIP_SELL_TIMING
+            SELL_NOW(t_d)
+            acc0 += t_b - t_a, acc1 += t_c - t_b, acc2 += t_d - t_c, nsl += 1;
+            if (!moreB && lane == 0) {
+                const uint gw = blockIdx.x * C::kWaves + w;
+                if (gw < 4096) {
+                    g_sell_t[0][gw] = acc0, g_sell_t[1][gw] = acc1, g_sell_t[2][gw] = acc2, g_sell_t[3][gw] = nsl;
+                    g_sell_t[4][gw] = t_d - t_begin;
+                }
+            }
+#endif
             if (!moreB) break;
             sA = sB, rowA = rowB, lenA = lenB, baseA = baseB, wordA = wordB;
             sB = sC, moreB = moreC, rowB = rowC, lenB = lenC, baseB = baseC;
@@ -396,11 +435,12 @@ namespace splahip {
                                                                      const uint* __restrict__ vlen, const uint* __restrict__ vslot, const uint* __restrict__ off,
                                                                      const uint* __restrict__ Aj2, const uint* __restrict__ Ax2, const T* __restrict__ hot_values,
                                                                      uint n_hot, const T* __restrict__ mask, const T* __restrict__ v, T* __restrict__ r,
-                                                                     T* __restrict__ partial, Mult mult, Add add, int op_select, T init) {
+                                                                     T* __restrict__ partial, Mult mult, Add add, int op_select, T init,
+                                                                     const uint* __restrict__ sorder) {
         __shared__ T    s_hot[SellCfg::kHot];
         __shared__ uint s_next;
         sell_mxv_body<T, Mult, Add, false>(s_hot, &s_next, n_rows, Ap, n_slices, vrow, vlen, vslot, off, Aj2, Ax2, hot_values, n_hot, mask, v, r, partial, mult, add,
-                                           op_select, init, false, 0u, nullptr, nullptr, nullptr);
+                                           op_select, init, false, 0u, nullptr, nullptr, nullptr, sorder);
     }
 
     // both forms in one launch: wave 0 of every workgroup reads sell_vprep's statistics (12-48 KB; all 4096 waves doing so cost
@@ -414,7 +454,7 @@ namespace splahip {
                                                                           const T* __restrict__ mask, const T* __restrict__ v, T* __restrict__ r,
                                                                           T* __restrict__ partial, Mult mult, Add add, int op_select, T init, uint* __restrict__ stats,
                                                                           uint n_cols, int force, const uint* __restrict__ vbits, const uint* __restrict__ vranked,
-                                                                          const uint* __restrict__ selbits) {
+                                                                          const uint* __restrict__ selbits, const uint* __restrict__ sorder) {
         using C = SellCfg;
         static_assert(C::kBitWords <= C::kHot, "the two forms share one LDS table");
         __shared__ T    s_hot[C::kHot];
@@ -438,10 +478,10 @@ namespace splahip {
         __syncthreads();
         if (s_dec[0] != 0u)
             sell_mxv_body<T, Mult, Add, true>(s_hot, &s_next, n_rows, Ap, n_slices, vrow, vlen, vslot, off, Aj2r, Ax2, reinterpret_cast<const T*>(vbits), C::kBitWords,
-                                              mask, v, r, partial, mult, add, op_select, init, s_dec[1] != 0u, s_dec[2], vbits, vranked, selbits);
+                                              mask, v, r, partial, mult, add, op_select, init, s_dec[1] != 0u, s_dec[2], vbits, vranked, selbits, sorder);
         else
             sell_mxv_body<T, Mult, Add, false>(s_hot, &s_next, n_rows, Ap, n_slices, vrow, vlen, vslot, off, Aj2, Ax2, hot_values, n_hot, mask, v, r, partial, mult,
-                                               add, op_select, init, false, 0u, nullptr, nullptr, nullptr);
+                                               add, op_select, init, false, 0u, nullptr, nullptr, nullptr, sorder);
     }
 
     // BITS form, entries of columns beyond the LDS-resident ranks (ascending rank: the bitmap reads are sequential): a set bit on a

@@ -12,6 +12,9 @@ struct splahip_sell_s {
     uint32_t  n_hot      = 0;
     uint32_t  n_lrows    = 0;// rows longer than one chunk
     uint32_t  n_partials = 0;
+    uint32_t  n_xslices  = 0;// leading row-exclusive slices (rows longer than kXL): selection is uniform per slice; the fold order inside
+                             // such a row is lane-strided, so op_add must also be commutative when n_xslices > 0
+    uint32_t* d_sorder   = nullptr;// n_slices: slice ids by descending width (the order the workgroups take them in)
     uint32_t* d_vrow     = nullptr;// n_vrows: row id | bit 31 "chunk of a long row"
     uint32_t* d_vlen     = nullptr;// n_vrows: entries of the chunk (0 = padding lane)
     uint32_t* d_vslot    = nullptr;// n_vrows: partial slot of a long row's chunk

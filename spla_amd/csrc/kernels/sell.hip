@@ -21,31 +21,58 @@ namespace {
 
     // ---- plan-time kernels ----------------------------------------------------------------------------------------------
     // per row: chunks it contributes, chunks that need a partial slot (rows longer than one chunk), "is long" flag
+    constexpr uint kXBlock = kWave * SC::kC;// entries of a row-exclusive slice
+
     __global__ __launch_bounds__(256) void sell_rowinfo_kernel(const uint* __restrict__ Ap, uint n_rows, uint* __restrict__ vcount, uint* __restrict__ pcount,
-                                                               uint* __restrict__ lflag) {
+                                                               uint* __restrict__ lflag, uint* __restrict__ xcount) {
         const uint row = blockIdx.x * 256 + threadIdx.x;
         if (row > n_rows) return;
-        uint c = 0, l = 0;
+        uint c = 0, l = 0, pc = 0, xs = 0;
         if (row < n_rows) {
             const uint len = Ap[row + 1] - Ap[row];
-            c              = (len + SC::kC - 1) / SC::kC;
             l              = len > SC::kC ? 1u : 0u;
+            if (len > SC::kXL) {// row-exclusive slices; a partial slot per non-empty lane
+                xs = (len + kXBlock - 1) / kXBlock;
+                pc = (xs - 1) * kWave + min(kWave, len - (xs - 1) * kXBlock);
+                l  = 1;
+            } else {
+                c  = (len + SC::kC - 1) / SC::kC;
+                pc = l ? c : 0u;
+            }
         }
         vcount[row] = c;// entry n_rows = 0: the scans run over n_rows + 1 values so their last output is the total
-        pcount[row] = l ? c : 0u;
+        pcount[row] = pc;
         lflag[row]  = l;
+        xcount[row] = xs;
     }
     // per row: its chunks in row order (the stable sort below keeps a long row's chunks adjacent and ascending)
     __global__ __launch_bounds__(256) void sell_emit_kernel(const uint* __restrict__ Ap, uint n_rows, const uint* __restrict__ vfirst, const uint* __restrict__ pfirst,
                                                             const uint* __restrict__ lfirst, uint* __restrict__ q_key, uint* __restrict__ q_id, uint* __restrict__ q_row,
                                                             uint* __restrict__ q_len, uint* __restrict__ q_k0, uint* __restrict__ q_slot, uint* __restrict__ lr_row,
-                                                            uint* __restrict__ lr_first) {
+                                                            uint* __restrict__ lr_first, const uint* __restrict__ xfirst, uint* __restrict__ vrow,
+                                                            uint* __restrict__ vlen, uint* __restrict__ vk0, uint* __restrict__ vslot) {
         const uint row = blockIdx.x * 256 + threadIdx.x;
         if (row >= n_rows) return;
         const uint k0  = Ap[row];
         const uint len = Ap[row + 1] - k0;
         if (len == 0) return;
         const bool is_long = len > SC::kC;
+        if (len > SC::kXL) {// row-exclusive slices go straight to the head of the virtual-row arrays (row order; taken by width via sorder)
+            const uint xs = (len + kXBlock - 1) / kXBlock;
+            for (uint S = 0; S < xs; ++S) {
+                const uint rem = min(kXBlock, len - S * kXBlock);// entries of this slice's block
+                for (uint l = 0; l < kWave; ++l) {
+                    const uint p = (xfirst[row] + S) * kWave + l;
+                    vrow[p]      = row | SC::kPartial;
+                    vlen[p]      = l < rem ? (rem - l + kWave - 1) / kWave : 0u;
+                    vk0[p]       = k0 + S * kXBlock + l;
+                    vslot[p]     = pfirst[row] + S * kWave + l;// lanes >= rem hold nothing and own no slot
+                }
+            }
+            lr_row[lfirst[row]]   = row;
+            lr_first[lfirst[row]] = pfirst[row];
+            return;
+        }
         const uint nch     = (len + SC::kC - 1) / SC::kC;
         const uint q0      = vfirst[row];
         const uint p0      = pfirst[row];
@@ -64,13 +91,15 @@ namespace {
             lr_first[lfirst[row]] = p0;
         }
     }
-    __global__ __launch_bounds__(256) void sell_permute_kernel(uint n_chunks, uint n_vrows, const uint* __restrict__ order, const uint* __restrict__ q_row,
+    // the sorted chunks follow the row-exclusive slices: virtual rows [first, n_vrows)
+    __global__ __launch_bounds__(256) void sell_permute_kernel(uint n_chunks, uint first, uint n_vrows, const uint* __restrict__ order, const uint* __restrict__ q_row,
                                                                const uint* __restrict__ q_len, const uint* __restrict__ q_k0, const uint* __restrict__ q_slot,
                                                                uint* __restrict__ vrow, uint* __restrict__ vlen, uint* __restrict__ vk0, uint* __restrict__ vslot) {
-        const uint p = blockIdx.x * 256 + threadIdx.x;
+        const uint i = blockIdx.x * 256 + threadIdx.x;
+        const uint p = first + i;
         if (p >= n_vrows) return;
-        if (p < n_chunks) {
-            const uint q = order[p];
+        if (i < n_chunks) {
+            const uint q = order[i];
             vrow[p]      = q_row[q];
             vlen[p]      = q_len[q];
             vk0[p]       = q_k0[q];
@@ -80,9 +109,14 @@ namespace {
             vlen[p] = vk0[p] = vslot[p] = 0;
         }
     }
-    __global__ __launch_bounds__(256) void sell_width_kernel(const uint* __restrict__ vlen, uint n_slices, uint* __restrict__ slots) {
+    __global__ __launch_bounds__(256) void sell_width_kernel(const uint* __restrict__ vlen, uint n_slices, uint* __restrict__ slots, uint* __restrict__ wkey,
+                                                             uint* __restrict__ sid) {
         const uint s = blockIdx.x * 256 + threadIdx.x;
-        if (s <= n_slices) slots[s] = s < n_slices ? vlen[s * kWave] * kWave : 0u;// sorted descending: lane 0 holds the slice's width
+        if (s <= n_slices) slots[s] = s < n_slices ? vlen[s * kWave] * kWave : 0u;// lane 0 holds the slice's width
+        if (s < n_slices) {
+            wkey[s] = SC::kC - vlen[s * kWave];// ascending key = descending width
+            sid[s]  = s;
+        }
     }
     // column reference counts -> the n_hot most referenced columns get an LDS slot
     __global__ __launch_bounds__(256) void sell_col_count_kernel(const uint* __restrict__ Aj, uint nnz, uint* __restrict__ count) {
@@ -107,7 +141,7 @@ namespace {
     }
     // one wave per slice: lane l copies chunk l into the slice's column-major block, re-encoding hot columns; the rest of the
     // lane's column is padding that reads slot 0 of the hot table and multiplies by a zero word (never folded)
-    __global__ __launch_bounds__(256) void sell_fill_kernel(uint n_slices, const uint* __restrict__ off, const uint* __restrict__ vlen, const uint* __restrict__ vk0,
+    __global__ __launch_bounds__(256) void sell_fill_kernel(uint n_slices, uint n_xslices, const uint* __restrict__ off, const uint* __restrict__ vlen, const uint* __restrict__ vk0,
                                                             const uint* __restrict__ Aj, const uint* __restrict__ Ax, const uint* __restrict__ rank_of, uint n_hot,
                                                             uint* __restrict__ Aj2, uint* __restrict__ Aj2r, uint* __restrict__ Ax2) {
         const uint s = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
@@ -115,15 +149,16 @@ namespace {
         const uint lane  = lane_id();
         const uint base  = off[s];
         const uint width = (off[s + 1] - base) / kWave;
-        const uint len   = vlen[s * kWave + lane];
-        const uint k0    = vk0[s * kWave + lane];
+        const uint len    = vlen[s * kWave + lane];
+        const uint k0     = vk0[s * kWave + lane];
+        const uint stride = s < n_xslices ? kWave : 1u;// row-exclusive slice: the block in CSR order, lane-strided
         for (uint e = 0; e < width; ++e) {
             uint j = SC::kHotFlag, rank = SC::kBitsLds, x = 0;
             if (e < len) {
-                const uint col = Aj[k0 + e];
+                const uint col = Aj[k0 + e * stride];
                 rank           = rank_of[col];
                 j              = rank < n_hot ? (rank | SC::kHotFlag) : col;
-                x              = Ax[k0 + e];
+                x              = Ax[k0 + e * stride];
             }
             Aj2[base + e * kWave + lane]  = j;
             Aj2r[base + e * kWave + lane] = min(rank, SC::kBitsLds);// colder columns: the never-set bit (their entries are in the cold list)
@@ -240,14 +275,14 @@ namespace {
             hipLaunchKernelGGL((sell_mxv_dual_kernel<T, Mult, Add>), dim3(grid), dim3(SC::kTpb), 0, st, plan->n_rows, Ap, g->n_slices, g->d_vrow, g->d_vlen,
                                g->d_vslot, g->d_off, g->d_Aj2, g->d_Aj2r, g->d_Ax2, reinterpret_cast<const T*>(g->d_hot_vals), g->n_hot,
                                static_cast<const T*>(mask), static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(g->d_partial), Mult(op_mult),
-                               Add(op_add), op_select, from_bits<T>(init_bits), stats, g->n_cols, mode == 2 ? 1 : 0, vbits, g->d_vranked, g->d_selbits);
+                               Add(op_add), op_select, from_bits<T>(init_bits), stats, g->n_cols, mode == 2 ? 1 : 0, vbits, g->d_vranked, g->d_selbits, g->d_sorder);
         } else {
             hipLaunchKernelGGL((sell_hot_pack_kernel<T>), dim3((g->n_hot + 255) / 256), dim3(256), 0, st, g->d_hot_cols, g->n_hot, static_cast<const T*>(v),
                                reinterpret_cast<T*>(g->d_hot_vals));
             hipLaunchKernelGGL((sell_mxv_kernel<T, Mult, Add>), dim3(grid), dim3(SC::kTpb), 0, st, plan->n_rows, Ap, g->n_slices, g->d_vrow, g->d_vlen, g->d_vslot,
                                g->d_off, g->d_Aj2, g->d_Ax2, reinterpret_cast<const T*>(g->d_hot_vals), g->n_hot, static_cast<const T*>(mask),
                                static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(g->d_partial), Mult(op_mult), Add(op_add), op_select,
-                               from_bits<T>(init_bits));
+                               from_bits<T>(init_bits), g->d_sorder);
         }
         SPLAHIP_TRY(hipGetLastError());
         if (g->n_lrows) {
@@ -294,7 +329,7 @@ namespace splahip {
     void sell_release(splahip_sell_s* g) {
         if (!g) return;
         for (uint32_t* p : {g->d_vrow, g->d_vlen, g->d_vslot, g->d_off, g->d_Aj2, g->d_Ax2, g->d_hot_cols, g->d_hot_vals, g->d_lr_row, g->d_lr_first, g->d_partial,
-                            g->d_rank_of, g->d_Aj2r, g->d_vbits, g->d_vranked, g->d_cold_rank, g->d_selbits})
+                            g->d_rank_of, g->d_Aj2r, g->d_vbits, g->d_vranked, g->d_cold_rank, g->d_selbits, g->d_sorder})
             if (p) (void) hipFree(p);
         if (g->d_cold_entry) (void) hipFree(g->d_cold_entry);
         delete g;
@@ -337,21 +372,23 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     };
 
     // 1. chunks per row, partial slots per long row, long-row index: three exclusive scans over n_rows + 1 counters
-    uint32_t *vcount, *pcount, *lflag, *vfirst, *pfirst, *lfirst;
-    for (uint32_t** q : {&vcount, &pcount, &lflag, &vfirst, &pfirst, &lfirst})
+    uint32_t *vcount, *pcount, *lflag, *xcount, *vfirst, *pfirst, *lfirst, *xfirst;
+    for (uint32_t** q : {&vcount, &pcount, &lflag, &xcount, &vfirst, &pfirst, &lfirst, &xfirst})
         if (e == hipSuccess) e = tmp.alloc(q, (size_t) n_rows + 1);
     if (e != hipSuccess) return bail("scratch");
-    hipLaunchKernelGGL(sell_rowinfo_kernel, dim3((n_rows + 256) / 256), dim3(256), 0, s, d_Ap, n_rows, vcount, pcount, lflag);
+    hipLaunchKernelGGL(sell_rowinfo_kernel, dim3((n_rows + 256) / 256), dim3(256), 0, s, d_Ap, n_rows, vcount, pcount, lflag, xcount);
     e = hipGetLastError();
     if (e == hipSuccess) e = exclusive_scan_u32(vcount, vfirst, (size_t) n_rows + 1, s);
     if (e == hipSuccess) e = exclusive_scan_u32(pcount, pfirst, (size_t) n_rows + 1, s);
     if (e == hipSuccess) e = exclusive_scan_u32(lflag, lfirst, (size_t) n_rows + 1, s);
+    if (e == hipSuccess) e = exclusive_scan_u32(xcount, xfirst, (size_t) n_rows + 1, s);
     uint32_t n_chunks = 0;
     if (e == hipSuccess) e = hipMemcpy(&n_chunks, vfirst + n_rows, 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&g->n_xslices, xfirst + n_rows, 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(&g->n_partials, pfirst + n_rows, 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(&g->n_lrows, lfirst + n_rows, 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return bail("row scan");
-    g->n_vrows  = (n_chunks + kWave - 1) / kWave * kWave;
+    g->n_vrows  = g->n_xslices * kWave + (n_chunks + kWave - 1) / kWave * kWave;// row-exclusive slices first, then the sorted chunks
     g->n_slices = g->n_vrows / kWave;
 
     // 2. chunks in row order -> stable sort by descending length
@@ -371,22 +408,30 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     own(&g->d_partial, g->n_partials);
     if (e != hipSuccess) return bail("chunk arrays");
     hipLaunchKernelGGL(sell_emit_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, d_Ap, n_rows, vfirst, pfirst, lfirst, q_key, q_id, q_row, q_len, q_k0, q_slot,
-                       g->d_lr_row, g->d_lr_first);
+                       g->d_lr_row, g->d_lr_first, xfirst, g->d_vrow, g->d_vlen, vk0, g->d_vslot);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(g->d_lr_first + g->n_lrows, &g->n_partials, 4, hipMemcpyHostToDevice, s);
     unsigned key_bits = 1;
     while ((1u << key_bits) < SC::kC) ++key_bits;// keys are kC - len in [0, kC)
     if (e == hipSuccess) e = stable_sort_pairs(q_key, key_s, q_id, order, n_chunks, key_bits, s);
     if (e != hipSuccess) return bail("chunk sort");
-    hipLaunchKernelGGL(sell_permute_kernel, dim3((g->n_vrows + 255) / 256), dim3(256), 0, s, n_chunks, g->n_vrows, order, q_row, q_len, q_k0, q_slot, g->d_vrow,
-                       g->d_vlen, vk0, g->d_vslot);
+    hipLaunchKernelGGL(sell_permute_kernel, dim3((g->n_vrows + 255) / 256), dim3(256), 0, s, n_chunks, g->n_xslices * kWave, g->n_vrows, order, q_row, q_len, q_k0,
+                       q_slot, g->d_vrow, g->d_vlen, vk0, g->d_vslot);
 
     // 3. slice offsets
     uint32_t* slots = nullptr;
     e               = tmp.alloc(&slots, (size_t) g->n_slices + 1);
     if (e != hipSuccess) return bail("slice scratch");
-    hipLaunchKernelGGL(sell_width_kernel, dim3((g->n_slices + 256) / 256), dim3(256), 0, s, g->d_vlen, g->n_slices, slots);
+    // slice widths; the order the workgroups take the slices in: by descending width (stable)
+    uint32_t *wkey = nullptr, *wkey_s = nullptr, *sid = nullptr;
+    if (e == hipSuccess) e = tmp.alloc(&wkey, g->n_slices);
+    if (e == hipSuccess) e = tmp.alloc(&wkey_s, g->n_slices);
+    if (e == hipSuccess) e = tmp.alloc(&sid, g->n_slices);
+    own(&g->d_sorder, g->n_slices);
+    if (e != hipSuccess) return bail("slice order");
+    hipLaunchKernelGGL(sell_width_kernel, dim3((g->n_slices + 256) / 256), dim3(256), 0, s, g->d_vlen, g->n_slices, slots, wkey, sid);
     e = hipGetLastError();
+    if (e == hipSuccess) e = stable_sort_pairs(wkey, wkey_s, sid, g->d_sorder, g->n_slices, key_bits + 1, s);
     // the padded entry count must stay below 2^32 (offsets are 32-bit); padding is < 1 % after a global sort, so check the bound up front
     if (e == hipSuccess && (uint64_t) nnz + (uint64_t) g->n_slices * kWave * 2 >= 0xF0000000ull) {
         sell_release(g);
@@ -456,7 +501,7 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     }
 
     // 5. the entries
-    hipLaunchKernelGGL(sell_fill_kernel, dim3((g->n_slices + 3) / 4), dim3(256), 0, s, g->n_slices, g->d_off, g->d_vlen, vk0, d_Aj,
+    hipLaunchKernelGGL(sell_fill_kernel, dim3((g->n_slices + 3) / 4), dim3(256), 0, s, g->n_slices, g->n_xslices, g->d_off, g->d_vlen, vk0, d_Aj,
                        static_cast<const uint32_t*>(d_Ax), g->d_rank_of, g->n_hot, g->d_Aj2, g->d_Aj2r, g->d_Ax2);
     hipLaunchKernelGGL(sell_tail_kernel, dim3((kTail + 255) / 256), dim3(256), 0, s, g->n_slots, kTail, g->d_Aj2, g->d_Aj2r, g->d_Ax2);
     e = hipGetLastError();
@@ -475,3 +520,11 @@ extern "C" int splahip_csr_plan_sell_info(splahip_plan plan, uint32_t* n_slices,
     if (n_long_rows) *n_long_rows = g ? g->n_lrows : 0;
     return SPLAHIP_OK;
 }
+
+#ifdef SPLAHIP_SELL_TIMING
+// DIAGNOSTIC BUILD ONLY: copy out the per-wave slice timings of the last sliced-ELL launch (6 x 4096 64-bit words)
+extern "C" int splahip_debug_sell_timing(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(splahip::g_sell_t), sizeof(unsigned long long) * 6 * 4096) == hipSuccess ? SPLAHIP_OK : SPLAHIP_ERROR;
+}
+#endif
+
