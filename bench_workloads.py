@@ -178,8 +178,9 @@ def sssp_step(args):
     v[idx] = torch.randint(0, 5000, (n // 8,), generator=g, device="cuda", dtype=torch.int32)
     mask = torch.zeros(n, dtype=torch.int32, device="cuda")
     r = torch.empty(n, dtype=torch.int32, device="cuda")
-    plan = kernels.CsrPlan(n, nnz, Ap)
-    _log(f"[bench] sssp-step: R-MAT scale {scale}: n={n} nnz={nnz} items={plan.n_items}")
+    use_sell = os.environ.get("SPLA_BENCH_PLAN", "sell") == "sell"  # the sliced-ELL copy (built once per matrix) or the CSR kernels only
+    plan = kernels.CsrPlan(n, nnz, Ap, n, Aj, Ax) if use_sell else kernels.CsrPlan(n, nnz, Ap)
+    _log(f"[bench] sssp-step: R-MAT scale {scale}: n={n} nnz={nnz} items={plan.n_items} sliced-ELL copy: {plan.sell}")
     step = lambda: kernels.mxv_masked(plan, "INT", n, Ap, Aj, Ax, mask, v, r, "PLUS", "MIN", "ALWAYS", INF)
     wall, per = _time_calls(step, args.steps, args.warmup)
     ms = float(np.mean(per))
@@ -187,7 +188,7 @@ def sssp_step(args):
     line = _line("masked SpMV GTEPS (SSSP step)", "GTEPS", nnz / (wall / args.steps) / 1e9, args, wall / args.steps * 1e3, "int32",
                  {"workload": f"exec_mxv_masked PLUS/MIN int32 (min-plus), ALWAYS, init 2^30, weights 1..255, 1/8 of v finite; R-MAT scale {scale} "
                               f"ef {args.edge_factor}, raw labels", "n": n, "nnz": nnz, "work_items": plan.n_items},
-                 _roof(alg, ms, kernels.mxv_variant("INT", "PLUS", "MIN")))
+                 _roof(alg, ms, kernels.mxv_variant("INT", "PLUS", "MIN", False, plan)))
     if not args.no_verify:
         orc = pyoracle.Oracle()
         want = orc.mxv_masked("INT", n, n, Ap.cpu().numpy(), Aj.cpu().numpy(), Ax.cpu().numpy(), mask.cpu().numpy(), v.cpu().numpy(), "PLUS", "MIN", "ALWAYS", INF)
