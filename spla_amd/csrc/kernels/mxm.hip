@@ -210,7 +210,9 @@ namespace splahip {
             uint       ka = Ap[i], ea = Ap[i + 1];
             uint       kb = Bp[j], eb = Bp[j + 1];
             if ((ea - ka) + (eb - kb) > kHeavy && ea > ka && eb > kb) {
-                heavy_list[atomicAdd(heavy_count, 1u)] = e;
+                const uint slot          = atomicAdd(heavy_count, 1u);
+                heavy_list[2 * slot]     = e;
+                heavy_list[2 * slot + 1] = i;// the row travels with the entry: the heavy kernel need not search Mp again (20 dependent loads)
                 done                                   = false;
             } else {
                 while (ka < ea && kb < eb) {
@@ -246,8 +248,8 @@ namespace splahip {
         const uint w = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
         if (w >= *heavy_count) return;
         const uint lane = lane_id();
-        const uint e    = heavy_list[w];
-        const uint i    = row_of_entry(Mp, n_rows, e);
+        const uint e    = heavy_list[2 * w];
+        const uint i    = heavy_list[2 * w + 1];
         const uint j    = Mj[e];
         const uint sa = Ap[i], ea = Ap[i + 1], sb = Bp[j], eb = Bp[j + 1];
         T          r = init;
@@ -331,7 +333,7 @@ namespace splahip {
         SPLAHIP_TRY(keep.alloc(sizeof(uint) * (size_t) n_entries));
         SPLAHIP_TRY(rank.alloc(sizeof(uint) * ((size_t) n_entries + 1)));
         SPLAHIP_TRY(hcount.alloc(sizeof(uint)));
-        SPLAHIP_TRY(hlist.alloc(sizeof(uint) * (size_t) n_entries));
+        SPLAHIP_TRY(hlist.alloc(sizeof(uint) * 2 * (size_t) n_entries));
         SPLAHIP_TRY(hipMemsetAsync(hcount.p, 0, sizeof(uint), s));
         hipLaunchKernelGGL((mxmT_entry_kernel<T, DynBin, DynBin>), dim3((n_entries + 255) / 256), dim3(256), 0, s, n_rows, n_entries, Mp, Mj,
                            static_cast<const T*>(Mx), Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(),
