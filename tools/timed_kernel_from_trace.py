@@ -29,5 +29,5 @@ for needle in needles:
     print(f"  launches in the trace: {len(rows)}; timed region = last {len(dur)}: avg {statistics.mean(dur):.2f} us, median {statistics.median(dur):.2f} us, "
           f"min {min(dur):.2f}, max {max(dur):.2f}")
 print(f"sum over the step's kernels (rocprofv3 kernel-trace): avg {total_avg:.2f} us, median {total_med:.2f} us")
-print(f"bench.py HIP events around the whole call (same command, same run; includes the gaps between its launches and a 160 KB memset): "
+print(f"bench.py HIP events around the whole call (same command, same run; includes the gaps between its launches): "
       f"avg {b['roofline']['kernel_avg_us']} us, median {b['roofline']['kernel_median_us']} us")
