@@ -109,7 +109,7 @@ namespace splahip {
     // kPrepBlocks workgroups, grid-stride; every workgroup writes its own statistics slot (a same-address atomic per wave cost 0.8 ms)
     template<typename T>
     __global__ __launch_bounds__(256) void sell_vprep_kernel(uint n_cols, const T* __restrict__ v, const uint* __restrict__ rank_of, uint n_hot,
-                                                             T* __restrict__ hot_values, uint* __restrict__ vbits, uint* __restrict__ vranked,
+                                                             const uint* __restrict__ hot_cols, T* __restrict__ hot_values, uint* __restrict__ vbits, uint* __restrict__ vranked,
                                                              uint* __restrict__ stats, uint n_rows, const T* __restrict__ mask, int op_select,
                                                              unsigned long long* __restrict__ selbits, uint4* __restrict__ next_bits, uint n_bit_quads) {
         __shared__ uint s_red[3][256 / kWave];
@@ -124,10 +124,14 @@ namespace splahip {
             if (lane_id() == 0) selbits[row / kWave] = b;
         }
 #endif
+        // hot values of the value form: a gather by the plan's hot-column list (the rank of a column is only looked up where v is not 0:
+        // the pass reads v once and, for a sparse v, almost nothing of rank_of — its cost must not grow with the padded column count of
+        // a multi-GPU run)
+        for (uint t = blockIdx.x * 256 + threadIdx.x; t < n_hot; t += gridDim.x * 256) hot_values[t] = v[hot_cols[t]];
         uint            count = 0, notmin = 0, mx = 0;
-        auto            one   = [&](uint rank, uint b) {
-            if (rank < n_hot) hot_values[rank] = from_bits<T>(b);
+        auto            one   = [&](uint j, uint b) {
             if (b != 0) {
+                const uint rank = rank_of[j];
                 atomicOr(&vbits[rank >> 5], 1u << (rank & 31u));
                 vranked[rank] = b;
                 count += 1;
@@ -141,11 +145,10 @@ namespace splahip {
         if (false)
 #endif
         for (uint j = (blockIdx.x * 256 + threadIdx.x) * 4; j < n4; j += gridDim.x * 1024) {
-            const uint4 rk = *reinterpret_cast<const uint4*>(rank_of + j);
-            const uint4 x  = *reinterpret_cast<const uint4*>(v + j);
-            one(rk.x, x.x), one(rk.y, x.y), one(rk.z, x.z), one(rk.w, x.w);
+            const uint4 x = *reinterpret_cast<const uint4*>(v + j);
+            one(j, x.x), one(j + 1, x.y), one(j + 2, x.z), one(j + 3, x.w);
         }
-        if (blockIdx.x == 0 && threadIdx.x < (n_cols & 3u)) one(rank_of[n4 + threadIdx.x], to_bits(v[n4 + threadIdx.x]));
+        if (blockIdx.x == 0 && threadIdx.x < (n_cols & 3u)) one(n4 + threadIdx.x, to_bits(v[n4 + threadIdx.x]));
         count  = wave_sum(count);
         notmin = wave_max(notmin);
         mx     = wave_max(mx);

@@ -270,7 +270,7 @@ namespace {
         if (bits) {
             g->bit_buffer ^= 1u;
             hipLaunchKernelGGL((sell_vprep_kernel<T>), dim3(SC::kPrepBlocks), dim3(256), 0, st, g->n_cols, static_cast<const T*>(v), g->d_rank_of, g->n_hot,
-                               reinterpret_cast<T*>(g->d_hot_vals), vbits, g->d_vranked, stats, plan->n_rows, static_cast<const T*>(mask), op_select,
+                               g->d_hot_cols, reinterpret_cast<T*>(g->d_hot_vals), vbits, g->d_vranked, stats, plan->n_rows, static_cast<const T*>(mask), op_select,
                                reinterpret_cast<unsigned long long*>(g->d_selbits), reinterpret_cast<uint4*>(vnext), g->n_bit_words / 4);
             hipLaunchKernelGGL((sell_mxv_dual_kernel<T, Mult, Add>), dim3(grid), dim3(SC::kTpb), 0, st, plan->n_rows, Ap, g->n_slices, g->d_vrow, g->d_vlen,
                                g->d_vslot, g->d_off, g->d_Aj2, g->d_Aj2r, g->d_Ax2, reinterpret_cast<const T*>(g->d_hot_vals), g->n_hot,
