@@ -105,13 +105,30 @@ namespace splahip {
         return is_const || count <= n_cols / 4;
     }
 
+    template<class Add>
+    __device__ __forceinline__ int functor_op(const Add& add) {
+        if constexpr (Add::is_static) return Add::op_id;
+        else
+            return add.op;
+    }
+    // the integer atomic of a bit-form op_add (BOR, PLUS, BXOR, uint MAX: sell_zero_skippable)
+    __device__ __forceinline__ void atomic_fold(uint* d, uint p, int op_add) {
+        switch (op_add) {
+            case SPLAHIP_BOR: atomicOr(d, p); break;
+            case SPLAHIP_BXOR: atomicXor(d, p); break;
+            case SPLAHIP_MAX: atomicMax(d, p); break;
+            default: atomicAdd(d, p); break;// PLUS: two's complement, same bits for int and uint
+        }
+    }
+
     // column-order pass over v: hot values for the value form; bits, rank-ordered values and statistics for the BITS form.
     // kPrepBlocks workgroups, grid-stride; every workgroup writes its own statistics slot (a same-address atomic per wave cost 0.8 ms)
     template<typename T>
     __global__ __launch_bounds__(256) void sell_vprep_kernel(uint n_cols, const T* __restrict__ v, const uint* __restrict__ rank_of, uint n_hot,
                                                              const uint* __restrict__ hot_cols, T* __restrict__ hot_values, uint* __restrict__ vbits, uint* __restrict__ vranked,
                                                              uint* __restrict__ stats, uint n_rows, const T* __restrict__ mask, int op_select,
-                                                             unsigned long long* __restrict__ selbits, uint4* __restrict__ next_bits, uint n_bit_quads) {
+                                                             unsigned long long* __restrict__ selbits, uint4* __restrict__ next_bits, uint n_bit_quads,
+                                                             T* __restrict__ r, T init) {
         __shared__ uint s_red[3][256 / kWave];
         // the bitmap is double-buffered: this call fills `vbits` (cleared by the previous call) and clears the other one for the next
         // call — no memset launch per call
@@ -122,6 +139,9 @@ namespace splahip {
             const bool               sel = row < n_rows && eval_sel(op_select, mask[row]);
             const unsigned long long b   = __ballot(sel);
             if (lane_id() == 0) selbits[row / kWave] = b;
+            // every row starts at init: the bit form has no row pass; its slice lanes overwrite (rows of one chunk) or fold into it with
+            // the integer atomic of op_add (row-exclusive slices, the cold list)
+            if (row < n_rows) r[row] = init;
         }
 #endif
         // hot values of the value form: a gather by the plan's hot-column list (the rank of a column is only looked up where v is not 0:
@@ -216,7 +236,7 @@ namespace splahip {
         //    row pointers and mask values arrive as 16-byte loads; the stores stay per row (a selected non-empty row is written
         //    by its slice lane, possibly from another workgroup, and must not be touched here).
 #if SPLAHIP_SELL_EXP != 3 /* diagnostic 3: no row pass */
-        {
+        if constexpr (!BITS) {// (bit form: sell_vprep already wrote init to every row)
             const uint per = ((n_rows + gridDim.x - 1) / gridDim.x + 3u) & ~3u;
             const uint rb  = blockIdx.x * per;
             const uint re  = min(n_rows, rb + per);
@@ -408,7 +428,16 @@ namespace splahip {
 #if SPLAHIP_SELL_EXP == 11
                 if (selected && to_bits(acc) == 0x12345u) r[row] = acc;
 #else
-                if (selected) {
+                if constexpr (BITS) {
+                    if (chunk) {// a row-exclusive slice: the 64 lane results are one row's — fold them in the wave, one atomic into r[row]
+                        bool pv = selected;
+                        T    t  = acc;
+                        wave_reduce_ordered(t, pv, add);
+                        if (lane == 0 && pv) atomic_fold(reinterpret_cast<uint*>(r + row), to_bits(t), functor_op(add));
+                    } else if (selected) {
+                        r[row] = acc;
+                    }
+                } else if (selected) {
                     if (chunk) partial[vslot[s_cur * kWave + lane]] = acc;
                     else
                         r[row] = acc;
@@ -520,7 +549,8 @@ namespace splahip {
     template<typename T, class Add>
     __global__ __launch_bounds__(256) void sell_combine_kernel(uint n_lrows, const uint* __restrict__ lr_row, const uint* __restrict__ lr_first,
                                                                const T* __restrict__ partial, const T* __restrict__ mask, T* __restrict__ r, Add add,
-                                                               int op_select, T init) {
+                                                               int op_select, T init, const uint* __restrict__ gate) {
+        if (gate != nullptr && gate[SellCfg::kDecision] != 0u) return;// the bit form folded its long rows with atomics
         const uint i = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
         if (i >= n_lrows) return;
         const uint row = lr_row[i];

@@ -271,7 +271,8 @@ namespace {
             g->bit_buffer ^= 1u;
             hipLaunchKernelGGL((sell_vprep_kernel<T>), dim3(SC::kPrepBlocks), dim3(256), 0, st, g->n_cols, static_cast<const T*>(v), g->d_rank_of, g->n_hot,
                                g->d_hot_cols, reinterpret_cast<T*>(g->d_hot_vals), vbits, g->d_vranked, stats, plan->n_rows, static_cast<const T*>(mask), op_select,
-                               reinterpret_cast<unsigned long long*>(g->d_selbits), reinterpret_cast<uint4*>(vnext), g->n_bit_words / 4);
+                               reinterpret_cast<unsigned long long*>(g->d_selbits), reinterpret_cast<uint4*>(vnext), g->n_bit_words / 4, static_cast<T*>(r),
+                               from_bits<T>(init_bits));
             hipLaunchKernelGGL((sell_mxv_dual_kernel<T, Mult, Add>), dim3(grid), dim3(SC::kTpb), 0, st, plan->n_rows, Ap, g->n_slices, g->d_vrow, g->d_vlen,
                                g->d_vslot, g->d_off, g->d_Aj2, g->d_Aj2r, g->d_Ax2, reinterpret_cast<const T*>(g->d_hot_vals), g->n_hot,
                                static_cast<const T*>(mask), static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(g->d_partial), Mult(op_mult),
@@ -288,7 +289,7 @@ namespace {
         if (g->n_lrows) {
             hipLaunchKernelGGL((sell_combine_kernel<T, Add>), dim3((g->n_lrows + 3) / 4), dim3(256), 0, st, g->n_lrows, g->d_lr_row, g->d_lr_first,
                                reinterpret_cast<const T*>(g->d_partial), static_cast<const T*>(mask), static_cast<T*>(r), Add(op_add), op_select,
-                               from_bits<T>(init_bits));
+                               from_bits<T>(init_bits), bits ? stats : nullptr);
             SPLAHIP_TRY(hipGetLastError());
         }
         if (bits && g->n_cold) {
