@@ -519,14 +519,12 @@ namespace splahip {
     // BITS form, entries of columns beyond the LDS-resident ranks (ascending rank: the bitmap reads are sequential): a set bit on a
     // selected row folds its product into r[row] with the integer atomic of op_add.  Runs after the main kernel and sell_combine.
     template<typename T, class Mult>
-    __global__ __launch_bounds__(256) void sell_cold_kernel(uint n_cold, const uint* __restrict__ cold_rank, const unsigned long long* __restrict__ cold_entry,
-                                                            const uint* __restrict__ stats, uint n_cols, int force, const uint* __restrict__ vbits,
-                                                            const uint* __restrict__ vranked, const T* __restrict__ mask, T* __restrict__ r, Mult mult,
-                                                            int op_add, int op_select) {
-        if (stats[SellCfg::kDecision] == 0u) return;
+    __device__ __forceinline__ void sell_cold_block(uint block, uint n_cold, const uint* __restrict__ cold_rank, const unsigned long long* __restrict__ cold_entry,
+                                                    const uint* __restrict__ stats, const uint* __restrict__ vbits, const uint* __restrict__ vranked,
+                                                    const T* __restrict__ mask, T* __restrict__ r, Mult mult, int op_add, int op_select) {
         const bool is_const = stats[SellCfg::kDecision + 1] != 0u;
         const uint cbits    = stats[SellCfg::kDecision + 2];
-        const uint k        = blockIdx.x * 256 + threadIdx.x;
+        const uint k        = block * 256 + threadIdx.x;
         if (k >= n_cold) return;
         const uint rank = cold_rank[k];
         if (((vbits[rank >> 5] >> (rank & 31u)) & 1u) == 0) return;
@@ -534,24 +532,16 @@ namespace splahip {
         const uint row = (uint) (e >> 32);
         if (!eval_sel(op_select, mask[row])) return;
         const T    x = from_bits<T>(is_const ? cbits : vranked[rank]);
-        const uint p = to_bits(mult(from_bits<T>((uint) e), x));
-        uint*      d = reinterpret_cast<uint*>(r + row);
-        switch (op_add) {
-            case SPLAHIP_BOR: atomicOr(d, p); break;
-            case SPLAHIP_BXOR: atomicXor(d, p); break;
-            case SPLAHIP_MAX: atomicMax(d, p); break;// uint only (zero_skippable)
-            default: atomicAdd(d, p); break;         // PLUS: two's complement, same bits for int and uint
-        }
+        atomic_fold(reinterpret_cast<uint*>(r + row), to_bits(mult(from_bits<T>((uint) e), x)), op_add);
     }
 
     // rows longer than kC: r[row] = init (+) partial[first] (+) partial[first + 1] ... in chunk order.  One wave per row: lane l
     // folds a contiguous run of the row's partials, then an in-order wave reduction joins the runs (associative op_add).
     template<typename T, class Add>
-    __global__ __launch_bounds__(256) void sell_combine_kernel(uint n_lrows, const uint* __restrict__ lr_row, const uint* __restrict__ lr_first,
-                                                               const T* __restrict__ partial, const T* __restrict__ mask, T* __restrict__ r, Add add,
-                                                               int op_select, T init, const uint* __restrict__ gate) {
-        if (gate != nullptr && gate[SellCfg::kDecision] != 0u) return;// the bit form folded its long rows with atomics
-        const uint i = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+    __device__ __forceinline__ void sell_combine_block(uint block, uint n_lrows, const uint* __restrict__ lr_row, const uint* __restrict__ lr_first,
+                                                       const T* __restrict__ partial, const T* __restrict__ mask, T* __restrict__ r, Add add, int op_select,
+                                                       T init) {
+        const uint i = block * (256 / kWave) + threadIdx.x / kWave;
         if (i >= n_lrows) return;
         const uint row = lr_row[i];
         if (!eval_sel(op_select, mask[row])) return;// the main kernel's row pass wrote init
@@ -566,6 +556,29 @@ namespace splahip {
         }
         wave_reduce_ordered(acc, valid, add);
         if (lane_id() == 0) r[row] = valid ? add(init, acc) : init;
+    }
+
+    // value-form calls of semirings the bit form cannot serve: the long rows' partials
+    template<typename T, class Add>
+    __global__ __launch_bounds__(256) void sell_combine_kernel(uint n_lrows, const uint* __restrict__ lr_row, const uint* __restrict__ lr_first,
+                                                               const T* __restrict__ partial, const T* __restrict__ mask, T* __restrict__ r, Add add,
+                                                               int op_select, T init) {
+        sell_combine_block<T, Add>(blockIdx.x, n_lrows, lr_row, lr_first, partial, mask, r, add, op_select, init);
+    }
+    // the launch behind sell_mxv_dual: the cold list when the workgroups chose the bit form (blocks [0, cold_blocks)), else the long rows'
+    // partials (the blocks behind them) — one launch whichever form ran
+    template<typename T, class Mult, class Add>
+    __global__ __launch_bounds__(256) void sell_post_kernel(uint cold_blocks, uint n_cold, const uint* __restrict__ cold_rank,
+                                                            const unsigned long long* __restrict__ cold_entry, const uint* __restrict__ stats,
+                                                            const uint* __restrict__ vbits, const uint* __restrict__ vranked, uint n_lrows,
+                                                            const uint* __restrict__ lr_row, const uint* __restrict__ lr_first, const T* __restrict__ partial,
+                                                            const T* __restrict__ mask, T* __restrict__ r, Mult mult, Add add, int op_select, T init) {
+        const bool bits_form = stats[SellCfg::kDecision] != 0u;
+        if (blockIdx.x < cold_blocks) {
+            if (bits_form) sell_cold_block<T, Mult>(blockIdx.x, n_cold, cold_rank, cold_entry, stats, vbits, vranked, mask, r, mult, functor_op(add), op_select);
+        } else if (!bits_form) {
+            sell_combine_block<T, Add>(blockIdx.x - cold_blocks, n_lrows, lr_row, lr_first, partial, mask, r, add, op_select, init);
+        }
     }
 
 }// namespace splahip

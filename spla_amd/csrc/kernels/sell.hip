@@ -286,16 +286,19 @@ namespace {
                                from_bits<T>(init_bits), g->d_sorder);
         }
         SPLAHIP_TRY(hipGetLastError());
-        if (g->n_lrows) {
+        if (bits) {
+            const uint cold_blocks = (g->n_cold + 255) / 256, comb_blocks = (g->n_lrows + 3) / 4;
+            if (cold_blocks + comb_blocks) {
+                hipLaunchKernelGGL((sell_post_kernel<T, Mult, Add>), dim3(cold_blocks + comb_blocks), dim3(256), 0, st, cold_blocks, g->n_cold, g->d_cold_rank,
+                                   reinterpret_cast<const unsigned long long*>(g->d_cold_entry), stats, vbits, g->d_vranked, g->n_lrows, g->d_lr_row,
+                                   g->d_lr_first, reinterpret_cast<const T*>(g->d_partial), static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult),
+                                   Add(op_add), op_select, from_bits<T>(init_bits));
+                SPLAHIP_TRY(hipGetLastError());
+            }
+        } else if (g->n_lrows) {
             hipLaunchKernelGGL((sell_combine_kernel<T, Add>), dim3((g->n_lrows + 3) / 4), dim3(256), 0, st, g->n_lrows, g->d_lr_row, g->d_lr_first,
                                reinterpret_cast<const T*>(g->d_partial), static_cast<const T*>(mask), static_cast<T*>(r), Add(op_add), op_select,
-                               from_bits<T>(init_bits), bits ? stats : nullptr);
-            SPLAHIP_TRY(hipGetLastError());
-        }
-        if (bits && g->n_cold) {
-            hipLaunchKernelGGL((sell_cold_kernel<T, Mult>), dim3((g->n_cold + 255) / 256), dim3(256), 0, st, g->n_cold, g->d_cold_rank,
-                               reinterpret_cast<const unsigned long long*>(g->d_cold_entry), stats, g->n_cols, mode == 2 ? 1 : 0, vbits, g->d_vranked,
-                               static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), op_add, op_select);
+                               from_bits<T>(init_bits));
             SPLAHIP_TRY(hipGetLastError());
         }
         return SPLAHIP_OK;

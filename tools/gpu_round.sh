@@ -11,7 +11,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_o
 echo "== rocprof kernel trace of the timed configuration only"
 rm -rf "$R/gpurun_out/prof_timed"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_timed" -- python3 "$R/bench.py" --steps 30 --warmup 5 --no-cpu-baseline --no-verify --no-variants > "$R/gpurun_out/prof_timed_bench.json" 2> /dev/null; echo "rocprof timed exit $?"
-python3 "$R/tools/timed_kernel_from_trace.py" "$R/gpurun_out/prof_timed" 'sell_vprep_kernel<int>|sell_mxv_dual_kernel<int, splahip::StaBin<13>, splahip::StaBin<12> >|sell_combine_kernel<int|sell_cold_kernel<int' 30 "$R/gpurun_out/prof_timed_bench.json" | tee "$R/gpurun_out/prof_timed_summary.txt"
+python3 "$R/tools/timed_kernel_from_trace.py" "$R/gpurun_out/prof_timed" 'sell_vprep_kernel<int>|sell_mxv_dual_kernel<int, splahip::StaBin<13>, splahip::StaBin<12> >|sell_post_kernel<int' 30 "$R/gpurun_out/prof_timed_bench.json" | tee "$R/gpurun_out/prof_timed_summary.txt"
 echo "== rocprof pmc FETCH_SIZE"
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_fetch" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-variants > /dev/null 2> "$R/gpurun_out/pmc_fetch.err"; echo "pmc fetch exit $?"
 echo "== rocprof pmc WRITE_SIZE"
