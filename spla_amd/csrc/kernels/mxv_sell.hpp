@@ -134,7 +134,6 @@ namespace splahip {
         // call — no memset launch per call
         for (uint q = blockIdx.x * 256 + threadIdx.x; q < n_bit_quads; q += gridDim.x * 256) next_bits[q] = make_uint4(0, 0, 0, 0);
         // row selection as one bit per row (64 rows per wave and step, one 8-byte store)
-#if SPLAHIP_SELL_EXP != 21
         for (uint row = blockIdx.x * 256 + threadIdx.x; row < ((n_rows + kWave - 1) & ~(kWave - 1)); row += gridDim.x * 256) {
             const bool               sel = row < n_rows && eval_sel(op_select, mask[row]);
             const unsigned long long b   = __ballot(sel);
@@ -143,7 +142,6 @@ namespace splahip {
             // the integer atomic of op_add (row-exclusive slices, the cold list)
             if (row < n_rows) r[row] = init;
         }
-#endif
         // hot values of the value form: a gather by the plan's hot-column list (the rank of a column is only looked up where v is not 0:
         // the pass reads v once and, for a sparse v, almost nothing of rank_of — its cost must not grow with the padded column count of
         // a multi-GPU run)
@@ -161,9 +159,6 @@ namespace splahip {
         };
         // four columns per lane and step (16-byte loads; hipMalloc'ed operands are 256-byte aligned), tail by single columns
         const uint n4 = n_cols & ~3u;
-#if SPLAHIP_SELL_EXP == 22
-        if (false)
-#endif
         for (uint j = (blockIdx.x * 256 + threadIdx.x) * 4; j < n4; j += gridDim.x * 1024) {
             const uint4 x = *reinterpret_cast<const uint4*>(v + j);
             one(j, x.x), one(j + 1, x.y), one(j + 2, x.z), one(j + 3, x.w);
@@ -382,11 +377,7 @@ namespace splahip {
                         on[u]           = take;
                         if constexpr (BITS) {
                             const uint rank = jc[u];
-#if SPLAHIP_SELL_EXP == 10
-                            const uint a = 0xFFFFFFFFu;
-#else
                             const uint a = to_bits(s_hot[rank >> 5]);
-#endif
                             on[u] = take && ((a >> (rank & 31u)) & 1u) != 0;
                             vv[u] = cval;
                             continue;
@@ -425,9 +416,6 @@ namespace splahip {
                         has             = has || take;
                     }
                 }
-#if SPLAHIP_SELL_EXP == 11
-                if (selected && to_bits(acc) == 0x12345u) r[row] = acc;
-#else
                 if constexpr (BITS) {
                     if (chunk) {// a row-exclusive slice: the 64 lane results are one row's — fold them in the wave, one atomic into r[row]
                         bool pv = selected;
@@ -442,7 +430,6 @@ namespace splahip {
                     else
                         r[row] = acc;
                 }
-#endif
             }
 #ifdef SPLAHIP_SELL_TIMING
             SELL_NOW(t_d)
