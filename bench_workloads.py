@@ -84,7 +84,8 @@ def pagerank_vxm(args):
     del rows
     _log(f"[bench] pagerank-vxm stand-in: symmetrised R-MAT scale {scale} ef {ef}: n={n} nnz={nnz}")
     Tp, Tj, Tx = kernels.csr_transpose(n, n, Ap, Aj, Ax)
-    plan_T = kernels.CsrPlan(n, nnz, Tp)
+    use_sell = os.environ.get("SPLA_BENCH_PLAN", "sell") == "sell"  # sliced-ELL copy on the transposed matrix (its vxm mode) or the CSR kernels only
+    plan_T = kernels.CsrPlan(n, nnz, Tp, n, Tj, Tx) if use_sell else kernels.CsrPlan(n, nnz, Tp)
     vi = torch.arange(n, device="cuda", dtype=torch.int32)
     vx = torch.full((n,), 1.0 / n, device="cuda", dtype=torch.float32)
     mask = torch.zeros(n, device="cuda", dtype=torch.float32)  # the dummy mask of pr(): ALWAYS ignores it
@@ -101,8 +102,9 @@ def pagerank_vxm(args):
     line = _line("masked vxm GTEPS (PageRank step)", "GTEPS", nnz / (wall / args.steps) / 1e9, args, wall / args.steps * 1e3, "f32",
                  {"workload": f"exec_vxm_masked MULT/PLUS fp32, ALWAYS mask, every v entry stored; symmetrised R-MAT scale {scale} ef {ef} "
                               "(stand-in for com-Orkut, which is not on the box)", "n": n, "nnz": nnz, "out_entries": int(ri.numel()),
-                  "form": "pull over the transposed CSR (spmv_wavetile, VXM mode) + order-preserving compaction"},
-                 _roof(alg, ms, "spmv_wavetile<VXM> + compaction"))
+                  "form": ("pull over the sliced-ELL copy of the transposed matrix (sell_vxm: value form, vxm mode)" if use_sell else
+                           "pull over the transposed CSR (spmv_wavetile, VXM mode)") + " + order-preserving compaction"},
+                 _roof(alg, ms, ("sell_vxm" if use_sell else "spmv_wavetile<VXM>") + " + compaction"))
     if not args.no_verify:
         # structure: identical to the oracle's (same touched columns, index-sorted).  values: the oracle (= the reference) folds
         # every column sequentially in fp32; columns here have up to ~1e5 products, where that sequential fold itself is ~2e-5 off

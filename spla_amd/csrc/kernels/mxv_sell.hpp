@@ -65,11 +65,10 @@ namespace splahip {
 
     struct SellCfg {
         static constexpr uint kC       = 256;  // max entries per virtual row (chunk)
-#ifndef SPLAHIP_SELL_XL
-#define SPLAHIP_SELL_XL 256
-#endif
-        static constexpr uint kXL      = SPLAHIP_SELL_XL;// rows longer than this get ROW-EXCLUSIVE slices: 64 lanes x <= kC entries of one row,
-                                               // lane l holding entries l, l + 64, ... of the slice's 16 Ki-entry block (= the row in CSR order)
+        static constexpr uint kXL      = kC;   // rows longer than this get ROW-EXCLUSIVE slices: 64 lanes x <= kC entries of one row, lane l
+                                               // holding entries l, l + 64, ... of the slice's 16 Ki-entry block (= the row in CSR order).
+                                               // Must equal kC: a "partial" lane then always belongs to a row-exclusive slice (the bit form
+                                               // folds such a slice's lanes in the wave)
         static constexpr uint kHot     = 40000;// LDS-resident values of the gathered vector (156.25 KB of the 160 KB)
         static constexpr uint kTpb     = 1024; // one workgroup per CU
         static constexpr uint kWaves   = kTpb / kWave;
@@ -197,7 +196,10 @@ namespace splahip {
     // BITS = true : Aj2 holds ranks, s_hot the hot BITS (vbits), cold ranks read the global bitmap, set bits take const_bits or
     //               gather vranked; `gate` (the statistics) != nullptr makes the launch a no-op unless its form is the chosen one.
     // The slice walk of one workgroup.  s_hot / s_next live in the calling kernel (the two forms share one LDS allocation).
-    template<typename T, class Mult, class Add, bool BITS>
+    // VXM (value form only): the pull form of vxm over the transposed matrix with EVERY index of v stored — products are mult(v, x),
+    // a row folds from its first product (no init) and touched[row] tells whether the output entry exists (reference
+    // src/cpu/cpu_vxm.hpp:101-107); r is only written for touched rows.
+    template<typename T, class Mult, class Add, bool BITS, bool VXM = false>
     __device__ __forceinline__ void sell_mxv_body(T* s_hot, uint* s_next_p, uint n_rows, const uint* __restrict__ Ap, uint n_slices,
                                                   const uint* __restrict__ vrow, const uint* __restrict__ vlen,
                                                   const uint* __restrict__ vslot, const uint* __restrict__ off,
@@ -208,8 +210,10 @@ namespace splahip {
                                                   Mult mult, Add add, int op_select, T init,
                                                   bool is_const, uint cbits,
                                                   const uint* __restrict__ vbits, const uint* __restrict__ vranked,
-                                                  const uint* __restrict__ selbits, const uint* __restrict__ sorder) {
+                                                  const uint* __restrict__ selbits, const uint* __restrict__ sorder,
+                                                  uint* __restrict__ touched = nullptr) {
         using C = SellCfg;
+        static_assert(!(BITS && VXM), "the pull form of vxm uses the value form");
         uint& s_next = *s_next_p;// next of this workgroup's slices nobody has taken yet (ordinal)
 
         const bool always = op_select == SPLAHIP_ALWAYS;
@@ -245,10 +249,18 @@ namespace splahip {
                     const uint mm[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
                     for (uint i = 0; i < 4; ++i)
-                        if (b[i + 1] == b[i] || (!always && !eval_sel(op_select, from_bits<T>(mm[i])))) r[row + i] = init;
+                        if (b[i + 1] == b[i] || (!always && !eval_sel(op_select, from_bits<T>(mm[i])))) {
+                            if constexpr (VXM) touched[row + i] = 0;
+                            else
+                                r[row + i] = init;
+                        }
                 } else {
                     for (uint i = row; i < re; ++i)
-                        if (Ap[i + 1] == Ap[i] || (!always && !eval_sel(op_select, mask[i]))) r[i] = init;
+                        if (Ap[i + 1] == Ap[i] || (!always && !eval_sel(op_select, mask[i]))) {
+                            if constexpr (VXM) touched[i] = 0;
+                            else
+                                r[i] = init;
+                        }
                 }
             }
         }
@@ -347,7 +359,7 @@ namespace splahip {
                 // chunks are sorted by length: the first selected lane holds the longest selected chunk
                 const uint width = __builtin_amdgcn_readlane(mylen, __ffsll((long long) live) - 1);
                 T          acc   = init;
-                bool       has   = !chunk;// a row's only chunk folds from init; chunks of a long row fold from their first product
+                bool       has   = !chunk && !VXM;// a row's only chunk folds from init (mxv); chunks of a long row and vxm rows fold from their first product
                 if constexpr (BITS) {// a chunk may hold no product at all: its partial is then op_add's identity (0 for every BITS semiring)
                     if (chunk) acc = T(0);
                     has = true;
@@ -410,7 +422,7 @@ namespace splahip {
 #pragma unroll
                     for (uint u = 0; u < C::kU; ++u) {
                         const bool take = on[u];
-                        const T    p    = mult(from_bits<T>(xc[u]), vv[u]);
+                        const T    p    = VXM ? mult(vv[u], from_bits<T>(xc[u])) : mult(from_bits<T>(xc[u]), vv[u]);
                         const T    both = add(acc, p);
                         acc             = take ? (has ? both : p) : acc;
                         has             = has || take;
@@ -427,8 +439,10 @@ namespace splahip {
                     }
                 } else if (selected) {
                     if (chunk) partial[vslot[s_cur * kWave + lane]] = acc;
-                    else
+                    else {
                         r[row] = acc;
+                        if constexpr (VXM) touched[row] = 1;
+                    }
                 }
             }
 #ifdef SPLAHIP_SELL_TIMING
@@ -460,6 +474,26 @@ namespace splahip {
         __shared__ uint s_next;
         sell_mxv_body<T, Mult, Add, false>(s_hot, &s_next, n_rows, Ap, n_slices, vrow, vlen, vslot, off, Aj2, Ax2, hot_values, n_hot, mask, v, r, partial, mult, add,
                                            op_select, init, false, 0u, nullptr, nullptr, nullptr, sorder);
+    }
+
+    // the pull form of vxm (identity: every index of v stored) over the sliced-ELL copy of the TRANSPOSED matrix
+    template<typename T, class Mult, class Add>
+    __global__ __launch_bounds__(SellCfg::kTpb) void sell_vxm_kernel(uint n_rows, const uint* __restrict__ Ap, uint n_slices, const uint* __restrict__ vrow,
+                                                                     const uint* __restrict__ vlen, const uint* __restrict__ vslot, const uint* __restrict__ off,
+                                                                     const uint* __restrict__ Aj2, const uint* __restrict__ Ax2, const T* __restrict__ hot_values,
+                                                                     uint n_hot, const T* __restrict__ mask, const T* __restrict__ v, T* __restrict__ r,
+                                                                     uint* __restrict__ touched, T* __restrict__ partial, Mult mult, Add add, int op_select,
+                                                                     const uint* __restrict__ sorder) {
+        __shared__ T    s_hot[SellCfg::kHot];
+        __shared__ uint s_next;
+        sell_mxv_body<T, Mult, Add, false, true>(s_hot, &s_next, n_rows, Ap, n_slices, vrow, vlen, vslot, off, Aj2, Ax2, hot_values, n_hot, mask, v, r, partial,
+                                                 mult, add, op_select, T(0), false, 0u, nullptr, nullptr, nullptr, sorder, touched);
+    }
+    template<typename T, class Add>
+    __global__ __launch_bounds__(256) void sell_vxm_combine_kernel(uint n_lrows, const uint* __restrict__ lr_row, const uint* __restrict__ lr_first,
+                                                                   const T* __restrict__ partial, const T* __restrict__ mask, T* __restrict__ r,
+                                                                   uint* __restrict__ touched, Add add, int op_select) {
+        sell_combine_block<T, Add, true>(blockIdx.x, n_lrows, lr_row, lr_first, partial, mask, r, add, op_select, T(0), touched);
     }
 
     // both forms in one launch: wave 0 of every workgroup reads sell_vprep's statistics (12-48 KB; all 4096 waves doing so cost
@@ -524,14 +558,14 @@ namespace splahip {
 
     // rows longer than kC: r[row] = init (+) partial[first] (+) partial[first + 1] ... in chunk order.  One wave per row: lane l
     // folds a contiguous run of the row's partials, then an in-order wave reduction joins the runs (associative op_add).
-    template<typename T, class Add>
+    template<typename T, class Add, bool VXM = false>
     __device__ __forceinline__ void sell_combine_block(uint block, uint n_lrows, const uint* __restrict__ lr_row, const uint* __restrict__ lr_first,
                                                        const T* __restrict__ partial, const T* __restrict__ mask, T* __restrict__ r, Add add, int op_select,
-                                                       T init) {
+                                                       T init, uint* __restrict__ touched = nullptr) {
         const uint i = block * (256 / kWave) + threadIdx.x / kWave;
         if (i >= n_lrows) return;
         const uint row = lr_row[i];
-        if (!eval_sel(op_select, mask[row])) return;// the main kernel's row pass wrote init
+        if (!eval_sel(op_select, mask[row])) return;// the main kernel's row pass wrote init (vxm: touched = 0)
         const uint k0 = lr_first[i], k1 = lr_first[i + 1];
         const uint c  = (k1 - k0 + kWave - 1) / kWave;
         const uint ks = k0 + lane_id() * c, ke = min(k1, ks + c);
@@ -542,7 +576,14 @@ namespace splahip {
             valid = true;
         }
         wave_reduce_ordered(acc, valid, add);
-        if (lane_id() == 0) r[row] = valid ? add(init, acc) : init;
+        if (lane_id() == 0) {
+            if constexpr (VXM) {// every lane of a long row holds an entry, and every entry is a product: the row is touched
+                r[row]       = acc;
+                touched[row] = 1;
+            } else {
+                r[row] = valid ? add(init, acc) : init;
+            }
+        }
     }
 
     // value-form calls of semirings the bit form cannot serve: the long rows' partials

@@ -59,7 +59,11 @@ struct splahip_plan_s {
 
 namespace splahip {
     void sell_release(splahip_sell_s* sell);
-    bool sell_zero_skippable(int type, int op_mult, int op_add);// may the sparse-vector (BITS) form serve this semiring
+    bool sell_zero_skippable(int type, int op_mult, int op_add);
+    // the pull form of vxm with every index of v stored, over the sliced-ELL copy attached to the TRANSPOSED matrix's plan: out values and
+    // touched flags per output column (associative + commutative op_add); returns a SPLAHIP status
+    int sell_vxm(const splahip_plan_s* plan_T, int type, const uint32_t* Tp, const void* mask, const void* v, void* out, uint32_t* touched, int op_mult,
+                 int op_add, int op_select, void* stream);// may the sparse-vector (BITS) form serve this semiring
     // the sliced-ELL masked SpMV (associative op_add, no early exit); returns a SPLAHIP status
     int sell_mxv(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
                  uint32_t init_bits, void* stream);

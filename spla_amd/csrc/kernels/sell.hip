@@ -321,6 +321,36 @@ namespace {
 
 }// namespace
 
+namespace {
+    template<typename T, class Mult, class Add>
+    int launch_sell_vxm(const splahip_plan_s* plan, const uint32_t* Tp, const void* mask, const void* v, void* out, uint32_t* touched, int op_mult, int op_add,
+                        int op_select, hipStream_t st) {
+        const splahip_sell_s* g = plan->sell;
+        hipLaunchKernelGGL((sell_hot_pack_kernel<T>), dim3((g->n_hot + 255) / 256), dim3(256), 0, st, g->d_hot_cols, g->n_hot, static_cast<const T*>(v),
+                           reinterpret_cast<T*>(g->d_hot_vals));
+        hipLaunchKernelGGL((sell_vxm_kernel<T, Mult, Add>), dim3(compute_units()), dim3(SC::kTpb), 0, st, plan->n_rows, Tp, g->n_slices, g->d_vrow, g->d_vlen,
+                           g->d_vslot, g->d_off, g->d_Aj2, g->d_Ax2, reinterpret_cast<const T*>(g->d_hot_vals), g->n_hot, static_cast<const T*>(mask),
+                           static_cast<const T*>(v), static_cast<T*>(out), touched, reinterpret_cast<T*>(g->d_partial), Mult(op_mult), Add(op_add), op_select,
+                           g->d_sorder);
+        SPLAHIP_TRY(hipGetLastError());
+        if (g->n_lrows) {
+            hipLaunchKernelGGL((sell_vxm_combine_kernel<T, Add>), dim3((g->n_lrows + 3) / 4), dim3(256), 0, st, g->n_lrows, g->d_lr_row, g->d_lr_first,
+                               reinterpret_cast<const T*>(g->d_partial), static_cast<const T*>(mask), static_cast<T*>(out), touched, Add(op_add), op_select);
+            SPLAHIP_TRY(hipGetLastError());
+        }
+        return SPLAHIP_OK;
+    }
+    template<typename T>
+    int sell_vxm_typed(const splahip_plan_s* plan, const uint32_t* Tp, const void* mask, const void* v, void* out, uint32_t* touched, int op_mult, int op_add,
+                       int op_select, hipStream_t st) {
+        if (op_mult == SPLAHIP_MULT && op_add == SPLAHIP_PLUS)
+            return launch_sell_vxm<T, StaBin<SPLAHIP_MULT>, StaBin<SPLAHIP_PLUS>>(plan, Tp, mask, v, out, touched, op_mult, op_add, op_select, st);
+        if (op_mult == SPLAHIP_PLUS && op_add == SPLAHIP_MIN)
+            return launch_sell_vxm<T, StaBin<SPLAHIP_PLUS>, StaBin<SPLAHIP_MIN>>(plan, Tp, mask, v, out, touched, op_mult, op_add, op_select, st);
+        return launch_sell_vxm<T, DynBin, DynBin>(plan, Tp, mask, v, out, touched, op_mult, op_add, op_select, st);
+    }
+}// namespace
+
 namespace splahip {
 
     bool sell_zero_skippable(int type, int op_mult, int op_add) {
@@ -337,6 +367,17 @@ namespace splahip {
             if (p) (void) hipFree(p);
         if (g->d_cold_entry) (void) hipFree(g->d_cold_entry);
         delete g;
+    }
+
+    int sell_vxm(const splahip_plan_s* plan_T, int type, const uint32_t* Tp, const void* mask, const void* v, void* out, uint32_t* touched, int op_mult,
+                 int op_add, int op_select, void* stream) {
+        hipStream_t st = as_stream(stream);
+        switch (type) {
+            case SPLAHIP_INT: return sell_vxm_typed<int32_t>(plan_T, Tp, mask, v, out, touched, op_mult, op_add, op_select, st);
+            case SPLAHIP_UINT: return sell_vxm_typed<uint32_t>(plan_T, Tp, mask, v, out, touched, op_mult, op_add, op_select, st);
+            case SPLAHIP_FLOAT: return sell_vxm_typed<float>(plan_T, Tp, mask, v, out, touched, op_mult, op_add, op_select, st);
+        }
+        return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
     }
 
     int sell_mxv(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,

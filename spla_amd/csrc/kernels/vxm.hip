@@ -469,7 +469,13 @@ namespace splahip {
         if (((reinterpret_cast<uintptr_t>(Tj) | reinterpret_cast<uintptr_t>(Tx)) & 15u) != 0)
             return fail(SPLAHIP_INVALID_ARGUMENT, "the transposed CSR arrays must be 16-byte aligned");
         const uint grid   = (plan->n_items + Cfg::kWaves - 1) / Cfg::kWaves;
-        if (plan->n_items) {
+        // every index of v stored + a sliced-ELL copy on the transposed matrix's plan: the value-form kernel in its vxm mode
+        const char* sell_env = std::getenv("SPLAHIP_SELL");
+        if (plan->sell && v_is_identity && plan->sell->n_cols == n_in && !(sell_env && sell_env[0] == '0') &&
+            ((reinterpret_cast<uintptr_t>(Tp) | reinterpret_cast<uintptr_t>(mask)) & 15u) == 0) {
+            int st = sell_vxm(plan, TypeId<T>::value, Tp, mask, d_v, ws_outv, ws_touched, op_mult, op_add, op_select, s);
+            if (st != SPLAHIP_OK) return st;
+        } else if (plan->n_items) {
             hipLaunchKernelGGL((spmv_wavetile_kernel<Cfg, T, Mult, Add, true>), dim3(grid), dim3(Cfg::kTpb), 0, s,
                                plan->d_item_row, plan->d_item_k0, plan->n_items, Tp, Tj, static_cast<const uint*>(Tx),
                                static_cast<const T*>(mask), d_v, d_present, reinterpret_cast<T*>(ws_outv), ws_touched,

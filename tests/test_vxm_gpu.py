@@ -22,12 +22,13 @@ def _push(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel):
     return host(ri, np.uint32), host(rx, NP[t])
 
 
-def _pull(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel, identity=False):
+def _pull(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel, identity=False, sell=False):
+    """sell: attach the sliced-ELL copy to the transposed matrix's plan (served by its vxm mode when every index of v is stored)"""
     from gpu_utils import dev, host
     from spla_amd import kernels
     dAp, dAj, dAx = dev(Ap), dev(Aj), dev(np.asarray(Ax, NP[t]))
     Tp, Tj, Tx = kernels.csr_transpose(n_rows, n_cols, dAp, dAj, dAx)
-    plan = kernels.CsrPlan(n_cols, len(Aj), Tp)
+    plan = kernels.CsrPlan(n_cols, len(Aj), Tp, n_rows, Tj, Tx) if sell else kernels.CsrPlan(n_cols, len(Aj), Tp)
     ri, rx = kernels.vxm_pull(plan, t, n_rows, n_cols, Tp, Tj, Tx, dev(np.asarray(mask, NP[t])), dev(np.asarray(vi, np.uint32)),
                               dev(np.asarray(vx, NP[t])), mul, add, sel, identity=identity)
     return host(ri, np.uint32), host(rx, NP[t])
@@ -82,16 +83,17 @@ def test_pull_commutative_cells(oracle, t):
     for k, (mul, add) in enumerate(sems):
         sel = SELECTS[k % len(SELECTS)]
         mask = random_mask(rng, n_cols, t)
-        nv = n_rows if k % 4 == 0 else int(rng.integers(1, n_rows))
+        nv = n_rows if k % 2 == 0 else int(rng.integers(1, n_rows))
         vi = np.sort(rng.permutation(n_rows)[:nv]).astype(np.uint32)
         vx = random_values(rng, nv, t, zeros=0.2)
         want = oracle.vxm_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel)
-        got = _pull(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel, identity=(nv == n_rows))
-        np.testing.assert_array_equal(got[0], want[0], err_msg=f"{t} {mul}/{add} {sel} idx")
-        if t == "FLOAT" and add in ("PLUS", "MULT"):
-            np.testing.assert_allclose(got[1], want[1], rtol=FP32_RTOL, err_msg=f"{t} {mul}/{add}")
-        else:
-            np.testing.assert_array_equal(got[1].view(np.uint32), want[1].view(np.uint32), err_msg=f"{t} {mul}/{add} {sel} val")
+        for form in ((False, True) if nv == n_rows else (False,)):  # the sliced-ELL vxm mode serves the identity case
+            got = _pull(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel, identity=(nv == n_rows), sell=form)
+            np.testing.assert_array_equal(got[0], want[0], err_msg=f"{t} {mul}/{add} {sel} idx sell={form}")
+            if t == "FLOAT" and add in ("PLUS", "MULT"):
+                np.testing.assert_allclose(got[1], want[1], rtol=FP32_RTOL, err_msg=f"{t} {mul}/{add} sell={form}")
+            else:
+                np.testing.assert_array_equal(got[1].view(np.uint32), want[1].view(np.uint32), err_msg=f"{t} {mul}/{add} {sel} val sell={form}")
 
 
 def test_vxm_naive_reference_case_through_api():
