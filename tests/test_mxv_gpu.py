@@ -242,3 +242,35 @@ def test_sparse_input_vector_cold_ranks(oracle):
         want = oracle.mxv_masked("INT", n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
         got = hip_mxv("INT", n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
         assert_same(got, want, "INT", what=f"cold ranks {mul}/{add}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", ["INT", "FLOAT"])
+def test_row_lengths_at_the_slice_boundaries(oracle, t):
+    """rows of exactly 255 / 256 / 257 entries (last single-chunk row, first row-exclusive slice), around one 64 x 256 = 16,384-entry
+    block of a row-exclusive slice (partly filled last lanes, a second slice of one entry) and a 40,000-entry row; value form, bit form
+    and the CSR kernels against the oracle, masks that select / skip exactly those rows"""
+    from gpu_utils import hip_mxv
+    rng = np.random.default_rng(303)
+    lens = [255, 256, 257, 319, 320, 321, 511, 512, 513, 16383, 16384, 16385, 16447, 16448, 16449, 40000, 1, 0, 64, 63, 65]
+    n_cols = 41000
+    n_rows = len(lens) * 3
+    degs = np.zeros(n_rows, np.int64)
+    degs[::3] = lens                       # the special rows, separated by short / empty ones
+    degs[1::3] = rng.integers(0, 6, len(lens))
+    Ap = np.zeros(n_rows + 1, np.uint32)
+    np.cumsum(degs, out=Ap[1:])
+    Aj = np.concatenate([np.sort(rng.choice(n_cols, size=int(d), replace=False)) for d in degs if d]).astype(np.uint32)
+    Ax = random_values(rng, len(Aj), t)
+    if t == "INT":
+        Ax[Ax == 0] = 1
+    v_dense = random_values(rng, n_cols, t, zeros=0.1)
+    v_sparse = np.where(rng.random(n_cols) < 0.02, 1, 0).astype(NP[t])
+    cells = [("MULT", "PLUS", "ALWAYS", 0, v_dense), ("PLUS", "MIN", "NQZERO", 1 << 20, v_dense), ("MULT", "PLUS", "EQZERO", 7, v_sparse)]
+    if t == "INT":
+        cells += [("BAND", "BOR", "EQZERO", 0, v_sparse), ("BAND", "BOR", "ALWAYS", 3, v_dense)]
+    for mul, add, sel, init, v in cells:
+        for mask in (random_mask(rng, n_rows, t), np.zeros(n_rows, NP[t]), np.ones(n_rows, NP[t])):
+            want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
+            got = hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init, junk=-5)
+            assert_same(got, want, t, what=f"{t} {mul}/{add}/{sel}")
