@@ -186,7 +186,7 @@ namespace spla {
                 }
                 if (products == 0) return Status::Ok;
 
-                const bool can_pull = sorted && op_assoc_comm(op_add);
+                const bool can_pull = sorted && op_assoc_comm(op_add) && !(TypeTraits<T>::id == SPLAHIP_FLOAT && op_add == SPLAHIP_MULT);// (fp32 products: left fold only)
                 const bool pull     = can_pull && products * 8ull >= a->values;// push costs ~9x the products, pull costs nnz(M)
                 if (pull) {
                     auto*     tr       = ensure_transpose<T>(M.get());

@@ -344,7 +344,7 @@ namespace splahip {
         SPLAHIP_TRY(hipStreamSynchronize(s));
         if (h_heavy) {
             const uint grid = (h_heavy + 3) / 4;
-            if (binop_is_associative(op_add))
+            if (fold_is_reorderable(op_add, TypeId<T>::value))
                 hipLaunchKernelGGL((mxmT_heavy_kernel<T, DynBin, DynBin, true>), dim3(grid), dim3(256), 0, s, n_rows, hcount.as<uint>(), hlist.as<uint>(),
                                    Mp, Mj, Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(), keep.as<uint>(),
                                    DynBin(op_mult), DynBin(op_add), init);
@@ -718,7 +718,7 @@ namespace splahip {
                 SPLAHIP_TRY(hipStreamSynchronize(s));
                 if (h_long) {
                     const uint grid = (h_long + 3) / 4;
-                    if (binop_is_associative(op_add))
+                    if (fold_is_reorderable(op_add, TypeId<T>::value))
                         hipLaunchKernelGGL((mxm_long_run_kernel<T, K, DynBin, true>), dim3(grid), dim3(256), 0, s, key_b.as<K>(), val_b.as<T>(), n_products,
                                            lcount.as<uint>(), lpos.as<uint>(), run_rank.as<uint>(), run_val.as<T>(), run_keep.as<uint>(), DynBin(op_add), init);
                     else

@@ -48,7 +48,7 @@ namespace {
             const char* e = std::getenv("SPLAHIP_FORCE_ROWSEQ");
             if (e && e[0] == '1') return Variant::RowSeq;
         }
-        if (!binop_is_associative(op_add) || !binop_is_commutative(op_add)) return Variant::RowSeq;
+        if (!fold_is_reorderable(op_add, type) || !binop_is_commutative(op_add)) return Variant::RowSeq;
         return static_semiring(type, op_mult, op_add) ? Variant::WaveTileStatic : Variant::WaveTileDynamic;
     }
 
@@ -206,7 +206,7 @@ int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_items, uint32_t* n_long
 }
 
 const char* splahip_mxv_variant_of(splahip_plan plan, int type, int op_mult, int op_add, int early_exit) {
-    if (plan && plan->sell && !early_exit && binop_is_associative(op_add) && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add)) && !sell_disabled()) {
+    if (plan && plan->sell && !early_exit && fold_is_reorderable(op_add, type) && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add)) && !sell_disabled()) {
         if (sell_zero_skippable(type, op_mult, op_add))// the device picks the bit form or the value form from the input vector's statistics
             return static_semiring(type, op_mult, op_add) ? "mxv_sell<static semiring; sparse-vector bit form | value form>" : "mxv_sell<runtime ops; sparse-vector bit form | value form>";
         return static_semiring(type, op_mult, op_add) ? "mxv_sell<static semiring>" : "mxv_sell<runtime ops>";
@@ -243,7 +243,7 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
     // the sliced-ELL copy (splahip_csr_plan_attach_sell) serves every associative op_add without early exit; its lanes fold in
     // entry order, so op_add need not be commutative.  SPLAHIP_SELL=0 keeps the CSR kernels (A/B runs, tests).
     // (rows with row-exclusive slices are folded lane-strided: then op_add must be commutative too — FIRST / SECOND keep the row kernel)
-    if (plan->sell && !early_exit && binop_is_associative(op_add) && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add)) &&
+    if (plan->sell && !early_exit && fold_is_reorderable(op_add, type) && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add)) &&
         plan->sell->n_cols == n_cols && !sell_disabled() && d_r != d_mask && d_r != d_v &&// (its prep pass writes r before the kernel reads mask / v)
         ((reinterpret_cast<uintptr_t>(d_Ap) | reinterpret_cast<uintptr_t>(d_mask) | reinterpret_cast<uintptr_t>(d_v)) & 15u) == 0)// 16-byte loads of Ap / mask / v
         return sell_mxv(plan, type, d_Ap, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, stream);

@@ -224,6 +224,12 @@ namespace splahip {
             default: return true;
         }
     }
+    // may a kernel fold with this op_add in another association than the reference's left fold?  Associativity — except fp32 MULT: a
+    // tree of products overflows to inf (or underflows to 0) where the sequential fold does not (a row of 600 values around 2 under
+    // init 0: the reference keeps 0, a tree reaches 0 x inf = NaN), which no rounding tolerance covers.  fp32 PLUS differs by rounding
+    // only (the stated 1e-5 bar).
+    inline bool fold_is_reorderable(int op, int type) { return binop_is_associative(op) && !(type == SPLAHIP_FLOAT && op == SPLAHIP_MULT); }
+
     inline bool binop_is_commutative(int op) {
         switch (op) {
             case SPLAHIP_MINUS:

@@ -346,7 +346,7 @@ namespace splahip {
         T*    out     = mem.as<T>();
         T*    partial = out + 1;
         uint* ok      = reinterpret_cast<uint*>(partial + blocks);
-        if (binop_is_associative(op) && binop_is_commutative(op)) {
+        if (fold_is_reorderable(op, TypeId<T>::value) && binop_is_commutative(op)) {
             hipLaunchKernelGGL(reduce_partial_kernel<T>, dim3(blocks), dim3(256), 0, s, n, static_cast<const T*>(x), partial, ok, DynBin(op));
             hipLaunchKernelGGL(reduce_final_kernel<T>, dim3(1), dim3(256), 0, s, blocks, partial, ok, from_bits<T>(s_bits), out, DynBin(op));
         } else {

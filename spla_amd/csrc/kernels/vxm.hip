@@ -629,7 +629,7 @@ namespace splahip {
                            chunk, ri, static_cast<T*>(rx), lcount, lpos, lrank, DynBin(op_add));
         // the long-run pass is launched for the worst case and sizes itself from the device-side counter (no read-back in between)
         const uint grid = (max_long + 3) / 4;
-        if (binop_is_associative(op_add))
+        if (fold_is_reorderable(op_add, TypeId<T>::value))
             hipLaunchKernelGGL((long_run_kernel<T, DynBin, true>), dim3(grid), dim3(256), 0, s, key_b, reinterpret_cast<const T*>(val_b), n_products, lcount, lpos,
                                lrank, static_cast<T*>(rx), DynBin(op_add));
         else
@@ -727,8 +727,8 @@ int splahip_vxm_pull(splahip_plan plan_T, int type, uint32_t n_rows, uint32_t n_
     SPLAHIP_REQUIRE(plan_T != nullptr && h_count != nullptr, "null argument");
     SPLAHIP_REQUIRE(plan_T->n_rows == n_cols, "plan_T must be the plan of the transposed matrix (n_cols rows)");
     SPLAHIP_REQUIRE(binop_valid_for(op_mult, type) && binop_valid_for(op_add, type), "op not defined for this type");
-    SPLAHIP_REQUIRE(binop_is_associative(op_add) && binop_is_commutative(op_add),
-                    "the pull form needs an associative and commutative op_add (use splahip_vxm_push)");
+    SPLAHIP_REQUIRE(fold_is_reorderable(op_add, type) && binop_is_commutative(op_add),
+                    "the pull form needs an op_add that may be folded in any order: associative, commutative, not an fp32 MULT (use splahip_vxm_push)");
     *h_count = 0;
     if (n_cols == 0) return SPLAHIP_OK;
     int st = ensure_device();

@@ -274,3 +274,24 @@ def test_row_lengths_at_the_slice_boundaries(oracle, t):
             want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
             got = hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init, junk=-5)
             assert_same(got, want, t, what=f"{t} {mul}/{add}/{sel}")
+
+
+@pytest.mark.gpu
+def test_fp32_product_monoid_keeps_the_left_fold(oracle):
+    """op_add = MULT in fp32: a tree of 600 factors around 2 overflows to inf (and 0 x inf = NaN) where the reference's left fold from
+    init 0 stays 0 — no tolerance covers that, so the kernels must fold such rows strictly left to right (found by tools/exp/fuzz_mxv.py)"""
+    from gpu_utils import hip_mxv
+    rng = np.random.default_rng(404)
+    n_rows, n_cols = 300, 5000
+    degs = rng.integers(1, 40, n_rows)
+    degs[::10] = rng.integers(300, 900, len(degs[::10]))
+    Ap = np.zeros(n_rows + 1, np.uint32)
+    np.cumsum(degs, out=Ap[1:])
+    Aj = np.concatenate([np.sort(rng.choice(n_cols, size=int(d), replace=False)) for d in degs]).astype(np.uint32)
+    Ax = (rng.integers(24, 64, len(Aj)) / 16.0).astype(np.float32)       # 1.5 .. 4
+    v = (rng.integers(16, 48, n_cols) / 16.0).astype(np.float32)          # 1 .. 3
+    for init in (0.0, 1.0, 1e-30):
+        mask = random_mask(rng, n_rows, "FLOAT")
+        want = oracle.mxv_masked("FLOAT", n_rows, n_cols, Ap, Aj, Ax, mask, v, "MULT", "MULT", "ALWAYS", init)
+        got = hip_mxv("FLOAT", n_rows, n_cols, Ap, Aj, Ax, mask, v, "MULT", "MULT", "ALWAYS", init)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), init

@@ -79,7 +79,8 @@ def test_pull_commutative_cells(oracle, t):
     rng = np.random.default_rng(37)
     n_rows, n_cols = 1700, 1300
     Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 9, t, skew=True, long_rows=2, long_len=1200)
-    sems = [s for s in SEMIRINGS_COMMON + (SEMIRINGS_INT if t != "FLOAT" else [])]
+    # (fp32 MULT as op_add is not reorderable — a tree of products overflows where the left fold does not — and is refused by the pull form)
+    sems = [s for s in SEMIRINGS_COMMON + (SEMIRINGS_INT if t != "FLOAT" else []) if not (t == "FLOAT" and s[1] == "MULT")]
     for k, (mul, add) in enumerate(sems):
         sel = SELECTS[k % len(SELECTS)]
         mask = random_mask(rng, n_cols, t)
