@@ -245,7 +245,7 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
     // (rows with row-exclusive slices are folded lane-strided: then op_add must be commutative too — FIRST / SECOND keep the row kernel)
     if (plan->sell && !early_exit && fold_is_reorderable(op_add, type) && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add)) &&
         plan->sell->n_cols == n_cols && !sell_disabled() && d_r != d_mask && d_r != d_v &&// (its prep pass writes r before the kernel reads mask / v)
-        ((reinterpret_cast<uintptr_t>(d_Ap) | reinterpret_cast<uintptr_t>(d_mask) | reinterpret_cast<uintptr_t>(d_v)) & 15u) == 0)// 16-byte loads of Ap / mask / v
+        ((reinterpret_cast<uintptr_t>(d_Ap) | reinterpret_cast<uintptr_t>(d_mask) | reinterpret_cast<uintptr_t>(d_v) | reinterpret_cast<uintptr_t>(d_r)) & 15u) == 0)// 16-byte accesses of Ap / mask / v / r
         return sell_mxv(plan, type, d_Ap, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, stream);
     switch (type) {
         case SPLAHIP_INT:

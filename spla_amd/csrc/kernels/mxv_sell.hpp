@@ -132,14 +132,31 @@ namespace splahip {
         // the bitmap is double-buffered: this call fills `vbits` (cleared by the previous call) and clears the other one for the next
         // call — no memset launch per call
         for (uint q = blockIdx.x * 256 + threadIdx.x; q < n_bit_quads; q += gridDim.x * 256) next_bits[q] = make_uint4(0, 0, 0, 0);
-        // row selection as one bit per row (64 rows per wave and step, one 8-byte store)
-        for (uint row = blockIdx.x * 256 + threadIdx.x; row < ((n_rows + kWave - 1) & ~(kWave - 1)); row += gridDim.x * 256) {
-            const bool               sel = row < n_rows && eval_sel(op_select, mask[row]);
-            const unsigned long long b   = __ballot(sel);
-            if (lane_id() == 0) selbits[row / kWave] = b;
-            // every row starts at init: the bit form has no row pass; its slice lanes overwrite (rows of one chunk) or fold into it with
-            // the integer atomic of op_add (row-exclusive slices, the cold list)
-            if (row < n_rows) r[row] = init;
+        // row selection as one bit per row, and init into every row.  Four consecutive rows per lane (16-byte load and store): a lane's
+        // four bits sit at positions 4 l .. 4 l + 3 of its wave's 256-row string; the 16 lanes of a 64-bit word OR their nibbles together
+        // with four shuffles and the group's first lane stores the word.  (mask and r are 16-byte aligned: the dispatch checks it.)
+        {
+            const uint4 init4 = make_uint4(to_bits(init), to_bits(init), to_bits(init), to_bits(init));
+            const uint  span  = (n_rows + 255u) & ~255u;// whole 256-row wave steps
+            for (uint row = (blockIdx.x * 256 + threadIdx.x) * 4; row < span; row += gridDim.x * 1024) {
+                uint nib = 0;
+                if (row + 4 <= n_rows) {
+                    const uint4 m                       = *reinterpret_cast<const uint4*>(mask + row);
+                    *reinterpret_cast<uint4*>(r + row) = init4;
+                    nib = (eval_sel(op_select, from_bits<T>(m.x)) ? 1u : 0u) | (eval_sel(op_select, from_bits<T>(m.y)) ? 2u : 0u) |
+                          (eval_sel(op_select, from_bits<T>(m.z)) ? 4u : 0u) | (eval_sel(op_select, from_bits<T>(m.w)) ? 8u : 0u);
+                } else {
+                    for (uint i = 0; i < 4; ++i)
+                        if (row + i < n_rows) {
+                            r[row + i] = init;
+                            nib |= eval_sel(op_select, mask[row + i]) ? (1u << i) : 0u;
+                        }
+                }
+                unsigned long long wd = (unsigned long long) nib << (4u * (lane_id() & 15u));
+#pragma unroll
+                for (uint off = 1; off < 16; off <<= 1) wd |= __shfl_xor(wd, off, kWave);
+                if ((lane_id() & 15u) == 0) selbits[row / kWave] = wd;// row = first row of this 16-lane group: a multiple of 64
+            }
         }
         // hot values of the value form: a gather by the plan's hot-column list (the rank of a column is only looked up where v is not 0:
         // the pass reads v once and, for a sparse v, almost nothing of rank_of — its cost must not grow with the padded column count of

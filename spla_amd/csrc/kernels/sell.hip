@@ -502,7 +502,7 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     g->n_bit_words = ((std::max<uint32_t>((n_cols + 31) / 32, SC::kHot) + 3u) & ~3u);
     own(&g->d_vbits, 2 * (size_t) g->n_bit_words + 4 * SC::kPrepBlocks + 4);
     if (e == hipSuccess) e = hipMemsetAsync(g->d_vbits, 0, sizeof(uint32_t) * 2 * (size_t) g->n_bit_words, s);// both bitmaps start clear
-    own(&g->d_selbits, 2 * ((size_t) n_rows / 64 + 2));
+    own(&g->d_selbits, 2 * ((size_t) n_rows / 64 + 8));// 64-bit words, whole 256-row wave steps
     if (e == hipSuccess) e = hipMemsetAsync(count, 0, sizeof(uint32_t) * (size_t) n_cols, s);
     if (e != hipSuccess) return bail("hot-column arrays");
     hipLaunchKernelGGL(sell_col_count_kernel, dim3((nnz + 255) / 256), dim3(256), 0, s, d_Aj, nnz, count);
