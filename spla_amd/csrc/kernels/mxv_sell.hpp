@@ -162,24 +162,36 @@ namespace splahip {
         // the pass reads v once and, for a sparse v, almost nothing of rank_of — its cost must not grow with the padded column count of
         // a multi-GPU run)
         for (uint t = blockIdx.x * 256 + threadIdx.x; t < n_hot; t += gridDim.x * 256) hot_values[t] = v[hot_cols[t]];
-        uint            count = 0, notmin = 0, mx = 0;
-        auto            one   = [&](uint j, uint b) {
-            if (b != 0) {
-                const uint rank = rank_of[j];
-                atomicOr(&vbits[rank >> 5], 1u << (rank & 31u));
-                vranked[rank] = b;
-                count += 1;
-                notmin = max(notmin, ~b);
-                mx     = max(mx, b);
-            }
+        uint count = 0, notmin = 0, mx = 0;
+        // four columns per lane and step (16-byte loads; hipMalloc'ed operands are 256-byte aligned), tail by single columns.  The rank
+        // lookups of a lane's non-zero entries are requested together and the bit / value scatters are fire-and-forget: one round trip
+        // per step, not one per non-zero entry
+        auto step = [&](uint j, const uint (&b)[4], uint nb) {
+            uint rank[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint i = 0; i < 4; ++i)
+                if (i < nb && b[i] != 0) rank[i] = rank_of[j + i];
+#pragma unroll
+            for (uint i = 0; i < 4; ++i)
+                if (i < nb && b[i] != 0) {
+                    atomicOr(&vbits[rank[i] >> 5], 1u << (rank[i] & 31u));
+                    vranked[rank[i]] = b[i];
+                    count += 1;
+                    notmin = max(notmin, ~b[i]);
+                    mx     = max(mx, b[i]);
+                }
         };
-        // four columns per lane and step (16-byte loads; hipMalloc'ed operands are 256-byte aligned), tail by single columns
         const uint n4 = n_cols & ~3u;
         for (uint j = (blockIdx.x * 256 + threadIdx.x) * 4; j < n4; j += gridDim.x * 1024) {
-            const uint4 x = *reinterpret_cast<const uint4*>(v + j);
-            one(j, x.x), one(j + 1, x.y), one(j + 2, x.z), one(j + 3, x.w);
+            const uint4 x    = *reinterpret_cast<const uint4*>(v + j);
+            const uint  b[4] = {x.x, x.y, x.z, x.w};
+            step(j, b, 4);
         }
-        if (blockIdx.x == 0 && threadIdx.x < (n_cols & 3u)) one(n4 + threadIdx.x, to_bits(v[n4 + threadIdx.x]));
+        if (blockIdx.x == 0 && threadIdx.x == 0 && n4 < n_cols) {
+            uint b[4] = {0, 0, 0, 0};
+            for (uint i = 0; n4 + i < n_cols; ++i) b[i] = to_bits(v[n4 + i]);
+            step(n4, b, n_cols - n4);
+        }
         count  = wave_sum(count);
         notmin = wave_max(notmin);
         mx     = wave_max(mx);
