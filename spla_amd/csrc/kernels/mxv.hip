@@ -207,7 +207,7 @@ int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_items, uint32_t* n_long
 
 const char* splahip_mxv_variant_of(splahip_plan plan, int type, int op_mult, int op_add, int early_exit) {
     if (plan && plan->sell && !early_exit && fold_is_reorderable(op_add, type) && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add)) && !sell_disabled()) {
-        if (sell_zero_skippable(type, op_mult, op_add))// the device picks the bit form or the value form from the input vector's statistics
+        if (sell_skip_family(type, op_mult, op_add) != 0)// the device picks the bit form or the value form from the input vector's statistics
             return static_semiring(type, op_mult, op_add) ? "mxv_sell<static semiring; sparse-vector bit form | value form>" : "mxv_sell<runtime ops; sparse-vector bit form | value form>";
         return static_semiring(type, op_mult, op_add) ? "mxv_sell<static semiring>" : "mxv_sell<runtime ops>";
     }

@@ -110,12 +110,29 @@ namespace splahip {
         else
             return add.op;
     }
-    // the integer atomic of a bit-form op_add (BOR, PLUS, BXOR, uint MAX: sell_zero_skippable)
-    __device__ __forceinline__ void atomic_fold(uint* d, uint p, int op_add) {
+    // the atomic of a bit-form op_add: BOR, PLUS, BXOR, uint MAX (zero family) and MIN (min-plus family; fp32 through compare-and-swap with
+    // the reference's `b < a ? b : a`, so a NaN never replaces a number)
+    template<typename T>
+    __device__ __forceinline__ void atomic_fold(T* dst, T value, int op_add) {
+        uint*      d = reinterpret_cast<uint*>(dst);
+        const uint p = to_bits(value);
         switch (op_add) {
             case SPLAHIP_BOR: atomicOr(d, p); break;
             case SPLAHIP_BXOR: atomicXor(d, p); break;
             case SPLAHIP_MAX: atomicMax(d, p); break;
+            case SPLAHIP_MIN:
+                if constexpr (std::is_same<T, int32_t>::value) atomicMin(reinterpret_cast<int*>(d), (int) p);
+                else if constexpr (std::is_same<T, uint32_t>::value)
+                    atomicMin(d, p);
+                else {
+                    uint seen = __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while (value < from_bits<T>(seen)) {
+                        const uint prev = atomicCAS(d, seen, p);
+                        if (prev == seen) break;
+                        seen = prev;
+                    }
+                }
+                break;
             default: atomicAdd(d, p); break;// PLUS: two's complement, same bits for int and uint
         }
     }
@@ -127,7 +144,7 @@ namespace splahip {
                                                              const uint* __restrict__ hot_cols, T* __restrict__ hot_values, uint* __restrict__ vbits, uint* __restrict__ vranked,
                                                              uint* __restrict__ stats, uint n_rows, const T* __restrict__ mask, int op_select,
                                                              unsigned long long* __restrict__ selbits, uint4* __restrict__ next_bits, uint n_bit_quads,
-                                                             T* __restrict__ r, T init) {
+                                                             T* __restrict__ r, T init, uint skip) {
         __shared__ uint s_red[3][256 / kWave];
         // the bitmap is double-buffered: this call fills `vbits` (cleared by the previous call) and clears the other one for the next
         // call — no memset launch per call
@@ -170,10 +187,10 @@ namespace splahip {
             uint rank[4] = {0, 0, 0, 0};
 #pragma unroll
             for (uint i = 0; i < 4; ++i)
-                if (i < nb && b[i] != 0) rank[i] = rank_of[j + i];
+                if (i < nb && b[i] != skip) rank[i] = rank_of[j + i];
 #pragma unroll
             for (uint i = 0; i < 4; ++i)
-                if (i < nb && b[i] != 0) {
+                if (i < nb && b[i] != skip) {
                     atomicOr(&vbits[rank[i] >> 5], 1u << (rank[i] & 31u));
                     vranked[rank[i]] = b[i];
                     count += 1;
@@ -240,7 +257,7 @@ namespace splahip {
                                                   bool is_const, uint cbits,
                                                   const uint* __restrict__ vbits, const uint* __restrict__ vranked,
                                                   const uint* __restrict__ selbits, const uint* __restrict__ sorder,
-                                                  uint* __restrict__ touched = nullptr) {
+                                                  uint* __restrict__ touched = nullptr, T ident = T()) {
         using C = SellCfg;
         static_assert(!(BITS && VXM), "the pull form of vxm uses the value form");
         uint& s_next = *s_next_p;// next of this workgroup's slices nobody has taken yet (ordinal)
@@ -390,7 +407,7 @@ namespace splahip {
                 T          acc   = init;
                 bool       has   = !chunk && !VXM;// a row's only chunk folds from init (mxv); chunks of a long row and vxm rows fold from their first product
                 if constexpr (BITS) {// a chunk may hold no product at all: its partial is then op_add's identity (0 for every BITS semiring)
-                    if (chunk) acc = T(0);
+                    if (chunk) acc = ident;// (0 for the zero family; init for min-plus: min(init, x) is folded with init again anyway)
                     has = true;
                 }
                 for (uint e = 0; e < width; e += C::kU) {
@@ -462,7 +479,7 @@ namespace splahip {
                         bool pv = selected;
                         T    t  = acc;
                         wave_reduce_ordered(t, pv, add);
-                        if (lane == 0 && pv) atomic_fold(reinterpret_cast<uint*>(r + row), to_bits(t), functor_op(add));
+                        if (lane == 0 && pv) atomic_fold(r + row, t, functor_op(add));
                     } else if (selected) {
                         r[row] = acc;
                     }
@@ -536,7 +553,7 @@ namespace splahip {
                                                                           const T* __restrict__ mask, const T* __restrict__ v, T* __restrict__ r,
                                                                           T* __restrict__ partial, Mult mult, Add add, int op_select, T init, uint* __restrict__ stats,
                                                                           uint n_cols, int force, const uint* __restrict__ vbits, const uint* __restrict__ vranked,
-                                                                          const uint* __restrict__ selbits, const uint* __restrict__ sorder) {
+                                                                          const uint* __restrict__ selbits, const uint* __restrict__ sorder, T ident) {
         using C = SellCfg;
         static_assert(C::kBitWords <= C::kHot, "the two forms share one LDS table");
         __shared__ T    s_hot[C::kHot];
@@ -560,7 +577,7 @@ namespace splahip {
         __syncthreads();
         if (s_dec[0] != 0u)
             sell_mxv_body<T, Mult, Add, true>(s_hot, &s_next, n_rows, Ap, n_slices, vrow, vlen, vslot, off, Aj2r, Ax2, reinterpret_cast<const T*>(vbits), C::kBitWords,
-                                              mask, v, r, partial, mult, add, op_select, init, s_dec[1] != 0u, s_dec[2], vbits, vranked, selbits, sorder);
+                                              mask, v, r, partial, mult, add, op_select, init, s_dec[1] != 0u, s_dec[2], vbits, vranked, selbits, sorder, nullptr, ident);
         else
             sell_mxv_body<T, Mult, Add, false>(s_hot, &s_next, n_rows, Ap, n_slices, vrow, vlen, vslot, off, Aj2, Ax2, hot_values, n_hot, mask, v, r, partial, mult,
                                                add, op_select, init, false, 0u, nullptr, nullptr, nullptr, sorder);
@@ -582,7 +599,7 @@ namespace splahip {
         const uint row = (uint) (e >> 32);
         if (!eval_sel(op_select, mask[row])) return;
         const T    x = from_bits<T>(is_const ? cbits : vranked[rank]);
-        atomic_fold(reinterpret_cast<uint*>(r + row), to_bits(mult(from_bits<T>((uint) e), x)), op_add);
+        atomic_fold(r + row, mult(from_bits<T>((uint) e), x), op_add);
     }
 
     // rows longer than kC: r[row] = init (+) partial[first] (+) partial[first + 1] ... in chunk order.  One wave per row: lane l

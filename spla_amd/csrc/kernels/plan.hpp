@@ -34,6 +34,10 @@ struct splahip_sell_s {
     uint32_t  n_bit_words = 0;     // words of ONE bitmap; d_vbits = bitmap 0 | bitmap 1 | statistics (double-buffered: a call fills one and
                                    // clears the other for the next call)
     mutable uint32_t bit_buffer = 0;// which bitmap the next call fills
+    // value statistics of the copy, taken on the first min-plus call of a type (sell.hip: ax_stats): -1 = not taken yet
+    mutable int      ax_type    = -1;
+    mutable uint32_t ax_bad     = 0;// some value is negative (INT / FLOAT) or NaN
+    mutable uint32_t ax_max     = 0;// largest value's bits (INT / UINT; meaningful when !ax_bad)
     uint32_t* d_selbits   = nullptr;// per launch: bit `row` = op_select(mask[row]) (the slices' rows are length-sorted: a bit is 32x denser than
                                     // a mask word, and the popular lengths keep ascending row order, so a slice's 64 tests share a few lines)
     // entries whose column rank is beyond the LDS-resident bits: out of d_Aj2r (coded as a never-set bit), listed here by ascending rank
@@ -59,11 +63,13 @@ struct splahip_plan_s {
 
 namespace splahip {
     void sell_release(splahip_sell_s* sell);
-    bool sell_zero_skippable(int type, int op_mult, int op_add);
+    // may the sparse-vector (BITS) form serve this semiring: 0 no, 1 zero family (0 annihilates op_mult and is op_add's identity), 2 min-plus
+    // family (an entry whose v value equals init cannot lower the minimum when no matrix value is negative: checked per call)
+    int sell_skip_family(int type, int op_mult, int op_add);
     // the pull form of vxm with every index of v stored, over the sliced-ELL copy attached to the TRANSPOSED matrix's plan: out values and
     // touched flags per output column (associative + commutative op_add); returns a SPLAHIP status
     int sell_vxm(const splahip_plan_s* plan_T, int type, const uint32_t* Tp, const void* mask, const void* v, void* out, uint32_t* touched, int op_mult,
-                 int op_add, int op_select, void* stream);// may the sparse-vector (BITS) form serve this semiring
+                 int op_add, int op_select, void* stream);
     // the sliced-ELL masked SpMV (associative op_add, no early exit); returns a SPLAHIP status
     int sell_mxv(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
                  uint32_t init_bits, void* stream);

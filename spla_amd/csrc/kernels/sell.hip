@@ -251,7 +251,52 @@ namespace {
     }
 
     // 0 annihilates op_mult and is op_add's identity: an entry whose v value is 0 cannot change the fold (mxv_sell.hpp, BITS form)
-    bool zero_skippable(int type, int op_mult, int op_add) { return sell_zero_skippable(type, op_mult, op_add); }
+    // any negative / NaN value, and the largest value, of the copy's value array (padding words are 0)
+    template<typename T>
+    __global__ __launch_bounds__(256) void sell_ax_stats_kernel(uint n, const T* __restrict__ x, uint* __restrict__ out) {
+        uint bad = 0, mx = 0;
+        for (uint k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+            const T a = x[k];
+            if constexpr (std::is_same<T, uint32_t>::value) mx = max(mx, a);
+            else {
+                if (a < T(0) || a != a) bad = 1;
+                else if constexpr (std::is_same<T, int32_t>::value)
+                    mx = max(mx, (uint) a);
+            }
+        }
+        bad = wave_max(bad);
+        mx  = wave_max(mx);
+        if (lane_id() == 0) {
+            if (bad) atomicOr(&out[0], 1u);
+            atomicMax(&out[1], mx);
+        }
+    }
+    template<typename T>
+    int ax_stats(const splahip_sell_s* g, hipStream_t st) {
+        if (g->ax_type == TypeId<T>::value) return SPLAHIP_OK;
+        DevMem out;
+        SPLAHIP_TRY(out.alloc(st, 8));
+        SPLAHIP_TRY(hipMemsetAsync(out.p, 0, 8, st));
+        hipLaunchKernelGGL((sell_ax_stats_kernel<T>), dim3(1024), dim3(256), 0, st, g->n_slots, reinterpret_cast<const T*>(g->d_Ax2), out.as<uint>());
+        uint h[2] = {1, 0};
+        SPLAHIP_TRY(hipMemcpyAsync(h, out.p, 8, hipMemcpyDeviceToHost, st));
+        SPLAHIP_TRY(hipStreamSynchronize(st));
+        g->ax_bad = h[0], g->ax_max = h[1], g->ax_type = TypeId<T>::value;
+        return SPLAHIP_OK;
+    }
+    // min-plus family: is "v[j] == init contributes nothing" true for this matrix and this init?  a + init >= init for every matrix value a
+    // (none negative, no NaN) and, for the integer types, without wrap-around
+    template<typename T>
+    bool min_plus_skippable(const splahip_sell_s* g, uint32_t init_bits) {
+        if (g->ax_bad) return false;
+        if constexpr (std::is_same<T, float>::value) {
+            const float init = from_bits<float>(init_bits);
+            return init == init;
+        } else if constexpr (std::is_same<T, int32_t>::value)
+            return (long long) from_bits<int32_t>(init_bits) + (long long) g->ax_max <= 0x7FFFFFFFll;
+        else
+            return (unsigned long long) init_bits + (unsigned long long) g->ax_max <= 0xFFFFFFFFull;
+    }
     int bits_force() {// SPLAHIP_SELL_BITS: 0 = never, 1 / unset = the device statistics decide, 2 = always (where the semiring allows it)
         const char* e = std::getenv("SPLAHIP_SELL_BITS");
         return e ? std::atoi(e) : 1;
@@ -263,7 +308,14 @@ namespace {
         const splahip_sell_s* g    = plan->sell;
         const uint            grid = compute_units();
         const int             mode = bits_force();
-        const bool            bits = mode != 0 && zero_skippable(TypeId<T>::value, op_mult, op_add);
+        const int             family = mode != 0 ? sell_skip_family(TypeId<T>::value, op_mult, op_add) : 0;
+        bool                  bits   = family == 1;
+        if (family == 2) {
+            if (int rc = ax_stats<T>(g, st)) return rc;
+            bits = min_plus_skippable<T>(g, init_bits);
+        }
+        const uint skip  = family == 2 ? init_bits : 0u;                          // the v value whose entries cannot change a fold
+        const T    ident = family == 2 ? from_bits<T>(init_bits) : T(0);          // what a lane of a row-exclusive slice starts from
         uint*                 stats = g->d_vbits + 2 * (size_t) g->n_bit_words;
         uint*                 vbits = g->d_vbits + (size_t) g->bit_buffer * g->n_bit_words;
         uint*                 vnext = g->d_vbits + (size_t) (g->bit_buffer ^ 1u) * g->n_bit_words;
@@ -272,11 +324,11 @@ namespace {
             hipLaunchKernelGGL((sell_vprep_kernel<T>), dim3(SC::kPrepBlocks), dim3(256), 0, st, g->n_cols, static_cast<const T*>(v), g->d_rank_of, g->n_hot,
                                g->d_hot_cols, reinterpret_cast<T*>(g->d_hot_vals), vbits, g->d_vranked, stats, plan->n_rows, static_cast<const T*>(mask), op_select,
                                reinterpret_cast<unsigned long long*>(g->d_selbits), reinterpret_cast<uint4*>(vnext), g->n_bit_words / 4, static_cast<T*>(r),
-                               from_bits<T>(init_bits));
+                               from_bits<T>(init_bits), skip);
             hipLaunchKernelGGL((sell_mxv_dual_kernel<T, Mult, Add>), dim3(grid), dim3(SC::kTpb), 0, st, plan->n_rows, Ap, g->n_slices, g->d_vrow, g->d_vlen,
                                g->d_vslot, g->d_off, g->d_Aj2, g->d_Aj2r, g->d_Ax2, reinterpret_cast<const T*>(g->d_hot_vals), g->n_hot,
                                static_cast<const T*>(mask), static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(g->d_partial), Mult(op_mult),
-                               Add(op_add), op_select, from_bits<T>(init_bits), stats, g->n_cols, mode == 2 ? 1 : 0, vbits, g->d_vranked, g->d_selbits, g->d_sorder);
+                               Add(op_add), op_select, from_bits<T>(init_bits), stats, g->n_cols, mode == 2 ? 1 : 0, vbits, g->d_vranked, g->d_selbits, g->d_sorder, ident);
         } else {
             hipLaunchKernelGGL((sell_hot_pack_kernel<T>), dim3((g->n_hot + 255) / 256), dim3(256), 0, st, g->d_hot_cols, g->n_hot, static_cast<const T*>(v),
                                reinterpret_cast<T*>(g->d_hot_vals));
@@ -353,11 +405,12 @@ namespace {
 
 namespace splahip {
 
-    bool sell_zero_skippable(int type, int op_mult, int op_add) {
-        if (type == SPLAHIP_FLOAT) return false;// 0 * inf, -0 + 0: not bit-safe
-        if (op_mult != SPLAHIP_BAND && op_mult != SPLAHIP_MULT && op_mult != SPLAHIP_LAND) return false;
-        if (op_add == SPLAHIP_BOR || op_add == SPLAHIP_PLUS || op_add == SPLAHIP_BXOR) return true;
-        return type == SPLAHIP_UINT && op_add == SPLAHIP_MAX;
+    int sell_skip_family(int type, int op_mult, int op_add) {
+        if (op_mult == SPLAHIP_PLUS && op_add == SPLAHIP_MIN) return 2;// min-plus: every type
+        if (type == SPLAHIP_FLOAT) return 0;                            // 0 * inf, -0 + 0: not bit-safe
+        if (op_mult != SPLAHIP_BAND && op_mult != SPLAHIP_MULT && op_mult != SPLAHIP_LAND) return 0;
+        if (op_add == SPLAHIP_BOR || op_add == SPLAHIP_PLUS || op_add == SPLAHIP_BXOR) return 1;
+        return type == SPLAHIP_UINT && op_add == SPLAHIP_MAX ? 1 : 0;
     }
 
     void sell_release(splahip_sell_s* g) {

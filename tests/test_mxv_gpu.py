@@ -295,3 +295,51 @@ def test_fp32_product_monoid_keeps_the_left_fold(oracle):
         want = oracle.mxv_masked("FLOAT", n_rows, n_cols, Ap, Aj, Ax, mask, v, "MULT", "MULT", "ALWAYS", init)
         got = hip_mxv("FLOAT", n_rows, n_cols, Ap, Aj, Ax, mask, v, "MULT", "MULT", "ALWAYS", init)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), init
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", ["INT", "UINT", "FLOAT"])
+def test_min_plus_bit_form(oracle, t):
+    """min-plus with the bit form of the sliced-ELL kernel: an entry whose v value equals init (the "infinity" of a shortest-path step)
+    cannot lower a minimum when no matrix value is negative.  Sparse / dense / constant finite parts of v, long rows, masks; and the
+    cases the form must refuse (a negative weight, an init that would wrap) still equal the oracle through the value form."""
+    from gpu_utils import hip_mxv
+    rng = np.random.default_rng(505)
+    n_rows, n_cols = 4000, 70000
+    degs = rng.integers(0, 25, n_rows)
+    degs[rng.integers(0, n_rows, 20)] = rng.integers(257, 3000, 20)
+    Ap = np.zeros(n_rows + 1, np.uint32)
+    np.cumsum(degs, out=Ap[1:])
+    pop = rng.pareto(1.1, n_cols) + 1e-3
+    pop /= pop.sum()
+    Aj = np.concatenate([np.sort(rng.choice(n_cols, size=int(d), replace=False, p=pop)) for d in degs if d]).astype(np.uint32)
+    INF = {"INT": 1 << 30, "UINT": 1 << 31, "FLOAT": np.finfo(np.float32).max}[t]
+    w = rng.integers(1, 256, len(Aj)).astype(NP[t])
+    for name, frac in (("sparse", 0.02), ("eighth", 0.125), ("dense", 0.9), ("none", 0.0)):
+        v = np.full(n_cols, INF, NP[t])
+        k = rng.random(n_cols) < frac
+        v[k] = rng.integers(0, 5000, int(k.sum())).astype(NP[t])
+        for sel in ("ALWAYS", "EQZERO"):
+            mask = random_mask(rng, n_rows, t)
+            want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, w, mask, v, "PLUS", "MIN", sel, INF)
+            got = hip_mxv(t, n_rows, n_cols, Ap, Aj, w, mask, v, "PLUS", "MIN", sel, INF, junk=7)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (t, name, sel)
+    # all finite values equal: the constant case of the form
+    v = np.full(n_cols, INF, NP[t])
+    v[rng.random(n_cols) < 0.05] = 17
+    want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, w, np.zeros(n_rows, NP[t]), v, "PLUS", "MIN", "ALWAYS", INF)
+    got = hip_mxv(t, n_rows, n_cols, Ap, Aj, w, np.zeros(n_rows, NP[t]), v, "PLUS", "MIN", "ALWAYS", INF)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # refused: a negative weight (INT / FLOAT), or an init so large that init + weight wraps (UINT)
+    if t == "UINT":
+        big = np.uint32(0xFFFFFF00)
+        v2 = np.where(rng.random(n_cols) < 0.1, 5, big).astype(np.uint32)
+        want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, w, np.zeros(n_rows, NP[t]), v2, "PLUS", "MIN", "ALWAYS", int(big))
+        got = hip_mxv(t, n_rows, n_cols, Ap, Aj, w, np.zeros(n_rows, NP[t]), v2, "PLUS", "MIN", "ALWAYS", int(big))
+    else:
+        w2 = w.copy()
+        w2[::97] = -3
+        v2 = np.where(rng.random(n_cols) < 0.1, 5, INF).astype(NP[t])
+        want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, w2, np.zeros(n_rows, NP[t]), v2, "PLUS", "MIN", "ALWAYS", INF)
+        got = hip_mxv(t, n_rows, n_cols, Ap, Aj, w2, np.zeros(n_rows, NP[t]), v2, "PLUS", "MIN", "ALWAYS", INF)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
