@@ -468,6 +468,14 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
     res[-1]["max_rel_vs_csr_kernel"] = rel
     res[-1]["plan"] = sell_f.sell
     sell_f.close()
+    sell_w = kernels.CsrPlan(n_local, nnz_local, g["Ap"], sh.n_cols_padded, g["Aj"], w_i)
+    r_w = torch.empty_like(r_i)
+    run("all rows selected, PLUS/MIN int32 (SSSP step), sliced-ELL copy (1/8 of v finite: bit form)", "INT", w_i, zeros_i, d_i, r_w, "PLUS", "MIN", "ALWAYS", 1 << 30, False,
+        nnz_local, plan=sell_w)
+    kernels.mxv_masked(sh.plan_csr, "INT", sh.n_cols_padded, g["Ap"], g["Aj"], w_i, zeros_i, d_i, r_i, "PLUS", "MIN", "ALWAYS", 1 << 30)
+    torch.cuda.synchronize()
+    res[-1]["identical_to_csr_kernel"] = bool(torch.equal(r_w, r_i))
+    sell_w.close()
     sell_i = kernels.CsrPlan(n_local, nnz_local, g["Ap"], sh.n_cols_padded, g["Aj"], ones_i)
     r_chk = torch.empty_like(r_i)
     run("bfs-step early_exit=false, sliced-ELL copy", "INT", ones_i, mask, v_full, r_chk, "BAND", "BOR", "EQZERO", 0, False, nnz_sel_local, plan=sell_i)
