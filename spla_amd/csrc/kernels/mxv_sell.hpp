@@ -158,15 +158,18 @@ namespace splahip {
             for (uint row = (blockIdx.x * 256 + threadIdx.x) * 4; row < span; row += gridDim.x * 1024) {
                 uint nib = 0;
                 if (row + 4 <= n_rows) {
-                    const uint4 m                       = *reinterpret_cast<const uint4*>(mask + row);
                     *reinterpret_cast<uint4*>(r + row) = init4;
-                    nib = (eval_sel(op_select, from_bits<T>(m.x)) ? 1u : 0u) | (eval_sel(op_select, from_bits<T>(m.y)) ? 2u : 0u) |
-                          (eval_sel(op_select, from_bits<T>(m.z)) ? 4u : 0u) | (eval_sel(op_select, from_bits<T>(m.w)) ? 8u : 0u);
+                    if (op_select == SPLAHIP_ALWAYS) nib = 0xFu;// (the mask is not read: 4 B per row less)
+                    else {
+                        const uint4 m = *reinterpret_cast<const uint4*>(mask + row);
+                        nib = (eval_sel(op_select, from_bits<T>(m.x)) ? 1u : 0u) | (eval_sel(op_select, from_bits<T>(m.y)) ? 2u : 0u) |
+                              (eval_sel(op_select, from_bits<T>(m.z)) ? 4u : 0u) | (eval_sel(op_select, from_bits<T>(m.w)) ? 8u : 0u);
+                    }
                 } else {
                     for (uint i = 0; i < 4; ++i)
                         if (row + i < n_rows) {
                             r[row + i] = init;
-                            nib |= eval_sel(op_select, mask[row + i]) ? (1u << i) : 0u;
+                            nib |= (op_select == SPLAHIP_ALWAYS || eval_sel(op_select, mask[row + i])) ? (1u << i) : 0u;
                         }
                 }
                 unsigned long long wd = (unsigned long long) nib << (4u * (lane_id() & 15u));
@@ -597,7 +600,7 @@ namespace splahip {
         if (((vbits[rank >> 5] >> (rank & 31u)) & 1u) == 0) return;
         const unsigned long long e = cold_entry[k];
         const uint row = (uint) (e >> 32);
-        if (!eval_sel(op_select, mask[row])) return;
+        if (op_select != SPLAHIP_ALWAYS && !eval_sel(op_select, mask[row])) return;
         const T    x = from_bits<T>(is_const ? cbits : vranked[rank]);
         atomic_fold(r + row, mult(from_bits<T>((uint) e), x), op_add);
     }
@@ -611,7 +614,7 @@ namespace splahip {
         const uint i = block * (256 / kWave) + threadIdx.x / kWave;
         if (i >= n_lrows) return;
         const uint row = lr_row[i];
-        if (!eval_sel(op_select, mask[row])) return;// the main kernel's row pass wrote init (vxm: touched = 0)
+        if (op_select != SPLAHIP_ALWAYS && !eval_sel(op_select, mask[row])) return;// the main kernel's row pass wrote init (vxm: touched = 0)
         const uint k0 = lr_first[i], k1 = lr_first[i + 1];
         const uint c  = (k1 - k0 + kWave - 1) / kWave;
         const uint ks = k0 + lane_id() * c, ke = min(k1, ks + c);
