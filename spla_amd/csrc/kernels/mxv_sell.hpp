@@ -482,9 +482,9 @@ namespace splahip {
                         bool pv = selected;
                         T    t  = acc;
                         wave_reduce_ordered(t, pv, add);
-                        if (lane == 0 && pv) atomic_fold(r + row, t, functor_op(add));
-                    } else if (selected) {
-                        r[row] = acc;
+                        if (lane == 0 && pv && to_bits(t) != to_bits(ident)) atomic_fold(r + row, t, functor_op(add));// (folding the identity changes nothing)
+                    } else if (selected && to_bits(acc) != to_bits(init)) {// the prep pass wrote init to every row: a row without a product
+                        r[row] = acc;                                        // (most rows of a BFS level) costs no scattered 4-byte store
                     }
                 } else if (selected) {
                     if (chunk) partial[vslot[s_cur * kWave + lane]] = acc;
