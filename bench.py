@@ -161,6 +161,24 @@ def bfs_state(sh: Sharded, Ax):
     return depth, L, sizes, src
 
 
+def copy_ceiling_gbs(n_words=1 << 28, reps=10):
+    """GB/s (read + write) of a 1 GiB device-to-device copy on the current stream: the streaming ceiling measured in the same run."""
+    a = torch.ones(n_words, dtype=torch.int32, device="cuda")
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    ms = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    del a, b
+    return 2 * 4 * n_words / (float(np.median(ms)) * 1e-3) / 1e9
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -290,6 +308,12 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "kernel": kernel_name(sh.plan, "INT", "BAND", "BOR", False), "kernel_avg_us": round(k_ms * 1e3, 2),
                 "kernel_median_us": round(float(np.median(per_k)) * 1e3, 2), "algorithmic_bytes": alg_bytes}
+
+    # measured streaming ceiling of this GPU in this run: a 1 GiB device-to-device copy, read + write bytes / time.
+    # `frac` stays against the nominal 8 TB/s; `frac_of_measured_copy` is the same numerator against what a plain copy reaches here.
+    copy_gbs = copy_ceiling_gbs()
+    roofline["measured_copy_gbs"] = round(copy_gbs, 1)
+    roofline["frac_of_measured_copy"] = round(achieved / copy_gbs, 4)
 
     # HBM-side traffic of the same kernel from the rocprofv3 PMC passes (tools/gpu_round.sh -> tools/pmc_traffic.py):
     # collected by a separate profiler run of this command, so it is read from profiles/ when it matches this workload
