@@ -302,12 +302,19 @@ def main():
     else:
         per_k = per
     k_ms = float(np.mean(per_k))
-    alg_bytes = 8 * nnz_sel_local + 4 * (n_local + 1) + 8 * n_local + 4 * sh.n_cols_padded
+    # a matrix whose stored values are all one word (the BFS step's adjacency matrix of ones) is served structure-only by the sliced-ELL
+    # bit form: 4 B per entry (the column word), and the byte model says so ("report against 4*nnz_sel instead")
+    structure_only = bool(args.plan == "sell" and sh.plan.sell and sh.plan.sell.get("uniform_values"))
+    entry_bytes = 4 if structure_only else 8
+    alg_bytes = entry_bytes * nnz_sel_local + 4 * (n_local + 1) + 8 * n_local + 4 * sh.n_cols_padded
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "kernel": kernel_name(sh.plan, "INT", "BAND", "BOR", False), "kernel_avg_us": round(k_ms * 1e3, 2),
-                "kernel_median_us": round(float(np.median(per_k)) * 1e3, 2), "algorithmic_bytes": alg_bytes}
+                "kernel_median_us": round(float(np.median(per_k)) * 1e3, 2), "algorithmic_bytes": alg_bytes,
+                "bytes_per_entry": entry_bytes,
+                "byte_model": ("structure-only: every stored value is the same word, the kernel streams column words only; " if structure_only else "")
+                              + "B = %d*nnz_sel + 4*(n_rows+1) + 4*n_rows (mask) + 4*n_rows (r) + 4*n_cols (v once)" % entry_bytes}
 
     # measured streaming ceiling of this GPU in this run: a 1 GiB device-to-device copy, read + write bytes / time.
     # `frac` stays against the nominal 8 TB/s; `frac_of_measured_copy` is the same numerator against what a plain copy reaches here.
@@ -451,18 +458,18 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
     n_local, nnz_local = sh.n_local, g["nnz_local"]
     steps = max(10, args.steps // 2)
 
-    def run(name, t, Ax, m, v, r, mul, add, sel, init, early, nnz_sel, plan=None):
+    def run(name, t, Ax, m, v, r, mul, add, sel, init, early, nnz_sel, plan=None, entry_bytes=8):
         plan = plan or sh.plan_csr
         fn = lambda: kernels.mxv_masked(plan, t, sh.n_cols_padded, g["Ap"], g["Aj"], Ax, m, v, r, mul, add, sel, init, early_exit=early)
         _, per = timed(fn, steps, 3)
         ms = float(np.mean(per))
-        b = 8 * nnz_sel + 4 * (n_local + 1) + 8 * n_local + 4 * sh.n_cols_padded
+        b = entry_bytes * nnz_sel + 4 * (n_local + 1) + 8 * n_local + 4 * sh.n_cols_padded
         tot = torch.tensor([nnz_sel], device=coll_device(), dtype=torch.int64)
         if world > 1:
             dist.all_reduce(tot)
         res.append({"name": name, "kernel": kernels.mxv_variant(t, mul, add, early, plan), "kernel_avg_us": round(ms * 1e3, 2),
                     "gteps_local": round(nnz_sel / (ms * 1e-3) / 1e9, 2), "hbm_gbs": round(b / (ms * 1e-3) / 1e9, 1),
-                    "roofline_frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "nnz_selected_local": nnz_sel})
+                    "roofline_frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "nnz_selected_local": nnz_sel, "bytes_per_entry": entry_bytes})
 
     r_i = torch.empty(n_local, dtype=torch.int32, device="cuda")
     ones_i = torch.ones(nnz_local, dtype=torch.int32, device="cuda")
@@ -502,14 +509,22 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
     sell_w.close()
     sell_i = kernels.CsrPlan(n_local, nnz_local, g["Ap"], sh.n_cols_padded, g["Aj"], ones_i)
     r_chk = torch.empty_like(r_i)
-    run("bfs-step early_exit=false, sliced-ELL copy", "INT", ones_i, mask, v_full, r_chk, "BAND", "BOR", "EQZERO", 0, False, nnz_sel_local, plan=sell_i)
+    uni = bool(sell_i.sell and sell_i.sell.get("uniform_values"))
+    run("bfs-step early_exit=false, sliced-ELL copy" + (" (structure-only: all stored values equal)" if uni else ""), "INT", ones_i, mask, v_full, r_chk,
+        "BAND", "BOR", "EQZERO", 0, False, nnz_sel_local, plan=sell_i, entry_bytes=4 if uni else 8)
+    r_chk3 = torch.empty_like(r_i)
+    os.environ["SPLAHIP_SELL_UNIFORM"] = "0"
+    run("bfs-step early_exit=false, sliced-ELL copy, value words streamed (SPLAHIP_SELL_UNIFORM=0)", "INT", ones_i, mask, v_full, r_chk3, "BAND", "BOR", "EQZERO", 0,
+        False, nnz_sel_local, plan=sell_i)
+    os.environ.pop("SPLAHIP_SELL_UNIFORM")
     r_chk2 = torch.empty_like(r_i)
     os.environ["SPLAHIP_SELL_BITS"] = "0"
     run("bfs-step early_exit=false, sliced-ELL copy, value form forced (SPLAHIP_SELL_BITS=0)", "INT", ones_i, mask, v_full, r_chk2, "BAND", "BOR", "EQZERO", 0, False, nnz_sel_local, plan=sell_i)
     os.environ["SPLAHIP_SELL_BITS"] = "1"
     run("bfs-step early_exit=false, CSR wave-tile kernel (no sliced-ELL copy)", "INT", ones_i, mask, v_full, r_i, "BAND", "BOR", "EQZERO", 0, False, nnz_sel_local)
     torch.cuda.synchronize()
-    res[-3]["identical_to_csr_kernel"] = bool(torch.equal(r_chk, r_i))
+    res[-4]["identical_to_csr_kernel"] = bool(torch.equal(r_chk, r_i))
+    res[-3]["identical_to_csr_kernel"] = bool(torch.equal(r_chk3, r_i))
     res[-2]["identical_to_csr_kernel"] = bool(torch.equal(r_chk2, r_i))
     sell_i.close()
     return res

@@ -75,6 +75,9 @@ int splahip_csr_plan_create(splahip_plan* plan, uint32_t n_rows, uint32_t nnz, c
  * Blocks.  sell_info: slices, stored entries incl. padding, LDS-resident columns, rows longer than one chunk.            */
 int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, void* stream);
 int splahip_csr_plan_sell_info(splahip_plan plan, uint32_t* n_slices, uint32_t* n_slots, uint32_t* n_hot, uint32_t* n_long_rows);
+/* sell_values: *uniform = 1 when every stored value of the matrix is the same 4-byte word (*bits), as in a graph's adjacency matrix of
+ * ones; the sparse-vector (bit) form then streams the 4-byte column words only — a structure-only pass, 4 B per entry instead of 8.   */
+int splahip_csr_plan_sell_values(splahip_plan plan, int* uniform, uint32_t* bits);
 int splahip_csr_plan_destroy(splahip_plan plan);
 /* n_items: work items; n_long: rows cut into segment items */
 int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_items, uint32_t* n_long);

@@ -248,7 +248,7 @@ namespace splahip {
     // VXM (value form only): the pull form of vxm over the transposed matrix with EVERY index of v stored — products are mult(v, x),
     // a row folds from its first product (no init) and touched[row] tells whether the output entry exists (reference
     // src/cpu/cpu_vxm.hpp:101-107); r is only written for touched rows.
-    template<typename T, class Mult, class Add, bool BITS, bool VXM = false>
+    template<typename T, class Mult, class Add, bool BITS, bool VXM = false, uint KU = SellCfg::kU>
     __device__ __forceinline__ void sell_mxv_body(T* s_hot, uint* s_next_p, uint n_rows, const uint* __restrict__ Ap, uint n_slices,
                                                   const uint* __restrict__ vrow, const uint* __restrict__ vlen,
                                                   const uint* __restrict__ vslot, const uint* __restrict__ off,
@@ -260,8 +260,9 @@ namespace splahip {
                                                   bool is_const, uint cbits,
                                                   const uint* __restrict__ vbits, const uint* __restrict__ vranked,
                                                   const uint* __restrict__ selbits, const uint* __restrict__ sorder,
-                                                  uint* __restrict__ touched = nullptr, T ident = T()) {
+                                                  uint* __restrict__ touched = nullptr, T ident = T(), uint xbits = 0) {
         using C = SellCfg;
+        const bool xu = Ax2 == nullptr;// every matrix value is the word `xbits`: the value stream is not read
         static_assert(!(BITS && VXM), "the pull form of vxm uses the value form");
         uint& s_next = *s_next_p;// next of this workgroup's slices nobody has taken yet (ordinal)
 
@@ -391,14 +392,14 @@ namespace splahip {
             const uint mylen    = selected ? lenA : 0u;
             const uint* pj = Aj2 + base + lane;
             const uint* px = Ax2 + base + lane;
-            uint        jn[C::kU], xn[C::kU];
+            uint        jn[KU], xn[KU];
 #pragma unroll
-            for (uint u = 0; u < C::kU; ++u) {// first group: only lanes that will fold the entry ask for it
+            for (uint u = 0; u < KU; ++u) {// first group: only lanes that will fold the entry ask for it
                 jn[u] = BITS ? C::kBitsLds : C::kHotFlag;// a lane without an entry reads the never-set bit / hot slot 0 and folds nothing
-                xn[u] = 0;
+                xn[u] = xu ? xbits : 0u;
                 if (u < mylen) {
                     jn[u] = sell_stream_load(pj + u * kWave);
-                    xn[u] = sell_stream_load(px + u * kWave);
+                    if (!xu) xn[u] = sell_stream_load(px + u * kWave);
                 }
             }
             SELL_NOW(t_b)
@@ -413,27 +414,27 @@ namespace splahip {
                     if (chunk) acc = ident;// (0 for the zero family; init for min-plus: min(init, x) is folded with init again anyway)
                     has = true;
                 }
-                for (uint e = 0; e < width; e += C::kU) {
-                    uint jc[C::kU], xc[C::kU];
+                for (uint e = 0; e < width; e += KU) {
+                    uint jc[KU], xc[KU];
 #pragma unroll
-                    for (uint u = 0; u < C::kU; ++u) {
+                    for (uint u = 0; u < KU; ++u) {
                         jc[u] = jn[u];
                         xc[u] = xn[u];
                     }
-                    pj += C::kU * kWave;
-                    px += C::kU * kWave;
+                    pj += KU * kWave;
+                    px += KU * kWave;
                     // prefetch the next group before this group's gathers are issued (uniform conditions)
 #pragma unroll
-                    for (uint u = 0; u < C::kU; ++u) {
-                        if (e + C::kU + u < mylen) {
+                    for (uint u = 0; u < KU; ++u) {
+                        if (e + KU + u < mylen) {
                             jn[u] = sell_stream_load(pj + u * kWave);
-                            xn[u] = sell_stream_load(px + u * kWave);
+                            if (!xu) xn[u] = sell_stream_load(px + u * kWave);
                         }
                     }
-                    T    vv[C::kU];
-                    bool on[C::kU];
+                    T    vv[KU];
+                    bool on[KU];
 #pragma unroll
-                    for (uint u = 0; u < C::kU; ++u) {
+                    for (uint u = 0; u < KU; ++u) {
                         const bool take = e + u < mylen;
                         on[u]           = take;
                         if constexpr (BITS) {
@@ -464,12 +465,12 @@ namespace splahip {
                     if constexpr (BITS) {
                         if (!is_const) {// set bits fetch their value from the rank-ordered copy of v (all of the group's gathers in flight together)
 #pragma unroll
-                            for (uint u = 0; u < C::kU; ++u)
+                            for (uint u = 0; u < KU; ++u)
                                 if (on[u]) vv[u] = from_bits<T>(vranked[jc[u]]);
                         }
                     }
 #pragma unroll
-                    for (uint u = 0; u < C::kU; ++u) {
+                    for (uint u = 0; u < KU; ++u) {
                         const bool take = on[u];
                         const T    p    = VXM ? mult(vv[u], from_bits<T>(xc[u])) : mult(from_bits<T>(xc[u]), vv[u]);
                         const T    both = add(acc, p);
@@ -556,7 +557,7 @@ namespace splahip {
                                                                           const T* __restrict__ mask, const T* __restrict__ v, T* __restrict__ r,
                                                                           T* __restrict__ partial, Mult mult, Add add, int op_select, T init, uint* __restrict__ stats,
                                                                           uint n_cols, int force, const uint* __restrict__ vbits, const uint* __restrict__ vranked,
-                                                                          const uint* __restrict__ selbits, const uint* __restrict__ sorder, T ident) {
+                                                                          const uint* __restrict__ selbits, const uint* __restrict__ sorder, T ident, uint xbits) {
         using C = SellCfg;
         static_assert(C::kBitWords <= C::kHot, "the two forms share one LDS table");
         __shared__ T    s_hot[C::kHot];
@@ -578,12 +579,16 @@ namespace splahip {
             }
         }
         __syncthreads();
-        if (s_dec[0] != 0u)
+        if (s_dec[0] != 0u && Ax2 == nullptr)// structure-only: no value stream, so a group is twice as many entries for the same loads in flight
+            sell_mxv_body<T, Mult, Add, true, false, 2 * C::kU>(s_hot, &s_next, n_rows, Ap, n_slices, vrow, vlen, vslot, off, Aj2r, Ax2, reinterpret_cast<const T*>(vbits),
+                                                                C::kBitWords, mask, v, r, partial, mult, add, op_select, init, s_dec[1] != 0u, s_dec[2], vbits, vranked,
+                                                                selbits, sorder, nullptr, ident, xbits);
+        else if (s_dec[0] != 0u)
             sell_mxv_body<T, Mult, Add, true>(s_hot, &s_next, n_rows, Ap, n_slices, vrow, vlen, vslot, off, Aj2r, Ax2, reinterpret_cast<const T*>(vbits), C::kBitWords,
-                                              mask, v, r, partial, mult, add, op_select, init, s_dec[1] != 0u, s_dec[2], vbits, vranked, selbits, sorder, nullptr, ident);
+                                              mask, v, r, partial, mult, add, op_select, init, s_dec[1] != 0u, s_dec[2], vbits, vranked, selbits, sorder, nullptr, ident, xbits);
         else
             sell_mxv_body<T, Mult, Add, false>(s_hot, &s_next, n_rows, Ap, n_slices, vrow, vlen, vslot, off, Aj2, Ax2, hot_values, n_hot, mask, v, r, partial, mult,
-                                               add, op_select, init, false, 0u, nullptr, nullptr, nullptr, sorder);
+                                               add, op_select, init, false, 0u, nullptr, nullptr, nullptr, sorder, nullptr, T(), xbits);
     }
 
     // BITS form, entries of columns beyond the LDS-resident ranks (ascending rank: the bitmap reads are sequential): a set bit on a

@@ -35,6 +35,10 @@ struct splahip_sell_s {
                                    // clears the other for the next call)
     mutable uint32_t bit_buffer = 0;// which bitmap the next call fills
     // value statistics of the copy, taken on the first min-plus call of a type (sell.hip: ax_stats): -1 = not taken yet
+    // every stored matrix value has the same bits (a graph's adjacency matrix of ones): the bit-form kernel then streams the rank words
+    // only, 4 B per entry instead of 8 (taken once at attach time; sell.hip)
+    bool     x_uniform = false;
+    uint32_t x_bits    = 0;
     mutable int      ax_type    = -1;
     mutable uint32_t ax_bad     = 0;// some value is negative (INT / FLOAT) or NaN
     mutable uint32_t ax_max     = 0;// largest value's bits (INT / UINT; meaningful when !ax_bad)

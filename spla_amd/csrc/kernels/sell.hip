@@ -197,7 +197,7 @@ namespace {
         cold_entry[pos[k]] = ((unsigned long long) lo << 32) | Ax[k];
     }
 
-    constexpr uint kTail = 2 * SC::kU * kWave;// read-ahead of the last slice's group prefetch
+    constexpr uint kTail = 4 * SC::kU * kWave;// read-ahead of the last slice's group prefetch
 
     struct Scratch {
         std::vector<void*> ptrs;
@@ -271,6 +271,20 @@ namespace {
             atomicMax(&out[1], mx);
         }
     }
+    // smallest and largest value bits of the CSR value array (equal <=> every stored value is the same word)
+    __global__ __launch_bounds__(256) void sell_ax_range_kernel(uint n, const uint* __restrict__ x, uint* __restrict__ out) {
+        uint lo = 0xFFFFFFFFu, hi = 0;
+        for (uint k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+            const uint a = x[k];
+            lo = min(lo, a), hi = max(hi, a);
+        }
+        lo = ~wave_max(~lo);
+        hi = wave_max(hi);
+        if (lane_id() == 0) {
+            atomicMin(&out[0], lo);
+            atomicMax(&out[1], hi);
+        }
+    }
     template<typename T>
     int ax_stats(const splahip_sell_s* g, hipStream_t st) {
         if (g->ax_type == TypeId<T>::value) return SPLAHIP_OK;
@@ -296,6 +310,10 @@ namespace {
             return (long long) from_bits<int32_t>(init_bits) + (long long) g->ax_max <= 0x7FFFFFFFll;
         else
             return (unsigned long long) init_bits + (unsigned long long) g->ax_max <= 0xFFFFFFFFull;
+    }
+    bool uniform_disabled() {// SPLAHIP_SELL_UNIFORM=0: stream the value words even when they are all equal (diagnostic / A-B)
+        const char* e = std::getenv("SPLAHIP_SELL_UNIFORM");
+        return e && e[0] == '0';
     }
     int bits_force() {// SPLAHIP_SELL_BITS: 0 = never, 1 / unset = the device statistics decide, 2 = always (where the semiring allows it)
         const char* e = std::getenv("SPLAHIP_SELL_BITS");
@@ -326,9 +344,11 @@ namespace {
                                reinterpret_cast<unsigned long long*>(g->d_selbits), reinterpret_cast<uint4*>(vnext), g->n_bit_words / 4, static_cast<T*>(r),
                                from_bits<T>(init_bits), skip);
             hipLaunchKernelGGL((sell_mxv_dual_kernel<T, Mult, Add>), dim3(grid), dim3(SC::kTpb), 0, st, plan->n_rows, Ap, g->n_slices, g->d_vrow, g->d_vlen,
-                               g->d_vslot, g->d_off, g->d_Aj2, g->d_Aj2r, g->d_Ax2, reinterpret_cast<const T*>(g->d_hot_vals), g->n_hot,
+                               g->d_vslot, g->d_off, g->d_Aj2, g->d_Aj2r, g->x_uniform && !uniform_disabled() ? nullptr : g->d_Ax2,
+                               reinterpret_cast<const T*>(g->d_hot_vals), g->n_hot,
                                static_cast<const T*>(mask), static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(g->d_partial), Mult(op_mult),
-                               Add(op_add), op_select, from_bits<T>(init_bits), stats, g->n_cols, mode == 2 ? 1 : 0, vbits, g->d_vranked, g->d_selbits, g->d_sorder, ident);
+                               Add(op_add), op_select, from_bits<T>(init_bits), stats, g->n_cols, mode == 2 ? 1 : 0, vbits, g->d_vranked, g->d_selbits, g->d_sorder, ident,
+                               g->x_bits);
         } else {
             hipLaunchKernelGGL((sell_hot_pack_kernel<T>), dim3((g->n_hot + 255) / 256), dim3(256), 0, st, g->d_hot_cols, g->n_hot, static_cast<const T*>(v),
                                reinterpret_cast<T*>(g->d_hot_vals));
@@ -605,6 +625,21 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return bail("fill");
+    // 6. are all stored values one word?  (d_vbits is not in use yet: two of its words take the result)
+    if (nnz > 0) {
+        const uint range_init[2] = {0xFFFFFFFFu, 0u};
+        uint       range[2]      = {0, 1};
+        e = hipMemcpyAsync(g->d_vbits, range_init, 8, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(sell_ax_range_kernel, dim3(1024), dim3(256), 0, s, nnz, static_cast<const uint32_t*>(d_Ax), g->d_vbits);
+            e = hipMemcpyAsync(range, g->d_vbits, 8, hipMemcpyDeviceToHost, s);
+        }
+        if (e == hipSuccess) e = hipMemsetAsync(g->d_vbits, 0, 8, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return bail("value range");
+        g->x_uniform = range[0] == range[1];
+        g->x_bits    = range[0];
+    }
     plan->sell = g;
     return SPLAHIP_OK;
 }
@@ -616,6 +651,14 @@ extern "C" int splahip_csr_plan_sell_info(splahip_plan plan, uint32_t* n_slices,
     if (n_slots) *n_slots = g ? g->n_slots : 0;
     if (n_hot) *n_hot = g ? g->n_hot : 0;
     if (n_long_rows) *n_long_rows = g ? g->n_lrows : 0;
+    return SPLAHIP_OK;
+}
+
+extern "C" int splahip_csr_plan_sell_values(splahip_plan plan, int* uniform, uint32_t* bits) {
+    SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
+    const splahip_sell_s* g = plan->sell;
+    if (uniform) *uniform = g && g->x_uniform && !uniform_disabled() ? 1 : 0;
+    if (bits) *bits = g ? g->x_bits : 0;
     return SPLAHIP_OK;
 }
 

@@ -54,7 +54,9 @@ class CsrPlan:
                   current_stream_ptr())
         a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
         _lib.call("splahip_csr_plan_sell_info", self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
-        self.sell = {"slices": a.value, "slots": b.value, "hot_columns": c.value, "long_rows": d.value} if a.value else None
+        u, xb = C.c_int(), C.c_uint32()
+        _lib.call("splahip_csr_plan_sell_values", self._h, C.byref(u), C.byref(xb))
+        self.sell = {"slices": a.value, "slots": b.value, "hot_columns": c.value, "long_rows": d.value, "uniform_values": bool(u.value)} if a.value else None
 
     @property
     def handle(self):

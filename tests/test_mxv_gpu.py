@@ -343,3 +343,51 @@ def test_min_plus_bit_form(oracle, t):
         want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, w2, np.zeros(n_rows, NP[t]), v2, "PLUS", "MIN", "ALWAYS", INF)
         got = hip_mxv(t, n_rows, n_cols, Ap, Aj, w2, np.zeros(n_rows, NP[t]), v2, "PLUS", "MIN", "ALWAYS", INF)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", ["INT", "UINT", "FLOAT"])
+def test_uniform_matrix_values_structure_only(oracle, t):
+    """A matrix whose stored values are all one word (a graph's adjacency matrix) is served by the sliced-ELL bit form without its value
+    stream.  Values other than 1, every bit-form semiring family, long rows, both input-vector densities; one odd value switches the
+    shortcut off; SPLAHIP_SELL_UNIFORM=0 streams the words again — all equal the oracle."""
+    import os
+    import torch
+    from gpu_utils import dev, hip_mxv
+    from spla_amd import kernels
+    rng = np.random.default_rng(707)
+    n_rows, n_cols = 5000, 90000
+    Ap, Aj, _ = random_csr(rng, n_rows, n_cols, 10, t, skew=True, long_rows=3, long_len=1500)
+    fams = [("PLUS", "MIN", 1 << 20)] + ([("BAND", "BOR", 0), ("MULT", "PLUS", 2), ("LAND", "BXOR", 0)] if t != "FLOAT" else [])
+    for xval in (1, 6):
+        Ax = np.full(len(Aj), xval, NP[t])
+        plan = kernels.CsrPlan(n_rows, len(Aj), dev(Ap), n_cols, dev(Aj), dev(Ax))
+        assert plan.sell["uniform_values"] is True
+        plan.close()
+        for mul, add, init in fams:
+            for frac in (0.01, 0.6):
+                v = np.full(n_cols, init if add == "MIN" else 0, NP[t])
+                k = rng.random(n_cols) < frac
+                v[k] = rng.integers(1, 9, int(k.sum())).astype(NP[t])
+                for sel in ("ALWAYS", "EQZERO"):
+                    mask = random_mask(rng, n_rows, t)
+                    want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
+                    for uni in ("1", "0"):
+                        os.environ["SPLAHIP_SELL_UNIFORM"] = uni
+                        try:
+                            got = hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init, junk=3)
+                        finally:
+                            os.environ.pop("SPLAHIP_SELL_UNIFORM")
+                        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (t, xval, mul, add, frac, sel, uni)
+    Ax = np.full(len(Aj), 1, NP[t])
+    Ax[len(Aj) // 2] = 2
+    plan = kernels.CsrPlan(n_rows, len(Aj), dev(Ap), n_cols, dev(Aj), dev(Ax))
+    assert plan.sell["uniform_values"] is False
+    plan.close()
+    v = (rng.random(n_cols) < 0.05).astype(NP[t])
+    mul, add, init = ("PLUS", "MIN", 1 << 20) if t == "FLOAT" else ("MULT", "PLUS", 0)
+    if add == "MIN":
+        v = np.where(v > 0, v, init).astype(NP[t])
+    want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, np.zeros(n_rows, NP[t]), v, mul, add, "ALWAYS", init)
+    got = hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, np.zeros(n_rows, NP[t]), v, mul, add, "ALWAYS", init)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
