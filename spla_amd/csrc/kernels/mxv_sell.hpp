@@ -539,6 +539,10 @@ namespace splahip {
         sell_mxv_body<T, Mult, Add, false, true>(s_hot, &s_next, n_rows, Ap, n_slices, vrow, vlen, vslot, off, Aj2, Ax2, hot_values, n_hot, mask, v, r, partial,
                                                  mult, add, op_select, T(0), false, 0u, nullptr, nullptr, nullptr, sorder, touched);
     }
+    template<typename T, class Add, bool VXM = false>
+    __device__ __forceinline__ void sell_combine_block(uint block, uint n_lrows, const uint* __restrict__ lr_row, const uint* __restrict__ lr_first,
+                                                       const T* __restrict__ partial, const T* __restrict__ mask, T* __restrict__ r, Add add, int op_select,
+                                                       T init, uint* __restrict__ touched = nullptr);// (defined below, next to its mxv user)
     template<typename T, class Add>
     __global__ __launch_bounds__(256) void sell_vxm_combine_kernel(uint n_lrows, const uint* __restrict__ lr_row, const uint* __restrict__ lr_first,
                                                                    const T* __restrict__ partial, const T* __restrict__ mask, T* __restrict__ r,
@@ -612,10 +616,10 @@ namespace splahip {
 
     // rows longer than kC: r[row] = init (+) partial[first] (+) partial[first + 1] ... in chunk order.  One wave per row: lane l
     // folds a contiguous run of the row's partials, then an in-order wave reduction joins the runs (associative op_add).
-    template<typename T, class Add, bool VXM = false>
+    template<typename T, class Add, bool VXM>
     __device__ __forceinline__ void sell_combine_block(uint block, uint n_lrows, const uint* __restrict__ lr_row, const uint* __restrict__ lr_first,
                                                        const T* __restrict__ partial, const T* __restrict__ mask, T* __restrict__ r, Add add, int op_select,
-                                                       T init, uint* __restrict__ touched = nullptr) {
+                                                       T init, uint* __restrict__ touched) {
         const uint i = block * (256 / kWave) + threadIdx.x / kWave;
         if (i >= n_lrows) return;
         const uint row = lr_row[i];
