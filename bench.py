@@ -348,7 +348,7 @@ def main():
         _, per_x = timed(exchange, args.steps, 2)
         x_ms = float(np.mean(per_x))
         # what this rank receives from EACH peer (direct all-gather over the xGMI mesh): a padded dense slice, or the longest position list
-        slice_bytes = 4 * sh.max_rows if not sparse else 8 * int(sx.prev.numel() // world)
+        slice_bytes = 4 * sh.max_rows if not sparse else 4 * int(sx.prev.numel() // world)
         xm = torch.tensor([x_ms], device=coll_device(), dtype=torch.float64)
         dist.all_reduce(xm, op=dist.ReduceOp.MAX)
         out["exchange"] = {"mode": "sparse (positions of the non-fill entries)" if sparse else "dense (padded slices)",

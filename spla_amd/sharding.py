@@ -89,6 +89,7 @@ class SparseExchange:
     def __init__(self, blk: RowBlock, dtype, device, fill=0):
         self.blk, self.fill = blk, fill
         self.trash = blk.n_cols_padded
+        assert blk.n_cols_padded < 2 ** 31, "positions are exchanged as 4-byte words"
         self.v_full = torch.full((blk.n_cols_padded + 1,), fill, dtype=dtype, device=device)
         self.prev = None  # positions written by the previous exchange
         self.last_count = 0  # entries exchanged by the last call (all ranks)
@@ -124,8 +125,10 @@ class SparseExchange:
             send[:c] = idx + blk.rank * blk.max_rows  # position in the padded [world][max_rows] layout
             idx = torch.cat([idx, torch.full((m - c,), -1, dtype=torch.int64, device=dev)])
             total = sum(counts)
-        recv = torch.empty(blk.world * m, dtype=torch.int64, device=dev)
-        self._all_gather(recv, send)
+        # positions travel as 4-byte words (n_cols_padded < 2^31), half the bytes of the index type torch scatters with
+        recv32 = torch.empty(blk.world * m, dtype=torch.int32, device=dev)
+        self._all_gather(recv32, send.to(torch.int32))
+        recv = recv32.to(torch.int64)
         if self.prev is not None:
             self.v_full.index_fill_(0, self.prev, self.fill)
         if value is not None:
