@@ -247,12 +247,16 @@ def main():
     if sparse:
         from spla_amd import sharding
         sx = sharding.SparseExchange(sh.blk, torch.int32, "cuda", fill=0)
-        v_full = sx.exchange(front[:n_local], value=1, upper_bound=front_total)[:sh.n_cols_padded]
+        # the bound every rank pads its position list to: the largest per-rank frontier count — in a real traversal the previous level's
+        # count reduction delivers it (a MAX beside the SUM); padding to the global count would send world x the bytes
+        fmax = torch.tensor([int((depth == L).sum())], device=coll_device(), dtype=torch.int64)
+        dist.all_reduce(fmax, op=dist.ReduceOp.MAX)
+        front_bound = int(fmax[0])
+        v_full = sx.exchange(front[:n_local], value=1, upper_bound=front_bound)[:sh.n_cols_padded]
 
     def exchange():
         if sparse:
-            # the global frontier size is what the previous level's count_mf returned in a real traversal: every rank knows it
-            sx.exchange(front[:n_local], value=1, upper_bound=front_total)
+            sx.exchange(front[:n_local], value=1, upper_bound=front_bound)
         else:
             sh.gather(front, v_full)
 
