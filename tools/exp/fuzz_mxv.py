@@ -23,6 +23,8 @@ while time.time() - t0 < budget:
     long_len = int(min(n_cols, rng.choice([257, 300, 700, 5000, 16384, 16500, 33000])))
     Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, float(rng.choice([0.5, 3, 12, 40])), t, skew=bool(rng.integers(0, 2)), empty_frac=float(rng.choice([0.0, 0.3, 0.9])),
                             long_rows=long_rows, long_len=long_len)
+    if rng.random() < 0.2 and len(Ax):  # a matrix of equal values: the structure-only pass of the sliced-ELL bit form
+        Ax = np.full_like(Ax, Ax[0] if rng.integers(0, 2) else 1)
     sems = SEMIRINGS_COMMON + (SEMIRINGS_INT if t != "FLOAT" else []) + ([("MULT", "BXOR"), ("LAND", "PLUS"), ("BAND", "BOR")] if t != "FLOAT" else [])
     mul, add = sems[int(rng.integers(0, len(sems)))]
     sel = SELECTS[int(rng.integers(0, len(SELECTS)))]
