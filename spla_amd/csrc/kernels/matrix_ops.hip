@@ -19,24 +19,33 @@ namespace splahip {
 
     constexpr uint kEntriesPerThread = 8;
 
-    // payload[k] = (row of entry k) << 32 | value bits.  A thread owns 8 consecutive entries: one binary search, then a walk.
+    // payload[k] = (row of entry k) << 32 | value bits.  A workgroup owns a tile of 2048 consecutive entries and its lanes stride across
+    // it (coalesced value reads and payload writes); the row of an entry = the last row with Ap[row] <= k, by a binary search inside the
+    // tile's own row range (a few steps over row pointers the whole workgroup keeps re-reading, i.e. cache hits).
     __global__ __launch_bounds__(256) void transpose_payload_kernel(uint n_rows, uint nnz, const uint* __restrict__ Ap, const uint* __restrict__ Ax,
                                                                     unsigned long long* __restrict__ payload) {
-        const unsigned long long first = ((unsigned long long) blockIdx.x * 256 + threadIdx.x) * kEntriesPerThread;
-        if (first >= nnz) return;
-        uint lo = 0, hi = n_rows;// last row with Ap[row] <= first
-        while (hi - lo > 1) {
-            const uint mid = lo + ((hi - lo) >> 1);
-            if (Ap[mid] <= first) lo = mid;
-            else
-                hi = mid;
-        }
-        uint row  = lo;
-        uint next = Ap[row + 1];
-        const uint last = (uint) min((unsigned long long) nnz, first + kEntriesPerThread);
-        for (uint k = (uint) first; k < last; ++k) {
-            while (k >= next) next = Ap[++row + 1];
-            payload[k] = ((unsigned long long) row << 32) | Ax[k];
+        const unsigned long long tile = (unsigned long long) blockIdx.x * (256 * kEntriesPerThread);
+        if (tile >= nnz) return;
+        const uint t0 = (uint) tile;
+        const uint t1 = (uint) min((unsigned long long) nnz, tile + 256 * kEntriesPerThread) - 1u;// the tile's last entry
+        auto row_of = [&](uint k, uint lo, uint hi) {// Ap[lo] <= k < Ap[hi]
+            while (hi - lo > 1) {
+                const uint mid = lo + ((hi - lo) >> 1);
+                if (Ap[mid] <= k) lo = mid;
+                else
+                    hi = mid;
+            }
+            return lo;
+        };
+        const uint r0 = row_of(t0, 0, n_rows);
+        const uint r1 = row_of(t1, r0, n_rows);
+#pragma unroll
+        for (uint i = 0; i < kEntriesPerThread; ++i) {
+            const unsigned long long kk = tile + threadIdx.x + 256 * i;// (64-bit: a tile may end at nnz = 2^32 - 1)
+            if (kk <= t1) {
+                const uint k = (uint) kk;
+                payload[k]   = ((unsigned long long) row_of(k, r0, r1 + 1) << 32) | Ax[k];
+            }
         }
     }
 
