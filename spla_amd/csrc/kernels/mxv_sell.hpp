@@ -611,7 +611,17 @@ namespace splahip {
         const uint row = (uint) (e >> 32);
         if (op_select != SPLAHIP_ALWAYS && !eval_sel(op_select, mask[row])) return;
         const T    x = from_bits<T>(is_const ? cbits : vranked[rank]);
-        atomic_fold(r + row, mult(from_bits<T>((uint) e), x), op_add);
+        const T    p = mult(from_bits<T>((uint) e), x);
+        // MIN / MAX / BOR only ever move r[row] one way: a product that cannot move the value read now cannot move the final one either,
+        // and most cold products of a shortest-path step do not beat what the LDS-resident columns already gave the row — a plain
+        // load instead of a read-modify-write in the L2
+        if (op_add == SPLAHIP_MIN || op_add == SPLAHIP_MAX || op_add == SPLAHIP_BOR) {
+            const T cur = from_bits<T>(__hip_atomic_load(reinterpret_cast<const uint*>(r + row), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (op_add == SPLAHIP_MIN && !(p < cur)) return;
+            if (op_add == SPLAHIP_MAX && !(cur < p)) return;
+            if (op_add == SPLAHIP_BOR && (to_bits(cur) | to_bits(p)) == to_bits(cur)) return;
+        }
+        atomic_fold(r + row, p, op_add);
     }
 
     // rows longer than kC: r[row] = init (+) partial[first] (+) partial[first + 1] ... in chunk order.  One wave per row: lane l
