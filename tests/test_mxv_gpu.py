@@ -242,6 +242,18 @@ def test_sparse_input_vector_cold_ranks(oracle):
         want = oracle.mxv_masked("INT", n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
         got = hip_mxv("INT", n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
         assert_same(got, want, "INT", what=f"cold ranks {mul}/{add}")
+    # the one-way folds of the cold list (a plain load decides whether the product can still move r[row]): min-plus with weights and
+    # varying finite values (int32, fp32) and uint MAX, most entries of a row cold
+    for t, mul, add, init in (("INT", "PLUS", "MIN", 1 << 30), ("FLOAT", "PLUS", "MIN", 3.0e38), ("UINT", "MULT", "MAX", 0)):
+        w = rng.integers(1, 200, len(Aj)).astype(NP[t])
+        vv = np.full(n_cols, 0 if add == "MAX" else init, NP[t])
+        k = rng.random(n_cols) < 0.15
+        vv[k] = rng.integers(1, 100000, int(k.sum())).astype(NP[t])
+        m = random_mask(rng, n_rows, t)
+        for sel in ("ALWAYS", "EQZERO"):
+            want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, w, m, vv, mul, add, sel, init)
+            got = hip_mxv(t, n_rows, n_cols, Ap, Aj, w, m, vv, mul, add, sel, init, junk=5)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (t, mul, add, sel)
 
 
 @pytest.mark.gpu
