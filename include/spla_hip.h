@@ -78,6 +78,17 @@ int splahip_csr_plan_sell_info(splahip_plan plan, uint32_t* n_slices, uint32_t* 
 /* sell_values: *uniform = 1 when every stored value of the matrix is the same 4-byte word (*bits), as in a graph's adjacency matrix of
  * ones; the sparse-vector (bit) form then streams the 4-byte column words only — a structure-only pass, 4 B per entry instead of 8.   */
 int splahip_csr_plan_sell_values(splahip_plan plan, int* uniform, uint32_t* bits);
+/* Optional: a "column-ordered blocks" copy of the matrix, kept with the plan (+8 bytes per entry; DESIGN.md 4.9, spla_amd/csrc/kernels/mxv_cob.hpp).
+ * Rows are cut into ranges of 2^row_bits rows whose result slice lives in LDS; a range's entries are stored sorted by column, so the
+ * gathers of v ascend and one 128-byte request serves several products; products enter the slice with the LDS atomic of op_add.
+ * With it splahip_mxv_masked serves every call without early exit whose op_add has such an atomic (PLUS; MIN / MAX / BOR / BAND / BXOR on
+ * int and uint; LOR / LAND): int / uint results stay bit-identical, fp32 PLUS folds in column-block order (1e-5 relative).
+ * row_bits: 0 = default (14), else 8..15; tile_chunks: 256-entry chunks per workgroup, 0 = default (256).  The copy holds the VALUES:
+ * rebuild it when Aj or Ax change.  A hypersparse matrix (more (range, column window) groups than nnz / 512) is left without a copy.
+ * Blocks.  cob_info: workgroups, chunks, partial slabs, row_bits (all 0 when no copy was built).                                  */
+int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, uint32_t row_bits,
+                                uint32_t tile_chunks, void* stream);
+int splahip_csr_plan_cob_info(splahip_plan plan, uint32_t* n_tiles, uint32_t* n_chunks, uint32_t* n_slabs, uint32_t* row_bits);
 int splahip_csr_plan_destroy(splahip_plan plan);
 /* n_items: work items; n_long: rows cut into segment items */
 int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_items, uint32_t* n_long);

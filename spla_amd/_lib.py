@@ -42,6 +42,8 @@ _SIGNATURES = {
     "splahip_csr_plan_attach_sell": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, _vp]),
     "splahip_csr_plan_sell_info": (C.c_int, [_vp, _u32p, _u32p, _u32p, _u32p]),
     "splahip_csr_plan_sell_values": (C.c_int, [_vp, C.POINTER(C.c_int), _u32p]),
+    "splahip_csr_plan_attach_cob": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp]),
+    "splahip_csr_plan_cob_info": (C.c_int, [_vp, _u32p, _u32p, _u32p, _u32p]),
     "splahip_mxv_variant_of": (C.c_char_p, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "splahip_csr_plan_destroy": (C.c_int, [_vp]),
     "splahip_csr_plan_info": (C.c_int, [_vp, _u32p, _u32p]),

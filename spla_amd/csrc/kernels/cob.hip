@@ -1,0 +1,439 @@
+// cob.hip — the "column-ordered blocks" copy of a device CSR matrix: built once per matrix on the device, kept with the plan
+// (part of the AccCsr decoration, like the wave-tile items and the sliced-ELL copy), and the masked SpMV / pull-form vxm over it.
+//
+// Semantics served: reference Algo_mxv_masked_cpu, src/cpu/cpu_mxv.hpp:88-103, and the dense-frontier case of Algo_vxm_masked_cpu,
+// src/cpu/cpu_vxm.hpp:92-125, for an op_add with an LDS atomic (mxv_cob.hpp: cob_acc_kind).  Kernels: mxv_cob.hpp.
+//
+// Build (all on the device; the host reads three counters):
+//   1. cob_key_kernel     key(k) = ((range << cbits | column) << row_bits) | row_in_range for every stored entry, by one binary search of
+//                         the entry's 2048-entry tile in Ap and one inside the tile's row span
+//   2. a stable LSD radix sort of the keys on the (range, column) bits only, carrying the value word (rocprim, one-off per matrix):
+//      inside a (range, column) run the entries keep ascending row order
+//   3. cob_group_kernel   first sorted entry of every (range, column window) group by binary search; chunks per group; scan
+//   4. cob_scatter_kernel one workgroup per chunk: pack cr / ax / hdr, pad a group's last chunk
+//   5. cob_tile_kernels   tiles (<= tile_chunks consecutive chunks of one range), slab ids of the ranges that need several tiles
+#include "block_utils.hpp"
+#include "common.hpp"
+#include "mxv_cob.hpp"
+#include "ops.hpp"
+#include "plan.hpp"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <cstdlib>
+
+using namespace splahip;
+
+namespace {
+
+    constexpr uint32_t kKeyTile = 2048;// entries per workgroup of the key pass
+    constexpr unsigned kTpb     = 1024;// threads of a tile's workgroup
+
+    // first index in a[0..n) with a[index] > x
+    __device__ __forceinline__ uint32_t upper_bound_u32(const uint32_t* __restrict__ a, uint32_t n, uint32_t x) {
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a[mid] <= x) lo = mid + 1;
+            else
+                hi = mid;
+        }
+        return lo;
+    }
+
+    __global__ __launch_bounds__(256) void cob_key_kernel(uint32_t n_rows, uint32_t nnz, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ Aj,
+                                                          uint32_t row_bits, uint32_t cbits, unsigned long long* __restrict__ key) {
+        const uint32_t k0 = blockIdx.x * kKeyTile;
+        const uint32_t k1 = min(nnz, k0 + kKeyTile);
+        // rows spanned by this tile of the entry stream (uniform searches: every lane reads the same words)
+        const uint32_t r_lo = upper_bound_u32(Ap, n_rows + 1, k0) - 1;
+        const uint32_t r_hi = upper_bound_u32(Ap, n_rows + 1, k1 - 1) - 1;
+        const uint32_t rmask = (1u << row_bits) - 1u;
+        for (uint32_t k = k0 + threadIdx.x; k < k1; k += 256) {
+            const uint32_t row = r_lo + upper_bound_u32(Ap + r_lo, r_hi - r_lo + 1, k) - 1;
+            const unsigned long long range = row >> row_bits;
+            key[k] = (((range << cbits) | Aj[k]) << row_bits) | (row & rmask);
+        }
+    }
+
+    // start[g] = first sorted entry whose (range, window) group is >= g, g = 0 .. n_groups; chunks[g] = chunks of group g
+    __global__ __launch_bounds__(256) void cob_group_kernel(uint32_t nnz, const unsigned long long* __restrict__ key, uint32_t shift, uint32_t n_groups,
+                                                            uint32_t* __restrict__ start) {
+        const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+        if (g > n_groups) return;
+        uint32_t lo = 0, hi = nnz;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((key[mid] >> shift) < g) lo = mid + 1;
+            else
+                hi = mid;
+        }
+        start[g] = lo;
+    }
+    __global__ __launch_bounds__(256) void cob_chunk_count_kernel(uint32_t n_groups, const uint32_t* __restrict__ start, uint32_t* __restrict__ chunks) {
+        const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+        if (g < n_groups) chunks[g] = (start[g + 1] - start[g] + kCobChunk - 1) / kCobChunk;
+    }
+
+    // one workgroup (256 threads = 256 slots) per chunk
+    __global__ __launch_bounds__(256) void cob_scatter_kernel(const unsigned long long* __restrict__ key, const uint32_t* __restrict__ val, const uint32_t* __restrict__ start,
+                                                              const uint32_t* __restrict__ chunk_first, uint32_t n_groups, uint32_t row_bits, uint32_t col_bits,
+                                                              uint32_t win_bits, uint32_t* __restrict__ cr, uint32_t* __restrict__ ax, uint32_t* __restrict__ hdr) {
+        const uint32_t c = blockIdx.x;
+        const uint32_t g = upper_bound_u32(chunk_first, n_groups + 1, c) - 1;// largest g with chunk_first[g] <= c (uniform)
+        const uint32_t i = c - chunk_first[g];
+        const uint32_t s0 = start[g], s1 = start[g + 1];
+        // memory position p = 4 * lane + j holds the chunk's sorted entry 64 * j + lane: a lane's 16-byte load brings its four slots, and the
+        // wave's j-th gather instruction covers 64 consecutive sorted entries (ascending, neighbouring columns)
+        const uint32_t src = s0 + i * kCobChunk + 64 * (threadIdx.x & 3) + (threadIdx.x >> 2);
+        uint32_t       w = (1u << row_bits) << col_bits, x = 0;// padding: row field R (the spare LDS word), column offset 0
+        if (src < s1) {
+            const unsigned long long k = key[src];
+            const uint32_t           rl = (uint32_t) k & ((1u << row_bits) - 1u);
+            const uint32_t           co = (uint32_t) (k >> row_bits) & ((1u << col_bits) - 1u);
+            w                           = (rl << col_bits) | co;
+            x                           = val[src];
+        }
+        cr[(size_t) c * kCobChunk + threadIdx.x] = w;
+        ax[(size_t) c * kCobChunk + threadIdx.x] = x;
+        if (threadIdx.x == 0) {
+            const uint32_t window = win_bits ? (g & ((1u << win_bits) - 1u)) : 0u;
+            hdr[c]                = window << col_bits;
+        }
+    }
+
+    __global__ __launch_bounds__(256) void cob_padchunk_kernel(uint32_t c, uint32_t row_bits, uint32_t col_bits, uint32_t* __restrict__ cr, uint32_t* __restrict__ ax,
+                                                               uint32_t* __restrict__ hdr) {
+        cr[(size_t) c * kCobChunk + threadIdx.x] = (1u << row_bits) << col_bits;
+        ax[(size_t) c * kCobChunk + threadIdx.x] = 0;
+        if (threadIdx.x == 0) hdr[c] = 0;
+    }
+
+    // per range: tiles = ceil(chunks / tile_chunks); a range with several tiles needs that many slabs
+    __global__ __launch_bounds__(256) void cob_tile_count_kernel(uint32_t n_ranges, uint32_t win_bits, const uint32_t* __restrict__ chunk_first, uint32_t tile_chunks,
+                                                                 uint32_t* __restrict__ tiles, uint32_t* __restrict__ slabs, uint32_t* __restrict__ multi) {
+        const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+        if (q >= n_ranges) return;
+        const uint32_t cc = chunk_first[(q + 1) << win_bits] - chunk_first[q << win_bits];
+        const uint32_t nt = (cc + tile_chunks - 1) / tile_chunks;
+        tiles[q]          = nt;
+        slabs[q]          = nt > 1 ? nt : 0;
+        multi[q]          = nt > 1 ? 1 : 0;
+    }
+    // a range without an entry still owns rows: they are finished by cob_fill_kernel (below), not by a tile
+    __global__ __launch_bounds__(256) void cob_tile_write_kernel(uint32_t n_ranges, uint32_t win_bits, const uint32_t* __restrict__ chunk_first, uint32_t tile_chunks,
+                                                                 const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ slab_first,
+                                                                 const uint32_t* __restrict__ multi_first, CobTile* __restrict__ tiles, CobMulti* __restrict__ multi,
+                                                                 uint32_t* __restrict__ empty_ranges, uint32_t* __restrict__ n_empty) {
+        const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+        if (q >= n_ranges) return;
+        const uint32_t c0 = chunk_first[q << win_bits], c1 = chunk_first[(q + 1) << win_bits];
+        const uint32_t nt = tile_first[q + 1] - tile_first[q];
+        if (nt == 0) {
+            empty_ranges[atomicAdd(n_empty, 1u)] = q;
+            return;
+        }
+        // equal tiles rather than full ones plus a remainder: the first cc % nt tiles hold one chunk more
+        const uint32_t cc = c1 - c0, per = cc / nt, rem = cc % nt;
+        uint32_t       f  = c0;
+        for (uint32_t t = 0; t < nt; ++t) {
+            const uint32_t len = per + (t < rem ? 1u : 0u);
+            tiles[tile_first[q] + t] = CobTile{f, len, q, nt > 1 ? slab_first[q] + t : kCobNoSlab};
+            f += len;
+        }
+        if (nt > 1) multi[multi_first[q]] = CobMulti{q, slab_first[q], nt, 0};
+    }
+
+    // rows of ranges that hold no entry at all: r = init (grid.y = empty range)
+    template<typename T>
+    __global__ __launch_bounds__(256) void cob_fill_kernel(const uint32_t* __restrict__ empty_ranges, uint32_t n_rows, uint32_t row_bits, T* __restrict__ r, T init) {
+        const uint32_t i   = blockIdx.x * 256 + threadIdx.x;
+        const uint32_t row = (empty_ranges[blockIdx.y] << row_bits) + i;
+        if (i < (1u << row_bits) && row < n_rows) r[row] = init;
+    }
+
+    struct Scratch {
+        std::vector<void*> ptrs;
+        ~Scratch() {
+            for (void* p : ptrs)
+                if (p) (void) hipFree(p);
+        }
+        template<typename U>
+        hipError_t alloc(U** out, size_t count) {
+            void*      p = nullptr;
+            hipError_t e = hipMalloc(&p, sizeof(U) * (count ? count : 1));
+            if (e == hipSuccess) ptrs.push_back(p);
+            *out = static_cast<U*>(p);
+            return e;
+        }
+    };
+
+    uint32_t bits_for(uint64_t count) {// bits needed to tell `count` values apart (0 for count <= 1)
+        uint32_t b = 0;
+        while ((uint64_t(1) << b) < count) ++b;
+        return b;
+    }
+
+    bool cob_disabled() {
+        const char* e = std::getenv("SPLAHIP_COB");
+        return e && e[0] == '0';
+    }
+    uint32_t env_u32(const char* name, uint32_t dflt) {
+        const char* e = std::getenv(name);
+        return e && *e ? (uint32_t) std::strtoul(e, nullptr, 10) : dflt;
+    }
+
+    template<typename T, class Mult, int ACC, bool VXM>
+    int launch_cob(const splahip_cob_s* g, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select, uint32_t init_bits,
+                   hipStream_t st) {
+        CobArgs a;
+        a.tiles    = reinterpret_cast<const CobTile*>(g->d_tiles);
+        a.hdr      = g->d_hdr;
+        a.cr       = g->d_cr;
+        a.ax       = g->d_ax;
+        a.Ap       = Ap;
+        a.slabs    = g->d_slabs;
+        a.n_rows   = g->n_rows;
+        a.row_bits = g->row_bits;
+        a.col_bits = g->col_bits;
+        a.pad_chunk = g->n_chunks;
+        const T        init = from_bits<T>(init_bits);
+        const uint32_t R    = 1u << g->row_bits;
+        if (g->n_tiles) {
+            static bool lds_raised = false;// a range of 16 Ki rows plus the spare words is just over the 64 KB a kernel gets without asking
+            if (!lds_raised) {
+                SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                160 * 1024));
+                lds_raised = true;
+            }
+            hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb>), dim3(g->n_tiles), dim3(kTpb), (R + 4) * sizeof(typename CobSlice<T, ACC>::word), st, a, static_cast<const T*>(v),
+                               static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
+            SPLAHIP_TRY(hipGetLastError());
+        }
+        if (g->n_multi) {
+            const uint32_t bx = (R / 4 + 255) / 256;
+            hipLaunchKernelGGL((cob_combine_kernel<T, DynBin, ACC, 256>), dim3(bx, g->n_multi), dim3(256), 0, st, reinterpret_cast<const CobMulti*>(g->d_multi), g->d_slabs, Ap,
+                               static_cast<const T*>(mask), static_cast<T*>(r), g->n_rows, g->row_bits, DynBin(op_add), op_select, init);
+            SPLAHIP_TRY(hipGetLastError());
+        }
+        if (g->n_empty) {
+            hipLaunchKernelGGL((cob_fill_kernel<T>), dim3((R + 255) / 256, g->n_empty), dim3(256), 0, st, g->d_empty, g->n_rows, g->row_bits, static_cast<T*>(r), init);
+            SPLAHIP_TRY(hipGetLastError());
+        }
+        return SPLAHIP_OK;
+    }
+
+    template<typename T, int ACC, bool VXM>
+    int cob_by_mult(const splahip_cob_s* g, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select, uint32_t init_bits,
+                    hipStream_t st) {
+        // the semirings of the configs get a compile-time op_mult; every other pair runs the runtime-switched functor
+        if constexpr (ACC == COB_ADD) {
+            if (op_mult == SPLAHIP_MULT) return launch_cob<T, StaBin<SPLAHIP_MULT>, ACC, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+        }
+        if constexpr (ACC == COB_MIN) {
+            if (op_mult == SPLAHIP_PLUS) return launch_cob<T, StaBin<SPLAHIP_PLUS>, ACC, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+        }
+        if constexpr (ACC == COB_OR && !std::is_same<T, float>::value) {
+            if (op_mult == SPLAHIP_BAND) return launch_cob<T, StaBin<SPLAHIP_BAND>, ACC, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+        }
+        if constexpr (ACC == COB_LOR) {
+            if (op_mult == SPLAHIP_LAND) return launch_cob<T, StaBin<SPLAHIP_LAND>, ACC, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+        }
+        return launch_cob<T, DynBin, ACC, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+    }
+
+    template<typename T, bool VXM>
+    int cob_typed(const splahip_cob_s* g, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select, uint32_t init_bits,
+                  hipStream_t st) {
+        constexpr int type = TypeId<T>::value;
+        switch (cob_acc_kind(op_add, type)) {
+            case COB_ADD: return cob_by_mult<T, COB_ADD, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+            case COB_LOR: return cob_by_mult<T, COB_LOR, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+            case COB_LAND: return cob_by_mult<T, COB_LAND, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+            default: break;
+        }
+        if constexpr (!std::is_same<T, float>::value) {
+            switch (cob_acc_kind(op_add, type)) {
+                case COB_MIN: return cob_by_mult<T, COB_MIN, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+                case COB_MAX: return cob_by_mult<T, COB_MAX, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+                case COB_OR: return cob_by_mult<T, COB_OR, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+                case COB_AND: return cob_by_mult<T, COB_AND, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+                case COB_XOR: return cob_by_mult<T, COB_XOR, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+                default: break;
+            }
+        }
+        return fail(SPLAHIP_NOT_IMPLEMENTED, "the column-ordered-blocks form has no LDS atomic for this op_add");
+    }
+
+}// namespace
+
+namespace splahip {
+
+    void cob_release(splahip_cob_s* g) {
+        if (!g) return;
+        for (void* p : {(void*) g->d_tiles, (void*) g->d_hdr, (void*) g->d_cr, (void*) g->d_ax, (void*) g->d_slabs, (void*) g->d_multi, (void*) g->d_empty})
+            if (p) (void) hipFree(p);
+        delete g;
+    }
+
+    bool cob_serves(const splahip_plan_s* plan, int type, int op_add, uint32_t n_cols) {
+        return plan && plan->cob && plan->cob->n_cols == n_cols && cob_acc_kind(op_add, type) != COB_NONE && !cob_disabled();
+    }
+
+    int cob_mxv(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
+                uint32_t init_bits, void* stream) {
+        hipStream_t st = as_stream(stream);
+        switch (type) {
+            case SPLAHIP_INT: return cob_typed<int32_t, false>(plan->cob, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+            case SPLAHIP_UINT: return cob_typed<uint32_t, false>(plan->cob, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+            case SPLAHIP_FLOAT: return cob_typed<float, false>(plan->cob, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+        }
+        return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
+    }
+
+}// namespace splahip
+
+extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, uint32_t row_bits,
+                                           uint32_t tile_chunks, void* stream) {
+    SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
+    if (plan->cob) {
+        cob_release(plan->cob);
+        plan->cob = nullptr;
+    }
+    if (plan->nnz == 0 || plan->n_rows == 0 || n_cols == 0) return SPLAHIP_OK;// nothing to lay out: mxv keeps the CSR kernels
+    SPLAHIP_REQUIRE(d_Ap && d_Aj && d_Ax, "null device pointer");
+    if (row_bits == 0) row_bits = env_u32("SPLAHIP_COB_ROW_BITS", 14);
+    if (tile_chunks == 0) tile_chunks = env_u32("SPLAHIP_COB_TILE_CHUNKS", 256);
+    SPLAHIP_REQUIRE(row_bits >= 8 && row_bits <= 15, "row_bits must be in [8, 15] (the range's result slice lives in LDS: 4 << row_bits bytes)");
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    hipStream_t    s      = as_stream(stream);
+    const uint32_t n_rows = plan->n_rows, nnz = plan->nnz;
+
+    const uint32_t col_bits = 31 - row_bits;                              // the row field is one bit wider than a row needs (padding slots: row value R)
+    const uint32_t cbits    = std::max(bits_for(n_cols), col_bits);      // column field of the sort key: at least one whole window
+    const uint32_t win_bits = cbits - col_bits;                          // column windows per range = 2^win_bits
+    const uint32_t n_ranges = (uint32_t) (((uint64_t) n_rows + (1u << row_bits) - 1) >> row_bits);
+    const uint64_t n_groups64 = (uint64_t) n_ranges << win_bits;
+    // every (range, window) group pads its last chunk: with more groups than nnz / 512 the copy would be mostly padding (a hypersparse
+    // matrix) — the CSR kernels keep such a matrix
+    if (n_groups64 > (uint64_t) nnz / 512 + 64 || n_groups64 >= (1u << 30)) return SPLAHIP_OK;
+    const uint32_t n_groups = (uint32_t) n_groups64;
+    SPLAHIP_REQUIRE(row_bits + cbits + bits_for(n_ranges) <= 64, "key does not fit 64 bits");
+
+    Scratch tmp;
+    auto*   g   = new splahip_cob_s();
+    g->n_rows   = n_rows;
+    g->n_cols   = n_cols;
+    g->row_bits = row_bits;
+    g->col_bits = col_bits;
+    hipError_t e    = hipSuccess;
+    auto       bail = [&](const char* what) {
+        cob_release(g);
+        return fail(SPLAHIP_ERROR, "column-ordered-blocks plan failed (%s): %s", what, hipGetErrorString(e));
+    };
+
+    // 1 + 2: keys, stable sort on the (range, column) bits
+    unsigned long long *key = nullptr, *key_s = nullptr;
+    uint32_t*           val_s = nullptr;
+    e                         = tmp.alloc(&key, nnz);
+    if (e == hipSuccess) e = tmp.alloc(&key_s, nnz);
+    if (e == hipSuccess) e = tmp.alloc(&val_s, nnz);
+    if (e != hipSuccess) return bail("scratch");
+    hipLaunchKernelGGL(cob_key_kernel, dim3((nnz + kKeyTile - 1) / kKeyTile), dim3(256), 0, s, n_rows, nnz, d_Ap, d_Aj, row_bits, cbits, key);
+    e = hipGetLastError();
+    {
+        size_t      bytes = 0;
+        const auto* vin   = static_cast<const uint32_t*>(d_Ax);
+        const unsigned b0 = row_bits, b1 = row_bits + cbits + bits_for(n_ranges);
+        if (b1 == b0) {// one range, one column: the entries are in order already
+            if (e == hipSuccess) e = hipMemcpyAsync(key_s, key, sizeof(unsigned long long) * nnz, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(val_s, vin, sizeof(uint32_t) * nnz, hipMemcpyDeviceToDevice, s);
+        } else {
+            if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, bytes, key, key_s, vin, val_s, (size_t) nnz, b0, b1, s);
+            void* st_tmp = nullptr;
+            if (e == hipSuccess) e = hipMalloc(&st_tmp, bytes ? bytes : 4);
+            if (e == hipSuccess) {
+                tmp.ptrs.push_back(st_tmp);
+                e = rocprim::radix_sort_pairs(st_tmp, bytes, key, key_s, vin, val_s, (size_t) nnz, b0, b1, s);
+            }
+        }
+    }
+    if (e != hipSuccess) return bail("sort");
+
+    // 3: groups -> chunks
+    uint32_t *start = nullptr, *chunk_first = nullptr;
+    e = tmp.alloc(&start, (size_t) n_groups + 1);
+    if (e == hipSuccess) e = tmp.alloc(&chunk_first, (size_t) n_groups + 1);
+    if (e != hipSuccess) return bail("scratch");
+    hipLaunchKernelGGL(cob_group_kernel, dim3((n_groups + 256) / 256), dim3(256), 0, s, nnz, key_s, row_bits + col_bits, n_groups, start);
+    hipLaunchKernelGGL(cob_chunk_count_kernel, dim3((n_groups + 255) / 256), dim3(256), 0, s, n_groups, start, chunk_first);
+    hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk_first, n_groups);
+    e = hipGetLastError();
+    uint32_t n_chunks = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&n_chunks, chunk_first + n_groups, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return bail("groups");
+    g->n_chunks = n_chunks;
+
+    // 4: the packed streams
+    auto own = [&](auto** q, size_t count) {
+        using U = std::remove_pointer_t<std::remove_pointer_t<decltype(q)>>;
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(q), sizeof(U) * (count ? count : 1));
+    };
+    own(&g->d_cr, ((size_t) n_chunks + 1) * kCobChunk);// + one all-padding chunk (the main loop's steps beyond a tile's end walk it)
+    own(&g->d_ax, ((size_t) n_chunks + 1) * kCobChunk);
+    own(&g->d_hdr, (size_t) n_chunks + 1);
+    if (e != hipSuccess) return bail("hipMalloc");
+    hipLaunchKernelGGL(cob_padchunk_kernel, dim3(1), dim3(256), 0, s, n_chunks, row_bits, col_bits, g->d_cr, g->d_ax, g->d_hdr);
+    hipLaunchKernelGGL(cob_scatter_kernel, dim3(n_chunks), dim3(256), 0, s, key_s, val_s, start, chunk_first, n_groups, row_bits, col_bits, win_bits, g->d_cr, g->d_ax,
+                       g->d_hdr);
+    e = hipGetLastError();
+    if (e != hipSuccess) return bail("scatter");
+
+    // 5: tiles
+    uint32_t *tile_first = nullptr, *slab_first = nullptr, *multi_first = nullptr, *n_empty = nullptr;
+    e = tmp.alloc(&tile_first, (size_t) n_ranges + 1);
+    if (e == hipSuccess) e = tmp.alloc(&slab_first, (size_t) n_ranges + 1);
+    if (e == hipSuccess) e = tmp.alloc(&multi_first, (size_t) n_ranges + 1);
+    if (e == hipSuccess) e = tmp.alloc(&n_empty, 1);
+    if (e != hipSuccess) return bail("scratch");
+    hipLaunchKernelGGL(cob_tile_count_kernel, dim3((n_ranges + 255) / 256), dim3(256), 0, s, n_ranges, win_bits, chunk_first, tile_chunks, tile_first, slab_first, multi_first);
+    hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, tile_first, n_ranges);
+    hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, slab_first, n_ranges);
+    hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, multi_first, n_ranges);
+    e = hipGetLastError();
+    uint32_t h[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(&h[0], tile_first + n_ranges, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h[1], slab_first + n_ranges, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h[2], multi_first + n_ranges, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemsetAsync(n_empty, 0, 4, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return bail("tiles");
+    g->n_tiles = h[0];
+    g->n_slabs = h[1];
+    g->n_multi = h[2];
+    own(&g->d_tiles, (size_t) g->n_tiles * 4);
+    own(&g->d_multi, (size_t) g->n_multi * 4);
+    own(&g->d_slabs, (size_t) g->n_slabs << row_bits);
+    own(&g->d_empty, n_ranges);
+    if (e != hipSuccess) return bail("hipMalloc");
+    hipLaunchKernelGGL(cob_tile_write_kernel, dim3((n_ranges + 255) / 256), dim3(256), 0, s, n_ranges, win_bits, chunk_first, tile_chunks, tile_first, slab_first, multi_first,
+                       reinterpret_cast<CobTile*>(g->d_tiles), reinterpret_cast<CobMulti*>(g->d_multi), g->d_empty, n_empty);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&g->n_empty, n_empty, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return bail("tile write");
+    plan->cob = g;
+    return SPLAHIP_OK;
+}
+
+extern "C" int splahip_csr_plan_cob_info(splahip_plan plan, uint32_t* n_tiles, uint32_t* n_chunks, uint32_t* n_slabs, uint32_t* row_bits) {
+    SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
+    const splahip_cob_s* g = plan->cob;
+    if (n_tiles) *n_tiles = g ? g->n_tiles : 0;
+    if (n_chunks) *n_chunks = g ? g->n_chunks : 0;
+    if (n_slabs) *n_slabs = g ? g->n_slabs : 0;
+    if (row_bits) *row_bits = g ? g->row_bits : 0;
+    return SPLAHIP_OK;
+}

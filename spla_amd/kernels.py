@@ -39,6 +39,7 @@ class CsrPlan:
         sliced-ELL + hot-column copy that mxv uses for associative op_add (attach_sell)."""
         self.n_rows, self.nnz = int(n_rows), int(nnz)
         self.sell = None
+        self.cob = None
         self._h = C.c_void_p()
         _lib.call("splahip_csr_plan_create", C.byref(self._h), self.n_rows, self.nnz, _ptr(Ap), current_stream_ptr())
         nb, nl = C.c_uint32(), C.c_uint32()
@@ -57,6 +58,16 @@ class CsrPlan:
         u, xb = C.c_int(), C.c_uint32()
         _lib.call("splahip_csr_plan_sell_values", self._h, C.byref(u), C.byref(xb))
         self.sell = {"slices": a.value, "slots": b.value, "hot_columns": c.value, "long_rows": d.value, "uniform_values": bool(u.value)} if a.value else None
+
+    def attach_cob(self, n_cols: int, Ap: torch.Tensor, Aj: torch.Tensor, Ax: torch.Tensor, row_bits: int = 0, tile_chunks: int = 0):
+        """column-ordered-blocks copy of the matrix (values included: rebuild when the matrix changes); mxv then uses it for every
+        op_add with an LDS atomic.  row_bits / tile_chunks: 0 = the library's defaults."""
+        _lib.call("splahip_csr_plan_attach_cob", self._h, int(n_cols), _ptr(Ap), _ptr(Aj) if self.nnz else None, _ptr(Ax) if self.nnz else None,
+                  int(row_bits), int(tile_chunks), current_stream_ptr())
+        a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _lib.call("splahip_csr_plan_cob_info", self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        self.cob = {"tiles": a.value, "chunks": b.value, "slabs": c.value, "row_bits": d.value} if a.value else None
+        return self.cob
 
     @property
     def handle(self):

@@ -30,9 +30,13 @@ def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, 
     outs = {}
     # sell-bits: the sparse-input-vector form forced on wherever the semiring allows it (SPLAHIP_SELL_BITS=2); plain "sell" lets the
     # device statistics choose
-    for form in ("csr", "sell", "sell-bits"):
+    for form in ("csr", "sell", "sell-bits", "cob", "cob-small"):
         os.environ["SPLAHIP_SELL_BITS"] = "2" if form == "sell-bits" else "1"
-        plan = kernels.CsrPlan(n_rows, len(Aj), dAp, n_cols, dAj, dAx) if form != "csr" else kernels.CsrPlan(n_rows, len(Aj), dAp)
+        plan = kernels.CsrPlan(n_rows, len(Aj), dAp, n_cols, dAj, dAx) if form.startswith("sell") else kernels.CsrPlan(n_rows, len(Aj), dAp)
+        if form == "cob":        # column-ordered blocks, default geometry (ranges of 16 Ki rows)
+            plan.attach_cob(n_cols, dAp, dAj, dAx)
+        elif form == "cob-small":  # ranges of 256 rows, tiles of 2 chunks: many ranges, column windows, multi-tile ranges and slabs even on small inputs
+            plan.attach_cob(n_cols, dAp, dAj, dAx, row_bits=8, tile_chunks=2)
         r = torch.empty(n_rows, dtype=kernels.torch_dtype(t), device="cuda")
         if junk is not None:
             r.fill_(junk)
@@ -49,4 +53,12 @@ def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, 
         assert np.all(np.abs(a[fin] - b[fin]) <= 1e-5 * np.maximum(np.abs(b[fin]), 1e-30) + 1e-30), "sliced-ELL kernel differs from the CSR kernels"
     else:
         assert np.array_equal(outs["sell"], outs["csr"]), "sliced-ELL kernel differs from the CSR kernels"
+    for form in ("cob", "cob-small"):
+        if t == "FLOAT":
+            a, b = outs[form].astype(np.float64), outs["csr"].astype(np.float64)
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isinf(a), np.isinf(b)), f"{form} kernel differs from the CSR kernels"
+            fin = np.isfinite(a) & np.isfinite(b)
+            assert np.all(np.abs(a[fin] - b[fin]) <= 1e-5 * np.maximum(np.abs(b[fin]), 1e-30) + 1e-30), f"{form} kernel differs from the CSR kernels"
+        else:
+            assert np.array_equal(outs[form], outs["csr"]), f"{form} (column-ordered blocks) kernel differs from the CSR kernels"
     return outs["csr"]

@@ -1,0 +1,324 @@
+"""Every BASELINE.json config in the -m gpu suite, on the generators SURVEY.md 8d prescribes.
+
+  cfg1  exec_mxv plus-times fp32, uniform random 100k x 100k, 1 M nnz, dense v      (through spla_Exec_mxv_masked, full size)
+  cfg2  exec_mxv BAND/BOR int32, R-MAT, mask = BFS depth with EQZERO (the BFS step)   (scale 14 vs oracle: both early_exit values, all plans;
+                                                                                       scale 22 full size: row-sampled oracle check + properties)
+  cfg3  exec_vxm plus-times fp32, symmetrised R-MAT (stand-in for com-Orkut), 0.85/outdeg values, v = 1/n dense (PageRank step)
+  cfg4  exec_mxv min-plus int32, INF = 2^30, weights 1..255, R-MAT; whole and as 2 / 4 / 8 nnz-balanced row blocks stitched
+        (scale 15 vs oracle; scale 24 at N = 1 full size: row-sampled oracle check + monotonicity property)
+  cfg5  exec_mxm plus-times fp32 A x A and exec_mxmT_masked(L, L, L) int32 (triangle-count form), R-MAT scale 12 vs oracle
+
+Exact checks are written the way the reference writes them (tests/test_mxv.cpp:91-130: every output element compared);
+int32 / uint32 bit-exact, fp32 plus-times within 1e-5 relative (north star).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import NP
+
+pytestmark = pytest.mark.gpu
+
+FP32_RTOL = 1e-5
+
+
+def _rmat(scale, ef=16, seed=1, device="cpu", symmetric=False):
+    from spla_amd import graphgen
+    n = 1 << scale
+    key = graphgen.rmat_edge_keys(scale, ef, seed=seed, device=device)
+    if symmetric:
+        i, j = torch.div(key, n, rounding_mode="floor"), key % n
+        key = torch.unique(torch.cat([key, j * n + i]), sorted=True)
+    Ap, Aj = graphgen.keys_to_csr(key, n, n)
+    return n, Ap, Aj
+
+
+def _np_u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def _bfs_depth(n, Ap, Aj, src):
+    """depth vector (1 at the source, 0 unreached) of the graph whose edge i -> j is stored at A[i, j]; a pull step r = A x frontier
+    discovers row i when some A[i, j] has j in the frontier (reference src/algorithm.cpp:97-99), so levels follow the TRANSPOSED edges."""
+    import scipy.sparse as sp
+    A = sp.csr_matrix((np.ones(len(Aj), np.int8), Aj.astype(np.int64), Ap.astype(np.int64)), shape=(n, n))
+    depth = np.zeros(n, np.int32)
+    depth[src] = 1
+    front = np.zeros(n, np.int8)
+    front[src] = 1
+    level = 1
+    sizes = []
+    while True:
+        hit = (A @ front > 0) & (depth == 0)
+        if not hit.any():
+            break
+        level += 1
+        depth[hit] = level
+        front = hit.astype(np.int8)
+        sizes.append(int(hit.sum()))
+    return depth, sizes
+
+
+# ------------------------------------------------------------------------------------------------------------------ cfg1
+def test_cfg1_uniform_100k_fp32_plus_times_through_exec_api(oracle):
+    """configs[0] at full size through the operator API: spla_Exec_mxv_masked on Matrix / Vector objects (host COO -> AccCsr upload ->
+    HIP kernel -> read back), MULT_FLOAT / PLUS_FLOAT, init 0, all rows selected (NQZERO on a mask of ones)."""
+    from spla_amd import api, graphgen
+    n, nnz = 100_000, 1_000_000
+    Ap, Aj = graphgen.uniform_csr(n, nnz, seed=1, device="cpu")
+    Ap, Aj = _np_u32(Ap), _np_u32(Aj)
+    rng = np.random.default_rng(1)
+    Ax = rng.random(nnz, dtype=np.float32)
+    v = rng.random(n, dtype=np.float32)
+    api.set_accelerator(api.ACCELERATOR_HIP)
+    M = api.Matrix.from_csr(Ap, Aj, Ax, (n, n), api.FLOAT)
+    hv = api.Vector.from_lists(np.arange(n, dtype=np.uint32), v, n, api.FLOAT)
+    hm = api.Vector.from_lists(np.arange(n, dtype=np.uint32), np.ones(n, np.float32), n, api.FLOAT)
+    r = M.mxv(hm, hv, api.FLOAT.MULT, api.FLOAT.PLUS, api.FLOAT.NQZERO, init=api.Scalar(api.FLOAT, 0.0))
+    ri, rx = r.read()
+    got = np.zeros(n, np.float32)
+    got[ri] = rx
+    want = oracle.mxv_masked("FLOAT", n, n, Ap, Aj, Ax, np.ones(n, np.float32), v, "MULT", "PLUS", "NQZERO", 0.0)
+    np.testing.assert_allclose(got, want, rtol=FP32_RTOL, atol=0)
+    # rows without an entry keep init = 0 = the fill value: they must be absent from the sparse read-back, like the reference's
+    assert set(ri.tolist()) == set(np.nonzero(want != 0)[0].tolist())
+
+
+# ------------------------------------------------------------------------------------------------------------------ cfg2
+@pytest.mark.parametrize("ops", [("BAND", "BOR"), ("LAND", "LOR")])
+def test_cfg2_bfs_step_rmat_all_plans_both_early_exit(oracle, ops):
+    """configs[1] at an oracle-affordable scale: R-MAT scale 14 (ef 16, directed, loops + duplicates removed), int32 ones, mask = BFS depth
+    at the level producing the largest frontier with EQZERO, v = that frontier as dense 0/1, init 0; early_exit false and true; the CSR
+    kernels, the sliced-ELL copy and its forced bit form (gpu_utils.hip_mxv cross-checks the three)."""
+    from gpu_utils import hip_mxv
+    n, Ap, Aj = _rmat(14)
+    Ap, Aj = _np_u32(Ap), _np_u32(Aj)
+    deg = np.diff(Ap.astype(np.int64))
+    depth, sizes = _bfs_depth(n, Ap, Aj, int(np.argmax(deg)))
+    L = 1 + int(np.argmax(sizes))
+    mask = np.where(depth <= L, depth, 0).astype(np.int32)
+    v = (depth == L).astype(np.int32)
+    Ax = np.ones(len(Aj), np.int32)
+    for early in (False, True):
+        want = oracle.mxv_masked("INT", n, n, Ap, Aj, Ax, mask, v, ops[0], ops[1], "EQZERO", 0, early)
+        got = hip_mxv("INT", n, n, Ap, Aj, Ax, mask, v, ops[0], ops[1], "EQZERO", 0, early, junk=-7)
+        np.testing.assert_array_equal(got, want, err_msg=f"{ops} early_exit={early}")
+        assert int((want != 0).sum()) == sizes[L - 1]  # the step discovers exactly the next BFS level
+
+
+def _sampled_rows_oracle(oracle, t, Ap_d, Aj_d, Ax_d, rows_idx, n_cols, mask_d, v_d, mul, add, sel, init, early=False):
+    """oracle result of the rows `rows_idx` (device int64 tensor) of a device-resident CSR: rows are independent, so a row sample of the
+    full-size result can be checked at full size in seconds."""
+    Ap64 = Ap_d.to(torch.int64)
+    deg = (Ap64[1:] - Ap64[:-1])[rows_idx]
+    Ap_s = torch.zeros(rows_idx.numel() + 1, dtype=torch.int64, device=Ap_d.device)
+    torch.cumsum(deg, 0, out=Ap_s[1:])
+    nnz_s = int(Ap_s[-1])
+    rep = torch.repeat_interleave(torch.arange(rows_idx.numel(), device=Ap_d.device), deg)
+    src = Ap64[rows_idx][rep] + (torch.arange(nnz_s, device=Ap_d.device) - Ap_s[:-1][rep])
+    Aj_s, Ax_s = Aj_d[src].cpu().numpy().view(np.uint32), Ax_d[src].cpu().numpy()
+    return oracle.mxv_masked(t, int(rows_idx.numel()), n_cols, Ap_s.to(torch.int32).cpu().numpy().view(np.uint32), Aj_s, Ax_s,
+                             mask_d[rows_idx].cpu().numpy(), v_d.cpu().numpy(), mul, add, sel, init, early)
+
+
+def test_cfg2_full_size_scale22_properties_and_row_sample(oracle):
+    """configs[1] at BASELINE's full size (R-MAT scale 22, ~65 M nnz) through the kernel-level C ABI with the sliced-ELL copy attached (what
+    bench.py times): every 64th row against the oracle, plus size-independent properties: unselected rows == init, the result is 0/1,
+    early_exit=true gives the same vector (BOR of 0/1 is witness-independent), and the call is idempotent."""
+    from spla_amd import kernels
+    n, Ap, Aj = _rmat(22, device="cuda")
+    nnz = int(Ap[-1])
+    ones = torch.ones(nnz, dtype=torch.int32, device="cuda")
+    deg = (Ap[1:] - Ap[:-1]).to(torch.int64)
+    src = int(deg.argmax())
+    plan_csr = kernels.CsrPlan(n, nnz, Ap)
+    depth = torch.zeros(n, dtype=torch.int32, device="cuda")
+    depth[src] = 1
+    front = torch.zeros(n, dtype=torch.int32, device="cuda")
+    front[src] = 1
+    new = torch.empty(n, dtype=torch.int32, device="cuda")
+    sizes, level = [], 1
+    while True:
+        kernels.mxv_masked(plan_csr, "INT", n, Ap, Aj, ones, depth, front, new, "BAND", "BOR", "EQZERO", 0)
+        hit = new != 0
+        c = int(hit.sum())
+        if c == 0:
+            break
+        level += 1
+        depth[hit] = level
+        front = hit.to(torch.int32)
+        sizes.append(c)
+    L = 1 + int(np.argmax(sizes))
+    mask = torch.where(depth <= L, depth, torch.zeros_like(depth)).contiguous()
+    v = (depth == L).to(torch.int32)
+    plan = kernels.CsrPlan(n, nnz, Ap, n, Aj, ones)
+    r = torch.full((n,), -5, dtype=torch.int32, device="cuda")
+    kernels.mxv_masked(plan, "INT", n, Ap, Aj, ones, mask, v, r, "BAND", "BOR", "EQZERO", 0)
+    torch.cuda.synchronize()
+    assert int(((r != 0) & (r != 1)).sum()) == 0
+    assert int((r[mask != 0] != 0).sum()) == 0                      # unselected rows hold init
+    assert int((r != 0).sum()) == sizes[L - 1]                      # exactly the next level
+    r2 = torch.empty_like(r)
+    kernels.mxv_masked(plan, "INT", n, Ap, Aj, ones, mask, v, r2, "BAND", "BOR", "EQZERO", 0)
+    assert torch.equal(r, r2)                                       # idempotent (double-buffered bitmaps, plan-owned workspaces)
+    r3 = torch.empty_like(r)
+    kernels.mxv_masked(plan, "INT", n, Ap, Aj, ones, mask, v, r3, "BAND", "BOR", "EQZERO", 0, early_exit=True)
+    assert torch.equal(r, r3)
+    kernels.mxv_masked(plan_csr, "INT", n, Ap, Aj, ones, mask, v, r3, "BAND", "BOR", "EQZERO", 0)
+    assert torch.equal(r, r3)                                       # CSR wave-tile kernel == sliced-ELL bit form
+    rows_idx = torch.arange(0, n, 64, device="cuda")
+    want = _sampled_rows_oracle(oracle, "INT", Ap, Aj, ones, rows_idx, n, mask, v, "BAND", "BOR", "EQZERO", 0)
+    np.testing.assert_array_equal(r[rows_idx].cpu().numpy(), want)
+    plan.close()
+    plan_csr.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------ cfg3
+def test_cfg3_pagerank_step_vxm_fp32_symmetrised_rmat(oracle):
+    """configs[2] on the stated stand-in (com-Orkut is not on the box): symmetrised R-MAT scale 13 ef 28, values 0.85 / outdeg(row)
+    (reference examples/pr.cpp:81-88), v = 1/n with every index stored, MULT_FLOAT / PLUS_FLOAT, ALWAYS: the pull form over the CSR of
+    M^T and over its sliced-ELL copy, and the push form (it keeps the reference's fold order for runs of <= 64 products; longer runs are
+    folded by an in-order tree, hence the same 1e-5 bar)."""
+    from gpu_utils import dev, host
+    from spla_amd import kernels
+    n, Ap, Aj = _rmat(13, ef=28, symmetric=True)
+    Ap, Aj = _np_u32(Ap), _np_u32(Aj)
+    nnz = len(Aj)
+    deg = np.diff(Ap.astype(np.int64))
+    Ax = np.repeat((0.85 / np.maximum(deg, 1)).astype(np.float32), deg)
+    vi, vx = np.arange(n, dtype=np.uint32), np.full(n, 1.0 / n, np.float32)
+    mask = np.zeros(n, np.float32)
+    wi, wx = oracle.vxm_masked("FLOAT", n, n, Ap, Aj, Ax, mask, vi, vx, "MULT", "PLUS", "ALWAYS")
+    dAp, dAj, dAx, dm, dvi, dvx = dev(Ap), dev(Aj), dev(Ax), dev(mask), dev(vi), dev(vx)
+    Tp, Tj, Tx = kernels.csr_transpose(n, n, dAp, dAj, dAx)
+    for sell in (False, True):
+        plan_T = kernels.CsrPlan(n, nnz, Tp, n, Tj, Tx) if sell else kernels.CsrPlan(n, nnz, Tp)
+        ri, rx = kernels.vxm_pull(plan_T, "FLOAT", n, n, Tp, Tj, Tx, dm, dvi, dvx, "MULT", "PLUS", "ALWAYS", identity=True)
+        np.testing.assert_array_equal(host(ri, np.uint32), wi, err_msg=f"pull sell={sell}: structure")
+        np.testing.assert_allclose(host(rx, np.float32), wx, rtol=FP32_RTOL, atol=0, err_msg=f"pull sell={sell}")
+        plan_T.close()
+    ri, rx = kernels.vxm_push("FLOAT", n, n, dAp, dAj, dAx, dm, dvi, dvx, "MULT", "PLUS", "ALWAYS")
+    np.testing.assert_array_equal(host(ri, np.uint32), wi)
+    np.testing.assert_allclose(host(rx, np.float32), wx, rtol=FP32_RTOL, atol=0, err_msg="push")
+
+
+# ------------------------------------------------------------------------------------------------------------------ cfg4
+def _sssp_state(n, rng, finite_frac=0.125):
+    """distance vector of a mid-SSSP iteration: INF = 2^30 except a random 1/8 of the vertices with a finite distance"""
+    INF = 1 << 30
+    d = np.full(n, INF, np.int32)
+    k = int(n * finite_frac)
+    d[rng.permutation(n)[:k]] = rng.integers(0, 5000, k).astype(np.int32)
+    return d, INF
+
+
+@pytest.mark.parametrize("parts", [1, 2, 4, 8])
+def test_cfg4_sssp_step_min_plus_int32_row_blocks_stitched(oracle, parts):
+    """configs[3] at scale 15: PLUS_INT (mult) / MIN_INT (add), init INF = 2^30, weights uniform 1..255, ALWAYS; the whole matrix and its
+    2 / 4 / 8 nnz-balanced 1-D row blocks (global column ids, the full gathered v — what a rank computes after the all-gather), stitched:
+    a row-block split changes no row's fold, so the stitched vector equals the unsharded oracle result bit for bit."""
+    from gpu_utils import hip_mxv
+    from spla_amd import graphgen
+    n, Ap_t, Aj_t = _rmat(15)
+    Ap, Aj = _np_u32(Ap_t), _np_u32(Aj_t)
+    rng = np.random.default_rng(4)
+    Ax = rng.integers(1, 256, len(Aj)).astype(np.int32)
+    v, INF = _sssp_state(n, rng)
+    mask = np.zeros(n, np.int32)
+    want = oracle.mxv_masked("INT", n, n, Ap, Aj, Ax, mask, v, "PLUS", "MIN", "ALWAYS", INF)
+    bounds = graphgen.nnz_balanced_row_splits(Ap_t, parts)
+    got = np.empty(n, np.int32)
+    for p in range(parts):
+        lo, hi = bounds[p], bounds[p + 1]
+        if hi == lo:
+            continue
+        s, e = int(Ap[lo]), int(Ap[hi])
+        Ap_b = (Ap[lo:hi + 1].astype(np.int64) - s).astype(np.uint32)
+        got[lo:hi] = hip_mxv("INT", hi - lo, n, Ap_b, Aj[s:e].copy(), Ax[s:e].copy(), mask[lo:hi], v, "PLUS", "MIN", "ALWAYS", INF, junk=3)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_cfg4_full_size_scale24_row_sample_and_monotone(oracle):
+    """configs[3] at N = 1, full size (R-MAT scale 24, ~256 M nnz, 2.1 GB CSR): sliced-ELL copy attached; every 512th row against the oracle;
+    properties: r <= INF everywhere, r == INF exactly on rows none of whose neighbours is finite, and relaxing a second time with
+    v' = min(v, r) can only lower a distance (min-plus is monotone)."""
+    from spla_amd import kernels
+    n, Ap, Aj = _rmat(24, device="cuda")
+    nnz = int(Ap[-1])
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(44)
+    Ax = torch.randint(1, 256, (nnz,), generator=gen, device="cuda", dtype=torch.int32)
+    INF = 1 << 30
+    v = torch.full((n,), INF, dtype=torch.int32, device="cuda")
+    pos = torch.randint(0, n, (n // 8,), generator=gen, device="cuda")
+    v[pos] = torch.randint(0, 5000, (n // 8,), generator=gen, device="cuda", dtype=torch.int32)
+    mask = torch.zeros(n, dtype=torch.int32, device="cuda")
+    plan = kernels.CsrPlan(n, nnz, Ap, n, Aj, Ax)
+    r = torch.empty(n, dtype=torch.int32, device="cuda")
+    kernels.mxv_masked(plan, "INT", n, Ap, Aj, Ax, mask, v, r, "PLUS", "MIN", "ALWAYS", INF)
+    torch.cuda.synchronize()
+    assert int((r > INF).sum()) == 0 and int((r < 1).sum()) == 0
+    rows_idx = torch.arange(0, n, 512, device="cuda")
+    want = _sampled_rows_oracle(oracle, "INT", Ap, Aj, Ax, rows_idx, n, mask, v, "PLUS", "MIN", "ALWAYS", INF)
+    np.testing.assert_array_equal(r[rows_idx].cpu().numpy(), want)
+    # rows with no finite neighbour stay at INF, all others drop below it: structure-only product over the 0/1 "finite" vector
+    fin = (v < INF).to(torch.int32)
+    ones = torch.ones(nnz, dtype=torch.int32, device="cuda")
+    plan_csr = kernels.CsrPlan(n, nnz, Ap)
+    reach = torch.empty(n, dtype=torch.int32, device="cuda")
+    kernels.mxv_masked(plan_csr, "INT", n, Ap, Aj, ones, mask, fin, reach, "BAND", "BOR", "ALWAYS", 0)
+    assert torch.equal(reach != 0, r < INF)
+    v2 = torch.minimum(v, r)
+    r2 = torch.empty_like(r)
+    kernels.mxv_masked(plan, "INT", n, Ap, Aj, Ax, mask, v2, r2, "PLUS", "MIN", "ALWAYS", INF)
+    assert int((r2 > r).sum()) == 0
+    plan.close()
+    plan_csr.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------ cfg5
+def test_cfg5_mxm_fp32_rmat_AxA(oracle):
+    """configs[4], A x A: R-MAT scale 12 fp32 U(0,1) values, MULT / PLUS, init 0 (the oracle's dense accumulator row is O(n_cols) per row:
+    scale 12 keeps it in seconds).  Structure identical; values within 1e-5 (runs longer than 64 products are folded as a tree)."""
+    from gpu_utils import dev, host
+    from spla_amd import kernels
+    n, Ap, Aj = _rmat(12)
+    Ap, Aj = _np_u32(Ap), _np_u32(Aj)
+    rng = np.random.default_rng(5)
+    Ax = (rng.random(len(Aj), dtype=np.float32) + np.float32(0.01))
+    wp, wj, wx = oracle.mxm("FLOAT", n, n, (Ap, Aj, Ax), (Ap, Aj, Ax), "MULT", "PLUS", 0.0)
+    A = (dev(Ap), dev(Aj), dev(Ax))
+    for block in (0, 1 << 16):  # default row blocks, and many small ones
+        (Rp, Rj, Rx), products = kernels.mxm("FLOAT", n, n, A, A, "MULT", "PLUS", 0.0, block_products=block)
+        deg = np.diff(Ap.astype(np.int64))
+        assert products == int(deg[Aj].sum())
+        np.testing.assert_array_equal(host(Rp, np.uint32), wp)
+        np.testing.assert_array_equal(host(Rj, np.uint32), wj)
+        np.testing.assert_allclose(host(Rx, np.float32), wx, rtol=FP32_RTOL, atol=0)
+
+
+def test_cfg5_triangle_count_form_mxmT_LLL(oracle):
+    """configs[4], triangle-count path: L = strictly-lower triangle of the symmetrised R-MAT scale 12 pattern, int32 ones,
+    exec_mxmT_masked(L, L, L) with MULT / PLUS / GTZERO, init 0 (reference src/algorithm.cpp:398, examples/tc.cpp:82-86); bit-exact,
+    and the reduced sum equals the triangle count obtained from the dense A^3 trace."""
+    from gpu_utils import dev, host
+    from spla_amd import kernels
+    import scipy.sparse as sp
+    n, Ap, Aj = _rmat(12, symmetric=True)
+    Ap, Aj = _np_u32(Ap), _np_u32(Aj)
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(Ap.astype(np.int64)))
+    keep = Aj.astype(np.int64) < rows
+    Lj = Aj[keep]
+    Lp = np.zeros(n + 1, np.uint32)
+    Lp[1:] = np.cumsum(np.bincount(rows[keep], minlength=n))
+    Lx = np.ones(len(Lj), np.int32)
+    Lt = (Lp, Lj, Lx)
+    wp, wj, wx = oracle.mxmT_masked("INT", n, Lt, Lt, Lt, "MULT", "PLUS", "GTZERO", 0)
+    L = (dev(Lp), dev(Lj), dev(Lx))
+    Rp, Rj, Rx = kernels.mxmT_masked("INT", n, L, L, L, "MULT", "PLUS", "GTZERO", 0)
+    np.testing.assert_array_equal(host(Rp, np.uint32), wp)
+    np.testing.assert_array_equal(host(Rj, np.uint32), wj)
+    np.testing.assert_array_equal(host(Rx, np.int32), wx)
+    Ls = sp.csr_matrix((Lx.astype(np.int64), Lj.astype(np.int64), Lp.astype(np.int64)), shape=(n, n))
+    tri = int((Ls @ Ls.T).multiply(Ls).sum())
+    assert int(host(Rx, np.int32).astype(np.int64).sum()) == tri
