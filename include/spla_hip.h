@@ -83,7 +83,8 @@ int splahip_csr_plan_sell_values(splahip_plan plan, int* uniform, uint32_t* bits
  * gathers of v ascend and one 128-byte request serves several products; products enter the slice with the LDS atomic of op_add.
  * With it splahip_mxv_masked serves every call without early exit whose op_add has such an atomic (PLUS; MIN / MAX / BOR / BAND / BXOR on
  * int and uint; LOR / LAND): int / uint results stay bit-identical, fp32 PLUS folds in column-block order (1e-5 relative).
- * row_bits: 0 = default (14), else 8..15; tile_chunks: 256-entry chunks per workgroup, 0 = default (256).  The copy holds the VALUES:
+ * row_bits: 0 = default (14), else 8..15; tile_chunks: 0 = every workgroup walks one equal span of the chunk sequence, cut into pieces at range
+ * boundaries only; > 0 = pieces of at most that many 256-entry chunks (tests: many pieces and partial slabs on small inputs).  The copy holds the VALUES:
  * rebuild it when Aj or Ax change.  A hypersparse matrix (more (range, column window) groups than nnz / 512) is left without a copy.
  * Blocks.  cob_info: workgroups, chunks, partial slabs, row_bits (all 0 when no copy was built).                                  */
 int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, uint32_t row_bits,

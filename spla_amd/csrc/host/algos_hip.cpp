@@ -34,6 +34,30 @@ namespace spla {
         void ensure_plan(HipCsr<T>* a, uint n_rows) {
             if (!a->plan) hip_check(splahip_csr_plan_create(&a->plan, n_rows, a->values, a->Ap.template as<uint32_t>(), nullptr), "csr plan");
         }
+        unsigned env_calls(const char* name, unsigned dflt) {
+            const char* e = std::getenv(name);
+            return e ? static_cast<unsigned>(std::strtoul(e, nullptr, 10)) : dflt;
+        }
+        // A matrix that keeps being multiplied gets its layout copies — rent or buy.  The column-ordered-blocks copy (+8 B per entry, ~5 ms per
+        // 65 M entries: what about thirty SpMV calls save) is built when the second call arrives: SPLA_HIP_COB_AFTER=<calls> (0 = never).  The
+        // sliced-ELL copy (+12 B per entry, tens of ms) once 256 calls have been served: SPLA_HIP_SELL_AFTER.  Matrix::set_format(AccCsr) builds both
+        // at once (storage.hpp).  A copy that cannot be built is not an error: the CSR kernels stay in use.
+        template<typename T>
+        void maybe_build_copies(HipCsr<T>* a, uint n_cols) {
+            ++a->mxv_calls;
+            const unsigned cob_after = env_calls("SPLA_HIP_COB_AFTER", 2u), sell_after = env_calls("SPLA_HIP_SELL_AFTER", 256u);
+            if (!a->cob_tried && cob_after != 0 && (a->prepared || a->mxv_calls >= cob_after)) {
+                a->cob_tried = true;
+                if (splahip_csr_plan_attach_cob(a->plan, n_cols, a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(), 0, 0, nullptr) != SPLAHIP_OK)
+                    SPLA_LOG(Status::Error, "column-ordered-blocks copy not built (" << splahip_last_error() << "); the CSR kernels stay in use");
+            }
+            if (!a->sell_tried && sell_after != 0 && (a->prepared || a->mxv_calls >= sell_after)) {
+                a->sell_tried = true;
+                if (splahip_csr_plan_attach_sell(a->plan, n_cols, a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(), nullptr) != SPLAHIP_OK)
+                    SPLA_LOG(Status::Error, "sliced-ELL copy not built (" << splahip_last_error() << "); the CSR kernels stay in use");
+            }
+        }
+
         template<typename T>
         class Algo_mxv_masked_hip final : public RegistryAlgo {
         public:
@@ -68,17 +92,7 @@ namespace spla {
                 auto* a = M->acc_csr();
                 ensure_plan(a, M->get_n_rows());
                 const bool early = t->get_desc_or_default()->get_early_exit();
-                // A matrix that keeps being multiplied gets the sliced-ELL copy (+12 B per entry).  Building it costs as much as a few
-                // hundred SpMV calls save (33 ms vs ~90 us per call at 65 M entries), so — rent-or-buy — it is built once that many calls
-                // have been served: SPLA_HIP_SELL_AFTER=<calls> (default 256, 0 = never).
-                if (!early && a->values > 0) {
-                    const char*    e     = std::getenv("SPLA_HIP_SELL_AFTER");
-                    const unsigned after = e ? static_cast<unsigned>(std::strtoul(e, nullptr, 10)) : 256u;
-                    if (after != 0 && ++a->mxv_calls == after &&
-                        splahip_csr_plan_attach_sell(a->plan, M->get_n_cols(), a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(),
-                                                     nullptr) != SPLAHIP_OK)
-                        SPLA_LOG(Status::Error, "sliced-ELL copy not built (" << splahip_last_error() << "); the CSR kernels stay in use");
-                }
+                if (!early && a->values > 0) maybe_build_copies(a, M->get_n_cols());
                 hip_check(splahip_mxv_masked(a->plan, TypeTraits<T>::id, M->get_n_rows(), M->get_n_cols(),
                                              a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(),
                                              mask->acc_dense()->Ax.ptr(), v->acc_dense()->Ax.ptr(), r->acc_dense()->Ax.ptr(),
@@ -191,6 +205,11 @@ namespace spla {
                 if (pull) {
                     auto*     tr       = ensure_transpose<T>(M.get());
                     const int identity = nvals == M->get_n_rows() ? 1 : 0;
+                    // a dense v (a PageRank step) over a transpose that keeps being used: the layout copies of M^T, same rent-or-buy rule as mxv
+                    if (identity && tr->values > 0) {
+                        tr->prepared = tr->prepared || M->acc_csr()->prepared;
+                        maybe_build_copies(tr, M->get_n_rows());
+                    }
                     hip_check(splahip_vxm_pull(tr->plan, TypeTraits<T>::id, M->get_n_rows(), M->get_n_cols(), tr->Ap.template as<uint32_t>(),
                                                tr->Aj.template as<uint32_t>(), tr->Ax.ptr(), mask->acc_dense()->Ax.ptr(), nvals,
                                                vin->Ai.template as<uint32_t>(), vin->Ax.ptr(), identity, out->Ai.template as<uint32_t>(),

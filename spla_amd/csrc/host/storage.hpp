@@ -141,7 +141,10 @@ namespace spla {
     struct HipCsr final : Decoration<T> {
         DeviceBuffer Ap, Aj, Ax;
         splahip_plan plan      = nullptr;
-        unsigned     mxv_calls = 0;// mxv calls without early exit served by this plan (algos_hip.cpp: when the sliced-ELL copy gets built)
+        unsigned     mxv_calls = 0;    // mxv / pull-vxm calls without early exit served by this plan (algos_hip.cpp: when the copies of the matrix get built)
+        bool         cob_tried = false;// the column-ordered-blocks copy has been asked for (it may have been declined: hypersparse matrix)
+        bool         sell_tried = false;
+        bool         prepared  = false;// Matrix::set_format(AccCsr / AccCsc): build every copy at the next chance instead of renting first
         ~HipCsr() override {
             if (plan) splahip_csr_plan_destroy(plan);
         }
@@ -149,6 +152,7 @@ namespace spla {
             if (plan) splahip_csr_plan_destroy(plan);
             plan      = nullptr;
             mxv_calls = 0;
+            cob_tried = sell_tried = false;
         }
     };
 
@@ -412,7 +416,30 @@ namespace spla {
         uint               get_n_cols() override { return m_s.n_cols; }
         ref_ptr<Type>      get_type() override { return TypeTraits<T>::type(); }
 
-        Status set_format(FormatMatrix format) override { return guarded([&] { validate_rw(format); }); }
+        // reference include/spla/matrix.hpp:51-65: "set_format ... instructs the matrix to keep this format valid".  For the accelerator formats it is
+        // also the caller's way to say "prepare now": the plan and both layout copies of the device CSR are built here, before the first product,
+        // instead of after the matrix has shown that it keeps being multiplied (algos_hip.cpp: rent-or-buy).  AccCsc: flagged, built with the transpose.
+        Status set_format(FormatMatrix format) override {
+            return guarded([&] {
+                validate_rw(format);
+                if (format == FormatMatrix::AccCsr) {
+                    auto* a     = acc_csr();
+                    a->prepared = true;
+                    if (a->values > 0) {
+                        if (!a->plan && splahip_csr_plan_create(&a->plan, m_s.n_rows, a->values, a->Ap.template as<uint32_t>(), nullptr) != SPLAHIP_OK)
+                            throw std::runtime_error(std::string("csr plan: ") + splahip_last_error());
+                        if (!a->cob_tried) {
+                            a->cob_tried = true;
+                            (void) splahip_csr_plan_attach_cob(a->plan, m_s.n_cols, a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(), 0, 0, nullptr);
+                        }
+                        if (!a->sell_tried) {
+                            a->sell_tried = true;
+                            (void) splahip_csr_plan_attach_sell(a->plan, m_s.n_cols, a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(), nullptr);
+                        }
+                    }
+                }
+            });
+        }
         Status set_fill_value(const ref_ptr<Scalar>& value) override {
             if (!value) return Status::InvalidArgument;
             m_s.invalidate();

@@ -20,7 +20,9 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 using namespace splahip;
 
@@ -109,41 +111,6 @@ namespace {
         if (threadIdx.x == 0) hdr[c] = 0;
     }
 
-    // per range: tiles = ceil(chunks / tile_chunks); a range with several tiles needs that many slabs
-    __global__ __launch_bounds__(256) void cob_tile_count_kernel(uint32_t n_ranges, uint32_t win_bits, const uint32_t* __restrict__ chunk_first, uint32_t tile_chunks,
-                                                                 uint32_t* __restrict__ tiles, uint32_t* __restrict__ slabs, uint32_t* __restrict__ multi) {
-        const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-        if (q >= n_ranges) return;
-        const uint32_t cc = chunk_first[(q + 1) << win_bits] - chunk_first[q << win_bits];
-        const uint32_t nt = (cc + tile_chunks - 1) / tile_chunks;
-        tiles[q]          = nt;
-        slabs[q]          = nt > 1 ? nt : 0;
-        multi[q]          = nt > 1 ? 1 : 0;
-    }
-    // a range without an entry still owns rows: they are finished by cob_fill_kernel (below), not by a tile
-    __global__ __launch_bounds__(256) void cob_tile_write_kernel(uint32_t n_ranges, uint32_t win_bits, const uint32_t* __restrict__ chunk_first, uint32_t tile_chunks,
-                                                                 const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ slab_first,
-                                                                 const uint32_t* __restrict__ multi_first, CobTile* __restrict__ tiles, CobMulti* __restrict__ multi,
-                                                                 uint32_t* __restrict__ empty_ranges, uint32_t* __restrict__ n_empty) {
-        const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-        if (q >= n_ranges) return;
-        const uint32_t c0 = chunk_first[q << win_bits], c1 = chunk_first[(q + 1) << win_bits];
-        const uint32_t nt = tile_first[q + 1] - tile_first[q];
-        if (nt == 0) {
-            empty_ranges[atomicAdd(n_empty, 1u)] = q;
-            return;
-        }
-        // equal tiles rather than full ones plus a remainder: the first cc % nt tiles hold one chunk more
-        const uint32_t cc = c1 - c0, per = cc / nt, rem = cc % nt;
-        uint32_t       f  = c0;
-        for (uint32_t t = 0; t < nt; ++t) {
-            const uint32_t len = per + (t < rem ? 1u : 0u);
-            tiles[tile_first[q] + t] = CobTile{f, len, q, nt > 1 ? slab_first[q] + t : kCobNoSlab};
-            f += len;
-        }
-        if (nt > 1) multi[multi_first[q]] = CobMulti{q, slab_first[q], nt, 0};
-    }
-
     // rows of ranges that hold no entry at all: r = init (grid.y = empty range)
     template<typename T>
     __global__ __launch_bounds__(256) void cob_fill_kernel(const uint32_t* __restrict__ empty_ranges, uint32_t n_rows, uint32_t row_bits, T* __restrict__ r, T init) {
@@ -178,87 +145,99 @@ namespace {
         const char* e = std::getenv("SPLAHIP_COB");
         return e && e[0] == '0';
     }
+    uint32_t compute_units() {
+        int             dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) return (uint32_t) prop.multiProcessorCount;
+        return 256;
+    }
     uint32_t env_u32(const char* name, uint32_t dflt) {
         const char* e = std::getenv(name);
         return e && *e ? (uint32_t) std::strtoul(e, nullptr, 10) : dflt;
     }
 
     template<typename T, class Mult, int ACC, bool VXM>
-    int launch_cob(const splahip_cob_s* g, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select, uint32_t init_bits,
-                   hipStream_t st) {
-        CobArgs a;
-        a.tiles    = reinterpret_cast<const CobTile*>(g->d_tiles);
+    int launch_cob(const splahip_cob_s* g, const uint32_t* Ap, const void* mask, const void* v, void* r, uint32_t* touched, int op_mult, int op_add, int op_select,
+                   uint32_t init_bits, hipStream_t st) {
+        constexpr int               W  = sizeof(typename CobSlice<T, ACC>::word) == 8 ? 1 : 0;
+        const splahip_cob_sched_s&  sc = g->sched[W];
+        CobArgs                     a;
+        a.span_first = sc.d_span_first;
+        a.tiles      = reinterpret_cast<const CobTile*>(sc.d_tiles);
         a.hdr      = g->d_hdr;
         a.cr       = g->d_cr;
         a.ax       = g->d_ax;
         a.Ap       = Ap;
         a.slabs    = g->d_slabs;
+        a.touched  = touched;
         a.n_rows   = g->n_rows;
         a.row_bits = g->row_bits;
         a.col_bits = g->col_bits;
         a.pad_chunk = g->n_chunks;
         const T        init = from_bits<T>(init_bits);
         const uint32_t R    = 1u << g->row_bits;
-        if (g->n_tiles) {
+        if (sc.n_tiles) {
             static bool lds_raised = false;// a range of 16 Ki rows plus the spare words is just over the 64 KB a kernel gets without asking
             if (!lds_raised) {
                 SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 160 * 1024));
                 lds_raised = true;
             }
-            hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb>), dim3(g->n_tiles), dim3(kTpb), (R + 4) * sizeof(typename CobSlice<T, ACC>::word), st, a, static_cast<const T*>(v),
+            hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb>), dim3(sc.n_spans), dim3(kTpb), (R + 4) * sizeof(typename CobSlice<T, ACC>::word), st, a, static_cast<const T*>(v),
                                static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
             SPLAHIP_TRY(hipGetLastError());
         }
-        if (g->n_multi) {
+        if (sc.n_multi) {
             const uint32_t bx = (R / 4 + 255) / 256;
-            hipLaunchKernelGGL((cob_combine_kernel<T, DynBin, ACC, 256>), dim3(bx, g->n_multi), dim3(256), 0, st, reinterpret_cast<const CobMulti*>(g->d_multi), g->d_slabs, Ap,
-                               static_cast<const T*>(mask), static_cast<T*>(r), g->n_rows, g->row_bits, DynBin(op_add), op_select, init);
+            hipLaunchKernelGGL((cob_combine_kernel<T, DynBin, ACC, VXM, 256>), dim3(bx, sc.n_multi), dim3(256), 0, st, reinterpret_cast<const CobMulti*>(sc.d_multi), g->d_slabs, Ap,
+                               static_cast<const T*>(mask), static_cast<T*>(r), touched, g->n_rows, g->row_bits, DynBin(op_add), op_select, init);
             SPLAHIP_TRY(hipGetLastError());
         }
-        if (g->n_empty) {
-            hipLaunchKernelGGL((cob_fill_kernel<T>), dim3((R + 255) / 256, g->n_empty), dim3(256), 0, st, g->d_empty, g->n_rows, g->row_bits, static_cast<T*>(r), init);
+        if (g->n_empty) {// ranges without an entry: r = init (mxv) / touched = 0 (vxm)
+            if constexpr (VXM) hipLaunchKernelGGL((cob_fill_kernel<uint32_t>), dim3((R + 255) / 256, g->n_empty), dim3(256), 0, st, g->d_empty, g->n_rows, g->row_bits, touched, 0u);
+            else
+                hipLaunchKernelGGL((cob_fill_kernel<T>), dim3((R + 255) / 256, g->n_empty), dim3(256), 0, st, g->d_empty, g->n_rows, g->row_bits, static_cast<T*>(r), init);
             SPLAHIP_TRY(hipGetLastError());
         }
         return SPLAHIP_OK;
     }
 
     template<typename T, int ACC, bool VXM>
-    int cob_by_mult(const splahip_cob_s* g, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select, uint32_t init_bits,
-                    hipStream_t st) {
+    int cob_by_mult(const splahip_cob_s* g, const uint32_t* Ap, const void* mask, const void* v, void* r, uint32_t* touched, int op_mult, int op_add, int op_select,
+                    uint32_t init_bits, hipStream_t st) {
         // the semirings of the configs get a compile-time op_mult; every other pair runs the runtime-switched functor
         if constexpr (ACC == COB_ADD) {
-            if (op_mult == SPLAHIP_MULT) return launch_cob<T, StaBin<SPLAHIP_MULT>, ACC, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+            if (op_mult == SPLAHIP_MULT) return launch_cob<T, StaBin<SPLAHIP_MULT>, ACC, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
         }
         if constexpr (ACC == COB_MIN) {
-            if (op_mult == SPLAHIP_PLUS) return launch_cob<T, StaBin<SPLAHIP_PLUS>, ACC, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+            if (op_mult == SPLAHIP_PLUS) return launch_cob<T, StaBin<SPLAHIP_PLUS>, ACC, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
         }
         if constexpr (ACC == COB_OR && !std::is_same<T, float>::value) {
-            if (op_mult == SPLAHIP_BAND) return launch_cob<T, StaBin<SPLAHIP_BAND>, ACC, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+            if (op_mult == SPLAHIP_BAND) return launch_cob<T, StaBin<SPLAHIP_BAND>, ACC, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
         }
         if constexpr (ACC == COB_LOR) {
-            if (op_mult == SPLAHIP_LAND) return launch_cob<T, StaBin<SPLAHIP_LAND>, ACC, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+            if (op_mult == SPLAHIP_LAND) return launch_cob<T, StaBin<SPLAHIP_LAND>, ACC, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
         }
-        return launch_cob<T, DynBin, ACC, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+        return launch_cob<T, DynBin, ACC, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
     }
 
     template<typename T, bool VXM>
-    int cob_typed(const splahip_cob_s* g, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select, uint32_t init_bits,
-                  hipStream_t st) {
+    int cob_typed(const splahip_cob_s* g, const uint32_t* Ap, const void* mask, const void* v, void* r, uint32_t* touched, int op_mult, int op_add, int op_select,
+                  uint32_t init_bits, hipStream_t st) {
         constexpr int type = TypeId<T>::value;
         switch (cob_acc_kind(op_add, type)) {
-            case COB_ADD: return cob_by_mult<T, COB_ADD, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
-            case COB_LOR: return cob_by_mult<T, COB_LOR, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
-            case COB_LAND: return cob_by_mult<T, COB_LAND, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+            case COB_ADD: return cob_by_mult<T, COB_ADD, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
+            case COB_LOR: return cob_by_mult<T, COB_LOR, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
+            case COB_LAND: return cob_by_mult<T, COB_LAND, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
             default: break;
         }
         if constexpr (!std::is_same<T, float>::value) {
             switch (cob_acc_kind(op_add, type)) {
-                case COB_MIN: return cob_by_mult<T, COB_MIN, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
-                case COB_MAX: return cob_by_mult<T, COB_MAX, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
-                case COB_OR: return cob_by_mult<T, COB_OR, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
-                case COB_AND: return cob_by_mult<T, COB_AND, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
-                case COB_XOR: return cob_by_mult<T, COB_XOR, VXM>(g, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+                case COB_MIN: return cob_by_mult<T, COB_MIN, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
+                case COB_MAX: return cob_by_mult<T, COB_MAX, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
+                case COB_OR: return cob_by_mult<T, COB_OR, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
+                case COB_AND: return cob_by_mult<T, COB_AND, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
+                case COB_XOR: return cob_by_mult<T, COB_XOR, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
                 default: break;
             }
         }
@@ -271,22 +250,43 @@ namespace splahip {
 
     void cob_release(splahip_cob_s* g) {
         if (!g) return;
-        for (void* p : {(void*) g->d_tiles, (void*) g->d_hdr, (void*) g->d_cr, (void*) g->d_ax, (void*) g->d_slabs, (void*) g->d_multi, (void*) g->d_empty})
+        for (void* p : {(void*) g->d_hdr, (void*) g->d_cr, (void*) g->d_ax, (void*) g->d_slabs, (void*) g->d_empty, (void*) g->sched[0].d_span_first,
+                        (void*) g->sched[0].d_tiles, (void*) g->sched[0].d_multi, (void*) g->sched[1].d_span_first, (void*) g->sched[1].d_tiles, (void*) g->sched[1].d_multi})
             if (p) (void) hipFree(p);
         delete g;
     }
 
     bool cob_serves(const splahip_plan_s* plan, int type, int op_add, uint32_t n_cols) {
-        return plan && plan->cob && plan->cob->n_cols == n_cols && cob_acc_kind(op_add, type) != COB_NONE && !cob_disabled();
+        if (!plan || !plan->cob || plan->cob->n_cols != n_cols || cob_disabled()) return false;
+        const int acc = cob_acc_kind(op_add, type);
+        if (acc == COB_NONE) return false;
+        const bool wide = acc == COB_ADD && type == SPLAHIP_FLOAT;// fp32 sums keep a double slice
+        return plan->cob->sched[wide ? 1 : 0].n_spans != 0;
     }
 
     int cob_mxv(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
                 uint32_t init_bits, void* stream) {
         hipStream_t st = as_stream(stream);
         switch (type) {
-            case SPLAHIP_INT: return cob_typed<int32_t, false>(plan->cob, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
-            case SPLAHIP_UINT: return cob_typed<uint32_t, false>(plan->cob, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
-            case SPLAHIP_FLOAT: return cob_typed<float, false>(plan->cob, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+            case SPLAHIP_INT: return cob_typed<int32_t, false>(plan->cob, Ap, mask, v, r, nullptr, op_mult, op_add, op_select, init_bits, st);
+            case SPLAHIP_UINT: return cob_typed<uint32_t, false>(plan->cob, Ap, mask, v, r, nullptr, op_mult, op_add, op_select, init_bits, st);
+            case SPLAHIP_FLOAT: return cob_typed<float, false>(plan->cob, Ap, mask, v, r, nullptr, op_mult, op_add, op_select, init_bits, st);
+        }
+        return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
+    }
+
+    // the pull form of vxm with every index of v stored, over the copy attached to the TRANSPOSED matrix's plan: out values and touched flags per
+    // output index.  Only an op_add with a true identity (not LOR / LAND: a lone product must come out as itself, not as its truth value)
+    bool cob_vxm_serves(const splahip_plan_s* plan_T, int type, int op_add, uint32_t n_in) {
+        return op_add != SPLAHIP_LOR && op_add != SPLAHIP_LAND && cob_serves(plan_T, type, op_add, n_in);
+    }
+    int cob_vxm(const splahip_plan_s* plan_T, int type, const uint32_t* Tp, const void* mask, const void* v, void* out, uint32_t* touched, int op_mult, int op_add,
+                int op_select, void* stream) {
+        hipStream_t st = as_stream(stream);
+        switch (type) {
+            case SPLAHIP_INT: return cob_typed<int32_t, true>(plan_T->cob, Tp, mask, v, out, touched, op_mult, op_add, op_select, 0u, st);
+            case SPLAHIP_UINT: return cob_typed<uint32_t, true>(plan_T->cob, Tp, mask, v, out, touched, op_mult, op_add, op_select, 0u, st);
+            case SPLAHIP_FLOAT: return cob_typed<float, true>(plan_T->cob, Tp, mask, v, out, touched, op_mult, op_add, op_select, 0u, st);
         }
         return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
     }
@@ -303,7 +303,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     if (plan->nnz == 0 || plan->n_rows == 0 || n_cols == 0) return SPLAHIP_OK;// nothing to lay out: mxv keeps the CSR kernels
     SPLAHIP_REQUIRE(d_Ap && d_Aj && d_Ax, "null device pointer");
     if (row_bits == 0) row_bits = env_u32("SPLAHIP_COB_ROW_BITS", 14);
-    if (tile_chunks == 0) tile_chunks = env_u32("SPLAHIP_COB_TILE_CHUNKS", 256);
+    if (tile_chunks == 0) tile_chunks = env_u32("SPLAHIP_COB_TILE_CHUNKS", 0);// 0: pieces are cut at range and span boundaries only
     SPLAHIP_REQUIRE(row_bits >= 8 && row_bits <= 15, "row_bits must be in [8, 15] (the range's result slice lives in LDS: 4 << row_bits bytes)");
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
@@ -391,39 +391,80 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     e = hipGetLastError();
     if (e != hipSuccess) return bail("scatter");
 
-    // 5: tiles
-    uint32_t *tile_first = nullptr, *slab_first = nullptr, *multi_first = nullptr, *n_empty = nullptr;
-    e = tmp.alloc(&tile_first, (size_t) n_ranges + 1);
-    if (e == hipSuccess) e = tmp.alloc(&slab_first, (size_t) n_ranges + 1);
-    if (e == hipSuccess) e = tmp.alloc(&multi_first, (size_t) n_ranges + 1);
-    if (e == hipSuccess) e = tmp.alloc(&n_empty, 1);
-    if (e != hipSuccess) return bail("scratch");
-    hipLaunchKernelGGL(cob_tile_count_kernel, dim3((n_ranges + 255) / 256), dim3(256), 0, s, n_ranges, win_bits, chunk_first, tile_chunks, tile_first, slab_first, multi_first);
-    hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, tile_first, n_ranges);
-    hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, slab_first, n_ranges);
-    hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, multi_first, n_ranges);
-    e = hipGetLastError();
-    uint32_t h[3] = {0, 0, 0};
-    if (e == hipSuccess) e = hipMemcpyAsync(&h[0], tile_first + n_ranges, 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(&h[1], slab_first + n_ranges, 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(&h[2], multi_first + n_ranges, 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemsetAsync(n_empty, 0, 4, s);
+    // 5: the work schedules, on the host (a few hundred pieces).  A piece = consecutive chunks of ONE range (the LDS slice belongs to a range) =
+    // one workgroup.  A range of at most `share` chunks — what one workgroup slot of the chip would get if the chunks were dealt evenly — is a
+    // single piece and finishes its rows itself; a larger range is cut into equal pieces of at most `share` chunks that store partial slabs
+    // (cob_combine_kernel folds them in piece order).  Workgroups are launched largest piece first, so the small pieces fill the tail.
+    // tile_chunks > 0 caps a piece explicitly (tests: many pieces and slabs on small inputs).
+    std::vector<uint32_t> h_first((size_t) n_groups + 1);
+    e = hipMemcpyAsync(h_first.data(), chunk_first, sizeof(uint32_t) * h_first.size(), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return bail("tiles");
-    g->n_tiles = h[0];
-    g->n_slabs = h[1];
-    g->n_multi = h[2];
-    own(&g->d_tiles, (size_t) g->n_tiles * 4);
-    own(&g->d_multi, (size_t) g->n_multi * 4);
-    own(&g->d_slabs, (size_t) g->n_slabs << row_bits);
-    own(&g->d_empty, n_ranges);
-    if (e != hipSuccess) return bail("hipMalloc");
-    hipLaunchKernelGGL(cob_tile_write_kernel, dim3((n_ranges + 255) / 256), dim3(256), 0, s, n_ranges, win_bits, chunk_first, tile_chunks, tile_first, slab_first, multi_first,
-                       reinterpret_cast<CobTile*>(g->d_tiles), reinterpret_cast<CobMulti*>(g->d_multi), g->d_empty, n_empty);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(&g->n_empty, n_empty, 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return bail("tile write");
+    if (e != hipSuccess) return bail("schedule");
+    std::vector<uint32_t> range_chunk((size_t) n_ranges + 1);
+    for (uint32_t q = 0; q <= n_ranges; ++q) range_chunk[q] = h_first[(size_t) q << win_bits];
+    std::vector<uint32_t> empty;
+    for (uint32_t q = 0; q < n_ranges; ++q)
+        if (range_chunk[q + 1] == range_chunk[q]) empty.push_back(q);
+    g->n_empty = (uint32_t) empty.size();
+    own(&g->d_empty, empty.size());
+    if (e == hipSuccess && !empty.empty()) e = hipMemcpyAsync(g->d_empty, empty.data(), 4 * empty.size(), hipMemcpyHostToDevice, s);
+    const uint32_t cus = compute_units();
+    uint32_t       max_slabs = 0;
+    for (int w = 0; w < 2 && e == hipSuccess; ++w) {
+        splahip_cob_sched_s& sc     = g->sched[w];
+        const size_t         lds    = ((size_t) (1u << row_bits) + 4) * (w ? 8 : 4);
+        const uint32_t       per_cu = (uint32_t) std::min<size_t>(env_u32("SPLAHIP_COB_PER_CU", 2), (160 * 1024) / lds);// 1024-thread workgroups: at most 2 per CU
+        if (per_cu == 0) continue;                                                         // this slice width does not fit: not served
+        const uint32_t slots = cus * per_cu;
+        const uint32_t share = std::max(1u, (n_chunks + slots - 1) / slots * env_u32("SPLAHIP_COB_SHARE_PCT", 100) / 100);
+        const uint32_t cap   = tile_chunks ? tile_chunks : share;
+        std::vector<uint32_t> tiles, multi;
+        std::vector<uint32_t> range_pieces(n_ranges, 0u);
+        for (uint32_t q = 0; q < n_ranges; ++q) {
+            const uint32_t cc = range_chunk[q + 1] - range_chunk[q];
+            if (cc == 0) continue;
+            const uint32_t np = (cc + cap - 1) / cap, per = cc / np, rem = cc % np;
+            uint32_t       f  = range_chunk[q];
+            for (uint32_t t = 0; t < np; ++t) {
+                const uint32_t len = per + (t < rem ? 1u : 0u);
+                tiles.insert(tiles.end(), {f, len, q, kCobNoSlab});
+                f += len;
+            }
+            range_pieces[q] = np;
+        }
+        // slab ids in piece order: the pieces of a range are consecutive
+        uint32_t n_slabs = 0;
+        for (size_t t = 0; t < tiles.size() / 4; ++t) {
+            const uint32_t rq = tiles[4 * t + 2];
+            if (range_pieces[rq] > 1) {
+                if (multi.empty() || multi[multi.size() - 4] != rq) multi.insert(multi.end(), {rq, n_slabs, 0u, 0u});
+                ++multi[multi.size() - 2];
+                tiles[4 * t + 3] = n_slabs++;
+            }
+        }
+        // launch order: largest piece first (stable: equal pieces keep range order)
+        const uint32_t        n_tiles = (uint32_t) (tiles.size() / 4);
+        std::vector<uint32_t> order(n_tiles), sorted(tiles.size()), span_first((size_t) n_tiles + 1);
+        for (uint32_t t = 0; t < n_tiles; ++t) order[t] = t;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return tiles[4 * x + 1] > tiles[4 * y + 1]; });
+        for (uint32_t t = 0; t < n_tiles; ++t)
+            for (int k = 0; k < 4; ++k) sorted[4 * t + k] = tiles[4 * order[t] + k];
+        for (uint32_t t = 0; t <= n_tiles; ++t) span_first[t] = t;
+        sc.n_spans = n_tiles;
+        sc.n_tiles = n_tiles;
+        sc.n_slabs = n_slabs;
+        sc.n_multi = (uint32_t) (multi.size() / 4);
+        max_slabs  = std::max(max_slabs, n_slabs);
+        own(&sc.d_span_first, span_first.size());
+        own(&sc.d_tiles, sorted.size());
+        own(&sc.d_multi, multi.size());
+        if (e == hipSuccess) e = hipMemcpyAsync(sc.d_span_first, span_first.data(), 4 * span_first.size(), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && !sorted.empty()) e = hipMemcpyAsync(sc.d_tiles, sorted.data(), 4 * sorted.size(), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && !multi.empty()) e = hipMemcpyAsync(sc.d_multi, multi.data(), 4 * multi.size(), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);// the vectors go out of scope
+    }
+    own(&g->d_slabs, (size_t) max_slabs << row_bits);
+    if (e != hipSuccess) return bail("schedule upload");
     plan->cob = g;
     return SPLAHIP_OK;
 }
@@ -431,9 +472,9 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
 extern "C" int splahip_csr_plan_cob_info(splahip_plan plan, uint32_t* n_tiles, uint32_t* n_chunks, uint32_t* n_slabs, uint32_t* row_bits) {
     SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
     const splahip_cob_s* g = plan->cob;
-    if (n_tiles) *n_tiles = g ? g->n_tiles : 0;
+    if (n_tiles) *n_tiles = g ? std::max(g->sched[0].n_tiles, g->sched[1].n_tiles) : 0;
     if (n_chunks) *n_chunks = g ? g->n_chunks : 0;
-    if (n_slabs) *n_slabs = g ? g->n_slabs : 0;
+    if (n_slabs) *n_slabs = g ? std::max(g->sched[0].n_slabs, g->sched[1].n_slabs) : 0;
     if (row_bits) *row_bits = g ? g->row_bits : 0;
     return SPLAHIP_OK;
 }

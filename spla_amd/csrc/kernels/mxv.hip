@@ -207,7 +207,9 @@ int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_items, uint32_t* n_long
 }
 
 const char* splahip_mxv_variant_of(splahip_plan plan, int type, int op_mult, int op_add, int early_exit) {
-    if (!early_exit && plan && plan->cob && cob_serves(plan, type, op_add, plan->cob->n_cols)) return "mxv_cob<column-ordered blocks, LDS accumulation>";
+    if (!early_exit && plan && plan->cob && cob_serves(plan, type, op_add, plan->cob->n_cols) &&
+        !(plan->sell && !sell_disabled() && sell_skip_family(type, op_mult, op_add) == 1))
+        return type == SPLAHIP_FLOAT && op_add == SPLAHIP_PLUS ? "mxv_cob<column-ordered blocks, fp64 LDS accumulation>" : "mxv_cob<column-ordered blocks, LDS accumulation>";
     if (plan && plan->sell && !early_exit && fold_is_reorderable(op_add, type) && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add)) && !sell_disabled()) {
         if (sell_skip_family(type, op_mult, op_add) != 0)// the device picks the bit form or the value form from the input vector's statistics
             return static_semiring(type, op_mult, op_add) ? "mxv_sell<static semiring; sparse-vector bit form | value form>" : "mxv_sell<runtime ops; sparse-vector bit form | value form>";
@@ -243,8 +245,15 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
     if (st != SPLAHIP_OK) return st;
     hipStream_t s = as_stream(stream);
     // the column-ordered-blocks copy (splahip_csr_plan_attach_cob): associative + commutative op_add with an LDS atomic, no early exit
-    if (!early_exit && cob_serves(plan, type, op_add, n_cols) && d_r != d_mask && d_r != d_v && (reinterpret_cast<uintptr_t>(d_r) & 15u) == 0)
-        return cob_mxv(plan, type, d_Ap, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, stream);
+    // When the plan also holds a sliced-ELL copy, the semirings of its sparse-vector (bit) form whose skippable value is 0 (BAND / BOR, LAND / LOR,
+    // ... on int / uint: a BFS step, where a few per cent of v are non-zero and half the rows are masked out) stay with it: it reads only the
+    // selected rows' entries and one bit per column; every other call is faster over the column-ordered blocks (SPLAHIP_PREFER=cob|sell overrides).
+    if (!early_exit && cob_serves(plan, type, op_add, n_cols) && d_r != d_mask && d_r != d_v && (reinterpret_cast<uintptr_t>(d_r) & 15u) == 0) {
+        const char* pref     = std::getenv("SPLAHIP_PREFER");
+        const bool  sell_ok  = plan->sell && plan->sell->n_cols == n_cols && !sell_disabled() && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add));
+        const bool  use_sell = sell_ok && (pref ? pref[0] == 's' : sell_skip_family(type, op_mult, op_add) == 1);
+        if (!use_sell) return cob_mxv(plan, type, d_Ap, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, stream);
+    }
     // the sliced-ELL copy (splahip_csr_plan_attach_sell) serves every associative op_add without early exit; its lanes fold in
     // entry order, so op_add need not be commutative.  SPLAHIP_SELL=0 keeps the CSR kernels (A/B runs, tests).
     // (rows with row-exclusive slices are folded lane-strided: then op_add must be commutative too — FIRST / SECOND keep the row kernel)

@@ -178,12 +178,14 @@ namespace splahip {
     }
 
     struct CobArgs {
+        const uint32_t* span_first;// first piece of every workgroup (n_spans + 1)
         const CobTile*  tiles;
         const uint32_t* hdr;// per chunk: first column of its window
         const uint32_t* cr;
         const uint32_t* ax;
         const uint32_t* Ap;// n_rows + 1 (rows without an entry keep init exactly; LOR / LAND only)
         uint32_t*       slabs;
+        uint32_t*       touched;// VXM only: per output index, 1 = selected and at least one product
         uint32_t        n_rows;
         uint32_t        row_bits;
         uint32_t        col_bits;
@@ -201,7 +203,9 @@ namespace splahip {
         word* const        s_acc = reinterpret_cast<word*>(s_raw);
         constexpr unsigned NW    = TPB / kWave;
         const uint32_t     R     = 1u << a.row_bits;
-        const CobTile      t     = a.tiles[blockIdx.x];
+        const uint32_t     t_end = a.span_first[blockIdx.x + 1];
+        for (uint32_t ti = a.span_first[blockIdx.x]; ti < t_end; ++ti) {// the workgroup's pieces, one after the other
+        const CobTile t = a.tiles[ti];
         {
             const uint32_t id = cob_identity<T, ACC>();
             uint4*         s4 = reinterpret_cast<uint4*>(s_raw);
@@ -297,37 +301,49 @@ namespace splahip {
         if (t.slab != kCobNoSlab) {
             uint4* out = reinterpret_cast<uint4*>(a.slabs + (size_t) t.slab * R);
             for (uint32_t i = threadIdx.x; i < R / 4; i += TPB) out[i] = slice4(i * 4);
-            return;
-        }
-        // the tile is the whole range: finish its rows (16 bytes of r per thread)
+        } else
+        // the piece is the whole range: finish its rows (16 bytes of r per thread)
         for (uint32_t i = threadIdx.x * 4; i < R; i += TPB * 4) {
             const uint32_t row = row0 + i;
             if (row >= a.n_rows) break;
             const uint4 acc = slice4(i);
             const uint32_t aw[4] = {acc.x, acc.y, acc.z, acc.w};
             T              out[4];
+            uint32_t       tch[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t rj = row + j;
+                const uint32_t rj  = row + j;
                 bool           sel = rj < a.n_rows;
                 if (sel && op_select != SPLAHIP_ALWAYS) sel = eval_sel<T>(op_select, mask[rj]);
-                if constexpr (ACC == COB_LOR || ACC == COB_LAND) {
-                    if (sel) sel = a.Ap[rj + 1] != a.Ap[rj];// a row without an entry keeps init itself, not its truth value
+                if constexpr (VXM) {// no init: an output exists where the index is selected and holds a product; its value is the fold itself
+                    tch[j] = sel && a.Ap[rj + 1] != a.Ap[rj];
+                    out[j] = from_bits<T>(aw[j]);
+                } else {
+                    if constexpr (ACC == COB_LOR || ACC == COB_LAND) {
+                        if (sel) sel = a.Ap[rj + 1] != a.Ap[rj];// a row without an entry keeps init itself, not its truth value
+                    }
+                    out[j] = sel ? cob_finish<T, ACC>(aw[j], init, add) : init;
                 }
-                out[j] = sel ? cob_finish<T, ACC>(aw[j], init, add) : init;
             }
-            if (row + 3 < a.n_rows) *reinterpret_cast<uint4*>(r + row) = make_uint4(to_bits(out[0]), to_bits(out[1]), to_bits(out[2]), to_bits(out[3]));
-            else
-                for (int j = 0; j < 4 && row + j < a.n_rows; ++j) r[row + j] = out[j];
+            if (row + 3 < a.n_rows) {
+                *reinterpret_cast<uint4*>(r + row) = make_uint4(to_bits(out[0]), to_bits(out[1]), to_bits(out[2]), to_bits(out[3]));
+                if constexpr (VXM) *reinterpret_cast<uint4*>(a.touched + row) = make_uint4(tch[0], tch[1], tch[2], tch[3]);
+            } else
+                for (int j = 0; j < 4 && row + j < a.n_rows; ++j) {
+                    r[row + j] = out[j];
+                    if constexpr (VXM) a.touched[row + j] = tch[j];
+                }
+        }
+        __syncthreads();// the slice is re-initialised for the next piece
         }
     }
 
     // rows of the ranges that were cut into several tiles: merge the range's slabs in tile order, then finish like the main kernel.
     // grid: (R / (TPB * 4) blocks per range) x n_multi
-    template<typename T, class Add, int ACC, unsigned TPB>
+    template<typename T, class Add, int ACC, bool VXM, unsigned TPB>
     __global__ __launch_bounds__(TPB) void cob_combine_kernel(const CobMulti* __restrict__ multi, const uint32_t* __restrict__ slabs, const uint32_t* __restrict__ Ap,
-                                                              const T* __restrict__ mask, T* __restrict__ r, uint32_t n_rows, uint32_t row_bits, Add add, int op_select,
-                                                              T init) {
+                                                              const T* __restrict__ mask, T* __restrict__ r, uint32_t* __restrict__ touched, uint32_t n_rows,
+                                                              uint32_t row_bits, Add add, int op_select, T init) {
         const uint32_t R   = 1u << row_bits;
         const CobMulti m   = multi[blockIdx.y];
         const uint32_t i   = (blockIdx.x * TPB + threadIdx.x) * 4;
@@ -343,19 +359,30 @@ namespace splahip {
         }
         const uint32_t aw[4] = {acc.x, acc.y, acc.z, acc.w};
         T              out[4];
+        uint32_t       tch[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t rj  = row + j;
             bool           sel = rj < n_rows;
             if (sel && op_select != SPLAHIP_ALWAYS) sel = eval_sel<T>(op_select, mask[rj]);
-            if constexpr (ACC == COB_LOR || ACC == COB_LAND) {
-                if (sel) sel = Ap[rj + 1] != Ap[rj];
+            if constexpr (VXM) {
+                tch[j] = sel && Ap[rj + 1] != Ap[rj];
+                out[j] = from_bits<T>(aw[j]);
+            } else {
+                if constexpr (ACC == COB_LOR || ACC == COB_LAND) {
+                    if (sel) sel = Ap[rj + 1] != Ap[rj];
+                }
+                out[j] = sel ? cob_finish<T, ACC>(aw[j], init, add) : init;
             }
-            out[j] = sel ? cob_finish<T, ACC>(aw[j], init, add) : init;
         }
-        if (row + 3 < n_rows) *reinterpret_cast<uint4*>(r + row) = make_uint4(to_bits(out[0]), to_bits(out[1]), to_bits(out[2]), to_bits(out[3]));
-        else
-            for (int j = 0; j < 4 && row + j < n_rows; ++j) r[row + j] = out[j];
+        if (row + 3 < n_rows) {
+            *reinterpret_cast<uint4*>(r + row) = make_uint4(to_bits(out[0]), to_bits(out[1]), to_bits(out[2]), to_bits(out[3]));
+            if constexpr (VXM) *reinterpret_cast<uint4*>(touched + row) = make_uint4(tch[0], tch[1], tch[2], tch[3]);
+        } else
+            for (int j = 0; j < 4 && row + j < n_rows; ++j) {
+                r[row + j] = out[j];
+                if constexpr (VXM) touched[row + j] = tch[j];
+            }
     }
 
 }// namespace splahip

@@ -51,22 +51,29 @@ struct splahip_sell_s {
 };
 
 // column-ordered blocks copy of the matrix (cob.hip / mxv_cob.hpp); owned by the plan
+struct splahip_cob_sched_s {// one work schedule: which workgroup walks which pieces (a piece = consecutive chunks of one range)
+    uint32_t  n_spans   = 0;// workgroups of the main kernel
+    uint32_t  n_tiles   = 0;// pieces
+    uint32_t  n_slabs   = 0;// partial result slices (pieces of ranges that are cut into several pieces)
+    uint32_t  n_multi   = 0;// such ranges
+    uint32_t* d_span_first = nullptr;// n_spans + 1: first piece of every workgroup
+    uint32_t* d_tiles   = nullptr;// n_tiles x CobTile
+    uint32_t* d_multi   = nullptr;// n_multi x CobMulti
+};
 struct splahip_cob_s {
     uint32_t  n_rows   = 0;
     uint32_t  n_cols   = 0;
     uint32_t  row_bits = 0;// a range = 2^row_bits consecutive rows (its result slice lives in LDS)
     uint32_t  col_bits = 0;// 31 - row_bits: a chunk's columns are stored relative to its 2^col_bits-column window
     uint32_t  n_chunks = 0;// 256-slot chunks
-    uint32_t  n_tiles  = 0;// workgroups of the main kernel
-    uint32_t  n_slabs  = 0;// partial result slices of the ranges cut into several tiles
-    uint32_t  n_multi  = 0;// such ranges
     uint32_t  n_empty  = 0;// ranges without an entry
-    uint32_t* d_tiles  = nullptr;// n_tiles x CobTile
+    // [0]: 4-byte slice words (int / uint, LOR / LAND), [1]: 8-byte slice words (fp32 PLUS); they differ in the workgroups a CU can hold.
+    // n_spans == 0: this slice width does not fit the LDS at this row_bits
+    splahip_cob_sched_s sched[2];
     uint32_t* d_hdr    = nullptr;// n_chunks: first column of the chunk's window
     uint32_t* d_cr     = nullptr;// n_chunks x 256: row in range << col_bits | column - window base
     uint32_t* d_ax     = nullptr;// n_chunks x 256 value words
-    uint32_t* d_slabs  = nullptr;// n_slabs << row_bits words, per call
-    uint32_t* d_multi  = nullptr;// n_multi x CobMulti
+    uint32_t* d_slabs  = nullptr;// max(sched[].n_slabs) << row_bits words, per call
     uint32_t* d_empty  = nullptr;// n_empty range ids
 };
 
@@ -94,6 +101,10 @@ namespace splahip {
     // masked SpMV over the column-ordered-blocks copy (associative + commutative op_add with an LDS atomic, no early exit); SPLAHIP status
     int cob_mxv(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
                 uint32_t init_bits, void* stream);
+    // the pull form of vxm with every index of v stored, over the copy attached to the TRANSPOSED matrix's plan (out values + touched flags)
+    bool cob_vxm_serves(const splahip_plan_s* plan_T, int type, int op_add, uint32_t n_in);
+    int  cob_vxm(const splahip_plan_s* plan_T, int type, const uint32_t* Tp, const void* mask, const void* v, void* out, uint32_t* touched, int op_mult, int op_add,
+                 int op_select, void* stream);
     // may the sparse-vector (BITS) form serve this semiring: 0 no, 1 zero family (0 annihilates op_mult and is op_add's identity), 2 min-plus
     // family (an entry whose v value equals init cannot lower the minimum when no matrix value is negative: checked per call)
     int sell_skip_family(int type, int op_mult, int op_add);

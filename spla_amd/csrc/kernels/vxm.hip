@@ -443,7 +443,8 @@ namespace splahip {
         // workspace kept with the plan: [dense v | present bitmap | out values | touched flags | chunk counts]
         const uint   words    = (n_in + 31u) / 32u;
         const uint   n_chunks = (n_out + 1023u) / 1024u;
-        const size_t need     = sizeof(uint) * ((size_t) n_in + words + 2 * (size_t) n_out + n_chunks + 8);
+        const uint   n_in4    = (n_in + 3u) & ~3u, words4 = (words + 3u) & ~3u, n_out4 = (n_out + 3u) & ~3u;// every sub-array starts 16-byte aligned
+        const size_t need     = sizeof(uint) * ((size_t) n_in4 + words4 + 2 * (size_t) n_out4 + n_chunks + 8);
         if (plan->ws_bytes < need) {
             if (plan->d_ws) (void) hipFree(plan->d_ws);
             plan->d_ws = nullptr, plan->ws_bytes = 0;
@@ -451,10 +452,10 @@ namespace splahip {
             plan->ws_bytes = need;
         }
         uint* ws_dense   = static_cast<uint*>(plan->d_ws);
-        uint* ws_present = ws_dense + n_in;
-        uint* ws_outv    = ws_present + words;
-        uint* ws_touched = ws_outv + n_out;
-        uint* ws_chunk   = ws_touched + n_out;
+        uint* ws_present = ws_dense + n_in4;
+        uint* ws_outv    = ws_present + words4;
+        uint* ws_touched = ws_outv + n_out4;
+        uint* ws_chunk   = ws_touched + n_out4;
 
         const uint* d_present = nullptr;
         const T*    d_v       = static_cast<const T*>(vx);
@@ -471,7 +472,11 @@ namespace splahip {
         const uint grid   = (plan->n_items + Cfg::kWaves - 1) / Cfg::kWaves;
         // every index of v stored + a sliced-ELL copy on the transposed matrix's plan: the value-form kernel in its vxm mode
         const char* sell_env = std::getenv("SPLAHIP_SELL");
-        if (plan->sell && v_is_identity && plan->sell->n_cols == n_in && !(sell_env && sell_env[0] == '0') &&
+        // every index of v stored + a column-ordered-blocks copy on the transposed matrix's plan: its kernel in vxm mode
+        if (v_is_identity && cob_vxm_serves(plan, TypeId<T>::value, op_add, n_in) && ((reinterpret_cast<uintptr_t>(ws_outv) | reinterpret_cast<uintptr_t>(ws_touched)) & 15u) == 0) {
+            int st = cob_vxm(plan, TypeId<T>::value, Tp, mask, d_v, ws_outv, ws_touched, op_mult, op_add, op_select, s);
+            if (st != SPLAHIP_OK) return st;
+        } else if (plan->sell && v_is_identity && plan->sell->n_cols == n_in && !(sell_env && sell_env[0] == '0') &&
             ((reinterpret_cast<uintptr_t>(Tp) | reinterpret_cast<uintptr_t>(mask)) & 15u) == 0) {
             int st = sell_vxm(plan, TypeId<T>::value, Tp, mask, d_v, ws_outv, ws_touched, op_mult, op_add, op_select, s);
             if (st != SPLAHIP_OK) return st;

@@ -104,3 +104,29 @@ def test_type_mismatch_is_an_error():
     with pytest.raises(api.SplaError) as e:
         M.mxv(mask, v, api.INT.MULT, api.INT.PLUS, api.INT.NQZERO)
     assert e.value.status == 1  # Status::Error via the dispatcher's exception handler
+
+
+def test_mxv_layout_copies_through_the_api(oracle, monkeypatch):
+    """Matrix::set_format(AccCsr) is "prepare now" (reference include/spla/matrix.hpp:51-65): plan + both layout copies are built before the first
+    product; without it the column-ordered-blocks copy arrives with the second call (rent or buy).  Results identical either way."""
+    api = _api()
+    rng = np.random.default_rng(77)
+    n_rows, n_cols = 5000, 4000
+    for t, mul, add, init in (("INT", "PLUS", "MIN", 1 << 20), ("FLOAT", "MULT", "PLUS", 0.0), ("UINT", "BAND", "BOR", 0)):
+        T = getattr(api, t)
+        Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 12, t, skew=True, long_rows=1, long_len=3000)
+        mask_np = random_mask(rng, n_rows, t)
+        v_np = random_values(rng, n_cols, t, zeros=0.2)
+        want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask_np, v_np, mul, add, "EQZERO", init)
+        for prepare in (False, True):
+            M = api.Matrix.from_csr(Ap, Aj, Ax, (n_rows, n_cols), T)
+            if prepare:
+                M.set_format(6)  # FormatMatrix::AccCsr (include/spla.hpp; reference include/spla/config.hpp:102-122)
+            mask = api.Vector.from_lists(np.arange(n_rows), mask_np, n_rows, T)
+            v = api.Vector.from_lists(np.arange(n_cols), v_np, n_cols, T)
+            for call in range(3):  # call 1: CSR kernels (or the prepared copies); call 2 builds the copy; call 3 runs on it
+                r = M.mxv(mask, v, getattr(T, mul), getattr(T, add), T.EQZERO, init=api.Scalar(T, init))
+                ri, rx = r.read()
+                got = np.full(n_rows, 0, dtype=want.dtype)
+                got[ri] = rx
+                assert_same(got, want, t, what=f"{t} {mul}/{add} prepare={prepare} call {call + 1}")  # (entries equal to the fill value 0 are not stored)

@@ -177,7 +177,7 @@ def test_cfg2_full_size_scale22_properties_and_row_sample(oracle):
 def test_cfg3_pagerank_step_vxm_fp32_symmetrised_rmat(oracle):
     """configs[2] on the stated stand-in (com-Orkut is not on the box): symmetrised R-MAT scale 13 ef 28, values 0.85 / outdeg(row)
     (reference examples/pr.cpp:81-88), v = 1/n with every index stored, MULT_FLOAT / PLUS_FLOAT, ALWAYS: the pull form over the CSR of
-    M^T and over its sliced-ELL copy, and the push form (it keeps the reference's fold order for runs of <= 64 products; longer runs are
+    M^T, over its sliced-ELL copy and over its column-ordered-blocks copy, and the push form (it keeps the reference's fold order for runs of <= 64 products; longer runs are
     folded by an in-order tree, hence the same 1e-5 bar)."""
     from gpu_utils import dev, host
     from spla_amd import kernels
@@ -191,8 +191,10 @@ def test_cfg3_pagerank_step_vxm_fp32_symmetrised_rmat(oracle):
     wi, wx = oracle.vxm_masked("FLOAT", n, n, Ap, Aj, Ax, mask, vi, vx, "MULT", "PLUS", "ALWAYS")
     dAp, dAj, dAx, dm, dvi, dvx = dev(Ap), dev(Aj), dev(Ax), dev(mask), dev(vi), dev(vx)
     Tp, Tj, Tx = kernels.csr_transpose(n, n, dAp, dAj, dAx)
-    for sell in (False, True):
-        plan_T = kernels.CsrPlan(n, nnz, Tp, n, Tj, Tx) if sell else kernels.CsrPlan(n, nnz, Tp)
+    for sell in (False, True, "cob"):
+        plan_T = kernels.CsrPlan(n, nnz, Tp, n, Tj, Tx) if sell is True else kernels.CsrPlan(n, nnz, Tp)
+        if sell == "cob":
+            assert plan_T.attach_cob(n, Tp, Tj, Tx) is not None
         ri, rx = kernels.vxm_pull(plan_T, "FLOAT", n, n, Tp, Tj, Tx, dm, dvi, dvx, "MULT", "PLUS", "ALWAYS", identity=True)
         np.testing.assert_array_equal(host(ri, np.uint32), wi, err_msg=f"pull sell={sell}: structure")
         np.testing.assert_allclose(host(rx, np.float32), wx, rtol=FP32_RTOL, atol=0, err_msg=f"pull sell={sell}")

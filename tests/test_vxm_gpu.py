@@ -28,7 +28,11 @@ def _pull(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel, identity=F
     from spla_amd import kernels
     dAp, dAj, dAx = dev(Ap), dev(Aj), dev(np.asarray(Ax, NP[t]))
     Tp, Tj, Tx = kernels.csr_transpose(n_rows, n_cols, dAp, dAj, dAx)
-    plan = kernels.CsrPlan(n_cols, len(Aj), Tp, n_rows, Tj, Tx) if sell else kernels.CsrPlan(n_cols, len(Aj), Tp)
+    plan = kernels.CsrPlan(n_cols, len(Aj), Tp, n_rows, Tj, Tx) if sell is True else kernels.CsrPlan(n_cols, len(Aj), Tp)
+    if sell == "cob":        # column-ordered blocks copy of the transposed matrix (its vxm mode serves the identity case)
+        plan.attach_cob(n_rows, Tp, Tj, Tx)
+    elif sell == "cob-small":  # many ranges / pieces / slabs on a small input
+        plan.attach_cob(n_rows, Tp, Tj, Tx, row_bits=8, tile_chunks=2)
     ri, rx = kernels.vxm_pull(plan, t, n_rows, n_cols, Tp, Tj, Tx, dev(np.asarray(mask, NP[t])), dev(np.asarray(vi, np.uint32)),
                               dev(np.asarray(vx, NP[t])), mul, add, sel, identity=identity)
     return host(ri, np.uint32), host(rx, NP[t])
@@ -88,7 +92,7 @@ def test_pull_commutative_cells(oracle, t):
         vi = np.sort(rng.permutation(n_rows)[:nv]).astype(np.uint32)
         vx = random_values(rng, nv, t, zeros=0.2)
         want = oracle.vxm_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel)
-        for form in ((False, True) if nv == n_rows else (False,)):  # the sliced-ELL vxm mode serves the identity case
+        for form in ((False, True, "cob", "cob-small") if nv == n_rows else (False,)):  # the sliced-ELL / column-ordered-blocks vxm modes serve the identity case
             got = _pull(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel, identity=(nv == n_rows), sell=form)
             np.testing.assert_array_equal(got[0], want[0], err_msg=f"{t} {mul}/{add} {sel} idx sell={form}")
             if t == "FLOAT" and add in ("PLUS", "MULT"):
