@@ -65,6 +65,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-variants", action="store_true")
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--no-scale23", action="store_true", help="skip the R-MAT scale-23 fp32 plus-times variant (the ~100 M-nnz north-star configuration)")
     p.add_argument("--workload", default="bfs-step", choices=["bfs-step", "pagerank-vxm", "sssp-step", "tc-mxmT", "mxm", "algorithms", "transpose"],
                    help="bfs-step (default, the contract line) or one of the other hot-path operators (bench_workloads.py; N = 1 only)")
     return p.parse_args()
@@ -199,9 +200,17 @@ def main():
     _lib.load()
     _lib.call("splahip_init", device_index)
 
+    if args.workload == "sssp-step" and world > 1:  # BASELINE configs[3] as specified: strong 1-D row split of R-MAT scale 24 over the C-ABI dist layer
+        import bench_dist
+        line = bench_dist.sssp_step_sharded(args, rank, world)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if args.workload != "bfs-step":
         if world != 1:
-            raise SystemExit("the operator workloads run on one GPU")
+            raise SystemExit("this operator workload runs on one GPU (sssp-step and the default bfs-step take --gpus N)")
         import bench_workloads
         print(json.dumps(bench_workloads.WORKLOADS[args.workload](args)), flush=True)
         return
@@ -260,7 +269,20 @@ def main():
         else:
             sh.gather(front, v_full)
 
+    # SPLA_EXCHANGE=abi: the whole step through the C-ABI dist layer (spla_amd/csrc/kernels/dist.hip): RCCL all-gather of the dense slice on the
+    # communicator's stream, overlapped with the local-column part of the SpMV over the column-ordered blocks; the remote-column part folds onto it
+    abi = None
+    if world > 1 and mode == "abi":
+        import bench_dist
+        blk_x = sh.blk
+        blk_x.Ax = ones_i
+        abi = bench_dist.ShardedProduct(blk_x, ones_i, "INT", "BAND", "BOR", "EQZERO", 0, 0, world, rank, direct=os.environ.get("SPLA_ALLGATHER", "nccl") == "direct")
+        v_full = abi.v_full
+
     def step(early=False):
+        if abi is not None and not early:
+            abi.step(mask, front, r)
+            return
         if world > 1:
             exchange()
         kernels.mxv_masked(sh.plan, "INT", sh.n_cols_padded, g["Ap"], g["Aj"], ones_i, mask, v_full, r,
@@ -355,13 +377,18 @@ def main():
         slice_bytes = 4 * sh.max_rows if not sparse else 4 * int(sx.prev.numel() // world)
         xm = torch.tensor([x_ms], device=coll_device(), dtype=torch.float64)
         dist.all_reduce(xm, op=dist.ReduceOp.MAX)
-        out["exchange"] = {"mode": "sparse (positions of the non-fill entries)" if sparse else "dense (padded slices)",
+        if abi is not None:
+            out["exchange_abi"] = bench_dist.phase_report(abi, mask, front, r, max(5, args.steps // 2), world)
+        out["exchange"] = {"mode": "C ABI: splahip_dist_mxv_masked (RCCL all-gather on its own stream || local-column part)" if abi is not None else
+                           "sparse (positions of the non-fill entries)" if sparse else "dense (padded slices)",
                            "collective": "all_gather_into_tensor (%s)" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " debug backend"), "avg_us": round(x_ms * 1e3, 2), "max_over_ranks_us": round(float(xm[0]) * 1e3, 2),
                            "bytes_per_peer": slice_bytes, "bytes_received_per_rank": slice_bytes * (world - 1),
                            "gbs_per_link_if_direct": round(slice_bytes / (x_ms * 1e-3) / 1e9, 2),
-                           "local_spmv_us": round(k_ms * 1e3, 2), "overlap_fraction": 0.0,
+                           "local_spmv_us": round(k_ms * 1e3, 2), "overlap_fraction": out["exchange_abi"]["overlap_fraction"] if abi is not None else 0.0,
                            "entries_exchanged": int(front_total) if sparse else int(g["n"]),
-                           "note": "exchange and local SpMV run back to back on one stream in round 1 (no overlap)"}
+                           "note": ("exchange on the communicator's stream beside the local-column part (exchange_abi: the phases on their own)" if abi is not None else
+                                    "torch.distributed exchange, then the SpMV, back to back on one stream (SPLA_EXCHANGE=abi: the overlapped C-ABI step; "
+                                    "--workload sssp-step --gpus N uses it by default)")}
 
     # ---- verification of the timed result against the oracle (full local rows), and the CPU baseline ------------
     if rank == 0 and not args.no_verify:
@@ -455,6 +482,20 @@ def cpu_baseline(args, g, sh, mask, v_full, r):
             "host_cpus": os.cpu_count(), "ms": round(med * 1e3, 2), "matches_hip": same}
 
 
+def required_entries_early_exit(g, mask, v_full):
+    """entries an early-exit BFS step has to read: per selected row, up to and including its first entry whose column is in the frontier"""
+    Ap64 = g["Ap"].to(torch.int64)
+    deg = Ap64[1:] - Ap64[:-1]
+    n_local = deg.numel()
+    rows = torch.repeat_interleave(torch.arange(n_local, device="cuda"), deg)
+    hit = v_full[g["Aj"].to(torch.int64)] != 0
+    pos = torch.arange(rows.numel(), device="cuda") - Ap64[:-1][rows]
+    first = torch.full((n_local,), 1 << 40, dtype=torch.int64, device="cuda")
+    first.scatter_reduce_(0, rows[hit], pos[hit], reduce="amin", include_self=True)
+    need = torch.minimum(first + 1, deg)  # no hit: the whole row is read
+    return int(need[mask == 0].sum())
+
+
 def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total, nnz_sel_local):
     """Other measured forms of the same kernel family on the same matrix (kernel-only, inputs resident)."""
     from spla_amd import kernels
@@ -478,6 +519,17 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
     r_i = torch.empty(n_local, dtype=torch.int32, device="cuda")
     ones_i = torch.ones(nnz_local, dtype=torch.int32, device="cuda")
     run("bfs-step early_exit=true (as reference bfs())", "INT", ones_i, mask, v_full, r_i, "BAND", "BOR", "EQZERO", 0, True, nnz_sel_local)
+    # an early-exit variant reports against the bytes of the entries actually REQUIRED — up to and including the first entry of every
+    # selected row whose product makes the sum differ from init (cpu_mxv.hpp:96-98: here the first entry whose column is in the frontier) — and
+    # against the full nnz_sel.  The kernel's time divided into the full figure says nothing about bandwidth: it is listed, not claimed.
+    req = required_entries_early_exit(g, mask, v_full)
+    b_req = 8 * req + 4 * (n_local + 1) + 8 * n_local + 4 * sh.n_cols_padded
+    ms_e = res[-1]["kernel_avg_us"] * 1e-3
+    res[-1]["entries_required"] = req
+    res[-1]["hbm_gbs_required_bytes"] = round(b_req / (ms_e * 1e-3) / 1e9, 1)
+    res[-1]["roofline_frac_required_bytes"] = round(b_req / (ms_e * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    res[-1]["roofline_frac_full_nnz_sel"] = res[-1].pop("roofline_frac")
+    res[-1]["note"] = "one lane per row walks its row until the first hit: the required-bytes fraction is the bandwidth figure; the full-nnz_sel fraction is listed as SURVEY 8d asks and is not a bandwidth claim"
     zeros_i = torch.zeros(n_local, dtype=torch.int32, device="cuda")
     run("all rows selected, BAND/BOR int32", "INT", ones_i, zeros_i, v_full, r_i, "BAND", "BOR", "EQZERO", 0, False, nnz_local)
     gen = torch.Generator(device="cuda")
@@ -511,6 +563,24 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
     torch.cuda.synchronize()
     res[-1]["identical_to_csr_kernel"] = bool(torch.equal(r_w, r_i))
     sell_w.close()
+    # the column-ordered-blocks copy (splahip_csr_plan_attach_cob): the north-star form, fp32 plus-times over all rows
+    t0 = time.perf_counter()
+    cob_f = kernels.CsrPlan(n_local, nnz_local, g["Ap"])
+    cob_info = cob_f.attach_cob(sh.n_cols_padded, g["Ap"], g["Aj"], Ax_f)
+    torch.cuda.synchronize()
+    cob_ms = (time.perf_counter() - t0) * 1e3
+    r_c = torch.empty_like(r_f)
+    run("all rows selected, MULT/PLUS fp32, column-ordered blocks copy (north-star form)", "FLOAT", Ax_f, zeros_f, v_f, r_c, "MULT", "PLUS", "ALWAYS", 0.0, False, nnz_local, plan=cob_f)
+    res[-1]["max_rel_vs_csr_kernel"] = ((r_c - r_ref).abs() / r_ref.abs().clamp_min(1e-30)).max().item() if n_local else 0.0
+    res[-1]["plan"] = cob_info
+    res[-1]["plan_build_ms"] = round(cob_ms, 1)
+    cob_f.close()
+    cob_w = kernels.CsrPlan(n_local, nnz_local, g["Ap"])
+    cob_w.attach_cob(sh.n_cols_padded, g["Ap"], g["Aj"], w_i)
+    r_cw = torch.empty_like(r_i)
+    run("all rows selected, PLUS/MIN int32 (SSSP step), column-ordered blocks copy", "INT", w_i, zeros_i, d_i, r_cw, "PLUS", "MIN", "ALWAYS", 1 << 30, False, nnz_local, plan=cob_w)
+    res[-1]["identical_to_csr_kernel"] = bool(torch.equal(r_cw, r_i))
+    cob_w.close()
     sell_i = kernels.CsrPlan(n_local, nnz_local, g["Ap"], sh.n_cols_padded, g["Aj"], ones_i)
     r_chk = torch.empty_like(r_i)
     uni = bool(sell_i.sell and sell_i.sell.get("uniform_values"))
@@ -531,7 +601,83 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
     res[-3]["identical_to_csr_kernel"] = bool(torch.equal(r_chk3, r_i))
     res[-2]["identical_to_csr_kernel"] = bool(torch.equal(r_chk2, r_i))
     sell_i.close()
+    res.append(api_path_bfs_step(args, g, sh, mask, v_full, timed, nnz_sel_local, res))
+    if args.scale == 22 and not args.no_scale23:
+        res.append(fp32_scale23(args, timed))
     return res
+
+
+def api_path_bfs_step(args, g, sh, mask, v_full, timed, nnz_sel_local, res):
+    """The bench step through the operator API: spla_Exec_mxv_masked on Matrix / Vector objects (include/spla.h), the matrix prepared with
+    Matrix::set_format(AccCsr) = plan + layout copies built before the first product.  What an API user gets, next to the kernel-level number."""
+    from spla_amd import api
+    api.set_accelerator(api.ACCELERATOR_HIP)
+    n, n_cols = sh.n_local, sh.n_cols_padded
+    t0 = time.perf_counter()
+    M = api.Matrix.from_csr(g["Ap"].cpu().numpy().view(np.uint32), g["Aj"].cpu().numpy().view(np.uint32), np.ones(g["nnz_local"], np.int32), (n, n_cols), api.INT)
+    M.set_format(6)  # FormatMatrix::AccCsr: upload + plan + both layout copies
+    hm = api.Vector.from_lists(np.arange(n, dtype=np.uint32), mask.cpu().numpy(), n, api.INT)
+    hv = api.Vector.from_lists(np.arange(n_cols, dtype=np.uint32), v_full.cpu().numpy(), n_cols, api.INT)
+    hr = api.Vector(n, api.INT)
+    init = api.Scalar(api.INT, 0)
+    opm, opa, ops = api.INT.BAND, api.INT.BOR, api.INT.EQZERO
+    prep_s = time.perf_counter() - t0
+    fn = lambda: M.mxv(hm, hv, opm, opa, ops, out=hr, init=init)
+    fn()
+    steps = max(10, args.steps // 2)
+    _, per = timed(fn, steps, 3)
+    ms = float(np.mean(per))
+    ri, rx = hr.read()
+    got = np.zeros(n, np.int32)
+    got[ri] = rx
+    torch.cuda.synchronize()
+    ref = [x for x in res if x["name"].startswith("bfs-step early_exit=false, sliced-ELL copy")][0]
+    same = None
+    try:
+        r_k = torch.empty(n, dtype=torch.int32, device="cuda")
+        from spla_amd import kernels
+        kernels.mxv_masked(sh.plan, "INT", n_cols, g["Ap"], g["Aj"], torch.ones(g["nnz_local"], dtype=torch.int32, device="cuda"), mask, v_full, r_k, "BAND", "BOR", "EQZERO", 0)
+        same = bool(np.array_equal(got, r_k.cpu().numpy()))
+    except Exception as exc:  # pragma: no cover
+        log(f"[bench] api-path comparison failed: {exc}")
+    return {"name": "bfs-step early_exit=false through spla_Exec_mxv_masked (operator API, matrix prepared with set_format(AccCsr))", "kernel": "operator API -> dispatcher -> splahip_mxv_masked",
+            "kernel_avg_us": round(ms * 1e3, 2), "gteps_local": round(nnz_sel_local / (ms * 1e-3) / 1e9, 2), "kernel_level_us": ref["kernel_avg_us"],
+            "ratio_to_kernel_level": round(ms * 1e3 / ref["kernel_avg_us"], 3), "identical_to_kernel_level": same,
+            "host_prepare_s": round(prep_s, 2), "note": "time per call as HIP events around the API call (asynchronous, like the kernel-level call); host_prepare_s = COO build + COO->CSR + upload + plan + copies"}
+
+
+def fp32_scale23(args, timed):
+    """The north-star configuration: fp32 plus-times masked SpMV (all rows) on a ~100 M-nnz scale-free CSR = R-MAT scale 23 (131 M nnz)."""
+    from spla_amd import graphgen, kernels
+    n, Ap, Aj = graphgen.rmat_csr(23, args.edge_factor, seed=args.seed, device="cuda")
+    nnz = int(Ap[-1])
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(args.seed + 300)
+    Ax = torch.rand(nnz, generator=gen, device="cuda", dtype=torch.float32)
+    v = torch.rand(n, generator=gen, device="cuda", dtype=torch.float32)
+    zeros = torch.zeros(n, dtype=torch.float32, device="cuda")
+    out = {}
+    b = 8 * nnz + 4 * (n + 1) + 8 * n + 4 * n
+    for name, attach in (("csr wave-tile", None), ("sliced-ELL copy", "sell"), ("column-ordered blocks copy", "cob")):
+        plan = kernels.CsrPlan(n, nnz, Ap, n, Aj, Ax) if attach == "sell" else kernels.CsrPlan(n, nnz, Ap)
+        if attach == "cob":
+            plan.attach_cob(n, Ap, Aj, Ax)
+        r = torch.empty(n, dtype=torch.float32, device="cuda")
+        _, per = timed(lambda: kernels.mxv_masked(plan, "FLOAT", n, Ap, Aj, Ax, zeros, v, r, "MULT", "PLUS", "ALWAYS", 0.0), max(10, args.steps // 2), 3)
+        ms = float(np.mean(per))
+        out[name] = {"kernel": kernels.mxv_variant("FLOAT", "MULT", "PLUS", False, plan), "kernel_avg_us": round(ms * 1e3, 2), "gteps": round(nnz / (ms * 1e-3) / 1e9, 2),
+                     "hbm_gbs": round(b / (ms * 1e-3) / 1e9, 1), "roofline_frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if attach == "cob":
+            exact = torch.zeros(n, dtype=torch.float64, device="cuda")
+            rows = torch.repeat_interleave(torch.arange(n, device="cuda"), (Ap[1:] - Ap[:-1]).to(torch.int64))
+            exact.index_add_(0, rows, Ax.to(torch.float64) * v[Aj.to(torch.int64)].to(torch.float64))
+            out[name]["max_rel_vs_fp64"] = ((r.to(torch.float64) - exact).abs() / exact.abs().clamp_min(1e-30)).max().item()
+            del rows, exact
+        plan.close()
+    best = out["column-ordered blocks copy"]
+    return {"name": "NORTH STAR: all rows, MULT/PLUS fp32, R-MAT scale 23 (%d nnz, the ~100 M-nnz scale-free configuration)" % nnz, "kernel": best["kernel"],
+            "kernel_avg_us": best["kernel_avg_us"], "gteps_local": best["gteps"], "hbm_gbs": best["hbm_gbs"], "roofline_frac": best["roofline_frac"],
+            "nnz_selected_local": nnz, "bytes_per_entry": 8, "algorithmic_bytes": b, "forms": out}
 
 
 if __name__ == "__main__":

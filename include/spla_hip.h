@@ -24,6 +24,12 @@
  *     the only calls that block are the ones documented as returning a host-side count.
  *   - every function returns 0 on success or a non-zero splahip_status; splahip_last_error() describes it.
  *   - there is NO CPU fallback behind this ABI: without a usable gfx950 device every call fails loudly.
+ *   - concurrency: a plan carries per-call workspaces of its layout copies (bitmaps, partial slabs, statistics): ONE call at a time per plan —
+ *     calls on the same plan from several streams or threads must be serialised by the caller (different plans are independent).
+ *     splahip_malloc / splahip_free are ordered on the DEFAULT stream: a buffer that kernels on another (non-blocking) stream still use must
+ *     not be freed before that stream has been synchronised.
+ *   - memory: idle device memory the library caches (returned mxm results, mxm workspaces, the stream-ordered pool) is handed back to the driver
+ *     when one of its allocations reports out-of-memory, and that allocation is retried once.
  */
 #ifndef SPLA_HIP_H
 #define SPLA_HIP_H
@@ -104,6 +110,42 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
                        const void* d_mask, const void* d_v, void* d_r,
                        int op_mult, int op_add, int op_select, uint32_t init_bits, int early_exit,
                        void* stream);
+
+/* ---- 1-D row-block decomposition across the GPUs of one node (spla_amd/csrc/kernels/dist.hip) -------------------------------
+ * One process per GPU.  Rank p owns a contiguous block of rows (its CSR slice with the column ids remapped to the PADDED layout
+ * owner * max_rows + offset, the matching slices of mask and r) and slice p of the input vector; one exchange per product: the all-gather of v.
+ *   splahip_comm : an RCCL communicator (RCCL is loaded at run time; splahip_dist_available() == 0 when it cannot be).  Rank 0 makes the 128-byte
+ *                  id with splahip_dist_get_unique_id and hands it to the other ranks by any means (the host's launcher, torch.distributed, MPI).
+ *   all_gather   : every rank contributes `words` 4-byte words, d_recv receives world x words in rank order; direct != 0 replaces ncclAllGather
+ *                  by a grouped send / receive pair per peer (every slice over its own xGMI link instead of a ring).
+ *   splahip_shard: the row block cut by column owner into a local part (needs only the rank's own slice of v) and a remote part (needs the
+ *                  gathered vector), each with its plan and column-ordered-blocks copy; the caller's CSR arrays must outlive the shard.
+ *   splahip_dist_mxv_masked: exchange on the communicator's stream || local part on `stream`, then the remote part folds onto r:
+ *                  r[i] = select(mask[i]) ? add(add(init, local fold), remote fold) : init  (reference cpu_mxv.hpp:88-103 for an associative and
+ *                  commutative op_add: bit-identical for int / uint, rounding-only for fp32 PLUS).  Calls the two-part form cannot serve (no LDS
+ *                  atomic for op_add, early exit) run the unsplit block after the exchange (*overlapped = 0).  d_v_local: max_rows words (the
+ *                  slice, padded); d_v_full: world x max_rows words of workspace.  The phases are also exported one by one (mxv_local / mxv_remote /
+ *                  mxv_whole) for hosts that bring their own exchange.                                                                        */
+typedef struct splahip_comm_s*  splahip_comm;
+typedef struct splahip_shard_s* splahip_shard;
+int splahip_dist_available(void);
+int splahip_dist_get_unique_id(void* id128);
+int splahip_dist_comm_create(splahip_comm* comm, int world, int rank, const void* id128);
+int splahip_dist_comm_destroy(splahip_comm comm);
+int splahip_dist_comm_info(splahip_comm comm, int* world, int* rank);
+int splahip_dist_all_gather(splahip_comm comm, const void* d_send, void* d_recv, size_t words, int direct, void* stream);
+int splahip_shard_create(splahip_shard* shard, int world, int rank, uint32_t n_local, uint32_t max_rows, uint32_t nnz, const uint32_t* d_Ap,
+                         const uint32_t* d_Aj_padded, const void* d_Ax, void* stream);
+int splahip_shard_destroy(splahip_shard shard);
+int splahip_shard_info(splahip_shard shard, uint32_t* nnz_local_cols, uint32_t* nnz_remote_cols, int* split_ok);
+int splahip_shard_split_serves(splahip_shard shard, int type, int op_add, int early_exit); /* 1: the two-part (overlapped) form serves this call */
+int splahip_shard_mxv_local(splahip_shard shard, int type, const void* d_mask, const void* d_v_local, void* d_r, int op_mult, int op_add, int op_select,
+                            uint32_t init_bits, void* stream);
+int splahip_shard_mxv_remote(splahip_shard shard, int type, const void* d_mask, const void* d_v_full, void* d_r, int op_mult, int op_add, int op_select, void* stream);
+int splahip_shard_mxv_whole(splahip_shard shard, int type, const void* d_mask, const void* d_v_full, void* d_r, int op_mult, int op_add, int op_select,
+                            uint32_t init_bits, int early_exit, void* stream);
+int splahip_dist_mxv_masked(splahip_comm comm, splahip_shard shard, int type, const void* d_mask, const void* d_v_local, void* d_v_full, void* d_r, int op_mult,
+                            int op_add, int op_select, uint32_t init_bits, int early_exit, int direct, int* overlapped, void* stream);
 
 /* ---- masked vxm: r = v^T * M on the columns j with select(mask[j]) (reference cpu_vxm.hpp:92-125) ----------------
  * v is sparse: nvals (index, value) pairs IN STORED ORDER; r is index-sorted COO written to d_ri / d_rx (room for

@@ -44,6 +44,20 @@ _SIGNATURES = {
     "splahip_csr_plan_sell_values": (C.c_int, [_vp, C.POINTER(C.c_int), _u32p]),
     "splahip_csr_plan_attach_cob": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp]),
     "splahip_csr_plan_cob_info": (C.c_int, [_vp, _u32p, _u32p, _u32p, _u32p]),
+    "splahip_dist_available": (C.c_int, []),
+    "splahip_dist_get_unique_id": (C.c_int, [_vp]),
+    "splahip_dist_comm_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _vp]),
+    "splahip_dist_comm_destroy": (C.c_int, [_vp]),
+    "splahip_dist_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "splahip_dist_all_gather": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp]),
+    "splahip_shard_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "splahip_shard_destroy": (C.c_int, [_vp]),
+    "splahip_shard_info": (C.c_int, [_vp, _u32p, _u32p, C.POINTER(C.c_int)]),
+    "splahip_shard_split_serves": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
+    "splahip_shard_mxv_local": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_uint32, _vp]),
+    "splahip_shard_mxv_remote": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "splahip_shard_mxv_whole": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, _vp]),
+    "splahip_dist_mxv_masked": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_int), _vp]),
     "splahip_mxv_variant_of": (C.c_char_p, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "splahip_csr_plan_destroy": (C.c_int, [_vp]),
     "splahip_csr_plan_info": (C.c_int, [_vp, _u32p, _u32p]),
@@ -75,7 +89,8 @@ _SIGNATURES = {
     "splahip_m_transpose": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "splahip_map": (C.c_int, [C.c_int, C.c_uint32, _vp, _vp, C.c_int, _vp]),
 }
-_RAW = {"splahip_device_count", "splahip_last_error", "splahip_version", "splahip_mxv_variant", "splahip_mxv_variant_of"}
+_RAW = {"splahip_device_count", "splahip_last_error", "splahip_version", "splahip_mxv_variant", "splahip_mxv_variant_of", "splahip_dist_available",
+        "splahip_shard_split_serves"}
 
 _lib = None
 

@@ -128,7 +128,7 @@ namespace {
         template<typename U>
         hipError_t alloc(U** out, size_t count) {
             void*      p = nullptr;
-            hipError_t e = hipMalloc(&p, sizeof(U) * (count ? count : 1));
+            hipError_t e = device_malloc(&p, sizeof(U) * (count ? count : 1));
             if (e == hipSuccess) ptrs.push_back(p);
             *out = static_cast<U*>(p);
             return e;
@@ -156,6 +156,9 @@ namespace {
         return e && *e ? (uint32_t) std::strtoul(e, nullptr, 10) : dflt;
     }
 
+    // set by cob_mxv_accumulate around its call (per host thread): the launch below then folds onto the values r already holds
+    thread_local uint32_t tl_accumulate = 0;
+
     template<typename T, class Mult, int ACC, bool VXM>
     int launch_cob(const splahip_cob_s* g, const uint32_t* Ap, const void* mask, const void* v, void* r, uint32_t* touched, int op_mult, int op_add, int op_select,
                    uint32_t init_bits, hipStream_t st) {
@@ -174,6 +177,7 @@ namespace {
         a.row_bits = g->row_bits;
         a.col_bits = g->col_bits;
         a.pad_chunk = g->n_chunks;
+        a.accumulate = VXM ? 0u : tl_accumulate;
         const T        init = from_bits<T>(init_bits);
         const uint32_t R    = 1u << g->row_bits;
         if (sc.n_tiles) {
@@ -190,10 +194,10 @@ namespace {
         if (sc.n_multi) {
             const uint32_t bx = (R / 4 + 255) / 256;
             hipLaunchKernelGGL((cob_combine_kernel<T, DynBin, ACC, VXM, 256>), dim3(bx, sc.n_multi), dim3(256), 0, st, reinterpret_cast<const CobMulti*>(sc.d_multi), g->d_slabs, Ap,
-                               static_cast<const T*>(mask), static_cast<T*>(r), touched, g->n_rows, g->row_bits, DynBin(op_add), op_select, init);
+                               static_cast<const T*>(mask), static_cast<T*>(r), touched, g->n_rows, g->row_bits, DynBin(op_add), op_select, init, a.accumulate);
             SPLAHIP_TRY(hipGetLastError());
         }
-        if (g->n_empty) {// ranges without an entry: r = init (mxv) / touched = 0 (vxm)
+        if (g->n_empty && !a.accumulate) {// ranges without an entry: r = init (mxv) / touched = 0 (vxm); an accumulating pass leaves them alone
             if constexpr (VXM) hipLaunchKernelGGL((cob_fill_kernel<uint32_t>), dim3((R + 255) / 256, g->n_empty), dim3(256), 0, st, g->d_empty, g->n_rows, g->row_bits, touched, 0u);
             else
                 hipLaunchKernelGGL((cob_fill_kernel<T>), dim3((R + 255) / 256, g->n_empty), dim3(256), 0, st, g->d_empty, g->n_rows, g->row_bits, static_cast<T*>(r), init);
@@ -275,6 +279,15 @@ namespace splahip {
         return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
     }
 
+    // second column part of a row block (dist.hip): r[row] = add(r[row], fold of this part's products) for the selected rows that hold an entry here
+    int cob_mxv_accumulate(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add,
+                           int op_select, void* stream) {
+        tl_accumulate = 1;
+        const int st  = cob_mxv(plan, type, Ap, mask, v, r, op_mult, op_add, op_select, 0u, stream);
+        tl_accumulate = 0;
+        return st;
+    }
+
     // the pull form of vxm with every index of v stored, over the copy attached to the TRANSPOSED matrix's plan: out values and touched flags per
     // output index.  Only an op_add with a true identity (not LOR / LAND: a lone product must come out as itself, not as its truth value)
     bool cob_vxm_serves(const splahip_plan_s* plan_T, int type, int op_add, uint32_t n_in) {
@@ -352,7 +365,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         } else {
             if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, bytes, key, key_s, vin, val_s, (size_t) nnz, b0, b1, s);
             void* st_tmp = nullptr;
-            if (e == hipSuccess) e = hipMalloc(&st_tmp, bytes ? bytes : 4);
+            if (e == hipSuccess) e = device_malloc(&st_tmp, bytes ? bytes : 4);
             if (e == hipSuccess) {
                 tmp.ptrs.push_back(st_tmp);
                 e = rocprim::radix_sort_pairs(st_tmp, bytes, key, key_s, vin, val_s, (size_t) nnz, b0, b1, s);
@@ -379,7 +392,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     // 4: the packed streams
     auto own = [&](auto** q, size_t count) {
         using U = std::remove_pointer_t<std::remove_pointer_t<decltype(q)>>;
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(q), sizeof(U) * (count ? count : 1));
+        if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(q), sizeof(U) * (count ? count : 1));
     };
     own(&g->d_cr, ((size_t) n_chunks + 1) * kCobChunk);// + one all-padding chunk (the main loop's steps beyond a tile's end walk it)
     own(&g->d_ax, ((size_t) n_chunks + 1) * kCobChunk);

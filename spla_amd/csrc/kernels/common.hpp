@@ -36,6 +36,14 @@ namespace splahip {
 
     // Result arrays that a call hands to its caller (mxm / mxmT) are plain hipMalloc allocations — the stream-ordered pool is erratic
     // for multi-GB buffers — tracked (and cached when returned) in runtime.hip; splahip_free recognises them.
+    // Every cache of idle device memory this library keeps (returned hand-off blocks, mxm's grow-only workspaces, the stream-ordered pool's
+    // free list) is given back to the driver when an allocation reports out-of-memory, and the allocation is tried once more: in a process that
+    // shares the GPU with another allocator (torch's caching allocator in bench.py / the tests / the N > 1 path) tens of GB could otherwise sit
+    // idle here while a later request fails.  Translation units with a cache of their own register a trim callback.
+    void       release_idle_memory();
+    void       register_trim(void (*fn)());
+    hipError_t device_malloc(void** p, size_t bytes);                           // hipMalloc with release-and-retry
+    hipError_t device_malloc_async(void** p, size_t bytes, hipStream_t stream);// hipMallocAsync with release-and-retry
     hipError_t handoff_alloc(void** p, size_t bytes);
     bool       handoff_release(void* p);// true: p was a hand-off allocation and has been taken back (cached or freed)
     void       handoff_trim();          // free the cached hand-off blocks
@@ -57,7 +65,7 @@ namespace splahip {
         hipError_t alloc(hipStream_t stream, size_t bytes) {
             release();
             s = stream;
-            return hipMallocAsync(&p, bytes ? bytes : 4, stream);
+            return device_malloc_async(&p, bytes ? bytes : 4, stream);
         }
         template<typename U>
         U* as() { return static_cast<U*>(p); }

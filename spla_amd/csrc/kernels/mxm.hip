@@ -54,7 +54,7 @@ namespace splahip {
             drop();
             s      = tl_stream;
             pooled = true;
-            return hipMallocAsync(&p, bytes ? bytes : 4, s);
+            return device_malloc_async(&p, bytes ? bytes : 4, s);
         }
         hipError_t alloc_plain(size_t bytes) {// a result array: handed to the caller with release(), returned with splahip_free
             drop();
@@ -72,7 +72,8 @@ namespace splahip {
             if (c[slot].bytes < bytes) {
                 if (c[slot].p) (void) hipFree(c[slot].p);
                 c[slot] = {nullptr, 0};
-                hipError_t e = hipMalloc(&c[slot].p, bytes);
+                register_trim(&DevBuf::trim);// (idempotent) the cache goes back to the driver when any allocation of the library runs out of memory
+                hipError_t e = device_malloc(&c[slot].p, bytes);
                 if (e != hipSuccess) return e;
                 c[slot].bytes = bytes;
             }
@@ -88,7 +89,13 @@ namespace splahip {
             static thread_local std::vector<Slot> c;
             return c;
         }
+        // > 0 while an mxm / mxmT call of this thread is using the cached workspaces: an out-of-memory retry inside that call must not free them
+        static int& busy() {
+            static thread_local int b = 0;
+            return b;
+        }
         static void trim() {
+            if (busy() > 0) return;
             for (auto& sl : cache())
                 if (sl.p) (void) hipFree(sl.p);
             cache().clear();
@@ -322,6 +329,11 @@ namespace splahip {
     int mxmT_typed(uint n_rows, uint n_entries, const uint* Mp, const uint* Mj, const void* Mx, const uint* Ap, const uint* Aj, const void* Ax,
                    const uint* Bp, const uint* Bj, const void* Bx, uint* Rp, uint** Rj, void** Rx, uint* h_nnz,
                    int op_mult, int op_add, int op_select, uint32_t init_bits, hipStream_t s) {
+        struct Busy {
+            Busy() { ++DevBuf::busy(); }
+            ~Busy() { --DevBuf::busy(); }
+        } busy_scope;// the cached workspaces are in use until this call returns
+
         *Rj = nullptr, *Rx = nullptr, *h_nnz = 0;
         if (n_entries == 0) {
             SPLAHIP_TRY(hipMemsetAsync(Rp, 0, sizeof(uint) * ((size_t) n_rows + 1), s));
@@ -592,6 +604,11 @@ namespace splahip {
     int mxm_typed(uint a_rows, uint b_cols, const uint* Ap, const uint* Aj, const void* Ax, const uint* Bp, const uint* Bj, const void* Bx,
                   uint* Rp, uint** Rj, void** Rx, uint* h_nnz, u64* h_products, int op_mult, int op_add, uint32_t init_bits,
                   u64 block_products, hipStream_t s) {
+        struct Busy {
+            Busy() { ++DevBuf::busy(); }
+            ~Busy() { --DevBuf::busy(); }
+        } busy_scope;// the cached workspaces are in use until this call returns
+
         *Rj = nullptr, *Rx = nullptr, *h_nnz = 0;
         if (h_products) *h_products = 0;
         const T    init = from_bits<T>(init_bits);
@@ -678,8 +695,16 @@ namespace splahip {
             arena_words = arena_want;
         }
         trace.mark("workspace allocation");
-        uint total_out = 0;
-        int  status    = SPLAHIP_OK;
+        // The result's row pointers and *h_nnz are 32-bit (reference include/spla/config.hpp:56: uint): the entry count is summed in 64 bits and a
+        // result that cannot be indexed is refused BEFORE anything is sized from a wrapped count (R-MAT scale 19 x itself already holds 3.5 G
+        // entries).  SPLAHIP_MXM_MAX_NNZ lowers the limit (tests).
+        u64       total_out = 0;
+        const u64 nnz_limit = [] {
+            const char* e = std::getenv("SPLAHIP_MXM_MAX_NNZ");
+            const u64   v = e ? std::strtoull(e, nullptr, 10) : 0;
+            return v ? std::min<u64>(v, 0xFFFFFFF0ull) : 0xFFFFFFF0ull;
+        }();
+        int status = SPLAHIP_OK;
         for (const Block& blk : blocks) {
             if (trace.on && &blk == &blocks.back()) trace.mark("all blocks but the last");
             const uint e0 = blk.e0, n_entries = blk.n_entries, n_products = blk.n_products;
@@ -752,6 +777,8 @@ namespace splahip {
                     SPLAHIP_TRY(hipStreamSynchronize(s));
                     pieces.push_back({orow.release(), ocol.release(), oval.release(), n_out});
                     total_out += n_out;
+                    if (total_out > nnz_limit)
+                        return fail(SPLAHIP_NOT_IMPLEMENTED, "the product holds more than %llu entries: not representable with 32-bit row pointers", (unsigned long long) nnz_limit);
                 }
                 if (trace.on && &blk == &blocks.back()) trace.mark("  last block: compact + emit");
                 return SPLAHIP_OK;
@@ -778,7 +805,7 @@ namespace splahip {
             off += pc.n;
         }
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(rowptr_from_rows_kernel, dim3((a_rows + 1 + 255) / 256), dim3(256), 0, s, a_rows, total_out, rows.as<uint>(), Rp);
+            hipLaunchKernelGGL(rowptr_from_rows_kernel, dim3((a_rows + 1 + 255) / 256), dim3(256), 0, s, a_rows, (uint) total_out, rows.as<uint>(), Rp);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -787,7 +814,7 @@ namespace splahip {
         trace.mark("free pieces");
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm assembly failed: %s", hipGetErrorString(e));
         arena_want = std::max(arena_want, 3 * (size_t) total_out + 64);
-        *h_nnz     = total_out;
+        *h_nnz     = (uint) total_out;
         if (h_products) *h_products = total_products;
         *Rj = static_cast<uint*>(outj.release());
         *Rx = outx.release();

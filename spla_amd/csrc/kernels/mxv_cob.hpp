@@ -190,6 +190,8 @@ namespace splahip {
         uint32_t        row_bits;
         uint32_t        col_bits;
         uint32_t        pad_chunk;// an all-padding chunk behind the last real one
+        uint32_t        accumulate;// 1: r already holds the fold of another column part of the same rows (1-D row decomposition, dist.hip): a selected
+                                   // row that holds an entry here becomes add(r[row], acc); every other row is left as it is
     };
 
     // One workgroup per tile.  LDS: the range's R result words.  VXM: products are mult(v, x) (the pull form of vxm over the copy of the
@@ -318,6 +320,10 @@ namespace splahip {
                 if constexpr (VXM) {// no init: an output exists where the index is selected and holds a product; its value is the fold itself
                     tch[j] = sel && a.Ap[rj + 1] != a.Ap[rj];
                     out[j] = from_bits<T>(aw[j]);
+                } else if (a.accumulate) {
+                    const T prev = rj < a.n_rows ? r[rj] : init;
+                    if (sel) sel = a.Ap[rj + 1] != a.Ap[rj];
+                    out[j] = sel ? cob_finish<T, ACC>(aw[j], prev, add) : prev;
                 } else {
                     if constexpr (ACC == COB_LOR || ACC == COB_LAND) {
                         if (sel) sel = a.Ap[rj + 1] != a.Ap[rj];// a row without an entry keeps init itself, not its truth value
@@ -343,7 +349,7 @@ namespace splahip {
     template<typename T, class Add, int ACC, bool VXM, unsigned TPB>
     __global__ __launch_bounds__(TPB) void cob_combine_kernel(const CobMulti* __restrict__ multi, const uint32_t* __restrict__ slabs, const uint32_t* __restrict__ Ap,
                                                               const T* __restrict__ mask, T* __restrict__ r, uint32_t* __restrict__ touched, uint32_t n_rows,
-                                                              uint32_t row_bits, Add add, int op_select, T init) {
+                                                              uint32_t row_bits, Add add, int op_select, T init, uint32_t accumulate) {
         const uint32_t R   = 1u << row_bits;
         const CobMulti m   = multi[blockIdx.y];
         const uint32_t i   = (blockIdx.x * TPB + threadIdx.x) * 4;
@@ -368,6 +374,10 @@ namespace splahip {
             if constexpr (VXM) {
                 tch[j] = sel && Ap[rj + 1] != Ap[rj];
                 out[j] = from_bits<T>(aw[j]);
+            } else if (accumulate) {
+                const T prev = rj < n_rows ? r[rj] : init;
+                if (sel) sel = Ap[rj + 1] != Ap[rj];
+                out[j] = sel ? cob_finish<T, ACC>(aw[j], prev, add) : prev;
             } else {
                 if constexpr (ACC == COB_LOR || ACC == COB_LAND) {
                     if (sel) sel = Ap[rj + 1] != Ap[rj];

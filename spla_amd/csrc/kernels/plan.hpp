@@ -101,6 +101,9 @@ namespace splahip {
     // masked SpMV over the column-ordered-blocks copy (associative + commutative op_add with an LDS atomic, no early exit); SPLAHIP status
     int cob_mxv(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
                 uint32_t init_bits, void* stream);
+    // the same over a second column part of the same rows: r[row] = add(r[row], this part's fold) where the row is selected and holds an entry here
+    int cob_mxv_accumulate(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add,
+                           int op_select, void* stream);
     // the pull form of vxm with every index of v stored, over the copy attached to the TRANSPOSED matrix's plan (out values + touched flags)
     bool cob_vxm_serves(const splahip_plan_s* plan_T, int type, int op_add, uint32_t n_in);
     int  cob_vxm(const splahip_plan_s* plan_T, int type, const uint32_t* Tp, const void* mask, const void* v, void* out, uint32_t* touched, int op_mult, int op_add,

@@ -3,6 +3,7 @@
 // create/read/write (reference src/opencl/cl_accelerator.cpp:60-190, src/opencl/cl_format_dense_vec.hpp:40-88).
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
@@ -33,7 +34,8 @@ namespace splahip {
         char       g_name[256];
     }// namespace
 
-    static int select_device(int device) {
+    static void handoff_cache_limit(size_t bytes);
+    static int  select_device(int device) {
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
             (void) hipGetLastError();
@@ -54,6 +56,12 @@ namespace splahip {
                 (void) hipGetLastError();
             }
         }
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) handoff_cache_limit(free_b / 4);
+            else
+                (void) hipGetLastError();
+        }
         g_device = device;
         std::snprintf(g_arch, sizeof(g_arch), "%s", prop.gcnArchName);
         std::snprintf(g_name, sizeof(g_name), "%s", prop.name);
@@ -65,12 +73,57 @@ namespace splahip {
     // pool, whose latency for buffers of this size is erratic.  A returned block is reused for a request of at least half
     // its size; at most kHandoffCacheBytes stay cached (splahip_mxm_trim() drops them).
     namespace {
-        constexpr size_t                  kHandoffCacheBytes = size_t(48) << 30;
+        std::mutex                 g_trim_lock;
+        std::vector<void (*)()>    g_trim_fns;
+    }// namespace
+    void register_trim(void (*fn)()) {
+        std::lock_guard<std::mutex> guard(g_trim_lock);
+        for (auto f : g_trim_fns)
+            if (f == fn) return;
+        g_trim_fns.push_back(fn);
+    }
+    void release_idle_memory() {
+        (void) hipDeviceSynchronize();// nothing queued may still use a block that goes back to the driver
+        handoff_trim();
+        std::vector<void (*)()> fns;
+        {
+            std::lock_guard<std::mutex> guard(g_trim_lock);
+            fns = g_trim_fns;
+        }
+        for (auto f : fns) f();
+        int          dev  = 0;
+        hipMemPool_t pool = nullptr;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) (void) hipMemPoolTrimTo(pool, 0);
+        (void) hipGetLastError();
+    }
+    hipError_t device_malloc(void** p, size_t bytes) {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e == hipErrorOutOfMemory) {
+            (void) hipGetLastError();
+            release_idle_memory();
+            e = hipMalloc(p, bytes);
+        }
+        return e;
+    }
+    hipError_t device_malloc_async(void** p, size_t bytes, hipStream_t stream) {
+        hipError_t e = hipMallocAsync(p, bytes, stream);
+        if (e == hipErrorOutOfMemory) {
+            (void) hipGetLastError();
+            release_idle_memory();
+            e = hipMallocAsync(p, bytes, stream);
+        }
+        return e;
+    }
+
+    namespace {
+        // returned hand-off blocks kept for reuse: at most a quarter of the memory that was free when the device was selected, and at most 48 GiB
+        size_t                            kHandoffCacheBytes = size_t(48) << 30;
         std::mutex                        g_handoff_lock;
         std::unordered_map<void*, size_t> g_handoff_live;  // handed out: capacity
         std::vector<std::pair<void*, size_t>> g_handoff_free;// returned, reusable
         size_t                            g_handoff_free_bytes = 0;
     }// namespace
+    static void handoff_cache_limit(size_t bytes) { kHandoffCacheBytes = std::min(kHandoffCacheBytes, bytes); }
     hipError_t handoff_alloc(void** p, size_t bytes) {
         if (bytes == 0) bytes = 4;
         {
@@ -88,7 +141,7 @@ namespace splahip {
                 return hipSuccess;
             }
         }
-        hipError_t e = hipMalloc(p, bytes);
+        hipError_t e = device_malloc(p, bytes);
         if (e == hipSuccess) {
             std::lock_guard<std::mutex> guard(g_handoff_lock);
             g_handoff_live[*p] = bytes;
@@ -175,7 +228,7 @@ int splahip_malloc(void** d_ptr, size_t bytes) {
     *d_ptr = nullptr;
     // from the device's default memory pool, ordered on the default stream: hipMalloc / hipFree pairs synchronise the device and cost
     // ~0.1 ms each, which dominated short-lived objects (a BFS creates and drops a dozen vectors)
-    SPLAHIP_TRY(hipMallocAsync(d_ptr, bytes ? bytes : 4, nullptr));
+    SPLAHIP_TRY(device_malloc_async(d_ptr, bytes ? bytes : 4, nullptr));
     return SPLAHIP_OK;
 }
 

@@ -207,7 +207,7 @@ namespace {
         }
         hipError_t alloc(uint32_t** out, size_t words) {
             void*      p = nullptr;
-            hipError_t e = hipMalloc(&p, sizeof(uint32_t) * (words ? words : 1));
+            hipError_t e = device_malloc(&p, sizeof(uint32_t) * (words ? words : 1));
             if (e == hipSuccess) ptrs.push_back(p);
             *out = static_cast<uint32_t*>(p);
             return e;
@@ -515,7 +515,7 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
         if (e == hipSuccess) e = tmp.alloc(q, n_chunks);
     if (e == hipSuccess) e = tmp.alloc(&vk0, g->n_vrows);
     auto own = [&](uint32_t** q, size_t words) {
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(q), sizeof(uint32_t) * (words ? words : 1));
+        if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(q), sizeof(uint32_t) * (words ? words : 1));
     };
     own(&g->d_vrow, g->n_vrows);
     own(&g->d_vlen, g->n_vrows);

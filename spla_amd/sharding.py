@@ -14,6 +14,8 @@ Everything here is device-agnostic torch + torch.distributed (nccl == RCCL on RO
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -110,6 +112,8 @@ class SparseExchange:
         live = x_local != self.fill
         if upper_bound is not None and hasattr(torch, "nonzero_static"):
             m = max(int(min(upper_bound, blk.max_rows)), 1)
+            if os.environ.get("SPLA_CHECK_BOUNDS") == "1":  # debug: nonzero_static truncates silently when the caller's bound is too small
+                assert int(live.sum()) <= m, "SparseExchange: upper_bound is smaller than this rank's non-fill count"
             idx = torch.nonzero_static(live, size=m, fill_value=-1).squeeze(1)  # ascending local row ids, -1 beyond the count: no sync
             send = torch.where(idx >= 0, idx + blk.rank * blk.max_rows, torch.full_like(idx, self.trash))
             total = None
@@ -142,3 +146,120 @@ class SparseExchange:
         self.prev = recv
         self.last_count = total  # None when the caller supplied the bound (the count is then the caller's knowledge)
         return self.v_full
+
+
+# ---- the product behind the kernel-level C ABI (spla_amd/csrc/kernels/dist.hip) ------------------------------------------------------------
+def split_columns(blk: RowBlock):
+    """Torch mirror of splahip_shard_create's column split (CPU tests): the row block cut by column OWNER into the local part
+    (columns of this rank's own slice, rebased to [0, max_rows)) and the remote part (padded-layout column ids); a stable partition,
+    so both parts keep the rows' entry order.  Returns ((LAp, LAj, LAx), (RAp, RAj, RAx))."""
+    lo = blk.rank * blk.max_rows if blk.world > 1 else 0
+    hi = lo + (blk.max_rows if blk.world > 1 else blk.n)
+    cols = blk.Aj.to(torch.int64)
+    loc = (cols >= lo) & (cols < hi)
+    rows = torch.repeat_interleave(torch.arange(blk.n_local, device=cols.device), (blk.Ap[1:] - blk.Ap[:-1]).to(torch.int64))
+    parts = []
+    for sel, rebase in ((loc, lo), (~loc, 0)):
+        cnt = torch.bincount(rows[sel], minlength=blk.n_local)
+        p = torch.zeros(blk.n_local + 1, dtype=torch.int64, device=cols.device)
+        torch.cumsum(cnt, 0, out=p[1:])
+        parts.append((p.to(blk.Ap.dtype), (cols[sel] - rebase).to(blk.Aj.dtype), blk.Ax[sel] if blk.Ax is not None else None))
+    return parts[0], parts[1]
+
+
+class DistComm:
+    """RCCL communicator of the C ABI (splahip_dist_comm_*); rank 0's unique id travels through torch.distributed (any backend)."""
+
+    def __init__(self, world: int, rank: int):
+        import ctypes as C
+        from . import _lib
+        self.world, self.rank = world, rank
+        buf = (C.c_ubyte * 128)()
+        if rank == 0:
+            _lib.call("splahip_dist_get_unique_id", C.byref(buf))
+        if world > 1:
+            t = torch.tensor(list(buf), dtype=torch.uint8)
+            dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            t = t.to(dev)
+            dist.broadcast(t, src=0)
+            buf = (C.c_ubyte * 128)(*t.cpu().tolist())
+        self._h = C.c_void_p()
+        _lib.call("splahip_dist_comm_create", C.byref(self._h), world, rank, C.byref(buf))
+
+    def all_gather(self, send: torch.Tensor, recv: torch.Tensor, direct=False):
+        from . import _lib
+        from .kernels import _ptr, current_stream_ptr
+        _lib.call("splahip_dist_all_gather", self._h, _ptr(send), _ptr(recv), int(send.numel()), 1 if direct else 0, current_stream_ptr())
+        return recv
+
+    def close(self):
+        from . import _lib
+        if self._h:
+            _lib.call("splahip_dist_comm_destroy", self._h)
+            self._h = None
+
+
+class Shard:
+    """This rank's row block behind the C ABI: the column split, both plans and their column-ordered-blocks copies (splahip_shard_*).
+    Works without a communicator: the phases (local part / remote part / whole block) are separate calls, so a host that brings its own
+    exchange — torch.distributed over gloo in the one-GPU debug run, the sequential two-rank simulation of the GPU tests — drives them."""
+
+    def __init__(self, blk: RowBlock, Ax: torch.Tensor):
+        import ctypes as C
+        from . import _lib
+        from .kernels import _ptr, current_stream_ptr
+        self.blk = blk
+        self._keep = (blk.Ap, blk.Aj, Ax)  # the shard references the caller's arrays
+        self._h = C.c_void_p()
+        max_rows = blk.max_rows if blk.world > 1 else blk.n
+        _lib.call("splahip_shard_create", C.byref(self._h), blk.world, blk.rank, blk.n_local, max_rows, blk.nnz_local, _ptr(blk.Ap),
+                  _ptr(blk.Aj) if blk.nnz_local else None, _ptr(Ax) if blk.nnz_local else None, current_stream_ptr())
+        a, b, ok = C.c_uint32(), C.c_uint32(), C.c_int()
+        _lib.call("splahip_shard_info", self._h, C.byref(a), C.byref(b), C.byref(ok))
+        self.nnz_local_cols, self.nnz_remote_cols, self.split_ok = a.value, b.value, bool(ok.value)
+
+    def serves(self, t, op_add, early_exit=False) -> bool:
+        from . import _lib
+        from .ops import binop_id, type_id
+        return bool(_lib.call("splahip_shard_split_serves", self._h, type_id(t), binop_id(op_add), 1 if early_exit else 0))
+
+    def mxv_local(self, t, mask, v_local, r, op_mult, op_add, op_select, init):
+        from . import _lib
+        from .kernels import _ptr, current_stream_ptr
+        from .ops import binop_id, scalar_bits, selop_id, type_id
+        tid = type_id(t)
+        _lib.call("splahip_shard_mxv_local", self._h, tid, _ptr(mask), _ptr(v_local), _ptr(r), binop_id(op_mult), binop_id(op_add), selop_id(op_select),
+                  scalar_bits(init, tid), current_stream_ptr())
+
+    def mxv_remote(self, t, mask, v_full, r, op_mult, op_add, op_select):
+        from . import _lib
+        from .kernels import _ptr, current_stream_ptr
+        from .ops import binop_id, selop_id, type_id
+        _lib.call("splahip_shard_mxv_remote", self._h, type_id(t), _ptr(mask), _ptr(v_full), _ptr(r), binop_id(op_mult), binop_id(op_add), selop_id(op_select),
+                  current_stream_ptr())
+
+    def mxv_whole(self, t, mask, v_full, r, op_mult, op_add, op_select, init, early_exit=False):
+        from . import _lib
+        from .kernels import _ptr, current_stream_ptr
+        from .ops import binop_id, scalar_bits, selop_id, type_id
+        tid = type_id(t)
+        _lib.call("splahip_shard_mxv_whole", self._h, tid, _ptr(mask), _ptr(v_full), _ptr(r), binop_id(op_mult), binop_id(op_add), selop_id(op_select),
+                  scalar_bits(init, tid), 1 if early_exit else 0, current_stream_ptr())
+
+    def product(self, comm: DistComm, t, mask, v_local, v_full, r, op_mult, op_add, op_select, init, early_exit=False, direct=False) -> bool:
+        """one sharded masked SpMV over RCCL (splahip_dist_mxv_masked): returns True when the overlapped two-part form ran"""
+        import ctypes as C
+        from . import _lib
+        from .kernels import _ptr, current_stream_ptr
+        from .ops import binop_id, scalar_bits, selop_id, type_id
+        tid = type_id(t)
+        ov = C.c_int()
+        _lib.call("splahip_dist_mxv_masked", comm._h, self._h, tid, _ptr(mask), _ptr(v_local), _ptr(v_full), _ptr(r), binop_id(op_mult), binop_id(op_add),
+                  selop_id(op_select), scalar_bits(init, tid), 1 if early_exit else 0, 1 if direct else 0, C.byref(ov), current_stream_ptr())
+        return bool(ov.value)
+
+    def close(self):
+        from . import _lib
+        if self._h:
+            _lib.call("splahip_shard_destroy", self._h)
+            self._h = None

@@ -127,3 +127,23 @@ def test_triangle_count_form():
     _, _, V = Bm.read()
     a = dense.astype(np.int64)
     assert int(V.sum()) == int(np.trace(a @ a @ a) // 6)
+
+
+def test_mxm_refuses_a_result_beyond_32bit_row_pointers(monkeypatch):
+    """The entry count of the product is summed in 64 bits and checked before anything is sized from it (reference row pointers are uint,
+    include/spla/config.hpp:56); SPLAHIP_MXM_MAX_NNZ lowers the limit so the guard can be exercised on a small input: the call must fail with
+    NOT_IMPLEMENTED, leave nothing behind, and the same call without the limit must still work."""
+    from spla_amd import _lib, kernels
+    rng = np.random.default_rng(5)
+    A = random_csr(rng, 300, 300, 8, "INT")
+    dA = _dev3(A, "INT")
+    ok, _ = kernels.mxm("INT", 300, 300, dA, dA, "MULT", "PLUS", 0, block_products=500)
+    nnz = int(ok[1].numel())
+    assert nnz > 100
+    monkeypatch.setenv("SPLAHIP_MXM_MAX_NNZ", str(nnz // 3))
+    with pytest.raises(_lib.SplaHipError) as err:
+        kernels.mxm("INT", 300, 300, dA, dA, "MULT", "PLUS", 0, block_products=500)  # many row blocks: the limit is crossed mid-way
+    assert err.value.status == 1024 and "32-bit row pointers" in str(err.value)
+    monkeypatch.delenv("SPLAHIP_MXM_MAX_NNZ")
+    again, _ = kernels.mxm("INT", 300, 300, dA, dA, "MULT", "PLUS", 0, block_products=500)
+    assert int(again[1].numel()) == nnz

@@ -1,0 +1,122 @@
+"""The 1-D row-block decomposition behind the kernel-level C ABI (spla_amd/csrc/kernels/dist.hip) on ONE GPU: the shards of every rank are built
+and driven one after the other — local-column part, "exchange" (a device-side concatenation here), remote-column part — and the stitched result
+must equal the unsharded oracle result: a row-block split changes no row's fold (bit-exact for int32; 1e-5 for fp32 plus-times).  The RCCL
+communicator is exercised at world size 1 (a single-GPU box cannot host two RCCL ranks); the N > 1 exchange itself is covered by the gloo tests on
+CPU and by bench.py --gpus N on a multi-GPU node."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(scale=13, ef=16):
+    from spla_amd import graphgen
+    n, Ap, Aj = graphgen.rmat_csr(scale, ef, seed=3, device="cpu")
+    return n, Ap, Aj
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_phases_equal_whole_min_plus_int32(oracle, world):
+    """BASELINE configs[3] in its sharded form: min-plus int32, INF = 2^30, weights 1..255, 2 / 3 / 8 nnz-balanced row blocks."""
+    from spla_amd import sharding
+    n, Ap, Aj = _graph()
+    g = torch.Generator().manual_seed(11)
+    w = torch.randint(1, 256, (int(Ap[-1]),), generator=g, dtype=torch.int32)
+    INF = 1 << 30
+    d = torch.full((n,), INF, dtype=torch.int32)
+    d[torch.randperm(n, generator=g)[: n // 8]] = torch.randint(0, 5000, (n // 8,), generator=g, dtype=torch.int32)
+    mask = torch.zeros(n, dtype=torch.int32)
+    want = oracle.mxv_masked("INT", n, n, Ap.numpy(), Aj.numpy(), w.numpy(), mask.numpy(), d.numpy(), "PLUS", "MIN", "ALWAYS", INF)
+    bounds = sharding.row_splits(Ap, world)
+    blks = [sharding.RowBlock(Ap.cuda(), Aj.cuda(), w.cuda(), bounds, r) for r in range(world)]
+    shards = [sharding.Shard(b, b.Ax) for b in blks]
+    assert sum(s.nnz_local_cols + s.nnz_remote_cols for s in shards) == int(Ap[-1])
+    # the "exchange": every rank's padded slice, concatenated in rank order = what the all-gather delivers
+    slices = [b.pad_local(d[b.lo:b.hi].cuda(), fill=INF) for b in blks]
+    v_full = torch.cat(slices)
+    got = np.empty(n, np.int32)
+    for b, s, v_loc in zip(blks, shards, slices):
+        assert s.split_ok and s.serves("INT", "MIN")
+        r = torch.full((b.n_local,), -7, dtype=torch.int32, device="cuda")
+        m = mask[b.lo:b.hi].cuda()
+        s.mxv_local("INT", m, v_loc, r, "PLUS", "MIN", "ALWAYS", INF)
+        s.mxv_remote("INT", m, v_full, r, "PLUS", "MIN", "ALWAYS")
+        r2 = torch.empty_like(r)
+        s.mxv_whole("INT", m, v_full, r2, "PLUS", "MIN", "ALWAYS", INF)
+        assert torch.equal(r, r2)
+        got[b.lo:b.hi] = r.cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    for s in shards:
+        s.close()
+
+
+@pytest.mark.parametrize("case", [("FLOAT", "MULT", "PLUS", "NQZERO", 0.0), ("INT", "LAND", "LOR", "EQZERO", 5), ("UINT", "BAND", "BOR", "ALWAYS", 0),
+                                  ("INT", "MULT", "SECOND", "ALWAYS", 0)])
+def test_sharded_phases_other_semirings(oracle, case):
+    """fp32 plus-times (1e-5), LOR with a non-zero init (rows without an entry keep init itself), BOR; and an op_add the blocks cannot serve
+    (SECOND: order-dependent) takes the unsplit block after the exchange."""
+    from helpers import NP, random_mask, random_values
+    from spla_amd import sharding
+    t, mul, add, sel, init = case
+    n, Ap, Aj = _graph(12, 8)
+    rng = np.random.default_rng(17)
+    Ax = random_values(rng, int(Ap[-1]), t)
+    v = random_values(rng, n, t, zeros=0.3)
+    mask = random_mask(rng, n, t)
+    want = oracle.mxv_masked(t, n, n, Ap.numpy(), Aj.numpy(), Ax, mask, v, mul, add, sel, init)
+    world = 4
+    bounds = sharding.row_splits(Ap, world)
+    tx = torch.from_numpy(Ax.view(np.int32) if t == "UINT" else Ax)
+    tv = torch.from_numpy(v.view(np.int32) if t == "UINT" else v)
+    tm = torch.from_numpy(mask.view(np.int32) if t == "UINT" else mask)
+    blks = [sharding.RowBlock(Ap.cuda(), Aj.cuda(), tx.cuda(), bounds, r) for r in range(world)]
+    slices = [b.pad_local(tv[b.lo:b.hi].cuda()) for b in blks]
+    v_full = torch.cat(slices)
+    got = np.empty(n, NP[t])
+    for b, v_loc in zip(blks, slices):
+        s = sharding.Shard(b, b.Ax)
+        r = torch.empty(b.n_local, dtype=tx.dtype, device="cuda")
+        m = tm[b.lo:b.hi].cuda()
+        if s.serves(t, add):
+            s.mxv_local(t, m, v_loc, r, mul, add, sel, init)
+            s.mxv_remote(t, m, v_full, r, mul, add, sel)
+        else:
+            assert add == "SECOND"
+            s.mxv_whole(t, m, v_full, r, mul, add, sel, init)
+        got[b.lo:b.hi] = r.cpu().numpy().view(NP[t])
+        s.close()
+    if t == "FLOAT":
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=0)
+    else:
+        np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_rccl_communicator_world1_and_dist_product(oracle):
+    """splahip_dist_*: RCCL loads, a one-rank communicator initialises, both all-gather forms move the slice, and splahip_dist_mxv_masked (exchange
+    stream || local part, then the remote part) returns the oracle's result."""
+    from spla_amd import _lib, sharding
+    assert _lib.call("splahip_dist_available") == 1
+    comm = sharding.DistComm(1, 0)
+    x = torch.arange(1000, dtype=torch.int32, device="cuda")
+    for direct in (False, True):
+        y = torch.zeros_like(x)
+        comm.all_gather(x, y, direct=direct)
+        torch.cuda.synchronize()
+        assert torch.equal(x, y)
+    n, Ap, Aj = _graph(12, 8)
+    g = torch.Generator().manual_seed(5)
+    w = torch.randint(1, 50, (int(Ap[-1]),), generator=g, dtype=torch.int32)
+    v = torch.randint(0, 100, (n,), generator=g, dtype=torch.int32)
+    mask = torch.randint(0, 2, (n,), generator=g, dtype=torch.int32)
+    want = oracle.mxv_masked("INT", n, n, Ap.numpy(), Aj.numpy(), w.numpy(), mask.numpy(), v.numpy(), "MULT", "PLUS", "EQZERO", 3)
+    blk = sharding.RowBlock(Ap.cuda(), Aj.cuda(), w.cuda(), [0, n], 0)
+    s = sharding.Shard(blk, blk.Ax)
+    r = torch.empty(n, dtype=torch.int32, device="cuda")
+    v_full = torch.empty(n, dtype=torch.int32, device="cuda")
+    overlapped = s.product(comm, "INT", mask.cuda(), v.cuda(), v_full, r, "MULT", "PLUS", "EQZERO", 3)
+    torch.cuda.synchronize()
+    assert overlapped
+    np.testing.assert_array_equal(r.cpu().numpy(), want)
+    s.close()
+    comm.close()

@@ -62,6 +62,36 @@ def _worker(rank, world, port, out_dir):
             assert torch.equal(got[:blk.n_cols_padded], want), (fill, rnd)
             assert torch.equal(got[:blk.n_cols_padded][blk.Aj.to(torch.int64)], x[blk.Aj_global.to(torch.int64)])
             assert sx.last_count == (None if rnd % 2 else k)
+    # the two-part (overlappable) form of the product: the block cut by column owner; the local part needs only this rank's slice of v,
+    # the remote part folds onto its result once the exchange has landed (splahip_shard_mxv_local / _remote, dist.hip).  BASELINE configs[3]:
+    # min-plus int32, init = INF = 2^30, weights 1..255; and plus-times / or-and for the other monoid families
+    (LAp, LAj, LAx), (RAp, RAj, RAx) = sharding.split_columns(blk)
+    assert int(LAp[-1]) + int(RAp[-1]) == blk.nnz_local and (world == 1 or int(RAp[-1]) > 0)
+    w = torch.randint(1, 256, (int(Ap[-1]),), generator=g, dtype=torch.int32)
+    wblk = sharding.RowBlock(Ap, Aj, w, bounds, rank)
+    (_, _, LAw), (_, _, RAw) = sharding.split_columns(wblk)
+    INF = 1 << 30
+    d = torch.full((n,), INF, dtype=torch.int32)
+    d[torch.randperm(n, generator=g)[: n // 8]] = torch.randint(0, 5000, (n // 8,), generator=g, dtype=torch.int32)
+    d_pad = blk.all_gather(blk.pad_local(d[blk.lo:blk.hi], fill=INF))
+    v_loc = blk.pad_local(d[blk.lo:blk.hi], fill=INF)
+    for (mul, add, init, LX, RX, vec_l, vec_f) in (("PLUS", "MIN", INF, LAw, RAw, v_loc, d_pad),
+                                                    ("MULT", "PLUS", 0, LAx, RAx, blk.pad_local(v[blk.lo:blk.hi]), v_pad),
+                                                    ("LAND", "LOR", 0, LAx, RAx, blk.pad_local(v[blk.lo:blk.hi]), v_pad)):
+        whole_x = wblk.Ax if mul == "PLUS" else blk.Ax
+        whole_v = d if mul == "PLUS" else v
+        want = orc.mxv_masked("INT", n, n, Ap.numpy(), Aj.numpy(), (w if mul == "PLUS" else Ax).numpy(), mask.numpy(), whole_v.numpy(), mul, add, "EQZERO", init)[blk.lo:blk.hi]
+        m_loc = mask[blk.lo:blk.hi].numpy()
+        r1 = orc.mxv_masked("INT", blk.n_local, blk.max_rows, LAp.numpy(), LAj.numpy(), LX.numpy(), m_loc, vec_l.numpy(), mul, add, "EQZERO", init)
+        # remote part: fold from the monoid's identity, then fold onto r1 where the row is selected and holds a remote entry
+        ident = {"MIN": 2 ** 31 - 1, "PLUS": 0, "LOR": 0}[add]
+        r2 = orc.mxv_masked("INT", blk.n_local, blk.n_cols_padded, RAp.numpy(), RAj.numpy(), RX.numpy(), m_loc, vec_f.numpy(), mul, add, "EQZERO", ident)
+        has = (np.diff(RAp.numpy().astype(np.int64)) > 0) & (m_loc == 0)
+        fold = {"MIN": np.minimum, "PLUS": np.add, "LOR": lambda a, b: ((a != 0) | (b != 0)).astype(np.int32)}[add]  # reference src/op.cpp:194-234
+        got = np.where(has, fold(r1, r2), r1)
+        assert np.array_equal(got, want), (mul, add)
+        whole = orc.mxv_masked("INT", blk.n_local, blk.n_cols_padded, blk.Ap.numpy(), blk.Aj.numpy(), whole_x.numpy(), m_loc, vec_f.numpy(), mul, add, "EQZERO", init)
+        assert np.array_equal(whole, want)
     Path(out_dir, f"ok{rank}").write_text("ok")
     dist.barrier()
     dist.destroy_process_group()

@@ -1,13 +1,12 @@
 #!/bin/bash
-# control-flow check of the N=2 bench path on a 1-GPU box: two ranks share GPU 0, exchange staged through gloo; both exchange forms
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"; mkdir -p gpurun_out
-for mode in dense sparse; do
-  SPLA_EXCHANGE=$mode SPLA_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 \
-     bench.py --gpus 2 --steps 5 --warmup 2 --scale 18 > gpurun_out/bench_n2_debug_$mode.json 2> gpurun_out/bench_n2_debug_$mode.err
-  echo "$mode exit $?"; grep -E "^\[bench\]|Error|error" gpurun_out/bench_n2_debug_$mode.err | tail -5
-  python - gpurun_out/bench_n2_debug_$mode.json <<'PY'
-import json, sys
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print({k: d[k] for k in ("value", "n_gpus", "ms_per_step", "verified")}, d["exchange"])
-PY
-done
+# two ranks on ONE GPU (control flow + overlap of the exchange with the local-column part): the exchange is staged through the host with gloo
+# (RCCL cannot host two ranks on one device), the phases of the product run through the C ABI (spla_amd/csrc/kernels/dist.hip)
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+export SPLA_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --workload sssp-step --scale ${SCALE:-21} --steps 20 --warmup 3 \
+    > gpurun_out/bench_n2_sssp_gloo_debug.json 2> gpurun_out/bench_n2_sssp_gloo_debug.log
+tail -3 gpurun_out/bench_n2_sssp_gloo_debug.log; cat gpurun_out/bench_n2_sssp_gloo_debug.json
+SPLA_EXCHANGE=abi python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --scale ${SCALE:-21} --steps 20 --warmup 3 --no-variants \
+    > gpurun_out/bench_n2_bfs_abi_gloo_debug.json 2> gpurun_out/bench_n2_bfs_abi_gloo_debug.log
+tail -3 gpurun_out/bench_n2_bfs_abi_gloo_debug.log; cat gpurun_out/bench_n2_bfs_abi_gloo_debug.json
