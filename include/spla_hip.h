@@ -111,6 +111,16 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
                        int op_mult, int op_add, int op_select, uint32_t init_bits, int early_exit,
                        void* stream);
 
+/* ---- user-defined ops: run-time compilation (spla_amd/csrc/kernels/jit.hip) ---------------------------------------------------------------
+ * The same masked SpMV with ops given as SOURCE TEXT — the body a reference user passes to OpBinary::make_* / OpSelect::make_*, e.g.
+ * "(float a, float b) { return 0.25f * a + 0.75f * b; }" (reference src/op.cpp:294-317, tests/test_op.cpp:56-59) — compiled with hiprtc, cached by
+ * text.  *_src == NULL means the built-in op with the given id.  One lane per row, strict left fold with the reference's early-exit rule: exact for
+ * any op.  Returns 8 (the reference's Status::CompilationError) with the compiler's log in splahip_last_error() when the text does not compile. */
+int splahip_jit_available(void);
+int splahip_mxv_masked_jit(int type, uint32_t n_rows, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, const void* d_mask, const void* d_v, void* d_r,
+                           int op_mult, const char* mult_src, int op_add, const char* add_src, int op_select, const char* select_src, uint32_t init_bits,
+                           int early_exit, void* stream);
+
 /* ---- 1-D row-block decomposition across the GPUs of one node (spla_amd/csrc/kernels/dist.hip) -------------------------------
  * One process per GPU.  Rank p owns a contiguous block of rows (its CSR slice with the column ids remapped to the PADDED layout
  * owner * max_rows + offset, the matching slices of mask and r) and slice p of the input vector; one exchange per product: the all-gather of v.

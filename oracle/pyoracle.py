@@ -46,6 +46,9 @@ def build(force: bool = False) -> None:
     product = HERE.parent / "spla_amd" / "lib" / "libspla_amd.so"
     if Path("/root/reference/tests/test_mxv.cpp").exists() and product.exists():
         subprocess.run(["make", "-C", str(HERE), "-j4", "reftests", "refexamples"], check=True, capture_output=True)
+    # this repo's own C++ tests of the operator API (tests/cpp), same place, same linkage
+    if product.exists() and (HERE.parent / "tests" / "cpp").is_dir():
+        subprocess.run(["make", "-C", str(HERE), "usertests"], check=True, capture_output=True)
 
 
 def _tid(t) -> int:

@@ -75,12 +75,32 @@ namespace spla {
                 const int op_mult = device_binop<T>(t->op_multiply);
                 const int op_add  = device_binop<T>(t->op_add);
                 const int op_sel  = device_selop<T>(t->op_select);
-                if (op_mult < 0 || op_add < 0 || op_sel < 0) {
-                    SPLA_LOG(Status::NotImplemented, "user-defined ops have no device code in this build");
-                    return Status::NotImplemented;
-                }
                 if (r->get_n_rows() != M->get_n_rows() || mask->get_n_rows() != M->get_n_rows() || v->get_n_rows() != M->get_n_cols())
                     return Status::InvalidArgument;
+                if (op_mult < 0 || op_add < 0 || op_sel < 0) {
+                    // a user-defined op (OpBinary::make_* / OpSelect::make_*): its body text is compiled for the device at run time (jit.hip) — what the
+                    // reference's OpenCL backend does with the same text (cl_program_builder.cpp:65-120); there is no CPU path to fall back to
+                    r->validate_wd(FormatVector::AccDense);
+                    mask->validate_rw(FormatVector::AccDense);
+                    v->validate_rw(FormatVector::AccDense);
+                    M->validate_rw(FormatMatrix::AccCsr);
+                    auto*             a  = M->acc_csr();
+                    const std::string sm = op_mult < 0 ? t->op_multiply->get_source_cl() : std::string();
+                    const std::string sa = op_add < 0 ? t->op_add->get_source_cl() : std::string();
+                    const std::string ss = op_sel < 0 ? t->op_select->get_source_cl() : std::string();
+                    const int         st = splahip_mxv_masked_jit(TypeTraits<T>::id, M->get_n_rows(), a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(),
+                                                                  mask->acc_dense()->Ax.ptr(), v->acc_dense()->Ax.ptr(), r->acc_dense()->Ax.ptr(), op_mult,
+                                                                  op_mult < 0 ? sm.c_str() : nullptr, op_add, op_add < 0 ? sa.c_str() : nullptr, op_sel,
+                                                                  op_sel < 0 ? ss.c_str() : nullptr, word_of(init->get_value()),
+                                                                  t->get_desc_or_default()->get_early_exit() ? 1 : 0, nullptr);
+                    if (st == 8) {
+                        SPLA_LOG(Status::CompilationError, splahip_last_error());
+                        return Status::CompilationError;
+                    }
+                    if (st == SPLAHIP_NOT_IMPLEMENTED) return Status::NotImplemented;
+                    hip_check(st, "splahip_mxv_masked_jit");
+                    return Status::Ok;
+                }
 
                 // same format requests as the reference's accelerated mxv (cl_mxv.hpp:91-94); r is write-discard:
                 // every row is overwritten (cpu_mxv.hpp:88-103)
