@@ -234,6 +234,14 @@ def sssp_step(args):
     return line
 
 
+def _mxm_info():
+    import ctypes as C
+    from spla_amd import _lib
+    a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    _lib.call("splahip_mxm_last_info", C.byref(a), C.byref(b), C.byref(c))
+    return {"heavy_items": a.value, "light_rows_nnz": b.value, "dense_corner_h": c.value}
+
+
 # --------------------------------------------------------------------------------------------------------------- mxmT
 def _row_sample_csr(Ap, Aj, Ax, rows):
     """CSR (on the host, numpy) that keeps only the given rows' entries, other rows empty (same shape)."""
@@ -344,8 +352,10 @@ def mxm(args):
     line = _line("SpGEMM (mxm) G products/s", "Gproducts/s", P / (wall / steps) / 1e9, args, wall / steps * 1e3, "f32",
                  {"workload": f"exec_mxm A x A, MULT/PLUS fp32, init 0; R-MAT scale {scale} ef {args.edge_factor} (scale 20 of BASELINE configs[4] expands to more "
                               "products than one ESC pass should hold in round 1; stated fallback)", "n": n, "nnz_A": nnz, "products": P, "nnz_C": nnz_c,
-                  "form": "ESC: expand / stable radix sort of compact (row in block, column) keys (rocPRIM) / in-order run fold / compact, row blocks of 2^27 products; timed: the blocking C call"},
-                 _roof(alg, ms, "mxm ESC pipeline"))
+                  "form": "row classes (mxm_spa.hip): rows of > 4096 products keep the result row's accumulators in LDS (Gustavson; symbolic pass, then the ranked form "
+                          "for rows whose entries fit one block and column blocks for the hubs), lighter rows through ESC; a dense leading corner would run on MFMA "
+                          "(none in R-MAT: the 1 K x 1 K hub corner is ~23 % full); timed: the blocking C call", "row_classes": _mxm_info()},
+                 _roof(alg, ms, "mxm_spa (symbolic + numeric) + ESC for the light rows"))
     args.steps = args_steps
     if not args.no_verify or not args.no_cpu_baseline:
         srows = torch.arange(0, n, 256, device="cuda")

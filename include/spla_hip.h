@@ -209,8 +209,10 @@ int splahip_csr_transpose(uint32_t n_rows, uint32_t n_cols, uint32_t nnz, const 
  *   r == init are dropped (reference cpu_mxmT_masked.hpp:87-125).  mask/A/R have n_rows rows; B has one row per
  *   column of R.
  * mxm: R = A * B — R[i,j] folds mult(a_ik, b_kj) over k in the order of A[i,:], starting at init; entries == init are
- *   dropped; columns ascending (reference cpu_mxm.hpp:85-114).  ESC over row blocks of at most `block_products`
- *   expanded products (0 = default); *h_products (optional) receives the total number of products.               */
+ *   dropped; columns ascending (reference cpu_mxm.hpp:85-114).  An op_add with an LDS atomic (PLUS; MIN / MAX / BOR / BAND / BXOR on int and
+ *   uint; LOR / LAND) runs by row classes (mxm_spa.hip): rows of more than 4096 products keep one result row's accumulator block in LDS
+ *   (Gustavson), lighter rows and every other op_add run ESC over row blocks of at most `block_products` expanded products (0 = default);
+ *   fp32 MULT / PLUS: a dense leading corner of A and B is multiplied on the matrix cores.  *h_products (optional) = total number of products. */
 int splahip_mxmT_masked(int type, uint32_t n_rows, uint32_t mask_nnz,
                         const uint32_t* d_Mp, const uint32_t* d_Mj, const void* d_Mx,
                         const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax,
@@ -222,6 +224,9 @@ int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols,
                 const uint32_t* d_Bp, const uint32_t* d_Bj, const void* d_Bx,
                 uint32_t* d_Rp, uint32_t** d_Rj, void** d_Rx, uint32_t* h_nnz, uint64_t* h_products,
                 int op_mult, int op_add, uint32_t init_bits, uint64_t block_products, void* stream);
+/* which row classes the last splahip_mxm of this host thread used (mxm_spa.hip): rows served by the LDS-accumulator form, entries the light rows'
+ * ESC call produced, side of the dense corner computed on the matrix cores (0 = none).  All 0: the whole call ran the ESC form. */
+int splahip_mxm_last_info(uint32_t* n_heavy_rows, uint32_t* light_nnz, uint32_t* dense_h);
 /* mxm keeps its GB-sized workspaces between calls (per host thread, grow-only); this returns them to the driver */
 int splahip_mxm_trim(void);
 

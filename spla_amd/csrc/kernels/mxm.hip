@@ -823,6 +823,10 @@ namespace splahip {
 
 }// namespace splahip
 
+namespace splahip {
+    int mxm_spa(int type, uint32_t a_rows, uint32_t b_cols, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const uint32_t* Bp, const uint32_t* Bj, const void* Bx, uint32_t* Rp,
+                uint32_t** Rj, void** Rx, uint32_t* h_nnz, unsigned long long* h_products, int op_mult, int op_add, uint32_t init_bits, hipStream_t s);
+}
 using namespace splahip;
 
 extern "C" {
@@ -868,6 +872,12 @@ int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols,
     if (block_products == 0) block_products = 1ull << 27;// 128 Mi products per row block (~5 GiB of sort buffers)
     unsigned long long prod = 0;
     int                rc;
+    // row classes with LDS accumulators (mxm_spa.hip) for every op_add that has an LDS atomic; -1: not applicable -> the ESC form below
+    rc = mxm_spa(type, a_rows, b_cols, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, &prod, op_mult, op_add, init_bits, s);
+    if (rc != -1) {
+        if (h_products) *h_products = prod;
+        return rc;
+    }
     switch (type) {
         case SPLAHIP_INT: rc = mxm_typed<int32_t>(a_rows, b_cols, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, &prod, op_mult, op_add, init_bits, block_products, s); break;
         case SPLAHIP_UINT: rc = mxm_typed<uint32_t>(a_rows, b_cols, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, &prod, op_mult, op_add, init_bits, block_products, s); break;

@@ -1,0 +1,839 @@
+// mxm_spa.hip — SpGEMM by row classes: Gustavson's row-by-row product with the accumulator of one result row kept in LDS, one column block at a
+// time (the reference keeps a dense accumulator row of width n_cols per row of A, src/cpu/cpu_mxm.hpp:93-113 — this is that, cut to what 160 KB of
+// LDS hold), for every op_add that has an LDS atomic (mxv_cob.hpp: cob_acc_kind — PLUS, MIN / MAX / BOR / BAND / BXOR on int and uint, LOR / LAND).
+//
+// Semantics: reference Algo_mxm_cpu<T>::execute, cpu_mxm.hpp:85-114: R[i,j] = fold over k in A[i,:]'s order of add(., mult(a_ik, b_kj)) from init;
+// an entry exists where at least one product exists and its value != init; columns ascending.  For an associative + commutative op_add the fold
+// order is free: int / uint results are bit-identical, fp32 PLUS is summed in a double slice and rounded once (the 1e-5 bar).  Everything else
+// (MINUS, FIRST, SECOND, fp32 MULT, fp32 MIN / MAX ...) keeps the expand / sort / compress form of mxm.hip, which folds in the reference's order.
+//
+// Row classes (by the row's product count P_i = sum over k of nnz(B[k,:])):
+//   light  P_i <= kLight : compacted into a CSR of their own and handed to the ESC form (a global sort of few products is cheap; a workgroup that
+//                          zeroes and scans an LDS block per row is not)
+//   heavy  the rest      : one workgroup per row, rows taken largest first from a device counter.  Two passes over the same traversal:
+//                          SYMBOLIC (a bitmap of the touched columns -> the row's entry count -> Rp), then NUMERIC (the LDS accumulator block,
+//                          ds_add / ds_min / ds_or ..., entries emitted in ascending column order straight into the result arrays).
+//   dense  (fp32 MULT / PLUS only) where the leading h x h corners of A and B are dense tiles, their product runs on the matrix cores
+//                          (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains) and is pre-loaded into the accumulators of the rows it belongs to;
+//                          the sparse traversal then skips those products (see "dense corner" below).
+//
+// The traversal of one (row i, column block [c0, c1)): for chunks of 1024 entries (i, k) of A's row — a thread per k finds the part of B[k,:]
+// inside the block (B's rows are column-sorted: a cursor per k kept in scratch memory advances from block to block, one binary search for the
+// block's end), a workgroup scan turns the part lengths into product offsets, and the products are dealt evenly over the threads (a binary
+// search of the offsets in LDS finds a product's k) — a hub's 100 K-entry row and a 3-entry row keep every lane busy alike.
+#include "block_utils.hpp"
+#include "common.hpp"
+#include "mxv_cob.hpp"
+#include "ops.hpp"
+
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+#include <vector>
+
+extern "C" int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, const uint32_t* d_Bp,
+                           const uint32_t* d_Bj, const void* d_Bx, uint32_t* d_Rp, uint32_t** d_Rj, void** d_Rx, uint32_t* h_nnz, uint64_t* h_products, int op_mult,
+                           int op_add, uint32_t init_bits, uint64_t block_products, void* stream);
+extern "C" int splahip_free(void* d_ptr);
+
+namespace splahip {
+
+    thread_local bool tl_mxm_force_esc = false;// set around the light rows' call into the ESC form
+    thread_local uint32_t tl_last_dense_h = 0, tl_last_heavy = 0, tl_last_light_nnz = 0, tl_last_ranked = 0;// what the last mxm of this thread did (splahip_mxm_last_info)
+
+    namespace {
+
+        using u64 = unsigned long long;
+        constexpr unsigned kTpb   = 1024;
+        const u64 kLight = [] {// rows with at most this many products go to the ESC form
+            const char* e = std::getenv("SPLAHIP_MXM_LIGHT");
+            return e && *e ? (u64) std::strtoull(e, nullptr, 10) : 4096ull;
+        }();
+
+        struct SpaArgs {
+            const uint32_t *Ap, *Aj, *Ax, *Bp, *Bj, *Bx;
+            // work items, largest first: a heavy row, or — for a row of millions of products — one range of its column blocks (the blocks of a row are
+            // independent: a hub's row is walked by many workgroups at once)
+            const uint32_t* item_row;
+            const uint32_t* item_c0;
+            const uint32_t* item_c1;
+            const uint32_t* item_out;// NUMERIC in: first result entry of the item
+            uint32_t        n_heavy; // items
+            uint32_t        b_cols;
+            uint32_t        block;  // columns per LDS block
+            // boundaries of every row of B at the numeric blocks' edges, found once per call: bblk[k * (nb + 1) + j] = first entry of B[k,:] whose column is
+            // >= j * bunit (j = nb: the row's end).  With it a (row, block) step needs no search and no cursor.  nullptr: search + cursors
+            const uint32_t* bblk;
+            uint32_t        bunit;  // columns per numeric block
+            uint32_t        nb;     // numeric blocks
+            uint32_t*       cursor; // gridDim.x x max_deg words (only read / written when the row needs more than one block)
+            uint32_t        max_deg;
+            uint32_t*       counts; // SYMBOLIC out: entries of item q
+            uint32_t*       Rj;
+            uint32_t*       Rx;
+            uint32_t*       dropped;// NUMERIC out: entries whose value equals init
+            // dense corner (fp32 MULT / PLUS): rows, inner indices and columns below `dense_h` meet in dense tiles whose product is in dense_c (row-major
+            // h x h) with dense_n = number of products per cell; 0 = no dense corner
+            uint32_t     dense_h;
+            const float* dense_c;
+            const float* dense_n;
+        };
+
+        __device__ __forceinline__ uint32_t lower_bound_dev(const uint32_t* __restrict__ a, uint32_t lo, uint32_t hi, uint32_t x) {// first index in [lo, hi) with a[index] >= x
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (a[mid] < x) lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            return lo;
+        }
+
+        // LDS: [accumulator block: `block` slice words (NUMERIC)] [touched bitmap: block / 32 words] [offsets 1025] [part starts 1024] [k 1024] [a values 1024] [scan scratch]
+        template<typename T, class Mult, int ACC, bool NUMERIC>
+        __global__ __launch_bounds__(kTpb) void mxm_spa_kernel(SpaArgs a, Mult mult, DynBin add, T init) {
+            using word = typename CobSlice<T, ACC>::word;
+            extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+            word*     s_acc  = reinterpret_cast<word*>(s_raw);
+            uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_raw + (NUMERIC ? (size_t) a.block * sizeof(word) : 0));
+            uint32_t* s_pref = s_bits + a.block / 32;
+            uint32_t* s_seg  = s_pref + kTpb + 1;
+            uint32_t* s_kk   = s_seg + kTpb;
+            uint32_t* s_av   = s_kk + kTpb;
+            uint32_t* s_tmp  = s_av + kTpb;// kTpb / 64 + 2 words
+            const uint32_t      tid = threadIdx.x;
+            uint32_t*           cur = a.cursor + (size_t) blockIdx.x * a.max_deg;
+            uint32_t            n_dropped = 0;
+#ifdef SPLAHIP_SPA_WATCHDOG
+            const long long wd_t0 = wall_clock64();
+#define SPA_WD(code, va, vb)                                                                                                           \
+    if (wall_clock64() - wd_t0 > 200000000ll) {                                                                                       \
+        if ((threadIdx.x & 63) == 0) printf("[spa watchdog] block %u wave %u loop %d: %u %u\n", blockIdx.x, threadIdx.x / 64, code, (unsigned) (va), (unsigned) (vb)); \
+        __builtin_trap();                                                                                                            \
+    }
+#else
+#define SPA_WD(code, va, vb)
+#endif
+            // the accumulator block and the touched bitmap start clean and are left clean by every emit pass (it resets what it reads): a block in
+            // which the row holds no product costs a scan of its part lengths and nothing else
+            {
+                for (uint32_t w = tid; w < a.block / 32; w += kTpb) s_bits[w] = 0;
+                if constexpr (NUMERIC) {
+                    const word id = [] {
+                        if constexpr (sizeof(word) == 8) return -0.0;
+                        else
+                            return cob_identity<T, ACC>();
+                    }();
+                    for (uint32_t j = tid; j < a.block; j += kTpb) s_acc[j] = id;
+                }
+                __syncthreads();
+            }
+            // rows are sorted by descending product count: dealing them round-robin gives every workgroup a similar share, largest first
+            for (uint32_t q = blockIdx.x; q < a.n_heavy; q += gridDim.x) {
+                SPA_WD(1, q, a.n_heavy)
+                const uint32_t i = a.item_row[q], cb = a.item_c0[q], ce = a.item_c1[q], a0 = a.Ap[i], deg = a.Ap[i + 1] - a0;
+                uint32_t       run = 0;// entries of the item emitted so far (the same in every thread)
+                for (uint32_t c0 = cb; c0 < ce; c0 += a.block) {
+                    SPA_WD(2, c0, a.block)
+                    const uint32_t c1 = min(ce, c0 + a.block), width = c1 - c0, words = (width + 31) / 32;
+                    const bool     last = c1 == ce, to_end = c1 >= a.b_cols;
+                    const bool dense_rows = a.dense_h && i < a.dense_h && c0 < a.dense_h;// this row meets the dense corner inside this block
+                    uint32_t   block_products = dense_rows ? 1u : 0u;// (uniform) anything to emit from this block?
+                    if (dense_rows) {// pre-load what the matrix cores computed for the cells (i, j < h): value and presence
+                        for (uint32_t j = c0 + tid; j < min(c1, a.dense_h); j += kTpb) {
+                            if (a.dense_n[(size_t) i * a.dense_h + j] > 0.5f) {
+                                (void) __hip_atomic_fetch_or(s_bits + ((j - c0) >> 5), 1u << ((j - c0) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if constexpr (NUMERIC && sizeof(word) == 8) s_acc[j - c0] = (double) a.dense_c[(size_t) i * a.dense_h + j];
+                            }
+                        }
+                        __syncthreads();
+                    }
+                    for (uint32_t kc = 0; kc < deg; kc += kTpb) {
+                        SPA_WD(3, kc, deg)
+                        const uint32_t nk  = min(kTpb, deg - kc);
+                        uint32_t       len = 0;
+                        if (tid < nk) {
+                            const uint32_t k  = a.Aj[a0 + kc + tid];
+                            const uint32_t b1 = a.Bp[k + 1];
+                            uint32_t       b, e;
+                            if (a.bblk) {// (c0 and c1 are multiples of the numeric block width, or the last column)
+                                const uint32_t* t = a.bblk + (size_t) k * (a.nb + 1);
+                                b                 = t[c0 / a.bunit];
+                                e                 = to_end ? b1 : t[c1 / a.bunit];
+                            } else {
+                                b = c0 != cb ? cur[kc + tid] : (cb == 0 ? a.Bp[k] : lower_bound_dev(a.Bj, a.Bp[k], b1, cb));
+                                e = to_end ? b1 : lower_bound_dev(a.Bj, b, b1, c1);
+                            }
+                            if (dense_rows && k < a.dense_h && c0 == 0) b = lower_bound_dev(a.Bj, b, min(e, b1), a.dense_h);// products (i, k, j) below h live in the dense tile: skip them
+                            len              = e - b;
+                            s_seg[tid]       = b;
+                            s_kk[tid]        = k;
+                            if (!last && !a.bblk) cur[kc + tid] = e;
+                            if constexpr (NUMERIC) s_av[tid] = a.Ax[a0 + kc + tid];
+                        }
+                        uint32_t       total;
+                        const uint32_t ex = block_exclusive_sum<kTpb>(len, s_tmp, total);
+                        s_pref[tid]       = ex;// threads beyond nk hold `total`: a sentinel for the search
+                        block_products |= total;
+                        __syncthreads();
+                        for (uint32_t p = tid; p < total; p += kTpb) {
+                            SPA_WD(4, p, total)
+                            uint32_t lo = 0, hi = nk;// largest t with s_pref[t] <= p
+                            while (hi - lo > 1) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                if (s_pref[mid] <= p) lo = mid;
+                                else
+                                    hi = mid;
+                            }
+                            const uint32_t idx = s_seg[lo] + (p - s_pref[lo]);
+                            const uint32_t col = a.Bj[idx] - c0;
+                            (void) __hip_atomic_fetch_or(s_bits + (col >> 5), 1u << (col & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if constexpr (NUMERIC) {
+                                const T prod = mult(from_bits<T>(s_av[lo]), from_bits<T>(a.Bx[idx]));
+                                if constexpr (sizeof(word) == 8) (void) __hip_atomic_fetch_add(s_acc + col, (double) prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                else
+                                    cob_accumulate<T, ACC>(s_acc + col, prod);
+                            }
+                        }
+                        __syncthreads();
+                    }
+                    // the block's entries, ascending: a popcount scan over the bitmap words (which are cleared on the way, like the accumulators)
+                    if (block_products)
+                    for (uint32_t w0 = 0; w0 < words; w0 += kTpb) {
+                        SPA_WD(5, w0, words)
+                        const uint32_t w    = w0 + tid;
+                        const uint32_t bits = w < words ? s_bits[w] : 0u;
+                        if (bits) s_bits[w] = 0u;
+                        uint32_t       total;
+                        const uint32_t ex = block_exclusive_sum<kTpb>(__popc(bits), s_tmp, total);
+                        if constexpr (NUMERIC) {
+                            uint32_t o = a.item_out[q] + run + ex;
+                            for (uint32_t b = bits; b; b &= b - 1) {
+                                const uint32_t j = w * 32 + (uint32_t) __ffs((int) b) - 1;
+                                uint32_t       accw;
+                                if constexpr (sizeof(word) == 8) {
+                                    accw     = to_bits((float) s_acc[j]);
+                                    s_acc[j] = -0.0;
+                                } else {
+                                    accw     = s_acc[j];
+                                    s_acc[j] = cob_identity<T, ACC>();
+                                }
+                                const T val = cob_finish<T, ACC>(accw, init, add);
+                                a.Rj[o]     = c0 + j;
+                                a.Rx[o]     = to_bits(val);
+                                if (!(val != init)) ++n_dropped;// the reference drops r == init (cpu_mxm.hpp:110): compacted afterwards when any
+                                ++o;
+                            }
+                        }
+                        run += total;
+                    }
+                    __syncthreads();
+                }
+                if constexpr (!NUMERIC) {
+                    if (tid == 0) a.counts[q] = run;
+                }
+            }
+            if constexpr (NUMERIC) {
+                if (n_dropped) atomicAdd(a.dropped, n_dropped);
+            }
+        }
+
+        // NUMERIC, "ranked" form — for an item whose entry count (known from the symbolic pass) fits one accumulator block: no column blocks at all.  Per
+        // super-block of `wr` columns: pass A sets the touched bitmap (as the symbolic pass did), a popcount scan over its words gives every touched column its
+        // RANK among the item's entries, pass B walks the products again and adds each one into acc[rank(column)], and the entries leave in rank order =
+        // ascending column order.  A row of a few thousand entries spread over 260 K columns costs two walks over its products instead of 43 block steps.
+        // LDS: [acc: cap slice words] [bitmap: wr / 32] [word ranks: wr / 32] [offsets 1025] [part starts 1024] [a values 1024] [scan scratch]
+        template<typename T, class Mult, int ACC>
+        __global__ __launch_bounds__(kTpb) void mxm_spa_ranked_kernel(SpaArgs a, uint32_t cap, uint32_t wr, Mult mult, DynBin add, T init) {
+            using word = typename CobSlice<T, ACC>::word;
+            extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+            word*          s_acc  = reinterpret_cast<word*>(s_raw);
+            uint32_t*      s_bits = reinterpret_cast<uint32_t*>(s_raw + (size_t) cap * sizeof(word));
+            uint32_t*      s_rank = s_bits + wr / 32;
+            uint32_t*      s_pref = s_rank + wr / 32;
+            uint32_t*      s_seg  = s_pref + kTpb + 1;
+            uint32_t*      s_av   = s_seg + kTpb;
+            uint32_t*      s_tmp  = s_av + kTpb;
+            const uint32_t tid    = threadIdx.x;
+            uint32_t       n_dropped = 0;
+            const word     id = [] {
+                if constexpr (sizeof(word) == 8) return -0.0;
+                else
+                    return cob_identity<T, ACC>();
+            }();
+            for (uint32_t q = blockIdx.x; q < a.n_heavy; q += gridDim.x) {
+                const uint32_t i = a.item_row[q], cb = a.item_c0[q], ce = a.item_c1[q], a0 = a.Ap[i], deg = a.Ap[i + 1] - a0;
+                uint32_t       run = 0;
+                for (uint32_t s0 = cb; s0 < ce; s0 += wr) {
+                    const uint32_t s1 = min(ce, s0 + wr), words = (s1 - s0 + 31) / 32;
+                    const bool     to_end = s1 >= a.b_cols;
+                    // one walk over the products of (row i, columns [s0, s1)): fn(value word of a_ik, index into B's arrays, column - s0)
+                    auto walk = [&](auto fn) {
+                        for (uint32_t kc = 0; kc < deg; kc += kTpb) {
+                            const uint32_t nk  = min(kTpb, deg - kc);
+                            uint32_t       len = 0;
+                            if (tid < nk) {
+                                const uint32_t  k = a.Aj[a0 + kc + tid];
+                                const uint32_t* t = a.bblk + (size_t) k * (a.nb + 1);
+                                const uint32_t  b = t[s0 / a.bunit], e = to_end ? a.Bp[k + 1] : t[s1 / a.bunit];
+                                len               = e - b;
+                                s_seg[tid]        = b;
+                                s_av[tid]         = a.Ax[a0 + kc + tid];
+                            }
+                            uint32_t       total;
+                            const uint32_t ex = block_exclusive_sum<kTpb>(len, s_tmp, total);
+                            s_pref[tid]       = ex;
+                            __syncthreads();
+                            for (uint32_t p = tid; p < total; p += kTpb) {
+                                uint32_t lo = 0, hi = nk;
+                                while (hi - lo > 1) {
+                                    const uint32_t mid = (lo + hi) >> 1;
+                                    if (s_pref[mid] <= p) lo = mid;
+                                    else
+                                        hi = mid;
+                                }
+                                const uint32_t idx = s_seg[lo] + (p - s_pref[lo]);
+                                fn(s_av[lo], idx, a.Bj[idx] - s0);
+                            }
+                            __syncthreads();
+                        }
+                    };
+                    for (uint32_t w = tid; w < words; w += kTpb) s_bits[w] = 0;
+                    __syncthreads();
+                    walk([&](uint32_t, uint32_t, uint32_t col) { (void) __hip_atomic_fetch_or(s_bits + (col >> 5), 1u << (col & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); });
+                    // ranks: exclusive popcount prefix over the bitmap words
+                    uint32_t cnt = 0;
+                    for (uint32_t w0 = 0; w0 < words; w0 += kTpb) {
+                        const uint32_t w = w0 + tid;
+                        uint32_t       total;
+                        const uint32_t ex = block_exclusive_sum<kTpb>(w < words ? __popc(s_bits[w]) : 0, s_tmp, total);
+                        if (w < words) s_rank[w] = cnt + ex;
+                        cnt += total;
+                    }
+                    for (uint32_t j = tid; j < cnt; j += kTpb) s_acc[j] = id;
+                    __syncthreads();
+                    walk([&](uint32_t av, uint32_t idx, uint32_t col) {
+                        const uint32_t pos  = s_rank[col >> 5] + __popc(s_bits[col >> 5] & ((1u << (col & 31)) - 1u));
+                        const T        prod = mult(from_bits<T>(av), from_bits<T>(a.Bx[idx]));
+                        if constexpr (sizeof(word) == 8) (void) __hip_atomic_fetch_add(s_acc + pos, (double) prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else
+                            cob_accumulate<T, ACC>(s_acc + pos, prod);
+                    });
+                    // entries in rank order = ascending columns
+                    const uint32_t out = a.item_out[q] + run;
+                    for (uint32_t w = tid; w < words; w += kTpb) {
+                        uint32_t p = s_rank[w];
+                        for (uint32_t b = s_bits[w]; b; b &= b - 1, ++p) {
+                            uint32_t accw;
+                            if constexpr (sizeof(word) == 8) accw = to_bits((float) s_acc[p]);
+                            else
+                                accw = s_acc[p];
+                            const T val   = cob_finish<T, ACC>(accw, init, add);
+                            a.Rj[out + p] = s0 + w * 32 + (uint32_t) __ffs((int) b) - 1;
+                            a.Rx[out + p] = to_bits(val);
+                            if (!(val != init)) ++n_dropped;
+                        }
+                    }
+                    run += cnt;
+                    __syncthreads();
+                }
+            }
+            if (n_dropped) atomicAdd(a.dropped, n_dropped);
+        }
+
+        // bblk[k][j]: a thread per (row of B, block edge)
+        __global__ __launch_bounds__(256) void bblk_kernel(uint32_t b_rows, uint32_t nb, uint32_t bunit, const uint32_t* __restrict__ Bp, const uint32_t* __restrict__ Bj,
+                                                           uint32_t* __restrict__ bblk) {
+            const size_t t = (size_t) blockIdx.x * 256 + threadIdx.x;
+            if (t >= (size_t) b_rows * (nb + 1)) return;
+            const uint32_t k = (uint32_t) (t / (nb + 1)), j = (uint32_t) (t % (nb + 1));
+            bblk[t]          = j == nb ? Bp[k + 1] : lower_bound_dev(Bj, Bp[k], Bp[k + 1], j * bunit);
+        }
+
+        // light rows -> a CSR of their own (heavy rows empty): a thread per row copies its few entries
+        __global__ __launch_bounds__(256) void light_len_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const u64* __restrict__ P, uint32_t* __restrict__ len, u64 kLight) {
+            const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+            if (i <= n_rows) len[i] = (i < n_rows && P[i] <= kLight) ? Ap[i + 1] - Ap[i] : 0u;
+        }
+        __global__ __launch_bounds__(256) void light_copy_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ Aj, const uint32_t* __restrict__ Ax,
+                                                                 const u64* __restrict__ P, const uint32_t* __restrict__ Lp, uint32_t* __restrict__ Lj, uint32_t* __restrict__ Lx, u64 kLight) {
+            const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+            if (i >= n_rows || P[i] > kLight) return;
+            uint32_t o = Lp[i];
+            for (uint32_t e = Ap[i]; e < Ap[i + 1]; ++e, ++o) Lj[o] = Aj[e], Lx[o] = Ax[e];
+        }
+        // per-row entry counts of the result: light rows from the ESC result, heavy rows from the symbolic pass
+        __global__ __launch_bounds__(256) void count_light_kernel(uint32_t n_rows, const uint32_t* __restrict__ Lrp, uint32_t* __restrict__ cnt) {
+            const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+            if (i <= n_rows) cnt[i] = i < n_rows ? Lrp[i + 1] - Lrp[i] : 0u;
+        }
+        __global__ __launch_bounds__(256) void count_heavy_kernel(uint32_t n_heavy, const uint32_t* __restrict__ rows, const uint32_t* __restrict__ counts, uint32_t* __restrict__ cnt) {
+            const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+            if (q < n_heavy) cnt[rows[q]] = counts[q];
+        }
+        __global__ __launch_bounds__(256) void place_light_kernel(uint32_t n_rows, const uint32_t* __restrict__ Lrp, const uint32_t* __restrict__ Lrj, const uint32_t* __restrict__ Lrx,
+                                                                  const uint32_t* __restrict__ Rp, uint32_t* __restrict__ Rj, uint32_t* __restrict__ Rx) {
+            const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+            if (i >= n_rows) return;
+            uint32_t o = Rp[i];
+            for (uint32_t e = Lrp[i]; e < Lrp[i + 1]; ++e, ++o) Rj[o] = Lrj[e], Rx[o] = Lrx[e];
+        }
+        // compaction of the entries equal to init (rare: a numeric cancellation)
+        template<typename T>
+        __global__ __launch_bounds__(256) void keep_flag_kernel(uint32_t nnz, const uint32_t* __restrict__ Rx, T init, uint32_t* __restrict__ keep) {
+            const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+            if (k <= nnz) keep[k] = (k < nnz && from_bits<T>(Rx[k]) != init) ? 1u : 0u;
+        }
+        __global__ __launch_bounds__(256) void keep_scatter_kernel(uint32_t nnz, const uint32_t* __restrict__ keep, const uint32_t* __restrict__ rank, const uint32_t* __restrict__ Rj,
+                                                                   const uint32_t* __restrict__ Rx, uint32_t* __restrict__ Oj, uint32_t* __restrict__ Ox) {
+            const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+            if (k < nnz && keep[k]) Oj[rank[k]] = Rj[k], Ox[rank[k]] = Rx[k];
+        }
+        __global__ __launch_bounds__(256) void keep_rowptr_kernel(uint32_t n_rows, const uint32_t* __restrict__ rank, uint32_t* __restrict__ Rp) {
+            const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+            if (i <= n_rows) Rp[i] = rank[Rp[i]];
+        }
+
+        // ---- dense corner on the matrix cores --------------------------------------------------------------------------------------------------
+        // densify M[0:h, 0:h] (row-major, zeros where no entry) and its 0 / 1 structure; `bad` is raised by a value that is not finite (0 x inf in a
+        // dense tile would invent a NaN the sparse product does not have)
+        __global__ __launch_bounds__(256) void densify_kernel(uint32_t h, const uint32_t* __restrict__ Mp, const uint32_t* __restrict__ Mj, const float* __restrict__ Mx,
+                                                              float* __restrict__ D, float* __restrict__ S, uint32_t* __restrict__ bad, uint32_t* __restrict__ count) {
+            const uint32_t i = blockIdx.x;// one workgroup per row < h
+            uint32_t       c = 0;
+            for (uint32_t e = Mp[i] + threadIdx.x; e < Mp[i + 1]; e += 256) {
+                const uint32_t j = Mj[e];
+                if (j >= h) break;// columns ascend; (threads further right see larger columns: they stop too)
+                const float x = Mx[e];
+                D[(size_t) i * h + j] = x;
+                S[(size_t) i * h + j] = 1.0f;
+                ++c;
+                if (!(fabsf(x) <= 3.0e38f)) atomicOr(bad, 1u);
+            }
+            if (c) atomicAdd(count, c);
+        }
+        // C[h x h] = A[h x h] x B[h x h], fp32 on v_mfma_f32_32x32x2_f32: one wavefront per 32 x 32 tile of C, k in steps of 2.  Operand layout of the
+        // instruction (cdna_hip_programming.md 3): lane l supplies A[row = l % 32][k = l / 32] and B[k = l / 32][col = l % 32]; the 16 accumulator
+        // registers of lane l hold C[row = 8 * (r / 4) + (l / 32) * 4 + r % 4 ... ] — written back through the same formula below.
+        __global__ __launch_bounds__(64) void dense_gemm_mfma_kernel(uint32_t h, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C) {
+            typedef float f16v __attribute__((ext_vector_type(16)));
+            const uint32_t ti = blockIdx.y * 32, tj = blockIdx.x * 32, lane = threadIdx.x;
+            const uint32_t m = lane & 31, kh = lane >> 5;
+            f16v           acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t k = 0; k < h; k += 2) {
+                const float av = A[(size_t) (ti + m) * h + k + kh];
+                const float bv = B[(size_t) (k + kh) * h + tj + m];
+                acc            = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t row = 8 * (r / 4) + kh * 4 + (r % 4);
+                C[(size_t) (ti + row) * h + tj + m] = acc[r];
+            }
+        }
+
+        uint32_t env_u32(const char* name, uint32_t dflt) {
+            const char* e = std::getenv(name);
+            return e && *e ? (uint32_t) std::strtoul(e, nullptr, 10) : dflt;
+        }
+
+        struct Scratch {
+            std::vector<void*> ptrs;
+            ~Scratch() {
+                for (void* p : ptrs)
+                    if (p) (void) hipFree(p);
+            }
+            template<typename U>
+            hipError_t alloc(U** out, size_t count) {
+                void*      p = nullptr;
+                hipError_t e = device_malloc(&p, sizeof(U) * (count ? count : 1));
+                if (e == hipSuccess) ptrs.push_back(p);
+                *out = static_cast<U*>(p);
+                return e;
+            }
+        };
+
+        hipError_t scan_u32(uint32_t* in, uint32_t* out, size_t n, Scratch& tmp, hipStream_t s) {
+            size_t     bytes = 0;
+            hipError_t e     = rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), s);
+            void*      t     = nullptr;
+            if (e == hipSuccess) e = tmp.alloc(reinterpret_cast<unsigned char**>(&t), bytes ? bytes : 4);
+            if (e == hipSuccess) e = rocprim::exclusive_scan(t, bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), s);
+            return e;
+        }
+
+        // SPLAHIP_MXM_TRACE=1: the phases of the row-class form on stderr, each closed by a device synchronisation (diagnostic)
+        void spa_trace(const char* what, hipStream_t s) {
+            static const bool on = std::getenv("SPLAHIP_MXM_TRACE") != nullptr;
+            if (!on) return;
+            static thread_local auto t0 = std::chrono::steady_clock::now();
+            const hipError_t         e  = hipStreamSynchronize(s);
+            const auto               t1 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[mxm-spa] %-22s %9.2f ms  (%s)\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count(), hipGetErrorString(e));
+            t0 = t1;
+        }
+
+        template<typename T, class Mult, int ACC>
+        int spa_run(uint32_t a_rows, uint32_t b_cols, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const uint32_t* Bp, const uint32_t* Bj, const void* Bx, uint32_t* Rp,
+                    uint32_t** Rj, void** Rx, uint32_t* h_nnz, const std::vector<u64>& hP, const u64* dP, const std::vector<uint32_t>& hAp, int op_mult, int op_add,
+                    uint32_t init_bits, uint32_t b_rows_hint, hipStream_t s) {
+            using word      = typename CobSlice<T, ACC>::word;
+            constexpr int t = TypeId<T>::value;
+            Scratch       tmp;
+            hipError_t    e = hipSuccess;
+            spa_trace("start", s);
+            // heavy rows, largest first
+            std::vector<uint32_t> heavy;
+            bool                  any_light = false;
+            uint32_t              max_deg   = 1;
+            for (uint32_t i = 0; i < a_rows; ++i) {
+                if (hP[i] > kLight) {
+                    heavy.push_back(i);
+                    max_deg = std::max(max_deg, hAp[i + 1] - hAp[i]);
+                } else if (hP[i] > 0)
+                    any_light = true;
+            }
+            std::stable_sort(heavy.begin(), heavy.end(), [&](uint32_t x, uint32_t y) { return hP[x] > hP[y]; });
+            const uint32_t n_heavy = (uint32_t) heavy.size();
+
+            // ---- light rows through the ESC form -------------------------------------------------------------------------------------------------
+            uint32_t *Lrp = nullptr, *Lrj = nullptr, *Lrx = nullptr, l_nnz = 0;
+            if (any_light) {
+                uint32_t *len = nullptr, *Lp = nullptr, *Lj = nullptr, *Lx = nullptr;
+                e = tmp.alloc(&len, (size_t) a_rows + 1);
+                if (e == hipSuccess) e = tmp.alloc(&Lp, (size_t) a_rows + 1);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(light_len_kernel, dim3((a_rows + 256) / 256), dim3(256), 0, s, a_rows, Ap, dP, len, kLight);
+                    e = scan_u32(len, Lp, (size_t) a_rows + 1, tmp, s);
+                }
+                uint32_t l_entries = 0;
+                if (e == hipSuccess) e = hipMemcpyAsync(&l_entries, Lp + a_rows, 4, hipMemcpyDeviceToHost, s);
+                if (e == hipSuccess) e = hipStreamSynchronize(s);
+                if (e == hipSuccess) e = tmp.alloc(&Lj, l_entries);
+                if (e == hipSuccess) e = tmp.alloc(&Lx, l_entries);
+                if (e == hipSuccess) e = tmp.alloc(&Lrp, (size_t) a_rows + 1);
+                if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm (row classes): %s", hipGetErrorString(e));
+                hipLaunchKernelGGL(light_copy_kernel, dim3((a_rows + 255) / 256), dim3(256), 0, s, a_rows, Ap, Aj, static_cast<const uint32_t*>(Ax), dP, Lp, Lj, Lx, kLight);
+                tl_mxm_force_esc = true;
+                void*     lrx    = nullptr;
+                const int st     = splahip_mxm(t, a_rows, b_cols, Lp, Lj, Lx, Bp, Bj, Bx, Lrp, &Lrj, &lrx, &l_nnz, nullptr, op_mult, op_add, init_bits, 0, s);
+                tl_mxm_force_esc = false;
+                if (st != SPLAHIP_OK) return st;
+                Lrx = static_cast<uint32_t*>(lrx);
+            }
+            spa_trace("light rows (ESC)", s);
+            struct FreeLight {
+                uint32_t *&j, *&x;
+                ~FreeLight() {
+                    if (j) (void) splahip_free(j);
+                    if (x) (void) splahip_free(x);
+                }
+            } free_light{Lrj, Lrx};
+
+            // ---- dense corner (fp32 MULT / PLUS): the leading h x h tiles of A and B, when both are at least half full and finite ---------------------
+            uint32_t dense_h = 0;
+            float *  dA = nullptr, *dB = nullptr, *dC = nullptr, *dN = nullptr, *sA = nullptr, *sB = nullptr;
+            if constexpr (std::is_same<T, float>::value && ACC == COB_ADD) {
+                if (op_mult == SPLAHIP_MULT && env_u32("SPLAHIP_MXM_DENSE", 1) != 0) {
+                    uint32_t h = std::min({a_rows, b_cols, b_rows_hint, env_u32("SPLAHIP_MXM_DENSE_H", 1024u)}) & ~31u;
+                    while (h >= 64 && dense_h == 0) {
+                        uint32_t* stat = nullptr;// bad, count A, count B
+                        e              = tmp.alloc(&stat, 4);
+                        for (float** q : {&dA, &dB, &dC, &dN, &sA, &sB})
+                            if (e == hipSuccess) e = tmp.alloc(q, (size_t) h * h);
+                        if (e != hipSuccess) break;
+                        (void) hipMemsetAsync(stat, 0, 16, s);
+                        for (float* q : {dA, dB, sA, sB}) (void) hipMemsetAsync(q, 0, sizeof(float) * (size_t) h * h, s);
+                        hipLaunchKernelGGL(densify_kernel, dim3(h), dim3(256), 0, s, h, Ap, Aj, static_cast<const float*>(Ax), dA, sA, stat, stat + 1);
+                        hipLaunchKernelGGL(densify_kernel, dim3(h), dim3(256), 0, s, h, Bp, Bj, static_cast<const float*>(Bx), dB, sB, stat, stat + 2);
+                        uint32_t hs[3] = {0, 0, 0};
+                        e              = hipMemcpyAsync(hs, stat, 12, hipMemcpyDeviceToHost, s);
+                        if (e == hipSuccess) e = hipStreamSynchronize(s);
+                        if (e != hipSuccess) break;
+                        const double full = (double) h * h;
+                        if (!hs[0] && hs[1] >= 0.5 * full && hs[2] >= 0.5 * full) {
+                            hipLaunchKernelGGL(dense_gemm_mfma_kernel, dim3(h / 32, h / 32), dim3(64), 0, s, h, dA, dB, dC);
+                            hipLaunchKernelGGL(dense_gemm_mfma_kernel, dim3(h / 32, h / 32), dim3(64), 0, s, h, sA, sB, dN);
+                            dense_h = h;
+                        } else
+                            h = (h / 2) & ~31u;// a smaller corner may still be a dense tile
+                    }
+                    if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm (dense corner): %s", hipGetErrorString(e));
+                }
+            }
+
+            // ---- heavy rows: work items, symbolic pass, row pointers + item offsets, numeric pass -----------------------------------------------
+            int dev = 0, cus = 256;
+            (void) hipGetDevice(&dev);
+            (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            const uint32_t extra = sizeof(uint32_t) * (4 * kTpb + 1 + kTpb / 64 + 4);
+            // numeric: accumulator block + bitmap; symbolic: bitmap only (a much wider block)
+            const uint32_t blk_num = sizeof(word) == 8 ? 6144u : 12288u;// 48 KB of accumulators: two workgroups per CU
+            const uint32_t blk_sym = std::max(blk_num, std::min<uint32_t>((1u << 20) - 32768u, b_cols + blk_num - 1) / blk_num * blk_num);// a multiple of blk_num; bitmap + chunk arrays < 160 KB
+            const uint32_t lds_num = blk_num * (uint32_t) sizeof(word) + blk_num / 8 + extra, lds_sym = blk_sym / 8 + extra;
+            // items: a heavy row; a row of more than kSplit products is cut into ranges of whole numeric blocks (its column blocks are independent), so that
+            // the few hub rows that carry most of the products are walked by many workgroups at once
+            const u64      kSplit = env_u32("SPLAHIP_MXM_SPLIT", 1u << 19);
+            const uint32_t nb_num = (b_cols + blk_num - 1) / blk_num;
+            struct Item {
+                uint32_t row, c0, c1;
+                u64      est;
+            };
+            std::vector<Item> items;
+            for (uint32_t i : heavy) {
+                const uint32_t pieces = (uint32_t) std::min<u64>(nb_num, std::max<u64>(1, (hP[i] + kSplit - 1) / kSplit));
+                for (uint32_t pc = 0; pc < pieces; ++pc) {
+                    const uint32_t b0 = (uint32_t) ((u64) nb_num * pc / pieces), b1 = (uint32_t) ((u64) nb_num * (pc + 1) / pieces);
+                    if (b1 > b0) items.push_back({i, b0 * blk_num, std::min(b_cols, b1 * blk_num), hP[i] / pieces});
+                }
+            }
+            std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.est > y.est; });
+            const uint32_t        n_items = (uint32_t) items.size();
+            std::vector<uint32_t> h_item(3 * (size_t) n_items);
+            for (uint32_t q = 0; q < n_items; ++q) h_item[q] = items[q].row, h_item[n_items + q] = items[q].c0, h_item[2 * (size_t) n_items + q] = items[q].c1;
+            const uint32_t grid_sym = std::max(1u, std::min(n_items, (uint32_t) cus * std::max(1u, std::min(2u, (160u * 1024u - 256u) / lds_sym))));
+            const uint32_t grid_num = std::max(1u, std::min(n_items, (uint32_t) cus * std::max(1u, std::min(2u, (160u * 1024u - 256u) / lds_num))));
+            const uint32_t grid     = std::max(grid_sym, grid_num);
+            uint32_t *d_item = nullptr, *d_out = nullptr, *d_counts = nullptr, *d_cursor = nullptr, *d_dropped = nullptr;
+            e = tmp.alloc(&d_item, 3 * (size_t) n_items);
+            if (e == hipSuccess) e = tmp.alloc(&d_out, n_items);
+            if (e == hipSuccess) e = tmp.alloc(&d_counts, n_items);
+            if (e == hipSuccess) e = tmp.alloc(&d_cursor, (size_t) grid * max_deg);
+            if (e == hipSuccess) e = tmp.alloc(&d_dropped, 1);
+            if (e == hipSuccess && n_items) e = hipMemcpyAsync(d_item, h_item.data(), 4 * h_item.size(), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipMemsetAsync(d_dropped, 0, 4, s);
+            if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm (row classes): %s", hipGetErrorString(e));
+            // block boundaries of B's rows, once per call (up to 1 GiB; beyond that the kernels search and keep cursors)
+            uint32_t* d_bblk = nullptr;
+            if (nb_num > 1 && (u64) b_rows_hint * (nb_num + 1) * 4ull <= (1ull << 30)) {
+                e = tmp.alloc(&d_bblk, (size_t) b_rows_hint * (nb_num + 1));
+                if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm (row classes): %s", hipGetErrorString(e));
+                const size_t cells = (size_t) b_rows_hint * (nb_num + 1);
+                hipLaunchKernelGGL(bblk_kernel, dim3((unsigned) ((cells + 255) / 256)), dim3(256), 0, s, b_rows_hint, nb_num, blk_num, Bp, Bj, d_bblk);
+            }
+            SpaArgs a{Ap, Aj, static_cast<const uint32_t*>(Ax), Bp, Bj, static_cast<const uint32_t*>(Bx), d_item, d_item + n_items, d_item + 2 * (size_t) n_items, d_out, n_items, b_cols,
+                      blk_sym, d_bblk, blk_num, nb_num, d_cursor, max_deg, d_counts, nullptr, nullptr, d_dropped, dense_h, dC, dN};
+            const T init = from_bits<T>(init_bits);
+            if (n_items) {
+                static bool raised = false;
+                if (!raised) {
+                    SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxm_spa_kernel<T, Mult, ACC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                    SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxm_spa_kernel<T, Mult, ACC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                    raised = true;
+                }
+                hipLaunchKernelGGL((mxm_spa_kernel<T, Mult, ACC, false>), dim3(grid_sym), dim3(kTpb), lds_sym, s, a, Mult(op_mult), DynBin(op_add), init);
+                SPLAHIP_TRY(hipGetLastError());
+                spa_trace("symbolic pass", s);
+            }
+            // row pointers and item offsets on the host (a few hundred thousand counters): entries per row = the light rows' ESC result or the sum of the
+            // row's items; an item's entries start at Rp[row] + the counts of the row's items to its left
+            std::vector<uint32_t> h_counts(n_items), h_cnt((size_t) a_rows + 1, 0u), h_Rp((size_t) a_rows + 1), h_out(n_items);
+            if (n_items) SPLAHIP_TRY(hipMemcpyAsync(h_counts.data(), d_counts, 4 * (size_t) n_items, hipMemcpyDeviceToHost, s));
+            if (Lrp) SPLAHIP_TRY(hipMemcpyAsync(h_Rp.data(), Lrp, 4 * ((size_t) a_rows + 1), hipMemcpyDeviceToHost, s));
+            SPLAHIP_TRY(hipStreamSynchronize(s));
+            if (Lrp)
+                for (uint32_t i = 0; i < a_rows; ++i) h_cnt[i] = h_Rp[i + 1] - h_Rp[i];
+            u64 total = l_nnz;
+            for (uint32_t q = 0; q < n_items; ++q) total += h_counts[q];
+            if (total > 0xFFFFFFF0ull) return fail(SPLAHIP_NOT_IMPLEMENTED, "the product holds %llu entries: not representable with 32-bit row pointers", total);
+            std::vector<uint32_t> by_pos(n_items);
+            std::iota(by_pos.begin(), by_pos.end(), 0u);
+            std::sort(by_pos.begin(), by_pos.end(), [&](uint32_t x, uint32_t y) { return items[x].row != items[y].row ? items[x].row < items[y].row : items[x].c0 < items[y].c0; });
+            for (uint32_t q : by_pos) {
+                h_out[q] = h_cnt[items[q].row];// offset inside the row so far
+                h_cnt[items[q].row] += h_counts[q];
+            }
+            h_Rp[0] = 0;
+            for (uint32_t i = 0; i < a_rows; ++i) h_Rp[i + 1] = h_Rp[i] + h_cnt[i];
+            for (uint32_t q = 0; q < n_items; ++q) h_out[q] += h_Rp[items[q].row];
+            SPLAHIP_TRY(hipMemcpyAsync(Rp, h_Rp.data(), 4 * ((size_t) a_rows + 1), hipMemcpyHostToDevice, s));
+            if (n_items) SPLAHIP_TRY(hipMemcpyAsync(d_out, h_out.data(), 4 * (size_t) n_items, hipMemcpyHostToDevice, s));
+            spa_trace("row pointers", s);
+            uint32_t *oj = nullptr, *ox = nullptr;
+            e = handoff_alloc(reinterpret_cast<void**>(&oj), sizeof(uint32_t) * (size_t) total);
+            if (e == hipSuccess) e = handoff_alloc(reinterpret_cast<void**>(&ox), sizeof(uint32_t) * (size_t) total);
+            if (e != hipSuccess) {
+                if (oj) (void) handoff_release(oj);
+                return fail(SPLAHIP_ERROR, "mxm result allocation: %s", hipGetErrorString(e));
+            }
+            spa_trace("result allocation", s);
+            if (Lrp && l_nnz) hipLaunchKernelGGL(place_light_kernel, dim3((a_rows + 255) / 256), dim3(256), 0, s, a_rows, Lrp, Lrj, Lrx, Rp, oj, ox);
+            if (n_items) {
+                // items whose entries fit one accumulator block take the ranked form (two walks, no column blocks); hub rows, rows that meet the dense corner and
+                // everything when B's boundary table was too large keep the blocked form
+                const uint32_t wr  = std::max(1u, 245760u / blk_num) * blk_num;
+                const uint32_t cap = ((160u * 1024u - 256u - 2u * (wr / 8) - (uint32_t) sizeof(uint32_t) * (3 * kTpb + 1 + kTpb / 64 + 4)) / (uint32_t) sizeof(word)) & ~63u;// what is left of the LDS
+                std::vector<uint32_t> rk[4], bl[4];
+                for (uint32_t q = 0; q < n_items; ++q) {
+                    const bool ranked = d_bblk && h_counts[q] <= cap && !(dense_h && items[q].row < dense_h) && env_u32("SPLAHIP_MXM_RANKED", 1) != 0;
+                    auto&      dst    = ranked ? rk : bl;
+                    dst[0].push_back(items[q].row), dst[1].push_back(items[q].c0), dst[2].push_back(items[q].c1), dst[3].push_back(h_out[q]);
+                }
+                auto upload = [&](std::vector<uint32_t>* v, uint32_t** d) -> hipError_t {
+                    const size_t n = v[0].size();
+                    hipError_t   er = tmp.alloc(d, 4 * n);
+                    for (int f = 0; f < 4 && er == hipSuccess && n; ++f) er = hipMemcpyAsync(*d + f * n, v[f].data(), 4 * n, hipMemcpyHostToDevice, s);
+                    return er;
+                };
+                uint32_t *d_rk = nullptr, *d_bl = nullptr;
+                e = upload(rk, &d_rk);
+                if (e == hipSuccess) e = upload(bl, &d_bl);
+                if (e == hipSuccess) e = hipStreamSynchronize(s);// (the vectors are locals of this block)
+                if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm (row classes): %s", hipGetErrorString(e));
+                a.Rj = oj, a.Rx = ox;
+                if (const uint32_t n = (uint32_t) bl[0].size()) {
+                    a.block = blk_num, a.item_row = d_bl, a.item_c0 = d_bl + n, a.item_c1 = d_bl + 2 * (size_t) n, a.item_out = d_bl + 3 * (size_t) n, a.n_heavy = n;
+                    hipLaunchKernelGGL((mxm_spa_kernel<T, Mult, ACC, true>), dim3(std::min(n, grid_num)), dim3(kTpb), lds_num, s, a, Mult(op_mult), DynBin(op_add), init);
+                }
+                if (const uint32_t n = (uint32_t) rk[0].size()) {
+                    static bool raised_r = false;
+                    if (!raised_r) {
+                        SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxm_spa_ranked_kernel<T, Mult, ACC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                        raised_r = true;
+                    }
+                    const uint32_t lds_r = cap * (uint32_t) sizeof(word) + 2 * (wr / 8) + sizeof(uint32_t) * (3 * kTpb + 1 + kTpb / 64 + 4);
+                    a.item_row = d_rk, a.item_c0 = d_rk + n, a.item_c1 = d_rk + 2 * (size_t) n, a.item_out = d_rk + 3 * (size_t) n, a.n_heavy = n;
+                    hipLaunchKernelGGL((mxm_spa_ranked_kernel<T, Mult, ACC>), dim3(std::min(n, (uint32_t) cus)), dim3(kTpb), lds_r, s, a, cap, wr, Mult(op_mult), DynBin(op_add), init);
+                }
+                tl_last_ranked = (uint32_t) rk[0].size();
+            }
+            SPLAHIP_TRY(hipStreamSynchronize(s));// (h_Rp / h_out were read by the copies above)
+            spa_trace("numeric pass", s);
+            uint32_t dropped = 0;
+            e                = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(&dropped, d_dropped, 4, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e == hipSuccess && dropped) {// entries that folded to init: squeeze them out (flags, scan, scatter, new row pointers)
+                uint32_t *keep = nullptr, *rank = nullptr, *nj = nullptr, *nx = nullptr;
+                const uint32_t n = (uint32_t) total;
+                e                = tmp.alloc(&keep, (size_t) n + 1);
+                if (e == hipSuccess) e = tmp.alloc(&rank, (size_t) n + 1);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(keep_flag_kernel<T>, dim3((n + 256) / 256), dim3(256), 0, s, n, ox, init, keep);
+                    e = scan_u32(keep, rank, (size_t) n + 1, tmp, s);
+                }
+                if (e == hipSuccess) e = handoff_alloc(reinterpret_cast<void**>(&nj), sizeof(uint32_t) * (size_t) (n - dropped));
+                if (e == hipSuccess) e = handoff_alloc(reinterpret_cast<void**>(&nx), sizeof(uint32_t) * (size_t) (n - dropped));
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(keep_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, keep, rank, oj, ox, nj, nx);
+                    hipLaunchKernelGGL(keep_rowptr_kernel, dim3((a_rows + 256) / 256), dim3(256), 0, s, a_rows, rank, Rp);
+                    e = hipStreamSynchronize(s);
+                }
+                if (e == hipSuccess) {
+                    (void) handoff_release(oj);
+                    (void) handoff_release(ox);
+                    oj = nj, ox = nx, total -= dropped;
+                }
+            }
+            if (e != hipSuccess) {
+                (void) handoff_release(oj);
+                (void) handoff_release(ox);
+                return fail(SPLAHIP_ERROR, "mxm (row classes): %s", hipGetErrorString(e));
+            }
+            spa_trace("compaction / done", s);
+            *Rj = oj, *Rx = ox, *h_nnz = (uint32_t) total;
+            tl_last_dense_h = dense_h, tl_last_heavy = n_items, tl_last_light_nnz = l_nnz;
+            return SPLAHIP_OK;
+        }
+
+        template<typename T, int ACC>
+        int spa_by_mult(uint32_t a_rows, uint32_t b_cols, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const uint32_t* Bp, const uint32_t* Bj, const void* Bx, uint32_t* Rp,
+                        uint32_t** Rj, void** Rx, uint32_t* h_nnz, const std::vector<u64>& hP, const u64* dP, const std::vector<uint32_t>& hAp, int op_mult, int op_add,
+                        uint32_t init_bits, uint32_t b_rows_hint, hipStream_t s) {
+            if (op_mult == SPLAHIP_MULT) return spa_run<T, StaBin<SPLAHIP_MULT>, ACC>(a_rows, b_cols, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, hP, dP, hAp, op_mult, op_add, init_bits, b_rows_hint, s);
+            return spa_run<T, DynBin, ACC>(a_rows, b_cols, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, hP, dP, hAp, op_mult, op_add, init_bits, b_rows_hint, s);
+        }
+
+        __global__ __launch_bounds__(256) void max_col_kernel(uint32_t nnz, const uint32_t* __restrict__ Aj, uint32_t* __restrict__ out) {
+            uint32_t m = 0;
+            for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nnz; k += gridDim.x * 256) m = max(m, Aj[k]);
+            m = wave_max(m);
+            if (lane_id() == 0) atomicMax(out, m);
+        }
+        __global__ __launch_bounds__(256) void rowprod_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ Aj, const uint32_t* __restrict__ Bp,
+                                                              u64* __restrict__ P) {
+            const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+            if (i >= n_rows) return;
+            u64 sum = 0;
+            for (uint32_t e = Ap[i]; e < Ap[i + 1]; ++e) sum += Bp[Aj[e] + 1] - Bp[Aj[e]];
+            P[i] = sum;
+        }
+
+    }// namespace
+
+    // -1: the row-class form does not apply (op_add without an LDS atomic, no heavy row, switched off): the caller runs the ESC form
+    int mxm_spa(int type, uint32_t a_rows, uint32_t b_cols, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const uint32_t* Bp, const uint32_t* Bj, const void* Bx, uint32_t* Rp,
+                uint32_t** Rj, void** Rx, uint32_t* h_nnz, unsigned long long* h_products, int op_mult, int op_add, uint32_t init_bits, hipStream_t s) {
+        if (!tl_mxm_force_esc) tl_last_dense_h = tl_last_heavy = tl_last_light_nnz = 0;
+        if (tl_mxm_force_esc || env_u32("SPLAHIP_MXM_SPA", 1) == 0) return -1;
+        const int acc = cob_acc_kind(op_add, type);
+        if (acc == COB_NONE || b_cols == 0) return -1;
+        Scratch tmp;
+        u64*    dP = nullptr;
+        if (tmp.alloc(&dP, a_rows) != hipSuccess) return -1;
+        hipLaunchKernelGGL(rowprod_kernel, dim3((a_rows + 255) / 256), dim3(256), 0, s, a_rows, Ap, Aj, Bp, dP);
+        std::vector<u64>      hP(a_rows);
+        std::vector<uint32_t> hAp((size_t) a_rows + 1);
+        SPLAHIP_TRY(hipMemcpyAsync(hP.data(), dP, sizeof(u64) * (size_t) a_rows, hipMemcpyDeviceToHost, s));
+        SPLAHIP_TRY(hipMemcpyAsync(hAp.data(), Ap, 4 * ((size_t) a_rows + 1), hipMemcpyDeviceToHost, s));
+        SPLAHIP_TRY(hipStreamSynchronize(s));
+        u64  total = 0;
+        bool heavy = false;
+        for (u64 p : hP) total += p, heavy = heavy || p > kLight;
+        if (!heavy) return -1;
+        if (h_products) *h_products = total;
+        // the number of rows of B is not an argument of splahip_mxm: the largest inner index A refers to bounds what the dense corner may touch
+        uint32_t* d_max = nullptr;
+        uint32_t  h_max = 0;
+        if (tmp.alloc(&d_max, 1) != hipSuccess) return -1;
+        SPLAHIP_TRY(hipMemsetAsync(d_max, 0, 4, s));
+        if (hAp[a_rows]) hipLaunchKernelGGL(max_col_kernel, dim3(1024), dim3(256), 0, s, hAp[a_rows], Aj, d_max);
+        SPLAHIP_TRY(hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, s));
+        SPLAHIP_TRY(hipStreamSynchronize(s));
+        const uint32_t b_rows_hint = h_max + 1;
+#define SPLAHIP_SPA(TT, AA) return spa_by_mult<TT, AA>(a_rows, b_cols, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, hP, dP, hAp, op_mult, op_add, init_bits, b_rows_hint, s)
+        switch (type) {
+            case SPLAHIP_FLOAT:
+                if (acc == COB_ADD) SPLAHIP_SPA(float, COB_ADD);
+                if (acc == COB_LOR) SPLAHIP_SPA(float, COB_LOR);
+                if (acc == COB_LAND) SPLAHIP_SPA(float, COB_LAND);
+                break;
+            case SPLAHIP_INT:
+                if (acc == COB_ADD) SPLAHIP_SPA(int32_t, COB_ADD);
+                if (acc == COB_MIN) SPLAHIP_SPA(int32_t, COB_MIN);
+                if (acc == COB_MAX) SPLAHIP_SPA(int32_t, COB_MAX);
+                if (acc == COB_OR) SPLAHIP_SPA(int32_t, COB_OR);
+                if (acc == COB_AND) SPLAHIP_SPA(int32_t, COB_AND);
+                if (acc == COB_XOR) SPLAHIP_SPA(int32_t, COB_XOR);
+                if (acc == COB_LOR) SPLAHIP_SPA(int32_t, COB_LOR);
+                if (acc == COB_LAND) SPLAHIP_SPA(int32_t, COB_LAND);
+                break;
+            case SPLAHIP_UINT:
+                if (acc == COB_ADD) SPLAHIP_SPA(uint32_t, COB_ADD);
+                if (acc == COB_MIN) SPLAHIP_SPA(uint32_t, COB_MIN);
+                if (acc == COB_MAX) SPLAHIP_SPA(uint32_t, COB_MAX);
+                if (acc == COB_OR) SPLAHIP_SPA(uint32_t, COB_OR);
+                if (acc == COB_AND) SPLAHIP_SPA(uint32_t, COB_AND);
+                if (acc == COB_XOR) SPLAHIP_SPA(uint32_t, COB_XOR);
+                if (acc == COB_LOR) SPLAHIP_SPA(uint32_t, COB_LOR);
+                if (acc == COB_LAND) SPLAHIP_SPA(uint32_t, COB_LAND);
+                break;
+        }
+#undef SPLAHIP_SPA
+        return -1;
+    }
+
+}// namespace splahip
+
+// which row classes the last splahip_mxm of this thread used: heavy rows (LDS accumulator form), entries produced by the light rows' ESC call,
+// side of the dense corner that ran on the matrix cores (0 = none)
+extern "C" int splahip_mxm_last_info(uint32_t* n_heavy_rows, uint32_t* light_nnz, uint32_t* dense_h) {
+    if (n_heavy_rows) *n_heavy_rows = splahip::tl_last_heavy;
+    if (light_nnz) *light_nnz = splahip::tl_last_light_nnz;
+    if (dense_h) *dense_h = splahip::tl_last_dense_h;
+    return SPLAHIP_OK;
+}

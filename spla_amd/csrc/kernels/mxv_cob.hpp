@@ -113,9 +113,9 @@ namespace splahip {
         else if constexpr (ACC == COB_XOR)
             (void) __hip_atomic_fetch_xor(slot, to_bits(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else if constexpr (ACC == COB_LOR) {
-            if (p != T(0)) *reinterpret_cast<volatile uint32_t*>(slot) = 1u;// idempotent: a plain store is the atomic
+            if (p != T(0)) (void) __hip_atomic_fetch_or(slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else if constexpr (ACC == COB_LAND) {
-            if (p == T(0)) *reinterpret_cast<volatile uint32_t*>(slot) = 0u;
+            if (p == T(0)) (void) __hip_atomic_fetch_and(slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 

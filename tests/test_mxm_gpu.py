@@ -147,3 +147,71 @@ def test_mxm_refuses_a_result_beyond_32bit_row_pointers(monkeypatch):
     monkeypatch.delenv("SPLAHIP_MXM_MAX_NNZ")
     again, _ = kernels.mxm("INT", 300, 300, dA, dA, "MULT", "PLUS", 0, block_products=500)
     assert int(again[1].numel()) == nnz
+
+
+def _last_info():
+    import ctypes as C
+    from spla_amd import _lib
+    a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    _lib.call("splahip_mxm_last_info", C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+@pytest.mark.parametrize("t", ["INT", "UINT", "FLOAT"])
+def test_mxm_row_classes_heavy_rows_vs_oracle(oracle, t):
+    """Rows of more than 4096 products take the LDS-accumulator form (mxm_spa.hip): several column blocks (30,000 columns), chunks of more than
+    1024 entries per row, rows mixed with light ones (ESC), cancellations that fold to init (dropped, then compacted), every op_add with an LDS
+    atomic; the ordered / non-atomic op_add cases of the same input stay with ESC and stay exact."""
+    from spla_amd import kernels
+    rng = np.random.default_rng(61)
+    m, k, n = 700, 2600, 30000
+    A = random_csr(rng, m, k, 45, t, skew=True, long_rows=3, long_len=2500, empty_frac=0.1)
+    B = random_csr(rng, k, n, 55, t, skew=True, long_rows=2, long_len=20000)
+    dA, dB = _dev3(A, t), _dev3(B, t)
+    cases = [("MULT", "PLUS", 0), ("PLUS", "MIN", 100), ("LAND", "LOR", 0), ("MULT", "LAND", 1), ("MIN", "MAX", 0), ("MULT", "SECOND", 0)]
+    if t != "FLOAT":
+        cases += [("BAND", "BOR", 0), ("MULT", "BXOR", 0), ("BOR", "BAND", 0)]
+    for mul, add, init in cases:
+        want = oracle.mxm(t, m, n, A, B, mul, add, init)
+        got, products = kernels.mxm(t, m, n, dA, dB, mul, add, init)
+        heavy, light_nnz, dense_h = _last_info()
+        served = not (add == "SECOND" or (t == "FLOAT" and add in ("MIN", "MAX")))
+        assert (heavy > 0) == served, (mul, add, heavy)
+        exact = not (t == "FLOAT" and add in ("PLUS", "MULT"))
+        _same_csr(_host3(got, t), want, t, exact, f"mxm row classes {t} {mul}/{add}")
+        assert products == sum(int(B[0][c + 1]) - int(B[0][c]) for c in A[1])
+
+
+def test_mxm_dense_corner_on_the_matrix_cores(oracle, monkeypatch):
+    """SURVEY / north star g1: where a row bucket degenerates to a dense tile the product runs on MFMA.  A and B carry a dense 160 x 160 leading
+    block (90 % full) inside sparse matrices: splahip_mxm densifies the corners, multiplies them with v_mfma_f32_32x32x2_f32 (values and product
+    counts), pre-loads the accumulators of rows < h with the tile and lets the sparse traversal skip those products.  Same structure as the oracle,
+    values within 1e-5; identical structure and 1e-5 agreement with the all-sparse run (SPLAHIP_MXM_DENSE=0)."""
+    from spla_amd import kernels
+    rng = np.random.default_rng(67)
+    n = 1200
+    def with_block(seed):
+        r = np.random.default_rng(seed)
+        Ap, Aj, Ax = random_csr(r, n, n, 30, "FLOAT", skew=True)
+        import scipy.sparse as sp
+        S = sp.csr_matrix((Ax, Aj.astype(np.int64), Ap.astype(np.int64)), shape=(n, n)).tolil()
+        blk = (r.random((160, 160)) < 0.9) * (r.integers(1, 64, (160, 160)) / 16.0)
+        S[:160, :160] = blk.astype(np.float32)
+        S = S.tocsr()
+        S.sort_indices()
+        S.eliminate_zeros()
+        return S.indptr.astype(np.uint32), S.indices.astype(np.uint32), S.data.astype(np.float32)
+    A, B = with_block(1), with_block(2)
+    want = oracle.mxm("FLOAT", n, n, A, B, "MULT", "PLUS", 0.0)
+    dA, dB = _dev3(A, "FLOAT"), _dev3(B, "FLOAT")
+    got, _ = kernels.mxm("FLOAT", n, n, dA, dB, "MULT", "PLUS", 0.0)
+    heavy, _, dense_h = _last_info()
+    assert heavy > 0 and dense_h >= 128, (heavy, dense_h)
+    _same_csr(_host3(got, "FLOAT"), want, "FLOAT", False, "mxm dense corner (MFMA)")
+    monkeypatch.setenv("SPLAHIP_MXM_DENSE", "0")
+    got2, _ = kernels.mxm("FLOAT", n, n, dA, dB, "MULT", "PLUS", 0.0)
+    assert _last_info()[2] == 0
+    a, b = _host3(got, "FLOAT"), _host3(got2, "FLOAT")
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-5, atol=0)
