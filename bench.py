@@ -581,6 +581,15 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
     run("all rows selected, PLUS/MIN int32 (SSSP step), column-ordered blocks copy", "INT", w_i, zeros_i, d_i, r_cw, "PLUS", "MIN", "ALWAYS", 1 << 30, False, nnz_local, plan=cob_w)
     res[-1]["identical_to_csr_kernel"] = bool(torch.equal(r_cw, r_i))
     cob_w.close()
+    cob_i = kernels.CsrPlan(n_local, nnz_local, g["Ap"])
+    cob_i.attach_cob(sh.n_cols_padded, g["Ap"], g["Aj"], ones_i)
+    r_cb = torch.empty_like(r_i)
+    run("bfs-step early_exit=false, column-ordered blocks copy (sparse-vector bit form, structure-only: all stored values equal)", "INT", ones_i, mask, v_full, r_cb,
+        "BAND", "BOR", "EQZERO", 0, False, nnz_sel_local, plan=cob_i, entry_bytes=4)
+    kernels.mxv_masked(sh.plan_csr, "INT", sh.n_cols_padded, g["Ap"], g["Aj"], ones_i, mask, v_full, r_i, "BAND", "BOR", "EQZERO", 0)
+    torch.cuda.synchronize()
+    res[-1]["identical_to_csr_kernel"] = bool(torch.equal(r_cb, r_i))
+    cob_i.close()
     sell_i = kernels.CsrPlan(n_local, nnz_local, g["Ap"], sh.n_cols_padded, g["Aj"], ones_i)
     r_chk = torch.empty_like(r_i)
     uni = bool(sell_i.sell and sell_i.sell.get("uniform_values"))

@@ -84,8 +84,11 @@ def pagerank_vxm(args):
     del rows
     _log(f"[bench] pagerank-vxm stand-in: symmetrised R-MAT scale {scale} ef {ef}: n={n} nnz={nnz}")
     Tp, Tj, Tx = kernels.csr_transpose(n, n, Ap, Aj, Ax)
-    use_sell = os.environ.get("SPLA_BENCH_PLAN", "sell") == "sell"  # sliced-ELL copy on the transposed matrix (its vxm mode) or the CSR kernels only
+    mode = os.environ.get("SPLA_BENCH_PLAN", "cob")  # layout copy on the transposed matrix: column-ordered blocks (default), sliced-ELL, or the CSR kernels only
+    use_sell = mode == "sell"
     plan_T = kernels.CsrPlan(n, nnz, Tp, n, Tj, Tx) if use_sell else kernels.CsrPlan(n, nnz, Tp)
+    if mode == "cob":
+        plan_T.attach_cob(n, Tp, Tj, Tx)
     vi = torch.arange(n, device="cuda", dtype=torch.int32)
     vx = torch.full((n,), 1.0 / n, device="cuda", dtype=torch.float32)
     mask = torch.zeros(n, device="cuda", dtype=torch.float32)  # the dummy mask of pr(): ALWAYS ignores it
@@ -102,9 +105,10 @@ def pagerank_vxm(args):
     line = _line("masked vxm GTEPS (PageRank step)", "GTEPS", nnz / (wall / args.steps) / 1e9, args, wall / args.steps * 1e3, "f32",
                  {"workload": f"exec_vxm_masked MULT/PLUS fp32, ALWAYS mask, every v entry stored; symmetrised R-MAT scale {scale} ef {ef} "
                               "(stand-in for com-Orkut, which is not on the box)", "n": n, "nnz": nnz, "out_entries": int(ri.numel()),
-                  "form": ("pull over the sliced-ELL copy of the transposed matrix (sell_vxm: value form, vxm mode)" if use_sell else
+                  "form": ("pull over the column-ordered-blocks copy of the transposed matrix (cob_vxm: fp64 LDS accumulation)" if mode == "cob" else
+                           "pull over the sliced-ELL copy of the transposed matrix (sell_vxm: value form, vxm mode)" if use_sell else
                            "pull over the transposed CSR (spmv_wavetile, VXM mode)") + " + order-preserving compaction"},
-                 _roof(alg, ms, ("sell_vxm" if use_sell else "spmv_wavetile<VXM>") + " + compaction"))
+                 _roof(alg, ms, ("cob_vxm" if mode == "cob" else "sell_vxm" if use_sell else "spmv_wavetile<VXM>") + " + compaction"))
     if not args.no_verify:
         # structure: identical to the oracle's (same touched columns, index-sorted).  values: the oracle (= the reference) folds
         # every column sequentially in fp32; columns here have up to ~1e5 products, where that sequential fold itself is ~2e-5 off
@@ -180,9 +184,11 @@ def sssp_step(args):
     v[idx] = torch.randint(0, 5000, (n // 8,), generator=g, device="cuda", dtype=torch.int32)
     mask = torch.zeros(n, dtype=torch.int32, device="cuda")
     r = torch.empty(n, dtype=torch.int32, device="cuda")
-    use_sell = os.environ.get("SPLA_BENCH_PLAN", "sell") == "sell"  # the sliced-ELL copy (built once per matrix) or the CSR kernels only
-    plan = kernels.CsrPlan(n, nnz, Ap, n, Aj, Ax) if use_sell else kernels.CsrPlan(n, nnz, Ap)
-    _log(f"[bench] sssp-step: R-MAT scale {scale}: n={n} nnz={nnz} items={plan.n_items} sliced-ELL copy: {plan.sell}")
+    mode = os.environ.get("SPLA_BENCH_PLAN", "cob")  # column-ordered blocks (default), the sliced-ELL copy, or the CSR kernels only
+    plan = kernels.CsrPlan(n, nnz, Ap, n, Aj, Ax) if mode == "sell" else kernels.CsrPlan(n, nnz, Ap)
+    if mode == "cob":  # an integer matrix only uses 4-byte LDS slices: 2^15-row ranges from 2^23 rows on (the host API's rule, storage.hpp: cob_row_bits)
+        plan.attach_cob(n, Ap, Aj, Ax, row_bits=15 if n >= 1 << 23 else 0)
+    _log(f"[bench] sssp-step: R-MAT scale {scale}: n={n} nnz={nnz} items={plan.n_items} sliced-ELL copy: {plan.sell} column-ordered blocks: {plan.cob}")
     step = lambda: kernels.mxv_masked(plan, "INT", n, Ap, Aj, Ax, mask, v, r, "PLUS", "MIN", "ALWAYS", INF)
     wall, per = _time_calls(step, args.steps, args.warmup)
     ms = float(np.mean(per))

@@ -43,12 +43,12 @@ namespace spla {
         // sliced-ELL copy (+12 B per entry, tens of ms) once 256 calls have been served: SPLA_HIP_SELL_AFTER.  Matrix::set_format(AccCsr) builds both
         // at once (storage.hpp).  A copy that cannot be built is not an error: the CSR kernels stay in use.
         template<typename T>
-        void maybe_build_copies(HipCsr<T>* a, uint n_cols) {
+        void maybe_build_copies(HipCsr<T>* a, uint n_rows, uint n_cols) {
             ++a->mxv_calls;
             const unsigned cob_after = env_calls("SPLA_HIP_COB_AFTER", 2u), sell_after = env_calls("SPLA_HIP_SELL_AFTER", 256u);
             if (!a->cob_tried && cob_after != 0 && (a->prepared || a->mxv_calls >= cob_after)) {
                 a->cob_tried = true;
-                if (splahip_csr_plan_attach_cob(a->plan, n_cols, a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(), 0, 0, nullptr) != SPLAHIP_OK)
+                if (splahip_csr_plan_attach_cob(a->plan, n_cols, a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(), cob_row_bits<T>(n_rows), 0, nullptr) != SPLAHIP_OK)
                     SPLA_LOG(Status::Error, "column-ordered-blocks copy not built (" << splahip_last_error() << "); the CSR kernels stay in use");
             }
             if (!a->sell_tried && sell_after != 0 && (a->prepared || a->mxv_calls >= sell_after)) {
@@ -112,7 +112,7 @@ namespace spla {
                 auto* a = M->acc_csr();
                 ensure_plan(a, M->get_n_rows());
                 const bool early = t->get_desc_or_default()->get_early_exit();
-                if (!early && a->values > 0) maybe_build_copies(a, M->get_n_cols());
+                if (!early && a->values > 0) maybe_build_copies(a, M->get_n_rows(), M->get_n_cols());
                 hip_check(splahip_mxv_masked(a->plan, TypeTraits<T>::id, M->get_n_rows(), M->get_n_cols(),
                                              a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(),
                                              mask->acc_dense()->Ax.ptr(), v->acc_dense()->Ax.ptr(), r->acc_dense()->Ax.ptr(),
@@ -228,7 +228,7 @@ namespace spla {
                     // a dense v (a PageRank step) over a transpose that keeps being used: the layout copies of M^T, same rent-or-buy rule as mxv
                     if (identity && tr->values > 0) {
                         tr->prepared = tr->prepared || M->acc_csr()->prepared;
-                        maybe_build_copies(tr, M->get_n_rows());
+                        maybe_build_copies(tr, M->get_n_cols(), M->get_n_rows());
                     }
                     hip_check(splahip_vxm_pull(tr->plan, TypeTraits<T>::id, M->get_n_rows(), M->get_n_cols(), tr->Ap.template as<uint32_t>(),
                                                tr->Aj.template as<uint32_t>(), tr->Ax.ptr(), mask->acc_dense()->Ax.ptr(), nvals,

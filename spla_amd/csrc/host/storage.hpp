@@ -16,6 +16,7 @@
 
 #include "internal.hpp"
 
+#include <type_traits>
 #include <spla_hip.h>
 
 #include <algorithm>
@@ -136,6 +137,14 @@ namespace spla {
         std::vector<uint> Ap, Aj;
         std::vector<T>    Ax;
     };
+    // row_bits of the column-ordered-blocks copy (spla_hip.h: splahip_csr_plan_attach_cob): 0 = the library's default (2^14 rows per range: both the
+    // 4-byte and the double LDS slice fit twice per CU).  Integer matrices only ever use 4-byte slices, and from 2^23 rows on the wider range pays
+    // (R-MAT scale 24, int min-plus: 976 -> 828 us; scale 22: 178 vs 185 us — profiles/r02_cob_launch_bounds.txt).
+    template<typename T>
+    inline uint32_t cob_row_bits(uint64_t n_rows) {
+        return (std::is_integral<T>::value && n_rows >= (1ull << 23)) ? 15u : 0u;
+    }
+
     // device CSR + its work decomposition (splahip_plan); used for AccCsr (the matrix) and AccCsc (its transpose)
     template<typename T>
     struct HipCsr final : Decoration<T> {
@@ -430,7 +439,7 @@ namespace spla {
                             throw std::runtime_error(std::string("csr plan: ") + splahip_last_error());
                         if (!a->cob_tried) {
                             a->cob_tried = true;
-                            (void) splahip_csr_plan_attach_cob(a->plan, m_s.n_cols, a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(), 0, 0, nullptr);
+                            (void) splahip_csr_plan_attach_cob(a->plan, m_s.n_cols, a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(), cob_row_bits<T>(m_s.n_rows), 0, nullptr);
                         }
                         if (!a->sell_tried) {
                             a->sell_tried = true;

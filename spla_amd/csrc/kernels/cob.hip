@@ -111,6 +111,31 @@ namespace {
         if (threadIdx.x == 0) hdr[c] = 0;
     }
 
+    // smallest and largest value word of the matrix (equal <=> one value, as in an adjacency matrix of ones)
+    __global__ __launch_bounds__(256) void cob_ax_range_kernel(uint32_t n, const uint32_t* __restrict__ x, uint32_t* __restrict__ out) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0;
+        for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+            const uint32_t w = x[k];
+            lo = min(lo, w), hi = max(hi, w);
+        }
+        lo = ~wave_max(~lo);
+        hi = wave_max(hi);
+        if (lane_id() == 0) {
+            atomicMin(&out[0], lo);
+            atomicMax(&out[1], hi);
+        }
+    }
+    // per call, sparse-input-vector form: bit c of the bitmap = v[c] != 0 (a wave's ballot is two bitmap words)
+    template<typename T>
+    __global__ __launch_bounds__(256) void cob_vbits_kernel(uint32_t n, const T* __restrict__ v, uint32_t* __restrict__ bits) {
+        const uint32_t           c  = blockIdx.x * 256 + threadIdx.x;
+        const unsigned long long b  = __ballot(c < n && v[c] != T(0));
+        if (lane_id() == 0) {
+            bits[c >> 5]       = (uint32_t) b;
+            bits[(c >> 5) + 1] = (uint32_t) (b >> 32);
+        }
+    }
+
     // rows of ranges that hold no entry at all: r = init (grid.y = empty range)
     template<typename T>
     __global__ __launch_bounds__(256) void cob_fill_kernel(const uint32_t* __restrict__ empty_ranges, uint32_t n_rows, uint32_t row_bits, T* __restrict__ r, T init) {
@@ -159,7 +184,7 @@ namespace {
     // set by cob_mxv_accumulate around its call (per host thread): the launch below then folds onto the values r already holds
     thread_local uint32_t tl_accumulate = 0;
 
-    template<typename T, class Mult, int ACC, bool VXM>
+    template<typename T, class Mult, int ACC, bool VXM, int MODE = 0>
     int launch_cob(const splahip_cob_s* g, const uint32_t* Ap, const void* mask, const void* v, void* r, uint32_t* touched, int op_mult, int op_add, int op_select,
                    uint32_t init_bits, hipStream_t st) {
         constexpr int               W  = sizeof(typename CobSlice<T, ACC>::word) == 8 ? 1 : 0;
@@ -178,16 +203,22 @@ namespace {
         a.col_bits = g->col_bits;
         a.pad_chunk = g->n_chunks;
         a.accumulate = VXM ? 0u : tl_accumulate;
+        a.vbits      = g->d_vbits;
+        a.x_uniform  = g->x_bits;
+        if constexpr (MODE != 0) {// the bitmap of v for this call
+            hipLaunchKernelGGL((cob_vbits_kernel<T>), dim3((g->n_cols + 255) / 256), dim3(256), 0, st, g->n_cols, static_cast<const T*>(v), g->d_vbits);
+            SPLAHIP_TRY(hipGetLastError());
+        }
         const T        init = from_bits<T>(init_bits);
         const uint32_t R    = 1u << g->row_bits;
         if (sc.n_tiles) {
             static bool lds_raised = false;// a range of 16 Ki rows plus the spare words is just over the 64 KB a kernel gets without asking
             if (!lds_raised) {
-                SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 160 * 1024));
                 lds_raised = true;
             }
-            hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb>), dim3(sc.n_spans), dim3(kTpb), (R + 4) * sizeof(typename CobSlice<T, ACC>::word), st, a, static_cast<const T*>(v),
+            hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), dim3(sc.n_spans), dim3(kTpb), (R + 4) * sizeof(typename CobSlice<T, ACC>::word), st, a, static_cast<const T*>(v),
                                static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
             SPLAHIP_TRY(hipGetLastError());
         }
@@ -209,6 +240,19 @@ namespace {
     template<typename T, int ACC, bool VXM>
     int cob_by_mult(const splahip_cob_s* g, const uint32_t* Ap, const void* mask, const void* v, void* r, uint32_t* touched, int op_mult, int op_add, int op_select,
                     uint32_t init_bits, hipStream_t st) {
+        // the sparse-input-vector form (mxv_cob.hpp MODE 1 / 2) for the semirings in which a zero of v cannot change a row (sell_skip_family == 1): int / uint only
+        if constexpr (!VXM && !std::is_same<T, float>::value && (ACC == COB_OR || ACC == COB_ADD || ACC == COB_XOR || ACC == COB_MAX)) {
+            const char* be = std::getenv("SPLAHIP_COB_BITS");
+            if (g->d_vbits && !(be && be[0] == '0') && !tl_accumulate && sell_skip_family(TypeId<T>::value, op_mult, op_add) == 1) {
+                const char* ue = std::getenv("SPLAHIP_COB_UNIFORM");
+                if (g->x_uniform && !(ue && ue[0] == '0')) {
+                    if (op_mult == SPLAHIP_BAND) return launch_cob<T, StaBin<SPLAHIP_BAND>, ACC, VXM, 2>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
+                    return launch_cob<T, DynBin, ACC, VXM, 2>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
+                }
+                if (op_mult == SPLAHIP_BAND) return launch_cob<T, StaBin<SPLAHIP_BAND>, ACC, VXM, 1>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
+                return launch_cob<T, DynBin, ACC, VXM, 1>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
+            }
+        }
         // the semirings of the configs get a compile-time op_mult; every other pair runs the runtime-switched functor
         if constexpr (ACC == COB_ADD) {
             if (op_mult == SPLAHIP_MULT) return launch_cob<T, StaBin<SPLAHIP_MULT>, ACC, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
@@ -254,7 +298,7 @@ namespace splahip {
 
     void cob_release(splahip_cob_s* g) {
         if (!g) return;
-        for (void* p : {(void*) g->d_hdr, (void*) g->d_cr, (void*) g->d_ax, (void*) g->d_slabs, (void*) g->d_empty, (void*) g->sched[0].d_span_first,
+        for (void* p : {(void*) g->d_hdr, (void*) g->d_cr, (void*) g->d_ax, (void*) g->d_slabs, (void*) g->d_empty, (void*) g->d_vbits, (void*) g->sched[0].d_span_first,
                         (void*) g->sched[0].d_tiles, (void*) g->sched[0].d_multi, (void*) g->sched[1].d_span_first, (void*) g->sched[1].d_tiles, (void*) g->sched[1].d_multi})
             if (p) (void) hipFree(p);
         delete g;
@@ -477,7 +521,23 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         if (e == hipSuccess) e = hipStreamSynchronize(s);// the vectors go out of scope
     }
     own(&g->d_slabs, (size_t) max_slabs << row_bits);
+    own(&g->d_vbits, ((size_t) n_cols + 255) / 256 * 8 + 2);// every wave of cob_vbits_kernel writes its two words
     if (e != hipSuccess) return bail("schedule upload");
+    {// one value word in the whole matrix?  (the sparse-vector form then skips the value stream)
+        uint32_t* rng = nullptr;
+        e             = tmp.alloc(&rng, 2);
+        const uint32_t init_rng[2] = {0xFFFFFFFFu, 0u};
+        uint32_t       h_rng[2]    = {0, 1};
+        if (e == hipSuccess) e = hipMemcpyAsync(rng, init_rng, 8, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(cob_ax_range_kernel, dim3(1024), dim3(256), 0, s, nnz, static_cast<const uint32_t*>(d_Ax), rng);
+            e = hipMemcpyAsync(h_rng, rng, 8, hipMemcpyDeviceToHost, s);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return bail("value range");
+        g->x_uniform = h_rng[0] == h_rng[1];
+        g->x_bits    = h_rng[0];
+    }
     plan->cob = g;
     return SPLAHIP_OK;
 }

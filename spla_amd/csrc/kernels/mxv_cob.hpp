@@ -190,14 +190,32 @@ namespace splahip {
         uint32_t        row_bits;
         uint32_t        col_bits;
         uint32_t        pad_chunk;// an all-padding chunk behind the last real one
+        const uint32_t* vbits;     // MODE 1 / 2: bit c = v[c] != 0 (n_cols bits)
+        uint32_t        x_uniform; // MODE 2: the one value word of the matrix
         uint32_t        accumulate;// 1: r already holds the fold of another column part of the same rows (1-D row decomposition, dist.hip): a selected
                                    // row that holds an entry here becomes add(r[row], acc); every other row is left as it is
     };
 
     // One workgroup per tile.  LDS: the range's R result words.  VXM: products are mult(v, x) (the pull form of vxm over the copy of the
     // transposed matrix, reference cpu_vxm.hpp:113) — everything else is the same fold.
-    template<typename T, class Mult, class Add, int ACC, bool VXM, unsigned TPB>
-    __global__ __launch_bounds__(TPB) void cob_mxv_kernel(CobArgs a, const T* __restrict__ v, const T* __restrict__ mask, T* __restrict__ r, Mult mult,
+    // MODE 0: every entry gathers its value of v.  MODE 1 / 2 — the sparse-input-vector form for semirings in which a zero of v cannot change a row's fold
+    // (0 annihilates op_mult and is op_add's identity: BAND / BOR, LAND / LOR, MULT / PLUS ... on int / uint; sell.hip: sell_skip_family == 1): an entry first
+    // gathers one BIT of a bitmap of v (a.vbits, written per call by cob_vbits_kernel: 128 bytes cover 1024 columns, so a wave's gather is one or two
+    // requests), and only the entries whose bit is set gather the value and touch the LDS slice — a BFS step adds a few per cent of its products.
+    // MODE 2: every stored value of the matrix is the same word (a.x_uniform: an adjacency matrix of ones): the value stream is not read at all.
+    // waves per SIMD the register budget is cut for: the bit forms run two 16-wave workgroups per CU on 4-byte slices (8); the value form keeps the
+    // compiler's own choice (a forced 8 spilled 20 words in the int instantiations)
+    template<typename T, int ACC, int MODE>
+    constexpr unsigned cob_min_waves() {
+#ifdef SPLAHIP_COB_MIN_WAVES
+        return SPLAHIP_COB_MIN_WAVES;
+#else
+        return (MODE != 0 && sizeof(typename CobSlice<T, ACC>::word) == 4) ? 8u : 4u;
+#endif
+    }
+
+    template<typename T, class Mult, class Add, int ACC, bool VXM, unsigned TPB, int MODE = 0>
+    __global__ __launch_bounds__(TPB, (cob_min_waves<T, ACC, MODE>())) void cob_mxv_kernel(CobArgs a, const T* __restrict__ v, const T* __restrict__ mask, T* __restrict__ r, Mult mult,
                                                           Add add, int op_select, T init) {
         using word = typename CobSlice<T, ACC>::word;
         constexpr bool kWide = sizeof(word) == 8;// fp32 PLUS: the slice holds doubles
@@ -237,52 +255,87 @@ namespace splahip {
         u4             E[4], X[4];
         uint32_t       B[4];
         T              G[2][4];
+        u4             W[2];   // MODE 1 / 2: the gathered bitmap words of a step
+        uint32_t       M[2];   //             and, once they are in, the step's four bits
         auto load_set = [&](int q, uint32_t ci) {
             const uint32_t k = chunk_of(ci);
             E[q]             = __builtin_nontemporal_load(cr4 + (size_t) k * (kCobChunk / 4));
-            X[q]             = __builtin_nontemporal_load(ax4 + (size_t) k * (kCobChunk / 4));
-            B[q]             = hb[k];
+            if constexpr (MODE != 2) X[q] = __builtin_nontemporal_load(ax4 + (size_t) k * (kCobChunk / 4));
+            B[q] = hb[k];
         };
         auto gather_set = [&](int q, int gq) {
 #if defined(SPLAHIP_COB_EXP) && (SPLAHIP_COB_EXP == 2 || SPLAHIP_COB_EXP == 4)
             G[gq][0] = from_bits<T>(B[q] + (E[q].x & cmask)), G[gq][1] = from_bits<T>(B[q] + (E[q].y & cmask)), G[gq][2] = from_bits<T>(B[q] + (E[q].z & cmask)),
             G[gq][3] = from_bits<T>(B[q] + (E[q].w & cmask));// DIAGNOSTIC BUILD: no gathers
 #else
-            G[gq][0] = v[B[q] + (E[q].x & cmask)];
-            G[gq][1] = v[B[q] + (E[q].y & cmask)];
-            G[gq][2] = v[B[q] + (E[q].z & cmask)];
-            G[gq][3] = v[B[q] + (E[q].w & cmask)];
+            if constexpr (MODE == 0) {
+                G[gq][0] = v[B[q] + (E[q].x & cmask)];
+                G[gq][1] = v[B[q] + (E[q].y & cmask)];
+                G[gq][2] = v[B[q] + (E[q].z & cmask)];
+                G[gq][3] = v[B[q] + (E[q].w & cmask)];
+            } else {// the bits of this step arrived one step ago: extract them, then gather v only where a bit is set (every other lane re-reads v[base]: one line)
+                const uint32_t c0 = B[q] + (E[q].x & cmask), c1 = B[q] + (E[q].y & cmask), c2 = B[q] + (E[q].z & cmask), c3 = B[q] + (E[q].w & cmask);
+                const uint32_t m  = ((W[gq].x >> (c0 & 31)) & 1u) | (((W[gq].y >> (c1 & 31)) & 1u) << 1) | (((W[gq].z >> (c2 & 31)) & 1u) << 2) | (((W[gq].w >> (c3 & 31)) & 1u) << 3);
+                M[gq]    = m;
+                G[gq][0] = v[(m & 1u) ? c0 : B[q]];
+                G[gq][1] = v[(m & 2u) ? c1 : B[q]];
+                G[gq][2] = v[(m & 4u) ? c2 : B[q]];
+                G[gq][3] = v[(m & 8u) ? c3 : B[q]];
+            }
 #endif
+        };
+        auto bits_set = [&](int q, int wq) {// MODE 1 / 2: one bitmap word per slot (a padding slot reads the word of the base column)
+            W[wq].x = a.vbits[(B[q] + (E[q].x & cmask)) >> 5];
+            W[wq].y = a.vbits[(B[q] + (E[q].y & cmask)) >> 5];
+            W[wq].z = a.vbits[(B[q] + (E[q].z & cmask)) >> 5];
+            W[wq].w = a.vbits[(B[q] + (E[q].w & cmask)) >> 5];
         };
 #if defined(SPLAHIP_COB_EXP) && SPLAHIP_COB_EXP == 1
         T dbg = T(0);
 #endif
         auto add_set = [&](int q, int gq) {
-            const u4 e = E[q], x = X[q];
-            const T  g0 = G[gq][0], g1 = G[gq][1], g2 = G[gq][2], g3 = G[gq][3];
+            const u4 e = E[q];
+            u4       x;
+            if constexpr (MODE == 2) x = {a.x_uniform, a.x_uniform, a.x_uniform, a.x_uniform};
+            else
+                x = X[q];
+            const T g0 = G[gq][0], g1 = G[gq][1], g2 = G[gq][2], g3 = G[gq][3];
 #if defined(SPLAHIP_COB_EXP) && SPLAHIP_COB_EXP == 1
             dbg = dbg + mult(from_bits<T>(x.x), g0) + mult(from_bits<T>(x.y), g1) + mult(from_bits<T>(x.z), g2) + mult(from_bits<T>(x.w), g3) + T(e.x >> a.col_bits);// DIAGNOSTIC BUILD: no LDS accumulation
             return;
 #endif
-            if constexpr (VXM)
+            if constexpr (MODE != 0) {// only the products of the set bits can change a row (a padding slot's bit may be set: its row field is the spare word)
+                const uint32_t m = M[gq];
+                if (m & 1u) cob_accumulate<T, ACC>(s_acc + (e.x >> a.col_bits), mult(from_bits<T>(x.x), g0));
+                if (m & 2u) cob_accumulate<T, ACC>(s_acc + (e.y >> a.col_bits), mult(from_bits<T>(x.y), g1));
+                if (m & 4u) cob_accumulate<T, ACC>(s_acc + (e.z >> a.col_bits), mult(from_bits<T>(x.z), g2));
+                if (m & 8u) cob_accumulate<T, ACC>(s_acc + (e.w >> a.col_bits), mult(from_bits<T>(x.w), g3));
+            } else if constexpr (VXM)
                 cob_accumulate4<T, ACC>(s_acc, e.x >> a.col_bits, e.y >> a.col_bits, e.z >> a.col_bits, e.w >> a.col_bits, mult(g0, from_bits<T>(x.x)),
                                         mult(g1, from_bits<T>(x.y)), mult(g2, from_bits<T>(x.z)), mult(g3, from_bits<T>(x.w)));
             else
                 cob_accumulate4<T, ACC>(s_acc, e.x >> a.col_bits, e.y >> a.col_bits, e.z >> a.col_bits, e.w >> a.col_bits, mult(from_bits<T>(x.x), g0),
                                         mult(from_bits<T>(x.y), g1), mult(from_bits<T>(x.z), g2), mult(from_bits<T>(x.w), g3));
         };
-        // prologue: streams of steps 0, 1, 2; gathers of step 0
+        // prologue: streams of steps 0, 1, 2; (bits of steps 0 and 1;) gathers of step 0
         load_set(0, c0);
         load_set(1, c0 + NW);
         load_set(2, c0 + 2 * NW);
+        if constexpr (MODE != 0) {
+            bits_set(0, 0);
+            bits_set(1, 1);
+        }
         gather_set(0, 0);
         for (uint32_t s = 0; s < steps; s += 4) {
             const uint32_t cs = c0 + s * NW;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                // step s + k works on set k (k & 3): streams of step s + k + 3 go into set (k + 3) & 3, which step s + k - 1 has just finished with
+                // step s + k works on set k (k & 3): streams of step s + k + 3 go into set (k + 3) & 3, which step s + k - 1 has just finished with;
+                // the value gathers run one step ahead (MODE 1 / 2: the bitmap words two steps ahead, in the word set the gathers of step s + k + 1 — issued
+                // just before — have consumed... the other one: W[(k + 2) & 1] was read by gather_set of step s + k, one body earlier)
                 load_set((k + 3) & 3, cs + (k + 3) * NW);
                 gather_set((k + 1) & 3, (k + 1) & 1);
+                if constexpr (MODE != 0) bits_set((k + 2) & 3, (k + 2) & 1);
                 add_set(k, k & 1);
             }
         }

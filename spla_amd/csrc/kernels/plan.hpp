@@ -75,6 +75,9 @@ struct splahip_cob_s {
     uint32_t* d_ax     = nullptr;// n_chunks x 256 value words
     uint32_t* d_slabs  = nullptr;// max(sched[].n_slabs) << row_bits words, per call
     uint32_t* d_empty  = nullptr;// n_empty range ids
+    uint32_t* d_vbits  = nullptr;// per call: bit c = v[c] != 0 (sparse-input-vector form, mxv_cob.hpp MODE 1 / 2)
+    bool      x_uniform = false; // every stored value of the matrix is the same word (found at attach time) ...
+    uint32_t  x_bits    = 0;     // ... this one: the sparse-vector form then does not read the value stream
 };
 
 struct splahip_plan_s {
