@@ -53,7 +53,7 @@ namespace splahip {
 #ifdef SPLAHIP_SELL_TIMING
     // DIAGNOSTIC BUILD ONLY (tools/exp/exp_sell_timing.py): per wave of the launch (4096), s_memtime ticks summed over its slices:
     // [0] top of the loop .. loads issued, [1] .. first group landed, [2] .. fold + stores issued, [3] slices, [4] wave total, [5] prologue
-    static __device__ unsigned long long g_sell_t[6][4096];
+    static __device__ unsigned long long g_sell_t[12][4096];// [6] live slices [7] group rounds [8] sum of widths [9] selected lanes [10] kernel entry .. first slice
 #define SELL_STAMP(t)                                            \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
     t = __builtin_amdgcn_s_memtime();
@@ -75,11 +75,16 @@ namespace splahip {
         static constexpr uint kU       = 8;    // entries per lane and group (16: same speed, 98 VGPRs)
         static constexpr uint kHotFlag = 0x80000000u;
         static constexpr uint kPartial = 0x80000000u;// in vrow: this chunk belongs to a row longer than kC
-        // BITS form: ranks [0, kBitsLds) have an LDS-resident bit; bit kBitsLds of the LDS copy is kept 0 and entries of colder columns
-        // are coded with that rank (they live in the cold list).  (80 KB of bits and two workgroups per CU was tried: the 64-VGPR cap
-        // spills inside the slice loop, 165 -> 173 us on the BFS step.)
+        // BITS form: ranks [0, kBitsLds) have an LDS-resident bit; entries of colder columns live in the cold list.  (80 KB of bits and two
+        // workgroups per CU was tried: the 64-VGPR cap spills inside the slice loop, 165 -> 173 us on the BFS step.)
         static constexpr uint kBitWords = kHot;
         static constexpr uint kBitsLds  = kBitWords * 32 - 1;
+        // What Aj2r stores for a column of rank r: bit b = r + 1 of the bitmap is the column's (bit 0 is never set), and the CODE of an
+        // LDS-resident bit is (b >> 5) << 7 | (b & 31) — code >> 5 is the byte address of its LDS word, the low five bits are the shift.
+        // Code 0 folds nothing: padding, colder columns (their entries are in the cold list), and what a bounds-checked buffer load
+        // returns for a lane that asks beyond its slice.
+        __host__ __device__ static constexpr uint bits_code(uint rank) { return rank < kBitsLds ? ((((rank + 1u) >> 5) << 7) | ((rank + 1u) & 31u)) : 0u; }
+        __host__ __device__ static constexpr uint code_rank(uint code) { return (((code >> 7) << 5) | (code & 31u)) - 1u; }
         // statistics behind the bitmap, 4 words per sell_vprep workgroup: count of non-zero v entries, max of ~bits (= ~min), max of bits
         static constexpr uint kPrepBlocks = 4096;
         static constexpr uint kStatCount = 0, kStatNotMin = 1, kStatMax = 2;
@@ -194,7 +199,7 @@ namespace splahip {
 #pragma unroll
             for (uint i = 0; i < 4; ++i)
                 if (i < nb && b[i] != skip) {
-                    atomicOr(&vbits[rank[i] >> 5], 1u << (rank[i] & 31u));
+                    atomicOr(&vbits[(rank[i] + 1u) >> 5], 1u << ((rank[i] + 1u) & 31u));// (bit rank + 1: SellCfg::bits_code)
                     vranked[rank[i]] = b[i];
                     count += 1;
                     notmin = max(notmin, ~b[i]);
@@ -263,6 +268,10 @@ namespace splahip {
                                                   uint* __restrict__ touched = nullptr, T ident = T(), uint xbits = 0) {
         using C = SellCfg;
         const bool xu = Ax2 == nullptr;// every matrix value is the word `xbits`: the value stream is not read
+#ifdef SPLAHIP_SELL_TIMING
+        unsigned long long t_entry = 0;
+        SELL_NOW(t_entry)
+#endif
         static_assert(!(BITS && VXM), "the pull form of vxm uses the value form");
         uint& s_next = *s_next_p;// next of this workgroup's slices nobody has taken yet (ordinal)
 
@@ -276,9 +285,6 @@ namespace splahip {
             uint4*       dst = reinterpret_cast<uint4*>(s_hot);
             const uint   nq  = (n_hot + 3u) / 4u;
             for (uint q = threadIdx.x; q < nq; q += C::kTpb) dst[q] = src[q];
-        }
-        if constexpr (BITS) {// the reserved "never set" bit (the same thread copied that word)
-            if (threadIdx.x == ((C::kBitWords - 1) / 4) % C::kTpb) s_hot[C::kBitWords - 1] = from_bits<T>(to_bits(s_hot[C::kBitWords - 1]) & 0x7FFFFFFFu);
         }
 
         // 1. rows that no slice lane will write: empty rows and unselected rows.  Four consecutive rows per lane and step: the
@@ -355,7 +361,7 @@ namespace splahip {
         };
 
 #ifdef SPLAHIP_SELL_TIMING
-        unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, acc0 = 0, acc1 = 0, acc2 = 0, nsl = 0, t_begin = 0;
+        unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, acc0 = 0, acc1 = 0, acc2 = 0, nsl = 0, t_begin = 0, n_live = 0, n_rounds = 0, n_width = 0, n_lanes = 0;
         SELL_NOW(t_begin)
 #endif
         uint rowA = vrow[sA * kWave + lane], lenA = vlen[sA * kWave + lane], baseA = off[sA];
@@ -368,20 +374,11 @@ namespace splahip {
             baseB = off[sB];
         }
         uint wordA = sel_word(rowA, lenA);
+        // the slice after B: its ID is resolved a whole slice ahead of its header (ordinal from the LDS counter, then the plan's permutation —
+        // a dependent global load that would otherwise stall every pass of the loop for a full memory latency)
+        uint sC = moreB ? take_slice() : n_slices;
         while (true) {
             SELL_NOW(t_a)
-            // C's header and B's selection word travel while A is folded
-            uint sC = n_slices, rowC = 0, lenC = 0, baseC = 0;
-            if (moreB) sC = take_slice();
-            const bool moreC = moreB && sC < n_slices;
-            if (moreC) {
-                rowC  = vrow[sC * kWave + lane];
-                lenC  = vlen[sC * kWave + lane];
-                baseC = off[sC];
-            }
-            uint wordB = 0;
-            if (moreB) wordB = sel_word(rowB, lenB);
-
             // ---- slice A
             const uint rowinfo = rowA;
             const uint base    = __builtin_amdgcn_readfirstlane(baseA);
@@ -395,19 +392,37 @@ namespace splahip {
             uint        jn[KU], xn[KU];
 #pragma unroll
             for (uint u = 0; u < KU; ++u) {// first group: only lanes that will fold the entry ask for it
-                jn[u] = BITS ? C::kBitsLds : C::kHotFlag;// a lane without an entry reads the never-set bit / hot slot 0 and folds nothing
+                jn[u] = BITS ? 0u : C::kHotFlag;// a lane without an entry reads the never-set bit (code 0) / hot slot 0 and folds nothing
                 xn[u] = xu ? xbits : 0u;
                 if (u < mylen) {
                     jn[u] = sell_stream_load(pj + u * kWave);
                     if (!xu) xn[u] = sell_stream_load(px + u * kWave);
                 }
             }
+            // (requested AFTER A's first group: the loads below sit in uniform branches, so the wait for anything older than them is a
+            // wait for them too — ahead of A's loads they cost every slice a second memory round trip)
+            // C's header, D's id and B's selection word travel while A is folded
+            uint       rowC = 0, lenC = 0, baseC = 0;
+            const bool moreC = moreB && sC < n_slices;
+            if (moreC) {
+                rowC  = vrow[sC * kWave + lane];
+                lenC  = vlen[sC * kWave + lane];
+                baseC = off[sC];
+            }
+            uint sD = n_slices;
+            if (moreC) sD = take_slice();
+            uint wordB = 0;
+            if (moreB) wordB = sel_word(rowB, lenB);
+
             SELL_NOW(t_b)
             SELL_STAMP(t_c)
             const unsigned long long live = __ballot(selected);
             if (live != 0ull) {
                 // chunks are sorted by length: the first selected lane holds the longest selected chunk
                 const uint width = __builtin_amdgcn_readlane(mylen, __ffsll((long long) live) - 1);
+#ifdef SPLAHIP_SELL_TIMING
+                n_live += 1, n_rounds += (width + KU - 1) / KU, n_width += width, n_lanes += __popcll(live);
+#endif
                 T          acc   = init;
                 bool       has   = !chunk && !VXM;// a row's only chunk folds from init (mxv); chunks of a long row and vxm rows fold from their first product
                 if constexpr (BITS) {// a chunk may hold no product at all: its partial is then op_add's identity (0 for every BITS semiring)
@@ -433,17 +448,20 @@ namespace splahip {
                     }
                     T    vv[KU];
                     bool on[KU];
+                    if constexpr (BITS) {// the group's LDS words are requested together, then tested (one LDS round trip per group, not per entry)
+                        uint a[KU];
 #pragma unroll
-                    for (uint u = 0; u < KU; ++u) {
+                        for (uint u = 0; u < KU; ++u) a[u] = to_bits(s_hot[jc[u] >> 7]);
+#pragma unroll
+                        for (uint u = 0; u < KU; ++u) {
+                            on[u] = (e + u < mylen) & (((a[u] >> (jc[u] & 31u)) & 1u) != 0);
+                            vv[u] = cval;
+                        }
+                    }
+#pragma unroll
+                    for (uint u = 0; u < KU && !BITS; ++u) {
                         const bool take = e + u < mylen;
                         on[u]           = take;
-                        if constexpr (BITS) {
-                            const uint rank = jc[u];
-                            const uint a = to_bits(s_hot[rank >> 5]);
-                            on[u] = take && ((a >> (rank & 31u)) & 1u) != 0;
-                            vv[u] = cval;
-                            continue;
-                        }
                         const bool hot  = (jc[u] & C::kHotFlag) != 0;
 #if SPLAHIP_SELL_EXP == 1 /* diagnostic: no gather at all */
                         vv[u] = from_bits<T>(jc[u] | (hot ? 1u : 0u) | (take ? 2u : 0u));
@@ -466,7 +484,7 @@ namespace splahip {
                         if (!is_const) {// set bits fetch their value from the rank-ordered copy of v (all of the group's gathers in flight together)
 #pragma unroll
                             for (uint u = 0; u < KU; ++u)
-                                if (on[u]) vv[u] = from_bits<T>(vranked[jc[u]]);
+                                if (on[u]) vv[u] = from_bits<T>(vranked[C::code_rank(jc[u])]);
                         }
                     }
 #pragma unroll
@@ -503,12 +521,210 @@ namespace splahip {
                 if (gw < 4096) {
                     g_sell_t[0][gw] = acc0, g_sell_t[1][gw] = acc1, g_sell_t[2][gw] = acc2, g_sell_t[3][gw] = nsl;
                     g_sell_t[4][gw] = t_d - t_begin;
+                    g_sell_t[6][gw] = n_live, g_sell_t[7][gw] = n_rounds, g_sell_t[8][gw] = n_width, g_sell_t[9][gw] = n_lanes;
+                    g_sell_t[10][gw] = t_begin - t_entry;
                 }
             }
 #endif
             if (!moreB) break;
             sA = sB, rowA = rowB, lenA = lenB, baseA = baseB, wordA = wordB;
             sB = sC, moreB = moreC, rowB = rowC, lenB = lenC, baseB = baseC;
+            sC = sD;
+        }
+    }
+
+    // n products of the same value p folded into acc: what the frontier form below needs instead of one add per entry.
+    // PLUS / BXOR (integer types only — the dispatch keeps other types away) count; every other bit-form op_add is idempotent.
+    template<typename T, class Add>
+    __device__ __forceinline__ T fold_repeated(T acc, T p, uint n, const Add& add) {
+        if (n == 0) return acc;
+        const int op = functor_op(add);
+        if constexpr (std::is_integral<T>::value) {
+            if (op == SPLAHIP_PLUS) return from_bits<T>(to_bits(acc) + n * to_bits(p));
+            if (op == SPLAHIP_BXOR) return (n & 1u) ? from_bits<T>(to_bits(acc) ^ to_bits(p)) : acc;
+        }
+        return add(acc, p);
+    }
+
+    // FRONTIER form of the bit form: every non-skipped value of v is the same word AND every stored matrix value is the same word (a BFS
+    // step over an adjacency matrix) — all products are one value pc, a row's result is fold_repeated(init, pc, hits), and the slice walk
+    // only COUNTS set bits.  What that buys, measured with per-wave s_memtime stamps on the general walk (R-MAT 22 BFS step: 16 slices
+    // per wave, 9.6 of them with a selected lane, mean selected width 13.5 entries): the walk is bound by instruction issue, not by bytes
+    // — 16 predicated loads (six instructions each) and 16 folds of ~9 VALU per group whatever the slice's width.  Here:
+    //   * loads are bounds-checked BUFFER loads over the slice (descriptor: width x 256 bytes; voffset: the lane's column, or beyond the
+    //     buffer for an unselected lane): a lane without an entry at a position gets code 0 — the never-set bit — without a request, a
+    //     branch or a select, the per-load offset is an immediate / a scalar, and the load count is static (exact vmcnt waits);
+    //   * a slice of at most 16 positions is walked in quads under UNIFORM branches (a width-3 slice issues 4 loads and 4 folds, not 16);
+    //   * a wider slice keeps a sliding window of 32 loads per lane in flight, consumed in place eight at a time (the slot's old code is
+    //     taken apart before the slot is re-requested, so the slot stays in one register across the back edge);
+    //   * an entry is four instructions: code >> 5 (LDS byte address), ds_read, shift by the code's low five bits, add.
+    template<typename T, class Mult, class Add>
+    __device__ __forceinline__ void sell_frontier_body(uint* s_bits, uint* s_next_p, uint n_slices, const uint* __restrict__ vrow, const uint* __restrict__ vlen,
+                                                       const uint* __restrict__ off, const uint* __restrict__ Aj2r, const uint* __restrict__ vbits,
+                                                       const uint* __restrict__ selbits, const uint* __restrict__ sorder, T* __restrict__ r, Mult mult, Add add,
+                                                       int op_select, T init, T ident, uint cbits, uint xbits) {
+        using C = SellCfg;
+        uint&      s_next = *s_next_p;
+        const bool always = op_select == SPLAHIP_ALWAYS;
+#ifdef SPLAHIP_SELL_TIMING
+        unsigned long long t_entry = 0;
+        SELL_NOW(t_entry)
+#endif
+        if (threadIdx.x == 0) s_next = C::kWaves;
+        {// the bitmap's LDS-resident words, 16 bytes per lane
+            const uint4* src = reinterpret_cast<const uint4*>(vbits);
+            uint4*       dst = reinterpret_cast<uint4*>(s_bits);
+            for (uint q = threadIdx.x; q < C::kBitWords / 4; q += C::kTpb) dst[q] = src[q];
+        }
+        static_assert(C::kBitWords % 4 == 0, "the bitmap is copied in quads");
+        __syncthreads();
+        const T    pc   = mult(from_bits<T>(xbits), from_bits<T>(cbits));
+        const uint lane = lane_id();
+        const uint w    = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+        auto phys = [&](uint q) -> uint { return q < n_slices ? (sorder ? sorder[q] : q) : n_slices; };
+        auto take_slice = [&]() -> uint {
+            uint ord = 0;
+            if (lane == 0) ord = atomicAdd(&s_next, 1u);
+            return phys(blockIdx.x + __builtin_amdgcn_readfirstlane(ord) * gridDim.x);
+        };
+        auto sel_word = [&](uint rowinfo, uint len) -> uint { return (always || len == 0) ? 0u : selbits[(rowinfo & ~C::kPartial) >> 5]; };
+        const unsigned char* lds = reinterpret_cast<const unsigned char*>(s_bits);
+        auto                 hit = [&](uint code, uint word) -> uint { return (word >> (code & 31u)) & 1u; };
+        auto                 lds_word = [&](uint code) -> uint { return *reinterpret_cast<const uint*>(lds + (code >> 5)); };
+
+        uint sA = phys(blockIdx.x + w * gridDim.x);
+        if (sA >= n_slices) return;
+        uint rowA = vrow[sA * kWave + lane], lenA = vlen[sA * kWave + lane], baseA = off[sA];
+        uint sB    = take_slice();
+        bool moreB = sB < n_slices;
+        uint rowB = 0, lenB = 0, baseB = 0;
+        if (moreB) {
+            rowB  = vrow[sB * kWave + lane];
+            lenB  = vlen[sB * kWave + lane];
+            baseB = off[sB];
+        }
+        uint wordA = sel_word(rowA, lenA);
+        uint sC    = moreB ? take_slice() : n_slices;// (resolved a slice ahead of its header: see sell_mxv_body)
+#ifdef SPLAHIP_SELL_TIMING
+        unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, acc0 = 0, acc1 = 0, acc2 = 0, nsl = 0, t_begin = 0, n_live = 0, n_rounds = 0, n_width = 0, n_lanes = 0;
+        SELL_NOW(t_begin)
+#endif
+        while (true) {
+            SELL_NOW(t_a)
+            // ---- slice A: who is selected, how far the longest selected lane goes
+            const uint row      = rowA & ~C::kPartial;
+            const bool selected = lenA != 0 && (always || ((wordA >> (rowA & 31u)) & 1u) != 0);
+            const uint mylen    = selected ? lenA : 0u;
+            const unsigned long long live = __ballot(selected);
+            const uint base  = __builtin_amdgcn_readfirstlane(baseA);
+            const uint width = live ? __builtin_amdgcn_readlane(mylen, __ffsll((long long) live) - 1) : 0u;// lanes are sorted by length
+            // C's header, D's id and B's selection word travel with A's entries
+            uint       rowC = 0, lenC = 0, baseC = 0;
+            const bool moreC = moreB && sC < n_slices;
+            if (moreC) {
+                rowC  = vrow[sC * kWave + lane];
+                lenC  = vlen[sC * kWave + lane];
+                baseC = off[sC];
+            }
+            uint sD = n_slices;
+            if (moreC) sD = take_slice();
+            uint wordB = 0;
+            if (moreB) wordB = sel_word(rowB, lenB);
+
+            SELL_NOW(t_b)
+            if (live != 0ull) {
+#ifdef SPLAHIP_SELL_TIMING
+                n_live += 1, n_rounds += (width + 3) / 4, n_width += width, n_lanes += __popcll(live);
+#endif
+                const __amdgpu_buffer_rsrc_t rs   = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint*>(Aj2r + base), 0, width * kWave * 4u, 0x00020000);
+                const uint                   voff = selected ? lane * 4u : 0x80000000u;
+                // position t of this lane; s: the uniform part of the byte offset (a scalar register), the rest an immediate
+                auto request = [&](uint s_bytes, uint t_imm) -> uint {
+                    return __builtin_amdgcn_raw_buffer_load_b32(rs, voff + t_imm * (kWave * 4u), (int) s_bytes, 2 /* nt */);
+                };
+                uint hits = 0;
+                if (width <= 16u) {
+                    uint code[16], word[16];
+#pragma unroll
+                    for (uint g = 0; g < 4; ++g)
+                        if (4 * g < width) {
+#pragma unroll
+                            for (uint i = 0; i < 4; ++i) code[4 * g + i] = request(0, 4 * g + i);
+                        }
+#pragma unroll
+                    for (uint g = 0; g < 4; ++g)
+                        if (4 * g < width) {
+#pragma unroll
+                            for (uint i = 0; i < 4; ++i) word[4 * g + i] = lds_word(code[4 * g + i]);
+                        }
+#pragma unroll
+                    for (uint g = 0; g < 4; ++g)
+                        if (4 * g < width) {
+#pragma unroll
+                            for (uint i = 0; i < 4; ++i) hits += hit(code[4 * g + i], word[4 * g + i]);
+                        }
+                } else {
+                    constexpr uint D = 32, NB = 8;// entry t lives in window slot t % D
+                    uint           q[D];
+#pragma unroll
+                    for (uint u = 0; u < D; ++u) q[u] = request((u & ~(NB - 1u)) * (kWave * 4u), u & (NB - 1u));
+                    uint e = 0;
+                    for (; e + D < width; e += D) {
+#pragma unroll
+                        for (uint b = 0; b < D; b += NB) {
+                            uint addr[NB], sh[NB], word[NB];
+#pragma unroll
+                            for (uint i = 0; i < NB; ++i) {
+                                addr[i] = q[b + i] >> 5;
+                                sh[i]   = q[b + i] & 31u;
+                            }
+#pragma unroll
+                            for (uint i = 0; i < NB; ++i) asm volatile("" : "+v"(addr[i]), "+v"(sh[i])::"memory");// (pins the lines above ahead of the requests)
+#pragma unroll
+                            for (uint i = 0; i < NB; ++i) q[b + i] = request((e + D + b) * (kWave * 4u), i);
+#pragma unroll
+                            for (uint i = 0; i < NB; ++i) word[i] = *reinterpret_cast<const uint*>(lds + addr[i]);
+#pragma unroll
+                            for (uint i = 0; i < NB; ++i) hits += (word[i] >> sh[i]) & 1u;
+                        }
+                    }
+#pragma unroll
+                    for (uint b = 0; b < D; b += NB) {
+                        uint word[NB];
+#pragma unroll
+                        for (uint i = 0; i < NB; ++i) word[i] = lds_word(q[b + i]);
+#pragma unroll
+                        for (uint i = 0; i < NB; ++i) hits += hit(q[b + i], word[i]);
+                    }
+                }
+                SELL_NOW(t_c)
+                if ((__builtin_amdgcn_readfirstlane(rowA) & C::kPartial) != 0) {// a row-exclusive slice: 64 lanes of ONE row
+                    const uint total = wave_sum(hits);
+                    const T    t     = fold_repeated(ident, pc, total, add);
+                    if (lane == 0 && total != 0 && to_bits(t) != to_bits(ident)) atomic_fold(r + row, t, functor_op(add));
+                } else if (selected && hits != 0) {
+                    const T t = fold_repeated(init, pc, hits, add);
+                    if (to_bits(t) != to_bits(init)) r[row] = t;// (the prep pass wrote init to every row)
+                }
+            }
+#ifdef SPLAHIP_SELL_TIMING
+            SELL_NOW(t_d)
+            if (live == 0ull) t_c = t_b;
+            acc0 += t_b - t_a, acc1 += t_c - t_b, acc2 += t_d - t_c, nsl += 1;
+            if (!moreB && lane == 0) {
+                const uint gw = blockIdx.x * C::kWaves + w;
+                if (gw < 4096) {
+                    g_sell_t[0][gw] = acc0, g_sell_t[1][gw] = acc1, g_sell_t[2][gw] = acc2, g_sell_t[3][gw] = nsl;
+                    g_sell_t[4][gw] = t_d - t_begin;
+                    g_sell_t[6][gw] = n_live, g_sell_t[7][gw] = n_rounds, g_sell_t[8][gw] = n_width, g_sell_t[9][gw] = n_lanes;
+                    g_sell_t[10][gw] = t_begin - t_entry;
+                }
+            }
+#endif
+            if (!moreB) break;
+            sA = sB, rowA = rowB, lenA = lenB, baseA = baseB, wordA = wordB;
+            sB = sC, moreB = moreC, rowB = rowC, lenB = lenC, baseB = baseC;
+            sC = sD;
         }
     }
 
@@ -583,7 +799,10 @@ namespace splahip {
             }
         }
         __syncthreads();
-        if (s_dec[0] != 0u && Ax2 == nullptr)// structure-only: no value stream, so a group is twice as many entries for the same loads in flight
+        if (s_dec[0] != 0u && s_dec[1] != 0u && Ax2 == nullptr)// all products are one value: the walk only counts set bits
+            sell_frontier_body<T, Mult, Add>(reinterpret_cast<uint*>(s_hot), &s_next, n_slices, vrow, vlen, off, Aj2r, vbits, selbits, sorder, r, mult, add, op_select, init,
+                                             ident, s_dec[2], xbits);
+        else if (s_dec[0] != 0u && Ax2 == nullptr)// structure-only: no value stream, so a group is twice as many entries for the same loads in flight
             sell_mxv_body<T, Mult, Add, true, false, 2 * C::kU>(s_hot, &s_next, n_rows, Ap, n_slices, vrow, vlen, vslot, off, Aj2r, Ax2, reinterpret_cast<const T*>(vbits),
                                                                 C::kBitWords, mask, v, r, partial, mult, add, op_select, init, s_dec[1] != 0u, s_dec[2], vbits, vranked,
                                                                 selbits, sorder, nullptr, ident, xbits);
@@ -606,7 +825,7 @@ namespace splahip {
         const uint k        = block * 256 + threadIdx.x;
         if (k >= n_cold) return;
         const uint rank = cold_rank[k];
-        if (((vbits[rank >> 5] >> (rank & 31u)) & 1u) == 0) return;
+        if (((vbits[(rank + 1u) >> 5] >> ((rank + 1u) & 31u)) & 1u) == 0) return;
         const unsigned long long e = cold_entry[k];
         const uint row = (uint) (e >> 32);
         if (op_select != SPLAHIP_ALWAYS && !eval_sel(op_select, mask[row])) return;

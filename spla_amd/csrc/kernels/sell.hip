@@ -161,7 +161,7 @@ namespace {
                 x              = Ax[k0 + e * stride];
             }
             Aj2[base + e * kWave + lane]  = j;
-            Aj2r[base + e * kWave + lane] = min(rank, SC::kBitsLds);// colder columns: the never-set bit (their entries are in the cold list)
+            Aj2r[base + e * kWave + lane] = SC::bits_code(rank);// padding and colder columns (their entries are in the cold list): code 0
             Ax2[base + e * kWave + lane]  = x;
         }
     }
@@ -169,7 +169,7 @@ namespace {
         const uint k = blockIdx.x * 256 + threadIdx.x;
         if (k < count) {
             Aj2[first + k]  = SC::kHotFlag;
-            Aj2r[first + k] = SC::kBitsLds;
+            Aj2r[first + k] = 0;
             Ax2[first + k]  = 0;
         }
     }
@@ -572,7 +572,7 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     own(&g->d_rank_of, n_cols);
     own(&g->d_vranked, n_cols);
     // bitmap of v in rank order: at least the kHot words every workgroup copies to LDS, then the statistics (4 words per sell_vprep workgroup)
-    g->n_bit_words = ((std::max<uint32_t>((n_cols + 31) / 32, SC::kHot) + 3u) & ~3u);
+    g->n_bit_words = ((std::max<uint32_t>(n_cols / 32 + 1, SC::kHot) + 3u) & ~3u);// bits 1 .. n_cols (bit rank + 1)
     own(&g->d_vbits, 2 * (size_t) g->n_bit_words + 4 * SC::kPrepBlocks + 4);
     if (e == hipSuccess) e = hipMemsetAsync(g->d_vbits, 0, sizeof(uint32_t) * 2 * (size_t) g->n_bit_words, s);// both bitmaps start clear
     own(&g->d_selbits, 2 * ((size_t) n_rows / 64 + 8));// 64-bit words, whole 256-row wave steps
@@ -663,9 +663,9 @@ extern "C" int splahip_csr_plan_sell_values(splahip_plan plan, int* uniform, uin
 }
 
 #ifdef SPLAHIP_SELL_TIMING
-// DIAGNOSTIC BUILD ONLY: copy out the per-wave slice timings of the last sliced-ELL launch (6 x 4096 64-bit words)
+// DIAGNOSTIC BUILD ONLY: copy out the per-wave slice timings of the last sliced-ELL launch (12 x 4096 64-bit words)
 extern "C" int splahip_debug_sell_timing(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(splahip::g_sell_t), sizeof(unsigned long long) * 6 * 4096) == hipSuccess ? SPLAHIP_OK : SPLAHIP_ERROR;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(splahip::g_sell_t), sizeof(unsigned long long) * 12 * 4096) == hipSuccess ? SPLAHIP_OK : SPLAHIP_ERROR;
 }
 #endif
 
