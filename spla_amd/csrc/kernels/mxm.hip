@@ -198,6 +198,20 @@ namespace splahip {
     // mxmT_masked
     // =============================================================================================================
     constexpr uint kHeavy = 192;// len(A row) + len(B row) above which a mask entry is handled by a wavefront
+    // row form of the heavy entries (mxmT_row_kernel)
+    constexpr uint kRowCap     = 4095;// longest A row a wavefront stages in its LDS (4096 words with the padding)
+    constexpr uint kRowSmall   = 1023;// rows up to here use the small LDS layout (8 KB per wavefront, 20 wavefronts per CU)
+    constexpr uint kRowPiece   = 512; // cost units (about a wave step each) per work item
+    constexpr uint kRowPending = 2;   // keep[e]: the entry waits for the row kernel
+    constexpr uint kRowHits    = 128; // matches recorded per wavefront before their value words are fetched
+    constexpr uint kRowQueue   = 128; // filter candidates waiting for the exact search
+    __host__ __device__ constexpr uint row_lds_words(uint cap) { return (cap + 1) + (cap + 1) / 2 + 2 * kRowQueue + 2 * kRowHits; }// columns, filter bits, queue, matches
+    __host__ __device__ __forceinline__ bool row_streams(uint len_a, uint len_b) { return len_b <= 16u * len_a; }
+    __host__ __device__ __forceinline__ uint row_entry_cost(uint len_a, uint len_b) {
+        return 1u + (row_streams(len_a, len_b) ? (len_b + 63u) / 64u : (len_a + 3u) / 4u);
+    }
+    __global__ void len_sum_kernel(const uint* __restrict__ x, uint n, uint* __restrict__ chunk);
+    __global__ void len_scan_kernel(const uint* __restrict__ x, uint n, const uint* __restrict__ chunk, uint n_chunks, uint* __restrict__ out);
 
     template<typename T, class Mult, class Add>
     __global__ __launch_bounds__(256) void mxmT_entry_kernel(uint n_rows, uint n_entries,
@@ -206,21 +220,27 @@ namespace splahip {
                                                              const uint* __restrict__ Bp, const uint* __restrict__ Bj, const T* __restrict__ Bx,
                                                              T* __restrict__ val, uint* __restrict__ keep,
                                                              uint* __restrict__ heavy_count, uint* __restrict__ heavy_list,
-                                                             Mult mult, Add add, int op_select, T init) {
+                                                             Mult mult, Add add, int op_select, T init, uint row_cap, uint* __restrict__ cost) {
         const uint e = blockIdx.x * 256 + threadIdx.x;
         if (e >= n_entries) return;
         T    r    = init;
         bool done = true;
+        uint c    = 0;
         if (eval_sel(op_select, Mx[e])) {
             const uint i  = row_of_entry(Mp, n_rows, e);
             const uint j  = Mj[e];
             uint       ka = Ap[i], ea = Ap[i + 1];
             uint       kb = Bp[j], eb = Bp[j + 1];
             if ((ea - ka) + (eb - kb) > kHeavy && ea > ka && eb > kb) {
-                const uint slot          = atomicAdd(heavy_count, 1u);
-                heavy_list[2 * slot]     = e;
-                heavy_list[2 * slot + 1] = i;// the row travels with the entry: the heavy kernel need not search Mp again (20 dependent loads)
-                done                                   = false;
+                if (ea - ka <= row_cap) {// row form (mxmT_row_kernel): A[i, :] staged in LDS once for a run of the row's entries
+                    keep[e] = kRowPending;
+                    c       = row_entry_cost(ea - ka, eb - kb);
+                } else {
+                    const uint slot          = atomicAdd(heavy_count, 1u);
+                    heavy_list[2 * slot]     = e;
+                    heavy_list[2 * slot + 1] = i;// the row travels with the entry: the heavy kernel need not search Mp again (20 dependent loads)
+                }
+                done = false;
             } else {
                 while (ka < ea && kb < eb) {
                     const uint ca = Aj[ka], cb = Bj[kb];
@@ -240,6 +260,214 @@ namespace splahip {
             val[e]  = r;
             keep[e] = differs(r, init) ? 1u : 0u;
         }
+        if (cost) cost[e] = c;
+    }
+
+    // ---- heavy entries, ROW FORM.  All heavy entries (i, j) of a mask row share A[i, :]; the per-entry kernel below searches every
+    // column of the shorter row in the longer one with DEPENDENT global loads (R-MAT 20 triangle form: 7.1 G L1-to-L2 requests and 61 GB
+    // of fabric traffic per call — profiles/r02_pmc_tc_mxmT.json: the L2's request rate is what bounds it).  Here a WAVEFRONT takes a
+    // work item = (row i, a run of its heavy entries worth ~kRowPiece wave steps) and, once per item, builds in its own LDS
+    //   * the columns of A[i, :] (sorted, padded to a power of two with 0xFFFFFFFF), and
+    //   * a one-hash FILTER of them, 16 bits per column slot (a column outside the row passes it with probability <= 1/16).
+    // Then, per entry (the 64 entries of a batch fetch j and B's row bounds lane-parallel — one dependent chain per batch, not per
+    // entry):
+    //   * len(B[j, :]) <= 16 len(A[i, :]):  B[j, :] STREAMS by, 4 x 64 coalesced column words per step; a word costs one LDS read (its
+    //     filter bit).  The few that pass are queued (ballot compaction) and searched exactly, 64 at a time, by a branch-free binary
+    //     search over the LDS columns — so the 12-level search runs on full wavefronts of candidates, not on every streamed word;
+    //   * else: the lanes take the LDS-resident columns of A[i, :] and search each in B[j, :] (global).
+    // Matches are only RECORDED (position in A[i, :], position in B); their value words are fetched kRowHits at a time with all loads of
+    // a batch in flight.  No workgroup barrier anywhere (a workgroup's wavefronts are independent); items are cut by a prefix sum of
+    // per-entry costs so a hub row's 20,000 entries spread over many wavefronts.  Needs a commutative, associative op_add (the queue
+    // reorders the products); anything else stays with the per-entry kernel.
+    __device__ __forceinline__ uint pow2_above(uint x) {// smallest power of two > x
+        return 2u << (31u - __builtin_clz(x | 1u));
+    }
+    template<typename T, class Mult, class Add, uint CAP, uint WAVES>
+    __global__ __launch_bounds__(WAVES* kWave) void mxmT_row_kernel(uint n_rows, uint item0, uint n_items, const uint* __restrict__ piece_first,
+                                                                    const uint* __restrict__ item_row,
+                                                                    const uint* __restrict__ cost_before, const uint* __restrict__ Mp, const uint* __restrict__ Mj,
+                                                                    const uint* __restrict__ Ap, const uint* __restrict__ Aj, const T* __restrict__ Ax,
+                                                                    const uint* __restrict__ Bp, const uint* __restrict__ Bj, const T* __restrict__ Bx,
+                                                                    T* __restrict__ val, uint* __restrict__ keep, Mult mult, Add add, T init) {
+        extern __shared__ uint s_row[];
+        const uint      wv = threadIdx.x / kWave, lane = lane_id();
+        if (blockIdx.x * WAVES + wv >= n_items) return;// (whole wavefronts leave: nothing below synchronises across wavefronts)
+        const uint  item  = item0 + blockIdx.x * WAVES + wv;
+        uint* const cols  = s_row + wv * row_lds_words(CAP);
+        uint* const bits  = cols + (CAP + 1);
+        uint* const queue = bits + (CAP + 1) / 2;
+        uint* const hits  = queue + 2 * kRowQueue;
+        const uint  i     = item_row[item];
+        const uint m0 = Mp[i], m1 = Mp[i + 1];
+        const uint c0 = cost_before[m0] + (item - piece_first[i]) * kRowPiece, c1 = min(cost_before[m1], c0 + kRowPiece);
+        auto       first_at = [&](uint c) {// first entry of the row whose cost interval starts at or after c
+            uint lo = m0, hi = m1;
+            while (lo < hi) {
+                const uint mid = lo + ((hi - lo) >> 1);
+                if (cost_before[mid] < c) lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            return lo;
+        };
+        const uint e0 = first_at(c0), e1 = c1 == cost_before[m1] ? m1 : first_at(c1);
+        const uint sa = Ap[i], len_a = Ap[i + 1] - sa;
+        const uint pad = pow2_above(len_a);// > len_a: the last word is padding, so a lower bound always exists
+        const uint filter_mask = 16u * pad - 1u;// a filter of 16 pad bits, indexed by the column's low bits (no multiply in the stream loop)
+        auto       filter_bit  = [&](uint col) -> uint { return col & filter_mask; };
+        for (uint t = lane; t < pad / 2; t += kWave) bits[t] = 0;
+        for (uint t = lane; t < pad; t += kWave) cols[t] = t < len_a ? Aj[sa + t] : 0xFFFFFFFFu;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint t = lane; t < len_a; t += kWave) {
+            const uint h = filter_bit(cols[t]);
+            atomicOr(&bits[h >> 5], 1u << (h & 31u));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        auto find = [&](uint col) -> uint {// lower bound of col among cols[0, pad)
+            uint pos = 0;
+            for (uint step = pad >> 1; step != 0; step >>= 1)
+                if (cols[pos + step - 1] < col) pos += step;
+            return pos;
+        };
+        auto rank_in = [&](unsigned long long m) -> uint { return __builtin_amdgcn_mbcnt_hi((uint) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint) m, 0u)); };
+
+        for (uint eb0 = e0; eb0 < e1; eb0 += kWave) {
+            // this batch's entries, a lane each: pending?  j, B's row bounds
+            uint my_sb = 0, my_eb = 0;
+            bool my_pending = false;
+            if (eb0 + lane < e1 && keep[eb0 + lane] == kRowPending) {
+                const uint j = Mj[eb0 + lane];
+                my_sb        = Bp[j];
+                my_eb        = Bp[j + 1];
+                my_pending   = true;
+            }
+            unsigned long long todo = __ballot(my_pending);
+            while (todo != 0ull) {
+                const uint l = (uint) __ffsll((long long) todo) - 1u;
+                todo &= todo - 1ull;
+                const uint e  = eb0 + l;
+                const uint sb = __builtin_amdgcn_readlane(my_sb, l), eb = __builtin_amdgcn_readlane(my_eb, l);
+                T          acc = init;
+                bool       has = false;
+                uint       n_hits = 0, n_queue = 0;// (uniform)
+                auto flush = [&]() {// fetch the value words of the recorded matches, fold their products
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    for (uint h0 = 0; h0 < n_hits; h0 += kWave) {
+                        const uint h = h0 + lane;
+                        if (h < n_hits) {
+                            const T p = mult(Ax[sa + hits[2 * h]], Bx[hits[2 * h + 1]]);
+                            acc       = has ? add(acc, p) : p;
+                            has       = true;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    n_hits = 0;
+                };
+                auto record = [&](bool hit, uint ia, uint kb) {
+                    const unsigned long long m = __ballot(hit);
+                    if (m == 0ull) return;
+                    const uint cnt = (uint) __popcll(m);
+                    if (n_hits + cnt > kRowHits) flush();
+                    if (hit) {
+                        const uint slot    = n_hits + rank_in(m);
+                        hits[2 * slot]     = ia;
+                        hits[2 * slot + 1] = kb;
+                    }
+                    n_hits += cnt;
+                };
+                auto search_top = [&](uint count) {// exact search of the newest `count` (<= 64) queued candidates
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const uint q   = n_queue - count + lane;
+                    bool       hit = false;
+                    uint       pos = 0, kb = 0;
+                    if (lane < count) {
+                        const uint col = queue[2 * q];
+                        kb             = queue[2 * q + 1];
+                        pos            = find(col);
+                        hit            = cols[pos] == col;
+                    }
+                    n_queue -= count;
+                    record(hit, pos, kb);
+                };
+                if (row_streams(len_a, eb - sb)) {
+                    constexpr uint U = 4;
+                    uint           nxt[U];
+                    auto           load_step = [&](uint base) {// (a position behind the row's end reads the row's last word: no branch, and masked below)
+#pragma unroll
+                        for (uint u = 0; u < U; ++u) nxt[u] = Bj[min(base + u * kWave + lane, eb - 1u)];
+                    };
+                    load_step(sb);
+                    for (uint base = sb; base < eb; base += U * kWave) {
+                        uint col[U], word[U];
+#pragma unroll
+                        for (uint u = 0; u < U; ++u) col[u] = nxt[u];
+                        if (base + U * kWave < eb) load_step(base + U * kWave);// the next step's words travel while this step is filtered
+#pragma unroll
+                        for (uint u = 0; u < U; ++u) word[u] = bits[filter_bit(col[u]) >> 5];
+#pragma unroll
+                        for (uint u = 0; u < U; ++u) {
+                            const uint k    = base + u * kWave + lane;
+                            const bool cand = k < eb && ((word[u] >> (filter_bit(col[u]) & 31u)) & 1u) != 0;
+                            const unsigned long long m = __ballot(cand);
+                            if (m != 0ull) {
+                                if (cand) {
+                                    const uint slot     = n_queue + rank_in(m);
+                                    queue[2 * slot]     = col[u];
+                                    queue[2 * slot + 1] = k;
+                                }
+                                n_queue += (uint) __popcll(m);
+                                if (n_queue >= kWave) search_top(kWave);
+                            }
+                        }
+                    }
+                    if (n_queue) search_top(n_queue);
+                } else {
+                    for (uint t0 = 0; t0 < len_a; t0 += kWave) {
+                        const uint t   = t0 + lane;
+                        bool       hit = false;
+                        uint       lo  = sb;
+                        if (t < len_a) {
+                            const uint col = cols[t];
+                            uint       hi  = eb;
+                            while (lo < hi) {
+                                const uint mid = lo + ((hi - lo) >> 1);
+                                if (Bj[mid] < col) lo = mid + 1;
+                                else
+                                    hi = mid;
+                            }
+                            hit = lo < eb && Bj[lo] == col;
+                        }
+                        record(hit, t, lo);
+                    }
+                }
+                flush();
+                wave_reduce_ordered(acc, has, add);
+                if (lane == 0) {
+                    const T r = has ? add(init, acc) : init;
+                    val[e]    = r;
+                    keep[e]   = differs(r, init) ? 1u : 0u;
+                }
+            }
+        }
+    }
+    // work items of a mask row in its size class (0: A row <= kRowSmall, 1: up to kRowCap): its pending cost in pieces of kRowPiece.
+    // pieces[c * n_rows + i]; the prefix sum over both halves gives class 0's items first.
+    __global__ __launch_bounds__(256) void mxmT_row_pieces_kernel(uint n_rows, const uint* __restrict__ Mp, const uint* __restrict__ Ap,
+                                                                  const uint* __restrict__ cost_before, uint* __restrict__ pieces) {
+        const uint i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= n_rows) return;
+        const uint n = (cost_before[Mp[i + 1]] - cost_before[Mp[i]] + kRowPiece - 1) / kRowPiece;
+        const uint c = (Ap[i + 1] - Ap[i]) <= kRowSmall ? 0u : 1u;
+        pieces[c * n_rows + i]        = n;
+        pieces[(1u - c) * n_rows + i] = 0;
+    }
+
+    __global__ __launch_bounds__(256) void mxmT_row_items_kernel(uint n_rows, const uint* __restrict__ piece_first, uint* __restrict__ item_row) {
+        const uint v = blockIdx.x * 256 + threadIdx.x;// class * n_rows + row
+        if (v >= 2 * n_rows) return;
+        const uint i = v < n_rows ? v : v - n_rows;
+        for (uint t = piece_first[v]; t < piece_first[v + 1]; ++t) item_row[t] = i;
     }
 
     // one wavefront per heavy mask entry.  TREE: lanes take contiguous pieces of the shorter row (ascending column), look every
@@ -276,6 +504,16 @@ namespace splahip {
             for (uint k = ks; k < ke; ++k) {
                 const uint col = Sj[k];
                 uint       hi  = le;
+                if (k != ks) {// behind the lane's first column the next match is near: gallop from the last lower bound (steps ~ 2 log2(gap), and
+                              // the probes stay in the lines the previous search touched) instead of halving the whole rest of the row
+                    uint step = 4;
+                    hi        = lo;
+                    while (hi < le && Lj[hi] < col) {
+                        lo = hi + 1;
+                        hi = min(le, hi + step);
+                        step <<= 1;
+                    }
+                }
                 while (lo < hi) {
                     const uint mid = lo + ((hi - lo) >> 1);
                     if (Lj[mid] < col) lo = mid + 1;
@@ -325,6 +563,21 @@ namespace splahip {
         if (i <= n_rows) Rp[i] = rank[Mp[i]];
     }
 
+    // out[k] = x[0] + ... + x[k - 1] for k in [0, n]
+    static hipError_t values_exclusive_scan(const uint* x, uint n, uint* out, hipStream_t s) {
+        if (n == 0) return hipMemsetAsync(out, 0, sizeof(uint), s);
+        const uint n_chunks = (n + 1023u) / 1024u;
+        DevBuf     chunk;
+        hipError_t e = chunk.alloc(sizeof(uint) * (size_t) (n_chunks + 1));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(len_sum_kernel, dim3(n_chunks), dim3(256), 0, s, x, n, chunk.as<uint>());
+        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk.as<uint>(), n_chunks);
+        hipLaunchKernelGGL(len_scan_kernel, dim3(n_chunks), dim3(256), 0, s, x, n, chunk.as<uint>(), n_chunks, out);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(s);// (the chunk sums go out of scope)
+        return e;
+    }
+
     template<typename T>
     int mxmT_typed(uint n_rows, uint n_entries, const uint* Mp, const uint* Mj, const void* Mx, const uint* Ap, const uint* Aj, const void* Ax,
                    const uint* Bp, const uint* Bj, const void* Bx, uint* Rp, uint** Rj, void** Rx, uint* h_nnz,
@@ -347,13 +600,53 @@ namespace splahip {
         SPLAHIP_TRY(hcount.alloc(sizeof(uint)));
         SPLAHIP_TRY(hlist.alloc(sizeof(uint) * 2 * (size_t) n_entries));
         SPLAHIP_TRY(hipMemsetAsync(hcount.p, 0, sizeof(uint), s));
+        // the row form (mxmT_row_kernel) regroups and reorders the products: op_add must be associative and commutative.  OPT-IN with
+        // SPLAHIP_MXMT_ROW=1: on the R-MAT 20 triangle form it is bit-identical and, so far, no faster than the galloping per-entry kernel
+        // (35.5 ms against 33.1 ms per call; rows <= 1023: 18.4 ms, longer rows 11.0 ms — 12 M entries of ~650 streamed words each leave the
+        // per-entry fixed costs, one round trip for the matches' value words and an in-order reduction, as large as the stream itself)
+        const char* row_env  = std::getenv("SPLAHIP_MXMT_ROW");
+        const bool  row_form = fold_is_reorderable(op_add, TypeId<T>::value) && binop_is_commutative(op_add) && row_env && row_env[0] == '1';
+        DevBuf      cost, cost_before, pieces, piece_first;
+        if (row_form) {
+            SPLAHIP_TRY(cost.alloc(sizeof(uint) * (size_t) n_entries));
+            SPLAHIP_TRY(cost_before.alloc(sizeof(uint) * ((size_t) n_entries + 1)));
+            SPLAHIP_TRY(pieces.alloc(sizeof(uint) * 2 * (size_t) n_rows));
+            SPLAHIP_TRY(piece_first.alloc(sizeof(uint) * (2 * (size_t) n_rows + 1)));
+        }
         hipLaunchKernelGGL((mxmT_entry_kernel<T, DynBin, DynBin>), dim3((n_entries + 255) / 256), dim3(256), 0, s, n_rows, n_entries, Mp, Mj,
                            static_cast<const T*>(Mx), Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(),
-                           keep.as<uint>(), hcount.as<uint>(), hlist.as<uint>(), DynBin(op_mult), DynBin(op_add), op_select, init);
+                           keep.as<uint>(), hcount.as<uint>(), hlist.as<uint>(), DynBin(op_mult), DynBin(op_add), op_select, init, row_form ? kRowCap : 0u,
+                           row_form ? cost.as<uint>() : nullptr);
         SPLAHIP_TRY(hipGetLastError());
-        uint h_heavy = 0;
+        uint h_heavy = 0, h_first[2] = {0, 0};
+        if (row_form) {
+            SPLAHIP_TRY(values_exclusive_scan(cost.as<uint>(), n_entries, cost_before.as<uint>(), s));
+            hipLaunchKernelGGL(mxmT_row_pieces_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, n_rows, Mp, Ap, cost_before.as<uint>(), pieces.as<uint>());
+            SPLAHIP_TRY(values_exclusive_scan(pieces.as<uint>(), 2 * n_rows, piece_first.as<uint>(), s));
+            SPLAHIP_TRY(hipMemcpyAsync(&h_first[0], piece_first.as<uint>() + n_rows, sizeof(uint), hipMemcpyDeviceToHost, s));
+            SPLAHIP_TRY(hipMemcpyAsync(&h_first[1], piece_first.as<uint>() + 2 * (size_t) n_rows, sizeof(uint), hipMemcpyDeviceToHost, s));
+        }
         SPLAHIP_TRY(hipMemcpyAsync(&h_heavy, hcount.p, sizeof(uint), hipMemcpyDeviceToHost, s));
         SPLAHIP_TRY(hipStreamSynchronize(s));
+        DevBuf item_row;
+        if (h_first[1]) {
+            SPLAHIP_TRY(item_row.alloc(sizeof(uint) * (size_t) h_first[1]));
+            hipLaunchKernelGGL(mxmT_row_items_kernel, dim3((2 * n_rows + 255) / 256), dim3(256), 0, s, n_rows, piece_first.as<uint>(), item_row.as<uint>());
+        }
+        if (h_first[0]) {// rows up to kRowSmall: 8 KB of LDS per wavefront
+            constexpr uint W = 4, kLds = W * row_lds_words(kRowSmall) * 4;
+            hipLaunchKernelGGL((mxmT_row_kernel<T, DynBin, DynBin, kRowSmall, W>), dim3((h_first[0] + W - 1) / W), dim3(W * kWave), kLds, s, n_rows, 0u, h_first[0],
+                               piece_first.as<uint>(), item_row.as<uint>(), cost_before.as<uint>(), Mp, Mj, Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx),
+                               val.as<T>(), keep.as<uint>(), DynBin(op_mult), DynBin(op_add), init);
+            SPLAHIP_TRY(hipGetLastError());
+        }
+        if (h_first[1] > h_first[0]) {// rows up to kRowCap: 26 KB per wavefront, two wavefronts per workgroup
+            constexpr uint W = 2, kLds = W * row_lds_words(kRowCap) * 4;
+            hipLaunchKernelGGL((mxmT_row_kernel<T, DynBin, DynBin, kRowCap, W>), dim3((h_first[1] - h_first[0] + W - 1) / W), dim3(W * kWave), kLds, s, n_rows, h_first[0],
+                               h_first[1] - h_first[0], piece_first.as<uint>() + n_rows, item_row.as<uint>(), cost_before.as<uint>(), Mp, Mj, Ap, Aj, static_cast<const T*>(Ax), Bp, Bj,
+                               static_cast<const T*>(Bx), val.as<T>(), keep.as<uint>(), DynBin(op_mult), DynBin(op_add), init);
+            SPLAHIP_TRY(hipGetLastError());
+        }
         if (h_heavy) {
             const uint grid = (h_heavy + 3) / 4;
             if (fold_is_reorderable(op_add, TypeId<T>::value))

@@ -64,6 +64,30 @@ def test_mxmT_masked_vs_oracle(oracle, t):
         _same_csr(_host3(got, t), want, t, exact, f"mxmT {t} {mul}/{add} {sel}")
 
 
+@pytest.mark.parametrize("t", ["INT", "UINT", "FLOAT"])
+def test_mxmT_row_form_vs_oracle(oracle, t, monkeypatch):
+    """The opt-in row form of the heavy mask entries (SPLAHIP_MXMT_ROW=1: A[i, :] in a wavefront's LDS with a one-hash filter, B[j, :]
+    streamed against it — mxm.hip: mxmT_row_kernel).  Rows on both sides of its two LDS layouts (<= 1023 / <= 4095 entries), rows it leaves
+    to the per-entry kernel (> 4095), B rows far longer than the A row (searched, not streamed), and an op_add it must refuse
+    (FIRST is not commutative)."""
+    from spla_amd import kernels
+    monkeypatch.setenv("SPLAHIP_MXMT_ROW", "1")
+    rng = np.random.default_rng(59)
+    m, k, n = 260, 9000, 300
+    A = random_csr(rng, m, k, 40, t, skew=True, long_rows=6, long_len=900)
+    A2 = random_csr(rng, m, k, 40, t, skew=True, long_rows=4, long_len=3000)
+    A3 = random_csr(rng, m, k, 40, t, skew=True, long_rows=2, long_len=5000)
+    B = random_csr(rng, n, k, 60, t, skew=True, long_rows=8, long_len=7000)
+    Mk = random_csr(rng, m, n, 120, t)
+    Mk = (Mk[0], Mk[1], random_mask(rng, len(Mk[1]), t))
+    for Am in (A, A2, A3):
+        for (mul, add, init), sel in zip(CASES + [("MULT", "FIRST", 0)], ["GTZERO", "ALWAYS", "EQZERO", "NQZERO", "ALWAYS", "GEZERO", "ALWAYS"]):
+            want = oracle.mxmT_masked(t, m, Mk, Am, B, mul, add, sel, init)
+            got = kernels.mxmT_masked(t, m, _dev3(Mk, t), _dev3(Am, t), _dev3(B, t), mul, add, sel, init)
+            exact = not (t == "FLOAT" and add in ("PLUS", "MULT"))
+            _same_csr(_host3(got, t), want, t, exact, f"mxmT row form {t} {mul}/{add} {sel}")
+
+
 def test_mxm_naive_reference_case():
     # reference tests/test_mxm.cpp:33-94: 3x4 . 4x2 fp32 known answer
     from spla_amd import api
