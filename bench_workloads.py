@@ -53,10 +53,27 @@ def _line(metric, unit, value, args, ms, dtype, config, roofline, extra=None):
     return out
 
 
-def _roof(alg_bytes, ms, kernel):
+def _roof(alg_bytes, ms, kernel, pmc=None):
+    """`pmc`: name of the committed counter pass of this workload (profiles/r02_pmc_<pmc>.json, written by tools/gpu_pmc_r02*.sh in
+    separate rocprofv3 --pmc runs of the same command): its per-call fabric traffic becomes `traffic` (a builder-side figure, like
+    bench.py's pmc_traffic.json — counters need their own pass)."""
     gbs = alg_bytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+    roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": None, "kernel": kernel, "kernel_avg_us": round(ms * 1e3, 2), "algorithmic_bytes": int(alg_bytes)}
+    if pmc:
+        import json
+        from pathlib import Path
+        f = Path(__file__).resolve().parent / "profiles" / f"r02_pmc_{pmc}.json"
+        try:
+            per_call = json.loads(f.read_text()).get("_per_call")
+            if per_call:
+                roof["traffic"] = per_call["traffic_bytes"]
+                roof["traffic_over_algorithmic"] = round(per_call["traffic_bytes"] / alg_bytes, 3)
+                roof["l1_to_l2_read_requests"] = per_call["tcp_tcc_read_req"]
+                roof["traffic_source"] = f"profiles/{f.name}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per call, separate rocprofv3 --pmc passes"
+        except (OSError, ValueError, KeyError):
+            pass
+    return roof
 
 
 def _sym_rmat(scale, edge_factor, seed):
@@ -108,7 +125,8 @@ def pagerank_vxm(args):
                   "form": ("pull over the column-ordered-blocks copy of the transposed matrix (cob_vxm: fp64 LDS accumulation)" if mode == "cob" else
                            "pull over the sliced-ELL copy of the transposed matrix (sell_vxm: value form, vxm mode)" if use_sell else
                            "pull over the transposed CSR (spmv_wavetile, VXM mode)") + " + order-preserving compaction"},
-                 _roof(alg, ms, ("cob_vxm" if mode == "cob" else "sell_vxm" if use_sell else "spmv_wavetile<VXM>") + " + compaction"))
+                 _roof(alg, ms, ("cob_vxm" if mode == "cob" else "sell_vxm" if use_sell else "spmv_wavetile<VXM>") + " + compaction",
+                       pmc="pagerank_vxm" if mode == "cob" and scale == 22 else None))
     if not args.no_verify:
         # structure: identical to the oracle's (same touched columns, index-sorted).  values: the oracle (= the reference) folds
         # every column sequentially in fp32; columns here have up to ~1e5 products, where that sequential fold itself is ~2e-5 off
@@ -196,7 +214,7 @@ def sssp_step(args):
     line = _line("masked SpMV GTEPS (SSSP step)", "GTEPS", nnz / (wall / args.steps) / 1e9, args, wall / args.steps * 1e3, "int32",
                  {"workload": f"exec_mxv_masked PLUS/MIN int32 (min-plus), ALWAYS, init 2^30, weights 1..255, 1/8 of v finite; R-MAT scale {scale} "
                               f"ef {args.edge_factor}, raw labels", "n": n, "nnz": nnz, "work_items": plan.n_items},
-                 _roof(alg, ms, kernels.mxv_variant("INT", "PLUS", "MIN", False, plan)))
+                 _roof(alg, ms, kernels.mxv_variant("INT", "PLUS", "MIN", False, plan), pmc="sssp_step" if mode == "cob" and scale == 24 else None))
     if not args.no_verify:
         orc = pyoracle.Oracle()
         want = orc.mxv_masked("INT", n, n, Ap.cpu().numpy(), Aj.cpu().numpy(), Ax.cpu().numpy(), mask.cpu().numpy(), v.cpu().numpy(), "PLUS", "MIN", "ALWAYS", INF)
@@ -292,7 +310,7 @@ def tc_mxmT(args):
     line = _line("masked SpGEMM (mxmT) G merge-steps/s", "Gsteps/s", work / (wall / args.steps) / 1e9, args, wall / args.steps * 1e3, "int32",
                  {"workload": f"exec_mxmT_masked(L, L, L) MULT/PLUS/GTZERO int32 (triangle-count form), L = strict lower triangle of symmetrised R-MAT "
                               f"scale {scale} ef {args.edge_factor}", "n": n, "nnz_L": nnz, "merge_steps": work, "nnz_R": nnz_r, "triangles": triangles},
-                 _roof(alg, ms, "mxmT_entry + mxmT_heavy + compaction"))
+                 _roof(alg, ms, "mxmT_entry + mxmT_heavy + compaction", pmc="tc_mxmT" if scale == 20 and not os.environ.get("SPLAHIP_MXMT_ROW") else None))
     if not args.no_verify or not args.no_cpu_baseline:
         # restrict the mask to every 64th row: the same call on the sample is checked against the oracle and timed on the reference
         srows = torch.arange(0, n, 64, device="cuda")
@@ -361,7 +379,7 @@ def mxm(args):
                   "form": "row classes (mxm_spa.hip): rows of > 4096 products keep the result row's accumulators in LDS (Gustavson; symbolic pass, then the ranked form "
                           "for rows whose entries fit one block and column blocks for the hubs), lighter rows through ESC; a dense leading corner would run on MFMA "
                           "(none in R-MAT: the 1 K x 1 K hub corner is ~23 % full); timed: the blocking C call", "row_classes": _mxm_info()},
-                 _roof(alg, ms, "mxm_spa (symbolic + numeric) + ESC for the light rows"))
+                 _roof(alg, ms, "mxm_spa (symbolic + numeric) + ESC for the light rows", pmc="mxm" if scale == 18 else None))
     args.steps = args_steps
     if not args.no_verify or not args.no_cpu_baseline:
         srows = torch.arange(0, n, 256, device="cuda")
