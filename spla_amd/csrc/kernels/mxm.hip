@@ -210,6 +210,13 @@ namespace splahip {
     __host__ __device__ __forceinline__ uint row_entry_cost(uint len_a, uint len_b) {
         return 1u + (row_streams(len_a, len_b) ? (len_b + 63u) / 64u : (len_a + 3u) / 4u);
     }
+    // block merge of two rows of comparable length (mxmT_merge_kernel)
+    constexpr uint kMergeTile = 256;// words of the longer row staged per step
+    constexpr uint kMergeHits = 128;// matches recorded per wavefront before their value words are fetched
+    __host__ __device__ __forceinline__ bool merge_streams(uint len_a, uint len_b, uint factor) {
+        const uint mn = len_a < len_b ? len_a : len_b, mx = len_a < len_b ? len_b : len_a;
+        return mx <= factor * mn;
+    }
     __global__ void len_sum_kernel(const uint* __restrict__ x, uint n, uint* __restrict__ chunk);
     __global__ void len_scan_kernel(const uint* __restrict__ x, uint n, const uint* __restrict__ chunk, uint n_chunks, uint* __restrict__ out);
 
@@ -220,13 +227,13 @@ namespace splahip {
                                                              const uint* __restrict__ Bp, const uint* __restrict__ Bj, const T* __restrict__ Bx,
                                                              T* __restrict__ val, uint* __restrict__ keep,
                                                              uint* __restrict__ heavy_count, uint* __restrict__ heavy_list,
-                                                             Mult mult, Add add, int op_select, T init, uint row_cap, uint* __restrict__ cost) {
-        const uint e = blockIdx.x * 256 + threadIdx.x;
-        if (e >= n_entries) return;
+                                                             Mult mult, Add add, int op_select, T init, uint row_cap, uint* __restrict__ cost,
+                                                             uint merge_on, uint merge_factor) {
+        const uint e = blockIdx.x * 256 + threadIdx.x;// (lanes behind the last entry stay for the wave-wide list appends below)
         T    r    = init;
         bool done = true;
-        uint c    = 0;
-        if (eval_sel(op_select, Mx[e])) {
+        uint c    = 0, which = 0, row_i = 0;// which: 1 = search kernel's list, 2 = block merge's list
+        if (e < n_entries && eval_sel(op_select, Mx[e])) {
             const uint i  = row_of_entry(Mp, n_rows, e);
             const uint j  = Mj[e];
             uint       ka = Ap[i], ea = Ap[i + 1];
@@ -235,12 +242,13 @@ namespace splahip {
                 if (ea - ka <= row_cap) {// row form (mxmT_row_kernel): A[i, :] staged in LDS once for a run of the row's entries
                     keep[e] = kRowPending;
                     c       = row_entry_cost(ea - ka, eb - kb);
+                } else if (merge_on && merge_streams(ea - ka, eb - kb, merge_factor)) {// rows of comparable length: the block merge (mxmT_merge_kernel)
+                    which = 2;
                 } else {
-                    const uint slot          = atomicAdd(heavy_count, 1u);
-                    heavy_list[2 * slot]     = e;
-                    heavy_list[2 * slot + 1] = i;// the row travels with the entry: the heavy kernel need not search Mp again (20 dependent loads)
+                    which = 1;
                 }
-                done = false;
+                row_i = i;
+                done  = false;
             } else {
                 while (ka < ea && kb < eb) {
                     const uint ca = Aj[ka], cb = Bj[kb];
@@ -256,6 +264,35 @@ namespace splahip {
                 }
             }
         }
+        // the two lists: ONE 64-bit atomic per WORKGROUP (low word: the search kernel's count, high word: the block merge's) — same-address
+        // atomics retire at ~5 ns each, and two per wavefront were 2.5 ms of this kernel; slots by rank among the workgroup's appenders
+        {
+            __shared__ uint               s_cnt[2][256 / kWave];
+            __shared__ unsigned long long s_base;
+            const unsigned long long      m1 = __ballot(which == 1), m2 = __ballot(which == 2);
+            if (lane_id() == 0) {
+                s_cnt[0][wave_id()] = (uint) __popcll(m1);
+                s_cnt[1][wave_id()] = (uint) __popcll(m2);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned long long add = 0;
+                for (uint w = 0; w < 256 / kWave; ++w) add += (unsigned long long) s_cnt[0][w] | ((unsigned long long) s_cnt[1][w] << 32);
+                s_base = add ? atomicAdd(reinterpret_cast<unsigned long long*>(heavy_count), add) : 0ull;
+            }
+            __syncthreads();
+            if (which != 0) {
+                const uint               l = which - 1u;
+                const unsigned long long m = l ? m2 : m1;
+                uint                     rank = (uint) (s_base >> (32u * l)) + __builtin_amdgcn_mbcnt_hi((uint) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint) m, 0u));
+                for (uint w = 0; w < wave_id(); ++w) rank += s_cnt[l][w];
+                // ONE buffer of n_entries pairs: the search kernel's list grows from its front, the block merge's from its back
+                const uint slot          = l == 0 ? rank : n_entries - 1u - rank;
+                heavy_list[2 * slot]     = e;
+                heavy_list[2 * slot + 1] = row_i;// the row travels with the entry: the heavy kernels need not search Mp again (20 dependent loads)
+            }
+        }
+        if (e >= n_entries) return;
         if (done) {
             val[e]  = r;
             keep[e] = differs(r, init) ? 1u : 0u;
@@ -470,6 +507,136 @@ namespace splahip {
         for (uint t = piece_first[v]; t < piece_first[v + 1]; ++t) item_row[t] = i;
     }
 
+    // ---- heavy entries whose two rows are of comparable length (longer <= 32 x shorter): BLOCK MERGE, one wavefront per entry.
+    // The per-entry search kernel below is bound by the L2's request rate: every probe of every binary search is its own request
+    // (R-MAT 20 triangle form: 4.35 G requests per call even with galloping).  Here both rows are read ONCE, coalesced: 64 words of the
+    // shorter row sit in the lanes, 256 words of the longer row in the wavefront's LDS tile; every lane whose word is <= the tile's last
+    // word finds its lower bound in the tile (8 LDS reads, branch-free) — those lanes are a prefix, the shorter row being sorted; when
+    // the whole block is placed the next 64 words of the shorter row are loaded, otherwise the next tile of the longer row (and the
+    // block is shifted by the number of placed words).  A step therefore retires 64 words of one row or 256 of the other; requests are
+    // the rows' lines, once.  Matches are recorded (position in each row) and their value words fetched kMergeHits at a time; products
+    // fold lane-privately for a commutative op_add, in ascending column order otherwise (an in-order wave reduction per step).  (64 entries
+    // per wavefront with their indices and row bounds fetched lane-parallel was tried: 10.4 against 9.7 ms — one entry per wavefront hides
+    // the metadata chain behind other wavefronts better than it is amortised.)
+    template<typename T, class Mult, class Add>
+    __global__ __launch_bounds__(256) void mxmT_merge_kernel(const uint* __restrict__ count, const uint* __restrict__ list, uint list_last, const uint* __restrict__ Mj,
+                                                             const uint* __restrict__ Ap, const uint* __restrict__ Aj, const T* __restrict__ Ax,
+                                                             const uint* __restrict__ Bp, const uint* __restrict__ Bj, const T* __restrict__ Bx,
+                                                             T* __restrict__ val, uint* __restrict__ keep, Mult mult, Add add, T init, uint commutative) {
+        __shared__ uint s_tile[256 / kWave][kMergeTile];
+        __shared__ uint s_hits[256 / kWave][2 * kMergeHits];
+        const uint      wv = threadIdx.x / kWave, lane = lane_id();
+        const uint      w  = blockIdx.x * (256 / kWave) + wv;
+        if (w >= *count) return;// (whole wavefronts leave: nothing below synchronises across wavefronts)
+        uint* const tile = s_tile[wv];
+        uint* const hits = s_hits[wv];
+        const uint  e = list[2 * (list_last - w)], i = list[2 * (list_last - w) + 1], j = Mj[e];// (this list grows from the buffer's back)
+        const uint  sa = Ap[i], ea = Ap[i + 1], sb = Bp[j], eb = Bp[j + 1];
+        const bool  a_short = (ea - sa) <= (eb - sb);// S = shorter row (in the lanes), L = longer row (in the tile); products keep mult(a, b)
+        const uint* Sj = a_short ? Aj : Bj;
+        const uint* Lj = a_short ? Bj : Aj;
+        const uint  se = a_short ? ea : eb, le = a_short ? eb : ea;
+        uint        ks = a_short ? sa : sb, kl = a_short ? sb : sa;
+        T           acc = init, tot = init;
+        bool        has = false, tot_has = false;
+        uint        n_hits = 0;// (uniform)
+        auto product = [&](uint ps, uint pl) -> T { return a_short ? mult(Ax[ps], Bx[pl]) : mult(Ax[pl], Bx[ps]); };
+        auto flush   = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (uint h0 = 0; h0 < n_hits; h0 += kWave) {
+                const uint h = h0 + lane;
+                if (h < n_hits) {
+                    const T p = product(hits[2 * h], hits[2 * h + 1]);
+                    acc       = has ? add(acc, p) : p;
+                    has       = true;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            n_hits = 0;
+        };
+        // every load is a PREFETCH: the block after this one and the tile after this one are requested a step before they can be needed
+        // (a block shifted past its placed words is put together from the current and the prefetched block with two lane permutes)
+        constexpr uint kTileRegs = kMergeTile / kWave;
+        auto load_block = [&](uint k) -> uint { return k + lane < se ? Sj[k + lane] : 0xFFFFFFFFu; };
+        auto load_tile  = [&](uint k, uint (&reg)[kTileRegs]) {
+#pragma unroll
+            for (uint u = 0; u < kTileRegs; ++u) {
+                const uint t = k + u * kWave + lane;
+                reg[u]       = t < le ? Lj[t] : 0xFFFFFFFFu;
+            }
+        };
+        auto store_tile = [&](const uint (&reg)[kTileRegs]) {
+#pragma unroll
+            for (uint u = 0; u < kTileRegs; ++u) tile[u * kWave + lane] = reg[u];
+        };
+        uint s_col = load_block(ks), s_next = load_block(ks + kWave);
+        uint t_next[kTileRegs];
+        load_tile(kl, t_next);
+        store_tile(t_next);
+        load_tile(kl + kMergeTile, t_next);
+        while (true) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint n_l   = min(kMergeTile, le - kl);
+            const uint l_max = tile[n_l - 1];
+            const bool valid = ks + lane < se;
+            const bool placed = valid && s_col <= l_max;
+            uint       pos    = 0;
+#pragma unroll
+            for (uint step = kMergeTile >> 1; step != 0; step >>= 1)
+                if (tile[pos + step - 1] < s_col) pos += step;
+            const bool hit = placed && tile[pos] == s_col;
+            if (commutative) {
+                const unsigned long long m = __ballot(hit);
+                if (m != 0ull) {
+                    const uint cnt = (uint) __popcll(m);
+                    if (n_hits + cnt > kMergeHits) flush();
+                    if (hit) {
+                        const uint slot    = n_hits + __builtin_amdgcn_mbcnt_hi((uint) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint) m, 0u));
+                        hits[2 * slot]     = ks + lane;
+                        hits[2 * slot + 1] = kl + pos;
+                    }
+                    n_hits += cnt;
+                }
+            } else {// ascending column order: this step's lanes in order, behind what earlier steps gave
+                T    x = init;
+                bool v = hit;
+                if (hit) x = product(ks + lane, kl + pos);
+                wave_reduce_ordered(x, v, add);
+                if (v) tot = tot_has ? add(tot, x) : x;
+                tot_has = tot_has || v;
+            }
+            const uint n_valid = min((uint) kWave, se - ks), n_placed = (uint) __popcll(__ballot(placed));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");// (the tile is rewritten below)
+            if (n_placed == n_valid) {// the block is placed: the next 64 words of the shorter row, same tile
+                ks += kWave;
+                if (ks >= se) break;
+                s_col  = s_next;
+                s_next = load_block(ks + kWave);
+            } else {// words beyond the tile remain: the next tile, the block shifted past the placed words
+                kl += kMergeTile;
+                if (kl >= le) break;
+                const uint src = lane + n_placed;// word `src` of the 128 words (current block, prefetched block)
+                const uint lo_part = __shfl(s_col, (int) (src & (kWave - 1u)), kWave), hi_part = __shfl(s_next, (int) (src & (kWave - 1u)), kWave);
+                s_col = src < kWave ? lo_part : hi_part;
+                ks += n_placed;
+                if (n_placed != 0) s_next = load_block(ks + kWave);
+                store_tile(t_next);
+                load_tile(kl + kMergeTile, t_next);
+            }
+        }
+        if (commutative) {
+            flush();
+            wave_reduce_ordered(acc, has, add);
+            tot     = acc;
+            tot_has = has;
+        }
+        if (lane == 0) {
+            const T r = tot_has ? add(init, tot) : init;
+            val[e]    = r;
+            keep[e]   = differs(r, init) ? 1u : 0u;
+        }
+    }
+
     // one wavefront per heavy mask entry.  TREE: lanes take contiguous pieces of the shorter row (ascending column), look every
     // column up in the longer row by binary search, fold their matches in order, then an in-order shuffle reduction:
     // the products are combined in ascending column order = the merge's order (needs an associative op_add).
@@ -597,9 +764,15 @@ namespace splahip {
         SPLAHIP_TRY(val.alloc(sizeof(uint) * (size_t) n_entries));
         SPLAHIP_TRY(keep.alloc(sizeof(uint) * (size_t) n_entries));
         SPLAHIP_TRY(rank.alloc(sizeof(uint) * ((size_t) n_entries + 1)));
-        SPLAHIP_TRY(hcount.alloc(sizeof(uint)));
+        SPLAHIP_TRY(hcount.alloc(2 * sizeof(uint)));// one 64-bit counter: low word = entries for the galloping search kernel, high word = for the block merge
         SPLAHIP_TRY(hlist.alloc(sizeof(uint) * 2 * (size_t) n_entries));
-        SPLAHIP_TRY(hipMemsetAsync(hcount.p, 0, sizeof(uint), s));
+        SPLAHIP_TRY(hipMemsetAsync(hcount.p, 0, 2 * sizeof(uint), s));
+        // the block merge regroups the products like the tree of the search kernel: same condition.  SPLAHIP_MXMT_MERGE=0: search kernel only
+        const char* merge_env = std::getenv("SPLAHIP_MXMT_MERGE");
+        const bool  merge_form = fold_is_reorderable(op_add, TypeId<T>::value) && !(merge_env && merge_env[0] == '0');
+        const char* factor_env   = std::getenv("SPLAHIP_MXMT_MERGE_FACTOR");// longer row <= factor x shorter row: block merge (default 32; 16 .. 256 are within 4 % of each other on the R-MAT 20 triangle form)
+        const uint  merge_factor = factor_env ? (uint) std::strtoul(factor_env, nullptr, 10) : 32u;
+
         // the row form (mxmT_row_kernel) regroups and reorders the products: op_add must be associative and commutative.  OPT-IN with
         // SPLAHIP_MXMT_ROW=1: on the R-MAT 20 triangle form it is bit-identical and, so far, no faster than the galloping per-entry kernel
         // (35.5 ms against 33.1 ms per call; rows <= 1023: 18.4 ms, longer rows 11.0 ms — 12 M entries of ~650 streamed words each leave the
@@ -616,9 +789,9 @@ namespace splahip {
         hipLaunchKernelGGL((mxmT_entry_kernel<T, DynBin, DynBin>), dim3((n_entries + 255) / 256), dim3(256), 0, s, n_rows, n_entries, Mp, Mj,
                            static_cast<const T*>(Mx), Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(),
                            keep.as<uint>(), hcount.as<uint>(), hlist.as<uint>(), DynBin(op_mult), DynBin(op_add), op_select, init, row_form ? kRowCap : 0u,
-                           row_form ? cost.as<uint>() : nullptr);
+                           row_form ? cost.as<uint>() : nullptr, merge_form ? 1u : 0u, merge_factor);
         SPLAHIP_TRY(hipGetLastError());
-        uint h_heavy = 0, h_first[2] = {0, 0};
+        uint h_heavy[2] = {0, 0}, h_first[2] = {0, 0};
         if (row_form) {
             SPLAHIP_TRY(values_exclusive_scan(cost.as<uint>(), n_entries, cost_before.as<uint>(), s));
             hipLaunchKernelGGL(mxmT_row_pieces_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, n_rows, Mp, Ap, cost_before.as<uint>(), pieces.as<uint>());
@@ -626,8 +799,14 @@ namespace splahip {
             SPLAHIP_TRY(hipMemcpyAsync(&h_first[0], piece_first.as<uint>() + n_rows, sizeof(uint), hipMemcpyDeviceToHost, s));
             SPLAHIP_TRY(hipMemcpyAsync(&h_first[1], piece_first.as<uint>() + 2 * (size_t) n_rows, sizeof(uint), hipMemcpyDeviceToHost, s));
         }
-        SPLAHIP_TRY(hipMemcpyAsync(&h_heavy, hcount.p, sizeof(uint), hipMemcpyDeviceToHost, s));
+        SPLAHIP_TRY(hipMemcpyAsync(h_heavy, hcount.p, 2 * sizeof(uint), hipMemcpyDeviceToHost, s));
         SPLAHIP_TRY(hipStreamSynchronize(s));
+        if (h_heavy[1]) {
+            hipLaunchKernelGGL((mxmT_merge_kernel<T, DynBin, DynBin>), dim3((h_heavy[1] + 3) / 4), dim3(256), 0, s, hcount.as<uint>() + 1, hlist.as<uint>(), n_entries - 1u, Mj, Ap, Aj,
+                               static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(), keep.as<uint>(), DynBin(op_mult), DynBin(op_add), init,
+                               binop_is_commutative(op_add) ? 1u : 0u);
+            SPLAHIP_TRY(hipGetLastError());
+        }
         DevBuf item_row;
         if (h_first[1]) {
             SPLAHIP_TRY(item_row.alloc(sizeof(uint) * (size_t) h_first[1]));
@@ -647,8 +826,8 @@ namespace splahip {
                                static_cast<const T*>(Bx), val.as<T>(), keep.as<uint>(), DynBin(op_mult), DynBin(op_add), init);
             SPLAHIP_TRY(hipGetLastError());
         }
-        if (h_heavy) {
-            const uint grid = (h_heavy + 3) / 4;
+        if (h_heavy[0]) {
+            const uint grid = (h_heavy[0] + 3) / 4;
             if (fold_is_reorderable(op_add, TypeId<T>::value))
                 hipLaunchKernelGGL((mxmT_heavy_kernel<T, DynBin, DynBin, true>), dim3(grid), dim3(256), 0, s, n_rows, hcount.as<uint>(), hlist.as<uint>(),
                                    Mp, Mj, Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(), keep.as<uint>(),
