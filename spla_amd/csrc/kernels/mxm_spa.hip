@@ -572,7 +572,11 @@ namespace splahip {
             (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             const uint32_t extra = sizeof(uint32_t) * (4 * kTpb + 1 + kTpb / 64 + 4);
             // numeric: accumulator block + bitmap; symbolic: bitmap only (a much wider block)
-            const uint32_t blk_num = sizeof(word) == 8 ? 6144u : 12288u;// 48 KB of accumulators: two workgroups per CU
+            // columns per accumulator block of the blocked numeric form.  SPLAHIP_MXM_BLOCK_KB: its LDS footprint, default 128 KB = one workgroup
+            // per CU.  Every (row, block) step pays a scan of the row's part lengths, an emit scan and six barriers whatever it holds, and a
+            // hub row meets every block: R-MAT 18 per call 107 / 92 / 84 / 77 ms with 48 (two workgroups per CU, 43 blocks) / 64 / 96 / 128 KB (16 blocks)
+            const uint32_t blk_kb  = std::min(128u, std::max(16u, env_u32("SPLAHIP_MXM_BLOCK_KB", 128)));
+            const uint32_t blk_num = blk_kb * 1024u / (uint32_t) sizeof(word) / 2048u * 2048u;
             const uint32_t blk_sym = std::max(blk_num, std::min<uint32_t>((1u << 20) - 32768u, b_cols + blk_num - 1) / blk_num * blk_num);// a multiple of blk_num; bitmap + chunk arrays < 160 KB
             const uint32_t lds_num = blk_num * (uint32_t) sizeof(word) + blk_num / 8 + extra, lds_sym = blk_sym / 8 + extra;
             // items: a heavy row; a row of more than kSplit products is cut into ranges of whole numeric blocks (its column blocks are independent), so that
