@@ -49,6 +49,7 @@ namespace splahip {
 
         using u64 = unsigned long long;
         constexpr unsigned kTpb   = 1024;
+        constexpr unsigned kLongPart = 128;// products of one (A entry, column block) part from which a wavefront walks the part on its own
         const u64 kLight = [] {// rows with at most this many products go to the ESC form
             const char* e = std::getenv("SPLAHIP_MXM_LIGHT");
             return e && *e ? (u64) std::strtoull(e, nullptr, 10) : 4096ull;
@@ -93,7 +94,7 @@ namespace splahip {
             return lo;
         }
 
-        // LDS: [accumulator block: `block` slice words (NUMERIC)] [touched bitmap: block / 32 words] [offsets 1025] [part starts 1024] [k 1024] [a values 1024] [scan scratch]
+        // LDS: [accumulator block: `block` slice words (NUMERIC)] [touched bitmap: block / 32 words] [offsets 1025] [part starts 1024] [long-part lengths 1024] [a values 1024] [scan scratch]
         template<typename T, class Mult, int ACC, bool NUMERIC>
         __global__ __launch_bounds__(kTpb) void mxm_spa_kernel(SpaArgs a, Mult mult, DynBin add, T init) {
             using word = typename CobSlice<T, ACC>::word;
@@ -102,8 +103,8 @@ namespace splahip {
             uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_raw + (NUMERIC ? (size_t) a.block * sizeof(word) : 0));
             uint32_t* s_pref = s_bits + a.block / 32;
             uint32_t* s_seg  = s_pref + kTpb + 1;
-            uint32_t* s_kk   = s_seg + kTpb;
-            uint32_t* s_av   = s_kk + kTpb;
+            uint32_t* s_len  = s_seg + kTpb;// long parts: their length (0 for a short one)
+            uint32_t* s_av   = s_len + kTpb;
             uint32_t* s_tmp  = s_av + kTpb;// kTpb / 64 + 2 words
             const uint32_t      tid = threadIdx.x;
             uint32_t*           cur = a.cursor + (size_t) blockIdx.x * a.max_deg;
@@ -171,15 +172,20 @@ namespace splahip {
                             if (dense_rows && k < a.dense_h && c0 == 0) b = lower_bound_dev(a.Bj, b, min(e, b1), a.dense_h);// products (i, k, j) below h live in the dense tile: skip them
                             len              = e - b;
                             s_seg[tid]       = b;
-                            s_kk[tid]        = k;
                             if (!last && !a.bblk) cur[kc + tid] = e;
                             if constexpr (NUMERIC) s_av[tid] = a.Ax[a0 + kc + tid];
                         }
+                        // two classes of parts (the run of B[k, :] inside this block).  SHORT ones go through the flat walk below: a thread per
+                        // product, which finds its part by a 10-step search of the prefix sums.  LONG ones (a hub row of B: most of the products of
+                        // a heavy row) are walked by a wavefront each, lanes striding the run — no search, and the column / value words of a step
+                        // are one coalesced run of B's row
+                        const bool is_long = len >= kLongPart;
+                        s_len[tid]         = is_long ? len : 0u;
                         uint32_t       total;
-                        const uint32_t ex = block_exclusive_sum<kTpb>(len, s_tmp, total);
+                        const uint32_t ex = block_exclusive_sum<kTpb>(is_long ? 0u : len, s_tmp, total);
                         s_pref[tid]       = ex;// threads beyond nk hold `total`: a sentinel for the search
-                        block_products |= total;
-                        __syncthreads();
+                        const bool any_long = __syncthreads_or(is_long ? 1 : 0) != 0;
+                        block_products |= total | (any_long ? 1u : 0u);
                         for (uint32_t p = tid; p < total; p += kTpb) {
                             SPA_WD(4, p, total)
                             uint32_t lo = 0, hi = nk;// largest t with s_pref[t] <= p
@@ -197,6 +203,35 @@ namespace splahip {
                                 if constexpr (sizeof(word) == 8) (void) __hip_atomic_fetch_add(s_acc + col, (double) prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 else
                                     cob_accumulate<T, ACC>(s_acc + col, prod);
+                            }
+                        }
+                        if (any_long) {
+                            for (uint32_t t = tid / 64; t < nk; t += kTpb / 64) {
+                                const uint32_t n = s_len[t];
+                                if (n == 0) continue;// (uniform per wavefront)
+                                const uint32_t b0 = s_seg[t];
+                                T              av = T();
+                                if constexpr (NUMERIC) av = from_bits<T>(s_av[t]);
+                                for (uint32_t p = tid & 63u; p < n; p += 128u) {// two steps of 64 in flight per lane
+                                    const uint32_t p1 = p + 64u;
+                                    const uint32_t col0 = a.Bj[b0 + p] - c0, col1 = p1 < n ? a.Bj[b0 + p1] - c0 : 0u;
+                                    uint32_t       x0 = 0, x1 = 0;
+                                    if constexpr (NUMERIC) {
+                                        x0 = a.Bx[b0 + p];
+                                        if (p1 < n) x1 = a.Bx[b0 + p1];
+                                    }
+                                    auto put = [&](uint32_t col, uint32_t xw) {
+                                        (void) __hip_atomic_fetch_or(s_bits + (col >> 5), 1u << (col & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        if constexpr (NUMERIC) {
+                                            const T prod = mult(av, from_bits<T>(xw));
+                                            if constexpr (sizeof(word) == 8) (void) __hip_atomic_fetch_add(s_acc + col, (double) prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                            else
+                                                cob_accumulate<T, ACC>(s_acc + col, prod);
+                                        }
+                                    };
+                                    put(col0, x0);
+                                    if (p1 < n) put(col1, x1);
+                                }
                             }
                         }
                         __syncthreads();
