@@ -204,8 +204,8 @@ def sssp_step(args):
     r = torch.empty(n, dtype=torch.int32, device="cuda")
     mode = os.environ.get("SPLA_BENCH_PLAN", "cob")  # column-ordered blocks (default), the sliced-ELL copy, or the CSR kernels only
     plan = kernels.CsrPlan(n, nnz, Ap, n, Aj, Ax) if mode == "sell" else kernels.CsrPlan(n, nnz, Ap)
-    if mode == "cob":  # an integer matrix only uses 4-byte LDS slices: 2^15-row ranges from 2^23 rows on (the host API's rule, storage.hpp: cob_row_bits)
-        plan.attach_cob(n, Ap, Aj, Ax, row_bits=15 if n >= 1 << 23 else 0)
+    if mode == "cob":  # default geometry (2^14-row ranges): the step runs the sparse-input-vector form of the min-plus family (1/8 of v finite)
+        plan.attach_cob(n, Ap, Aj, Ax, row_bits=int(os.environ.get("SPLA_BENCH_COB_ROW_BITS", 0)))
     _log(f"[bench] sssp-step: R-MAT scale {scale}: n={n} nnz={nnz} items={plan.n_items} sliced-ELL copy: {plan.sell} column-ordered blocks: {plan.cob}")
     step = lambda: kernels.mxv_masked(plan, "INT", n, Ap, Aj, Ax, mask, v, r, "PLUS", "MIN", "ALWAYS", INF)
     wall, per = _time_calls(step, args.steps, args.warmup)

@@ -137,12 +137,13 @@ namespace spla {
         std::vector<uint> Ap, Aj;
         std::vector<T>    Ax;
     };
-    // row_bits of the column-ordered-blocks copy (spla_hip.h: splahip_csr_plan_attach_cob): 0 = the library's default (2^14 rows per range: both the
-    // 4-byte and the double LDS slice fit twice per CU).  Integer matrices only ever use 4-byte slices, and from 2^23 rows on the wider range pays
-    // (R-MAT scale 24, int min-plus: 976 -> 828 us; scale 22: 178 vs 185 us — profiles/r02_cob_launch_bounds.txt).
+    // row_bits of the column-ordered-blocks copy (spla_hip.h: splahip_csr_plan_attach_cob): 0 = the library's default, 2^14 rows per range (both the
+    // 4-byte and the double LDS slice fit twice per CU).  2^15-row ranges help the VALUE form of an integer matrix of >= 2^23 rows (R-MAT 24 int
+    // min-plus with every entry gathering v: 976 -> 828 us) but cost the sparse-input-vector form, which is what the integer workloads of this path
+    // (BFS / SSSP steps: most of v is the skipped value) run: 0.70 ms with 2^14, 0.80 ms with 2^15 (profiles/r02_notes.md) — so: the default.
     template<typename T>
-    inline uint32_t cob_row_bits(uint64_t n_rows) {
-        return (std::is_integral<T>::value && n_rows >= (1ull << 23)) ? 15u : 0u;
+    inline uint32_t cob_row_bits(uint64_t) {
+        return 0u;
     }
 
     // device CSR + its work decomposition (splahip_plan); used for AccCsr (the matrix) and AccCsc (its transpose)

@@ -125,11 +125,12 @@ namespace {
             atomicMax(&out[1], hi);
         }
     }
-    // per call, sparse-input-vector form: bit c of the bitmap = v[c] != 0 (a wave's ballot is two bitmap words)
+    // per call, sparse-input-vector form: bit c of the bitmap = v[c] is not the value that cannot change a fold (0 for the zero family,
+    // init — the step's "infinity" — for min-plus); a wave's ballot is two bitmap words
     template<typename T>
-    __global__ __launch_bounds__(256) void cob_vbits_kernel(uint32_t n, const T* __restrict__ v, uint32_t* __restrict__ bits) {
+    __global__ __launch_bounds__(256) void cob_vbits_kernel(uint32_t n, const T* __restrict__ v, uint32_t* __restrict__ bits, uint32_t skip) {
         const uint32_t           c  = blockIdx.x * 256 + threadIdx.x;
-        const unsigned long long b  = __ballot(c < n && v[c] != T(0));
+        const unsigned long long b  = __ballot(c < n && to_bits(v[c]) != skip);
         if (lane_id() == 0) {
             bits[c >> 5]       = (uint32_t) b;
             bits[(c >> 5) + 1] = (uint32_t) (b >> 32);
@@ -184,6 +185,42 @@ namespace {
     // set by cob_mxv_accumulate around its call (per host thread): the launch below then folds onto the values r already holds
     thread_local uint32_t tl_accumulate = 0;
 
+    static thread_local uint32_t tl_skip_bits = 0;// the v value whose entries the sparse-vector form skips in the running call (0; init for min-plus)
+
+    // any negative / NaN value, and the largest value, of the copy's value words (padding slots hold 0)
+    template<typename T>
+    __global__ __launch_bounds__(256) void cob_ax_stats_kernel(size_t n, const T* __restrict__ x, uint32_t* __restrict__ out) {
+        uint32_t bad = 0, mx = 0;
+        for (size_t k = (size_t) blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t) gridDim.x * 256) {
+            const T a = x[k];
+            if constexpr (std::is_same<T, uint32_t>::value) mx = max(mx, a);
+            else {
+                if (a < T(0) || a != a) bad = 1;
+                else if constexpr (std::is_same<T, int32_t>::value)
+                    mx = max(mx, (uint32_t) a);
+            }
+        }
+        bad = wave_max(bad);
+        mx  = wave_max(mx);
+        if (lane_id() == 0) {
+            if (bad) atomicOr(&out[0], 1u);
+            atomicMax(&out[1], mx);
+        }
+    }
+    template<typename T>
+    int cob_ax_stats(const splahip_cob_s* g, hipStream_t st) {
+        if (g->ax_type == TypeId<T>::value) return SPLAHIP_OK;
+        DevMem out;
+        SPLAHIP_TRY(out.alloc(st, 8));
+        SPLAHIP_TRY(hipMemsetAsync(out.p, 0, 8, st));
+        hipLaunchKernelGGL((cob_ax_stats_kernel<T>), dim3(1024), dim3(256), 0, st, (size_t) g->n_chunks * kCobChunk, reinterpret_cast<const T*>(g->d_ax), out.as<uint32_t>());
+        uint32_t h[2] = {1, 0};
+        SPLAHIP_TRY(hipMemcpyAsync(h, out.p, 8, hipMemcpyDeviceToHost, st));
+        SPLAHIP_TRY(hipStreamSynchronize(st));
+        g->ax_bad = h[0], g->ax_max = h[1], g->ax_type = TypeId<T>::value;
+        return SPLAHIP_OK;
+    }
+
     template<typename T, class Mult, int ACC, bool VXM, int MODE = 0>
     int launch_cob(const splahip_cob_s* g, const uint32_t* Ap, const void* mask, const void* v, void* r, uint32_t* touched, int op_mult, int op_add, int op_select,
                    uint32_t init_bits, hipStream_t st) {
@@ -206,7 +243,7 @@ namespace {
         a.vbits      = g->d_vbits;
         a.x_uniform  = g->x_bits;
         if constexpr (MODE != 0) {// the bitmap of v for this call
-            hipLaunchKernelGGL((cob_vbits_kernel<T>), dim3((g->n_cols + 255) / 256), dim3(256), 0, st, g->n_cols, static_cast<const T*>(v), g->d_vbits);
+            hipLaunchKernelGGL((cob_vbits_kernel<T>), dim3((g->n_cols + 255) / 256), dim3(256), 0, st, g->n_cols, static_cast<const T*>(v), g->d_vbits, tl_skip_bits);
             SPLAHIP_TRY(hipGetLastError());
         }
         const T        init = from_bits<T>(init_bits);
@@ -251,6 +288,22 @@ namespace {
                 }
                 if (op_mult == SPLAHIP_BAND) return launch_cob<T, StaBin<SPLAHIP_BAND>, ACC, VXM, 1>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
                 return launch_cob<T, DynBin, ACC, VXM, 1>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
+            }
+        }
+        // the same form for min-plus (PLUS / MIN on int / uint, sell_skip_family == 2: the shortest-path step): an entry whose v value is `init` cannot
+        // lower a minimum that starts at init, provided no matrix value is negative and init + max(A) does not wrap (checked once per type / per call)
+        if constexpr (!VXM && !std::is_same<T, float>::value && ACC == COB_MIN) {
+            const char* be = std::getenv("SPLAHIP_COB_BITS");
+            if (g->d_vbits && !(be && be[0] == '0') && !tl_accumulate && sell_skip_family(TypeId<T>::value, op_mult, op_add) == 2) {
+                if (int rc = cob_ax_stats<T>(g, st)) return rc;
+                const bool fits = std::is_same<T, int32_t>::value ? (long long) (int32_t) init_bits + (long long) g->ax_max <= 0x7FFFFFFFll
+                                                                  : (unsigned long long) init_bits + (unsigned long long) g->ax_max <= 0xFFFFFFFFull;
+                if (!g->ax_bad && fits) {
+                    tl_skip_bits = init_bits;
+                    const int rc = launch_cob<T, StaBin<SPLAHIP_PLUS>, ACC, VXM, 1>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
+                    tl_skip_bits = 0;
+                    return rc;
+                }
             }
         }
         // the semirings of the configs get a compile-time op_mult; every other pair runs the runtime-switched functor

@@ -78,6 +78,10 @@ struct splahip_cob_s {
     uint32_t* d_vbits  = nullptr;// per call: bit c = v[c] != 0 (sparse-input-vector form, mxv_cob.hpp MODE 1 / 2)
     bool      x_uniform = false; // every stored value of the matrix is the same word (found at attach time) ...
     uint32_t  x_bits    = 0;     // ... this one: the sparse-vector form then does not read the value stream
+    // min-plus family of the sparse-vector form: any negative / NaN value and the largest value of the copy's value words, per type (like
+    // splahip_sell_s: found by the first min-plus call of a type)
+    mutable int      ax_type = -1;
+    mutable uint32_t ax_bad = 1, ax_max = 0;
 };
 
 struct splahip_plan_s {
