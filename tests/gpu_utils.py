@@ -32,6 +32,8 @@ def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, 
     # device statistics choose
     for form in ("csr", "sell", "sell-bits", "cob", "cob-small"):
         os.environ["SPLAHIP_SELL_BITS"] = "2" if form == "sell-bits" else "1"
+        # cob-small also forces cob's sparse-input-vector form of min-plus, which the library only picks for >= 2^23 columns
+        os.environ["SPLAHIP_COB_BITS"] = "2" if form == "cob-small" else "1"
         plan = kernels.CsrPlan(n_rows, len(Aj), dAp, n_cols, dAj, dAx) if form.startswith("sell") else kernels.CsrPlan(n_rows, len(Aj), dAp)
         if form == "cob":        # column-ordered blocks, default geometry (ranges of 16 Ki rows)
             plan.attach_cob(n_cols, dAp, dAj, dAx)
@@ -45,6 +47,7 @@ def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, 
         outs[form] = host(r, NP[t])
         plan.close()
     os.environ["SPLAHIP_SELL_BITS"] = "1"
+    os.environ["SPLAHIP_COB_BITS"] = "1"
     assert np.array_equal(outs["sell-bits"].view(np.uint32), outs["sell"].view(np.uint32)), "sliced-ELL sparse-vector form differs from the value form"
     if t == "FLOAT":
         a, b = outs["sell"].astype(np.float64), outs["csr"].astype(np.float64)
