@@ -138,6 +138,22 @@ namespace splahip {
                 SPA_WD(1, q, a.n_heavy)
                 const uint32_t i = a.item_row[q], cb = a.item_c0[q], ce = a.item_c1[q], a0 = a.Ap[i], deg = a.Ap[i + 1] - a0;
                 uint32_t       run = 0;// entries of the item emitted so far (the same in every thread)
+                // a row of at most kTpb entries (one part per thread) keeps its inner index, value and part boundaries in registers across the column
+                // blocks: the end of a part in one block is its start in the next, and the boundary behind that is requested a block ahead — a block
+                // step then starts without the Aj -> boundary-table chain (two dependent round trips of the ~5 a step had; with one workgroup per CU
+                // nothing else hides them)
+                const bool single = a.bblk != nullptr && deg <= kTpb;
+                uint32_t   h_k = 0, h_b1 = 0, h_b = 0, h_e = 0, h_av = 0;
+                const uint32_t* h_t = nullptr;
+                auto            end_of = [&](uint32_t c_end) -> uint32_t { return c_end >= a.b_cols ? h_b1 : h_t[c_end / a.bunit]; };
+                if (single && tid < deg) {
+                    h_k  = a.Aj[a0 + tid];
+                    h_b1 = a.Bp[h_k + 1];
+                    h_t  = a.bblk + (size_t) h_k * (a.nb + 1);
+                    h_b  = h_t[cb / a.bunit];
+                    h_e  = end_of(min(ce, cb + a.block));
+                    if constexpr (NUMERIC) h_av = a.Ax[a0 + tid];
+                }
                 for (uint32_t c0 = cb; c0 < ce; c0 += a.block) {
                     SPA_WD(2, c0, a.block)
                     const uint32_t c1 = min(ce, c0 + a.block), width = c1 - c0, words = (width + 31) / 32;
@@ -157,7 +173,18 @@ namespace splahip {
                         SPA_WD(3, kc, deg)
                         const uint32_t nk  = min(kTpb, deg - kc);
                         uint32_t       len = 0;
-                        if (tid < nk) {
+                        if (single) {
+                            if (tid < nk) {
+                                uint32_t b = h_b;
+                                const uint32_t e = h_e;
+                                h_b              = e;
+                                if (!last) h_e = end_of(min(ce, c1 + a.block));// the boundary behind the NEXT block travels during this one
+                                if (dense_rows && h_k < a.dense_h && c0 == 0) b = lower_bound_dev(a.Bj, b, min(e, h_b1), a.dense_h);// products (i, k, j) below h live in the dense tile
+                                len        = e - b;
+                                s_seg[tid] = b;
+                                if constexpr (NUMERIC) s_av[tid] = h_av;
+                            }
+                        } else if (tid < nk) {
                             const uint32_t k  = a.Aj[a0 + kc + tid];
                             const uint32_t b1 = a.Bp[k + 1];
                             uint32_t       b, e;
@@ -711,6 +738,18 @@ namespace splahip {
                     const bool ranked = d_bblk && h_counts[q] <= cap && !(dense_h && items[q].row < dense_h) && env_u32("SPLAHIP_MXM_RANKED", 1) != 0;
                     auto&      dst    = ranked ? rk : bl;
                     dst[0].push_back(items[q].row), dst[1].push_back(items[q].c0), dst[2].push_back(items[q].c1), dst[3].push_back(h_out[q]);
+                }
+                if (std::getenv("SPLAHIP_MXM_TRACE")) {// class sizes (diagnostic)
+                    u64 re = 0, be = 0, rp = 0, bp = 0, bsteps = 0;
+                    for (uint32_t q = 0; q < n_items; ++q) {
+                        const bool ranked = d_bblk && h_counts[q] <= cap && !(dense_h && items[q].row < dense_h) && env_u32("SPLAHIP_MXM_RANKED", 1) != 0;
+                        (ranked ? re : be) += h_counts[q];
+                        (ranked ? rp : bp) += items[q].est;
+                        if (!ranked) bsteps += (items[q].c1 - items[q].c0 + blk_num - 1) / blk_num;
+                    }
+                    std::fprintf(stderr, "[mxm-spa] items: ranked %zu (entries %llu, products ~%llu), blocked %zu (entries %llu, products ~%llu, block steps %llu), cap %u\n",
+                                 rk[0].size(), (unsigned long long) re, (unsigned long long) rp, bl[0].size(), (unsigned long long) be, (unsigned long long) bp,
+                                 (unsigned long long) bsteps, cap);
                 }
                 auto upload = [&](std::vector<uint32_t>* v, uint32_t** d) -> hipError_t {
                     const size_t n = v[0].size();
