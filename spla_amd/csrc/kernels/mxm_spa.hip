@@ -94,6 +94,14 @@ namespace splahip {
             return lo;
         }
 
+#ifdef SPLAHIP_SPA_TIMING
+        // DIAGNOSTIC BUILD ONLY (tools/exp/exp_spa_timing.py): s_memtime ticks of workgroup b (thread 0) in the phases of the blocked numeric form:
+        // [0] part lengths + scan, [1] product walk, [2] emit, [3] steps
+        static __device__ unsigned long long g_spa_t[4][1024];
+#define SPA_T(t) t = __builtin_amdgcn_s_memtime();
+#else
+#define SPA_T(t)
+#endif
         // LDS: [accumulator block: `block` slice words (NUMERIC)] [touched bitmap: block / 32 words] [offsets 1025] [part starts 1024] [long-part lengths 1024] [a values 1024] [scan scratch]
         template<typename T, class Mult, int ACC, bool NUMERIC>
         __global__ __launch_bounds__(kTpb) void mxm_spa_kernel(SpaArgs a, Mult mult, DynBin add, T init) {
@@ -109,6 +117,9 @@ namespace splahip {
             const uint32_t      tid = threadIdx.x;
             uint32_t*           cur = a.cursor + (size_t) blockIdx.x * a.max_deg;
             uint32_t            n_dropped = 0;
+#ifdef SPLAHIP_SPA_TIMING
+            unsigned long long tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0, acc_a = 0, acc_b = 0, acc_c = 0, n_steps = 0;
+#endif
 #ifdef SPLAHIP_SPA_WATCHDOG
             const long long wd_t0 = wall_clock64();
 #define SPA_WD(code, va, vb)                                                                                                           \
@@ -169,6 +180,10 @@ namespace splahip {
                         }
                         __syncthreads();
                     }
+                    SPA_T(tp0)
+#ifdef SPLAHIP_SPA_TIMING
+                    unsigned long long walk = 0;
+#endif
                     for (uint32_t kc = 0; kc < deg; kc += kTpb) {
                         SPA_WD(3, kc, deg)
                         const uint32_t nk  = min(kTpb, deg - kc);
@@ -213,6 +228,7 @@ namespace splahip {
                         s_pref[tid]       = ex;// threads beyond nk hold `total`: a sentinel for the search
                         const bool any_long = __syncthreads_or(is_long ? 1 : 0) != 0;
                         block_products |= total | (any_long ? 1u : 0u);
+                        SPA_T(tp1)
                         for (uint32_t p = tid; p < total; p += kTpb) {
                             SPA_WD(4, p, total)
                             uint32_t lo = 0, hi = nk;// largest t with s_pref[t] <= p
@@ -262,7 +278,12 @@ namespace splahip {
                             }
                         }
                         __syncthreads();
+#ifdef SPLAHIP_SPA_TIMING
+                        SPA_T(tp2)
+                        walk += tp2 - tp1;
+#endif
                     }
+                    SPA_T(tp2)
                     // the block's entries, ascending: a popcount scan over the bitmap words (which are cleared on the way, like the accumulators)
                     if (block_products)
                     for (uint32_t w0 = 0; w0 < words; w0 += kTpb) {
@@ -294,6 +315,10 @@ namespace splahip {
                         run += total;
                     }
                     __syncthreads();
+#ifdef SPLAHIP_SPA_TIMING
+                    SPA_T(tp3)
+                    acc_a += (tp2 - tp0) - walk, acc_b += walk, acc_c += tp3 - tp2, n_steps += 1;
+#endif
                 }
                 if constexpr (!NUMERIC) {
                     if (tid == 0) a.counts[q] = run;
@@ -301,6 +326,9 @@ namespace splahip {
             }
             if constexpr (NUMERIC) {
                 if (n_dropped) atomicAdd(a.dropped, n_dropped);
+#ifdef SPLAHIP_SPA_TIMING
+                if (tid == 0 && blockIdx.x < 1024) g_spa_t[0][blockIdx.x] = acc_a, g_spa_t[1][blockIdx.x] = acc_b, g_spa_t[2][blockIdx.x] = acc_c, g_spa_t[3][blockIdx.x] = n_steps;
+#endif
             }
         }
 
@@ -915,3 +943,10 @@ extern "C" int splahip_mxm_last_info(uint32_t* n_heavy_rows, uint32_t* light_nnz
     if (dense_h) *dense_h = splahip::tl_last_dense_h;
     return SPLAHIP_OK;
 }
+
+#ifdef SPLAHIP_SPA_TIMING
+// DIAGNOSTIC BUILD ONLY: per-workgroup phase ticks of the last blocked numeric launch (4 x 1024 64-bit words)
+extern "C" int splahip_debug_spa_timing(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(splahip::g_spa_t), sizeof(unsigned long long) * 4 * 1024) == hipSuccess ? SPLAHIP_OK : SPLAHIP_ERROR;
+}
+#endif
