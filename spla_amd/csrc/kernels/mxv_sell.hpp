@@ -571,13 +571,18 @@ namespace splahip {
         SELL_NOW(t_entry)
 #endif
         if (threadIdx.x == 0) s_next = C::kWaves;
-        {// the bitmap's LDS-resident words, 16 bytes per lane
-            const uint4* src = reinterpret_cast<const uint4*>(vbits);
-            uint4*       dst = reinterpret_cast<uint4*>(s_bits);
-            for (uint q = threadIdx.x; q < C::kBitWords / 4; q += C::kTpb) dst[q] = src[q];
-        }
-        static_assert(C::kBitWords % 4 == 0, "the bitmap is copied in quads");
         __syncthreads();
+        // The bitmap's LDS-resident words are REQUESTED first (16 bytes per lane, ten quads into registers), then the wave resolves its first
+        // slices — id, header, selection word: a chain of four dependent round trips — and only then are the quads stored to LDS: the two
+        // used to run one after the other in every workgroup's prologue.
+        static_assert(C::kBitWords % 4 == 0, "the bitmap is copied in quads");
+        constexpr uint kFillPer = (C::kBitWords / 4 + C::kTpb - 1) / C::kTpb;
+        uint4          fill[kFillPer];
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(vbits);
+#pragma unroll
+            for (uint k = 0; k < kFillPer; ++k) fill[k] = src[min(threadIdx.x + k * C::kTpb, C::kBitWords / 4 - 1u)];
+        }
         const T    pc   = mult(from_bits<T>(xbits), from_bits<T>(cbits));
         const uint lane = lane_id();
         const uint w    = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -592,19 +597,32 @@ namespace splahip {
         auto                 hit = [&](uint code, uint word) -> uint { return (word >> (code & 31u)) & 1u; };
         auto                 lds_word = [&](uint code) -> uint { return *reinterpret_cast<const uint*>(lds + (code >> 5)); };
 
-        uint sA = phys(blockIdx.x + w * gridDim.x);
-        if (sA >= n_slices) return;
-        uint rowA = vrow[sA * kWave + lane], lenA = vlen[sA * kWave + lane], baseA = off[sA];
-        uint sB    = take_slice();
-        bool moreB = sB < n_slices;
-        uint rowB = 0, lenB = 0, baseB = 0;
-        if (moreB) {
-            rowB  = vrow[sB * kWave + lane];
-            lenB  = vlen[sB * kWave + lane];
-            baseB = off[sB];
+        uint       sA    = phys(blockIdx.x + w * gridDim.x);
+        const bool haveA = sA < n_slices;
+        uint       rowA = 0, lenA = 0, baseA = 0, sB = n_slices, rowB = 0, lenB = 0, baseB = 0, wordA = 0, sC = n_slices;
+        bool       moreB = false;
+        if (haveA) {
+            rowA = vrow[sA * kWave + lane], lenA = vlen[sA * kWave + lane], baseA = off[sA];
+            sB    = take_slice();
+            moreB = sB < n_slices;
+            if (moreB) {
+                rowB  = vrow[sB * kWave + lane];
+                lenB  = vlen[sB * kWave + lane];
+                baseB = off[sB];
+            }
+            wordA = sel_word(rowA, lenA);
+            sC    = moreB ? take_slice() : n_slices;// (resolved a slice ahead of its header: see sell_mxv_body)
         }
-        uint wordA = sel_word(rowA, lenA);
-        uint sC    = moreB ? take_slice() : n_slices;// (resolved a slice ahead of its header: see sell_mxv_body)
+        {
+            uint4* dst = reinterpret_cast<uint4*>(s_bits);
+#pragma unroll
+            for (uint k = 0; k < kFillPer; ++k) {
+                const uint q = threadIdx.x + k * C::kTpb;
+                if (q < C::kBitWords / 4) dst[q] = fill[k];
+            }
+        }
+        __syncthreads();
+        if (!haveA) return;
 #ifdef SPLAHIP_SELL_TIMING
         unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, acc0 = 0, acc1 = 0, acc2 = 0, nsl = 0, t_begin = 0, n_live = 0, n_rounds = 0, n_width = 0, n_lanes = 0;
         SELL_NOW(t_begin)
