@@ -7,6 +7,7 @@
 #include "ops.hpp"
 #include "plan.hpp"
 
+#include <chrono>
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -489,6 +490,16 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
         return fail(SPLAHIP_ERROR, "sliced-ELL plan failed (%s): %s", what, hipGetErrorString(e));
     };
 
+    // SPLAHIP_SELL_TRACE=1: host wall time of the build's phases on stderr, each closed by a device synchronisation (diagnostic)
+    static const bool trace = std::getenv("SPLAHIP_SELL_TRACE") != nullptr;
+    auto              t_last = std::chrono::steady_clock::now();
+    auto              mark   = [&](const char* what) {
+        if (!trace) return;
+        (void) hipStreamSynchronize(s);
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[sell attach] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t_last).count());
+        t_last = t1;
+    };
     // 1. chunks per row, partial slots per long row, long-row index: three exclusive scans over n_rows + 1 counters
     uint32_t *vcount, *pcount, *lflag, *xcount, *vfirst, *pfirst, *lfirst, *xfirst;
     for (uint32_t** q : {&vcount, &pcount, &lflag, &xcount, &vfirst, &pfirst, &lfirst, &xfirst})
@@ -509,6 +520,7 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     g->n_vrows  = g->n_xslices * kWave + (n_chunks + kWave - 1) / kWave * kWave;// row-exclusive slices first, then the sorted chunks
     g->n_slices = g->n_vrows / kWave;
 
+    mark("1 row counts + scans");
     // 2. chunks in row order -> stable sort by descending length
     uint32_t *q_key, *q_id, *q_row, *q_len, *q_k0, *q_slot, *key_s, *order, *vk0;
     for (uint32_t** q : {&q_key, &q_id, &q_row, &q_len, &q_k0, &q_slot, &key_s, &order})
@@ -536,6 +548,7 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     hipLaunchKernelGGL(sell_permute_kernel, dim3((g->n_vrows + 255) / 256), dim3(256), 0, s, n_chunks, g->n_xslices * kWave, g->n_vrows, order, q_row, q_len, q_k0,
                        q_slot, g->d_vrow, g->d_vlen, vk0, g->d_vslot);
 
+    mark("2 chunk sort");
     // 3. slice offsets
     uint32_t* slots = nullptr;
     e               = tmp.alloc(&slots, (size_t) g->n_slices + 1);
@@ -562,6 +575,7 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     own(&g->d_Aj2r, (size_t) g->n_slots + kTail);
     own(&g->d_Ax2, (size_t) g->n_slots + kTail);
 
+    mark("3 slice offsets");
     // 4. hot columns: the n_hot most referenced ones (stable: ties keep ascending column order)
     g->n_hot = n_cols < SC::kHot ? n_cols : SC::kHot;
     uint32_t *count, *ckey, *ccol, *ckey_s, *ccol_s;
@@ -585,6 +599,7 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     if (e != hipSuccess) return bail("hot-column sort");
     hipLaunchKernelGGL(sell_rank_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, s, ccol_s, n_cols, g->n_hot, g->d_rank_of, g->d_hot_cols);
 
+    mark("4 hot columns");
     // 4b. cold list of the sparse-vector form: entries of columns ranked beyond the LDS-resident bits, sorted by rank
     if (n_cols > SC::kBitsLds) {
         uint32_t *flag, *pos;
@@ -618,6 +633,7 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
         }
     }
 
+    mark("4b cold list");
     // 5. the entries
     hipLaunchKernelGGL(sell_fill_kernel, dim3((g->n_slices + 3) / 4), dim3(256), 0, s, g->n_slices, g->n_xslices, g->d_off, g->d_vlen, vk0, d_Aj,
                        static_cast<const uint32_t*>(d_Ax), g->d_rank_of, g->n_hot, g->d_Aj2, g->d_Aj2r, g->d_Ax2);
@@ -625,6 +641,7 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return bail("fill");
+    mark("5 entries");
     // 6. are all stored values one word?  (d_vbits is not in use yet: two of its words take the result)
     if (nnz > 0) {
         const uint range_init[2] = {0xFFFFFFFFu, 0u};
