@@ -403,3 +403,42 @@ def test_uniform_matrix_values_structure_only(oracle, t):
     want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, np.zeros(n_rows, NP[t]), v, mul, add, "ALWAYS", init)
     got = hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, np.zeros(n_rows, NP[t]), v, mul, add, "ALWAYS", init)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", ["INT", "UINT"])
+def test_frontier_form_counts_hits(oracle, t):
+    """The frontier form of the sliced-ELL bit form (mxv_sell.hpp: sell_frontier_body): matrix values all one word AND every non-skipped
+    value of v one word, so a row's result is fold_repeated(init, product, hits).  Row lengths on both sides of every boundary of its walk
+    (quads of 4, the 16-position first group, the 32-load window, 256-entry chunks, row-exclusive slices of 16 Ki entries), hit counts 0 /
+    1 / many, the counting (PLUS), parity (BXOR) and idempotent (BOR, MAX, LOR, min-plus) families, non-zero init, ALWAYS and a mask, and
+    more columns than the LDS bitmap holds (the cold list folds the rest)."""
+    from gpu_utils import hip_mxv
+    rng = np.random.default_rng(4711)
+    lens = [0, 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 127, 255, 256, 257, 300, 511, 1000, 4095, 16384, 16385, 40000]
+    lens = lens + [int(x) for x in rng.integers(0, 40, 400)]
+    for n_cols in (60000, 1500000):
+        n_rows = len(lens)
+        Ap = np.zeros(n_rows + 1, np.uint32)
+        cols = []
+        for i, ln in enumerate(lens):
+            ln = min(ln, n_cols)
+            c = np.sort(rng.choice(n_cols, ln, replace=False)) if ln else np.zeros(0, np.int64)
+            cols.append(c.astype(np.uint32))
+            Ap[i + 1] = Ap[i] + ln
+        Aj = np.concatenate(cols)
+        for xval, cval in ((1, 1), (3, 5)):
+            Ax = np.full(len(Aj), xval, NP[t])
+            fams = [("BAND", "BOR", 0), ("MULT", "PLUS", 0), ("MULT", "PLUS", 7), ("LAND", "BXOR", 0), ("LAND", "LOR", 0), ("PLUS", "MIN", 1 << 20)]
+            if t == "UINT":
+                fams.append(("MULT", "MAX", 0))
+            for mul, add, init in fams:
+                for frac in (0.0, 0.002, 0.5):
+                    skip = init if add == "MIN" else 0
+                    v = np.full(n_cols, skip, NP[t])
+                    v[rng.random(n_cols) < frac] = cval
+                    for sel in ("ALWAYS", "NQZERO"):
+                        mask = random_mask(rng, n_rows, t)
+                        want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
+                        got = hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init, junk=9)
+                        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (t, n_cols, xval, cval, mul, add, init, frac, sel)
