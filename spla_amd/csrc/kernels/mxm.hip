@@ -802,9 +802,16 @@ namespace splahip {
         SPLAHIP_TRY(hipMemcpyAsync(h_heavy, hcount.p, 2 * sizeof(uint), hipMemcpyDeviceToHost, s));
         SPLAHIP_TRY(hipStreamSynchronize(s));
         if (h_heavy[1]) {
-            hipLaunchKernelGGL((mxmT_merge_kernel<T, DynBin, DynBin>), dim3((h_heavy[1] + 3) / 4), dim3(256), 0, s, hcount.as<uint>() + 1, hlist.as<uint>(), n_entries - 1u, Mj, Ap, Aj,
-                               static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(), keep.as<uint>(), DynBin(op_mult), DynBin(op_add), init,
-                               binop_is_commutative(op_add) ? 1u : 0u);
+            // the plus-times semiring (the triangle count, SpGEMM proper) gets compile-time functors: the runtime-switched ones cost a switch per
+            // product and per step of the final reduction
+            if (op_mult == SPLAHIP_MULT && op_add == SPLAHIP_PLUS)
+                hipLaunchKernelGGL((mxmT_merge_kernel<T, StaBin<SPLAHIP_MULT>, StaBin<SPLAHIP_PLUS>>), dim3((h_heavy[1] + 3) / 4), dim3(256), 0, s, hcount.as<uint>() + 1,
+                                   hlist.as<uint>(), n_entries - 1u, Mj, Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(), keep.as<uint>(),
+                                   StaBin<SPLAHIP_MULT>(), StaBin<SPLAHIP_PLUS>(), init, 1u);
+            else
+                hipLaunchKernelGGL((mxmT_merge_kernel<T, DynBin, DynBin>), dim3((h_heavy[1] + 3) / 4), dim3(256), 0, s, hcount.as<uint>() + 1, hlist.as<uint>(), n_entries - 1u, Mj,
+                                   Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(), keep.as<uint>(), DynBin(op_mult), DynBin(op_add), init,
+                                   binop_is_commutative(op_add) ? 1u : 0u);
             SPLAHIP_TRY(hipGetLastError());
         }
         DevBuf item_row;
