@@ -518,11 +518,52 @@ namespace splahip {
     // fold lane-privately for a commutative op_add, in ascending column order otherwise (an in-order wave reduction per step).  (64 entries
     // per wavefront with their indices and row bounds fetched lane-parallel was tried: 10.4 against 9.7 ms — one entry per wavefront hides
     // the metadata chain behind other wavefronts better than it is amortised.)
+    template<class Add>
+    __device__ __forceinline__ int merge_op_id(const Add& add) {
+        if constexpr (Add::is_static) return Add::op_id;
+        else
+            return add.op;
+    }
+    // may an entry's value be computed from the number of matches when all products are equal?  PLUS / BXOR count (integer types: n x p wraps
+    // like n additions), MIN / MAX / BOR / BAND / FIRST / SECOND are idempotent (p (+) p = p bit for bit); the logical ops normalise their
+    // operands (LOR(5, 5) = 1) and a float sum of n equal terms rounds differently from n x p: those keep the match list
+    inline bool merge_counts(int op_add, int type) {
+        switch (op_add) {
+            case SPLAHIP_PLUS:
+            case SPLAHIP_BXOR: return type != SPLAHIP_FLOAT;
+            case SPLAHIP_BOR:
+            case SPLAHIP_BAND: return type != SPLAHIP_FLOAT;
+            case SPLAHIP_MIN:
+            case SPLAHIP_MAX:
+            case SPLAHIP_FIRST:
+            case SPLAHIP_SECOND: return true;
+            default: return false;
+        }
+    }
+    // smallest and largest value word of an array (equal <=> every stored value is the same word)
+    __global__ __launch_bounds__(256) void value_range_kernel(uint n, const uint* __restrict__ x, uint* __restrict__ out) {
+        uint lo = 0xFFFFFFFFu, hi = 0;
+        for (uint k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+            const uint a = x[k];
+            lo = min(lo, a), hi = max(hi, a);
+        }
+        lo = ~wave_max(~lo);
+        hi = wave_max(hi);
+        if (lane_id() == 0) {
+            atomicMin(&out[0], lo);
+            atomicMax(&out[1], hi);
+        }
+    }
+
     template<typename T, class Mult, class Add>
     __global__ __launch_bounds__(256) void mxmT_merge_kernel(const uint* __restrict__ count, const uint* __restrict__ list, uint list_last, const uint* __restrict__ Mj,
                                                              const uint* __restrict__ Ap, const uint* __restrict__ Aj, const T* __restrict__ Ax,
                                                              const uint* __restrict__ Bp, const uint* __restrict__ Bj, const T* __restrict__ Bx,
-                                                             T* __restrict__ val, uint* __restrict__ keep, Mult mult, Add add, T init, uint commutative) {
+                                                             T* __restrict__ val, uint* __restrict__ keep, Mult mult, Add add, T init, uint commutative,
+                                                             uint count_mode, uint a_word, uint b_word) {
+        const T pc = mult(from_bits<T>(a_word), from_bits<T>(b_word));// (count_mode: the one product)
+        // count_mode: every stored value of A is one word and every stored value of B is one word (adjacency matrices: the triangle count), so
+        // every product is pc and the entry's value follows from the NUMBER of matches — no match list, no value fetches (host: merge_counts())
         __shared__ uint s_tile[256 / kWave][kMergeTile];
         __shared__ uint s_hits[256 / kWave][2 * kMergeHits];
         const uint      wv = threadIdx.x / kWave, lane = lane_id();
@@ -585,7 +626,8 @@ namespace splahip {
             for (uint step = kMergeTile >> 1; step != 0; step >>= 1)
                 if (tile[pos + step - 1] < s_col) pos += step;
             const bool hit = placed && tile[pos] == s_col;
-            if (commutative) {
+            if (count_mode) n_hits += (uint) __popcll(__ballot(hit));
+            else if (commutative) {
                 const unsigned long long m = __ballot(hit);
                 if (m != 0ull) {
                     const uint cnt = (uint) __popcll(m);
@@ -624,7 +666,15 @@ namespace splahip {
                 load_tile(kl + kMergeTile, t_next);
             }
         }
-        if (commutative) {
+        if (count_mode) {// n_hits equal products folded: n x pc for PLUS, parity for BXOR, pc itself for the idempotent ops (merge_counts())
+            tot_has = n_hits != 0;
+            tot     = pc;
+            if constexpr (std::is_integral<T>::value) {
+                const int op = merge_op_id(add);
+                if (op == SPLAHIP_PLUS) tot = from_bits<T>(n_hits * to_bits(pc));
+                if (op == SPLAHIP_BXOR) tot = (n_hits & 1u) ? pc : from_bits<T>(0u);
+            }
+        } else if (commutative) {
             flush();
             wave_reduce_ordered(acc, has, add);
             tot     = acc;
@@ -801,17 +851,40 @@ namespace splahip {
         }
         SPLAHIP_TRY(hipMemcpyAsync(h_heavy, hcount.p, 2 * sizeof(uint), hipMemcpyDeviceToHost, s));
         SPLAHIP_TRY(hipStreamSynchronize(s));
+        // count mode of the block merge: every stored value of A one word and every stored value of B one word.  The boundary passes no entry
+        // counts for A and B, so the check runs when they are known anyway: nnz(A) = Ap[n_rows], and B is either the same matrix as A or the mask
+        uint count_mode = 0, a_word = 0, b_word = 0;
+        {
+            const char* cenv = std::getenv("SPLAHIP_MXMT_COUNT");
+            const bool  b_is_a = Bp == Ap && Bx == Ax, b_is_m = Bp == Mp && Bx == Mx;
+            if (h_heavy[1] && merge_counts(op_add, TypeId<T>::value) && (b_is_a || b_is_m) && !(cenv && cenv[0] == '0')) {
+                uint   a_nnz = 0;
+                DevBuf rng;
+                SPLAHIP_TRY(rng.alloc(4 * sizeof(uint)));
+                const uint init_rng[4] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
+                SPLAHIP_TRY(hipMemcpyAsync(rng.p, init_rng, sizeof(init_rng), hipMemcpyHostToDevice, s));
+                SPLAHIP_TRY(hipMemcpyAsync(&a_nnz, Ap + n_rows, sizeof(uint), hipMemcpyDeviceToHost, s));
+                SPLAHIP_TRY(hipStreamSynchronize(s));
+                if (a_nnz) hipLaunchKernelGGL(value_range_kernel, dim3(1024), dim3(256), 0, s, a_nnz, static_cast<const uint*>(Ax), rng.as<uint>());
+                const uint b_nnz = b_is_a ? a_nnz : n_entries;
+                if (b_nnz) hipLaunchKernelGGL(value_range_kernel, dim3(1024), dim3(256), 0, s, b_nnz, static_cast<const uint*>(Bx), rng.as<uint>() + 2);
+                uint h_rng[4] = {0, 1, 0, 1};
+                SPLAHIP_TRY(hipMemcpyAsync(h_rng, rng.p, sizeof(h_rng), hipMemcpyDeviceToHost, s));
+                SPLAHIP_TRY(hipStreamSynchronize(s));
+                if (a_nnz && b_nnz && h_rng[0] == h_rng[1] && h_rng[2] == h_rng[3]) count_mode = 1, a_word = h_rng[0], b_word = h_rng[2];
+            }
+        }
         if (h_heavy[1]) {
             // the plus-times semiring (the triangle count, SpGEMM proper) gets compile-time functors: the runtime-switched ones cost a switch per
             // product and per step of the final reduction
             if (op_mult == SPLAHIP_MULT && op_add == SPLAHIP_PLUS)
                 hipLaunchKernelGGL((mxmT_merge_kernel<T, StaBin<SPLAHIP_MULT>, StaBin<SPLAHIP_PLUS>>), dim3((h_heavy[1] + 3) / 4), dim3(256), 0, s, hcount.as<uint>() + 1,
                                    hlist.as<uint>(), n_entries - 1u, Mj, Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(), keep.as<uint>(),
-                                   StaBin<SPLAHIP_MULT>(), StaBin<SPLAHIP_PLUS>(), init, 1u);
+                                   StaBin<SPLAHIP_MULT>(), StaBin<SPLAHIP_PLUS>(), init, 1u, count_mode, a_word, b_word);
             else
                 hipLaunchKernelGGL((mxmT_merge_kernel<T, DynBin, DynBin>), dim3((h_heavy[1] + 3) / 4), dim3(256), 0, s, hcount.as<uint>() + 1, hlist.as<uint>(), n_entries - 1u, Mj,
                                    Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(), keep.as<uint>(), DynBin(op_mult), DynBin(op_add), init,
-                                   binop_is_commutative(op_add) ? 1u : 0u);
+                                   binop_is_commutative(op_add) ? 1u : 0u, count_mode, a_word, b_word);
             SPLAHIP_TRY(hipGetLastError());
         }
         DevBuf item_row;

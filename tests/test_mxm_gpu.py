@@ -239,3 +239,38 @@ def test_mxm_dense_corner_on_the_matrix_cores(oracle, monkeypatch):
     np.testing.assert_array_equal(a[0], b[0])
     np.testing.assert_array_equal(a[1], b[1])
     np.testing.assert_allclose(a[2], b[2], rtol=1e-5, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", ["INT", "UINT", "FLOAT"])
+def test_mxmT_count_mode_of_uniform_values(oracle, t):
+    """mxmT_masked(L, L, L) with every stored value one word — the triangle-count form — lets the block merge compute an entry from the NUMBER
+    of matches (mxm.hip: count_mode / merge_counts): PLUS and BXOR count, MIN / MAX / BOR / BAND / FIRST / SECOND are idempotent, the
+    logical ops and a float sum keep the match list.  Values other than 1, rows long enough for the heavy classes, and one odd value that
+    must switch the shortcut off."""
+    from spla_amd import kernels
+    rng = np.random.default_rng(97)
+    n = 700
+    dense = np.tril(rng.random((n, n)) < 0.35, -1)
+    dense[:, :40] |= np.tril(rng.random((n, 40)) < 0.9, -1)[:, :40]
+    I, J = np.nonzero(dense)
+    order = np.lexsort((J, I))
+    I, J = I[order], J[order]
+    Lp = np.zeros(n + 1, np.uint32)
+    np.add.at(Lp, I + 1, 1)
+    Lp = np.cumsum(Lp).astype(np.uint32)
+    Lj = J.astype(np.uint32)
+    ops = [("MULT", "PLUS", 0), ("MULT", "MIN", 50), ("PLUS", "MAX", 0), ("MULT", "FIRST", 0), ("MULT", "SECOND", 0), ("LAND", "LOR", 0)]
+    if t != "FLOAT":
+        ops += [("MULT", "BXOR", 0), ("BAND", "BOR", 1), ("BOR", "BAND", 7)]
+    for xval, odd in ((1, False), (3, False), (3, True)):
+        Lx = np.full(len(Lj), xval, NP[t])
+        if odd:
+            Lx[len(Lx) // 3] = 5
+        L = (Lp, Lj, Lx)
+        dL = _dev3(L, t)
+        for mul, add, init in ops:
+            want = oracle.mxmT_masked(t, n, L, L, L, mul, add, "ALWAYS", init)
+            got = kernels.mxmT_masked(t, n, dL, dL, dL, mul, add, "ALWAYS", init)
+            exact = not (t == "FLOAT" and add in ("PLUS", "MULT"))
+            _same_csr(_host3(got, t), want, t, exact, f"mxmT count mode {t} x={xval} odd={odd} {mul}/{add}")
