@@ -211,7 +211,7 @@ namespace splahip {
         return 1u + (row_streams(len_a, len_b) ? (len_b + 63u) / 64u : (len_a + 3u) / 4u);
     }
     // block merge of two rows of comparable length (mxmT_merge_kernel)
-    constexpr uint kMergeTile = 256;// words of the longer row staged per step
+    constexpr uint kMergeTile = 512;// words of the longer row staged per step (256 / 512 / 1024: merge kernel 8.6 / 8.0 / 10.5 ms on the R-MAT 20 triangle form)
     constexpr uint kMergeHits = 128;// matches recorded per wavefront before their value words are fetched
     __host__ __device__ __forceinline__ bool merge_streams(uint len_a, uint len_b, uint factor) {
         const uint mn = len_a < len_b ? len_a : len_b, mx = len_a < len_b ? len_b : len_a;
@@ -510,7 +510,7 @@ namespace splahip {
     // ---- heavy entries whose two rows are of comparable length (longer <= 32 x shorter): BLOCK MERGE, one wavefront per entry.
     // The per-entry search kernel below is bound by the L2's request rate: every probe of every binary search is its own request
     // (R-MAT 20 triangle form: 4.35 G requests per call even with galloping).  Here both rows are read ONCE, coalesced: 64 words of the
-    // shorter row sit in the lanes, 256 words of the longer row in the wavefront's LDS tile; every lane whose word is <= the tile's last
+    // shorter row sit in the lanes, 512 words of the longer row in the wavefront's LDS tile; every lane whose word is <= the tile's last
     // word finds its lower bound in the tile (8 LDS reads, branch-free) — those lanes are a prefix, the shorter row being sorted; when
     // the whole block is placed the next 64 words of the shorter row are loaded, otherwise the next tile of the longer row (and the
     // block is shifted by the number of placed words).  A step therefore retires 64 words of one row or 256 of the other; requests are
