@@ -507,7 +507,7 @@ namespace splahip {
         for (uint t = piece_first[v]; t < piece_first[v + 1]; ++t) item_row[t] = i;
     }
 
-    // ---- heavy entries whose two rows are of comparable length (longer <= 32 x shorter): BLOCK MERGE, one wavefront per entry.
+    // ---- heavy entries whose two rows are of comparable length (longer <= 128 x shorter): BLOCK MERGE, one wavefront per entry.
     // The per-entry search kernel below is bound by the L2's request rate: every probe of every binary search is its own request
     // (R-MAT 20 triangle form: 4.35 G requests per call even with galloping).  Here both rows are read ONCE, coalesced: 64 words of the
     // shorter row sit in the lanes, 512 words of the longer row in the wavefront's LDS tile; every lane whose word is <= the tile's last
@@ -820,8 +820,8 @@ namespace splahip {
         // the block merge regroups the products like the tree of the search kernel: same condition.  SPLAHIP_MXMT_MERGE=0: search kernel only
         const char* merge_env = std::getenv("SPLAHIP_MXMT_MERGE");
         const bool  merge_form = fold_is_reorderable(op_add, TypeId<T>::value) && !(merge_env && merge_env[0] == '0');
-        const char* factor_env   = std::getenv("SPLAHIP_MXMT_MERGE_FACTOR");// longer row <= factor x shorter row: block merge (default 32; 16 .. 256 are within 4 % of each other on the R-MAT 20 triangle form)
-        const uint  merge_factor = factor_env ? (uint) std::strtoul(factor_env, nullptr, 10) : 32u;
+        const char* factor_env   = std::getenv("SPLAHIP_MXMT_MERGE_FACTOR");// longer row <= factor x shorter row: block merge (default 128; 32 / 128 / all = 13.6 / 13.1 / 13.5 ms on the R-MAT 20 triangle form)
+        const uint  merge_factor = factor_env ? (uint) std::strtoul(factor_env, nullptr, 10) : 128u;
 
         // the row form (mxmT_row_kernel) regroups and reorders the products: op_add must be associative and commutative.  OPT-IN with
         // SPLAHIP_MXMT_ROW=1: on the R-MAT 20 triangle form it is bit-identical and, so far, no faster than the galloping per-entry kernel

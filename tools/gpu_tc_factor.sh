@@ -1,7 +1,7 @@
 #!/bin/bash
 # mxmT triangle form: block-merge threshold sweep + kernel split per setting
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp; export TMPDIR=/tmp
-for f in 32; do
+for f in 32 128 100000; do
   if [ $f = 0 ]; then export SPLAHIP_MXMT_MERGE=0; else export SPLAHIP_MXMT_MERGE=1 SPLAHIP_MXMT_MERGE_FACTOR=$f; fi
   rm -rf $R/gpurun_out/prof_tcf
   timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_tcf --output-format csv -- python3 $R/bench.py --workload tc-mxmT --steps 3 --warmup 1 --no-cpu-baseline --no-verify > /tmp/line.json 2>/dev/null
