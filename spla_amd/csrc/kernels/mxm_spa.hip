@@ -294,9 +294,25 @@ namespace splahip {
                         uint32_t       total;
                         const uint32_t ex = block_exclusive_sum<kTpb>(__popc(bits), s_tmp, total);
                         if constexpr (NUMERIC) {
-                            uint32_t o = a.item_out[q] + run + ex;
-                            for (uint32_t b = bits; b; b &= b - 1) {
-                                const uint32_t j = w * 32 + (uint32_t) __ffs((int) b) - 1;
+                            // a thread per OUTPUT entry, not per bitmap word: entry o of the block belongs to the word whose prefix count covers it (a
+                            // 10-step search of the word offsets, kept in LDS) and is that word's k-th set bit — so consecutive threads write consecutive
+                            // entries of Rj / Rx.  A thread per word wrote its 3 - 4 entries one by one at a stride: the result stores (1.28 G entries,
+                            // 10 GB per R-MAT 18 call) were ~38 % of a block step
+                            s_pref[tid] = ex;  // (the part arrays are free between the walks)
+                            s_seg[tid]  = bits;
+                            __syncthreads();
+                            const uint32_t base = a.item_out[q] + run, n_words = min(kTpb, words - w0);
+                            for (uint32_t o = tid; o < total; o += kTpb) {
+                                uint32_t lo = 0, hi = n_words;// largest word index with s_pref[index] <= o
+                                while (hi - lo > 1) {
+                                    const uint32_t mid = (lo + hi) >> 1;
+                                    if (s_pref[mid] <= o) lo = mid;
+                                    else
+                                        hi = mid;
+                                }
+                                uint32_t b = s_seg[lo];
+                                for (uint32_t k = o - s_pref[lo]; k != 0; --k) b &= b - 1;// drop the k lowest set bits
+                                const uint32_t j = (w0 + lo) * 32 + (uint32_t) __ffs((int) b) - 1;
                                 uint32_t       accw;
                                 if constexpr (sizeof(word) == 8) {
                                     accw     = to_bits((float) s_acc[j]);
@@ -305,12 +321,12 @@ namespace splahip {
                                     accw     = s_acc[j];
                                     s_acc[j] = cob_identity<T, ACC>();
                                 }
-                                const T val = cob_finish<T, ACC>(accw, init, add);
-                                a.Rj[o]     = c0 + j;
-                                a.Rx[o]     = to_bits(val);
+                                const T val      = cob_finish<T, ACC>(accw, init, add);
+                                a.Rj[base + o]   = c0 + j;
+                                a.Rx[base + o]   = to_bits(val);
                                 if (!(val != init)) ++n_dropped;// the reference drops r == init (cpu_mxm.hpp:110): compacted afterwards when any
-                                ++o;
                             }
+                            __syncthreads();// (s_pref / s_seg are the next walk's again)
                         }
                         run += total;
                     }
