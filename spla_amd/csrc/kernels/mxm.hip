@@ -228,7 +228,7 @@ namespace splahip {
                                                              T* __restrict__ val, uint* __restrict__ keep,
                                                              uint* __restrict__ heavy_count, uint* __restrict__ heavy_list,
                                                              Mult mult, Add add, int op_select, T init, uint row_cap, uint* __restrict__ cost,
-                                                             uint merge_on, uint merge_factor) {
+                                                             uint merge_on, uint merge_factor, uint heavy_from) {
         const uint e = blockIdx.x * 256 + threadIdx.x;// (lanes behind the last entry stay for the wave-wide list appends below)
         T    r    = init;
         bool done = true;
@@ -238,7 +238,7 @@ namespace splahip {
             const uint j  = Mj[e];
             uint       ka = Ap[i], ea = Ap[i + 1];
             uint       kb = Bp[j], eb = Bp[j + 1];
-            if ((ea - ka) + (eb - kb) > kHeavy && ea > ka && eb > kb) {
+            if ((ea - ka) + (eb - kb) > heavy_from && ea > ka && eb > kb) {
                 if (ea - ka <= row_cap) {// row form (mxmT_row_kernel): A[i, :] staged in LDS once for a run of the row's entries
                     keep[e] = kRowPending;
                     c       = row_entry_cost(ea - ka, eb - kb);
@@ -820,6 +820,8 @@ namespace splahip {
         // the block merge regroups the products like the tree of the search kernel: same condition.  SPLAHIP_MXMT_MERGE=0: search kernel only
         const char* merge_env = std::getenv("SPLAHIP_MXMT_MERGE");
         const bool  merge_form = fold_is_reorderable(op_add, TypeId<T>::value) && !(merge_env && merge_env[0] == '0');
+        const char* heavy_env  = std::getenv("SPLAHIP_MXMT_HEAVY");// len(A row) + len(B row) above which an entry leaves the lane-per-entry merge
+        const uint  heavy_from = heavy_env ? (uint) std::strtoul(heavy_env, nullptr, 10) : kHeavy;
         const char* factor_env   = std::getenv("SPLAHIP_MXMT_MERGE_FACTOR");// longer row <= factor x shorter row: block merge (default 128; 32 / 128 / all = 13.6 / 13.1 / 13.5 ms on the R-MAT 20 triangle form)
         const uint  merge_factor = factor_env ? (uint) std::strtoul(factor_env, nullptr, 10) : 128u;
 
@@ -839,7 +841,7 @@ namespace splahip {
         hipLaunchKernelGGL((mxmT_entry_kernel<T, DynBin, DynBin>), dim3((n_entries + 255) / 256), dim3(256), 0, s, n_rows, n_entries, Mp, Mj,
                            static_cast<const T*>(Mx), Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(),
                            keep.as<uint>(), hcount.as<uint>(), hlist.as<uint>(), DynBin(op_mult), DynBin(op_add), op_select, init, row_form ? kRowCap : 0u,
-                           row_form ? cost.as<uint>() : nullptr, merge_form ? 1u : 0u, merge_factor);
+                           row_form ? cost.as<uint>() : nullptr, merge_form ? 1u : 0u, merge_factor, heavy_from);
         SPLAHIP_TRY(hipGetLastError());
         uint h_heavy[2] = {0, 0}, h_first[2] = {0, 0};
         if (row_form) {
