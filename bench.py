@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
 """bench.py — masked SpMV (exec_mxv_masked hot path) on MI355X: GTEPS + achieved HBM GB/s vs roofline.
 
-A "step" is ONE pass of the hot path over one batch of synthetic input: one masked SpMV of the BFS-step
-configuration (BASELINE.json configs[1]): R-MAT scale 22 (edge factor 16, self loops + duplicates removed,
-~64 M nnz), int32, op_mult = BAND, op_add = BOR, mask = BFS depth vector at the peak-frontier level with
-EQZERO (selects unvisited rows), v = that level's frontier as a dense 0/1 vector, init 0.  Inputs are resident
-in HBM before the timed region.  With N > 1 ranks (one process per GPU, launched by torch.distributed.run) the
-matrix is the R-MAT of scale 22 + log2(N) split into N nnz-balanced 1-D row blocks (weak scaling: ~64 M nnz per
-GPU) and every step first all-gathers the dense input vector over RCCL, then runs the local SpMV.
+Default workload (`--workload spmv-fp32`, the contract line since round 3) = the configuration north_star's >= 60 % target is quoted on:
+fp32 MULT / PLUS over all rows of a ~100 M-nnz scale-free CSR (R-MAT scale 23, 131 M nnz) — bench_spmv.py.  A "step" is ONE masked SpMV with
+the matrix (and its column-ordered-blocks copy) and the vectors resident in HBM.  With N > 1 ranks (one process per GPU, launched by
+torch.distributed.run) the matrix is the R-MAT of scale 23 + log2(N) split into N nnz-balanced 1-D row blocks (weak scaling: ~131 M nnz per
+GPU) and every step runs through the C-ABI dist layer (splahip_dist_mxv_masked: RCCL all-gather of the dense vector overlapped with the
+local-column part).
 
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` and `cpu_baseline`, and a `variants`
-list with the other measured forms of the same kernel family (early-exit BFS step, all-rows fp32 plus-times).
+`--workload bfs-step` = BASELINE.json configs[1], the contract line of rounds 1-2 (kept as variants[0] of the default line): one masked SpMV
+of the BFS step on R-MAT scale 22, int32, op_mult = BAND, op_add = BOR, mask = BFS depth vector at the peak-frontier level with EQZERO
+(selects unvisited rows), v = that level's frontier as a dense 0/1 vector, init 0.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` and `cpu_baseline`, and a `variants` list with the other measured
+forms of the same kernel family.
 """
 from __future__ import annotations
 
@@ -52,7 +55,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--scale", type=int, default=22, help="R-MAT scale per GPU (global scale = scale + log2(gpus))")
+    p.add_argument("--scale", type=int, default=0, help="R-MAT scale per GPU (global scale = scale + log2(gpus)); 0 = the workload's own (23 for spmv-fp32, 22 for bfs-step, ...)")
     p.add_argument("--edge-factor", type=int, default=16)
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--permute", type=int, default=-1, help="vertex relabelling: 0 raw, 1 random, 2 owner-sorted (one pseudo-random share of the "
@@ -66,9 +69,14 @@ def parse():
     p.add_argument("--no-variants", action="store_true")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--no-scale23", action="store_true", help="skip the R-MAT scale-23 fp32 plus-times variant (the ~100 M-nnz north-star configuration)")
-    p.add_argument("--workload", default="bfs-step", choices=["bfs-step", "pagerank-vxm", "sssp-step", "tc-mxmT", "mxm", "algorithms", "transpose"],
-                   help="bfs-step (default, the contract line) or one of the other hot-path operators (bench_workloads.py; N = 1 only)")
-    return p.parse_args()
+    p.add_argument("--workload", default="spmv-fp32", choices=["spmv-fp32", "bfs-step", "pagerank-vxm", "sssp-step", "tc-mxmT", "mxm", "algorithms", "transpose"],
+                   help="spmv-fp32 (default, the contract line: the north-star configuration), bfs-step (BASELINE configs[1], the contract line of rounds 1-2) "
+                        "or one of the other hot-path operators (bench_workloads.py; N = 1 only)")
+    a = p.parse_args()
+    a.scale_given = a.scale != 0
+    if a.scale == 0 and a.workload != "spmv-fp32":
+        a.scale = 22  # (bench_workloads.py maps 22 to each workload's own scale)
+    return a
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -208,13 +216,43 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    if args.workload == "spmv-fp32":
+        import bench_spmv
+        line = bench_spmv.run(args, rank, world)
+        if world == 1 and not args.no_variants:  # the contract line of rounds 1-2 (BASELINE configs[1]) rides along as variants[0]
+            import copy
+            b = copy.copy(args)
+            b.scale, b.no_scale23, b.steps, b.warmup = 22, True, max(20, args.steps), args.warmup
+            bl = bfs_step_line(b, rank, world)
+            keep = ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "verified", "cpu_baseline")
+            v0 = {"name": "BFS step (BASELINE configs[1]; the contract line of rounds 1-2)", **{k: bl[k] for k in keep if k in bl}}
+            v0["variants"] = [x for x in bl.get("variants", []) if x["name"].startswith("bfs-step")]
+            line["variants"] = [v0] + line.pop("variants_same_matrix", [])
+        elif "variants_same_matrix" in line:
+            line["variants"] = line.pop("variants_same_matrix")
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.workload != "bfs-step":
         if world != 1:
-            raise SystemExit("this operator workload runs on one GPU (sssp-step and the default bfs-step take --gpus N)")
+            raise SystemExit("this operator workload runs on one GPU (sssp-step, bfs-step and the default spmv-fp32 take --gpus N)")
         import bench_workloads
         print(json.dumps(bench_workloads.WORKLOADS[args.workload](args)), flush=True)
         return
+    out = bfs_step_line(args, rank, world)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+def bfs_step_line(args, rank, world):
+    """BASELINE configs[1]: the BFS-step masked SpMV on R-MAT scale 22 (+ log2 N), the bench line of rounds 1-2."""
+    from spla_amd import kernels
     g = build_graph(args, rank, world)
     sh = Sharded(g, rank, world)
     n_local, nnz_local = sh.n_local, g["nnz_local"]
@@ -398,12 +436,7 @@ def main():
 
     if not args.no_variants:
         out["variants"] = variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total, nnz_sel_local)
-
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return out
 
 
 def verify_full(g, sh, mask, v_full, r, Ax):

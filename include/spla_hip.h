@@ -84,18 +84,25 @@ int splahip_csr_plan_sell_info(splahip_plan plan, uint32_t* n_slices, uint32_t* 
 /* sell_values: *uniform = 1 when every stored value of the matrix is the same 4-byte word (*bits), as in a graph's adjacency matrix of
  * ones; the sparse-vector (bit) form then streams the 4-byte column words only — a structure-only pass, 4 B per entry instead of 8.   */
 int splahip_csr_plan_sell_values(splahip_plan plan, int* uniform, uint32_t* bits);
-/* Optional: a "column-ordered blocks" copy of the matrix, kept with the plan (+8 bytes per entry; DESIGN.md 4.9, spla_amd/csrc/kernels/mxv_cob.hpp).
- * Rows are cut into ranges of 2^row_bits rows whose result slice lives in LDS; a range's entries are stored sorted by column, so the
- * gathers of v ascend and one 128-byte request serves several products; products enter the slice with the LDS atomic of op_add.
- * With it splahip_mxv_masked serves every call without early exit whose op_add has such an atomic (PLUS; MIN / MAX / BOR / BAND / BXOR on
- * int and uint; LOR / LAND): int / uint results stay bit-identical, fp32 PLUS folds in column-block order (1e-5 relative).
- * row_bits: 0 = default (14), else 8..15; tile_chunks: 0 = every workgroup walks one equal span of the chunk sequence, cut into pieces at range
- * boundaries only; > 0 = pieces of at most that many 256-entry chunks (tests: many pieces and partial slabs on small inputs).  The copy holds the VALUES:
- * rebuild it when Aj or Ax change.  A hypersparse matrix (more (range, column window) groups than nnz / 512) is left without a copy.
- * Blocks.  cob_info: workgroups, chunks, partial slabs, row_bits (all 0 when no copy was built).                                  */
+/* Optional: a "column-ordered blocks" copy of the matrix, kept with the plan (+8 bytes per entry + 2 bytes per row; DESIGN.md 4.9,
+ * spla_amd/csrc/kernels/mxv_cob.hpp).  Rows are grouped into ranges of at most R rows whose result slice lives in LDS — the rows of highest
+ * degree, sorted by degree, form "hub" ranges; the other rows that hold an entry fill "natural" ranges in row order — and a range's entries are
+ * stored sorted by column, so the gathers of v ascend and one 128-byte request serves several products; products enter the slice with the LDS
+ * atomic of op_add.  With it splahip_mxv_masked serves every call without early exit whose op_add has such an atomic (PLUS; MIN / MAX / BOR /
+ * BAND / BXOR on int and uint; LOR / LAND; fp32 MIN / MAX over op_mult = PLUS when the matrix holds no -0.0f): int / uint results and fp32 MIN /
+ * MAX stay bit-identical to the reference; fp32 PLUS folds in column-block order, in double, rounded once per row and piece (1e-5 relative) and
+ * is NOT bit-reproducible from run to run (the arrival order of the atomics differs) — the CSR kernels are: SPLAHIP_COB=0 keeps every call on them.
+ * row_bits: 0 = the library's R (20224 slots: a double slice of that many rows fills a CU's LDS), else R = 2^row_bits, 8..14; tile_chunks: 0 = a
+ * range larger than one workgroup slot's share of the chunks is cut into equal pieces that meet in a shared accumulator (memory-side atomics, the
+ * last piece to arrive finishes the rows); > 0 = pieces of at most that many 256-entry chunks (tests: many pieces on small inputs).  The copy holds
+ * the VALUES: rebuild it when Aj or Ax change.  A hypersparse matrix (more (range, column window) groups than nnz / 512) is left without a copy.
+ * One call at a time per plan: the shared accumulators, tickets and the per-call bitmap of v belong to the plan.
+ * Blocks.  cob_info: workgroups, chunks, ranges cut into several pieces, slots per range (all 0 when no copy was built);
+ * cob_layout: ranges, hub ranges, hub rows, device bytes held by the copy.                                                          */
 int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, uint32_t row_bits,
                                 uint32_t tile_chunks, void* stream);
-int splahip_csr_plan_cob_info(splahip_plan plan, uint32_t* n_tiles, uint32_t* n_chunks, uint32_t* n_slabs, uint32_t* row_bits);
+int splahip_csr_plan_cob_info(splahip_plan plan, uint32_t* n_tiles, uint32_t* n_chunks, uint32_t* n_multi, uint32_t* slots_per_range);
+int splahip_csr_plan_cob_layout(splahip_plan plan, uint32_t* n_ranges, uint32_t* n_hub_ranges, uint32_t* n_hub_rows, uint64_t* bytes);
 int splahip_csr_plan_destroy(splahip_plan plan);
 /* n_items: work items; n_long: rows cut into segment items */
 int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_items, uint32_t* n_long);

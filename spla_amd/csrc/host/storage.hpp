@@ -137,10 +137,8 @@ namespace spla {
         std::vector<uint> Ap, Aj;
         std::vector<T>    Ax;
     };
-    // row_bits of the column-ordered-blocks copy (spla_hip.h: splahip_csr_plan_attach_cob): 0 = the library's default, 2^14 rows per range (both the
-    // 4-byte and the double LDS slice fit twice per CU).  2^15-row ranges help the VALUE form of an integer matrix of >= 2^23 rows (R-MAT 24 int
-    // min-plus with every entry gathering v: 976 -> 828 us) but cost the sparse-input-vector form, which is what the integer workloads of this path
-    // (BFS / SSSP steps: most of v is the skipped value) run: 0.70 ms with 2^14, 0.80 ms with 2^15 (profiles/r02_notes.md) — so: the default.
+    // row_bits of the column-ordered-blocks copy (spla_hip.h: splahip_csr_plan_attach_cob): 0 = the library's own range size for every type
+    // (20224 slots per range since round 3: a double slice of that many rows fills a CU's LDS, two 4-byte slices share it)
     template<typename T>
     inline uint32_t cob_row_bits(uint64_t) {
         return 0u;

@@ -4,14 +4,18 @@
 // Semantics served: reference Algo_mxv_masked_cpu, src/cpu/cpu_mxv.hpp:88-103, and the dense-frontier case of Algo_vxm_masked_cpu,
 // src/cpu/cpu_vxm.hpp:92-125, for an op_add with an LDS atomic (mxv_cob.hpp: cob_acc_kind).  Kernels: mxv_cob.hpp.
 //
-// Build (all on the device; the host reads three counters):
-//   1. cob_key_kernel     key(k) = ((range << cbits | column) << row_bits) | row_in_range for every stored entry, by one binary search of
+// Build (all on the device; the host reads a few counters and one byte per 8 rows):
+//   0. rows -> ranges     row degrees; the rows of degree >= max(16, 2 x average) sorted by degree become HUB ranges of R rows (at most
+//                         SPLAHIP_COB_HUB_RANGES = 16 ranges); the other rows that hold an entry fill NATURAL ranges of <= R such rows in row
+//                         order (boundaries at multiples of 8 rows, chosen by one greedy pass on the host over per-8-row counts)
+//   1. cob_key_kernel     key(k) = ((range << cbits | column) << 15) | slot_in_range for every stored entry, by one binary search of
 //                         the entry's 2048-entry tile in Ap and one inside the tile's row span
 //   2. a stable LSD radix sort of the keys on the (range, column) bits only, carrying the value word (rocprim, one-off per matrix):
-//      inside a (range, column) run the entries keep ascending row order
+//      inside a (range, column) run the entries keep their order
 //   3. cob_group_kernel   first sorted entry of every (range, column window) group by binary search; chunks per group; scan
 //   4. cob_scatter_kernel one workgroup per chunk: pack cr / ax / hdr, pad a group's last chunk
-//   5. cob_tile_kernels   tiles (<= tile_chunks consecutive chunks of one range), slab ids of the ranges that need several tiles
+//   5. the schedules      pieces (consecutive chunks of one range, at most one workgroup slot's share), largest first; shared accumulators
+//                         and tickets of the ranges cut into several pieces
 #include "block_utils.hpp"
 #include "common.hpp"
 #include "mxv_cob.hpp"
@@ -43,18 +47,85 @@ namespace {
         return lo;
     }
 
+    constexpr uint32_t kSlotBits = 15;// slot field of a sort key and of a cr word: R <= 2^15 - 1 (the value R itself marks a padding slot)
+
+    __global__ __launch_bounds__(256) void cob_deg_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, uint32_t* __restrict__ deg, uint32_t* __restrict__ row_id) {
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        if (i < n_rows) {
+            deg[i]    = Ap[i + 1] - Ap[i];
+            row_id[i] = i;
+        }
+    }
+    // deg_s is sorted descending: out[0] = number of rows of degree >= thr (one thread)
+    __global__ void cob_count_ge_kernel(uint32_t n_rows, const uint32_t* __restrict__ deg_s, uint32_t thr, uint32_t* __restrict__ out) {
+        uint32_t lo = 0, hi = n_rows;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (deg_s[mid] >= thr) lo = mid + 1;
+            else
+                hi = mid;
+        }
+        out[0] = lo;
+    }
+    // the H rows of highest degree take hub slots in degree order: rowmap = range << 15 | slot, slot16 = hub; hub_row lists them (padded to whole ranges)
+    __global__ __launch_bounds__(256) void cob_hub_kernel(uint32_t H, uint32_t H_padded, uint32_t R, const uint32_t* __restrict__ order, uint32_t* __restrict__ rowmap,
+                                                          uint16_t* __restrict__ slot16, uint32_t* __restrict__ hub_row) {
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= H_padded) return;
+        if (i < H) {
+            const uint32_t row = order[i];
+            rowmap[row]        = ((i / R) << kSlotBits) | (i % R);
+            slot16[row]        = (uint16_t) kCobSlotHub;
+            hub_row[i]         = row;
+        } else
+            hub_row[i] = 0xFFFFFFFFu;
+    }
+    // rows that take a natural slot (an entry, no hub) per group of 8 rows
+    __global__ __launch_bounds__(256) void cob_group8_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const uint16_t* __restrict__ slot16, uint8_t* __restrict__ cnt8) {
+        const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+        if (g * 8 >= n_rows) return;
+        uint32_t c = 0;
+        for (uint32_t row = g * 8; row < min(n_rows, g * 8 + 8); ++row) c += (Ap[row + 1] != Ap[row] && slot16[row] != kCobSlotHub) ? 1u : 0u;
+        cnt8[g] = (uint8_t) c;
+    }
+    // natural slots: gmap[g] = range << 15 | slot of the group's first slot-taking row (from the host's greedy pass)
+    __global__ __launch_bounds__(256) void cob_rowmap_kernel(uint32_t n_rows, uint32_t n_rows8, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ gmap,
+                                                             uint32_t* __restrict__ rowmap, uint16_t* __restrict__ slot16) {
+        const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+        if (g * 8 >= n_rows8) return;
+        uint32_t m = gmap[g];
+        for (uint32_t row = g * 8; row < g * 8 + 8; ++row) {
+            if (row >= n_rows) {
+                slot16[row] = (uint16_t) kCobSlotEmpty;// the padding behind the last row
+                continue;
+            }
+            if (slot16[row] == kCobSlotHub) continue;
+            if (Ap[row + 1] == Ap[row]) {
+                slot16[row] = (uint16_t) kCobSlotEmpty;
+                continue;
+            }
+            rowmap[row] = m;
+            slot16[row] = (uint16_t) (m & ((1u << kSlotBits) - 1u));
+            ++m;
+        }
+    }
+    // fill (accumulators to the identity of the running op_add; tickets to 0)
+    __global__ __launch_bounds__(256) void cob_fill32_kernel(size_t n, uint32_t* __restrict__ p, uint32_t w) {
+        for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) p[i] = w;
+    }
+
     __global__ __launch_bounds__(256) void cob_key_kernel(uint32_t n_rows, uint32_t nnz, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ Aj,
-                                                          uint32_t row_bits, uint32_t cbits, unsigned long long* __restrict__ key) {
+                                                          const uint32_t* __restrict__ rowmap, uint32_t cbits, unsigned long long* __restrict__ key) {
         const uint32_t k0 = blockIdx.x * kKeyTile;
         const uint32_t k1 = min(nnz, k0 + kKeyTile);
         // rows spanned by this tile of the entry stream (uniform searches: every lane reads the same words)
         const uint32_t r_lo = upper_bound_u32(Ap, n_rows + 1, k0) - 1;
         const uint32_t r_hi = upper_bound_u32(Ap, n_rows + 1, k1 - 1) - 1;
-        const uint32_t rmask = (1u << row_bits) - 1u;
         for (uint32_t k = k0 + threadIdx.x; k < k1; k += 256) {
             const uint32_t row = r_lo + upper_bound_u32(Ap + r_lo, r_hi - r_lo + 1, k) - 1;
-            const unsigned long long range = row >> row_bits;
-            key[k] = (((range << cbits) | Aj[k]) << row_bits) | (row & rmask);
+            const uint32_t m   = rowmap[row];
+            const unsigned long long range = m >> kSlotBits;
+            key[k] = (((range << cbits) | Aj[k]) << kSlotBits) | (m & ((1u << kSlotBits) - 1u));
         }
     }
 
@@ -79,8 +150,9 @@ namespace {
 
     // one workgroup (256 threads = 256 slots) per chunk
     __global__ __launch_bounds__(256) void cob_scatter_kernel(const unsigned long long* __restrict__ key, const uint32_t* __restrict__ val, const uint32_t* __restrict__ start,
-                                                              const uint32_t* __restrict__ chunk_first, uint32_t n_groups, uint32_t row_bits, uint32_t col_bits,
-                                                              uint32_t win_bits, uint32_t* __restrict__ cr, uint32_t* __restrict__ ax, uint32_t* __restrict__ hdr) {
+                                                              const uint32_t* __restrict__ chunk_first, uint32_t n_groups, uint32_t R, uint32_t col_bits,
+                                                              uint32_t win_bits, uint32_t* __restrict__ cr, uint32_t* __restrict__ ax, uint32_t* __restrict__ hdr,
+                                                              uint32_t* __restrict__ chunk_lines) {
         const uint32_t c = blockIdx.x;
         const uint32_t g = upper_bound_u32(chunk_first, n_groups + 1, c) - 1;// largest g with chunk_first[g] <= c (uniform)
         const uint32_t i = c - chunk_first[g];
@@ -88,25 +160,33 @@ namespace {
         // memory position p = 4 * lane + j holds the chunk's sorted entry 64 * j + lane: a lane's 16-byte load brings its four slots, and the
         // wave's j-th gather instruction covers 64 consecutive sorted entries (ascending, neighbouring columns)
         const uint32_t src = s0 + i * kCobChunk + 64 * (threadIdx.x & 3) + (threadIdx.x >> 2);
-        uint32_t       w = (1u << row_bits) << col_bits, x = 0;// padding: row field R (the spare LDS word), column offset 0
+        uint32_t       w = R << col_bits, x = 0;// padding: slot field R (the spare LDS word), column offset 0
         if (src < s1) {
             const unsigned long long k = key[src];
-            const uint32_t           rl = (uint32_t) k & ((1u << row_bits) - 1u);
-            const uint32_t           co = (uint32_t) (k >> row_bits) & ((1u << col_bits) - 1u);
+            const uint32_t           rl = (uint32_t) k & ((1u << kSlotBits) - 1u);
+            const uint32_t           co = (uint32_t) (k >> kSlotBits) & ((1u << col_bits) - 1u);
             w                           = (rl << col_bits) | co;
             x                           = val[src];
         }
         cr[(size_t) c * kCobChunk + threadIdx.x] = w;
         ax[(size_t) c * kCobChunk + threadIdx.x] = x;
+        // distinct 128-byte lines of v among the chunk's entries (they are sorted by column: count the changes): what the gathers of this chunk cost
+        bool fresh = false;
+        if (src < s1) {
+            const uint32_t line = (uint32_t) (key[src] >> (kSlotBits + 5)) & ((1u << (col_bits - 5)) - 1u);
+            fresh               = src == s0 + i * kCobChunk || line != ((uint32_t) (key[src - 1] >> (kSlotBits + 5)) & ((1u << (col_bits - 5)) - 1u));
+        }
+        const int lines = __syncthreads_count(fresh);
         if (threadIdx.x == 0) {
             const uint32_t window = win_bits ? (g & ((1u << win_bits) - 1u)) : 0u;
             hdr[c]                = window << col_bits;
+            chunk_lines[c]        = (uint32_t) lines;
         }
     }
 
-    __global__ __launch_bounds__(256) void cob_padchunk_kernel(uint32_t c, uint32_t row_bits, uint32_t col_bits, uint32_t* __restrict__ cr, uint32_t* __restrict__ ax,
+    __global__ __launch_bounds__(256) void cob_padchunk_kernel(uint32_t c, uint32_t R, uint32_t col_bits, uint32_t* __restrict__ cr, uint32_t* __restrict__ ax,
                                                                uint32_t* __restrict__ hdr) {
-        cr[(size_t) c * kCobChunk + threadIdx.x] = (1u << row_bits) << col_bits;
+        cr[(size_t) c * kCobChunk + threadIdx.x] = R << col_bits;
         ax[(size_t) c * kCobChunk + threadIdx.x] = 0;
         if (threadIdx.x == 0) hdr[c] = 0;
     }
@@ -135,14 +215,6 @@ namespace {
             bits[c >> 5]       = (uint32_t) b;
             bits[(c >> 5) + 1] = (uint32_t) (b >> 32);
         }
-    }
-
-    // rows of ranges that hold no entry at all: r = init (grid.y = empty range)
-    template<typename T>
-    __global__ __launch_bounds__(256) void cob_fill_kernel(const uint32_t* __restrict__ empty_ranges, uint32_t n_rows, uint32_t row_bits, T* __restrict__ r, T init) {
-        const uint32_t i   = blockIdx.x * 256 + threadIdx.x;
-        const uint32_t row = (empty_ranges[blockIdx.y] << row_bits) + i;
-        if (i < (1u << row_bits) && row < n_rows) r[row] = init;
     }
 
     struct Scratch {
@@ -190,7 +262,7 @@ namespace {
     // any negative / NaN value, and the largest value, of the copy's value words (padding slots hold 0)
     template<typename T>
     __global__ __launch_bounds__(256) void cob_ax_stats_kernel(size_t n, const T* __restrict__ x, uint32_t* __restrict__ out) {
-        uint32_t bad = 0, mx = 0;
+        uint32_t bad = 0, mx = 0, nz = 0;
         for (size_t k = (size_t) blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t) gridDim.x * 256) {
             const T a = x[k];
             if constexpr (std::is_same<T, uint32_t>::value) mx = max(mx, a);
@@ -198,26 +270,29 @@ namespace {
                 if (a < T(0) || a != a) bad = 1;
                 else if constexpr (std::is_same<T, int32_t>::value)
                     mx = max(mx, (uint32_t) a);
+                if constexpr (std::is_same<T, float>::value) nz |= to_bits(a) == 0x80000000u ? 1u : 0u;
             }
         }
         bad = wave_max(bad);
         mx  = wave_max(mx);
+        nz  = wave_max(nz);
         if (lane_id() == 0) {
             if (bad) atomicOr(&out[0], 1u);
             atomicMax(&out[1], mx);
+            if (nz) atomicOr(&out[2], 1u);
         }
     }
     template<typename T>
     int cob_ax_stats(const splahip_cob_s* g, hipStream_t st) {
         if (g->ax_type == TypeId<T>::value) return SPLAHIP_OK;
         DevMem out;
-        SPLAHIP_TRY(out.alloc(st, 8));
-        SPLAHIP_TRY(hipMemsetAsync(out.p, 0, 8, st));
+        SPLAHIP_TRY(out.alloc(st, 16));
+        SPLAHIP_TRY(hipMemsetAsync(out.p, 0, 16, st));
         hipLaunchKernelGGL((cob_ax_stats_kernel<T>), dim3(1024), dim3(256), 0, st, (size_t) g->n_chunks * kCobChunk, reinterpret_cast<const T*>(g->d_ax), out.as<uint32_t>());
-        uint32_t h[2] = {1, 0};
-        SPLAHIP_TRY(hipMemcpyAsync(h, out.p, 8, hipMemcpyDeviceToHost, st));
+        uint32_t h[4] = {1, 0, 1, 0};
+        SPLAHIP_TRY(hipMemcpyAsync(h, out.p, 16, hipMemcpyDeviceToHost, st));
         SPLAHIP_TRY(hipStreamSynchronize(st));
-        g->ax_bad = h[0], g->ax_max = h[1], g->ax_type = TypeId<T>::value;
+        g->ax_bad = h[0], g->ax_max = h[1], g->ax_negzero = h[2], g->ax_type = TypeId<T>::value;
         return SPLAHIP_OK;
     }
 
@@ -226,19 +301,22 @@ namespace {
                    uint32_t init_bits, hipStream_t st) {
         constexpr int               W  = sizeof(typename CobSlice<T, ACC>::word) == 8 ? 1 : 0;
         const splahip_cob_sched_s&  sc = g->sched[W];
+        (void) Ap;// which rows hold an entry is part of the copy (slot16)
         CobArgs                     a;
-        a.span_first = sc.d_span_first;
         a.tiles      = reinterpret_cast<const CobTile*>(sc.d_tiles);
-        a.hdr      = g->d_hdr;
-        a.cr       = g->d_cr;
-        a.ax       = g->d_ax;
-        a.Ap       = Ap;
-        a.slabs    = g->d_slabs;
-        a.touched  = touched;
-        a.n_rows   = g->n_rows;
-        a.row_bits = g->row_bits;
-        a.col_bits = g->col_bits;
-        a.pad_chunk = g->n_chunks;
+        a.ranges     = reinterpret_cast<const CobRange*>(sc.d_ranges);
+        a.hdr        = g->d_hdr;
+        a.cr         = g->d_cr;
+        a.ax         = g->d_ax;
+        a.slot16     = g->d_slot16;
+        a.hub_row    = g->d_hub_row;
+        a.acc        = g->d_acc;
+        a.ticket     = g->d_ticket;
+        a.touched    = touched;
+        a.n_rows     = g->n_rows;
+        a.R          = g->R;
+        a.col_bits   = g->col_bits;
+        a.pad_chunk  = g->n_chunks;
         a.accumulate = VXM ? 0u : tl_accumulate;
         a.vbits      = g->d_vbits;
         a.x_uniform  = g->x_bits;
@@ -246,31 +324,22 @@ namespace {
             hipLaunchKernelGGL((cob_vbits_kernel<T>), dim3((g->n_cols + 255) / 256), dim3(256), 0, st, g->n_cols, static_cast<const T*>(v), g->d_vbits, tl_skip_bits);
             SPLAHIP_TRY(hipGetLastError());
         }
-        const T        init = from_bits<T>(init_bits);
-        const uint32_t R    = 1u << g->row_bits;
-        if (sc.n_tiles) {
-            static bool lds_raised = false;// a range of 16 Ki rows plus the spare words is just over the 64 KB a kernel gets without asking
-            if (!lds_raised) {
-                SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                160 * 1024));
-                lds_raised = true;
-            }
-            hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), dim3(sc.n_spans), dim3(kTpb), (R + 4) * sizeof(typename CobSlice<T, ACC>::word), st, a, static_cast<const T*>(v),
-                               static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
+        const T init = from_bits<T>(init_bits);
+        if (!sc.n_tiles) return SPLAHIP_OK;
+        // the shared accumulators rest at the identity of the op_add that used them last: re-arm them when this call's differs
+        const uint32_t n_multi_max = std::max(g->sched[0].n_multi, g->sched[1].n_multi);
+        if (n_multi_max && (!g->acc_armed || g->acc_identity != cob_identity<T, ACC>())) {
+            hipLaunchKernelGGL(cob_fill32_kernel, dim3(256), dim3(256), 0, st, (size_t) n_multi_max * g->R, g->d_acc, cob_identity<T, ACC>());
+            hipLaunchKernelGGL(cob_fill32_kernel, dim3(1), dim3(256), 0, st, (size_t) n_multi_max, g->d_ticket, 0u);
             SPLAHIP_TRY(hipGetLastError());
+            g->acc_identity = cob_identity<T, ACC>();
+            g->acc_armed    = true;
         }
-        if (sc.n_multi) {
-            const uint32_t bx = (R / 4 + 255) / 256;
-            hipLaunchKernelGGL((cob_combine_kernel<T, DynBin, ACC, VXM, 256>), dim3(bx, sc.n_multi), dim3(256), 0, st, reinterpret_cast<const CobMulti*>(sc.d_multi), g->d_slabs, Ap,
-                               static_cast<const T*>(mask), static_cast<T*>(r), touched, g->n_rows, g->row_bits, DynBin(op_add), op_select, init, a.accumulate);
-            SPLAHIP_TRY(hipGetLastError());
-        }
-        if (g->n_empty && !a.accumulate) {// ranges without an entry: r = init (mxv) / touched = 0 (vxm); an accumulating pass leaves them alone
-            if constexpr (VXM) hipLaunchKernelGGL((cob_fill_kernel<uint32_t>), dim3((R + 255) / 256, g->n_empty), dim3(256), 0, st, g->d_empty, g->n_rows, g->row_bits, touched, 0u);
-            else
-                hipLaunchKernelGGL((cob_fill_kernel<T>), dim3((R + 255) / 256, g->n_empty), dim3(256), 0, st, g->d_empty, g->n_rows, g->row_bits, static_cast<T*>(r), init);
-            SPLAHIP_TRY(hipGetLastError());
-        }
+        // a range of 16 Ki+ slots plus the spare words is over the 64 KB a kernel gets without asking (cheap; per device, so not cached in a static)
+        SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), dim3(sc.n_tiles), dim3(kTpb), ((size_t) g->R + 4) * sizeof(typename CobSlice<T, ACC>::word), st, a,
+                           static_cast<const T*>(v), static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
+        SPLAHIP_TRY(hipGetLastError());
         return SPLAHIP_OK;
     }
 
@@ -292,14 +361,16 @@ namespace {
         }
         // the same form for min-plus (PLUS / MIN on int / uint, sell_skip_family == 2: the shortest-path step): an entry whose v value is `init` cannot
         // lower a minimum that starts at init, provided no matrix value is negative and init + max(A) does not wrap (checked once per type / per call)
-        if constexpr (!VXM && !std::is_same<T, float>::value && ACC == COB_MIN) {
+        if constexpr (!VXM && ACC == COB_MIN) {
             const char* be = std::getenv("SPLAHIP_COB_BITS");
             // (worth it once v no longer fits the L2s: R-MAT 24, 67 MB of v: 0.83 -> 0.70 ms; R-MAT 22, 16.8 MB: 178 -> 204 us.  SPLAHIP_COB_BITS=2 forces it)
             const bool big = g->n_cols >= (1u << 23) || (be && be[0] == '2');
             if (g->d_vbits && big && !(be && be[0] == '0') && !tl_accumulate && sell_skip_family(TypeId<T>::value, op_mult, op_add) == 2) {
                 if (int rc = cob_ax_stats<T>(g, st)) return rc;
-                const bool fits = std::is_same<T, int32_t>::value ? (long long) (int32_t) init_bits + (long long) g->ax_max <= 0x7FFFFFFFll
-                                                                  : (unsigned long long) init_bits + (unsigned long long) g->ax_max <= 0xFFFFFFFFull;
+                // (fp32: x >= 0 gives x + init >= init for every init that is no NaN — the reference's fp32 SSSP step, init = +inf)
+                const bool fits = std::is_same<T, float>::value ? from_bits<float>(init_bits) == from_bits<float>(init_bits)
+                                  : std::is_same<T, int32_t>::value ? (long long) (int32_t) init_bits + (long long) g->ax_max <= 0x7FFFFFFFll
+                                                                    : (unsigned long long) init_bits + (unsigned long long) g->ax_max <= 0xFFFFFFFFull;
                 if (!g->ax_bad && fits) {
                     tl_skip_bits = init_bits;
                     const int rc = launch_cob<T, StaBin<SPLAHIP_PLUS>, ACC, VXM, 1>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
@@ -312,7 +383,7 @@ namespace {
         if constexpr (ACC == COB_ADD) {
             if (op_mult == SPLAHIP_MULT) return launch_cob<T, StaBin<SPLAHIP_MULT>, ACC, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
         }
-        if constexpr (ACC == COB_MIN) {
+        if constexpr (ACC == COB_MIN || (ACC == COB_MAX && std::is_same<T, float>::value)) {
             if (op_mult == SPLAHIP_PLUS) return launch_cob<T, StaBin<SPLAHIP_PLUS>, ACC, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
         }
         if constexpr (ACC == COB_OR && !std::is_same<T, float>::value) {
@@ -343,8 +414,18 @@ namespace {
                 case COB_XOR: return cob_by_mult<T, COB_XOR, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
                 default: break;
             }
+        } else {// fp32 MIN / MAX over op_mult = PLUS: the keyed slice (mxv_cob.hpp: cob_fkey); cob_float_minmax_ok has been asked by the caller
+            if (op_mult == SPLAHIP_PLUS && op_add == SPLAHIP_MIN) return cob_by_mult<T, COB_MIN, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
+            if (op_mult == SPLAHIP_PLUS && op_add == SPLAHIP_MAX) return cob_by_mult<T, COB_MAX, VXM>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
         }
         return fail(SPLAHIP_NOT_IMPLEMENTED, "the column-ordered-blocks form has no LDS atomic for this op_add");
+    }
+
+    // fp32 MIN / MAX over PLUS: served when the copy's values hold no -0.0f (then no product is -0.0f; mxv_cob.hpp: cob_fkey); the value pass
+    // runs once per matrix on the stream of the first such call
+    bool cob_float_minmax_ok(const splahip_cob_s* g, void* stream) {
+        if (cob_ax_stats<float>(g, as_stream(stream)) != SPLAHIP_OK) return false;
+        return g->ax_negzero == 0;
     }
 
 }// namespace
@@ -353,8 +434,8 @@ namespace splahip {
 
     void cob_release(splahip_cob_s* g) {
         if (!g) return;
-        for (void* p : {(void*) g->d_hdr, (void*) g->d_cr, (void*) g->d_ax, (void*) g->d_slabs, (void*) g->d_empty, (void*) g->d_vbits, (void*) g->sched[0].d_span_first,
-                        (void*) g->sched[0].d_tiles, (void*) g->sched[0].d_multi, (void*) g->sched[1].d_span_first, (void*) g->sched[1].d_tiles, (void*) g->sched[1].d_multi})
+        for (void* p : {(void*) g->d_hdr, (void*) g->d_cr, (void*) g->d_ax, (void*) g->d_slot16, (void*) g->d_hub_row, (void*) g->d_acc, (void*) g->d_ticket, (void*) g->d_vbits,
+                        (void*) g->sched[0].d_tiles, (void*) g->sched[0].d_ranges, (void*) g->sched[1].d_tiles, (void*) g->sched[1].d_ranges})
             if (p) (void) hipFree(p);
         delete g;
     }
@@ -364,7 +445,18 @@ namespace splahip {
         const int acc = cob_acc_kind(op_add, type);
         if (acc == COB_NONE) return false;
         const bool wide = acc == COB_ADD && type == SPLAHIP_FLOAT;// fp32 sums keep a double slice
-        return plan->cob->sched[wide ? 1 : 0].n_spans != 0;
+        return plan->cob->sched[wide ? 1 : 0].n_tiles != 0;
+    }
+
+    // the masked SpMV's own question: cob_serves, plus fp32 MIN / MAX over op_mult = PLUS (the reference's fp32 SSSP semiring) when the matrix
+    // holds no -0.0f (one pass over the copy's values on `stream`, the first time it is asked)
+    bool cob_serves_mxv(const splahip_plan_s* plan, int type, int op_mult, int op_add, uint32_t n_cols, void* stream) {
+        if (cob_serves(plan, type, op_add, n_cols)) return true;
+        if (!plan || !plan->cob || plan->cob->n_cols != n_cols || cob_disabled()) return false;
+        if (type != SPLAHIP_FLOAT || cob_acc_kind_mxv(op_add, op_mult, type) == COB_NONE || plan->cob->sched[0].n_tiles == 0) return false;
+        const char* e = std::getenv("SPLAHIP_COB_FMINMAX");
+        if (e && e[0] == '0') return false;
+        return cob_float_minmax_ok(plan->cob, stream);
     }
 
     int cob_mxv(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
@@ -414,36 +506,130 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     }
     if (plan->nnz == 0 || plan->n_rows == 0 || n_cols == 0) return SPLAHIP_OK;// nothing to lay out: mxv keeps the CSR kernels
     SPLAHIP_REQUIRE(d_Ap && d_Aj && d_Ax, "null device pointer");
-    if (row_bits == 0) row_bits = env_u32("SPLAHIP_COB_ROW_BITS", 14);
-    if (tile_chunks == 0) tile_chunks = env_u32("SPLAHIP_COB_TILE_CHUNKS", 0);// 0: pieces are cut at range and span boundaries only
-    SPLAHIP_REQUIRE(row_bits >= 8 && row_bits <= 15, "row_bits must be in [8, 15] (the range's result slice lives in LDS: 4 << row_bits bytes)");
+    // slots per range: row_bits = 0 -> the library's choice, 20224 (a double slice of that many rows + the spare words fills the 160 KB of LDS a CU has,
+    // and two 4-byte slices fit it together); row_bits in [8, 14] -> 2^row_bits (tests: many ranges and pieces on small inputs)
+    uint32_t R = row_bits ? 0u : env_u32("SPLAHIP_COB_SLOTS", 0);
+    if (R == 0) {
+        if (row_bits == 0) row_bits = env_u32("SPLAHIP_COB_ROW_BITS", 0);
+        SPLAHIP_REQUIRE(row_bits == 0 || (row_bits >= 8 && row_bits <= 14), "row_bits must be 0 or in [8, 14] (the range's result slice lives in LDS)");
+        R = row_bits ? (1u << row_bits) : 20224u;
+    }
+    SPLAHIP_REQUIRE(R % 256 == 0 && R >= 256 && R <= 20224, "slots per range must be a multiple of 256 in [256, 20224]");
+    if (tile_chunks == 0) tile_chunks = env_u32("SPLAHIP_COB_TILE_CHUNKS", 0);// 0: pieces are cut at range and share boundaries only
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
     hipStream_t    s      = as_stream(stream);
     const uint32_t n_rows = plan->n_rows, nnz = plan->nnz;
+    const uint32_t n_rows8 = (n_rows + 7) & ~7u;
 
-    const uint32_t col_bits = 31 - row_bits;                              // the row field is one bit wider than a row needs (padding slots: row value R)
+    const uint32_t col_bits = 31 - kSlotBits;                            // a cr word: 15-bit slot field (the value R marks padding) + 16-bit... 17 column bits
     const uint32_t cbits    = std::max(bits_for(n_cols), col_bits);      // column field of the sort key: at least one whole window
     const uint32_t win_bits = cbits - col_bits;                          // column windows per range = 2^win_bits
-    const uint32_t n_ranges = (uint32_t) (((uint64_t) n_rows + (1u << row_bits) - 1) >> row_bits);
-    const uint64_t n_groups64 = (uint64_t) n_ranges << win_bits;
-    // every (range, window) group pads its last chunk: with more groups than nnz / 512 the copy would be mostly padding (a hypersparse
-    // matrix) — the CSR kernels keep such a matrix
-    if (n_groups64 > (uint64_t) nnz / 512 + 64 || n_groups64 >= (1u << 30)) return SPLAHIP_OK;
-    const uint32_t n_groups = (uint32_t) n_groups64;
-    SPLAHIP_REQUIRE(row_bits + cbits + bits_for(n_ranges) <= 64, "key does not fit 64 bits");
 
     Scratch tmp;
     auto*   g   = new splahip_cob_s();
     g->n_rows   = n_rows;
     g->n_cols   = n_cols;
-    g->row_bits = row_bits;
+    g->R        = R;
     g->col_bits = col_bits;
     hipError_t e    = hipSuccess;
     auto       bail = [&](const char* what) {
         cob_release(g);
         return fail(SPLAHIP_ERROR, "column-ordered-blocks plan failed (%s): %s", what, hipGetErrorString(e));
     };
+    auto own = [&](auto** q, size_t count) {
+        using U = std::remove_pointer_t<std::remove_pointer_t<decltype(q)>>;
+        if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(q), sizeof(U) * (count ? count : 1));
+        if (e == hipSuccess) g->bytes += sizeof(U) * (count ? count : 1);
+    };
+
+    // 0: rows -> (range, slot).  Hub rows first.
+    uint32_t *deg = nullptr, *deg_s = nullptr, *row_id = nullptr, *order = nullptr, *rowmap = nullptr, *cnt = nullptr;
+    e = tmp.alloc(&deg, n_rows);
+    if (e == hipSuccess) e = tmp.alloc(&deg_s, n_rows);
+    if (e == hipSuccess) e = tmp.alloc(&row_id, n_rows);
+    if (e == hipSuccess) e = tmp.alloc(&order, n_rows);
+    if (e == hipSuccess) e = tmp.alloc(&rowmap, n_rows);
+    if (e == hipSuccess) e = tmp.alloc(&cnt, 4);
+    own(&g->d_slot16, (size_t) n_rows8 + 8);
+    if (e != hipSuccess) return bail("scratch");
+    e = hipMemsetAsync(g->d_slot16, 0, sizeof(uint16_t) * ((size_t) n_rows8 + 8), s);// no row is a hub yet
+    const uint32_t max_hub_ranges = env_u32("SPLAHIP_COB_HUB_RANGES", 16);
+    // hub candidates: degree >= max(16, 2 x average); SPLAHIP_COB_HUB_MIN_DEGREE sets the threshold itself (tests: hub ranges on small inputs)
+    const uint32_t thr            = env_u32("SPLAHIP_COB_HUB_MIN_DEGREE", std::max<uint32_t>(16, (uint32_t) (2ull * nnz / n_rows)));
+    uint32_t       H              = 0;
+    if (max_hub_ranges && e == hipSuccess) {
+        hipLaunchKernelGGL(cob_deg_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, n_rows, d_Ap, deg, row_id);
+        size_t bytes = 0;
+        e            = rocprim::radix_sort_pairs_desc(nullptr, bytes, deg, deg_s, row_id, order, (size_t) n_rows, 0, 32, s);
+        void* st_tmp = nullptr;
+        if (e == hipSuccess) e = device_malloc(&st_tmp, bytes ? bytes : 4);
+        if (e == hipSuccess) {
+            tmp.ptrs.push_back(st_tmp);
+            e = rocprim::radix_sort_pairs_desc(st_tmp, bytes, deg, deg_s, row_id, order, (size_t) n_rows, 0, 32, s);
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(cob_count_ge_kernel, dim3(1), dim3(1), 0, s, n_rows, deg_s, thr, cnt);
+            e = hipMemcpyAsync(&H, cnt, 4, hipMemcpyDeviceToHost, s);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return bail("hub rows");
+        H = (uint32_t) std::min<uint64_t>(H, (uint64_t) max_hub_ranges * R);
+        if (H < R / 8) H = 0;// not a skewed matrix: every row stays in its natural range
+    }
+    const uint32_t n_hub_ranges = (H + R - 1) / R;
+    g->n_hub_ranges             = n_hub_ranges;
+    g->n_hub_rows               = H;
+    own(&g->d_hub_row, (size_t) n_hub_ranges * R);
+    if (e != hipSuccess) return bail("hub list");
+    if (H) hipLaunchKernelGGL(cob_hub_kernel, dim3((n_hub_ranges * R + 255) / 256), dim3(256), 0, s, H, n_hub_ranges * R, R, order, rowmap, g->d_slot16, g->d_hub_row);
+    // natural ranges: one greedy pass on the host over the per-8-row counts of slot-taking rows; a range closes when the next group would overflow
+    // its R slots, or its span a bound that keeps one workgroup's row pass short
+    std::vector<uint8_t>  h_cnt8(n_rows8 / 8);
+    std::vector<uint32_t> h_gmap(n_rows8 / 8), nat_row0;
+    {
+        uint8_t* cnt8 = nullptr;
+        e             = tmp.alloc(&cnt8, h_cnt8.size());
+        if (e != hipSuccess) return bail("scratch");
+        hipLaunchKernelGGL(cob_group8_kernel, dim3((n_rows8 / 8 + 255) / 256), dim3(256), 0, s, n_rows, d_Ap, g->d_slot16, cnt8);
+        e = hipMemcpyAsync(h_cnt8.data(), cnt8, h_cnt8.size(), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return bail("row counts");
+        const uint32_t span_cap = std::max(8u, env_u32("SPLAHIP_COB_SPAN_CAP", 8) * R);
+        uint32_t       q = n_hub_ranges, used = 0, span = 0;
+        nat_row0.push_back(0);
+        for (size_t gi = 0; gi < h_cnt8.size(); ++gi) {
+            if (used + h_cnt8[gi] > R || span + 8 > span_cap) {
+                nat_row0.push_back((uint32_t) gi * 8);
+                ++q, used = 0, span = 0;
+            }
+            h_gmap[gi] = (q << kSlotBits) | used;
+            used += h_cnt8[gi];
+            span += 8;
+        }
+        nat_row0.push_back(n_rows);
+    }
+    const uint32_t n_nat    = (uint32_t) nat_row0.size() - 1;
+    const uint32_t n_ranges = n_hub_ranges + n_nat;
+    g->n_ranges             = n_ranges;
+    const uint64_t n_groups64 = (uint64_t) n_ranges << win_bits;
+    // every (range, window) group pads its last chunk: with more groups than nnz / 512 the copy would be mostly padding (a hypersparse
+    // matrix) — the CSR kernels keep such a matrix
+    if (n_groups64 > (uint64_t) nnz / 512 + 64 || n_groups64 >= (1u << 30) || n_ranges >= (1u << 17)) {
+        cob_release(g);
+        return SPLAHIP_OK;
+    }
+    const uint32_t n_groups = (uint32_t) n_groups64;
+    SPLAHIP_REQUIRE(kSlotBits + cbits + bits_for(n_ranges) <= 64, "key does not fit 64 bits");
+    {
+        uint32_t* gmap = nullptr;
+        e              = tmp.alloc(&gmap, h_gmap.size());
+        if (e == hipSuccess) e = hipMemcpyAsync(gmap, h_gmap.data(), 4 * h_gmap.size(), hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return bail("row map");
+        hipLaunchKernelGGL(cob_rowmap_kernel, dim3((n_rows8 / 8 + 255) / 256), dim3(256), 0, s, n_rows, n_rows8, d_Ap, gmap, rowmap, g->d_slot16);
+        e = hipStreamSynchronize(s);// h_gmap is read by the copy
+        if (e != hipSuccess) return bail("row map");
+    }
 
     // 1 + 2: keys, stable sort on the (range, column) bits
     unsigned long long *key = nullptr, *key_s = nullptr;
@@ -452,12 +638,12 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     if (e == hipSuccess) e = tmp.alloc(&key_s, nnz);
     if (e == hipSuccess) e = tmp.alloc(&val_s, nnz);
     if (e != hipSuccess) return bail("scratch");
-    hipLaunchKernelGGL(cob_key_kernel, dim3((nnz + kKeyTile - 1) / kKeyTile), dim3(256), 0, s, n_rows, nnz, d_Ap, d_Aj, row_bits, cbits, key);
+    hipLaunchKernelGGL(cob_key_kernel, dim3((nnz + kKeyTile - 1) / kKeyTile), dim3(256), 0, s, n_rows, nnz, d_Ap, d_Aj, rowmap, cbits, key);
     e = hipGetLastError();
     {
         size_t      bytes = 0;
         const auto* vin   = static_cast<const uint32_t*>(d_Ax);
-        const unsigned b0 = row_bits, b1 = row_bits + cbits + bits_for(n_ranges);
+        const unsigned b0 = kSlotBits, b1 = kSlotBits + cbits + bits_for(n_ranges);
         if (b1 == b0) {// one range, one column: the entries are in order already
             if (e == hipSuccess) e = hipMemcpyAsync(key_s, key, sizeof(unsigned long long) * nnz, hipMemcpyDeviceToDevice, s);
             if (e == hipSuccess) e = hipMemcpyAsync(val_s, vin, sizeof(uint32_t) * nnz, hipMemcpyDeviceToDevice, s);
@@ -478,7 +664,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     e = tmp.alloc(&start, (size_t) n_groups + 1);
     if (e == hipSuccess) e = tmp.alloc(&chunk_first, (size_t) n_groups + 1);
     if (e != hipSuccess) return bail("scratch");
-    hipLaunchKernelGGL(cob_group_kernel, dim3((n_groups + 256) / 256), dim3(256), 0, s, nnz, key_s, row_bits + col_bits, n_groups, start);
+    hipLaunchKernelGGL(cob_group_kernel, dim3((n_groups + 256) / 256), dim3(256), 0, s, nnz, key_s, kSlotBits + col_bits, n_groups, start);
     hipLaunchKernelGGL(cob_chunk_count_kernel, dim3((n_groups + 255) / 256), dim3(256), 0, s, n_groups, start, chunk_first);
     hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk_first, n_groups);
     e = hipGetLastError();
@@ -489,105 +675,115 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     g->n_chunks = n_chunks;
 
     // 4: the packed streams
-    auto own = [&](auto** q, size_t count) {
-        using U = std::remove_pointer_t<std::remove_pointer_t<decltype(q)>>;
-        if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(q), sizeof(U) * (count ? count : 1));
-    };
-    own(&g->d_cr, ((size_t) n_chunks + 1) * kCobChunk);// + one all-padding chunk (the main loop's steps beyond a tile's end walk it)
+    own(&g->d_cr, ((size_t) n_chunks + 1) * kCobChunk);// + one all-padding chunk (the main loop's steps beyond a piece's end walk it)
     own(&g->d_ax, ((size_t) n_chunks + 1) * kCobChunk);
     own(&g->d_hdr, (size_t) n_chunks + 1);
     if (e != hipSuccess) return bail("hipMalloc");
-    hipLaunchKernelGGL(cob_padchunk_kernel, dim3(1), dim3(256), 0, s, n_chunks, row_bits, col_bits, g->d_cr, g->d_ax, g->d_hdr);
-    hipLaunchKernelGGL(cob_scatter_kernel, dim3(n_chunks), dim3(256), 0, s, key_s, val_s, start, chunk_first, n_groups, row_bits, col_bits, win_bits, g->d_cr, g->d_ax,
-                       g->d_hdr);
+    hipLaunchKernelGGL(cob_padchunk_kernel, dim3(1), dim3(256), 0, s, n_chunks, R, col_bits, g->d_cr, g->d_ax, g->d_hdr);
+    uint32_t* chunk_lines = nullptr;
+    e                     = tmp.alloc(&chunk_lines, (size_t) n_chunks + 1);
+    if (e != hipSuccess) return bail("scratch");
+    if (n_chunks)
+        hipLaunchKernelGGL(cob_scatter_kernel, dim3(n_chunks), dim3(256), 0, s, key_s, val_s, start, chunk_first, n_groups, R, col_bits, win_bits, g->d_cr, g->d_ax, g->d_hdr,
+                           chunk_lines);
     e = hipGetLastError();
     if (e != hipSuccess) return bail("scatter");
 
     // 5: the work schedules, on the host (a few hundred pieces).  A piece = consecutive chunks of ONE range (the LDS slice belongs to a range) =
-    // one workgroup.  A range of at most `share` chunks — what one workgroup slot of the chip would get if the chunks were dealt evenly — is a
-    // single piece and finishes its rows itself; a larger range is cut into equal pieces of at most `share` chunks that store partial slabs
-    // (cob_combine_kernel folds them in piece order).  Workgroups are launched largest piece first, so the small pieces fill the tail.
-    // tile_chunks > 0 caps a piece explicitly (tests: many pieces and slabs on small inputs).
-    std::vector<uint32_t> h_first((size_t) n_groups + 1);
+    // one workgroup.  What a chunk costs a CU is its memory requests: 16 lines of the two streams + the distinct lines of v its gathers touch
+    // (round 3 timeline, profiles/r03_notes.md: a hub piece walks a chunk in 80 - 100 ns, a cold natural piece in 150 - 700 ns — a CU's miss queue
+    // holds ~76 requests whatever they bring), so pieces are cut by that cost, not by chunk count: a range that costs at most `share` — what one
+    // workgroup slot of the chip would get if the cost were dealt evenly, times SPLAHIP_COB_SHARE_PCT % — is a single piece and finishes its rows
+    // itself; a dearer range is cut into pieces of equal cost that meet in the range's shared accumulator (mxv_cob.hpp).  Workgroups are launched
+    // dearest piece first, so the cheap pieces fill the tail.  tile_chunks > 0 caps a piece's chunks explicitly (tests: many pieces on small inputs).
+    std::vector<uint32_t> h_first((size_t) n_groups + 1), h_lines((size_t) n_chunks + 1);
     e = hipMemcpyAsync(h_first.data(), chunk_first, sizeof(uint32_t) * h_first.size(), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && n_chunks) e = hipMemcpyAsync(h_lines.data(), chunk_lines, sizeof(uint32_t) * n_chunks, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return bail("schedule");
     std::vector<uint32_t> range_chunk((size_t) n_ranges + 1);
     for (uint32_t q = 0; q <= n_ranges; ++q) range_chunk[q] = h_first[(size_t) q << win_bits];
-    std::vector<uint32_t> empty;
-    for (uint32_t q = 0; q < n_ranges; ++q)
-        if (range_chunk[q + 1] == range_chunk[q]) empty.push_back(q);
-    g->n_empty = (uint32_t) empty.size();
-    own(&g->d_empty, empty.size());
-    if (e == hipSuccess && !empty.empty()) e = hipMemcpyAsync(g->d_empty, empty.data(), 4 * empty.size(), hipMemcpyHostToDevice, s);
+    // cost of a chunk in units of one stream line's stay in the miss queue: 16 stream lines + its gather lines weighted SPLAHIP_COB_LINE_PCT % (default 60:
+    // part of them hit the L2); cost_pre[c] = cost of the chunks before c
+    const uint32_t        line_pct = env_u32("SPLAHIP_COB_LINE_PCT", 60);
+    std::vector<uint64_t> cost_pre((size_t) n_chunks + 1, 0);
+    for (uint32_t c = 0; c < n_chunks; ++c) cost_pre[c + 1] = cost_pre[c] + 1600 + (uint64_t) h_lines[c] * line_pct;
     const uint32_t cus = compute_units();
-    uint32_t       max_slabs = 0;
+    uint32_t       max_multi = 0;
     for (int w = 0; w < 2 && e == hipSuccess; ++w) {
         splahip_cob_sched_s& sc     = g->sched[w];
-        const size_t         lds    = ((size_t) (1u << row_bits) + 4) * (w ? 8 : 4);
+        const size_t         lds    = ((size_t) R + 4) * (w ? 8 : 4);
         const uint32_t       per_cu = (uint32_t) std::min<size_t>(env_u32("SPLAHIP_COB_PER_CU", 2), (160 * 1024) / lds);// 1024-thread workgroups: at most 2 per CU
         if (per_cu == 0) continue;                                                         // this slice width does not fit: not served
         const uint32_t slots = cus * per_cu;
-        // piece size in % of a slot's even share.  Larger pieces mean fewer slabs to write and merge, smaller ones a better-balanced tail; measured
-        // (fp32, one workgroup per CU, pieces in brackets): R-MAT 22 — 100 / 140 / 200 / 300 % = 171.9 (402) / 171.1 (378) / 188 (329) / 271 us (280);
-        // R-MAT 23 — 405.8 (657) / 373.8 (598) / 380.5 (584) / 494 us (536).  SPLAHIP_COB_SHARE_PCT overrides.
-        auto pieces_at = [&](uint32_t pct) -> uint32_t {
-            const uint32_t sh = std::max(1u, (n_chunks + slots - 1) / slots * pct / 100);
-            uint32_t       n  = 0;
-            for (uint32_t q = 0; q < n_ranges; ++q) n += (range_chunk[q + 1] - range_chunk[q] + sh - 1) / sh;
-            return n;
-        };
-        // (the 4-byte schedule, two workgroups per CU, keeps 100 %: the SSSP step at R-MAT 24 runs 0.70 ms with 100 % and 0.76 ms with 140 %)
-        const uint32_t share_pct = env_u32("SPLAHIP_COB_SHARE_PCT", w ? 140 : 100);
-        const uint32_t share     = std::max(1u, (n_chunks + slots - 1) / slots * share_pct / 100);
-        if (std::getenv("SPLAHIP_COB_TRACE")) std::fprintf(stderr, "[cob] schedule %d: slots %u, piece size %u %% of a share = %u chunks, %u pieces\n", w, slots, share_pct, share, pieces_at(share_pct));
-        const uint32_t cap   = tile_chunks ? tile_chunks : share;
-        std::vector<uint32_t> tiles, multi;
-        std::vector<uint32_t> range_pieces(n_ranges, 0u);
+        // piece size in % of a slot's even share of the cost.  Smaller pieces balance the tail better, larger ones mean fewer partial slices to merge.
+        const uint32_t share_pct = env_u32("SPLAHIP_COB_SHARE_PCT", 50);
+        const uint64_t share     = std::max<uint64_t>(1, (cost_pre[n_chunks] + slots - 1) / slots * share_pct / 100);
+        std::vector<uint32_t> tiles, ranges((size_t) n_ranges * 4);
+        std::vector<uint64_t> cost;
+        uint32_t              n_multi = 0;
         for (uint32_t q = 0; q < n_ranges; ++q) {
-            const uint32_t cc = range_chunk[q + 1] - range_chunk[q];
-            if (cc == 0) continue;
-            const uint32_t np = (cc + cap - 1) / cap, per = cc / np, rem = cc % np;
-            uint32_t       f  = range_chunk[q];
+            const uint32_t c0 = range_chunk[q], c1 = range_chunk[q + 1], cc = c1 - c0;
+            const bool     hub = q < n_hub_ranges;
+            const uint32_t row0 = hub ? 0u : nat_row0[q - n_hub_ranges], row1 = hub ? 0u : nat_row0[q - n_hub_ranges + 1];
+            const uint64_t rc   = cost_pre[c1] - cost_pre[c0];
+            uint32_t       np   = (uint32_t) std::max<uint64_t>(1, (rc + share - 1) / share);
+            if (tile_chunks) np = std::max(np, (cc + tile_chunks - 1) / tile_chunks);
+            np = std::max(1u, std::min(np, std::max(1u, cc)));
+            // the row pass of the range (its last piece to arrive): rows x (2 B slot + 4 B result [+ 4 B mask]) for a natural range, R scattered words for a hub range
+            const uint64_t row_pass = hub ? (uint64_t) R * 8 : (uint64_t) (row1 - row0) / 4;
+            uint32_t       f = c0, first_tile = (uint32_t) (tiles.size() / 4);
             for (uint32_t t = 0; t < np; ++t) {
-                const uint32_t len = per + (t < rem ? 1u : 0u);
-                tiles.insert(tiles.end(), {f, len, q, kCobNoSlab});
-                f += len;
+                // piece t ends where the range's cost passes (t + 1) / np of its total (at least one chunk per piece)
+                uint32_t end = c1;
+                if (t + 1 < np) {
+                    const uint64_t target = cost_pre[c0] + rc * (t + 1) / np;
+                    end                   = (uint32_t) (std::lower_bound(cost_pre.begin() + f + 1, cost_pre.begin() + c1, target) - cost_pre.begin());
+                    end                   = std::max(end, f + 1);
+                    end                   = std::min(end, c1 - (np - 1 - t));
+                    if (tile_chunks) end = std::min(end, f + tile_chunks);
+                }
+                tiles.insert(tiles.end(), {f, end - f, q, kCobNoSlab});
+                cost.push_back(cost_pre[end] - cost_pre[f] + (t == 0 ? row_pass : 0));
+                f = end;
             }
-            range_pieces[q] = np;
-        }
-        // slab ids in piece order: the pieces of a range are consecutive
-        uint32_t n_slabs = 0;
-        for (size_t t = 0; t < tiles.size() / 4; ++t) {
-            const uint32_t rq = tiles[4 * t + 2];
-            if (range_pieces[rq] > 1) {
-                if (multi.empty() || multi[multi.size() - 4] != rq) multi.insert(multi.end(), {rq, n_slabs, 0u, 0u});
-                ++multi[multi.size() - 2];
-                tiles[4 * t + 3] = n_slabs++;
+            if (tile_chunks && f < c1) {// an explicit cap left chunks over: more pieces of at most tile_chunks
+                while (f < c1) {
+                    const uint32_t end = std::min(c1, f + tile_chunks);
+                    tiles.insert(tiles.end(), {f, end - f, q, kCobNoSlab});
+                    cost.push_back(cost_pre[end] - cost_pre[f]);
+                    f = end;
+                }
             }
+            const uint32_t pieces = (uint32_t) (tiles.size() / 4) - first_tile;
+            if (pieces > 1) {
+                for (uint32_t t = first_tile; t < first_tile + pieces; ++t) tiles[4 * (size_t) t + 3] = n_multi;
+                ++n_multi;
+            }
+            ranges[4 * (size_t) q + 0] = row0, ranges[4 * (size_t) q + 1] = row1, ranges[4 * (size_t) q + 2] = hub ? q * R : 0xFFFFFFFFu, ranges[4 * (size_t) q + 3] = pieces;
         }
-        // launch order: largest piece first (stable: equal pieces keep range order)
+        // launch order: dearest piece first (stable: equal pieces keep range order)
         const uint32_t        n_tiles = (uint32_t) (tiles.size() / 4);
-        std::vector<uint32_t> order(n_tiles), sorted(tiles.size()), span_first((size_t) n_tiles + 1);
-        for (uint32_t t = 0; t < n_tiles; ++t) order[t] = t;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return tiles[4 * x + 1] > tiles[4 * y + 1]; });
+        std::vector<uint32_t> order_t(n_tiles), sorted(tiles.size());
+        for (uint32_t t = 0; t < n_tiles; ++t) order_t[t] = t;
+        std::stable_sort(order_t.begin(), order_t.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
         for (uint32_t t = 0; t < n_tiles; ++t)
-            for (int k = 0; k < 4; ++k) sorted[4 * t + k] = tiles[4 * order[t] + k];
-        for (uint32_t t = 0; t <= n_tiles; ++t) span_first[t] = t;
-        sc.n_spans = n_tiles;
+            for (int k = 0; k < 4; ++k) sorted[4 * t + k] = tiles[4 * order_t[t] + k];
+        if (std::getenv("SPLAHIP_COB_TRACE"))
+            std::fprintf(stderr, "[cob] schedule %d: R %u, %u hub rows in %u hub ranges + %u natural ranges; slots %u, cost %.1f M (%.1f %% gathers), piece <= %u %% of a share, %u pieces, "
+                                 "%u ranges in several pieces\n",
+                         w, R, H, n_hub_ranges, n_nat, slots, cost_pre[n_chunks] / 1e8, 100.0 - 100.0 * 1600.0 * n_chunks / std::max<uint64_t>(1, cost_pre[n_chunks]), share_pct, n_tiles, n_multi);
         sc.n_tiles = n_tiles;
-        sc.n_slabs = n_slabs;
-        sc.n_multi = (uint32_t) (multi.size() / 4);
-        max_slabs  = std::max(max_slabs, n_slabs);
-        own(&sc.d_span_first, span_first.size());
+        sc.n_multi = n_multi;
+        max_multi  = std::max(max_multi, n_multi);
         own(&sc.d_tiles, sorted.size());
-        own(&sc.d_multi, multi.size());
-        if (e == hipSuccess) e = hipMemcpyAsync(sc.d_span_first, span_first.data(), 4 * span_first.size(), hipMemcpyHostToDevice, s);
+        own(&sc.d_ranges, ranges.size());
         if (e == hipSuccess && !sorted.empty()) e = hipMemcpyAsync(sc.d_tiles, sorted.data(), 4 * sorted.size(), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess && !multi.empty()) e = hipMemcpyAsync(sc.d_multi, multi.data(), 4 * multi.size(), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(sc.d_ranges, ranges.data(), 4 * ranges.size(), hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);// the vectors go out of scope
     }
-    own(&g->d_slabs, (size_t) max_slabs << row_bits);
+    own(&g->d_acc, (size_t) max_multi * R);
+    own(&g->d_ticket, (size_t) max_multi + 4);
     own(&g->d_vbits, ((size_t) n_cols + 255) / 256 * 8 + 2);// every wave of cob_vbits_kernel writes its two words
     if (e != hipSuccess) return bail("schedule upload");
     {// one value word in the whole matrix?  (the sparse-vector form then skips the value stream)
@@ -609,12 +805,29 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     return SPLAHIP_OK;
 }
 
-extern "C" int splahip_csr_plan_cob_info(splahip_plan plan, uint32_t* n_tiles, uint32_t* n_chunks, uint32_t* n_slabs, uint32_t* row_bits) {
+extern "C" int splahip_csr_plan_cob_info(splahip_plan plan, uint32_t* n_tiles, uint32_t* n_chunks, uint32_t* n_multi, uint32_t* slots_per_range) {
     SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
     const splahip_cob_s* g = plan->cob;
     if (n_tiles) *n_tiles = g ? std::max(g->sched[0].n_tiles, g->sched[1].n_tiles) : 0;
     if (n_chunks) *n_chunks = g ? g->n_chunks : 0;
-    if (n_slabs) *n_slabs = g ? std::max(g->sched[0].n_slabs, g->sched[1].n_slabs) : 0;
-    if (row_bits) *row_bits = g ? g->row_bits : 0;
+    if (n_multi) *n_multi = g ? std::max(g->sched[0].n_multi, g->sched[1].n_multi) : 0;
+    if (slots_per_range) *slots_per_range = g ? g->R : 0;
     return SPLAHIP_OK;
 }
+
+extern "C" int splahip_csr_plan_cob_layout(splahip_plan plan, uint32_t* n_ranges, uint32_t* n_hub_ranges, uint32_t* n_hub_rows, uint64_t* bytes) {
+    SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
+    const splahip_cob_s* g = plan->cob;
+    if (n_ranges) *n_ranges = g ? g->n_ranges : 0;
+    if (n_hub_ranges) *n_hub_ranges = g ? g->n_hub_ranges : 0;
+    if (n_hub_rows) *n_hub_rows = g ? g->n_hub_rows : 0;
+    if (bytes) *bytes = g ? (uint64_t) g->bytes : 0;
+    return SPLAHIP_OK;
+}
+
+#ifdef SPLAHIP_COB_TIMING
+// DIAGNOSTIC BUILD ONLY: copy out the per-workgroup stamps of the last cob launch (8 x 8192 64-bit words)
+extern "C" int splahip_debug_cob_timing(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(splahip::g_cob_t), sizeof(unsigned long long) * 8 * 8192) == hipSuccess ? SPLAHIP_OK : SPLAHIP_ERROR;
+}
+#endif

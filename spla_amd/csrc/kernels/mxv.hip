@@ -207,9 +207,11 @@ int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_items, uint32_t* n_long
 }
 
 const char* splahip_mxv_variant_of(splahip_plan plan, int type, int op_mult, int op_add, int early_exit) {
-    if (!early_exit && plan && plan->cob && cob_serves(plan, type, op_add, plan->cob->n_cols) &&
+    if (!early_exit && plan && plan->cob && cob_serves_mxv(plan, type, op_mult, op_add, plan->cob->n_cols, nullptr) &&
         !(plan->sell && !sell_disabled() && sell_skip_family(type, op_mult, op_add) == 1))
-        return type == SPLAHIP_FLOAT && op_add == SPLAHIP_PLUS ? "mxv_cob<column-ordered blocks, fp64 LDS accumulation>" : "mxv_cob<column-ordered blocks, LDS accumulation>";
+        return type == SPLAHIP_FLOAT && op_add == SPLAHIP_PLUS ? "mxv_cob<column-ordered blocks, fp64 LDS accumulation>"
+               : type == SPLAHIP_FLOAT && (op_add == SPLAHIP_MIN || op_add == SPLAHIP_MAX) ? "mxv_cob<column-ordered blocks, order-preserving integer keys in LDS>"
+                                                                                            : "mxv_cob<column-ordered blocks, LDS accumulation>";
     if (plan && plan->sell && !early_exit && fold_is_reorderable(op_add, type) && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add)) && !sell_disabled()) {
         if (sell_skip_family(type, op_mult, op_add) != 0)// the device picks the bit form or the value form from the input vector's statistics
             return static_semiring(type, op_mult, op_add) ? "mxv_sell<static semiring; sparse-vector bit form | value form>" : "mxv_sell<runtime ops; sparse-vector bit form | value form>";
@@ -248,7 +250,7 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
     // When the plan also holds a sliced-ELL copy, the semirings of its sparse-vector (bit) form whose skippable value is 0 (BAND / BOR, LAND / LOR,
     // ... on int / uint: a BFS step, where a few per cent of v are non-zero and half the rows are masked out) stay with it: it reads only the
     // selected rows' entries and one bit per column; every other call is faster over the column-ordered blocks (SPLAHIP_PREFER=cob|sell overrides).
-    if (!early_exit && cob_serves(plan, type, op_add, n_cols) && d_r != d_mask && d_r != d_v && (reinterpret_cast<uintptr_t>(d_r) & 15u) == 0) {
+    if (!early_exit && cob_serves_mxv(plan, type, op_mult, op_add, n_cols, stream) && d_r != d_mask && d_r != d_v && (reinterpret_cast<uintptr_t>(d_r) & 15u) == 0) {
         const char* pref     = std::getenv("SPLAHIP_PREFER");
         const bool  sell_ok  = plan->sell && plan->sell->n_cols == n_cols && !sell_disabled() && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add));
         const bool  use_sell = sell_ok && (pref ? pref[0] == 's' : sell_skip_family(type, op_mult, op_add) == 1);

@@ -6,22 +6,29 @@
 // so int / uint results are bit-identical to the reference and fp32 PLUS differs by rounding only (the stated 1e-5 bar).
 //
 // Why this form exists (profiles/r01_notes.md): with one 4-byte gather of v per entry every L1-missing gather costs a
-// 128-byte request, and the chip serves ~110 G such requests per second: R-MAT scale 22 needs 28.7 M of them beyond the 4.2 M lines
-// of the entry stream.  Here the rows are cut into RANGES of R = 2^row_bits consecutive rows whose result slice lives in LDS, and a
-// range's entries are stored sorted by column, so the 64 lanes of a wave gather ascending, mostly neighbouring columns of v: one request
-// serves several products (7.4 M gather requests for the same matrix at R = 16 Ki, 5.5 M at 32 Ki; tools/exp/sim_requests.py), and the
-// products are added into the LDS slice with ds_add / ds_min / ds_or ... — no row walk, no segmented reduction, no padding by row length.
+// 128-byte request, and the chip serves ~110 G such requests per second.  Here the rows are grouped into RANGES of at most R rows whose
+// result slice lives in LDS, and a range's entries are stored sorted by column, so the 64 lanes of a wave gather ascending, mostly
+// neighbouring columns of v: one request serves several products, and the products are added into the LDS slice with ds_add / ds_min /
+// ds_or ... — no row walk, no segmented reduction, no padding by row length.
+//
+// Which rows share a range decides how many distinct lines of v a range touches (round 3, tools/exp/sim_ranges.py: R-MAT 22, 128-byte
+// lines summed over ranges: 6.5 M for 2^14 consecutive rows; 3.0 M for the grouping below):
+//   * HUB ranges: the rows of highest degree, sorted by degree, R per range — a few ranges that hold most of the entries, cut into
+//     many pieces by column; slot s of hub range q is row hub_row[q R + s]; their results are scattered to r one word at a time
+//   * NATURAL ranges: consecutive rows in their own order, but only the rows that hold an entry and are no hub take a slot, so a range
+//     spans R such rows however many empty rows lie between them; slot16[row] = slot, 0xFFFF = no entry (r = init), 0xFFFE = hub row
+//     (written by its hub range); a natural range's rows are written in order, 16 bytes per lane where no hub row intervenes
 //
 // Layout (all built on the device, cob.hip):
 //   chunk  = 256 entry slots = one wave iteration (a 16-byte load of 4 slots per lane for each of the two streams); the word at memory
 //            position 4 l + j is the chunk's sorted entry 64 j + l, so the wave's j-th gather instruction covers 64 CONSECUTIVE sorted entries
-//            cr[slot] = row_in_range << col_bits | column - base_col      ax[slot] = value bits      hdr[chunk] = base_col
-//            col_bits = 31 - row_bits: the row field has one bit more than a row needs, and a padding slot carries the row value R,
-//            the spare word behind the LDS slice — no count, no predicate in the loop
+//            cr[slot] = slot_in_range << col_bits | column - base_col      ax[slot] = value bits      hdr[chunk] = base_col
+//            a padding slot carries the slot value R, the spare word behind the LDS slice — no count, no predicate in the loop
 //            a chunk never straddles a (range, column window of 2^col_bits columns) group; only a group's last chunk is padded
-//   tile   = up to T consecutive chunks of ONE range = one workgroup's work: zero the LDS slice, walk the chunks (wave w takes chunks
-//            w, w + waves, ...), then either finish the rows (a range that is a single tile) or store the slice as a partial slab
-//   cob_combine_kernel finishes the rows of the ranges that were cut into several tiles from their slabs, in tile order (deterministic)
+//   piece  = consecutive chunks of ONE range = one workgroup's work: zero the LDS slice, walk the chunks (wave w takes chunks
+//            w, w + waves, ...), then either finish the rows (a range that is a single piece) or add the slice into the range's shared
+//            accumulator in global memory (memory-side atomics of op_add) and take a ticket: the piece that arrives last reads the
+//            accumulator back, re-arms it for the next call, and finishes the rows — one launch, no slabs, no combine pass
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -32,18 +39,25 @@
 
 namespace splahip {
 
+#ifdef SPLAHIP_COB_TIMING
+    // DIAGNOSTIC BUILD ONLY (tools/exp/exp_cob_timing.py): per workgroup of the last cob launch: [0] s_memrealtime at entry, [1] after the slice is zeroed,
+    // [2] after the chunk loop, [3] at exit (100 MHz ticks), [4] XCC id, [5] HW_ID, [6] chunks of the piece, [7] slab id
+    static __device__ unsigned long long g_cob_t[8][8192];
+#endif
+
     struct CobTile {
         uint32_t first_chunk;
         uint32_t n_chunks;
         uint32_t range;
-        uint32_t slab;// partial-slab index, or 0xFFFFFFFF when the tile is the whole range (it finishes its rows itself)
+        uint32_t multi;// index of the range's shared accumulator, or 0xFFFFFFFF when the piece is the whole range (it finishes its rows itself)
     };
-    struct CobMulti {// a range cut into several tiles
-        uint32_t range;
-        uint32_t first_slab;
-        uint32_t n_slabs;
-        uint32_t pad;
+    struct CobRange {
+        uint32_t row0, row1;// natural range: its rows [row0, row1); row0 is a multiple of 8
+        uint32_t hub_base;  // hub range: first word of its slot -> row list in hub_row; 0xFFFFFFFF for a natural range
+        uint32_t n_pieces;
     };
+    constexpr uint32_t kCobSlotEmpty = 0xFFFFu;// slot16: the row holds no entry
+    constexpr uint32_t kCobSlotHub   = 0xFFFEu;// slot16: the row belongs to a hub range
 
     constexpr uint32_t kCobChunk  = 256;// slots per chunk
     constexpr uint32_t kCobNoSlab = 0xFFFFFFFFu;
@@ -74,14 +88,31 @@ namespace splahip {
         }
     }
 
+    // fp32 MIN / MAX (the reference's own SSSP semiring is fp32 min-plus, src/algorithm.cpp:208-213): the slice holds the ORDER-PRESERVING integer
+    // key of a float, b ^ ((b >> 31) & 0x7fffffff) as int32, and products enter it with ds_min_i32 / ds_max_i32.  That is the reference's
+    // b < a ? b : a fold (src/op.cpp:222-227) bit for bit provided (1) NaN products are dropped — std::min / std::max never pick a NaN second
+    // argument, and a NaN accumulator can only come from init, which is folded in last by the reference's own functor — and (2) no product is
+    // -0.0f (key order puts -0 below +0, the reference keeps whichever zero came first): the caller serves op_mult = PLUS only, where a -0
+    // product needs a -0 matrix value, and checks the matrix for one (cob.hip: cob_ax_stats).  A slot still at the identity key held no product.
+    __host__ __device__ inline int32_t cob_fkey(float f) {
+        const uint32_t b = to_bits(f);
+        return (int32_t) (b ^ ((uint32_t) ((int32_t) b >> 31) & 0x7FFFFFFFu));
+    }
+    __host__ __device__ inline float cob_funkey(int32_t k) { return from_bits<float>((uint32_t) k ^ ((uint32_t) (k >> 31) & 0x7FFFFFFFu)); }
+    // which LDS atomic serves (op_add, type) in the masked SpMV, where the caller has checked what the keyed float forms need
+    inline int cob_acc_kind_mxv(int op_add, int op_mult, int type) {
+        if (type == SPLAHIP_FLOAT && op_mult == SPLAHIP_PLUS && (op_add == SPLAHIP_MIN || op_add == SPLAHIP_MAX)) return op_add == SPLAHIP_MIN ? COB_MIN : COB_MAX;
+        return cob_acc_kind(op_add, type);
+    }
+
     // bits of the fold identity the slice starts from
     template<typename T, int ACC>
     __host__ __device__ constexpr uint32_t cob_identity() {
         if constexpr (ACC == COB_ADD) return std::is_same<T, float>::value ? 0x80000000u : 0u;// -0.0f: x + -0.0f == x for every x, +0.0f and -0.0f included
         else if constexpr (ACC == COB_MIN)
-            return std::is_same<T, int32_t>::value ? 0x7FFFFFFFu : 0xFFFFFFFFu;
+            return std::is_same<T, uint32_t>::value ? 0xFFFFFFFFu : 0x7FFFFFFFu;// float: the largest key (the bits of a NaN: no product has them)
         else if constexpr (ACC == COB_MAX)
-            return std::is_same<T, int32_t>::value ? 0x80000000u : 0u;
+            return std::is_same<T, uint32_t>::value ? 0u : 0x80000000u;
         else if constexpr (ACC == COB_AND)
             return 0xFFFFFFFFu;
         else if constexpr (ACC == COB_LAND)
@@ -100,11 +131,15 @@ namespace splahip {
             (void) __hip_atomic_fetch_add(slot, to_bits(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);// int / uint (fp32 sums live in a double slice: cob_accumulate4)
         } else if constexpr (ACC == COB_MIN) {
             if constexpr (std::is_same<T, int32_t>::value) (void) __hip_atomic_fetch_min(reinterpret_cast<int32_t*>(slot), p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else
+            else if constexpr (std::is_same<T, float>::value) {
+                if (p == p) (void) __hip_atomic_fetch_min(reinterpret_cast<int32_t*>(slot), cob_fkey(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else
                 (void) __hip_atomic_fetch_min(slot, to_bits(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else if constexpr (ACC == COB_MAX) {
             if constexpr (std::is_same<T, int32_t>::value) (void) __hip_atomic_fetch_max(reinterpret_cast<int32_t*>(slot), p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else
+            else if constexpr (std::is_same<T, float>::value) {
+                if (p == p) (void) __hip_atomic_fetch_max(reinterpret_cast<int32_t*>(slot), cob_fkey(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else
                 (void) __hip_atomic_fetch_max(slot, to_bits(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else if constexpr (ACC == COB_OR)
             (void) __hip_atomic_fetch_or(slot, to_bits(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -153,41 +188,60 @@ namespace splahip {
         }
     }
 
-    // two partial slices of the same rows (combine pass): the same monoid on plain values
+    // a piece of a range that is cut into several pieces adds its slice word into the range's shared accumulator in global memory: the same
+    // monoid as a memory-side atomic (agent scope, no return value)
     template<typename T, int ACC>
-    __device__ __forceinline__ uint32_t cob_merge(uint32_t a, uint32_t b) {
-        if constexpr (ACC == COB_ADD) return to_bits(wrap_add(from_bits<T>(a), from_bits<T>(b)));
-        else if constexpr (ACC == COB_MIN)
-            return to_bits(eval_bin<SPLAHIP_MIN>(from_bits<T>(a), from_bits<T>(b)));
-        else if constexpr (ACC == COB_MAX)
-            return to_bits(eval_bin<SPLAHIP_MAX>(from_bits<T>(a), from_bits<T>(b)));
-        else if constexpr (ACC == COB_OR || ACC == COB_LOR)
-            return a | b;
+    __device__ __forceinline__ void cob_merge_global(uint32_t* acc, uint32_t w) {
+        if constexpr (ACC == COB_ADD) {
+            if constexpr (std::is_same<T, float>::value) unsafeAtomicAdd(reinterpret_cast<float*>(acc), from_bits<float>(w));// global_atomic_add_f32
+            else
+                (void) __hip_atomic_fetch_add(acc, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if constexpr (ACC == COB_MIN) {
+            if constexpr (std::is_same<T, uint32_t>::value) (void) __hip_atomic_fetch_min(acc, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                (void) __hip_atomic_fetch_min(reinterpret_cast<int32_t*>(acc), (int32_t) w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);// int32, or a float's key
+        } else if constexpr (ACC == COB_MAX) {
+            if constexpr (std::is_same<T, uint32_t>::value) (void) __hip_atomic_fetch_max(acc, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                (void) __hip_atomic_fetch_max(reinterpret_cast<int32_t*>(acc), (int32_t) w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if constexpr (ACC == COB_OR || ACC == COB_LOR)
+            (void) __hip_atomic_fetch_or(acc, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else if constexpr (ACC == COB_AND || ACC == COB_LAND)
-            return a & b;
+            (void) __hip_atomic_fetch_and(acc, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else
-            return a ^ b;
+            (void) __hip_atomic_fetch_xor(acc, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
-    // the row's result from its accumulated slice word: add(init, acc); LOR / LAND slices hold a truth value
+    // the row's result from its accumulated slice word: add(init, acc); LOR / LAND slices hold a truth value, fp32 MIN / MAX slices a key
     template<typename T, int ACC, class Add>
     __device__ __forceinline__ T cob_finish(uint32_t acc, T init, const Add& add) {
         if constexpr (ACC == COB_LOR || ACC == COB_LAND) return add(init, acc ? T(1) : T(0));
+        else if constexpr (std::is_same<T, float>::value && (ACC == COB_MIN || ACC == COB_MAX))
+            return acc == cob_identity<T, ACC>() ? init : add(init, cob_funkey((int32_t) acc));
         else
             return add(init, from_bits<T>(acc));
     }
+    // the fold itself as a value of T (vxm mode: an output is the fold, there is no init)
+    template<typename T, int ACC>
+    __device__ __forceinline__ T cob_value(uint32_t acc) {
+        if constexpr (std::is_same<T, float>::value && (ACC == COB_MIN || ACC == COB_MAX)) return cob_funkey((int32_t) acc);
+        else
+            return from_bits<T>(acc);
+    }
 
     struct CobArgs {
-        const uint32_t* span_first;// first piece of every workgroup (n_spans + 1)
         const CobTile*  tiles;
+        const CobRange* ranges;
         const uint32_t* hdr;// per chunk: first column of its window
         const uint32_t* cr;
         const uint32_t* ax;
-        const uint32_t* Ap;// n_rows + 1 (rows without an entry keep init exactly; LOR / LAND only)
-        uint32_t*       slabs;
+        const uint16_t* slot16; // per row: its slot in its natural range, kCobSlotEmpty, or kCobSlotHub (padded to a multiple of 8 rows)
+        const uint32_t* hub_row;// per hub slot: its row, 0xFFFFFFFF for the padding behind the last hub row
+        uint32_t*       acc;    // shared accumulators of the ranges cut into several pieces (n_multi x R words, at the identity between calls)
+        uint32_t*       ticket; // n_multi arrival counters, 0 between calls
         uint32_t*       touched;// VXM only: per output index, 1 = selected and at least one product
         uint32_t        n_rows;
-        uint32_t        row_bits;
+        uint32_t        R;       // slots per range (a multiple of 4)
         uint32_t        col_bits;
         uint32_t        pad_chunk;// an all-padding chunk behind the last real one
         const uint32_t* vbits;     // MODE 1 / 2: bit c = v[c] != 0 (n_cols bits)
@@ -222,10 +276,20 @@ namespace splahip {
         extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
         word* const        s_acc = reinterpret_cast<word*>(s_raw);
         constexpr unsigned NW    = TPB / kWave;
-        const uint32_t     R     = 1u << a.row_bits;
-        const uint32_t     t_end = a.span_first[blockIdx.x + 1];
-        for (uint32_t ti = a.span_first[blockIdx.x]; ti < t_end; ++ti) {// the workgroup's pieces, one after the other
-        const CobTile t = a.tiles[ti];
+        const uint32_t     R     = a.R;
+        const CobTile      t     = a.tiles[blockIdx.x];// one piece per workgroup, launched largest piece first
+#ifdef SPLAHIP_COB_TIMING
+        if (threadIdx.x == 0 && blockIdx.x < 8192) {
+            uint32_t xcc, hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            g_cob_t[0][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+            g_cob_t[4][blockIdx.x] = xcc;
+            g_cob_t[5][blockIdx.x] = hwid;
+            g_cob_t[6][blockIdx.x] = t.n_chunks;
+            g_cob_t[7][blockIdx.x] = ((unsigned long long) t.range << 32) | t.multi;
+        }
+#endif
         {
             const uint32_t id = cob_identity<T, ACC>();
             uint4*         s4 = reinterpret_cast<uint4*>(s_raw);
@@ -233,6 +297,9 @@ namespace splahip {
             for (uint32_t i = threadIdx.x; i < R * sizeof(word) / 16 + 1; i += TPB) s4[i] = z;// + the spare words the padding slots add into
         }
         __syncthreads();
+#ifdef SPLAHIP_COB_TIMING
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_cob_t[1][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
         const unsigned lane  = lane_id();
         const uint32_t cmask = (1u << a.col_bits) - 1u;
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -269,10 +336,18 @@ namespace splahip {
             G[gq][3] = from_bits<T>(B[q] + (E[q].w & cmask));// DIAGNOSTIC BUILD: no gathers
 #else
             if constexpr (MODE == 0) {
+#if defined(SPLAHIP_COB_EXP) && SPLAHIP_COB_EXP >= 16// DIAGNOSTIC BUILD: every gather folded into the first 2^EXP words of v (same lines per instruction, all cache-resident)
+                constexpr uint32_t wm = (1u << SPLAHIP_COB_EXP) - 1u;
+                G[gq][0] = v[(B[q] + (E[q].x & cmask)) & wm];
+                G[gq][1] = v[(B[q] + (E[q].y & cmask)) & wm];
+                G[gq][2] = v[(B[q] + (E[q].z & cmask)) & wm];
+                G[gq][3] = v[(B[q] + (E[q].w & cmask)) & wm];
+#else
                 G[gq][0] = v[B[q] + (E[q].x & cmask)];
                 G[gq][1] = v[B[q] + (E[q].y & cmask)];
                 G[gq][2] = v[B[q] + (E[q].z & cmask)];
                 G[gq][3] = v[B[q] + (E[q].w & cmask)];
+#endif
             } else {// the bits of this step arrived one step ago: extract them, then gather v only where a bit is set (every other lane re-reads v[base]: one line)
                 const uint32_t c0 = B[q] + (E[q].x & cmask), c1 = B[q] + (E[q].y & cmask), c2 = B[q] + (E[q].z & cmask), c3 = B[q] + (E[q].w & cmask);
                 const uint32_t m  = ((W[gq].x >> (c0 & 31)) & 1u) | (((W[gq].y >> (c1 & 31)) & 1u) << 1) | (((W[gq].z >> (c2 & 31)) & 1u) << 2) | (((W[gq].w >> (c3 & 31)) & 1u) << 3);
@@ -343,109 +418,155 @@ namespace splahip {
         reinterpret_cast<uint32_t*>(s_raw)[threadIdx.x] = to_bits(dbg);
 #endif
         __syncthreads();
-        const uint32_t row0 = t.range << a.row_bits;
-        // four consecutive slice words as fp32 / int bits (a double slice is rounded to fp32 here, once per row and tile)
-        auto slice4 = [&](uint32_t i) {
-            if constexpr (kWide) {
-                const double2 lo = *reinterpret_cast<const double2*>(s_acc + i), hi = *reinterpret_cast<const double2*>(s_acc + i + 2);
-                return make_uint4(to_bits((float) lo.x), to_bits((float) lo.y), to_bits((float) hi.x), to_bits((float) hi.y));
+#ifdef SPLAHIP_COB_TIMING
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_cob_t[2][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
+        const CobRange rg = a.ranges[t.range];
+        // slice word i as the 4-byte result word (a double slice is rounded to fp32 here, once per row and piece)
+        auto own_word = [&](uint32_t i) -> uint32_t {
+            if constexpr (kWide) return to_bits((float) s_acc[i]);
+            else
+                return s_acc[i];
+        };
+        const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_raw);// the last arriver's view: the accumulated 4-byte words
+        bool            merged  = false;
+        if (t.multi != kCobNoSlab) {
+            // add the slice into the range's shared accumulator (words still at the identity hold nothing), then take a ticket
+            uint32_t* const gacc = a.acc + (size_t) t.multi * R;
+            for (uint32_t i = threadIdx.x; i < R; i += TPB) {
+                const uint32_t w = own_word(i);
+                if (w != cob_identity<T, ACC>()) cob_merge_global<T, ACC>(gacc + i, w);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");// every adding wave: its atomics have been performed
+            __syncthreads();
+            uint32_t* const s_flag = reinterpret_cast<uint32_t*>(s_raw + (size_t) (R + 3) * sizeof(word));
+            if (threadIdx.x == 0) *s_flag = __hip_atomic_fetch_add(a.ticket + t.multi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == rg.n_pieces - 1 ? 1u : 0u;
+            __syncthreads();
+            if (*s_flag == 0) {
+#ifdef SPLAHIP_COB_TIMING
+                if (threadIdx.x == 0 && blockIdx.x < 8192) g_cob_t[3][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
+                return;
+            }
+            // the last piece of the range: every other piece's atomics were performed before its ticket add.  Read the accumulator back (agent-scope
+            // loads: past this CU's L1), re-arm it and the ticket for the next call, and finish the rows from the LDS copy
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+            uint32_t* s_w = reinterpret_cast<uint32_t*>(s_raw);
+            constexpr int KB = 8;// loads requested together (one memory round trip per batch, not per word)
+            for (uint32_t base = threadIdx.x; base < R; base += TPB * KB) {
+                uint32_t w[KB];
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    const uint32_t i = base + k * TPB;
+                    w[k]             = i < R ? __hip_atomic_load(gacc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    const uint32_t i = base + k * TPB;
+                    if (i < R) {
+                        s_w[i] = w[k];
+                        __hip_atomic_store(gacc + i, cob_identity<T, ACC>(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            if (threadIdx.x == 0) __hip_atomic_store(a.ticket + t.multi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            merged = true;
+        }
+        auto word_of = [&](uint32_t i) -> uint32_t { return merged ? s_words[i] : own_word(i); };
+        // one row's output from its slot: value and (VXM) touched flag; `has` = the row holds an entry in this copy
+        auto finish_row = [&](uint32_t row, uint32_t w, bool has, T& out, uint32_t& tch) -> bool {// returns whether r[row] is to be written
+            bool sel = true;
+            if (op_select != SPLAHIP_ALWAYS) sel = eval_sel<T>(op_select, mask[row]);
+            if constexpr (VXM) {// no init: an output exists where the index is selected and holds a product; its value is the fold itself
+                tch = sel && has;
+                out = cob_value<T, ACC>(has ? w : cob_identity<T, ACC>());
+                return true;
+            } else if (a.accumulate) {
+                if (!(sel && has)) return false;
+                out = cob_finish<T, ACC>(w, r[row], add);
+                return true;
             } else {
-                return *reinterpret_cast<const uint4*>(s_acc + i);
+                if constexpr (ACC == COB_LOR || ACC == COB_LAND) sel = sel && has;// a row without an entry keeps init itself, not its truth value
+                out = sel && has ? cob_finish<T, ACC>(w, init, add) : init;
+                return true;
             }
         };
-        if (t.slab != kCobNoSlab) {
-            uint4* out = reinterpret_cast<uint4*>(a.slabs + (size_t) t.slab * R);
-            for (uint32_t i = threadIdx.x; i < R / 4; i += TPB) out[i] = slice4(i * 4);
-        } else
-        // the piece is the whole range: finish its rows (16 bytes of r per thread)
-        for (uint32_t i = threadIdx.x * 4; i < R; i += TPB * 4) {
-            const uint32_t row = row0 + i;
-            if (row >= a.n_rows) break;
-            const uint4 acc = slice4(i);
-            const uint32_t aw[4] = {acc.x, acc.y, acc.z, acc.w};
-            T              out[4];
-            uint32_t       tch[4];
+        if (rg.hub_base != 0xFFFFFFFFu) {
+            // hub range: slot s is row hub_row[hub_base + s]; one scattered word per row (rows, then masks, requested in batches)
+            constexpr int KH = 4;
+            for (uint32_t base = threadIdx.x; base < R; base += TPB * KH) {
+                uint32_t rows[KH];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t rj  = row + j;
-                bool           sel = rj < a.n_rows;
-                if (sel && op_select != SPLAHIP_ALWAYS) sel = eval_sel<T>(op_select, mask[rj]);
-                if constexpr (VXM) {// no init: an output exists where the index is selected and holds a product; its value is the fold itself
-                    tch[j] = sel && a.Ap[rj + 1] != a.Ap[rj];
-                    out[j] = from_bits<T>(aw[j]);
-                } else if (a.accumulate) {
-                    const T prev = rj < a.n_rows ? r[rj] : init;
-                    if (sel) sel = a.Ap[rj + 1] != a.Ap[rj];
-                    out[j] = sel ? cob_finish<T, ACC>(aw[j], prev, add) : prev;
-                } else {
-                    if constexpr (ACC == COB_LOR || ACC == COB_LAND) {
-                        if (sel) sel = a.Ap[rj + 1] != a.Ap[rj];// a row without an entry keeps init itself, not its truth value
+                for (int k = 0; k < KH; ++k) {
+                    const uint32_t sidx = base + k * TPB;
+                    rows[k]             = sidx < R ? a.hub_row[rg.hub_base + sidx] : 0xFFFFFFFFu;
+                }
+                T    mk[KH];
+                T    prev[KH];
+#pragma unroll
+                for (int k = 0; k < KH; ++k) {
+                    mk[k]   = rows[k] != 0xFFFFFFFFu && op_select != SPLAHIP_ALWAYS ? mask[rows[k]] : T(0);
+                    prev[k] = rows[k] != 0xFFFFFFFFu && !VXM && a.accumulate ? r[rows[k]] : init;
+                }
+#pragma unroll
+                for (int k = 0; k < KH; ++k) {
+                    const uint32_t row = rows[k];
+                    if (row == 0xFFFFFFFFu) continue;
+                    const uint32_t w   = word_of(base + k * TPB);
+                    const bool     sel = op_select == SPLAHIP_ALWAYS || eval_sel<T>(op_select, mk[k]);
+                    if constexpr (VXM) {
+                        r[row]         = cob_value<T, ACC>(w);
+                        a.touched[row] = sel ? 1u : 0u;
+                    } else if (a.accumulate) {
+                        if (sel) r[row] = cob_finish<T, ACC>(w, prev[k], add);
+                    } else
+                        r[row] = sel ? cob_finish<T, ACC>(w, init, add) : init;
+                }
+            }
+        } else {
+            // natural range: its rows in order, 8 per thread and step (one 16-byte load of their slots); 16-byte stores where all 4 rows are written
+            uint32_t row = rg.row0 + threadIdx.x * 8;
+            uint4    nx  = row < rg.row1 ? *reinterpret_cast<const uint4*>(a.slot16 + row) : make_uint4(0, 0, 0, 0);
+            for (; row < rg.row1; row += TPB * 8) {
+                const uint4 sl = nx;// the next step's slots are requested before this step's rows are finished
+                if (row + TPB * 8 < rg.row1) nx = *reinterpret_cast<const uint4*>(a.slot16 + row + TPB * 8);
+                const uint32_t sw[4] = {sl.x, sl.y, sl.z, sl.w};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t rb = row + 4 * h;
+                    if (rb >= a.n_rows) break;
+                    T        out[4];
+                    uint32_t tch[4] = {0, 0, 0, 0};
+                    bool     wr[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t rj = rb + j;
+                        const uint32_t sj = (sw[2 * h + (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
+                        wr[j]             = false;
+                        if (rj < a.n_rows && sj != kCobSlotHub) {
+                            const bool has = sj != kCobSlotEmpty;
+                            wr[j]          = finish_row(rj, has ? word_of(sj) : cob_identity<T, ACC>(), has, out[j], tch[j]);
+                        }
                     }
-                    out[j] = sel ? cob_finish<T, ACC>(aw[j], init, add) : init;
-                }
-            }
-            if (row + 3 < a.n_rows) {
-                *reinterpret_cast<uint4*>(r + row) = make_uint4(to_bits(out[0]), to_bits(out[1]), to_bits(out[2]), to_bits(out[3]));
-                if constexpr (VXM) *reinterpret_cast<uint4*>(a.touched + row) = make_uint4(tch[0], tch[1], tch[2], tch[3]);
-            } else
-                for (int j = 0; j < 4 && row + j < a.n_rows; ++j) {
-                    r[row + j] = out[j];
-                    if constexpr (VXM) a.touched[row + j] = tch[j];
-                }
-        }
-        __syncthreads();// the slice is re-initialised for the next piece
-        }
-    }
-
-    // rows of the ranges that were cut into several tiles: merge the range's slabs in tile order, then finish like the main kernel.
-    // grid: (R / (TPB * 4) blocks per range) x n_multi
-    template<typename T, class Add, int ACC, bool VXM, unsigned TPB>
-    __global__ __launch_bounds__(TPB) void cob_combine_kernel(const CobMulti* __restrict__ multi, const uint32_t* __restrict__ slabs, const uint32_t* __restrict__ Ap,
-                                                              const T* __restrict__ mask, T* __restrict__ r, uint32_t* __restrict__ touched, uint32_t n_rows,
-                                                              uint32_t row_bits, Add add, int op_select, T init, uint32_t accumulate) {
-        const uint32_t R   = 1u << row_bits;
-        const CobMulti m   = multi[blockIdx.y];
-        const uint32_t i   = (blockIdx.x * TPB + threadIdx.x) * 4;
-        const uint32_t row = (m.range << row_bits) + i;
-        if (i >= R || row >= n_rows) return;
-        uint4 acc = *reinterpret_cast<const uint4*>(slabs + (size_t) m.first_slab * R + i);
-        for (uint32_t s = 1; s < m.n_slabs; ++s) {
-            const uint4 b = *reinterpret_cast<const uint4*>(slabs + (size_t) (m.first_slab + s) * R + i);
-            acc.x         = cob_merge<T, ACC>(acc.x, b.x);
-            acc.y         = cob_merge<T, ACC>(acc.y, b.y);
-            acc.z         = cob_merge<T, ACC>(acc.z, b.z);
-            acc.w         = cob_merge<T, ACC>(acc.w, b.w);
-        }
-        const uint32_t aw[4] = {acc.x, acc.y, acc.z, acc.w};
-        T              out[4];
-        uint32_t       tch[4];
+                    if (wr[0] && wr[1] && wr[2] && wr[3]) {
+                        *reinterpret_cast<uint4*>(r + rb) = make_uint4(to_bits(out[0]), to_bits(out[1]), to_bits(out[2]), to_bits(out[3]));
+                        if constexpr (VXM) *reinterpret_cast<uint4*>(a.touched + rb) = make_uint4(tch[0], tch[1], tch[2], tch[3]);
+                    } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t rj  = row + j;
-            bool           sel = rj < n_rows;
-            if (sel && op_select != SPLAHIP_ALWAYS) sel = eval_sel<T>(op_select, mask[rj]);
-            if constexpr (VXM) {
-                tch[j] = sel && Ap[rj + 1] != Ap[rj];
-                out[j] = from_bits<T>(aw[j]);
-            } else if (accumulate) {
-                const T prev = rj < n_rows ? r[rj] : init;
-                if (sel) sel = Ap[rj + 1] != Ap[rj];
-                out[j] = sel ? cob_finish<T, ACC>(aw[j], prev, add) : prev;
-            } else {
-                if constexpr (ACC == COB_LOR || ACC == COB_LAND) {
-                    if (sel) sel = Ap[rj + 1] != Ap[rj];
+                        for (int j = 0; j < 4; ++j)
+                            if (wr[j]) {
+                                r[rb + j] = out[j];
+                                if constexpr (VXM) a.touched[rb + j] = tch[j];
+                            }
+                    }
                 }
-                out[j] = sel ? cob_finish<T, ACC>(aw[j], init, add) : init;
             }
         }
-        if (row + 3 < n_rows) {
-            *reinterpret_cast<uint4*>(r + row) = make_uint4(to_bits(out[0]), to_bits(out[1]), to_bits(out[2]), to_bits(out[3]));
-            if constexpr (VXM) *reinterpret_cast<uint4*>(touched + row) = make_uint4(tch[0], tch[1], tch[2], tch[3]);
-        } else
-            for (int j = 0; j < 4 && row + j < n_rows; ++j) {
-                r[row + j] = out[j];
-                if constexpr (VXM) touched[row + j] = tch[j];
-            }
+#ifdef SPLAHIP_COB_TIMING
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_cob_t[3][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
 
 }// namespace splahip

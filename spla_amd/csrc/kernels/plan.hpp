@@ -51,37 +51,41 @@ struct splahip_sell_s {
 };
 
 // column-ordered blocks copy of the matrix (cob.hip / mxv_cob.hpp); owned by the plan
-struct splahip_cob_sched_s {// one work schedule: which workgroup walks which pieces (a piece = consecutive chunks of one range)
-    uint32_t  n_spans   = 0;// workgroups of the main kernel
-    uint32_t  n_tiles   = 0;// pieces
-    uint32_t  n_slabs   = 0;// partial result slices (pieces of ranges that are cut into several pieces)
-    uint32_t  n_multi   = 0;// such ranges
-    uint32_t* d_span_first = nullptr;// n_spans + 1: first piece of every workgroup
+struct splahip_cob_sched_s {// one work schedule: the pieces (consecutive chunks of one range), one workgroup each, largest first
+    uint32_t  n_tiles   = 0;// pieces = workgroups of the kernel
+    uint32_t  n_multi   = 0;// ranges cut into several pieces (each has a shared accumulator + a ticket)
     uint32_t* d_tiles   = nullptr;// n_tiles x CobTile
-    uint32_t* d_multi   = nullptr;// n_multi x CobMulti
+    uint32_t* d_ranges  = nullptr;// n_ranges x CobRange (n_pieces differs between the schedules)
 };
 struct splahip_cob_s {
     uint32_t  n_rows   = 0;
     uint32_t  n_cols   = 0;
-    uint32_t  row_bits = 0;// a range = 2^row_bits consecutive rows (its result slice lives in LDS)
-    uint32_t  col_bits = 0;// 31 - row_bits: a chunk's columns are stored relative to its 2^col_bits-column window
+    uint32_t  R        = 0;// slots per range (the range's result slice lives in LDS)
+    uint32_t  col_bits = 0;// a chunk's columns are stored relative to its 2^col_bits-column window
     uint32_t  n_chunks = 0;// 256-slot chunks
-    uint32_t  n_empty  = 0;// ranges without an entry
-    // [0]: 4-byte slice words (int / uint, LOR / LAND), [1]: 8-byte slice words (fp32 PLUS); they differ in the workgroups a CU can hold.
-    // n_spans == 0: this slice width does not fit the LDS at this row_bits
+    uint32_t  n_ranges = 0;// hub ranges first, then the natural ranges in row order
+    uint32_t  n_hub_ranges = 0;
+    uint32_t  n_hub_rows   = 0;
+    size_t    bytes    = 0;// device memory the copy holds
+    // [0]: 4-byte slice words (int / uint, LOR / LAND, fp32 MIN / MAX keys), [1]: 8-byte slice words (fp32 PLUS); they differ in the workgroups a CU
+    // can hold.  n_tiles == 0: this slice width does not fit the LDS at this R
     splahip_cob_sched_s sched[2];
     uint32_t* d_hdr    = nullptr;// n_chunks: first column of the chunk's window
-    uint32_t* d_cr     = nullptr;// n_chunks x 256: row in range << col_bits | column - window base
+    uint32_t* d_cr     = nullptr;// n_chunks x 256: slot in range << col_bits | column - window base
     uint32_t* d_ax     = nullptr;// n_chunks x 256 value words
-    uint32_t* d_slabs  = nullptr;// max(sched[].n_slabs) << row_bits words, per call
-    uint32_t* d_empty  = nullptr;// n_empty range ids
+    uint16_t* d_slot16 = nullptr;// n_rows (padded to 8): slot of the row in its natural range, 0xFFFF no entry, 0xFFFE hub row
+    uint32_t* d_hub_row = nullptr;// n_hub_ranges x R: row of a hub slot, 0xFFFFFFFF padding
+    uint32_t* d_acc    = nullptr;// max(sched[].n_multi) x R words: shared accumulators, at the identity of `acc_identity` between calls
+    uint32_t* d_ticket = nullptr;// max(sched[].n_multi) arrival counters, 0 between calls
+    mutable uint32_t acc_identity = 0;
+    mutable bool     acc_armed    = false;
     uint32_t* d_vbits  = nullptr;// per call: bit c = v[c] != 0 (sparse-input-vector form, mxv_cob.hpp MODE 1 / 2)
     bool      x_uniform = false; // every stored value of the matrix is the same word (found at attach time) ...
     uint32_t  x_bits    = 0;     // ... this one: the sparse-vector form then does not read the value stream
-    // min-plus family of the sparse-vector form: any negative / NaN value and the largest value of the copy's value words, per type (like
-    // splahip_sell_s: found by the first min-plus call of a type)
+    // value statistics of the copy's value words, per type (found by the first call of a type that needs them): any negative / NaN value,
+    // the largest value (int / uint), any -0.0f (float)
     mutable int      ax_type = -1;
-    mutable uint32_t ax_bad = 1, ax_max = 0;
+    mutable uint32_t ax_bad = 1, ax_max = 0, ax_negzero = 1;
 };
 
 struct splahip_plan_s {
@@ -105,6 +109,8 @@ namespace splahip {
     void cob_release(splahip_cob_s* cob);
     // does the plan hold a column-ordered-blocks copy that can serve this op_add on this type (an LDS atomic exists, SPLAHIP_COB != 0)
     bool cob_serves(const splahip_plan_s* plan, int type, int op_add, uint32_t n_cols);
+    // the masked SpMV's question: the above, plus fp32 MIN / MAX over op_mult = PLUS when the matrix holds no -0.0f (first asked: one value pass on `stream`)
+    bool cob_serves_mxv(const splahip_plan_s* plan, int type, int op_mult, int op_add, uint32_t n_cols, void* stream);
     // masked SpMV over the column-ordered-blocks copy (associative + commutative op_add with an LDS atomic, no early exit); SPLAHIP status
     int cob_mxv(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
                 uint32_t init_bits, void* stream);

@@ -35,10 +35,12 @@ def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, 
         # cob-small also forces cob's sparse-input-vector form of min-plus, which the library only picks for >= 2^23 columns
         os.environ["SPLAHIP_COB_BITS"] = "2" if form == "cob-small" else "1"
         plan = kernels.CsrPlan(n_rows, len(Aj), dAp, n_cols, dAj, dAx) if form.startswith("sell") else kernels.CsrPlan(n_rows, len(Aj), dAp)
-        if form == "cob":        # column-ordered blocks, default geometry (ranges of 16 Ki rows)
+        if form == "cob":        # column-ordered blocks, default geometry (ranges of 20224 slots)
             plan.attach_cob(n_cols, dAp, dAj, dAx)
-        elif form == "cob-small":  # ranges of 256 rows, tiles of 2 chunks: many ranges, column windows, multi-tile ranges and slabs even on small inputs
+        elif form == "cob-small":  # ranges of 256 slots, pieces of 2 chunks, every row of degree >= 3 a hub candidate: hub and natural ranges, column
+            os.environ["SPLAHIP_COB_HUB_MIN_DEGREE"] = "3"  # windows, ranges in several pieces (shared accumulators, tickets) even on small inputs
             plan.attach_cob(n_cols, dAp, dAj, dAx, row_bits=8, tile_chunks=2)
+            os.environ.pop("SPLAHIP_COB_HUB_MIN_DEGREE")
         r = torch.empty(n_rows, dtype=kernels.torch_dtype(t), device="cuda")
         if junk is not None:
             r.fill_(junk)
@@ -57,7 +59,9 @@ def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, 
     else:
         assert np.array_equal(outs["sell"], outs["csr"]), "sliced-ELL kernel differs from the CSR kernels"
     for form in ("cob", "cob-small"):
-        if t == "FLOAT":
+        if t == "FLOAT" and op_add in ("MIN", "MAX") and op_mult == "PLUS":  # the keyed fp32 MIN / MAX form is the reference's fold bit for bit
+            assert np.array_equal(outs[form].view(np.uint32), outs["csr"].view(np.uint32)), f"{form} fp32 {op_add} differs from the CSR kernels"
+        elif t == "FLOAT":
             a, b = outs[form].astype(np.float64), outs["csr"].astype(np.float64)
             assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isinf(a), np.isinf(b)), f"{form} kernel differs from the CSR kernels"
             fin = np.isfinite(a) & np.isfinite(b)

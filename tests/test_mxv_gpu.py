@@ -442,3 +442,92 @@ def test_frontier_form_counts_hits(oracle, t):
                         want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
                         got = hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init, junk=9)
                         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (t, n_cols, xval, cval, mul, add, init, frac, sel)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("add", ["MIN", "MAX"])
+def test_fp32_min_max_keyed_form(oracle, add):
+    """fp32 MIN / MAX over op_mult = PLUS on the column-ordered blocks (the reference's own SSSP semiring, src/algorithm.cpp:208-213): the LDS
+    slice holds order-preserving integer keys.  Infinities of both signs, NaN in v (a NaN product is never picked by std::min / std::max as
+    the second argument), negative weights, a NaN / infinite init, and a matrix holding -0.0f (the form must decline) — all bit for bit."""
+    import os
+    import torch
+    from gpu_utils import dev, hip_mxv, host
+    from spla_amd import kernels
+    rng = np.random.default_rng(808 + (add == "MAX"))
+    n_rows, n_cols = 3500, 4000
+    Ap, Aj, _ = random_csr(rng, n_rows, n_cols, 11, "FLOAT", skew=True, long_rows=2, long_len=1500)
+    nnz = len(Aj)
+    w = (rng.integers(-40, 400, nnz) / 8.0).astype(np.float32)
+    v = (rng.integers(-500, 5000, n_cols) / 4.0).astype(np.float32)
+    v[rng.random(n_cols) < 0.3] = np.inf
+    v[rng.random(n_cols) < 0.02] = -np.inf
+    v[rng.random(n_cols) < 0.02] = -0.0
+    v_nan = v.copy()
+    v_nan[rng.random(n_cols) < 0.03] = np.nan
+    dAp, dAj, dw = dev(Ap), dev(Aj), dev(w)
+    plans = []
+    for small in (False, True):
+        if small:
+            os.environ["SPLAHIP_COB_HUB_MIN_DEGREE"] = "3"
+        p = kernels.CsrPlan(n_rows, nnz, dAp)
+        assert p.attach_cob(n_cols, dAp, dAj, dw, row_bits=8 if small else 0, tile_chunks=2 if small else 0)
+        os.environ.pop("SPLAHIP_COB_HUB_MIN_DEGREE", None)
+        assert "integer keys" in kernels.mxv_variant("FLOAT", "PLUS", add, False, p)
+        plans.append(p)
+    for init in (np.float32(np.inf), np.float32(-np.inf), np.float32(12.5), np.float32(np.nan), np.float32(-0.0)):
+        for sel in ("ALWAYS", "NQZERO"):
+            mask = random_mask(rng, n_rows, "FLOAT")
+            want = oracle.mxv_masked("FLOAT", n_rows, n_cols, Ap, Aj, w, mask, v, "PLUS", add, sel, init)
+            got = hip_mxv("FLOAT", n_rows, n_cols, Ap, Aj, w, mask, v, "PLUS", add, sel, init, junk=3.0)  # every layout, cross-checked
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (add, init, sel)
+            # NaN among the products: the keyed form drops them as the reference's sequential fold does (the CSR tree and the sliced-ELL lanes
+            # reorder the fold, which a NaN does not survive — so these inputs go through the column-ordered blocks only)
+            want = oracle.mxv_masked("FLOAT", n_rows, n_cols, Ap, Aj, w, mask, v_nan, "PLUS", add, sel, init)
+            for p in plans:
+                r = torch.full((n_rows,), 3.0, dtype=torch.float32, device="cuda")
+                kernels.mxv_masked(p, "FLOAT", n_cols, dAp, dAj, dw, dev(mask), dev(v_nan), r, "PLUS", add, sel, init)
+                torch.cuda.synchronize()
+                assert np.array_equal(host(r, np.float32).view(np.uint32), want.view(np.uint32)), (add, init, sel, "NaN products")
+    for p in plans:
+        p.close()
+    # a -0.0f among the matrix values: key order would put -0 below +0 where the reference keeps the first zero — the form declines
+    w2 = w.copy()
+    w2[::53] = -0.0
+    v2 = np.where(rng.random(n_cols) < 0.5, np.float32(-0.0), np.float32(0.0)).astype(np.float32)
+    want = oracle.mxv_masked("FLOAT", n_rows, n_cols, Ap, Aj, w2, np.zeros(n_rows, np.float32), v2, "PLUS", add, "ALWAYS", np.float32(5.0))
+    got = hip_mxv("FLOAT", n_rows, n_cols, Ap, Aj, w2, np.zeros(n_rows, np.float32), v2, "PLUS", add, "ALWAYS", np.float32(5.0))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_cob_plan_reused_across_semirings(oracle):
+    """One plan, many calls: the shared accumulators of the ranges cut into several pieces rest at the identity of the op_add that used them
+    last and the tickets at zero — alternate semirings (and repeat each) on the same plan and compare every result with the oracle."""
+    import torch
+    from gpu_utils import dev, host
+    from spla_amd import kernels
+    rng = np.random.default_rng(4711)
+    n_rows, n_cols = 6000, 5000
+    Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 14, "INT", skew=True, long_rows=3, long_len=3000)
+    dAp, dAj, dAx = dev(Ap), dev(Aj), dev(Ax)
+    import os
+    os.environ["SPLAHIP_COB_HUB_MIN_DEGREE"] = "4"
+    plan = kernels.CsrPlan(n_rows, len(Aj), dAp)
+    info = plan.attach_cob(n_cols, dAp, dAj, dAx, row_bits=8, tile_chunks=3)
+    os.environ.pop("SPLAHIP_COB_HUB_MIN_DEGREE")
+    assert info and info["ranges_in_pieces"] > 0 and info["hub_rows"] > 0, info
+    r = torch.empty(n_rows, dtype=torch.int32, device="cuda")
+    calls = [("MULT", "PLUS", 0), ("PLUS", "MIN", 1 << 20), ("PLUS", "MIN", 1 << 20), ("BAND", "BOR", 0), ("MULT", "PLUS", 7), ("MULT", "MAX", -5),
+             ("BOR", "BAND", -1), ("MULT", "BXOR", 0), ("LAND", "LOR", 0), ("LOR", "LAND", 1), ("MULT", "PLUS", 0)]
+    for it, (mul, add, init) in enumerate(calls * 2):
+        mask = random_mask(rng, n_rows, "INT")
+        v = random_values(rng, n_cols, "INT", zeros=0.2)
+        sel = SELECTS[it % len(SELECTS)]
+        assert "mxv_cob" in kernels.mxv_variant("INT", mul, add, False, plan)
+        r.fill_(-77)
+        kernels.mxv_masked(plan, "INT", n_cols, dAp, dAj, dAx, dev(mask), dev(v), r, mul, add, sel, init)
+        torch.cuda.synchronize()
+        want = oracle.mxv_masked("INT", n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
+        assert np.array_equal(host(r, np.int32), want), (it, mul, add, sel)
+    plan.close()

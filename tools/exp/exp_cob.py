@@ -56,7 +56,13 @@ def main():
         print(f"sliced-ELL             : {us:8.1f} us  {alg / us / 1e6:6.2f} TB/s  frac {alg / us / 1e6 / 8:.3f}   (attach {1e3 * (t1 - t0):.0f} ms)", flush=True)
         ps.close()
     for cfg in configs:
-        rb, tc = (int(x) for x in cfg.split(":"))
+        parts = [int(x) for x in cfg.split(":")]
+        rb, tc = parts[0], parts[1]
+        if len(parts) > 2:  # rb:tc:share_pct:line_pct[:hub_ranges] — the schedule knobs of the column-ordered blocks (read at attach time)
+            os.environ["SPLAHIP_COB_SHARE_PCT"] = str(parts[2])
+            os.environ["SPLAHIP_COB_LINE_PCT"] = str(parts[3])
+        if len(parts) > 4:
+            os.environ["SPLAHIP_COB_HUB_RANGES"] = str(parts[4])
         p = kernels.CsrPlan(n, nnz, Ap)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -67,7 +73,7 @@ def main():
         us = timeit(lambda: kernels.mxv_masked(p, "FLOAT", n, Ap, Aj, Ax, mask, v, r, "MULT", "PLUS", "ALWAYS", 0.0))
         rel = ((r.to(torch.float64) - exact).abs() / exact.abs().clamp_min(1e-30)).max().item()
         relc = ((ref.to(torch.float64) - exact).abs() / exact.abs().clamp_min(1e-30)).max().item()
-        print(f"cob row_bits {rb} tile {tc:4d}: {us:8.1f} us  {alg / us / 1e6:6.2f} TB/s  frac {alg / us / 1e6 / 8:.3f}   attach {1e3 * (t1 - t0):.0f} ms  {info}  "
+        print(f"cob {cfg}: {us:8.1f} us  {alg / us / 1e6:6.2f} TB/s  frac {alg / us / 1e6 / 8:.3f}   attach {1e3 * (t1 - t0):.0f} ms  {info}  "
               f"max rel vs fp64 {rel:.2e} (csr kernel {relc:.2e})", flush=True)
         if os.environ.get("EXP_INT", "0") == "1":
             w_i = torch.randint(1, 256, (nnz,), generator=gen, device="cuda", dtype=torch.int32)
