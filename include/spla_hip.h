@@ -127,6 +127,20 @@ int splahip_jit_available(void);
 int splahip_mxv_masked_jit(int type, uint32_t n_rows, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, const void* d_mask, const void* d_v, void* d_r,
                            int op_mult, const char* mult_src, int op_add, const char* add_src, int op_select, const char* select_src, uint32_t init_bits,
                            int early_exit, void* stream);
+/* the other three operators with user-defined ops: each the reference's own fold order, one run-time-compiled kernel inside the operator's usual driver
+ * (spla_amd/csrc/kernels/jit.hip, jit_hooks.hpp).  *_src as above.  vxm: plan_T / d_T* = the plan and CSR of the TRANSPOSED matrix, n_in = rows of M (length of
+ * v), n_out = columns of M; sorted = the indices of v ascend (splahip_vxm_probe); output as splahip_vxm_pull.  mxmT / mxm: arguments and hand-off of the
+ * result arrays as splahip_mxmT_masked / splahip_mxm.  Blocking.                                                                                           */
+int splahip_vxm_masked_jit(splahip_plan plan_T, int type, uint32_t n_in, uint32_t n_out, const uint32_t* d_Tp, const uint32_t* d_Tj, const void* d_Tx, const void* d_mask,
+                           uint32_t nvals, const uint32_t* d_vi, const void* d_vx, int sorted, uint32_t* d_ri, void* d_rx, uint32_t* h_count, int op_mult, const char* mult_src,
+                           int op_add, const char* add_src, int op_select, const char* select_src, void* stream);
+int splahip_mxmT_masked_jit(int type, uint32_t n_rows, uint32_t mask_nnz, const uint32_t* d_Mp, const uint32_t* d_Mj, const void* d_Mx, const uint32_t* d_Ap,
+                            const uint32_t* d_Aj, const void* d_Ax, const uint32_t* d_Bp, const uint32_t* d_Bj, const void* d_Bx, uint32_t* d_Rp, uint32_t** d_Rj, void** d_Rx,
+                            uint32_t* h_nnz, int op_mult, const char* mult_src, int op_add, const char* add_src, int op_select, const char* select_src, uint32_t init_bits,
+                            void* stream);
+int splahip_mxm_jit(int type, uint32_t a_rows, uint32_t b_cols, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, const uint32_t* d_Bp, const uint32_t* d_Bj,
+                    const void* d_Bx, uint32_t* d_Rp, uint32_t** d_Rj, void** d_Rx, uint32_t* h_nnz, int op_mult, const char* mult_src, int op_add, const char* add_src,
+                    uint32_t init_bits, void* stream);
 
 /* ---- 1-D row-block decomposition across the GPUs of one node (spla_amd/csrc/kernels/dist.hip) -------------------------------
  * One process per GPU.  Rank p owns a contiguous block of rows (its CSR slice with the column ids remapped to the PADDED layout

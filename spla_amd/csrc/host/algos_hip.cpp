@@ -58,6 +58,28 @@ namespace spla {
             }
         }
 
+        // a user-defined op (OpBinary::make_* / OpSelect::make_*) carries its body as text (reference src/op.cpp:294-317): text for the run-time compiler, or
+        // null for a built-in op
+        struct UserSrc {
+            std::string mult, add, sel;
+            const char *pm = nullptr, *pa = nullptr, *ps = nullptr;
+            template<class Mul, class Add, class Sel>
+            UserSrc(int op_mult, const Mul& m, int op_add, const Add& a, int op_sel, const Sel* sl) {
+                if (op_mult < 0) mult = m->get_source_cl(), pm = mult.c_str();
+                if (op_add < 0) add = a->get_source_cl(), pa = add.c_str();
+                if (sl && op_sel < 0) sel = (*sl)->get_source_cl(), ps = sel.c_str();
+            }
+        };
+        inline Status jit_status(int st, const char* what) {
+            if (st == 8) {
+                SPLA_LOG(Status::CompilationError, splahip_last_error());
+                return Status::CompilationError;
+            }
+            if (st == SPLAHIP_NOT_IMPLEMENTED) return Status::NotImplemented;
+            hip_check(st, what);
+            return Status::Ok;
+        }
+
         template<typename T>
         class Algo_mxv_masked_hip final : public RegistryAlgo {
         public:
@@ -173,12 +195,35 @@ namespace spla {
                 const int op_mult = device_binop<T>(t->op_multiply);
                 const int op_add  = device_binop<T>(t->op_add);
                 const int op_sel  = device_selop<T>(t->op_select);
-                if (op_mult < 0 || op_add < 0 || op_sel < 0) {
-                    SPLA_LOG(Status::NotImplemented, "user-defined ops have no device code in this build");
-                    return Status::NotImplemented;
-                }
                 if (v->get_n_rows() != M->get_n_rows() || mask->get_n_rows() != M->get_n_cols() || r->get_n_rows() != M->get_n_cols())
                     return Status::InvalidArgument;
+                if (op_mult < 0 || op_add < 0 || op_sel < 0) {
+                    // user-defined ops: the pull form over the transposed matrix with the per-column fold compiled at run time (jit.hip), products in the
+                    // stored order of v like the reference's loop (cpu_vxm.hpp:92-125)
+                    r->validate_wd(FormatVector::AccCoo);
+                    mask->validate_rw(FormatVector::AccDense);
+                    v->validate_rw(FormatVector::AccCoo);
+                    M->validate_rw(FormatMatrix::AccCsr);
+                    auto* vin = v->acc_coo();
+                    auto* out = r->acc_coo();
+                    out->Ai.reserve(M->get_n_cols());
+                    out->Ax.reserve(M->get_n_cols());
+                    out->values = 0;
+                    if (vin->values == 0 || M->acc_csr()->values == 0) return Status::Ok;
+                    uint64_t products = 0;
+                    int      sorted   = 1;
+                    hip_check(splahip_vxm_probe(vin->values, vin->Ai.template as<uint32_t>(), M->acc_csr()->Ap.template as<uint32_t>(), &products, &sorted, nullptr), "splahip_vxm_probe");
+                    auto*         tr = ensure_transpose<T>(M.get());
+                    const UserSrc src(op_mult, t->op_multiply, op_add, t->op_add, op_sel, &t->op_select);
+                    uint32_t      count = 0;
+                    const Status  js    = jit_status(splahip_vxm_masked_jit(tr->plan, TypeTraits<T>::id, M->get_n_rows(), M->get_n_cols(), tr->Ap.template as<uint32_t>(),
+                                                                            tr->Aj.template as<uint32_t>(), tr->Ax.ptr(), mask->acc_dense()->Ax.ptr(), vin->values,
+                                                                            vin->Ai.template as<uint32_t>(), vin->Ax.ptr(), sorted, out->Ai.template as<uint32_t>(), out->Ax.ptr(),
+                                                                            &count, op_mult, src.pm, op_add, src.pa, op_sel, src.ps, nullptr),
+                                                     "splahip_vxm_masked_jit");
+                    if (js == Status::Ok) out->values = count;
+                    return js;
+                }
 
                 // sparse in / sparse out, dense mask (reference cpu_vxm.hpp:74-77, cl_vxm.hpp:85-88)
                 r->validate_wd(FormatVector::AccCoo);
@@ -265,13 +310,10 @@ namespace spla {
                 const int op_mult = device_binop<T>(t->op_multiply);
                 const int op_add  = device_binop<T>(t->op_add);
                 const int op_sel  = device_selop<T>(t->op_select);
-                if (op_mult < 0 || op_add < 0 || op_sel < 0) {
-                    SPLA_LOG(Status::NotImplemented, "user-defined ops have no device code in this build");
-                    return Status::NotImplemented;
-                }
                 if (R->get_n_rows() != A->get_n_rows() || R->get_n_cols() != B->get_n_rows() || A->get_n_cols() != B->get_n_cols() ||
                     mask->get_n_rows() != R->get_n_rows() || mask->get_n_cols() != R->get_n_cols())
                     return Status::InvalidArgument;
+                const bool user_ops = op_mult < 0 || op_add < 0 || op_sel < 0;// compiled at run time (jit.hip): a lane per mask entry, the reference's merge order
 
                 R->validate_wd(FormatMatrix::AccCsr);
                 mask->validate_rw(FormatMatrix::AccCsr);
@@ -283,11 +325,20 @@ namespace spla {
                 void*     Rx  = nullptr;
                 uint32_t  nnz = 0;
                 r->Ap.reserve(R->get_n_rows() + 1);
-                hip_check(splahip_mxmT_masked(TypeTraits<T>::id, R->get_n_rows(), m->values, m->Ap.template as<uint32_t>(), m->Aj.template as<uint32_t>(),
-                                              m->Ax.ptr(), a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(),
-                                              b->Ap.template as<uint32_t>(), b->Aj.template as<uint32_t>(), b->Ax.ptr(), r->Ap.template as<uint32_t>(),
-                                              &Rj, &Rx, &nnz, op_mult, op_add, op_sel, word_of(init->get_value()), nullptr),
-                          "splahip_mxmT_masked");
+                if (user_ops) {
+                    const UserSrc src(op_mult, t->op_multiply, op_add, t->op_add, op_sel, &t->op_select);
+                    const Status  js = jit_status(splahip_mxmT_masked_jit(TypeTraits<T>::id, R->get_n_rows(), m->values, m->Ap.template as<uint32_t>(), m->Aj.template as<uint32_t>(),
+                                                                          m->Ax.ptr(), a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(),
+                                                                          b->Ap.template as<uint32_t>(), b->Aj.template as<uint32_t>(), b->Ax.ptr(), r->Ap.template as<uint32_t>(),
+                                                                          &Rj, &Rx, &nnz, op_mult, src.pm, op_add, src.pa, op_sel, src.ps, word_of(init->get_value()), nullptr),
+                                                  "splahip_mxmT_masked_jit");
+                    if (js != Status::Ok) return js;
+                } else
+                    hip_check(splahip_mxmT_masked(TypeTraits<T>::id, R->get_n_rows(), m->values, m->Ap.template as<uint32_t>(), m->Aj.template as<uint32_t>(),
+                                                  m->Ax.ptr(), a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(),
+                                                  b->Ap.template as<uint32_t>(), b->Aj.template as<uint32_t>(), b->Ax.ptr(), r->Ap.template as<uint32_t>(),
+                                                  &Rj, &Rx, &nnz, op_mult, op_add, op_sel, word_of(init->get_value()), nullptr),
+                              "splahip_mxmT_masked");
                 r->drop_plan();
                 r->Aj.adopt(Rj, nnz);
                 r->Ax.adopt(Rx, nnz);
@@ -311,12 +362,9 @@ namespace spla {
 
                 const int op_mult = device_binop<T>(t->op_multiply);
                 const int op_add  = device_binop<T>(t->op_add);
-                if (op_mult < 0 || op_add < 0) {
-                    SPLA_LOG(Status::NotImplemented, "user-defined ops have no device code in this build");
-                    return Status::NotImplemented;
-                }
                 if (R->get_n_rows() != A->get_n_rows() || R->get_n_cols() != B->get_n_cols() || A->get_n_cols() != B->get_n_rows())
                     return Status::InvalidArgument;
+                const bool user_ops = op_mult < 0 || op_add < 0;// compiled at run time (jit.hip): expand / stable sort / in-order compress, the reference's fold order
 
                 R->validate_wd(FormatMatrix::AccCsr);
                 A->validate_rw(FormatMatrix::AccCsr);
@@ -327,10 +375,18 @@ namespace spla {
                 void*     Rx  = nullptr;
                 uint32_t  nnz = 0;
                 r->Ap.reserve(R->get_n_rows() + 1);
-                hip_check(splahip_mxm(TypeTraits<T>::id, A->get_n_rows(), B->get_n_cols(), a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(),
-                                      a->Ax.ptr(), b->Ap.template as<uint32_t>(), b->Aj.template as<uint32_t>(), b->Ax.ptr(),
-                                      r->Ap.template as<uint32_t>(), &Rj, &Rx, &nnz, nullptr, op_mult, op_add, word_of(init->get_value()), 0, nullptr),
-                          "splahip_mxm");
+                if (user_ops) {
+                    const UserSrc src(op_mult, t->op_multiply, op_add, t->op_add, 0, static_cast<const ref_ptr<OpSelect>*>(nullptr));
+                    const Status  js = jit_status(splahip_mxm_jit(TypeTraits<T>::id, A->get_n_rows(), B->get_n_cols(), a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(),
+                                                                  a->Ax.ptr(), b->Ap.template as<uint32_t>(), b->Aj.template as<uint32_t>(), b->Ax.ptr(),
+                                                                  r->Ap.template as<uint32_t>(), &Rj, &Rx, &nnz, op_mult, src.pm, op_add, src.pa, word_of(init->get_value()), nullptr),
+                                                  "splahip_mxm_jit");
+                    if (js != Status::Ok) return js;
+                } else
+                    hip_check(splahip_mxm(TypeTraits<T>::id, A->get_n_rows(), B->get_n_cols(), a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(),
+                                          a->Ax.ptr(), b->Ap.template as<uint32_t>(), b->Aj.template as<uint32_t>(), b->Ax.ptr(),
+                                          r->Ap.template as<uint32_t>(), &Rj, &Rx, &nnz, nullptr, op_mult, op_add, word_of(init->get_value()), 0, nullptr),
+                              "splahip_mxm");
                 r->drop_plan();
                 r->Aj.adopt(Rj, nnz);
                 r->Ax.adopt(Rx, nnz);

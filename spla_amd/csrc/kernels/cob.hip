@@ -26,6 +26,8 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <functional>
+#include <queue>
 #include <vector>
 
 using namespace splahip;
@@ -703,9 +705,9 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     if (e != hipSuccess) return bail("schedule");
     std::vector<uint32_t> range_chunk((size_t) n_ranges + 1);
     for (uint32_t q = 0; q <= n_ranges; ++q) range_chunk[q] = h_first[(size_t) q << win_bits];
-    // cost of a chunk in units of one stream line's stay in the miss queue: 16 stream lines + its gather lines weighted SPLAHIP_COB_LINE_PCT % (default 60:
+    // cost of a chunk in units of one stream line's stay in the miss queue: 16 stream lines + its gather lines weighted SPLAHIP_COB_LINE_PCT % (default 25: measured, a cold chunk of ~230 lines walks in ~340 ns, a hub chunk in ~95;
     // part of them hit the L2); cost_pre[c] = cost of the chunks before c
-    const uint32_t        line_pct = env_u32("SPLAHIP_COB_LINE_PCT", 60);
+    const uint32_t        line_pct = env_u32("SPLAHIP_COB_LINE_PCT", 25);
     std::vector<uint64_t> cost_pre((size_t) n_chunks + 1, 0);
     for (uint32_t c = 0; c < n_chunks; ++c) cost_pre[c + 1] = cost_pre[c] + 1600 + (uint64_t) h_lines[c] * line_pct;
     const uint32_t cus = compute_units();
@@ -716,52 +718,99 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         const uint32_t       per_cu = (uint32_t) std::min<size_t>(env_u32("SPLAHIP_COB_PER_CU", 2), (160 * 1024) / lds);// 1024-thread workgroups: at most 2 per CU
         if (per_cu == 0) continue;                                                         // this slice width does not fit: not served
         const uint32_t slots = cus * per_cu;
-        // piece size in % of a slot's even share of the cost.  Smaller pieces balance the tail better, larger ones mean fewer partial slices to merge.
-        const uint32_t share_pct = env_u32("SPLAHIP_COB_SHARE_PCT", 50);
-        const uint64_t share     = std::max<uint64_t>(1, (cost_pre[n_chunks] + slots - 1) / slots * share_pct / 100);
+        // piece size in % of a slot's even share of the cost.  Smaller pieces balance the tail better, larger ones mean fewer partial slices to merge,
+        // and with pieces of similar cost the COUNT matters: 2.2 x slots pieces run in three rounds.  So the candidates are tried on a model of the launch
+        // — dearest piece first onto the slot that frees first; a piece costs its chunks + ~4 us of zeroing and pipeline fill (+ ~3.5 us of merging
+        // for a range in several pieces), a range's row pass goes to one of its pieces — and the share with the shortest modelled makespan is kept.
+        // (cost unit: 1600 = one chunk's streams ~ 95 ns.)  SPLAHIP_COB_SHARE_PCT fixes the share instead.
         std::vector<uint32_t> tiles, ranges((size_t) n_ranges * 4);
         std::vector<uint64_t> cost;
         uint32_t              n_multi = 0;
-        for (uint32_t q = 0; q < n_ranges; ++q) {
-            const uint32_t c0 = range_chunk[q], c1 = range_chunk[q + 1], cc = c1 - c0;
-            const bool     hub = q < n_hub_ranges;
-            const uint32_t row0 = hub ? 0u : nat_row0[q - n_hub_ranges], row1 = hub ? 0u : nat_row0[q - n_hub_ranges + 1];
-            const uint64_t rc   = cost_pre[c1] - cost_pre[c0];
-            uint32_t       np   = (uint32_t) std::max<uint64_t>(1, (rc + share - 1) / share);
-            if (tile_chunks) np = std::max(np, (cc + tile_chunks - 1) / tile_chunks);
-            np = std::max(1u, std::min(np, std::max(1u, cc)));
-            // the row pass of the range (its last piece to arrive): rows x (2 B slot + 4 B result [+ 4 B mask]) for a natural range, R scattered words for a hub range
-            const uint64_t row_pass = hub ? (uint64_t) R * 8 : (uint64_t) (row1 - row0) / 4;
-            uint32_t       f = c0, first_tile = (uint32_t) (tiles.size() / 4);
-            for (uint32_t t = 0; t < np; ++t) {
-                // piece t ends where the range's cost passes (t + 1) / np of its total (at least one chunk per piece)
-                uint32_t end = c1;
-                if (t + 1 < np) {
-                    const uint64_t target = cost_pre[c0] + rc * (t + 1) / np;
-                    end                   = (uint32_t) (std::lower_bound(cost_pre.begin() + f + 1, cost_pre.begin() + c1, target) - cost_pre.begin());
-                    end                   = std::max(end, f + 1);
-                    end                   = std::min(end, c1 - (np - 1 - t));
+        // levels > 1: TAPERED pieces — of a range's cost the first 4/7 go into pieces of size a, the next 2/7 into pieces of a / 2, the last 1/7 into pieces of a / 4
+        // (levels = 3; 2/3 + 1/3 for levels = 2): launched dearest first, the rounds end at a, 1.5 a, 1.75 a and the tail is made of small pieces
+        auto cut = [&](uint32_t share_pct, uint32_t levels) {
+            const uint64_t share = std::max<uint64_t>(1, (cost_pre[n_chunks] + slots - 1) / slots * share_pct / 100);
+            tiles.clear(), cost.clear();
+            n_multi = 0;
+            for (uint32_t q = 0; q < n_ranges; ++q) {
+                const uint32_t c0 = range_chunk[q], c1 = range_chunk[q + 1], cc = c1 - c0;
+                const bool     hub = q < n_hub_ranges;
+                const uint32_t row0 = hub ? 0u : nat_row0[q - n_hub_ranges], row1 = hub ? 0u : nat_row0[q - n_hub_ranges + 1];
+                const uint64_t rc   = cost_pre[c1] - cost_pre[c0];
+                // the cost marks at which the range is cut
+                std::vector<uint64_t> marks;
+                if (rc > share && cc > 1) {
+                    const uint32_t L     = std::max(1u, std::min(levels, 3u));
+                    const uint64_t denom = (1u << L) - 1u;// 1, 3, 7
+                    uint64_t       at    = 0;
+                    for (uint32_t l = 0; l < L; ++l) {
+                        const uint64_t part = rc * (1u << (L - 1 - l)) / denom, size = std::max<uint64_t>(1, share >> l);
+                        const uint64_t np   = std::max<uint64_t>(1, (part + size - 1) / size);
+                        for (uint64_t t = 1; t <= np; ++t) marks.push_back(at + part * t / np);
+                        at += part;
+                    }
+                    marks.back() = rc;
+                } else
+                    marks.push_back(rc);
+                // the row pass of the range (its last piece to arrive): ~12 us of round trips for a hub range's scattered rows; ~6 us + 2 us per 2^15 rows
+                const uint64_t row_pass = hub ? 200000 : 100000 + (uint64_t) (row1 - row0);
+                uint32_t       f = c0, first_tile = (uint32_t) (tiles.size() / 4);
+                for (size_t t = 0; t < marks.size() && (f < c1 || t == 0); ++t) {
+                    uint32_t end = c1;
+                    if (t + 1 < marks.size()) {
+                        end = (uint32_t) (std::lower_bound(cost_pre.begin() + f, cost_pre.begin() + c1, cost_pre[c0] + marks[t]) - cost_pre.begin());
+                        end = std::min(std::max(end, f + 1), c1);
+                    }
                     if (tile_chunks) end = std::min(end, f + tile_chunks);
-                }
-                tiles.insert(tiles.end(), {f, end - f, q, kCobNoSlab});
-                cost.push_back(cost_pre[end] - cost_pre[f] + (t == 0 ? row_pass : 0));
-                f = end;
-            }
-            if (tile_chunks && f < c1) {// an explicit cap left chunks over: more pieces of at most tile_chunks
-                while (f < c1) {
-                    const uint32_t end = std::min(c1, f + tile_chunks);
                     tiles.insert(tiles.end(), {f, end - f, q, kCobNoSlab});
-                    cost.push_back(cost_pre[end] - cost_pre[f]);
+                    cost.push_back(cost_pre[end] - cost_pre[f] + 67000);
                     f = end;
                 }
+                while (f < c1) {// (an explicit cap left chunks over: more pieces of at most tile_chunks)
+                    const uint32_t end = tile_chunks ? std::min(c1, f + tile_chunks) : c1;
+                    tiles.insert(tiles.end(), {f, end - f, q, kCobNoSlab});
+                    cost.push_back(cost_pre[end] - cost_pre[f] + 67000);
+                    f = end;
+                }
+                const uint32_t pieces = (uint32_t) (tiles.size() / 4) - first_tile;
+                cost.back() += row_pass;// (the range's cheapest piece is launched last: it is the likely last arriver)
+                if (pieces > 1) {
+                    for (uint32_t t = first_tile; t < first_tile + pieces; ++t) tiles[4 * (size_t) t + 3] = n_multi, cost[t] += 59000;
+                    ++n_multi;
+                }
+                ranges[4 * (size_t) q + 0] = row0, ranges[4 * (size_t) q + 1] = row1, ranges[4 * (size_t) q + 2] = hub ? q * R : 0xFFFFFFFFu, ranges[4 * (size_t) q + 3] = pieces;
             }
-            const uint32_t pieces = (uint32_t) (tiles.size() / 4) - first_tile;
-            if (pieces > 1) {
-                for (uint32_t t = first_tile; t < first_tile + pieces; ++t) tiles[4 * (size_t) t + 3] = n_multi;
-                ++n_multi;
+        };
+        auto makespan = [&]() -> uint64_t {
+            std::vector<uint64_t> c(cost);
+            std::sort(c.begin(), c.end(), std::greater<uint64_t>());
+            std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> free_at;
+            for (uint32_t k = 0; k < slots; ++k) free_at.push(0);
+            uint64_t end = 0;
+            for (uint64_t x : c) {
+                const uint64_t t = free_at.top() + x;
+                free_at.pop();
+                free_at.push(t);
+                end = std::max(end, t);
             }
-            ranges[4 * (size_t) q + 0] = row0, ranges[4 * (size_t) q + 1] = row1, ranges[4 * (size_t) q + 2] = hub ? q * R : 0xFFFFFFFFu, ranges[4 * (size_t) q + 3] = pieces;
+            return end;
+        };
+        uint32_t share_pct = env_u32("SPLAHIP_COB_SHARE_PCT", 0), levels = env_u32("SPLAHIP_COB_LEVELS", 0);
+        if (share_pct == 0 || levels == 0) {
+            uint64_t       best = ~0ull;
+            const uint32_t pct_fixed = share_pct, lev_fixed = levels;
+            for (uint32_t lv : {1u, 2u, 3u}) {
+                if (lev_fixed && lv != lev_fixed) continue;
+                for (uint32_t pct : {140u, 120u, 110u, 100u, 90u, 80u, 70u, 65u, 60u, 55u, 50u, 45u, 40u, 35u, 30u, 25u}) {
+                    if (pct_fixed && pct != pct_fixed) continue;
+                    cut(pct, lv);
+                    const uint64_t m = makespan();
+                    if (m < best) best = m, share_pct = pct, levels = lv;
+                }
+            }
+            if (best == ~0ull) share_pct = pct_fixed ? pct_fixed : 60, levels = lev_fixed ? lev_fixed : 1;
         }
+        cut(share_pct, levels);
         // launch order: dearest piece first (stable: equal pieces keep range order)
         const uint32_t        n_tiles = (uint32_t) (tiles.size() / 4);
         std::vector<uint32_t> order_t(n_tiles), sorted(tiles.size());
@@ -770,9 +819,10 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         for (uint32_t t = 0; t < n_tiles; ++t)
             for (int k = 0; k < 4; ++k) sorted[4 * t + k] = tiles[4 * order_t[t] + k];
         if (std::getenv("SPLAHIP_COB_TRACE"))
-            std::fprintf(stderr, "[cob] schedule %d: R %u, %u hub rows in %u hub ranges + %u natural ranges; slots %u, cost %.1f M (%.1f %% gathers), piece <= %u %% of a share, %u pieces, "
-                                 "%u ranges in several pieces\n",
-                         w, R, H, n_hub_ranges, n_nat, slots, cost_pre[n_chunks] / 1e8, 100.0 - 100.0 * 1600.0 * n_chunks / std::max<uint64_t>(1, cost_pre[n_chunks]), share_pct, n_tiles, n_multi);
+            std::fprintf(stderr, "[cob] schedule %d: R %u, %u hub rows in %u hub ranges + %u natural ranges; slots %u, cost %.1f M (%.1f %% gathers), piece <= %u %% of a share in %u size levels, %u pieces, "
+                                 "%u ranges in several pieces, modelled makespan %.1f us (even: %.1f)\n",
+                         w, R, H, n_hub_ranges, n_nat, slots, cost_pre[n_chunks] / 1e8, 100.0 - 100.0 * 1600.0 * n_chunks / std::max<uint64_t>(1, cost_pre[n_chunks]), share_pct, levels, n_tiles, n_multi,
+                         makespan() * 95e-3 / 1600, cost_pre[n_chunks] * 95e-3 / 1600 / slots);
         sc.n_tiles = n_tiles;
         sc.n_multi = n_multi;
         max_multi  = std::max(max_multi, n_multi);

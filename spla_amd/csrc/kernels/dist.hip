@@ -337,7 +337,7 @@ int splahip_shard_mxv_remote(splahip_shard s, int type, const void* d_mask, cons
     SPLAHIP_REQUIRE(s != nullptr, "shard is null");
     if (!splahip_shard_split_serves(s, type, op_add, 0)) return fail(SPLAHIP_NOT_IMPLEMENTED, "the two-part form does not serve this op_add: use splahip_shard_mxv_whole");
     if (s->n_local == 0 || s->nnz_rem == 0) return SPLAHIP_OK;
-    SPLAHIP_REQUIRE((reinterpret_cast<uintptr_t>(d_r) & 15u) == 0, "r must be 16-byte aligned");
+    SPLAHIP_REQUIRE(((reinterpret_cast<uintptr_t>(d_r) | reinterpret_cast<uintptr_t>(d_mask)) & 15u) == 0, "r and mask must be 16-byte aligned");
     return cob_mxv_accumulate(s->plan_rem, type, s->RAp, d_mask, d_v_full, d_r, op_mult, op_add, op_select, stream);
 }
 

@@ -5,12 +5,19 @@
 // run time (src/opencl/cl_program_builder.cpp:65-120); without an accelerator it falls back to the host function (src/core/dispatcher.cpp:55-58).
 // This library has no CPU path, so hiprtc is what keeps "arbitrary (op_add, op_mult) semirings" true: the body text is valid HIP device code.
 //
-// One kernel form serves every combination: a lane per row, the reference's strict left fold from init with its early-exit rule
-// (src/cpu/cpu_mxv.hpp:88-103) — exact for any op, associative or not; built-in ops that appear beside a user-defined one are emitted from
+// One kernel form per operator serves every combination, each the reference's own fold order — exact for any op, associative or not:
+//   mxv          a lane per row, strict left fold from init with the early-exit rule (src/cpu/cpu_mxv.hpp:88-103)
+//   vxm          a lane per output index over the transposed matrix, products in the stored order of v, the first product initialises
+//                (src/cpu/cpu_vxm.hpp:92-125)
+//   mxm          expand / stable sort / a lane per run folding in expand order from init (src/cpu/cpu_mxm.hpp:85-114)
+//   mxmT_masked  a lane per stored mask entry, two-pointer merge of the sorted rows (src/cpu/cpu_mxmT_masked.hpp:87-125)
+// The drivers around them are the built-in ops' own (jit_hooks.hpp).  Built-in ops that appear beside a user-defined one are emitted from
 // the same expressions ops.hpp evaluates (two's-complement int arithmetic, std::min / std::max comparisons, guarded integer division).
+// Device code is compiled with -ffp-contract=off: the op's host std::function — the reference's CPU result — is not fused either.
 // Compiled kernels are cached by their full source text.  hiprtc is loaded at run time from the directory of the HIP runtime the process
 // already uses (PyTorch-ROCm bundles its own), then from the default search path.
 #include "common.hpp"
+#include "jit_hooks.hpp"
 #include "ops.hpp"
 
 #include <hip/hiprtc.h>
@@ -117,13 +124,120 @@ namespace {
         return s + "(T a) { return " + builtin_sel(op) + "; }\n";
     }
 
-    std::string mxv_source(int type, int op_mult, const char* mult_src, int op_add, const char* add_src, int op_select, const char* select_src) {
+    std::string prologue(int type, int op_mult, const char* mult_src, int op_add, const char* add_src, int op_select, const char* select_src, bool with_select = true) {
         std::string s;
-        s += "typedef unsigned int uint;\n";
+        s += "typedef unsigned int uint;\ntypedef unsigned long long u64;\n";
         s += std::string("typedef ") + type_text(type) + " T;\n";
         s += binary_fn("op_mult", type, op_mult, mult_src);
         s += binary_fn("op_add", type, op_add, add_src);
-        s += select_fn(op_select, select_src);
+        if (with_select) s += select_fn(op_select, select_src);
+        return s;
+    }
+
+    // reference src/cpu/cpu_mxmT_masked.hpp:87-125: per stored mask entry (i, j, m): r = init; if select(m): merge the column-sorted rows A[i, :] and
+    // B[j, :], r = add(r, mult(a, b)) on equal columns in ascending column order; the entry is kept iff r != init
+    std::string mxmT_source(int type, int op_mult, const char* mult_src, int op_add, const char* add_src, int op_select, const char* select_src) {
+        std::string s = prologue(type, op_mult, mult_src, op_add, add_src, op_select, select_src);
+        s += "extern \"C\" __global__ void __launch_bounds__(256) splahip_mxmT_jit(uint n_rows, uint n_entries, const uint* __restrict__ Mp, const uint* __restrict__ Mj,\n"
+             "        const T* __restrict__ Mx, const uint* __restrict__ Ap, const uint* __restrict__ Aj, const T* __restrict__ Ax, const uint* __restrict__ Bp,\n"
+             "        const uint* __restrict__ Bj, const T* __restrict__ Bx, T* __restrict__ val, uint* __restrict__ keep, T init) {\n"
+             "    const uint e = blockIdx.x * 256u + threadIdx.x;\n"
+             "    if (e >= n_entries) return;\n"
+             "    T r = init;\n"
+             "    if (op_select(Mx[e])) {\n"
+             "        uint lo = 0, hi = n_rows;\n"
+             "        while (hi - lo > 1) { const uint mid = lo + ((hi - lo) >> 1); if (Mp[mid] <= e) lo = mid; else hi = mid; }\n"
+             "        const uint j = Mj[e];\n"
+             "        uint ka = Ap[lo], ea = Ap[lo + 1], kb = Bp[j], eb = Bp[j + 1];\n"
+             "        while (ka < ea && kb < eb) {\n"
+             "            const uint ca = Aj[ka], cb = Bj[kb];\n"
+             "            if (ca == cb) { r = op_add(r, op_mult(Ax[ka], Bx[kb])); ++ka; ++kb; }\n"
+             "            else if (ca < cb) ++ka; else ++kb;\n"
+             "        }\n"
+             "    }\n"
+             "    val[e] = r;\n"
+             "    keep[e] = (r != init) ? 1u : 0u;\n"
+             "}\n";
+        return s;
+    }
+
+    // reference src/cpu/cpu_mxm.hpp:85-114: R[i, j] = fold over k in A[i, :] (row order) of add(., mult(a, b)) from init; entries equal to init are dropped.
+    // expand: product p of a row block -> (key = row in block << col_bits | column, value = mult(a, b)), in (A entry, B entry) order; the stable sort keeps
+    // that order inside a key; run: the lane at a run's head folds it from init
+    std::string mxm_source(int type, int op_mult, const char* mult_src, int op_add, const char* add_src) {
+        std::string s = prologue(type, op_mult, mult_src, op_add, add_src, 0, nullptr, false);
+        s += "extern \"C\" __global__ void __launch_bounds__(256) splahip_mxm_expand_jit(uint n_products, uint e0, uint n_entries, const uint* __restrict__ offs, uint n_rows,\n"
+             "        const uint* __restrict__ Ap, const uint* __restrict__ Aj, const T* __restrict__ Ax, const uint* __restrict__ Bp, const uint* __restrict__ Bj,\n"
+             "        const T* __restrict__ Bx, uint r0, uint col_bits, u64* __restrict__ key, T* __restrict__ val) {\n"
+             "    const uint p = blockIdx.x * 256u + threadIdx.x;\n"
+             "    if (p >= n_products) return;\n"
+             "    uint lo = 0, hi = n_entries;\n"
+             "    while (hi - lo > 1) { const uint mid = lo + ((hi - lo) >> 1); if (offs[mid] <= p) lo = mid; else hi = mid; }\n"
+             "    const uint e = e0 + lo;\n"
+             "    uint rl = 0, rh = n_rows;\n"
+             "    while (rh - rl > 1) { const uint mid = rl + ((rh - rl) >> 1); if (Ap[mid] <= e) rl = mid; else rh = mid; }\n"
+             "    const uint kb = Bp[Aj[e]] + (p - offs[lo]);\n"
+             "    key[p] = ((u64) (rl - r0) << col_bits) | (u64) Bj[kb];\n"
+             "    val[p] = op_mult(Ax[e], Bx[kb]);\n"
+             "}\n"
+             "extern \"C\" __global__ void __launch_bounds__(256) splahip_mxm_run_jit(const u64* __restrict__ key, const T* __restrict__ val, uint n, const uint* __restrict__ head,\n"
+             "        const uint* __restrict__ run_rank, u64* __restrict__ run_key, T* __restrict__ run_val, uint* __restrict__ run_keep, T init) {\n"
+             "    const uint p = blockIdx.x * 256u + threadIdx.x;\n"
+             "    if (p >= n || head[p] == 0) return;\n"
+             "    T acc = init;\n"
+             "    uint q = p;\n"
+             "    do { acc = op_add(acc, val[q]); ++q; } while (q < n && head[q] == 0);\n"
+             "    const uint rr = run_rank[p];\n"
+             "    run_key[rr] = key[p];\n"
+             "    run_val[rr] = acc;\n"
+             "    run_keep[rr] = (acc != init) ? 1u : 0u;\n"
+             "}\n";
+        return s;
+    }
+
+    // reference src/cpu/cpu_vxm.hpp:92-125: for every stored entry (i, v_i) of v in stored order, for (j, x) in M[i, :] with select(mask[j]): the first product
+    // of column j initialises r[j] = mult(v_i, x), later ones fold r[j] = add(r[j], mult(v_i, x)); init is never used.  Pull form: column j of M is row j of the
+    // transposed matrix, whose entries ascend in i — the stored order of v when v is index-sorted; otherwise the products are taken by ascending position in v
+    std::string vxm_source(int type, int op_mult, const char* mult_src, int op_add, const char* add_src, int op_select, const char* select_src) {
+        std::string s = prologue(type, op_mult, mult_src, op_add, add_src, op_select, select_src);
+        s += "extern \"C\" __global__ void __launch_bounds__(256) splahip_vxm_jit(uint n_out, const uint* __restrict__ Tp, const uint* __restrict__ Tj, const T* __restrict__ Tx,\n"
+             "        const T* __restrict__ mask, const T* __restrict__ v, const uint* __restrict__ present, const uint* __restrict__ vpos, int sorted,\n"
+             "        T* __restrict__ outv, uint* __restrict__ touched) {\n"
+             "    const uint j = blockIdx.x * 256u + threadIdx.x;\n"
+             "    if (j >= n_out) return;\n"
+             "    T acc = (T) 0;\n"
+             "    uint t = 0;\n"
+             "    if (op_select(mask[j])) {\n"
+             "        const uint k0 = Tp[j], k1 = Tp[j + 1];\n"
+             "        if (sorted) {\n"
+             "            for (uint k = k0; k < k1; ++k) {\n"
+             "                const uint i = Tj[k];\n"
+             "                if ((present[i >> 5] >> (i & 31u)) & 1u) { const T p = op_mult(v[i], Tx[k]); acc = t ? op_add(acc, p) : p; t = 1; }\n"
+             "            }\n"
+             "        } else {\n"
+             "            long long last = -1;\n"
+             "            for (;;) {\n"
+             "                uint best = 0xFFFFFFFFu, bk = 0;\n"
+             "                for (uint k = k0; k < k1; ++k) {\n"
+             "                    const uint i = Tj[k];\n"
+             "                    if ((present[i >> 5] >> (i & 31u)) & 1u) { const uint pos = vpos[i]; if ((long long) pos > last && pos < best) { best = pos; bk = k; } }\n"
+             "                }\n"
+             "                if (best == 0xFFFFFFFFu) break;\n"
+             "                const T p = op_mult(v[Tj[bk]], Tx[bk]);\n"
+             "                acc = t ? op_add(acc, p) : p;\n"
+             "                t = 1;\n"
+             "                last = (long long) best;\n"
+             "            }\n"
+             "        }\n"
+             "    }\n"
+             "    outv[j] = acc;\n"
+             "    touched[j] = t;\n"
+             "}\n";
+        return s;
+    }
+
+    std::string mxv_source(int type, int op_mult, const char* mult_src, int op_add, const char* add_src, int op_select, const char* select_src) {
+        std::string s = prologue(type, op_mult, mult_src, op_add, add_src, op_select, select_src);
         // reference src/cpu/cpu_mxv.hpp:88-103: every row is written; a selected row folds its products left to right from init and, with
         // early exit, stops after the product that makes the sum differ from init
         s += "extern \"C\" __global__ void __launch_bounds__(256) splahip_mxv_jit(uint n_rows, const uint* __restrict__ Ap, const uint* __restrict__ Aj,\n"
@@ -146,7 +260,8 @@ namespace {
     std::mutex                                     g_jit_lock;
     std::unordered_map<std::string, hipFunction_t> g_jit_cache;// full source text -> kernel (modules stay loaded for the life of the process)
 
-    int compile(const std::string& src, hipFunction_t* fn) {
+    int compile(const std::string& source, const char* kernel_name, hipFunction_t* fn) {
+        const std::string src = std::string("// ") + kernel_name + "\n" + source;// (one cache entry per kernel of a source)
         {
             std::lock_guard<std::mutex> guard(g_jit_lock);
             auto                        it = g_jit_cache.find(src);
@@ -159,8 +274,17 @@ namespace {
         if (!r.ok) return fail(SPLAHIP_NOT_IMPLEMENTED, "hiprtc is not loadable in this process: user-defined ops cannot be compiled for the device");
         hiprtcProgram prog = nullptr;
         if (r.CreateProgram(&prog, src.c_str(), "splahip_user_ops.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return fail(SPLAHIP_ERROR, "hiprtcCreateProgram failed");
-        const char*  opts[] = {"--offload-arch=gfx950", "-O3"};
-        hiprtcResult cr     = r.CompileProgram(prog, 2, opts);
+        // the architecture of the device this process runs on (gcnArchName, e.g. "gfx950:sramecc+:xnack-"); no fused multiply-add across the user's
+        // expression: the op's host function, which stands in for the reference's CPU result, is not contracted either
+        std::string     arch = "--offload-arch=gfx950";
+        int             dev  = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.gcnArchName[0]) {
+            std::string name = prop.gcnArchName;
+            arch             = "--offload-arch=" + name.substr(0, name.find(':'));
+        }
+        const char*  opts[] = {arch.c_str(), "-O3", "-ffp-contract=off"};
+        hiprtcResult cr     = r.CompileProgram(prog, 3, opts);
         if (cr != HIPRTC_SUCCESS) {
             size_t      n = 0;
             std::string log;
@@ -180,7 +304,7 @@ namespace {
         hipModule_t mod = nullptr;
         SPLAHIP_TRY(hipModuleLoadData(&mod, code.data()));
         hipFunction_t f = nullptr;
-        SPLAHIP_TRY(hipModuleGetFunction(&f, mod, "splahip_mxv_jit"));
+        SPLAHIP_TRY(hipModuleGetFunction(&f, mod, kernel_name));
         std::lock_guard<std::mutex> guard(g_jit_lock);
         g_jit_cache.emplace(src, f);
         *fn = f;
@@ -206,12 +330,70 @@ int splahip_mxv_masked_jit(int type, uint32_t n_rows, const uint32_t* d_Ap, cons
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
     hipFunction_t fn = nullptr;
-    st               = compile(mxv_source(type, op_mult, mult_src, op_add, add_src, op_select, select_src), &fn);
+    st               = compile(mxv_source(type, op_mult, mult_src, op_add, add_src, op_select, select_src), "splahip_mxv_jit", &fn);
     if (st != SPLAHIP_OK) return st;
     uint32_t init = init_bits;
     int      ee   = early_exit ? 1 : 0;
     void*    args[] = {&n_rows, &d_Ap, &d_Aj, &d_Ax, &d_mask, &d_v, &d_r, &init, &ee};
     SPLAHIP_TRY(hipModuleLaunchKernel(fn, (n_rows + 255u) / 256u, 1, 1, 256, 1, 1, 0, as_stream(stream), args, nullptr));
     return SPLAHIP_OK;
+}
+
+// exec_vxm_masked with user-defined ops: the pull form over the transposed matrix (plan_T = the plan of M^T, n_in = rows of M = length of v, n_out = columns
+// of M); sorted: the indices of v ascend (splahip_vxm_probe).  Output: index-sorted COO, one entry per selected column that holds a product.
+int splahip_vxm_masked_jit(splahip_plan plan_T, int type, uint32_t n_in, uint32_t n_out, const uint32_t* d_Tp, const uint32_t* d_Tj, const void* d_Tx, const void* d_mask,
+                           uint32_t nvals, const uint32_t* d_vi, const void* d_vx, int sorted, uint32_t* d_ri, void* d_rx, uint32_t* h_count, int op_mult, const char* mult_src,
+                           int op_add, const char* add_src, int op_select, const char* select_src, void* stream) {
+    SPLAHIP_REQUIRE(plan_T != nullptr && h_count != nullptr, "null argument");
+    SPLAHIP_REQUIRE(type == SPLAHIP_INT || type == SPLAHIP_UINT || type == SPLAHIP_FLOAT, "unknown element type");
+    SPLAHIP_REQUIRE(mult_src || binop_valid_for(op_mult, type), "op_multiply not defined for this type");
+    SPLAHIP_REQUIRE(add_src || binop_valid_for(op_add, type), "op_add not defined for this type");
+    SPLAHIP_REQUIRE(select_src || (op_select >= 0 && op_select < SPLAHIP_SELOP_COUNT), "unknown op_select");
+    *h_count = 0;
+    if (n_out == 0 || nvals == 0) return SPLAHIP_OK;
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    hipFunction_t fn = nullptr;
+    st               = compile(vxm_source(type, op_mult, mult_src, op_add, add_src, op_select, select_src), "splahip_vxm_jit", &fn);
+    if (st != SPLAHIP_OK) return st;
+    return vxm_pull_jit(plan_T, n_out, n_in, d_Tp, d_Tj, d_Tx, d_mask, nvals, d_vi, d_vx, sorted, d_ri, d_rx, h_count, fn, as_stream(stream));
+}
+
+// exec_mxmT_masked with user-defined ops (arguments as splahip_mxmT_masked)
+int splahip_mxmT_masked_jit(int type, uint32_t n_rows, uint32_t mask_nnz, const uint32_t* d_Mp, const uint32_t* d_Mj, const void* d_Mx, const uint32_t* d_Ap,
+                            const uint32_t* d_Aj, const void* d_Ax, const uint32_t* d_Bp, const uint32_t* d_Bj, const void* d_Bx, uint32_t* d_Rp, uint32_t** d_Rj, void** d_Rx,
+                            uint32_t* h_nnz, int op_mult, const char* mult_src, int op_add, const char* add_src, int op_select, const char* select_src, uint32_t init_bits,
+                            void* stream) {
+    SPLAHIP_REQUIRE(d_Rp && d_Rj && d_Rx && h_nnz, "null output argument");
+    SPLAHIP_REQUIRE(type == SPLAHIP_INT || type == SPLAHIP_UINT || type == SPLAHIP_FLOAT, "unknown element type");
+    SPLAHIP_REQUIRE(mult_src || binop_valid_for(op_mult, type), "op_multiply not defined for this type");
+    SPLAHIP_REQUIRE(add_src || binop_valid_for(op_add, type), "op_add not defined for this type");
+    SPLAHIP_REQUIRE(select_src || (op_select >= 0 && op_select < SPLAHIP_SELOP_COUNT), "unknown op_select");
+    SPLAHIP_REQUIRE(d_Mp && d_Ap && d_Bp, "null row pointer array");
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    hipFunction_t fn = nullptr;
+    st               = compile(mxmT_source(type, op_mult, mult_src, op_add, add_src, op_select, select_src), "splahip_mxmT_jit", &fn);
+    if (st != SPLAHIP_OK) return st;
+    return mxmT_jit(n_rows, mask_nnz, d_Mp, d_Mj, d_Mx, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, init_bits, fn, as_stream(stream));
+}
+
+// exec_mxm with user-defined ops (arguments as splahip_mxm)
+int splahip_mxm_jit(int type, uint32_t a_rows, uint32_t b_cols, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, const uint32_t* d_Bp, const uint32_t* d_Bj,
+                    const void* d_Bx, uint32_t* d_Rp, uint32_t** d_Rj, void** d_Rx, uint32_t* h_nnz, int op_mult, const char* mult_src, int op_add, const char* add_src,
+                    uint32_t init_bits, void* stream) {
+    SPLAHIP_REQUIRE(d_Rp && d_Rj && d_Rx && h_nnz, "null output argument");
+    SPLAHIP_REQUIRE(type == SPLAHIP_INT || type == SPLAHIP_UINT || type == SPLAHIP_FLOAT, "unknown element type");
+    SPLAHIP_REQUIRE(mult_src || binop_valid_for(op_mult, type), "op_multiply not defined for this type");
+    SPLAHIP_REQUIRE(add_src || binop_valid_for(op_add, type), "op_add not defined for this type");
+    SPLAHIP_REQUIRE(d_Ap && d_Bp, "null row pointer array");
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    const std::string src = mxm_source(type, op_mult, mult_src, op_add, add_src);
+    hipFunction_t     expand = nullptr, run = nullptr;
+    st = compile(src, "splahip_mxm_expand_jit", &expand);
+    if (st == SPLAHIP_OK) st = compile(src, "splahip_mxm_run_jit", &run);
+    if (st != SPLAHIP_OK) return st;
+    return mxm_jit(a_rows, b_cols, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, init_bits, expand, run, as_stream(stream));
 }
 }

@@ -20,6 +20,7 @@
 //   included) when runs are folded sequentially; runs longer than 64 products use an in-order tree (associative ops).
 #include "block_utils.hpp"
 #include "common.hpp"
+#include "jit_hooks.hpp"
 #include "ops.hpp"
 
 #include <cstring>
@@ -798,7 +799,7 @@ namespace splahip {
     template<typename T>
     int mxmT_typed(uint n_rows, uint n_entries, const uint* Mp, const uint* Mj, const void* Mx, const uint* Ap, const uint* Aj, const void* Ax,
                    const uint* Bp, const uint* Bj, const void* Bx, uint* Rp, uint** Rj, void** Rx, uint* h_nnz,
-                   int op_mult, int op_add, int op_select, uint32_t init_bits, hipStream_t s) {
+                   int op_mult, int op_add, int op_select, uint32_t init_bits, hipStream_t s, hipFunction_t jit_entry = nullptr) {
         struct Busy {
             Busy() { ++DevBuf::busy(); }
             ~Busy() { --DevBuf::busy(); }
@@ -817,6 +818,13 @@ namespace splahip {
         SPLAHIP_TRY(hcount.alloc(2 * sizeof(uint)));// one 64-bit counter: low word = entries for the galloping search kernel, high word = for the block merge
         SPLAHIP_TRY(hlist.alloc(sizeof(uint) * 2 * (size_t) n_entries));
         SPLAHIP_TRY(hipMemsetAsync(hcount.p, 0, 2 * sizeof(uint), s));
+        if (jit_entry) {// user-defined ops (jit.hip): the run-time-compiled per-entry kernel computes every entry; the compaction below is shared
+            void* pv = val.p;
+            void* pk = keep.p;
+            uint  ib = init_bits;
+            void* args[] = {&n_rows, &n_entries, &Mp, &Mj, &Mx, &Ap, &Aj, &Ax, &Bp, &Bj, &Bx, &pv, &pk, &ib};
+            SPLAHIP_TRY(hipModuleLaunchKernel(jit_entry, (n_entries + 255u) / 256u, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+        }
         // the block merge regroups the products like the tree of the search kernel: same condition.  SPLAHIP_MXMT_MERGE=0: search kernel only
         const char* merge_env = std::getenv("SPLAHIP_MXMT_MERGE");
         const bool  merge_form = fold_is_reorderable(op_add, TypeId<T>::value) && !(merge_env && merge_env[0] == '0');
@@ -830,7 +838,7 @@ namespace splahip {
         // (35.5 ms against 33.1 ms per call; rows <= 1023: 18.4 ms, longer rows 11.0 ms — 12 M entries of ~650 streamed words each leave the
         // per-entry fixed costs, one round trip for the matches' value words and an in-order reduction, as large as the stream itself)
         const char* row_env  = std::getenv("SPLAHIP_MXMT_ROW");
-        const bool  row_form = fold_is_reorderable(op_add, TypeId<T>::value) && binop_is_commutative(op_add) && row_env && row_env[0] == '1';
+        const bool  row_form = !jit_entry && fold_is_reorderable(op_add, TypeId<T>::value) && binop_is_commutative(op_add) && row_env && row_env[0] == '1';
         DevBuf      cost, cost_before, pieces, piece_first;
         if (row_form) {
             SPLAHIP_TRY(cost.alloc(sizeof(uint) * (size_t) n_entries));
@@ -838,10 +846,11 @@ namespace splahip {
             SPLAHIP_TRY(pieces.alloc(sizeof(uint) * 2 * (size_t) n_rows));
             SPLAHIP_TRY(piece_first.alloc(sizeof(uint) * (2 * (size_t) n_rows + 1)));
         }
-        hipLaunchKernelGGL((mxmT_entry_kernel<T, DynBin, DynBin>), dim3((n_entries + 255) / 256), dim3(256), 0, s, n_rows, n_entries, Mp, Mj,
-                           static_cast<const T*>(Mx), Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(),
-                           keep.as<uint>(), hcount.as<uint>(), hlist.as<uint>(), DynBin(op_mult), DynBin(op_add), op_select, init, row_form ? kRowCap : 0u,
-                           row_form ? cost.as<uint>() : nullptr, merge_form ? 1u : 0u, merge_factor, heavy_from);
+        if (!jit_entry)
+            hipLaunchKernelGGL((mxmT_entry_kernel<T, DynBin, DynBin>), dim3((n_entries + 255) / 256), dim3(256), 0, s, n_rows, n_entries, Mp, Mj,
+                               static_cast<const T*>(Mx), Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(),
+                               keep.as<uint>(), hcount.as<uint>(), hlist.as<uint>(), DynBin(op_mult), DynBin(op_add), op_select, init, row_form ? kRowCap : 0u,
+                               row_form ? cost.as<uint>() : nullptr, merge_form ? 1u : 0u, merge_factor, heavy_from);
         SPLAHIP_TRY(hipGetLastError());
         uint h_heavy[2] = {0, 0}, h_first[2] = {0, 0};
         if (row_form) {
@@ -1176,7 +1185,7 @@ namespace splahip {
     template<typename T>
     int mxm_typed(uint a_rows, uint b_cols, const uint* Ap, const uint* Aj, const void* Ax, const uint* Bp, const uint* Bj, const void* Bx,
                   uint* Rp, uint** Rj, void** Rx, uint* h_nnz, u64* h_products, int op_mult, int op_add, uint32_t init_bits,
-                  u64 block_products, hipStream_t s) {
+                  u64 block_products, hipStream_t s, hipFunction_t jit_expand = nullptr, hipFunction_t jit_run = nullptr) {
         struct Busy {
             Busy() { ++DevBuf::busy(); }
             ~Busy() { --DevBuf::busy(); }
@@ -1288,9 +1297,15 @@ namespace splahip {
                 hipLaunchKernelGGL(len_sum_kernel, dim3(n_chunks), dim3(256), 0, s, len.as<uint>(), n_entries, chunk.as<uint>());
                 hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk.as<uint>(), n_chunks);
                 hipLaunchKernelGGL(len_scan_kernel, dim3(n_chunks), dim3(256), 0, s, len.as<uint>(), n_entries, chunk.as<uint>(), n_chunks, offs.as<uint>());
-                hipLaunchKernelGGL((mxm_expand_kernel<T, K, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, n_products, e0, n_entries,
-                                   offs.as<uint>(), a_rows, Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), DynBin(op_mult),
-                                   blk.r0, col_bits, key_a.as<K>(), val_a.as<T>());
+                if (jit_expand) {// user-defined ops (jit.hip): 64-bit keys, the run-time-compiled expand kernel
+                    uint  np = n_products, ee = e0, ne = n_entries, nr = a_rows, r0 = blk.r0, cb = col_bits;
+                    void *po = offs.p, *pk = key_a.p, *pv = val_a.p;
+                    void* args[] = {&np, &ee, &ne, &po, &nr, &Ap, &Aj, &Ax, &Bp, &Bj, &Bx, &r0, &cb, &pk, &pv};
+                    SPLAHIP_TRY(hipModuleLaunchKernel(jit_expand, (n_products + 255u) / 256u, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+                } else
+                    hipLaunchKernelGGL((mxm_expand_kernel<T, K, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, n_products, e0, n_entries,
+                                       offs.as<uint>(), a_rows, Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), DynBin(op_mult),
+                                       blk.r0, col_bits, key_a.as<K>(), val_a.as<T>());
                 SPLAHIP_TRY(hipGetLastError());
                 if (trace.on && &blk == &blocks.back()) trace.mark("  last block: expand");
                 // stable sort by (row, column): equal keys keep the expand order = the reference's fold order
@@ -1307,9 +1322,15 @@ namespace splahip {
                 SPLAHIP_TRY(hipMemcpyAsync(&n_runs, run_rank.as<uint>() + n_products, sizeof(uint), hipMemcpyDeviceToHost, s));
                 SPLAHIP_TRY(hipMemsetAsync(lcount.p, 0, sizeof(uint), s));
                 SPLAHIP_TRY(hipStreamSynchronize(s));
-                hipLaunchKernelGGL((mxm_run_kernel<T, K, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, key_b.as<K>(), val_b.as<T>(), n_products,
-                                   head.as<uint>(), run_rank.as<uint>(), run_key.as<K>(), run_val.as<T>(), run_keep.as<uint>(), lcount.as<uint>(),
-                                   lpos.as<uint>(), DynBin(op_add), init);
+                if (jit_run) {// a lane per run, the whole run in order (no queue of long runs)
+                    uint  np = n_products, ib = init_bits;
+                    void *pk = key_b.p, *pv = val_b.p, *ph = head.p, *pr = run_rank.p, *qk = run_key.p, *qv = run_val.p, *qe = run_keep.p;
+                    void* args[] = {&pk, &pv, &np, &ph, &pr, &qk, &qv, &qe, &ib};
+                    SPLAHIP_TRY(hipModuleLaunchKernel(jit_run, (n_products + 255u) / 256u, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+                } else
+                    hipLaunchKernelGGL((mxm_run_kernel<T, K, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, key_b.as<K>(), val_b.as<T>(), n_products,
+                                       head.as<uint>(), run_rank.as<uint>(), run_key.as<K>(), run_val.as<T>(), run_keep.as<uint>(), lcount.as<uint>(),
+                                       lpos.as<uint>(), DynBin(op_add), init);
                 SPLAHIP_TRY(hipGetLastError());
                 uint h_long = 0;
                 SPLAHIP_TRY(hipMemcpyAsync(&h_long, lcount.p, sizeof(uint), hipMemcpyDeviceToHost, s));
@@ -1356,7 +1377,7 @@ namespace splahip {
                 if (trace.on && &blk == &blocks.back()) trace.mark("  last block: compact + emit");
                 return SPLAHIP_OK;
             };
-            status = (col_bits + std::max(1u, bit_width(blk.r1 - blk.r0 - 1)) <= 32u) ? run_block(uint{}) : run_block(u64{});
+            status = (!jit_expand && col_bits + std::max(1u, bit_width(blk.r1 - blk.r0 - 1)) <= 32u) ? run_block(uint{}) : run_block(u64{});
             if (status != SPLAHIP_OK) break;
         }
         if (status != SPLAHIP_OK) {
@@ -1394,6 +1415,25 @@ namespace splahip {
         return SPLAHIP_OK;
     }
 
+}// namespace splahip
+
+namespace splahip {
+    // jit_hooks.hpp: the drivers above with the op-dependent kernels replaced by run-time-compiled ones (4-byte elements of any type: uint32_t stands in)
+    int mxmT_jit(uint32_t n_rows, uint32_t n_entries, const uint32_t* Mp, const uint32_t* Mj, const void* Mx, const uint32_t* Ap, const uint32_t* Aj, const void* Ax,
+                 const uint32_t* Bp, const uint32_t* Bj, const void* Bx, uint32_t* Rp, uint32_t** Rj, void** Rx, uint32_t* h_nnz, uint32_t init_bits, hipFunction_t entry,
+                 hipStream_t s) {
+        tl_stream = s;
+        return mxmT_typed<uint32_t>(n_rows, n_entries, Mp, Mj, Mx, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, SPLAHIP_FIRST, SPLAHIP_FIRST, SPLAHIP_ALWAYS, init_bits, s, entry);
+    }
+    int mxm_jit(uint32_t a_rows, uint32_t b_cols, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const uint32_t* Bp, const uint32_t* Bj, const void* Bx, uint32_t* Rp,
+                uint32_t** Rj, void** Rx, uint32_t* h_nnz, uint32_t init_bits, hipFunction_t expand, hipFunction_t run, hipStream_t s) {
+        tl_stream = s;
+        if (a_rows == 0) {
+            *Rj = nullptr, *Rx = nullptr, *h_nnz = 0;
+            return SPLAHIP_OK;
+        }
+        return mxm_typed<uint32_t>(a_rows, b_cols, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, nullptr, SPLAHIP_FIRST, SPLAHIP_FIRST, init_bits, 1ull << 26, s, expand, run);
+    }
 }// namespace splahip
 
 namespace splahip {

@@ -250,7 +250,8 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
     // When the plan also holds a sliced-ELL copy, the semirings of its sparse-vector (bit) form whose skippable value is 0 (BAND / BOR, LAND / LOR,
     // ... on int / uint: a BFS step, where a few per cent of v are non-zero and half the rows are masked out) stay with it: it reads only the
     // selected rows' entries and one bit per column; every other call is faster over the column-ordered blocks (SPLAHIP_PREFER=cob|sell overrides).
-    if (!early_exit && cob_serves_mxv(plan, type, op_mult, op_add, n_cols, stream) && d_r != d_mask && d_r != d_v && (reinterpret_cast<uintptr_t>(d_r) & 15u) == 0) {
+    if (!early_exit && cob_serves_mxv(plan, type, op_mult, op_add, n_cols, stream) && d_r != d_mask && d_r != d_v &&
+        ((reinterpret_cast<uintptr_t>(d_r) | reinterpret_cast<uintptr_t>(d_mask)) & 15u) == 0) {// (its row pass moves r and mask 16 bytes at a time)
         const char* pref     = std::getenv("SPLAHIP_PREFER");
         const bool  sell_ok  = plan->sell && plan->sell->n_cols == n_cols && !sell_disabled() && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add));
         const bool  use_sell = sell_ok && (pref ? pref[0] == 's' : sell_skip_family(type, op_mult, op_add) == 1);

@@ -268,6 +268,131 @@ namespace splahip {
 #endif
     }
 
+    // The row pass of a range: results leave the LDS slice (4-byte words: a double slice has been rounded in place, a merged range's words read back).
+    // One copy per (type, op_add family, mode) however many op_mult / input-vector forms of the kernel exist — a real call, not inlined.
+    // TIGHT: the caller is one of the kernels cut for 64 registers (two 16-wave workgroups per CU): smaller batches, so that the pass fits them too.
+    template<typename T, int ACC, bool VXM, unsigned TPB, bool TIGHT>
+    __device__ __noinline__ void cob_row_pass(const uint32_t* s_words, const CobRange rg, const uint16_t* __restrict__ slot16, const uint32_t* __restrict__ hub_row,
+                                              uint32_t* __restrict__ touched, uint32_t n_rows, uint32_t R, uint32_t accumulate, const T* __restrict__ mask, T* __restrict__ r,
+                                              DynBin add, int op_select, T init) {
+        auto s_words_at = [&](uint32_t i) -> uint32_t { return s_words[i]; };
+        if (rg.hub_base != 0xFFFFFFFFu) {
+            // hub range: slot s is row hub_row[hub_base + s]; one scattered word per row (rows, then masks, requested in batches)
+            constexpr int KH = TIGHT ? 4 : 8;
+            for (uint32_t base = threadIdx.x; base < R; base += TPB * KH) {
+                uint32_t rows[KH];
+#pragma unroll
+                for (int k = 0; k < KH; ++k) {
+                    const uint32_t sidx = base + k * TPB;
+                    rows[k]             = sidx < R ? hub_row[rg.hub_base + sidx] : 0xFFFFFFFFu;
+                }
+                T    mk[KH];
+                T    prev[KH];
+#pragma unroll
+                for (int k = 0; k < KH; ++k) {
+                    mk[k]   = rows[k] != 0xFFFFFFFFu && op_select != SPLAHIP_ALWAYS ? mask[rows[k]] : T(0);
+                    prev[k] = rows[k] != 0xFFFFFFFFu && !VXM && accumulate ? r[rows[k]] : init;
+                }
+#pragma unroll
+                for (int k = 0; k < KH; ++k) {
+                    const uint32_t row = rows[k];
+                    if (row == 0xFFFFFFFFu) continue;
+                    const uint32_t w   = s_words_at(base + k * TPB);
+                    const bool     sel = op_select == SPLAHIP_ALWAYS || eval_sel<T>(op_select, mk[k]);
+                    if constexpr (VXM) {
+                        r[row]         = cob_value<T, ACC>(w);
+                        touched[row] = sel ? 1u : 0u;
+                    } else if (accumulate) {
+                        if (sel) r[row] = cob_finish<T, ACC>(w, prev[k], add);
+                    } else
+                        r[row] = sel ? cob_finish<T, ACC>(w, init, add) : init;
+                }
+            }
+        } else {
+            // natural range: its rows in order, 8 per thread and step (one 16-byte load of their slots; the mask / the previous r as 16-byte loads too);
+            // KN steps' loads are requested together — a row pass is a chain of memory round trips, one per batch — and rows are stored 16 bytes at a
+            // time where all 4 of a group are written
+            auto pass = [&](auto kn_tag, auto side_tag) {
+                constexpr int  KN   = decltype(kn_tag)::value;
+                constexpr bool SIDE = decltype(side_tag)::value;// the call reads mask (op_select != ALWAYS) or r (accumulate)
+                const bool     need_mask = SIDE && op_select != SPLAHIP_ALWAYS, need_prev = SIDE && !VXM && accumulate;
+                for (uint32_t row0 = rg.row0 + threadIdx.x * 8; row0 < rg.row1; row0 += TPB * 8 * KN) {
+                    uint4 sl[KN], mk[SIDE ? KN : 1][2], pv[SIDE ? KN : 1][2];
+#pragma unroll
+                    for (int k = 0; k < KN; ++k) {
+                        const uint32_t row = row0 + k * TPB * 8;
+                        sl[k]              = row < rg.row1 ? *reinterpret_cast<const uint4*>(slot16 + row) : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                        if constexpr (SIDE) {
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const uint32_t rb = row + 4 * h;
+                                const bool     in = row < rg.row1 && rb + 4 <= n_rows;// (the last group of the matrix may be cut short: its words are read one by one)
+                                mk[k][h]          = need_mask && in ? *reinterpret_cast<const uint4*>(mask + rb) : make_uint4(0, 0, 0, 0);
+                                pv[k][h]          = need_prev && in ? *reinterpret_cast<const uint4*>(r + rb) : make_uint4(0, 0, 0, 0);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < KN; ++k) {
+                        const uint32_t row = row0 + k * TPB * 8;
+                        if (row >= rg.row1) break;
+                        const uint32_t sw[4] = {sl[k].x, sl[k].y, sl[k].z, sl[k].w};
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const uint32_t rb = row + 4 * h;
+                            if (rb >= n_rows) break;
+                            const bool     whole = rb + 4 <= n_rows;
+                            const uint32_t mw[4] = {mk[SIDE ? k : 0][h].x, mk[SIDE ? k : 0][h].y, mk[SIDE ? k : 0][h].z, mk[SIDE ? k : 0][h].w};
+                            const uint32_t pw[4] = {pv[SIDE ? k : 0][h].x, pv[SIDE ? k : 0][h].y, pv[SIDE ? k : 0][h].z, pv[SIDE ? k : 0][h].w};
+                            T              out[4];
+                            uint32_t       tch[4] = {0, 0, 0, 0};
+                            bool           wr[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const uint32_t rj = rb + j;
+                                const uint32_t sj = (sw[2 * h + (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
+                                wr[j]             = false;
+                                if (rj >= n_rows || sj == kCobSlotHub) continue;
+                                const bool     has = sj != kCobSlotEmpty;
+                                const uint32_t w   = has ? s_words_at(sj) : cob_identity<T, ACC>();
+                                bool           sel = true;
+                                if (need_mask) sel = eval_sel<T>(op_select, whole ? from_bits<T>(mw[j]) : mask[rj]);
+                                if constexpr (VXM) {// no init: an output exists where the index is selected and holds a product; its value is the fold itself
+                                    tch[j] = sel && has;
+                                    out[j] = cob_value<T, ACC>(w);
+                                    wr[j]  = true;
+                                } else if (need_prev) {
+                                    if (sel && has) {
+                                        out[j] = cob_finish<T, ACC>(w, whole ? from_bits<T>(pw[j]) : r[rj], add);
+                                        wr[j]  = true;
+                                    }
+                                } else {
+                                    // (LOR / LAND: a row without an entry keeps init itself, not its truth value — `has` covers it)
+                                    out[j] = sel && has ? cob_finish<T, ACC>(w, init, add) : init;
+                                    wr[j]  = true;
+                                }
+                            }
+                            if (wr[0] && wr[1] && wr[2] && wr[3]) {
+                                *reinterpret_cast<uint4*>(r + rb) = make_uint4(to_bits(out[0]), to_bits(out[1]), to_bits(out[2]), to_bits(out[3]));
+                                if constexpr (VXM) *reinterpret_cast<uint4*>(touched + rb) = make_uint4(tch[0], tch[1], tch[2], tch[3]);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if (wr[j]) {
+                                        r[rb + j] = out[j];
+                                        if constexpr (VXM) touched[rb + j] = tch[j];
+                                    }
+                            }
+                        }
+                    }
+                }
+            };
+            if (op_select == SPLAHIP_ALWAYS && (VXM || !accumulate)) pass(std::integral_constant<int, TIGHT ? 2 : 4>{}, std::false_type{});
+            else
+                pass(std::integral_constant<int, TIGHT ? 1 : 2>{}, std::true_type{});
+        }
+    }
+
     template<typename T, class Mult, class Add, int ACC, bool VXM, unsigned TPB, int MODE = 0>
     __global__ __launch_bounds__(TPB, (cob_min_waves<T, ACC, MODE>())) void cob_mxv_kernel(CobArgs a, const T* __restrict__ v, const T* __restrict__ mask, T* __restrict__ r, Mult mult,
                                                           Add add, int op_select, T init) {
@@ -452,21 +577,29 @@ namespace splahip {
             // loads: past this CU's L1), re-arm it and the ticket for the next call, and finish the rows from the LDS copy
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             __syncthreads();
-            uint32_t* s_w = reinterpret_cast<uint32_t*>(s_raw);
-            constexpr int KB = 8;// loads requested together (one memory round trip per batch, not per word)
-            for (uint32_t base = threadIdx.x; base < R; base += TPB * KB) {
-                uint32_t w[KB];
+            // 16 bytes per lane with the sc1 bit (agent-scope, like the atomic loads the compiler would emit one word at a time): R / 4 / TPB <= 5 loads per
+            // thread, all requested before the one wait — one memory round trip for the whole accumulator.  The re-arming stores are plain 16-byte
+            // stores: nobody reads these words again in this launch, and a launch boundary makes them visible to the next call's atomics.
+            uint4* s_w4 = reinterpret_cast<uint4*>(s_raw);
+            uint4* g4   = reinterpret_cast<uint4*>(gacc);
+            typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+            constexpr int KB = 5;
+            for (uint32_t base = threadIdx.x; base < R / 4; base += TPB * KB) {
+                u4v w[KB];
 #pragma unroll
                 for (int k = 0; k < KB; ++k) {
                     const uint32_t i = base + k * TPB;
-                    w[k]             = i < R ? __hip_atomic_load(gacc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    const uint4*   q = g4 + (i < R / 4 ? i : 0);
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w[k]) : "v"(q) : "memory");
                 }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4])::"memory");
+                const uint32_t id = cob_identity<T, ACC>();
 #pragma unroll
                 for (int k = 0; k < KB; ++k) {
                     const uint32_t i = base + k * TPB;
-                    if (i < R) {
-                        s_w[i] = w[k];
-                        __hip_atomic_store(gacc + i, cob_identity<T, ACC>(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (i < R / 4) {
+                        s_w4[i] = make_uint4(w[k].x, w[k].y, w[k].z, w[k].w);
+                        g4[i]   = make_uint4(id, id, id, id);
                     }
                 }
             }
@@ -474,96 +607,26 @@ namespace splahip {
             __syncthreads();
             merged = true;
         }
-        auto word_of = [&](uint32_t i) -> uint32_t { return merged ? s_words[i] : own_word(i); };
-        // one row's output from its slot: value and (VXM) touched flag; `has` = the row holds an entry in this copy
-        auto finish_row = [&](uint32_t row, uint32_t w, bool has, T& out, uint32_t& tch) -> bool {// returns whether r[row] is to be written
-            bool sel = true;
-            if (op_select != SPLAHIP_ALWAYS) sel = eval_sel<T>(op_select, mask[row]);
-            if constexpr (VXM) {// no init: an output exists where the index is selected and holds a product; its value is the fold itself
-                tch = sel && has;
-                out = cob_value<T, ACC>(has ? w : cob_identity<T, ACC>());
-                return true;
-            } else if (a.accumulate) {
-                if (!(sel && has)) return false;
-                out = cob_finish<T, ACC>(w, r[row], add);
-                return true;
-            } else {
-                if constexpr (ACC == COB_LOR || ACC == COB_LAND) sel = sel && has;// a row without an entry keeps init itself, not its truth value
-                out = sel && has ? cob_finish<T, ACC>(w, init, add) : init;
-                return true;
-            }
-        };
-        if (rg.hub_base != 0xFFFFFFFFu) {
-            // hub range: slot s is row hub_row[hub_base + s]; one scattered word per row (rows, then masks, requested in batches)
-            constexpr int KH = 4;
-            for (uint32_t base = threadIdx.x; base < R; base += TPB * KH) {
-                uint32_t rows[KH];
+        if constexpr (kWide) {
+            if (!merged) {// round the double slice to fp32 words in place: every thread's doubles into registers, a barrier, then the words
+                constexpr uint32_t KC = 20;
+                float              f[KC];
 #pragma unroll
-                for (int k = 0; k < KH; ++k) {
-                    const uint32_t sidx = base + k * TPB;
-                    rows[k]             = sidx < R ? a.hub_row[rg.hub_base + sidx] : 0xFFFFFFFFu;
+                for (uint32_t k = 0; k < KC; ++k) {
+                    const uint32_t i = threadIdx.x + k * TPB;
+                    f[k]             = i < R ? (float) s_acc[i] : 0.0f;
                 }
-                T    mk[KH];
-                T    prev[KH];
+                __syncthreads();
+                float* s_f = reinterpret_cast<float*>(s_raw);
 #pragma unroll
-                for (int k = 0; k < KH; ++k) {
-                    mk[k]   = rows[k] != 0xFFFFFFFFu && op_select != SPLAHIP_ALWAYS ? mask[rows[k]] : T(0);
-                    prev[k] = rows[k] != 0xFFFFFFFFu && !VXM && a.accumulate ? r[rows[k]] : init;
+                for (uint32_t k = 0; k < KC; ++k) {
+                    const uint32_t i = threadIdx.x + k * TPB;
+                    if (i < R) s_f[i] = f[k];
                 }
-#pragma unroll
-                for (int k = 0; k < KH; ++k) {
-                    const uint32_t row = rows[k];
-                    if (row == 0xFFFFFFFFu) continue;
-                    const uint32_t w   = word_of(base + k * TPB);
-                    const bool     sel = op_select == SPLAHIP_ALWAYS || eval_sel<T>(op_select, mk[k]);
-                    if constexpr (VXM) {
-                        r[row]         = cob_value<T, ACC>(w);
-                        a.touched[row] = sel ? 1u : 0u;
-                    } else if (a.accumulate) {
-                        if (sel) r[row] = cob_finish<T, ACC>(w, prev[k], add);
-                    } else
-                        r[row] = sel ? cob_finish<T, ACC>(w, init, add) : init;
-                }
-            }
-        } else {
-            // natural range: its rows in order, 8 per thread and step (one 16-byte load of their slots); 16-byte stores where all 4 rows are written
-            uint32_t row = rg.row0 + threadIdx.x * 8;
-            uint4    nx  = row < rg.row1 ? *reinterpret_cast<const uint4*>(a.slot16 + row) : make_uint4(0, 0, 0, 0);
-            for (; row < rg.row1; row += TPB * 8) {
-                const uint4 sl = nx;// the next step's slots are requested before this step's rows are finished
-                if (row + TPB * 8 < rg.row1) nx = *reinterpret_cast<const uint4*>(a.slot16 + row + TPB * 8);
-                const uint32_t sw[4] = {sl.x, sl.y, sl.z, sl.w};
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t rb = row + 4 * h;
-                    if (rb >= a.n_rows) break;
-                    T        out[4];
-                    uint32_t tch[4] = {0, 0, 0, 0};
-                    bool     wr[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t rj = rb + j;
-                        const uint32_t sj = (sw[2 * h + (j >> 1)] >> (16 * (j & 1))) & 0xFFFFu;
-                        wr[j]             = false;
-                        if (rj < a.n_rows && sj != kCobSlotHub) {
-                            const bool has = sj != kCobSlotEmpty;
-                            wr[j]          = finish_row(rj, has ? word_of(sj) : cob_identity<T, ACC>(), has, out[j], tch[j]);
-                        }
-                    }
-                    if (wr[0] && wr[1] && wr[2] && wr[3]) {
-                        *reinterpret_cast<uint4*>(r + rb) = make_uint4(to_bits(out[0]), to_bits(out[1]), to_bits(out[2]), to_bits(out[3]));
-                        if constexpr (VXM) *reinterpret_cast<uint4*>(a.touched + rb) = make_uint4(tch[0], tch[1], tch[2], tch[3]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (wr[j]) {
-                                r[rb + j] = out[j];
-                                if constexpr (VXM) a.touched[rb + j] = tch[j];
-                            }
-                    }
-                }
+                __syncthreads();
             }
         }
+        cob_row_pass<T, ACC, VXM, TPB, (cob_min_waves<T, ACC, MODE>() > 4u)>(s_words, rg, a.slot16, a.hub_row, a.touched, a.n_rows, R, a.accumulate, mask, r, add, op_select, init);
 #ifdef SPLAHIP_COB_TIMING
         if (threadIdx.x == 0 && blockIdx.x < 8192) g_cob_t[3][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif

@@ -15,6 +15,7 @@
 //         non-commutative op_add, because the run order is the reference's fold order.
 #include "block_utils.hpp"
 #include "common.hpp"
+#include "jit_hooks.hpp"
 #include "mxv_kernels.hpp"
 #include "ops.hpp"
 #include "plan.hpp"
@@ -473,7 +474,8 @@ namespace splahip {
         // every index of v stored + a sliced-ELL copy on the transposed matrix's plan: the value-form kernel in its vxm mode
         const char* sell_env = std::getenv("SPLAHIP_SELL");
         // every index of v stored + a column-ordered-blocks copy on the transposed matrix's plan: its kernel in vxm mode
-        if (v_is_identity && cob_vxm_serves(plan, TypeId<T>::value, op_add, n_in) && ((reinterpret_cast<uintptr_t>(ws_outv) | reinterpret_cast<uintptr_t>(ws_touched)) & 15u) == 0) {
+        if (v_is_identity && cob_vxm_serves(plan, TypeId<T>::value, op_add, n_in) &&
+            ((reinterpret_cast<uintptr_t>(ws_outv) | reinterpret_cast<uintptr_t>(ws_touched) | reinterpret_cast<uintptr_t>(mask)) & 15u) == 0) {
             int st = cob_vxm(plan, TypeId<T>::value, Tp, mask, d_v, ws_outv, ws_touched, op_mult, op_add, op_select, s);
             if (st != SPLAHIP_OK) return st;
         } else if (plan->sell && v_is_identity && plan->sell->n_cols == n_in && !(sell_env && sell_env[0] == '0') &&
@@ -494,6 +496,48 @@ namespace splahip {
         }
         SPLAHIP_TRY(hipGetLastError());
         // compaction of the touched columns, ascending
+        hipLaunchKernelGGL(flag_count_kernel, dim3(n_chunks), dim3(256), 0, s, ws_touched, n_out, ws_chunk);
+        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, ws_chunk, n_chunks);
+        hipLaunchKernelGGL(flag_write_kernel, dim3(n_chunks), dim3(256), 0, s, ws_touched, ws_outv, n_out, ws_chunk, ri, static_cast<uint*>(rx));
+        SPLAHIP_TRY(hipGetLastError());
+        SPLAHIP_TRY(hipMemcpyAsync(h_count, ws_chunk + n_chunks, sizeof(uint), hipMemcpyDeviceToHost, s));
+        SPLAHIP_TRY(hipStreamSynchronize(s));
+        return SPLAHIP_OK;
+    }
+
+    // jit_hooks.hpp: the pull form with the per-column fold replaced by a run-time-compiled kernel (user-defined ops, jit.hip): dense image of v + presence
+    // bitmap (+ the position of every index in v's stored order when v is not index-sorted) in the plan's workspace, then the same compaction
+    __global__ __launch_bounds__(256) void scatter_vpos_kernel(uint nvals, const uint* __restrict__ vi, uint* __restrict__ vpos) {
+        const uint idx = blockIdx.x * 256 + threadIdx.x;
+        if (idx < nvals) vpos[vi[idx]] = idx;
+    }
+    int vxm_pull_jit(splahip_plan plan, uint32_t n_out, uint32_t n_in, const uint32_t* Tp, const uint32_t* Tj, const void* Tx, const void* mask, uint32_t nvals,
+                     const uint32_t* vi, const void* vx, int sorted, uint32_t* ri, void* rx, uint32_t* h_count, hipFunction_t column, hipStream_t s) {
+        const uint   words    = (n_in + 31u) / 32u;
+        const uint   n_chunks = (n_out + 1023u) / 1024u;
+        const uint   n_in4    = (n_in + 3u) & ~3u, words4 = (words + 3u) & ~3u, n_out4 = (n_out + 3u) & ~3u;
+        const size_t need     = sizeof(uint) * (2 * (size_t) n_in4 + words4 + 2 * (size_t) n_out4 + n_chunks + 8);
+        if (plan->ws_bytes < need) {
+            if (plan->d_ws) (void) hipFree(plan->d_ws);
+            plan->d_ws = nullptr, plan->ws_bytes = 0;
+            SPLAHIP_TRY(hipMalloc(&plan->d_ws, need));
+            plan->ws_bytes = need;
+        }
+        uint* ws_dense   = static_cast<uint*>(plan->d_ws);
+        uint* ws_present = ws_dense + n_in4;
+        uint* ws_outv    = ws_present + words4;
+        uint* ws_touched = ws_outv + n_out4;
+        uint* ws_chunk   = ws_touched + n_out4;
+        uint* ws_vpos    = ws_chunk + n_chunks + 8;
+        SPLAHIP_TRY(hipMemsetAsync(ws_present, 0, sizeof(uint) * (size_t) words, s));
+        hipLaunchKernelGGL(scatter_present_kernel, dim3((nvals + 255) / 256), dim3(256), 0, s, nvals, vi, static_cast<const uint*>(vx), ws_dense, ws_present);
+        if (!sorted) hipLaunchKernelGGL(scatter_vpos_kernel, dim3((nvals + 255) / 256), dim3(256), 0, s, nvals, vi, ws_vpos);
+        SPLAHIP_TRY(hipGetLastError());
+        uint  no = n_out;
+        int   so = sorted ? 1 : 0;
+        void *pd = ws_dense, *pp = ws_present, *pq = ws_vpos, *po = ws_outv, *pt = ws_touched;
+        void* args[] = {&no, &Tp, &Tj, &Tx, &mask, &pd, &pp, &pq, &so, &po, &pt};
+        SPLAHIP_TRY(hipModuleLaunchKernel(column, (n_out + 255u) / 256u, 1, 1, 256, 1, 1, 0, s, args, nullptr));
         hipLaunchKernelGGL(flag_count_kernel, dim3(n_chunks), dim3(256), 0, s, ws_touched, n_out, ws_chunk);
         hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, ws_chunk, n_chunks);
         hipLaunchKernelGGL(flag_write_kernel, dim3(n_chunks), dim3(256), 0, s, ws_touched, ws_outv, n_out, ws_chunk, ri, static_cast<uint*>(rx));

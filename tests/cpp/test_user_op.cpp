@@ -1,6 +1,10 @@
-// A user-defined op through the C++ operator API, the way a reference user writes it (reference tests/test_op.cpp:56-59 makes the op,
-// tests/test_mxv.cpp:33-89 is the product): exec_mxv_masked with OpBinary::make_float / OpSelect::make_int ops runs ON THE DEVICE —
-// the body text is compiled at run time (spla_amd/csrc/kernels/jit.hip) — and must equal the host evaluation of the same std::function.
+// User-defined ops through the C++ operator API, the way a reference user writes them (reference tests/test_op.cpp:56-59 makes the op,
+// tests/test_mxv.cpp:33-89 / test_vxm.cpp / test_mxm.cpp / test_mxmT.cpp are the products): exec_mxv_masked, exec_vxm_masked, exec_mxm and
+// exec_mxmT_masked with OpBinary::make_float / OpSelect::make_float ops run ON THE DEVICE — the body text is compiled at run time
+// (spla_amd/csrc/kernels/jit.hip) — and must equal the host evaluation of the same std::function in the reference's fold order
+// (src/cpu/cpu_mxv.hpp:88-103, cpu_vxm.hpp:92-125, cpu_mxm.hpp:85-114, cpu_mxmT_masked.hpp:87-125).  The ops are NOT associative and their
+// products are inexact in fp32 (a * b + 1 would contract to a fused multiply-add if the device compiler were allowed to), so any other order
+// or any contraction shows.
 // Built by oracle/Makefile (target usertests) against include/spla.hpp + libspla_amd.so; run by tests/test_user_ops_gpu.py.
 #include <spla.hpp>
 
@@ -67,6 +71,134 @@ int main() {
             if (got != want) {
                 std::fprintf(stderr, "row %u early=%d: got %.9g want %.9g\n", i, early, got, want);
                 return 1;
+            }
+        }
+    }
+
+    // ---- the other three operators with the same non-associative, inexact ops (values with long mantissas: 1/3-ish steps) ----
+    {
+        auto fplus = [](float a, float b) { return 0.25f * a + 0.75f * b; };
+        auto fmult = [](float a, float b) { return a * b + 1.0f; };
+        auto fsel  = [](float a) { return a > 0.5f; };
+        const spla::uint P = 60, Q = 70, K = 50;// A: P x K, B: K x Q (mxm); Bt: Q x K (mxmT); vxm: u (P) x A (P x K)
+        std::vector<std::vector<std::pair<spla::uint, float>>> ra(P), rb(K), rbt(Q);
+        auto val = [&]() { return 0.1f + (rnd() % 97) / 29.0f; };
+        auto A2 = spla::Matrix::make(P, K, spla::FLOAT), B2 = spla::Matrix::make(K, Q, spla::FLOAT), Bt = spla::Matrix::make(Q, K, spla::FLOAT);
+        for (spla::uint i = 0; i < P; ++i)
+            for (spla::uint k = rnd() % 4; k < K; k += 1 + rnd() % 5) {
+                const float x = val();
+                ra[i].push_back({k, x});
+                A2->set_float(i, k, x);
+            }
+        for (spla::uint k = 0; k < K; ++k)
+            for (spla::uint j = rnd() % 3; j < Q; j += 1 + rnd() % 4) {
+                const float x = val();
+                rb[k].push_back({j, x});
+                B2->set_float(k, j, x);
+            }
+        for (spla::uint j = 0; j < Q; ++j)
+            for (spla::uint k = rnd() % 4; k < K; k += 1 + rnd() % 5) {
+                const float x = val();
+                rbt[j].push_back({k, x});
+                Bt->set_float(j, k, x);
+            }
+        const float init = 0.375f;
+        // mxm: R[i, j] = fold over k in A[i, :] (row order) of plus(., mult(a, b)) from init; kept iff != init
+        {
+            auto R = spla::Matrix::make(P, Q, spla::FLOAT);
+            CHECK(spla::exec_mxm(R, A2, B2, custom_mult, custom_plus, spla::Scalar::make_float(init)) == spla::Status::Ok);
+            for (spla::uint i = 0; i < P; ++i) {
+                std::vector<float> acc(Q, init);
+                for (auto& ea : ra[i])
+                    for (auto& eb : rb[ea.first]) acc[eb.first] = fplus(acc[eb.first], fmult(ea.second, eb.second));
+                for (spla::uint j = 0; j < Q; ++j) {
+                    float got = -7.0f;
+                    R->get_float(i, j, got);
+                    const float want = acc[j] != init ? acc[j] : 0.0f;// an absent entry reads as the fill value
+                    if (got != want) {
+                        std::fprintf(stderr, "mxm (%u, %u): got %.9g want %.9g\n", i, j, got, want);
+                        return 1;
+                    }
+                }
+            }
+        }
+        // mxmT_masked: for every stored mask entry (i, j, m) with select(m): merge of the sorted rows A[i, :] and Bt[j, :]
+        {
+            auto Mk = spla::Matrix::make(P, Q, spla::FLOAT);
+            std::vector<std::vector<std::pair<spla::uint, float>>> rm(P);
+            for (spla::uint i = 0; i < P; ++i)
+                for (spla::uint j = rnd() % 3; j < Q; j += 1 + rnd() % 3) {
+                    const float m = (rnd() % 4) / 4.0f + 0.125f;
+                    rm[i].push_back({j, m});
+                    Mk->set_float(i, j, m);
+                }
+            auto R = spla::Matrix::make(P, Q, spla::FLOAT);
+            CHECK(spla::exec_mxmT_masked(R, Mk, A2, Bt, custom_mult, custom_plus, custom_sel, spla::Scalar::make_float(init)) == spla::Status::Ok);
+            for (spla::uint i = 0; i < P; ++i) {
+                std::vector<float> want(Q, 0.0f);
+                for (auto& em : rm[i]) {
+                    float r0 = init;
+                    if (fsel(em.second)) {
+                        size_t ka = 0, kb = 0;
+                        const auto &a = ra[i], &b = rbt[em.first];
+                        while (ka < a.size() && kb < b.size()) {
+                            if (a[ka].first == b[kb].first) r0 = fplus(r0, fmult(a[ka].second, b[kb].second)), ++ka, ++kb;
+                            else if (a[ka].first < b[kb].first) ++ka;
+                            else ++kb;
+                        }
+                    }
+                    if (r0 != init) want[em.first] = r0;
+                }
+                for (spla::uint j = 0; j < Q; ++j) {
+                    float got = -7.0f;
+                    R->get_float(i, j, got);
+                    if (got != want[j]) {
+                        std::fprintf(stderr, "mxmT (%u, %u): got %.9g want %.9g\n", i, j, got, want[j]);
+                        return 1;
+                    }
+                }
+            }
+        }
+        // vxm: for every stored entry (i, u_i) of u in stored order, for (k, x) in A[i, :] with select(mask[k]): the first product of column k
+        // initialises, later ones fold.  Twice: u set element by element (stored index-sorted), and u built from an UNSORTED list (stored as given)
+        for (int unsorted = 0; unsorted < 2; ++unsorted) {
+            std::vector<spla::uint> ui;
+            std::vector<float>      ux;
+            for (spla::uint i = rnd() % 2; i < P; i += 1 + rnd() % 3) ui.push_back(i), ux.push_back(val());
+            auto u = spla::Vector::make(P, spla::FLOAT);
+            if (unsorted) {
+                for (size_t t = ui.size(); t > 1; --t) {
+                    const size_t o = rnd() % t;
+                    std::swap(ui[t - 1], ui[o]);
+                    std::swap(ux[t - 1], ux[o]);
+                }
+                CHECK(u->build(spla::MemView::make(ui.data(), ui.size() * sizeof(spla::uint)), spla::MemView::make(ux.data(), ux.size() * sizeof(float))) == spla::Status::Ok);
+            } else
+                for (size_t t = 0; t < ui.size(); ++t) u->set_float(ui[t], ux[t]);
+            auto               mk2 = spla::Vector::make(K, spla::FLOAT);
+            std::vector<float> hm2(K);
+            for (spla::uint k = 0; k < K; ++k) {
+                hm2[k] = (rnd() % 4) / 4.0f + 0.125f;
+                mk2->set_float(k, hm2[k]);
+            }
+            auto w = spla::Vector::make(K, spla::FLOAT);
+            CHECK(spla::exec_vxm_masked(w, mk2, u, A2, custom_mult, custom_plus, custom_sel, spla::Scalar::make_float(init)) == spla::Status::Ok);
+            std::vector<float> want(K, 0.0f);
+            std::vector<char>  has(K, 0);
+            for (size_t t = 0; t < ui.size(); ++t)
+                for (auto& e : ra[ui[t]]) {
+                    if (!fsel(hm2[e.first])) continue;
+                    const float p = fmult(ux[t], e.second);
+                    want[e.first] = has[e.first] ? fplus(want[e.first], p) : p;
+                    has[e.first]  = 1;
+                }
+            for (spla::uint k = 0; k < K; ++k) {
+                float got = -7.0f;
+                w->get_float(k, got);
+                if (got != want[k]) {
+                    std::fprintf(stderr, "vxm (unsorted=%d) column %u: got %.9g want %.9g\n", unsorted, k, got, want[k]);
+                    return 1;
+                }
             }
         }
     }
