@@ -177,6 +177,22 @@ int splahip_shard_mxv_whole(splahip_shard shard, int type, const void* d_mask, c
                             uint32_t init_bits, int early_exit, void* stream);
 int splahip_dist_mxv_masked(splahip_comm comm, splahip_shard shard, int type, const void* d_mask, const void* d_v_local, void* d_v_full, void* d_r, int op_mult,
                             int op_add, int op_select, uint32_t init_bits, int early_exit, int direct, int* overlapped, void* stream);
+/* Sparsity-aware exchange of the input vector (a BFS frontier, the distances an SSSP step changed): only the entries that differ from the vector's fill
+ * value travel — (position in the padded layout[, value]) — and land in d_v_full, which then equals what the dense all-gather would hold.  capacity = most
+ * entries one rank may contribute to one exchange; m (0 = capacity) = the bound every rank knows for THIS exchange (e.g. the frontier size the previous
+ * step counted): a rank's message is 1 + m (positions) [+ m (values)] words, so no count exchange and no host synchronisation is needed.  with_values = 0:
+ * every live entry is written as value_bits (a 0/1 frontier).  The previous exchange's positions are returned to the fill value first.  pack / buffers /
+ * scatter are the phases for a host that brings its own transport; exchange_sparse runs them around splahip_dist_all_gather.  overflowed: some rank met
+ * more entries than its bound (the exchange was incomplete — redo it dense).                                                                          */
+typedef struct splahip_sx_s* splahip_sx;
+int splahip_dist_sx_create(splahip_sx* sx, int world, int rank, uint32_t max_rows, uint32_t capacity);
+int splahip_dist_sx_destroy(splahip_sx sx);
+int splahip_dist_sx_pack(splahip_sx sx, const void* d_v_local, uint32_t n_local, uint32_t fill_bits, uint32_t m, int with_values, void* stream);
+int splahip_dist_sx_buffers(splahip_sx sx, uint32_t m, int with_values, void** d_send, void** d_recv, size_t* words_per_rank);
+int splahip_dist_sx_scatter(splahip_sx sx, void* d_v_full, uint32_t fill_bits, uint32_t m, int with_values, uint32_t value_bits, void* stream);
+int splahip_dist_sx_overflowed(splahip_sx sx, int* overflowed);
+int splahip_dist_exchange_sparse(splahip_comm comm, splahip_sx sx, const void* d_v_local, uint32_t n_local, uint32_t fill_bits, uint32_t m, int with_values,
+                                 uint32_t value_bits, void* d_v_full, int direct, void* stream);
 
 /* ---- masked vxm: r = v^T * M on the columns j with select(mask[j]) (reference cpu_vxm.hpp:92-125) ----------------
  * v is sparse: nvals (index, value) pairs IN STORED ORDER; r is index-sorted COO written to d_ri / d_rx (room for

@@ -61,6 +61,13 @@ _SIGNATURES = {
     "splahip_shard_mxv_local": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_uint32, _vp]),
     "splahip_shard_mxv_remote": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "splahip_shard_mxv_whole": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, _vp]),
+    "splahip_dist_sx_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_uint32, C.c_uint32]),
+    "splahip_dist_sx_destroy": (C.c_int, [_vp]),
+    "splahip_dist_sx_pack": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _vp]),
+    "splahip_dist_sx_buffers": (C.c_int, [_vp, C.c_uint32, C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "splahip_dist_sx_scatter": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, _vp]),
+    "splahip_dist_sx_overflowed": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "splahip_dist_exchange_sparse": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, _vp, C.c_int, _vp]),
     "splahip_dist_mxv_masked": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_int), _vp]),
     "splahip_mxv_variant_of": (C.c_char_p, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "splahip_csr_plan_destroy": (C.c_int, [_vp]),

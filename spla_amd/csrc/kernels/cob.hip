@@ -338,6 +338,18 @@ namespace {
             g->acc_armed    = true;
         }
         // a range of 16 Ki+ slots plus the spare words is over the 64 KB a kernel gets without asking (cheap; per device, so not cached in a static)
+        // a double slice of at most half a CU's LDS: two 8-wave workgroups per CU instead of one 16-wave workgroup (their zeroing, pipeline fill and row
+        // passes then run under each other's streams) — the fp32 PLUS forms only
+        if constexpr (W == 1 && MODE == 0) {
+            if (g->half_groups) {
+                constexpr unsigned kHalf = 512;
+                SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kHalf, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kHalf, MODE>), dim3(sc.n_tiles), dim3(kHalf), ((size_t) g->R + 4) * sizeof(typename CobSlice<T, ACC>::word), st, a,
+                                   static_cast<const T*>(v), static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
+                SPLAHIP_TRY(hipGetLastError());
+                return SPLAHIP_OK;
+            }
+        }
         SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), dim3(sc.n_tiles), dim3(kTpb), ((size_t) g->R + 4) * sizeof(typename CobSlice<T, ACC>::word), st, a,
                            static_cast<const T*>(v), static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
@@ -516,7 +528,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         SPLAHIP_REQUIRE(row_bits == 0 || (row_bits >= 8 && row_bits <= 14), "row_bits must be 0 or in [8, 14] (the range's result slice lives in LDS)");
         R = row_bits ? (1u << row_bits) : 20224u;
     }
-    SPLAHIP_REQUIRE(R % 256 == 0 && R >= 256 && R <= 20224, "slots per range must be a multiple of 256 in [256, 20224]");
+    SPLAHIP_REQUIRE(R % 64 == 0 && R >= 256 && R <= 20224, "slots per range must be a multiple of 64 in [256, 20224]");
     if (tile_chunks == 0) tile_chunks = env_u32("SPLAHIP_COB_TILE_CHUNKS", 0);// 0: pieces are cut at range and share boundaries only
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
@@ -534,6 +546,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     g->n_cols   = n_cols;
     g->R        = R;
     g->col_bits = col_bits;
+    g->half_groups = 2 * ((size_t) R + 4) * 8 <= 160 * 1024 && env_u32("SPLAHIP_COB_HALF_GROUPS", 1) != 0;
     hipError_t e    = hipSuccess;
     auto       bail = [&](const char* what) {
         cob_release(g);

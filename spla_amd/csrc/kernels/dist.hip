@@ -51,6 +51,21 @@ struct splahip_shard_s {
     bool         split_ok = false;// both parts carry a column-ordered-blocks copy (or are empty)
 };
 
+// Sparsity-aware exchange of the input vector (a BFS frontier, the changed distances of an SSSP step): positions (+ values) of the entries that
+// differ from the fill value travel instead of the whole slice.  Buffers of one rank's message: [count | m positions in the padded layout | m values],
+// m = the caller's bound on any rank's count for this exchange (<= capacity).  Two receive buffers alternate: the one of the previous exchange lists
+// the positions to clear.
+struct splahip_sx_s {
+    int       world = 1, rank = 0;
+    uint32_t  max_rows = 0, capacity = 0;
+    uint32_t* d_send    = nullptr;// 1 + 2 capacity words
+    uint32_t* d_recv[2] = {nullptr, nullptr};// world x (1 + 2 capacity) words each
+    uint32_t  prev_m = 0, prev_with_values = 0;
+    int       cur = 0;   // buffer the next exchange receives into
+    bool      has_prev = false;
+    uint32_t* d_overflow = nullptr;// set by pack when this rank's count exceeded m
+};
+
 namespace {
 
     // ---- RCCL, loaded at run time ---------------------------------------------------------------------------------------------------------
@@ -132,6 +147,38 @@ namespace {
             LAp[i] = l;
             RAp[i] = a - l;
         }
+    }
+
+    // ---- sparse exchange ------------------------------------------------------------------------------------------------------------------------
+    // entries of the slice that differ from `fill`: appended (order free) behind one atomic per wavefront; msg[0] = count, positions in the padded layout
+    __global__ __launch_bounds__(256) void sx_pack_kernel(uint32_t n_local, const uint32_t* __restrict__ v, uint32_t fill, uint32_t base, uint32_t m, int with_values,
+                                                          uint32_t* __restrict__ msg, uint32_t* __restrict__ overflow) {
+        const uint32_t           i    = blockIdx.x * 256 + threadIdx.x;
+        const bool               live = i < n_local && v[i] != fill;
+        const unsigned long long b    = __ballot(live);
+        if (b == 0ull) return;
+        uint32_t first = 0;
+        if (lane_id() == 0) first = atomicAdd(&msg[0], (uint32_t) __popcll(b));
+        first = __shfl(first, 0, kWave);
+        if (!live) return;
+        const uint32_t slot = first + __builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0u));
+        if (slot >= m) {
+            *overflow = 1u;// the caller's bound was too small: the exchange is incomplete and says so
+            return;
+        }
+        msg[1 + slot] = base + i;
+        if (with_values) msg[1 + m + slot] = v[i];
+    }
+    // rank p's message sits at recv + p * words: positions [0, min(count, m)) are written (`clear`: with the fill value — the previous round's)
+    __global__ __launch_bounds__(256) void sx_scatter_kernel(uint32_t world, uint32_t words, uint32_t m, const uint32_t* __restrict__ recv, int with_values, uint32_t value,
+                                                             uint32_t* __restrict__ v_full, uint32_t limit) {
+        const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+        const uint32_t p = blockIdx.y;
+        if (p >= world || k >= m) return;
+        const uint32_t* msg = recv + (size_t) p * words;
+        if (k >= min(msg[0], m)) return;
+        const uint32_t pos = msg[1 + k];
+        if (pos < limit) v_full[pos] = with_values ? msg[1 + m + k] : value;
     }
 
     void shard_release(splahip_shard_s* s) {
@@ -374,5 +421,99 @@ int splahip_dist_mxv_masked(splahip_comm c, splahip_shard s, int type, const voi
     }
     SPLAHIP_TRY(hipStreamWaitEvent(cs, c->done, 0));
     return splahip_shard_mxv_whole(s, type, d_mask, d_v_full, d_r, op_mult, op_add, op_select, init_bits, early_exit, stream);
+}
+
+// ---- sparsity-aware exchange -------------------------------------------------------------------------------------------------------------------
+int splahip_dist_sx_create(splahip_sx* out, int world, int rank, uint32_t max_rows, uint32_t capacity) {
+    SPLAHIP_REQUIRE(out != nullptr, "null argument");
+    SPLAHIP_REQUIRE(world >= 1 && rank >= 0 && rank < world, "rank / world out of range");
+    SPLAHIP_REQUIRE(capacity >= 1 && capacity <= max_rows, "capacity must be in [1, max_rows]");
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    auto* x     = new splahip_sx_s();
+    x->world    = world, x->rank = rank, x->max_rows = max_rows, x->capacity = capacity;
+    const size_t words = 1 + 2 * (size_t) capacity;
+    hipError_t   e     = device_malloc(reinterpret_cast<void**>(&x->d_send), 4 * words);
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) e = device_malloc(reinterpret_cast<void**>(&x->d_recv[b]), 4 * words * (size_t) world);
+    if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(&x->d_overflow), 4);
+    if (e == hipSuccess) e = hipMemset(x->d_overflow, 0, 4);
+    if (e != hipSuccess) {
+        (void) splahip_dist_sx_destroy(x);
+        return fail(SPLAHIP_ERROR, "sparse exchange buffers: %s", hipGetErrorString(e));
+    }
+    *out = x;
+    return SPLAHIP_OK;
+}
+int splahip_dist_sx_destroy(splahip_sx x) {
+    if (!x) return SPLAHIP_OK;
+    for (void* p : {(void*) x->d_send, (void*) x->d_recv[0], (void*) x->d_recv[1], (void*) x->d_overflow})
+        if (p) (void) hipFree(p);
+    delete x;
+    return SPLAHIP_OK;
+}
+// phase 1: this rank's message for an exchange whose per-rank count is bounded by m (0: the capacity)
+int splahip_dist_sx_pack(splahip_sx x, const void* d_v_local, uint32_t n_local, uint32_t fill_bits, uint32_t m, int with_values, void* stream) {
+    SPLAHIP_REQUIRE(x != nullptr && (d_v_local != nullptr || n_local == 0), "null argument");
+    SPLAHIP_REQUIRE(n_local <= x->max_rows, "n_local exceeds the padded slice length");
+    if (m == 0 || m > x->capacity) m = x->capacity;
+    hipStream_t s = as_stream(stream);
+    SPLAHIP_TRY(hipMemsetAsync(x->d_send, 0, 4, s));
+    if (n_local)
+        hipLaunchKernelGGL(sx_pack_kernel, dim3((n_local + 255) / 256), dim3(256), 0, s, n_local, static_cast<const uint32_t*>(d_v_local), fill_bits,
+                           x->world > 1 ? (uint32_t) x->rank * x->max_rows : 0u, m, with_values, x->d_send, x->d_overflow);
+    SPLAHIP_TRY(hipGetLastError());
+    return SPLAHIP_OK;
+}
+// the message buffers of the running exchange, for a host that brings its own transport: this rank's message (1 + (1 or 2) m words are meaningful) and
+// where rank p's message must land (d_recv + p * words_per_rank)
+int splahip_dist_sx_buffers(splahip_sx x, uint32_t m, int with_values, void** d_send, void** d_recv, size_t* words_per_rank) {
+    SPLAHIP_REQUIRE(x != nullptr, "null argument");
+    if (m == 0 || m > x->capacity) m = x->capacity;
+    if (d_send) *d_send = x->d_send;
+    if (d_recv) *d_recv = x->d_recv[x->cur];
+    if (words_per_rank) *words_per_rank = 1 + (with_values ? 2 : 1) * (size_t) m;
+    return SPLAHIP_OK;
+}
+// phase 3: the previous exchange's positions go back to the fill value, this exchange's are written (values from the messages, or `value_bits` for all)
+int splahip_dist_sx_scatter(splahip_sx x, void* d_v_full, uint32_t fill_bits, uint32_t m, int with_values, uint32_t value_bits, void* stream) {
+    SPLAHIP_REQUIRE(x != nullptr && d_v_full != nullptr, "null argument");
+    if (m == 0 || m > x->capacity) m = x->capacity;
+    hipStream_t    s     = as_stream(stream);
+    const uint32_t limit = x->world > 1 ? (uint32_t) x->world * x->max_rows : x->max_rows;
+    if (x->has_prev) {
+        const uint32_t pm = x->prev_m, pw = 1 + (x->prev_with_values ? 2 : 1) * pm;
+        hipLaunchKernelGGL(sx_scatter_kernel, dim3((pm + 255) / 256, x->world), dim3(256), 0, s, (uint32_t) x->world, pw, pm, x->d_recv[x->cur ^ 1], 0, fill_bits,
+                           static_cast<uint32_t*>(d_v_full), limit);
+    }
+    const uint32_t words = 1 + (with_values ? 2 : 1) * m;
+    hipLaunchKernelGGL(sx_scatter_kernel, dim3((m + 255) / 256, x->world), dim3(256), 0, s, (uint32_t) x->world, words, m, x->d_recv[x->cur], with_values, value_bits,
+                       static_cast<uint32_t*>(d_v_full), limit);
+    SPLAHIP_TRY(hipGetLastError());
+    x->prev_m = m, x->prev_with_values = with_values ? 1u : 0u, x->has_prev = true;
+    x->cur ^= 1;
+    return SPLAHIP_OK;
+}
+// 1 when some pack since the last query met more entries than its bound (blocking: reads one word)
+int splahip_dist_sx_overflowed(splahip_sx x, int* overflowed) {
+    SPLAHIP_REQUIRE(x != nullptr && overflowed != nullptr, "null argument");
+    uint32_t h = 0;
+    SPLAHIP_TRY(hipMemcpy(&h, x->d_overflow, 4, hipMemcpyDeviceToHost));
+    if (h) SPLAHIP_TRY(hipMemset(x->d_overflow, 0, 4));
+    *overflowed = h ? 1 : 0;
+    return SPLAHIP_OK;
+}
+// the three phases with RCCL between them, all on `stream`: d_v_full (world x max_rows words, at the fill value before the first exchange) then holds
+// what the dense all-gather of the slices would
+int splahip_dist_exchange_sparse(splahip_comm c, splahip_sx x, const void* d_v_local, uint32_t n_local, uint32_t fill_bits, uint32_t m, int with_values,
+                                 uint32_t value_bits, void* d_v_full, int direct, void* stream) {
+    SPLAHIP_REQUIRE(c != nullptr && x != nullptr, "null communicator / exchange");
+    SPLAHIP_REQUIRE(c->world == x->world && c->rank == x->rank, "communicator and exchange disagree on rank / world");
+    if (m == 0 || m > x->capacity) m = x->capacity;
+    int st = splahip_dist_sx_pack(x, d_v_local, n_local, fill_bits, m, with_values, stream);
+    if (st != SPLAHIP_OK) return st;
+    const size_t words = 1 + (with_values ? 2 : 1) * (size_t) m;
+    st                 = splahip_dist_all_gather(c, x->d_send, x->d_recv[x->cur], words, direct, stream);
+    if (st != SPLAHIP_OK) return st;
+    return splahip_dist_sx_scatter(x, d_v_full, fill_bits, m, with_values, value_bits, stream);
 }
 }

@@ -604,7 +604,6 @@ namespace splahip {
                     any_light = true;
             }
             std::stable_sort(heavy.begin(), heavy.end(), [&](uint32_t x, uint32_t y) { return hP[x] > hP[y]; });
-            const uint32_t n_heavy = (uint32_t) heavy.size();
 
             // ---- light rows through the ESC form -------------------------------------------------------------------------------------------------
             uint32_t *Lrp = nullptr, *Lrj = nullptr, *Lrx = nullptr, l_nnz = 0;
@@ -729,12 +728,9 @@ namespace splahip {
                       blk_sym, d_bblk, blk_num, nb_num, d_cursor, max_deg, d_counts, nullptr, nullptr, d_dropped, dense_h, dC, dN};
             const T init = from_bits<T>(init_bits);
             if (n_items) {
-                static bool raised = false;
-                if (!raised) {
-                    SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxm_spa_kernel<T, Mult, ACC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-                    SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxm_spa_kernel<T, Mult, ACC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-                    raised = true;
-                }
+                // (a per-device setting and cheap: set on every call rather than remembered in a process-wide flag)
+                SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxm_spa_kernel<T, Mult, ACC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxm_spa_kernel<T, Mult, ACC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
                 hipLaunchKernelGGL((mxm_spa_kernel<T, Mult, ACC, false>), dim3(grid_sym), dim3(kTpb), lds_sym, s, a, Mult(op_mult), DynBin(op_add), init);
                 SPLAHIP_TRY(hipGetLastError());
                 spa_trace("symbolic pass", s);
@@ -770,6 +766,16 @@ namespace splahip {
                 if (oj) (void) handoff_release(oj);
                 return fail(SPLAHIP_ERROR, "mxm result allocation: %s", hipGetErrorString(e));
             }
+            struct ResultGuard {// the result arrays go back to the hand-off cache on every early return below; disarmed when they are handed to the caller
+                uint32_t **j, **x;
+                bool       armed = true;
+                ~ResultGuard() {
+                    if (armed) {
+                        if (*j) (void) handoff_release(*j);
+                        if (*x) (void) handoff_release(*x);
+                    }
+                }
+            } result_guard{&oj, &ox};
             spa_trace("result allocation", s);
             if (Lrp && l_nnz) hipLaunchKernelGGL(place_light_kernel, dim3((a_rows + 255) / 256), dim3(256), 0, s, a_rows, Lrp, Lrj, Lrx, Rp, oj, ox);
             if (n_items) {
@@ -812,11 +818,7 @@ namespace splahip {
                     hipLaunchKernelGGL((mxm_spa_kernel<T, Mult, ACC, true>), dim3(std::min(n, grid_num)), dim3(kTpb), lds_num, s, a, Mult(op_mult), DynBin(op_add), init);
                 }
                 if (const uint32_t n = (uint32_t) rk[0].size()) {
-                    static bool raised_r = false;
-                    if (!raised_r) {
-                        SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxm_spa_ranked_kernel<T, Mult, ACC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-                        raised_r = true;
-                    }
+                    SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxm_spa_ranked_kernel<T, Mult, ACC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
                     const uint32_t lds_r = cap * (uint32_t) sizeof(word) + 2 * (wr / 8) + sizeof(uint32_t) * (3 * kTpb + 1 + kTpb / 64 + 4);
                     a.item_row = d_rk, a.item_c0 = d_rk + n, a.item_c1 = d_rk + 2 * (size_t) n, a.item_out = d_rk + 3 * (size_t) n, a.n_heavy = n;
                     hipLaunchKernelGGL((mxm_spa_ranked_kernel<T, Mult, ACC>), dim3(std::min(n, (uint32_t) cus)), dim3(kTpb), lds_r, s, a, cap, wr, Mult(op_mult), DynBin(op_add), init);
@@ -851,12 +853,9 @@ namespace splahip {
                     oj = nj, ox = nx, total -= dropped;
                 }
             }
-            if (e != hipSuccess) {
-                (void) handoff_release(oj);
-                (void) handoff_release(ox);
-                return fail(SPLAHIP_ERROR, "mxm (row classes): %s", hipGetErrorString(e));
-            }
+            if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm (row classes): %s", hipGetErrorString(e));// (result_guard releases oj / ox)
             spa_trace("compaction / done", s);
+            result_guard.armed = false;
             *Rj = oj, *Rx = ox, *h_nnz = (uint32_t) total;
             tl_last_dense_h = dense_h, tl_last_heavy = n_items, tl_last_light_nnz = l_nnz;
             return SPLAHIP_OK;

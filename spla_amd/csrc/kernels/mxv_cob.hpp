@@ -609,7 +609,7 @@ namespace splahip {
         }
         if constexpr (kWide) {
             if (!merged) {// round the double slice to fp32 words in place: every thread's doubles into registers, a barrier, then the words
-                constexpr uint32_t KC = 20;
+                constexpr uint32_t KC = TPB >= 1024 ? 20 : 24;// (R <= 20224 with 1024 threads; R <= 10112 + with 512: 24 x 512 covers 12288)
                 float              f[KC];
 #pragma unroll
                 for (uint32_t k = 0; k < KC; ++k) {

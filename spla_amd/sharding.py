@@ -148,6 +148,123 @@ class SparseExchange:
         return self.v_full
 
 
+class SparseExchangeABI:
+    """The sparsity-aware exchange behind the kernel-level C ABI (splahip_dist_sx_* / splahip_dist_exchange_sparse, dist.hip): a rank's message is
+    [count | m positions in the padded layout | m values], m = a bound every rank knows for this exchange; the receivers return the previous exchange's
+    positions to the fill value and write the new ones.  Same contract as SparseExchange (v_full[:n_cols_padded] equals the dense all-gather).
+      * device tensors + a DistComm: one C-ABI call (pack, RCCL all-gather, scatter on the caller's stream);
+      * device tensors without a communicator (gloo debug run, ranks sharing a GPU): the C ABI's pack / scatter kernels around a host-staged
+        torch.distributed all-gather of the messages;
+      * CPU tensors (the gloo tests of this container, which has no GPU): `_pack_host` / `_scatter_host` below mirror the two kernels word for word
+        on numpy-style torch ops, so the message layout, the bound and the clearing of the previous round are what the tests exercise."""
+
+    def __init__(self, blk: RowBlock, dtype, device, fill=0, capacity: int = None, comm: "DistComm" = None):
+        self.blk, self.fill, self.comm = blk, fill, comm
+        self.max_rows = blk.max_rows if blk.world > 1 else blk.n
+        self.capacity = int(min(capacity or self.max_rows, self.max_rows))
+        self.v_full = torch.full((blk.n_cols_padded,), fill, dtype=dtype, device=device)
+        self.on_device = torch.device(device).type == "cuda"
+        self.last_words = 0
+        self._prev = None  # host mirror: (recv messages, m, with_values) of the previous exchange
+        self._h = None
+        if self.on_device:
+            import ctypes as C
+            from . import _lib
+            self._h = C.c_void_p()
+            _lib.call("splahip_dist_sx_create", C.byref(self._h), blk.world, blk.rank, self.max_rows, self.capacity)
+
+    @staticmethod
+    def _bits(x, dtype):
+        return int(torch.tensor([x], dtype=dtype).view(torch.int32)[0]) & 0xFFFFFFFF
+
+    # ---- host mirror of sx_pack_kernel / sx_scatter_kernel (CPU tensors) ----
+    def _pack_host(self, x_local, m, with_values):
+        words = 1 + (2 if with_values else 1) * m
+        msg = torch.zeros(words, dtype=torch.int32)
+        idx = torch.nonzero(x_local != self.fill).squeeze(1)
+        msg[0] = int(idx.numel())
+        k = min(int(idx.numel()), m)  # entries beyond the bound are dropped and reported (overflow)
+        self.overflow = self.overflow or int(idx.numel()) > m
+        base = self.blk.rank * self.max_rows if self.blk.world > 1 else 0
+        msg[1:1 + k] = (idx[:k] + base).to(torch.int32)
+        if with_values:
+            msg[1 + m:1 + m + k] = x_local[idx[:k]].view(torch.int32) if x_local.dtype != torch.int32 else x_local[idx[:k]]
+        return msg
+
+    def _scatter_host(self, recv, m, layout_values, write_values, value_i32):
+        """rank p's message = recv[p * words:(p + 1) * words]; its first min(count, m) positions are written: with the message's values (write_values)
+        or with the one word value_i32 (a value-less exchange; the clearing of the previous round)"""
+        words = 1 + (2 if layout_values else 1) * m
+        vf = self.v_full.view(torch.int32) if self.v_full.dtype != torch.int32 else self.v_full
+        for p in range(self.blk.world):
+            msg = recv[p * words:(p + 1) * words]
+            k = min(int(msg[0]), m)
+            pos = msg[1:1 + k].to(torch.int64)
+            vf[pos] = msg[1 + m:1 + m + k] if write_values else torch.full((k,), value_i32, dtype=torch.int32)
+
+    def exchange(self, x_local: torch.Tensor, value=None, upper_bound: int = None, direct=False) -> torch.Tensor:
+        blk = self.blk
+        m = int(min(upper_bound or self.capacity, self.capacity))
+        with_values = value is None
+        words = 1 + (2 if with_values else 1) * m
+        self.last_words = words
+        fill_bits = self._bits(self.fill, self.v_full.dtype)
+        value_bits = 0 if with_values else self._bits(value, self.v_full.dtype)
+        if not self.on_device:
+            self.overflow = getattr(self, "overflow", False)
+            send = self._pack_host(x_local, m, with_values)
+            recv = torch.empty(blk.world * words, dtype=torch.int32)
+            if blk.world > 1:
+                dist.all_gather_into_tensor(recv, send)
+            else:
+                recv.copy_(send)
+            i32 = lambda b: b if b < 2 ** 31 else b - 2 ** 32
+            if self._prev is not None:
+                pr, pm, pw = self._prev
+                self._scatter_host(pr, pm, pw, False, i32(fill_bits))
+            self._scatter_host(recv, m, with_values, with_values, i32(value_bits))
+            self._prev = (recv, m, with_values)
+            return self.v_full
+        import ctypes as C
+        from . import _lib
+        from .kernels import _ptr, current_stream_ptr
+        if self.comm is not None and blk.world > 1:
+            _lib.call("splahip_dist_exchange_sparse", self.comm._h, self._h, _ptr(x_local), int(x_local.numel()), fill_bits, m, 1 if with_values else 0, value_bits,
+                      _ptr(self.v_full), 1 if direct else 0, current_stream_ptr())
+            return self.v_full
+        _lib.call("splahip_dist_sx_pack", self._h, _ptr(x_local), int(x_local.numel()), fill_bits, m, 1 if with_values else 0, current_stream_ptr())
+        ps, pr, w = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        _lib.call("splahip_dist_sx_buffers", self._h, m, 1 if with_values else 0, C.byref(ps), C.byref(pr), C.byref(w))
+        assert w.value == words
+        if blk.world > 1:  # host-staged transport between the C-ABI phases (ranks sharing one GPU under the gloo debug backend)
+            torch.cuda.synchronize()
+            send = torch.empty(words, dtype=torch.int32)
+            _lib.call("splahip_memcpy_d2h", send.data_ptr(), ps, 4 * words, None)
+            recv = torch.empty(blk.world * words, dtype=torch.int32)
+            dist.all_gather_into_tensor(recv, send)
+            _lib.call("splahip_memcpy_h2d", pr, recv.data_ptr(), 4 * words * blk.world, None)
+        else:
+            _lib.call("splahip_memcpy_d2d", pr, ps, 4 * words, current_stream_ptr())
+        _lib.call("splahip_dist_sx_scatter", self._h, _ptr(self.v_full), fill_bits, m, 1 if with_values else 0, value_bits, current_stream_ptr())
+        return self.v_full
+
+    def overflowed(self) -> bool:
+        if not self.on_device:
+            o, self.overflow = getattr(self, "overflow", False), False
+            return o
+        import ctypes as C
+        from . import _lib
+        f = C.c_int()
+        _lib.call("splahip_dist_sx_overflowed", self._h, C.byref(f))
+        return bool(f.value)
+
+    def close(self):
+        if self._h:
+            from . import _lib
+            _lib.call("splahip_dist_sx_destroy", self._h)
+            self._h = None
+
+
 # ---- the product behind the kernel-level C ABI (spla_amd/csrc/kernels/dist.hip) ------------------------------------------------------------
 def split_columns(blk: RowBlock):
     """Torch mirror of splahip_shard_create's column split (CPU tests): the row block cut by column OWNER into the local part

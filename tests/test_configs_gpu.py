@@ -475,5 +475,6 @@ def test_cfg3_full_size_pagerank_pull_column_ordered_blocks(oracle):
     want = _sampled_rows_oracle(oracle, "FLOAT", Tp, Tj, Tx, rows_idx, n, mask, vx, "MULT", "PLUS", "ALWAYS", 0.0)  # x * v == v * x in fp32
     exact = _fp64_fold(Tp, Tj, Tx, vx)
     assert float(((dense.to(torch.float64) - exact).abs() / exact.abs().clamp_min(1e-30)).max()) < 2e-6
-    _assert_fp32_sum_parity(dense[rows_idx].cpu().numpy(), want, exact[rows_idx].cpu().numpy())
+    # (PageRank products are tiny and of mixed magnitude: the reference's sequential fold strays from the sum on many more rows than with U(0, 1) values)
+    _assert_fp32_sum_parity(dense[rows_idx].cpu().numpy(), want, exact[rows_idx].cpu().numpy(), min_plain=0.5)
     plan_T.close()

@@ -120,3 +120,73 @@ def test_rccl_communicator_world1_and_dist_product(oracle):
     np.testing.assert_array_equal(r.cpu().numpy(), want)
     s.close()
     comm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 3])
+def test_sparse_exchange_c_abi_simulated_ranks(world):
+    """splahip_dist_sx_pack / _buffers / _scatter (dist.hip): the sparsity-aware exchange of the input vector, driven rank by rank on one GPU — every
+    simulated rank packs its slice, the messages are copied into every rank's receive buffer (what the RCCL all-gather of splahip_dist_exchange_sparse
+    does), every rank scatters; each rank's v_full must equal the dense all-gather of the slices, over several rounds (the previous round's positions are
+    cleared), with and without values, with a caller-supplied bound, and an overflow must be reported."""
+    import ctypes as C
+    from spla_amd import _lib, sharding
+    n, Ap, Aj = _graph(12)
+    bounds = sharding.row_splits(Ap, world)
+    blks = [sharding.RowBlock(Ap, Aj, None, bounds, p) for p in range(world)]
+    for fill, const in ((0, 1), (7, None)):
+        sxs = [sharding.SparseExchangeABI(b, torch.int32, "cuda", fill=fill) for b in blks]
+        for rnd in range(5):
+            gg = torch.Generator().manual_seed(500 + rnd)
+            x = torch.full((n,), fill, dtype=torch.int32)
+            k = [n // 40, n // 5, 0, 5, n // 11][rnd]
+            pos = torch.randperm(n, generator=gg)[:k]
+            x[pos] = 1 if const is not None else torch.randint(8, 99, (k,), generator=gg, dtype=torch.int32)
+            xd = x.cuda()
+            with_values = const is None
+            m = sxs[0].capacity if rnd % 2 == 0 else max(1, min(k, sxs[0].capacity))
+            words = 1 + (2 if with_values else 1) * m
+            fill_bits = fill
+            sends, recvs = [], []
+            for p, (b, sx) in enumerate(zip(blks, sxs)):
+                xl = xd[b.lo:b.hi].contiguous()
+                _lib.call("splahip_dist_sx_pack", sx._h, xl.data_ptr(), int(xl.numel()), fill_bits, m, 1 if with_values else 0, None)
+                ps, pr, w = C.c_void_p(), C.c_void_p(), C.c_size_t()
+                _lib.call("splahip_dist_sx_buffers", sx._h, m, 1 if with_values else 0, C.byref(ps), C.byref(pr), C.byref(w))
+                assert w.value == words
+                sends.append(ps.value), recvs.append(pr.value)
+            torch.cuda.synchronize()
+            for pr in recvs:  # the all-gather: rank q's message lands at word q * words of every rank's receive buffer
+                for q, ps in enumerate(sends):
+                    _lib.call("splahip_memcpy_d2d", pr + 4 * words * q, ps, 4 * words, None)
+            want = torch.full((blks[0].n_cols_padded,), fill, dtype=torch.int32, device="cuda")
+            for q, b in enumerate(blks):
+                base = q * b.max_rows if world > 1 else 0
+                want[base:base + b.n_local] = xd[b.lo:b.hi]
+            for sx in sxs:
+                _lib.call("splahip_dist_sx_scatter", sx._h, sx.v_full.data_ptr(), fill_bits, m, 1 if with_values else 0, 0 if with_values else const, None)
+                torch.cuda.synchronize()
+                assert torch.equal(sx.v_full, want), (world, fill, rnd)
+                assert not sx.overflowed()
+        # a bound smaller than a rank's count: reported
+        x = torch.full((n,), fill, dtype=torch.int32, device="cuda")
+        x[::3] = 1 if const is not None else 55
+        b, sx = blks[0], sxs[0]
+        xl = x[b.lo:b.hi].contiguous()
+        _lib.call("splahip_dist_sx_pack", sx._h, xl.data_ptr(), int(xl.numel()), fill, 2, 0 if const is not None else 1, None)
+        torch.cuda.synchronize()
+        assert sx.overflowed()
+        for sx in sxs:
+            sx.close()
+    # the whole exchange through RCCL at world size 1 (one GPU): splahip_dist_exchange_sparse
+    if world == 1 and _lib.call("splahip_dist_available"):
+        comm = sharding.DistComm(1, 0)
+        sx = sharding.SparseExchangeABI(blks[0], torch.float32, "cuda", fill=float("inf"), comm=comm)
+        for rnd in range(3):
+            x = torch.full((n,), float("inf"), dtype=torch.float32, device="cuda")
+            x[torch.randperm(n, generator=torch.Generator().manual_seed(rnd))[: n // (3 + rnd)].cuda()] = float(rnd) + 0.5
+            got = sx.exchange(x)
+            torch.cuda.synchronize()
+            assert torch.equal(got, x)
+        sx.close()
+        comm.close()

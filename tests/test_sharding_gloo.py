@@ -62,6 +62,27 @@ def _worker(rank, world, port, out_dir):
             assert torch.equal(got[:blk.n_cols_padded], want), (fill, rnd)
             assert torch.equal(got[:blk.n_cols_padded][blk.Aj.to(torch.int64)], x[blk.Aj_global.to(torch.int64)])
             assert sx.last_count == (None if rnd % 2 else k)
+    # the same exchange in the C ABI's protocol (splahip_dist_exchange_sparse: a message = [count | m positions | m values], m = a bound every rank
+    # knows; two receive buffers alternate, the older one lists what to clear).  On CPU tensors SparseExchangeABI runs the word-for-word host mirror
+    # of the pack / scatter kernels (this container has no GPU; tests/test_shard_gpu.py drives the kernels themselves), over the gloo all-gather
+    for fill, const in ((0, 1), (7, None)):
+        sa = sharding.SparseExchangeABI(blk, torch.int32, "cpu", fill=fill, capacity=max(1, blk.max_rows if world > 1 else n))
+        for rnd in range(5):
+            gg = torch.Generator().manual_seed(300 + rnd)
+            x = torch.full((n,), fill, dtype=torch.int32)
+            k = [n // 50, n // 7, 0, 3, n // 9][rnd]
+            pos = torch.randperm(n, generator=gg)[:k]
+            x[pos] = 1 if const is not None else torch.randint(8, 99, (k,), generator=gg, dtype=torch.int32)
+            got = sa.exchange(x[blk.lo:blk.hi], value=const, upper_bound=(max(k, 1) if rnd % 2 else None))
+            want = blk.all_gather(blk.pad_local(x[blk.lo:blk.hi], fill=fill))
+            assert torch.equal(got, want), ("abi protocol", fill, rnd)
+            assert not sa.overflowed()
+            assert sa.last_words == 1 + (1 if const is not None else 2) * (min(max(k, 1), sa.capacity) if rnd % 2 else sa.capacity)
+        # a bound that is too small is reported, not silently wrong
+        x = torch.full((n,), fill, dtype=torch.int32)
+        x[:: 3] = 1 if const is not None else 55
+        sa.exchange(x[blk.lo:blk.hi], value=const, upper_bound=2)
+        assert sa.overflowed()
     # the two-part (overlappable) form of the product: the block cut by column owner; the local part needs only this rank's slice of v,
     # the remote part folds onto its result once the exchange has landed (splahip_shard_mxv_local / _remote, dist.hip).  BASELINE configs[3]:
     # min-plus int32, init = INF = 2^30, weights 1..255; and plus-times / or-and for the other monoid families
