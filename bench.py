@@ -285,15 +285,25 @@ def bfs_step_line(args, rank, world):
     if world == 1:
         v_full.copy_(front)
 
-    # the exchange step (N > 1): dense all-gather of the padded slices, or — when the frontier is sparse — the sparsity-aware form (positions only; every step does the full exchange of a fresh vector:
-    # local compaction, count exchange, position all-gather, clear + scatter).  SPLA_EXCHANGE=dense|sparse overrides the rule;
-    # the rule depends on global quantities only, so every rank picks the same form.
+    # the exchange step (N > 1): dense all-gather of the padded slices, or — when the frontier is sparse — the sparsity-aware form behind the C ABI
+    # (splahip_dist_exchange_sparse, dist.hip: positions only, bounded messages, no count exchange; sharding.SparseExchangeABI — over RCCL, or with a
+    # host-staged transport between its pack / scatter kernels under the gloo debug backend).  SPLA_EXCHANGE=dense|sparse|torch-sparse|abi overrides the rule
+    # (torch-sparse: round 1's chain of torch ops); the rule depends on global quantities only, so every rank picks the same form.
     mode = os.environ.get("SPLA_EXCHANGE", "auto")
-    sparse = world > 1 and (mode == "sparse" or (mode == "auto" and front_total * 16 < g["n"]))
+    sparse = world > 1 and (mode in ("sparse", "torch-sparse") or (mode == "auto" and front_total * 16 < g["n"]))
     sx = None
+    sx_comm = None
     if sparse:
         from spla_amd import sharding
-        sx = sharding.SparseExchange(sh.blk, torch.int32, "cuda", fill=0)
+        if mode == "torch-sparse":
+            sx = sharding.SparseExchange(sh.blk, torch.int32, "cuda", fill=0)
+        else:
+            if dist.get_backend() == "nccl":
+                try:
+                    sx_comm = sharding.DistComm(world, rank)
+                except Exception as exc:  # the host-staged transport stays available
+                    log(f"[bench] splahip_dist_comm_create failed ({exc}); sparse exchange staged through torch.distributed")
+            sx = sharding.SparseExchangeABI(sh.blk, torch.int32, "cuda", fill=0, comm=sx_comm)
         # the bound every rank pads its position list to: the largest per-rank frontier count — in a real traversal the previous level's
         # count reduction delivers it (a MAX beside the SUM); padding to the global count would send world x the bytes
         fmax = torch.tensor([int((depth == L).sum())], device=coll_device(), dtype=torch.int64)
@@ -412,13 +422,15 @@ def bfs_step_line(args, rank, world):
         _, per_x = timed(exchange, args.steps, 2)
         x_ms = float(np.mean(per_x))
         # what this rank receives from EACH peer (direct all-gather over the xGMI mesh): a padded dense slice, or the longest position list
-        slice_bytes = 4 * sh.max_rows if not sparse else 4 * int(sx.prev.numel() // world)
+        slice_bytes = 4 * sh.max_rows if not sparse else (4 * int(sx.prev.numel() // world) if mode == "torch-sparse" else 4 * int(sx.last_words))
         xm = torch.tensor([x_ms], device=coll_device(), dtype=torch.float64)
         dist.all_reduce(xm, op=dist.ReduceOp.MAX)
         if abi is not None:
             out["exchange_abi"] = bench_dist.phase_report(abi, mask, front, r, max(5, args.steps // 2), world)
         out["exchange"] = {"mode": "C ABI: splahip_dist_mxv_masked (RCCL all-gather on its own stream || local-column part)" if abi is not None else
-                           "sparse (positions of the non-fill entries)" if sparse else "dense (padded slices)",
+                           ("sparse, torch ops (positions of the non-fill entries)" if mode == "torch-sparse" else
+                            "C ABI: splahip_dist_exchange_sparse (pack kernel, RCCL all-gather of bounded position messages, scatter kernel)" if sx_comm is not None else
+                            "C ABI: splahip_dist_sx_pack / _scatter kernels around a host-staged torch.distributed all-gather (debug backend)") if sparse else "dense (padded slices)",
                            "collective": "all_gather_into_tensor (%s)" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " debug backend"), "avg_us": round(x_ms * 1e3, 2), "max_over_ranks_us": round(float(xm[0]) * 1e3, 2),
                            "bytes_per_peer": slice_bytes, "bytes_received_per_rank": slice_bytes * (world - 1),
                            "gbs_per_link_if_direct": round(slice_bytes / (x_ms * 1e-3) / 1e9, 2),

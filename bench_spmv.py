@@ -219,7 +219,8 @@ def run(args, rank, world):
            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"exec_mxv_masked fp32 MULT/PLUS over all rows (op_select ALWAYS, init 0), values and v uniform in [0, 1): R-MAT scale {scale} (ef {args.edge_factor}, {label} labels) "
                                   f"— the north-star ~100 M-nnz scale-free CSR", "n": n, "nnz": nnz, "nnz_selected": nnz, "rows_selected": n,
-                      "parallelism": "1 GPU", "layout": info, "layout_build_ms": round(attach_ms, 1)},
+                      "parallelism": "1 GPU", "layout": info, "layout_build_ms": round(attach_ms, 1),
+                      "device_bytes": {"csr": 8 * nnz + 4 * (n + 1), **plan.footprint()}},
            "roofline": roof}
     step()
     torch.cuda.synchronize()
@@ -356,4 +357,13 @@ def _run_sharded(args, rank, world, scale, label, n, nnz, Ap, Aj, Ax, v):
     if sp.fallback:
         line["exchange"]["fallback"] = sp.fallback
     sp.close()
+    del sp, blk, r, mask, v_loc
+    torch.cuda.empty_cache()
+    if not args.no_variants:  # BASELINE configs[3] in the same command: the STRONG split of the min-plus SSSP step on R-MAT scale 24 over the same dist layer
+        import copy
+        b = copy.copy(args)
+        b.scale = 22 if not getattr(args, "scale_given", False) else args.scale + 1  # (bench_dist maps 22 to configs[3]'s own scale, 24; a reduced debug run scales it down too)
+        v = bench_dist.sssp_step_sharded(b, rank, world)
+        v["name"] = "SSSP step (BASELINE configs[3]): min-plus int32 on R-MAT scale 24, strong 1-D row split, all-gather of the distance vector per step"
+        line["variants"] = [v]
     return line

@@ -103,6 +103,11 @@ int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, const uint32
                                 uint32_t tile_chunks, void* stream);
 int splahip_csr_plan_cob_info(splahip_plan plan, uint32_t* n_tiles, uint32_t* n_chunks, uint32_t* n_multi, uint32_t* slots_per_range);
 int splahip_csr_plan_cob_layout(splahip_plan plan, uint32_t* n_ranges, uint32_t* n_hub_ranges, uint32_t* n_hub_rows, uint64_t* bytes);
+/* footprint: device bytes held for the matrix besides its CSR arrays — plan (work items + call workspace), sliced-ELL copy, column-ordered blocks (0: not built).
+ * prefers_sell: 1 when splahip_mxv_masked runs this semiring on the sliced-ELL copy even beside the column-ordered blocks (the zero-family sparse-vector
+ * forms, a BFS step): a host that builds copies on demand needs the +12 B per entry of the sliced-ELL copy only for these.                          */
+int splahip_csr_plan_footprint(splahip_plan plan, uint64_t* plan_bytes, uint64_t* sell_bytes, uint64_t* cob_bytes);
+int splahip_mxv_prefers_sell(int type, int op_mult, int op_add);
 int splahip_csr_plan_destroy(splahip_plan plan);
 /* n_items: work items; n_long: rows cut into segment items */
 int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_items, uint32_t* n_long);

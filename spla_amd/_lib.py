@@ -44,6 +44,8 @@ _SIGNATURES = {
     "splahip_csr_plan_sell_values": (C.c_int, [_vp, C.POINTER(C.c_int), _u32p]),
     "splahip_csr_plan_attach_cob": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp]),
     "splahip_csr_plan_cob_info": (C.c_int, [_vp, _u32p, _u32p, _u32p, _u32p]),
+    "splahip_csr_plan_footprint": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "splahip_mxv_prefers_sell": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "splahip_csr_plan_cob_layout": (C.c_int, [_vp, _u32p, _u32p, _u32p, C.POINTER(C.c_uint64)]),
     "splahip_jit_available": (C.c_int, []),
     "splahip_mxv_masked_jit": (C.c_int, [C.c_int, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p,
@@ -101,7 +103,7 @@ _SIGNATURES = {
     "splahip_m_transpose": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "splahip_map": (C.c_int, [C.c_int, C.c_uint32, _vp, _vp, C.c_int, _vp]),
 }
-_RAW = {"splahip_device_count", "splahip_last_error", "splahip_version", "splahip_mxv_variant", "splahip_mxv_variant_of", "splahip_dist_available",
+_RAW = {"splahip_mxv_prefers_sell", "splahip_device_count", "splahip_last_error", "splahip_version", "splahip_mxv_variant", "splahip_mxv_variant_of", "splahip_dist_available",
         "splahip_shard_split_serves", "splahip_jit_available"}
 
 _lib = None

@@ -38,20 +38,23 @@ namespace spla {
             const char* e = std::getenv(name);
             return e ? static_cast<unsigned>(std::strtoul(e, nullptr, 10)) : dflt;
         }
-        // A matrix that keeps being multiplied gets its layout copies — rent or buy.  The column-ordered-blocks copy (+8 B per entry, ~5 ms per
-        // 65 M entries: what about thirty SpMV calls save) is built when the second call arrives: SPLA_HIP_COB_AFTER=<calls> (0 = never).  The
-        // sliced-ELL copy (+12 B per entry, tens of ms) once 256 calls have been served: SPLA_HIP_SELL_AFTER.  Matrix::set_format(AccCsr) builds both
-        // at once (storage.hpp).  A copy that cannot be built is not an error: the CSR kernels stay in use.
+        // A matrix that keeps being multiplied gets its layout copies — rent or buy.  The column-ordered-blocks copy (+8 B per entry + 2 B per row, ~10 ms
+        // per 65 M entries: what a few dozen SpMV calls save) is built when the second call arrives: SPLA_HIP_COB_AFTER=<calls> (0 = never).  The
+        // sliced-ELL copy (+12 B per entry, tens of ms) serves only the calls the blocks do not take from it — the zero-family sparse-vector forms, a BFS
+        // step (splahip_mxv_prefers_sell) — so only THOSE calls count towards it: once 256 of them have been served (SPLA_HIP_SELL_AFTER), or at the first
+        // one for a matrix prepared with Matrix::set_format(AccCsr) (which builds the blocks at once, storage.hpp).  A matrix that never sees such a call
+        // keeps 16 B per entry on the device (CSR 8 + blocks 8) instead of 28.  A copy that cannot be built is not an error: the CSR kernels stay in use.
         template<typename T>
-        void maybe_build_copies(HipCsr<T>* a, uint n_rows, uint n_cols) {
+        void maybe_build_copies(HipCsr<T>* a, uint n_rows, uint n_cols, bool wants_sell = false) {
             ++a->mxv_calls;
+            if (wants_sell) ++a->sell_calls;
             const unsigned cob_after = env_calls("SPLA_HIP_COB_AFTER", 2u), sell_after = env_calls("SPLA_HIP_SELL_AFTER", 256u);
             if (!a->cob_tried && cob_after != 0 && (a->prepared || a->mxv_calls >= cob_after)) {
                 a->cob_tried = true;
                 if (splahip_csr_plan_attach_cob(a->plan, n_cols, a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(), cob_row_bits<T>(n_rows), 0, nullptr) != SPLAHIP_OK)
                     SPLA_LOG(Status::Error, "column-ordered-blocks copy not built (" << splahip_last_error() << "); the CSR kernels stay in use");
             }
-            if (!a->sell_tried && sell_after != 0 && (a->prepared || a->mxv_calls >= sell_after)) {
+            if (!a->sell_tried && sell_after != 0 && wants_sell && (a->prepared || a->sell_calls >= sell_after)) {
                 a->sell_tried = true;
                 if (splahip_csr_plan_attach_sell(a->plan, n_cols, a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(), nullptr) != SPLAHIP_OK)
                     SPLA_LOG(Status::Error, "sliced-ELL copy not built (" << splahip_last_error() << "); the CSR kernels stay in use");
@@ -134,7 +137,7 @@ namespace spla {
                 auto* a = M->acc_csr();
                 ensure_plan(a, M->get_n_rows());
                 const bool early = t->get_desc_or_default()->get_early_exit();
-                if (!early && a->values > 0) maybe_build_copies(a, M->get_n_rows(), M->get_n_cols());
+                if (!early && a->values > 0) maybe_build_copies(a, M->get_n_rows(), M->get_n_cols(), splahip_mxv_prefers_sell(TypeTraits<T>::id, op_mult, op_add) != 0);
                 hip_check(splahip_mxv_masked(a->plan, TypeTraits<T>::id, M->get_n_rows(), M->get_n_cols(),
                                              a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(),
                                              mask->acc_dense()->Ax.ptr(), v->acc_dense()->Ax.ptr(), r->acc_dense()->Ax.ptr(),

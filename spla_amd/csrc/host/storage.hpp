@@ -152,6 +152,7 @@ namespace spla {
         unsigned     mxv_calls = 0;    // mxv / pull-vxm calls without early exit served by this plan (algos_hip.cpp: when the copies of the matrix get built)
         bool         cob_tried = false;// the column-ordered-blocks copy has been asked for (it may have been declined: hypersparse matrix)
         bool         sell_tried = false;
+        unsigned     sell_calls = 0;// products that would run on the sliced-ELL copy (splahip_mxv_prefers_sell)
         bool         prepared  = false;// Matrix::set_format(AccCsr / AccCsc): build every copy at the next chance instead of renting first
         ~HipCsr() override {
             if (plan) splahip_csr_plan_destroy(plan);
@@ -159,7 +160,7 @@ namespace spla {
         void drop_plan() {
             if (plan) splahip_csr_plan_destroy(plan);
             plan      = nullptr;
-            mxv_calls = 0;
+            mxv_calls = 0, sell_calls = 0;
             cob_tried = sell_tried = false;
         }
     };
@@ -425,7 +426,7 @@ namespace spla {
         ref_ptr<Type>      get_type() override { return TypeTraits<T>::type(); }
 
         // reference include/spla/matrix.hpp:51-65: "set_format ... instructs the matrix to keep this format valid".  For the accelerator formats it is
-        // also the caller's way to say "prepare now": the plan and both layout copies of the device CSR are built here, before the first product,
+        // also the caller's way to say "prepare now": the plan and the column-ordered-blocks copy of the device CSR are built here, before the first product,
         // instead of after the matrix has shown that it keeps being multiplied (algos_hip.cpp: rent-or-buy).  AccCsc: flagged, built with the transpose.
         Status set_format(FormatMatrix format) override {
             return guarded([&] {
@@ -440,10 +441,7 @@ namespace spla {
                             a->cob_tried = true;
                             (void) splahip_csr_plan_attach_cob(a->plan, m_s.n_cols, a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(), cob_row_bits<T>(m_s.n_rows), 0, nullptr);
                         }
-                        if (!a->sell_tried) {
-                            a->sell_tried = true;
-                            (void) splahip_csr_plan_attach_sell(a->plan, m_s.n_cols, a->Ap.template as<uint32_t>(), a->Aj.template as<uint32_t>(), a->Ax.ptr(), nullptr);
-                        }
+                        // (the sliced-ELL copy, +12 B per entry, follows at the first product that would use it: algos_hip.cpp, maybe_build_copies)
                     }
                 }
             });

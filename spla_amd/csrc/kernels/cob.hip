@@ -162,7 +162,7 @@ namespace {
         // memory position p = 4 * lane + j holds the chunk's sorted entry 64 * j + lane: a lane's 16-byte load brings its four slots, and the
         // wave's j-th gather instruction covers 64 consecutive sorted entries (ascending, neighbouring columns)
         const uint32_t src = s0 + i * kCobChunk + 64 * (threadIdx.x & 3) + (threadIdx.x >> 2);
-        uint32_t       w = R << col_bits, x = 0;// padding: slot field R (the spare LDS word), column offset 0
+        uint32_t       w = (R + (threadIdx.x >> 2)) << col_bits, x = 0;// padding: slot field R + lane (the lane's spare LDS word: position 4 l + j belongs to lane l), column offset 0
         if (src < s1) {
             const unsigned long long k = key[src];
             const uint32_t           rl = (uint32_t) k & ((1u << kSlotBits) - 1u);
@@ -188,7 +188,7 @@ namespace {
 
     __global__ __launch_bounds__(256) void cob_padchunk_kernel(uint32_t c, uint32_t R, uint32_t col_bits, uint32_t* __restrict__ cr, uint32_t* __restrict__ ax,
                                                                uint32_t* __restrict__ hdr) {
-        cr[(size_t) c * kCobChunk + threadIdx.x] = R << col_bits;
+        cr[(size_t) c * kCobChunk + threadIdx.x] = (R + (threadIdx.x >> 2)) << col_bits;
         ax[(size_t) c * kCobChunk + threadIdx.x] = 0;
         if (threadIdx.x == 0) hdr[c] = 0;
     }
@@ -344,14 +344,14 @@ namespace {
             if (g->half_groups) {
                 constexpr unsigned kHalf = 512;
                 SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kHalf, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kHalf, MODE>), dim3(sc.n_tiles), dim3(kHalf), ((size_t) g->R + 4) * sizeof(typename CobSlice<T, ACC>::word), st, a,
+                hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kHalf, MODE>), dim3(sc.n_tiles), dim3(kHalf), ((size_t) g->R + kCobLdsExtra) * sizeof(typename CobSlice<T, ACC>::word), st, a,
                                    static_cast<const T*>(v), static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
                 SPLAHIP_TRY(hipGetLastError());
                 return SPLAHIP_OK;
             }
         }
         SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), dim3(sc.n_tiles), dim3(kTpb), ((size_t) g->R + 4) * sizeof(typename CobSlice<T, ACC>::word), st, a,
+        hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), dim3(sc.n_tiles), dim3(kTpb), ((size_t) g->R + kCobLdsExtra) * sizeof(typename CobSlice<T, ACC>::word), st, a,
                            static_cast<const T*>(v), static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
         SPLAHIP_TRY(hipGetLastError());
         return SPLAHIP_OK;
@@ -546,7 +546,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     g->n_cols   = n_cols;
     g->R        = R;
     g->col_bits = col_bits;
-    g->half_groups = 2 * ((size_t) R + 4) * 8 <= 160 * 1024 && env_u32("SPLAHIP_COB_HALF_GROUPS", 1) != 0;
+    g->half_groups = 2 * ((size_t) R + kCobLdsExtra) * 8 <= 160 * 1024 && env_u32("SPLAHIP_COB_HALF_GROUPS", 1) != 0;
     hipError_t e    = hipSuccess;
     auto       bail = [&](const char* what) {
         cob_release(g);
@@ -727,7 +727,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     uint32_t       max_multi = 0;
     for (int w = 0; w < 2 && e == hipSuccess; ++w) {
         splahip_cob_sched_s& sc     = g->sched[w];
-        const size_t         lds    = ((size_t) R + 4) * (w ? 8 : 4);
+        const size_t         lds    = ((size_t) R + kCobLdsExtra) * (w ? 8 : 4);
         const uint32_t       per_cu = (uint32_t) std::min<size_t>(env_u32("SPLAHIP_COB_PER_CU", 2), (160 * 1024) / lds);// 1024-thread workgroups: at most 2 per CU
         if (per_cu == 0) continue;                                                         // this slice width does not fit: not served
         const uint32_t slots = cus * per_cu;
@@ -794,21 +794,46 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
                 ranges[4 * (size_t) q + 0] = row0, ranges[4 * (size_t) q + 1] = row1, ranges[4 * (size_t) q + 2] = hub ? q * R : 0xFFFFFFFFu, ranges[4 * (size_t) q + 3] = pieces;
             }
         };
+        // launch order.  0: dearest piece first.  1 (SPLAHIP_COB_ORDER): RANGE-MAJOR — the natural ranges' pieces first (latency-bound walks and long row
+        // passes: all under the hub pieces' streams), then the hub ranges one after the other, dearest range first, each range's pieces dearest first — so a
+        // range's row pass (its last arriver's ~12 - 20 us) falls under the next ranges' streams and only the last range's is in the tail
+        const uint32_t order_mode = env_u32("SPLAHIP_COB_ORDER", 0);
+        auto launch_order = [&]() {
+            const uint32_t        nt = (uint32_t) (tiles.size() / 4);
+            std::vector<uint32_t> o(nt);
+            for (uint32_t t = 0; t < nt; ++t) o[t] = t;
+            if (order_mode == 0) {
+                std::stable_sort(o.begin(), o.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+                return o;
+            }
+            std::vector<uint64_t> range_cost(n_ranges, 0);
+            for (uint32_t t = 0; t < nt; ++t) range_cost[tiles[4 * (size_t) t + 2]] += cost[t];
+            std::stable_sort(o.begin(), o.end(), [&](uint32_t x, uint32_t y) {
+                const uint32_t qx = tiles[4 * (size_t) x + 2], qy = tiles[4 * (size_t) y + 2];
+                const bool     hx = qx < n_hub_ranges, hy = qy < n_hub_ranges;
+                if (hx != hy) return !hx;// natural pieces first
+                if (!hx) return cost[x] > cost[y];
+                if (qx != qy) return range_cost[qx] != range_cost[qy] ? range_cost[qx] > range_cost[qy] : qx < qy;
+                return cost[x] > cost[y];
+            });
+            return o;
+        };
         auto makespan = [&]() -> uint64_t {
-            std::vector<uint64_t> c(cost);
-            std::sort(c.begin(), c.end(), std::greater<uint64_t>());
+            const std::vector<uint32_t> o = launch_order();
             std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> free_at;
             for (uint32_t k = 0; k < slots; ++k) free_at.push(0);
             uint64_t end = 0;
-            for (uint64_t x : c) {
-                const uint64_t t = free_at.top() + x;
+            for (uint32_t t : o) {
+                const uint64_t e2 = free_at.top() + cost[t];
                 free_at.pop();
-                free_at.push(t);
-                end = std::max(end, t);
+                free_at.push(e2);
+                end = std::max(end, e2);
             }
             return end;
         };
-        uint32_t share_pct = env_u32("SPLAHIP_COB_SHARE_PCT", 0), levels = env_u32("SPLAHIP_COB_LEVELS", 0);
+        // (three size levels measured best at both bench scales whatever the model preferred — R-MAT 22: 154 us against 166 / 172 with two / one level, R-MAT 23: 308
+        // against 336 / 327 — so the level count is fixed and the model picks the share; SPLAHIP_COB_LEVELS=0 lets it pick both)
+        uint32_t share_pct = env_u32("SPLAHIP_COB_SHARE_PCT", 0), levels = env_u32("SPLAHIP_COB_LEVELS", 3);
         if (share_pct == 0 || levels == 0) {
             uint64_t       best = ~0ull;
             const uint32_t pct_fixed = share_pct, lev_fixed = levels;
@@ -824,11 +849,9 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
             if (best == ~0ull) share_pct = pct_fixed ? pct_fixed : 60, levels = lev_fixed ? lev_fixed : 1;
         }
         cut(share_pct, levels);
-        // launch order: dearest piece first (stable: equal pieces keep range order)
-        const uint32_t        n_tiles = (uint32_t) (tiles.size() / 4);
-        std::vector<uint32_t> order_t(n_tiles), sorted(tiles.size());
-        for (uint32_t t = 0; t < n_tiles; ++t) order_t[t] = t;
-        std::stable_sort(order_t.begin(), order_t.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+        const uint32_t              n_tiles = (uint32_t) (tiles.size() / 4);
+        const std::vector<uint32_t> order_t = launch_order();
+        std::vector<uint32_t>       sorted(tiles.size());
         for (uint32_t t = 0; t < n_tiles; ++t)
             for (int k = 0; k < 4; ++k) sorted[4 * t + k] = tiles[4 * order_t[t] + k];
         if (std::getenv("SPLAHIP_COB_TRACE"))

@@ -23,7 +23,7 @@
 //   chunk  = 256 entry slots = one wave iteration (a 16-byte load of 4 slots per lane for each of the two streams); the word at memory
 //            position 4 l + j is the chunk's sorted entry 64 j + l, so the wave's j-th gather instruction covers 64 CONSECUTIVE sorted entries
 //            cr[slot] = slot_in_range << col_bits | column - base_col      ax[slot] = value bits      hdr[chunk] = base_col
-//            a padding slot carries the slot value R, the spare word behind the LDS slice — no count, no predicate in the loop
+//            a padding slot carries a slot value >= R, one of the spare words behind the LDS slice (kCobSpare: one per lane) — no count, no predicate in the loop
 //            a chunk never straddles a (range, column window of 2^col_bits columns) group; only a group's last chunk is padded
 //   piece  = consecutive chunks of ONE range = one workgroup's work: zero the LDS slice, walk the chunks (wave w takes chunks
 //            w, w + waves, ...), then either finish the rows (a range that is a single piece) or add the slice into the range's shared
@@ -60,6 +60,12 @@ namespace splahip {
     constexpr uint32_t kCobSlotHub   = 0xFFFEu;// slot16: the row belongs to a hub range
 
     constexpr uint32_t kCobChunk  = 256;// slots per chunk
+    // spare words behind a range's R slice words: the padding slot at memory position 4 l + j of a chunk carries the slot value R + l, so the 64 lanes of a
+    // wave add their padding products into 64 DIFFERENT words.  (One shared spare word — rounds 2 and early 3 — made every padded chunk 64 same-address LDS
+    // atomics per instruction: the partially filled last chunk of every (range, window) group and the all-padding steps behind every piece ran at
+    // 350 - 700 ns per chunk against ~90; profiles/r03_notes.md.)  + 4 words: the last arriver's flag
+    constexpr uint32_t kCobSpare  = 64;
+    constexpr uint32_t kCobLdsExtra = kCobSpare + 4;
     constexpr uint32_t kCobNoSlab = 0xFFFFFFFFu;
 
     // how a product enters the LDS slice: the LDS atomic of op_add
@@ -387,10 +393,136 @@ namespace splahip {
                     }
                 }
             };
-            if (op_select == SPLAHIP_ALWAYS && (VXM || !accumulate)) pass(std::integral_constant<int, TIGHT ? 2 : 4>{}, std::false_type{});
+            if (op_select == SPLAHIP_ALWAYS && (VXM || !accumulate)) pass(std::integral_constant<int, TIGHT ? 2 : 8>{}, std::false_type{});
             else
                 pass(std::integral_constant<int, TIGHT ? 1 : 2>{}, std::true_type{});
         }
+    }
+
+    // What a piece does behind its chunk loop, as ONE real call per (type, op_add family, mode): merge into the range's shared accumulator and take a
+    // ticket (a range in several pieces), read the accumulator back as the last arriver, round a double slice, then the row pass above.  A hub range's
+    // slot -> row words are requested BEFORE the merge (they depend on nothing), so the scattered stores behind it wait for no load of their own.
+    template<typename T, int ACC, bool VXM, unsigned TPB, bool TIGHT>
+    __device__ __noinline__ void cob_piece_end(unsigned char* s_raw, const CobTile t, const CobRange rg, const uint16_t* __restrict__ slot16, const uint32_t* __restrict__ hub_row,
+                                               uint32_t* __restrict__ acc, uint32_t* __restrict__ ticket, uint32_t* __restrict__ touched, uint32_t n_rows, uint32_t R,
+                                               uint32_t accumulate, const T* __restrict__ mask, T* __restrict__ r, DynBin add, int op_select, T init) {
+        using word = typename CobSlice<T, ACC>::word;
+        constexpr bool kWide = sizeof(word) == 8;
+        word* const    s_acc = reinterpret_cast<word*>(s_raw);
+        // a hub range's slot -> row words: requested by the piece that will run the row pass as soon as it knows it (under the accumulator read-back), so the
+        // scattered stores wait for no load of their own (not in the 64-register kernels: their row pass loads them in batches)
+        constexpr uint32_t KP = TIGHT ? 1 : 20;// 20 x TPB >= R (20224 with 1024 threads, <= 10236 with 512)
+        uint32_t           hrow[KP];
+        const bool         hub_early = !TIGHT && rg.hub_base != 0xFFFFFFFFu;
+        auto               request_hub_rows = [&]() {
+            if (hub_early) {
+#pragma unroll
+                for (uint32_t k = 0; k < KP; ++k) {
+                    const uint32_t sidx = threadIdx.x + k * TPB;
+                    hrow[k]             = sidx < R ? hub_row[rg.hub_base + sidx] : 0xFFFFFFFFu;
+                }
+            }
+        };
+        if (t.multi == kCobNoSlab) request_hub_rows();
+        // slice word i as the 4-byte result word (a double slice is rounded to fp32 here, once per row and piece)
+        auto own_word = [&](uint32_t i) -> uint32_t {
+            if constexpr (kWide) return to_bits((float) s_acc[i]);
+            else
+                return s_acc[i];
+        };
+        const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_raw);// the last arriver's view: the accumulated 4-byte words
+        bool            merged  = false;
+        if (t.multi != kCobNoSlab) {
+            // add the slice into the range's shared accumulator (words still at the identity hold nothing), then take a ticket
+            uint32_t* const gacc = acc + (size_t) t.multi * R;
+            for (uint32_t i = threadIdx.x; i < R; i += TPB) {
+                const uint32_t w = own_word(i);
+                if (w != cob_identity<T, ACC>()) cob_merge_global<T, ACC>(gacc + i, w);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");// every adding wave: its atomics have been performed
+            __syncthreads();
+            uint32_t* const s_flag = reinterpret_cast<uint32_t*>(s_raw + (size_t) (R + kCobSpare) * sizeof(word));
+            if (threadIdx.x == 0) *s_flag = __hip_atomic_fetch_add(ticket + t.multi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == rg.n_pieces - 1 ? 1u : 0u;
+            __syncthreads();
+            if (*s_flag == 0) return;
+            request_hub_rows();
+            // the last piece of the range: every other piece's atomics were performed before its ticket add.  Read the accumulator back (agent-scope
+            // loads: past this CU's L1), re-arm it and the ticket for the next call, and finish the rows from the LDS copy
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+            // 16 bytes per lane with the sc1 bit (agent-scope, like the atomic loads the compiler would emit one word at a time): R / 4 / TPB <= 5 loads per
+            // thread, all requested before the one wait — one memory round trip for the whole accumulator.  The re-arming stores are plain 16-byte
+            // stores: nobody reads these words again in this launch, and a launch boundary makes them visible to the next call's atomics.
+            uint4* s_w4 = reinterpret_cast<uint4*>(s_raw);
+            uint4* g4   = reinterpret_cast<uint4*>(gacc);
+            typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+            constexpr int KB = 5;
+            for (uint32_t base = threadIdx.x; base < R / 4; base += TPB * KB) {
+                u4v w[KB];
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    const uint32_t i = base + k * TPB;
+                    const uint4*   q = g4 + (i < R / 4 ? i : 0);
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w[k]) : "v"(q) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4])::"memory");
+                const uint32_t id = cob_identity<T, ACC>();
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    const uint32_t i = base + k * TPB;
+                    if (i < R / 4) {
+                        s_w4[i] = make_uint4(w[k].x, w[k].y, w[k].z, w[k].w);
+                        g4[i]   = make_uint4(id, id, id, id);
+                    }
+                }
+            }
+            if (threadIdx.x == 0) __hip_atomic_store(ticket + t.multi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            merged = true;
+        }
+        if constexpr (kWide) {
+            if (!merged) {// round the double slice to fp32 words in place: every thread's doubles into registers, a barrier, then the words
+                constexpr uint32_t KC = TPB >= 1024 ? 20 : 24;// (R <= 20224 with 1024 threads; R <= 10112 + with 512: 24 x 512 covers 12288)
+                float              f[KC];
+#pragma unroll
+                for (uint32_t k = 0; k < KC; ++k) {
+                    const uint32_t i = threadIdx.x + k * TPB;
+                    f[k]             = i < R ? (float) s_acc[i] : 0.0f;
+                }
+                __syncthreads();
+                float* s_f = reinterpret_cast<float*>(s_raw);
+#pragma unroll
+                for (uint32_t k = 0; k < KC; ++k) {
+                    const uint32_t i = threadIdx.x + k * TPB;
+                    if (i < R) s_f[i] = f[k];
+                }
+                __syncthreads();
+            }
+        }
+        if (hub_early) {// slot s of the hub range is row hrow[.]: one scattered word per row, no load in front of the stores (mask / previous r: one batch)
+            T mk[KP], prev[KP];
+#pragma unroll
+            for (uint32_t k = 0; k < KP; ++k) {
+                mk[k]   = hrow[k] != 0xFFFFFFFFu && op_select != SPLAHIP_ALWAYS ? mask[hrow[k]] : T(0);
+                prev[k] = hrow[k] != 0xFFFFFFFFu && !VXM && accumulate ? r[hrow[k]] : init;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < KP; ++k) {
+                const uint32_t row = hrow[k];
+                if (row == 0xFFFFFFFFu) continue;
+                const uint32_t w   = s_words[threadIdx.x + k * TPB];
+                const bool     sel = op_select == SPLAHIP_ALWAYS || eval_sel<T>(op_select, mk[k]);
+                if constexpr (VXM) {
+                    r[row]       = cob_value<T, ACC>(w);
+                    touched[row] = sel ? 1u : 0u;
+                } else if (accumulate) {
+                    if (sel) r[row] = cob_finish<T, ACC>(w, prev[k], add);
+                } else
+                    r[row] = sel ? cob_finish<T, ACC>(w, init, add) : init;
+            }
+            return;
+        }
+        cob_row_pass<T, ACC, VXM, TPB, TIGHT>(s_words, rg, slot16, hub_row, touched, n_rows, R, accumulate, mask, r, add, op_select, init);
     }
 
     template<typename T, class Mult, class Add, int ACC, bool VXM, unsigned TPB, int MODE = 0>
@@ -419,7 +551,7 @@ namespace splahip {
             const uint32_t id = cob_identity<T, ACC>();
             uint4*         s4 = reinterpret_cast<uint4*>(s_raw);
             const uint4    z  = kWide ? make_uint4(0u, id, 0u, id) : make_uint4(id, id, id, id);// a double's high word carries the sign of -0.0
-            for (uint32_t i = threadIdx.x; i < R * sizeof(word) / 16 + 1; i += TPB) s4[i] = z;// + the spare words the padding slots add into
+            for (uint32_t i = threadIdx.x; i < (R + kCobSpare) * sizeof(word) / 16; i += TPB) s4[i] = z;// + the spare words the padding slots add into
         }
         __syncthreads();
 #ifdef SPLAHIP_COB_TIMING
@@ -546,87 +678,8 @@ namespace splahip {
 #ifdef SPLAHIP_COB_TIMING
         if (threadIdx.x == 0 && blockIdx.x < 8192) g_cob_t[2][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
-        const CobRange rg = a.ranges[t.range];
-        // slice word i as the 4-byte result word (a double slice is rounded to fp32 here, once per row and piece)
-        auto own_word = [&](uint32_t i) -> uint32_t {
-            if constexpr (kWide) return to_bits((float) s_acc[i]);
-            else
-                return s_acc[i];
-        };
-        const uint32_t* s_words = reinterpret_cast<const uint32_t*>(s_raw);// the last arriver's view: the accumulated 4-byte words
-        bool            merged  = false;
-        if (t.multi != kCobNoSlab) {
-            // add the slice into the range's shared accumulator (words still at the identity hold nothing), then take a ticket
-            uint32_t* const gacc = a.acc + (size_t) t.multi * R;
-            for (uint32_t i = threadIdx.x; i < R; i += TPB) {
-                const uint32_t w = own_word(i);
-                if (w != cob_identity<T, ACC>()) cob_merge_global<T, ACC>(gacc + i, w);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");// every adding wave: its atomics have been performed
-            __syncthreads();
-            uint32_t* const s_flag = reinterpret_cast<uint32_t*>(s_raw + (size_t) (R + 3) * sizeof(word));
-            if (threadIdx.x == 0) *s_flag = __hip_atomic_fetch_add(a.ticket + t.multi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == rg.n_pieces - 1 ? 1u : 0u;
-            __syncthreads();
-            if (*s_flag == 0) {
-#ifdef SPLAHIP_COB_TIMING
-                if (threadIdx.x == 0 && blockIdx.x < 8192) g_cob_t[3][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-#endif
-                return;
-            }
-            // the last piece of the range: every other piece's atomics were performed before its ticket add.  Read the accumulator back (agent-scope
-            // loads: past this CU's L1), re-arm it and the ticket for the next call, and finish the rows from the LDS copy
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __syncthreads();
-            // 16 bytes per lane with the sc1 bit (agent-scope, like the atomic loads the compiler would emit one word at a time): R / 4 / TPB <= 5 loads per
-            // thread, all requested before the one wait — one memory round trip for the whole accumulator.  The re-arming stores are plain 16-byte
-            // stores: nobody reads these words again in this launch, and a launch boundary makes them visible to the next call's atomics.
-            uint4* s_w4 = reinterpret_cast<uint4*>(s_raw);
-            uint4* g4   = reinterpret_cast<uint4*>(gacc);
-            typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-            constexpr int KB = 5;
-            for (uint32_t base = threadIdx.x; base < R / 4; base += TPB * KB) {
-                u4v w[KB];
-#pragma unroll
-                for (int k = 0; k < KB; ++k) {
-                    const uint32_t i = base + k * TPB;
-                    const uint4*   q = g4 + (i < R / 4 ? i : 0);
-                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w[k]) : "v"(q) : "memory");
-                }
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4])::"memory");
-                const uint32_t id = cob_identity<T, ACC>();
-#pragma unroll
-                for (int k = 0; k < KB; ++k) {
-                    const uint32_t i = base + k * TPB;
-                    if (i < R / 4) {
-                        s_w4[i] = make_uint4(w[k].x, w[k].y, w[k].z, w[k].w);
-                        g4[i]   = make_uint4(id, id, id, id);
-                    }
-                }
-            }
-            if (threadIdx.x == 0) __hip_atomic_store(a.ticket + t.multi, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            merged = true;
-        }
-        if constexpr (kWide) {
-            if (!merged) {// round the double slice to fp32 words in place: every thread's doubles into registers, a barrier, then the words
-                constexpr uint32_t KC = TPB >= 1024 ? 20 : 24;// (R <= 20224 with 1024 threads; R <= 10112 + with 512: 24 x 512 covers 12288)
-                float              f[KC];
-#pragma unroll
-                for (uint32_t k = 0; k < KC; ++k) {
-                    const uint32_t i = threadIdx.x + k * TPB;
-                    f[k]             = i < R ? (float) s_acc[i] : 0.0f;
-                }
-                __syncthreads();
-                float* s_f = reinterpret_cast<float*>(s_raw);
-#pragma unroll
-                for (uint32_t k = 0; k < KC; ++k) {
-                    const uint32_t i = threadIdx.x + k * TPB;
-                    if (i < R) s_f[i] = f[k];
-                }
-                __syncthreads();
-            }
-        }
-        cob_row_pass<T, ACC, VXM, TPB, (cob_min_waves<T, ACC, MODE>() > 4u)>(s_words, rg, a.slot16, a.hub_row, a.touched, a.n_rows, R, a.accumulate, mask, r, add, op_select, init);
+        cob_piece_end<T, ACC, VXM, TPB, (cob_min_waves<T, ACC, MODE>() > 4u)>(s_raw, t, a.ranges[t.range], a.slot16, a.hub_row, a.acc, a.ticket, a.touched, a.n_rows, R, a.accumulate,
+                                                                              mask, r, add, op_select, init);
 #ifdef SPLAHIP_COB_TIMING
         if (threadIdx.x == 0 && blockIdx.x < 8192) g_cob_t[3][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif

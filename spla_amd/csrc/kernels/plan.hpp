@@ -6,6 +6,7 @@
 // sliced-ELL copy of the matrix + hot-column table (sell.hip / mxv_sell.hpp); owned by the plan
 struct splahip_sell_s {
     uint32_t  n_cols     = 0;
+    size_t    bytes      = 0;// device memory the copy holds
     uint32_t  n_vrows    = 0;// virtual rows (chunks), padded to a multiple of 64
     uint32_t  n_slices   = 0;
     uint32_t  n_slots    = 0;// entries of Aj2 / Ax2 incl. in-slice padding (the allocation adds a read-ahead tail)

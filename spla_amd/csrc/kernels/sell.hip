@@ -528,6 +528,7 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     if (e == hipSuccess) e = tmp.alloc(&vk0, g->n_vrows);
     auto own = [&](uint32_t** q, size_t words) {
         if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(q), sizeof(uint32_t) * (words ? words : 1));
+        if (e == hipSuccess) g->bytes += sizeof(uint32_t) * (words ? words : 1);
     };
     own(&g->d_vrow, g->n_vrows);
     own(&g->d_vlen, g->n_vrows);
@@ -660,6 +661,18 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     plan->sell = g;
     return SPLAHIP_OK;
 }
+
+// device memory held for one matrix besides its CSR arrays: the wave-tile plan, the sliced-ELL copy, the column-ordered-blocks copy (bytes; 0 = not built)
+extern "C" int splahip_csr_plan_footprint(splahip_plan plan, uint64_t* plan_bytes, uint64_t* sell_bytes, uint64_t* cob_bytes) {
+    SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
+    if (plan_bytes) *plan_bytes = (uint64_t) plan->n_items * 16 + 8 + (uint64_t) plan->ws_bytes;
+    if (sell_bytes) *sell_bytes = plan->sell ? (uint64_t) plan->sell->bytes : 0;
+    if (cob_bytes) *cob_bytes = plan->cob ? (uint64_t) plan->cob->bytes : 0;
+    return SPLAHIP_OK;
+}
+// 1 when splahip_mxv_masked would run this semiring on the sliced-ELL copy even beside a column-ordered-blocks copy (the zero-family sparse-vector forms:
+// a BFS step); a host that builds copies on demand needs the sliced-ELL one only for these
+extern "C" int splahip_mxv_prefers_sell(int type, int op_mult, int op_add) { return splahip::sell_skip_family(type, op_mult, op_add) == 1 ? 1 : 0; }
 
 extern "C" int splahip_csr_plan_sell_info(splahip_plan plan, uint32_t* n_slices, uint32_t* n_slots, uint32_t* n_hot, uint32_t* n_long_rows) {
     SPLAHIP_REQUIRE(plan != nullptr, "plan is null");

@@ -72,6 +72,12 @@ class CsrPlan:
                     "hub_ranges": nh.value, "hub_rows": hr.value, "bytes": by.value} if a.value else None
         return self.cob
 
+    def footprint(self):
+        """device bytes held for the matrix besides its CSR arrays: {"plan", "sliced_ell", "column_ordered_blocks"}"""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _lib.call("splahip_csr_plan_footprint", self._h, C.byref(a), C.byref(b), C.byref(c))
+        return {"plan": a.value, "sliced_ell": b.value, "column_ordered_blocks": c.value}
+
     @property
     def handle(self):
         return self._h
