@@ -340,6 +340,7 @@ namespace {
         // a range of 16 Ki+ slots plus the spare words is over the 64 KB a kernel gets without asking (cheap; per device, so not cached in a static)
         // a double slice of at most half a CU's LDS: two 8-wave workgroups per CU instead of one 16-wave workgroup (their zeroing, pipeline fill and row
         // passes then run under each other's streams) — the fp32 PLUS forms only
+        bool launched = false;
         if constexpr (W == 1 && MODE == 0) {
             if (g->half_groups) {
                 constexpr unsigned kHalf = 512;
@@ -347,13 +348,21 @@ namespace {
                 hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kHalf, MODE>), dim3(sc.n_tiles), dim3(kHalf), ((size_t) g->R + kCobLdsExtra) * sizeof(typename CobSlice<T, ACC>::word), st, a,
                                    static_cast<const T*>(v), static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
                 SPLAHIP_TRY(hipGetLastError());
-                return SPLAHIP_OK;
+                launched = true;
             }
         }
-        SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), dim3(sc.n_tiles), dim3(kTpb), ((size_t) g->R + kCobLdsExtra) * sizeof(typename CobSlice<T, ACC>::word), st, a,
-                           static_cast<const T*>(v), static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
-        SPLAHIP_TRY(hipGetLastError());
+        if (!launched) {
+            SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), dim3(sc.n_tiles), dim3(kTpb), ((size_t) g->R + kCobLdsExtra) * sizeof(typename CobSlice<T, ACC>::word), st, a,
+                               static_cast<const T*>(v), static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
+            SPLAHIP_TRY(hipGetLastError());
+        }
+        if (g->hub_finish && g->n_hub_ranges) {
+            const uint32_t n_slots = g->n_hub_ranges * g->R;
+            hipLaunchKernelGGL((cob_hub_finish_kernel<T, ACC, VXM>), dim3((n_slots + 255) / 256), dim3(256), 0, st, n_slots, g->d_acc, g->d_hub_row, static_cast<const T*>(mask),
+                               static_cast<T*>(r), touched, a.accumulate, DynBin(op_add), op_select, init);
+            SPLAHIP_TRY(hipGetLastError());
+        }
         return SPLAHIP_OK;
     }
 
@@ -547,6 +556,9 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     g->R        = R;
     g->col_bits = col_bits;
     g->half_groups = 2 * ((size_t) R + kCobLdsExtra) * 8 <= 160 * 1024 && env_u32("SPLAHIP_COB_HALF_GROUPS", 1) != 0;
+    // the hub ranges' row pass as a kernel of its own behind the main launch (mxv_cob.hpp: cob_hub_finish_kernel).  Measured with it / without: fp32 plus-times
+    // R-MAT 22 154 - 156 / 162 - 166 us, R-MAT 23 322 - 330 / 321 - 331 us; int32 min-plus 189 / 195 and 302 / 319 us.  SPLAHIP_COB_HUB_FINISH=0: one launch
+    g->hub_finish  = env_u32("SPLAHIP_COB_HUB_FINISH", 1) != 0;
     hipError_t e    = hipSuccess;
     auto       bail = [&](const char* what) {
         cob_release(g);
@@ -786,7 +798,13 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
                     f = end;
                 }
                 const uint32_t pieces = (uint32_t) (tiles.size() / 4) - first_tile;
-                cost.back() += row_pass;// (the range's cheapest piece is launched last: it is the likely last arriver)
+                if (!(hub && g->hub_finish)) cost.back() += row_pass;// (the range's cheapest piece is launched last: it is the likely last arriver)
+                if (hub && g->hub_finish) {// every piece merges, none runs the row pass (cob_hub_finish_kernel): accumulator q belongs to hub range q
+                    for (uint32_t t = first_tile; t < first_tile + pieces; ++t) tiles[4 * (size_t) t + 3] = n_multi, cost[t] += 59000;
+                    ++n_multi;
+                    ranges[4 * (size_t) q + 0] = row0, ranges[4 * (size_t) q + 1] = row1, ranges[4 * (size_t) q + 2] = q * R, ranges[4 * (size_t) q + 3] = kCobNoLast;
+                    continue;
+                }
                 if (pieces > 1) {
                     for (uint32_t t = first_tile; t < first_tile + pieces; ++t) tiles[4 * (size_t) t + 3] = n_multi, cost[t] += 59000;
                     ++n_multi;

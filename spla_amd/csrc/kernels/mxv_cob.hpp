@@ -56,6 +56,7 @@ namespace splahip {
         uint32_t hub_base;  // hub range: first word of its slot -> row list in hub_row; 0xFFFFFFFF for a natural range
         uint32_t n_pieces;
     };
+    constexpr uint32_t kCobNoLast    = 0xFFFFFFFFu;// CobRange::n_pieces: no piece of this range runs its row pass (cob_hub_finish_kernel does, after the launch)
     constexpr uint32_t kCobSlotEmpty = 0xFFFFu;// slot16: the row holds no entry
     constexpr uint32_t kCobSlotHub   = 0xFFFEu;// slot16: the row belongs to a hub range
 
@@ -218,14 +219,22 @@ namespace splahip {
             (void) __hip_atomic_fetch_xor(acc, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
+    // op_add of an accumulation kind (cob_acc_kind maps one to one): the row pass folds init with a compile-time functor — a runtime-switched one costs a
+    // 15-way switch per ROW, and a natural range's row pass is instruction-bound on ONE CU (160 K rows at ~20 instructions each ran 28 - 34 us)
+    template<int ACC>
+    constexpr int cob_op_of() {
+        return ACC == COB_ADD ? SPLAHIP_PLUS : ACC == COB_MIN ? SPLAHIP_MIN : ACC == COB_MAX ? SPLAHIP_MAX : ACC == COB_OR ? SPLAHIP_BOR : ACC == COB_AND ? SPLAHIP_BAND
+               : ACC == COB_XOR ? SPLAHIP_BXOR : ACC == COB_LOR ? SPLAHIP_LOR : SPLAHIP_LAND;
+    }
     // the row's result from its accumulated slice word: add(init, acc); LOR / LAND slices hold a truth value, fp32 MIN / MAX slices a key
     template<typename T, int ACC, class Add>
-    __device__ __forceinline__ T cob_finish(uint32_t acc, T init, const Add& add) {
-        if constexpr (ACC == COB_LOR || ACC == COB_LAND) return add(init, acc ? T(1) : T(0));
+    __device__ __forceinline__ T cob_finish(uint32_t acc, T init, const Add&) {
+        constexpr int OP = cob_op_of<ACC>();
+        if constexpr (ACC == COB_LOR || ACC == COB_LAND) return eval_bin<OP>(init, acc ? T(1) : T(0));
         else if constexpr (std::is_same<T, float>::value && (ACC == COB_MIN || ACC == COB_MAX))
-            return acc == cob_identity<T, ACC>() ? init : add(init, cob_funkey((int32_t) acc));
+            return acc == cob_identity<T, ACC>() ? init : eval_bin<OP>(init, cob_funkey((int32_t) acc));
         else
-            return add(init, from_bits<T>(acc));
+            return eval_bin<OP>(init, from_bits<T>(acc));
     }
     // the fold itself as a value of T (vxm mode: an output is the fold, there is no init)
     template<typename T, int ACC>
@@ -342,6 +351,14 @@ namespace splahip {
                     for (int k = 0; k < KN; ++k) {
                         const uint32_t row = row0 + k * TPB * 8;
                         if (row >= rg.row1) break;
+                        if constexpr (!SIDE && !VXM) {// eight rows without an entry (most of a cold range's span): two 16-byte stores of init and on
+                            if ((sl[k].x & sl[k].y & sl[k].z & sl[k].w) == 0xFFFFFFFFu && row + 8 <= n_rows) {
+                                const uint4 iv = make_uint4(to_bits(init), to_bits(init), to_bits(init), to_bits(init));
+                                *reinterpret_cast<uint4*>(r + row)     = iv;
+                                *reinterpret_cast<uint4*>(r + row + 4) = iv;
+                                continue;
+                            }
+                        }
                         const uint32_t sw[4] = {sl[k].x, sl[k].y, sl[k].z, sl[k].w};
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
@@ -439,6 +456,7 @@ namespace splahip {
                 const uint32_t w = own_word(i);
                 if (w != cob_identity<T, ACC>()) cob_merge_global<T, ACC>(gacc + i, w);
             }
+            if (rg.n_pieces == kCobNoLast) return;// (the end of the launch makes the atomics visible to the finishing kernel)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");// every adding wave: its atomics have been performed
             __syncthreads();
             uint32_t* const s_flag = reinterpret_cast<uint32_t*>(s_raw + (size_t) (R + kCobSpare) * sizeof(word));
@@ -683,6 +701,28 @@ namespace splahip {
 #ifdef SPLAHIP_COB_TIMING
         if (threadIdx.x == 0 && blockIdx.x < 8192) g_cob_t[3][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
+    }
+
+    // Row pass of the hub ranges as a kernel of its own (SPLAHIP_COB_HUB_FINISH=1): a hub range's 20 K results are 20 K scattered 4-byte stores, ~19 us when
+    // ONE workgroup — the range's last arriver — issues them at the very end of the launch, ~2 us when every CU takes a share.  Thread = hub slot: read the
+    // merged accumulator word (plain load: the launch boundary is the release / acquire), re-arm it, finish the row.
+    template<typename T, int ACC, bool VXM>
+    __global__ __launch_bounds__(256) void cob_hub_finish_kernel(uint32_t n_slots, uint32_t* __restrict__ acc, const uint32_t* __restrict__ hub_row, const T* __restrict__ mask,
+                                                                 T* __restrict__ r, uint32_t* __restrict__ touched, uint32_t accumulate, DynBin add, int op_select, T init) {
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= n_slots) return;
+        const uint32_t w   = acc[i];
+        const uint32_t row = hub_row[i];
+        acc[i]             = cob_identity<T, ACC>();
+        if (row == 0xFFFFFFFFu) return;
+        const bool sel = op_select == SPLAHIP_ALWAYS || eval_sel<T>(op_select, mask[row]);
+        if constexpr (VXM) {
+            r[row]       = cob_value<T, ACC>(w);
+            touched[row] = sel ? 1u : 0u;
+        } else if (accumulate) {
+            if (sel) r[row] = cob_finish<T, ACC>(w, r[row], add);
+        } else
+            r[row] = sel ? cob_finish<T, ACC>(w, init, add) : init;
     }
 
 }// namespace splahip

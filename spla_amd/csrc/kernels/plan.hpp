@@ -62,6 +62,7 @@ struct splahip_cob_s {
     uint32_t  n_rows   = 0;
     uint32_t  n_cols   = 0;
     uint32_t  R        = 0;// slots per range (the range's result slice lives in LDS)
+    bool      hub_finish  = false;// the hub ranges' row pass runs as a kernel of its own behind the main launch (SPLAHIP_COB_HUB_FINISH=1)
     bool      half_groups = false;// two double slices fit a CU's LDS: the fp32 PLUS forms run 8-wave workgroups, two per CU
     uint32_t  col_bits = 0;// a chunk's columns are stored relative to its 2^col_bits-column window
     uint32_t  n_chunks = 0;// 256-slot chunks
