@@ -190,3 +190,17 @@ def test_sparse_exchange_c_abi_simulated_ranks(world):
             assert torch.equal(got, x)
         sx.close()
         comm.close()
+
+
+@pytest.mark.gpu
+def test_dist_layer_from_cpp_without_python():
+    """tests/cpp/test_dist_c_abi.cpp: the decomposition driven through the kernel-level C ABI alone (what a C++ host binds): shards of 1 and
+    3 simulated ranks, the dense exchange (RCCL communicator at world size 1 + splahip_dist_mxv_masked), the sparse exchange's pack / scatter kernels, the
+    two-part fold — stitched results bit-identical to splahip_mxv_masked on the whole matrix."""
+    import subprocess
+    from pathlib import Path
+    exe = Path(__file__).resolve().parents[1] / "oracle" / "_ref" / "test_dist_c_abi"
+    if not exe.exists():
+        pytest.skip(f"{exe} not built (oracle/Makefile target usertests)")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "DIST C-ABI OK" in out.stdout, (out.stdout + out.stderr)[-2000:]
