@@ -69,7 +69,17 @@ namespace {
         }
         out[0] = lo;
     }
-    // the H rows of highest degree take hub slots in degree order: rowmap = range << 15 | slot, slot16 = hub; hub_row lists them (padded to whole ranges)
+    // within a hub range the slots go in ROW order (the range's composition is by degree, its slot order is free): the rows' mask words and results are then
+    // visited in ascending address order by the pass that finishes them
+    __global__ __launch_bounds__(256) void cob_hub_key_kernel(uint32_t H, uint32_t R, const uint32_t* __restrict__ order, unsigned long long* __restrict__ key) {
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        if (i < H) key[i] = ((unsigned long long) (i / R) << 32) | order[i];
+    }
+    __global__ __launch_bounds__(256) void cob_hub_unkey_kernel(uint32_t H, const unsigned long long* __restrict__ key, uint32_t* __restrict__ order) {
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        if (i < H) order[i] = (uint32_t) key[i];
+    }
+    // the H rows of highest degree take hub slots, range by range in degree order: rowmap = range << 15 | slot, slot16 = hub; hub_row lists them (padded to whole ranges)
     __global__ __launch_bounds__(256) void cob_hub_kernel(uint32_t H, uint32_t H_padded, uint32_t R, const uint32_t* __restrict__ order, uint32_t* __restrict__ rowmap,
                                                           uint16_t* __restrict__ slot16, uint32_t* __restrict__ hub_row) {
         const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -604,6 +614,22 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         H = (uint32_t) std::min<uint64_t>(H, (uint64_t) max_hub_ranges * R);
         if (H < R / 8) H = 0;// not a skewed matrix: every row stays in its natural range
     }
+    if (H && env_u32("SPLAHIP_COB_HUB_ROW_ORDER", 1)) {
+        unsigned long long *key = nullptr, *key_s = nullptr;
+        e                       = tmp.alloc(&key, H);
+        if (e == hipSuccess) e = tmp.alloc(&key_s, H);
+        size_t bytes = 0;
+        if (e == hipSuccess) e = rocprim::radix_sort_keys(nullptr, bytes, key, key_s, (size_t) H, 0, 36, s);
+        void* st_tmp = nullptr;
+        if (e == hipSuccess) e = device_malloc(&st_tmp, bytes ? bytes : 4);
+        if (e == hipSuccess) {
+            tmp.ptrs.push_back(st_tmp);
+            hipLaunchKernelGGL(cob_hub_key_kernel, dim3((H + 255) / 256), dim3(256), 0, s, H, R, order, key);
+            e = rocprim::radix_sort_keys(st_tmp, bytes, key, key_s, (size_t) H, 0, 36, s);
+            hipLaunchKernelGGL(cob_hub_unkey_kernel, dim3((H + 255) / 256), dim3(256), 0, s, H, key_s, order);
+        }
+        if (e != hipSuccess) return bail("hub row order");
+    }
     const uint32_t n_hub_ranges = (H + R - 1) / R;
     g->n_hub_ranges             = n_hub_ranges;
     g->n_hub_rows               = H;
@@ -765,8 +791,8 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
                 // the cost marks at which the range is cut
                 std::vector<uint64_t> marks;
                 if (rc > share && cc > 1) {
-                    const uint32_t L     = std::max(1u, std::min(levels, 3u));
-                    const uint64_t denom = (1u << L) - 1u;// 1, 3, 7
+                    const uint32_t L     = std::max(1u, std::min(levels, 5u));
+                    const uint64_t denom = (1u << L) - 1u;// 1, 3, 7, 15, 31
                     uint64_t       at    = 0;
                     for (uint32_t l = 0; l < L; ++l) {
                         const uint64_t part = rc * (1u << (L - 1 - l)) / denom, size = std::max<uint64_t>(1, share >> l);

@@ -654,11 +654,14 @@ namespace splahip {
 #ifdef SPLAHIP_SELL_TIMING
                 n_live += 1, n_rounds += (width + 3) / 4, n_width += width, n_lanes += __popcll(live);
 #endif
-                const __amdgpu_buffer_rsrc_t rs   = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint*>(Aj2r + base), 0, width * kWave * 4u, 0x00020000);
-                const uint                   voff = selected ? lane * 4u : 0x80000000u;
-                // position t of this lane; s: the uniform part of the byte offset (a scalar register), the rest an immediate
-                auto request = [&](uint s_bytes, uint t_imm) -> uint {
-                    return __builtin_amdgcn_raw_buffer_load_b32(rs, voff + t_imm * (kWave * 4u), (int) s_bytes, 2 /* nt */);
+                const uint voff = selected ? lane * 4u : 0x80000000u;
+                // position t of this lane = t_first (uniform) + t_imm.  The uniform part goes into the DESCRIPTOR — base moved to position t_first, the
+                // record count cut to what is left of the slice (scalar arithmetic) — not into the load's scalar offset, which the range check of a raw
+                // buffer load need not cover: a request past the slice's width then returns 0 by the checked vector offset + immediate alone
+                auto request = [&](uint t_first, uint t_imm) -> uint {
+                    const uint                   left = width > t_first ? (width - t_first) * (kWave * 4u) : 0u;
+                    const __amdgpu_buffer_rsrc_t rs   = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint*>(Aj2r + base + (size_t) t_first * kWave), 0, left, 0x00020000);
+                    return __builtin_amdgcn_raw_buffer_load_b32(rs, voff + t_imm * (kWave * 4u), 0, 2 /* nt */);
                 };
                 uint hits = 0;
                 if (width <= 16u) {
@@ -685,7 +688,7 @@ namespace splahip {
                     constexpr uint D = 32, NB = 8;// entry t lives in window slot t % D
                     uint           q[D];
 #pragma unroll
-                    for (uint u = 0; u < D; ++u) q[u] = request((u & ~(NB - 1u)) * (kWave * 4u), u & (NB - 1u));
+                    for (uint u = 0; u < D; ++u) q[u] = request(u & ~(NB - 1u), u & (NB - 1u));
                     uint e = 0;
                     for (; e + D < width; e += D) {
 #pragma unroll
@@ -699,7 +702,7 @@ namespace splahip {
 #pragma unroll
                             for (uint i = 0; i < NB; ++i) asm volatile("" : "+v"(addr[i]), "+v"(sh[i])::"memory");// (pins the lines above ahead of the requests)
 #pragma unroll
-                            for (uint i = 0; i < NB; ++i) q[b + i] = request((e + D + b) * (kWave * 4u), i);
+                            for (uint i = 0; i < NB; ++i) q[b + i] = request(e + D + b, i);
 #pragma unroll
                             for (uint i = 0; i < NB; ++i) word[i] = *reinterpret_cast<const uint*>(lds + addr[i]);
 #pragma unroll
