@@ -153,6 +153,14 @@ namespace splahip {
         __shared__ uint s_red[3][256 / kWave];
         // the bitmap is double-buffered: this call fills `vbits` (cleared by the previous call) and clears the other one for the next
         // call — no memset launch per call
+        // the first step's mask quad and v quad are requested before anything is stored (at the bench sizes every lane has ONE step of each loop: without
+        // this the v load waited behind the selection words' shuffles and store)
+        const uint  t0    = (blockIdx.x * 256 + threadIdx.x) * 4;
+        const uint  n4    = n_cols & ~3u;
+        const bool  pre_m = op_select != SPLAHIP_ALWAYS && t0 + 4 <= n_rows, pre_v = t0 < n4;
+        uint4       m_pre = make_uint4(0, 0, 0, 0), x_pre = make_uint4(0, 0, 0, 0);
+        if (pre_m) m_pre = *reinterpret_cast<const uint4*>(mask + t0);
+        if (pre_v) x_pre = *reinterpret_cast<const uint4*>(v + t0);
         for (uint q = blockIdx.x * 256 + threadIdx.x; q < n_bit_quads; q += gridDim.x * 256) next_bits[q] = make_uint4(0, 0, 0, 0);
         // row selection as one bit per row, and init into every row.  Four consecutive rows per lane (16-byte load and store): a lane's
         // four bits sit at positions 4 l .. 4 l + 3 of its wave's 256-row string; the 16 lanes of a 64-bit word OR their nibbles together
@@ -166,7 +174,7 @@ namespace splahip {
                     *reinterpret_cast<uint4*>(r + row) = init4;
                     if (op_select == SPLAHIP_ALWAYS) nib = 0xFu;// (the mask is not read: 4 B per row less)
                     else {
-                        const uint4 m = *reinterpret_cast<const uint4*>(mask + row);
+                        const uint4 m = row == t0 ? m_pre : *reinterpret_cast<const uint4*>(mask + row);
                         nib = (eval_sel(op_select, from_bits<T>(m.x)) ? 1u : 0u) | (eval_sel(op_select, from_bits<T>(m.y)) ? 2u : 0u) |
                               (eval_sel(op_select, from_bits<T>(m.z)) ? 4u : 0u) | (eval_sel(op_select, from_bits<T>(m.w)) ? 8u : 0u);
                     }
@@ -206,9 +214,8 @@ namespace splahip {
                     mx     = max(mx, b[i]);
                 }
         };
-        const uint n4 = n_cols & ~3u;
-        for (uint j = (blockIdx.x * 256 + threadIdx.x) * 4; j < n4; j += gridDim.x * 1024) {
-            const uint4 x    = *reinterpret_cast<const uint4*>(v + j);
+        for (uint j = t0; j < n4; j += gridDim.x * 1024) {
+            const uint4 x    = j == t0 ? x_pre : *reinterpret_cast<const uint4*>(v + j);
             const uint  b[4] = {x.x, x.y, x.z, x.w};
             step(j, b, 4);
         }
