@@ -103,6 +103,8 @@ int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, const uint32
                                 uint32_t tile_chunks, void* stream);
 int splahip_csr_plan_cob_info(splahip_plan plan, uint32_t* n_tiles, uint32_t* n_chunks, uint32_t* n_multi, uint32_t* slots_per_range);
 int splahip_csr_plan_cob_layout(splahip_plan plan, uint32_t* n_ranges, uint32_t* n_hub_ranges, uint32_t* n_hub_rows, uint64_t* bytes);
+/* slots (rows) of a hub range and of a natural range of the copy (0 / 0 without one) */
+int splahip_csr_plan_cob_slots(splahip_plan plan, uint32_t* hub_slots, uint32_t* natural_slots);
 /* footprint: device bytes held for the matrix besides its CSR arrays — plan (work items + call workspace), sliced-ELL copy, column-ordered blocks (0: not built).
  * prefers_sell: 1 when splahip_mxv_masked runs this semiring on the sliced-ELL copy even beside the column-ordered blocks (the zero-family sparse-vector
  * forms, a BFS step): a host that builds copies on demand needs the +12 B per entry of the sliced-ELL copy only for these.                          */

@@ -162,13 +162,14 @@ namespace {
 
     // one workgroup (256 threads = 256 slots) per chunk
     __global__ __launch_bounds__(256) void cob_scatter_kernel(const unsigned long long* __restrict__ key, const uint32_t* __restrict__ val, const uint32_t* __restrict__ start,
-                                                              const uint32_t* __restrict__ chunk_first, uint32_t n_groups, uint32_t R, uint32_t col_bits,
-                                                              uint32_t win_bits, uint32_t* __restrict__ cr, uint32_t* __restrict__ ax, uint32_t* __restrict__ hdr,
+                                                              const uint32_t* __restrict__ chunk_first, uint32_t n_groups, uint32_t R_hub, uint32_t R_nat, uint32_t n_hub_ranges,
+                                                              uint32_t col_bits, uint32_t win_bits, uint32_t* __restrict__ cr, uint32_t* __restrict__ ax, uint32_t* __restrict__ hdr,
                                                               uint32_t* __restrict__ chunk_lines) {
         const uint32_t c = blockIdx.x;
         const uint32_t g = upper_bound_u32(chunk_first, n_groups + 1, c) - 1;// largest g with chunk_first[g] <= c (uniform)
         const uint32_t i = c - chunk_first[g];
         const uint32_t s0 = start[g], s1 = start[g + 1];
+        const uint32_t R  = (g >> win_bits) < n_hub_ranges ? R_hub : R_nat;// the group's range decides which slot value marks padding
         // memory position p = 4 * lane + j holds the chunk's sorted entry 64 * j + lane: a lane's 16-byte load brings its four slots, and the
         // wave's j-th gather instruction covers 64 consecutive sorted entries (ascending, neighbouring columns)
         const uint32_t src = s0 + i * kCobChunk + 64 * (threadIdx.x & 3) + (threadIdx.x >> 2);
@@ -327,6 +328,9 @@ namespace {
         a.touched    = touched;
         a.n_rows     = g->n_rows;
         a.R          = g->R;
+        a.Rn         = g->Rn;
+        a.n_hub_ranges = g->n_hub_ranges;
+        a.acc_stride = g->acc_stride;
         a.col_bits   = g->col_bits;
         a.pad_chunk  = g->n_chunks;
         a.accumulate = VXM ? 0u : tl_accumulate;
@@ -337,11 +341,11 @@ namespace {
             SPLAHIP_TRY(hipGetLastError());
         }
         const T init = from_bits<T>(init_bits);
-        if (!sc.n_tiles) return SPLAHIP_OK;
+        if (!sc.n_tiles) return fail(SPLAHIP_NOT_IMPLEMENTED, "the column-ordered blocks hold no schedule for this slice width");// (cob_serves says so beforehand)
         // the shared accumulators rest at the identity of the op_add that used them last: re-arm them when this call's differs
         const uint32_t n_multi_max = std::max(g->sched[0].n_multi, g->sched[1].n_multi);
         if (n_multi_max && (!g->acc_armed || g->acc_identity != cob_identity<T, ACC>())) {
-            hipLaunchKernelGGL(cob_fill32_kernel, dim3(256), dim3(256), 0, st, (size_t) n_multi_max * g->R, g->d_acc, cob_identity<T, ACC>());
+            hipLaunchKernelGGL(cob_fill32_kernel, dim3(256), dim3(256), 0, st, (size_t) n_multi_max * g->acc_stride, g->d_acc, cob_identity<T, ACC>());
             hipLaunchKernelGGL(cob_fill32_kernel, dim3(1), dim3(256), 0, st, (size_t) n_multi_max, g->d_ticket, 0u);
             SPLAHIP_TRY(hipGetLastError());
             g->acc_identity = cob_identity<T, ACC>();
@@ -355,7 +359,7 @@ namespace {
             if (g->half_groups) {
                 constexpr unsigned kHalf = 512;
                 SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kHalf, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kHalf, MODE>), dim3(sc.n_tiles), dim3(kHalf), ((size_t) g->R + kCobLdsExtra) * sizeof(typename CobSlice<T, ACC>::word), st, a,
+                hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kHalf, MODE>), dim3(sc.n_tiles), dim3(kHalf), sc.lds_bytes, st, a,
                                    static_cast<const T*>(v), static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
                 SPLAHIP_TRY(hipGetLastError());
                 launched = true;
@@ -363,13 +367,13 @@ namespace {
         }
         if (!launched) {
             SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), dim3(sc.n_tiles), dim3(kTpb), ((size_t) g->R + kCobLdsExtra) * sizeof(typename CobSlice<T, ACC>::word), st, a,
+            hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), dim3(sc.n_tiles), dim3(kTpb), sc.lds_bytes, st, a,
                                static_cast<const T*>(v), static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
             SPLAHIP_TRY(hipGetLastError());
         }
         if (g->hub_finish && g->n_hub_ranges) {
             const uint32_t n_slots = g->n_hub_ranges * g->R;
-            hipLaunchKernelGGL((cob_hub_finish_kernel<T, ACC, VXM>), dim3((n_slots + 255) / 256), dim3(256), 0, st, n_slots, g->d_acc, g->d_hub_row, static_cast<const T*>(mask),
+            hipLaunchKernelGGL((cob_hub_finish_kernel<T, ACC, VXM>), dim3((n_slots + 255) / 256), dim3(256), 0, st, n_slots, g->R, g->acc_stride, g->d_acc, g->d_hub_row, static_cast<const T*>(mask),
                                static_cast<T*>(r), touched, a.accumulate, DynBin(op_add), op_select, init);
             SPLAHIP_TRY(hipGetLastError());
         }
@@ -530,6 +534,14 @@ namespace splahip {
 
 }// namespace splahip
 
+namespace {
+    // library default for the natural ranges' slot count (see splahip_csr_plan_attach_cob)
+    uint32_t nat_slots_default(uint32_t R, bool explicit_bits) {
+        (void) explicit_bits;
+        return R;// (measured: 32704-slot natural ranges cost the fp32 call more in its tail than they save in gathers — profiles/r03_notes.md 7; opt-in by SPLAHIP_COB_NAT_SLOTS)
+    }
+}// namespace
+
 extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, uint32_t row_bits,
                                            uint32_t tile_chunks, void* stream) {
     SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
@@ -548,6 +560,13 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         R = row_bits ? (1u << row_bits) : 20224u;
     }
     SPLAHIP_REQUIRE(R % 64 == 0 && R >= 256 && R <= 20224, "slots per range must be a multiple of 64 in [256, 20224]");
+    // slots of a NATURAL range (the low-degree rows, in row order): at least R.  More rows per range = fewer ranges = fewer (range, line of v) pairs, and
+    // the natural ranges are where a scale-free matrix's gather traffic is (profiles/r03_notes.md 6).  A natural range's fp32 sum then lives in FLOAT
+    // words (compare-and-swap adds: its rows have few entries each, so neither the adds collide nor the sum needs the double), 32704 of them = 128 KB;
+    // 4-byte slices of that size run one workgroup per CU.  SPLAHIP_COB_NAT_SLOTS overrides (tests: 2 x R on small inputs).
+    uint32_t Rn = env_u32("SPLAHIP_COB_NAT_SLOTS", nat_slots_default(R, row_bits != 0));
+    if (Rn < R) Rn = R;
+    SPLAHIP_REQUIRE(Rn % 64 == 0 && Rn <= 32704, "natural slots per range must be a multiple of 64, at most 32704");
     if (tile_chunks == 0) tile_chunks = env_u32("SPLAHIP_COB_TILE_CHUNKS", 0);// 0: pieces are cut at range and share boundaries only
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
@@ -565,7 +584,6 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     g->n_cols   = n_cols;
     g->R        = R;
     g->col_bits = col_bits;
-    g->half_groups = 2 * ((size_t) R + kCobLdsExtra) * 8 <= 160 * 1024 && env_u32("SPLAHIP_COB_HALF_GROUPS", 1) != 0;
     // the hub ranges' row pass as a kernel of its own behind the main launch (mxv_cob.hpp: cob_hub_finish_kernel).  Measured with it / without: fp32 plus-times
     // R-MAT 22 154 - 156 / 162 - 166 us, R-MAT 23 322 - 330 / 321 - 331 us; int32 min-plus 189 / 195 and 302 / 319 us.  SPLAHIP_COB_HUB_FINISH=0: one launch
     g->hub_finish  = env_u32("SPLAHIP_COB_HUB_FINISH", 1) != 0;
@@ -613,7 +631,20 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         if (e != hipSuccess) return bail("hub rows");
         H = (uint32_t) std::min<uint64_t>(H, (uint64_t) max_hub_ranges * R);
         if (H < R / 8) H = 0;// not a skewed matrix: every row stays in its natural range
-    }
+        if (Rn > R) {// the longest row left to the natural ranges: the first one behind the hub rows in degree order
+            uint32_t longest = 0;
+            if (H < n_rows) e = hipMemcpy(&longest, deg_s + H, 4, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return bail("hub rows");
+            if (longest > env_u32("SPLAHIP_COB_NAT_MAX_DEGREE", 64)) Rn = R;
+        }
+    } else
+        Rn = R;
+    // (larger natural ranges keep an fp32 sum in float words, added in no fixed order: only where every natural row is short — <= 64 entries: a rounding error
+    // of at most 64 x 2^-24 of the sum of the magnitudes, next to the 1e-5 bar; the reference's own sequential fold is no closer — do the ranges grow.
+    // A matrix without hub rows, or with long rows left over behind 16 hub ranges, keeps ranges of R slots and double slices everywhere.)
+    g->Rn          = Rn;
+    g->acc_stride  = std::max(R, Rn);
+    g->half_groups = Rn == R && 2 * ((size_t) R + kCobLdsExtra) * 8 <= 160 * 1024 && env_u32("SPLAHIP_COB_HALF_GROUPS", 1) != 0;
     if (H && env_u32("SPLAHIP_COB_HUB_ROW_ORDER", 1)) {
         unsigned long long *key = nullptr, *key_s = nullptr;
         e                       = tmp.alloc(&key, H);
@@ -648,11 +679,11 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         e = hipMemcpyAsync(h_cnt8.data(), cnt8, h_cnt8.size(), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return bail("row counts");
-        const uint32_t span_cap = std::max(8u, env_u32("SPLAHIP_COB_SPAN_CAP", 8) * R);
+        const uint32_t span_cap = std::max(8u, env_u32("SPLAHIP_COB_SPAN_CAP", 8) * Rn);
         uint32_t       q = n_hub_ranges, used = 0, span = 0;
         nat_row0.push_back(0);
         for (size_t gi = 0; gi < h_cnt8.size(); ++gi) {
-            if (used + h_cnt8[gi] > R || span + 8 > span_cap) {
+            if (used + h_cnt8[gi] > Rn || span + 8 > span_cap) {
                 nat_row0.push_back((uint32_t) gi * 8);
                 ++q, used = 0, span = 0;
             }
@@ -728,16 +759,17 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     g->n_chunks = n_chunks;
 
     // 4: the packed streams
-    own(&g->d_cr, ((size_t) n_chunks + 1) * kCobChunk);// + one all-padding chunk (the main loop's steps beyond a piece's end walk it)
-    own(&g->d_ax, ((size_t) n_chunks + 1) * kCobChunk);
-    own(&g->d_hdr, (size_t) n_chunks + 1);
+    own(&g->d_cr, ((size_t) n_chunks + 2) * kCobChunk);// + two all-padding chunks (the main loop's steps beyond a piece's end walk one: hub / natural slot values)
+    own(&g->d_ax, ((size_t) n_chunks + 2) * kCobChunk);
+    own(&g->d_hdr, (size_t) n_chunks + 2);
     if (e != hipSuccess) return bail("hipMalloc");
     hipLaunchKernelGGL(cob_padchunk_kernel, dim3(1), dim3(256), 0, s, n_chunks, R, col_bits, g->d_cr, g->d_ax, g->d_hdr);
+    hipLaunchKernelGGL(cob_padchunk_kernel, dim3(1), dim3(256), 0, s, n_chunks + 1, Rn, col_bits, g->d_cr, g->d_ax, g->d_hdr);
     uint32_t* chunk_lines = nullptr;
     e                     = tmp.alloc(&chunk_lines, (size_t) n_chunks + 1);
     if (e != hipSuccess) return bail("scratch");
     if (n_chunks)
-        hipLaunchKernelGGL(cob_scatter_kernel, dim3(n_chunks), dim3(256), 0, s, key_s, val_s, start, chunk_first, n_groups, R, col_bits, win_bits, g->d_cr, g->d_ax, g->d_hdr,
+        hipLaunchKernelGGL(cob_scatter_kernel, dim3(n_chunks), dim3(256), 0, s, key_s, val_s, start, chunk_first, n_groups, R, Rn, n_hub_ranges, col_bits, win_bits, g->d_cr, g->d_ax, g->d_hdr,
                            chunk_lines);
     e = hipGetLastError();
     if (e != hipSuccess) return bail("scatter");
@@ -765,9 +797,13 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     uint32_t       max_multi = 0;
     for (int w = 0; w < 2 && e == hipSuccess; ++w) {
         splahip_cob_sched_s& sc     = g->sched[w];
-        const size_t         lds    = ((size_t) R + kCobLdsExtra) * (w ? 8 : 4);
+        // LDS of a workgroup: the larger of a hub slice and a natural slice.  8-byte schedule (fp32 PLUS): hub slices hold doubles; natural slices too when
+        // they are no larger than the hub ones, floats otherwise (mxv_cob.hpp: COB_FADD)
+        const size_t lds = w ? std::max(((size_t) R + kCobLdsExtra) * 8, ((size_t) Rn + kCobLdsExtra) * (Rn > R ? 4 : 8)) : ((size_t) Rn + kCobLdsExtra) * 4;
+        sc.lds_bytes     = (uint32_t) lds;
         const uint32_t       per_cu = (uint32_t) std::min<size_t>(env_u32("SPLAHIP_COB_PER_CU", 2), (160 * 1024) / lds);// 1024-thread workgroups: at most 2 per CU
         if (per_cu == 0) continue;                                                         // this slice width does not fit: not served
+        if (per_cu == 1 && 2 * lds <= 160 * 1024) sc.lds_bytes = 160 * 1024 / 2 + 1024;       // (one per CU asked for: ask for LDS a second workgroup cannot share)
         const uint32_t slots = cus * per_cu;
         // piece size in % of a slot's even share of the cost.  Smaller pieces balance the tail better, larger ones mean fewer partial slices to merge,
         // and with pieces of similar cost the COUNT matters: 2.2 x slots pieces run in three rounds.  So the candidates are tried on a model of the launch
@@ -899,9 +935,9 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         for (uint32_t t = 0; t < n_tiles; ++t)
             for (int k = 0; k < 4; ++k) sorted[4 * t + k] = tiles[4 * order_t[t] + k];
         if (std::getenv("SPLAHIP_COB_TRACE"))
-            std::fprintf(stderr, "[cob] schedule %d: R %u, %u hub rows in %u hub ranges + %u natural ranges; slots %u, cost %.1f M (%.1f %% gathers), piece <= %u %% of a share in %u size levels, %u pieces, "
+            std::fprintf(stderr, "[cob] schedule %d: R %u / %u, %u hub rows in %u hub ranges + %u natural ranges; slots %u, cost %.1f M (%.1f %% gathers), piece <= %u %% of a share in %u size levels, %u pieces, "
                                  "%u ranges in several pieces, modelled makespan %.1f us (even: %.1f)\n",
-                         w, R, H, n_hub_ranges, n_nat, slots, cost_pre[n_chunks] / 1e8, 100.0 - 100.0 * 1600.0 * n_chunks / std::max<uint64_t>(1, cost_pre[n_chunks]), share_pct, levels, n_tiles, n_multi,
+                         w, R, Rn, H, n_hub_ranges, n_nat, slots, cost_pre[n_chunks] / 1e8, 100.0 - 100.0 * 1600.0 * n_chunks / std::max<uint64_t>(1, cost_pre[n_chunks]), share_pct, levels, n_tiles, n_multi,
                          makespan() * 95e-3 / 1600, cost_pre[n_chunks] * 95e-3 / 1600 / slots);
         sc.n_tiles = n_tiles;
         sc.n_multi = n_multi;
@@ -912,7 +948,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         if (e == hipSuccess) e = hipMemcpyAsync(sc.d_ranges, ranges.data(), 4 * ranges.size(), hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);// the vectors go out of scope
     }
-    own(&g->d_acc, (size_t) max_multi * R);
+    own(&g->d_acc, (size_t) max_multi * g->acc_stride);
     own(&g->d_ticket, (size_t) max_multi + 4);
     own(&g->d_vbits, ((size_t) n_cols + 255) / 256 * 8 + 2);// every wave of cob_vbits_kernel writes its two words
     if (e != hipSuccess) return bail("schedule upload");
@@ -952,6 +988,14 @@ extern "C" int splahip_csr_plan_cob_layout(splahip_plan plan, uint32_t* n_ranges
     if (n_hub_ranges) *n_hub_ranges = g ? g->n_hub_ranges : 0;
     if (n_hub_rows) *n_hub_rows = g ? g->n_hub_rows : 0;
     if (bytes) *bytes = g ? (uint64_t) g->bytes : 0;
+    return SPLAHIP_OK;
+}
+
+extern "C" int splahip_csr_plan_cob_slots(splahip_plan plan, uint32_t* hub_slots, uint32_t* natural_slots) {
+    SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
+    const splahip_cob_s* g = plan->cob;
+    if (hub_slots) *hub_slots = g ? g->R : 0;
+    if (natural_slots) *natural_slots = g ? g->Rn : 0;
     return SPLAHIP_OK;
 }
 

@@ -78,6 +78,8 @@ namespace splahip {
                         COB_XOR,
                         COB_LOR, // slice holds the truth value 0 / 1 (identity 0)
                         COB_LAND,// slice holds the truth value 0 / 1 (identity 1)
+                        COB_FADD,// fp32 sum in a FLOAT slice, added with a compare-and-swap loop: the natural ranges of an fp32 PLUS call when they hold more slots
+                                 // than a double slice has room for (never picked by cob_acc_kind: the kernel of COB_ADD on float switches to it per piece)
                         COB_NONE };
 
     // which LDS atomic serves (op_add, type); COB_NONE: the cob form cannot serve it
@@ -115,7 +117,7 @@ namespace splahip {
     // bits of the fold identity the slice starts from
     template<typename T, int ACC>
     __host__ __device__ constexpr uint32_t cob_identity() {
-        if constexpr (ACC == COB_ADD) return std::is_same<T, float>::value ? 0x80000000u : 0u;// -0.0f: x + -0.0f == x for every x, +0.0f and -0.0f included
+        if constexpr (ACC == COB_ADD || ACC == COB_FADD) return std::is_same<T, float>::value ? 0x80000000u : 0u;// -0.0f: x + -0.0f == x for every x, +0.0f and -0.0f included
         else if constexpr (ACC == COB_MIN)
             return std::is_same<T, uint32_t>::value ? 0xFFFFFFFFu : 0x7FFFFFFFu;// float: the largest key (the bits of a NaN: no product has them)
         else if constexpr (ACC == COB_MAX)
@@ -134,7 +136,14 @@ namespace splahip {
         *reinterpret_cast<volatile uint32_t*>(slot) = to_bits(p);// DIAGNOSTIC BUILD: a plain LDS store where the atomic would be
         return;
 #endif
-        if constexpr (ACC == COB_ADD) {
+        if constexpr (ACC == COB_FADD) {// (one word at a time: the bit forms; the value form batches four, cob_accumulate4)
+            uint32_t old = *reinterpret_cast<volatile uint32_t*>(slot);
+            for (;;) {
+                uint32_t seen = old;
+                if (__hip_atomic_compare_exchange_strong(slot, &seen, to_bits(from_bits<float>(old) + (float) p), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                old = seen;
+            }
+        } else if constexpr (ACC == COB_ADD) {
             (void) __hip_atomic_fetch_add(slot, to_bits(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);// int / uint (fp32 sums live in a double slice: cob_accumulate4)
         } else if constexpr (ACC == COB_MIN) {
             if constexpr (std::is_same<T, int32_t>::value) (void) __hip_atomic_fetch_min(reinterpret_cast<int32_t*>(slot), p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -187,6 +196,33 @@ namespace splahip {
             (void) __hip_atomic_fetch_add(s_acc + r2, (double) p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             (void) __hip_atomic_fetch_add(s_acc + r3, (double) p3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
+        } else if constexpr (ACC == COB_FADD) {
+            // four compare-and-swap adds in flight (one read round trip, one swap round trip); a swap that lost — two lanes of the wave on one row, or another
+            // wave in between — is retried on its own.  20 - 26 cycles per wave instruction on uniformly spread rows, which is what a natural range's
+            // low-degree rows are (profiles/r02_lds_atomic_bench.txt; under a skewed row stream 110: the hub ranges keep their double slice and ds_add_f64)
+            uint32_t* const q[4] = {s_acc + r0, s_acc + r1, s_acc + r2, s_acc + r3};
+            const float     x[4] = {(float) p0, (float) p1, (float) p2, (float) p3};
+            uint32_t        o[4], seen[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = *reinterpret_cast<volatile uint32_t*>(q[j]);
+            bool again = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                seen[j] = o[j];
+                if (!__hip_atomic_compare_exchange_strong(q[j], &seen[j], to_bits(from_bits<float>(o[j]) + x[j]), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) again = true;
+            }
+            if (again) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (seen[j] != o[j]) {
+                        uint32_t old = seen[j];
+                        for (;;) {
+                            uint32_t sn = old;
+                            if (__hip_atomic_compare_exchange_strong(q[j], &sn, to_bits(from_bits<float>(old) + x[j]), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                            old = sn;
+                        }
+                    }
+            }
         } else {
             cob_accumulate<T, ACC>(s_acc + r0, p0);
             cob_accumulate<T, ACC>(s_acc + r1, p1);
@@ -199,7 +235,7 @@ namespace splahip {
     // monoid as a memory-side atomic (agent scope, no return value)
     template<typename T, int ACC>
     __device__ __forceinline__ void cob_merge_global(uint32_t* acc, uint32_t w) {
-        if constexpr (ACC == COB_ADD) {
+        if constexpr (ACC == COB_ADD || ACC == COB_FADD) {
             if constexpr (std::is_same<T, float>::value) unsafeAtomicAdd(reinterpret_cast<float*>(acc), from_bits<float>(w));// global_atomic_add_f32
             else
                 (void) __hip_atomic_fetch_add(acc, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -223,7 +259,7 @@ namespace splahip {
     // 15-way switch per ROW, and a natural range's row pass is instruction-bound on ONE CU (160 K rows at ~20 instructions each ran 28 - 34 us)
     template<int ACC>
     constexpr int cob_op_of() {
-        return ACC == COB_ADD ? SPLAHIP_PLUS : ACC == COB_MIN ? SPLAHIP_MIN : ACC == COB_MAX ? SPLAHIP_MAX : ACC == COB_OR ? SPLAHIP_BOR : ACC == COB_AND ? SPLAHIP_BAND
+        return (ACC == COB_ADD || ACC == COB_FADD) ? SPLAHIP_PLUS : ACC == COB_MIN ? SPLAHIP_MIN : ACC == COB_MAX ? SPLAHIP_MAX : ACC == COB_OR ? SPLAHIP_BOR : ACC == COB_AND ? SPLAHIP_BAND
                : ACC == COB_XOR ? SPLAHIP_BXOR : ACC == COB_LOR ? SPLAHIP_LOR : SPLAHIP_LAND;
     }
     // the row's result from its accumulated slice word: add(init, acc); LOR / LAND slices hold a truth value, fp32 MIN / MAX slices a key
@@ -256,9 +292,12 @@ namespace splahip {
         uint32_t*       ticket; // n_multi arrival counters, 0 between calls
         uint32_t*       touched;// VXM only: per output index, 1 = selected and at least one product
         uint32_t        n_rows;
-        uint32_t        R;       // slots per range (a multiple of 4)
+        uint32_t        R;       // slots of a hub range (a multiple of 64)
+        uint32_t        Rn;      // slots of a natural range (ranges >= n_hub_ranges); Rn > R: the natural ranges of an fp32 sum keep FLOAT words (COB_FADD)
+        uint32_t        n_hub_ranges;
+        uint32_t        acc_stride;// words between two shared accumulators: max(R, Rn)
         uint32_t        col_bits;
-        uint32_t        pad_chunk;// an all-padding chunk behind the last real one
+        uint32_t        pad_chunk;// two all-padding chunks behind the last real one: pad_chunk for a hub piece (slot values R + lane), pad_chunk + 1 for a natural one (Rn + lane)
         const uint32_t* vbits;     // MODE 1 / 2: bit c = v[c] != 0 (n_cols bits)
         uint32_t        x_uniform; // MODE 2: the one value word of the matrix
         uint32_t        accumulate;// 1: r already holds the fold of another column part of the same rows (1-D row decomposition, dist.hip): a selected
@@ -422,7 +461,7 @@ namespace splahip {
     template<typename T, int ACC, bool VXM, unsigned TPB, bool TIGHT>
     __device__ __noinline__ void cob_piece_end(unsigned char* s_raw, const CobTile t, const CobRange rg, const uint16_t* __restrict__ slot16, const uint32_t* __restrict__ hub_row,
                                                uint32_t* __restrict__ acc, uint32_t* __restrict__ ticket, uint32_t* __restrict__ touched, uint32_t n_rows, uint32_t R,
-                                               uint32_t accumulate, const T* __restrict__ mask, T* __restrict__ r, DynBin add, int op_select, T init) {
+                                               uint32_t acc_stride, uint32_t accumulate, const T* __restrict__ mask, T* __restrict__ r, DynBin add, int op_select, T init) {
         using word = typename CobSlice<T, ACC>::word;
         constexpr bool kWide = sizeof(word) == 8;
         word* const    s_acc = reinterpret_cast<word*>(s_raw);
@@ -451,7 +490,7 @@ namespace splahip {
         bool            merged  = false;
         if (t.multi != kCobNoSlab) {
             // add the slice into the range's shared accumulator (words still at the identity hold nothing), then take a ticket
-            uint32_t* const gacc = acc + (size_t) t.multi * R;
+            uint32_t* const gacc = acc + (size_t) t.multi * acc_stride;
             for (uint32_t i = threadIdx.x; i < R; i += TPB) {
                 const uint32_t w = own_word(i);
                 if (w != cob_identity<T, ACC>()) cob_merge_global<T, ACC>(gacc + i, w);
@@ -551,8 +590,12 @@ namespace splahip {
         extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
         word* const        s_acc = reinterpret_cast<word*>(s_raw);
         constexpr unsigned NW    = TPB / kWave;
-        const uint32_t     R     = a.R;
         const CobTile      t     = a.tiles[blockIdx.x];// one piece per workgroup, launched largest piece first
+        const bool         nat   = t.range >= a.n_hub_ranges;
+        const uint32_t     R     = nat ? a.Rn : a.R;
+        // fp32 PLUS over a natural range that holds more slots than a double slice has room for: float words, compare-and-swap adds (COB_FADD)
+        [[maybe_unused]] const bool narrow = kWide && nat && a.Rn > a.R;
+        uint32_t* const    s_acc32 = reinterpret_cast<uint32_t*>(s_raw);
 #ifdef SPLAHIP_COB_TIMING
         if (threadIdx.x == 0 && blockIdx.x < 8192) {
             uint32_t xcc, hwid;
@@ -568,8 +611,9 @@ namespace splahip {
         {
             const uint32_t id = cob_identity<T, ACC>();
             uint4*         s4 = reinterpret_cast<uint4*>(s_raw);
-            const uint4    z  = kWide ? make_uint4(0u, id, 0u, id) : make_uint4(id, id, id, id);// a double's high word carries the sign of -0.0
-            for (uint32_t i = threadIdx.x; i < (R + kCobSpare) * sizeof(word) / 16; i += TPB) s4[i] = z;// + the spare words the padding slots add into
+            const uint4    z  = kWide && !narrow ? make_uint4(0u, id, 0u, id) : make_uint4(id, id, id, id);// a double's high word carries the sign of -0.0
+            const uint32_t n16 = (R + kCobSpare) * (narrow ? 4u : (uint32_t) sizeof(word)) / 16;
+            for (uint32_t i = threadIdx.x; i < n16; i += TPB) s4[i] = z;// + the spare words the padding slots add into
         }
         __syncthreads();
 #ifdef SPLAHIP_COB_TIMING
@@ -593,7 +637,8 @@ namespace splahip {
         // spare word behind the slice.
         const uint32_t steps    = ((t.n_chunks + NW - 1) / NW + 3) & ~3u;
         const uint32_t c0       = threadIdx.x / kWave;
-        auto           chunk_of = [&](uint32_t ci) { return ci < t.n_chunks ? t.first_chunk + ci : a.pad_chunk; };
+        const uint32_t pad_chunk = a.pad_chunk + (nat ? 1u : 0u);
+        auto           chunk_of = [&](uint32_t ci) { return ci < t.n_chunks ? t.first_chunk + ci : pad_chunk; };
         u4             E[4], X[4];
         uint32_t       B[4];
         T              G[2][4];
@@ -660,12 +705,28 @@ namespace splahip {
                 if (m & 2u) cob_accumulate<T, ACC>(s_acc + (e.y >> a.col_bits), mult(from_bits<T>(x.y), g1));
                 if (m & 4u) cob_accumulate<T, ACC>(s_acc + (e.z >> a.col_bits), mult(from_bits<T>(x.z), g2));
                 if (m & 8u) cob_accumulate<T, ACC>(s_acc + (e.w >> a.col_bits), mult(from_bits<T>(x.w), g3));
-            } else if constexpr (VXM)
+            } else if constexpr (VXM) {
+                if constexpr (kWide) {
+                    if (narrow) {
+                        cob_accumulate4<T, COB_FADD>(s_acc32, e.x >> a.col_bits, e.y >> a.col_bits, e.z >> a.col_bits, e.w >> a.col_bits, mult(g0, from_bits<T>(x.x)),
+                                                     mult(g1, from_bits<T>(x.y)), mult(g2, from_bits<T>(x.z)), mult(g3, from_bits<T>(x.w)));
+                        return;
+                    }
+                }
                 cob_accumulate4<T, ACC>(s_acc, e.x >> a.col_bits, e.y >> a.col_bits, e.z >> a.col_bits, e.w >> a.col_bits, mult(g0, from_bits<T>(x.x)),
                                         mult(g1, from_bits<T>(x.y)), mult(g2, from_bits<T>(x.z)), mult(g3, from_bits<T>(x.w)));
-            else
+            }
+            else {
+                if constexpr (kWide) {
+                    if (narrow) {
+                        cob_accumulate4<T, COB_FADD>(s_acc32, e.x >> a.col_bits, e.y >> a.col_bits, e.z >> a.col_bits, e.w >> a.col_bits, mult(from_bits<T>(x.x), g0),
+                                                     mult(from_bits<T>(x.y), g1), mult(from_bits<T>(x.z), g2), mult(from_bits<T>(x.w), g3));
+                        return;
+                    }
+                }
                 cob_accumulate4<T, ACC>(s_acc, e.x >> a.col_bits, e.y >> a.col_bits, e.z >> a.col_bits, e.w >> a.col_bits, mult(from_bits<T>(x.x), g0),
                                         mult(from_bits<T>(x.y), g1), mult(from_bits<T>(x.z), g2), mult(from_bits<T>(x.w), g3));
+            }
         };
         // prologue: streams of steps 0, 1, 2; (bits of steps 0 and 1;) gathers of step 0
         load_set(0, c0);
@@ -696,8 +757,18 @@ namespace splahip {
 #ifdef SPLAHIP_COB_TIMING
         if (threadIdx.x == 0 && blockIdx.x < 8192) g_cob_t[2][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
-        cob_piece_end<T, ACC, VXM, TPB, (cob_min_waves<T, ACC, MODE>() > 4u)>(s_raw, t, a.ranges[t.range], a.slot16, a.hub_row, a.acc, a.ticket, a.touched, a.n_rows, R, a.accumulate,
-                                                                              mask, r, add, op_select, init);
+        if constexpr (kWide) {
+            if (narrow) {
+                cob_piece_end<T, COB_FADD, VXM, TPB, false>(s_raw, t, a.ranges[t.range], a.slot16, a.hub_row, a.acc, a.ticket, a.touched, a.n_rows, R, a.acc_stride, a.accumulate, mask,
+                                                            r, add, op_select, init);
+#ifdef SPLAHIP_COB_TIMING
+                if (threadIdx.x == 0 && blockIdx.x < 8192) g_cob_t[3][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
+                return;
+            }
+        }
+        cob_piece_end<T, ACC, VXM, TPB, (cob_min_waves<T, ACC, MODE>() > 4u)>(s_raw, t, a.ranges[t.range], a.slot16, a.hub_row, a.acc, a.ticket, a.touched, a.n_rows, R, a.acc_stride,
+                                                                              a.accumulate, mask, r, add, op_select, init);
 #ifdef SPLAHIP_COB_TIMING
         if (threadIdx.x == 0 && blockIdx.x < 8192) g_cob_t[3][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -707,13 +778,15 @@ namespace splahip {
     // ONE workgroup — the range's last arriver — issues them at the very end of the launch, ~2 us when every CU takes a share.  Thread = hub slot: read the
     // merged accumulator word (plain load: the launch boundary is the release / acquire), re-arm it, finish the row.
     template<typename T, int ACC, bool VXM>
-    __global__ __launch_bounds__(256) void cob_hub_finish_kernel(uint32_t n_slots, uint32_t* __restrict__ acc, const uint32_t* __restrict__ hub_row, const T* __restrict__ mask,
-                                                                 T* __restrict__ r, uint32_t* __restrict__ touched, uint32_t accumulate, DynBin add, int op_select, T init) {
+    __global__ __launch_bounds__(256) void cob_hub_finish_kernel(uint32_t n_slots, uint32_t R, uint32_t acc_stride, uint32_t* __restrict__ acc, const uint32_t* __restrict__ hub_row,
+                                                                 const T* __restrict__ mask, T* __restrict__ r, uint32_t* __restrict__ touched, uint32_t accumulate, DynBin add,
+                                                                 int op_select, T init) {
         const uint32_t i = blockIdx.x * 256 + threadIdx.x;
         if (i >= n_slots) return;
-        const uint32_t w   = acc[i];
+        const size_t   ia  = (size_t) (i / R) * acc_stride + i % R;// accumulator q belongs to hub range q
+        const uint32_t w   = acc[ia];
         const uint32_t row = hub_row[i];
-        acc[i]             = cob_identity<T, ACC>();
+        acc[ia]            = cob_identity<T, ACC>();
         if (row == 0xFFFFFFFFu) return;
         const bool sel = op_select == SPLAHIP_ALWAYS || eval_sel<T>(op_select, mask[row]);
         if constexpr (VXM) {

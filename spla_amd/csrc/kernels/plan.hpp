@@ -57,11 +57,14 @@ struct splahip_cob_sched_s {// one work schedule: the pieces (consecutive chunks
     uint32_t  n_multi   = 0;// ranges cut into several pieces (each has a shared accumulator + a ticket)
     uint32_t* d_tiles   = nullptr;// n_tiles x CobTile
     uint32_t* d_ranges  = nullptr;// n_ranges x CobRange (n_pieces differs between the schedules)
+    uint32_t  lds_bytes = 0;// dynamic LDS of a workgroup: the larger of a hub slice and a natural slice + the spare words
 };
 struct splahip_cob_s {
     uint32_t  n_rows   = 0;
     uint32_t  n_cols   = 0;
     uint32_t  R        = 0;// slots per range (the range's result slice lives in LDS)
+    uint32_t  Rn       = 0;// slots of a natural range (>= R; > R: an fp32 sum keeps the natural ranges in float words)
+    uint32_t  acc_stride = 0;// words between two shared accumulators: max(R, Rn)
     bool      hub_finish  = false;// the hub ranges' row pass runs as a kernel of its own behind the main launch (SPLAHIP_COB_HUB_FINISH=1)
     bool      half_groups = false;// two double slices fit a CU's LDS: the fp32 PLUS forms run 8-wave workgroups, two per CU
     uint32_t  col_bits = 0;// a chunk's columns are stored relative to its 2^col_bits-column window

@@ -68,7 +68,9 @@ class CsrPlan:
         _lib.call("splahip_csr_plan_cob_info", self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
         nr, nh, hr, by = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
         _lib.call("splahip_csr_plan_cob_layout", self._h, C.byref(nr), C.byref(nh), C.byref(hr), C.byref(by))
-        self.cob = {"tiles": a.value, "chunks": b.value, "ranges_in_pieces": c.value, "slots_per_range": d.value, "ranges": nr.value,
+        hs, ns = C.c_uint32(), C.c_uint32()
+        _lib.call("splahip_csr_plan_cob_slots", self._h, C.byref(hs), C.byref(ns))
+        self.cob = {"tiles": a.value, "chunks": b.value, "ranges_in_pieces": c.value, "slots_per_range": d.value, "natural_slots": ns.value, "ranges": nr.value,
                     "hub_ranges": nh.value, "hub_rows": hr.value, "bytes": by.value} if a.value else None
         return self.cob
 

@@ -39,8 +39,10 @@ def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, 
             plan.attach_cob(n_cols, dAp, dAj, dAx)
         elif form == "cob-small":  # ranges of 256 slots, pieces of 2 chunks, every row of degree >= 3 a hub candidate: hub and natural ranges, column
             os.environ["SPLAHIP_COB_HUB_MIN_DEGREE"] = "3"  # windows, ranges in several pieces (shared accumulators, tickets) even on small inputs
+            os.environ["SPLAHIP_COB_NAT_SLOTS"] = "512"     # natural ranges twice the hub ranges' size: an fp32 sum keeps them in float words (COB_FADD)
             plan.attach_cob(n_cols, dAp, dAj, dAx, row_bits=8, tile_chunks=2)
             os.environ.pop("SPLAHIP_COB_HUB_MIN_DEGREE")
+            os.environ.pop("SPLAHIP_COB_NAT_SLOTS")
         r = torch.empty(n_rows, dtype=kernels.torch_dtype(t), device="cuda")
         if junk is not None:
             r.fill_(junk)
