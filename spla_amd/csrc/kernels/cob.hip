@@ -325,6 +325,7 @@ namespace {
         a.hub_row    = g->d_hub_row;
         a.acc        = g->d_acc;
         a.ticket     = g->d_ticket;
+        a.fin        = g->d_ticket + (g->ticket_words - 32);
         a.touched    = touched;
         a.n_rows     = g->n_rows;
         a.R          = g->R;
@@ -346,7 +347,7 @@ namespace {
         const uint32_t n_multi_max = std::max(g->sched[0].n_multi, g->sched[1].n_multi);
         if (n_multi_max && (!g->acc_armed || g->acc_identity != cob_identity<T, ACC>())) {
             hipLaunchKernelGGL(cob_fill32_kernel, dim3(256), dim3(256), 0, st, (size_t) n_multi_max * g->acc_stride, g->d_acc, cob_identity<T, ACC>());
-            hipLaunchKernelGGL(cob_fill32_kernel, dim3(1), dim3(256), 0, st, (size_t) n_multi_max, g->d_ticket, 0u);
+            hipLaunchKernelGGL(cob_fill32_kernel, dim3(1), dim3(256), 0, st, (size_t) g->ticket_words, g->d_ticket, 0u);
             SPLAHIP_TRY(hipGetLastError());
             g->acc_identity = cob_identity<T, ACC>();
             g->acc_armed    = true;
@@ -371,7 +372,7 @@ namespace {
                                static_cast<const T*>(v), static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
             SPLAHIP_TRY(hipGetLastError());
         }
-        if (g->hub_finish && g->n_hub_ranges) {
+        if (g->hub_finish == 1 && g->n_hub_ranges) {
             const uint32_t n_slots = g->n_hub_ranges * g->R;
             hipLaunchKernelGGL((cob_hub_finish_kernel<T, ACC, VXM>), dim3((n_slots + 255) / 256), dim3(256), 0, st, n_slots, g->R, g->acc_stride, g->d_acc, g->d_hub_row, static_cast<const T*>(mask),
                                static_cast<T*>(r), touched, a.accumulate, DynBin(op_add), op_select, init);
@@ -586,7 +587,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     g->col_bits = col_bits;
     // the hub ranges' row pass as a kernel of its own behind the main launch (mxv_cob.hpp: cob_hub_finish_kernel).  Measured with it / without: fp32 plus-times
     // R-MAT 22 154 - 156 / 162 - 166 us, R-MAT 23 322 - 330 / 321 - 331 us; int32 min-plus 189 / 195 and 302 / 319 us.  SPLAHIP_COB_HUB_FINISH=0: one launch
-    g->hub_finish  = env_u32("SPLAHIP_COB_HUB_FINISH", 1) != 0;
+    g->hub_finish  = std::min(2u, env_u32("SPLAHIP_COB_HUB_FINISH", 1));
     hipError_t e    = hipSuccess;
     auto       bail = [&](const char* what) {
         cob_release(g);
@@ -609,7 +610,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     own(&g->d_slot16, (size_t) n_rows8 + 8);
     if (e != hipSuccess) return bail("scratch");
     e = hipMemsetAsync(g->d_slot16, 0, sizeof(uint16_t) * ((size_t) n_rows8 + 8), s);// no row is a hub yet
-    const uint32_t max_hub_ranges = env_u32("SPLAHIP_COB_HUB_RANGES", 16);
+    const uint32_t max_hub_ranges = std::min(32u, env_u32("SPLAHIP_COB_HUB_RANGES", 16));
     // hub candidates: degree >= max(16, 2 x average); SPLAHIP_COB_HUB_MIN_DEGREE sets the threshold itself (tests: hub ranges on small inputs)
     const uint32_t thr            = env_u32("SPLAHIP_COB_HUB_MIN_DEGREE", std::max<uint32_t>(16, (uint32_t) (2ull * nnz / n_rows)));
     uint32_t       H              = 0;
@@ -818,6 +819,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         uint32_t              n_multi = 0;
         // levels > 1: TAPERED pieces — of a range's cost the first 4/7 go into pieces of size a, the next 2/7 into pieces of a / 2, the last 1/7 into pieces of a / 4
         // (levels = 3; 2/3 + 1/3 for levels = 2): launched dearest first, the rounds end at a, 1.5 a, 1.75 a and the tail is made of small pieces
+        const uint32_t fin_slots = std::max(256u, (env_u32("SPLAHIP_COB_FIN_SLOTS", 2560) + 63u) & ~63u);// hub slots per finisher workgroup (in-kernel finishers)
         auto cut = [&](uint32_t share_pct, uint32_t levels) {
             const uint64_t share = std::max<uint64_t>(1, (cost_pre[n_chunks] + slots - 1) / slots * share_pct / 100);
             tiles.clear(), cost.clear();
@@ -867,7 +869,10 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
                 if (hub && g->hub_finish) {// every piece merges, none runs the row pass (cob_hub_finish_kernel): accumulator q belongs to hub range q
                     for (uint32_t t = first_tile; t < first_tile + pieces; ++t) tiles[4 * (size_t) t + 3] = n_multi, cost[t] += 59000;
                     ++n_multi;
-                    ranges[4 * (size_t) q + 0] = row0, ranges[4 * (size_t) q + 1] = row1, ranges[4 * (size_t) q + 2] = q * R, ranges[4 * (size_t) q + 3] = kCobNoLast;
+                    // (in-kernel finishers: row0 = the tickets they wait for, row1 = how many of them share the range)
+                    const uint32_t hub_slots = std::min(R, H - q * R);
+                    ranges[4 * (size_t) q + 0] = g->hub_finish == 2 ? pieces : 0u, ranges[4 * (size_t) q + 1] = g->hub_finish == 2 ? (hub_slots + fin_slots - 1) / fin_slots : 0u;
+                    ranges[4 * (size_t) q + 2] = q * R, ranges[4 * (size_t) q + 3] = kCobNoLast;
                     continue;
                 }
                 if (pieces > 1) {
@@ -937,12 +942,18 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         std::vector<uint32_t>       sorted(tiles.size());
         for (uint32_t t = 0; t < n_tiles; ++t)
             for (int k = 0; k < 4; ++k) sorted[4 * t + k] = tiles[4 * order_t[t] + k];
+        uint32_t n_fin = 0;
+        if (g->hub_finish == 2)// the finishers of the hub ranges, behind every piece (mxv_cob.hpp: cob_hub_finisher)
+            for (uint32_t q = 0; q < n_hub_ranges; ++q) {
+                const uint32_t hub_slots = std::min(R, H - q * R);
+                for (uint32_t f0 = 0; f0 < hub_slots; f0 += fin_slots, ++n_fin) sorted.insert(sorted.end(), {q * R + f0, std::min(fin_slots, hub_slots - f0), kCobFinisher, q});
+            }
         if (std::getenv("SPLAHIP_COB_TRACE"))
             std::fprintf(stderr, "[cob] schedule %d: R %u / %u, %u hub rows in %u hub ranges + %u natural ranges; slots %u, cost %.1f M (%.1f %% gathers), piece <= %u %% of a share in %u size levels, %u pieces, "
                                  "%u ranges in several pieces, modelled makespan %.1f us (even: %.1f)\n",
                          w, R, Rn, H, n_hub_ranges, n_nat, slots, cost_pre[n_chunks] / 1e8, 100.0 - 100.0 * 1600.0 * n_chunks / std::max<uint64_t>(1, cost_pre[n_chunks]), share_pct, levels, n_tiles, n_multi,
                          makespan() * 95e-3 / 1600, cost_pre[n_chunks] * 95e-3 / 1600 / slots);
-        sc.n_tiles = n_tiles;
+        sc.n_tiles = n_tiles + n_fin;
         sc.n_multi = n_multi;
         max_multi  = std::max(max_multi, n_multi);
         own(&sc.d_tiles, sorted.size());
@@ -952,7 +963,8 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         if (e == hipSuccess) e = hipStreamSynchronize(s);// the vectors go out of scope
     }
     own(&g->d_acc, (size_t) max_multi * g->acc_stride);
-    own(&g->d_ticket, (size_t) max_multi + 4);
+    g->ticket_words = max_multi + 4 + 32;
+    own(&g->d_ticket, (size_t) g->ticket_words);
     own(&g->d_vbits, ((size_t) n_cols + 255) / 256 * 8 + 2);// every wave of cob_vbits_kernel writes its two words
     if (e != hipSuccess) return bail("schedule upload");
     {// one value word in the whole matrix?  (the sparse-vector form then skips the value stream)
