@@ -54,7 +54,7 @@ def _line(metric, unit, value, args, ms, dtype, config, roofline, extra=None):
 
 
 def _roof(alg_bytes, ms, kernel, pmc=None):
-    """`pmc`: name of the committed counter pass of this workload (profiles/r02_pmc_<pmc>.json, written by tools/gpu_pmc_r02*.sh in
+    """`pmc`: name of the committed counter pass of this workload (profiles/r03_pmc_<pmc>.json or r02_pmc_<pmc>.json, written by tools/gpu_pmc_r0*.sh in
     separate rocprofv3 --pmc runs of the same command): its per-call fabric traffic becomes `traffic` (a builder-side figure, like
     bench.py's pmc_traffic.json — counters need their own pass)."""
     gbs = alg_bytes / (ms * 1e-3) / 1e9
@@ -63,7 +63,9 @@ def _roof(alg_bytes, ms, kernel, pmc=None):
     if pmc:
         import json
         from pathlib import Path
-        f = Path(__file__).resolve().parent / "profiles" / f"r02_pmc_{pmc}.json"
+        f = Path(__file__).resolve().parent / "profiles" / f"r03_pmc_{pmc}.json"
+        if not f.exists():  # (a workload whose kernels did not change since round 2 keeps that round's pass; the file name is printed as traffic_source)
+            f = Path(__file__).resolve().parent / "profiles" / f"r02_pmc_{pmc}.json"
         try:
             per_call = json.loads(f.read_text()).get("_per_call")
             if per_call:

@@ -93,8 +93,9 @@ int splahip_csr_plan_sell_values(splahip_plan plan, int* uniform, uint32_t* bits
  * MAX stay bit-identical to the reference; fp32 PLUS folds in column-block order, in double, rounded once per row and piece (1e-5 relative) and
  * is NOT bit-reproducible from run to run (the arrival order of the atomics differs) — the CSR kernels are: SPLAHIP_COB=0 keeps every call on them.
  * row_bits: 0 = the library's R (20224 slots: a double slice of that many rows fills a CU's LDS), else R = 2^row_bits, 8..14; tile_chunks: 0 = a
- * range larger than one workgroup slot's share of the chunks is cut into equal pieces that meet in a shared accumulator (memory-side atomics, the
- * last piece to arrive finishes the rows); > 0 = pieces of at most that many 256-entry chunks (tests: many pieces on small inputs).  The copy holds
+ * range dearer than one workgroup slot's share of the launch's memory requests is cut into pieces of three size levels that meet in a shared
+ * accumulator (memory-side atomics; a natural range's last piece to arrive finishes its rows, the hub ranges' rows are finished by a small second
+ * launch); > 0 = pieces of at most that many 256-entry chunks (tests: many pieces on small inputs).  One 16-wave workgroup per CU.  The copy holds
  * the VALUES: rebuild it when Aj or Ax change.  A hypersparse matrix (more (range, column window) groups than nnz / 512) is left without a copy.
  * One call at a time per plan: the shared accumulators, tickets and the per-call bitmap of v belong to the plan.
  * Blocks.  cob_info: workgroups, chunks, ranges cut into several pieces, slots per range (all 0 when no copy was built);

@@ -36,3 +36,4 @@ print(f"{'calls':>6} {'avg us':>10} {'total ms':>10} {'%':>6}  name")
 for r in rows[:40]:
     print(f"{int(r['Calls']):6d} {float(r['AverageNs']) / 1e3:10.2f} {float(r['TotalDurationNs']) / 1e6:10.2f} {float(r['Percentage']):6.2f}  {r['Name'][:150]}")
 PY
+t=$(ls "$R"/gpurun_out/prof_r03/*/*kernel_trace.csv 2>/dev/null | tail -1); python3 "$R/tools/cob_trace_groups.py" "$t" | tee -a "$R/gpurun_out/r03_rocprof_kernel_stats.txt"
