@@ -538,8 +538,8 @@ namespace splahip {
 namespace {
     // library default for the natural ranges' slot count (see splahip_csr_plan_attach_cob)
     uint32_t nat_slots_default(uint32_t R, bool explicit_bits) {
-        (void) explicit_bits;
-        return R;// (measured: 32704-slot natural ranges cost the fp32 call more in its tail than they save in gathers — profiles/r03_notes.md 7; opt-in by SPLAHIP_COB_NAT_SLOTS)
+        if (explicit_bits || R != 20224u) return R;// a caller that sets the geometry gets one size
+        return 32704u;// (the library's own geometry: as large as a 4-byte slice can be, where the attach finds that it pays — see there)
     }
 }// namespace
 
@@ -565,7 +565,8 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     // the natural ranges are where a scale-free matrix's gather traffic is (profiles/r03_notes.md 6).  A natural range's fp32 sum then lives in FLOAT
     // words (compare-and-swap adds: its rows have few entries each, so neither the adds collide nor the sum needs the double), 32704 of them = 128 KB;
     // 4-byte slices of that size run one workgroup per CU.  SPLAHIP_COB_NAT_SLOTS overrides (tests: 2 x R on small inputs).
-    uint32_t Rn = env_u32("SPLAHIP_COB_NAT_SLOTS", nat_slots_default(R, row_bits != 0));
+    const bool nat_auto = std::getenv("SPLAHIP_COB_NAT_SLOTS") == nullptr;// the size is the library's proposal: the attach may take it back (below)
+    uint32_t   Rn       = env_u32("SPLAHIP_COB_NAT_SLOTS", nat_slots_default(R, row_bits != 0));
     if (Rn < R) Rn = R;
     SPLAHIP_REQUIRE(Rn % 64 == 0 && Rn <= 32704, "natural slots per range must be a multiple of 64, at most 32704");
     if (tile_chunks == 0) tile_chunks = env_u32("SPLAHIP_COB_TILE_CHUNKS", 0);// 0: pieces are cut at range and share boundaries only
@@ -610,7 +611,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     own(&g->d_slot16, (size_t) n_rows8 + 8);
     if (e != hipSuccess) return bail("scratch");
     e = hipMemsetAsync(g->d_slot16, 0, sizeof(uint16_t) * ((size_t) n_rows8 + 8), s);// no row is a hub yet
-    const uint32_t max_hub_ranges = std::min(32u, env_u32("SPLAHIP_COB_HUB_RANGES", 16));
+    const uint32_t max_hub_ranges = std::min(32u, env_u32("SPLAHIP_COB_HUB_RANGES", 32));// (16 until late in round 3: R-MAT 23 has 22 ranges' worth of rows of degree >= 2 x average; alone neutral, and what lets the natural ranges grow there)
     // hub candidates: degree >= max(16, 2 x average); SPLAHIP_COB_HUB_MIN_DEGREE sets the threshold itself (tests: hub ranges on small inputs)
     const uint32_t thr            = env_u32("SPLAHIP_COB_HUB_MIN_DEGREE", std::max<uint32_t>(16, (uint32_t) (2ull * nnz / n_rows)));
     uint32_t       H              = 0;
@@ -637,6 +638,26 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
             if (H < n_rows) e = hipMemcpy(&longest, deg_s + H, 4, hipMemcpyDeviceToHost);
             if (e != hipSuccess) return bail("hub rows");
             if (longest > env_u32("SPLAHIP_COB_NAT_MAX_DEGREE", 64)) Rn = R;
+        }
+        if (Rn > R && nat_auto) {
+            // ... and only where a natural range of that size still is ONE piece of the launch: a range dearer than a workgroup slot's share is cut, and then
+            // every piece of it merges 128 KB into the shared accumulator and the last one reads them back — R-MAT 22: 161 us against 145 with the ranges
+            // left at R, where R-MAT 23 / 24 (larger shares) gain: 297 against 304 / 640 against 700 us (profiles/r03_notes.md 8).  Estimate before anything is
+            // built: a natural entry costs ~1.7 hub entries (its gather line is mostly its own), a range holds Rn rows of the natural rows' average degree.
+            std::vector<uint32_t> hd(H);
+            uint32_t              n_nonempty = 0;
+            if (H) e = hipMemcpy(hd.data(), deg_s, sizeof(uint32_t) * H, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(cob_count_ge_kernel, dim3(1), dim3(1), 0, s, n_rows, deg_s, 1u, cnt);
+                e = hipMemcpyAsync(&n_nonempty, cnt, 4, hipMemcpyDeviceToHost, s);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return bail("hub rows");
+            uint64_t hub_e = 0;
+            for (uint32_t d : hd) hub_e += d;
+            const double nat_e = (double) nnz - (double) hub_e, nat_rows = (double) n_nonempty - (double) H;
+            const double share = ((double) hub_e + 1.7 * nat_e) / std::max(1u, compute_units());
+            if (nat_rows <= 0 || 1.7 * nat_e / nat_rows * Rn > 0.8 * share) Rn = R;
         }
     } else
         Rn = R;
@@ -789,9 +810,9 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     if (e != hipSuccess) return bail("schedule");
     std::vector<uint32_t> range_chunk((size_t) n_ranges + 1);
     for (uint32_t q = 0; q <= n_ranges; ++q) range_chunk[q] = h_first[(size_t) q << win_bits];
-    // cost of a chunk in units of one stream line's stay in the miss queue: 16 stream lines + its gather lines weighted SPLAHIP_COB_LINE_PCT % (default 25: measured, a cold chunk of ~230 lines walks in ~340 ns, a hub chunk in ~95;
+    // cost of a chunk in units of one stream line's stay in the miss queue: 16 stream lines + its gather lines weighted SPLAHIP_COB_LINE_PCT % (default 40: measured, a cold chunk of ~230 lines walks in ~340 ns, a hub chunk in ~95;
     // part of them hit the L2); cost_pre[c] = cost of the chunks before c
-    const uint32_t        line_pct = env_u32("SPLAHIP_COB_LINE_PCT", 25);
+    const uint32_t        line_pct = env_u32("SPLAHIP_COB_LINE_PCT", 40);// (25 / 40 / 60 on one box, twice: R-MAT 22 151.5 / 145.2 / 147.9 us, R-MAT 23 307.5 / 304.1 / 308.7)
     std::vector<uint64_t> cost_pre((size_t) n_chunks + 1, 0);
     for (uint32_t c = 0; c < n_chunks; ++c) cost_pre[c + 1] = cost_pre[c] + 1600 + (uint64_t) h_lines[c] * line_pct;
     const uint32_t cus = compute_units();

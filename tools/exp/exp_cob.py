@@ -63,6 +63,8 @@ def main():
             os.environ["SPLAHIP_COB_LINE_PCT"] = str(parts[3])
         if len(parts) > 4:
             os.environ["SPLAHIP_COB_HUB_RANGES"] = str(parts[4])
+        if len(parts) > 5:  # ... :natural_slots
+            os.environ["SPLAHIP_COB_NAT_SLOTS"] = str(parts[5])
         p = kernels.CsrPlan(n, nnz, Ap)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -12,3 +12,5 @@ for w in pagerank-vxm sssp-step tc-mxmT mxm algorithms; do
 done
 echo "== n2 debug"; timeout 1200 bash tools/gpu_n2_debug_r03.sh 2>&1 | tail -6 | cut -c1-400
 echo "== pmc + trace"; timeout 2400 bash tools/gpu_pmc_r03.sh 2>&1 | tail -45 | cut -c1-300
+echo "== pmc of the SSSP / PageRank steps"; timeout 2400 bash tools/gpu_pmc_r03_ops.sh 2>&1 | tail -12 | cut -c1-300
+for sc in 22 23 24; do echo "== layout chosen at scale $sc"; SPLAHIP_COB_TRACE=1 EXP_INT=1 EXP_SELL=0 timeout 900 python3 tools/exp/exp_cob.py $sc 0:0 2>&1 | grep "^cob\|schedule 1\|min-plus" | cut -c1-420; done
