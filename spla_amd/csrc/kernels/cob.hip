@@ -840,6 +840,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         uint32_t              n_multi = 0;
         // levels > 1: TAPERED pieces — of a range's cost the first 4/7 go into pieces of size a, the next 2/7 into pieces of a / 2, the last 1/7 into pieces of a / 4
         // (levels = 3; 2/3 + 1/3 for levels = 2): launched dearest first, the rounds end at a, 1.5 a, 1.75 a and the tail is made of small pieces
+        const uint32_t taper_mode = env_u32("SPLAHIP_COB_TAPER", 0);
         const uint32_t fin_slots = std::max(256u, (env_u32("SPLAHIP_COB_FIN_SLOTS", 2560) + 63u) & ~63u);// hub slots per finisher workgroup (in-kernel finishers)
         auto cut = [&](uint32_t share_pct, uint32_t levels) {
             const uint64_t share = std::max<uint64_t>(1, (cost_pre[n_chunks] + slots - 1) / slots * share_pct / 100);
@@ -857,7 +858,9 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
                     const uint64_t denom = (1u << L) - 1u;// 1, 3, 7, 15, 31
                     uint64_t       at    = 0;
                     for (uint32_t l = 0; l < L; ++l) {
-                        const uint64_t part = rc * (1u << (L - 1 - l)) / denom, size = std::max<uint64_t>(1, share >> l);
+                        // taper 0: equal piece COUNTS per level (4/7, 2/7, 1/7 of the cost); 1 (SPLAHIP_COB_TAPER): equal COST per level — 1, 2, 4 ... times as many
+                        // pieces from level to level, i.e. far more small pieces for the second half of the launch to balance with
+                        const uint64_t part = taper_mode ? rc / L : rc * (1u << (L - 1 - l)) / denom, size = std::max<uint64_t>(1, share >> l);
                         const uint64_t np   = std::max<uint64_t>(1, (part + size - 1) / size);
                         for (uint64_t t = 1; t <= np; ++t) marks.push_back(at + part * t / np);
                         at += part;
@@ -906,13 +909,23 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         // launch order.  0: dearest piece first.  1 (SPLAHIP_COB_ORDER): RANGE-MAJOR — the natural ranges' pieces first (latency-bound walks and long row
         // passes: all under the hub pieces' streams), then the hub ranges one after the other, dearest range first, each range's pieces dearest first — so a
         // range's row pass (its last arriver's ~12 - 20 us) falls under the next ranges' streams and only the last range's is in the tail
-        const uint32_t order_mode = env_u32("SPLAHIP_COB_ORDER", 0);
+        const uint32_t order_mode = env_u32("SPLAHIP_COB_ORDER", 2);// (2 since the last A/B of round 3: R-MAT 23 288 against 294 us, R-MAT 22 / 24 level)
         auto launch_order = [&]() {
             const uint32_t        nt = (uint32_t) (tiles.size() / 4);
             std::vector<uint32_t> o(nt);
             for (uint32_t t = 0; t < nt; ++t) o[t] = t;
             if (order_mode == 0) {
                 std::stable_sort(o.begin(), o.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+                return o;
+            }
+            if (order_mode == 2) {// NATURAL pieces first (dearest first), then the hub pieces dearest first: a natural range's last piece ends with a read-back and a
+                                  // row pass of ~20 us on its one CU and walks cold lines at 250 ns per chunk — launched last for being small, such pieces WERE the tail
+                                  // of the launch (R-MAT 23: the last 55 us); a hub piece ends with 2.7 us of merging and is the better tail filler
+                std::stable_sort(o.begin(), o.end(), [&](uint32_t x, uint32_t y) {
+                    const bool hx = tiles[4 * (size_t) x + 2] < n_hub_ranges, hy = tiles[4 * (size_t) y + 2] < n_hub_ranges;
+                    if (hx != hy) return !hx;
+                    return cost[x] > cost[y];
+                });
                 return o;
             }
             std::vector<uint64_t> range_cost(n_ranges, 0);

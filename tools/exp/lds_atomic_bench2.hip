@@ -74,6 +74,23 @@ __global__ __launch_bounds__(1024) void bench(unsigned* __restrict__ out) {
             h2 one = {(_Float16) 1.0f, (_Float16) 1.0f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) (void) __builtin_amdgcn_ds_atomic_fadd_v2f16(reinterpret_cast<__attribute__((address_space(3))) h2*>((__attribute__((address_space(3))) unsigned*) (s + a[j])), one);
+        } else if constexpr (MODE == 9) {// float add WITH its return value used (ds_add_rtn_f32)
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += __hip_atomic_fetch_add(reinterpret_cast<float*>(s + a[j]), 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (acc == -12345.f) s[0] = 1;
+        } else if constexpr (MODE == 10) {// float add through inline ds_add_f32 (no compiler lowering in between)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned addr = (unsigned) (size_t) (__attribute__((address_space(3))) unsigned*) (s + a[j]);
+                asm volatile("ds_add_f32 %0, %1" ::"v"(addr), "v"(1.0f) : "memory");
+            }
+        } else if constexpr (MODE == 11) {// float max as an atomic (does any fp32 LDS atomic run at rate?)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned addr = (unsigned) (size_t) (__attribute__((address_space(3))) unsigned*) (s + a[j]);
+                asm volatile("ds_max_f32 %0, %1" ::"v"(addr), "v"(1.0f) : "memory");
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) *reinterpret_cast<volatile unsigned*>(s + a[j]) = a[j];
@@ -108,6 +125,9 @@ void all(unsigned* d_out, const char* pn) {
     run<1, PAT>(d_out, "ds_add_u32");
     run<2, PAT>(d_out, "ds_min_i32");
     run<0, PAT>(d_out, "ds_add_f32");
+    run<9, PAT>(d_out, "ds_add_rtn_f32 (value used)");
+    run<10, PAT>(d_out, "ds_add_f32 (inline asm)");
+    run<11, PAT>(d_out, "ds_max_f32 (inline asm)");
     run<3, PAT>(d_out, "plain read, add, write x4");
     run<4, PAT>(d_out, "CAS float add x4 + retry");
     run<6, PAT>(d_out, "ds_add_f64");
