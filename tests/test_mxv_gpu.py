@@ -531,3 +531,53 @@ def test_cob_plan_reused_across_semirings(oracle):
         want = oracle.mxv_masked("INT", n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
         assert np.array_equal(host(r, np.int32), want), (it, mul, add, sel)
     plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knobs", [{"SPLAHIP_COB_HUB_FINISH": "0"}, {"SPLAHIP_COB_HUB_FINISH": "2", "SPLAHIP_COB_FIN_SLOTS": "256"}, {"SPLAHIP_COB_ORDER": "0"},
+                                   {"SPLAHIP_COB_ORDER": "1"}, {"SPLAHIP_COB_PER_CU": "2"}, {"SPLAHIP_COB_TAPER": "1", "SPLAHIP_COB_LEVELS": "2"},
+                                   {"SPLAHIP_COB_NAT_SLOTS": "1024", "SPLAHIP_COB_HUB_FINISH": "2"}, {"SPLAHIP_COB_HUB_ROW_ORDER": "0", "SPLAHIP_COB_HUB_RANGES": "2"}])
+def test_cob_schedule_and_geometry_knobs(oracle, knobs):
+    """The selectable forms of the column-ordered blocks that are not the default (cob.hip: who finishes the hub rows — the range's last piece, the second
+    launch, finisher workgroups inside the main launch —, launch orders, two workgroups per CU, the equal-cost taper, natural ranges larger than hub ranges,
+    degree-ordered hub slots, few hub ranges): same results as the oracle, bit for bit on int32 (PLUS, MIN, BOR) and within 1e-5 on fp32 PLUS, twice per plan
+    (accumulators, tickets and finisher counters must be back at rest after a call)."""
+    import os
+
+    import torch
+    from gpu_utils import dev, host
+    from spla_amd import kernels
+    rng = np.random.default_rng(99)
+    n_rows, n_cols = 9000, 7000
+    Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 12, "INT", skew=True, long_rows=3, long_len=2500)
+    Axf = rng.random(len(Aj)).astype(np.float32)
+    dAp, dAj = dev(Ap), dev(Aj)
+    env = dict(knobs, SPLAHIP_COB_HUB_MIN_DEGREE="4")
+    for k, val in env.items():
+        os.environ[k] = val
+    try:
+        for t, ax in (("INT", Ax), ("FLOAT", Axf)):
+            dAx = dev(ax)
+            plan = kernels.CsrPlan(n_rows, len(Aj), dAp)
+            info = plan.attach_cob(n_cols, dAp, dAj, dAx, row_bits=8, tile_chunks=3)
+            assert info and info["ranges_in_pieces"] > 0 and info["hub_rows"] > 0, info
+            r = torch.empty(n_rows, dtype=kernels.torch_dtype(t), device="cuda")
+            calls = [("MULT", "PLUS", 0), ("PLUS", "MIN", 1 << 20), ("BAND", "BOR", 0)] if t == "INT" else [("MULT", "PLUS", 0.0), ("PLUS", "MIN", 1e30)]
+            for it, (mul, add, init) in enumerate(calls * 2):
+                mask = random_mask(rng, n_rows, t)
+                v = random_values(rng, n_cols, t, zeros=0.2) if t == "INT" else rng.random(n_cols).astype(np.float32)
+                sel = SELECTS[it % len(SELECTS)]
+                assert "mxv_cob" in kernels.mxv_variant(t, mul, add, False, plan)
+                r.fill_(-77)
+                kernels.mxv_masked(plan, t, n_cols, dAp, dAj, dAx, dev(mask), dev(v), r, mul, add, sel, init)
+                torch.cuda.synchronize()
+                want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, ax, mask, v, mul, add, sel, init)
+                got = host(r, NP[t])
+                if t == "INT" or add != "PLUS":
+                    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (knobs, t, it, mul, add, sel)
+                else:
+                    assert np.allclose(got, want.view(np.float32), rtol=FP32_RTOL, atol=1e-6), (knobs, t, it, mul, add, sel)
+            plan.close()
+    finally:
+        for k in env:
+            os.environ.pop(k)
