@@ -841,6 +841,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         // levels > 1: TAPERED pieces — of a range's cost the first 4/7 go into pieces of size a, the next 2/7 into pieces of a / 2, the last 1/7 into pieces of a / 4
         // (levels = 3; 2/3 + 1/3 for levels = 2): launched dearest first, the rounds end at a, 1.5 a, 1.75 a and the tail is made of small pieces
         const uint32_t taper_mode = env_u32("SPLAHIP_COB_TAPER", 0);
+        const uint32_t round_chunks = env_u32("SPLAHIP_COB_ROUND_CHUNKS", 64);// chunks of one round of the kernel's loop: 16 waves x 4 steps
         const uint32_t fin_slots = std::max(256u, (env_u32("SPLAHIP_COB_FIN_SLOTS", 2560) + 63u) & ~63u);// hub slots per finisher workgroup (in-kernel finishers)
         auto cut = [&](uint32_t share_pct, uint32_t levels) {
             const uint64_t share = std::max<uint64_t>(1, (cost_pre[n_chunks] + slots - 1) / slots * share_pct / 100);
@@ -876,6 +877,12 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
                     if (t + 1 < marks.size()) {
                         end = (uint32_t) (std::lower_bound(cost_pre.begin() + f, cost_pre.begin() + c1, cost_pre[c0] + marks[t]) - cost_pre.begin());
                         end = std::min(std::max(end, f + 1), c1);
+                        // a workgroup walks its piece 16 chunks a step, in rounds of 4 steps: a piece of a whole number of rounds leaves no wave walking the
+                        // padding chunk (a 233-chunk piece walks 256).  Pieces of >= 4 rounds are cut at the nearest whole round (SPLAHIP_COB_ROUND_CHUNKS=0: as cut)
+                        if (round_chunks && end - f >= 4 * round_chunks && end < c1) {
+                            const uint32_t len = (end - f + round_chunks / 2) / round_chunks * round_chunks;
+                            if (f + len < c1) end = f + len;
+                        }
                     }
                     if (tile_chunks) end = std::min(end, f + tile_chunks);
                     tiles.insert(tiles.end(), {f, end - f, q, kCobNoSlab});
