@@ -33,7 +33,7 @@ class ShardedProduct:
         from spla_amd import sharding
         self.blk, self.t, self.ops, self.init, self.world, self.rank, self.direct = blk, t, (mul, add, sel), init, world, rank, direct
         self.shard = sharding.Shard(blk, Ax)
-        self.two_part = self.shard.serves(t, add)
+        self.two_part = self.shard.serves(t, add) and not self.shard.prefers_whole(t, add)  # (what splahip_dist_mxv_masked itself decides)
         self.rccl = world > 1 and dist.get_backend() == "nccl"
         self.comm = None
         self.fallback = None
@@ -110,6 +110,9 @@ def phase_report(sp: ShardedProduct, mask, v_loc, r, steps, world):
         _, pr = timed(lambda: sp.shard.mxv_remote(sp.t, mask, sp.v_full, r, mul, add, sel), steps, 2, world)
         out["local_part_avg_us"] = round(float(np.mean(pl)) * 1e3, 2)
         out["remote_part_avg_us"] = round(float(np.mean(pr)) * 1e3, 2)
+    else:  # the unsplit block over the gathered vector (what two ranks run): the product on its own
+        _, pw = timed(lambda: sp.shard.mxv_whole(sp.t, mask, sp.v_full, r, mul, add, sel, sp.init), steps, 2, world)
+        out["whole_part_avg_us"] = round(float(np.mean(pw)) * 1e3, 2)
     _, ps = timed(lambda: sp.step(mask, v_loc, r), steps, 2, world)
     out["step_avg_us"] = round(float(np.mean(ps)) * 1e3, 2)
     if sp.two_part and world > 1:
@@ -174,7 +177,7 @@ def sssp_step_sharded(args, rank, world):
         if not ok:
             raise SystemExit("bench: sharded HIP result differs from the oracle")
     # roofline of this rank's launch: algorithmic bytes of its row block / the step's kernel time (local + remote parts)
-    k_us = phases.get("local_part_avg_us", 0.0) + phases.get("remote_part_avg_us", 0.0) if sp.two_part else phases["step_avg_us"] - phases["exchange_avg_us"]
+    k_us = phases.get("local_part_avg_us", 0.0) + phases.get("remote_part_avg_us", 0.0) if sp.two_part else phases.get("whole_part_avg_us", phases["step_avg_us"] - phases["exchange_avg_us"])
     alg = 8 * blk.nnz_local + 4 * (blk.n_local + 1) + 8 * blk.n_local + 4 * blk.n_cols_padded
     gbs = alg / (k_us * 1e-6) / 1e9 if k_us > 0 else 0.0
     slice_bytes = 4 * blk.max_rows

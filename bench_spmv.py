@@ -337,7 +337,7 @@ def _run_sharded(args, rank, world, scale, label, n, nnz, Ap, Aj, Ax, v):
         ok = bool(int(flag[0]))
         if not ok:
             raise SystemExit("bench: sharded HIP result differs from the oracle")
-    k_us = phases.get("local_part_avg_us", 0.0) + phases.get("remote_part_avg_us", 0.0) if sp.two_part else phases["step_avg_us"] - phases["exchange_avg_us"]
+    k_us = phases.get("local_part_avg_us", 0.0) + phases.get("remote_part_avg_us", 0.0) if sp.two_part else phases.get("whole_part_avg_us", phases["step_avg_us"] - phases["exchange_avg_us"])
     alg = alg_bytes(blk.nnz_local, blk.n_local, blk.n_cols_padded)
     gbs = alg / (k_us * 1e-6) / 1e9 if k_us > 0 else 0.0
     slice_bytes = 4 * blk.max_rows

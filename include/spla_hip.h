@@ -178,6 +178,9 @@ int splahip_shard_create(splahip_shard* shard, int world, int rank, uint32_t n_l
 int splahip_shard_destroy(splahip_shard shard);
 int splahip_shard_info(splahip_shard shard, uint32_t* nnz_local_cols, uint32_t* nnz_remote_cols, int* split_ok);
 int splahip_shard_split_serves(splahip_shard shard, int type, int op_add, int early_exit); /* 1: the two-part (overlapped) form serves this call */
+/* 1: splahip_dist_mxv_masked runs the UNSPLIT block for this call — the exchange first, then one product over the block's own column-ordered blocks — although the
+ * two-part form could serve it (SPLAHIP_DIST_FORM=whole; measured slower than the two-part form at the sizes tried, so not the default) */
+int splahip_shard_prefers_whole(splahip_shard shard, int type, int op_add);
 int splahip_shard_mxv_local(splahip_shard shard, int type, const void* d_mask, const void* d_v_local, void* d_r, int op_mult, int op_add, int op_select,
                             uint32_t init_bits, void* stream);
 int splahip_shard_mxv_remote(splahip_shard shard, int type, const void* d_mask, const void* d_v_full, void* d_r, int op_mult, int op_add, int op_select, void* stream);

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "splahip_shard_destroy": (C.c_int, [_vp]),
     "splahip_shard_info": (C.c_int, [_vp, _u32p, _u32p, C.POINTER(C.c_int)]),
     "splahip_shard_split_serves": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
+    "splahip_shard_prefers_whole": (C.c_int, [_vp, C.c_int, C.c_int]),
     "splahip_shard_mxv_local": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_uint32, _vp]),
     "splahip_shard_mxv_remote": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "splahip_shard_mxv_whole": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, _vp]),
@@ -105,7 +106,7 @@ _SIGNATURES = {
     "splahip_map": (C.c_int, [C.c_int, C.c_uint32, _vp, _vp, C.c_int, _vp]),
 }
 _RAW = {"splahip_mxv_prefers_sell", "splahip_device_count", "splahip_last_error", "splahip_version", "splahip_mxv_variant", "splahip_mxv_variant_of", "splahip_dist_available",
-        "splahip_shard_split_serves", "splahip_jit_available"}
+        "splahip_shard_split_serves", "splahip_shard_prefers_whole", "splahip_jit_available"}
 
 _lib = None
 

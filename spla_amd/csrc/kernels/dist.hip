@@ -49,6 +49,7 @@ struct splahip_shard_s {
     uint32_t *LAp = nullptr, *LAj = nullptr, *LAx = nullptr, *RAp = nullptr, *RAj = nullptr, *RAx = nullptr;
     splahip_plan plan_loc = nullptr, plan_rem = nullptr;
     bool         split_ok = false;// both parts carry a column-ordered-blocks copy (or are empty)
+    bool         whole_form = false;// splahip_dist_mxv_masked prefers the UNSPLIT block over its own column-ordered blocks (exchange first, then one product)
 };
 
 // Sparsity-aware exchange of the input vector (a BFS frontier, the changed distances of an SSSP step): positions (+ values) of the entries that
@@ -297,6 +298,20 @@ int splahip_shard_create(splahip_shard* out, int world, int rank, uint32_t n_loc
     };
     st = splahip_csr_plan_create(&sh->plan_whole, n_local, nnz, d_Ap, stream);
     if (st != SPLAHIP_OK) return bail(st);
+    // Which form splahip_dist_mxv_masked runs.  Default: the two-part form (exchange hidden under the local-column part).  SPLAHIP_DIST_FORM=whole: the exchange
+    // first, then ONE product over the unsplit block's own column-ordered blocks.  Measured with two ranks on one GPU at the driver's N = 2 size (R-MAT 24,
+    // owner-sorted labels, two blocks of 131 M nnz x 16.8 M columns): local part 337 us + remote part 352 us against 641 us for the unsplit block — a block of
+    // a permuted graph with twice the columns is a harder matrix than the R-MAT 23 of the one-GPU line (285 us), split or not; with ~220 us of exchange over one
+    // xGMI link the two-part form (max(220, 337) + 352) beats exchange + unsplit (220 + 641), so it stays the default at every rank count.
+    {
+        const char* fe         = std::getenv("SPLAHIP_DIST_FORM");
+        const bool  want_whole = fe && fe[0] == 'w';
+        if (want_whole && nnz != 0 && n_local != 0) {
+            st = splahip_csr_plan_attach_cob(sh->plan_whole, n_cols_padded, d_Ap, d_Aj_padded, d_Ax, 0, 0, stream);
+            if (st != SPLAHIP_OK) return bail(st);
+            sh->whole_form = sh->plan_whole->cob != nullptr;
+        }
+    }
     if (nnz == 0 || n_local == 0) {
         sh->split_ok = true;
         *out         = sh;
@@ -362,6 +377,13 @@ int splahip_shard_info(splahip_shard s, uint32_t* nnz_local_cols, uint32_t* nnz_
 }
 
 // may the two-part form serve this call (else: splahip_shard_mxv_whole after the exchange)
+// 1: splahip_dist_mxv_masked runs the unsplit block (exchange first) although the two-part form could serve the call
+int splahip_shard_prefers_whole(splahip_shard s, int type, int op_add) {
+    if (!s || !s->whole_form) return 0;
+    const uint32_t n_cols_padded = s->world > 1 ? (uint32_t) s->world * s->max_rows : s->max_rows;
+    return cob_serves(s->plan_whole, type, op_add, n_cols_padded) ? 1 : 0;
+}
+
 int splahip_shard_split_serves(splahip_shard s, int type, int op_add, int early_exit) {
     if (!s || !s->split_ok || early_exit) return 0;
     const uint32_t n_cols_padded = s->world > 1 ? (uint32_t) s->world * s->max_rows : s->max_rows;
@@ -405,7 +427,8 @@ int splahip_dist_mxv_masked(splahip_comm c, splahip_shard s, int type, const voi
     SPLAHIP_REQUIRE(c != nullptr && s != nullptr, "null communicator / shard");
     SPLAHIP_REQUIRE(c->world == s->world && c->rank == s->rank, "communicator and shard disagree on rank / world");
     hipStream_t cs = as_stream(stream);
-    const bool  two = splahip_shard_split_serves(s, type, op_add, early_exit) != 0;
+    const uint32_t n_cols_all = s->world > 1 ? (uint32_t) s->world * s->max_rows : s->max_rows;
+    const bool     two = splahip_shard_split_serves(s, type, op_add, early_exit) != 0 && !(s->whole_form && cob_serves(s->plan_whole, type, op_add, n_cols_all));
     if (overlapped) *overlapped = two ? 1 : 0;
     // the exchange starts as soon as the input slice is ready on the compute stream
     SPLAHIP_TRY(hipEventRecord(c->ready, cs));

@@ -340,6 +340,12 @@ class Shard:
         from .ops import binop_id, type_id
         return bool(_lib.call("splahip_shard_split_serves", self._h, type_id(t), binop_id(op_add), 1 if early_exit else 0))
 
+    def prefers_whole(self, t, op_add) -> bool:
+        """the C-ABI product runs the unsplit block (exchange first) for this call although the two-part form could serve it (two ranks)"""
+        from . import _lib
+        from .ops import binop_id, type_id
+        return bool(_lib.call("splahip_shard_prefers_whole", self._h, type_id(t), binop_id(op_add)))
+
     def mxv_local(self, t, mask, v_local, r, op_mult, op_add, op_select, init):
         from . import _lib
         from .kernels import _ptr, current_stream_ptr

@@ -119,6 +119,20 @@ def test_rccl_communicator_world1_and_dist_product(oracle):
     assert overlapped
     np.testing.assert_array_equal(r.cpu().numpy(), want)
     s.close()
+    # the unsplit form (what two ranks run by default: the exchange first, then ONE product over the block's own column-ordered blocks), forced here by the switch
+    import os
+    os.environ["SPLAHIP_DIST_FORM"] = "whole"
+    try:
+        s2 = sharding.Shard(blk, blk.Ax)
+        assert s2.prefers_whole("INT", "PLUS") and s2.serves("INT", "PLUS")
+        r.fill_(-5)
+        overlapped = s2.product(comm, "INT", mask.cuda(), v.cuda(), v_full, r, "MULT", "PLUS", "EQZERO", 3)
+        torch.cuda.synchronize()
+        assert not overlapped
+        np.testing.assert_array_equal(r.cpu().numpy(), want)
+        s2.close()
+    finally:
+        os.environ.pop("SPLAHIP_DIST_FORM")
     comm.close()
 
 
