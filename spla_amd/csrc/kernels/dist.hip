@@ -299,10 +299,9 @@ int splahip_shard_create(splahip_shard* out, int world, int rank, uint32_t n_loc
     st = splahip_csr_plan_create(&sh->plan_whole, n_local, nnz, d_Ap, stream);
     if (st != SPLAHIP_OK) return bail(st);
     // Which form splahip_dist_mxv_masked runs.  Default: the two-part form (exchange hidden under the local-column part).  SPLAHIP_DIST_FORM=whole: the exchange
-    // first, then ONE product over the unsplit block's own column-ordered blocks.  Measured with two ranks on one GPU at the driver's N = 2 size (R-MAT 24,
-    // owner-sorted labels, two blocks of 131 M nnz x 16.8 M columns): local part 337 us + remote part 352 us against 641 us for the unsplit block — a block of
-    // a permuted graph with twice the columns is a harder matrix than the R-MAT 23 of the one-GPU line (285 us), split or not; with ~220 us of exchange over one
-    // xGMI link the two-part form (max(220, 337) + 352) beats exchange + unsplit (220 + 641), so it stays the default at every rank count.
+    // first, then ONE product over the unsplit block's own column-ordered blocks.  At the driver's N = 2 size (R-MAT 24, two blocks of 131 M nnz x 16.8 M columns)
+    // the attach's launch model gives 176 us per part and 342 us for the unsplit block (two ranks sharing one GPU measured twice that: 338 + 358 against 641 us);
+    // with ~220 us of exchange over one xGMI link, max(220, 176) + 176 beats 220 + 342: the two-part form stays the default at every rank count.
     {
         const char* fe         = std::getenv("SPLAHIP_DIST_FORM");
         const bool  want_whole = fe && fe[0] == 'w';
