@@ -223,11 +223,18 @@ void oracle_mxm(int type, uint32_t a_rows, uint32_t b_cols,
             }
         }
         qsort(list, n_touched, sizeof(uint32_t), cmp_u32);
+        if (neq(type, init, init)) {
+            /* a NaN init (fp32): `R_tmp[col] != I` (cpu_mxm.hpp:109-113) holds for EVERY column, touched or not — the reference emits a dense row */
+            for (uint32_t j = 0; j < b_cols; ++j) out_push(&out, j, acc[j]);
+        } else {
+            for (uint32_t t = 0; t < n_touched; ++t) {
+                const uint32_t j = list[t];
+                if (neq(type, acc[j], init)) out_push(&out, j, acc[j]);
+            }
+        }
         for (uint32_t t = 0; t < n_touched; ++t) {
-            const uint32_t j = list[t];
-            if (neq(type, acc[j], init)) out_push(&out, j, acc[j]);
-            acc[j]     = init;
-            touched[j] = 0;
+            acc[list[t]]     = init;
+            touched[list[t]] = 0;
         }
         Rp[i + 1] = (uint32_t) out.size;
     }

@@ -393,7 +393,8 @@ int splahip_shard_split_serves(splahip_shard s, int type, int op_add, int early_
 int splahip_shard_mxv_local(splahip_shard s, int type, const void* d_mask, const void* d_v_local, void* d_r, int op_mult, int op_add, int op_select, uint32_t init_bits,
                             void* stream) {
     SPLAHIP_REQUIRE(s != nullptr, "shard is null");
-    if (!splahip_shard_split_serves(s, type, op_add, 0)) return fail(SPLAHIP_NOT_IMPLEMENTED, "the two-part form does not serve this op_add: use splahip_shard_mxv_whole");
+    if (!splahip_shard_split_serves(s, type, canonical_add(type, op_add, init_bits), 0))// (fp32 MIN / MAX from a NaN init is FIRST, ops.hpp: the unsplit block)
+        return fail(SPLAHIP_NOT_IMPLEMENTED, "the two-part form does not serve this op_add: use splahip_shard_mxv_whole");
     if (s->n_local == 0) return SPLAHIP_OK;
     if (s->nnz_loc == 0)// no local-column entry: every row is init (the remote part folds onto it)
         return splahip_memset32(d_r, init_bits, s->n_local, stream);
@@ -427,6 +428,7 @@ int splahip_dist_mxv_masked(splahip_comm c, splahip_shard s, int type, const voi
     SPLAHIP_REQUIRE(c->world == s->world && c->rank == s->rank, "communicator and shard disagree on rank / world");
     hipStream_t cs = as_stream(stream);
     const uint32_t n_cols_all = s->world > 1 ? (uint32_t) s->world * s->max_rows : s->max_rows;
+    op_add             = canonical_add(type, op_add, init_bits);// fp32 MIN / MAX from a NaN init: FIRST (ops.hpp) -> the unsplit block
     const bool     two = splahip_shard_split_serves(s, type, op_add, early_exit) != 0 && !(s->whole_form && cob_serves(s->plan_whole, type, op_add, n_cols_all));
     if (overlapped) *overlapped = two ? 1 : 0;
     // the exchange starts as soon as the input slice is ready on the compute stream

@@ -326,7 +326,8 @@ namespace splahip {
                                                                     const uint* __restrict__ cost_before, const uint* __restrict__ Mp, const uint* __restrict__ Mj,
                                                                     const uint* __restrict__ Ap, const uint* __restrict__ Aj, const T* __restrict__ Ax,
                                                                     const uint* __restrict__ Bp, const uint* __restrict__ Bj, const T* __restrict__ Bx,
-                                                                    T* __restrict__ val, uint* __restrict__ keep, Mult mult, Add add, T init) {
+                                                                    T* __restrict__ val, uint* __restrict__ keep, Mult mult, Add add_raw, T init) {
+        const Reassoc<Add> add(add_raw);// (ops.hpp) partial folds start at products
         extern __shared__ uint s_row[];
         const uint      wv = threadIdx.x / kWave, lane = lane_id();
         if (blockIdx.x * WAVES + wv >= n_items) return;// (whole wavefronts leave: nothing below synchronises across wavefronts)
@@ -521,9 +522,7 @@ namespace splahip {
     // the metadata chain behind other wavefronts better than it is amortised.)
     template<class Add>
     __device__ __forceinline__ int merge_op_id(const Add& add) {
-        if constexpr (Add::is_static) return Add::op_id;
-        else
-            return add.op;
+        return binop_id(add);
     }
     // may an entry's value be computed from the number of matches when all products are equal?  PLUS / BXOR count (integer types: n x p wraps
     // like n additions), MIN / MAX / BOR / BAND / FIRST / SECOND are idempotent (p (+) p = p bit for bit); the logical ops normalise their
@@ -560,8 +559,9 @@ namespace splahip {
     __global__ __launch_bounds__(256) void mxmT_merge_kernel(const uint* __restrict__ count, const uint* __restrict__ list, uint list_last, const uint* __restrict__ Mj,
                                                              const uint* __restrict__ Ap, const uint* __restrict__ Aj, const T* __restrict__ Ax,
                                                              const uint* __restrict__ Bp, const uint* __restrict__ Bj, const T* __restrict__ Bx,
-                                                             T* __restrict__ val, uint* __restrict__ keep, Mult mult, Add add, T init, uint commutative,
+                                                             T* __restrict__ val, uint* __restrict__ keep, Mult mult, Add add_raw, T init, uint commutative,
                                                              uint count_mode, uint a_word, uint b_word) {
+        const Reassoc<Add> add(add_raw);// (ops.hpp) partial folds start at products
         const T pc = mult(from_bits<T>(a_word), from_bits<T>(b_word));// (count_mode: the one product)
         // count_mode: every stored value of A is one word and every stored value of B is one word (adjacency matrices: the triangle count), so
         // every product is pc and the entry's value follows from the NUMBER of matches — no match list, no value fetches (host: merge_counts())
@@ -697,7 +697,8 @@ namespace splahip {
                                                              const uint* __restrict__ Mp, const uint* __restrict__ Mj,
                                                              const uint* __restrict__ Ap, const uint* __restrict__ Aj, const T* __restrict__ Ax,
                                                              const uint* __restrict__ Bp, const uint* __restrict__ Bj, const T* __restrict__ Bx,
-                                                             T* __restrict__ val, uint* __restrict__ keep, Mult mult, Add add, T init) {
+                                                             T* __restrict__ val, uint* __restrict__ keep, Mult mult, Add add_raw, T init) {
+        const Reassoc<Add> add(add_raw);// (ops.hpp) partial folds start at products
         const uint w = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
         if (w >= *heavy_count) return;
         const uint lane = lane_id();
@@ -1112,7 +1113,8 @@ namespace splahip {
     __global__ __launch_bounds__(256) void mxm_long_run_kernel(const K* __restrict__ key, const T* __restrict__ val, uint n,
                                                                const uint* __restrict__ long_count, const uint* __restrict__ long_pos,
                                                                const uint* __restrict__ run_rank, T* __restrict__ run_val, uint* __restrict__ run_keep,
-                                                               Add add, T init) {
+                                                               Add add_raw, T init) {
+        const Reassoc<Add> add(add_raw);// (ops.hpp) partial folds start at products
         const uint w = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
         if (w >= *long_count) return;
         const uint lane = lane_id();
@@ -1175,6 +1177,24 @@ namespace splahip {
                 hi = mid;
         }
         Rp[i] = lo;
+    }
+
+    // fp32 NaN init: the reference keeps a column when `R_tmp[col] != I` (src/cpu/cpu_mxm.hpp:109-113), which holds for EVERY column when I is a NaN —
+    // its result is dense, untouched columns carrying I.  The sparse product (every touched entry survives the same test) is spread over dense rows.
+    __global__ __launch_bounds__(256) void mxm_dense_fill_kernel(uint n_rows, uint n_cols, uint init_bits, uint* __restrict__ Rp, uint* __restrict__ Rj,
+                                                                 uint* __restrict__ Rx) {
+        const size_t t = (size_t) blockIdx.x * 256 + threadIdx.x, n = (size_t) n_rows * n_cols;
+        if (t <= n_rows) Rp[t] = (uint) (t * n_cols);
+        if (t < n) {
+            Rj[t] = (uint) (t % n_cols);
+            Rx[t] = init_bits;
+        }
+    }
+    __global__ __launch_bounds__(256) void mxm_dense_scatter_kernel(uint n_rows, uint n_cols, const uint* __restrict__ Sp, const uint* __restrict__ Sj,
+                                                                    const uint* __restrict__ Sx, uint* __restrict__ Rx) {
+        const uint i = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+        if (i >= n_rows) return;
+        for (uint k = Sp[i] + lane_id(); k < Sp[i + 1]; k += kWave) Rx[(size_t) i * n_cols + Sj[k]] = Sx[k];
     }
 
     struct Piece {
@@ -1454,6 +1474,7 @@ int splahip_mxmT_masked(int type, uint32_t n_rows, uint32_t mask_nnz,
     SPLAHIP_REQUIRE(binop_valid_for(op_mult, type) && binop_valid_for(op_add, type), "op not defined for this type");
     SPLAHIP_REQUIRE(op_select >= 0 && op_select < SPLAHIP_SELOP_COUNT, "unknown op_select");
     SPLAHIP_REQUIRE(d_Mp && d_Ap && d_Bp, "null row pointer array");
+    op_add = canonical_add(type, op_add, init_bits);// fp32 MIN / MAX from a NaN init: the reference's fold keeps init (ops.hpp)
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
     hipStream_t s = as_stream(stream);
@@ -1474,6 +1495,7 @@ int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols,
     SPLAHIP_REQUIRE(d_Rp && d_Rj && d_Rx && h_nnz, "null output argument");
     SPLAHIP_REQUIRE(binop_valid_for(op_mult, type) && binop_valid_for(op_add, type), "op not defined for this type");
     SPLAHIP_REQUIRE(d_Ap && d_Bp, "null row pointer array");
+    op_add = canonical_add(type, op_add, init_bits);// fp32 MIN / MAX from a NaN init: the reference's fold keeps init (ops.hpp)
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
     hipStream_t s = as_stream(stream);
@@ -1485,8 +1507,11 @@ int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols,
     if (block_products == 0) block_products = 1ull << 27;// 128 Mi products per row block (~5 GiB of sort buffers)
     unsigned long long prod = 0;
     int                rc;
+    const bool nan_init = type == SPLAHIP_FLOAT && (init_bits & 0x7fffffffu) > 0x7f800000u;// -> a dense result, see mxm_dense_fill_kernel
+    if (nan_init && (uint64_t) a_rows * b_cols > 0xFFFFFFF0ull)
+        return fail(SPLAHIP_NOT_IMPLEMENTED, "a NaN init makes the reference's result dense (%u x %u entries): not representable with 32-bit row pointers", a_rows, b_cols);
     // row classes with LDS accumulators (mxm_spa.hip) for every op_add that has an LDS atomic; -1: not applicable -> the ESC form below
-    rc = mxm_spa(type, a_rows, b_cols, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, &prod, op_mult, op_add, init_bits, s);
+    rc = nan_init ? -1 : mxm_spa(type, a_rows, b_cols, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, &prod, op_mult, op_add, init_bits, s);
     if (rc != -1) {
         if (h_products) *h_products = prod;
         return rc;
@@ -1498,6 +1523,30 @@ int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols,
         default: return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
     }
     if (h_products) *h_products = prod;
+    if (rc == SPLAHIP_OK && nan_init && b_cols != 0) {
+        const size_t n = (size_t) a_rows * b_cols;
+        DevBuf       sp, dj, dx;
+        hipError_t   e = sp.alloc(sizeof(uint) * ((size_t) a_rows + 1));
+        if (e == hipSuccess) e = dj.alloc_plain(sizeof(uint) * n);
+        if (e == hipSuccess) e = dx.alloc_plain(sizeof(uint) * n);
+        if (e == hipSuccess) e = hipMemcpyAsync(sp.p, d_Rp, sizeof(uint) * ((size_t) a_rows + 1), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(mxm_dense_fill_kernel, dim3((uint) ((std::max<size_t>(n, a_rows + 1) + 255) / 256)), dim3(256), 0, s, a_rows, b_cols, init_bits, d_Rp,
+                               dj.as<uint>(), dx.as<uint>());
+            if (*h_nnz)
+                hipLaunchKernelGGL(mxm_dense_scatter_kernel, dim3((a_rows + 3) / 4), dim3(256), 0, s, a_rows, b_cols, sp.as<uint>(), *d_Rj,
+                                   static_cast<const uint*>(*d_Rx), dx.as<uint>());
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (*d_Rj) (void) splahip_free(*d_Rj);
+        if (*d_Rx) (void) splahip_free(*d_Rx);
+        *d_Rj = nullptr, *d_Rx = nullptr, *h_nnz = 0;
+        if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm (dense result of a NaN init) failed: %s", hipGetErrorString(e));
+        *d_Rj  = static_cast<uint32_t*>(dj.release());
+        *d_Rx  = dx.release();
+        *h_nnz = (uint32_t) n;
+    }
     return rc;
 }
 

@@ -240,6 +240,7 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
     SPLAHIP_REQUIRE(binop_valid_for(op_mult, type), "op_multiply not defined for this type");
     SPLAHIP_REQUIRE(binop_valid_for(op_add, type), "op_add not defined for this type");
     SPLAHIP_REQUIRE(op_select >= 0 && op_select < SPLAHIP_SELOP_COUNT, "unknown op_select");
+    op_add = canonical_add(type, op_add, init_bits);// fp32 MIN / MAX from a NaN init: the reference's fold keeps init (ops.hpp) -> FIRST, the row kernel
     if (n_rows == 0) return SPLAHIP_OK;
     SPLAHIP_REQUIRE(d_Ap && d_mask && d_r, "null device pointer");
     SPLAHIP_REQUIRE(plan->nnz == 0 || (d_Aj && d_Ax && d_v), "null device pointer");

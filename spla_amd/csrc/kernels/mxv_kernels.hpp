@@ -233,7 +233,8 @@ namespace splahip {
                                                                     uint* __restrict__ touched,
                                                                     T* __restrict__ partial,
                                                                     uint* __restrict__ partial_ok,
-                                                                    Mult mult, Add add, int op_select, T init, uint nnz) {
+                                                                    Mult mult, Add add_raw, int op_select, T init, uint nnz) {
+        const Reassoc<Add> add(add_raw);// partials start at products: fp32 MIN / MAX must drop NaN products like the left fold from `init` does
         __shared__ uint    s_ap_all[C::kWaves][C::kRowsCap + 1];
         __shared__ Quad<T> s_prod_all[C::kWaves][C::kStage / 4 + 1];
         __shared__ uint    s_ok_all[C::kWaves][VXM ? C::kStage / 4 + 1 : 1];// VXM: 4 "product defined" bytes per quad
@@ -503,7 +504,8 @@ namespace splahip {
                                                                uint n_items, const uint* __restrict__ Ap,
                                                                const T* __restrict__ mask, T* __restrict__ r, uint* __restrict__ touched,
                                                                const T* __restrict__ partial, const uint* __restrict__ partial_ok,
-                                                               Add add, int op_select, T init) {
+                                                               Add add_raw, int op_select, T init) {
+        const Reassoc<Add> add(add_raw);
         const uint i = blockIdx.x * 256 + threadIdx.x;
         if (i >= n_items) return;
         const uint e0 = item_row[i];

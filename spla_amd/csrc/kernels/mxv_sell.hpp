@@ -111,9 +111,7 @@ namespace splahip {
 
     template<class Add>
     __device__ __forceinline__ int functor_op(const Add& add) {
-        if constexpr (Add::is_static) return Add::op_id;
-        else
-            return add.op;
+        return binop_id(add);
     }
     // the atomic of a bit-form op_add: BOR, PLUS, BXOR, uint MAX (zero family) and MIN (min-plus family; fp32 through compare-and-swap with
     // the reference's `b < a ? b : a`, so a NaN never replaces a number)
@@ -268,12 +266,13 @@ namespace splahip {
                                                   const T* __restrict__ hot_values, uint n_hot,
                                                   const T* __restrict__ mask, const T* __restrict__ v,
                                                   T* __restrict__ r, T* __restrict__ partial,
-                                                  Mult mult, Add add, int op_select, T init,
+                                                  Mult mult, Add add_raw, int op_select, T init,
                                                   bool is_const, uint cbits,
                                                   const uint* __restrict__ vbits, const uint* __restrict__ vranked,
                                                   const uint* __restrict__ selbits, const uint* __restrict__ sorder,
                                                   uint* __restrict__ touched = nullptr, T ident = T(), uint xbits = 0) {
         using C = SellCfg;
+        const Reassoc<Add> add(add_raw);// lane partials of row-exclusive slices start at products (ops.hpp: fp32 MIN / MAX drop NaN products)
         const bool xu = Ax2 == nullptr;// every matrix value is the word `xbits`: the value stream is not read
 #ifdef SPLAHIP_SELL_TIMING
         unsigned long long t_entry = 0;
@@ -875,8 +874,9 @@ namespace splahip {
     // folds a contiguous run of the row's partials, then an in-order wave reduction joins the runs (associative op_add).
     template<typename T, class Add, bool VXM>
     __device__ __forceinline__ void sell_combine_block(uint block, uint n_lrows, const uint* __restrict__ lr_row, const uint* __restrict__ lr_first,
-                                                       const T* __restrict__ partial, const T* __restrict__ mask, T* __restrict__ r, Add add, int op_select,
+                                                       const T* __restrict__ partial, const T* __restrict__ mask, T* __restrict__ r, Add add_raw, int op_select,
                                                        T init, uint* __restrict__ touched) {
+        const Reassoc<Add> add(add_raw);
         const uint i = block * (256 / kWave) + threadIdx.x / kWave;
         if (i >= n_lrows) return;
         const uint row = lr_row[i];

@@ -149,6 +149,32 @@ namespace splahip {
         }
     };
 
+    __host__ __device__ inline int binop_id(const DynBin& f) { return f.op; }
+    template<int OP>
+    __host__ __device__ constexpr int binop_id(const StaBin<OP>&) { return OP; }
+
+    // op_add as the kernels that RE-ASSOCIATE a fold use it (tree / lane-strided / segment partials that start at a product instead of
+    // at `init`).  Identical to the op except for fp32 MIN / MAX, where the reference's left fold `b < a ? b : a` from a non-NaN `init`
+    // (src/op.cpp:151-155,222-227, src/cpu/cpu_mxv.hpp:94-99) never picks a NaN second argument: a partial that STARTS at a NaN product
+    // would keep it, so the join drops a NaN on either side.  With `init` folded in by the same functor the result is the left fold's,
+    // bit for bit, for every input whose `init` is not NaN; a NaN `init` sticks in the reference and is served as op_add = FIRST
+    // (canonical_add below).  Wrap at kernel entry: `const Reassoc<Add> add(add_raw);`.
+    template<class Add>
+    struct Reassoc {
+        Add raw;
+        __host__ __device__ explicit Reassoc(const Add& a) : raw(a) {}
+        template<typename T>
+        __device__ __forceinline__ T operator()(T x, T y) const {
+            if constexpr (std::is_same<T, float>::value) {
+                const int op = binop_id(raw);
+                if (op == SPLAHIP_MIN || op == SPLAHIP_MAX) return y != y ? x : (x != x ? y : raw(x, y));
+            }
+            return raw(x, y);
+        }
+    };
+    template<class Add>
+    __host__ __device__ inline int binop_id(const Reassoc<Add>& f) { return binop_id(f.raw); }
+
     // select op, evaluated once per row: always runtime-switched
     template<typename T>
     __device__ __forceinline__ bool eval_sel(int op, T a) {
@@ -229,6 +255,14 @@ namespace splahip {
     // init 0: the reference keeps 0, a tree reaches 0 x inf = NaN), which no rounding tolerance covers.  fp32 PLUS differs by rounding
     // only (the stated 1e-5 bar).
     inline bool fold_is_reorderable(int op, int type) { return binop_is_associative(op) && !(type == SPLAHIP_FLOAT && op == SPLAHIP_MULT); }
+
+    // fp32 MIN / MAX from a NaN `init`: `b < a` is false for every b, so the reference's fold returns `init` whatever the products are
+    // (and its early exit `sum != init` fires on the first product with the sum still `init`).  That is exactly FIRST; every entry point
+    // that folds from `init` (mxv, mxm, mxmT, reduce) replaces op_add by it, so no kernel ever sees a NaN `init` under MIN / MAX.
+    inline int canonical_add(int type, int op_add, uint32_t init_bits) {
+        if (type == SPLAHIP_FLOAT && (op_add == SPLAHIP_MIN || op_add == SPLAHIP_MAX) && (init_bits & 0x7fffffffu) > 0x7f800000u) return SPLAHIP_FIRST;
+        return op_add;
+    }
 
     inline bool binop_is_commutative(int op) {
         switch (op) {

@@ -262,7 +262,7 @@ namespace splahip {
     constexpr uint kReduceBlocks = 1024;
 
     template<typename T>
-    __device__ __forceinline__ void block_fold(T& acc, bool& valid, const DynBin& op, T* s_val, int* s_ok) {
+    __device__ __forceinline__ void block_fold(T& acc, bool& valid, const Reassoc<DynBin>& op, T* s_val, int* s_ok) {
         wave_reduce_ordered(acc, valid, op);
         if (lane_id() == 0) {
             s_val[wave_id()] = acc;
@@ -282,7 +282,8 @@ namespace splahip {
         }
     }
     template<typename T>
-    __global__ __launch_bounds__(256) void reduce_partial_kernel(uint n, const T* __restrict__ x, T* __restrict__ partial, uint* __restrict__ partial_ok, DynBin op) {
+    __global__ __launch_bounds__(256) void reduce_partial_kernel(uint n, const T* __restrict__ x, T* __restrict__ partial, uint* __restrict__ partial_ok, DynBin op_raw) {
+        const Reassoc<DynBin> op(op_raw);// (ops.hpp) the tree's partials start at elements: fp32 MIN / MAX drop NaN elements like the fold from `s` does
         __shared__ T   s_val[256 / kWave];
         __shared__ int s_ok[256 / kWave];
         T              acc   = T();
@@ -307,7 +308,8 @@ namespace splahip {
         }
     }
     template<typename T>
-    __global__ __launch_bounds__(256) void reduce_final_kernel(uint n_partial, const T* __restrict__ partial, const uint* __restrict__ partial_ok, T s, T* __restrict__ out, DynBin op) {
+    __global__ __launch_bounds__(256) void reduce_final_kernel(uint n_partial, const T* __restrict__ partial, const uint* __restrict__ partial_ok, T s, T* __restrict__ out, DynBin op_raw) {
+        const Reassoc<DynBin> op(op_raw);
         __shared__ T   s_val[256 / kWave];
         __shared__ int s_ok[256 / kWave];
         T              acc   = T();
@@ -340,6 +342,7 @@ namespace splahip {
 
     template<typename T>
     int reduce_typed(uint n, const void* x, uint32_t s_bits, uint32_t* h_result, int op, hipStream_t s) {
+        op = canonical_add(TypeId<T>::value, op, s_bits);// fp32 MIN / MAX from a NaN `s`: the reference's fold keeps `s` (ops.hpp)
         const uint blocks  = std::max(1u, std::min(kReduceBlocks, (n / 4 + 255u) / 256u));
         DevMem     mem;// out[1] | partial[blocks] | ok[blocks]
         SPLAHIP_TRY(mem.alloc(s, sizeof(uint32_t) * (1 + 2 * (size_t) blocks)));

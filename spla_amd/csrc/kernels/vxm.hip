@@ -128,9 +128,38 @@ namespace splahip {
         }
     }
 
+    // vxm has no `init`: a column's fold STARTS at its first product (reference src/cpu/cpu_vxm.hpp:101-107).  Under fp32 MIN / MAX a NaN first
+    // product therefore is the result (`b < NaN` is false for every later b), while a NaN anywhere else is never picked.  The re-associating
+    // kernels drop every NaN (Reassoc, ops.hpp); the first product's rule is applied on top by whoever knows which product came first.
+    template<class Add, typename T>
+    __device__ __forceinline__ bool lead_nan_sticks(const Add& add, T first) {
+        if constexpr (std::is_same<T, float>::value) {
+            const int op = binop_id(add);
+            return (op == SPLAHIP_MIN || op == SPLAHIP_MAX) && first != first;
+        }
+        return false;
+    }
+
     // ------------------------------------------------------------------------------------------------------------
     // pull helpers
     // ------------------------------------------------------------------------------------------------------------
+    // fp32 MIN / MAX behind a pull kernel: one lane per touched output column re-evaluates the column's first product (the first present entry of
+    // row j of the transposed matrix: v's indices ascend in the pull form, so that is the reference's first) and lets a NaN there stick
+    template<class Mult>
+    __global__ __launch_bounds__(256) void pull_lead_nan_kernel(uint n_out, const uint* __restrict__ Tp, const uint* __restrict__ Tj, const uint* __restrict__ Tx,
+                                                                const uint* __restrict__ present, const float* __restrict__ v, Mult mult,
+                                                                float* __restrict__ outv, const uint* __restrict__ touched) {
+        const uint j = blockIdx.x * 256 + threadIdx.x;
+        if (j >= n_out || !touched[j]) return;
+        const uint e = Tp[j + 1];
+        for (uint k = Tp[j]; k < e; ++k) {
+            const uint i = Tj[k];
+            if (present != nullptr && ((present[i >> 5] >> (i & 31u)) & 1u) == 0) continue;
+            const float p = mult(v[i], from_bits<float>(Tx[k]));
+            if (p != p) outv[j] = p;
+            break;
+        }
+    }
     __global__ __launch_bounds__(256) void scatter_present_kernel(uint nvals, const uint* __restrict__ vi, const uint* __restrict__ vx,
                                                                   uint* __restrict__ dense, uint* __restrict__ present) {
         const uint idx = blockIdx.x * 256 + threadIdx.x;
@@ -207,7 +236,7 @@ namespace splahip {
     __global__ __launch_bounds__(256) void push_atomic_kernel(uint n_products, uint nvals, const uint* __restrict__ offs, const uint* __restrict__ vi,
                                                               const T* __restrict__ vx, const uint* __restrict__ Ap, const uint* __restrict__ Aj,
                                                               const uint* __restrict__ Ax, const T* __restrict__ mask, int op_select, Mult mult, Add add,
-                                                              u64* __restrict__ acc) {
+                                                              u64* __restrict__ acc, uint* __restrict__ nan_seen) {
         const uint p = blockIdx.x * 256 + threadIdx.x;
         if (p >= n_products) return;
         const uint idx = upper_row(offs, nvals, p);
@@ -215,6 +244,7 @@ namespace splahip {
         const uint j   = Aj[k];
         if (!eval_sel(op_select, mask[j])) return;
         const T prod = mult(vx[idx], from_bits<T>(Ax[k]));
+        if (lead_nan_sticks(add, prod)) *nan_seen = 1u;// fp32 MIN / MAX: whether a NaN sticks depends on the fold order -> the host redoes the call in the sort form
         u64*    slot = acc + j;
         u64     seen = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (true) {
@@ -273,6 +303,7 @@ namespace splahip {
                                                               const T* __restrict__ vx, const uint* __restrict__ Ap, const uint* __restrict__ Aj,
                                                               const uint* __restrict__ Ax, const T* __restrict__ mask, int op_select, Mult mult, Add add,
                                                               u64* __restrict__ acc) {
+        // gate[4]: a NaN product under fp32 MIN / MAX was seen — whether it sticks depends on the fold order, the host discards this call's result
         if (!small_gate_open(gate, max_products)) return;
         // blockIdx.y: the row is shared by gridDim.y workgroups (a lone hub of 64 K entries would otherwise be one workgroup's 250 rounds)
         const uint row = vi[blockIdx.x];
@@ -282,6 +313,7 @@ namespace splahip {
             const uint j = Aj[k];
             if (!eval_sel(op_select, mask[j])) continue;
             const T prod = mult(x, from_bits<T>(Ax[k]));
+            if (lead_nan_sticks(add, prod)) const_cast<uint*>(gate)[4] = 1u;
             u64*    slot = acc + j;
             u64     seen = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             while (true) {
@@ -398,7 +430,8 @@ namespace splahip {
     template<typename T, class Add, bool TREE>
     __global__ __launch_bounds__(256) void long_run_kernel(const uint* __restrict__ key, const T* __restrict__ val, uint n,
                                                            const uint* __restrict__ long_count, const uint* __restrict__ long_pos,
-                                                           const uint* __restrict__ long_rank, T* __restrict__ out_x, Add add) {
+                                                           const uint* __restrict__ long_rank, T* __restrict__ out_x, Add add_raw) {
+        const Reassoc<Add> add(add_raw);// (ops.hpp) lane partials start at products
         const uint w = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
         if (w >= *long_count) return;
         const uint lane = lane_id();
@@ -424,7 +457,11 @@ namespace splahip {
                 for (uint q = ks + 1; q < ke; ++q) part = add(part, val[q]);
             }
             wave_reduce_ordered(part, valid, add);
-            if (lane == 0) out_x[long_rank[w]] = part;
+            if (lane == 0) {
+                // a column folds from its FIRST product (cpu_vxm.hpp:101-107): under fp32 MIN / MAX a NaN there sticks (`b < NaN` is false)
+                if (lead_nan_sticks(add_raw, val[p])) part = val[p];
+                out_x[long_rank[w]] = part;
+            }
         } else {
             if (lane == 0) {
                 T acc = val[p];
@@ -495,6 +532,11 @@ namespace splahip {
                                    op_select, T(0));
         }
         SPLAHIP_TRY(hipGetLastError());
+        if constexpr (std::is_same<T, float>::value) {
+            if (op_add == SPLAHIP_MIN || op_add == SPLAHIP_MAX)
+                hipLaunchKernelGGL((pull_lead_nan_kernel<Mult>), dim3((n_out + 255) / 256), dim3(256), 0, s, n_out, Tp, Tj, static_cast<const uint*>(Tx), d_present,
+                                   reinterpret_cast<const float*>(d_v), Mult(op_mult), reinterpret_cast<float*>(ws_outv), ws_touched);
+        }
         // compaction of the touched columns, ascending
         hipLaunchKernelGGL(flag_count_kernel, dim3(n_chunks), dim3(256), 0, s, ws_touched, n_out, ws_chunk);
         hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, ws_chunk, n_chunks);
@@ -561,7 +603,7 @@ namespace splahip {
 
     template<typename T>
     int push_small_typed(uint n_cols, const uint* Ap, const uint* Aj, const void* Ax, const void* mask, uint nvals, const uint* vi, const void* vx, uint* ri,
-                         void* rx, uint max_products, uint* h_out /* count, products lo, products hi, unsorted */, int op_mult, int op_add, int op_select,
+                         void* rx, uint max_products, uint* h_out /* count, products lo, products hi, unsorted, NaN seen */, int op_mult, int op_add, int op_select,
                          hipStream_t s) {
         SmallPushWs& ws       = small_push_ws();
         const uint   n_chunks = (n_cols + 1023u) / 1024u;
@@ -572,15 +614,15 @@ namespace splahip {
             ws.words = n_cols;
             SPLAHIP_TRY(hipMemsetAsync(ws.acc, 0, sizeof(u64) * (size_t) n_cols, s));
         }
-        if (ws.misc_words < (size_t) n_chunks + 8) {
+        if (ws.misc_words < (size_t) n_chunks + 12) {
             if (ws.misc) (void) hipFree(ws.misc);
             ws.misc = nullptr, ws.misc_words = 0;
-            SPLAHIP_TRY(hipMalloc(reinterpret_cast<void**>(&ws.misc), sizeof(uint) * ((size_t) n_chunks + 8)));
-            ws.misc_words = (size_t) n_chunks + 8;
+            SPLAHIP_TRY(hipMalloc(reinterpret_cast<void**>(&ws.misc), sizeof(uint) * ((size_t) n_chunks + 12)));
+            ws.misc_words = (size_t) n_chunks + 12;
         }
-        uint* gate  = ws.misc;// [0..1] products, [2] unsorted
-        uint* chunk = ws.misc + 4;
-        SPLAHIP_TRY(hipMemsetAsync(gate, 0, 16, s));
+        uint* gate  = ws.misc;// [0..1] products, [2] unsorted, [3] count, [4] NaN product under fp32 MIN / MAX
+        uint* chunk = ws.misc + 8;
+        SPLAHIP_TRY(hipMemsetAsync(gate, 0, 32, s));
         hipLaunchKernelGGL(probe_kernel, dim3((nvals + 255) / 256), dim3(256), 0, s, nvals, vi, Ap, reinterpret_cast<unsigned long long*>(gate), gate + 2);
         const uint share = std::max(1u, std::min(64u, 16384u / nvals));// workgroups per frontier entry: few entries -> split their rows
         hipLaunchKernelGGL((push_direct_kernel<T, DynBin, DynBin>), dim3(nvals, share), dim3(256), 0, s, gate, max_products, vi, static_cast<const T*>(vx), Ap, Aj,
@@ -589,10 +631,10 @@ namespace splahip {
         hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk, n_chunks);
         hipLaunchKernelGGL(acc_write_reset_kernel, dim3(n_chunks), dim3(256), 0, s, gate, max_products, ws.acc, n_cols, chunk, ri, static_cast<uint*>(rx));
         SPLAHIP_TRY(hipGetLastError());
-        uint h[4] = {0, 0, 0, 0};// products lo, hi, unsorted, count
-        SPLAHIP_TRY(hipMemcpyAsync(h, gate, 4 * sizeof(uint), hipMemcpyDeviceToHost, s));
+        uint h[5] = {0, 0, 0, 0, 0};// products lo, hi, unsorted, count, NaN seen
+        SPLAHIP_TRY(hipMemcpyAsync(h, gate, 5 * sizeof(uint), hipMemcpyDeviceToHost, s));
         SPLAHIP_TRY(hipStreamSynchronize(s));
-        h_out[0] = h[3], h_out[1] = h[0], h_out[2] = h[1], h_out[3] = h[2];
+        h_out[0] = h[3], h_out[1] = h[0], h_out[2] = h[1], h_out[3] = h[2], h_out[4] = h[4];
         return SPLAHIP_OK;
     }
 
@@ -629,21 +671,27 @@ namespace splahip {
 
         if (n_products <= kPushAtomicMax && push_order_free(op_add, TypeId<T>::value) && !push_atomic_disabled()) {
             const uint n_chunks = (n_cols + 1023u) / 1024u;
-            DevMem     body;// acc[n_cols] (8 bytes each) | chunk[n_chunks + 1]
-            SPLAHIP_TRY(body.alloc(s, sizeof(u64) * (size_t) n_cols + sizeof(uint) * ((size_t) n_chunks + 1)));
+            DevMem     body;// acc[n_cols] (8 bytes each) | chunk[n_chunks + 1] | NaN-seen flag
+            SPLAHIP_TRY(body.alloc(s, sizeof(u64) * (size_t) n_cols + sizeof(uint) * ((size_t) n_chunks + 2)));
             u64*  acc   = body.as<u64>();
             uint* chunk = reinterpret_cast<uint*>(acc + n_cols);
             SPLAHIP_TRY(hipMemsetAsync(acc, 0, sizeof(u64) * (size_t) n_cols, s));
+            SPLAHIP_TRY(hipMemsetAsync(chunk + n_chunks + 1, 0, sizeof(uint), s));
             hipLaunchKernelGGL((push_atomic_kernel<T, DynBin, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, n_products, nvals, offs, vi,
                                static_cast<const T*>(vx), Ap, Aj, static_cast<const uint*>(Ax), static_cast<const T*>(mask), op_select, DynBin(op_mult),
-                               DynBin(op_add), acc);
+                               DynBin(op_add), acc, chunk + n_chunks + 1);
             hipLaunchKernelGGL(acc_count_kernel, dim3(n_chunks), dim3(256), 0, s, acc, n_cols, chunk);
             hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk, n_chunks);
             hipLaunchKernelGGL(acc_write_kernel, dim3(n_chunks), dim3(256), 0, s, acc, n_cols, chunk, ri, static_cast<uint*>(rx));
             SPLAHIP_TRY(hipGetLastError());
-            SPLAHIP_TRY(hipMemcpyAsync(h_count, chunk + n_chunks, sizeof(uint), hipMemcpyDeviceToHost, s));
+            uint h[2] = {0, 0};// count, NaN seen
+            SPLAHIP_TRY(hipMemcpyAsync(h, chunk + n_chunks, 2 * sizeof(uint), hipMemcpyDeviceToHost, s));
             SPLAHIP_TRY(hipStreamSynchronize(s));
-            return SPLAHIP_OK;
+            if (h[1] == 0) {
+                *h_count = h[0];
+                return SPLAHIP_OK;
+            }
+            // a NaN product under fp32 MIN / MAX: the sort form below folds in the reference's order
         }
 
         // stable LSD radix sort by column: equal columns keep the expand order = the reference's fold order
@@ -753,7 +801,7 @@ int splahip_vxm_push_small(int type, uint32_t n_rows, uint32_t n_cols, const uin
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
     hipStream_t s = as_stream(stream);
-    uint32_t    out[4] = {0, 0, 0, 0};
+    uint32_t    out[5] = {0, 0, 0, 0, 0};
     switch (type) {
         case SPLAHIP_INT: st = push_small_typed<int32_t>(n_cols, d_Ap, d_Aj, d_Ax, d_mask, nvals, d_vi, d_vx, d_ri, d_rx, max_products, out, op_mult, op_add, op_select, s); break;
         case SPLAHIP_UINT: st = push_small_typed<uint32_t>(n_cols, d_Ap, d_Aj, d_Ax, d_mask, nvals, d_vi, d_vx, d_ri, d_rx, max_products, out, op_mult, op_add, op_select, s); break;
@@ -763,7 +811,7 @@ int splahip_vxm_push_small(int type, uint32_t n_rows, uint32_t n_cols, const uin
     if (st != SPLAHIP_OK) return st;
     *h_products = ((uint64_t) out[2] << 32) | out[1];
     *h_sorted   = out[3] ? 0 : 1;
-    *h_done     = (*h_products == 0 || *h_products <= max_products) ? 1 : 0;
+    *h_done     = (*h_products == 0 || *h_products <= max_products) && out[4] == 0 ? 1 : 0;// (out[4]: a NaN product under fp32 MIN / MAX -> the ordered forms)
     *h_count    = *h_done ? out[0] : 0;
     return SPLAHIP_OK;
 }

@@ -20,7 +20,7 @@ def host(t: torch.Tensor, np_dtype) -> np.ndarray:
     return a.view(np_dtype) if a.dtype != np_dtype else a
 
 
-def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, init, early_exit=False, junk=None):
+def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, init, early_exit=False, junk=None, exact=False):
     """Run the masked SpMV twice — the CSR wave-tile / row kernels (what the operator API uses) and the same call with the opt-in
     sliced-ELL copy attached — and cross-check them: bit-identical for int / uint, within 1e-5 for fp32 (the sliced-ELL form folds
     every row <= 256 entries strictly in entry order, the CSR form uses an in-order tree for rows > 32).  Returns the CSR result."""
@@ -52,6 +52,9 @@ def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, 
         plan.close()
     os.environ["SPLAHIP_SELL_BITS"] = "1"
     os.environ["SPLAHIP_COB_BITS"] = "1"
+    if exact:  # folds that select (MIN / MAX): every form must give the reference's word, NaN payloads and all
+        for form, out in outs.items():
+            assert np.array_equal(out.view(np.uint32), outs["csr"].view(np.uint32)), f"{form} differs bit-wise from the CSR kernels"
     assert np.array_equal(outs["sell-bits"].view(np.uint32), outs["sell"].view(np.uint32)), "sliced-ELL sparse-vector form differs from the value form"
     if t == "FLOAT":
         a, b = outs["sell"].astype(np.float64), outs["csr"].astype(np.float64)

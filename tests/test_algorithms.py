@@ -160,6 +160,27 @@ def test_hip_eadd_and_reduce_equal_oracle(oracle, t):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("op", ["MIN", "MAX"])
+def test_hip_reduce_fp32_min_max_with_nan(oracle, op):
+    """the reduce tree under fp32 MIN / MAX: NaN elements are never picked by the reference's fold from `s`, a NaN `s` sticks (src/op.cpp:151-155)"""
+    import ctypes as C
+    from gpu_utils import dev
+    from spla_amd import _lib
+    from spla_amd.kernels import _ptr, current_stream_ptr
+    from spla_amd.ops import binop_id, type_id
+    rng = np.random.default_rng(37)
+    x = (rng.integers(-4000, 4000, 300001) / 8.0).astype(np.float32)
+    x[rng.random(len(x)) < 0.1] = np.nan
+    x[:9] = np.nan  # whole quads of NaN at the start of the first lane's share
+    dx = dev(x)
+    for s in (np.float32(0.5), np.float32(np.inf), np.float32(-np.inf), np.float32(np.nan)):
+        out = C.c_uint32()
+        _lib.call("splahip_reduce", type_id("FLOAT"), len(x), _ptr(dx), int(np.array([s]).view(np.uint32)[0]), C.byref(out), binop_id(op), current_stream_ptr())
+        want = np.array([oracle.reduce("FLOAT", x, op, s)], np.float32).view(np.uint32)[0]
+        assert out.value == want, (op, s, hex(out.value), hex(want))
+
+
+@pytest.mark.gpu
 def test_hip_reduce_fp32_plus_within_tolerance(oracle):
     """fp32 PLUS through a fixed tree instead of the sequential fold: <= 1e-5 relative on positive data (tolerance of the north star)"""
     import ctypes as C

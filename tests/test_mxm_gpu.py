@@ -274,3 +274,38 @@ def test_mxmT_count_mode_of_uniform_values(oracle, t):
             got = kernels.mxmT_masked(t, n, dL, dL, dL, mul, add, "ALWAYS", init)
             exact = not (t == "FLOAT" and add in ("PLUS", "MULT"))
             _same_csr(_host3(got, t), want, t, exact, f"mxmT count mode {t} x={xval} odd={odd} {mul}/{add}")
+
+
+@pytest.mark.parametrize("add", ["MIN", "MAX"])
+def test_fp32_min_max_nan_products_and_nan_init(oracle, add):
+    """mxm / mxmT fold from `init` (src/cpu/cpu_mxm.hpp:93-113, cpu_mxmT_masked.hpp:94-123): under fp32 MIN / MAX a NaN product is never picked and
+    a NaN init sticks (and `r != init` then keeps every touched entry).  Long runs / heavy entries are folded by whole wavefronts — same words."""
+    from spla_amd import kernels
+    t = "FLOAT"
+    rng = np.random.default_rng(59 + (add == "MAX"))
+    m, k, n = 300, 350, 260
+    A = random_csr(rng, m, k, 8, t, skew=True, long_rows=2, long_len=300)
+    B = random_csr(rng, k, n, 8, t, skew=True, long_rows=2, long_len=250)
+    A = (A[0], A[1], (rng.integers(-50, 400, len(A[1])) / 8.0).astype(np.float32))
+    bx = (rng.integers(-50, 400, len(B[1])) / 8.0).astype(np.float32)
+    bx[rng.random(len(bx)) < 0.05] = np.nan
+    bx[rng.random(len(bx)) < 0.05] = np.inf
+    B = (B[0], B[1], bx)
+    for init in (np.float32(100.0), np.float32(np.inf), np.float32(-np.inf), np.float32(np.nan)):
+        want = oracle.mxm(t, m, n, A, B, "PLUS", add, init)
+        got, _ = kernels.mxm(t, m, n, _dev3(A, t), _dev3(B, t), "PLUS", add, init)
+        _same_csr(_host3(got, t), want, t, True, f"mxm PLUS/{add} init={init}")
+    # mxmT: B^T rows share columns with A rows
+    m, k, n = 400, 500, 380
+    A = random_csr(rng, m, k, 14, t, skew=True, long_rows=3, long_len=420)
+    Bt = random_csr(rng, n, k, 14, t, skew=True, long_rows=3, long_len=400)
+    ax = (rng.integers(-50, 400, len(A[1])) / 8.0).astype(np.float32)
+    ax[rng.random(len(ax)) < 0.05] = np.nan
+    A = (A[0], A[1], ax)
+    Bt = (Bt[0], Bt[1], (rng.integers(-50, 400, len(Bt[1])) / 8.0).astype(np.float32))
+    Mk = random_csr(rng, m, n, 25, t)
+    Mk = (Mk[0], Mk[1], random_mask(rng, len(Mk[1]), t))
+    for init, sel in ((np.float32(100.0), "ALWAYS"), (np.float32(np.nan), "NQZERO"), (np.float32(-np.inf), "GTZERO")):
+        want = oracle.mxmT_masked(t, m, Mk, A, Bt, "PLUS", add, sel, init)
+        got = kernels.mxmT_masked(t, m, _dev3(Mk, t), _dev3(A, t), _dev3(Bt, t), "PLUS", add, sel, init)
+        _same_csr(_host3(got, t), want, t, True, f"mxmT PLUS/{add} init={init} {sel}")

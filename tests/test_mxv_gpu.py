@@ -449,7 +449,8 @@ def test_frontier_form_counts_hits(oracle, t):
 def test_fp32_min_max_keyed_form(oracle, add):
     """fp32 MIN / MAX over op_mult = PLUS on the column-ordered blocks (the reference's own SSSP semiring, src/algorithm.cpp:208-213): the LDS
     slice holds order-preserving integer keys.  Infinities of both signs, NaN in v (a NaN product is never picked by std::min / std::max as
-    the second argument), negative weights, a NaN / infinite init, and a matrix holding -0.0f (the form must decline) — all bit for bit."""
+    the second argument) through ALL FIVE kernel forms, negative weights, a NaN / infinite init, and a matrix holding -0.0f (the keyed form
+    must decline) — all bit for bit."""
     import os
     import torch
     from gpu_utils import dev, hip_mxv, host
@@ -481,9 +482,12 @@ def test_fp32_min_max_keyed_form(oracle, add):
             want = oracle.mxv_masked("FLOAT", n_rows, n_cols, Ap, Aj, w, mask, v, "PLUS", add, sel, init)
             got = hip_mxv("FLOAT", n_rows, n_cols, Ap, Aj, w, mask, v, "PLUS", add, sel, init, junk=3.0)  # every layout, cross-checked
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (add, init, sel)
-            # NaN among the products: the keyed form drops them as the reference's sequential fold does (the CSR tree and the sliced-ELL lanes
-            # reorder the fold, which a NaN does not survive — so these inputs go through the column-ordered blocks only)
+            # NaN among the products: the reference's sequential fold never picks a NaN second argument (src/op.cpp:151-155) and a NaN init
+            # sticks.  Every form — CSR wave tiles (in-order tree), sliced-ELL (lane-strided partials), the blocks' keyed form — must agree
+            # with it bit for bit (Reassoc / canonical_add, ops.hpp)
             want = oracle.mxv_masked("FLOAT", n_rows, n_cols, Ap, Aj, w, mask, v_nan, "PLUS", add, sel, init)
+            got = hip_mxv("FLOAT", n_rows, n_cols, Ap, Aj, w, mask, v_nan, "PLUS", add, sel, init, junk=3.0, exact=True)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (add, init, sel, "NaN products, all five forms")
             for p in plans:
                 r = torch.full((n_rows,), 3.0, dtype=torch.float32, device="cuda")
                 kernels.mxv_masked(p, "FLOAT", n_cols, dAp, dAj, dw, dev(mask), dev(v_nan), r, "PLUS", add, sel, init)

@@ -115,3 +115,48 @@ def test_mxm_and_mxmT_oracle_equals_reference(oracle, reference, t):
         b = reference.mxmT_masked(t, m, Mk, A, Bt, mul, add, sel, init, n_cols=n, inner=k)
         for x, y in zip(a, b):
             np.testing.assert_array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32), err_msg=f"mxmT {t} {mul}/{add} {sel}")
+
+
+@pytest.mark.parametrize("add", ["MIN", "MAX"])
+def test_fp32_min_max_nan_rules_oracle_equals_reference(oracle, reference, add):
+    """The NaN rules the HIP kernels are held to (tests/test_*_gpu.py: *nan*), pinned on the reference itself: std::min / std::max never pick a NaN
+    second argument, a NaN first argument (init, or the first product of a vxm column) sticks (src/op.cpp:151-155,222-227)."""
+    rng = np.random.default_rng(5 + (add == "MAX"))
+    t = "FLOAT"
+    n_rows, n_cols = 61, 53
+    Ap, Aj, _ = random_csr(rng, n_rows, n_cols, 7, t, skew=True)
+    Ax = (rng.integers(-40, 400, len(Aj)) / 8.0).astype(np.float32)
+    v = (rng.integers(-500, 5000, n_cols) / 4.0).astype(np.float32)
+    v[rng.random(n_cols) < 0.25] = np.nan
+    v[rng.random(n_cols) < 0.2] = np.inf
+    for init in (np.float32(12.5), np.float32(np.inf), np.float32(np.nan)):
+        for early in (False, True):
+            mask = random_mask(rng, n_rows, t)
+            a = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, "PLUS", add, "NQZERO", init, early)
+            b = reference.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, "PLUS", add, "NQZERO", init, early)
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32), err_msg=f"mxv init={init} early={early}")
+    vi = np.sort(rng.permutation(n_cols)[:30]).astype(np.uint32)  # vxm: v indexes the ROWS of the (n_cols x n_rows) transposed problem below
+    AT = random_csr(rng, n_cols, n_rows, 7, t, skew=True)
+    ATx = (rng.integers(-40, 400, len(AT[1])) / 8.0).astype(np.float32)
+    vx = v[vi].copy()
+    vx[0] = np.nan
+    a = oracle.vxm_masked(t, n_cols, n_rows, AT[0], AT[1], ATx, np.ones(n_rows, np.float32), vi, vx, "PLUS", add, "ALWAYS")
+    b = reference.vxm_masked(t, n_cols, n_rows, AT[0], AT[1], ATx, np.ones(n_rows, np.float32), vi, vx, "PLUS", add, "ALWAYS")
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    assert np.isnan(a[1]).any() and not np.isnan(a[1]).all()
+    A = random_csr(rng, 23, 31, 5, t)
+    B = random_csr(rng, 31, 19, 5, t)
+    bx = B[2].astype(np.float32)
+    bx[rng.random(len(bx)) < 0.2] = np.nan
+    B = (B[0], B[1], bx)
+    for init in (np.float32(100.0), np.float32(np.nan)):
+        a = oracle.mxm(t, 23, 19, A, B, "PLUS", add, init)
+        b = reference.mxm(t, 23, 19, A, B, "PLUS", add, init)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(np.asarray(x).view(np.uint32), np.asarray(y).view(np.uint32), err_msg=f"mxm init={init}")
+    x = (rng.integers(-400, 400, 77) / 8.0).astype(np.float32)
+    x[rng.random(77) < 0.3] = np.nan
+    x[0] = np.nan
+    for s in (np.float32(0.5), np.float32(np.nan)):
+        assert np.array_equal(np.array([oracle.reduce(t, x, add, s)], np.float32).view(np.uint32), np.array([reference.reduce(t, x, add, s)], np.float32).view(np.uint32))

@@ -191,3 +191,38 @@ def test_push_small_frontier_form(oracle, t):
     done, _, _, ri, rx = kernels.vxm_push_small(t, n_rows, n_cols, dAp, dAj, dAx, dev(np.zeros(n_cols, NP[t])), dev(vi), dev(np.asarray(vx, NP[t])), "MULT", "MIN",
                                                 "ALWAYS", 1 << 20)
     assert done and np.array_equal(host(ri, np.uint32), want_i) and np.array_equal(host(rx, NP[t]).view(np.uint32), want_x.view(np.uint32))
+
+
+@pytest.mark.parametrize("add", ["MIN", "MAX"])
+def test_fp32_min_max_nan_products_every_form(oracle, add, monkeypatch):
+    """fp32 MIN / MAX with NaN among the products (reference src/op.cpp:151-155 via src/cpu/cpu_vxm.hpp:101-107): a column folds from its FIRST
+    product, so a NaN there is the result, and a NaN anywhere else is never picked.  Every form of vxm — the compare-and-swap push (must notice the
+    NaN and hand over to the ordered form), the sort form with its wave-folded long runs, the pull kernels over the CSR of the transpose, its
+    sliced-ELL copy and its column-ordered blocks — must reproduce that bit for bit."""
+    rng = np.random.default_rng(97 + (add == "MAX"))
+    t = "FLOAT"
+    n_rows, n_cols = 1700, 1300
+    Ap, Aj, _ = random_csr(rng, n_rows, n_cols, 9, t, skew=True, long_rows=3, long_len=1200)
+    nnz = len(Aj)
+    Ax = (rng.integers(1, 400, nnz) / 8.0).astype(np.float32)
+    for frac_nan, nv in ((0.05, n_rows), (0.3, n_rows), (0.1, 600), (0.5, 40)):
+        vi = np.sort(rng.permutation(n_rows)[:nv]).astype(np.uint32)
+        vx = (rng.integers(-500, 5000, nv) / 4.0).astype(np.float32)
+        vx[rng.random(nv) < 0.2] = np.inf
+        vx[rng.random(nv) < frac_nan] = np.nan
+        if nv == n_rows:
+            vx[0] = np.nan  # the first product of every column row 0 reaches
+        for sel in ("ALWAYS", "NQZERO"):
+            mask = random_mask(rng, n_cols, t)
+            want = oracle.vxm_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, "PLUS", add, sel)
+            assert np.isnan(want[1]).any() and not np.isnan(want[1]).all()
+            for form in ("auto", "sort"):
+                monkeypatch.setenv("SPLAHIP_PUSH_ATOMIC", "0" if form == "sort" else "1")
+                got = _push(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, "PLUS", add, sel)
+                np.testing.assert_array_equal(got[0], want[0], err_msg=f"push {form} idx")
+                np.testing.assert_array_equal(got[1].view(np.uint32), want[1].view(np.uint32), err_msg=f"push {form} val nv={nv}")
+            monkeypatch.delenv("SPLAHIP_PUSH_ATOMIC")
+            for form in ((False, True, "cob", "cob-small") if nv == n_rows else (False,)):
+                got = _pull(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, "PLUS", add, sel, identity=(nv == n_rows), sell=form)
+                np.testing.assert_array_equal(got[0], want[0], err_msg=f"pull idx sell={form}")
+                np.testing.assert_array_equal(got[1].view(np.uint32), want[1].view(np.uint32), err_msg=f"pull val sell={form} nv={nv}")
