@@ -106,6 +106,11 @@ int splahip_csr_plan_cob_info(splahip_plan plan, uint32_t* n_tiles, uint32_t* n_
 int splahip_csr_plan_cob_layout(splahip_plan plan, uint32_t* n_ranges, uint32_t* n_hub_ranges, uint32_t* n_hub_rows, uint64_t* bytes);
 /* slots (rows) of a hub range and of a natural range of the copy (0 / 0 without one) */
 int splahip_csr_plan_cob_slots(splahip_plan plan, uint32_t* hub_slots, uint32_t* natural_slots);
+/* What the last MASKED call over the blocks (op_select other than ALWAYS) found when it probed its mask on the device — a blocking read-back for tests and
+ * benches: *selected_entries ~ entries of the selected rows (a 1-in-16 sample of the rows, scaled; exact below 2^18 rows), *served_by_rows = 1 when the
+ * selected-rows kernels served the call (the selection holds too few entries for the blocks, which stream the whole matrix whatever the mask).  Both zero when
+ * no probe has run.  Reference behaviour served: src/cpu/cpu_mxv.hpp:89-92 (unselected rows cost nothing). */
+int splahip_csr_plan_cob_probe(splahip_plan plan, uint64_t* selected_entries, int* served_by_rows);
 /* footprint: device bytes held for the matrix besides its CSR arrays — plan (work items + call workspace), sliced-ELL copy, column-ordered blocks (0: not built).
  * prefers_sell: 1 when splahip_mxv_masked runs this semiring on the sliced-ELL copy even beside the column-ordered blocks (the zero-family sparse-vector
  * forms, a BFS step): a host that builds copies on demand needs the +12 B per entry of the sliced-ELL copy only for these.                          */

@@ -270,6 +270,77 @@ namespace {
     // set by cob_mxv_accumulate around its call (per host thread): the launch below then folds onto the values r already holds
     thread_local uint32_t tl_accumulate = 0;
 
+    // The mask probe of a masked call (op_select other than ALWAYS): how many ENTRIES does the selection cover?  A 1-in-`stride` sample of the rows (2048-row
+    // groups, every row of a group: coalesced loads of mask and Ap), scaled — a few MB, ~4 us at R-MAT 23; visiting every hub row instead cost 65 us of scattered
+    // 4-byte gathers (profiles/r04_notes.md 3).  The last workgroup to finish compares what the selected-rows kernels would cost — every selected row is
+    // ~20 line requests of its own: ~rows_x10 / 10 blocks-entries per selected entry, plus their passes over mask / Ap / r — with the blocks' stream of the whole
+    // matrix, and leaves the estimate and the verdict (1: the row kernels) in pinned HOST memory.  Both sides compute the reference's result for any mask, so the
+    // verdict is only a hint: the host reads the latest one that has arrived before it enqueues its NEXT masked call over the plan (no synchronisation, no gated
+    // launches: enqueueing both sides behind a device-side decision cost a dense masked call 4 - 5 us per launch that returned at once, 45 us in all).
+    template<typename T>
+    __global__ __launch_bounds__(256) void cob_mask_probe_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, uint32_t stride,
+                                                                 uint32_t rows_x10, uint32_t nnz, uint32_t* __restrict__ probe, volatile uint32_t* __restrict__ host_words,
+                                                                 uint32_t seq, const uint32_t* __restrict__ hub_row, uint32_t heavy_slots, uint32_t heavy_deg, uint32_t long_x10,
+                                                                 uint32_t* __restrict__ rows_ctl) {
+        __shared__ unsigned long long s_sum[2][256 / kWave];
+        unsigned long long sel_entries = 0, sel_cost = 0;// entries of the selected rows; what they cost the row kernels, in tenths of a blocks-entry
+        const uint32_t n_groups = (n_rows + stride * 2048u - 1) / (stride * 2048u);
+        for (uint32_t gi = blockIdx.x; gi < n_groups; gi += gridDim.x) {
+            // (which of the stride's groups is sampled varies pseudo-randomly: a generator's labels put its hubs at regular strides)
+            const uint32_t row0 = (gi * stride + ((gi * 2654435761u) >> 9) % stride) * 2048u + threadIdx.x * 8u;
+            if (row0 < n_rows) {// (every load issued before the first use; a row behind the matrix's end re-reads the last one)
+                T        mk[8];
+                uint32_t ap[9];
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j) mk[j] = mask[min(row0 + j, n_rows - 1)];
+#pragma unroll
+                for (uint32_t j = 0; j < 9; ++j) ap[j] = Ap[min(row0 + j, n_rows)];
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j)
+                    if (row0 + j < n_rows && ap[j + 1] - ap[j] < heavy_deg && eval_sel<T>(op_select, mk[j])) {
+                        sel_entries += (unsigned long long) (ap[j + 1] - ap[j]) * stride;
+                        sel_cost += (unsigned long long) (ap[j + 1] - ap[j]) * stride * rows_x10;
+                    }
+            }
+        }
+        // the heaviest rows are no matter for a sample (a generator's first rows hold a quarter of a scale-free matrix: one sampled group of them would say anything):
+        // the first two hub ranges' rows — the heavy_slots rows of degree >= heavy_deg — are visited one by one
+        for (uint32_t s0 = blockIdx.x * 256 + threadIdx.x; s0 < heavy_slots; s0 += gridDim.x * 256) {
+            const uint32_t row = hub_row[s0];
+            if (row != 0xFFFFFFFFu) {
+                const uint32_t d = Ap[row + 1] - Ap[row];
+                if (d >= heavy_deg && eval_sel<T>(op_select, mask[row])) sel_entries += d, sel_cost += (unsigned long long) d * long_x10;
+            }
+        }
+        for (unsigned off = kWave / 2; off > 0; off >>= 1) sel_entries += __shfl_xor(sel_entries, off, kWave), sel_cost += __shfl_xor(sel_cost, off, kWave);
+        if (lane_id() == 0) s_sum[0][threadIdx.x / kWave] = sel_entries, s_sum[1][threadIdx.x / kWave] = sel_cost;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long tot = 0, cost = 0;
+            for (uint32_t w = 0; w < 256 / kWave; ++w) tot += s_sum[0][w], cost += s_sum[1][w];
+            if (tot) {
+                atomicAdd(reinterpret_cast<unsigned long long*>(probe), tot);
+                atomicAdd(reinterpret_cast<unsigned long long*>(probe + 4), cost);
+            }
+            __threadfence();
+            if (atomicAdd(&probe[2], 1u) == gridDim.x - 1) {// the last workgroup: every other one's sum is behind its fence
+                __threadfence();
+                const unsigned long long sel_nnz = __hip_atomic_load(reinterpret_cast<unsigned long long*>(probe), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // what the HOST reads before its next masked call over this plan (pinned memory, no synchronisation: a hint that lags by a call)
+                host_words[0] = (uint32_t) sel_nnz, host_words[1] = (uint32_t) (sel_nnz >> 32);
+                const unsigned long long sel_cost_all = __hip_atomic_load(reinterpret_cast<unsigned long long*>(probe + 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                host_words[2] = sel_cost_all / 10ull + nnz / 6ull < nnz ? 1u : 0u;
+                __threadfence_system();
+                host_words[3] = seq;
+                // the accumulators return to zero for the next probe (nobody else touches them in this launch)
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(probe), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&probe[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(probe + 4), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (rows_ctl != nullptr) rows_ctl[0] = 0u, rows_ctl[1] = 0u;// the row kernels' list lengths (mxv_rows.hpp) start every call at zero: no memset to enqueue
+            }
+        }
+    }
+
     static thread_local uint32_t tl_skip_bits = 0;// the v value whose entries the sparse-vector form skips in the running call (0; init for min-plus)
 
     // any negative / NaN value, and the largest value, of the copy's value words (padding slots hold 0)
@@ -337,6 +408,7 @@ namespace {
         a.accumulate = VXM ? 0u : tl_accumulate;
         a.vbits      = g->d_vbits;
         a.x_uniform  = g->x_bits;
+        a.gate       = nullptr;
         if constexpr (MODE != 0) {// the bitmap of v for this call
             hipLaunchKernelGGL((cob_vbits_kernel<T>), dim3((g->n_cols + 255) / 256), dim3(256), 0, st, g->n_cols, static_cast<const T*>(v), g->d_vbits, tl_skip_bits);
             SPLAHIP_TRY(hipGetLastError());
@@ -375,7 +447,7 @@ namespace {
         if (g->hub_finish == 1 && g->n_hub_ranges) {
             const uint32_t n_slots = g->n_hub_ranges * g->R;
             hipLaunchKernelGGL((cob_hub_finish_kernel<T, ACC, VXM>), dim3((n_slots + 255) / 256), dim3(256), 0, st, n_slots, g->R, g->acc_stride, g->d_acc, g->d_hub_row, static_cast<const T*>(mask),
-                               static_cast<T*>(r), touched, a.accumulate, DynBin(op_add), op_select, init);
+                               static_cast<T*>(r), touched, a.accumulate, DynBin(op_add), op_select, init, a.gate);
             SPLAHIP_TRY(hipGetLastError());
         }
         return SPLAHIP_OK;
@@ -472,7 +544,8 @@ namespace splahip {
 
     void cob_release(splahip_cob_s* g) {
         if (!g) return;
-        for (void* p : {(void*) g->d_hdr, (void*) g->d_cr, (void*) g->d_ax, (void*) g->d_slot16, (void*) g->d_hub_row, (void*) g->d_acc, (void*) g->d_ticket, (void*) g->d_vbits,
+        if (g->h_probe) (void) hipHostFree(const_cast<uint32_t*>(g->h_probe));
+        for (void* p : {(void*) g->d_hdr, (void*) g->d_cr, (void*) g->d_ax, (void*) g->d_slot16, (void*) g->d_hub_row, (void*) g->d_acc, (void*) g->d_ticket, (void*) g->d_vbits, (void*) g->d_probe,
                         (void*) g->sched[0].d_tiles, (void*) g->sched[0].d_ranges, (void*) g->sched[1].d_tiles, (void*) g->sched[1].d_ranges})
             if (p) (void) hipFree(p);
         delete g;
@@ -506,6 +579,34 @@ namespace splahip {
             case SPLAHIP_FLOAT: return cob_typed<float, false>(plan->cob, Ap, mask, v, r, nullptr, op_mult, op_add, op_select, init_bits, st);
         }
         return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
+    }
+
+    int cob_mask_probe(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, int op_select, void* stream) {
+        const splahip_cob_s* g = plan ? plan->cob : nullptr;
+        if (!g || !g->d_probe || !g->h_probe || op_select == SPLAHIP_ALWAYS || env_u32("SPLAHIP_MASK_PROBE", 1) == 0) return 0;
+        // the verdict of the latest probe that has finished (of an earlier call: the masks of consecutive calls usually select alike)
+        const int      rows     = g->h_probe[3] != 0u && g->h_probe[2] != 0u ? 1 : 0;
+        hipStream_t    st       = as_stream(stream);
+        const uint32_t stride   = std::max(1u, std::min(64u, g->n_rows >> 16));// a 1-in-64 sample once there are millions of rows; every row of a small matrix
+        // a selected entry costs the row kernels ~9 x what an entry costs the blocks (19 ns against 2.2 at R-MAT 23: a selected short row is ~16 line requests of its
+        // own, and that kernel runs at the chip's request ceiling); a selection that reaches into the heaviest rows is dearer still (their segments go through the
+        // wave-tile kernel and its combine pass: random 10 % of all rows measured 361 us on the row kernels against 300 on the blocks) — weighted so that it stays there
+        const uint32_t rows_x10 = env_u32("SPLAHIP_MASK_ROWS_X10", 90), long_x10 = env_u32("SPLAHIP_MASK_LONG_X10", 300);
+        const uint32_t groups   = (g->n_rows + stride * 2048u - 1) / (stride * 2048u);
+        g->probe_seq            = g->probe_seq + 1 ? g->probe_seq + 1 : 1;
+#define SPLAHIP_PROBE(T)                                                                                                                                          \
+    hipLaunchKernelGGL((cob_mask_probe_kernel<T>), dim3(std::min(groups, 1024u)), dim3(256), 0, st, g->n_rows, Ap, static_cast<const T*>(mask), op_select, stride, \
+                       rows_x10, plan->nnz, g->d_probe, g->d_h_probe, g->probe_seq, g->d_hub_row, stride > 1 ? g->heavy_slots : 0u, stride > 1 ? g->heavy_deg : 0xFFFFFFFFu, \
+                       long_x10, plan->d_rows_ctl)
+        switch (type) {
+            case SPLAHIP_INT: SPLAHIP_PROBE(int32_t); break;
+            case SPLAHIP_UINT: SPLAHIP_PROBE(uint32_t); break;
+            default: SPLAHIP_PROBE(float); break;
+        }
+#undef SPLAHIP_PROBE
+        (void) hipGetLastError();
+        g->last_rows = rows;
+        return rows;
     }
 
     // second column part of a row block (dist.hip): r[row] = add(r[row], fold of this part's products) for the selected rows that hold an entry here
@@ -685,6 +786,12 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     }
     const uint32_t n_hub_ranges = (H + R - 1) / R;
     g->n_hub_ranges             = n_hub_ranges;
+    g->heavy_slots              = std::min(H, 2 * R);// the mask probe's exact stratum: the rows of the first two hub ranges ...
+    g->heavy_deg                = 0xFFFFFFFFu;
+    if (g->heavy_slots) {// ... = the rows of at least this degree
+        e = hipMemcpy(&g->heavy_deg, deg_s + g->heavy_slots - 1, 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return bail("hub rows");
+    }
     g->n_hub_rows               = H;
     own(&g->d_hub_row, (size_t) n_hub_ranges * R);
     if (e != hipSuccess) return bail("hub list");
@@ -815,6 +922,14 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     const uint32_t        line_pct = env_u32("SPLAHIP_COB_LINE_PCT", 40);// (25 / 40 / 60 on one box, twice: R-MAT 22 151.5 / 145.2 / 147.9 us, R-MAT 23 307.5 / 304.1 / 308.7)
     std::vector<uint64_t> cost_pre((size_t) n_chunks + 1, 0);
     for (uint32_t c = 0; c < n_chunks; ++c) cost_pre[c + 1] = cost_pre[c] + 1600 + (uint64_t) h_lines[c] * line_pct;
+    own(&g->d_probe, 8);
+    if (e == hipSuccess) e = hipMemsetAsync(g->d_probe, 0, sizeof(uint32_t) * 8, s);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(const_cast<uint32_t**>(&g->h_probe)), 4 * sizeof(uint32_t), hipHostMallocMapped);
+    if (e == hipSuccess) {
+        g->h_probe[0] = g->h_probe[1] = g->h_probe[2] = g->h_probe[3] = 0;
+        e = hipHostGetDevicePointer(reinterpret_cast<void**>(&g->d_h_probe), const_cast<uint32_t*>(g->h_probe), 0);
+    }
+    if (e != hipSuccess) return bail("probe words");
     const uint32_t cus = compute_units();
     uint32_t       max_multi = 0;
     for (int w = 0; w < 2 && e == hipSuccess; ++w) {
@@ -1044,6 +1159,19 @@ extern "C" int splahip_csr_plan_cob_layout(splahip_plan plan, uint32_t* n_ranges
     if (n_hub_ranges) *n_hub_ranges = g ? g->n_hub_ranges : 0;
     if (n_hub_rows) *n_hub_rows = g ? g->n_hub_rows : 0;
     if (bytes) *bytes = g ? (uint64_t) g->bytes : 0;
+    return SPLAHIP_OK;
+}
+
+extern "C" int splahip_csr_plan_cob_probe(splahip_plan plan, uint64_t* selected_entries, int* served_by_rows) {
+    SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
+    if (selected_entries) *selected_entries = 0;
+    if (served_by_rows) *served_by_rows = 0;
+    const splahip_cob_s* g = plan->cob;
+    if (!g || !g->h_probe) return SPLAHIP_OK;
+    SPLAHIP_TRY(hipDeviceSynchronize());
+    if (g->h_probe[3] == 0) return SPLAHIP_OK;// no probe has run
+    if (selected_entries) *selected_entries = ((uint64_t) g->h_probe[1] << 32) | g->h_probe[0];
+    if (served_by_rows) *served_by_rows = g->last_rows;
     return SPLAHIP_OK;
 }
 

@@ -16,6 +16,7 @@
 #include "block_utils.hpp"
 #include "common.hpp"
 #include "mxv_kernels.hpp"
+#include "mxv_rows.hpp"
 #include "ops.hpp"
 #include "plan.hpp"
 
@@ -57,6 +58,8 @@ namespace {
         return e && e[0] == '0';
     }
 
+    thread_local const uint32_t* tl_wavetile_gate = nullptr;// masked calls over a plan with blocks: the mask probe's words (the kernels run when word 3 is 1)
+
     template<typename T, class Mult, class Add>
     int launch_wavetile(splahip_plan plan, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const void* mask,
                         const void* v, void* r, int op_mult, int op_add, int op_select, uint32_t init_bits, hipStream_t st) {
@@ -66,13 +69,13 @@ namespace {
                            static_cast<const T*>(mask), static_cast<const T*>(v), static_cast<const uint32_t*>(nullptr),
                            static_cast<T*>(r), static_cast<uint32_t*>(nullptr), reinterpret_cast<T*>(plan->d_partial),
                            static_cast<uint32_t*>(nullptr), Mult(op_mult), Add(op_add), op_select,
-                           from_bits<T>(init_bits), plan->nnz);
+                           from_bits<T>(init_bits), plan->nnz, tl_wavetile_gate);
         SPLAHIP_TRY(hipGetLastError());
         if (plan->n_long > 0) {
             hipLaunchKernelGGL((spmv_combine_kernel<Cfg, T, Add, false>), dim3((plan->n_items + 255) / 256), dim3(256), 0, st,
                                plan->d_item_row, plan->d_item_k0, plan->n_items, Ap, static_cast<const T*>(mask),
                                static_cast<T*>(r), static_cast<uint32_t*>(nullptr), reinterpret_cast<const T*>(plan->d_partial),
-                               static_cast<const uint32_t*>(nullptr), Add(op_add), op_select, from_bits<T>(init_bits));
+                               static_cast<const uint32_t*>(nullptr), Add(op_add), op_select, from_bits<T>(init_bits), tl_wavetile_gate);
             SPLAHIP_TRY(hipGetLastError());
         }
         return SPLAHIP_OK;
@@ -87,6 +90,59 @@ namespace {
                            from_bits<T>(init_bits));
         SPLAHIP_TRY(hipGetLastError());
         return SPLAHIP_OK;
+    }
+
+    // workspaces of the selected-rows path, allocated on a plan's first masked call that may take it
+    int rows_prepare(splahip_plan plan, hipStream_t st) {
+        (void) st;
+        if (plan->rows_ready) return SPLAHIP_OK;
+        SPLAHIP_TRY(device_malloc(reinterpret_cast<void**>(&plan->d_rows_list), sizeof(uint32_t) * (size_t) plan->n_rows));
+        SPLAHIP_TRY(device_malloc(reinterpret_cast<void**>(&plan->d_rows_ctl), sizeof(uint32_t) * 8));// [0] short rows listed, [1] segment items listed, [4..7] the row kernels' gate: open
+        const uint32_t open_gate[4] = {0, 0, 0, 1};
+        SPLAHIP_TRY(hipMemcpy(plan->d_rows_ctl + 4, open_gate, sizeof(open_gate), hipMemcpyHostToDevice));
+        SPLAHIP_TRY(hipMemset(plan->d_rows_ctl, 0, 4 * sizeof(uint32_t)));
+        SPLAHIP_TRY(device_malloc(reinterpret_cast<void**>(&plan->d_long_items), sizeof(uint32_t) * ((size_t) plan->n_items + 1)));
+        plan->rows_ready = true;
+        return SPLAHIP_OK;
+    }
+
+    // the selected-rows path (mxv_rows.hpp), every launch gated on the mask probe's decision
+    template<typename T, class Mult, class Add>
+    int launch_rows(splahip_plan plan, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const void* mask, const void* v, void* r, int op_mult, int op_add,
+                    int op_select, uint32_t init_bits, const uint32_t* gate, hipStream_t st) {
+        const T        init = from_bits<T>(init_bits);
+        const uint32_t n    = plan->n_rows;
+        // (d_rows_ctl[0] short rows listed, [1] segment items listed: returned to zero by the call's mask probe, enqueued just before)
+        hipLaunchKernelGGL((rows_compact_kernel<T>), dim3(2048), dim3(256), 0, st, n, Ap, static_cast<const T*>(mask), op_select, init, static_cast<T*>(r), plan->d_rows_list,
+                           plan->d_rows_ctl, plan->d_item_row, plan->n_items, Cfg::kSegFlag, Cfg::kSeg, plan->d_long_items, gate);
+        hipLaunchKernelGGL((rows_short_kernel<T, Mult, Add>), dim3(2048), dim3(256), 0, st, plan->d_rows_list, plan->d_rows_ctl, Ap, Aj, static_cast<const uint32_t*>(Ax),
+                           static_cast<const T*>(v), static_cast<T*>(r), Mult(op_mult), Add(op_add), init, plan->nnz, gate);
+        SPLAHIP_TRY(hipGetLastError());
+        if (plan->n_items) {// the selected long rows' segment items: the list's length is only known on the device, so the launch covers the plan's items (a wave behind the
+                            // list's end returns at once)
+            const uint32_t long_grid = (plan->n_items + Cfg::kWaves - 1) / Cfg::kWaves;
+            hipLaunchKernelGGL((spmv_wavetile_kernel<Cfg, T, Mult, Add, false>), dim3(long_grid), dim3(Cfg::kTpb), 0, st, plan->d_item_row,
+                               plan->d_item_k0, plan->n_items, Ap, Aj, static_cast<const uint32_t*>(Ax), static_cast<const T*>(mask), static_cast<const T*>(v),
+                               static_cast<const uint32_t*>(nullptr), static_cast<T*>(r), static_cast<uint32_t*>(nullptr), reinterpret_cast<T*>(plan->d_partial),
+                               static_cast<uint32_t*>(nullptr), Mult(op_mult), Add(op_add), op_select, init, plan->nnz, gate, plan->d_long_items, plan->d_rows_ctl + 1);
+            SPLAHIP_TRY(hipGetLastError());
+            if (plan->n_long > 0) {
+                hipLaunchKernelGGL((spmv_combine_kernel<Cfg, T, Add, false>), dim3((plan->n_items + 255) / 256), dim3(256), 0, st, plan->d_item_row, plan->d_item_k0, plan->n_items,
+                                   Ap, static_cast<const T*>(mask), static_cast<T*>(r), static_cast<uint32_t*>(nullptr), reinterpret_cast<const T*>(plan->d_partial),
+                                   static_cast<const uint32_t*>(nullptr), Add(op_add), op_select, init, gate);
+                SPLAHIP_TRY(hipGetLastError());
+            }
+        }
+        return SPLAHIP_OK;
+    }
+    template<typename T>
+    int rows_typed(splahip_plan plan, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
+                   uint32_t init_bits, const uint32_t* gate, hipStream_t st) {
+        if (op_mult == SPLAHIP_MULT && op_add == SPLAHIP_PLUS)
+            return launch_rows<T, StaBin<SPLAHIP_MULT>, StaBin<SPLAHIP_PLUS>>(plan, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, gate, st);
+        if (op_mult == SPLAHIP_PLUS && op_add == SPLAHIP_MIN)
+            return launch_rows<T, StaBin<SPLAHIP_PLUS>, StaBin<SPLAHIP_MIN>>(plan, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, gate, st);
+        return launch_rows<T, DynBin, DynBin>(plan, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, gate, st);
     }
 
 #define SPLAHIP_WT(MUL, ADD) launch_wavetile<T, StaBin<MUL>, StaBin<ADD>>(plan, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, st)
@@ -123,6 +179,9 @@ namespace {
 
     void plan_release(splahip_plan plan) {
         if (!plan) return;
+        if (plan->d_rows_list) (void) hipFree(plan->d_rows_list);
+        if (plan->d_rows_ctl) (void) hipFree(plan->d_rows_ctl);
+        if (plan->d_long_items) (void) hipFree(plan->d_long_items);
         if (plan->d_item_row) (void) hipFree(plan->d_item_row);
         if (plan->d_item_k0) (void) hipFree(plan->d_item_k0);
         if (plan->d_partial) (void) hipFree(plan->d_partial);
@@ -256,7 +315,24 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
         const char* pref     = std::getenv("SPLAHIP_PREFER");
         const bool  sell_ok  = plan->sell && plan->sell->n_cols == n_cols && !sell_disabled() && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add));
         const bool  use_sell = sell_ok && (pref ? pref[0] == 's' : sell_skip_family(type, op_mult, op_add) == 1);
-        if (!use_sell) return cob_mxv(plan, type, d_Ap, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, stream);
+        if (!use_sell) {
+            // A mask that selects few ENTRIES (the reference skips unselected rows, src/cpu/cpu_mxv.hpp:89-92; its own perf test selects every 10th row,
+            // tests/test_mxv.cpp:91-130): the blocks stream every entry of a range that holds a selected row, the CSR wave-tile kernels only the selected rows'.
+            // Every masked call enqueues a small probe of its mask whose verdict lands in pinned host memory; the host enqueues whichever side the LATEST FINISHED
+            // probe favours (no round trip; both sides are correct for any mask, so a stale verdict only costs time).  op_select = ALWAYS needs none of it.
+            const Variant wv = pick_variant(type, op_mult, op_add, 0);
+            const bool    wt = (wv == Variant::WaveTileStatic || wv == Variant::WaveTileDynamic) && plan->n_items != 0 &&
+                            ((reinterpret_cast<uintptr_t>(d_Aj) | reinterpret_cast<uintptr_t>(d_Ax) | reinterpret_cast<uintptr_t>(d_Ap)) & 15u) == 0;
+            if (wt && op_select != SPLAHIP_ALWAYS && rows_prepare(plan, s) != SPLAHIP_OK) return SPLAHIP_ERROR;// (the probe zeroes the row kernels' list lengths)
+            if (wt && cob_mask_probe(plan, type, d_Ap, d_mask, op_select, stream) != 0) {
+                switch (type) {
+                    case SPLAHIP_INT: return rows_typed<int32_t>(plan, d_Ap, d_Aj, d_Ax, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, plan->d_rows_ctl + 4, s);
+                    case SPLAHIP_UINT: return rows_typed<uint32_t>(plan, d_Ap, d_Aj, d_Ax, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, plan->d_rows_ctl + 4, s);
+                    default: return rows_typed<float>(plan, d_Ap, d_Aj, d_Ax, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, plan->d_rows_ctl + 4, s);
+                }
+            }
+            return cob_mxv(plan, type, d_Ap, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, stream);
+        }
     }
     // the sliced-ELL copy (splahip_csr_plan_attach_sell) serves every associative op_add without early exit; its lanes fold in
     // entry order, so op_add need not be commutative.  SPLAHIP_SELL=0 keeps the CSR kernels (A/B runs, tests).

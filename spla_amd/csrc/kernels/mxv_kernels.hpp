@@ -233,7 +233,11 @@ namespace splahip {
                                                                     uint* __restrict__ touched,
                                                                     T* __restrict__ partial,
                                                                     uint* __restrict__ partial_ok,
-                                                                    Mult mult, Add add_raw, int op_select, T init, uint nnz) {
+                                                                    Mult mult, Add add_raw, int op_select, T init, uint nnz, const uint* __restrict__ gate = nullptr,
+                                                                    const uint* __restrict__ item_list = nullptr, const uint* __restrict__ list_count = nullptr) {
+        // gate (mxv.hip: a masked call over a plan that also holds the column-ordered blocks): word 3 of the mask probe's result says which kernels run — 1: these.
+        // item_list (mxv_rows.hpp): the launch walks only the listed items (the plan's segment items: the rows too long for the row kernel)
+        if (gate != nullptr && gate[3] == 0u) return;
         const Reassoc<Add> add(add_raw);// partials start at products: fp32 MIN / MAX must drop NaN products like the left fold from `init` does
         __shared__ uint    s_ap_all[C::kWaves][C::kRowsCap + 1];
         __shared__ Quad<T> s_prod_all[C::kWaves][C::kStage / 4 + 1];
@@ -241,7 +245,11 @@ namespace splahip {
 
         const uint lane = lane_id();
         const uint w    = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-        const uint item = blockIdx.x * C::kWaves + w;
+        uint       item = blockIdx.x * C::kWaves + w;
+        if (item_list != nullptr) {
+            if (item >= *list_count) return;
+            item = item_list[item];
+        }
         if (item >= n_items) return;
 #ifdef SPLAHIP_PHASE_TIMING
         unsigned long long t_begin = 0, t_header = 0, t_stream = 0, t_gather = 0, t_end = 0;
@@ -504,7 +512,8 @@ namespace splahip {
                                                                uint n_items, const uint* __restrict__ Ap,
                                                                const T* __restrict__ mask, T* __restrict__ r, uint* __restrict__ touched,
                                                                const T* __restrict__ partial, const uint* __restrict__ partial_ok,
-                                                               Add add_raw, int op_select, T init) {
+                                                               Add add_raw, int op_select, T init, const uint* __restrict__ gate = nullptr) {
+        if (gate != nullptr && gate[3] == 0u) return;
         const Reassoc<Add> add(add_raw);
         const uint i = blockIdx.x * 256 + threadIdx.x;
         if (i >= n_items) return;

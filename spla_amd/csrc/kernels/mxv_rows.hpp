@@ -1,0 +1,220 @@
+// mxv_rows.hpp — masked SpMV over the SELECTED rows only (round 4): what a mask that selects few entries runs instead of streaming the whole matrix.
+//
+// Semantics: reference Algo_mxv_masked_cpu<T>::execute, src/cpu/cpu_mxv.hpp:88-103 — an unselected row costs the reference nothing (:89-92) and its own perf
+// test selects every 10th row (tests/test_mxv.cpp:91-130).  The column-ordered blocks (mxv_cob.hpp) stream every entry of a range whatever the mask, and the
+// wave-tile CSR kernel still visits every work item (~170 us at R-MAT 23 before the first selected entry).  Here:
+//   rows_compact_kernel  one streaming pass over mask and Ap: r = init everywhere, and the selected rows of 1 .. kRowsShortMax entries are appended to a list, a
+//                        few thousand at a time (an LDS buffer per workgroup, one global atomic per flush)
+//   rows_short_kernel    8 lanes per listed row: coalesced Aj / Ax, gathers of v, lane partials joined in lane order, r[row] = add(init, fold)
+//   longer rows          the segment items (rows > 508 entries) of the SELECTED long rows, listed by rows_compact_kernel, through the wave-tile kernel (mxv_kernels.hpp);
+//                        rows made of several segments are finished by its combine kernel
+// op_add must be associative and commutative (the lanes of a row take its entries strided) — the same calls the wave-tile kernel serves.  Every kernel takes the
+// mask probe's words as its gate and returns at once unless word 3 says the row kernels serve the call (cob.hip: cob_mask_probe_kernel).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "block_utils.hpp"
+#include "ops.hpp"
+
+namespace splahip {
+
+    constexpr uint32_t kRowsShortMax = 508;// = MxvCfg's longest row of a run item: longer rows are segment items of the wave-tile plan
+    constexpr uint32_t kRowsGroup    = 8;  // lanes per row (an R-MAT's selected short rows hold ~15 entries: two steps)
+
+    // One streaming pass over mask and Ap, 8 rows per thread and step (16-byte loads): r = init for every row (the row kernels overwrite the selected ones
+    // behind this launch), and list[0 .. *count) = the selected rows with 1 .. kRowsShortMax entries, in no particular order (clusters of neighbouring rows:
+    // an LDS buffer per workgroup, one global atomic per flush).
+    template<typename T>
+    __global__ __launch_bounds__(256) void rows_compact_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, T init,
+                                                               T* __restrict__ r, uint32_t* __restrict__ list, uint32_t* __restrict__ count, const uint32_t* __restrict__ item_row,
+                                                               uint32_t n_items, uint32_t seg_flag, uint32_t seg_len, uint32_t* __restrict__ long_items,
+                                                               const uint32_t* __restrict__ gate) {
+        if (gate[3] == 0u) return;
+        constexpr uint32_t kBuf = 4096;
+        __shared__ uint32_t s_buf[kBuf + 2048];
+        __shared__ uint32_t s_n, s_base;
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        const uint32_t per = ((n_rows + gridDim.x - 1) / gridDim.x + 2047u) & ~2047u;// a contiguous share of the rows per workgroup, whole steps of 2048 rows
+        const uint32_t b0 = blockIdx.x * per, b1 = min(n_rows, b0 + per);
+        const uint4    iv = make_uint4(to_bits(init), to_bits(init), to_bits(init), to_bits(init));
+        for (uint32_t base = b0; base < b1; base += 2048) {
+            const uint32_t row0 = base + threadIdx.x * 8;
+            uint32_t       ap[9];
+            uint32_t       mk[8];
+            if (row0 + 8 <= b1 && row0 + 8 < n_rows) {// (Ap and mask are 16-byte aligned arrays; the last rows of the matrix go one by one)
+                const uint4 a0 = *reinterpret_cast<const uint4*>(Ap + row0), a1 = *reinterpret_cast<const uint4*>(Ap + row0 + 4);
+                const uint4 m0 = *reinterpret_cast<const uint4*>(mask + row0), m1 = *reinterpret_cast<const uint4*>(mask + row0 + 4);
+                ap[0] = a0.x, ap[1] = a0.y, ap[2] = a0.z, ap[3] = a0.w, ap[4] = a1.x, ap[5] = a1.y, ap[6] = a1.z, ap[7] = a1.w, ap[8] = Ap[row0 + 8];
+                mk[0] = m0.x, mk[1] = m0.y, mk[2] = m0.z, mk[3] = m0.w, mk[4] = m1.x, mk[5] = m1.y, mk[6] = m1.z, mk[7] = m1.w;
+                *reinterpret_cast<uint4*>(r + row0)     = iv;
+                *reinterpret_cast<uint4*>(r + row0 + 4) = iv;
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j) {
+                    const bool in = row0 + j < b1;
+                    ap[j]         = in ? Ap[row0 + j] : 0u;
+                    mk[j]         = in ? to_bits(mask[row0 + j]) : 0u;
+                    if (in) r[row0 + j] = init;
+                }
+                ap[8] = row0 + 8 <= b1 ? Ap[row0 + 8] : (row0 < b1 ? Ap[b1] : 0u);
+                for (uint32_t j = 0; j < 8; ++j)
+                    if (row0 + j >= b1) ap[j] = ap[8];// (rows behind the share: length 0)
+            }
+            uint32_t take = 0, cnt = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                const uint32_t d = ap[j + 1] - ap[j];
+                if (row0 + j < b1 && d != 0 && eval_sel<T>(op_select, from_bits<T>(mk[j]))) {
+                    if (d <= kRowsShortMax) take |= 1u << j, ++cnt;
+                    else {
+                        // a selected LONG row (rare: the plan cuts it into segment items of seg_len entries): its items go to the wave-tile kernel's list.  The row's first
+                        // item is the first one whose item_row is (row | seg_flag): item_row ascends in the row bits
+                        const uint32_t row = row0 + j, nseg = (d + seg_len - 1) / seg_len;
+                        uint32_t       lo = 0, hi = n_items;
+                        while (lo < hi) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if ((item_row[mid] & ~seg_flag) < row) lo = mid + 1;
+                            else
+                                hi = mid;
+                        }
+                        const uint32_t at = atomicAdd(count + 1, nseg);
+                        for (uint32_t g = 0; g < nseg; ++g) long_items[at + g] = lo + g;
+                    }
+                }
+            }
+            // positions: the wave's counts scanned, one LDS atomic per wave
+            uint32_t inc = cnt;
+#pragma unroll
+            for (uint32_t off = 1; off < kWave; off <<= 1) {
+                const uint32_t y = __shfl_up(inc, off, kWave);
+                if (lane_id() >= off) inc += y;
+            }
+            uint32_t wbase = 0;
+            if (lane_id() == kWave - 1 && inc) wbase = atomicAdd(&s_n, inc);
+            wbase        = __shfl(wbase, kWave - 1, kWave);
+            uint32_t pos = wbase + inc - cnt;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j)
+                if (take & (1u << j)) s_buf[pos++] = row0 + j;
+            __syncthreads();
+            if (s_n >= kBuf || base + 2048 >= b1) {// flush (uniform: s_n is read behind the barrier)
+                const uint32_t n = s_n;
+                if (threadIdx.x == 0 && n) s_base = atomicAdd(count, n);
+                __syncthreads();
+                for (uint32_t i = threadIdx.x; i < n; i += 256) list[s_base + i] = s_buf[i];
+                __syncthreads();
+                if (threadIdx.x == 0) s_n = 0;
+                __syncthreads();
+            }
+        }
+    }
+
+    // The listed rows, a wave at a time: 64 listed rows' bounds arrive in one round trip (lane l = row l); the wave then takes as many of them as fit its LDS stage
+    // (kRowsStage entries, rows padded to 16-byte quads), requests ALL their Aj / Ax quads at once (a lane's quads belong to whichever rows the scan of the quad
+    // counts says), gathers v for all of them, stages the products, and lane l folds row l's products out of LDS — strictly left to right from init, the
+    // reference's own order (cpu_mxv.hpp:94-99): bit-exact for every op_add, fp32 sums included.  Three round trips per ~1000 entries instead of two per row.
+    constexpr uint32_t kRowsStage = 1024;// entries of a wave's product stage (256 quads: 4 per lane)
+    template<typename T, class Mult, class Add>
+    __global__ __launch_bounds__(256) void rows_short_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, const uint32_t* __restrict__ Ap,
+                                                             const uint32_t* __restrict__ Aj, const uint32_t* __restrict__ Ax, const T* __restrict__ v, T* __restrict__ r, Mult mult,
+                                                             Add add, T init, uint32_t nnz, const uint32_t* __restrict__ gate) {
+        if (gate[3] == 0u) return;
+        __shared__ T        s_prod_all[256 / kWave][kRowsStage];
+        __shared__ uint32_t s_q_all[256 / kWave][kWave + 1];// exclusive scan of the rows' quad counts
+        __shared__ uint32_t s_a_all[256 / kWave][kWave];    // first (16-byte aligned) entry of the rows' quads
+        const uint32_t n    = *count;
+        const uint32_t lane = lane_id(), wv = threadIdx.x / kWave;
+        T* const        s_prod = s_prod_all[wv];
+        uint32_t* const s_q    = s_q_all[wv];
+        uint32_t* const s_a    = s_a_all[wv];
+        const uint32_t  wave = blockIdx.x * (256 / kWave) + wv, n_waves = gridDim.x * (256 / kWave);
+        for (uint32_t i0 = wave * kWave; i0 < n; i0 += n_waves * kWave) {
+            uint32_t my_row = 0, k0 = 0, k1 = 0;
+            if (i0 + lane < n) {
+                my_row = list[i0 + lane];
+                k0     = Ap[my_row];
+                k1     = Ap[my_row + 1];
+            }
+            const uint32_t a0 = k0 & ~3u;                            // 16-byte aligned origin of the row's quads
+            const uint32_t nq = k1 > k0 ? (k1 - a0 + 3) >> 2 : 0;   // quads of the row (<= 128)
+            uint32_t       done = 0;                                 // rows of this batch already folded
+            const uint32_t here = min(kWave, n - i0);
+            while (done < here) {
+                // rows [done, upto) fit the stage: scan the quad counts of the rows not yet done
+                uint32_t inc = lane >= done && lane < here ? nq : 0;
+#pragma unroll
+                for (uint32_t off = 1; off < kWave; off <<= 1) {
+                    const uint32_t y = __shfl_up(inc, off, kWave);
+                    if (lane >= off) inc += y;
+                }
+                const unsigned long long fits = __ballot(lane >= done && lane < here && inc <= kRowsStage / 4);
+                const uint32_t upto = done + (uint32_t) __popcll(fits);// (a single row always fits: nq <= 128; the fitting rows are a prefix of the rest)
+                const uint32_t ex   = inc - (lane >= done && lane < here ? nq : 0);
+                s_q[lane]           = ex;
+                s_a[lane]           = a0;
+                const uint32_t total = __shfl(inc, (int) (upto - 1), kWave);// quads of the rows [done, upto)
+                if (lane == 0) s_q[kWave] = total;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // the quads, 4 per lane: which row does virtual quad vq belong to (largest row in [done, upto) with s_q[row] <= vq)
+                uint4    jq[4], xq[4];
+                uint32_t qrow[4], qk[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) {
+                    const uint32_t vq = lane + u * kWave;
+                    qrow[u]           = 0xFFFFFFFFu;
+                    if (vq < total) {
+                        uint32_t lo = done, hi = upto;// s_q[lo] <= vq < s_q[hi]
+                        while (hi - lo > 1) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (s_q[mid] <= vq) lo = mid;
+                            else
+                                hi = mid;
+                        }
+                        qrow[u] = lo;
+                        qk[u]   = s_a[lo] + 4 * (vq - s_q[lo]);// (through LDS, not a shuffle: the lanes diverge here)
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u)
+                    if (qrow[u] != 0xFFFFFFFFu) {
+                        if (qk[u] + 4 <= nnz) {
+                            jq[u] = *reinterpret_cast<const uint4*>(Aj + qk[u]);
+                            xq[u] = *reinterpret_cast<const uint4*>(Ax + qk[u]);
+                        } else {// the last quad of the arrays may be cut short: its words one by one (what lies behind them is never folded)
+                            jq[u] = make_uint4(Aj[qk[u]], qk[u] + 1 < nnz ? Aj[qk[u] + 1] : 0u, qk[u] + 2 < nnz ? Aj[qk[u] + 2] : 0u, 0u);
+                            xq[u] = make_uint4(Ax[qk[u]], qk[u] + 1 < nnz ? Ax[qk[u] + 1] : 0u, qk[u] + 2 < nnz ? Ax[qk[u] + 2] : 0u, 0u);
+                        }
+                    }
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u)
+                    if (qrow[u] != 0xFFFFFFFFu) {
+                        const uint32_t jj[4] = {jq[u].x, jq[u].y, jq[u].z, jq[u].w};
+                        const uint32_t xx[4] = {xq[u].x, xq[u].y, xq[u].z, xq[u].w};
+                        T              vv[4];
+#pragma unroll
+                        for (uint32_t e = 0; e < 4; ++e) vv[e] = v[jj[e]];
+                        const uint32_t vq = lane + u * kWave;
+#pragma unroll
+                        for (uint32_t e = 0; e < 4; ++e) s_prod[4 * vq + e] = mult(from_bits<T>(xx[e]), vv[e]);
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane >= done && lane < upto) {
+                    T              sum = init;
+                    const uint32_t s0  = 4 * ex + (k0 - a0), s1 = s0 + (k1 - k0);
+                    for (uint32_t k = s0; k < s1; ++k) sum = add(sum, s_prod[k]);
+                    r[my_row] = sum;
+                }
+                done = upto;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+
+}// namespace splahip

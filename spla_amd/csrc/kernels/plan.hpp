@@ -87,6 +87,15 @@ struct splahip_cob_s {
     mutable uint32_t acc_identity = 0;
     mutable bool     acc_armed    = false;
     uint32_t* d_vbits  = nullptr;// per call: bit c = v[c] != 0 (sparse-input-vector form, mxv_cob.hpp MODE 1 / 2)
+    // masked calls (round 4): the mask probe — d_probe: [0..1] entries of the selected rows (64 bit; a sample of the rows, scaled), [2] workgroups done, [4..5] what the
+    // selection costs the row kernels (zero between probes); h_probe (pinned host memory the probe's last workgroup writes): [0..1] the estimate, [2] the verdict (1: the selected-rows kernels of mxv_rows.hpp
+    // would serve such a mask faster than the blocks), [3] the probe's sequence number (0: none has finished yet)
+    uint32_t*          d_probe   = nullptr;
+    volatile uint32_t* h_probe   = nullptr;
+    uint32_t*          d_h_probe = nullptr;// h_probe as the device sees it
+    mutable uint32_t   probe_seq = 0;
+    mutable int        last_rows = 0;// which side served the last masked call (1: the selected-rows kernels)
+    uint32_t           heavy_slots = 0, heavy_deg = 0xFFFFFFFFu;// the probe's exact stratum: the first heavy_slots hub slots hold the rows of degree >= heavy_deg
     bool      x_uniform = false; // every stored value of the matrix is the same word (found at attach time) ...
     uint32_t  x_bits    = 0;     // ... this one: the sparse-vector form then does not read the value stream
     // value statistics of the copy's value words, per type (found by the first call of a type that needs them): any negative / NaN value,
@@ -107,6 +116,12 @@ struct splahip_plan_s {
     // call workspace, grown on demand and kept with the plan so steady-state calls do not allocate (vxm pull form)
     void*     d_ws         = nullptr;
     size_t    ws_bytes     = 0;
+    // masked calls that select few entries (mxv_rows.hpp): the list of selected short rows of the running call, and the plan's segment items
+    uint32_t* d_rows_list  = nullptr;// n_rows words, built on the first such call
+    uint32_t* d_rows_ctl   = nullptr;// [0] rows listed by the running call, [1] segment items of the plan
+    uint32_t* d_long_items = nullptr;// the plan's segment items (rows longer than a run item's)
+    uint32_t  n_long_items = 0;
+    bool      rows_ready   = false;
     splahip_sell_s* sell   = nullptr;// splahip_csr_plan_attach_sell
     splahip_cob_s*  cob    = nullptr;// splahip_csr_plan_attach_cob
 };
@@ -121,6 +136,10 @@ namespace splahip {
     // masked SpMV over the column-ordered-blocks copy (associative + commutative op_add with an LDS atomic, no early exit); SPLAHIP status
     int cob_mxv(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
                 uint32_t init_bits, void* stream);
+    // masked calls (op_select other than ALWAYS): enqueue a probe of the mask (how many entries does the selection cover) whose verdict lands in pinned host memory,
+    // and return the verdict of the latest probe that has FINISHED — 1: the selected-rows kernels (mxv_rows.hpp) serve such a mask faster than the blocks, which
+    // stream the whole matrix whatever the mask.  Both compute the reference's result for any mask: the verdict is a hint that lags by a call.
+    int cob_mask_probe(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, int op_select, void* stream);
     // the same over a second column part of the same rows: r[row] = add(r[row], this part's fold) where the row is selected and holds an entry here
     int cob_mxv_accumulate(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add,
                            int op_select, void* stream);

@@ -74,6 +74,12 @@ class CsrPlan:
                     "hub_ranges": nh.value, "hub_rows": hr.value, "bytes": by.value} if a.value else None
         return self.cob
 
+    def mask_probe(self):
+        """what the last masked call over the blocks found when it probed its mask on the device (blocking): {"selected_entries", "served_by_rows"}"""
+        se, by = C.c_uint64(), C.c_int()
+        _lib.call("splahip_csr_plan_cob_probe", self._h, C.byref(se), C.byref(by))
+        return {"selected_entries": se.value, "served_by_rows": bool(by.value)}
+
     def footprint(self):
         """device bytes held for the matrix besides its CSR arrays: {"plan", "sliced_ell", "column_ordered_blocks"}"""
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -585,3 +585,59 @@ def test_cob_schedule_and_geometry_knobs(oracle, knobs):
     finally:
         for k in env:
             os.environ.pop(k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", ["INT", "FLOAT"])
+def test_masked_call_takes_the_side_its_mask_favours(oracle, t):
+    """Every masked call over a plan that holds the column-ordered blocks enqueues a probe of its mask (cob_mask_probe_kernel: how many ENTRIES does the selection
+    cover) whose verdict lands in pinned host memory; the host enqueues the side the latest finished probe favours: the selected-rows kernels (mxv_rows.hpp — they
+    read selected rows only, as the reference skips unselected rows: src/cpu/cpu_mxv.hpp:89-92) or the blocks, which stream the whole matrix.  Both sides give the
+    oracle's result for any mask (long rows included: the hub rows of this matrix hold thousands of entries); the second call with a mask runs the favoured side."""
+    import torch
+    from gpu_utils import dev, host
+    from spla_amd import kernels
+    rng = np.random.default_rng(2024)
+    n_rows, n_cols = 9000, 7000
+    Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 12, t, skew=True, long_rows=4, long_len=3500)
+    if t == "FLOAT":
+        Ax = (rng.integers(1, 64, len(Aj)) / 8.0).astype(np.float32)  # (sums of these are exact in any order)
+        v = (rng.integers(0, 32, n_cols) / 4.0).astype(np.float32)
+    else:
+        v = random_values(rng, n_cols, t, zeros=0.2)
+    deg = np.diff(Ap.astype(np.int64))
+    dAp, dAj, dAx, dv = dev(Ap), dev(Aj), dev(np.asarray(Ax, NP[t])), dev(np.asarray(v, NP[t]))
+    import os
+    os.environ["SPLAHIP_COB_HUB_MIN_DEGREE"] = "20"
+    plan = kernels.CsrPlan(n_rows, len(Aj), dAp)
+    info = plan.attach_cob(n_cols, dAp, dAj, dAx, row_bits=8, tile_chunks=3)
+    os.environ.pop("SPLAHIP_COB_HUB_MIN_DEGREE")
+    assert info and info["hub_ranges"] >= 2
+    hubs = deg >= 20
+    masks = {
+        "5 % of the rows": (rng.random(n_rows) < 0.05),
+        "60 % of the rows": (rng.random(n_rows) < 0.6),
+        "no hub row": ~hubs & (rng.random(n_rows) < 0.9),
+        "only hub rows": hubs,
+        "nothing": np.zeros(n_rows, bool),
+    }
+    seen = set()
+    for name, selrows in masks.items():
+        mask = np.where(selrows, 3, 0).astype(NP[t])
+        for mul, add, init in (("MULT", "PLUS", 0), ("PLUS", "MIN", 1000)):
+            want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, "NQZERO", init)
+            for attempt in (0, 1):  # the first call with a new mask runs the side the PREVIOUS mask's probe favoured, the second the side this mask's does
+                r = torch.full((n_rows,), 77, dtype=kernels.torch_dtype(t), device="cuda")
+                kernels.mxv_masked(plan, t, n_cols, dAp, dAj, dAx, dev(mask), dv, r, mul, add, "NQZERO", init)
+                torch.cuda.synchronize()
+                probe = plan.mask_probe()
+                got = host(r, NP[t])
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (t, name, mul, add, attempt, probe)
+            assert probe["selected_entries"] == int(deg[selrows].sum()), (name, probe)  # (a matrix this small is probed row by row; large ones sample 2048-row groups)
+            seen.add(probe["served_by_rows"])
+            if name in ("5 % of the rows", "nothing"):
+                assert probe["served_by_rows"], (name, probe)
+            if name in ("60 % of the rows", "only hub rows"):
+                assert not probe["served_by_rows"], (name, probe)
+    assert seen == {True, False}
+    plan.close()

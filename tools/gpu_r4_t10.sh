@@ -1,0 +1,8 @@
+#!/bin/bash
+out=gpurun_out/r04_t10.txt
+: > $out
+timeout 900 python -m pytest tests/test_mxv_gpu.py -x -q 2>&1 | grep -E "passed|failed|error|Error|assert" | tail -8 >> $out
+timeout 600 python tools/exp/exp_r4_mask.py 23 2>&1 | grep -v amdgpu.ids >> $out
+timeout 600 python tools/exp/exp_r4_mask.py 23 SPLAHIP_MASK_PROBE=0 2>&1 | grep -v amdgpu.ids >> $out
+timeout 600 python tools/exp/exp_r4_mask.py 22 2>&1 | grep -v amdgpu.ids >> $out
+cat $out
