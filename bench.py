@@ -227,9 +227,9 @@ def main():
             keep = ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline", "verified", "cpu_baseline")
             v0 = {"name": "BFS step (BASELINE configs[1]; the contract line of rounds 1-2)", **{k: bl[k] for k in keep if k in bl}}
             v0["variants"] = [x for x in bl.get("variants", []) if x["name"].startswith("bfs-step")]
-            line["variants"] = [v0] + line.pop("variants_same_matrix", [])
+            line["variants"] = [v0] + line.pop("variants", []) + line.pop("variants_masked", []) + line.pop("variants_same_matrix", [])
         elif "variants_same_matrix" in line:
-            line["variants"] = line.pop("variants_same_matrix")
+            line["variants"] = line.pop("variants", []) + line.pop("variants_masked", []) + line.pop("variants_same_matrix")
         if rank == 0:
             print(json.dumps(line), flush=True)
         if world > 1:

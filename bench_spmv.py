@@ -215,7 +215,8 @@ def run(args, rank, world):
         roof["traffic_over_algorithmic"] = round(per_call["traffic_bytes"] / alg, 3)
         roof["l1_to_l2_read_requests"] = per_call.get("tcp_tcc_read_req")
         roof["traffic_source"] = f"profiles/{fname}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per call, separate rocprofv3 --pmc passes of this command"
-    out = {"metric": "masked SpMV GTEPS", "value": round(nnz / (wall / args.steps) / 1e9, 3), "unit": "GTEPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+    out = {"metric": "masked SpMV GTEPS", "workload": "spmv-fp32 (north-star configuration; rounds 1-2 quoted the BFS step of configs[1] under this metric: it rides along as variants[0])",
+           "value": round(nnz / (wall / args.steps) / 1e9, 3), "unit": "GTEPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"exec_mxv_masked fp32 MULT/PLUS over all rows (op_select ALWAYS, init 0), values and v uniform in [0, 1): R-MAT scale {scale} (ef {args.edge_factor}, {label} labels) "
                                   f"— the north-star ~100 M-nnz scale-free CSR", "n": n, "nnz": nnz, "nnz_selected": nnz, "rows_selected": n,
@@ -252,8 +253,112 @@ def run(args, rank, world):
         out["cpu_baseline"] = cpu_reference_sample("FLOAT", Ap, Aj, Ax, mask, v, r, "MULT", "PLUS", "ALWAYS", 0.0, args.cpu_sample_nnz, 1e-5)
     if not args.no_variants:
         out["variants_same_matrix"] = same_matrix_variants(args, n, nnz, Ap, Aj, Ax, v, mask, r)
+        out["variants_masked"] = masked_variants(args, plan, n, nnz, Ap, Aj, Ax, v, k_ms)
     plan.close()
+    del plan, Ap, Aj, Ax, v, mask, r
+    torch.cuda.empty_cache()
+    if not args.no_variants and not getattr(args, "scale_given", False):
+        t_budget = time.time()
+        out["variants"] = []
+        out["variants"].append(permuted_headline(args))
+        out["variants"] += config_variants(args, t_budget)
     return out
+
+
+def masked_variants(args, plan, n, nnz, Ap, Aj, Ax, v, all_rows_ms):
+    """The same call under NQZERO masks (the reference skips unselected rows, src/cpu/cpu_mxv.hpp:89-92; its own perf test selects every 10th row,
+    tests/test_mxv.cpp:91-130): 10 % / 50 % of the rows at random, and the same with every hub row unselected.  GTEPS and roofline fraction are against the SELECTED
+    entries (8 nnz_sel + ...); each result is checked against the oracle on a sample of rows."""
+    from oracle import pyoracle
+    from spla_amd import kernels
+    res = []
+    steps = max(10, args.steps // 2)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(args.seed + 900)
+    deg = (Ap[1:] - Ap[:-1]).to(torch.int64)
+    thr = max(16, 2 * nnz // n)
+    u = torch.rand(n, generator=gen, device="cuda")
+    r = torch.empty(n, dtype=torch.float32, device="cuda")
+    orc = pyoracle.Oracle()
+    for name, sel in (("10 % of the rows, random", u < 0.1), ("50 % of the rows, random", u < 0.5),
+                      (f"10 % of the rows, no hub row (degree < {thr})", (u < 0.1) & (deg < thr)), (f"50 % of the rows, no hub row (degree < {thr})", (u < 0.5) & (deg < thr))):
+        m = sel.to(torch.float32)
+        nsel = int(deg[sel].sum())
+        _, per = time_calls(lambda: kernels.mxv_masked(plan, "FLOAT", n, Ap, Aj, Ax, m, v, r, "MULT", "PLUS", "NQZERO", 0.0), steps, 3)
+        ms = float(np.mean(per))
+        alg = alg_bytes(nsel, n, n)
+        probe = plan.mask_probe()
+        # parity on every 64th row: within 1e-5 of the oracle plus the oracle's own distance from the fp64 fold (the selected-rows kernels fold like the oracle: exact)
+        rows, Ap_s, Aj_s, Ax_s = sample_rows(Ap, Aj, Ax, 64)
+        mm, vh = int(rows.numel()), v.cpu().numpy()
+        want = orc.mxv_masked("FLOAT", mm, n, Ap_s, Aj_s, Ax_s, m[rows].cpu().numpy(), vh, "MULT", "PLUS", "NQZERO", 0.0).astype(np.float64)
+        ex = np.bincount(np.repeat(np.arange(mm), np.diff(Ap_s.astype(np.int64))), weights=Ax_s.astype(np.float64) * vh[Aj_s.astype(np.int64)].astype(np.float64), minlength=mm)
+        ex = np.where(m[rows].cpu().numpy() != 0, ex, 0.0)
+        got = r[rows].cpu().numpy().astype(np.float64)
+        ok = bool(np.all(np.abs(got - want) <= 1e-5 * np.abs(want) + 1.01 * np.abs(want - ex) + 1e-30))
+        if not ok:
+            raise SystemExit(f"bench: masked variant '{name}' differs from the oracle")
+        res.append({"name": "fp32 MULT/PLUS, NQZERO mask: " + name, "rows_selected": int(sel.sum()), "nnz_selected": nsel, "kernel_avg_us": round(ms * 1e3, 2),
+                    "ratio_to_all_rows": round(ms / all_rows_ms, 3), "gteps_selected": round(nsel / (ms * 1e-3) / 1e9, 2), "algorithmic_bytes_selected": alg,
+                    "roofline_frac_selected": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "served_by": "selected-rows kernels (mxv_rows.hpp)" if probe["served_by_rows"] else "column-ordered blocks (streams the whole copy)",
+                    "probe_selected_entries": probe["selected_entries"], "verified_rows": mm})
+    return res
+
+
+def permuted_headline(args):
+    """The headline call on the same graph with RANDOM vertex labels (a real graph's labels carry no locality; the generator's put the hubs at the low ids)."""
+    from spla_amd import graphgen, kernels
+    scale = 23
+    n, Ap, Aj = graphgen.rmat_csr(scale, args.edge_factor, seed=args.seed, device="cuda", permute=True)
+    nnz = int(Ap[-1])
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(args.seed + 300)
+    Ax = torch.rand(nnz, generator=gen, device="cuda", dtype=torch.float32)
+    v = torch.rand(n, generator=gen, device="cuda", dtype=torch.float32)
+    mask = torch.zeros(n, dtype=torch.float32, device="cuda")
+    r = torch.empty(n, dtype=torch.float32, device="cuda")
+    plan = kernels.CsrPlan(n, nnz, Ap)
+    info = plan.attach_cob(n, Ap, Aj, Ax)
+    _, per = time_calls(lambda: kernels.mxv_masked(plan, "FLOAT", n, Ap, Aj, Ax, mask, v, r, "MULT", "PLUS", "ALWAYS", 0.0), max(10, args.steps // 2), 3)
+    ms = float(np.mean(per))
+    alg = alg_bytes(nnz, n, n)
+    exact = torch.zeros(n, dtype=torch.float64, device="cuda")
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), (Ap[1:] - Ap[:-1]).to(torch.int64))
+    exact.index_add_(0, rows, Ax.to(torch.float64) * v[Aj.to(torch.int64)].to(torch.float64))
+    err = float(((r.to(torch.float64) - exact).abs() / exact.abs().clamp_min(1e-30)).max())
+    plan.close()
+    return {"name": f"headline call, RANDOM vertex labels (R-MAT scale {scale}, --permute 1)", "n": n, "nnz": nnz, "kernel_avg_us": round(ms * 1e3, 2), "gteps": round(nnz / (ms * 1e-3) / 1e9, 2),
+            "roofline": {"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "algorithmic_bytes": alg}, "max_rel_vs_fp64": err, "layout": info}
+
+
+def config_variants(args, t_start):
+    """The other BASELINE configs at N = 1, each with its own roofline / cpu_baseline objects (bench_workloads.py): configs[2] the PageRank-step vxm on the com-Orkut
+    stand-in, configs[3] the min-plus SSSP step on R-MAT 24, configs[4] mxmT(L, L, L) on R-MAT 20 and mxm on R-MAT 18; plus the BFS step of configs[1]
+    (the contract line of rounds 1 - 2).  A workload is skipped once the whole run has used its time budget."""
+    import copy
+    import bench_workloads
+    res = []
+    budget_s = float(os.environ.get("SPLA_BENCH_BUDGET_S", 420))
+    for key, label in (("pagerank-vxm", "configs[2]"), ("sssp-step", "configs[3] at N = 1"), ("tc-mxmT", "configs[4]: mxmT(L, L, L), R-MAT 20"), ("mxm", "configs[4]: mxm A x A, R-MAT 18")):
+        if time.time() - t_start > budget_s:
+            res.append({"name": f"{label} ({key})", "skipped": "time budget of the default run used up: python bench.py --workload " + key})
+            continue
+        b = copy.copy(args)
+        b.scale, b.steps, b.warmup, b.workload = 22, 10, 2, key  # (22: bench_workloads maps it to each workload's own size)
+        t0 = time.time()
+        try:
+            line = bench_workloads.WORKLOADS[key](b)
+        except Exception as exc:  # a variant must not take the contract line down with it
+            res.append({"name": f"{label} ({key})", "error": repr(exc)[:300]})
+            torch.cuda.empty_cache()
+            continue
+        line["name"] = f"BASELINE {label} ({key})"
+        line["variant_wall_s"] = round(time.time() - t0, 1)
+        res.append(line)
+        torch.cuda.empty_cache()
+    return res
 
 
 def same_matrix_variants(args, n, nnz, Ap, Aj, Ax, v, mask, r_cob):

@@ -91,17 +91,43 @@ def _sym_rmat(scale, edge_factor, seed):
 
 
 # ---------------------------------------------------------------------------------------------------------------- vxm
+def _orkut_like(args):
+    """BASELINE configs[2]'s matrix: SuiteSparse com-Orkut — 3,072,441 vertices, 234.4 M stored entries (117.2 M undirected edges), largest degree 33,313
+    (reference README.md:148; loader src/io.cpp:159-169).  Read through the MtxLoader mirror when SPLA_COM_ORKUT names the file; otherwise a symmetric Chung-Lu
+    graph matched to those three numbers (graphgen.chung_lu_csr).  `--scale S` other than the default shrinks n and nnz by 2^(22 - S) (tests, debug runs)."""
+    from spla_amd import graphgen
+    path = os.environ.get("SPLA_COM_ORKUT")
+    if path and os.path.exists(path):
+        from spla_amd import api
+        n, _, hAi, hAj = api.load_mtx(path, offset_indices=True, make_undirected=True, remove_loops=True)  # (this library's mirror of the reference's MtxLoader)
+        Ai, Aj = torch.from_numpy(np.asarray(hAi).astype(np.int64)).cuda(), torch.from_numpy(np.asarray(hAj).astype(np.int64)).cuda()
+        n = int(n)
+        key = torch.unique(Ai * n + Aj, sorted=True)
+        Ap, Aj = graphgen.keys_to_csr(key, n, n)
+        return n, Ap, Aj, f"SuiteSparse com-Orkut ({os.path.basename(path)})"
+    shrink = 1 << max(0, 22 - args.scale) if args.scale < 22 else 1
+    n, nnz_t, dmax = 3_072_441 // shrink, 234_400_000 // shrink, max(64, 33_313 // max(1, int(shrink ** 0.5)))
+    n, Ap, Aj = graphgen.chung_lu_csr(n, nnz_t, dmax, seed=args.seed, device="cuda")
+    return n, Ap, Aj, (f"symmetric Chung-Lu graph matched to com-Orkut's n = 3,072,441, 234.4 M entries, max degree 33,313 (random labels; the file is not on the box)"
+                       if shrink == 1 else f"Chung-Lu graph, com-Orkut's numbers shrunk by {shrink}")
+
+
 def pagerank_vxm(args):
     from oracle import pyoracle
     from spla_amd import kernels
-    scale, ef = (args.scale if args.scale != 22 or True else 22), 28
-    n, Ap, Aj = _sym_rmat(scale, ef, args.seed)
+    if os.environ.get("SPLA_BENCH_PR_GRAPH", "orkut-like") == "rmat":  # rounds 1-3's stand-in: symmetrised R-MAT scale 22, edge factor 28
+        scale, ef = args.scale, 28
+        n, Ap, Aj = _sym_rmat(scale, ef, args.seed)
+        what = f"symmetrised R-MAT scale {scale} ef {ef} (rounds 1-3's stand-in for com-Orkut)"
+    else:
+        n, Ap, Aj, what = _orkut_like(args)
     nnz = int(Ap[-1])
+    dmax_meas = int((Ap[1:] - Ap[:-1]).max())
     deg = (Ap[1:] - Ap[:-1]).to(torch.float32)
     rows = torch.repeat_interleave(torch.arange(n, device="cuda"), (Ap[1:] - Ap[:-1]).to(torch.int64))
     Ax = (0.85 / deg.clamp(min=1.0))[rows].contiguous()  # examples/pr.cpp:81-88: 0.85 / outdeg(row)
     del rows
-    _log(f"[bench] pagerank-vxm stand-in: symmetrised R-MAT scale {scale} ef {ef}: n={n} nnz={nnz}")
+    _log(f"[bench] pagerank-vxm: {what}: n={n} nnz={nnz} max degree={dmax_meas}")
     Tp, Tj, Tx = kernels.csr_transpose(n, n, Ap, Aj, Ax)
     mode = os.environ.get("SPLA_BENCH_PLAN", "cob")  # layout copy on the transposed matrix: column-ordered blocks (default), sliced-ELL, or the CSR kernels only
     use_sell = mode == "sell"
@@ -122,13 +148,13 @@ def pagerank_vxm(args):
     # B_vxm (dense frontier = mxv over M^T): CSR stream + row pointers + mask + v + (value, touched) + compaction
     alg = 8 * nnz + 4 * (n + 1) + 4 * n + 4 * n + 8 * n + 8 * n + 8 * int(ri.numel())
     line = _line("masked vxm GTEPS (PageRank step)", "GTEPS", nnz / (wall / args.steps) / 1e9, args, wall / args.steps * 1e3, "f32",
-                 {"workload": f"exec_vxm_masked MULT/PLUS fp32, ALWAYS mask, every v entry stored; symmetrised R-MAT scale {scale} ef {ef} "
-                              "(stand-in for com-Orkut, which is not on the box)", "n": n, "nnz": nnz, "out_entries": int(ri.numel()),
+                 {"workload": f"exec_vxm_masked MULT/PLUS fp32, ALWAYS mask, every v entry stored (a PageRank step); {what}", "n": n, "nnz": nnz, "max_degree": dmax_meas,
+                  "out_entries": int(ri.numel()),
                   "form": ("pull over the column-ordered-blocks copy of the transposed matrix (cob_vxm: fp64 LDS accumulation)" if mode == "cob" else
                            "pull over the sliced-ELL copy of the transposed matrix (sell_vxm: value form, vxm mode)" if use_sell else
                            "pull over the transposed CSR (spmv_wavetile, VXM mode)") + " + order-preserving compaction"},
                  _roof(alg, ms, ("cob_vxm" if mode == "cob" else "sell_vxm" if use_sell else "spmv_wavetile<VXM>") + " + compaction",
-                       pmc="pagerank_vxm" if mode == "cob" and scale == 22 else None))
+                       pmc="pagerank_vxm_orkut_like" if mode == "cob" and nnz == 234853298 else None))
     if not args.no_verify:
         # structure: identical to the oracle's (same touched columns, index-sorted).  values: the oracle (= the reference) folds
         # every column sequentially in fp32; columns here have up to ~1e5 products, where that sequential fold itself is ~2e-5 off

@@ -127,7 +127,12 @@ def load() -> C.CDLL:
             pass
         lib = C.CDLL(str(LIB_PATH))
         for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(lib, name)
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                if os.environ.get("SPLA_LIB_TAG"):  # (experiments only: a side-by-side build of an older tree may lack a newer entry point)
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = lib

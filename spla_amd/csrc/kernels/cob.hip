@@ -408,7 +408,6 @@ namespace {
         a.accumulate = VXM ? 0u : tl_accumulate;
         a.vbits      = g->d_vbits;
         a.x_uniform  = g->x_bits;
-        a.gate       = nullptr;
         if constexpr (MODE != 0) {// the bitmap of v for this call
             hipLaunchKernelGGL((cob_vbits_kernel<T>), dim3((g->n_cols + 255) / 256), dim3(256), 0, st, g->n_cols, static_cast<const T*>(v), g->d_vbits, tl_skip_bits);
             SPLAHIP_TRY(hipGetLastError());
@@ -447,7 +446,7 @@ namespace {
         if (g->hub_finish == 1 && g->n_hub_ranges) {
             const uint32_t n_slots = g->n_hub_ranges * g->R;
             hipLaunchKernelGGL((cob_hub_finish_kernel<T, ACC, VXM>), dim3((n_slots + 255) / 256), dim3(256), 0, st, n_slots, g->R, g->acc_stride, g->d_acc, g->d_hub_row, static_cast<const T*>(mask),
-                               static_cast<T*>(r), touched, a.accumulate, DynBin(op_add), op_select, init, a.gate);
+                               static_cast<T*>(r), touched, a.accumulate, DynBin(op_add), op_select, init);
             SPLAHIP_TRY(hipGetLastError());
         }
         return SPLAHIP_OK;

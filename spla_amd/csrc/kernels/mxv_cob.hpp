@@ -302,7 +302,6 @@ namespace splahip {
         uint32_t        pad_chunk;// two all-padding chunks behind the last real one: pad_chunk for a hub piece (slot values R + lane), pad_chunk + 1 for a natural one (Rn + lane)
         const uint32_t* vbits;     // MODE 1 / 2: bit c = v[c] != 0 (n_cols bits)
         uint32_t        x_uniform; // MODE 2: the one value word of the matrix
-        const uint32_t* gate;      // unused (nullptr): a device-side gate of the launch, tried in round 4 (profiles/r04_notes.md 3)
         uint32_t        accumulate;// 1: r already holds the fold of another column part of the same rows (1-D row decomposition, dist.hip): a selected
                                    // row that holds an entry here becomes add(r[row], acc); every other row is left as it is
     };
@@ -651,7 +650,6 @@ namespace splahip {
         extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
         word* const        s_acc = reinterpret_cast<word*>(s_raw);
         constexpr unsigned NW    = TPB / kWave;
-        if (a.gate != nullptr && a.gate[3] != 0u) return;// the mask selects so few entries that the selected-rows kernels serve this call (mxv.hip)
         const CobTile      t     = a.tiles[blockIdx.x];// one piece per workgroup, launched largest piece first
         if (t.range == kCobFinisher) {
             cob_hub_finisher<T, ACC, VXM, TPB>(t, a.ranges[t.multi], a.R, a.acc_stride, a.acc, a.ticket, a.fin, a.hub_row, mask, r, a.touched, a.accumulate, add, op_select, init);
@@ -846,8 +844,7 @@ namespace splahip {
     template<typename T, int ACC, bool VXM>
     __global__ __launch_bounds__(256) void cob_hub_finish_kernel(uint32_t n_slots, uint32_t R, uint32_t acc_stride, uint32_t* __restrict__ acc, const uint32_t* __restrict__ hub_row,
                                                                  const T* __restrict__ mask, T* __restrict__ r, uint32_t* __restrict__ touched, uint32_t accumulate, DynBin add,
-                                                                 int op_select, T init, const uint32_t* __restrict__ gate = nullptr) {
-        if (gate != nullptr && gate[3] != 0u) return;
+                                                                 int op_select, T init) {
         const uint32_t i = blockIdx.x * 256 + threadIdx.x;
         if (i >= n_slots) return;
         const size_t   ia  = (size_t) (i / R) * acc_stride + i % R;// accumulator q belongs to hub range q

@@ -119,3 +119,45 @@ def nnz_balanced_row_splits(Ap: torch.Tensor, parts: int):
     for k in range(1, len(bounds)):
         bounds[k] = max(bounds[k], bounds[k - 1])
     return bounds
+
+
+def chung_lu_csr(n: int, nnz_target: int, max_degree: int, seed: int = 1, device="cpu", chunk: int = 1 << 25):
+    """(n, Ap, Aj) of a SYMMETRIC Chung-Lu graph with a power-law expected degree sequence, matched to three numbers of a real graph: vertices n, stored
+    entries nnz_target (both directions of every edge), largest degree max_degree.  Expected degrees w_i = c (i + 1)^-alpha with alpha solved from
+    max / mean = (1 - alpha) n^alpha; both endpoints of an edge are drawn proportionally to w (inverse-CDF sampling), self loops and duplicates dropped,
+    vertex labels randomly permuted (a real graph's labels carry no degree order).  bench_workloads.py uses it as the stand-in for SuiteSparse com-Orkut
+    (n = 3,072,441, 234.4 M entries, max degree 33,313: reference README.md:148), which is not on the box."""
+    import math
+    mean = nnz_target / n
+    ratio = max_degree / mean
+    lo, hi = 0.01, 0.99
+    for _ in range(60):  # (1 - a) n^a is increasing in a on this interval for n >> 1
+        mid = 0.5 * (lo + hi)
+        if (1.0 - mid) * n ** mid < ratio:
+            lo = mid
+        else:
+            hi = mid
+    alpha = 0.5 * (lo + hi)
+    g = _gen(device, seed)
+    w = (torch.arange(1, n + 1, device=device, dtype=torch.float64)) ** (-alpha)
+    cdf = torch.cumsum(w, 0)
+    cdf /= cdf[-1].clone()
+    perm = torch.randperm(n, generator=_gen(device, seed + 7919), device=device)
+    m = int(nnz_target // 2 * 1.002)  # undirected edges to draw (a few per mille are duplicates / self loops)
+    keys = []
+    done = 0
+    while done < m:
+        cnt = min(chunk, m - done)
+        u = torch.searchsorted(cdf, torch.rand(cnt, generator=g, device=device, dtype=torch.float64)).clamp_(max=n - 1)
+        v = torch.searchsorted(cdf, torch.rand(cnt, generator=g, device=device, dtype=torch.float64)).clamp_(max=n - 1)
+        u, v = perm[u], perm[v]
+        keep = u != v
+        u, v = u[keep], v[keep]
+        keys.append(u * n + v)
+        keys.append(v * n + u)
+        done += cnt
+        del u, v, keep
+    key = torch.unique(torch.cat(keys), sorted=True)
+    del keys
+    Ap, Aj = keys_to_csr(key, n, n)
+    return n, Ap, Aj
