@@ -106,6 +106,9 @@ int splahip_csr_plan_cob_info(splahip_plan plan, uint32_t* n_tiles, uint32_t* n_
 int splahip_csr_plan_cob_layout(splahip_plan plan, uint32_t* n_ranges, uint32_t* n_hub_ranges, uint32_t* n_hub_rows, uint64_t* bytes);
 /* slots (rows) of a hub range and of a natural range of the copy (0 / 0 without one) */
 int splahip_csr_plan_cob_slots(splahip_plan plan, uint32_t* hub_slots, uint32_t* natural_slots);
+/* *hot_columns = K when the copy relabels the K most referenced columns (a matrix whose column labels carry no locality: the hot columns take the ids 0 .. K-1
+ * inside the copy and every call gathers from [v[hot columns] | v], one extra pass over v per call); 0 when the labels already cluster them or no copy exists. */
+int splahip_csr_plan_cob_relabel(splahip_plan plan, uint32_t* hot_columns);
 /* What the last MASKED call over the blocks (op_select other than ALWAYS) found when it probed its mask on the device — a blocking read-back for tests and
  * benches: *selected_entries ~ entries of the selected rows (a 1-in-16 sample of the rows, scaled; exact below 2^18 rows), *served_by_rows = 1 when the
  * selected-rows kernels served the call (the selection holds too few entries for the blocks, which stream the whole matrix whatever the mask).  Both zero when

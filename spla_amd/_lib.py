@@ -49,6 +49,7 @@ _SIGNATURES = {
     "splahip_csr_plan_cob_layout": (C.c_int, [_vp, _u32p, _u32p, _u32p, C.POINTER(C.c_uint64)]),
     "splahip_csr_plan_cob_slots": (C.c_int, [_vp, _u32p, _u32p]),
     "splahip_csr_plan_cob_probe": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "splahip_csr_plan_cob_relabel": (C.c_int, [_vp, _u32p]),
     "splahip_jit_available": (C.c_int, []),
     "splahip_mxv_masked_jit": (C.c_int, [C.c_int, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p,
                                          C.c_uint32, C.c_int, _vp]),

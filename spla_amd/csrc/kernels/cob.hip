@@ -126,8 +126,59 @@ namespace {
         for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) p[i] = w;
     }
 
+    // ---- hot-column relabelling ----
+    __global__ __launch_bounds__(256) void cob_colcount_kernel(uint32_t nnz, const uint32_t* __restrict__ Aj, uint32_t* __restrict__ cnt) {
+        for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nnz; k += gridDim.x * 256) atomicAdd(&cnt[Aj[k]], 1u);
+    }
+    // out[0] = columns referenced >= thr times, out[1] = those of them whose neighbour column (c ^ 1) is referenced >= thr times too, out[2..3] = the entries they hold (64 bit)
+    __global__ __launch_bounds__(256) void cob_colstat_kernel(uint32_t n_cols, const uint32_t* __restrict__ cnt, uint32_t thr, uint32_t* __restrict__ out) {
+        uint32_t           hot = 0, both = 0;
+        unsigned long long held = 0;
+        for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < n_cols; c += gridDim.x * 256)
+            if (cnt[c] >= thr) {
+                ++hot;
+                held += cnt[c];
+                if ((c ^ 1u) < n_cols && cnt[c ^ 1u] >= thr) ++both;
+            }
+        hot  = wave_sum(hot);
+        both = wave_sum(both);
+        for (unsigned off = kWave / 2; off > 0; off >>= 1) held += __shfl_xor(held, off, kWave);
+        if (lane_id() == 0) {
+            if (hot) atomicAdd(&out[0], hot);
+            if (both) atomicAdd(&out[1], both);
+            if (held) atomicAdd(reinterpret_cast<unsigned long long*>(out + 2), held);
+        }
+    }
+    // the hot columns as (count, column) pairs for the sort; the others marked cold
+    __global__ __launch_bounds__(256) void cob_hotlist_kernel(uint32_t n_cols, const uint32_t* __restrict__ cnt, uint32_t thr, uint32_t* __restrict__ n_out, uint32_t* __restrict__ key,
+                                                              uint32_t* __restrict__ col, uint32_t* __restrict__ col_map) {
+        const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+        const bool     hot = c < n_cols && cnt[c] >= thr;
+        const unsigned long long m = __ballot(hot);
+        uint32_t                 base = 0;
+        if (lane_id() == 0 && m) base = atomicAdd(n_out, (uint32_t) __popcll(m));
+        base = __shfl(base, 0, kWave);
+        if (hot) {
+            const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+            key[at] = cnt[c], col[at] = c;
+        } else if (c < n_cols)
+            col_map[c] = 0xFFFFFFFFu;
+    }
+    __global__ __launch_bounds__(256) void cob_hotrank_kernel(uint32_t n_hot, const uint32_t* __restrict__ hot_cols, uint32_t* __restrict__ col_map) {
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        if (i < n_hot) col_map[hot_cols[i]] = i;
+    }
+    // per call: the vector the kernels gather from = [v[hot_cols[0 .. K)] | zero padding to whole 64-word blocks | v]
+    template<typename T>
+    __global__ __launch_bounds__(256) void cob_vperm_kernel(uint32_t n_hot, uint32_t n_hot_pad, uint32_t n_cols, const uint32_t* __restrict__ hot_cols, const T* __restrict__ v,
+                                                            T* __restrict__ out) {
+        const uint32_t total = n_hot_pad + n_cols;
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) out[i] = i < n_hot ? v[hot_cols[i]] : (i < n_hot_pad ? T(0) : v[i - n_hot_pad]);
+    }
+
     __global__ __launch_bounds__(256) void cob_key_kernel(uint32_t n_rows, uint32_t nnz, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ Aj,
-                                                          const uint32_t* __restrict__ rowmap, uint32_t cbits, unsigned long long* __restrict__ key) {
+                                                          const uint32_t* __restrict__ rowmap, uint32_t cbits, unsigned long long* __restrict__ key,
+                                                          const uint32_t* __restrict__ col_map, uint32_t n_hot_pad) {
         const uint32_t k0 = blockIdx.x * kKeyTile;
         const uint32_t k1 = min(nnz, k0 + kKeyTile);
         // rows spanned by this tile of the entry stream (uniform searches: every lane reads the same words)
@@ -137,7 +188,12 @@ namespace {
             const uint32_t row = r_lo + upper_bound_u32(Ap + r_lo, r_hi - r_lo + 1, k) - 1;
             const uint32_t m   = rowmap[row];
             const unsigned long long range = m >> kSlotBits;
-            key[k] = (((range << cbits) | Aj[k]) << kSlotBits) | (m & ((1u << kSlotBits) - 1u));
+            uint32_t c = Aj[k];
+            if (col_map != nullptr) {// hot-column relabelling: a hot column takes its rank, every other one keeps its place behind the hot block
+                const uint32_t h = col_map[c];
+                c                = h != 0xFFFFFFFFu ? h : n_hot_pad + c;
+            }
+            key[k] = (((range << cbits) | c) << kSlotBits) | (m & ((1u << kSlotBits) - 1u));
         }
     }
 
@@ -408,8 +464,14 @@ namespace {
         a.accumulate = VXM ? 0u : tl_accumulate;
         a.vbits      = g->d_vbits;
         a.x_uniform  = g->x_bits;
+        if (g->n_hot) {// hot-column relabelling: the kernels gather from [v[hot columns] | v]
+            hipLaunchKernelGGL((cob_vperm_kernel<T>), dim3(2048), dim3(256), 0, st, g->n_hot, g->n_hot_pad, g->n_cols, g->d_hot_cols, static_cast<const T*>(v),
+                               reinterpret_cast<T*>(g->d_vperm));
+            SPLAHIP_TRY(hipGetLastError());
+            v = g->d_vperm;
+        }
         if constexpr (MODE != 0) {// the bitmap of v for this call
-            hipLaunchKernelGGL((cob_vbits_kernel<T>), dim3((g->n_cols + 255) / 256), dim3(256), 0, st, g->n_cols, static_cast<const T*>(v), g->d_vbits, tl_skip_bits);
+            hipLaunchKernelGGL((cob_vbits_kernel<T>), dim3((g->n_vcols + 255) / 256), dim3(256), 0, st, g->n_vcols, static_cast<const T*>(v), g->d_vbits, tl_skip_bits);
             SPLAHIP_TRY(hipGetLastError());
         }
         const T init = from_bits<T>(init_bits);
@@ -473,7 +535,7 @@ namespace {
         if constexpr (!VXM && ACC == COB_MIN) {
             const char* be = std::getenv("SPLAHIP_COB_BITS");
             // (worth it once v no longer fits the L2s: R-MAT 24, 67 MB of v: 0.83 -> 0.70 ms; R-MAT 22, 16.8 MB: 178 -> 204 us.  SPLAHIP_COB_BITS=2 forces it)
-            const bool big = g->n_cols >= (1u << 23) || (be && be[0] == '2');
+            const bool big = g->n_vcols >= (1u << 23) || (be && be[0] == '2');
             if (g->d_vbits && big && !(be && be[0] == '0') && !tl_accumulate && sell_skip_family(TypeId<T>::value, op_mult, op_add) == 2) {
                 if (int rc = cob_ax_stats<T>(g, st)) return rc;
                 // (fp32: x >= 0 gives x + init >= init for every init that is no NaN — the reference's fp32 SSSP step, init = +inf)
@@ -544,7 +606,7 @@ namespace splahip {
     void cob_release(splahip_cob_s* g) {
         if (!g) return;
         if (g->h_probe) (void) hipHostFree(const_cast<uint32_t*>(g->h_probe));
-        for (void* p : {(void*) g->d_hdr, (void*) g->d_cr, (void*) g->d_ax, (void*) g->d_slot16, (void*) g->d_hub_row, (void*) g->d_acc, (void*) g->d_ticket, (void*) g->d_vbits, (void*) g->d_probe,
+        for (void* p : {(void*) g->d_hdr, (void*) g->d_cr, (void*) g->d_ax, (void*) g->d_slot16, (void*) g->d_hub_row, (void*) g->d_acc, (void*) g->d_ticket, (void*) g->d_vbits, (void*) g->d_probe, (void*) g->d_hot_cols, (void*) g->d_vperm,
                         (void*) g->sched[0].d_tiles, (void*) g->sched[0].d_ranges, (void*) g->sched[1].d_tiles, (void*) g->sched[1].d_ranges})
             if (p) (void) hipFree(p);
         delete g;
@@ -677,13 +739,87 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     const uint32_t n_rows8 = (n_rows + 7) & ~7u;
 
     const uint32_t col_bits = 31 - kSlotBits;                            // a cr word: slot field (15 bits used; the values R .. R + 63 mark padding) above 16 column bits
-    const uint32_t cbits    = std::max(bits_for(n_cols), col_bits);      // column field of the sort key: at least one whole window
-    const uint32_t win_bits = cbits - col_bits;                          // column windows per range = 2^win_bits
 
     Scratch tmp;
     auto*   g   = new splahip_cob_s();
     g->n_rows   = n_rows;
     g->n_cols   = n_cols;
+    g->n_vcols  = n_cols;
+    // Hot-column relabelling.  What a range's gathers cost is the number of distinct 128-byte lines of v it touches; in a matrix whose column labels carry no
+    // locality (a real graph's; `--permute 1`) a hot column shares its line with 31 cold ones and every range fetches the line for it (profiles/r04_notes.md 1:
+    // R-MAT 23, 14.8 M (range, line) pairs with random labels against 7.3 M with the generator's).  The columns referenced >= max(16, average) times take new ids 0 .. K-1 in
+    // descending reference-count order — hot columns side by side, the hottest lines shared by every range — and a call gathers from [v[hot columns] | v] (one
+    // pass per call, ~15 us at R-MAT 23).  Decided here, per matrix: only where the labels do NOT already cluster the hot columns (a hot column's neighbour c ^ 1
+    // is mostly hot in a generator's labelling, rarely in a random one).  SPLAHIP_COB_RELABEL = 0 never, 2 always.
+    uint32_t* col_map = nullptr;
+    {
+        const uint32_t mode = env_u32("SPLAHIP_COB_RELABEL", 1);
+        if (mode != 0 && n_cols >= (1u << 16) && (uint64_t) n_cols + n_cols / 2 < (1ull << 31)) {
+            uint32_t *cnt = nullptr, *st4 = nullptr;
+            hipError_t e0 = tmp.alloc(&cnt, n_cols);
+            if (e0 == hipSuccess) e0 = tmp.alloc(&st4, 4);
+            if (e0 == hipSuccess) e0 = hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t) n_cols, s);
+            if (e0 == hipSuccess) e0 = hipMemsetAsync(st4, 0, 16, s);
+            uint32_t       h4[4]   = {0, 0, 0, 0};
+            const uint32_t hot_thr = env_u32("SPLAHIP_COB_RELABEL_MIN", std::max<uint32_t>(16, nnz / n_cols));// (hot: referenced at least 16 times and at least as often as the average column)
+            if (e0 == hipSuccess) {
+                hipLaunchKernelGGL(cob_colcount_kernel, dim3(4096), dim3(256), 0, s, nnz, d_Aj, cnt);
+                hipLaunchKernelGGL(cob_colstat_kernel, dim3(1024), dim3(256), 0, s, n_cols, cnt, hot_thr, st4);
+                e0 = hipMemcpyAsync(h4, st4, 16, hipMemcpyDeviceToHost, s);
+            }
+            if (e0 == hipSuccess) e0 = hipStreamSynchronize(s);
+            const uint32_t K = h4[0];
+            const bool     scattered = K != 0 && (double) h4[1] < 0.5 * K;// fewer than half of the hot columns sit beside another hot column
+            // ... and the matrix must be SKEWED: few hot columns holding most entries (R-MAT 23: 10 % of the columns, 90 % of the entries).  On a flatter degree
+            // sequence (the com-Orkut stand-in: a quarter of the columns above the average) every range touches nearly every line either way, and the pass over v
+            // per call is all the relabelling adds: 632 us against 579 on the PageRank step
+            const uint64_t held   = ((uint64_t) h4[3] << 32) | h4[2];
+            const bool     skewed = (double) K <= 0.15 * n_cols && (double) held >= 0.6 * nnz;
+            if (e0 == hipSuccess && K >= (mode == 2 ? 64u : 1024u) && K <= n_cols / 2 && (mode == 2 || (scattered && skewed))) {
+                uint32_t *hk = nullptr, *hc = nullptr, *hk_s = nullptr;
+                e0 = tmp.alloc(&hk, K);
+                if (e0 == hipSuccess) e0 = tmp.alloc(&hc, K);
+                if (e0 == hipSuccess) e0 = tmp.alloc(&hk_s, K);
+                if (e0 == hipSuccess) e0 = tmp.alloc(&col_map, n_cols);
+                if (e0 == hipSuccess) e0 = device_malloc(reinterpret_cast<void**>(&g->d_hot_cols), sizeof(uint32_t) * (size_t) K);
+                if (e0 == hipSuccess) {
+                    g->bytes += sizeof(uint32_t) * (size_t) K;
+                    e0 = hipMemsetAsync(st4, 0, 16, s);
+                }
+                size_t bytes = 0;
+                if (e0 == hipSuccess) {
+                    hipLaunchKernelGGL(cob_hotlist_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, s, n_cols, cnt, hot_thr, st4, hk, hc, col_map);
+                    e0 = rocprim::radix_sort_pairs_desc(nullptr, bytes, hk, hk_s, hc, g->d_hot_cols, (size_t) K, 0, 32, s);
+                }
+                void* st_tmp = nullptr;
+                if (e0 == hipSuccess) e0 = device_malloc(&st_tmp, bytes ? bytes : 4);
+                if (e0 == hipSuccess) {
+                    tmp.ptrs.push_back(st_tmp);
+                    e0 = rocprim::radix_sort_pairs_desc(st_tmp, bytes, hk, hk_s, hc, g->d_hot_cols, (size_t) K, 0, 32, s);
+                }
+                if (e0 == hipSuccess) {
+                    hipLaunchKernelGGL(cob_hotrank_kernel, dim3((K + 255) / 256), dim3(256), 0, s, K, g->d_hot_cols, col_map);
+                    e0 = hipGetLastError();
+                }
+                if (e0 == hipSuccess) {
+                    g->n_hot     = K;
+                    g->n_hot_pad = (K + 63u) & ~63u;
+                    g->n_vcols   = g->n_hot_pad + n_cols;
+                    e0           = device_malloc(reinterpret_cast<void**>(&g->d_vperm), sizeof(uint32_t) * (size_t) g->n_vcols);
+                    if (e0 == hipSuccess) g->bytes += sizeof(uint32_t) * (size_t) g->n_vcols;
+                }
+            }
+            if (e0 != hipSuccess) {
+                cob_release(g);
+                return fail(SPLAHIP_ERROR, "column-ordered-blocks plan failed (column relabelling): %s", hipGetErrorString(e0));
+            }
+            if (!g->n_hot) col_map = nullptr;
+            if (std::getenv("SPLAHIP_COB_TRACE"))
+                std::fprintf(stderr, "[cob] columns referenced >= %u times: %u, %u of them beside another one: relabelling %s\n", hot_thr, K, h4[1], g->n_hot ? "ON" : "off");
+        }
+    }
+    const uint32_t cbits    = std::max(bits_for(g->n_vcols), col_bits);  // column field of the sort key: at least one whole window
+    const uint32_t win_bits = cbits - col_bits;                          // column windows per range = 2^win_bits
     g->R        = R;
     g->col_bits = col_bits;
     // the hub ranges' row pass as a kernel of its own behind the main launch (mxv_cob.hpp: cob_hub_finish_kernel).  Measured with it / without: fp32 plus-times
@@ -850,7 +986,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     if (e == hipSuccess) e = tmp.alloc(&key_s, nnz);
     if (e == hipSuccess) e = tmp.alloc(&val_s, nnz);
     if (e != hipSuccess) return bail("scratch");
-    hipLaunchKernelGGL(cob_key_kernel, dim3((nnz + kKeyTile - 1) / kKeyTile), dim3(256), 0, s, n_rows, nnz, d_Ap, d_Aj, rowmap, cbits, key);
+    hipLaunchKernelGGL(cob_key_kernel, dim3((nnz + kKeyTile - 1) / kKeyTile), dim3(256), 0, s, n_rows, nnz, d_Ap, d_Aj, rowmap, cbits, key, col_map, g->n_hot_pad);
     e = hipGetLastError();
     {
         size_t      bytes = 0;
@@ -1120,7 +1256,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     own(&g->d_acc, (size_t) max_multi * g->acc_stride);
     g->ticket_words = max_multi + 4 + 32;
     own(&g->d_ticket, (size_t) g->ticket_words);
-    own(&g->d_vbits, ((size_t) n_cols + 255) / 256 * 8 + 2);// every wave of cob_vbits_kernel writes its two words
+    own(&g->d_vbits, ((size_t) g->n_vcols + 255) / 256 * 8 + 2);// every wave of cob_vbits_kernel writes its two words
     if (e != hipSuccess) return bail("schedule upload");
     {// one value word in the whole matrix?  (the sparse-vector form then skips the value stream)
         uint32_t* rng = nullptr;
@@ -1171,6 +1307,12 @@ extern "C" int splahip_csr_plan_cob_probe(splahip_plan plan, uint64_t* selected_
     if (g->h_probe[3] == 0) return SPLAHIP_OK;// no probe has run
     if (selected_entries) *selected_entries = ((uint64_t) g->h_probe[1] << 32) | g->h_probe[0];
     if (served_by_rows) *served_by_rows = g->last_rows;
+    return SPLAHIP_OK;
+}
+
+extern "C" int splahip_csr_plan_cob_relabel(splahip_plan plan, uint32_t* hot_columns) {
+    SPLAHIP_REQUIRE(plan != nullptr && hot_columns != nullptr, "null argument");
+    *hot_columns = plan->cob ? plan->cob->n_hot : 0;
     return SPLAHIP_OK;
 }
 

@@ -87,6 +87,13 @@ struct splahip_cob_s {
     mutable uint32_t acc_identity = 0;
     mutable bool     acc_armed    = false;
     uint32_t* d_vbits  = nullptr;// per call: bit c = v[c] != 0 (sparse-input-vector form, mxv_cob.hpp MODE 1 / 2)
+    // hot-column relabelling (round 4; cob.hip): the K most referenced columns of a matrix whose labels carry no locality take the ids 0 .. K-1 in descending
+    // reference-count order, every other column c the id n_hot_pad + c; a call gathers from d_vperm = [v[hot_cols[0 .. K)] | padding | v] (one pass per call)
+    uint32_t  n_vcols   = 0;      // columns of the vector the kernels gather from: n_cols, or n_hot_pad + n_cols
+    uint32_t  n_hot     = 0;      // K (0: no relabelling)
+    uint32_t  n_hot_pad = 0;      // K rounded up to whole 64-word blocks
+    uint32_t* d_hot_cols = nullptr;// K column ids in descending reference-count order
+    uint32_t* d_vperm   = nullptr;// n_hot_pad + n_cols words, written per call
     // masked calls (round 4): the mask probe — d_probe: [0..1] entries of the selected rows (64 bit; a sample of the rows, scaled), [2] workgroups done, [4..5] what the
     // selection costs the row kernels (zero between probes); h_probe (pinned host memory the probe's last workgroup writes): [0..1] the estimate, [2] the verdict (1: the selected-rows kernels of mxv_rows.hpp
     // would serve such a mask faster than the blocks), [3] the probe's sequence number (0: none has finished yet)

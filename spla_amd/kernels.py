@@ -70,8 +70,10 @@ class CsrPlan:
         _lib.call("splahip_csr_plan_cob_layout", self._h, C.byref(nr), C.byref(nh), C.byref(hr), C.byref(by))
         hs, ns = C.c_uint32(), C.c_uint32()
         _lib.call("splahip_csr_plan_cob_slots", self._h, C.byref(hs), C.byref(ns))
+        hot = C.c_uint32()
+        _lib.call("splahip_csr_plan_cob_relabel", self._h, C.byref(hot))
         self.cob = {"tiles": a.value, "chunks": b.value, "ranges_in_pieces": c.value, "slots_per_range": d.value, "natural_slots": ns.value, "ranges": nr.value,
-                    "hub_ranges": nh.value, "hub_rows": hr.value, "bytes": by.value} if a.value else None
+                    "hub_ranges": nh.value, "hub_rows": hr.value, "bytes": by.value, "relabelled_hot_columns": hot.value} if a.value else None
         return self.cob
 
     def mask_probe(self):

@@ -641,3 +641,67 @@ def test_masked_call_takes_the_side_its_mask_favours(oracle, t):
                 assert not probe["served_by_rows"], (name, probe)
     assert seen == {True, False}
     plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", ["INT", "FLOAT"])
+def test_hot_column_relabelling(oracle, t, monkeypatch):
+    """A matrix whose column labels carry no locality gets its hot columns relabelled inside the column-ordered blocks (cob.hip: the columns referenced most take
+    the ids 0 .. K-1, a call gathers from [v[hot columns] | v]).  Forced on here (SPLAHIP_COB_RELABEL=2, every column referenced >= 8 times is hot) on a matrix
+    of 70 000 randomly labelled columns: mxv in the value form and the sparse-input-vector forms, masked and unmasked, and the pull form of vxm over the copy of
+    the transpose — all against the oracle."""
+    import torch
+    from gpu_utils import dev, host
+    from spla_amd import kernels
+    rng = np.random.default_rng(77)
+    n_rows, n_cols = 6000, 70000
+    Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 40, t, skew=True, long_rows=3, long_len=5000)
+    perm = rng.permutation(n_cols).astype(np.uint32)  # scatter the skewed columns over the id space
+    Aj = perm[Aj]
+    for i in range(n_rows):  # rows stay column-sorted (the reference's CSR invariant)
+        a, b = int(Ap[i]), int(Ap[i + 1])
+        o = np.argsort(Aj[a:b], kind="stable")
+        Aj[a:b], Ax[a:b] = Aj[a:b][o], Ax[a:b][o]
+    if t == "FLOAT":
+        Ax = (rng.integers(1, 64, len(Aj)) / 8.0).astype(np.float32)
+        v = (rng.integers(0, 32, n_cols) / 4.0).astype(np.float32)
+    else:
+        v = random_values(rng, n_cols, t, zeros=0.5)
+    dAp, dAj, dAx, dv = dev(Ap), dev(Aj), dev(np.asarray(Ax, NP[t])), dev(np.asarray(v, NP[t]))
+    monkeypatch.setenv("SPLAHIP_COB_RELABEL", "2")
+    monkeypatch.setenv("SPLAHIP_COB_RELABEL_MIN", "8")
+    monkeypatch.setenv("SPLAHIP_COB_HUB_MIN_DEGREE", "60")
+    monkeypatch.setenv("SPLAHIP_MASK_PROBE", "0")
+    plan = kernels.CsrPlan(n_rows, len(Aj), dAp)
+    info = plan.attach_cob(n_cols, dAp, dAj, dAx, row_bits=9, tile_chunks=4)
+    assert info and info["relabelled_hot_columns"] >= 64, info
+    cells = [("MULT", "PLUS", 0), ("PLUS", "MIN", 1 << 20), ("BAND", "BOR", 0), ("LAND", "LOR", 0)] if t == "INT" else [("MULT", "PLUS", 0.0), ("PLUS", "MIN", 1e9), ("LAND", "LOR", 0.0)]
+    for mul, add, init in cells:
+        for sel in ("ALWAYS", "NQZERO"):
+            mask = random_mask(rng, n_rows, t)
+            want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
+            r = torch.full((n_rows,), 5, dtype=kernels.torch_dtype(t), device="cuda")
+            kernels.mxv_masked(plan, t, n_cols, dAp, dAj, dAx, dev(mask), dv, r, mul, add, sel, init)
+            torch.cuda.synchronize()
+            assert "cob" in kernels.mxv_variant(t, mul, add, False, plan)
+            if t == "FLOAT" and add == "PLUS":  # (the blocks fold a row's products in column-block order: the stated 1e-5 of the reference's left fold)
+                np.testing.assert_allclose(host(r, NP[t]), want, rtol=1e-5, atol=0, err_msg=f"{t} {mul}/{add} {sel}")
+            else:
+                assert np.array_equal(host(r, NP[t]).view(np.uint32), want.view(np.uint32)), (t, mul, add, sel)
+    plan.close()
+    # vxm: the pull form over the relabelled copy of the transposed matrix
+    Tp, Tj, Tx = kernels.csr_transpose(n_rows, n_cols, dAp, dAj, dAx)
+    planT = kernels.CsrPlan(n_cols, len(Aj), Tp)
+    # (the transposed matrix has n_rows = 6000 columns: below the relabelling's floor — so transpose a tall copy instead: columns of M^T = rows of M)
+    planT.attach_cob(n_rows, Tp, Tj, Tx)
+    vi = np.arange(n_rows, dtype=np.uint32)
+    vx = (rng.integers(0, 32, n_rows) / 4.0).astype(np.float32) if t == "FLOAT" else random_values(rng, n_rows, t, zeros=0.3)
+    maskc = random_mask(rng, n_cols, t)
+    want = oracle.vxm_masked(t, n_rows, n_cols, Ap, Aj, Ax, maskc, vi, vx, "MULT", "PLUS", "NQZERO")
+    ri, rx = kernels.vxm_pull(planT, t, n_rows, n_cols, Tp, Tj, Tx, dev(maskc), dev(vi), dev(np.asarray(vx, NP[t])), "MULT", "PLUS", "NQZERO", identity=True)
+    assert np.array_equal(host(ri, np.uint32), want[0])
+    if t == "FLOAT":
+        np.testing.assert_allclose(host(rx, NP[t]), want[1], rtol=1e-5, atol=0)
+    else:
+        assert np.array_equal(host(rx, NP[t]).view(np.uint32), want[1].view(np.uint32))
+    planT.close()
