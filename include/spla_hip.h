@@ -57,6 +57,8 @@ int         splahip_init(int device);             /* select device, check it is 
 int         splahip_device_info(char* buffer, int length);
 const char* splahip_last_error(void);
 int         splahip_version(void);
+/* SPLAHIP_* environment knobs (A/B switches for tests and experiments) are read once and cached; a process that changes one afterwards calls this. */
+int         splahip_env_refresh(void);
 
 int splahip_malloc(void** d_ptr, size_t bytes);
 int splahip_free(void* d_ptr);

@@ -31,6 +31,7 @@ _SIGNATURES = {
     "splahip_device_info": (C.c_int, [C.c_char_p, C.c_int]),
     "splahip_last_error": (C.c_char_p, []),
     "splahip_version": (C.c_int, []),
+    "splahip_env_refresh": (C.c_int, []),
     "splahip_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "splahip_free": (C.c_int, [_vp]),
     "splahip_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
@@ -144,9 +145,22 @@ def declared_symbols():
     return sorted(_SIGNATURES)
 
 
+_env_sig = None
+
+
+def _sync_env(lib):
+    """The library caches its SPLAHIP_* environment knobs; tests and experiments change them mid-process through os.environ: tell the library when they did."""
+    global _env_sig
+    sig = hash(frozenset((k, v) for k, v in os.environ.items() if k.startswith("SPLAHIP_") or k.startswith("SPLA_HIP_")))
+    if sig != _env_sig:
+        _env_sig = sig
+        lib.splahip_env_refresh()
+
+
 def call(name: str, *args):
     """Call a status-returning entry point and raise on failure."""
     lib = load()
+    _sync_env(lib)
     fn = getattr(lib, name)
     res = fn(*args)
     if name in _RAW:

@@ -309,7 +309,7 @@ namespace {
     }
 
     bool cob_disabled() {
-        const char* e = std::getenv("SPLAHIP_COB");
+        const char* e = knob_env("SPLAHIP_COB");
         return e && e[0] == '0';
     }
     uint32_t compute_units() {
@@ -319,7 +319,7 @@ namespace {
         return 256;
     }
     uint32_t env_u32(const char* name, uint32_t dflt) {
-        const char* e = std::getenv(name);
+        const char* e = knob_env(name);
         return e && *e ? (uint32_t) std::strtoul(e, nullptr, 10) : dflt;
     }
 
@@ -519,9 +519,9 @@ namespace {
                     uint32_t init_bits, hipStream_t st) {
         // the sparse-input-vector form (mxv_cob.hpp MODE 1 / 2) for the semirings in which a zero of v cannot change a row (sell_skip_family == 1): int / uint only
         if constexpr (!VXM && !std::is_same<T, float>::value && (ACC == COB_OR || ACC == COB_ADD || ACC == COB_XOR || ACC == COB_MAX)) {
-            const char* be = std::getenv("SPLAHIP_COB_BITS");
+            const char* be = knob_env("SPLAHIP_COB_BITS");
             if (g->d_vbits && !(be && be[0] == '0') && !tl_accumulate && sell_skip_family(TypeId<T>::value, op_mult, op_add) == 1) {
-                const char* ue = std::getenv("SPLAHIP_COB_UNIFORM");
+                const char* ue = knob_env("SPLAHIP_COB_UNIFORM");
                 if (g->x_uniform && !(ue && ue[0] == '0')) {
                     if (op_mult == SPLAHIP_BAND) return launch_cob<T, StaBin<SPLAHIP_BAND>, ACC, VXM, 2>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
                     return launch_cob<T, DynBin, ACC, VXM, 2>(g, Ap, mask, v, r, touched, op_mult, op_add, op_select, init_bits, st);
@@ -533,7 +533,7 @@ namespace {
         // the same form for min-plus (PLUS / MIN on int / uint, sell_skip_family == 2: the shortest-path step): an entry whose v value is `init` cannot
         // lower a minimum that starts at init, provided no matrix value is negative and init + max(A) does not wrap (checked once per type / per call)
         if constexpr (!VXM && ACC == COB_MIN) {
-            const char* be = std::getenv("SPLAHIP_COB_BITS");
+            const char* be = knob_env("SPLAHIP_COB_BITS");
             // (worth it once v no longer fits the L2s: R-MAT 24, 67 MB of v: 0.83 -> 0.70 ms; R-MAT 22, 16.8 MB: 178 -> 204 us.  SPLAHIP_COB_BITS=2 forces it)
             const bool big = g->n_vcols >= (1u << 23) || (be && be[0] == '2');
             if (g->d_vbits && big && !(be && be[0] == '0') && !tl_accumulate && sell_skip_family(TypeId<T>::value, op_mult, op_add) == 2) {
@@ -626,7 +626,7 @@ namespace splahip {
         if (cob_serves(plan, type, op_add, n_cols)) return true;
         if (!plan || !plan->cob || plan->cob->n_cols != n_cols || cob_disabled()) return false;
         if (type != SPLAHIP_FLOAT || cob_acc_kind_mxv(op_add, op_mult, type) == COB_NONE || plan->cob->sched[0].n_tiles == 0) return false;
-        const char* e = std::getenv("SPLAHIP_COB_FMINMAX");
+        const char* e = knob_env("SPLAHIP_COB_FMINMAX");
         if (e && e[0] == '0') return false;
         return cob_float_minmax_ok(plan->cob, stream);
     }
@@ -727,7 +727,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     // the natural ranges are where a scale-free matrix's gather traffic is (profiles/r03_notes.md 6).  A natural range's fp32 sum then lives in FLOAT
     // words (compare-and-swap adds: its rows have few entries each, so neither the adds collide nor the sum needs the double), 32704 of them = 128 KB;
     // 4-byte slices of that size run one workgroup per CU.  SPLAHIP_COB_NAT_SLOTS overrides (tests: 2 x R on small inputs).
-    const bool nat_auto = std::getenv("SPLAHIP_COB_NAT_SLOTS") == nullptr;// the size is the library's proposal: the attach may take it back (below)
+    const bool nat_auto = knob_env("SPLAHIP_COB_NAT_SLOTS") == nullptr;// the size is the library's proposal: the attach may take it back (below)
     uint32_t   Rn       = env_u32("SPLAHIP_COB_NAT_SLOTS", nat_slots_default(R, row_bits != 0));
     if (Rn < R) Rn = R;
     SPLAHIP_REQUIRE(Rn % 64 == 0 && Rn <= 32704, "natural slots per range must be a multiple of 64, at most 32704");
@@ -814,7 +814,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
                 return fail(SPLAHIP_ERROR, "column-ordered-blocks plan failed (column relabelling): %s", hipGetErrorString(e0));
             }
             if (!g->n_hot) col_map = nullptr;
-            if (std::getenv("SPLAHIP_COB_TRACE"))
+            if (knob_env("SPLAHIP_COB_TRACE"))
                 std::fprintf(stderr, "[cob] columns referenced >= %u times: %u, %u of them beside another one: relabelling %s\n", hot_thr, K, h4[1], g->n_hot ? "ON" : "off");
         }
     }
@@ -1239,7 +1239,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
                 const uint32_t hub_slots = std::min(R, H - q * R);
                 for (uint32_t f0 = 0; f0 < hub_slots; f0 += fin_slots, ++n_fin) sorted.insert(sorted.end(), {q * R + f0, std::min(fin_slots, hub_slots - f0), kCobFinisher, q});
             }
-        if (std::getenv("SPLAHIP_COB_TRACE"))
+        if (knob_env("SPLAHIP_COB_TRACE"))
             std::fprintf(stderr, "[cob] schedule %d: R %u / %u, %u hub rows in %u hub ranges + %u natural ranges; slots %u, cost %.1f M (%.1f %% gathers), piece <= %u %% of a share in %u size levels, %u pieces, "
                                  "%u ranges in several pieces, modelled makespan %.1f us (even: %.1f)\n",
                          w, R, Rn, H, n_hub_ranges, n_nat, slots, cost_pre[n_chunks] / 1e8, 100.0 - 100.0 * 1600.0 * n_chunks / std::max<uint64_t>(1, cost_pre[n_chunks]), share_pct, levels, n_tiles, n_multi,

@@ -29,6 +29,11 @@ namespace splahip {
 
     inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+    // An environment knob (SPLAHIP_...: A/B switches and tuning values for tests and experiments), read from the process environment ONCE and cached
+    // (runtime.hip): a call's dispatch costs a hash lookup, not a scan of the environment.  splahip_env_refresh() drops the cache (tests change knobs mid-process).
+    const char* knob_env(const char* name);
+    void        knob_cache_clear();
+
     // make sure a device has been selected and is a gfx950; returns SPLAHIP_OK or an error status
     int ensure_device();
 

@@ -303,7 +303,7 @@ int splahip_shard_create(splahip_shard* out, int world, int rank, uint32_t n_loc
     // the attach's launch model gives 176 us per part and 342 us for the unsplit block (two ranks sharing one GPU measured twice that: 338 + 358 against 641 us);
     // with ~220 us of exchange over one xGMI link, max(220, 176) + 176 beats 220 + 342: the two-part form stays the default at every rank count.
     {
-        const char* fe         = std::getenv("SPLAHIP_DIST_FORM");
+        const char* fe         = knob_env("SPLAHIP_DIST_FORM");
         const bool  want_whole = fe && fe[0] == 'w';
         if (want_whole && nnz != 0 && n_local != 0) {
             st = splahip_csr_plan_attach_cob(sh->plan_whole, n_cols_padded, d_Ap, d_Aj_padded, d_Ax, 0, 0, stream);

@@ -114,7 +114,7 @@ namespace splahip {
 
     // SPLAHIP_MXM_TRACE=1: host-side wall time of the phases of one mxm call on stderr (diagnostic)
     struct PhaseTrace {
-        bool                                  on = std::getenv("SPLAHIP_MXM_TRACE") != nullptr;
+        bool                                  on = knob_env("SPLAHIP_MXM_TRACE") != nullptr;
         std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
         void mark(const char* what) {
             if (!on) return;
@@ -827,18 +827,18 @@ namespace splahip {
             SPLAHIP_TRY(hipModuleLaunchKernel(jit_entry, (n_entries + 255u) / 256u, 1, 1, 256, 1, 1, 0, s, args, nullptr));
         }
         // the block merge regroups the products like the tree of the search kernel: same condition.  SPLAHIP_MXMT_MERGE=0: search kernel only
-        const char* merge_env = std::getenv("SPLAHIP_MXMT_MERGE");
+        const char* merge_env = knob_env("SPLAHIP_MXMT_MERGE");
         const bool  merge_form = fold_is_reorderable(op_add, TypeId<T>::value) && !(merge_env && merge_env[0] == '0');
-        const char* heavy_env  = std::getenv("SPLAHIP_MXMT_HEAVY");// len(A row) + len(B row) above which an entry leaves the lane-per-entry merge
+        const char* heavy_env  = knob_env("SPLAHIP_MXMT_HEAVY");// len(A row) + len(B row) above which an entry leaves the lane-per-entry merge
         const uint  heavy_from = heavy_env ? (uint) std::strtoul(heavy_env, nullptr, 10) : kHeavy;
-        const char* factor_env   = std::getenv("SPLAHIP_MXMT_MERGE_FACTOR");// longer row <= factor x shorter row: block merge (default 128; 32 / 128 / all = 13.6 / 13.1 / 13.5 ms on the R-MAT 20 triangle form)
+        const char* factor_env   = knob_env("SPLAHIP_MXMT_MERGE_FACTOR");// longer row <= factor x shorter row: block merge (default 128; 32 / 128 / all = 13.6 / 13.1 / 13.5 ms on the R-MAT 20 triangle form)
         const uint  merge_factor = factor_env ? (uint) std::strtoul(factor_env, nullptr, 10) : 128u;
 
         // the row form (mxmT_row_kernel) regroups and reorders the products: op_add must be associative and commutative.  OPT-IN with
         // SPLAHIP_MXMT_ROW=1: on the R-MAT 20 triangle form it is bit-identical and, so far, no faster than the galloping per-entry kernel
         // (35.5 ms against 33.1 ms per call; rows <= 1023: 18.4 ms, longer rows 11.0 ms — 12 M entries of ~650 streamed words each leave the
         // per-entry fixed costs, one round trip for the matches' value words and an in-order reduction, as large as the stream itself)
-        const char* row_env  = std::getenv("SPLAHIP_MXMT_ROW");
+        const char* row_env  = knob_env("SPLAHIP_MXMT_ROW");
         const bool  row_form = !jit_entry && fold_is_reorderable(op_add, TypeId<T>::value) && binop_is_commutative(op_add) && row_env && row_env[0] == '1';
         DevBuf      cost, cost_before, pieces, piece_first;
         if (row_form) {
@@ -867,7 +867,7 @@ namespace splahip {
         // counts for A and B, so the check runs when they are known anyway: nnz(A) = Ap[n_rows], and B is either the same matrix as A or the mask
         uint count_mode = 0, a_word = 0, b_word = 0;
         {
-            const char* cenv = std::getenv("SPLAHIP_MXMT_COUNT");
+            const char* cenv = knob_env("SPLAHIP_MXMT_COUNT");
             const bool  b_is_a = Bp == Ap && Bx == Ax, b_is_m = Bp == Mp && Bx == Mx;
             if (h_heavy[1] && merge_counts(op_add, TypeId<T>::value) && (b_is_a || b_is_m) && !(cenv && cenv[0] == '0')) {
                 uint   a_nnz = 0;
@@ -1302,7 +1302,7 @@ namespace splahip {
         // entries).  SPLAHIP_MXM_MAX_NNZ lowers the limit (tests).
         u64       total_out = 0;
         const u64 nnz_limit = [] {
-            const char* e = std::getenv("SPLAHIP_MXM_MAX_NNZ");
+            const char* e = knob_env("SPLAHIP_MXM_MAX_NNZ");
             const u64   v = e ? std::strtoull(e, nullptr, 10) : 0;
             return v ? std::min<u64>(v, 0xFFFFFFF0ull) : 0xFFFFFFF0ull;
         }();

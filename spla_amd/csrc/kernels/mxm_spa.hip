@@ -51,7 +51,7 @@ namespace splahip {
         constexpr unsigned kTpb   = 1024;
         constexpr unsigned kLongPart = 128;// products of one (A entry, column block) part from which a wavefront walks the part on its own
         const u64 kLight = [] {// rows with at most this many products go to the ESC form
-            const char* e = std::getenv("SPLAHIP_MXM_LIGHT");
+            const char* e = knob_env("SPLAHIP_MXM_LIGHT");
             return e && *e ? (u64) std::strtoull(e, nullptr, 10) : 4096ull;
         }();
 
@@ -543,7 +543,7 @@ namespace splahip {
         }
 
         uint32_t env_u32(const char* name, uint32_t dflt) {
-            const char* e = std::getenv(name);
+            const char* e = knob_env(name);
             return e && *e ? (uint32_t) std::strtoul(e, nullptr, 10) : dflt;
         }
 
@@ -574,7 +574,7 @@ namespace splahip {
 
         // SPLAHIP_MXM_TRACE=1: the phases of the row-class form on stderr, each closed by a device synchronisation (diagnostic)
         void spa_trace(const char* what, hipStream_t s) {
-            static const bool on = std::getenv("SPLAHIP_MXM_TRACE") != nullptr;
+            static const bool on = knob_env("SPLAHIP_MXM_TRACE") != nullptr;
             if (!on) return;
             static thread_local auto t0 = std::chrono::steady_clock::now();
             const hipError_t         e  = hipStreamSynchronize(s);
@@ -789,7 +789,7 @@ namespace splahip {
                     auto&      dst    = ranked ? rk : bl;
                     dst[0].push_back(items[q].row), dst[1].push_back(items[q].c0), dst[2].push_back(items[q].c1), dst[3].push_back(h_out[q]);
                 }
-                if (std::getenv("SPLAHIP_MXM_TRACE")) {// class sizes (diagnostic)
+                if (knob_env("SPLAHIP_MXM_TRACE")) {// class sizes (diagnostic)
                     u64 re = 0, be = 0, rp = 0, bp = 0, bsteps = 0;
                     for (uint32_t q = 0; q < n_items; ++q) {
                         const bool ranked = d_bblk && h_counts[q] <= cap && !(dense_h && items[q].row < dense_h) && env_u32("SPLAHIP_MXM_RANKED", 1) != 0;

@@ -46,7 +46,7 @@ namespace {
     Variant pick_variant(int type, int op_mult, int op_add, int early_exit) {
         if (early_exit) return Variant::RowSeqEarly;
         {// A/B runs only: SPLAHIP_FORCE_ROWSEQ=1 sends everything to the one-lane-per-row kernel
-            const char* e = std::getenv("SPLAHIP_FORCE_ROWSEQ");
+            const char* e = knob_env("SPLAHIP_FORCE_ROWSEQ");
             if (e && e[0] == '1') return Variant::RowSeq;
         }
         if (!fold_is_reorderable(op_add, type) || !binop_is_commutative(op_add)) return Variant::RowSeq;
@@ -54,7 +54,7 @@ namespace {
     }
 
     bool sell_disabled() {
-        const char* e = std::getenv("SPLAHIP_SELL");
+        const char* e = knob_env("SPLAHIP_SELL");
         return e && e[0] == '0';
     }
 
@@ -312,7 +312,7 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
     // selected rows' entries and one bit per column; every other call is faster over the column-ordered blocks (SPLAHIP_PREFER=cob|sell overrides).
     if (!early_exit && cob_serves_mxv(plan, type, op_mult, op_add, n_cols, stream) && d_r != d_mask && d_r != d_v &&
         ((reinterpret_cast<uintptr_t>(d_r) | reinterpret_cast<uintptr_t>(d_mask)) & 15u) == 0) {// (its row pass moves r and mask 16 bytes at a time)
-        const char* pref     = std::getenv("SPLAHIP_PREFER");
+        const char* pref     = knob_env("SPLAHIP_PREFER");
         const bool  sell_ok  = plan->sell && plan->sell->n_cols == n_cols && !sell_disabled() && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add));
         const bool  use_sell = sell_ok && (pref ? pref[0] == 's' : sell_skip_family(type, op_mult, op_add) == 1);
         if (!use_sell) {

@@ -12,6 +12,32 @@
 
 namespace splahip {
 
+    // cached environment knobs (common.hpp: knob_env)
+    namespace {
+        std::mutex& knob_mutex() {
+            static std::mutex m;
+            return m;
+        }
+        std::unordered_map<std::string, std::pair<bool, std::string>>& knob_map() {
+            static std::unordered_map<std::string, std::pair<bool, std::string>> m;
+            return m;
+        }
+    }// namespace
+    const char* knob_env(const char* name) {
+        std::lock_guard<std::mutex> lock(knob_mutex());
+        auto&                       m  = knob_map();
+        auto                        it = m.find(name);
+        if (it == m.end()) {
+            const char* e = std::getenv(name);
+            it            = m.emplace(name, std::make_pair(e != nullptr, std::string(e ? e : ""))).first;
+        }
+        return it->second.first ? it->second.second.c_str() : nullptr;// (the map's strings live until the next refresh)
+    }
+    void knob_cache_clear() {
+        std::lock_guard<std::mutex> lock(knob_mutex());
+        knob_map().clear();
+    }
+
     std::string& last_error() {
         static thread_local std::string text;
         return text;
@@ -193,6 +219,11 @@ using namespace splahip;
 extern "C" {
 
 int splahip_version(void) { return 100; }
+
+int splahip_env_refresh(void) {
+    splahip::knob_cache_clear();
+    return SPLAHIP_OK;
+}
 
 int splahip_device_count(void) {
     int count = 0;

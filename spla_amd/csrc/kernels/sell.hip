@@ -334,11 +334,11 @@ namespace {
             return (unsigned long long) init_bits + (unsigned long long) g->ax_max <= 0xFFFFFFFFull;
     }
     bool uniform_disabled() {// SPLAHIP_SELL_UNIFORM=0: stream the value words even when they are all equal (diagnostic / A-B)
-        const char* e = std::getenv("SPLAHIP_SELL_UNIFORM");
+        const char* e = knob_env("SPLAHIP_SELL_UNIFORM");
         return e && e[0] == '0';
     }
     int bits_force() {// SPLAHIP_SELL_BITS: 0 = never, 1 / unset = the device statistics decide, 2 = always (where the semiring allows it)
-        const char* e = std::getenv("SPLAHIP_SELL_BITS");
+        const char* e = knob_env("SPLAHIP_SELL_BITS");
         return e ? std::atoi(e) : 1;
     }
 
@@ -512,7 +512,7 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     };
 
     // SPLAHIP_SELL_TRACE=1: host wall time of the build's phases on stderr, each closed by a device synchronisation (diagnostic)
-    static const bool trace = std::getenv("SPLAHIP_SELL_TRACE") != nullptr;
+    static const bool trace = knob_env("SPLAHIP_SELL_TRACE") != nullptr;
     auto              t_last = std::chrono::steady_clock::now();
     auto              mark   = [&](const char* what) {
         if (!trace) return;
@@ -615,7 +615,7 @@ extern "C" int splahip_csr_plan_attach_sell(splahip_plan plan, uint32_t n_cols, 
     if (e == hipSuccess) e = hipMemsetAsync(count, 0, sizeof(uint32_t) * (size_t) n_cols, s);
     if (e != hipSuccess) return bail("hot-column arrays");
     {
-        const char*    se     = std::getenv("SPLAHIP_SELL_COUNT_STRIDE");
+        const char*    se     = knob_env("SPLAHIP_SELL_COUNT_STRIDE");
         const uint32_t stride = nnz >= (1u << 22) ? std::max(1u, se ? (uint32_t) std::strtoul(se, nullptr, 10) : 8u) : 1u;
         const uint32_t n_samples = (nnz + stride - 1) / stride;
         hipLaunchKernelGGL(sell_col_count_kernel, dim3((n_samples + kCountSpan - 1) / kCountSpan), dim3(256), 0, s, d_Aj, nnz, stride, count);

@@ -509,7 +509,7 @@ namespace splahip {
             return fail(SPLAHIP_INVALID_ARGUMENT, "the transposed CSR arrays must be 16-byte aligned");
         const uint grid   = (plan->n_items + Cfg::kWaves - 1) / Cfg::kWaves;
         // every index of v stored + a sliced-ELL copy on the transposed matrix's plan: the value-form kernel in its vxm mode
-        const char* sell_env = std::getenv("SPLAHIP_SELL");
+        const char* sell_env = knob_env("SPLAHIP_SELL");
         // every index of v stored + a column-ordered-blocks copy on the transposed matrix's plan: its kernel in vxm mode
         if (v_is_identity && cob_vxm_serves(plan, TypeId<T>::value, op_add, n_in) &&
             ((reinterpret_cast<uintptr_t>(ws_outv) | reinterpret_cast<uintptr_t>(ws_touched) | reinterpret_cast<uintptr_t>(mask)) & 15u) == 0) {
@@ -644,7 +644,7 @@ namespace splahip {
         return !(type == SPLAHIP_FLOAT && (op_add == SPLAHIP_PLUS || op_add == SPLAHIP_MULT));// fp32 sums / products round by order: sort form
     }
     inline bool push_atomic_disabled() {
-        const char* e = std::getenv("SPLAHIP_PUSH_ATOMIC");// A/B runs and tests: 0 keeps the sort form
+        const char* e = knob_env("SPLAHIP_PUSH_ATOMIC");// A/B runs and tests: 0 keeps the sort form
         return e && e[0] == '0';
     }
 
