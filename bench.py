@@ -448,6 +448,9 @@ def bfs_step_line(args, rank, world):
 
     if not args.no_variants:
         out["variants"] = variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total, nnz_sel_local)
+    for owned in (sx, sx_comm, abi):  # device buffers / the RCCL communicator behind the C ABI
+        if owned is not None and hasattr(owned, "close"):
+            owned.close()
     return out
 
 

@@ -187,7 +187,9 @@ int splahip_shard_create(splahip_shard* shard, int world, int rank, uint32_t n_l
                          const uint32_t* d_Aj_padded, const void* d_Ax, void* stream);
 int splahip_shard_destroy(splahip_shard shard);
 int splahip_shard_info(splahip_shard shard, uint32_t* nnz_local_cols, uint32_t* nnz_remote_cols, int* split_ok);
-int splahip_shard_split_serves(splahip_shard shard, int type, int op_add, int early_exit); /* 1: the two-part (overlapped) form serves this call */
+/* 1: the two-part (overlapped) form serves this call.  splahip_shard_mxv_remote additionally REQUIRES d_r and d_mask to be 16-byte aligned (its row pass moves them
+ * in 16-byte loads) and returns SPLAHIP_INVALID_ARGUMENT before touching r otherwise; splahip_dist_mxv_masked checks and runs the unsplit block for such a call. */
+int splahip_shard_split_serves(splahip_shard shard, int type, int op_add, int early_exit);
 /* 1: splahip_dist_mxv_masked runs the UNSPLIT block for this call — the exchange first, then one product over the block's own column-ordered blocks — although the
  * two-part form could serve it (SPLAHIP_DIST_FORM=whole; measured slower than the two-part form at the sizes tried, so not the default) */
 int splahip_shard_prefers_whole(splahip_shard shard, int type, int op_add);

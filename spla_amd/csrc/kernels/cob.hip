@@ -318,6 +318,13 @@ namespace {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) return (uint32_t) prop.multiProcessorCount;
         return 256;
     }
+    // LDS a workgroup may ask for on this device (the schedules are laid out for gfx950's 160 KB; a device with less is not served: CSR kernels)
+    size_t lds_optin_bytes() {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && v > 0) return (size_t) v;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0) return (size_t) v;
+        return 64 * 1024;
+    }
     uint32_t env_u32(const char* name, uint32_t dflt) {
         const char* e = knob_env(name);
         return e && *e ? (uint32_t) std::strtoul(e, nullptr, 10) : dflt;
@@ -422,6 +429,13 @@ namespace {
             if (nz) atomicOr(&out[2], 1u);
         }
     }
+    // does any value word of the copy read 0x80000000 (-0.0f as fp32)?  Asked once, at attach: the keyed fp32 MIN / MAX form needs to know (cob_float_minmax_ok)
+    __global__ __launch_bounds__(256) void cob_negzero_kernel(size_t n, const uint32_t* __restrict__ x, uint32_t* __restrict__ out) {
+        uint32_t nz = 0;
+        for (size_t k = (size_t) blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t) gridDim.x * 256) nz |= x[k] == 0x80000000u ? 1u : 0u;
+        nz = wave_max(nz);
+        if (lane_id() == 0 && nz) atomicOr(out, 1u);
+    }
     template<typename T>
     int cob_ax_stats(const splahip_cob_s* g, hipStream_t st) {
         if (g->ax_type == TypeId<T>::value) return SPLAHIP_OK;
@@ -432,7 +446,7 @@ namespace {
         uint32_t h[4] = {1, 0, 1, 0};
         SPLAHIP_TRY(hipMemcpyAsync(h, out.p, 16, hipMemcpyDeviceToHost, st));
         SPLAHIP_TRY(hipStreamSynchronize(st));
-        g->ax_bad = h[0], g->ax_max = h[1], g->ax_negzero = h[2], g->ax_type = TypeId<T>::value;
+        g->ax_bad = h[0], g->ax_max = h[1], g->ax_type = TypeId<T>::value;
         return SPLAHIP_OK;
     }
 
@@ -488,29 +502,39 @@ namespace {
         // a range of 16 Ki+ slots plus the spare words is over the 64 KB a kernel gets without asking (cheap; per device, so not cached in a static)
         // a double slice of at most half a CU's LDS: two 8-wave workgroups per CU instead of one 16-wave workgroup (their zeroing, pipeline fill and row
         // passes then run under each other's streams) — the fp32 PLUS forms only
+        // (a launch that fails past this point may leave accumulators or tickets half used: the next call fills them again)
+#define COB_TRY(expr)                                                       \
+    do {                                                                    \
+        const hipError_t cob_e_ = (expr);                                   \
+        if (cob_e_ != hipSuccess) {                                         \
+            g->acc_armed = false;                                           \
+            return fail(SPLAHIP_ERROR, "%s failed: %s", #expr, hipGetErrorString(cob_e_)); \
+        }                                                                   \
+    } while (0)
         bool launched = false;
         if constexpr (W == 1 && MODE == 0) {
             if (g->half_groups) {
                 constexpr unsigned kHalf = 512;
-                SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kHalf, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                COB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kHalf, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kHalf, MODE>), dim3(sc.n_tiles), dim3(kHalf), sc.lds_bytes, st, a,
                                    static_cast<const T*>(v), static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
-                SPLAHIP_TRY(hipGetLastError());
+                COB_TRY(hipGetLastError());
                 launched = true;
             }
         }
         if (!launched) {
-            SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            COB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             hipLaunchKernelGGL((cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), dim3(sc.n_tiles), dim3(kTpb), sc.lds_bytes, st, a,
                                static_cast<const T*>(v), static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
-            SPLAHIP_TRY(hipGetLastError());
+            COB_TRY(hipGetLastError());
         }
         if (g->hub_finish == 1 && g->n_hub_ranges) {
             const uint32_t n_slots = g->n_hub_ranges * g->R;
             hipLaunchKernelGGL((cob_hub_finish_kernel<T, ACC, VXM>), dim3((n_slots + 255) / 256), dim3(256), 0, st, n_slots, g->R, g->acc_stride, g->d_acc, g->d_hub_row, static_cast<const T*>(mask),
                                static_cast<T*>(r), touched, a.accumulate, DynBin(op_add), op_select, init);
-            SPLAHIP_TRY(hipGetLastError());
+            COB_TRY(hipGetLastError());
         }
+#undef COB_TRY
         return SPLAHIP_OK;
     }
 
@@ -592,12 +616,8 @@ namespace {
         return fail(SPLAHIP_NOT_IMPLEMENTED, "the column-ordered-blocks form has no LDS atomic for this op_add");
     }
 
-    // fp32 MIN / MAX over PLUS: served when the copy's values hold no -0.0f (then no product is -0.0f; mxv_cob.hpp: cob_fkey); the value pass
-    // runs once per matrix on the stream of the first such call
-    bool cob_float_minmax_ok(const splahip_cob_s* g, void* stream) {
-        if (cob_ax_stats<float>(g, as_stream(stream)) != SPLAHIP_OK) return false;
-        return g->ax_negzero == 0;
-    }
+    // fp32 MIN / MAX over PLUS: served when the copy's values hold no -0.0f (then no product is -0.0f; mxv_cob.hpp: cob_fkey) — known since the attach
+    bool cob_float_minmax_ok(const splahip_cob_s* g) { return g->ax_negzero == 0; }
 
 }// namespace
 
@@ -621,14 +641,15 @@ namespace splahip {
     }
 
     // the masked SpMV's own question: cob_serves, plus fp32 MIN / MAX over op_mult = PLUS (the reference's fp32 SSSP semiring) when the matrix
-    // holds no -0.0f (one pass over the copy's values on `stream`, the first time it is asked)
+    // holds no -0.0f (the attach looked).  No device work: a query (splahip_mxv_variant_of) may ask too
     bool cob_serves_mxv(const splahip_plan_s* plan, int type, int op_mult, int op_add, uint32_t n_cols, void* stream) {
         if (cob_serves(plan, type, op_add, n_cols)) return true;
         if (!plan || !plan->cob || plan->cob->n_cols != n_cols || cob_disabled()) return false;
         if (type != SPLAHIP_FLOAT || cob_acc_kind_mxv(op_add, op_mult, type) == COB_NONE || plan->cob->sched[0].n_tiles == 0) return false;
         const char* e = knob_env("SPLAHIP_COB_FMINMAX");
         if (e && e[0] == '0') return false;
-        return cob_float_minmax_ok(plan->cob, stream);
+        (void) stream;
+        return cob_float_minmax_ok(plan->cob);
     }
 
     int cob_mxv(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
@@ -824,7 +845,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     g->col_bits = col_bits;
     // the hub ranges' row pass as a kernel of its own behind the main launch (mxv_cob.hpp: cob_hub_finish_kernel).  Measured with it / without: fp32 plus-times
     // R-MAT 22 154 - 156 / 162 - 166 us, R-MAT 23 322 - 330 / 321 - 331 us; int32 min-plus 189 / 195 and 302 / 319 us.  SPLAHIP_COB_HUB_FINISH=0: one launch
-    g->hub_finish  = std::min(2u, env_u32("SPLAHIP_COB_HUB_FINISH", 1));
+    g->hub_finish  = std::min(1u, env_u32("SPLAHIP_COB_HUB_FINISH", 1));
     hipError_t e    = hipSuccess;
     auto       bail = [&](const char* what) {
         cob_release(g);
@@ -1037,6 +1058,11 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
                            chunk_lines);
     e = hipGetLastError();
     if (e != hipSuccess) return bail("scatter");
+    uint32_t* negzero_word = nullptr;
+    e                      = tmp.alloc(&negzero_word, 1);
+    if (e == hipSuccess) e = hipMemsetAsync(negzero_word, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return bail("scratch");
+    hipLaunchKernelGGL(cob_negzero_kernel, dim3(1024), dim3(256), 0, s, (size_t) n_chunks * kCobChunk, g->d_ax, negzero_word);
 
     // 5: the work schedules, on the host (a few hundred pieces).  A piece = consecutive chunks of ONE range (the LDS slice belongs to a range) =
     // one workgroup.  What a chunk costs a CU is its memory requests: 16 lines of the two streams + the distinct lines of v its gathers touch
@@ -1048,8 +1074,11 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     std::vector<uint32_t> h_first((size_t) n_groups + 1), h_lines((size_t) n_chunks + 1);
     e = hipMemcpyAsync(h_first.data(), chunk_first, sizeof(uint32_t) * h_first.size(), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && n_chunks) e = hipMemcpyAsync(h_lines.data(), chunk_lines, sizeof(uint32_t) * n_chunks, hipMemcpyDeviceToHost, s);
+    uint32_t h_negzero = 1;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_negzero, negzero_word, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return bail("schedule");
+    g->ax_negzero = h_negzero;
     std::vector<uint32_t> range_chunk((size_t) n_ranges + 1);
     for (uint32_t q = 0; q <= n_ranges; ++q) range_chunk[q] = h_first[(size_t) q << win_bits];
     // cost of a chunk in units of one stream line's stay in the miss queue: 16 stream lines + its gather lines weighted SPLAHIP_COB_LINE_PCT % (default 40: measured, a cold chunk of ~230 lines walks in ~340 ns, a hub chunk in ~95;
@@ -1066,6 +1095,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     }
     if (e != hipSuccess) return bail("probe words");
     const uint32_t cus = compute_units();
+    const size_t   lds_limit = lds_optin_bytes();
     uint32_t       max_multi = 0;
     for (int w = 0; w < 2 && e == hipSuccess; ++w) {
         splahip_cob_sched_s& sc     = g->sched[w];
@@ -1079,6 +1109,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         const uint32_t       per_cu = (uint32_t) std::min<size_t>(env_u32("SPLAHIP_COB_PER_CU", 1), (160 * 1024) / lds);// 1024-thread workgroups: at most 2 per CU
         if (per_cu == 0) continue;                                                         // this slice width does not fit: not served
         if (per_cu == 1 && 2 * lds <= 160 * 1024) sc.lds_bytes = 160 * 1024 / 2 + 1024;       // (one per CU asked for: ask for LDS a second workgroup cannot share)
+        if (sc.lds_bytes > lds_limit) continue;                                            // a device with less LDS than gfx950: not served (n_tiles stays 0)
         const uint32_t slots = cus * per_cu;
         // piece size in % of a slot's even share of the cost.  Smaller pieces balance the tail better, larger ones mean fewer partial slices to merge,
         // and with pieces of similar cost the COUNT matters: 2.2 x slots pieces run in three rounds.  So the candidates are tried on a model of the launch
@@ -1092,7 +1123,6 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         // (levels = 3; 2/3 + 1/3 for levels = 2): launched dearest first, the rounds end at a, 1.5 a, 1.75 a and the tail is made of small pieces
         const uint32_t taper_mode = env_u32("SPLAHIP_COB_TAPER", 0);
         const uint32_t round_chunks = env_u32("SPLAHIP_COB_ROUND_CHUNKS", 64);// chunks of one round of the kernel's loop: 16 waves x 4 steps
-        const uint32_t fin_slots = std::max(256u, (env_u32("SPLAHIP_COB_FIN_SLOTS", 2560) + 63u) & ~63u);// hub slots per finisher workgroup (in-kernel finishers)
         auto cut = [&](uint32_t share_pct, uint32_t levels) {
             const uint64_t share = std::max<uint64_t>(1, (cost_pre[n_chunks] + slots - 1) / slots * share_pct / 100);
             tiles.clear(), cost.clear();
@@ -1150,9 +1180,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
                 if (hub && g->hub_finish) {// every piece merges, none runs the row pass (cob_hub_finish_kernel): accumulator q belongs to hub range q
                     for (uint32_t t = first_tile; t < first_tile + pieces; ++t) tiles[4 * (size_t) t + 3] = n_multi, cost[t] += 59000;
                     ++n_multi;
-                    // (in-kernel finishers: row0 = the tickets they wait for, row1 = how many of them share the range)
-                    const uint32_t hub_slots = std::min(R, H - q * R);
-                    ranges[4 * (size_t) q + 0] = g->hub_finish == 2 ? pieces : 0u, ranges[4 * (size_t) q + 1] = g->hub_finish == 2 ? (hub_slots + fin_slots - 1) / fin_slots : 0u;
+                    ranges[4 * (size_t) q + 0] = 0u, ranges[4 * (size_t) q + 1] = 0u;
                     ranges[4 * (size_t) q + 2] = q * R, ranges[4 * (size_t) q + 3] = kCobNoLast;
                     continue;
                 }
@@ -1233,18 +1261,12 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         std::vector<uint32_t>       sorted(tiles.size());
         for (uint32_t t = 0; t < n_tiles; ++t)
             for (int k = 0; k < 4; ++k) sorted[4 * t + k] = tiles[4 * order_t[t] + k];
-        uint32_t n_fin = 0;
-        if (g->hub_finish == 2)// the finishers of the hub ranges, behind every piece (mxv_cob.hpp: cob_hub_finisher)
-            for (uint32_t q = 0; q < n_hub_ranges; ++q) {
-                const uint32_t hub_slots = std::min(R, H - q * R);
-                for (uint32_t f0 = 0; f0 < hub_slots; f0 += fin_slots, ++n_fin) sorted.insert(sorted.end(), {q * R + f0, std::min(fin_slots, hub_slots - f0), kCobFinisher, q});
-            }
         if (knob_env("SPLAHIP_COB_TRACE"))
             std::fprintf(stderr, "[cob] schedule %d: R %u / %u, %u hub rows in %u hub ranges + %u natural ranges; slots %u, cost %.1f M (%.1f %% gathers), piece <= %u %% of a share in %u size levels, %u pieces, "
                                  "%u ranges in several pieces, modelled makespan %.1f us (even: %.1f)\n",
                          w, R, Rn, H, n_hub_ranges, n_nat, slots, cost_pre[n_chunks] / 1e8, 100.0 - 100.0 * 1600.0 * n_chunks / std::max<uint64_t>(1, cost_pre[n_chunks]), share_pct, levels, n_tiles, n_multi,
                          makespan() * 95e-3 / 1600, cost_pre[n_chunks] * 95e-3 / 1600 / slots);
-        sc.n_tiles = n_tiles + n_fin;
+        sc.n_tiles = n_tiles;
         sc.n_multi = n_multi;
         max_multi  = std::max(max_multi, n_multi);
         own(&sc.d_tiles, sorted.size());

@@ -429,7 +429,9 @@ int splahip_dist_mxv_masked(splahip_comm c, splahip_shard s, int type, const voi
     hipStream_t cs = as_stream(stream);
     const uint32_t n_cols_all = s->world > 1 ? (uint32_t) s->world * s->max_rows : s->max_rows;
     op_add             = canonical_add(type, op_add, init_bits);// fp32 MIN / MAX from a NaN init: FIRST (ops.hpp) -> the unsplit block
-    const bool     two = splahip_shard_split_serves(s, type, op_add, early_exit) != 0 && !(s->whole_form && cob_serves(s->plan_whole, type, op_add, n_cols_all));
+    // (the remote part's row pass moves r and mask in 16-byte loads: a call whose r / mask is not 16-byte aligned runs the unsplit block, whose kernels take any alignment)
+    const bool aligned = ((reinterpret_cast<uintptr_t>(d_r) | reinterpret_cast<uintptr_t>(d_mask)) & 15u) == 0;
+    const bool     two = aligned && splahip_shard_split_serves(s, type, op_add, early_exit) != 0 && !(s->whole_form && cob_serves(s->plan_whole, type, op_add, n_cols_all));
     if (overlapped) *overlapped = two ? 1 : 0;
     // the exchange starts as soon as the input slice is ready on the compute stream
     SPLAHIP_TRY(hipEventRecord(c->ready, cs));

@@ -57,7 +57,6 @@ namespace splahip {
         uint32_t n_pieces;
     };
     constexpr uint32_t kCobNoLast    = 0xFFFFFFFFu;// CobRange::n_pieces: no piece of this range runs its row pass (cob_hub_finish_kernel does, after the launch)
-    constexpr uint32_t kCobFinisher  = 0xFFFFFFFFu;// CobTile::range: not a piece but a FINISHER of hub range `multi` (cob_hub_finisher): first_chunk / n_chunks = its hub slots
     constexpr uint32_t kCobSlotEmpty = 0xFFFFu;// slot16: the row holds no entry
     constexpr uint32_t kCobSlotHub   = 0xFFFEu;// slot16: the row belongs to a hub range
 
@@ -497,13 +496,9 @@ namespace splahip {
                 const uint32_t w = own_word(i);
                 if (w != cob_identity<T, ACC>()) cob_merge_global<T, ACC>(gacc + i, w);
             }
-            if (rg.n_pieces == kCobNoLast && rg.row1 == 0) return;// (the end of the launch makes the atomics visible to the finishing kernel)
+            if (rg.n_pieces == kCobNoLast) return;// (the end of the launch makes the atomics visible to the finishing kernel)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");// every adding wave: its atomics have been performed
             __syncthreads();
-            if (rg.n_pieces == kCobNoLast) {// finishers wait in this launch for the range's rg.row0 tickets (cob_hub_finisher)
-                if (threadIdx.x == 0) (void) __hip_atomic_fetch_add(ticket + t.multi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
-            }
             uint32_t* const s_flag = reinterpret_cast<uint32_t*>(s_raw + (size_t) (R + kCobSpare) * sizeof(word));
             if (threadIdx.x == 0) *s_flag = __hip_atomic_fetch_add(ticket + t.multi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == rg.n_pieces - 1 ? 1u : 0u;
             __syncthreads();
@@ -588,7 +583,7 @@ namespace splahip {
         cob_row_pass<T, ACC, VXM, TPB, TIGHT>(s_words, rg, slot16, hub_row, touched, n_rows, R, accumulate, mask, r, add, op_select, init);
     }
 
-    // one row of a hub range from its merged accumulator word (cob_hub_finish_kernel and cob_hub_finisher)
+    // one row of a hub range from its merged accumulator word (cob_hub_finish_kernel)
     template<typename T, int ACC, bool VXM>
     __device__ __forceinline__ void cob_hub_row(uint32_t w, uint32_t row, const T* __restrict__ mask, T* __restrict__ r, uint32_t* __restrict__ touched, uint32_t accumulate,
                                                 DynBin add, int op_select, T init) {
@@ -602,46 +597,6 @@ namespace splahip {
             r[row] = sel ? cob_finish<T, ACC>(w, init, add) : init;
     }
 
-    // A FINISHER of a hub range, inside the main launch (SPLAHIP_COB_HUB_FINISH=2): the last workgroups of the grid are not pieces; each waits until every piece of
-    // its hub range has merged and taken its ticket, then finishes a share of the range's rows from the shared accumulator and re-arms it.  Finishers come
-    // last in launch order, so every piece has been dispatched before the first of them gets a CU: they spin only where a CU would idle in the launch's tail
-    // anyway, and what they wait for never waits for them.  The wait is bounded (a few seconds) so that a broken schedule cannot hang the device.
-    template<typename T, int ACC, bool VXM, unsigned TPB>
-    __device__ __noinline__ void cob_hub_finisher(const CobTile t, const CobRange rg, uint32_t R, uint32_t acc_stride, uint32_t* __restrict__ acc, uint32_t* __restrict__ ticket,
-                                                  uint32_t* __restrict__ fin, const uint32_t* __restrict__ hub_row, const T* __restrict__ mask, T* __restrict__ r,
-                                                  uint32_t* __restrict__ touched, uint32_t accumulate, DynBin add, int op_select, T init) {
-        const uint32_t q = t.multi;
-        if (threadIdx.x == 0) {
-            uint32_t polls = 0;
-            while (__hip_atomic_load(ticket + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < rg.row0 && ++polls < (1u << 24)) __builtin_amdgcn_s_sleep(8);
-        }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        constexpr int KF = 4;
-        for (uint32_t base = t.first_chunk + threadIdx.x; base < t.first_chunk + t.n_chunks; base += TPB * KF) {
-            uint32_t w[KF], row[KF];
-#pragma unroll
-            for (int k = 0; k < KF; ++k) {
-                const uint32_t i = base + k * TPB;
-                row[k]           = 0xFFFFFFFFu;
-                if (i < t.first_chunk + t.n_chunks) {
-                    const size_t ia = (size_t) (i / R) * acc_stride + i % R;
-                    w[k]            = __hip_atomic_load(acc + ia, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);// past this CU's L1: the word was built by memory-side atomics
-                    row[k]          = hub_row[i];
-                    acc[ia]         = cob_identity<T, ACC>();// re-armed for the next call (a launch boundary away)
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < KF; ++k)
-                if (row[k] != 0xFFFFFFFFu) cob_hub_row<T, ACC, VXM>(w[k], row[k], mask, r, touched, accumulate, add, op_select, init);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0 && __hip_atomic_fetch_add(fin + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == rg.row1 - 1) {// the range's last finisher
-            __hip_atomic_store(ticket + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(fin + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-
     template<typename T, class Mult, class Add, int ACC, bool VXM, unsigned TPB, int MODE = 0>
     __global__ __launch_bounds__(TPB, (cob_min_waves<T, ACC, MODE>())) void cob_mxv_kernel(CobArgs a, const T* __restrict__ v, const T* __restrict__ mask, T* __restrict__ r, Mult mult,
                                                           Add add, int op_select, T init) {
@@ -651,10 +606,6 @@ namespace splahip {
         word* const        s_acc = reinterpret_cast<word*>(s_raw);
         constexpr unsigned NW    = TPB / kWave;
         const CobTile      t     = a.tiles[blockIdx.x];// one piece per workgroup, launched largest piece first
-        if (t.range == kCobFinisher) {
-            cob_hub_finisher<T, ACC, VXM, TPB>(t, a.ranges[t.multi], a.R, a.acc_stride, a.acc, a.ticket, a.fin, a.hub_row, mask, r, a.touched, a.accumulate, add, op_select, init);
-            return;
-        }
         const bool         nat   = t.range >= a.n_hub_ranges;
         const uint32_t     R     = nat ? a.Rn : a.R;
         // fp32 PLUS over a natural range that holds more slots than a double slice has room for: float words, compare-and-swap adds (COB_FADD)

@@ -65,7 +65,7 @@ struct splahip_cob_s {
     uint32_t  R        = 0;// slots per range (the range's result slice lives in LDS)
     uint32_t  Rn       = 0;// slots of a natural range (>= R; > R: an fp32 sum keeps the natural ranges in float words)
     uint32_t  acc_stride = 0;// words between two shared accumulators: max(R, Rn)
-    uint32_t  hub_finish  = 0;// who finishes the hub ranges' rows: 0 the range's last piece, 1 a kernel of its own behind the main launch, 2 finisher workgroups at the end of the main launch (SPLAHIP_COB_HUB_FINISH)
+    uint32_t  hub_finish  = 0;// who finishes the hub ranges' rows: 0 the range's last piece, 1 a kernel of its own behind the main launch (SPLAHIP_COB_HUB_FINISH)
     uint32_t  ticket_words = 0;// words of d_ticket: arrival counters, then the finishers' counters
     bool      half_groups = false;// two double slices fit a CU's LDS: the fp32 PLUS forms run 8-wave workgroups, two per CU
     uint32_t  col_bits = 0;// a chunk's columns are stored relative to its 2^col_bits-column window

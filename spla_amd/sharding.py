@@ -264,6 +264,19 @@ class SparseExchangeABI:
             _lib.call("splahip_dist_sx_destroy", self._h)
             self._h = None
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):  # the device buffers behind the handle go with the object (interpreter shutdown: the library may be gone already)
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 # ---- the product behind the kernel-level C ABI (spla_amd/csrc/kernels/dist.hip) ------------------------------------------------------------
 def split_columns(blk: RowBlock):
