@@ -216,6 +216,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    if args.workload in ("tc-mxmT", "mxm") and world > 1:  # BASELINE configs[4] by rows of the mask / of A, B whole on every rank
+        import bench_dist
+        line = bench_dist.spgemm_sharded(args, rank, world)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if args.workload == "spmv-fp32":
         import bench_spmv
         line = bench_spmv.run(args, rank, world)
@@ -238,7 +246,7 @@ def main():
         return
     if args.workload != "bfs-step":
         if world != 1:
-            raise SystemExit("this operator workload runs on one GPU (sssp-step, bfs-step and the default spmv-fp32 take --gpus N)")
+            raise SystemExit("this operator workload runs on one GPU (sssp-step, tc-mxmT, mxm, bfs-step and the default spmv-fp32 take --gpus N)")
         import bench_workloads
         print(json.dumps(bench_workloads.WORKLOADS[args.workload](args)), flush=True)
         return

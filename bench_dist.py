@@ -198,3 +198,107 @@ def sssp_step_sharded(args, rank, world):
         line["exchange"]["fallback"] = sp.fallback
     sp.close()
     return line
+
+
+def _lib_trim():
+    """give the SpGEMM's cached scratch back (splahip_mxm_trim)"""
+    from spla_amd import _lib
+    _lib.call("splahip_mxm_trim")
+
+
+def spgemm_sharded(args, rank, world):
+    """BASELINE configs[4] across N GPUs: the triangle-count call mxmT(L, L, L) by rows of the mask, or A x A by rows of A; B whole on every
+    rank, no exchange in the data path (sharding.sharded_mxmT / sharded_mxm).  STRONG scaling: the matrix is fixed, the row blocks balance the merge steps /
+    products.  The only collective is the reduction of one scalar per rank (the triangle count / the result's entry count), outside the timed region."""
+    from oracle import pyoracle
+    from spla_amd import graphgen, kernels, sharding
+    import bench_workloads as bw
+    tc = args.workload == "tc-mxmT"
+    scale = (20 if tc else 18) if args.scale == 22 else args.scale
+    dev = "cpu" if world > 1 and dist.get_backend() == "gloo" else "cuda"
+    if tc:
+        n, Ap, Aj = bw._sym_rmat(scale, args.edge_factor, args.seed)
+        rows = torch.repeat_interleave(torch.arange(n, device="cuda"), (Ap[1:] - Ap[:-1]).to(torch.int64))
+        low = Aj.to(torch.int64) < rows
+        Lp, Lj = graphgen.keys_to_csr(rows[low] * n + Aj[low].to(torch.int64), n, n)
+        del rows, low, Ap, Aj
+        A = (Lp, Lj, torch.ones(int(Lp[-1]), dtype=torch.int32, device="cuda"))
+        cost = sharding.mxmT_row_cost(A[0], A[1], A[0], A[0])
+        t = "INT"
+    else:
+        n, Ap, Aj = graphgen.rmat_csr(scale, args.edge_factor, seed=args.seed, device="cuda")
+        g = torch.Generator(device="cuda")
+        g.manual_seed(args.seed + 9)
+        A = (Ap, Aj, (torch.rand(int(Ap[-1]), generator=g, device="cuda") * 0.5 + 0.25).contiguous())
+        cost = sharding.mxm_row_cost(A[0], A[1], A[0])
+        t = "FLOAT"
+    nnz, work = int(A[0][-1]), int(cost.sum())
+    bounds = sharding.work_splits(cost, world)
+    my_work = int(cost[bounds[rank]:bounds[rank + 1]].sum())
+    if rank == 0:
+        _log(f"[bench] {args.workload} x{world}: R-MAT scale {scale}: n={n} nnz={nnz} work={work}; row blocks {bounds}")
+    out = {}
+
+    def step():
+        if tc:
+            out["R"] = sharding.sharded_mxmT(t, n, A, A, A, "MULT", "PLUS", "GTZERO", 0, world, rank, bounds=bounds)[1]
+        else:
+            out["R"] = sharding.sharded_mxm(t, n, n, A, A, "MULT", "PLUS", 0.0, world, rank, bounds=bounds)[1]
+
+    steps = args.steps if tc else max(1, min(args.steps, 5))
+    wall, per = timed(step, steps, 1 if not tc else args.warmup, world)
+    ms = wall / steps * 1e3
+    Rp, Rj, Rx = out["R"]
+    tally = torch.tensor([int(Rx.to(torch.int64).sum()) if tc else 0, int(Rj.numel()), my_work], dtype=torch.int64, device=dev)
+    shares = [torch.zeros_like(tally) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(shares, tally)
+    else:
+        shares = [tally]
+    total = torch.stack(shares).sum(0)
+    ok = None
+    if not args.no_verify:  # every 64th row of this rank's block against the oracle (mask / A restricted to the sample; B whole)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        srows = torch.arange(lo, hi, 64, device="cuda")
+        Ms = bw._row_sample_csr(A[0], A[1], A[2], srows) if tc else None
+        Ah = tuple(x.cpu().numpy() for x in A)
+        if tc:
+            got = kernels.mxmT_masked(t, n, Ms, A, A, "MULT", "PLUS", "GTZERO", 0)
+            want = pyoracle.Oracle().mxmT_masked(t, n, tuple(x.cpu().numpy() for x in Ms), Ah, Ah, "MULT", "PLUS", "GTZERO", 0)
+            # (the sampled mask keeps the rows' global positions: rows outside the sample are empty) and the block's own rows agree with it
+            ok = all(np.array_equal(np.asarray(a).view(np.uint32), b.cpu().numpy().view(np.uint32)) for a, b in zip(want, got))
+            sel = (srows - lo).to(torch.int64)
+            rp = Rp.to(torch.int64)
+            ok = ok and bool(torch.equal((rp[1:] - rp[:-1])[sel], (got[0].to(torch.int64)[1:] - got[0].to(torch.int64)[:-1])[srows.to(torch.int64)]))
+        else:
+            sub = sharding.CsrRows(A, lo, min(hi, lo + 256))  # the block's first 256 rows
+            want = pyoracle.Oracle().mxm(t, sub.n_rows, n, tuple(x.cpu().numpy() for x in sub.triple), Ah, "MULT", "PLUS", 0.0)
+            e = int(Rp[sub.n_rows])
+            ok = bool(np.array_equal(np.asarray(want[0]).astype(np.int64), Rp[:sub.n_rows + 1].cpu().numpy().astype(np.int64))) and \
+                bool(np.array_equal(np.asarray(want[1]).view(np.uint32), Rj[:e].cpu().numpy().view(np.uint32))) and \
+                bool(np.allclose(np.asarray(want[2]), Rx[:e].cpu().numpy(), rtol=1e-5, atol=0))
+        flag = torch.tensor([1 if ok else 0], device=dev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(int(flag[0]))
+        if not ok:
+            raise SystemExit(f"bench: sharded {args.workload} differs from the oracle")
+    nnz_r = int(total[1])
+    alg = 8 * (3 * nnz + nnz_r) + 16 * (n + 1) if tc else 8 * (2 * nnz + nnz_r) + 12 * (n + 1)
+    gbs = alg / (ms * 1e-3) / 1e9
+    unit = "Gsteps/s" if tc else "Gproducts/s"
+    line = {"metric": "masked SpGEMM (mxmT) G merge-steps/s" if tc else "SpGEMM (mxm) G products/s", "value": round(work / (ms * 1e-3) / 1e9, 3), "unit": unit, "n_gpus": world,
+            "steps": steps, "warmup": args.warmup if tc else 1, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "int32" if tc else "f32", "data": "synthetic",
+            "config": {"workload": (f"exec_mxmT_masked(L, L, L) MULT/PLUS/GTZERO int32 (triangle-count form), L = strict lower triangle of symmetrised R-MAT scale {scale}" if tc else
+                                    f"exec_mxm A x A MULT/PLUS fp32, R-MAT scale {scale}") + f" ef {args.edge_factor}; rows of the mask / of A in {world} work-balanced blocks, B whole on every rank",
+                       "n": n, "nnz": nnz, "work": work, "nnz_R": nnz_r, "row_blocks": bounds, "work_share_per_rank": [int(s[2]) for s in shares],
+                       **({"triangles": int(total[0])} if tc else {})},
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0 * world, "unit": "GB/s", "frac": round(gbs / (8000.0 * world), 4), "traffic": None,
+                         "kernel": "mxmT_entry + mxmT_heavy + compaction" if tc else "mxm_spa row classes", "algorithmic_bytes": int(alg),
+                         "note": "whole-job algorithmic bytes (operands counted once) / the slowest rank's call time, against N x 8 TB/s"},
+            "rank0_call_ms": [round(x, 3) for x in per[:5]]}
+    if ok is not None:
+        line["verified"] = ok
+    _lib_trim()
+    return line

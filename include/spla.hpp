@@ -242,6 +242,9 @@ namespace spla {
         void  set_front_factor(float value) { m_front_factor = value; }
         void  set_early_exit(bool value) { m_early_exit = value; }
         void  set_struct_only(bool value) { m_struct_only = value; }
+        // (an addition of this build) fp32 sums of this call run on the fixed-order kernels: bit-identical from run to run (include/spla_hip.h: splahip_set_deterministic)
+        void  set_deterministic(bool value) { m_deterministic = value; }
+        bool  get_deterministic() const { return m_deterministic; }
         bool  get_push_only() const { return m_mode == TraversalMode::Push; }
         bool  get_pull_only() const { return m_mode == TraversalMode::Pull; }
         bool  get_push_pull() const { return m_mode == TraversalMode::PushPull; }
@@ -260,6 +263,7 @@ namespace spla {
         float         m_front_factor = 0.1f;
         bool          m_early_exit   = false;
         bool          m_struct_only  = false;
+        bool          m_deterministic = false;
     };
 
     // ---- operations -----------------------------------------------------------------------------------------------------

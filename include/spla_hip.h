@@ -59,6 +59,12 @@ const char* splahip_last_error(void);
 int         splahip_version(void);
 /* SPLAHIP_* environment knobs (A/B switches for tests and experiments) are read once and cached; a process that changes one afterwards calls this. */
 int         splahip_env_refresh(void);
+/* Deterministic fp32 sums for the calls the CALLING HOST THREAD makes from now on (on != 0) / back to the default (0); returns the previous setting (not a
+ * status).  Default: an fp32 PLUS fold over the column-ordered blocks (mxv / vxm) or the LDS row classes (mxm) merges partial sums in arrival order — every
+ * result within the stated 1e-5 of the reference's sequential fold, but the last bit may differ from run to run.  Deterministic: those calls run on the
+ * fixed-order kernels (CSR wave-tile / row kernels, the sort form of mxm): two runs are bit-identical, at the CSR kernels' speed.  Integer and MIN / MAX
+ * folds are exact in every form and unaffected.  The operator API sets it per call from Descriptor::set_deterministic (include/spla.hpp). */
+int         splahip_set_deterministic(int on);
 
 int splahip_malloc(void** d_ptr, size_t bytes);
 int splahip_free(void* d_ptr);

@@ -422,6 +422,12 @@ namespace spla {
             SPLA_LOG(Status::NotImplemented, "no algorithm registered for key " << key << acc->get_suffix());
             return Status::NotImplemented;
         }
+        // the call's Descriptor may ask for run-to-run identical fp32 sums: a per-host-thread setting of the kernel library, held for this call only
+        struct DeterministicScope {
+            int before;
+            explicit DeterministicScope(bool on) : before(splahip_set_deterministic(on ? 1 : 0)) {}
+            ~DeterministicScope() { (void) splahip_set_deterministic(before); }
+        } scope(ctx.task->get_desc_or_default()->get_deterministic());
         try {
             return algo->execute(ctx);
         } catch (const std::exception& e) {

@@ -637,6 +637,7 @@ namespace splahip {
         const int acc = cob_acc_kind(op_add, type);
         if (acc == COB_NONE) return false;
         const bool wide = acc == COB_ADD && type == SPLAHIP_FLOAT;// fp32 sums keep a double slice
+        if (wide && deterministic_calls()) return false;            // partial sums meet in arrival order: the fixed-order kernels serve a deterministic call
         return plan->cob->sched[wide ? 1 : 0].n_tiles != 0;
     }
 
@@ -645,7 +646,8 @@ namespace splahip {
     bool cob_serves_mxv(const splahip_plan_s* plan, int type, int op_mult, int op_add, uint32_t n_cols, void* stream) {
         if (cob_serves(plan, type, op_add, n_cols)) return true;
         if (!plan || !plan->cob || plan->cob->n_cols != n_cols || cob_disabled()) return false;
-        if (type != SPLAHIP_FLOAT || cob_acc_kind_mxv(op_add, op_mult, type) == COB_NONE || plan->cob->sched[0].n_tiles == 0) return false;
+        if (type != SPLAHIP_FLOAT || (op_add != SPLAHIP_MIN && op_add != SPLAHIP_MAX) || cob_acc_kind_mxv(op_add, op_mult, type) == COB_NONE || plan->cob->sched[0].n_tiles == 0)
+            return false;
         const char* e = knob_env("SPLAHIP_COB_FMINMAX");
         if (e && e[0] == '0') return false;
         (void) stream;

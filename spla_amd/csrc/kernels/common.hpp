@@ -32,6 +32,10 @@ namespace splahip {
     // An environment knob (SPLAHIP_...: A/B switches and tuning values for tests and experiments), read from the process environment ONCE and cached
     // (runtime.hip): a call's dispatch costs a hash lookup, not a scan of the environment.  splahip_env_refresh() drops the cache (tests change knobs mid-process).
     const char* knob_env(const char* name);
+    // the calling host thread asked for run-to-run identical fp32 sums (splahip_set_deterministic; the Descriptor's deterministic flag): the forms whose
+    // fp32 PLUS merges partial sums in arrival order (column-ordered blocks, the LDS row classes of mxm) stand aside for the fixed-order kernels
+    bool deterministic_calls();
+    int  deterministic_exchange(int on);// returns the previous setting
     void        knob_cache_clear();
 
     // make sure a device has been selected and is a gfx950; returns SPLAHIP_OK or an error status

@@ -1511,7 +1511,9 @@ int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols,
     if (nan_init && (uint64_t) a_rows * b_cols > 0xFFFFFFF0ull)
         return fail(SPLAHIP_NOT_IMPLEMENTED, "a NaN init makes the reference's result dense (%u x %u entries): not representable with 32-bit row pointers", a_rows, b_cols);
     // row classes with LDS accumulators (mxm_spa.hip) for every op_add that has an LDS atomic; -1: not applicable -> the ESC form below
-    rc = nan_init ? -1 : mxm_spa(type, a_rows, b_cols, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, &prod, op_mult, op_add, init_bits, s);
+    // (a deterministic call's fp32 sums: the ESC form folds every output entry's products in (row of A, entry of B) order)
+    const bool fixed_order = deterministic_calls() && type == SPLAHIP_FLOAT && op_add == SPLAHIP_PLUS;
+    rc = nan_init || fixed_order ? -1 : mxm_spa(type, a_rows, b_cols, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, &prod, op_mult, op_add, init_bits, s);
     if (rc != -1) {
         if (h_products) *h_products = prod;
         return rc;

@@ -33,6 +33,15 @@ namespace splahip {
         }
         return it->second.first ? it->second.second.c_str() : nullptr;// (the map's strings live until the next refresh)
     }
+    namespace {
+        thread_local int tl_deterministic = 0;
+    }
+    bool deterministic_calls() { return tl_deterministic != 0; }
+    int  deterministic_exchange(int on) {
+        const int before = tl_deterministic;
+        tl_deterministic = on ? 1 : 0;
+        return before;
+    }
     void knob_cache_clear() {
         std::lock_guard<std::mutex> lock(knob_mutex());
         knob_map().clear();
@@ -219,6 +228,8 @@ using namespace splahip;
 extern "C" {
 
 int splahip_version(void) { return 100; }
+
+int splahip_set_deterministic(int on) { return splahip::deterministic_exchange(on); }
 
 int splahip_env_refresh(void) {
     splahip::knob_cache_clear();

@@ -399,3 +399,120 @@ class Shard:
         if self._h:
             _lib.call("splahip_shard_destroy", self._h)
             self._h = None
+
+
+# ---- SpGEMM across the ranks (mxm by rows of A, mxmT by rows of the mask; B replicated) -------------------------------------------
+# R = A x B and R = mask .* (A x B^T) compute every result row from ONE row of A (and of the mask) and the whole of B (reference
+# src/cpu/cpu_mxm.hpp:85-114, cpu_mxmT_masked.hpp:87-125): rank p takes a contiguous block of rows, keeps B whole, and its result rows are the same
+# words the unsharded call produces — no exchange in the data path.  The blocks balance the WORK (products of mxm, merge steps of mxmT), not the row
+# count.  What the callers do with R decides the only collective: tc() needs one all-reduced scalar; a host that wants the whole R gathers the row
+# blocks (`gather_csr_rows`, for validation and the tests).
+def work_splits(cost: torch.Tensor, parts: int):
+    """parts + 1 row indices that balance a per-row cost (an int64 tensor of n_rows entries)."""
+    n_rows = int(cost.numel())
+    pre = torch.zeros(n_rows + 1, dtype=torch.int64, device=cost.device)
+    if n_rows:
+        pre[1:] = torch.cumsum(cost.to(torch.int64), 0)
+    total = int(pre[-1])
+    targets = torch.tensor([total * p // parts for p in range(1, parts)], dtype=torch.int64, device=cost.device)
+    cuts = torch.searchsorted(pre, targets, right=False).clamp_(0, n_rows)
+    bounds = [0] + [int(x) for x in cuts.tolist()] + [n_rows]
+    for k in range(1, len(bounds)):
+        bounds[k] = max(bounds[k], bounds[k - 1])
+    return bounds
+
+
+def _row_sums(Ap: torch.Tensor, per_entry: torch.Tensor) -> torch.Tensor:
+    """sum of per_entry over every CSR row (int64)"""
+    pre = torch.zeros(per_entry.numel() + 1, dtype=torch.int64, device=per_entry.device)
+    if per_entry.numel():
+        pre[1:] = torch.cumsum(per_entry.to(torch.int64), 0)
+    ap = Ap.to(torch.int64)
+    return pre[ap[1:]] - pre[ap[:-1]]
+
+
+def mxm_row_cost(Ap, Aj, Bp) -> torch.Tensor:
+    """products of every row of A x B: sum over the row's entries (i, k) of the length of B's row k"""
+    deg_b = (Bp[1:] - Bp[:-1]).to(torch.int64)
+    return _row_sums(Ap, deg_b[Aj.to(torch.int64)])
+
+
+def mxmT_row_cost(Mp, Mj, Ap, Bp) -> torch.Tensor:
+    """merge steps of every row of mask .* (A x B^T): per mask entry (i, j) the lengths of A's row i and B's row j"""
+    deg_a = (Ap[1:] - Ap[:-1]).to(torch.int64)
+    deg_b = (Bp[1:] - Bp[:-1]).to(torch.int64)
+    deg_m = (Mp[1:] - Mp[:-1]).to(torch.int64)
+    return _row_sums(Mp, deg_b[Mj.to(torch.int64)]) + deg_a * deg_m
+
+
+class CsrRows:
+    """rows [lo, hi) of a CSR triple as a CSR triple of its own: the row pointers rebased, the column / value arrays VIEWS of the caller's
+    (a row block of a matrix every rank holds; a rank that loads only its rows passes them with lo = 0)"""
+
+    def __init__(self, A, lo: int, hi: int):
+        Ap, Aj, Ax = A
+        s, e = int(Ap[lo]), int(Ap[hi])
+        self.lo, self.hi, self.n_rows, self.nnz = lo, hi, hi - lo, e - s
+        self.Ap = (Ap[lo:hi + 1] - Ap[lo]).contiguous()
+        self.Aj, self.Ax = Aj[s:e], Ax[s:e]
+
+    @property
+    def triple(self):
+        return self.Ap, self.Aj, self.Ax
+
+
+def _hip_mxm(t, a_rows, b_cols, A, B, op_mult, op_add, init):
+    from . import kernels
+    return kernels.mxm(t, a_rows, b_cols, A, B, op_mult, op_add, init)[0]
+
+
+def _hip_mxmT(t, n_rows, M, A, B, op_mult, op_add, op_select, init):
+    from . import kernels
+    return kernels.mxmT_masked(t, n_rows, M, A, B, op_mult, op_add, op_select, init)
+
+
+def sharded_mxm(t, a_rows, b_cols, A, B, op_mult, op_add, init, world: int, rank: int, bounds=None, product=None):
+    """This rank's rows of R = A x B.  A, B: CSR triples every rank holds; returns (bounds, (Rp, Rj, Rx) of rows bounds[rank] .. bounds[rank + 1]).
+    `product` = the local call (default: the HIP kernels through the C ABI; the CPU tests pass the oracle)."""
+    if bounds is None:
+        bounds = work_splits(mxm_row_cost(A[0], A[1], B[0]), world)
+    rows = CsrRows(A, bounds[rank], bounds[rank + 1])
+    return bounds, (product or _hip_mxm)(t, rows.n_rows, b_cols, rows.triple, B, op_mult, op_add, init)
+
+
+def sharded_mxmT(t, n_rows, M, A, B, op_mult, op_add, op_select, init, world: int, rank: int, bounds=None, product=None):
+    """This rank's rows of R = mask .* (A x B^T): the same row block of the mask and of A, B whole."""
+    if bounds is None:
+        bounds = work_splits(mxmT_row_cost(M[0], M[1], A[0], B[0]), world)
+    m, a = CsrRows(M, bounds[rank], bounds[rank + 1]), CsrRows(A, bounds[rank], bounds[rank + 1])
+    return bounds, (product or _hip_mxmT)(t, m.n_rows, m.triple, a.triple, B, op_mult, op_add, op_select, init)
+
+
+def gather_csr_rows(local, bounds, group=None):
+    """every rank's row block (Rp, Rj, Rx) -> the whole CSR on every rank (validation; a host read of a sharded result).  One all-gather of the block sizes,
+    then one padded all-gather per array."""
+    Rp, Rj, Rx = local
+    world = len(bounds) - 1
+    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        return Rp, Rj, Rx
+    dev = Rp.device
+    nnz = torch.tensor([int(Rp[-1])], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, nnz, group=group)
+    sizes = [int(s[0]) for s in sizes]
+    max_nnz, max_rows = max(sizes + [1]), max(bounds[p + 1] - bounds[p] for p in range(world))
+
+    def gather(x, width, dtype):
+        send = torch.zeros(width, dtype=dtype, device=dev)
+        send[:x.numel()] = x
+        recv = [torch.empty(width, dtype=dtype, device=dev) for _ in range(world)]
+        dist.all_gather(recv, send, group=group)
+        return recv
+
+    rp = gather(Rp[1:].to(torch.int64), max_rows, torch.int64)
+    rj, rx = gather(Rj, max_nnz, Rj.dtype), gather(Rx, max_nnz, Rx.dtype)
+    out_p, base = [torch.zeros(1, dtype=torch.int64, device=dev)], 0
+    for p in range(world):
+        out_p.append(rp[p][:bounds[p + 1] - bounds[p]] + base)
+        base += sizes[p]
+    return (torch.cat(out_p).to(Rp.dtype), torch.cat([rj[p][:sizes[p]] for p in range(world)]), torch.cat([rx[p][:sizes[p]] for p in range(world)]))

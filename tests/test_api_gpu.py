@@ -130,3 +130,33 @@ def test_mxv_layout_copies_through_the_api(oracle, monkeypatch):
                 got = np.full(n_rows, 0, dtype=want.dtype)
                 got[ri] = rx
                 assert_same(got, want, t, what=f"{t} {mul}/{add} prepare={prepare} call {call + 1}")  # (entries equal to the fill value 0 are not stored)
+
+
+def test_deterministic_descriptor_gives_bit_identical_fp32_sums(oracle):
+    """Descriptor(deterministic=True) (an addition of this build; include/spla.hpp) sends an fp32 PLUS product to the fixed-order kernels although the
+    matrix is prepared (column-ordered blocks attached): repeated calls are bit-identical, equal to what an unprepared matrix's CSR kernels give, and within
+    1e-5 of the reference's sequential fold like every other form.  The default call on the same matrix stays within 1e-5 too (its last bit may vary)."""
+    api = _api()
+    rng = np.random.default_rng(78)
+    n_rows, n_cols = 6000, 5000
+    Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 14, "FLOAT", skew=True, long_rows=2, long_len=4000)
+    mask_np = random_mask(rng, n_rows, "FLOAT")
+    v_np = random_values(rng, n_cols, "FLOAT", zeros=0.1)
+    want = oracle.mxv_masked("FLOAT", n_rows, n_cols, Ap, Aj, Ax, mask_np, v_np, "MULT", "PLUS", "NQZERO", 0.0)
+    T = api.FLOAT
+
+    def product(M, desc):
+        mask = api.Vector.from_lists(np.arange(n_rows), mask_np, n_rows, T)
+        v = api.Vector.from_lists(np.arange(n_cols), v_np, n_cols, T)
+        return M.mxv(mask, v, T.MULT, T.PLUS, T.NQZERO, init=api.Scalar(T, 0.0), desc=desc).to_dense()
+
+    plain = api.Matrix.from_csr(Ap, Aj, Ax, (n_rows, n_cols), T)  # first call of an unprepared matrix: the CSR kernels
+    base = product(plain, api.Descriptor(deterministic=True))
+    M = api.Matrix.from_csr(Ap, Aj, Ax, (n_rows, n_cols), T)
+    M.set_format(6)  # prepared: the copies are attached before the first product
+    runs = [product(M, api.Descriptor(deterministic=True)) for _ in range(4)]
+    for got in runs:
+        assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), "a deterministic call must not depend on the attached copies or the run"
+        assert_same(got, want, "FLOAT", what="deterministic fp32 MULT/PLUS")
+    assert_same(product(M, None), want, "FLOAT", what="default fp32 MULT/PLUS on the prepared matrix")
+    assert_same(product(M, api.Descriptor()), want, "FLOAT", what="default descriptor after deterministic calls (the setting is per call)")

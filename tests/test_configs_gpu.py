@@ -106,7 +106,10 @@ def test_cfg2_bfs_step_rmat_all_plans_both_early_exit(oracle, ops):
         assert int((want != 0).sum()) == sizes[L - 1]  # the step discovers exactly the next BFS level
 
 
-def _assert_fp32_sum_parity(got, want, exact, min_plain=0.999):
+PARITY_REPORT = []  # (test, rows compared, fraction within the plain 1e-5 bar, worst relative difference): printed in the terminal summary (conftest.py)
+
+
+def _assert_fp32_sum_parity(got, want, exact, min_plain=0.999, what=""):
     """fp32 PLUS folds at full size: the oracle is the reference's sequential fp32 fold, which on a hub row of 10^5 entries is itself ~1e-4 away from the
     sum it approximates, so no reordered fold can agree with it more closely there.  got: HIP, want: oracle, exact: an fp64 fold of the same products
     (float64 arrays).  Every row: |got - want| <= 1e-5 |want| + the oracle's own distance from the fp64 sum; and the plain 1e-5 bar holds on (at least)
@@ -115,6 +118,9 @@ def _assert_fp32_sum_parity(got, want, exact, min_plain=0.999):
     diff = np.abs(got - want)
     assert np.all(diff <= FP32_RTOL * np.abs(want) + 1.01 * np.abs(want - exact) + 1e-30)
     plain = diff <= FP32_RTOL * np.abs(want)
+    worst = float(np.max(diff / np.maximum(np.abs(want), 1e-30))) if len(diff) else 0.0
+    PARITY_REPORT.append((what, int(len(diff)), float(plain.mean()), worst))
+    print(f"[fp32 parity] {what}: {len(diff)} rows against the reference's sequential fold; within plain 1e-5: {plain.mean():.6f}; worst relative difference {worst:.3e}")
     assert plain.mean() >= min_plain, plain.mean()
 
 
@@ -433,7 +439,7 @@ def test_north_star_full_size_scale23_fp32_column_ordered_blocks(oracle):
     exact = _fp64_fold(Ap, Aj, Ax, v)
     rel = ((r.to(torch.float64) - exact).abs() / exact.abs().clamp_min(1e-30)).max().item()
     assert rel < 2e-6, rel  # one rounding per row and piece on top of an exact double sum
-    _assert_fp32_sum_parity(r[rows_idx].cpu().numpy(), want, exact[rows_idx].cpu().numpy())
+    _assert_fp32_sum_parity(r[rows_idx].cpu().numpy(), want, exact[rows_idx].cpu().numpy(), what="configs[1] fp32 plus-times, R-MAT 23, every 256th row")
     assert int((r[(Ap[1:] == Ap[:-1])] != 0).sum()) == 0  # rows without an entry: init
     r2 = torch.empty_like(r)
     kernels.mxv_masked(plan, "FLOAT", n, Ap, Aj, Ax, mask, v, r2, "MULT", "PLUS", "ALWAYS", 0.0)
@@ -475,6 +481,8 @@ def test_cfg3_full_size_pagerank_pull_column_ordered_blocks(oracle):
     want = _sampled_rows_oracle(oracle, "FLOAT", Tp, Tj, Tx, rows_idx, n, mask, vx, "MULT", "PLUS", "ALWAYS", 0.0)  # x * v == v * x in fp32
     exact = _fp64_fold(Tp, Tj, Tx, vx)
     assert float(((dense.to(torch.float64) - exact).abs() / exact.abs().clamp_min(1e-30)).max()) < 2e-6
-    # (PageRank products are tiny and of mixed magnitude: the reference's sequential fold strays from the sum on many more rows than with U(0, 1) values)
-    _assert_fp32_sum_parity(dense[rows_idx].cpu().numpy(), want, exact[rows_idx].cpu().numpy(), min_plain=0.5)
+    # (PageRank products are tiny and of mixed magnitude: the reference's sequential fold strays from the sum on more rows than with U(0, 1) values —
+    # measured on this input: 99.35 % of the sampled outputs within plain 1e-5, the worst 1.8e-4 away, all of them inside the reference's own distance
+    # from the fp64 sum)
+    _assert_fp32_sum_parity(dense[rows_idx].cpu().numpy(), want, exact[rows_idx].cpu().numpy(), min_plain=0.98, what="configs[2] PageRank pull step, every 256th output")
     plan_T.close()

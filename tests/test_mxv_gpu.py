@@ -705,3 +705,39 @@ def test_hot_column_relabelling(oracle, t, monkeypatch):
     else:
         assert np.array_equal(host(rx, NP[t]).view(np.uint32), want[1].view(np.uint32))
     planT.close()
+
+
+def test_deterministic_setting_at_the_kernel_abi(oracle):
+    """splahip_set_deterministic (include/spla_hip.h): per host thread; an fp32 PLUS call then leaves the column-ordered blocks for the CSR kernels (the variant
+    query says so), twice bit-identical; MIN / MAX (exact in every form) and integer calls keep the blocks; the previous setting is returned."""
+    import torch
+    from gpu_utils import dev, host
+    from spla_amd import _lib, kernels
+    rng = np.random.default_rng(4242)
+    n_rows, n_cols = 9000, 7000
+    Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 10, "FLOAT", skew=True, long_rows=2, long_len=5000)
+    mask = random_mask(rng, n_rows, "FLOAT")
+    v = random_values(rng, n_cols, "FLOAT", zeros=0.2)
+    dAp, dAj, dAx, dm, dv = dev(Ap), dev(Aj), dev(Ax), dev(mask), dev(v)
+    plan = kernels.CsrPlan(n_rows, len(Aj), dAp)
+    assert plan.attach_cob(n_cols, dAp, dAj, dAx) is not None
+    bare = kernels.CsrPlan(n_rows, len(Aj), dAp)
+    assert _lib.call("splahip_set_deterministic", 1) == 0
+    try:
+        assert "mxv_cob" not in kernels.mxv_variant("FLOAT", "MULT", "PLUS", False, plan)
+        assert "mxv_cob" in kernels.mxv_variant("FLOAT", "PLUS", "MIN", False, plan)
+        assert "mxv_cob" in kernels.mxv_variant("INT", "MULT", "PLUS", False, plan)
+        outs = []
+        for p in (plan, plan, bare):
+            r = torch.full((n_rows,), -3.0, dtype=torch.float32, device="cuda")
+            kernels.mxv_masked(p, "FLOAT", n_cols, dAp, dAj, dAx, dm, dv, r, "MULT", "PLUS", "EQZERO", 0.5)
+            torch.cuda.synchronize()
+            outs.append(host(r, np.float32))
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)) and np.array_equal(outs[0].view(np.uint32), outs[2].view(np.uint32))
+        want = oracle.mxv_masked("FLOAT", n_rows, n_cols, Ap, Aj, Ax, mask, v, "MULT", "PLUS", "EQZERO", 0.5)
+        assert_same(outs[0], want, "FLOAT", what="deterministic fp32 MULT/PLUS")
+    finally:
+        assert _lib.call("splahip_set_deterministic", 0) == 1
+    assert "mxv_cob" in kernels.mxv_variant("FLOAT", "MULT", "PLUS", False, plan)
+    plan.close()
+    bare.close()

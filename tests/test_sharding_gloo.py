@@ -154,3 +154,79 @@ def test_owner_sorted_permutation():
     _, Ap1, Aj1 = graphgen.rmat_csr(10, 8, seed=4, device="cpu", permute="owner-sorted", owners=4)
     assert int(Ap0[-1]) == int(Ap1[-1])
     assert sorted((Ap0[1:] - Ap0[:-1]).tolist()) == sorted((Ap1[1:] - Ap1[:-1]).tolist())
+
+
+def _spgemm_worker(rank, world, port, out_dir):
+    """mxm by rows of A and mxmT by rows of the mask, B whole on every rank: the gathered row blocks are the unsharded result word for word.
+    The local products are the oracle's here (the checker; this container has no GPU) — tests/test_shard_gpu.py runs the same driver on the HIP kernels."""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle
+    from spla_amd import graphgen, sharding
+    orc = pyoracle.Oracle()
+
+    def as_t(triple):
+        return tuple(torch.from_numpy(np.ascontiguousarray(x).view(np.int32) if x.dtype == np.uint32 else np.ascontiguousarray(x)) for x in triple)
+
+    def o_mxm(t, a_rows, b_cols, A, B, op_mult, op_add, init):
+        return as_t(orc.mxm(t, a_rows, b_cols, tuple(x.numpy() for x in A), tuple(x.numpy() for x in B), op_mult, op_add, init))
+
+    def o_mxmT(t, n_rows, M, A, B, op_mult, op_add, op_select, init):
+        return as_t(orc.mxmT_masked(t, n_rows, tuple(x.numpy() for x in M), tuple(x.numpy() for x in A), tuple(x.numpy() for x in B), op_mult, op_add, op_select, init))
+
+    n, Ap, Aj = graphgen.rmat_csr(9, 8, seed=11, device="cpu")
+    g = torch.Generator().manual_seed(12)
+    for t, dt in (("INT", torch.int32), ("FLOAT", torch.float32)):
+        Ax = torch.randint(1, 9, (int(Ap[-1]),), generator=g, dtype=torch.int32).to(dt)
+        A = (Ap, Aj, Ax)
+        # mxm: the blocks balance the products; every rank's rows equal the same rows of the whole product
+        want = o_mxm(t, n, n, A, A, "MULT", "PLUS", 0)
+        bounds, local = sharding.sharded_mxm(t, n, n, A, A, "MULT", "PLUS", 0, world, rank, product=o_mxm)
+        cost = sharding.mxm_row_cost(Ap, Aj, Ap)
+        share = [int(cost[bounds[p]:bounds[p + 1]].sum()) for p in range(world)]
+        assert bounds[0] == 0 and bounds[-1] == n and max(share) <= int(cost.sum()) // world + int(cost.max())
+        got = sharding.gather_csr_rows(local, bounds)
+        for a, b in zip(got, want):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (t, "mxm", world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        assert torch.equal(local[0].to(torch.int64), want[0][lo:hi + 1].to(torch.int64) - int(want[0][lo]))
+        # mxmT: the strictly lower triangle L as mask, A and B (the triangle-count call, reference src/algorithm.cpp:380-414), and a general mask
+        rows = torch.repeat_interleave(torch.arange(n), (Ap[1:] - Ap[:-1]).to(torch.int64))
+        keep = Aj.to(torch.int64) < rows
+        Lp = torch.zeros(n + 1, dtype=torch.int32)
+        Lp[1:] = torch.cumsum(torch.bincount(rows[keep], minlength=n), 0).to(torch.int32)
+        L = (Lp, Aj[keep].contiguous(), Ax[keep].contiguous())
+        for (M, X, Y, sel) in ((L, L, L, "NQZERO"), (A, L, A, "GTZERO")):
+            want = o_mxmT(t, n, M, X, Y, "MULT", "PLUS", sel, 0)
+            bounds, local = sharding.sharded_mxmT(t, n, M, X, Y, "MULT", "PLUS", sel, 0, world, rank, product=o_mxmT)
+            got = sharding.gather_csr_rows(local, bounds)
+            for a, b in zip(got, want):
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (t, "mxmT", sel, world)
+            # the triangle count is one all-reduced scalar of the local sums (no gather of R in the data path)
+            if M is L and t == "INT":
+                part = torch.tensor([int(local[2].to(torch.int64).sum())])
+                dist.all_reduce(part)
+                assert int(part[0]) == int(want[2].to(torch.int64).sum())
+    # empty blocks (more ranks than rows with work): a 3-row matrix whose only entries sit in row 1
+    Ep = torch.tensor([0, 0, 2, 2], dtype=torch.int32)
+    Ej = torch.tensor([0, 2], dtype=torch.int32)
+    Ex = torch.tensor([3, 4], dtype=torch.int32)
+    E = (Ep, Ej, Ex)
+    want = o_mxm("INT", 3, 3, E, E, "MULT", "PLUS", 0)
+    bounds, local = sharding.sharded_mxm("INT", 3, 3, E, E, "MULT", "PLUS", 0, world, rank, product=o_mxm)
+    got = sharding.gather_csr_rows(local, bounds)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    Path(out_dir, f"ok{rank}").write_text("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_spgemm_gloo(tmp_path, world):
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_spgemm_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
