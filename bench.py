@@ -406,12 +406,14 @@ def bfs_step_line(args, rank, world):
 
     # HBM-side traffic of the same kernel from the rocprofv3 PMC passes (tools/gpu_round.sh -> tools/pmc_traffic.py):
     # collected by a separate profiler run of this command, so it is read from profiles/ when it matches this workload
-    tf = ROOT / "profiles" / "pmc_traffic.json"
+    tf = ROOT / "profiles" / "r04_pmc_traffic.json"
+    if not tf.exists():
+        tf = ROOT / "profiles" / "pmc_traffic.json"  # (round 2's pass)
     if world == 1 and tf.exists():
         t = json.loads(tf.read_text())
         if t.get("config", {}).get("nnz_selected") == nnz_sel_total and t.get("config", {}).get("nnz") == g["nnz_global"]:
             roofline["traffic"] = t["traffic_bytes"]
-            roofline["traffic_source"] = "profiles/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate rocprofv3 --pmc passes"
+            roofline["traffic_source"] = f"profiles/{tf.name}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate rocprofv3 --pmc passes"
 
     out = {
         "metric": "masked SpMV GTEPS", "value": round(gteps, 3), "unit": "GTEPS", "n_gpus": world,

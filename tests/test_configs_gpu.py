@@ -451,6 +451,28 @@ def test_north_star_full_size_scale23_fp32_column_ordered_blocks(oracle):
     assert bool(torch.all(r3[m2 == 0] == 7.5))
     sel = m2 != 0
     assert float((((r3[sel] - 7.5) - r[sel]).abs() / r[sel].abs().clamp_min(1.0)).max()) < 1e-5
+    # the bench's masked variants at full size (reference src/cpu/cpu_mxv.hpp:89-92: an unselected row is init and its entries are never read): NQZERO masks
+    # selecting 10 % / 50 % of the rows at random and 10 % / 50 % of the rows below hub degree; each call twice (the second runs the side its own probe
+    # favours: the selected-rows kernels or the blocks), every 256th row against the oracle, unselected rows == init exactly
+    deg = (Ap[1:] - Ap[:-1]).to(torch.int64)
+    served = {}
+    for name, frac, light in (("10 % random", 0.1, False), ("50 % random", 0.5, False), ("10 % no hub row", 0.1, True), ("50 % no hub row", 0.5, True)):
+        pick = torch.rand(n, generator=gen, device="cuda") < frac
+        if light:
+            pick &= deg < 31
+        m = pick.to(torch.float32)
+        rm = torch.empty_like(r)
+        for _ in range(2):
+            rm.fill_(-2.0)
+            kernels.mxv_masked(plan, "FLOAT", n, Ap, Aj, Ax, m, v, rm, "MULT", "PLUS", "NQZERO", 0.25)
+            torch.cuda.synchronize()
+        served[name] = plan.mask_probe()["served_by_rows"]
+        assert bool(torch.all(rm[~pick] == 0.25)), name
+        rows_m = torch.arange(0, n, 256, device="cuda")
+        want_m = _sampled_rows_oracle(oracle, "FLOAT", Ap, Aj, Ax, rows_m, n, m, v, "MULT", "PLUS", "NQZERO", 0.25)
+        exact_m = torch.where(pick, exact + 0.25, torch.full_like(exact, 0.25))
+        _assert_fp32_sum_parity(rm[rows_m].cpu().numpy(), want_m, exact_m[rows_m].cpu().numpy(), what=f"configs[1] masked, {name} (served by {'rows' if served[name] else 'blocks'})")
+    assert served["10 % no hub row"] and not served["50 % random"], served
     plan.close()
 
 

@@ -1,0 +1,45 @@
+#!/bin/bash
+# round 4: counter passes (separate rocprofv3 --pmc runs) of the SSSP step of configs[3] and of the PageRank pull step on the round-4 layout of the blocks
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp; export TMPDIR=/tmp; mkdir -p "$R/gpurun_out"
+run() { # name, reference kernel, other kernels (|-separated), command...
+  name=$1; ref=$2; others=$3; shift 3
+  rm -rf "$R/gpurun_out/pmc_r04/$name"
+  for c in FETCH_SIZE WRITE_SIZE TCP_TCC_READ_REQ; do
+    timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_r04/$name/$c" -- "$@" > /dev/null 2> "$R/gpurun_out/pmc_r04_${name}_$c.err"; echo "$name $c exit $?"
+  done
+  IFS='|' read -ra N <<< "$ref|$others"
+  python3 "$R/tools/pmc_kernels.py" "$R/gpurun_out/pmc_r04/$name" "${N[@]}" > "$R/gpurun_out/r04_pmc_$name.raw.json"
+  python3 - "$R/gpurun_out/r04_pmc_$name.raw.json" "$R/gpurun_out/r04_pmc_$name.json" "$ref" <<'PY'
+import json, sys
+raw = json.load(open(sys.argv[1])); ref = sys.argv[3]
+calls = raw[ref]["FETCH_SIZE"]["dispatches"]
+tot = 0.0
+for k, cs in raw.items():
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        tot += (2 * cs["FETCH_SIZE"]["median"] + cs["WRITE_SIZE"]["median"]) * 1024 * cs["FETCH_SIZE"]["dispatches"] / calls
+req = sum(cs["TCP_TCC_READ_REQ"]["median"] * cs["TCP_TCC_READ_REQ"]["dispatches"] / calls for cs in raw.values() if "TCP_TCC_READ_REQ" in cs)
+out = dict(raw)
+out["_per_call"] = {"calls_in_pass": calls, "reference_kernel": ref, "traffic_bytes": round(tot), "tcp_tcc_read_req": round(req),
+                    "how": "sum over the listed kernels of (median per dispatch) x (dispatches / calls); (2*FETCH_SIZE + WRITE_SIZE) KB * 1024"}
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print(json.dumps(out["_per_call"]))
+PY
+  find "$R/gpurun_out/pmc_r04/$name" -name "*.csv" -size +1M -delete
+}
+run sssp_step "cob_mxv_kernel<int" "cob_hub_finish_kernel<int|cob_vbits_kernel<int" python3 "$R/bench.py" --workload sssp-step --steps 5 --warmup 2 --no-cpu-baseline --no-verify
+run pagerank_vxm_orkut_like "cob_mxv_kernel<float" "cob_hub_finish_kernel<float|flag_write_kernel" python3 "$R/bench.py" --workload pagerank-vxm --steps 5 --warmup 2 --no-cpu-baseline --no-verify
+# the BFS step of configs[1] (profiles/pmc_traffic.json was round 2's pass): the three kernels of the sliced-ELL bit form
+run bfs_step "sell_mxv_dual_kernel<int" "sell_vprep_kernel<int|sell_post_kernel<int" python3 "$R/bench.py" --workload bfs-step --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-variants
+python3 - "$R/gpurun_out/r04_pmc_bfs_step.json" "$R/gpurun_out/r04_pmc_traffic.json" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1])); pc = d["_per_call"]
+n, nnz, nnz_sel = 4194304, 65244781, 28570647
+alg = 4 * nnz_sel + 4 * (n + 1) + 4 * n + 4 * n + 4 * n
+out = {"kernel": "sell_vprep_kernel<int>|sell_mxv_dual_kernel<int>|sell_post_kernel<int>", "traffic_bytes": pc["traffic_bytes"], "algorithmic_bytes": alg,
+       "traffic_over_algorithmic": round(pc["traffic_bytes"] / alg, 3), "tcp_tcc_read_req": pc["tcp_tcc_read_req"], "config": {"n": n, "nnz": nnz, "nnz_selected": nnz_sel},
+       "method": "round 4: tools/gpu_pmc_r04_ops.sh - rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCP_TCC_READ_REQ in separate passes (with --kernel-trace only) of `python3 bench.py --workload bfs-step --steps 10 "
+                 "--warmup 2 --no-cpu-baseline --no-verify --no-variants`; per-kernel medians by tools/pmc_kernels.py (profiles/r04_pmc_bfs_step.json); traffic = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024",
+       "per_kernel": {k: v for k, v in d.items() if not k.startswith("_")}}
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print(json.dumps({k: out[k] for k in ("traffic_bytes", "algorithmic_bytes", "traffic_over_algorithmic")}))
+PY
