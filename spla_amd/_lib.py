@@ -32,6 +32,7 @@ _SIGNATURES = {
     "splahip_last_error": (C.c_char_p, []),
     "splahip_version": (C.c_int, []),
     "splahip_env_refresh": (C.c_int, []),
+    "splahip_csr_plan_first_hit": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "splahip_set_deterministic": (C.c_int, [C.c_int]),
     "splahip_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "splahip_free": (C.c_int, [_vp]),

@@ -15,6 +15,7 @@
 // the reference's early-exit rule.  Exact for non-associative / non-commutative op_add.
 #include "block_utils.hpp"
 #include "common.hpp"
+#include "mxv_first_hit.hpp"
 #include "mxv_kernels.hpp"
 #include "mxv_rows.hpp"
 #include "ops.hpp"
@@ -88,6 +89,80 @@ namespace {
                            n_rows, Ap, Aj, static_cast<const uint32_t*>(Ax), static_cast<const T*>(mask),
                            static_cast<const T*>(v), static_cast<T*>(r), DynBin(op_mult), DynBin(op_add), op_select,
                            from_bits<T>(init_bits));
+        SPLAHIP_TRY(hipGetLastError());
+        return SPLAHIP_OK;
+    }
+
+    // ---- BFS-like calls over a structure-only matrix: a row stops at its first hit (mxv_first_hit.hpp) -------------------------------------------------
+    // the semirings: 0 annihilates op_mult and is op_add's identity (sell_skip_family == 1) and op_add is idempotent (PLUS and BXOR count, they do not qualify)
+    bool first_hit_family(int type, int op_mult, int op_add) {
+        return sell_skip_family(type, op_mult, op_add) == 1 && (op_add == SPLAHIP_BOR || op_add == SPLAHIP_MAX);
+    }
+    // every stored value of the matrix is one word: known from the attach pass of a layout copy (the plan alone does not own the caller's value array)
+    bool uniform_values(const splahip_plan_s* plan, uint32_t n_cols, uint32_t* xbits) {
+        if (plan->sell && plan->sell->n_cols == n_cols && plan->sell->x_uniform) return *xbits = plan->sell->x_bits, true;
+        if (plan->cob && plan->cob->n_cols == n_cols && plan->cob->x_uniform) return *xbits = plan->cob->x_bits, true;
+        return false;
+    }
+    uint32_t knob_u32(const char* name, uint32_t dflt) {
+        const char* e = knob_env(name);
+        return e && *e ? (uint32_t) std::strtoul(e, nullptr, 10) : dflt;
+    }
+    int first_hit_prepare(splahip_plan plan, uint32_t n_cols) {
+        if (plan->d_fh_ctl && plan->fh_cols == n_cols) return SPLAHIP_OK;
+        if (plan->d_fh_ctl) return SPLAHIP_ERROR;// (a plan serves one matrix: one column count)
+        const size_t bit_words = ((size_t) n_cols + 2047u) / 2048u * 64u;
+        SPLAHIP_TRY(device_malloc(reinterpret_cast<void**>(&plan->d_fh_bits), sizeof(uint32_t) * bit_words));
+        SPLAHIP_TRY(device_malloc(reinterpret_cast<void**>(&plan->d_fh_ctl), sizeof(uint32_t) * (8 + 8 * (size_t) kVstatBlocks)));
+        SPLAHIP_TRY(hipMemset(plan->d_fh_ctl, 0, sizeof(uint32_t) * (8 + 8 * (size_t) kVstatBlocks)));
+        SPLAHIP_TRY(hipHostMalloc(reinterpret_cast<void**>(const_cast<uint32_t**>(&plan->h_fh)), 8 * sizeof(uint32_t), hipHostMallocMapped));
+        for (int k = 0; k < 8; ++k) plan->h_fh[k] = 0;
+        SPLAHIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&plan->d_h_fh), const_cast<uint32_t*>(plan->h_fh), 0));
+        plan->fh_cols = n_cols;
+        return SPLAHIP_OK;
+    }
+    // Enqueue the pass over v (bitmap, uniformity, a sampled estimate of the walk's cost; its verdict also lands in pinned host memory) and say whether THIS call
+    // runs on the first-hit kernel: when the latest finished pass — of an earlier call — saw a frontier (one non-zero word) AND a walk that mostly ends within a
+    // row's first entries: the sampled rows that would be walked past their fourth entry hold at most SPLAHIP_FIRST_HIT_TAIL_PCT % (15) of the sampled selected
+    // entries.  (R-MAT 22: the level of a traversal that reaches the most vertices 62 us against 92 on the sliced-ELL copy; a random 2 % of the columns as
+    // frontier 211 against 62 — profiles/r04_first_hit_sweep.txt: most rows never hit, and scanning whole CSR rows a lane each is what the layout copies do
+    // better.)  The kernel is correct for any vector and mask (it sees this call's own verdict), so a stale hint only costs time; a traversal's levels differ,
+    // so the hint pays for repeated or slowly changing steps.  A plan whose calls keep not qualifying is probed every 16th call.
+    template<typename T>
+    int first_hit_probe(splahip_plan plan, uint32_t n_cols, const uint32_t* Ap, const uint32_t* Aj, const void* mask, int op_select, const void* v, hipStream_t st,
+                        bool* take) {
+        *take = false;
+        if (knob_u32("SPLAHIP_FIRST_HIT", 1) == 0 || n_cols == 0) return SPLAHIP_OK;
+        int rc = first_hit_prepare(plan, n_cols);
+        if (rc != SPLAHIP_OK) return SPLAHIP_OK;// (no workspace: the other forms serve the call)
+        const uint32_t pct = knob_u32("SPLAHIP_FIRST_HIT_TAIL_PCT", 15);
+        *take = plan->h_fh[3] != 0u && plan->h_fh[0] != 0u && plan->h_fh[2] != 0u && plan->h_fh[4] != 0u && (uint64_t) plan->h_fh[5] * 100u <= (uint64_t) plan->h_fh[4] * pct;
+        if (!*take) {
+            plan->fh_misses += 1;
+            if (plan->fh_misses > 4 && (plan->fh_misses & 15u) != 0u) return SPLAHIP_OK;
+        } else
+            plan->fh_misses = 0;
+        plan->fh_seq = plan->fh_seq + 1 ? plan->fh_seq + 1 : 1;
+        hipLaunchKernelGGL((vstat_kernel<T>), dim3(kVstatBlocks), dim3(kVstatTpb), 0, st, n_cols, static_cast<const T*>(v), plan->d_fh_bits, plan->d_fh_ctl + 8, plan->d_fh_ctl + 4,
+                           plan->d_fh_ctl, plan->d_h_fh, plan->fh_seq, plan->n_rows, Ap, Aj, static_cast<const T*>(mask), op_select);
+        SPLAHIP_TRY(hipGetLastError());
+        return SPLAHIP_OK;
+    }
+    template<typename T>
+    int launch_first_hit(splahip_plan plan, uint32_t n_rows, const uint32_t* Ap, const uint32_t* Aj, const void* mask, const void* v, void* r, int op_mult, int op_add,
+                         int op_select, uint32_t init_bits, uint32_t xbits, hipStream_t st) {
+        const dim3 grid((n_rows + 255) / 256);
+        if constexpr (!std::is_same<T, float>::value) {
+            if (op_mult == SPLAHIP_BAND && op_add == SPLAHIP_BOR) {
+                hipLaunchKernelGGL((mxv_first_hit_kernel<T, StaBin<SPLAHIP_BAND>, StaBin<SPLAHIP_BOR>>), grid, dim3(256), 0, st, n_rows, Ap, Aj, static_cast<const T*>(mask),
+                                   static_cast<const T*>(v), static_cast<T*>(r), StaBin<SPLAHIP_BAND>(), StaBin<SPLAHIP_BOR>(), op_select, from_bits<T>(init_bits), xbits,
+                                   plan->d_fh_ctl, plan->d_fh_bits);
+                SPLAHIP_TRY(hipGetLastError());
+                return SPLAHIP_OK;
+            }
+        }
+        hipLaunchKernelGGL((mxv_first_hit_kernel<T, DynBin, DynBin>), grid, dim3(256), 0, st, n_rows, Ap, Aj, static_cast<const T*>(mask), static_cast<const T*>(v),
+                           static_cast<T*>(r), DynBin(op_mult), DynBin(op_add), op_select, from_bits<T>(init_bits), xbits, plan->d_fh_ctl, plan->d_fh_bits);
         SPLAHIP_TRY(hipGetLastError());
         return SPLAHIP_OK;
     }
@@ -179,6 +254,9 @@ namespace {
 
     void plan_release(splahip_plan plan) {
         if (!plan) return;
+        if (plan->h_fh) (void) hipHostFree(const_cast<uint32_t*>(plan->h_fh));
+        if (plan->d_fh_bits) (void) hipFree(plan->d_fh_bits);
+        if (plan->d_fh_ctl) (void) hipFree(plan->d_fh_ctl);
         if (plan->d_rows_list) (void) hipFree(plan->d_rows_list);
         if (plan->d_rows_ctl) (void) hipFree(plan->d_rows_ctl);
         if (plan->d_long_items) (void) hipFree(plan->d_long_items);
@@ -258,6 +336,15 @@ int splahip_csr_plan_destroy(splahip_plan plan) {
     return SPLAHIP_OK;
 }
 
+int splahip_csr_plan_first_hit(splahip_plan plan, int* taken, int* uniform, uint32_t* nonzeros, uint32_t* tail_pct) {
+    SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
+    if (taken) *taken = plan->fh_taken;
+    if (uniform) *uniform = plan->h_fh && plan->h_fh[3] != 0u ? (int) plan->h_fh[0] : -1;
+    if (nonzeros) *nonzeros = plan->h_fh ? plan->h_fh[2] : 0u;
+    if (tail_pct) *tail_pct = plan->h_fh && plan->h_fh[4] ? (uint32_t) ((uint64_t) plan->h_fh[5] * 100u / plan->h_fh[4]) : 100u;
+    return SPLAHIP_OK;
+}
+
 int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_items, uint32_t* n_long) {
     SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
     if (n_items) *n_items = plan->n_items;
@@ -266,6 +353,10 @@ int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_items, uint32_t* n_long
 }
 
 const char* splahip_mxv_variant_of(splahip_plan plan, int type, int op_mult, int op_add, int early_exit) {
+    uint32_t xb = 0;
+    if (plan && type != SPLAHIP_FLOAT && first_hit_family(type, op_mult, op_add) && plan->fh_taken && plan->nnz != 0 &&
+        ((plan->sell && uniform_values(plan, plan->sell->n_cols, &xb)) || (plan->cob && uniform_values(plan, plan->cob->n_cols, &xb))))
+        return "mxv_first_hit<structure-only matrix, frontier vector: a row stops at its first hit>";// (what the plan's last such call ran on)
     if (!early_exit && plan && plan->cob && cob_serves_mxv(plan, type, op_mult, op_add, plan->cob->n_cols, nullptr) &&
         !(plan->sell && !sell_disabled() && sell_skip_family(type, op_mult, op_add) == 1))
         return type == SPLAHIP_FLOAT && op_add == SPLAHIP_PLUS ? "mxv_cob<column-ordered blocks, fp64 LDS accumulation>"
@@ -306,6 +397,21 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
     hipStream_t s = as_stream(stream);
+    // a BFS-like step over a structure-only matrix (one value word, a frontier vector, an idempotent fold): a row is settled by its first hit, whatever
+    // early_exit says (mxv_first_hit.hpp; reference src/algorithm.cpp:97-99 is this call with early_exit = true)
+    plan->fh_taken = 0;
+    uint32_t xbits = 0;
+    if (type != SPLAHIP_FLOAT && first_hit_family(type, op_mult, op_add) && uniform_values(plan, n_cols, &xbits) && d_r != d_mask && d_r != d_v && plan->nnz != 0) {
+        bool take = false;
+        int  rc   = type == SPLAHIP_INT ? first_hit_probe<int32_t>(plan, n_cols, d_Ap, d_Aj, d_mask, op_select, d_v, s, &take)
+                                        : first_hit_probe<uint32_t>(plan, n_cols, d_Ap, d_Aj, d_mask, op_select, d_v, s, &take);
+        if (rc != SPLAHIP_OK) return rc;
+        if (take) {
+            plan->fh_taken = 1;
+            return type == SPLAHIP_INT ? launch_first_hit<int32_t>(plan, n_rows, d_Ap, d_Aj, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, xbits, s)
+                                       : launch_first_hit<uint32_t>(plan, n_rows, d_Ap, d_Aj, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, xbits, s);
+        }
+    }
     // the column-ordered-blocks copy (splahip_csr_plan_attach_cob): associative + commutative op_add with an LDS atomic, no early exit
     // When the plan also holds a sliced-ELL copy, the semirings of its sparse-vector (bit) form whose skippable value is 0 (BAND / BOR, LAND / LOR,
     // ... on int / uint: a BFS step, where a few per cent of v are non-zero and half the rows are masked out) stay with it: it reads only the

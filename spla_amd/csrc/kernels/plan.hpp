@@ -129,6 +129,15 @@ struct splahip_plan_s {
     uint32_t* d_long_items = nullptr;// the plan's segment items (rows longer than a run item's)
     uint32_t  n_long_items = 0;
     bool      rows_ready   = false;
+    // BFS-like calls over a structure-only matrix (mxv_first_hit.hpp): per-call bitmap and statistics of the input vector, the verdict in pinned host memory
+    uint32_t*          d_fh_bits  = nullptr;// one bit per column (+ padding to whole 2048-column steps)
+    uint32_t*          d_fh_ctl   = nullptr;// [0..3] vflag (uniform, the word, non-zero count), [4] ticket, [8 ..] per-workgroup statistics
+    volatile uint32_t* h_fh       = nullptr;// pinned: [0] uniform, [1] the word, [2] non-zero count, [3] sequence number of the call that wrote them
+    uint32_t*          d_h_fh     = nullptr;// its device address
+    uint32_t           fh_cols    = 0;
+    uint32_t           fh_seq     = 0;
+    uint32_t           fh_misses  = 0;      // consecutive calls whose hint said "not a frontier": the probe backs off
+    int                fh_taken   = 0;      // did the last BFS-like call run on the first-hit kernel
     splahip_sell_s* sell   = nullptr;// splahip_csr_plan_attach_sell
     splahip_cob_s*  cob    = nullptr;// splahip_csr_plan_attach_cob
 };

@@ -82,6 +82,13 @@ class CsrPlan:
         _lib.call("splahip_csr_plan_cob_probe", self._h, C.byref(se), C.byref(by))
         return {"selected_entries": se.value, "served_by_rows": bool(by.value)}
 
+    def first_hit(self):
+        """what the plan's last BFS-like call did (mxv_first_hit.hpp): {"taken": ran on the first-hit kernel, "uniform": verdict of the last finished pass over
+        v (None: none yet), "nonzeros": its non-zero count, "tail_pct": share of the sampled selected entries in rows the walk would enter past their fourth entry}"""
+        t, u, n, p = C.c_int(), C.c_int(), C.c_uint32(), C.c_uint32()
+        _lib.call("splahip_csr_plan_first_hit", self._h, C.byref(t), C.byref(u), C.byref(n), C.byref(p))
+        return {"taken": bool(t.value), "uniform": None if u.value < 0 else bool(u.value), "nonzeros": n.value, "tail_pct": p.value}
+
     def footprint(self):
         """device bytes held for the matrix besides its CSR arrays: {"plan", "sliced_ell", "column_ordered_blocks"}"""
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

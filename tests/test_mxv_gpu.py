@@ -741,3 +741,61 @@ def test_deterministic_setting_at_the_kernel_abi(oracle):
     assert "mxv_cob" in kernels.mxv_variant("FLOAT", "MULT", "PLUS", False, plan)
     plan.close()
     bare.close()
+
+
+@pytest.mark.parametrize("copy", ["sell", "cob"])
+def test_first_hit_form_of_a_bfs_like_step(oracle, copy):
+    """A BFS-like step (BAND / MULT / LAND products folded by BOR / uint MAX) over a structure-only matrix with a frontier vector (one non-zero word) is settled
+    row by row at the first hit (mxv_first_hit.hpp) — taken from the second call on (the host follows the verdict of the latest FINISHED pass over v), only
+    while the sampled walk mostly ends within a row's first entries, and correct when the hint is stale: a vector that stops being uniform is folded completely
+    by the same launch.  Rows longer than 64 entries (finished by a whole wave) with and without a hit, non-zero init, an empty vector, masks."""
+    import torch
+    from gpu_utils import dev, host
+    from spla_amd import kernels
+    rng = np.random.default_rng(909)
+    n_rows, n_cols = 6000, 5000
+    Ap, Aj, _ = random_csr(rng, n_rows, n_cols, 9, "INT", skew=True, long_rows=6, long_len=2500)
+    longest = int(np.argmax(np.diff(Ap.astype(np.int64))))
+    for t, mul, add, xval in (("INT", "BAND", "BOR", 1), ("UINT", "MULT", "MAX", 3), ("INT", "LAND", "BOR", 5)):
+        Ax = np.full(len(Aj), xval, NP[t])
+        dAp, dAj, dAx = dev(Ap), dev(Aj), dev(Ax)
+        plan = kernels.CsrPlan(n_rows, len(Aj), dAp, n_cols, dAj, dAx) if copy == "sell" else kernels.CsrPlan(n_rows, len(Aj), dAp)
+        if copy == "cob":
+            assert plan.attach_cob(n_cols, dAp, dAj, dAx) is not None
+
+        def call(v, mask, sel, init):
+            r = torch.full((n_rows,), 91, dtype=kernels.torch_dtype(t), device="cuda")
+            kernels.mxv_masked(plan, t, n_cols, dAp, dAj, dAx, dev(mask), dev(v), r, mul, add, sel, init, False)
+            torch.cuda.synchronize()
+            want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
+            assert np.array_equal(host(r, NP[t]), want), (t, mul, add, sel, init, plan.first_hit())
+            return plan.first_hit()
+
+        depth = (rng.random(n_rows) < 0.4).astype(NP[t]) * 2
+        front = np.where(rng.random(n_cols) < 0.7, 1, 0).astype(NP[t])       # a dense frontier: nearly every row is settled within its first entries
+        first = call(front, depth, "EQZERO", 0)
+        assert not first["taken"]                                              # no finished pass over a vector of this plan yet
+        second = call(front, depth, "EQZERO", 0)
+        assert second["taken"] and second["uniform"] and second["nonzeros"] == int(front.sum()) and second["tail_pct"] <= 15, second
+        assert "first_hit" in kernels.mxv_variant(t, mul, add, False, plan)
+        for sel, init in (("ALWAYS", 0), ("NQZERO", 4), ("EQZERO", 1)):       # (an init that already holds the product's bits: nothing moves)
+            assert call(front * 6, depth, sel, init)["taken"]                  # another frontier word
+        lone = np.zeros(n_cols, NP[t])
+        lone[Aj[Ap[longest] + 2000]] = 1                                       # one column, deep inside the longest row: found by the wave's walk, not by a lane's
+        stale = call(lone, np.zeros(n_rows, NP[t]), "EQZERO", 0)               # (hint: the dense frontier of the call before)
+        assert stale["taken"] and stale["tail_pct"] > 50, stale
+        assert not call(lone, np.zeros(n_rows, NP[t]), "EQZERO", 0)["taken"]   # a frontier that leaves most rows without a hit goes back to the layout copy
+        assert not call(front, depth, "EQZERO", 0)["taken"]
+        assert call(front, depth, "EQZERO", 0)["taken"]
+        mixed = np.where(rng.random(n_cols) < 0.7, rng.integers(1, 8, n_cols), 0).astype(NP[t])
+        stale = call(mixed, depth, "EQZERO", 0)                                 # not a frontier: the launch sees it and folds every row completely
+        assert stale["taken"] and stale["uniform"] is False
+        assert not call(mixed, depth, "EQZERO", 0)["taken"]
+        empty = np.zeros(n_cols, NP[t])
+        call(empty, depth, "EQZERO", 7)
+        call(empty, depth, "EQZERO", 7)
+        early = torch.full((n_rows,), 91, dtype=kernels.torch_dtype(t), device="cuda")
+        kernels.mxv_masked(plan, t, n_cols, dAp, dAj, dAx, dev(depth), dev(front), early, mul, add, "EQZERO", 0, True)   # early_exit = true: same rule, same result
+        torch.cuda.synchronize()
+        assert np.array_equal(host(early, NP[t]), oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, depth, front, mul, add, "EQZERO", 0, True))
+        plan.close()
