@@ -397,6 +397,12 @@ def bfs_step_line(args, rank, world):
                 "bytes_per_entry": entry_bytes,
                 "byte_model": ("structure-only: every stored value is the same word, the kernel streams column words only; " if structure_only else "")
                               + "B = %d*nnz_sel + 4*(n_rows+1) + 4*n_rows (mask) + 4*n_rows (r) + 4*n_cols (v once)" % entry_bytes}
+    if world == 1 and "first_hit" in roofline["kernel"]:
+        fh = sh.plan.first_hit()
+        roofline["byte_model"] += ("; the first-hit kernel (frontier vector over a structure-only matrix: every product is 0 or one word, BOR is idempotent) stops a row at its first "
+                                   "hit and so reads fewer than the selected entries; `achieved` still divides the operation's algorithmic bytes by the call's time "
+                                   "(pass over v + first-hit kernel)")
+        roofline["first_hit"] = fh
 
     # measured streaming ceiling of this GPU in this run: a 1 GiB device-to-device copy, read + write bytes / time.
     # `frac` stays against the nominal 8 TB/s; `frac_of_measured_copy` is the same numerator against what a plain copy reaches here.
