@@ -20,7 +20,7 @@ def host(t: torch.Tensor, np_dtype) -> np.ndarray:
     return a.view(np_dtype) if a.dtype != np_dtype else a
 
 
-def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, init, early_exit=False, junk=None, exact=False):
+def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, init, early_exit=False, junk=None, exact=False, calls=1):
     """Run the masked SpMV twice — the CSR wave-tile / row kernels (what the operator API uses) and the same call with the opt-in
     sliced-ELL copy attached — and cross-check them: bit-identical for int / uint, within 1e-5 for fp32 (the sliced-ELL form folds
     every row <= 256 entries strictly in entry order, the CSR form uses an in-order tree for rows > 32).  Returns the CSR result."""
@@ -44,10 +44,11 @@ def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, 
             os.environ.pop("SPLAHIP_COB_HUB_MIN_DEGREE")
             os.environ.pop("SPLAHIP_COB_NAT_SLOTS")
         r = torch.empty(n_rows, dtype=kernels.torch_dtype(t), device="cuda")
-        if junk is not None:
-            r.fill_(junk)
-        kernels.mxv_masked(plan, t, n_cols, dAp, dAj, dAx, dm, dv, r, op_mult, op_add, op_select, init, early_exit)
-        torch.cuda.synchronize()
+        for _ in range(calls):  # calls > 1: the later calls of a plan follow the hints its earlier calls left (mask probe, first-hit pass); the last result is checked
+            if junk is not None:
+                r.fill_(junk)
+            kernels.mxv_masked(plan, t, n_cols, dAp, dAj, dAx, dm, dv, r, op_mult, op_add, op_select, init, early_exit)
+            torch.cuda.synchronize()
         outs[form] = host(r, NP[t])
         plan.close()
     os.environ["SPLAHIP_SELL_BITS"] = "1"

@@ -1,4 +1,5 @@
-"""Randomised soak of the masked SpMV forms (CSR kernels, sliced-ELL auto, sliced-ELL bit form forced) against the oracle:
+"""Randomised soak of the masked SpMV forms (CSR kernels, sliced-ELL auto, sliced-ELL bit form forced, column-ordered blocks in two geometries; one to three
+calls per plan, so that the selected-rows kernels and the first-hit kernel — which follow the hint of an earlier call — are reached) against the oracle:
 random shapes, degree skews, long rows, semirings, select ops, init values and input-vector densities for a given time budget.
     python tools/exp/fuzz_mxv.py [seconds] [seed]"""
 import sys, time
@@ -36,7 +37,7 @@ while time.time() - t0 < budget:
     mask = random_mask(rng, n_rows, t)
     want = orc.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
     try:
-        got = hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init, junk=-3)
+        got = hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init, junk=-3, calls=int(rng.integers(1, 4)))
     except AssertionError as e:
         print(f"FAILED case {n}: {t} {n_rows}x{n_cols} nnz={len(Aj)} {mul}/{add}/{sel} init={init} dens={dens} long={long_rows}x{long_len}: {e}")
         np.savez("/tmp/fuzz_fail.npz", Ap=Ap, Aj=Aj, Ax=Ax, mask=mask, v=v)
