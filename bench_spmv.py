@@ -473,4 +473,18 @@ def _run_sharded(args, rank, world, scale, label, n, nnz, Ap, Aj, Ax, v):
         v = bench_dist.sssp_step_sharded(b, rank, world)
         v["name"] = "SSSP step (BASELINE configs[3]): min-plus int32 on R-MAT scale 24, strong 1-D row split, all-gather of the distance vector per step"
         line["variants"] = [v]
+        budget = float(os.environ.get("SPLA_BENCH_BUDGET_S", "420"))
+        t_var = time.time()
+        if args.permute < 0:  # the headline ran on owner-sorted labels (the default for N > 1): the same step on the generator's own labels
+            c = copy.copy(args)
+            c.permute, c.no_variants, c.no_cpu_baseline = 0, True, True
+            raw = run(c, rank, world)
+            line["variants"].append({"name": "headline step, RAW (generator) vertex labels (--permute 0): hub rows and hub columns sit in the first ranks' blocks",
+                                     **{k: raw[k] for k in ("value", "unit", "ms_per_step", "roofline", "exchange", "shard", "verified") if k in raw}})
+        if time.time() - t_var < budget:  # BASELINE configs[4] across the ranks: the triangle-count call by rows of the mask, B whole on every rank
+            c = copy.copy(args)
+            c.workload, c.scale = "tc-mxmT", (22 if not getattr(args, "scale_given", False) else max(10, args.scale - 3))
+            t = bench_dist.spgemm_sharded(c, rank, world)
+            t["name"] = "BASELINE configs[4] across the ranks: mxmT(L, L, L) by rows of the mask (strong scaling; no exchange in the data path)"
+            line["variants"].append(t)
     return line
