@@ -21,6 +21,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+_T0 = time.time()
+
 HBM_PEAK_GBS = 8000.0
 ROOT = Path(__file__).resolve().parent
 
@@ -474,14 +476,19 @@ def _run_sharded(args, rank, world, scale, label, n, nnz, Ap, Aj, Ax, v):
         v["name"] = "SSSP step (BASELINE configs[3]): min-plus int32 on R-MAT scale 24, strong 1-D row split, all-gather of the distance vector per step"
         line["variants"] = [v]
         budget = float(os.environ.get("SPLA_BENCH_BUDGET_S", "420"))
-        t_var = time.time()
-        if args.permute < 0:  # the headline ran on owner-sorted labels (the default for N > 1): the same step on the generator's own labels
+        # (both extra variants only while the command is still young: the graph of the headline is built once more; _T0 = import time of this module)
+        def still_young(limit):  # one answer for every rank (the variants run collectives): the slowest rank's clock decides
+            flag = torch.tensor([1 if time.time() - _T0 < limit else 0], device="cpu" if dist.get_backend() == "gloo" else "cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(int(flag[0]))
+
+        if args.permute < 0 and still_young(budget):  # the headline ran on owner-sorted labels (the default for N > 1): the same step on the generator's own labels
             c = copy.copy(args)
             c.permute, c.no_variants, c.no_cpu_baseline = 0, True, True
             raw = run(c, rank, world)
             line["variants"].append({"name": "headline step, RAW (generator) vertex labels (--permute 0): hub rows and hub columns sit in the first ranks' blocks",
                                      **{k: raw[k] for k in ("value", "unit", "ms_per_step", "roofline", "exchange", "shard", "verified") if k in raw}})
-        if time.time() - t_var < budget:  # BASELINE configs[4] across the ranks: the triangle-count call by rows of the mask, B whole on every rank
+        if still_young(1.5 * budget):  # BASELINE configs[4] across the ranks: the triangle-count call by rows of the mask, B whole on every rank
             c = copy.copy(args)
             c.workload, c.scale = "tc-mxmT", (22 if not getattr(args, "scale_given", False) else max(10, args.scale - 3))
             t = bench_dist.spgemm_sharded(c, rank, world)
