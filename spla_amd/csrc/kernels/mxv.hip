@@ -136,7 +136,9 @@ namespace {
         int rc = first_hit_prepare(plan, n_cols);
         if (rc != SPLAHIP_OK) return SPLAHIP_OK;// (no workspace: the other forms serve the call)
         const uint32_t pct = knob_u32("SPLAHIP_FIRST_HIT_TAIL_PCT", 15);
-        *take = plan->h_fh[3] != 0u && plan->h_fh[0] != 0u && plan->h_fh[2] != 0u && plan->h_fh[4] != 0u && (uint64_t) plan->h_fh[5] * 100u <= (uint64_t) plan->h_fh[4] * pct;
+        uint32_t h[8];// (the pass writes two 16-byte halves, the call's sequence number in each: a torn read shows as two different numbers)
+        for (int k = 0; k < 8; ++k) h[k] = plan->h_fh[k];
+        *take = h[3] != 0u && h[3] == h[7] && h[0] != 0u && h[2] != 0u && h[4] != 0u && (uint64_t) h[5] * 100u <= (uint64_t) h[4] * pct;
         if (!*take) {
             plan->fh_misses += 1;
             if (plan->fh_misses > 4 && (plan->fh_misses & 15u) != 0u) return SPLAHIP_OK;

@@ -21,7 +21,7 @@ namespace splahip {
     // One pass over v: the bitmap of its non-zero entries (bits[c >> 5] bit c & 31), and whether all of them hold the same word.
     // part: kVstatBlocks x 8 words of per-workgroup statistics (count, min, max of the non-zero words; sampled selected entries, sampled tail entries); ticket: one word, 0 between calls.
     // The last workgroup to finish reduces them: vflag[0] = 1 if uniform (or empty), vflag[1] = the word, vflag[2] = non-zero count; and sums the workgroups' samples of
-    // what the first-hit walk would cost on this call (below); the verdicts and the call's sequence number go to pinned host memory (host_words[0..5]: the NEXT call's hint).
+    // what the first-hit walk would cost on this call (below); the verdicts and the call's sequence number go to pinned host memory (host_words[0..7]: the NEXT call's hint).
     constexpr uint32_t kVstatTpb    = 512;
     constexpr uint32_t kVstatBlocks = 256;// one workgroup per CU: the closing ticket is a same-address atomic per workgroup (~10 ns each, serialised)
     template<typename T>
@@ -37,25 +37,25 @@ namespace splahip {
         // per row, one of the row's first four entries each; the loads run under the wave's share of the stream below): a selected row that holds more than four
         // entries and no hit among its first four is a TAIL row — the walk goes on into it.  The host takes the first-hit kernel while the tail rows' entries stay
         // a small share of the sampled selected entries (mxv.hip).
-        uint32_t s_sel = 0, s_tail = 0;
-        if (threadIdx.x < kWave) {
+        // (three dependent rounds — mask / Ap, the column ids, the words of v — threaded through the wave's first step of the stream: the rounds wait for their own
+        // loads only, the 32 stream loads issued in between stay in flight)
+        uint32_t       s_sel = 0, s_tail = 0;
+        const bool     sampler = threadIdx.x < kWave;
+        const uint32_t s_i     = threadIdx.x & 3u;
+        uint32_t       s_k0 = 0, s_k1 = 0, s_c = 0, s_v = 0;
+        bool           s_has = false;
+        int            s_stage = 0;
+        if (sampler) {
             const uint32_t step = max(1u, n_rows / (kVstatBlocks * 16u));
             const uint64_t row  = (uint64_t) (blockIdx.x * 16u + threadIdx.x / 4u) * step;
-            const uint32_t i    = threadIdx.x & 3u;
             const bool     sel  = row < n_rows && eval_sel(op_select, mask[row]);
-            const uint32_t k0 = sel ? Ap[row] : 0u, k1 = sel ? Ap[row + 1] : 0u;
-            const bool     has  = k0 + i < k1;
-            const uint32_t c    = has ? Aj[k0 + i] : 0u;
-            uint32_t       any  = has && reinterpret_cast<const uint32_t*>(v)[c] != 0u ? 1u : 0u;
-            any |= (uint32_t) __shfl_xor((int) any, 1, kWave);
-            any |= (uint32_t) __shfl_xor((int) any, 2, kWave);
-            if (i == 0u && k1 > k0) {
-                s_sel = k1 - k0;
-                if (!any && k1 - k0 > 4u) s_tail = k1 - k0;
-            }
-            s_sel  = wave_sum(s_sel);
-            s_tail = wave_sum(s_tail);
+            s_k0 = sel ? Ap[row] : 0u, s_k1 = sel ? Ap[row + 1] : 0u;
         }
+        auto sample_columns = [&]() {
+            s_has = s_k0 + s_i < s_k1;
+            s_c   = s_has ? Aj[s_k0 + s_i] : 0u;
+        };
+        auto sample_values = [&]() { s_v = s_has ? w[s_c] : 0u; };
         // a wave takes 2048 consecutive columns per step: 32 coalesced loads in flight per lane, one ballot each = the 64 bits of the columns it covers; lane j keeps
         // ballot j and the wave stores its 32 words of 64 bits in one coalesced store (bits is 8-byte aligned: a hipMalloc'ed array)
         const uint32_t       lane    = lane_id();
@@ -68,6 +68,7 @@ namespace splahip {
                 const uint64_t c = base + (uint32_t) j * kWave + lane;
                 e[j]             = c < n_cols ? w[c] : 0u;
             }
+            if (sampler && s_stage == 0) sample_columns(), s_stage = 1;
             unsigned long long mine = 0ull;
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
@@ -75,7 +76,21 @@ namespace splahip {
                 if ((int) lane == j) mine = b;
                 if (e[j] != 0u) count += 1, mn = min(mn, e[j]), mx = max(mx, e[j]);
             }
+            if (sampler && s_stage == 1) sample_values(), s_stage = 2;
             if (lane < 32u && base + (uint64_t) lane * kWave < n_cols) bits64[(base >> 6) + lane] = mine;
+        }
+        if (sampler) {
+            if (s_stage == 0) sample_columns();
+            if (s_stage <= 1) sample_values();
+            uint32_t any = s_has && s_v != 0u ? 1u : 0u;
+            any |= (uint32_t) __shfl_xor((int) any, 1, kWave);
+            any |= (uint32_t) __shfl_xor((int) any, 2, kWave);
+            if (s_i == 0u && s_k1 > s_k0) {
+                s_sel = s_k1 - s_k0;
+                if (!any && s_k1 - s_k0 > 4u) s_tail = s_k1 - s_k0;
+            }
+            s_sel  = wave_sum(s_sel);
+            s_tail = wave_sum(s_tail);
         }
         count = wave_sum(count);
         mn    = ~wave_max(~mn);
@@ -119,14 +134,25 @@ namespace splahip {
             for (uint32_t k = 1; k < kVstatTpb / kWave; ++k) sel_entries += s_red[1][k], tail_entries += s_red[2][k];
             vflag[0] = uniform, vflag[1] = count ? mx : 0u, vflag[2] = count;
             *ticket  = 0u;
-            host_words[0] = uniform, host_words[1] = count ? mx : 0u, host_words[2] = count, host_words[4] = sel_entries, host_words[5] = tail_entries;
-            __threadfence_system();
-            host_words[3] = seq;
+            // two 16-byte stores to pinned host memory, the call's sequence number in both: the host trusts the words when the two numbers agree (no system-scope
+            // fence and second round trip at the end of the launch)
+            typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+            u4v*      hw = reinterpret_cast<u4v*>(const_cast<uint32_t*>(host_words));
+            const u4v a  = {uniform, count ? mx : 0u, count, seq};
+            const u4v b  = {sel_entries, tail_entries, 0u, seq};
+            __builtin_nontemporal_store(a, hw);
+            __builtin_nontemporal_store(b, hw + 1);
         }
     }
 
     // One wave per 64 consecutive rows, a lane per row (see the walk below); a hub row without a hit would otherwise keep one lane busy for its 10^5 entries.
-    constexpr uint32_t kFirstHitLane = 64;
+#ifndef SPLAHIP_FH_LANE
+#define SPLAHIP_FH_LANE 64
+#endif
+#ifndef SPLAHIP_FH_UNROLL
+#define SPLAHIP_FH_UNROLL 2// (measured on the R-MAT 22 traversal step, kernel + pass over v: 1 -> 56 - 63 us, 2 -> 53.5, 3 -> 56.7, 4 -> 63, 8 -> 92: what is read past the hit is wasted)
+#endif
+    constexpr uint32_t kFirstHitLane = SPLAHIP_FH_LANE;// entries of its own row a lane walks (SPLAHIP_FH_UNROLL at a time) before the wave takes the row over
     template<typename T, class Mult, class Add>
     __global__ __launch_bounds__(256) void mxv_first_hit_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ Aj, const T* __restrict__ mask,
                                                                 const T* __restrict__ v, T* __restrict__ r, Mult mult, Add add, int op_select, T init, uint32_t xbits,
@@ -147,10 +173,16 @@ namespace splahip {
             const uint32_t ke = min(k1, k0 + kFirstHitLane);
             bool           found_own = false;
             if (moves) {
-                for (uint32_t k = k0; k < ke; k += 4) {
-                    const uint32_t c0 = Aj[k], c1 = Aj[min(k + 1, ke - 1)], c2 = Aj[min(k + 2, ke - 1)], c3 = Aj[min(k + 3, ke - 1)];
-                    const uint32_t w0 = bits[c0 >> 5], w1 = bits[c1 >> 5], w2 = bits[c2 >> 5], w3 = bits[c3 >> 5];
-                    if ((((w0 >> (c0 & 31u)) | (w1 >> (c1 & 31u)) | (w2 >> (c2 & 31u)) | (w3 >> (c3 & 31u))) & 1u) != 0u) {
+                constexpr uint32_t KU = SPLAHIP_FH_UNROLL;
+                for (uint32_t k = k0; k < ke; k += KU) {
+                    uint32_t c[KU], w[KU], any = 0;
+#pragma unroll
+                    for (uint32_t u = 0; u < KU; ++u) c[u] = Aj[min(k + u, ke - 1)];
+#pragma unroll
+                    for (uint32_t u = 0; u < KU; ++u) w[u] = bits[c[u] >> 5];
+#pragma unroll
+                    for (uint32_t u = 0; u < KU; ++u) any |= w[u] >> (c[u] & 31u);
+                    if ((any & 1u) != 0u) {
                         found_own = true;
                         break;
                     }
