@@ -129,6 +129,16 @@ int splahip_csr_plan_footprint(splahip_plan plan, uint64_t* plan_bytes, uint64_t
 int splahip_mxv_prefers_sell(int type, int op_mult, int op_add);
 int splahip_csr_plan_destroy(splahip_plan plan);
 /* n_items: work items; n_long: rows cut into segment items */
+/* What the OWNER of a plan's value array says about it: every stored value is the word value_bits (is_uniform != 0) or not.  A plan is built from Ap alone and
+ * does not see the values; the BFS-like fast paths (splahip_csr_plan_first_hit below, and the pull form of vxm) need to know that every product of a frontier
+ * is one word.  The operator API calls it once per upload (splahip_words_range over the value array); attached layout copies know it from their own pass. */
+int splahip_csr_plan_set_uniform_values(splahip_plan plan, int is_uniform, uint32_t value_bits);
+/* smallest / largest 4-byte word of a device array (blocking): equal <=> one word */
+int splahip_words_range(const void* d_words, size_t n, uint32_t* lo, uint32_t* hi, void* stream);
+/* The products of the NEXT splahip_vxm_pull over this (transposed) plan, as counted by the splahip_vxm_probe / splahip_vxm_push_small its caller ran (one
+ * shot).  With it, a traversal's pull level — BAND / BOR ..., a frontier of equal stored values, a matrix of one value word — whose frontier rows hold >= 1/6 of
+ * the entries is settled output entry by output entry at the first stored in-neighbour (mxv_first_hit.hpp) instead of folding every row completely. */
+int splahip_csr_plan_hint_products(splahip_plan plan, uint64_t products);
 /* BFS-like calls (BAND / MULT / LAND products folded by BOR or uint MAX) over a matrix whose stored values are all one word (known from an attached layout
  * copy): splahip_mxv_masked passes over v once per call (bitmap; is every non-zero entry the same word?; a 4096-row sample of how far a first-hit walk would
  * go) and, when the LATEST FINISHED pass saw a frontier whose walk mostly ends within a row's first four entries, settles every row by its first hit over plain

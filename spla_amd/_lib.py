@@ -32,6 +32,9 @@ _SIGNATURES = {
     "splahip_last_error": (C.c_char_p, []),
     "splahip_version": (C.c_int, []),
     "splahip_env_refresh": (C.c_int, []),
+    "splahip_csr_plan_set_uniform_values": (C.c_int, [_vp, C.c_int, C.c_uint32]),
+    "splahip_words_range": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _vp]),
+    "splahip_csr_plan_hint_products": (C.c_int, [_vp, C.c_uint64]),
     "splahip_csr_plan_first_hit": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "splahip_set_deterministic": (C.c_int, [C.c_int]),
     "splahip_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),

@@ -30,9 +30,20 @@ namespace spla {
             return t->device_id;
         }
 
+        // the plan is told once per upload whether every stored value is one word (an adjacency matrix): the BFS-like steps then settle a row / an output entry
+        // at its first hit (spla_hip.h: splahip_csr_plan_set_uniform_values)
+        template<typename T>
+        void tell_value_range(HipCsr<T>* a) {
+            uint32_t lo = 1, hi = 0;
+            if (a->values > 0 && splahip_words_range(a->Ax.ptr(), a->values, &lo, &hi, nullptr) == SPLAHIP_OK)
+                (void) splahip_csr_plan_set_uniform_values(a->plan, lo == hi ? 1 : 0, lo);
+        }
         template<typename T>
         void ensure_plan(HipCsr<T>* a, uint n_rows) {
-            if (!a->plan) hip_check(splahip_csr_plan_create(&a->plan, n_rows, a->values, a->Ap.template as<uint32_t>(), nullptr), "csr plan");
+            if (!a->plan) {
+                hip_check(splahip_csr_plan_create(&a->plan, n_rows, a->values, a->Ap.template as<uint32_t>(), nullptr), "csr plan");
+                tell_value_range(a);
+            }
         }
         unsigned env_calls(const char* name, unsigned dflt) {
             const char* e = std::getenv(name);
@@ -176,6 +187,7 @@ namespace spla {
                           "splahip_csr_transpose");
                 t->values = nnz;
                 hip_check(splahip_csr_plan_create(&t->plan, M->get_n_cols(), nnz, t->Ap.template as<uint32_t>(), nullptr), "csr plan (transpose)");
+                tell_value_range(t);
                 M->storage().valid.set(slot);
             }
             return t;
@@ -278,6 +290,7 @@ namespace spla {
                         tr->prepared = tr->prepared || M->acc_csr()->prepared;
                         maybe_build_copies(tr, M->get_n_cols(), M->get_n_rows());
                     }
+                    (void) splahip_csr_plan_hint_products(tr->plan, products);// (the probe's count: a frontier whose rows hold much of the matrix is settled at the first hit)
                     hip_check(splahip_vxm_pull(tr->plan, TypeTraits<T>::id, M->get_n_rows(), M->get_n_cols(), tr->Ap.template as<uint32_t>(),
                                                tr->Aj.template as<uint32_t>(), tr->Ax.ptr(), mask->acc_dense()->Ax.ptr(), nvals,
                                                vin->Ai.template as<uint32_t>(), vin->Ax.ptr(), identity, out->Ai.template as<uint32_t>(),

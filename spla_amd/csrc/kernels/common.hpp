@@ -31,6 +31,10 @@ namespace splahip {
 
     // An environment knob (SPLAHIP_...: A/B switches and tuning values for tests and experiments), read from the process environment ONCE and cached
     // (runtime.hip): a call's dispatch costs a hash lookup, not a scan of the environment.  splahip_env_refresh() drops the cache (tests change knobs mid-process).
+    // A few result words of a call brought to the host: a one-wave kernel writes them into pinned (mapped) memory of the calling host thread, the stream is
+    // synchronised, the words are copied out.  hipMemcpyAsync to a pageable destination costs a staged blit (~15 us per call in the kernel trace of
+    // spla_Algorithm_bfs, two per level); this is one small launch.  n <= 16 words; h_dst any host memory.  Returns a hipError_t.
+    hipError_t fetch_words(void* h_dst, const void* d_src, uint32_t n_words, hipStream_t stream);
     const char* knob_env(const char* name);
     // the calling host thread asked for run-to-run identical fp32 sums (splahip_set_deterministic; the Descriptor's deterministic flag): the forms whose
     // fp32 PLUS merges partial sums in arrival order (column-ordered blocks, the LDS row classes of mxm) stand aside for the fixed-order kernels

@@ -28,6 +28,21 @@ using namespace splahip;
 
 using Cfg = MxvCfg;
 
+namespace splahip {
+    // the semirings: 0 annihilates op_mult and is op_add's identity (sell_skip_family == 1) and op_add is idempotent (PLUS and BXOR count, they do not qualify)
+    bool first_hit_family(int type, int op_mult, int op_add) {
+        return type != SPLAHIP_FLOAT && sell_skip_family(type, op_mult, op_add) == 1 && (op_add == SPLAHIP_BOR || op_add == SPLAHIP_MAX);
+    }
+    // every stored value of the matrix is one word: said by the owner of the value array (splahip_csr_plan_set_uniform_values), or known from the attach pass
+    // of a layout copy (the plan alone does not own the caller's value array)
+    bool uniform_values(const splahip_plan_s* plan, uint32_t n_cols, uint32_t* xbits) {
+        if (plan->values_uniform == 1) return *xbits = plan->values_bits, true;
+        if (plan->sell && plan->sell->n_cols == n_cols && plan->sell->x_uniform) return *xbits = plan->sell->x_bits, true;
+        if (plan->cob && plan->cob->n_cols == n_cols && plan->cob->x_uniform) return *xbits = plan->cob->x_bits, true;
+        return false;
+    }
+}// namespace splahip
+
 namespace {
 
     enum class Variant { WaveTileStatic,
@@ -95,15 +110,6 @@ namespace {
 
     // ---- BFS-like calls over a structure-only matrix: a row stops at its first hit (mxv_first_hit.hpp) -------------------------------------------------
     // the semirings: 0 annihilates op_mult and is op_add's identity (sell_skip_family == 1) and op_add is idempotent (PLUS and BXOR count, they do not qualify)
-    bool first_hit_family(int type, int op_mult, int op_add) {
-        return sell_skip_family(type, op_mult, op_add) == 1 && (op_add == SPLAHIP_BOR || op_add == SPLAHIP_MAX);
-    }
-    // every stored value of the matrix is one word: known from the attach pass of a layout copy (the plan alone does not own the caller's value array)
-    bool uniform_values(const splahip_plan_s* plan, uint32_t n_cols, uint32_t* xbits) {
-        if (plan->sell && plan->sell->n_cols == n_cols && plan->sell->x_uniform) return *xbits = plan->sell->x_bits, true;
-        if (plan->cob && plan->cob->n_cols == n_cols && plan->cob->x_uniform) return *xbits = plan->cob->x_bits, true;
-        return false;
-    }
     uint32_t knob_u32(const char* name, uint32_t dflt) {
         const char* e = knob_env(name);
         return e && *e ? (uint32_t) std::strtoul(e, nullptr, 10) : dflt;
@@ -156,15 +162,16 @@ namespace {
         const dim3 grid((n_rows + 255) / 256);
         if constexpr (!std::is_same<T, float>::value) {
             if (op_mult == SPLAHIP_BAND && op_add == SPLAHIP_BOR) {
-                hipLaunchKernelGGL((mxv_first_hit_kernel<T, StaBin<SPLAHIP_BAND>, StaBin<SPLAHIP_BOR>>), grid, dim3(256), 0, st, n_rows, Ap, Aj, static_cast<const T*>(mask),
+                hipLaunchKernelGGL((mxv_first_hit_kernel<T, StaBin<SPLAHIP_BAND>, StaBin<SPLAHIP_BOR>, false>), grid, dim3(256), 0, st, n_rows, Ap, Aj, static_cast<const T*>(mask),
                                    static_cast<const T*>(v), static_cast<T*>(r), StaBin<SPLAHIP_BAND>(), StaBin<SPLAHIP_BOR>(), op_select, from_bits<T>(init_bits), xbits,
-                                   plan->d_fh_ctl, plan->d_fh_bits);
+                                   plan->d_fh_ctl, plan->d_fh_bits, static_cast<uint32_t*>(nullptr));
                 SPLAHIP_TRY(hipGetLastError());
                 return SPLAHIP_OK;
             }
         }
-        hipLaunchKernelGGL((mxv_first_hit_kernel<T, DynBin, DynBin>), grid, dim3(256), 0, st, n_rows, Ap, Aj, static_cast<const T*>(mask), static_cast<const T*>(v),
-                           static_cast<T*>(r), DynBin(op_mult), DynBin(op_add), op_select, from_bits<T>(init_bits), xbits, plan->d_fh_ctl, plan->d_fh_bits);
+        hipLaunchKernelGGL((mxv_first_hit_kernel<T, DynBin, DynBin, false>), grid, dim3(256), 0, st, n_rows, Ap, Aj, static_cast<const T*>(mask), static_cast<const T*>(v),
+                           static_cast<T*>(r), DynBin(op_mult), DynBin(op_add), op_select, from_bits<T>(init_bits), xbits, plan->d_fh_ctl, plan->d_fh_bits,
+                           static_cast<uint32_t*>(nullptr));
         SPLAHIP_TRY(hipGetLastError());
         return SPLAHIP_OK;
     }
@@ -338,6 +345,54 @@ int splahip_csr_plan_destroy(splahip_plan plan) {
     return SPLAHIP_OK;
 }
 
+namespace {
+    // smallest and largest word of an array
+    __global__ __launch_bounds__(256) void words_range_kernel(size_t n, const uint32_t* __restrict__ x, uint32_t* __restrict__ out) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0;
+        for (size_t k = (size_t) blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t) gridDim.x * 256) {
+            const uint32_t a = x[k];
+            lo = min(lo, a), hi = max(hi, a);
+        }
+        lo = ~wave_max(~lo);
+        hi = wave_max(hi);
+        if (lane_id() == 0) {
+            atomicMax(&out[0], ~lo);
+            atomicMax(&out[1], hi);
+        }
+    }
+}// namespace
+
+int splahip_words_range(const void* d_words, size_t n, uint32_t* lo, uint32_t* hi, void* stream) {
+    SPLAHIP_REQUIRE(lo && hi, "null output");
+    *lo = 0xFFFFFFFFu, *hi = 0;
+    if (n == 0) return SPLAHIP_OK;
+    SPLAHIP_REQUIRE(d_words != nullptr, "null device pointer");
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    hipStream_t s = as_stream(stream);
+    DevMem      out;
+    SPLAHIP_TRY(out.alloc(s, 8));
+    SPLAHIP_TRY(hipMemsetAsync(out.p, 0, 8, s));
+    hipLaunchKernelGGL(words_range_kernel, dim3(1024), dim3(256), 0, s, n, static_cast<const uint32_t*>(d_words), out.as<uint32_t>());
+    uint32_t h[2] = {0, 0};
+    SPLAHIP_TRY(hipMemcpyAsync(h, out.p, 8, hipMemcpyDeviceToHost, s));
+    SPLAHIP_TRY(hipStreamSynchronize(s));
+    *lo = ~h[0], *hi = h[1];
+    return SPLAHIP_OK;
+}
+
+int splahip_csr_plan_set_uniform_values(splahip_plan plan, int is_uniform, uint32_t value_bits) {
+    SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
+    plan->values_uniform = is_uniform ? 1 : 0, plan->values_bits = value_bits;
+    return SPLAHIP_OK;
+}
+
+int splahip_csr_plan_hint_products(splahip_plan plan, uint64_t products) {
+    SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
+    plan->products_hint = products;
+    return SPLAHIP_OK;
+}
+
 int splahip_csr_plan_first_hit(splahip_plan plan, int* taken, int* uniform, uint32_t* nonzeros, uint32_t* tail_pct) {
     SPLAHIP_REQUIRE(plan != nullptr, "plan is null");
     if (taken) *taken = plan->fh_taken;
@@ -356,8 +411,8 @@ int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_items, uint32_t* n_long
 
 const char* splahip_mxv_variant_of(splahip_plan plan, int type, int op_mult, int op_add, int early_exit) {
     uint32_t xb = 0;
-    if (plan && type != SPLAHIP_FLOAT && first_hit_family(type, op_mult, op_add) && plan->fh_taken && plan->nnz != 0 &&
-        ((plan->sell && uniform_values(plan, plan->sell->n_cols, &xb)) || (plan->cob && uniform_values(plan, plan->cob->n_cols, &xb))))
+    if (plan && first_hit_family(type, op_mult, op_add) && plan->fh_taken && plan->nnz != 0 &&
+        (plan->values_uniform == 1 || (plan->sell && uniform_values(plan, plan->sell->n_cols, &xb)) || (plan->cob && uniform_values(plan, plan->cob->n_cols, &xb))))
         return "mxv_first_hit<structure-only matrix, frontier vector: a row stops at its first hit>";// (what the plan's last such call ran on)
     if (!early_exit && plan && plan->cob && cob_serves_mxv(plan, type, op_mult, op_add, plan->cob->n_cols, nullptr) &&
         !(plan->sell && !sell_disabled() && sell_skip_family(type, op_mult, op_add) == 1))
@@ -403,7 +458,7 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
     // early_exit says (mxv_first_hit.hpp; reference src/algorithm.cpp:97-99 is this call with early_exit = true)
     plan->fh_taken = 0;
     uint32_t xbits = 0;
-    if (type != SPLAHIP_FLOAT && first_hit_family(type, op_mult, op_add) && uniform_values(plan, n_cols, &xbits) && d_r != d_mask && d_r != d_v && plan->nnz != 0) {
+    if (first_hit_family(type, op_mult, op_add) && uniform_values(plan, n_cols, &xbits) && d_r != d_mask && d_r != d_v && plan->nnz != 0) {
         bool take = false;
         int  rc   = type == SPLAHIP_INT ? first_hit_probe<int32_t>(plan, n_cols, d_Ap, d_Aj, d_mask, op_select, d_v, s, &take)
                                         : first_hit_probe<uint32_t>(plan, n_cols, d_Ap, d_Aj, d_mask, op_select, d_v, s, &take);

@@ -153,23 +153,31 @@ namespace splahip {
 #define SPLAHIP_FH_UNROLL 2// (measured on the R-MAT 22 traversal step, kernel + pass over v: 1 -> 56 - 63 us, 2 -> 53.5, 3 -> 56.7, 4 -> 63, 8 -> 92: what is read past the hit is wasted)
 #endif
     constexpr uint32_t kFirstHitLane = SPLAHIP_FH_LANE;// entries of its own row a lane walks (SPLAHIP_FH_UNROLL at a time) before the wave takes the row over
-    template<typename T, class Mult, class Add>
+    // VXM = false: the masked SpMV (bits = vstat_kernel's bitmap of the non-zero entries of v; vflag[0] uniform, [1] the word, [2] the non-zero count).
+    // VXM = true: the pull form of vxm over the TRANSPOSED matrix (reference src/cpu/cpu_vxm.hpp:92-125): "rows" are output indices, bits = the bitmap of the
+    //   STORED indices of the sparse input vector (an entry whose index is not stored gives no product), v = its dense image, products are mult(v, x), the fold
+    //   starts at the first product (no init) and touched[row] says whether the output entry exists; vflag[0] / vflag[1] = max over the stored value words of
+    //   ~word / of word (vx_range_kernel): one stored word c  <=>  ~vflag[0] == vflag[1].  Every product is then mult(c, x): the first stored neighbour settles
+    //   the output entry.
+    template<typename T, class Mult, class Add, bool VXM>
     __global__ __launch_bounds__(256) void mxv_first_hit_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ Aj, const T* __restrict__ mask,
                                                                 const T* __restrict__ v, T* __restrict__ r, Mult mult, Add add, int op_select, T init, uint32_t xbits,
-                                                                const uint32_t* __restrict__ vflag, const uint32_t* __restrict__ bits) {
+                                                                const uint32_t* __restrict__ vflag, const uint32_t* __restrict__ bits, uint32_t* __restrict__ touched) {
         const uint32_t row     = blockIdx.x * 256 + threadIdx.x;
         const bool     in      = row < n_rows;
         const bool     sel     = in && eval_sel(op_select, mask[row]);
         const uint32_t k0      = sel ? Ap[row] : 0u;
         const uint32_t k1      = sel ? Ap[row + 1] : 0u;
-        const bool     uniform = vflag[0] != 0u;// (the same word for every lane of the launch)
+        const bool     uniform = VXM ? ~vflag[0] == vflag[1] : vflag[0] != 0u;// (the same word for every lane of the launch)
         const T        x       = from_bits<T>(xbits);
         T              sum     = init;
+        bool           found_any = false;
         if (uniform) {
-            const T    hit   = add(init, mult(x, from_bits<T>(vflag[1])));
-            const bool moves = to_bits(hit) != to_bits(init) && vflag[2] != 0u;// (a product that leaves init alone: nothing to look for)
-            // every lane walks the first kFirstHitLane entries of its own row, four at a time (the rows of a large BFS level are settled within a few entries,
-            // the long ones too); what is left of a long row without a hit so far is walked by the whole wave afterwards, 64 entries per step
+            const T    p     = VXM ? mult(from_bits<T>(vflag[1]), x) : mult(x, from_bits<T>(vflag[1]));
+            const T    hit   = VXM ? p : add(init, p);
+            const bool moves = VXM ? true : (to_bits(hit) != to_bits(init) && vflag[2] != 0u);// (a product that leaves init alone: nothing to look for)
+            // every lane walks the first kFirstHitLane entries of its own row, SPLAHIP_FH_UNROLL at a time (the rows of a large BFS level are settled within a few
+            // entries, the long ones too); what is left of a long row without a hit so far is walked by the whole wave afterwards, 64 entries per step
             const uint32_t ke = min(k1, k0 + kFirstHitLane);
             bool           found_own = false;
             if (moves) {
@@ -188,7 +196,7 @@ namespace splahip {
                     }
                 }
             }
-            if (found_own) sum = hit;
+            if (found_own) sum = hit, found_any = true;
             unsigned long long todo = __ballot(moves && !found_own && ke < k1);
             while (todo != 0ull) {
                 const int      src = __ffsll((long long) todo) - 1;
@@ -202,13 +210,51 @@ namespace splahip {
                     }
                     found = __ballot(mine) != 0ull;
                 }
-                if ((int) lane_id() == src && found) sum = hit;
+                if ((int) lane_id() == src && found) sum = hit, found_any = true;
                 todo &= todo - 1ull;
             }
         } else if (sel) {// any vector: the complete fold, in entry order
-            for (uint32_t k = k0; k < k1; ++k) sum = add(sum, mult(x, v[Aj[k]]));
+            if constexpr (VXM) {
+                for (uint32_t k = k0; k < k1; ++k) {
+                    const uint32_t c = Aj[k];
+                    if (((bits[c >> 5] >> (c & 31u)) & 1u) == 0u) continue;
+                    const T p = mult(v[c], x);
+                    sum       = found_any ? add(sum, p) : p;
+                    found_any = true;
+                }
+            } else {
+                for (uint32_t k = k0; k < k1; ++k) sum = add(sum, mult(x, v[Aj[k]]));
+            }
         }
-        if (in) r[row] = sum;
+        if constexpr (VXM) {
+            if (in) {
+                touched[row] = found_any ? 1u : 0u;
+                if (found_any) r[row] = sum;
+            }
+        } else {
+            if (in) r[row] = sum;
+        }
+    }
+
+    // vflag[0] = max(~word), vflag[1] = max(word) over the stored values of a sparse vector (both 0 before the launch).  One pair of atomics per WORKGROUP, at most
+    // 64 workgroups: same-address atomics serialise (one pair per wave of a 1024-workgroup grid cost 24 us for 10^5 values)
+    template<int = 0>// (a template: the header is included by two translation units)
+    __global__ __launch_bounds__(256) void vx_range_kernel(uint32_t nvals, const uint32_t* __restrict__ vx, uint32_t* __restrict__ vflag) {
+        __shared__ uint32_t s_lo[256 / kWave], s_hi[256 / kWave];
+        uint32_t            lo = 0xFFFFFFFFu, hi = 0;
+        for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nvals; k += gridDim.x * 256) {
+            const uint32_t a = vx[k];
+            lo = min(lo, a), hi = max(hi, a);
+        }
+        lo = ~wave_max(~lo);
+        hi = wave_max(hi);
+        if (lane_id() == 0) s_lo[threadIdx.x / kWave] = lo, s_hi[threadIdx.x / kWave] = hi;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (uint32_t k = 1; k < 256 / kWave; ++k) lo = min(lo, s_lo[k]), hi = max(hi, s_hi[k]);
+            atomicMax(&vflag[0], ~lo);
+            atomicMax(&vflag[1], hi);
+        }
     }
 
 }// namespace splahip

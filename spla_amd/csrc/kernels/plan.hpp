@@ -138,11 +138,19 @@ struct splahip_plan_s {
     uint32_t           fh_seq     = 0;
     uint32_t           fh_misses  = 0;      // consecutive calls whose hint said "not a frontier": the probe backs off
     int                fh_taken   = 0;      // did the last BFS-like call run on the first-hit kernel
+    // what the owner of the value array says about it (splahip_csr_plan_set_uniform_values): -1 nothing, 0 several words, 1 every stored value is values_bits
+    int                values_uniform = -1;
+    uint32_t           values_bits    = 0;
+    uint64_t           products_hint  = 0;  // products of the NEXT pull call over this (transposed) plan, if its caller counted them (splahip_csr_plan_hint_products; one shot)
     splahip_sell_s* sell   = nullptr;// splahip_csr_plan_attach_sell
     splahip_cob_s*  cob    = nullptr;// splahip_csr_plan_attach_cob
 };
 
 namespace splahip {
+    // BFS-like semirings: 0 annihilates op_mult and is op_add's identity (sell_skip_family == 1) and op_add is idempotent (mxv_first_hit.hpp)
+    bool first_hit_family(int type, int op_mult, int op_add);
+    // every stored value of the plan's matrix is one word: said by the owner of the arrays, or known from the attach pass of a layout copy
+    bool uniform_values(const splahip_plan_s* plan, uint32_t n_cols, uint32_t* xbits);
     void sell_release(splahip_sell_s* sell);
     void cob_release(splahip_cob_s* cob);
     // does the plan hold a column-ordered-blocks copy that can serve this op_add on this type (an LDS atomic exists, SPLAHIP_COB != 0)

@@ -42,6 +42,36 @@ namespace splahip {
         tl_deterministic = on ? 1 : 0;
         return before;
     }
+    namespace {
+        __global__ __launch_bounds__(64) void mailbox_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n) {
+            if (threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+        }
+        struct Mailbox {
+            uint32_t* host = nullptr;
+            uint32_t* dev  = nullptr;
+            ~Mailbox() {
+                if (host) (void) hipHostFree(host);
+            }
+        };
+    }// namespace
+    hipError_t fetch_words(void* h_dst, const void* d_src, uint32_t n_words, hipStream_t stream) {
+        static thread_local Mailbox box;
+        if (n_words == 0) return hipStreamSynchronize(stream);
+        if (n_words > 16) return hipErrorInvalidValue;
+        if (!box.host) {
+            hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&box.host), 16 * sizeof(uint32_t), hipHostMallocMapped);
+            if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&box.dev), box.host, 0);
+            if (e != hipSuccess) {
+                box.host = nullptr;
+                return e;
+            }
+        }
+        hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(64), 0, stream, static_cast<const uint32_t*>(d_src), box.dev, n_words);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e == hipSuccess) std::memcpy(h_dst, box.host, sizeof(uint32_t) * n_words);
+        return e;
+    }
     void knob_cache_clear() {
         std::lock_guard<std::mutex> lock(knob_mutex());
         knob_map().clear();

@@ -124,8 +124,7 @@ namespace splahip {
         hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk, n_chunks);
         hipLaunchKernelGGL(changed_write_kernel, dim3(n_chunks), dim3(256), 0, s, changed, vi, newval, nvals, chunk, fi, static_cast<uint*>(fx));
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(h_count, chunk + n_chunks, sizeof(uint), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = fetch_words(h_count, chunk + n_chunks, 1, s);
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "v_eadd_fdb (sparse) failed: %s", hipGetErrorString(e));
         return SPLAHIP_OK;
     }
@@ -248,8 +247,7 @@ namespace splahip {
         }
         hipError_t e      = hipGetLastError();
         uint       shared = 0;
-        if (e == hipSuccess && nv) e = hipMemcpyAsync(&shared, chunk_v + cv, sizeof(uint), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = fetch_words(&shared, chunk_v + cv, nv ? 1 : 0, s);
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "v_eadd (sparse) failed: %s", hipGetErrorString(e));
         *h_count = nu + nv - shared;
         return SPLAHIP_OK;
@@ -356,8 +354,7 @@ namespace splahip {
             hipLaunchKernelGGL(reduce_sequential_kernel<T>, dim3(1), dim3(64), 0, s, n, static_cast<const T*>(x), from_bits<T>(s_bits), out, DynBin(op));
         }
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(h_result, out, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = fetch_words(h_result, out, 1, s);
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "reduce failed: %s", hipGetErrorString(e));
         return SPLAHIP_OK;
     }
@@ -432,8 +429,7 @@ int splahip_v_count_mf_dense(int type, uint32_t n, const void* d_v, uint32_t fil
         e = hipGetLastError();
     }
     unsigned long long h = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&h, d_count, sizeof(h), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = fetch_words(&h, d_count, 2, s);
     if (e != hipSuccess) return fail(SPLAHIP_ERROR, "v_count_mf failed: %s", hipGetErrorString(e));
     *h_count = (uint32_t) h;
     return SPLAHIP_OK;

@@ -16,6 +16,7 @@
 #include "block_utils.hpp"
 #include "common.hpp"
 #include "jit_hooks.hpp"
+#include "mxv_first_hit.hpp"
 #include "mxv_kernels.hpp"
 #include "ops.hpp"
 #include "plan.hpp"
@@ -508,10 +509,41 @@ namespace splahip {
         if (((reinterpret_cast<uintptr_t>(Tj) | reinterpret_cast<uintptr_t>(Tx)) & 15u) != 0)
             return fail(SPLAHIP_INVALID_ARGUMENT, "the transposed CSR arrays must be 16-byte aligned");
         const uint grid   = (plan->n_items + Cfg::kWaves - 1) / Cfg::kWaves;
+        // A traversal's pull level (reference src/algorithm.cpp:93-99: BAND / BOR over an adjacency matrix, a frontier of equal values): every product is one
+        // word, so the first stored in-neighbour settles an output entry (mxv_first_hit.hpp, VXM mode) — taken when the owner of the transposed matrix said its
+        // values are one word (splahip_csr_plan_set_uniform_values) and the caller's product count (splahip_csr_plan_hint_products; the probe every caller of
+        // the pull form has run) says the frontier's rows hold at least 1 / SPLAHIP_PULL_FIRST_HIT_DEN (6) of the entries: a walk then ends within a few entries.
+        // The launch checks the stored values itself: a vector of several words is folded completely, in order.
+        uint32_t       xbits     = 0;
+        const uint64_t products  = plan->products_hint;
+        plan->products_hint      = 0;
+        bool           first_hit = false;
+        if constexpr (!std::is_same<T, float>::value) {
+            const char*    de  = knob_env("SPLAHIP_PULL_FIRST_HIT_DEN");
+            const uint64_t den = de && *de ? std::strtoull(de, nullptr, 10) : 6ull;
+            const char*    fe  = knob_env("SPLAHIP_FIRST_HIT");
+            first_hit = !v_is_identity && nvals != 0 && !(fe && fe[0] == '0') && first_hit_family(TypeId<T>::value, op_mult, op_add) && uniform_values(plan, n_in, &xbits) &&
+                        products != 0 && (den == 0 || products * den >= plan->nnz);
+        }
+        if (first_hit) {
+            if constexpr (!std::is_same<T, float>::value) {
+                uint* uf = ws_chunk + n_chunks + 2;// two spare words of the workspace: max(~word), max(word) over the stored values
+                SPLAHIP_TRY(hipMemsetAsync(uf, 0, 2 * sizeof(uint), s));
+                hipLaunchKernelGGL((vx_range_kernel<0>), dim3(std::min(64u, (nvals + 1023u) / 1024u)), dim3(256), 0, s, nvals, static_cast<const uint*>(vx), uf);
+                if (op_mult == SPLAHIP_BAND && op_add == SPLAHIP_BOR)
+                    hipLaunchKernelGGL((mxv_first_hit_kernel<T, StaBin<SPLAHIP_BAND>, StaBin<SPLAHIP_BOR>, true>), dim3((n_out + 255) / 256), dim3(256), 0, s, n_out, Tp, Tj,
+                                       static_cast<const T*>(mask), d_v, reinterpret_cast<T*>(ws_outv), StaBin<SPLAHIP_BAND>(), StaBin<SPLAHIP_BOR>(), op_select, T(0), xbits, uf,
+                                       d_present, ws_touched);
+                else
+                    hipLaunchKernelGGL((mxv_first_hit_kernel<T, DynBin, DynBin, true>), dim3((n_out + 255) / 256), dim3(256), 0, s, n_out, Tp, Tj, static_cast<const T*>(mask), d_v,
+                                       reinterpret_cast<T*>(ws_outv), DynBin(op_mult), DynBin(op_add), op_select, T(0), xbits, uf, d_present, ws_touched);
+            }
+        }
         // every index of v stored + a sliced-ELL copy on the transposed matrix's plan: the value-form kernel in its vxm mode
         const char* sell_env = knob_env("SPLAHIP_SELL");
         // every index of v stored + a column-ordered-blocks copy on the transposed matrix's plan: its kernel in vxm mode
-        if (v_is_identity && cob_vxm_serves(plan, TypeId<T>::value, op_add, n_in) &&
+        if (first_hit) {// (launched above)
+        } else if (v_is_identity && cob_vxm_serves(plan, TypeId<T>::value, op_add, n_in) &&
             ((reinterpret_cast<uintptr_t>(ws_outv) | reinterpret_cast<uintptr_t>(ws_touched) | reinterpret_cast<uintptr_t>(mask)) & 15u) == 0) {
             int st = cob_vxm(plan, TypeId<T>::value, Tp, mask, d_v, ws_outv, ws_touched, op_mult, op_add, op_select, s);
             if (st != SPLAHIP_OK) return st;
@@ -542,8 +574,7 @@ namespace splahip {
         hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, ws_chunk, n_chunks);
         hipLaunchKernelGGL(flag_write_kernel, dim3(n_chunks), dim3(256), 0, s, ws_touched, ws_outv, n_out, ws_chunk, ri, static_cast<uint*>(rx));
         SPLAHIP_TRY(hipGetLastError());
-        SPLAHIP_TRY(hipMemcpyAsync(h_count, ws_chunk + n_chunks, sizeof(uint), hipMemcpyDeviceToHost, s));
-        SPLAHIP_TRY(hipStreamSynchronize(s));
+        SPLAHIP_TRY(fetch_words(h_count, ws_chunk + n_chunks, 1, s));
         return SPLAHIP_OK;
     }
 
@@ -584,8 +615,7 @@ namespace splahip {
         hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, ws_chunk, n_chunks);
         hipLaunchKernelGGL(flag_write_kernel, dim3(n_chunks), dim3(256), 0, s, ws_touched, ws_outv, n_out, ws_chunk, ri, static_cast<uint*>(rx));
         SPLAHIP_TRY(hipGetLastError());
-        SPLAHIP_TRY(hipMemcpyAsync(h_count, ws_chunk + n_chunks, sizeof(uint), hipMemcpyDeviceToHost, s));
-        SPLAHIP_TRY(hipStreamSynchronize(s));
+        SPLAHIP_TRY(fetch_words(h_count, ws_chunk + n_chunks, 1, s));
         return SPLAHIP_OK;
     }
 
@@ -632,8 +662,7 @@ namespace splahip {
         hipLaunchKernelGGL(acc_write_reset_kernel, dim3(n_chunks), dim3(256), 0, s, gate, max_products, ws.acc, n_cols, chunk, ri, static_cast<uint*>(rx));
         SPLAHIP_TRY(hipGetLastError());
         uint h[5] = {0, 0, 0, 0, 0};// products lo, hi, unsorted, count, NaN seen
-        SPLAHIP_TRY(hipMemcpyAsync(h, gate, 5 * sizeof(uint), hipMemcpyDeviceToHost, s));
-        SPLAHIP_TRY(hipStreamSynchronize(s));
+        SPLAHIP_TRY(fetch_words(h, gate, 5, s));
         h_out[0] = h[3], h_out[1] = h[0], h_out[2] = h[1], h_out[3] = h[2], h_out[4] = h[4];
         return SPLAHIP_OK;
     }
@@ -664,8 +693,7 @@ namespace splahip {
         SPLAHIP_TRY(exclusive_scan_u32(len, nvals, offs, s));
         uint n_products = (uint) products_hint;
         if (products_hint == 0) {
-            SPLAHIP_TRY(hipMemcpyAsync(&n_products, offs + nvals, sizeof(uint), hipMemcpyDeviceToHost, s));
-            SPLAHIP_TRY(hipStreamSynchronize(s));
+            SPLAHIP_TRY(fetch_words(&n_products, offs + nvals, 1, s));
         }
         if (n_products == 0) return SPLAHIP_OK;
 
@@ -685,8 +713,7 @@ namespace splahip {
             hipLaunchKernelGGL(acc_write_kernel, dim3(n_chunks), dim3(256), 0, s, acc, n_cols, chunk, ri, static_cast<uint*>(rx));
             SPLAHIP_TRY(hipGetLastError());
             uint h[2] = {0, 0};// count, NaN seen
-            SPLAHIP_TRY(hipMemcpyAsync(h, chunk + n_chunks, 2 * sizeof(uint), hipMemcpyDeviceToHost, s));
-            SPLAHIP_TRY(hipStreamSynchronize(s));
+            SPLAHIP_TRY(fetch_words(h, chunk + n_chunks, 2, s));
             if (h[1] == 0) {
                 *h_count = h[0];
                 return SPLAHIP_OK;
@@ -733,8 +760,7 @@ namespace splahip {
             hipLaunchKernelGGL((long_run_kernel<T, DynBin, false>), dim3(grid), dim3(256), 0, s, key_b, reinterpret_cast<const T*>(val_b), n_products, lcount, lpos,
                                lrank, static_cast<T*>(rx), DynBin(op_add));
         SPLAHIP_TRY(hipGetLastError());
-        SPLAHIP_TRY(hipMemcpyAsync(h_count, chunk + n_chunks, sizeof(uint), hipMemcpyDeviceToHost, s));
-        SPLAHIP_TRY(hipStreamSynchronize(s));
+        SPLAHIP_TRY(fetch_words(h_count, chunk + n_chunks, 1, s));
         return SPLAHIP_OK;
     }
 
@@ -782,8 +808,7 @@ int splahip_vxm_probe(uint32_t nvals, const uint32_t* d_vi, const uint32_t* d_Ap
                        reinterpret_cast<uint*>(acc.as<unsigned long long>() + 1));
     SPLAHIP_TRY(hipGetLastError());
     unsigned long long h[2] = {0, 0};
-    SPLAHIP_TRY(hipMemcpyAsync(h, acc.p, 16, hipMemcpyDeviceToHost, s));
-    SPLAHIP_TRY(hipStreamSynchronize(s));
+    SPLAHIP_TRY(fetch_words(h, acc.p, 4, s));
     *h_products = h[0];
     *h_sorted   = (h[1] & 0xffffffffull) ? 0 : 1;
     return SPLAHIP_OK;

@@ -82,6 +82,14 @@ class CsrPlan:
         _lib.call("splahip_csr_plan_cob_probe", self._h, C.byref(se), C.byref(by))
         return {"selected_entries": se.value, "served_by_rows": bool(by.value)}
 
+    def set_uniform_values(self, is_uniform: bool, value_bits: int = 0):
+        """the owner of the value array says: every stored value is the word `value_bits` (or not)"""
+        _lib.call("splahip_csr_plan_set_uniform_values", self._h, 1 if is_uniform else 0, int(value_bits) & 0xFFFFFFFF)
+
+    def hint_products(self, products: int):
+        """products of the next vxm_pull over this (transposed) plan (vxm_probe's count)"""
+        _lib.call("splahip_csr_plan_hint_products", self._h, int(products))
+
     def first_hit(self):
         """what the plan's last BFS-like call did (mxv_first_hit.hpp): {"taken": ran on the first-hit kernel, "uniform": verdict of the last finished pass over
         v (None: none yet), "nonzeros": its non-zero count, "tail_pct": share of the sampled selected entries in rows the walk would enter past their fourth entry}"""

@@ -226,3 +226,33 @@ def test_fp32_min_max_nan_products_every_form(oracle, add, monkeypatch):
                 got = _pull(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, "PLUS", add, sel, identity=(nv == n_rows), sell=form)
                 np.testing.assert_array_equal(got[0], want[0], err_msg=f"pull idx sell={form}")
                 np.testing.assert_array_equal(got[1].view(np.uint32), want[1].view(np.uint32), err_msg=f"pull val sell={form} nv={nv}")
+
+
+@pytest.mark.parametrize("t,mul,add,xval", [("INT", "BAND", "BOR", 1), ("UINT", "MULT", "MAX", 3), ("INT", "LAND", "BOR", 7)])
+def test_pull_first_hit_form_of_a_traversal_level(oracle, t, mul, add, xval):
+    """The pull form of a traversal's level (reference src/algorithm.cpp:93-99) settles an output entry at its first stored in-neighbour (mxv_first_hit.hpp, VXM
+    mode) when the transposed matrix's owner said its values are one word and the caller's product count says the frontier's rows hold much of the matrix; the
+    launch checks the frontier's stored values itself — several words: the complete fold.  Same index-sorted COO as the reference in every case, explicit zeros
+    among the stored values included (they are products like any other)."""
+    from gpu_utils import dev, host
+    from spla_amd import kernels
+    rng = np.random.default_rng(4711)
+    n_rows, n_cols = 3000, 2600
+    Ap, Aj, _ = random_csr(rng, n_rows, n_cols, 10, "INT", skew=True, long_rows=4, long_len=2000)
+    Ax = np.full(len(Aj), xval, NP[t])
+    dAp, dAj, dAx = dev(Ap), dev(Aj), dev(Ax)
+    Tp, Tj, Tx = kernels.csr_transpose(n_rows, n_cols, dAp, dAj, dAx)
+    plan = kernels.CsrPlan(n_cols, len(Aj), Tp)
+    plan.set_uniform_values(True, xval)
+    deg = np.diff(Ap.astype(np.int64))
+    for dens, values in ((0.5, "one"), (0.5, "zero"), (0.5, "mixed"), (0.02, "one"), (1.0, "one")):
+        vi = np.nonzero(rng.random(n_rows) < dens)[0].astype(np.uint32)
+        vx = {"one": np.full(len(vi), 2, NP[t]), "zero": np.zeros(len(vi), NP[t]), "mixed": rng.integers(0, 5, len(vi)).astype(NP[t])}[values]
+        for sel in ("EQZERO", "ALWAYS"):
+            mask = (rng.random(n_cols) < 0.3).astype(NP[t])
+            wi, wx = oracle.vxm_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, mul, add, sel)
+            for hint in (int(deg[vi].sum()), 0):  # with the probe's count (first hit where the frontier is heavy enough) and without (the wave-tile kernels)
+                plan.hint_products(hint)
+                ri, rx = kernels.vxm_pull(plan, t, n_rows, n_cols, Tp, Tj, Tx, dev(mask), dev(vi), dev(vx), mul, add, sel, identity=len(vi) == n_rows)
+                assert np.array_equal(host(ri, np.uint32), wi) and np.array_equal(host(rx, NP[t]), wx), (dens, values, sel, hint)
+    plan.close()
