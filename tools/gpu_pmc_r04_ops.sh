@@ -29,16 +29,20 @@ PY
 run sssp_step "cob_mxv_kernel<int" "cob_hub_finish_kernel<int|cob_vbits_kernel<int" python3 "$R/bench.py" --workload sssp-step --steps 5 --warmup 2 --no-cpu-baseline --no-verify
 run pagerank_vxm_orkut_like "cob_mxv_kernel<float" "cob_hub_finish_kernel<float|flag_write_kernel" python3 "$R/bench.py" --workload pagerank-vxm --steps 5 --warmup 2 --no-cpu-baseline --no-verify
 # the BFS step of configs[1] (profiles/pmc_traffic.json was round 2's pass): the three kernels of the sliced-ELL bit form
-run bfs_step "sell_mxv_dual_kernel<int" "sell_vprep_kernel<int|sell_post_kernel<int" python3 "$R/bench.py" --workload bfs-step --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-variants
+# (round 4: the step runs on the first-hit kernel; the sliced-ELL form of the same step with SPLAHIP_FIRST_HIT=0)
+run bfs_step "mxv_first_hit_kernel<int" "vstat_kernel<int" python3 "$R/bench.py" --workload bfs-step --steps 10 --warmup 3 --no-cpu-baseline --no-verify --no-variants
+export SPLAHIP_FIRST_HIT=0
+run bfs_step_sell "sell_mxv_dual_kernel<int" "sell_vprep_kernel<int|sell_post_kernel<int" python3 "$R/bench.py" --workload bfs-step --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-variants
+unset SPLAHIP_FIRST_HIT
 python3 - "$R/gpurun_out/r04_pmc_bfs_step.json" "$R/gpurun_out/r04_pmc_traffic.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); pc = d["_per_call"]
 n, nnz, nnz_sel = 4194304, 65244781, 28570647
 alg = 4 * nnz_sel + 4 * (n + 1) + 4 * n + 4 * n + 4 * n
-out = {"kernel": "sell_vprep_kernel<int>|sell_mxv_dual_kernel<int>|sell_post_kernel<int>", "traffic_bytes": pc["traffic_bytes"], "algorithmic_bytes": alg,
+out = {"kernel": "vstat_kernel<int>|mxv_first_hit_kernel<int>", "traffic_bytes": pc["traffic_bytes"], "algorithmic_bytes": alg,
        "traffic_over_algorithmic": round(pc["traffic_bytes"] / alg, 3), "tcp_tcc_read_req": pc["tcp_tcc_read_req"], "config": {"n": n, "nnz": nnz, "nnz_selected": nnz_sel},
        "method": "round 4: tools/gpu_pmc_r04_ops.sh - rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCP_TCC_READ_REQ in separate passes (with --kernel-trace only) of `python3 bench.py --workload bfs-step --steps 10 "
-                 "--warmup 2 --no-cpu-baseline --no-verify --no-variants`; per-kernel medians by tools/pmc_kernels.py (profiles/r04_pmc_bfs_step.json); traffic = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024",
+                 "--warmup 2 --no-cpu-baseline --no-verify --no-variants`; per-kernel medians by tools/pmc_kernels.py (profiles/r04_pmc_bfs_step.json; the sliced-ELL form of the same step: r04_pmc_bfs_step_sell.json); traffic = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024",
        "per_kernel": {k: v for k, v in d.items() if not k.startswith("_")}}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("traffic_bytes", "algorithmic_bytes", "traffic_over_algorithmic")}))
