@@ -349,6 +349,21 @@ int splahip_reduce(int type, uint32_t n, const void* d_x, uint32_t s_bits, uint3
 int splahip_m_transpose(int type, uint32_t n_rows, uint32_t n_cols, uint32_t nnz, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax,
                         uint32_t* d_Rp, uint32_t* d_Rj, void* d_Rx, int op_apply, void* stream);
 int splahip_map(int type, uint32_t n, const void* d_x, void* d_out, int op, void* stream);
+/* The vector operations with USER-DEFINED ops (OpBinary::make_* / OpSelect::make_* / OpUnary::make_*, reference src/op.cpp:294-317): *_src is the op's body text
+ * "(T a, T b) { ... }" / "(T a) { ... }" with T spelled int / uint / float, compiled at run time (hiprtc) into the element-wise kernel of the operation; a NULL
+ * source where an id is also taken means the built-in op with that id.  Same semantics, formats and outputs as the built-in entry points above; the reduce folds
+ * strictly left to right from s (a user op need not be associative).  Status 8 = the body does not compile (the reference's Status::CompilationError).
+ * splahip_v_assign_masked_jit: sparse != 0: d_mi / d_mask = the mask's stored indices / values (n of them); else d_mask = its dense image (d_mi unused). */
+int splahip_v_assign_masked_jit(int type, int sparse, uint32_t n, void* d_r, const uint32_t* d_mi, const void* d_mask, uint32_t value_bits, int op_assign,
+                                const char* assign_src, int op_select, const char* select_src, void* stream);
+int splahip_v_eadd_fdb_dense_jit(int type, uint32_t n, void* d_r, const void* d_v, void* d_fdb, uint32_t fdb_fill_bits, const char* op_src, void* stream);
+int splahip_v_eadd_fdb_sparse_jit(int type, uint32_t nvals, void* d_r, const uint32_t* d_vi, const void* d_vx, uint32_t* d_fi, void* d_fx, uint32_t* h_count,
+                                  const char* op_src, void* stream);
+int splahip_v_eadd_dense_jit(int type, uint32_t n, void* d_r, const void* d_u, const void* d_v, const char* op_src, void* stream);
+int splahip_v_eadd_sparse_jit(int type, uint32_t nu, const uint32_t* d_ui, const void* d_ux, uint32_t u_fill_bits, uint32_t nv, const uint32_t* d_vi, const void* d_vx,
+                              uint32_t v_fill_bits, uint32_t* d_ri, void* d_rx, uint32_t* h_count, const char* op_src, void* stream);
+int splahip_reduce_jit(int type, uint32_t n, const void* d_x, uint32_t s_bits, uint32_t* h_result_bits, const char* op_src, void* stream);
+int splahip_map_jit(int type, uint32_t n, const void* d_x, void* d_out, const char* op_src, void* stream);
 
 /* ---- accelerator vector formats ------------------------------------------------------------------------------
  * AccDense <-> AccCoo (reference src/opencl/cl_format_dense_vec.hpp:90-143, cl_format_coo_vec.hpp:149-158).

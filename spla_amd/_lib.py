@@ -32,6 +32,13 @@ _SIGNATURES = {
     "splahip_last_error": (C.c_char_p, []),
     "splahip_version": (C.c_int, []),
     "splahip_env_refresh": (C.c_int, []),
+    "splahip_v_assign_masked_jit": (C.c_int, [C.c_int, C.c_int, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.c_int, C.c_char_p, C.c_int, C.c_char_p, _vp]),
+    "splahip_v_eadd_fdb_dense_jit": (C.c_int, [C.c_int, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.c_char_p, _vp]),
+    "splahip_v_eadd_fdb_sparse_jit": (C.c_int, [C.c_int, C.c_uint32, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32), C.c_char_p, _vp]),
+    "splahip_v_eadd_dense_jit": (C.c_int, [C.c_int, C.c_uint32, _vp, _vp, _vp, C.c_char_p, _vp]),
+    "splahip_v_eadd_sparse_jit": (C.c_int, [C.c_int, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32), C.c_char_p, _vp]),
+    "splahip_reduce_jit": (C.c_int, [C.c_int, C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.c_char_p, _vp]),
+    "splahip_map_jit": (C.c_int, [C.c_int, C.c_uint32, _vp, _vp, C.c_char_p, _vp]),
     "splahip_csr_plan_set_uniform_values": (C.c_int, [_vp, C.c_int, C.c_uint32]),
     "splahip_words_range": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _vp]),
     "splahip_csr_plan_hint_products": (C.c_int, [_vp, C.c_uint64]),

@@ -430,8 +430,10 @@ namespace spla {
                 auto value = t->value.template cast_safe<TScalar<T>>();
                 const int op_assign = device_binop<T>(t->op_assign);
                 const int op_sel    = device_selop<T>(t->op_select);
-                if (op_assign < 0 || op_sel < 0) return Status::NotImplemented;
                 if (r->get_n_rows() != mask->get_n_rows()) return Status::InvalidArgument;
+                // a user-defined op (OpBinary::make_* / OpSelect::make_*): its body text is compiled for the device at run time (jit.hip), like the hot-path operators'
+                const bool        user = op_assign < 0 || op_sel < 0;
+                const std::string sa = op_assign < 0 ? t->op_assign->get_source_cl() : std::string(), ss = op_sel < 0 ? t->op_select->get_source_cl() : std::string();
                 // sparse mask when its COO is valid, dense when only its dense image is, sparse otherwise (cpu_v_assign.hpp:59-64):
                 // the two forms differ on absent entries (the dense form applies op_select to the fill value)
                 const bool sparse = coo_valid(mask.get()) || !dense_valid(mask.get());
@@ -439,11 +441,21 @@ namespace spla {
                 if (sparse) {
                     mask->validate_rw(FormatVector::AccCoo);
                     auto* m = mask->acc_coo();
+                    if (user)
+                        return jit_status(splahip_v_assign_masked_jit(TypeTraits<T>::id, 1, m->values, r->acc_dense()->Ax.ptr(), m->Ai.template as<uint32_t>(), m->Ax.ptr(),
+                                                                      word_of(value->get_value()), op_assign, op_assign < 0 ? sa.c_str() : nullptr, op_sel,
+                                                                      op_sel < 0 ? ss.c_str() : nullptr, nullptr),
+                                          "splahip_v_assign_masked_jit");
                     hip_check(splahip_v_assign_masked_sparse(TypeTraits<T>::id, m->values, r->acc_dense()->Ax.ptr(), m->Ai.template as<uint32_t>(), m->Ax.ptr(),
                                                              word_of(value->get_value()), op_assign, op_sel, nullptr),
                               "splahip_v_assign_masked_sparse");
                 } else {
                     mask->validate_rw(FormatVector::AccDense);
+                    if (user)
+                        return jit_status(splahip_v_assign_masked_jit(TypeTraits<T>::id, 0, r->get_n_rows(), r->acc_dense()->Ax.ptr(), nullptr, mask->acc_dense()->Ax.ptr(),
+                                                                      word_of(value->get_value()), op_assign, op_assign < 0 ? sa.c_str() : nullptr, op_sel,
+                                                                      op_sel < 0 ? ss.c_str() : nullptr, nullptr),
+                                          "splahip_v_assign_masked_jit");
                     hip_check(splahip_v_assign_masked_dense(TypeTraits<T>::id, r->get_n_rows(), r->acc_dense()->Ax.ptr(), mask->acc_dense()->Ax.ptr(),
                                                             word_of(value->get_value()), op_assign, op_sel, nullptr),
                               "splahip_v_assign_masked_dense");
@@ -463,7 +475,7 @@ namespace spla {
                 auto v   = t->v.template cast_safe<TVector<T>>();
                 auto fdb = t->fdb.template cast_safe<TVector<T>>();
                 const int op = device_binop<T>(t->op);
-                if (op < 0) return Status::NotImplemented;
+                const std::string src = op < 0 ? t->op->get_source_cl() : std::string();// a user-defined op: compiled for the device at run time (jit.hip)
                 if (r->get_n_rows() != v->get_n_rows() || r->get_n_rows() != fdb->get_n_rows()) return Status::InvalidArgument;
                 // sp2dn when r is dense and v's COO is valid, dn2dn when both are dense, sp2dn otherwise (cpu_v_eadd_fdb.hpp:60-67)
                 const bool r_dense = dense_valid(r.get());
@@ -476,6 +488,13 @@ namespace spla {
                     uint32_t count = 0;
                     out->Ai.reserve(in->values);
                     out->Ax.reserve(in->values);
+                    if (op < 0) {
+                        const Status js = jit_status(splahip_v_eadd_fdb_sparse_jit(TypeTraits<T>::id, in->values, r->acc_dense()->Ax.ptr(), in->Ai.template as<uint32_t>(), in->Ax.ptr(),
+                                                                                   out->Ai.template as<uint32_t>(), out->Ax.ptr(), &count, src.c_str(), nullptr),
+                                                     "splahip_v_eadd_fdb_sparse_jit");
+                        if (js == Status::Ok) out->values = count;
+                        return js;
+                    }
                     hip_check(splahip_v_eadd_fdb_sparse(TypeTraits<T>::id, in->values, r->acc_dense()->Ax.ptr(), in->Ai.template as<uint32_t>(), in->Ax.ptr(),
                                                         out->Ai.template as<uint32_t>(), out->Ax.ptr(), &count, op, nullptr),
                               "splahip_v_eadd_fdb_sparse");
@@ -483,6 +502,10 @@ namespace spla {
                 } else {
                     v->validate_rw(FormatVector::AccDense);
                     fdb->validate_wd(FormatVector::AccDense);
+                    if (op < 0)
+                        return jit_status(splahip_v_eadd_fdb_dense_jit(TypeTraits<T>::id, r->get_n_rows(), r->acc_dense()->Ax.ptr(), v->acc_dense()->Ax.ptr(),
+                                                                       fdb->acc_dense()->Ax.ptr(), word_of(fdb->get_fill_value()), src.c_str(), nullptr),
+                                          "splahip_v_eadd_fdb_dense_jit");
                     hip_check(splahip_v_eadd_fdb_dense(TypeTraits<T>::id, r->get_n_rows(), r->acc_dense()->Ax.ptr(), v->acc_dense()->Ax.ptr(),
                                                        fdb->acc_dense()->Ax.ptr(), word_of(fdb->get_fill_value()), op, nullptr),
                               "splahip_v_eadd_fdb_dense");
@@ -530,7 +553,7 @@ namespace spla {
                 auto u = t->u.template cast_safe<TVector<T>>();
                 auto v = t->v.template cast_safe<TVector<T>>();
                 const int op = device_binop<T>(t->op);
-                if (op < 0) return Status::NotImplemented;
+                const std::string src = op < 0 ? t->op->get_source_cl() : std::string();// a user-defined op: compiled for the device at run time (jit.hip)
                 if (r->get_n_rows() != u->get_n_rows() || r->get_n_rows() != v->get_n_rows()) return Status::InvalidArgument;
                 // sparse x sparse when both COO images are valid, dense x dense when both dense images are, sparse otherwise (cpu_v_eadd.hpp:59-66)
                 const bool dense = !(coo_valid(u.get()) && coo_valid(v.get())) && dense_valid(u.get()) && dense_valid(v.get());
@@ -540,6 +563,10 @@ namespace spla {
                     if (r.get() != u.get() && r.get() != v.get()) r->validate_wd(FormatVector::AccDense);
                     else
                         r->validate_rwd(FormatVector::AccDense);// in place: keep the operand's image, drop its other formats
+                    if (op < 0)
+                        return jit_status(splahip_v_eadd_dense_jit(TypeTraits<T>::id, r->get_n_rows(), r->acc_dense()->Ax.ptr(), u->acc_dense()->Ax.ptr(), v->acc_dense()->Ax.ptr(),
+                                                                   src.c_str(), nullptr),
+                                          "splahip_v_eadd_dense_jit");
                     hip_check(splahip_v_eadd_dense(TypeTraits<T>::id, r->get_n_rows(), r->acc_dense()->Ax.ptr(), u->acc_dense()->Ax.ptr(), v->acc_dense()->Ax.ptr(), op, nullptr),
                               "splahip_v_eadd_dense");
                     return Status::Ok;
@@ -552,6 +579,14 @@ namespace spla {
                 uint32_t count = 0;
                 out->Ai.reserve(a->values + b->values);
                 out->Ax.reserve(a->values + b->values);
+                if (op < 0) {
+                    const Status js = jit_status(splahip_v_eadd_sparse_jit(TypeTraits<T>::id, a->values, a->Ai.template as<uint32_t>(), a->Ax.ptr(), word_of(u->get_fill_value()),
+                                                                           b->values, b->Ai.template as<uint32_t>(), b->Ax.ptr(), word_of(v->get_fill_value()),
+                                                                           out->Ai.template as<uint32_t>(), out->Ax.ptr(), &count, src.c_str(), nullptr),
+                                                 "splahip_v_eadd_sparse_jit");
+                    if (js == Status::Ok) out->values = count;
+                    return js;
+                }
                 hip_check(splahip_v_eadd_sparse(TypeTraits<T>::id, a->values, a->Ai.template as<uint32_t>(), a->Ax.ptr(), word_of(u->get_fill_value()), b->values,
                                                 b->Ai.template as<uint32_t>(), b->Ax.ptr(), word_of(v->get_fill_value()), out->Ai.template as<uint32_t>(),
                                                 out->Ax.ptr(), &count, op, nullptr),
@@ -572,7 +607,7 @@ namespace spla {
                 auto s = t->s.template cast_safe<TScalar<T>>();
                 auto v = t->v.template cast_safe<TVector<T>>();
                 const int op = device_binop<T>(t->op_reduce);
-                if (op < 0) return Status::NotImplemented;
+                const std::string src = op < 0 ? t->op_reduce->get_source_cl() : std::string();// a user-defined op: compiled for the device at run time (jit.hip)
                 // the stored values of the sparse image when it is valid, every entry of the dense image when only that is (cpu_v_reduce.hpp:58-67)
                 const bool  sparse = coo_valid(v.get()) || !dense_valid(v.get());
                 uint32_t    bits   = 0, n;
@@ -585,6 +620,11 @@ namespace spla {
                     v->validate_rw(FormatVector::AccDense);
                     n = v->get_n_rows();
                     x = v->acc_dense()->Ax.ptr();
+                }
+                if (op < 0) {
+                    const Status js = jit_status(splahip_reduce_jit(TypeTraits<T>::id, n, x, word_of(s->get_value()), &bits, src.c_str(), nullptr), "splahip_reduce_jit");
+                    if (js == Status::Ok) r->set_value(value_of_word<T>(bits));
+                    return js;
                 }
                 hip_check(splahip_reduce(TypeTraits<T>::id, n, x, word_of(s->get_value()), &bits, op, nullptr), "splahip_reduce");
                 r->set_value(value_of_word<T>(bits));
@@ -603,9 +643,15 @@ namespace spla {
                 auto s = t->s.template cast_safe<TScalar<T>>();
                 auto M = t->M.template cast_safe<TMatrix<T>>();
                 const int op = device_binop<T>(t->op_reduce);
-                if (op < 0) return Status::NotImplemented;
                 M->validate_rw(FormatMatrix::AccCsr);// values in row-major order (cpu_m_reduce.hpp:134-156)
                 uint32_t bits = 0;
+                if (op < 0) {// a user-defined op: compiled for the device at run time (jit.hip)
+                    const std::string src = t->op_reduce->get_source_cl();
+                    const Status      js  = jit_status(splahip_reduce_jit(TypeTraits<T>::id, M->acc_csr()->values, M->acc_csr()->Ax.ptr(), word_of(s->get_value()), &bits, src.c_str(), nullptr),
+                                                       "splahip_reduce_jit");
+                    if (js == Status::Ok) r->set_value(value_of_word<T>(bits));
+                    return js;
+                }
                 hip_check(splahip_reduce(TypeTraits<T>::id, M->acc_csr()->values, M->acc_csr()->Ax.ptr(), word_of(s->get_value()), &bits, op, nullptr), "splahip_reduce");
                 r->set_value(value_of_word<T>(bits));
                 return Status::Ok;
@@ -624,10 +670,6 @@ namespace spla {
                 auto R = t->R.template cast_safe<TMatrix<T>>();
                 auto M = t->M.template cast_safe<TMatrix<T>>();
                 const int op = device_unop<T>(t->op_apply);
-                if (op < 0) {
-                    SPLA_LOG(Status::NotImplemented, "user-defined ops have no device code in this build");
-                    return Status::NotImplemented;
-                }
                 if (R->get_n_rows() != M->get_n_cols() || R->get_n_cols() != M->get_n_rows() || R.get() == M.get()) return Status::InvalidArgument;
                 R->validate_wd(FormatMatrix::AccCsr);
                 M->validate_rw(FormatMatrix::AccCsr);
@@ -638,9 +680,13 @@ namespace spla {
                 r->Ax.reserve(m->values);
                 hip_check(splahip_m_transpose(TypeTraits<T>::id, M->get_n_rows(), M->get_n_cols(), m->values, m->Ap.template as<uint32_t>(),
                                               m->Aj.template as<uint32_t>(), m->Ax.ptr(), r->Ap.template as<uint32_t>(), r->Aj.template as<uint32_t>(),
-                                              r->Ax.ptr(), op, nullptr),
+                                              r->Ax.ptr(), op < 0 ? SPLAHIP_IDENTITY : op, nullptr),
                           "splahip_m_transpose");
                 r->values = m->values;
+                if (op < 0) {// a user-defined op: the transposed values go through the run-time-compiled map (jit.hip)
+                    const std::string src = t->op_apply->get_source_cl();
+                    return jit_status(splahip_map_jit(TypeTraits<T>::id, r->values, r->Ax.ptr(), r->Ax.ptr(), src.c_str(), nullptr), "splahip_map_jit");
+                }
                 return Status::Ok;
             }
         };
@@ -656,10 +702,7 @@ namespace spla {
                 auto r = t->r.template cast_safe<TVector<T>>();
                 auto v = t->v.template cast_safe<TVector<T>>();
                 const int op = device_unop<T>(t->op);
-                if (op < 0) {
-                    SPLA_LOG(Status::NotImplemented, "user-defined ops have no device code in this build");
-                    return Status::NotImplemented;
-                }
+                const std::string src = op < 0 ? t->op->get_source_cl() : std::string();// a user-defined op: compiled for the device at run time (jit.hip)
                 if (r->get_n_rows() != v->get_n_rows()) return Status::InvalidArgument;
                 const bool sparse = coo_valid(v.get()) || !dense_valid(v.get());
                 if (sparse) {
@@ -674,13 +717,16 @@ namespace spla {
                         out->Ax.reserve(n);
                         if (n) hip_check(splahip_memcpy_d2d(out->Ai.ptr(), in->Ai.ptr(), std::size_t(n) * 4, nullptr), "index copy");
                     }
-                    hip_check(splahip_map(TypeTraits<T>::id, n, in->Ax.ptr(), out->Ax.ptr(), op, nullptr), "splahip_map");
                     out->values = n;
+                    if (op < 0) return jit_status(splahip_map_jit(TypeTraits<T>::id, n, in->Ax.ptr(), out->Ax.ptr(), src.c_str(), nullptr), "splahip_map_jit");
+                    hip_check(splahip_map(TypeTraits<T>::id, n, in->Ax.ptr(), out->Ax.ptr(), op, nullptr), "splahip_map");
                 } else {
                     v->validate_rw(FormatVector::AccDense);
                     if (r.get() != v.get()) r->validate_wd(FormatVector::AccDense);
                     else
                         r->validate_rwd(FormatVector::AccDense);
+                    if (op < 0)
+                        return jit_status(splahip_map_jit(TypeTraits<T>::id, v->get_n_rows(), v->acc_dense()->Ax.ptr(), r->acc_dense()->Ax.ptr(), src.c_str(), nullptr), "splahip_map_jit");
                     hip_check(splahip_map(TypeTraits<T>::id, v->get_n_rows(), v->acc_dense()->Ax.ptr(), r->acc_dense()->Ax.ptr(), op, nullptr), "splahip_map");
                 }
                 return Status::Ok;

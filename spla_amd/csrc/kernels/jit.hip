@@ -257,6 +257,70 @@ namespace {
         return s;
     }
 
+    // ---- the vector operations around the hot path with user-defined ops: element-wise kernels, one lane per element / stored entry ----------
+    // reference src/cpu/cpu_v_assign.hpp:68-132, cpu_v_eadd_fdb.hpp:71-139, cpu_v_eadd.hpp:70-157, cpu_v_reduce.hpp:69-117, cpu_v_map.hpp:57-68
+    std::string vector_source(int type, int op, const char* op_src, int op_select, const char* select_src) {
+        std::string s = "typedef unsigned int uint;\n";
+        s += std::string("typedef ") + type_text(type) + " T;\n";
+        s += binary_fn("op_user", type, op, op_src);
+        s += select_fn(op_select, select_src);
+        s += "extern \"C\" __global__ void __launch_bounds__(256) splahip_assign_dense_jit(uint n, T* __restrict__ r, const T* __restrict__ mask, T value) {\n"
+             "    const uint i = blockIdx.x * 256u + threadIdx.x;\n"
+             "    if (i < n && op_select(mask[i])) r[i] = op_user(r[i], value);\n"
+             "}\n"
+             "extern \"C\" __global__ void __launch_bounds__(256) splahip_assign_sparse_jit(uint nvals, T* __restrict__ r, const uint* __restrict__ mi, const T* __restrict__ mx, T value) {\n"
+             "    const uint k = blockIdx.x * 256u + threadIdx.x;\n"
+             "    if (k < nvals && op_select(mx[k])) { const uint i = mi[k]; r[i] = op_user(r[i], value); }\n"
+             "}\n"
+             "extern \"C\" __global__ void __launch_bounds__(256) splahip_eadd_fdb_dense_jit(uint n, T* __restrict__ r, const T* __restrict__ v, T* __restrict__ fdb, T fdb_fill) {\n"
+             "    const uint i = blockIdx.x * 256u + threadIdx.x;\n"
+             "    if (i >= n) return;\n"
+             "    const T prev = r[i];\n"
+             "    const T next = op_user(prev, v[i]);\n"
+             "    r[i]   = next;\n"
+             "    fdb[i] = prev != next ? next : fdb_fill;\n"
+             "}\n"
+             "extern \"C\" __global__ void __launch_bounds__(256) splahip_eadd_fdb_apply_jit(uint nvals, T* __restrict__ r, const uint* __restrict__ vi, const T* __restrict__ vx,\n"
+             "        uint* __restrict__ changed, T* __restrict__ newval) {\n"
+             "    const uint k = blockIdx.x * 256u + threadIdx.x;\n"
+             "    if (k >= nvals) return;\n"
+             "    const uint i    = vi[k];\n"
+             "    const T    prev = r[i];\n"
+             "    const T    next = op_user(prev, vx[k]);\n"
+             "    r[i]       = next;\n"
+             "    changed[k] = prev != next ? 1u : 0u;\n"
+             "    newval[k]  = next;\n"
+             "}\n"
+             "extern \"C\" __global__ void __launch_bounds__(256) splahip_eadd_dense_jit(uint n, T* __restrict__ r, const T* __restrict__ u, const T* __restrict__ v) {\n"
+             "    const uint i = blockIdx.x * 256u + threadIdx.x;\n"
+             "    if (i < n) r[i] = op_user(u[i], v[i]);\n"
+             "}\n"
+             // the reference's strict left fold from s (a user op need not be associative): 64 lanes fetch 1024 elements, lane 0 folds them in order out of LDS
+             "extern \"C\" __global__ void __launch_bounds__(64) splahip_reduce_jit(uint n, const T* __restrict__ x, T s, T* __restrict__ out) {\n"
+             "    __shared__ T s_buf[1024];\n"
+             "    T sum = s;\n"
+             "    for (uint base = 0; base < n; base += 1024u) {\n"
+             "        const uint len = n - base < 1024u ? n - base : 1024u;\n"
+             "        for (uint k = threadIdx.x; k < len; k += 64u) s_buf[k] = x[base + k];\n"
+             "        __syncthreads();\n"
+             "        if (threadIdx.x == 0) for (uint k = 0; k < len; ++k) sum = op_user(sum, s_buf[k]);\n"
+             "        __syncthreads();\n"
+             "    }\n"
+             "    if (threadIdx.x == 0) out[0] = sum;\n"
+             "}\n";
+        return s;
+    }
+    std::string map_source(int type, const char* op_src) {
+        std::string s = "typedef unsigned int uint;\n";
+        s += std::string("typedef ") + type_text(type) + " T;\n";
+        s += std::string("__device__ __forceinline__ T op_apply") + op_src + "\n";
+        s += "extern \"C\" __global__ void __launch_bounds__(256) splahip_map_jit(uint n, const T* __restrict__ x, T* __restrict__ out) {\n"
+             "    const uint i = blockIdx.x * 256u + threadIdx.x;\n"
+             "    if (i < n) out[i] = op_apply(x[i]);\n"
+             "}\n";
+        return s;
+    }
+
     std::mutex                                     g_jit_lock;
     std::unordered_map<std::string, hipFunction_t> g_jit_cache;// full source text -> kernel (modules stay loaded for the life of the process)
 
@@ -395,5 +459,118 @@ int splahip_mxm_jit(int type, uint32_t a_rows, uint32_t b_cols, const uint32_t* 
     if (st == SPLAHIP_OK) st = compile(src, "splahip_mxm_run_jit", &run);
     if (st != SPLAHIP_OK) return st;
     return mxm_jit(a_rows, b_cols, d_Ap, d_Aj, d_Ax, d_Bp, d_Bj, d_Bx, d_Rp, d_Rj, d_Rx, h_nnz, init_bits, expand, run, as_stream(stream));
+}
+
+// ---- the vector operations with user-defined ops (op_src / select_src: the op's body text; NULL = the built-in op with that id) -----------------------------
+namespace {
+    int vector_kernel(int type, int op, const char* op_src, int op_select, const char* select_src, const char* name, hipFunction_t* fn) {
+        SPLAHIP_REQUIRE(type == SPLAHIP_INT || type == SPLAHIP_UINT || type == SPLAHIP_FLOAT, "unknown element type");
+        SPLAHIP_REQUIRE(op_src || binop_valid_for(op, type), "op not defined for this type");
+        SPLAHIP_REQUIRE(select_src || (op_select >= 0 && op_select < SPLAHIP_SELOP_COUNT), "unknown op_select");
+        int st = ensure_device();
+        if (st != SPLAHIP_OK) return st;
+        return compile(vector_source(type, op, op_src, op_select, select_src), name, fn);
+    }
+}// namespace
+
+int splahip_v_assign_masked_jit(int type, int sparse, uint32_t n, void* d_r, const uint32_t* d_mi, const void* d_mask, uint32_t value_bits, int op_assign, const char* assign_src,
+                                int op_select, const char* select_src, void* stream) {
+    if (n == 0) return SPLAHIP_OK;
+    SPLAHIP_REQUIRE(d_r && d_mask && (!sparse || d_mi), "null device pointer");
+    hipFunction_t fn = nullptr;
+    int           st = vector_kernel(type, op_assign, assign_src, op_select, select_src, sparse ? "splahip_assign_sparse_jit" : "splahip_assign_dense_jit", &fn);
+    if (st != SPLAHIP_OK) return st;
+    uint32_t value = value_bits;
+    if (sparse) {
+        void* args[] = {&n, &d_r, &d_mi, &d_mask, &value};
+        SPLAHIP_TRY(hipModuleLaunchKernel(fn, (n + 255u) / 256u, 1, 1, 256, 1, 1, 0, as_stream(stream), args, nullptr));
+    } else {
+        void* args[] = {&n, &d_r, &d_mask, &value};
+        SPLAHIP_TRY(hipModuleLaunchKernel(fn, (n + 255u) / 256u, 1, 1, 256, 1, 1, 0, as_stream(stream), args, nullptr));
+    }
+    return SPLAHIP_OK;
+}
+
+int splahip_v_eadd_fdb_dense_jit(int type, uint32_t n, void* d_r, const void* d_v, void* d_fdb, uint32_t fdb_fill_bits, const char* op_src, void* stream) {
+    SPLAHIP_REQUIRE(op_src != nullptr, "op source is null");
+    if (n == 0) return SPLAHIP_OK;
+    SPLAHIP_REQUIRE(d_r && d_v && d_fdb, "null device pointer");
+    hipFunction_t fn = nullptr;
+    int           st = vector_kernel(type, 0, op_src, SPLAHIP_ALWAYS, nullptr, "splahip_eadd_fdb_dense_jit", &fn);
+    if (st != SPLAHIP_OK) return st;
+    uint32_t fill   = fdb_fill_bits;
+    void*    args[] = {&n, &d_r, &d_v, &d_fdb, &fill};
+    SPLAHIP_TRY(hipModuleLaunchKernel(fn, (n + 255u) / 256u, 1, 1, 256, 1, 1, 0, as_stream(stream), args, nullptr));
+    return SPLAHIP_OK;
+}
+
+int splahip_v_eadd_fdb_sparse_jit(int type, uint32_t nvals, void* d_r, const uint32_t* d_vi, const void* d_vx, uint32_t* d_fi, void* d_fx, uint32_t* h_count, const char* op_src,
+                                  void* stream) {
+    SPLAHIP_REQUIRE(op_src != nullptr && h_count != nullptr, "null argument");
+    *h_count = 0;
+    if (nvals == 0) return SPLAHIP_OK;
+    SPLAHIP_REQUIRE(d_r && d_vi && d_vx && d_fi && d_fx, "null device pointer");
+    hipFunction_t fn = nullptr;
+    int           st = vector_kernel(type, 0, op_src, SPLAHIP_ALWAYS, nullptr, "splahip_eadd_fdb_apply_jit", &fn);
+    if (st != SPLAHIP_OK) return st;
+    return eadd_fdb_sparse_jit(nvals, d_r, d_vi, d_vx, d_fi, d_fx, h_count, fn, as_stream(stream));
+}
+
+int splahip_v_eadd_dense_jit(int type, uint32_t n, void* d_r, const void* d_u, const void* d_v, const char* op_src, void* stream) {
+    SPLAHIP_REQUIRE(op_src != nullptr, "op source is null");
+    if (n == 0) return SPLAHIP_OK;
+    SPLAHIP_REQUIRE(d_r && d_u && d_v, "null device pointer");
+    hipFunction_t fn = nullptr;
+    int           st = vector_kernel(type, 0, op_src, SPLAHIP_ALWAYS, nullptr, "splahip_eadd_dense_jit", &fn);
+    if (st != SPLAHIP_OK) return st;
+    void* args[] = {&n, &d_r, &d_u, &d_v};
+    SPLAHIP_TRY(hipModuleLaunchKernel(fn, (n + 255u) / 256u, 1, 1, 256, 1, 1, 0, as_stream(stream), args, nullptr));
+    return SPLAHIP_OK;
+}
+
+int splahip_v_eadd_sparse_jit(int type, uint32_t nu, const uint32_t* d_ui, const void* d_ux, uint32_t u_fill_bits, uint32_t nv, const uint32_t* d_vi, const void* d_vx,
+                              uint32_t v_fill_bits, uint32_t* d_ri, void* d_rx, uint32_t* h_count, const char* op_src, void* stream) {
+    SPLAHIP_REQUIRE(op_src != nullptr && h_count != nullptr, "null argument");
+    *h_count = 0;
+    if (nu + nv == 0) return SPLAHIP_OK;
+    SPLAHIP_REQUIRE(d_ri && d_rx && (nu == 0 || (d_ui && d_ux)) && (nv == 0 || (d_vi && d_vx)), "null device pointer");
+    hipFunction_t fn = nullptr;
+    int           st = vector_kernel(type, 0, op_src, SPLAHIP_ALWAYS, nullptr, "splahip_eadd_dense_jit", &fn);
+    if (st != SPLAHIP_OK) return st;
+    return eadd_sparse_jit(type, nu, d_ui, d_ux, u_fill_bits, nv, d_vi, d_vx, v_fill_bits, d_ri, d_rx, h_count, fn, as_stream(stream));
+}
+
+int splahip_reduce_jit(int type, uint32_t n, const void* d_x, uint32_t s_bits, uint32_t* h_result_bits, const char* op_src, void* stream) {
+    SPLAHIP_REQUIRE(op_src != nullptr && h_result_bits != nullptr, "null argument");
+    *h_result_bits = s_bits;
+    if (n == 0) return SPLAHIP_OK;
+    SPLAHIP_REQUIRE(d_x != nullptr, "null device pointer");
+    hipFunction_t fn = nullptr;
+    int           st = vector_kernel(type, 0, op_src, SPLAHIP_ALWAYS, nullptr, "splahip_reduce_jit", &fn);
+    if (st != SPLAHIP_OK) return st;
+    hipStream_t s = as_stream(stream);
+    DevMem      out;
+    SPLAHIP_TRY(out.alloc(s, 4));
+    uint32_t sb     = s_bits;
+    void*    po     = out.p;
+    void*    args[] = {&n, &d_x, &sb, &po};
+    SPLAHIP_TRY(hipModuleLaunchKernel(fn, 1, 1, 1, 64, 1, 1, 0, s, args, nullptr));
+    SPLAHIP_TRY(fetch_words(h_result_bits, out.p, 1, s));
+    return SPLAHIP_OK;
+}
+
+int splahip_map_jit(int type, uint32_t n, const void* d_x, void* d_out, const char* op_src, void* stream) {
+    SPLAHIP_REQUIRE(type == SPLAHIP_INT || type == SPLAHIP_UINT || type == SPLAHIP_FLOAT, "unknown element type");
+    SPLAHIP_REQUIRE(op_src != nullptr, "op source is null");
+    if (n == 0) return SPLAHIP_OK;
+    SPLAHIP_REQUIRE(d_x && d_out, "null device pointer");
+    int st = ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    hipFunction_t fn = nullptr;
+    st               = compile(map_source(type, op_src), "splahip_map_jit", &fn);
+    if (st != SPLAHIP_OK) return st;
+    void* args[] = {&n, &d_x, &d_out};
+    SPLAHIP_TRY(hipModuleLaunchKernel(fn, (n + 255u) / 256u, 1, 1, 256, 1, 1, 0, as_stream(stream), args, nullptr));
+    return SPLAHIP_OK;
 }
 }

@@ -26,4 +26,13 @@ namespace splahip {
     int vxm_pull_jit(splahip_plan plan_T, uint32_t n_out, uint32_t n_in, const uint32_t* Tp, const uint32_t* Tj, const void* Tx, const void* mask, uint32_t nvals,
                      const uint32_t* vi, const void* vx, int sorted, uint32_t* ri, void* rx, uint32_t* h_count, hipFunction_t column, hipStream_t s);
 
+    // vector_ops.hip — v_eadd_fdb, sparse operand (reference cpu_v_eadd_fdb.hpp:71-139): `apply` is the pass that applies the op and flags the changed entries,
+    //   (uint nvals, T* r, const uint* vi, const T* vx, uint* changed, T* newval); the order-preserving compaction of the feedback is the built-in drivers'
+    int eadd_fdb_sparse_jit(uint32_t nvals, void* r, const uint32_t* vi, const void* vx, uint32_t* fi, void* fx, uint32_t* h_count, hipFunction_t apply, hipStream_t s);
+    // vector_ops.hip — v_eadd, sparse (+) sparse (reference cpu_v_eadd.hpp:96-127): the built-in merge runs twice, with FIRST and with SECOND, so that the two
+    // operands of every output entry (a stored value or the other side's fill value) sit side by side; `combine` then applies the op,
+    //   (uint n, T* r, const T* a, const T* b)
+    int eadd_sparse_jit(int type, uint32_t nu, const uint32_t* ui, const void* ux, uint32_t u_fill, uint32_t nv, const uint32_t* vi, const void* vx, uint32_t v_fill,
+                        uint32_t* ri, void* rx, uint32_t* h_count, hipFunction_t combine, hipStream_t s);
+
 }// namespace splahip

@@ -20,6 +20,7 @@
 // compacted order-preservingly, so it lists the changed entries in the operand's stored order like the reference.
 #include "block_utils.hpp"
 #include "common.hpp"
+#include "jit_hooks.hpp"
 #include "ops.hpp"
 
 #include <algorithm>
@@ -356,6 +357,57 @@ namespace splahip {
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = fetch_words(h_result, out, 1, s);
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "reduce failed: %s", hipGetErrorString(e));
+        return SPLAHIP_OK;
+    }
+
+    // ---- user-defined ops (jit_hooks.hpp): the drivers above with the op-dependent kernel replaced by a run-time-compiled one --------------------------
+    int eadd_fdb_sparse_jit(uint32_t nvals, void* r, const uint32_t* vi, const void* vx, uint32_t* fi, void* fx, uint32_t* h_count, hipFunction_t apply, hipStream_t s) {
+        *h_count = 0;
+        if (nvals == 0) return SPLAHIP_OK;
+        const uint n_chunks = (nvals + 1023u) / 1024u;
+        DevMem     mem;// changed[nvals] | newval[nvals] | chunk[n_chunks + 1]
+        SPLAHIP_TRY(mem.alloc(s, sizeof(uint) * (2 * (size_t) nvals + n_chunks + 1)));
+        uint* changed = mem.as<uint>();
+        uint* newval  = changed + nvals;
+        uint* chunk   = newval + nvals;
+        uint  n       = nvals;
+        void* args[]  = {&n, &r, &vi, &vx, &changed, &newval};
+        SPLAHIP_TRY(hipModuleLaunchKernel(apply, (nvals + 255u) / 256u, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+        hipLaunchKernelGGL(changed_count_kernel, dim3(n_chunks), dim3(256), 0, s, changed, nvals, chunk);
+        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk, n_chunks);
+        hipLaunchKernelGGL(changed_write_kernel, dim3(n_chunks), dim3(256), 0, s, changed, vi, newval, nvals, chunk, fi, static_cast<uint*>(fx));
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = fetch_words(h_count, chunk + n_chunks, 1, s);
+        if (e != hipSuccess) return fail(SPLAHIP_ERROR, "v_eadd_fdb (sparse, user-defined op) failed: %s", hipGetErrorString(e));
+        return SPLAHIP_OK;
+    }
+
+    int eadd_sparse_jit(int type, uint32_t nu, const uint32_t* ui, const void* ux, uint32_t u_fill, uint32_t nv, const uint32_t* vi, const void* vx, uint32_t v_fill,
+                        uint32_t* ri, void* rx, uint32_t* h_count, hipFunction_t combine, hipStream_t s) {
+        *h_count = 0;
+        if (nu + nv == 0) return SPLAHIP_OK;
+        DevMem mem;// a[nu + nv] | b[nu + nv]: the left and the right operand of every output entry
+        SPLAHIP_TRY(mem.alloc(s, sizeof(uint) * 2 * ((size_t) nu + nv)));
+        uint* a  = mem.as<uint>();
+        uint* b  = a + nu + nv;
+        int   st = SPLAHIP_OK;
+        uint  count = 0;
+        for (int side = 0; side < 2 && st == SPLAHIP_OK; ++side) {
+            const int pick = side == 0 ? SPLAHIP_FIRST : SPLAHIP_SECOND;
+            void*     dst  = side == 0 ? a : b;
+            switch (type) {// (the values are moved, never computed with: the word-sized types share one instantiation's behaviour)
+                case SPLAHIP_FLOAT: st = eadd_sparse<float>(nu, ui, ux, u_fill, nv, vi, vx, v_fill, ri, dst, &count, pick, s); break;
+                case SPLAHIP_INT: st = eadd_sparse<int32_t>(nu, ui, ux, u_fill, nv, vi, vx, v_fill, ri, dst, &count, pick, s); break;
+                default: st = eadd_sparse<uint32_t>(nu, ui, ux, u_fill, nv, vi, vx, v_fill, ri, dst, &count, pick, s); break;
+            }
+        }
+        if (st != SPLAHIP_OK) return st;
+        if (count) {
+            void* args[] = {&count, &rx, &a, &b};
+            SPLAHIP_TRY(hipModuleLaunchKernel(combine, (count + 255u) / 256u, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+            SPLAHIP_TRY(hipStreamSynchronize(s));// (the scratch arrays go with this scope)
+        }
+        *h_count = count;
         return SPLAHIP_OK;
     }
 

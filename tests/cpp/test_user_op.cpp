@@ -1,4 +1,4 @@
-// User-defined ops through the C++ operator API, the way a reference user writes them (reference tests/test_op.cpp:56-59 makes the op,
+// User-defined ops through the C++ operator API (the four hot-path operators and, since round 4, the vector / matrix operations around them), the way a reference user writes them (reference tests/test_op.cpp:56-59 makes the op,
 // tests/test_mxv.cpp:33-89 / test_vxm.cpp / test_mxm.cpp / test_mxmT.cpp are the products): exec_mxv_masked, exec_vxm_masked, exec_mxm and
 // exec_mxmT_masked with OpBinary::make_float / OpSelect::make_float ops run ON THE DEVICE — the body text is compiled at run time
 // (spla_amd/csrc/kernels/jit.hip) — and must equal the host evaluation of the same std::function in the reference's fold order
@@ -201,6 +201,128 @@ int main() {
                 }
             }
         }
+    }
+
+    // ---- the vector operations around the hot path with user-defined ops: v_assign_masked, v_eadd_fdb, v_eadd, v_reduce, m_reduce, v_map, m_transpose,
+    //      each in its sparse form (operands set element by element) and its dense form (operands prepared with set_format(CpuDense)); reference semantics:
+    //      src/cpu/cpu_v_assign.hpp:68-132, cpu_v_eadd_fdb.hpp:71-139, cpu_v_eadd.hpp:70-157, cpu_v_reduce.hpp:69-117, cpu_m_reduce.hpp:134-156, cpu_v_map.hpp:57-68 ----
+    {
+        auto fop  = [](float a, float b) { return 0.25f * a + 0.75f * b; };// not associative, not commutative
+        auto fsel = [](float a) { return a > 0.5f; };
+        auto fun  = [](float a) { return a * a + 1.0f; };
+        auto custom_un = spla::OpUnary::make_float("custom_un", "(float a) { return a * a + 1.0f; }", fun);
+        const spla::uint L = 1500;
+        for (int dense = 0; dense < 2; ++dense) {
+            std::vector<float> hu(L, 0.0f), hw(L, 0.0f), hk(L, 0.0f), hr(L, 0.0f);
+            std::vector<char>  su(L, 0), sw(L, 0), sk(L, 0);
+            auto u = spla::Vector::make(L, spla::FLOAT), w = spla::Vector::make(L, spla::FLOAT), mk = spla::Vector::make(L, spla::FLOAT), rr = spla::Vector::make(L, spla::FLOAT);
+            for (spla::uint i = 0; i < L; ++i) {
+                if (rnd() % 3 != 0) hu[i] = 0.125f + (rnd() % 61) / 7.0f, su[i] = 1, u->set_float(i, hu[i]);
+                if (rnd() % 2 != 0) hw[i] = 0.125f + (rnd() % 53) / 11.0f, sw[i] = 1, w->set_float(i, hw[i]);
+                if (rnd() % 4 != 0) hk[i] = (rnd() % 5) / 4.0f, sk[i] = 1, mk->set_float(i, hk[i]);
+                hr[i] = (rnd() % 19) / 3.0f;
+                rr->set_float(i, hr[i]);
+            }
+            if (dense) {
+                CHECK(u->set_format(spla::FormatVector::CpuDense) == spla::Status::Ok);
+                CHECK(w->set_format(spla::FormatVector::CpuDense) == spla::Status::Ok);
+                CHECK(mk->set_format(spla::FormatVector::CpuDense) == spla::Status::Ok);
+            }
+            CHECK(rr->set_format(spla::FormatVector::CpuDense) == spla::Status::Ok);
+            auto same = [&](const spla::ref_ptr<spla::Vector>& x, const std::vector<float>& want, const char* what) {
+                for (spla::uint i = 0; i < L; ++i) {
+                    float got = -9.0f;
+                    x->get_float(i, got);
+                    if (got != want[i]) {
+                        std::fprintf(stderr, "%s (dense=%d) entry %u: got %.9g want %.9g\n", what, dense, i, got, want[i]);
+                        return false;
+                    }
+                }
+                return true;
+            };
+            // v_assign_masked: r[i] = op(r[i], value) where select(mask[i]) — over the stored mask entries (sparse) / over every index, absent = fill 0 (dense)
+            {
+                const float value = 3.5f;
+                CHECK(spla::exec_v_assign_masked(rr, mk, spla::Scalar::make_float(value), custom_plus, custom_sel) == spla::Status::Ok);
+                for (spla::uint i = 0; i < L; ++i)
+                    if ((dense || sk[i]) && fsel(hk[i])) hr[i] = fop(hr[i], value);
+                CHECK(same(rr, hr, "v_assign_masked"));
+            }
+            // v_eadd_fdb: r[i] = op(r[i], w[i]) over w's stored entries (sparse) / every index (dense); fdb = the changed entries
+            {
+                auto fdb = spla::Vector::make(L, spla::FLOAT);
+                CHECK(spla::exec_v_eadd_fdb(rr, w, fdb, custom_plus) == spla::Status::Ok);
+                std::vector<float> hf(L, 0.0f);
+                for (spla::uint i = 0; i < L; ++i)
+                    if (dense || sw[i]) {
+                        const float prev = hr[i], next = fop(prev, hw[i]);
+                        hr[i] = next;
+                        if (prev != next) hf[i] = next;
+                    }
+                CHECK(same(rr, hr, "v_eadd_fdb r"));
+                CHECK(same(fdb, hf, "v_eadd_fdb fdb"));
+            }
+            // v_eadd: op(u[i], w[i]) — sparse: over the union of the stored indices with the other side's fill value (0); dense: every index
+            {
+                auto out = spla::Vector::make(L, spla::FLOAT);
+                CHECK(spla::exec_v_eadd(out, u, w, custom_plus) == spla::Status::Ok);
+                std::vector<float> ho(L, 0.0f);
+                for (spla::uint i = 0; i < L; ++i)
+                    if (dense || su[i] || sw[i]) ho[i] = fop(hu[i], hw[i]);
+                CHECK(same(out, ho, "v_eadd"));
+            }
+            // v_reduce: the strict left fold from s over the stored values (sparse) / every entry (dense)
+            {
+                auto        res  = spla::Scalar::make_float(0.0f);
+                const float s0   = 1.75f;
+                float       want = s0;
+                for (spla::uint i = 0; i < L; ++i)
+                    if (dense || su[i]) want = fop(want, hu[i]);
+                CHECK(spla::exec_v_reduce(res, spla::Scalar::make_float(s0), u, custom_plus) == spla::Status::Ok);
+                if (res->as_float() != want) {
+                    std::fprintf(stderr, "v_reduce (dense=%d): got %.9g want %.9g\n", dense, res->as_float(), want);
+                    return 1;
+                }
+            }
+            // v_map: op(u[i]) over the stored entries (sparse) / every index (dense)
+            {
+                auto out = spla::Vector::make(L, spla::FLOAT);
+                CHECK(spla::exec_v_map(out, u, custom_un) == spla::Status::Ok);
+                std::vector<float> ho(L, 0.0f);
+                for (spla::uint i = 0; i < L; ++i)
+                    if (dense || su[i]) ho[i] = fun(hu[i]);
+                CHECK(same(out, ho, "v_map"));
+            }
+        }
+        // m_reduce (row-major fold of the stored values) and m_transpose with a user-defined unary op, on the matrix of the first test
+        {
+            auto        res  = spla::Scalar::make_float(0.0f);
+            const float s0   = 0.625f;
+            float       want = s0;
+            for (spla::uint i = 0; i < M; ++i)
+                for (auto& e : rows[i]) want = fop(want, e.second);
+            CHECK(spla::exec_m_reduce(res, spla::Scalar::make_float(s0), A, custom_plus) == spla::Status::Ok);
+            if (res->as_float() != want) {
+                std::fprintf(stderr, "m_reduce: got %.9g want %.9g\n", res->as_float(), want);
+                return 1;
+            }
+            auto At = spla::Matrix::make(N, M, spla::FLOAT);
+            CHECK(spla::exec_m_transpose(At, A, custom_un) == spla::Status::Ok);
+            for (spla::uint i = 0; i < M; ++i)
+                for (auto& e : rows[i]) {
+                    float got = -9.0f;
+                    At->get_float(e.first, i, got);
+                    if (got != fun(e.second)) {
+                        std::fprintf(stderr, "m_transpose (%u, %u): got %.9g want %.9g\n", e.first, i, got, fun(e.second));
+                        return 1;
+                    }
+                }
+        }
+        // a body that does not compile: CompilationError from a vector operation too
+        auto broken_f = spla::OpBinary::make_float("broken_f", "(float a, float b) { return a +* b; }", [](float a, float b) { return a + b; });
+        auto x1 = spla::Vector::make(8, spla::FLOAT), x2 = spla::Vector::make(8, spla::FLOAT), x3 = spla::Vector::make(8, spla::FLOAT);
+        x1->set_float(1, 1.0f), x2->set_float(2, 2.0f);
+        CHECK(spla::exec_v_eadd(x3, x1, x2, broken_f) == spla::Status::CompilationError);
     }
 
     // ---- int32: a user-defined op_add beside the built-in PLUS / EQZERO (saturating add: min(a + b, 1000)) ----
