@@ -508,3 +508,123 @@ def test_cfg3_full_size_pagerank_pull_column_ordered_blocks(oracle):
     # from the fp64 sum)
     _assert_fp32_sum_parity(dense[rows_idx].cpu().numpy(), want, exact[rows_idx].cpu().numpy(), min_plain=0.98, what="configs[2] PageRank pull step, every 256th output")
     plan_T.close()
+
+
+# ------------------------------------------------------------------------------------------ configs[4] and the N = 8 split of configs[3] at BASELINE's full sizes
+def test_cfg5_full_size_mxmT_rmat20_row_sample_and_triangle_count(oracle):
+    """configs[4], triangle-count form at full size: L = strict lower triangle of symmetrised R-MAT scale 20 (15.7 M entries), exec_mxmT_masked(L, L, L) MULT / PLUS /
+    GTZERO int32.  The triangle count is the known answer of this graph (423 516 054: the reference CPU backend's and the oracle's tc on it, profiles/r0*_ops_algorithms.json);
+    the same call with the mask restricted to every 64th row is checked entry for entry against the oracle (rows are independent), and the full result's rows agree with it."""
+    from spla_amd import graphgen, kernels
+    n, Ap, Aj = _rmat(20, device="cuda", symmetric=True)
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), (Ap[1:] - Ap[:-1]).to(torch.int64))
+    low = Aj.to(torch.int64) < rows
+    Lp, Lj = graphgen.keys_to_csr(rows[low] * n + Aj[low].to(torch.int64), n, n)
+    del rows, low
+    Lx = torch.ones(int(Lp[-1]), dtype=torch.int32, device="cuda")
+    L = (Lp, Lj, Lx)
+    Rp, Rj, Rx = kernels.mxmT_masked("INT", n, L, L, L, "MULT", "PLUS", "GTZERO", 0)
+    assert int(Rx.to(torch.int64).sum()) == 423516054
+    keep = torch.zeros(n, dtype=torch.bool, device="cuda")
+    keep[::64] = True
+    Lp64 = Lp.to(torch.int64)
+    deg = Lp64[1:] - Lp64[:-1]
+    Mp = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(torch.where(keep, deg, torch.zeros_like(deg)), 0, out=Mp[1:])
+    ent = torch.repeat_interleave(keep, deg)
+    M = (Mp.to(torch.int32), Lj[ent].contiguous(), Lx[ent].contiguous())
+    Sp, Sj, Sx = kernels.mxmT_masked("INT", n, M, L, L, "MULT", "PLUS", "GTZERO", 0)
+    Lh = tuple(_np_u32(t) if t.dtype == torch.int32 and i < 2 else t.cpu().numpy() for i, t in enumerate(L))
+    Mh = (_np_u32(M[0]), _np_u32(M[1]), M[2].cpu().numpy())
+    wp, wj, wx = oracle.mxmT_masked("INT", n, Mh, Lh, Lh, "MULT", "PLUS", "GTZERO", 0)
+    np.testing.assert_array_equal(_np_u32(Sp), wp)
+    np.testing.assert_array_equal(_np_u32(Sj), wj)
+    np.testing.assert_array_equal(Sx.cpu().numpy(), wx)
+    # the sampled rows of the full result are the same rows
+    Rp64, Sp64 = Rp.to(torch.int64), Sp.to(torch.int64)
+    sel = torch.nonzero(keep).flatten()
+    assert torch.equal((Rp64[1:] - Rp64[:-1])[sel], (Sp64[1:] - Sp64[:-1])[sel])
+    full_ent = torch.repeat_interleave(keep, Rp64[1:] - Rp64[:-1])
+    assert torch.equal(Rj[full_ent], Sj) and torch.equal(Rx[full_ent], Sx)
+
+
+def test_cfg5_full_size_mxm_rmat18_row_sample(oracle):
+    """configs[4], A x A at the bench's size (R-MAT scale 18, 3.9 M entries, 2.9 G products, 1.28 G result entries), fp32 MULT / PLUS: the product count, the row
+    pointers' total, and every 1024th row of A against the oracle (a row of the result depends on that row of A and on B only): structure identical, values within 1e-5."""
+    from spla_amd import kernels
+    n, Ap, Aj = _rmat(18, device="cuda")
+    nnz = int(Ap[-1])
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1809)
+    Ax = (torch.rand(nnz, generator=gen, device="cuda") * 0.5 + 0.25).contiguous()
+    A = (Ap, Aj, Ax)
+    raw, products = kernels.mxm("FLOAT", n, n, A, A, "MULT", "PLUS", 0.0, adopt=False)
+    deg = (Ap[1:] - Ap[:-1]).to(torch.int64)
+    assert products == int(deg[Aj.to(torch.int64)].sum())
+    Rp = raw.Rp.to(torch.int64)
+    assert int(Rp[-1]) == raw.nnz and raw.nnz > 1_000_000_000
+    rows_idx = torch.arange(0, n, 1024, device="cuda")
+    Ap64 = Ap.to(torch.int64)
+    d = deg[rows_idx]
+    Sp = torch.zeros(rows_idx.numel() + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(d, 0, out=Sp[1:])
+    rep = torch.repeat_interleave(torch.arange(rows_idx.numel(), device="cuda"), d)
+    src = Ap64[rows_idx][rep] + (torch.arange(int(Sp[-1]), device="cuda") - Sp[:-1][rep])
+    sub = (_np_u32(Sp.to(torch.int32)), _np_u32(Aj[src]), Ax[src].cpu().numpy())
+    wp, wj, wx = oracle.mxm("FLOAT", int(rows_idx.numel()), n, sub, (_np_u32(Ap), _np_u32(Aj), Ax.cpu().numpy()), "MULT", "PLUS", 0.0)
+    Rj, Rx = raw.adopt("FLOAT")[1:]
+    lens = (Rp[1:] - Rp[:-1])[rows_idx]
+    np.testing.assert_array_equal(lens.cpu().numpy(), np.diff(wp.astype(np.int64)))
+    take = torch.repeat_interleave(torch.zeros(n, dtype=torch.bool, device="cuda").index_fill_(0, rows_idx, True), Rp[1:] - Rp[:-1])
+    np.testing.assert_array_equal(_np_u32(Rj[take]), wj)
+    np.testing.assert_allclose(Rx[take].cpu().numpy(), wx, rtol=FP32_RTOL, atol=0)
+    del Rj, Rx, take
+    from spla_amd import _lib
+    _lib.call("splahip_mxm_trim")
+
+
+def test_cfg4_full_size_scale24_eight_way_split_stitched(oracle):
+    """configs[3] as BASELINE states it — R-MAT scale 24 across 8 ranks — with the eight nnz-balanced row blocks run one after the other on this one GPU through the
+    C-ABI shard (the split into local-column and remote-column parts with their own column-ordered blocks, splahip_shard_mxv_local / _remote over the gathered vector):
+    the stitched result equals the unsplit product over the blocks on every row, and the oracle on every 1024th row.  Owner-sorted labels, as `--gpus 8` runs."""
+    from spla_amd import graphgen, kernels, sharding
+    n, Ap, Aj = graphgen.rmat_csr(24, 16, seed=1, device="cuda", permute="owner-sorted", owners=8)
+    nnz = int(Ap[-1])
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(2408)
+    Ax = torch.randint(1, 256, (nnz,), generator=gen, device="cuda", dtype=torch.int32)
+    INF = 1 << 30
+    v = torch.full((n,), INF, dtype=torch.int32, device="cuda")
+    v[torch.randint(0, n, (n // 8,), generator=gen, device="cuda")] = torch.randint(0, 5000, (n // 8,), generator=gen, device="cuda", dtype=torch.int32)
+    mask = torch.zeros(n, dtype=torch.int32, device="cuda")
+    plan = kernels.CsrPlan(n, nnz, Ap)
+    assert plan.attach_cob(n, Ap, Aj, Ax) is not None
+    whole = torch.empty(n, dtype=torch.int32, device="cuda")
+    kernels.mxv_masked(plan, "INT", n, Ap, Aj, Ax, mask, v, whole, "PLUS", "MIN", "ALWAYS", INF)
+    torch.cuda.synchronize()
+    plan.close()
+    rows_idx = torch.arange(0, n, 1024, device="cuda")
+    want = _sampled_rows_oracle(oracle, "INT", Ap, Aj, Ax, rows_idx, n, mask, v, "PLUS", "MIN", "ALWAYS", INF)
+    np.testing.assert_array_equal(whole[rows_idx].cpu().numpy(), want)
+    world = 8
+    bounds = sharding.row_splits(Ap, world)
+    got = torch.empty(n, dtype=torch.int32, device="cuda")
+    for rank in range(world):
+        blk = sharding.RowBlock(Ap, Aj, Ax, bounds, rank)
+        sh = sharding.Shard(blk, blk.Ax)
+        v_full = torch.full((blk.n_cols_padded,), INF, dtype=torch.int32, device="cuda")
+        for p in range(world):  # what the all-gather of the padded slices leaves on every rank
+            v_full[p * blk.max_rows: p * blk.max_rows + (bounds[p + 1] - bounds[p])] = v[bounds[p]:bounds[p + 1]]
+        v_loc = blk.pad_local(v[blk.lo:blk.hi], fill=INF)
+        r = torch.empty(blk.n_local, dtype=torch.int32, device="cuda")
+        m = mask[blk.lo:blk.hi].clone()  # (a fresh allocation: the remote part moves mask and r in 16-byte loads)
+        if sh.serves("INT", "MIN"):
+            sh.mxv_local("INT", m, v_loc, r, "PLUS", "MIN", "ALWAYS", INF)
+            sh.mxv_remote("INT", m, v_full, r, "PLUS", "MIN", "ALWAYS")
+        else:
+            sh.mxv_whole("INT", m, v_full, r, "PLUS", "MIN", "ALWAYS", INF)
+        torch.cuda.synchronize()
+        got[blk.lo:blk.hi] = r
+        sh.close()
+        del blk, sh, v_full
+    assert torch.equal(got, whole)
