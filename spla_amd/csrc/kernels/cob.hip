@@ -25,6 +25,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <functional>
 #include <queue>
@@ -764,6 +765,16 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
 
     const uint32_t col_bits = 31 - kSlotBits;                            // a cr word: slot field (15 bits used; the values R .. R + 63 mark padding) above 16 column bits
 
+    // (SPLAHIP_COB_TRACE: wall time of the attach's phases on stderr; each stamp synchronises the stream)
+    const bool trace_phases = knob_env("SPLAHIP_COB_TRACE") != nullptr;
+    auto       t_last       = std::chrono::steady_clock::now();
+    auto       stamp        = [&](const char* what) {
+        if (!trace_phases) return;
+        (void) hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[cob] attach phase %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     Scratch tmp;
     auto*   g   = new splahip_cob_s();
     g->n_rows   = n_rows;
@@ -875,6 +886,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         if (e == hipSuccess) g->bytes += sizeof(U) * (count ? count : 1);
     };
 
+    stamp("column statistics / relabel");
     // 0: rows -> (range, slot).  Hub rows first.
     uint32_t *deg = nullptr, *deg_s = nullptr, *row_id = nullptr, *order = nullptr, *rowmap = nullptr, *cnt = nullptr;
     e = tmp.alloc(&deg, n_rows);
@@ -1018,6 +1030,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         if (e != hipSuccess) return bail("row map");
     }
 
+    stamp("hub rows, ranges, row map");
     // 1 + 2: keys, stable sort on the (range, column) bits
     unsigned long long *key = nullptr, *key_s = nullptr;
     uint32_t*           val_s = nullptr;
@@ -1046,6 +1059,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     }
     if (e != hipSuccess) return bail("sort");
 
+    stamp("keys + radix sort");
     // 3: groups -> chunks
     uint32_t *start = nullptr, *chunk_first = nullptr;
     e = tmp.alloc(&start, (size_t) n_groups + 1);
@@ -1061,6 +1075,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     if (e != hipSuccess) return bail("groups");
     g->n_chunks = n_chunks;
 
+    stamp("groups -> chunks");
     // 4: the packed streams
     own(&g->d_cr, ((size_t) n_chunks + 2) * kCobChunk);// + two all-padding chunks (the main loop's steps beyond a piece's end walk one: hub / natural slot values)
     own(&g->d_ax, ((size_t) n_chunks + 2) * kCobChunk);
@@ -1082,6 +1097,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     if (e != hipSuccess) return bail("scratch");
     hipLaunchKernelGGL(cob_negzero_kernel, dim3(1024), dim3(256), 0, s, (size_t) n_chunks * kCobChunk, g->d_ax, negzero_word);
 
+    stamp("packed streams (scatter)");
     // 5: the work schedules, on the host (a few hundred pieces).  A piece = consecutive chunks of ONE range (the LDS slice belongs to a range) =
     // one workgroup.  What a chunk costs a CU is its memory requests: 16 lines of the two streams + the distinct lines of v its gathers touch
     // (round 3 timeline, profiles/r03_notes.md: a hub piece walks a chunk in 80 - 100 ns, a cold natural piece in 150 - 700 ns — a CU's miss queue
@@ -1298,6 +1314,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     own(&g->d_ticket, (size_t) g->ticket_words);
     own(&g->d_vbits, ((size_t) g->n_vcols + 255) / 256 * 8 + 2);// every wave of cob_vbits_kernel writes its two words
     if (e != hipSuccess) return bail("schedule upload");
+    stamp("schedules");
     {// one value word in the whole matrix?  (the sparse-vector form then skips the value stream)
         uint32_t* rng = nullptr;
         e             = tmp.alloc(&rng, 2);
@@ -1313,6 +1330,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         g->x_uniform = h_rng[0] == h_rng[1];
         g->x_bits    = h_rng[0];
     }
+    stamp("value range");
     plan->cob = g;
     return SPLAHIP_OK;
 }
