@@ -593,4 +593,56 @@ def _dense_f(vec, n, fill=None):
     return out
 
 
-WORKLOADS = {"pagerank-vxm": pagerank_vxm, "sssp-step": sssp_step, "tc-mxmT": tc_mxmT, "mxm": mxm, "algorithms": algorithms, "transpose": transpose}
+# ---------------------------------------------------------------------------------------------------------------- vxm push, mid-size frontier
+def vxm_push(args):
+    """exec_vxm_masked in its push form on a mid-size frontier: 10^6 stored entries of v over R-MAT scale 22, fp32 PLUS / MIN products folded per
+    output column in the reference's order (expand, stable radix sort by output index, left fold of every run: bit-exact), and the int32 BAND / BOR step of a traversal
+    (order-free: memory-side atomics + compaction).  Throughput in products; algorithmic bytes = 12 B per product (Aj, Ax, the product's key / value once) + the vector
+    and the mask."""
+    from oracle import pyoracle
+    from spla_amd import graphgen, kernels
+    scale = 22 if args.scale == 22 else args.scale
+    n, Ap, Aj = graphgen.rmat_csr(scale, args.edge_factor, seed=args.seed, device="cuda")
+    nnz = int(Ap[-1])
+    g = torch.Generator(device="cuda")
+    g.manual_seed(args.seed + 31)
+    k = min(1_000_000, n // 4)
+    vi = torch.sort(torch.randperm(n, generator=g, device="cuda")[:k]).values.to(torch.int32)
+    deg = (Ap[1:] - Ap[:-1]).to(torch.int64)
+    products = int(deg[vi.to(torch.int64)].sum())
+    mask = torch.zeros(n, dtype=torch.float32, device="cuda")
+    lines = []
+    for t, mul, add, sel, Ax, vx in (("FLOAT", "PLUS", "MIN", "ALWAYS", torch.randint(1, 256, (nnz,), generator=g, device="cuda").to(torch.float32),
+                                      torch.randint(0, 5000, (k,), generator=g, device="cuda").to(torch.float32)),
+                                     ("INT", "BAND", "BOR", "EQZERO", torch.ones(nnz, dtype=torch.int32, device="cuda"), torch.ones(k, dtype=torch.int32, device="cuda"))):
+        m = mask if t == "FLOAT" else mask.to(torch.int32)
+        out = {}
+
+        def step():
+            out["r"] = kernels.vxm_push(t, n, n, Ap, Aj, Ax, m, vi, vx, mul, add, sel)
+
+        wall, per = _time_calls(step, args.steps, args.warmup)
+        ms = float(np.mean(per))
+        alg = 12 * products + 8 * k + 4 * n
+        e = {"name": f"{t} {mul}/{add}, {k} stored entries of v ({products} products)", "ms_per_call": round(ms, 4), "gproducts_per_s": round(products / (ms * 1e-3) / 1e9, 2),
+             "nnz_result": int(out["r"][0].numel()), "roofline_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if not args.no_verify:  # the first 20000 stored entries of v against the oracle (a prefix of the frontier is a valid frontier)
+            kk = 20000
+            ri, rx = kernels.vxm_push(t, n, n, Ap, Aj, Ax, m, vi[:kk], vx[:kk], mul, add, sel)
+            wi, wx = pyoracle.Oracle().vxm_masked(t, n, n, Ap.cpu().numpy(), Aj.cpu().numpy(), Ax.cpu().numpy(), m.cpu().numpy(), vi[:kk].cpu().numpy(), vx[:kk].cpu().numpy(), mul, add, sel)
+            ok = bool(np.array_equal(ri.cpu().numpy().view(np.uint32), wi) and np.array_equal(rx.cpu().numpy().view(np.uint32), np.asarray(wx).view(np.uint32)))
+            if not ok:
+                raise SystemExit("bench: vxm push differs from the oracle")
+            e["verified"] = True
+        lines.append(e)
+    f = lines[0]
+    alg = 12 * products + 8 * k + 4 * n
+    line = _line("vxm push G products/s (mid-size frontier)", "Gproducts/s", f["gproducts_per_s"], args, f["ms_per_call"], "f32",
+                 {"workload": f"exec_vxm_masked push form, fp32 PLUS/MIN, {k} stored entries of v over R-MAT scale {scale} ef {args.edge_factor}", "n": n, "nnz": nnz, "products": products},
+                 _roof(alg, f["ms_per_call"], "push: expand + radix sort by output index (rocPRIM) + in-order fold of every run"))
+    line["forms"] = lines
+    line["verified"] = all(x.get("verified", False) for x in lines) if not args.no_verify else None
+    return line
+
+
+WORKLOADS = {"vxm-push": vxm_push, "pagerank-vxm": pagerank_vxm, "sssp-step": sssp_step, "tc-mxmT": tc_mxmT, "mxm": mxm, "algorithms": algorithms, "transpose": transpose}

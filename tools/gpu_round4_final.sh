@@ -8,7 +8,7 @@ echo "== smoke"; timeout 300 python3 -c "import __graft_entry__ as g; g.smoke()"
 fi
 echo "== bench"; t0=$(date +%s); timeout 1500 python3 bench.py > gpurun_out/r04/bench.json 2> gpurun_out/r04/bench.err; echo "bench exit $? in $(( $(date +%s) - t0 )) s"; cut -c1-900 gpurun_out/r04/bench.json
 if [ -z "$SKIP_OPS" ]; then
-for w in bfs-step algorithms transpose; do
+for w in bfs-step algorithms transpose vxm-push; do
   echo "== $w"; timeout 1500 python3 bench.py --workload $w --steps ${STEPS:-10} --warmup 2 > gpurun_out/r04/ops_$w.json 2> gpurun_out/r04/ops_$w.err; echo "exit $?"; cut -c1-500 gpurun_out/r04/ops_$w.json
 done
 fi
