@@ -667,7 +667,9 @@ namespace splahip {
         return SPLAHIP_OK;
     }
 
-    constexpr uint kPushAtomicMax = 1u << 22;// products up to which the order-free form is used
+    // products up to which the order-free form is used (SPLAHIP_PUSH_ATOMIC_MAX).  Measured at R-MAT 22, a 10^6-entry frontier, 15.4 M products (bench.py --workload
+    // vxm-push): sort form 1.76 - 1.83 ms, this form 0.74 - 0.81 ms; the limit was 2^22 until round 4
+    constexpr uint kPushAtomicMax = 1u << 26;
     inline bool    push_order_free(int op_add, int type) {
         if (!binop_is_associative(op_add) || !binop_is_commutative(op_add)) return false;
         return !(type == SPLAHIP_FLOAT && (op_add == SPLAHIP_PLUS || op_add == SPLAHIP_MULT));// fp32 sums / products round by order: sort form
@@ -697,7 +699,9 @@ namespace splahip {
         }
         if (n_products == 0) return SPLAHIP_OK;
 
-        if (n_products <= kPushAtomicMax && push_order_free(op_add, TypeId<T>::value) && !push_atomic_disabled()) {
+        const char* pm_env     = knob_env("SPLAHIP_PUSH_ATOMIC_MAX");
+        const uint  atomic_max = pm_env && *pm_env ? (uint) std::strtoul(pm_env, nullptr, 10) : kPushAtomicMax;
+        if (n_products <= atomic_max && push_order_free(op_add, TypeId<T>::value) && !push_atomic_disabled()) {
             const uint n_chunks = (n_cols + 1023u) / 1024u;
             DevMem     body;// acc[n_cols] (8 bytes each) | chunk[n_chunks + 1] | NaN-seen flag
             SPLAHIP_TRY(body.alloc(s, sizeof(u64) * (size_t) n_cols + sizeof(uint) * ((size_t) n_chunks + 2)));
