@@ -135,8 +135,8 @@ namespace {
     // better.)  The kernel is correct for any vector and mask (it sees this call's own verdict), so a stale hint only costs time; a traversal's levels differ,
     // so the hint pays for repeated or slowly changing steps.  A plan whose calls keep not qualifying is probed every 16th call.
     template<typename T>
-    int first_hit_probe(splahip_plan plan, uint32_t n_cols, const uint32_t* Ap, const uint32_t* Aj, const void* mask, int op_select, const void* v, hipStream_t st,
-                        bool* take) {
+    int first_hit_probe(splahip_plan plan, uint32_t n_cols, const uint32_t* Ap, const uint32_t* Aj, const void* mask, int op_select, const void* v, bool early_exit,
+                        hipStream_t st, bool* take) {
         *take = false;
         if (knob_u32("SPLAHIP_FIRST_HIT", 1) == 0 || n_cols == 0) return SPLAHIP_OK;
         int rc = first_hit_prepare(plan, n_cols);
@@ -145,6 +145,10 @@ namespace {
         uint32_t h[8];// (the pass writes two 16-byte halves, the call's sequence number in each: a torn read shows as two different numbers)
         for (int k = 0; k < 8; ++k) h[k] = plan->h_fh[k];
         *take = h[3] != 0u && h[3] == h[7] && h[0] != 0u && h[2] != 0u && h[4] != 0u && (uint64_t) h[5] * 100u <= (uint64_t) h[4] * pct;
+        // an early_exit call needs no hint: what it would run otherwise is the one-lane-per-row CSR kernel, which walks the same way but reads the value words, gathers
+        // words of v instead of bits, and leaves a long row without a hit to ONE lane (this kernel hands it to the wave); a vector that is not a frontier is folded with
+        // the reference's early-exit rule by the same launch
+        if (early_exit) *take = true;
         if (!*take) {
             plan->fh_misses += 1;
             if (plan->fh_misses > 4 && (plan->fh_misses & 15u) != 0u) return SPLAHIP_OK;
@@ -158,20 +162,20 @@ namespace {
     }
     template<typename T>
     int launch_first_hit(splahip_plan plan, uint32_t n_rows, const uint32_t* Ap, const uint32_t* Aj, const void* mask, const void* v, void* r, int op_mult, int op_add,
-                         int op_select, uint32_t init_bits, uint32_t xbits, hipStream_t st) {
+                         int op_select, uint32_t init_bits, uint32_t xbits, int early_exit, hipStream_t st) {
         const dim3 grid((n_rows + 255) / 256);
         if constexpr (!std::is_same<T, float>::value) {
             if (op_mult == SPLAHIP_BAND && op_add == SPLAHIP_BOR) {
                 hipLaunchKernelGGL((mxv_first_hit_kernel<T, StaBin<SPLAHIP_BAND>, StaBin<SPLAHIP_BOR>, false>), grid, dim3(256), 0, st, n_rows, Ap, Aj, static_cast<const T*>(mask),
                                    static_cast<const T*>(v), static_cast<T*>(r), StaBin<SPLAHIP_BAND>(), StaBin<SPLAHIP_BOR>(), op_select, from_bits<T>(init_bits), xbits,
-                                   plan->d_fh_ctl, plan->d_fh_bits, static_cast<uint32_t*>(nullptr));
+                                   plan->d_fh_ctl, plan->d_fh_bits, static_cast<uint32_t*>(nullptr), early_exit);
                 SPLAHIP_TRY(hipGetLastError());
                 return SPLAHIP_OK;
             }
         }
         hipLaunchKernelGGL((mxv_first_hit_kernel<T, DynBin, DynBin, false>), grid, dim3(256), 0, st, n_rows, Ap, Aj, static_cast<const T*>(mask), static_cast<const T*>(v),
                            static_cast<T*>(r), DynBin(op_mult), DynBin(op_add), op_select, from_bits<T>(init_bits), xbits, plan->d_fh_ctl, plan->d_fh_bits,
-                           static_cast<uint32_t*>(nullptr));
+                           static_cast<uint32_t*>(nullptr), early_exit);
         SPLAHIP_TRY(hipGetLastError());
         return SPLAHIP_OK;
     }
@@ -460,13 +464,13 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
     uint32_t xbits = 0;
     if (first_hit_family(type, op_mult, op_add) && uniform_values(plan, n_cols, &xbits) && d_r != d_mask && d_r != d_v && plan->nnz != 0) {
         bool take = false;
-        int  rc   = type == SPLAHIP_INT ? first_hit_probe<int32_t>(plan, n_cols, d_Ap, d_Aj, d_mask, op_select, d_v, s, &take)
-                                        : first_hit_probe<uint32_t>(plan, n_cols, d_Ap, d_Aj, d_mask, op_select, d_v, s, &take);
+        int  rc   = type == SPLAHIP_INT ? first_hit_probe<int32_t>(plan, n_cols, d_Ap, d_Aj, d_mask, op_select, d_v, early_exit != 0, s, &take)
+                                        : first_hit_probe<uint32_t>(plan, n_cols, d_Ap, d_Aj, d_mask, op_select, d_v, early_exit != 0, s, &take);
         if (rc != SPLAHIP_OK) return rc;
         if (take) {
             plan->fh_taken = 1;
-            return type == SPLAHIP_INT ? launch_first_hit<int32_t>(plan, n_rows, d_Ap, d_Aj, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, xbits, s)
-                                       : launch_first_hit<uint32_t>(plan, n_rows, d_Ap, d_Aj, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, xbits, s);
+            return type == SPLAHIP_INT ? launch_first_hit<int32_t>(plan, n_rows, d_Ap, d_Aj, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, xbits, early_exit, s)
+                                       : launch_first_hit<uint32_t>(plan, n_rows, d_Ap, d_Aj, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, xbits, early_exit, s);
         }
     }
     // the column-ordered-blocks copy (splahip_csr_plan_attach_cob): associative + commutative op_add with an LDS atomic, no early exit

@@ -153,7 +153,8 @@ namespace splahip {
 #define SPLAHIP_FH_UNROLL 2// (measured on the R-MAT 22 traversal step, kernel + pass over v: 1 -> 56 - 63 us, 2 -> 53.5, 3 -> 56.7, 4 -> 63, 8 -> 92: what is read past the hit is wasted)
 #endif
     constexpr uint32_t kFirstHitLane = SPLAHIP_FH_LANE;// entries of its own row a lane walks (SPLAHIP_FH_UNROLL at a time) before the wave takes the row over
-    // VXM = false: the masked SpMV (bits = vstat_kernel's bitmap of the non-zero entries of v; vflag[0] uniform, [1] the word, [2] the non-zero count).
+    // VXM = false: the masked SpMV (bits = vstat_kernel's bitmap of the non-zero entries of v; vflag[0] uniform, [1] the word, [2] the non-zero count); early_exit: the
+    //   call's flag — it only matters when v turns out not to be a frontier (the complete fold then stops a row like the reference does).
     // VXM = true: the pull form of vxm over the TRANSPOSED matrix (reference src/cpu/cpu_vxm.hpp:92-125): "rows" are output indices, bits = the bitmap of the
     //   STORED indices of the sparse input vector (an entry whose index is not stored gives no product), v = its dense image, products are mult(v, x), the fold
     //   starts at the first product (no init) and touched[row] says whether the output entry exists; vflag[0] / vflag[1] = max over the stored value words of
@@ -162,7 +163,7 @@ namespace splahip {
     template<typename T, class Mult, class Add, bool VXM>
     __global__ __launch_bounds__(256) void mxv_first_hit_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ Aj, const T* __restrict__ mask,
                                                                 const T* __restrict__ v, T* __restrict__ r, Mult mult, Add add, int op_select, T init, uint32_t xbits,
-                                                                const uint32_t* __restrict__ vflag, const uint32_t* __restrict__ bits, uint32_t* __restrict__ touched) {
+                                                                const uint32_t* __restrict__ vflag, const uint32_t* __restrict__ bits, uint32_t* __restrict__ touched, int early_exit) {
         const uint32_t row     = blockIdx.x * 256 + threadIdx.x;
         const bool     in      = row < n_rows;
         const bool     sel     = in && eval_sel(op_select, mask[row]);
@@ -222,8 +223,11 @@ namespace splahip {
                     sum       = found_any ? add(sum, p) : p;
                     found_any = true;
                 }
-            } else {
-                for (uint32_t k = k0; k < k1; ++k) sum = add(sum, mult(x, v[Aj[k]]));
+            } else {// (early_exit: the reference's rule, cpu_mxv.hpp:96-98 — the row stops behind the product that moves the sum off init)
+                for (uint32_t k = k0; k < k1; ++k) {
+                    sum = add(sum, mult(x, v[Aj[k]]));
+                    if (early_exit && to_bits(sum) != to_bits(init)) break;
+                }
             }
         }
         if constexpr (VXM) {

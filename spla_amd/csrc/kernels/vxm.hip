@@ -533,10 +533,10 @@ namespace splahip {
                 if (op_mult == SPLAHIP_BAND && op_add == SPLAHIP_BOR)
                     hipLaunchKernelGGL((mxv_first_hit_kernel<T, StaBin<SPLAHIP_BAND>, StaBin<SPLAHIP_BOR>, true>), dim3((n_out + 255) / 256), dim3(256), 0, s, n_out, Tp, Tj,
                                        static_cast<const T*>(mask), d_v, reinterpret_cast<T*>(ws_outv), StaBin<SPLAHIP_BAND>(), StaBin<SPLAHIP_BOR>(), op_select, T(0), xbits, uf,
-                                       d_present, ws_touched);
+                                       d_present, ws_touched, 0);
                 else
                     hipLaunchKernelGGL((mxv_first_hit_kernel<T, DynBin, DynBin, true>), dim3((n_out + 255) / 256), dim3(256), 0, s, n_out, Tp, Tj, static_cast<const T*>(mask), d_v,
-                                       reinterpret_cast<T*>(ws_outv), DynBin(op_mult), DynBin(op_add), op_select, T(0), xbits, uf, d_present, ws_touched);
+                                       reinterpret_cast<T*>(ws_outv), DynBin(op_mult), DynBin(op_add), op_select, T(0), xbits, uf, d_present, ws_touched, 0);
             }
         }
         // every index of v stored + a sliced-ELL copy on the transposed matrix's plan: the value-form kernel in its vxm mode

@@ -798,4 +798,12 @@ def test_first_hit_form_of_a_bfs_like_step(oracle, copy):
         kernels.mxv_masked(plan, t, n_cols, dAp, dAj, dAx, dev(depth), dev(front), early, mul, add, "EQZERO", 0, True)   # early_exit = true: same rule, same result
         torch.cuda.synchronize()
         assert np.array_equal(host(early, NP[t]), oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, depth, front, mul, add, "EQZERO", 0, True))
+        # an early_exit call always takes this kernel (no hint needed); a vector of several words is folded with the reference's early-exit rule (a row stops behind the
+        # product that moves its sum off init: observable with BOR over different words), a sparse frontier and an init that already holds the bits included
+        for vec, init in ((mixed, 0), (mixed, 3), (lone, 0), (empty, 0), (front, 1)):
+            early.fill_(91)
+            kernels.mxv_masked(plan, t, n_cols, dAp, dAj, dAx, dev(depth), dev(vec), early, mul, add, "EQZERO", init, True)
+            torch.cuda.synchronize()
+            assert plan.first_hit()["taken"]
+            assert np.array_equal(host(early, NP[t]), oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, depth, vec, mul, add, "EQZERO", init, True)), (t, mul, add, init)
         plan.close()
