@@ -72,8 +72,7 @@ namespace splahip {
         hipLaunchKernelGGL(d2c_write_kernel<T>, dim3(n_chunks), dim3(256), 0, s, static_cast<const T*>(d_dense), n, fill, d_chunk,
                            static_cast<uint*>(d_idx), static_cast<T*>(d_val));
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(h_count, d_chunk + n_chunks, sizeof(uint), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = fetch_words(h_count, d_chunk + n_chunks, 1, s);
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "dense_to_coo failed: %s", hipGetErrorString(e));
         return SPLAHIP_OK;
     }
