@@ -46,12 +46,9 @@ namespace splahip {
         __global__ __launch_bounds__(64) void mailbox_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n) {
             if (threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
         }
-        struct Mailbox {
+        struct Mailbox {// (64 bytes of pinned memory per host thread, kept for the life of the process: a thread_local's destructor may run after the HIP runtime's)
             uint32_t* host = nullptr;
             uint32_t* dev  = nullptr;
-            ~Mailbox() {
-                if (host) (void) hipHostFree(host);
-            }
         };
     }// namespace
     hipError_t fetch_words(void* h_dst, const void* d_src, uint32_t n_words, hipStream_t stream) {
