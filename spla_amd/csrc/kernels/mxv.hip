@@ -118,13 +118,22 @@ namespace {
         if (plan->d_fh_ctl && plan->fh_cols == n_cols) return SPLAHIP_OK;
         if (plan->d_fh_ctl) return SPLAHIP_ERROR;// (a plan serves one matrix: one column count)
         const size_t bit_words = ((size_t) n_cols + 2047u) / 2048u * 64u;
-        SPLAHIP_TRY(device_malloc(reinterpret_cast<void**>(&plan->d_fh_bits), sizeof(uint32_t) * bit_words));
-        SPLAHIP_TRY(device_malloc(reinterpret_cast<void**>(&plan->d_fh_ctl), sizeof(uint32_t) * (8 + 8 * (size_t) kVstatBlocks)));
-        SPLAHIP_TRY(hipMemset(plan->d_fh_ctl, 0, sizeof(uint32_t) * (8 + 8 * (size_t) kVstatBlocks)));
-        SPLAHIP_TRY(hipHostMalloc(reinterpret_cast<void**>(const_cast<uint32_t**>(&plan->h_fh)), 8 * sizeof(uint32_t), hipHostMallocMapped));
-        for (int k = 0; k < 8; ++k) plan->h_fh[k] = 0;
-        SPLAHIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&plan->d_h_fh), const_cast<uint32_t*>(plan->h_fh), 0));
-        plan->fh_cols = n_cols;
+        uint32_t *   bits = nullptr, *ctl = nullptr, *host = nullptr, *host_dev = nullptr;
+        hipError_t   e    = device_malloc(reinterpret_cast<void**>(&bits), sizeof(uint32_t) * bit_words);
+        if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(&ctl), sizeof(uint32_t) * (8 + 8 * (size_t) kVstatBlocks));
+        if (e == hipSuccess) e = hipMemset(ctl, 0, sizeof(uint32_t) * (8 + 8 * (size_t) kVstatBlocks));
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&host), 8 * sizeof(uint32_t), hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&host_dev), host, 0);
+        if (e != hipSuccess) {// (nothing half-built stays with the plan: the other forms serve its calls)
+            if (bits) (void) hipFree(bits);
+            if (ctl) (void) hipFree(ctl);
+            if (host) (void) hipHostFree(host);
+            (void) hipGetLastError();
+            return SPLAHIP_ERROR;
+        }
+        for (int k = 0; k < 8; ++k) host[k] = 0;
+        plan->d_fh_bits = bits, plan->d_fh_ctl = ctl, plan->h_fh = host, plan->d_h_fh = host_dev;
+        plan->fh_cols   = n_cols;
         return SPLAHIP_OK;
     }
     // Enqueue the pass over v (bitmap, uniformity, a sampled estimate of the walk's cost; its verdict also lands in pinned host memory) and say whether THIS call
