@@ -594,6 +594,18 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
     res[-1]["roofline_frac_required_bytes"] = round(b_req / (ms_e * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     res[-1]["roofline_frac_full_nnz_sel"] = res[-1].pop("roofline_frac")
     res[-1]["note"] = "one lane per row walks its row until the first hit: the required-bytes fraction is the bandwidth figure; the full-nnz_sel fraction is listed as SURVEY 8d asks and is not a bandwidth claim"
+    # the same early-exit call as the operator API's bfs() issues it: the matrix's owner has told the plan that every stored value is one word (spla_hip.h:
+    # splahip_csr_plan_set_uniform_values; algos_hip.cpp does at upload), so the call runs on the first-hit kernel (mxv_first_hit.hpp) without any hint
+    plan_u = kernels.CsrPlan(n_local, nnz_local, g["Ap"])
+    plan_u.set_uniform_values(True, 1)
+    run("bfs-step early_exit=true, the plan told that the matrix is structure-only (what the operator API's bfs() runs)", "INT", ones_i, mask, v_full, r_i, "BAND", "BOR", "EQZERO", 0, True,
+        nnz_sel_local, plan=plan_u)
+    ms_u = res[-1]["kernel_avg_us"] * 1e-3
+    res[-1]["entries_required"] = req
+    res[-1]["roofline_frac_required_bytes"] = round((4 * req + 4 * (n_local + 1) + 8 * n_local + 4 * sh.n_cols_padded) / (ms_u * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    res[-1]["roofline_frac_full_nnz_sel"] = res[-1].pop("roofline_frac")
+    res[-1]["note"] = "pass over v (bitmap, one-word test) + first-hit kernel; required bytes at 4 B per required entry (column ids only)"
+    plan_u.close()
     zeros_i = torch.zeros(n_local, dtype=torch.int32, device="cuda")
     run("all rows selected, BAND/BOR int32", "INT", ones_i, zeros_i, v_full, r_i, "BAND", "BOR", "EQZERO", 0, False, nnz_local)
     gen = torch.Generator(device="cuda")
