@@ -143,7 +143,7 @@ int splahip_csr_plan_hint_products(splahip_plan plan, uint64_t products);
  * copy): splahip_mxv_masked passes over v once per call (bitmap; is every non-zero entry the same word?; a 4096-row sample of how far a first-hit walk would
  * go) and, when the LATEST FINISHED pass saw a frontier whose walk mostly ends within a row's first four entries, settles every row by its first hit over plain
  * CSR — the traversal step of reference src/algorithm.cpp:97-99 whatever early_exit says; results are the reference's for any vector and mask (a stale hint
- * only costs time).  Reports what the plan's last such call did: *taken = 1 if it ran on the first-hit kernel; *uniform = the last finished pass' verdict
+ * only costs time).  A call with early_exit != 0 takes the kernel without a hint (a vector of several words is then folded with the reference's early-exit rule).  Reports what the plan's last such call did: *taken = 1 if it ran on the first-hit kernel; *uniform = the last finished pass' verdict
  * (-1: none yet); *nonzeros = its non-zero count; *tail_pct = share (%) of the sampled selected entries in rows the walk would enter past their fourth entry. */
 int splahip_csr_plan_first_hit(splahip_plan plan, int* taken, int* uniform, uint32_t* nonzeros, uint32_t* tail_pct);
 int splahip_csr_plan_info(splahip_plan plan, uint32_t* n_items, uint32_t* n_long);
