@@ -42,10 +42,15 @@ while time.time() - t0 < budget:
         n_rows, n_cols = int(rng.integers(1, 3000)), int(rng.integers(1, 3000))
         A = random_csr(rng, n_rows, n_cols, float(rng.choice([1, 6, 25])), t, skew=bool(rng.integers(0, 2)), long_rows=int(rng.integers(0, 3)),
                        long_len=int(min(n_cols, rng.choice([100, 700, 2500]))))
+        uniform = rng.random() < 0.3 and len(A[2]) > 0  # a structure-only matrix: the pull form may settle an output entry at its first stored in-neighbour
+        if uniform:
+            A = (A[0], A[1], np.full_like(A[2], A[2][0]))
         mask = random_mask(rng, n_cols, t)
         nv = int(rng.choice([1, max(1, n_rows // 50), max(1, n_rows // 3), n_rows]))
         vi = np.sort(rng.permutation(n_rows)[:nv]).astype(np.uint32)
         vx = random_values(rng, nv, t, zeros=0.2)
+        if uniform and rng.random() < 0.7:
+            vx = np.full_like(vx, vx[0])  # a frontier: one stored word (possibly 0)
         want = orc.vxm_masked(t, n_rows, n_cols, *A, mask, vi, vx, mul, add, sel)
         dA, dm, dvi, dvx = d3(A, t), dev(np.asarray(mask, NP[t])), dev(vi), dev(np.asarray(vx, NP[t]))
         ri, rx = kernels.vxm_push(t, n_rows, n_cols, *dA, dm, dvi, dvx, mul, add, sel)
@@ -58,6 +63,9 @@ while time.time() - t0 < budget:
             Tp, Tj, Tx = kernels.csr_transpose(n_rows, n_cols, *dA)
             for sell in (False, True):
                 plan = kernels.CsrPlan(n_cols, len(A[1]), Tp, n_rows, Tj, Tx) if sell else kernels.CsrPlan(n_cols, len(A[1]), Tp)
+                if uniform:  # what the owner of the matrix and the caller's probe would say (spla_hip.h: set_uniform_values, hint_products)
+                    plan.set_uniform_values(True, int(np.asarray(A[2][:1], NP[t]).view(np.uint32)[0]))
+                    plan.hint_products(int(np.diff(A[0].astype(np.int64))[vi].sum()) * int(rng.choice([1, 1000])))
                 ri, rx = kernels.vxm_pull(plan, t, n_rows, n_cols, Tp, Tj, Tx, dm, dvi, dvx, mul, add, sel, identity=(nv == n_rows))
                 assert np.array_equal(host(ri, np.uint32), want[0]), what + f" pull idx sell={sell}"
                 close(t, add, host(rx, NP[t]), want[1], what + f" pull val sell={sell}")
