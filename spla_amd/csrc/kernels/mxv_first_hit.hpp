@@ -22,8 +22,11 @@ namespace splahip {
     // part: kVstatBlocks x 8 words of per-workgroup statistics (count, min, max of the non-zero words; sampled selected entries, sampled tail entries); ticket: one word, 0 between calls.
     // The last workgroup to finish reduces them: vflag[0] = 1 if uniform (or empty), vflag[1] = the word, vflag[2] = non-zero count; and sums the workgroups' samples of
     // what the first-hit walk would cost on this call (below); the verdicts and the call's sequence number go to pinned host memory (host_words[0..7]: the NEXT call's hint).
+#ifndef SPLAHIP_VSTAT_BLOCKS
+#define SPLAHIP_VSTAT_BLOCKS 256
+#endif
     constexpr uint32_t kVstatTpb    = 512;
-    constexpr uint32_t kVstatBlocks = 256;// one workgroup per CU: the closing ticket is a same-address atomic per workgroup (~10 ns each, serialised)
+    constexpr uint32_t kVstatBlocks = SPLAHIP_VSTAT_BLOCKS;// one workgroup per CU: the closing ticket is a same-address atomic per workgroup (~10 ns each, serialised)
     template<typename T>
     __global__ __launch_bounds__(kVstatTpb) void vstat_kernel(uint32_t n_cols, const T* __restrict__ v, uint32_t* __restrict__ bits, uint32_t* __restrict__ part,
                                                         uint32_t* __restrict__ ticket, uint32_t* __restrict__ vflag, volatile uint32_t* __restrict__ host_words, uint32_t seq,
@@ -40,7 +43,11 @@ namespace splahip {
         // (three dependent rounds — mask / Ap, the column ids, the words of v — threaded through the wave's first step of the stream: the rounds wait for their own
         // loads only, the 32 stream loads issued in between stay in flight)
         uint32_t       s_sel = 0, s_tail = 0;
+#ifdef SPLAHIP_VSTAT_NOSAMPLE
+        const bool     sampler = false;// (diagnostic build: what the sample costs)
+#else
         const bool     sampler = threadIdx.x < kWave;
+#endif
         const uint32_t s_i     = threadIdx.x & 3u;
         uint32_t       s_k0 = 0, s_k1 = 0, s_c = 0, s_v = 0;
         bool           s_has = false;
