@@ -140,7 +140,7 @@ int splahip_words_range(const void* d_words, size_t n, uint32_t* lo, uint32_t* h
  * the entries is settled output entry by output entry at the first stored in-neighbour (mxv_first_hit.hpp) instead of folding every row completely. */
 int splahip_csr_plan_hint_products(splahip_plan plan, uint64_t products);
 /* BFS-like calls (BAND / MULT / LAND products folded by BOR or uint MAX) over a matrix whose stored values are all one word (known from an attached layout
- * copy): splahip_mxv_masked passes over v once per call (bitmap; is every non-zero entry the same word?; a 4096-row sample of how far a first-hit walk would
+ * copy): splahip_mxv_masked passes over v once per call (bitmap; is every non-zero entry the same word?; a 2048-row sample of how far a first-hit walk would
  * go) and, when the LATEST FINISHED pass saw a frontier whose walk mostly ends within a row's first four entries, settles every row by its first hit over plain
  * CSR — the traversal step of reference src/algorithm.cpp:97-99 whatever early_exit says; results are the reference's for any vector and mask (a stale hint
  * only costs time).  A call with early_exit != 0 takes the kernel without a hint (a vector of several words is then folded with the reference's early-exit rule).  Reports what the plan's last such call did: *taken = 1 if it ran on the first-hit kernel; *uniform = the last finished pass' verdict

@@ -23,7 +23,7 @@ namespace splahip {
     // The last workgroup to finish reduces them: vflag[0] = 1 if uniform (or empty), vflag[1] = the word, vflag[2] = non-zero count; and sums the workgroups' samples of
     // what the first-hit walk would cost on this call (below); the verdicts and the call's sequence number go to pinned host memory (host_words[0..7]: the NEXT call's hint).
 #ifndef SPLAHIP_VSTAT_BLOCKS
-#define SPLAHIP_VSTAT_BLOCKS 256
+#define SPLAHIP_VSTAT_BLOCKS 128// (the closing ticket is a same-address atomic per workgroup: 32 / 64 / 128 / 256 / 512 workgroups -> 26.8 / 17.3 / 14.5 / 16.5 - 17.3 / 24.0 us at 4.2 M columns)
 #endif
     constexpr uint32_t kVstatTpb    = 512;
     constexpr uint32_t kVstatBlocks = SPLAHIP_VSTAT_BLOCKS;// one workgroup per CU: the closing ticket is a same-address atomic per workgroup (~10 ns each, serialised)
@@ -36,7 +36,7 @@ namespace splahip {
         __shared__ uint32_t s_last;
         uint32_t            count = 0, mn = 0xFFFFFFFFu, mx = 0;
         const uint32_t*     w     = reinterpret_cast<const uint32_t*>(v);
-        // What would the first-hit walk cost on THIS call?  A sample of kVstatBlocks x 16 = 4096 rows, evenly spaced, 16 per workgroup (its first wave: four lanes
+        // What would the first-hit walk cost on THIS call?  A sample of kVstatBlocks x 16 = 2048 rows, evenly spaced, 16 per workgroup (its first wave: four lanes
         // per row, one of the row's first four entries each; the loads run under the wave's share of the stream below): a selected row that holds more than four
         // entries and no hit among its first four is a TAIL row — the walk goes on into it.  The host takes the first-hit kernel while the tail rows' entries stay
         // a small share of the sampled selected entries (mxv.hip).
