@@ -210,18 +210,17 @@ namespace {
         const T        init = from_bits<T>(init_bits);
         const uint32_t n    = plan->n_rows;
         // (d_rows_ctl[0] short rows listed, [1] segment items listed: returned to zero by the call's mask probe, enqueued just before)
-        hipLaunchKernelGGL((rows_compact_kernel<T>), dim3(2048), dim3(256), 0, st, n, Ap, static_cast<const T*>(mask), op_select, init, static_cast<T*>(r), plan->d_rows_list,
+        // (workgroups: every flush of a workgroup's list is a same-address atomic — 256 / 512 / 1024 / 2048 / 4096 workgroups at R-MAT 23, 10 % of the light rows: 103 / 87 /
+        // 86 / 99 / 113 us per call)
+        hipLaunchKernelGGL((rows_compact_kernel<T>), dim3(knob_u32("SPLAHIP_ROWS_COMPACT_BLOCKS", 1024)), dim3(256), 0, st, n, Ap, static_cast<const T*>(mask), op_select, init, static_cast<T*>(r), plan->d_rows_list,
                            plan->d_rows_ctl, plan->d_item_row, plan->n_items, Cfg::kSegFlag, Cfg::kSeg, plan->d_long_items, gate);
-        hipLaunchKernelGGL((rows_short_kernel<T, Mult, Add>), dim3(2048), dim3(256), 0, st, plan->d_rows_list, plan->d_rows_ctl, Ap, Aj, static_cast<const uint32_t*>(Ax),
+        hipLaunchKernelGGL((rows_short_kernel<T, Mult, Add>), dim3(knob_u32("SPLAHIP_ROWS_SHORT_BLOCKS", 4096)), dim3(256), 0, st, plan->d_rows_list, plan->d_rows_ctl, Ap, Aj, static_cast<const uint32_t*>(Ax),
                            static_cast<const T*>(v), static_cast<T*>(r), Mult(op_mult), Add(op_add), init, plan->nnz, gate);
         SPLAHIP_TRY(hipGetLastError());
-        if (plan->n_items) {// the selected long rows' segment items: the list's length is only known on the device, so the launch covers the plan's items (a wave behind the
-                            // list's end returns at once)
-            const uint32_t long_grid = (plan->n_items + Cfg::kWaves - 1) / Cfg::kWaves;
-            hipLaunchKernelGGL((spmv_wavetile_kernel<Cfg, T, Mult, Add, false>), dim3(long_grid), dim3(Cfg::kTpb), 0, st, plan->d_item_row,
-                               plan->d_item_k0, plan->n_items, Ap, Aj, static_cast<const uint32_t*>(Ax), static_cast<const T*>(mask), static_cast<const T*>(v),
-                               static_cast<const uint32_t*>(nullptr), static_cast<T*>(r), static_cast<uint32_t*>(nullptr), reinterpret_cast<T*>(plan->d_partial),
-                               static_cast<uint32_t*>(nullptr), Mult(op_mult), Add(op_add), op_select, init, plan->nnz, gate, plan->d_long_items, plan->d_rows_ctl + 1);
+        if (plan->n_items && plan->n_long > 0) {// the selected long rows' segment items (mxv_rows.hpp: rows_long_kernel; a plan without long rows lists none)
+            hipLaunchKernelGGL((rows_long_kernel<T, Mult, Add>), dim3(512), dim3(256), 0, st, plan->d_long_items, plan->d_rows_ctl + 1, plan->d_item_row, plan->d_item_k0, Ap, Aj,
+                               static_cast<const uint32_t*>(Ax), static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(plan->d_partial), Mult(op_mult), Add(op_add), init,
+                               Cfg::kSegFlag, Cfg::kSeg, gate);
             SPLAHIP_TRY(hipGetLastError());
             if (plan->n_long > 0) {
                 hipLaunchKernelGGL((spmv_combine_kernel<Cfg, T, Add, false>), dim3((plan->n_items + 255) / 256), dim3(256), 0, st, plan->d_item_row, plan->d_item_k0, plan->n_items,

@@ -217,4 +217,38 @@ namespace splahip {
         }
     }
 
+    // The selected LONG rows (more than kRowsShortMax entries: the plan cuts them into segment items of seg_len entries; rows_compact_kernel listed the items of the
+    // selected ones): a fixed grid whose waves take listed items in turn — the list's length is only known on the device, and launching a wave per item of the PLAN
+    // (128 K at R-MAT 23, nearly all of which return at once) cost 17 us per call.  A wave folds its segment lane-strided (op_add is associative and commutative on
+    // this path), joins the lanes in order and leaves the partial for the combine kernel; a row of one segment is finished here (r = add(init, fold)).
+    template<typename T, class Mult, class Add>
+    __global__ __launch_bounds__(256) void rows_long_kernel(const uint32_t* __restrict__ long_items, const uint32_t* __restrict__ n_listed, const uint32_t* __restrict__ item_row,
+                                                            const uint32_t* __restrict__ item_k0, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ Aj,
+                                                            const uint32_t* __restrict__ Ax, const T* __restrict__ v, T* __restrict__ r, T* __restrict__ partial, Mult mult,
+                                                            Add add_raw, T init, uint32_t seg_flag, uint32_t seg_len, const uint32_t* __restrict__ gate) {
+        if (gate[3] == 0u) return;
+        const Reassoc<Add> add(add_raw);
+        const uint32_t     n    = *n_listed;
+        const uint32_t     lane = lane_id();
+        for (uint32_t w = blockIdx.x * (256 / kWave) + threadIdx.x / kWave; w < n; w += gridDim.x * (256 / kWave)) {
+            const uint32_t item = long_items[w];
+            const uint32_t row  = item_row[item] & ~seg_flag;
+            const uint32_t k0 = item_k0[item], k1 = item_k0[item + 1];
+            T    part  = init;
+            bool valid = false;
+            for (uint32_t k = k0 + lane; k < k1; k += kWave) {
+                const T p = mult(from_bits<T>(Ax[k]), v[Aj[k]]);
+                part      = valid ? add(part, p) : p;
+                valid     = true;
+            }
+            wave_reduce_ordered(part, valid, add);
+            if (lane == 0) {
+                const uint32_t len = Ap[row + 1] - Ap[row];
+                if (len <= seg_len) r[row] = valid ? add(init, part) : init;// a row of one segment: finished here (the combine kernel skips it)
+                else
+                    partial[item] = part;
+            }
+        }
+    }
+
 }// namespace splahip
