@@ -19,6 +19,7 @@
 #include "block_utils.hpp"
 #include "common.hpp"
 #include "mxv_cob.hpp"
+#include "mxv_cob_dyn.hpp"
 #include "ops.hpp"
 #include "plan.hpp"
 
@@ -498,10 +499,17 @@ namespace {
         const T init = from_bits<T>(init_bits);
         if (!sc.n_tiles) return fail(SPLAHIP_NOT_IMPLEMENTED, "the column-ordered blocks hold no schedule for this slice width");// (cob_serves says so beforehand)
         // the shared accumulators rest at the identity of the op_add that used them last: re-arm them when this call's differs
-        const uint32_t n_multi_max = std::max(g->sched[0].n_multi, g->sched[1].n_multi);
+        const uint32_t n_multi_max = std::max(std::max(g->sched[0].n_multi, g->sched[1].n_multi), g->n_ranges);
         if (n_multi_max && (!g->acc_armed || g->acc_identity != cob_identity<T, ACC>())) {
             hipLaunchKernelGGL(cob_fill32_kernel, dim3(256), dim3(256), 0, st, (size_t) n_multi_max * g->acc_stride, g->d_acc, cob_identity<T, ACC>());
             hipLaunchKernelGGL(cob_fill32_kernel, dim3(1), dim3(256), 0, st, (size_t) g->ticket_words, g->d_ticket, 0u);
+            // the run-time schedule's words: cursors and states 0, next listed job = the grid (a workgroup's first job is its own index), nobody has left
+            hipLaunchKernelGGL(cob_fill32_kernel, dim3(4), dim3(256), 0, st, (size_t) g->n_ranges * 3, g->d_dyn_words, 0u);
+            for (int w2 = 0; w2 < 2; ++w2)
+                if (g->sched[w2].d_dyn_ctl) {
+                    hipLaunchKernelGGL(cob_fill32_kernel, dim3(1), dim3(64), 0, st, (size_t) 1, g->sched[w2].d_dyn_ctl, g->sched[w2].slots);
+                    hipLaunchKernelGGL(cob_fill32_kernel, dim3(1), dim3(64), 0, st, (size_t) 1, g->sched[w2].d_dyn_ctl + 1, 0u);
+                }
             SPLAHIP_TRY(hipGetLastError());
             g->acc_identity = cob_identity<T, ACC>();
             g->acc_armed    = true;
@@ -528,6 +536,36 @@ namespace {
                 COB_TRY(hipGetLastError());
                 launched = true;
             }
+        }
+        if (!launched && g->dyn && sc.n_jobs) {
+            CobDynArgs d;
+            d.jobs          = sc.d_jobs;
+            d.spans         = reinterpret_cast<const CobDynSpan*>(g->d_spans);
+            d.cursor        = g->d_dyn_words;
+            d.state         = g->d_dyn_words + g->n_ranges;
+            d.ctl           = sc.d_dyn_ctl;
+            d.n_jobs        = sc.n_jobs;
+            d.n_ranges      = g->n_ranges;
+            d.weight        = g->d_dyn_weight;
+            d.fin_flag      = g->d_dyn_words + 2 * (size_t) g->n_ranges;
+            g->dyn_seq      = g->dyn_seq + 1 ? g->dyn_seq + 1 : 1;
+            d.seq           = g->dyn_seq;
+            a.ranges        = reinterpret_cast<const CobRange*>(g->d_dyn_ranges);
+            d.min_cost_hub   = g->dyn_min_hub;
+            d.min_cost_nat   = g->dyn_min_nat;
+            COB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_dyn_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            hipLaunchKernelGGL((cob_dyn_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), dim3(sc.slots), dim3(kTpb), sc.lds_bytes, st, a, d, static_cast<const T*>(v),
+                               static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
+            COB_TRY(hipGetLastError());
+            // the rows of every range: hub slots and natural row tasks in one launch
+            const uint32_t n_slots = g->n_hub_ranges * g->R, hub_blocks = (n_slots + 255) / 256;
+            if (hub_blocks + g->n_fin_tasks) {
+                hipLaunchKernelGGL((cob_finish_kernel<T, ACC, VXM>), dim3(hub_blocks + g->n_fin_tasks), dim3(256), 0, st, hub_blocks, n_slots, g->R, g->acc_stride, g->d_acc, g->d_hub_row,
+                                   reinterpret_cast<const CobRange*>(g->d_fin_tasks), d.fin_flag, d.seq, g->d_slot16, g->n_rows, static_cast<const T*>(mask), static_cast<T*>(r), touched, a.accumulate,
+                                   DynBin(op_add), op_select, init);
+                COB_TRY(hipGetLastError());
+            }
+            return SPLAHIP_OK;
         }
         if (!launched) {
             COB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_mxv_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -634,7 +672,9 @@ namespace splahip {
         if (!g) return;
         if (g->h_probe) (void) hipHostFree(const_cast<uint32_t*>(g->h_probe));
         for (void* p : {(void*) g->d_hdr, (void*) g->d_cr, (void*) g->d_ax, (void*) g->d_slot16, (void*) g->d_hub_row, (void*) g->d_acc, (void*) g->d_ticket, (void*) g->d_vbits, (void*) g->d_probe, (void*) g->d_hot_cols, (void*) g->d_vperm,
-                        (void*) g->sched[0].d_tiles, (void*) g->sched[0].d_ranges, (void*) g->sched[1].d_tiles, (void*) g->sched[1].d_ranges})
+                        (void*) g->sched[0].d_tiles, (void*) g->sched[0].d_ranges, (void*) g->sched[1].d_tiles, (void*) g->sched[1].d_ranges, (void*) g->d_spans, (void*) g->d_dyn_words,
+                        (void*) g->sched[0].d_jobs, (void*) g->d_fin_tasks, (void*) g->d_dyn_weight, (void*) g->d_dyn_ranges, (void*) g->sched[0].d_dyn_ctl, (void*) g->sched[1].d_jobs,
+                        (void*) g->sched[1].d_dyn_ctl})
             if (p) (void) hipFree(p);
         delete g;
     }
@@ -1312,8 +1352,106 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         own(&sc.d_ranges, ranges.size());
         if (e == hipSuccess && !sorted.empty()) e = hipMemcpyAsync(sc.d_tiles, sorted.data(), 4 * sorted.size(), hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipMemcpyAsync(sc.d_ranges, ranges.data(), 4 * ranges.size(), hipMemcpyHostToDevice, s);
+        // The run-time schedule (mxv_cob_dyn.hpp): `slots` persistent workgroups; the job list only says where they START.  A hub range is listed once per
+        // worker its modelled cost is worth (cost / a slot's even share, rounded), a natural range once (a second worker would cost both a 128 KB merge);
+        // order: as many natural ranges as the hub workers leave slots for, dearest first (a natural range is walked by ONE workgroup at cold-line speed:
+        // the longest ones must not start late), then the hub ranges' workers, then the remaining natural ranges dearest first — the natural workers take
+        // them as they finish.  Whatever the model got wrong is evened out at run time: a workgroup that finds the list used up joins the range with the
+        // most unclaimed quads per worker.  tile_chunks (tests) / SPLAHIP_COB_DYN_WORKERS list every range several times: the merge path on small inputs.
+        std::vector<uint32_t> jobs;
+        {
+            const uint32_t dyn_workers = env_u32("SPLAHIP_COB_DYN_WORKERS", 0);
+            std::vector<std::pair<uint64_t, uint32_t>> nat;
+            std::vector<uint64_t>                      hub_cost(n_hub_ranges, 0);
+            uint64_t                                   hub_total = 0;
+            for (uint32_t q = 0; q < n_ranges; ++q) {
+                const uint32_t c0 = range_chunk[q], c1 = range_chunk[q + 1];
+                const bool     hub = q < n_hub_ranges;
+                const uint64_t rc  = cost_pre[c1] - cost_pre[c0];
+                if (hub) hub_cost[q] = rc, hub_total += rc;
+                else
+                    nat.emplace_back(rc, q);
+            }
+            std::stable_sort(nat.begin(), nat.end(), [](const auto& x, const auto& y) { return x.first > y.first; });
+            // a natural range is walked by ONE workgroup from start to end at cold-line speed (measured: ~200 ns per chunk against ~95 in a hub range — a
+            // 1500-chunk range is as long as the whole launch), so the natural ranges start FIRST, as many as there are slots beside one worker per hub
+            // range; the hub ranges share the slots that are left in proportion to their cost (they are elastic: whoever runs out of work joins them)
+            const uint32_t first_nat  = (uint32_t) std::min<size_t>(nat.size(), slots > n_hub_ranges ? slots - n_hub_ranges : 0u);
+            for (uint32_t i = 0; i < first_nat; ++i) jobs.push_back(nat[i].second);
+            // ... and a natural range that ALONE would take most of the launch gets a second worker from the start (they then share its rounds and merge:
+            // ~25 us of a CU, against a pole of up to 1.2 x the launch at R-MAT 23).  Lengths from measured rates: ~95 ns per hub chunk, ~210 per natural chunk.
+            uint32_t n_second = 0;
+            {
+                const uint64_t hub_chunks = n_hub_ranges ? range_chunk[n_hub_ranges] : 0u, nat_chunks = n_chunks - hub_chunks;
+                const uint64_t ideal_ns   = (hub_chunks * 95u + nat_chunks * 210u) / std::max(1u, slots);
+                const uint32_t pct        = env_u32("SPLAHIP_COB_DYN_NAT_SOLO_PCT", 80);
+                for (uint32_t i = 0; i < first_nat && first_nat + n_second + n_hub_ranges < slots; ++i) {
+                    const uint32_t q = nat[i].second;
+                    if ((uint64_t) (range_chunk[q + 1] - range_chunk[q]) * 210u * 100u > ideal_ns * pct) jobs.push_back(q), ++n_second;
+                }
+            }
+            const uint32_t hub_slots = std::max(n_hub_ranges, slots > first_nat + n_second ? slots - first_nat - n_second : 0u);
+            uint32_t given = 0;
+            uint64_t run   = 0;
+            for (uint32_t q = 0; q < n_hub_ranges; ++q) {// largest-remainder shares of hub_slots, at least one each
+                run += hub_cost[q];
+                uint32_t upto = hub_total ? (uint32_t) ((run * hub_slots + hub_total / 2) / hub_total) : q + 1;
+                uint32_t k    = std::max(1u, upto > given ? upto - given : 0u);
+                if (dyn_workers) k = dyn_workers;
+                if (tile_chunks) k = std::max(k, std::min(8u, (range_chunk[q + 1] - range_chunk[q] + tile_chunks - 1) / tile_chunks));
+                given += k;
+                jobs.insert(jobs.end(), k, q);
+            }
+            for (size_t i = first_nat; i < nat.size(); ++i) jobs.push_back(nat[i].second);
+            if (dyn_workers > 1 || tile_chunks)// (tests: the merge path of the natural ranges on small inputs)
+                for (const auto& nq : nat) jobs.insert(jobs.end(), std::min(7u, std::max(dyn_workers, 2u) - 1u), nq.second);
+        }
+        sc.slots  = slots;
+        sc.n_jobs = (uint32_t) jobs.size();
+        own(&sc.d_jobs, jobs.size());
+        own(&sc.d_dyn_ctl, 2);
+        if (e == hipSuccess && !jobs.empty()) e = hipMemcpyAsync(sc.d_jobs, jobs.data(), 4 * jobs.size(), hipMemcpyHostToDevice, s);
+        if (knob_env("SPLAHIP_COB_TRACE")) std::fprintf(stderr, "[cob] run-time schedule %d: %u slots, %zu listed jobs over %u ranges\n", w, slots, jobs.size(), n_ranges);
         if (e == hipSuccess) e = hipStreamSynchronize(s);// the vectors go out of scope
     }
+    // SPLAHIP_COB_DYN=1: the run-time schedule of mxv_cob_dyn.hpp instead of the static pieces.  Measured (profiles/r05_notes.md 1): correct everywhere, and NOT
+    // faster — R-MAT 23 fp32 plus-times 282 us against 270 for the main launch (300 against 284 per call), R-MAT 22 165 against 143: the launch still ends with
+    // ~50 us in which few CUs walk the last rounds at latency speed, and every worker that joins a range late pays its zeroing, pipeline fill and merge.  Off by default.
+    g->dyn         = env_u32("SPLAHIP_COB_DYN", 0) != 0;
+    g->dyn_min_hub = env_u32("SPLAHIP_COB_DYN_MIN_HUB", 2400);// unclaimed weighted cost per worker: chunks x 1/16 plain-stream chunks (~5 ns each): 2400 ~ 12 us of walking (joining costs ~8 us; a natural range ~25)
+    g->dyn_min_nat = env_u32("SPLAHIP_COB_DYN_MIN_NAT", 8000);
+    {
+        std::vector<uint32_t> spans((size_t) n_ranges * 2);
+        for (uint32_t q = 0; q < n_ranges; ++q) spans[2 * (size_t) q] = range_chunk[q], spans[2 * (size_t) q + 1] = range_chunk[q + 1] - range_chunk[q];
+        own(&g->d_spans, spans.size());
+        own(&g->d_dyn_words, (size_t) n_ranges * 3);// cursors, states, finish flags
+        if (e == hipSuccess) e = hipMemcpyAsync(g->d_spans, spans.data(), 4 * spans.size(), hipMemcpyHostToDevice, s);
+        // modelled cost of one chunk of a range in 1/16 of a plain stream chunk's (the steal rule weighs a range's unclaimed chunks with it); the ranges
+        // as the row pass wants them (a lone worker of a natural range finishes its rows itself)
+        std::vector<uint16_t> weight(n_ranges);
+        std::vector<uint32_t> dyn_ranges((size_t) n_ranges * 4);
+        for (uint32_t q = 0; q < n_ranges; ++q) {
+            const uint32_t c0 = range_chunk[q], c1 = range_chunk[q + 1];
+            weight[q]         = (uint16_t) std::min<uint64_t>(65535, c1 > c0 ? (cost_pre[c1] - cost_pre[c0]) / (100ull * (c1 - c0)) : 16);
+            const bool hub    = q < n_hub_ranges;
+            dyn_ranges[4 * (size_t) q + 0] = hub ? 0u : nat_row0[q - n_hub_ranges], dyn_ranges[4 * (size_t) q + 1] = hub ? 0u : nat_row0[q - n_hub_ranges + 1];
+            dyn_ranges[4 * (size_t) q + 2] = hub ? q * R : 0xFFFFFFFFu, dyn_ranges[4 * (size_t) q + 3] = 1u;
+        }
+        own(&g->d_dyn_weight, weight.size());
+        own(&g->d_dyn_ranges, dyn_ranges.size());
+        if (e == hipSuccess) e = hipMemcpyAsync(g->d_dyn_weight, weight.data(), 2 * weight.size(), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(g->d_dyn_ranges, dyn_ranges.data(), 4 * dyn_ranges.size(), hipMemcpyHostToDevice, s);
+        // the finishing kernel's row tasks: at most 2048 consecutive rows of one natural range each (row0, row1, -, range)
+        std::vector<uint32_t> tasks;
+        for (uint32_t q = n_hub_ranges; q < n_ranges; ++q)
+            for (uint32_t r0 = nat_row0[q - n_hub_ranges]; r0 < nat_row0[q - n_hub_ranges + 1]; r0 += 2048u)
+                tasks.insert(tasks.end(), {r0, std::min(r0 + 2048u, nat_row0[q - n_hub_ranges + 1]), 0xFFFFFFFFu, q});
+        g->n_fin_tasks = (uint32_t) (tasks.size() / 4);
+        own(&g->d_fin_tasks, tasks.size());
+        if (e == hipSuccess && !tasks.empty()) e = hipMemcpyAsync(g->d_fin_tasks, tasks.data(), 4 * tasks.size(), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    max_multi = std::max(max_multi, n_ranges);// the run-time schedule: any range may be shared, accumulator q belongs to range q
     own(&g->d_acc, (size_t) max_multi * g->acc_stride);
     g->ticket_words = max_multi + 4 + 32;
     own(&g->d_ticket, (size_t) g->ticket_words);
@@ -1391,5 +1529,13 @@ extern "C" int splahip_csr_plan_cob_slots(splahip_plan plan, uint32_t* hub_slots
 // DIAGNOSTIC BUILD ONLY: copy out the per-workgroup stamps of the last cob launch (8 x 8192 64-bit words)
 extern "C" int splahip_debug_cob_timing(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(splahip::g_cob_t), sizeof(unsigned long long) * 8 * 8192) == hipSuccess ? SPLAHIP_OK : SPLAHIP_ERROR;
+}
+// the run-time schedule appends one record per (workgroup, range) visit: start over (and clear the records) before the launch to be looked at
+extern "C" int splahip_debug_cob_timing_reset(void) {
+    unsigned int zero = 0;
+    void*        p    = nullptr;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(splahip::g_cob_tn), &zero, sizeof(zero)) != hipSuccess) return SPLAHIP_ERROR;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(splahip::g_cob_t)) != hipSuccess) return SPLAHIP_ERROR;
+    return hipMemset(p, 0, sizeof(unsigned long long) * 8 * 8192) == hipSuccess ? SPLAHIP_OK : SPLAHIP_ERROR;
 }
 #endif

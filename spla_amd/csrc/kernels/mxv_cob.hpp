@@ -326,11 +326,17 @@ namespace splahip {
     // The row pass of a range: results leave the LDS slice (4-byte words: a double slice has been rounded in place, a merged range's words read back).
     // One copy per (type, op_add family, mode) however many op_mult / input-vector forms of the kernel exist — a real call, not inlined.
     // TIGHT: the caller is one of the kernels cut for 64 registers (two 16-wave workgroups per CU): smaller batches, so that the pass fits them too.
-    template<typename T, int ACC, bool VXM, unsigned TPB, bool TIGHT>
+    // REARM: the words are the range's shared accumulator in GLOBAL memory (the run-time schedule's finishing kernel, mxv_cob_dyn.hpp): a word that is read
+    // is set back to the fold identity by its reader — every slot of a range belongs to exactly one row, so the accumulator rests at the identity afterwards
+    template<typename T, int ACC, bool VXM, unsigned TPB, bool TIGHT, bool REARM = false>
     __device__ __noinline__ void cob_row_pass(const uint32_t* s_words, const CobRange rg, const uint16_t* __restrict__ slot16, const uint32_t* __restrict__ hub_row,
                                               uint32_t* __restrict__ touched, uint32_t n_rows, uint32_t R, uint32_t accumulate, const T* __restrict__ mask, T* __restrict__ r,
                                               DynBin add, int op_select, T init) {
-        auto s_words_at = [&](uint32_t i) -> uint32_t { return s_words[i]; };
+        auto s_words_at = [&](uint32_t i) -> uint32_t {
+            const uint32_t w = s_words[i];
+            if constexpr (REARM) const_cast<uint32_t*>(s_words)[i] = cob_identity<T, ACC>();
+            return w;
+        };
         if (rg.hub_base != 0xFFFFFFFFu) {
             // hub range: slot s is row hub_row[hub_base + s]; one scattered word per row (rows, then masks, requested in batches)
             constexpr int KH = TIGHT ? 4 : 8;

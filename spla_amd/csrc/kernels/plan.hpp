@@ -58,6 +58,11 @@ struct splahip_cob_sched_s {// one work schedule: the pieces (consecutive chunks
     uint32_t* d_tiles   = nullptr;// n_tiles x CobTile
     uint32_t* d_ranges  = nullptr;// n_ranges x CobRange (n_pieces differs between the schedules)
     uint32_t  lds_bytes = 0;// dynamic LDS of a workgroup: the larger of a hub slice and a natural slice + the spare words
+    // the run-time schedule (mxv_cob_dyn.hpp): a persistent grid of `slots` workgroups shares every range's chunks through the range's cursor
+    uint32_t  slots     = 0;      // workgroups of the persistent launch (one per CU)
+    uint32_t  n_jobs    = 0;      // listed jobs: range ids in start order, a range once per worker the cost model gives it
+    uint32_t* d_jobs    = nullptr;
+    uint32_t* d_dyn_ctl = nullptr;// [0] next listed job (== slots between calls), [1] workgroups that have left (0 between calls)
 };
 struct splahip_cob_s {
     uint32_t  n_rows   = 0;
@@ -84,6 +89,15 @@ struct splahip_cob_s {
     uint32_t* d_hub_row = nullptr;// n_hub_ranges x R: row of a hub slot, 0xFFFFFFFF padding
     uint32_t* d_acc    = nullptr;// max(sched[].n_multi) x R words: shared accumulators, at the identity of `acc_identity` between calls
     uint32_t* d_ticket = nullptr;// max(sched[].n_multi) arrival counters, 0 between calls
+    bool      dyn      = false;  // calls run the run-time schedule (mxv_cob_dyn.hpp); then d_acc holds one accumulator per RANGE
+    uint32_t* d_spans  = nullptr;// n_ranges x (first chunk, chunks)
+    uint32_t* d_dyn_words = nullptr;// n_ranges cursors, n_ranges state words (all 0 between calls), n_ranges finish flags (the number of the call that set them)
+    uint32_t* d_fin_tasks = nullptr;// the finishing kernel's row tasks: n_fin_tasks x (row0, row1, -, range): <= 2048 consecutive rows of one natural range
+    uint32_t  n_fin_tasks = 0;
+    uint16_t* d_dyn_weight = nullptr;// per range: modelled cost of one chunk, 1/16 of a plain stream chunk's
+    uint32_t* d_dyn_ranges = nullptr;// n_ranges x CobRange as the row pass wants them
+    mutable uint32_t dyn_seq = 0;    // call counter: a range whose workers merged carries it in its finish flag
+    uint32_t  dyn_min_hub = 0, dyn_min_nat = 0;// unclaimed rounds per worker below which a workgroup without a listed job no longer joins a hub / natural range
     mutable uint32_t acc_identity = 0;
     mutable bool     acc_armed    = false;
     uint32_t* d_vbits  = nullptr;// per call: bit c = v[c] != 0 (sparse-input-vector form, mxv_cob.hpp MODE 1 / 2)
