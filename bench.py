@@ -403,6 +403,16 @@ def bfs_step_line(args, rank, world):
                                    "hit and so reads fewer than the selected entries; `achieved` still divides the operation's algorithmic bytes by the call's time "
                                    "(pass over v + first-hit kernel)")
         roofline["first_hit"] = fh
+        #  the kernel stops a row at its first hit: its primary figure is what it HAS to read — the entries up to and including each selected row's
+        # first frontier column, 4 bytes each (column words only) — over the call's time; the figure on the operation's full algorithmic bytes (which a
+        # kernel that reads less can push past what the HBM delivers) stays beside it under its own name
+        req = required_entries_early_exit(g, mask, v_full)
+        req_bytes = 4 * req + 4 * (n_local + 1) + 8 * n_local + sh.n_cols_padded // 8 + 4 * sh.n_cols_padded
+        roofline["on_operation_bytes"] = {"achieved": roofline["achieved"], "frac": roofline["frac"], "algorithmic_bytes": alg_bytes}
+        achieved = req_bytes / (k_ms * 1e-3) / 1e9
+        roofline["achieved"], roofline["frac"] = round(achieved, 1), round(achieved / HBM_PEAK_GBS, 4)
+        roofline["entries_required"], roofline["required_bytes"] = req, req_bytes
+        roofline["basis"] = "required bytes of a first-hit walk: 4*entries_required + Ap + mask + r + one pass over v and its bitmap"
 
     # measured streaming ceiling of this GPU in this run: a 1 GiB device-to-device copy, read + write bytes / time.
     # `frac` stays against the nominal 8 TB/s; `frac_of_measured_copy` is the same numerator against what a plain copy reaches here.
@@ -562,7 +572,7 @@ def required_entries_early_exit(g, mask, v_full):
 
 def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total, nnz_sel_local):
     """Other measured forms of the same kernel family on the same matrix (kernel-only, inputs resident)."""
-    from spla_amd import kernels
+    from spla_amd import _lib, kernels
     res = []
     n_local, nnz_local = sh.n_local, g["nnz_local"]
     steps = max(10, args.steps // 2)
@@ -673,13 +683,17 @@ def variants(args, g, sh, mask, v_full, front, timed, world, rank, nnz_sel_total
         "BAND", "BOR", "EQZERO", 0, False, nnz_sel_local, plan=sell_i, entry_bytes=4 if uni else 8)
     r_chk3 = torch.empty_like(r_i)
     os.environ["SPLAHIP_SELL_UNIFORM"] = "0"
+    _lib.env_refresh()
     run("bfs-step early_exit=false, sliced-ELL copy, value words streamed (SPLAHIP_SELL_UNIFORM=0)", "INT", ones_i, mask, v_full, r_chk3, "BAND", "BOR", "EQZERO", 0,
         False, nnz_sel_local, plan=sell_i)
     os.environ.pop("SPLAHIP_SELL_UNIFORM")
+    _lib.env_refresh()
     r_chk2 = torch.empty_like(r_i)
     os.environ["SPLAHIP_SELL_BITS"] = "0"
+    _lib.env_refresh()
     run("bfs-step early_exit=false, sliced-ELL copy, value form forced (SPLAHIP_SELL_BITS=0)", "INT", ones_i, mask, v_full, r_chk2, "BAND", "BOR", "EQZERO", 0, False, nnz_sel_local, plan=sell_i)
     os.environ["SPLAHIP_SELL_BITS"] = "1"
+    _lib.env_refresh()
     run("bfs-step early_exit=false, CSR wave-tile kernel (no sliced-ELL copy)", "INT", ones_i, mask, v_full, r_i, "BAND", "BOR", "EQZERO", 0, False, nnz_sel_local)
     torch.cuda.synchronize()
     res[-4]["identical_to_csr_kernel"] = bool(torch.equal(r_chk, r_i))

@@ -160,9 +160,24 @@ def declared_symbols():
 _env_sig = None
 
 
-def _sync_env(lib):
-    """The library caches its SPLAHIP_* environment knobs; tests and experiments change them mid-process through os.environ: tell the library when they did."""
+def env_refresh():
+    """Tell the library that SPLAHIP_* environment knobs have changed (it reads each knob once and caches it).  Call this after changing os.environ."""
     global _env_sig
+    _env_sig = None
+    load().splahip_env_refresh()
+
+
+def _auto_sync() -> bool:
+    # Watching the environment on every call costs a scan of os.environ per kernel dispatch (as much host time as a small kernel): only the test suite,
+    # which flips knobs through os.environ / monkeypatch all the time, asks for it (pytest sets PYTEST_CURRENT_TEST; SPLA_ENV_AUTOSYNC=1 forces it).
+    return "PYTEST_CURRENT_TEST" in os.environ or os.environ.get("SPLA_ENV_AUTOSYNC") == "1"
+
+
+def _sync_env(lib):
+    """Under the test suite: tell the library when SPLAHIP_* knobs changed since the last call (everyone else calls env_refresh() after changing one)."""
+    global _env_sig
+    if not _auto_sync():
+        return
     sig = hash(frozenset((k, v) for k, v in os.environ.items() if k.startswith("SPLAHIP_") or k.startswith("SPLA_HIP_")))
     if sig != _env_sig:
         _env_sig = sig

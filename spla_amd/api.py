@@ -76,6 +76,7 @@ _bound = False
 def _c():
     global _bound
     lib = _lib.load()
+    _lib._sync_env(lib)  # (under the test suite: the operator API sees a changed SPLAHIP_* knob like the kernel-level calls do)
     if not _bound:
         for name in c_symbols():
             fn = getattr(lib, name)

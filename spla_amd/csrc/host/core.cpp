@@ -423,10 +423,16 @@ namespace spla {
             return Status::NotImplemented;
         }
         // the call's Descriptor may ask for run-to-run identical fp32 sums: a per-host-thread setting of the kernel library, held for this call only
+        // (the scope only ever RAISES the setting: a host thread that switched determinism on through the kernel-level call keeps it inside an operator-API
+        // call whose Descriptor does not ask for it)
         struct DeterministicScope {
-            int before;
-            explicit DeterministicScope(bool on) : before(splahip_set_deterministic(on ? 1 : 0)) {}
-            ~DeterministicScope() { (void) splahip_set_deterministic(before); }
+            bool raised = false;
+            explicit DeterministicScope(bool on) {
+                if (on) raised = splahip_set_deterministic(1) == 0;
+            }
+            ~DeterministicScope() {
+                if (raised) (void) splahip_set_deterministic(0);
+            }
         } scope(ctx.task->get_desc_or_default()->get_deterministic());
         try {
             return algo->execute(ctx);

@@ -735,7 +735,10 @@ namespace splahip {
             default: SPLAHIP_PROBE(float); break;
         }
 #undef SPLAHIP_PROBE
-        (void) hipGetLastError();
+        if (hipGetLastError() != hipSuccess) {// the probe did not launch: its last workgroup will not zero the row kernels' list lengths — this call stays on the blocks
+            g->last_rows = 0;
+            return 0;
+        }
         g->last_rows = rows;
         return rows;
     }

@@ -193,12 +193,20 @@ namespace {
     int rows_prepare(splahip_plan plan, hipStream_t st) {
         (void) st;
         if (plan->rows_ready) return SPLAHIP_OK;
-        SPLAHIP_TRY(device_malloc(reinterpret_cast<void**>(&plan->d_rows_list), sizeof(uint32_t) * (size_t) plan->n_rows));
-        SPLAHIP_TRY(device_malloc(reinterpret_cast<void**>(&plan->d_rows_ctl), sizeof(uint32_t) * 8));// [0] short rows listed, [1] segment items listed, [4..7] the row kernels' gate: open
+        // (nothing half-built stays with the plan when a step fails: the next call starts over)
+        uint32_t *list = nullptr, *ctl = nullptr, *items = nullptr;
+        hipError_t e = device_malloc(reinterpret_cast<void**>(&list), sizeof(uint32_t) * (size_t) plan->n_rows);
+        if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(&ctl), sizeof(uint32_t) * 8);// [0] short rows listed, [1] segment items listed, [4..7] the row kernels' gate: open
         const uint32_t open_gate[4] = {0, 0, 0, 1};
-        SPLAHIP_TRY(hipMemcpy(plan->d_rows_ctl + 4, open_gate, sizeof(open_gate), hipMemcpyHostToDevice));
-        SPLAHIP_TRY(hipMemset(plan->d_rows_ctl, 0, 4 * sizeof(uint32_t)));
-        SPLAHIP_TRY(device_malloc(reinterpret_cast<void**>(&plan->d_long_items), sizeof(uint32_t) * ((size_t) plan->n_items + 1)));
+        if (e == hipSuccess) e = hipMemcpy(ctl + 4, open_gate, sizeof(open_gate), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(ctl, 0, 4 * sizeof(uint32_t));
+        if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(&items), sizeof(uint32_t) * ((size_t) plan->n_items + 1));
+        if (e != hipSuccess) {
+            for (void* p : {(void*) list, (void*) ctl, (void*) items})
+                if (p) (void) hipFree(p);
+            return fail(SPLAHIP_ERROR, "selected-rows workspace: %s", hipGetErrorString(e));
+        }
+        plan->d_rows_list = list, plan->d_rows_ctl = ctl, plan->d_long_items = items;
         plan->rows_ready = true;
         return SPLAHIP_OK;
     }
@@ -209,7 +217,8 @@ namespace {
                     int op_select, uint32_t init_bits, const uint32_t* gate, hipStream_t st) {
         const T        init = from_bits<T>(init_bits);
         const uint32_t n    = plan->n_rows;
-        // (d_rows_ctl[0] short rows listed, [1] segment items listed: returned to zero by the call's mask probe, enqueued just before)
+        // (d_rows_ctl[0] short rows listed, [1] segment items listed: returned to zero by the call's mask probe, enqueued just before — a probe whose launch
+        // failed makes cob_mask_probe answer "the blocks", so this path never runs behind a probe that did not)
         // (workgroups: every flush of a workgroup's list is a same-address atomic — 256 / 512 / 1024 / 2048 / 4096 workgroups at R-MAT 23, 10 % of the light rows: 103 / 87 /
         // 86 / 99 / 113 us per call)
         hipLaunchKernelGGL((rows_compact_kernel<T>), dim3(knob_u32("SPLAHIP_ROWS_COMPACT_BLOCKS", 1024)), dim3(256), 0, st, n, Ap, static_cast<const T*>(mask), op_select, init, static_cast<T*>(r), plan->d_rows_list,

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <utility>
@@ -12,15 +13,23 @@
 
 namespace splahip {
 
-    // cached environment knobs (common.hpp: knob_env)
+    // cached environment knobs (common.hpp: knob_env).  The returned pointers stay valid for the life of the process: a value is INTERNED (a set of strings
+    // that only grows), the cache maps a knob's name to its interned value, and a refresh re-reads the environment into new map entries without freeing any
+    // string — a host thread inside a dispatch may still hold a pointer it was given before another thread refreshed.
     namespace {
         std::mutex& knob_mutex() {
             static std::mutex m;
             return m;
         }
-        std::unordered_map<std::string, std::pair<bool, std::string>>& knob_map() {
-            static std::unordered_map<std::string, std::pair<bool, std::string>> m;
+        std::unordered_map<std::string, const char*>& knob_map() {
+            static std::unordered_map<std::string, const char*> m;
             return m;
+        }
+        const char* knob_intern(const char* value) {
+            static std::unordered_map<std::string, std::unique_ptr<std::string>> pool;// (node-based and never erased: the strings do not move)
+            auto it = pool.find(value);
+            if (it == pool.end()) it = pool.emplace(value, std::make_unique<std::string>(value)).first;
+            return it->second->c_str();
         }
     }// namespace
     const char* knob_env(const char* name) {
@@ -29,9 +38,9 @@ namespace splahip {
         auto                        it = m.find(name);
         if (it == m.end()) {
             const char* e = std::getenv(name);
-            it            = m.emplace(name, std::make_pair(e != nullptr, std::string(e ? e : ""))).first;
+            it            = m.emplace(name, e ? knob_intern(e) : nullptr).first;
         }
-        return it->second.first ? it->second.second.c_str() : nullptr;// (the map's strings live until the next refresh)
+        return it->second;
     }
     namespace {
         thread_local int tl_deterministic = 0;

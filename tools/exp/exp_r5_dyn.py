@@ -35,6 +35,7 @@ res = {}
 for rep in range(2):
     for dyn in ("0", "1"):
         os.environ["SPLAHIP_COB_DYN"] = dyn
+        _lib.env_refresh()
         r = torch.full((n,), -1.0, dtype=torch.float32, device="cuda")
         p = kernels.CsrPlan(n, nnz, Ap)
         p.attach_cob(n, Ap, Aj, Ax)
