@@ -308,8 +308,12 @@ int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols,
                 uint32_t* d_Rp, uint32_t** d_Rj, void** d_Rx, uint32_t* h_nnz, uint64_t* h_products,
                 int op_mult, int op_add, uint32_t init_bits, uint64_t block_products, void* stream);
 /* which row classes the last splahip_mxm of this host thread used (mxm_spa.hip): rows served by the LDS-accumulator form, entries the light rows'
- * ESC call produced, side of the dense corner computed on the matrix cores (0 = none).  All 0: the whole call ran the ESC form. */
+ * ESC call produced, rows of the dense window computed on the matrix cores (0 = none; splahip_mxm_last_dense: where it lies).  All 0: the whole call ran the ESC form. */
 int splahip_mxm_last_info(uint32_t* n_heavy_rows, uint32_t* light_nnz, uint32_t* dense_h);
+/* the dense window of that call: six words i0, k0, j0, rows, inner, columns — A[i0 : i0 + rows, k0 : k0 + inner] x B[k0 : k0 + inner, j0 : j0 + columns], blocks of
+ * half-full 32 x 32 tiles found ANYWHERE in the operands (fp32 MULT / PLUS), went through the matrix cores (LDS-staged v_mfma_f32_32x32x2_f32); rows == 0: none.
+ * (reference: the accumulator row of Algo_mxm_cpu, src/cpu/cpu_mxm.hpp:93-113, restricted to the window's cells) */
+int splahip_mxm_last_dense(uint32_t* window6);
 /* mxm keeps its GB-sized workspaces between calls (per host thread, grow-only); this returns them to the driver */
 int splahip_mxm_trim(void);
 

@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <unordered_map>
 #include <vector>
 
 extern "C" int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols, const uint32_t* d_Ap, const uint32_t* d_Aj, const void* d_Ax, const uint32_t* d_Bp,
@@ -43,6 +44,7 @@ extern "C" int splahip_free(void* d_ptr);
 namespace splahip {
 
     thread_local bool tl_mxm_force_esc = false;// set around the light rows' call into the ESC form
+    thread_local uint32_t tl_last_dense[6] = {0, 0, 0, 0, 0, 0};// the dense window of the last mxm of this thread: i0, k0, j0, rows, inner, columns (splahip_mxm_last_dense)
     thread_local uint32_t tl_last_dense_h = 0, tl_last_heavy = 0, tl_last_light_nnz = 0, tl_last_ranked = 0;// what the last mxm of this thread did (splahip_mxm_last_info)
 
     namespace {
@@ -77,9 +79,10 @@ namespace splahip {
             uint32_t*       Rj;
             uint32_t*       Rx;
             uint32_t*       dropped;// NUMERIC out: entries whose value equals init
-            // dense corner (fp32 MULT / PLUS): rows, inner indices and columns below `dense_h` meet in dense tiles whose product is in dense_c (row-major
-            // h x h) with dense_n = number of products per cell; 0 = no dense corner
-            uint32_t     dense_h;
+            // dense window (fp32 MULT / PLUS): rows [d_i0, d_i0 + d_hi) x inner indices [d_k0, d_k0 + d_hk) of A and [d_k0 ..) x columns [d_j0, d_j0 + d_hj) of B are
+            // dense tiles anywhere in the matrices (sides multiples of 32); their product is in dense_c (row-major d_hi x d_hj) with dense_n = number of
+            // products per cell; d_hi = 0: no dense window
+            uint32_t     d_i0, d_k0, d_j0, d_hi, d_hk, d_hj;
             const float* dense_c;
             const float* dense_n;
         };
@@ -169,13 +172,19 @@ namespace splahip {
                     SPA_WD(2, c0, a.block)
                     const uint32_t c1 = min(ce, c0 + a.block), width = c1 - c0, words = (width + 31) / 32;
                     const bool     last = c1 == ce, to_end = c1 >= a.b_cols;
-                    const bool dense_rows = a.dense_h && i < a.dense_h && c0 < a.dense_h;// this row meets the dense corner inside this block
-                    uint32_t   block_products = dense_rows ? 1u : 0u;// (uniform) anything to emit from this block?
-                    if (dense_rows) {// pre-load what the matrix cores computed for the cells (i, j < h): value and presence
-                        for (uint32_t j = c0 + tid; j < min(c1, a.dense_h); j += kTpb) {
-                            if (a.dense_n[(size_t) i * a.dense_h + j] > 0.5f) {
+                    // this row meets the dense window inside this block?  Then the window's cells (i, j) are pre-loaded from what the matrix cores computed, and the
+                    // walk below leaves out the products (i, k, j) with k and j inside the window: by cutting the front of B[k, :]'s run when the window starts
+                    // where the block starts (a window at the matrices' origin: the common case of a hub corner), product by product otherwise
+                    const bool     dense_rows = a.d_hi && i - a.d_i0 < a.d_hi && c0 < a.d_j0 + a.d_hj && c1 > a.d_j0;
+                    const bool     dense_cut  = dense_rows && a.d_j0 == c0;
+                    const uint32_t d_j1       = a.d_j0 + a.d_hj;
+                    uint32_t       block_products = dense_rows ? 1u : 0u;// (uniform) anything to emit from this block?
+                    if (dense_rows) {
+                        for (uint32_t j = max(c0, a.d_j0) + tid; j < min(c1, d_j1); j += kTpb) {
+                            const size_t cell = (size_t) (i - a.d_i0) * a.d_hj + (j - a.d_j0);
+                            if (a.dense_n[cell] > 0.5f) {
                                 (void) __hip_atomic_fetch_or(s_bits + ((j - c0) >> 5), 1u << ((j - c0) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                if constexpr (NUMERIC && sizeof(word) == 8) s_acc[j - c0] = (double) a.dense_c[(size_t) i * a.dense_h + j];
+                                if constexpr (NUMERIC && sizeof(word) == 8) s_acc[j - c0] = (double) a.dense_c[cell];
                             }
                         }
                         __syncthreads();
@@ -188,13 +197,15 @@ namespace splahip {
                         SPA_WD(3, kc, deg)
                         const uint32_t nk  = min(kTpb, deg - kc);
                         uint32_t       len = 0;
+                        bool           in_win = false;// this part's inner index lies in the dense window and the window's columns are NOT cut off the run: product by product
                         if (single) {
                             if (tid < nk) {
                                 uint32_t b = h_b;
                                 const uint32_t e = h_e;
                                 h_b              = e;
                                 if (!last) h_e = end_of(min(ce, c1 + a.block));// the boundary behind the NEXT block travels during this one
-                                if (dense_rows && h_k < a.dense_h && c0 == 0) b = lower_bound_dev(a.Bj, b, min(e, h_b1), a.dense_h);// products (i, k, j) below h live in the dense tile
+                                in_win = dense_rows && h_k - a.d_k0 < a.d_hk;
+                                if (in_win && dense_cut) b = lower_bound_dev(a.Bj, b, min(e, h_b1), d_j1), in_win = false;// products (i, k, j) of the window live in the dense tile
                                 len        = e - b;
                                 s_seg[tid] = b;
                                 if constexpr (NUMERIC) s_av[tid] = h_av;
@@ -211,7 +222,8 @@ namespace splahip {
                                 b = c0 != cb ? cur[kc + tid] : (cb == 0 ? a.Bp[k] : lower_bound_dev(a.Bj, a.Bp[k], b1, cb));
                                 e = to_end ? b1 : lower_bound_dev(a.Bj, b, b1, c1);
                             }
-                            if (dense_rows && k < a.dense_h && c0 == 0) b = lower_bound_dev(a.Bj, b, min(e, b1), a.dense_h);// products (i, k, j) below h live in the dense tile: skip them
+                            in_win = dense_rows && k - a.d_k0 < a.d_hk;
+                            if (in_win && dense_cut) b = lower_bound_dev(a.Bj, b, min(e, b1), d_j1), in_win = false;// products (i, k, j) of the window live in the dense tile: skip them
                             len              = e - b;
                             s_seg[tid]       = b;
                             if (!last && !a.bblk) cur[kc + tid] = e;
@@ -222,7 +234,7 @@ namespace splahip {
                         // a heavy row) are walked by a wavefront each, lanes striding the run — no search, and the column / value words of a step
                         // are one coalesced run of B's row
                         const bool is_long = len >= kLongPart;
-                        s_len[tid]         = is_long ? len : 0u;
+                        s_len[tid]         = (is_long ? len : 0u) | (in_win ? 0x80000000u : 0u);// bit 31: leave out the products whose column lies in the dense window
                         uint32_t       total;
                         const uint32_t ex = block_exclusive_sum<kTpb>(is_long ? 0u : len, s_tmp, total);
                         s_pref[tid]       = ex;// threads beyond nk hold `total`: a sentinel for the search
@@ -240,6 +252,7 @@ namespace splahip {
                             }
                             const uint32_t idx = s_seg[lo] + (p - s_pref[lo]);
                             const uint32_t col = a.Bj[idx] - c0;
+                            if (dense_rows && (s_len[lo] >> 31) && col + c0 - a.d_j0 < a.d_hj) continue;// (in the dense tile)
                             (void) __hip_atomic_fetch_or(s_bits + (col >> 5), 1u << (col & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             if constexpr (NUMERIC) {
                                 const T prod = mult(from_bits<T>(s_av[lo]), from_bits<T>(a.Bx[idx]));
@@ -250,8 +263,9 @@ namespace splahip {
                         }
                         if (any_long) {
                             for (uint32_t t = tid / 64; t < nk; t += kTpb / 64) {
-                                const uint32_t n = s_len[t];
+                                const uint32_t n = s_len[t] & 0x7FFFFFFFu;
                                 if (n == 0) continue;// (uniform per wavefront)
+                                const bool     win = dense_rows && (s_len[t] >> 31);
                                 const uint32_t b0 = s_seg[t];
                                 T              av = T();
                                 if constexpr (NUMERIC) av = from_bits<T>(s_av[t]);
@@ -264,6 +278,7 @@ namespace splahip {
                                         if (p1 < n) x1 = a.Bx[b0 + p1];
                                     }
                                     auto put = [&](uint32_t col, uint32_t xw) {
+                                        if (win && col + c0 - a.d_j0 < a.d_hj) return;// (in the dense tile)
                                         (void) __hip_atomic_fetch_or(s_bits + (col >> 5), 1u << (col & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                         if constexpr (NUMERIC) {
                                             const T prod = mult(av, from_bits<T>(xw));
@@ -504,41 +519,99 @@ namespace splahip {
             if (i <= n_rows) Rp[i] = rank[Rp[i]];
         }
 
-        // ---- dense corner on the matrix cores --------------------------------------------------------------------------------------------------
-        // densify M[0:h, 0:h] (row-major, zeros where no entry) and its 0 / 1 structure; `bad` is raised by a value that is not finite (0 x inf in a
-        // dense tile would invent a NaN the sparse product does not have)
-        __global__ __launch_bounds__(256) void densify_kernel(uint32_t h, const uint32_t* __restrict__ Mp, const uint32_t* __restrict__ Mj, const float* __restrict__ Mx,
-                                                              float* __restrict__ D, float* __restrict__ S, uint32_t* __restrict__ bad, uint32_t* __restrict__ count) {
-            const uint32_t i = blockIdx.x;// one workgroup per row < h
+        // ---- dense tiles on the matrix cores ---------------------------------------------------------------------------------------------------
+        // Where are they?  Per 32-row panel of M: entries per 32-column tile (a histogram in LDS: n_cols / 32 counters); the tiles holding >= thr entries (half
+        // full: 512) are listed as (panel, tile, count).  A panel with fewer than thr entries holds none and costs two loads.
+        __global__ __launch_bounds__(256) void tile_fill_kernel(uint32_t n_rows, uint32_t n_tiles, const uint32_t* __restrict__ Mp, const uint32_t* __restrict__ Mj, uint32_t thr,
+                                                                uint32_t cap, uint32_t* __restrict__ n_out, uint32_t* __restrict__ out) {
+            extern __shared__ uint32_t s_cnt[];
+            const uint32_t n_panels = (n_rows + 31) / 32;
+            for (uint32_t p = blockIdx.x; p < n_panels; p += gridDim.x) {
+                const uint32_t e0 = Mp[p * 32], e1 = Mp[min(n_rows, p * 32 + 32)];
+                if (e1 - e0 < thr) continue;// (uniform)
+                for (uint32_t t = threadIdx.x; t < n_tiles; t += 256) s_cnt[t] = 0;
+                __syncthreads();
+                for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) (void) __hip_atomic_fetch_add(s_cnt + (Mj[e] >> 5), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __syncthreads();
+                for (uint32_t t = threadIdx.x; t < n_tiles; t += 256)
+                    if (s_cnt[t] >= thr) {
+                        const uint32_t at = atomicAdd(n_out, 1u);
+                        if (at < cap) out[3 * at] = p, out[3 * at + 1] = t, out[3 * at + 2] = s_cnt[t];
+                    }
+                __syncthreads();
+            }
+        }
+        // densify M[r0 : r0 + hr, c0 : c0 + hc] (row-major hr x hc, zeros where no entry) and its 0 / 1 structure; `bad` is raised by a value that is not finite
+        // (0 x inf in a dense tile would invent a NaN the sparse product does not have); count = entries of the window
+        __global__ __launch_bounds__(256) void densify_kernel(uint32_t r0, uint32_t c0, uint32_t hc, const uint32_t* __restrict__ Mp, const uint32_t* __restrict__ Mj,
+                                                              const float* __restrict__ Mx, float* __restrict__ D, float* __restrict__ S, uint32_t* __restrict__ bad,
+                                                              uint32_t* __restrict__ count) {
+            const uint32_t i = blockIdx.x;// one workgroup per row of the window
             uint32_t       c = 0;
-            for (uint32_t e = Mp[i] + threadIdx.x; e < Mp[i + 1]; e += 256) {
+            for (uint32_t e = Mp[r0 + i] + threadIdx.x; e < Mp[r0 + i + 1]; e += 256) {
                 const uint32_t j = Mj[e];
-                if (j >= h) break;// columns ascend; (threads further right see larger columns: they stop too)
+                if (j >= c0 + hc) break;// columns ascend; (threads further right see larger columns: they stop too)
+                if (j < c0) continue;
                 const float x = Mx[e];
-                D[(size_t) i * h + j] = x;
-                S[(size_t) i * h + j] = 1.0f;
+                D[(size_t) i * hc + (j - c0)] = x;
+                S[(size_t) i * hc + (j - c0)] = 1.0f;
                 ++c;
                 if (!(fabsf(x) <= 3.0e38f)) atomicOr(bad, 1u);
             }
             if (c) atomicAdd(count, c);
         }
-        // C[h x h] = A[h x h] x B[h x h], fp32 on v_mfma_f32_32x32x2_f32: one wavefront per 32 x 32 tile of C, k in steps of 2.  Operand layout of the
-        // instruction (cdna_hip_programming.md 3): lane l supplies A[row = l % 32][k = l / 32] and B[k = l / 32][col = l % 32]; the 16 accumulator
-        // registers of lane l hold C[row = 8 * (r / 4) + (l / 32) * 4 + r % 4 ... ] — written back through the same formula below.
-        __global__ __launch_bounds__(64) void dense_gemm_mfma_kernel(uint32_t h, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C) {
+        // C[M x N] = A[M x K] x B[K x N] (row-major, sides multiples of 32), fp32 on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains).  A workgroup of four
+        // wavefronts owns a 64 x 64 tile of C, a wavefront its 32 x 32 quarter; K runs in steps of 32 through LDS: the 64 x 32 panel of A and the 32 x 64
+        // panel of B are staged with coalesced 16-byte loads (the panel of the NEXT step is requested before the matrix cores work on this one), then every
+        // wavefront issues 16 MFMAs per step from LDS.  Operand layout of the instruction (cdna_hip_programming.md 3): lane l supplies A[row = l % 32][k = l / 32]
+        // and B[k = l / 32][col = l % 32]; accumulator register r of lane l holds C[row = 8 * (r / 4) + (l / 32) * 4 + r % 4][col = l % 32].  (A's panel is kept
+        // with a row stride of 33 words: the 32 lanes of a half-wave read one column of it.)
+        __global__ __launch_bounds__(256) void dense_gemm_mfma_kernel(uint32_t M, uint32_t N, uint32_t K, const float* __restrict__ A, const float* __restrict__ B,
+                                                                      float* __restrict__ C) {
             typedef float f16v __attribute__((ext_vector_type(16)));
-            const uint32_t ti = blockIdx.y * 32, tj = blockIdx.x * 32, lane = threadIdx.x;
-            const uint32_t m = lane & 31, kh = lane >> 5;
-            f16v           acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            for (uint32_t k = 0; k < h; k += 2) {
-                const float av = A[(size_t) (ti + m) * h + k + kh];
-                const float bv = B[(size_t) (k + kh) * h + tj + m];
-                acc            = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-            }
+            __shared__ float s_a[2][64][33];
+            __shared__ float s_b[2][32][64];
+            const uint32_t   tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+            const uint32_t   ti = blockIdx.y * 64, tj = blockIdx.x * 64;     // the workgroup's tile of C
+            const uint32_t   wi = (wv >> 1) * 32, wj = (wv & 1) * 32;        // the wavefront's quarter
+            const uint32_t   m = lane & 31, kh = lane >> 5;
+            // staging: thread t loads A[ti + t / 4][k0 + 8 (t % 4) .. + 8) (two float4) and B[k0 + t / 8][tj + 8 (t % 8) .. + 8) (two float4)
+            const uint32_t ar = tid >> 2, ac = (tid & 3) * 8, br = tid >> 3, bc = (tid & 7) * 8;
+            float4         ra[2], rb[2];
+            auto fetch = [&](uint32_t k0) {
+                const bool a_in = ti + ar < M, b_in = tj + bc < N;// (sides are multiples of 32: a half tile is all in or all out per 8 words... of 32)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t row = 8 * (r / 4) + kh * 4 + (r % 4);
-                C[(size_t) (ti + row) * h + tj + m] = acc[r];
+                for (int h = 0; h < 2; ++h) {
+                    ra[h] = a_in ? *reinterpret_cast<const float4*>(A + (size_t) (ti + ar) * K + k0 + ac + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    rb[h] = b_in ? *reinterpret_cast<const float4*>(B + (size_t) (k0 + br) * N + tj + bc + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            };
+            auto stage = [&](int buf) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    s_a[buf][ar][ac + 4 * h + 0] = ra[h].x, s_a[buf][ar][ac + 4 * h + 1] = ra[h].y, s_a[buf][ar][ac + 4 * h + 2] = ra[h].z, s_a[buf][ar][ac + 4 * h + 3] = ra[h].w;
+                    *reinterpret_cast<float4*>(&s_b[buf][br][bc + 4 * h]) = rb[h];
+                }
+            };
+            f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            fetch(0);
+            stage(0);
+            __syncthreads();
+            for (uint32_t k0 = 0, it = 0; k0 < K; k0 += 32, ++it) {
+                const int  buf  = (int) (it & 1u);
+                const bool more = k0 + 32 < K;
+                if (more) fetch(k0 + 32);// in flight under the MFMAs below
+#pragma unroll
+                for (int kk = 0; kk < 32; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_a[buf][wi + m][kk + kh], s_b[buf][kk + kh][wj + m], acc, 0, 0, 0);
+                if (more) stage(buf ^ 1);
+                __syncthreads();
+            }
+            if (ti + wi < M && tj + wj < N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t row = 8 * (r / 4) + kh * 4 + (r % 4);
+                    C[(size_t) (ti + wi + row) * N + tj + wj + m] = acc[r];
+                }
             }
         }
 
@@ -639,37 +712,116 @@ namespace splahip {
                 }
             } free_light{Lrj, Lrx};
 
-            // ---- dense corner (fp32 MULT / PLUS): the leading h x h tiles of A and B, when both are at least half full and finite ---------------------
-            uint32_t dense_h = 0;
+            // ---- dense window (fp32 MULT / PLUS): a block A[i0 : i0 + hi, k0 : k0 + hk] x B[k0 : k0 + hk, j0 : j0 + hj] of tiles that are at least half full and
+            // finite — ANYWHERE in the matrices (sides multiples of 32, at most SPLAHIP_MXM_DENSE_H = 1024) — goes through the matrix cores ---------------------
+            uint32_t d_i0 = 0, d_k0 = 0, d_j0 = 0, d_hi = 0, d_hk = 0, d_hj = 0;
             float *  dA = nullptr, *dB = nullptr, *dC = nullptr, *dN = nullptr, *sA = nullptr, *sB = nullptr;
             if constexpr (std::is_same<T, float>::value && ACC == COB_ADD) {
-                if (op_mult == SPLAHIP_MULT && env_u32("SPLAHIP_MXM_DENSE", 1) != 0) {
-                    uint32_t h = std::min({a_rows, b_cols, b_rows_hint, env_u32("SPLAHIP_MXM_DENSE_H", 1024u)}) & ~31u;
-                    while (h >= 64 && dense_h == 0) {
-                        uint32_t* stat = nullptr;// bad, count A, count B
-                        e              = tmp.alloc(&stat, 4);
-                        for (float** q : {&dA, &dB, &dC, &dN, &sA, &sB})
-                            if (e == hipSuccess) e = tmp.alloc(q, (size_t) h * h);
-                        if (e != hipSuccess) break;
-                        (void) hipMemsetAsync(stat, 0, 16, s);
-                        for (float* q : {dA, dB, sA, sB}) (void) hipMemsetAsync(q, 0, sizeof(float) * (size_t) h * h, s);
-                        hipLaunchKernelGGL(densify_kernel, dim3(h), dim3(256), 0, s, h, Ap, Aj, static_cast<const float*>(Ax), dA, sA, stat, stat + 1);
-                        hipLaunchKernelGGL(densify_kernel, dim3(h), dim3(256), 0, s, h, Bp, Bj, static_cast<const float*>(Bx), dB, sB, stat, stat + 2);
-                        uint32_t hs[3] = {0, 0, 0};
-                        e              = hipMemcpyAsync(hs, stat, 12, hipMemcpyDeviceToHost, s);
-                        if (e == hipSuccess) e = hipStreamSynchronize(s);
-                        if (e != hipSuccess) break;
-                        const double full = (double) h * h;
-                        if (!hs[0] && hs[1] >= 0.5 * full && hs[2] >= 0.5 * full) {
-                            hipLaunchKernelGGL(dense_gemm_mfma_kernel, dim3(h / 32, h / 32), dim3(64), 0, s, h, dA, dB, dC);
-                            hipLaunchKernelGGL(dense_gemm_mfma_kernel, dim3(h / 32, h / 32), dim3(64), 0, s, h, sA, sB, dN);
-                            dense_h = h;
-                        } else
-                            h = (h / 2) & ~31u;// a smaller corner may still be a dense tile
+                const uint32_t b_rows = b_rows_hint, h_max = std::max(32u, env_u32("SPLAHIP_MXM_DENSE_H", 1024u)) & ~31u;
+                if (op_mult == SPLAHIP_MULT && env_u32("SPLAHIP_MXM_DENSE", 1) != 0 && a_rows >= 32 && b_cols >= 32 && b_rows >= 32) {
+                    // 1. the half-full 32 x 32 tiles of A (row panels x inner tiles) and of B (inner panels x column tiles)
+                    constexpr uint32_t kCap = 1u << 16;// listed tiles per matrix (more: the densest region is still among them in practice; the window is verified below anyway)
+                    struct Tile {
+                        uint32_t p, t, c;
+                    };
+                    auto list_tiles = [&](uint32_t n_rows, uint32_t n_cols, const uint32_t* Mp, const uint32_t* Mj, std::vector<Tile>& out) -> hipError_t {
+                        const uint32_t n_tiles = (n_cols + 31) / 32;
+                        if ((size_t) n_tiles * 4 > 150u * 1024u) return hipSuccess;// (the histogram lives in LDS: matrices of up to 1.2 M columns)
+                        uint32_t *cnt = nullptr, *lst = nullptr;
+                        hipError_t e2 = tmp.alloc(&cnt, 1);
+                        if (e2 == hipSuccess) e2 = tmp.alloc(&lst, 3 * (size_t) kCap);
+                        if (e2 == hipSuccess) e2 = hipMemsetAsync(cnt, 0, 4, s);
+                        if (e2 != hipSuccess) return e2;
+                        if (n_tiles * 4 > 64 * 1024) (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        hipLaunchKernelGGL(tile_fill_kernel, dim3(std::min(4096u, (n_rows + 31) / 32)), dim3(256), n_tiles * 4, s, n_rows, n_tiles, Mp, Mj, 512u, kCap, cnt, lst);
+                        uint32_t n = 0;
+                        e2         = hipMemcpyAsync(&n, cnt, 4, hipMemcpyDeviceToHost, s);
+                        if (e2 == hipSuccess) e2 = hipStreamSynchronize(s);
+                        n = std::min(n, kCap);
+                        std::vector<uint32_t> h(3 * (size_t) n);
+                        if (e2 == hipSuccess && n) e2 = hipMemcpy(h.data(), lst, 12 * (size_t) n, hipMemcpyDeviceToHost);
+                        for (uint32_t q = 0; e2 == hipSuccess && q < n; ++q) out.push_back({h[3 * q], h[3 * q + 1], h[3 * q + 2]});
+                        return e2;
+                    };
+                    std::vector<Tile> ta, tb;
+                    e = list_tiles(a_rows, b_rows, Ap, Aj, ta);
+                    if (e == hipSuccess && !ta.empty()) e = list_tiles(b_rows, b_cols, Bp, Bj, tb);
+                    if (e == hipSuccess && !ta.empty() && !tb.empty()) {
+                        // 2. the seed: the fullest tile (ip, kp) of A whose inner panel kp holds a half-full tile (kp, jp) of B (the fullest of them); then the runs of
+                        // half-full tiles through the seed along rows, inner indices (both matrices) and columns give the window's sides
+                        auto key = [](uint32_t p, uint32_t t) { return ((u64) p << 32) | t; };
+                        std::unordered_map<u64, uint32_t> sa, sb;
+                        std::unordered_map<uint32_t, Tile> best_b;// per inner panel: B's fullest tile
+                        for (const Tile& t : ta) sa[key(t.p, t.t)] = t.c;
+                        for (const Tile& t : tb) {
+                            sb[key(t.p, t.t)] = t.c;
+                            auto it = best_b.find(t.p);
+                            if (it == best_b.end() || it->second.c < t.c) best_b[t.p] = t;
+                        }
+                        std::sort(ta.begin(), ta.end(), [](const Tile& x, const Tile& y) { return x.c != y.c ? x.c > y.c : (x.p != y.p ? x.p < y.p : x.t < y.t); });
+                        const Tile* seed = nullptr;
+                        for (const Tile& t : ta)
+                            if (best_b.count(t.t)) {
+                                seed = &t;
+                                break;
+                            }
+                        if (seed) {
+                            const uint32_t ip = seed->p, kp = seed->t, jp = best_b[kp].t, span = h_max / 32;
+                            auto in_a = [&](uint32_t p, uint32_t t) { return sa.count(key(p, t)) != 0; };
+                            auto in_b = [&](uint32_t p, uint32_t t) { return sb.count(key(p, t)) != 0; };
+                            uint32_t i_lo = ip, i_hi = ip + 1, k_lo = kp, k_hi = kp + 1, j_lo = jp, j_hi = jp + 1;
+                            while (i_lo > 0 && i_hi - i_lo < span && in_a(i_lo - 1, kp)) --i_lo;
+                            while (i_hi - i_lo < span && in_a(i_hi, kp)) ++i_hi;
+                            while (k_lo > 0 && k_hi - k_lo < span && in_a(ip, k_lo - 1) && in_b(k_lo - 1, jp)) --k_lo;
+                            while (k_hi - k_lo < span && in_a(ip, k_hi) && in_b(k_hi, jp)) ++k_hi;
+                            while (j_lo > 0 && j_hi - j_lo < span && in_b(kp, j_lo - 1)) --j_lo;
+                            while (j_hi - j_lo < span && in_b(kp, j_hi)) ++j_hi;
+                            // 3. the window is VERIFIED (both blocks half full over their whole area, every value finite) and shrunk towards the seed until it is:
+                            // the runs above only looked along the seed's row, column and inner panel
+                            for (int attempt = 0; attempt < 12 && d_hi == 0 && e == hipSuccess; ++attempt) {
+                                const uint32_t i0 = i_lo * 32, k0 = k_lo * 32, j0 = j_lo * 32;
+                                const uint32_t hi = std::min(i_hi * 32, a_rows & ~31u) - i0, hk = std::min({k_hi * 32, b_rows & ~31u}) - k0, hj = std::min(j_hi * 32, b_cols & ~31u) - j0;
+                                if ((int32_t) hi < 32 || (int32_t) hk < 32 || (int32_t) hj < 32) break;
+                                uint32_t* stat = nullptr;// bad, count A, count B
+                                e              = tmp.alloc(&stat, 4);
+                                if (e == hipSuccess) e = tmp.alloc(&dA, (size_t) hi * hk);
+                                if (e == hipSuccess) e = tmp.alloc(&sA, (size_t) hi * hk);
+                                if (e == hipSuccess) e = tmp.alloc(&dB, (size_t) hk * hj);
+                                if (e == hipSuccess) e = tmp.alloc(&sB, (size_t) hk * hj);
+                                if (e == hipSuccess) e = tmp.alloc(&dC, (size_t) hi * hj);
+                                if (e == hipSuccess) e = tmp.alloc(&dN, (size_t) hi * hj);
+                                if (e != hipSuccess) break;
+                                (void) hipMemsetAsync(stat, 0, 16, s);
+                                for (float* q : {dA, sA}) (void) hipMemsetAsync(q, 0, sizeof(float) * (size_t) hi * hk, s);
+                                for (float* q : {dB, sB}) (void) hipMemsetAsync(q, 0, sizeof(float) * (size_t) hk * hj, s);
+                                hipLaunchKernelGGL(densify_kernel, dim3(hi), dim3(256), 0, s, i0, k0, hk, Ap, Aj, static_cast<const float*>(Ax), dA, sA, stat, stat + 1);
+                                hipLaunchKernelGGL(densify_kernel, dim3(hk), dim3(256), 0, s, k0, j0, hj, Bp, Bj, static_cast<const float*>(Bx), dB, sB, stat, stat + 2);
+                                uint32_t hs[3] = {0, 0, 0};
+                                e              = hipMemcpyAsync(hs, stat, 12, hipMemcpyDeviceToHost, s);
+                                if (e == hipSuccess) e = hipStreamSynchronize(s);
+                                if (e != hipSuccess) break;
+                                if (!hs[0] && hs[1] >= 0.5 * hi * hk && hs[2] >= 0.5 * hk * hj) {
+                                    const dim3 grid((hj + 63) / 64, (hi + 63) / 64);
+                                    hipLaunchKernelGGL(dense_gemm_mfma_kernel, grid, dim3(256), 0, s, hi, hj, hk, dA, dB, dC);
+                                    hipLaunchKernelGGL(dense_gemm_mfma_kernel, grid, dim3(256), 0, s, hi, hj, hk, sA, sB, dN);
+                                    d_i0 = i0, d_k0 = k0, d_j0 = j0, d_hi = hi, d_hk = hk, d_hj = hj;
+                                } else {// halve the longest side, keeping the seed's tile inside
+                                    uint32_t &lo = (i_hi - i_lo >= k_hi - k_lo && i_hi - i_lo >= j_hi - j_lo) ? i_lo : (k_hi - k_lo >= j_hi - j_lo ? k_lo : j_lo);
+                                    uint32_t &up = (&lo == &i_lo) ? i_hi : (&lo == &k_lo ? k_hi : j_hi);
+                                    const uint32_t at = (&lo == &i_lo) ? ip : (&lo == &k_lo ? kp : jp);
+                                    if (up - lo <= 1) break;// the seed's tiles themselves are not finite: no window
+                                    const uint32_t half = (up - lo + 1) / 2;
+                                    if (at - lo < half) up = lo + half;
+                                    else
+                                        lo = up - half;
+                                }
+                            }
+                        }
                     }
-                    if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm (dense corner): %s", hipGetErrorString(e));
+                    if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm (dense window): %s", hipGetErrorString(e));
                 }
             }
+            const uint32_t dense_h = d_hi;// (non-zero: a dense window exists)
 
             // ---- heavy rows: work items, symbolic pass, row pointers + item offsets, numeric pass -----------------------------------------------
             int dev = 0, cus = 256;
@@ -725,7 +877,7 @@ namespace splahip {
                 hipLaunchKernelGGL(bblk_kernel, dim3((unsigned) ((cells + 255) / 256)), dim3(256), 0, s, b_rows_hint, nb_num, blk_num, Bp, Bj, d_bblk);
             }
             SpaArgs a{Ap, Aj, static_cast<const uint32_t*>(Ax), Bp, Bj, static_cast<const uint32_t*>(Bx), d_item, d_item + n_items, d_item + 2 * (size_t) n_items, d_out, n_items, b_cols,
-                      blk_sym, d_bblk, blk_num, nb_num, d_cursor, max_deg, d_counts, nullptr, nullptr, d_dropped, dense_h, dC, dN};
+                      blk_sym, d_bblk, blk_num, nb_num, d_cursor, max_deg, d_counts, nullptr, nullptr, d_dropped, d_i0, d_k0, d_j0, d_hi, d_hk, d_hj, dC, dN};
             const T init = from_bits<T>(init_bits);
             if (n_items) {
                 // (a per-device setting and cheap: set on every call rather than remembered in a process-wide flag)
@@ -785,14 +937,14 @@ namespace splahip {
                 const uint32_t cap = ((160u * 1024u - 256u - 2u * (wr / 8) - (uint32_t) sizeof(uint32_t) * (3 * kTpb + 1 + kTpb / 64 + 4)) / (uint32_t) sizeof(word)) & ~63u;// what is left of the LDS
                 std::vector<uint32_t> rk[4], bl[4];
                 for (uint32_t q = 0; q < n_items; ++q) {
-                    const bool ranked = d_bblk && h_counts[q] <= cap && !(dense_h && items[q].row < dense_h) && env_u32("SPLAHIP_MXM_RANKED", 1) != 0;
+                    const bool ranked = d_bblk && h_counts[q] <= cap && !(d_hi && items[q].row - d_i0 < d_hi) && env_u32("SPLAHIP_MXM_RANKED", 1) != 0;
                     auto&      dst    = ranked ? rk : bl;
                     dst[0].push_back(items[q].row), dst[1].push_back(items[q].c0), dst[2].push_back(items[q].c1), dst[3].push_back(h_out[q]);
                 }
                 if (knob_env("SPLAHIP_MXM_TRACE")) {// class sizes (diagnostic)
                     u64 re = 0, be = 0, rp = 0, bp = 0, bsteps = 0;
                     for (uint32_t q = 0; q < n_items; ++q) {
-                        const bool ranked = d_bblk && h_counts[q] <= cap && !(dense_h && items[q].row < dense_h) && env_u32("SPLAHIP_MXM_RANKED", 1) != 0;
+                        const bool ranked = d_bblk && h_counts[q] <= cap && !(d_hi && items[q].row - d_i0 < d_hi) && env_u32("SPLAHIP_MXM_RANKED", 1) != 0;
                         (ranked ? re : be) += h_counts[q];
                         (ranked ? rp : bp) += items[q].est;
                         if (!ranked) bsteps += (items[q].c1 - items[q].c0 + blk_num - 1) / blk_num;
@@ -858,6 +1010,7 @@ namespace splahip {
             result_guard.armed = false;
             *Rj = oj, *Rx = ox, *h_nnz = (uint32_t) total;
             tl_last_dense_h = dense_h, tl_last_heavy = n_items, tl_last_light_nnz = l_nnz;
+            tl_last_dense[0] = d_i0, tl_last_dense[1] = d_k0, tl_last_dense[2] = d_j0, tl_last_dense[3] = d_hi, tl_last_dense[4] = d_hk, tl_last_dense[5] = d_hj;
             return SPLAHIP_OK;
         }
 
@@ -889,7 +1042,10 @@ namespace splahip {
     // -1: the row-class form does not apply (op_add without an LDS atomic, no heavy row, switched off): the caller runs the ESC form
     int mxm_spa(int type, uint32_t a_rows, uint32_t b_cols, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const uint32_t* Bp, const uint32_t* Bj, const void* Bx, uint32_t* Rp,
                 uint32_t** Rj, void** Rx, uint32_t* h_nnz, unsigned long long* h_products, int op_mult, int op_add, uint32_t init_bits, hipStream_t s) {
-        if (!tl_mxm_force_esc) tl_last_dense_h = tl_last_heavy = tl_last_light_nnz = 0;
+        if (!tl_mxm_force_esc) {
+            tl_last_dense_h = tl_last_heavy = tl_last_light_nnz = 0;
+            for (uint32_t& w : tl_last_dense) w = 0;
+        }
         if (tl_mxm_force_esc || env_u32("SPLAHIP_MXM_SPA", 1) == 0) return -1;
         const int acc = cob_acc_kind(op_add, type);
         if (acc == COB_NONE || b_cols == 0) return -1;
@@ -956,6 +1112,14 @@ extern "C" int splahip_mxm_last_info(uint32_t* n_heavy_rows, uint32_t* light_nnz
     if (n_heavy_rows) *n_heavy_rows = splahip::tl_last_heavy;
     if (light_nnz) *light_nnz = splahip::tl_last_light_nnz;
     if (dense_h) *dense_h = splahip::tl_last_dense_h;
+    return SPLAHIP_OK;
+}
+
+// where the last mxm of the calling thread found its dense window (rows / inner indices / columns of A x B that went through the matrix cores): six words
+// i0, k0, j0, rows, inner, columns; rows == 0: none
+extern "C" int splahip_mxm_last_dense(uint32_t* window6) {
+    SPLAHIP_REQUIRE(window6 != nullptr, "null argument");
+    for (int k = 0; k < 6; ++k) window6[k] = splahip::tl_last_dense[k];
     return SPLAHIP_OK;
 }
 

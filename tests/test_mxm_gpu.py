@@ -241,6 +241,58 @@ def test_mxm_dense_corner_on_the_matrix_cores(oracle, monkeypatch):
     np.testing.assert_allclose(a[2], b[2], rtol=1e-5, atol=0)
 
 
+def _last_dense():
+    import ctypes as C
+    from spla_amd import _lib
+    w = (C.c_uint32 * 6)()
+    _lib.call("splahip_mxm_last_dense", w)
+    return tuple(int(x) for x in w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i0,k0,j0,hi,hk,hj,n", [(352, 608, 96, 160, 128, 192, 1500), (64, 0, 2016, 128, 128, 128, 2600), (0, 416, 0, 96, 160, 96, 900)])
+def test_mxm_dense_window_away_from_the_origin(oracle, monkeypatch, i0, k0, j0, hi, hk, hj, n):
+    """north star: "MFMA ... where a row-bucket degenerates to a dense tile" — ANYWHERE, not only in the leading corner.  A carries a dense hi x hk block at
+    (i0, k0), B a dense hk x hj block at (k0, j0) (90 % full, rectangular, off the diagonal; the second case's columns straddle a 2048-column accumulator
+    block), both inside sparse skewed matrices.  splahip_mxm finds the half-full 32 x 32 tiles (tile_fill_kernel), grows and verifies the window, multiplies
+    the blocks with the LDS-staged v_mfma_f32_32x32x2_f32 loop (values and product counts), pre-loads the window's cells of the rows it meets and leaves the
+    window's products out of the sparse walk.  Same structure as the oracle, values within 1e-5 (reference: src/cpu/cpu_mxm.hpp:85-114); identical structure
+    and 1e-5 agreement with the all-sparse run (SPLAHIP_MXM_DENSE=0)."""
+    from spla_amd import kernels
+    import scipy.sparse as sp
+
+    def with_block(seed, r0, c0, hr, hc):
+        r = np.random.default_rng(seed)
+        Ap, Aj, Ax = random_csr(r, n, n, 12, "FLOAT", skew=True)
+        S = sp.csr_matrix((Ax, Aj.astype(np.int64), Ap.astype(np.int64)), shape=(n, n)).tolil()
+        blk = (r.random((hr, hc)) < 0.9) * (r.integers(1, 64, (hr, hc)) / 16.0)
+        S[r0:r0 + hr, c0:c0 + hc] = blk.astype(np.float32)
+        S = S.tocsr()
+        S.sort_indices()
+        S.eliminate_zeros()
+        return S.indptr.astype(np.uint32), S.indices.astype(np.uint32), S.data.astype(np.float32)
+
+    A, B = with_block(11, i0, k0, hi, hk), with_block(12, k0, j0, hk, hj)
+    want = oracle.mxm("FLOAT", n, n, A, B, "MULT", "PLUS", 0.0)
+    dA, dB = _dev3(A, "FLOAT"), _dev3(B, "FLOAT")
+    got, _ = kernels.mxm("FLOAT", n, n, dA, dB, "MULT", "PLUS", 0.0)
+    heavy, _, dense_rows = _last_info()
+    w = _last_dense()
+    assert heavy > 0 and dense_rows >= 64, (heavy, dense_rows, w)
+    # the window lies inside the planted blocks (tiles are 32-aligned: a block that does not start on a multiple of 32 loses its ragged edge) and away from the origin
+    assert w[3] >= 64 and w[4] >= 64 and w[5] >= 64, w
+    assert i0 <= w[0] and w[0] + w[3] <= i0 + hi + 31 and k0 <= w[1] and w[1] + w[4] <= k0 + hk + 31 and j0 <= w[2] and w[2] + w[5] <= j0 + hj + 31, w
+    assert (w[0], w[1], w[2]) != (0, 0, 0)
+    _same_csr(_host3(got, "FLOAT"), want, "FLOAT", False, f"mxm dense window at {w}")
+    monkeypatch.setenv("SPLAHIP_MXM_DENSE", "0")
+    got2, _ = kernels.mxm("FLOAT", n, n, dA, dB, "MULT", "PLUS", 0.0)
+    assert _last_info()[2] == 0 and _last_dense()[3] == 0
+    a, b = _host3(got, "FLOAT"), _host3(got2, "FLOAT")
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-5, atol=0)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("t", ["INT", "UINT", "FLOAT"])
 def test_mxmT_count_mode_of_uniform_values(oracle, t):
