@@ -229,18 +229,22 @@ namespace splahip {
                                                              T* __restrict__ val, uint* __restrict__ keep,
                                                              uint* __restrict__ heavy_count, uint* __restrict__ heavy_list,
                                                              Mult mult, Add add, int op_select, T init, uint row_cap, uint* __restrict__ cost,
-                                                             uint merge_on, uint merge_factor, uint heavy_from) {
+                                                             uint merge_on, uint merge_factor, uint heavy_from, uint* __restrict__ owner_key, uint* __restrict__ erow) {
         const uint e = blockIdx.x * 256 + threadIdx.x;// (lanes behind the last entry stay for the wave-wide list appends below)
         T    r    = init;
         bool done = true;
-        uint c    = 0, which = 0, row_i = 0;// which: 1 = search kernel's list, 2 = block merge's list
+        uint c    = 0, which = 0, row_i = 0;// which: 1 = search kernel's list (owner form: the owner list), 2 = block merge's list
         if (e < n_entries && eval_sel(op_select, Mx[e])) {
             const uint i  = row_of_entry(Mp, n_rows, e);
             const uint j  = Mj[e];
             uint       ka = Ap[i], ea = Ap[i + 1];
             uint       kb = Bp[j], eb = Bp[j + 1];
             if ((ea - ka) + (eb - kb) > heavy_from && ea > ka && eb > kb) {
-                if (ea - ka <= row_cap) {// row form (mxmT_row_kernel): A[i, :] staged in LDS once for a run of the row's entries
+                if (owner_key != nullptr) {// owner form (mxmT_owner_kernel): the entry belongs to the LONGER of its two rows — A[i, :] (key i) or B[j, :] (key n_rows + j)
+                    which  = 1;
+                    row_i  = (ea - ka) >= (eb - kb) ? i : n_rows + j;
+                    erow[e] = i;
+                } else if (ea - ka <= row_cap) {// row form (mxmT_row_kernel): A[i, :] staged in LDS once for a run of the row's entries
                     keep[e] = kRowPending;
                     c       = row_entry_cost(ea - ka, eb - kb);
                 } else if (merge_on && merge_streams(ea - ka, eb - kb, merge_factor)) {// rows of comparable length: the block merge (mxmT_merge_kernel)
@@ -248,8 +252,8 @@ namespace splahip {
                 } else {
                     which = 1;
                 }
-                row_i = i;
-                done  = false;
+                if (owner_key == nullptr) row_i = i;
+                done = false;
             } else {
                 while (ka < ea && kb < eb) {
                     const uint ca = Aj[ka], cb = Bj[kb];
@@ -549,7 +553,12 @@ namespace splahip {
         }
         lo = ~wave_max(~lo);
         hi = wave_max(hi);
-        if (lane_id() == 0) {
+        // (one pair of atomics per WORKGROUP: same-address atomics serialise — a pair per wavefront of this 1024-workgroup grid cost 115 us per call)
+        __shared__ uint s_lo[256 / kWave], s_hi[256 / kWave];
+        if (lane_id() == 0) s_lo[wave_id()] = lo, s_hi[wave_id()] = hi;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (uint w = 1; w < 256 / kWave; ++w) lo = min(lo, s_lo[w]), hi = max(hi, s_hi[w]);
             atomicMin(&out[0], lo);
             atomicMax(&out[1], hi);
         }
@@ -685,6 +694,151 @@ namespace splahip {
             const T r = tot_has ? add(init, tot) : init;
             val[e]    = r;
             keep[e]   = differs(r, init) ? 1u : 0u;
+        }
+    }
+
+    // ---- heavy entries, OWNER FORM (count mode: every stored value of A one word, every stored value of B one word — the triangle count).
+    // The block merge reads BOTH rows of every entry: len(A[i, :]) + len(B[j, :]) words, 18.4 G on the R-MAT 20 triangle form (~75 GB through the caches,
+    // 9.4 ms).  Here an entry belongs to the LONGER of its two rows — its owner — and only the SHORTER one is read: 2.2 G words on the same input.  The
+    // heavy entries are sorted by owner (key: i for A[i, :], n_rows + j for B[j, :]); a workgroup takes 1024 consecutive sorted entries and, per run of equal
+    // owners, sets the owner's columns in a BITMAP over the inner dimension in LDS (n_cols / 8 bytes: up to 1.2 M columns), then its 16 wavefronts walk the
+    // run's entries: the other row streams by, 64 coalesced column words a step, a word costs one LDS read and the matches are counted by ballot; the run's
+    // bits are cleared by walking the owner's columns again.  An entry's value follows from the number of matches (merge_counts()).  The entry's bounds are
+    // fetched lane-parallel for the 1024 entries at once; a wavefront requests the first 64 words of its NEXT entry before it counts the current one.
+    // (reference: Algo_mxmT_masked_cpu's two-pointer merge, src/cpu/cpu_mxmT_masked.hpp:100-118: the same matches, counted instead of folded.)
+    constexpr uint kOwnerChunk = 1024;
+    // largest column id + 1 referred to by a CSR matrix of n_rows rows whose rows are column-sorted (the last entry of every row)
+    __global__ __launch_bounds__(256) void max_col_kernel(uint n_rows, const uint* __restrict__ Xp, const uint* __restrict__ Xj, uint* __restrict__ out) {
+        uint m = 0;
+        for (uint i = blockIdx.x * 256 + threadIdx.x; i < n_rows; i += gridDim.x * 256) {
+            const uint e = Xp[i + 1];
+            if (e > Xp[i]) m = max(m, Xj[e - 1] + 1u);
+        }
+        m = wave_max(m);
+        __shared__ uint s_m[256 / kWave];
+        if (lane_id() == 0) s_m[wave_id()] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (uint w = 1; w < 256 / kWave; ++w) m = max(m, s_m[w]);
+            if (m) atomicMax(out, m);
+        }
+    }
+    // (key, entry) pairs of the owner list from the (entry, key) pairs the per-entry kernel appended
+    __global__ __launch_bounds__(256) void owner_split_kernel(uint n, const uint* __restrict__ list, uint* __restrict__ key, uint* __restrict__ ent) {
+        const uint k = blockIdx.x * 256 + threadIdx.x;
+        if (k < n) ent[k] = list[2 * k], key[k] = list[2 * k + 1];
+    }
+    template<typename T, class Mult, class Add>
+    __global__ __launch_bounds__(1024) void mxmT_owner_kernel(uint n_owned, const uint* __restrict__ key, const uint* __restrict__ ent, const uint* __restrict__ erow, uint n_rows,
+                                                              uint n_words, const uint* __restrict__ Mj, const uint* __restrict__ Ap, const uint* __restrict__ Aj,
+                                                              const uint* __restrict__ Bp, const uint* __restrict__ Bj, T* __restrict__ val, uint* __restrict__ keep, Mult mult, Add add_raw,
+                                                              T init, uint a_word, uint b_word) {
+        const Reassoc<Add> add(add_raw);
+        const T            pc = mult(from_bits<T>(a_word), from_bits<T>(b_word));// the one product
+        extern __shared__ uint s_dyn[];
+        uint* const s_bits = s_dyn;                 // n_words
+        uint* const s_beg  = s_dyn + n_words;       // per entry of the chunk: first word of the row that streams
+        uint* const s_len  = s_beg + kOwnerChunk;   //                         its length | bit 31: the row that streams is B's (the owner is A's)
+        uint* const s_key  = s_len + kOwnerChunk;   //                         owner key
+        uint* const s_ent  = s_key + kOwnerChunk;   //                         the entry itself
+        uint* const s_val  = s_ent + kOwnerChunk;   //                         its result (written by the wavefront that counted it, stored at the end of the chunk)
+        uint* const s_run  = s_val + kOwnerChunk;   // first entry of every run of equal owners in the chunk
+        uint* const s_tmp  = s_run + kOwnerChunk;   // scan scratch (kOwnerChunk / 64 + 2 words)
+        const uint  tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+        for (uint w = tid; w < n_words; w += 1024) s_bits[w] = 0;
+        for (uint p0 = blockIdx.x * kOwnerChunk; p0 < n_owned; p0 += gridDim.x * kOwnerChunk) {
+            const uint n_here = min(kOwnerChunk, n_owned - p0);
+            __syncthreads();// (the arrays of the chunk before this one are free; first turn: the bitmap is clean)
+            if (tid < n_here) {// the bounds of every entry of the chunk at once: one dependent chain per chunk
+                const uint k = key[p0 + tid], my_e = ent[p0 + tid];
+                const uint i = erow[my_e], j = Mj[my_e];
+                const bool a_owns = k < n_rows;// the owner is A[i, :]: B[j, :] streams
+                const uint b = a_owns ? Bp[j] : Ap[i], e2 = a_owns ? Bp[j + 1] : Ap[i + 1];
+                s_beg[tid] = b, s_len[tid] = (e2 - b) | (a_owns ? 0x80000000u : 0u), s_key[tid] = k, s_ent[tid] = my_e;
+            }
+            __syncthreads();
+            // the runs of equal owners: every entry that differs from its predecessor starts one; their positions, in order, by a prefix sum over the chunk
+            uint n_runs;
+            {
+                const bool     head = tid < n_here && (tid == 0 || s_key[tid] != s_key[tid - 1]);
+                const uint     at   = block_exclusive_sum<kOwnerChunk>(head ? 1u : 0u, s_tmp, n_runs);
+                if (head) s_run[at] = tid;
+                __syncthreads();
+            }
+            for (uint rr = 0; rr < n_runs; ++rr) {
+                const uint r0 = s_run[rr], r1 = rr + 1 < n_runs ? s_run[rr + 1] : n_here;
+                const uint k  = s_key[r0];
+                const bool  a_owns = k < n_rows;
+                const uint  orow = a_owns ? k : k - n_rows;
+                const uint* Op = a_owns ? Ap : Bp;
+                const uint* Oj = a_owns ? Aj : Bj;
+                const uint* Sj = a_owns ? Bj : Aj;
+                const uint  ob = Op[orow], oe = Op[orow + 1];
+                for (uint q = ob + tid; q < oe; q += 1024) {
+                    const uint c = Oj[q];
+                    (void) __hip_atomic_fetch_or(s_bits + (c >> 5), 1u << (c & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                __syncthreads();
+                // wavefront wv walks the run's entries r0 + wv, r0 + wv + 16, ... as ONE sequence of 64-word steps (entry after entry, a row's steps in order) with
+                // SIX steps' (twelve) loads in flight: with one workgroup per CU (the bitmap) sixteen wavefronts are all there is to cover the memory latency.  The step
+                // generator is BRANCH-FREE — every step loads (a step behind the wavefront's last entry re-reads word 0), its bookkeeping is selects over two LDS
+                // reads — so that the loads sit in straight-line code: with a load inside a branch the compiler waits for every earlier load before each one.
+                constexpr uint kStep = 2 * kWave;// words per step: two coalesced loads per lane (a row's median length is ~90 words: most entries are one step)
+                uint n_total = 0;// the wavefront's steps in this run
+                for (uint t = r0 + wv; t < r1; t += 16) n_total += ((s_len[t] & 0x7FFFFFFFu) + kStep - 1u) / kStep;
+                constexpr uint kNoStep = 0x7FFFFFFFu;
+                uint           g_t = r0 + wv, g_q = 0, g_b = s_beg[min(g_t, n_here - 1u)], g_len = s_len[min(g_t, n_here - 1u)] & 0x7FFFFFFFu;
+                constexpr int  D = 6;
+                uint           W0[D], W1[D], F[D], hits = 0;
+                bool           P0[D], P1[D];
+                auto           issue = [&](int k) {
+                    const bool valid = g_t < r1, in0 = valid && g_q + lane < g_len, in1 = valid && g_q + kWave + lane < g_len, last = g_q + kStep >= g_len;
+                    W0[k]            = Sj[in0 ? g_b + g_q + lane : 0u];
+                    W1[k]            = Sj[in1 ? g_b + g_q + kWave + lane : 0u];
+                    P0[k] = in0, P1[k] = in1;
+                    F[k]             = valid ? (g_t | (last ? 0x80000000u : 0u)) : kNoStep;
+                    const uint t2    = valid && last ? g_t + 16u : g_t;
+                    const uint at    = min(t2, n_here - 1u);
+                    const uint nb2 = s_beg[at], nl2 = s_len[at] & 0x7FFFFFFFu;
+                    g_q   = last ? 0u : g_q + kStep;
+                    g_b   = last ? nb2 : g_b;
+                    g_len = last ? nl2 : g_len;
+                    g_t   = t2;
+                };
+#pragma unroll
+                for (int k = 0; k < D; ++k) issue(k);
+                for (uint st = 0; st < n_total; st += D) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        const uint w0 = W0[k], w1 = W1[k];
+                        const bool h0 = P0[k] && ((s_bits[w0 >> 5] >> (w0 & 31)) & 1u), h1 = P1[k] && ((s_bits[w1 >> 5] >> (w1 & 31)) & 1u);
+                        hits += (uint) __popcll(__ballot(h0)) + (uint) __popcll(__ballot(h1));
+                        if (F[k] >> 31) {// the entry's last step: `hits` equal products folded — n x pc for PLUS, parity for BXOR, pc itself for the idempotent ops (merge_counts())
+                            if (lane == 0) {
+                                T tot = pc;
+                                if constexpr (std::is_integral<T>::value) {
+                                    const int op = merge_op_id(add);
+                                    if (op == SPLAHIP_PLUS) tot = from_bits<T>(hits * to_bits(pc));
+                                    if (op == SPLAHIP_BXOR) tot = (hits & 1u) ? pc : from_bits<T>(0u);
+                                }
+                                // (the result waits in LDS for the end of the chunk: no global store among the loads)
+                                s_val[F[k] & 0x7FFFFFFFu] = to_bits(hits ? add(init, tot) : init);
+                            }
+                            hits = 0;
+                        }
+                        issue(k);
+                    }
+                }
+                __syncthreads();
+                for (uint q = ob + tid; q < oe; q += 1024) s_bits[Oj[q] >> 5] = 0;
+                __syncthreads();
+            }
+            __syncthreads();
+            if (tid < n_here) {// the chunk's results
+                const T r       = from_bits<T>(s_val[tid]);
+                val[s_ent[tid]] = r;
+                keep[s_ent[tid]] = differs(r, init) ? 1u : 0u;
+            }
         }
     }
 
@@ -847,11 +1001,47 @@ namespace splahip {
             SPLAHIP_TRY(pieces.alloc(sizeof(uint) * 2 * (size_t) n_rows));
             SPLAHIP_TRY(piece_first.alloc(sizeof(uint) * (2 * (size_t) n_rows + 1)));
         }
+        // count mode (every stored value of A one word and every stored value of B one word: the triangle count) is looked for BEFORE the entries are classified:
+        // it sends every heavy entry to the owner form (mxmT_owner_kernel).  The boundary passes no entry counts for A and B, so the check runs when they are
+        // known anyway: nnz(A) = Ap[n_rows], and B is either the same matrix as A or the mask.  SPLAHIP_MXMT_COUNT=0 / SPLAHIP_MXMT_OWNER=0 switch the two off.
+        uint count_mode = 0, a_word = 0, b_word = 0, owner_words = 0;
+        {
+            const char* cenv = knob_env("SPLAHIP_MXMT_COUNT");
+            const char* oenv = knob_env("SPLAHIP_MXMT_OWNER");
+            const bool  b_is_a = Bp == Ap && Bx == Ax, b_is_m = Bp == Mp && Bx == Mx;
+            if (!jit_entry && !row_form && merge_form && merge_counts(op_add, TypeId<T>::value) && (b_is_a || b_is_m) && !(cenv && cenv[0] == '0')) {
+                uint   a_nnz = 0;
+                DevBuf rng;
+                SPLAHIP_TRY(rng.alloc(5 * sizeof(uint)));
+                const uint init_rng[5] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u, 0u};
+                SPLAHIP_TRY(hipMemcpyAsync(rng.p, init_rng, sizeof(init_rng), hipMemcpyHostToDevice, s));
+                SPLAHIP_TRY(hipMemcpyAsync(&a_nnz, Ap + n_rows, sizeof(uint), hipMemcpyDeviceToHost, s));
+                SPLAHIP_TRY(hipStreamSynchronize(s));
+                const uint b_nnz = b_is_a ? a_nnz : n_entries;
+                if (a_nnz && b_nnz) {
+                    hipLaunchKernelGGL(value_range_kernel, dim3(256), dim3(256), 0, s, a_nnz, static_cast<const uint*>(Ax), rng.as<uint>());
+                    hipLaunchKernelGGL(value_range_kernel, dim3(256), dim3(256), 0, s, b_nnz, static_cast<const uint*>(Bx), rng.as<uint>() + 2);
+                    hipLaunchKernelGGL(max_col_kernel, dim3(256), dim3(256), 0, s, n_rows, Ap, Aj, rng.as<uint>() + 4);
+                    if (!b_is_a) hipLaunchKernelGGL(max_col_kernel, dim3(256), dim3(256), 0, s, n_rows, Bp, Bj, rng.as<uint>() + 4);
+                    uint h_rng[5] = {0, 1, 0, 1, 0};
+                    SPLAHIP_TRY(hipMemcpyAsync(h_rng, rng.p, sizeof(h_rng), hipMemcpyDeviceToHost, s));
+                    SPLAHIP_TRY(hipStreamSynchronize(s));
+                    if (h_rng[0] == h_rng[1] && h_rng[2] == h_rng[3]) {
+                        count_mode = 1, a_word = h_rng[0], b_word = h_rng[2];
+                        const uint words = (h_rng[4] + 31u) / 32u;// bitmap over the inner dimension; + the chunk's three arrays: it has to fit the LDS
+                        if (!(oenv && oenv[0] == '0') && n_rows < (1u << 30) && ((size_t) words + 6 * kOwnerChunk + 32) * 4 <= 159u * 1024u) owner_words = std::max(words, 1u);
+                    }
+                }
+            }
+        }
+        DevBuf okey, oent, okey_s, oent_s, erow;
+        if (owner_words) SPLAHIP_TRY(erow.alloc(sizeof(uint) * (size_t) n_entries));
         if (!jit_entry)
             hipLaunchKernelGGL((mxmT_entry_kernel<T, DynBin, DynBin>), dim3((n_entries + 255) / 256), dim3(256), 0, s, n_rows, n_entries, Mp, Mj,
                                static_cast<const T*>(Mx), Ap, Aj, static_cast<const T*>(Ax), Bp, Bj, static_cast<const T*>(Bx), val.as<T>(),
                                keep.as<uint>(), hcount.as<uint>(), hlist.as<uint>(), DynBin(op_mult), DynBin(op_add), op_select, init, row_form ? kRowCap : 0u,
-                               row_form ? cost.as<uint>() : nullptr, merge_form ? 1u : 0u, merge_factor, heavy_from);
+                               row_form ? cost.as<uint>() : nullptr, merge_form ? 1u : 0u, merge_factor, heavy_from, owner_words ? hlist.as<uint>() : nullptr,
+                               owner_words ? erow.as<uint>() : nullptr);
         SPLAHIP_TRY(hipGetLastError());
         uint h_heavy[2] = {0, 0}, h_first[2] = {0, 0};
         if (row_form) {
@@ -863,28 +1053,30 @@ namespace splahip {
         }
         SPLAHIP_TRY(hipMemcpyAsync(h_heavy, hcount.p, 2 * sizeof(uint), hipMemcpyDeviceToHost, s));
         SPLAHIP_TRY(hipStreamSynchronize(s));
-        // count mode of the block merge: every stored value of A one word and every stored value of B one word.  The boundary passes no entry
-        // counts for A and B, so the check runs when they are known anyway: nnz(A) = Ap[n_rows], and B is either the same matrix as A or the mask
-        uint count_mode = 0, a_word = 0, b_word = 0;
-        {
-            const char* cenv = knob_env("SPLAHIP_MXMT_COUNT");
-            const bool  b_is_a = Bp == Ap && Bx == Ax, b_is_m = Bp == Mp && Bx == Mx;
-            if (h_heavy[1] && merge_counts(op_add, TypeId<T>::value) && (b_is_a || b_is_m) && !(cenv && cenv[0] == '0')) {
-                uint   a_nnz = 0;
-                DevBuf rng;
-                SPLAHIP_TRY(rng.alloc(4 * sizeof(uint)));
-                const uint init_rng[4] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u};
-                SPLAHIP_TRY(hipMemcpyAsync(rng.p, init_rng, sizeof(init_rng), hipMemcpyHostToDevice, s));
-                SPLAHIP_TRY(hipMemcpyAsync(&a_nnz, Ap + n_rows, sizeof(uint), hipMemcpyDeviceToHost, s));
-                SPLAHIP_TRY(hipStreamSynchronize(s));
-                if (a_nnz) hipLaunchKernelGGL(value_range_kernel, dim3(1024), dim3(256), 0, s, a_nnz, static_cast<const uint*>(Ax), rng.as<uint>());
-                const uint b_nnz = b_is_a ? a_nnz : n_entries;
-                if (b_nnz) hipLaunchKernelGGL(value_range_kernel, dim3(1024), dim3(256), 0, s, b_nnz, static_cast<const uint*>(Bx), rng.as<uint>() + 2);
-                uint h_rng[4] = {0, 1, 0, 1};
-                SPLAHIP_TRY(hipMemcpyAsync(h_rng, rng.p, sizeof(h_rng), hipMemcpyDeviceToHost, s));
-                SPLAHIP_TRY(hipStreamSynchronize(s));
-                if (a_nnz && b_nnz && h_rng[0] == h_rng[1] && h_rng[2] == h_rng[3]) count_mode = 1, a_word = h_rng[0], b_word = h_rng[2];
-            }
+        if (owner_words && h_heavy[0]) {// the owner form: sort the heavy entries by owner, then one pass
+            const uint n_owned = h_heavy[0];
+            SPLAHIP_TRY(okey.alloc(sizeof(uint) * (size_t) n_owned));
+            SPLAHIP_TRY(oent.alloc(sizeof(uint) * (size_t) n_owned));
+            SPLAHIP_TRY(okey_s.alloc(sizeof(uint) * (size_t) n_owned));
+            SPLAHIP_TRY(oent_s.alloc(sizeof(uint) * (size_t) n_owned));
+            hipLaunchKernelGGL(owner_split_kernel, dim3((n_owned + 255) / 256), dim3(256), 0, s, n_owned, hlist.as<uint>(), okey.as<uint>(), oent.as<uint>());
+            size_t     tb   = 0;
+            const uint bits = std::max(1u, bit_width(2ull * n_rows));
+            SPLAHIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, okey.as<uint>(), okey_s.as<uint>(), oent.as<uint>(), oent_s.as<uint>(), (size_t) n_owned, 0u, bits, s));
+            DevBuf st;
+            SPLAHIP_TRY(st.alloc(tb ? tb : 4));
+            SPLAHIP_TRY(rocprim::radix_sort_pairs(st.p, tb, okey.as<uint>(), okey_s.as<uint>(), oent.as<uint>(), oent_s.as<uint>(), (size_t) n_owned, 0u, bits, s));
+            const size_t lds = ((size_t) owner_words + 6 * kOwnerChunk + 32) * 4;
+            int          dev = 0, cus = 256;
+            (void) hipGetDevice(&dev);
+            (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            const uint per_cu = (uint) std::max<size_t>(1, std::min<size_t>(2, (160u * 1024u) / lds));// 1024-thread workgroups: at most two per CU
+            const uint grid   = std::min((n_owned + kOwnerChunk - 1) / kOwnerChunk, (uint) cus * per_cu * 4u);
+            SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxmT_owner_kernel<T, DynBin, DynBin>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipLaunchKernelGGL((mxmT_owner_kernel<T, DynBin, DynBin>), dim3(grid), dim3(1024), lds, s, n_owned, okey_s.as<uint>(), oent_s.as<uint>(), erow.as<uint>(), n_rows, owner_words, Mj,
+                               Ap, Aj, Bp, Bj, val.as<T>(), keep.as<uint>(), DynBin(op_mult), DynBin(op_add), init, a_word, b_word);
+            SPLAHIP_TRY(hipGetLastError());
+            h_heavy[0] = 0;// (served: nothing is left for the search kernel)
         }
         if (h_heavy[1]) {
             // the plus-times semiring (the triangle count, SpGEMM proper) gets compile-time functors: the runtime-switched ones cost a switch per

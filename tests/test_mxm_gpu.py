@@ -328,6 +328,63 @@ def test_mxmT_count_mode_of_uniform_values(oracle, t):
             _same_csr(_host3(got, t), want, t, exact, f"mxmT count mode {t} x={xval} odd={odd} {mul}/{add}")
 
 
+@pytest.mark.parametrize("t", ["INT", "UINT"])
+@pytest.mark.parametrize("shape", ["M=A=B", "B=A", "B=M"])
+def test_mxmT_owner_form_of_the_heavy_entries(oracle, monkeypatch, t, shape):
+    """Count mode with heavy entries takes the OWNER form (mxm.hip: mxmT_owner_kernel): an entry belongs to the longer of its two rows, whose columns become a bitmap
+    in LDS, and only the shorter row is streamed.  Operands that are the same matrix (the triangle count), B = A under a separate mask, and B = the mask;
+    rectangular, empty rows, an inner dimension that is no multiple of 32, masks that reject entries, every op_add that may count matches; bit-exact against the
+    oracle and identical to the block-merge form (SPLAHIP_MXMT_OWNER=0).  Reference: src/cpu/cpu_mxmT_masked.hpp:87-125."""
+    from spla_amd import kernels
+    rng = np.random.default_rng(1234 + len(shape))
+    n, k = (900, 900) if shape == "M=A=B" else (700, 1237)
+
+    def struct(rows, cols, p, hot):
+        d = rng.random((rows, cols)) < p
+        d[:, :hot] |= rng.random((rows, hot)) < 0.8      # hub columns: long rows on both sides
+        d[rng.integers(0, rows, 12), :] = False          # a few empty rows
+        d[rng.integers(0, rows, 6), :] |= rng.random((6, cols)) < 0.7   # a few very long ones
+        I, J = np.nonzero(d)
+        P = np.zeros(rows + 1, np.uint32)
+        np.add.at(P, I + 1, 1)
+        return np.cumsum(P).astype(np.uint32), J.astype(np.uint32)
+
+    xa = 3
+    if shape == "M=A=B":
+        Ap, Aj = struct(n, n, 0.25, 60)
+        A = (Ap, Aj, np.full(len(Aj), xa, NP[t]))
+        M = B = A
+        rows_m = n
+    elif shape == "B=A":
+        Ap, Aj = struct(n, k, 0.2, 50)
+        A = B = (Ap, Aj, np.full(len(Aj), xa, NP[t]))
+        Mp, Mj = struct(n, n, 0.05, 10)
+        M = (Mp, Mj, random_mask(rng, len(Mj), t))
+        rows_m = n
+    else:  # B = M: the mask is n x n and doubles as B (n rows of n columns), A is n x n
+        Mp, Mj = struct(n, n, 0.2, 50)
+        M = B = (Mp, Mj, np.full(len(Mj), 2, NP[t]))
+        Ap, Aj = struct(n, n, 0.2, 40)
+        A = (Ap, Aj, np.full(len(Aj), xa, NP[t]))
+        rows_m = n
+    dA = _dev3(A, t)
+    dB = dA if B is A else (_dev3(B, t) if B is not M else None)
+    dM = dA if M is A else _dev3(M, t)
+    if dB is None:
+        dB = dM
+    for mul, add, sel, init in [("MULT", "PLUS", "ALWAYS", 0), ("MULT", "PLUS", "NQZERO", 5), ("PLUS", "MIN", "ALWAYS", 100), ("MULT", "BXOR", "ALWAYS", 0),
+                                ("BAND", "BOR", "GTZERO", 1), ("MULT", "SECOND", "ALWAYS", 0)]:
+        if shape == "B=M" and sel != "ALWAYS":
+            continue  # (the mask's values are one word there: every select answers alike)
+        want = oracle.mxmT_masked(t, rows_m, M, A, B, mul, add, sel, init)
+        got = kernels.mxmT_masked(t, rows_m, dM, dA, dB, mul, add, sel, init)
+        _same_csr(_host3(got, t), want, t, True, f"mxmT owner form {shape} {t} {mul}/{add}/{sel}")
+        monkeypatch.setenv("SPLAHIP_MXMT_OWNER", "0")
+        got2 = kernels.mxmT_masked(t, rows_m, dM, dA, dB, mul, add, sel, init)
+        monkeypatch.delenv("SPLAHIP_MXMT_OWNER")
+        _same_csr(_host3(got2, t), want, t, True, f"mxmT block merge {shape} {t} {mul}/{add}/{sel}")
+
+
 @pytest.mark.parametrize("add", ["MIN", "MAX"])
 def test_fp32_min_max_nan_products_and_nan_init(oracle, add):
     """mxm / mxmT fold from `init` (src/cpu/cpu_mxm.hpp:93-113, cpu_mxmT_masked.hpp:94-123): under fp32 MIN / MAX a NaN product is never picked and
