@@ -30,19 +30,27 @@ def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, 
     outs = {}
     # sell-bits: the sparse-input-vector form forced on wherever the semiring allows it (SPLAHIP_SELL_BITS=2); plain "sell" lets the
     # device statistics choose
-    for form in ("csr", "sell", "sell-bits", "cob", "cob-small"):
+    for form in ("csr", "sell", "sell-bits", "cob", "cob-small", "cob-dyn", "cob-small-dyn"):
         os.environ["SPLAHIP_SELL_BITS"] = "2" if form == "sell-bits" else "1"
         # cob-small also forces cob's sparse-input-vector form of min-plus, which the library only picks for >= 2^23 columns
-        os.environ["SPLAHIP_COB_BITS"] = "2" if form == "cob-small" else "1"
+        os.environ["SPLAHIP_COB_BITS"] = "2" if form in ("cob-small", "cob-small-dyn") else "1"
         plan = kernels.CsrPlan(n_rows, len(Aj), dAp, n_cols, dAj, dAx) if form.startswith("sell") else kernels.CsrPlan(n_rows, len(Aj), dAp)
-        if form == "cob":        # column-ordered blocks, default geometry (ranges of 20224 slots)
+        # "-dyn": the run-time schedule of the blocks kernel (mxv_cob_dyn.hpp: persistent workgroups that join ranges and claim rounds; shipped switched
+        # off) — on the small geometry with three listed workers per range so that ranges are shared, merged and finished by the kernel behind the launch
+        if form.endswith("-dyn"):
+            os.environ["SPLAHIP_COB_DYN"] = "1"
+            if form == "cob-small-dyn":
+                os.environ["SPLAHIP_COB_DYN_WORKERS"] = "3"
+        if form in ("cob", "cob-dyn"):  # column-ordered blocks, default geometry (ranges of 20224 slots)
             plan.attach_cob(n_cols, dAp, dAj, dAx)
-        elif form == "cob-small":  # ranges of 256 slots, pieces of 2 chunks, every row of degree >= 3 a hub candidate: hub and natural ranges, column
+        elif form in ("cob-small", "cob-small-dyn"):  # ranges of 256 slots, pieces of 2 chunks, every row of degree >= 3 a hub candidate: hub and natural ranges, column
             os.environ["SPLAHIP_COB_HUB_MIN_DEGREE"] = "3"  # windows, ranges in several pieces (shared accumulators, tickets) even on small inputs
             os.environ["SPLAHIP_COB_NAT_SLOTS"] = "512"     # natural ranges twice the hub ranges' size: an fp32 sum keeps them in float words (COB_FADD)
             plan.attach_cob(n_cols, dAp, dAj, dAx, row_bits=8, tile_chunks=2)
             os.environ.pop("SPLAHIP_COB_HUB_MIN_DEGREE")
             os.environ.pop("SPLAHIP_COB_NAT_SLOTS")
+        os.environ.pop("SPLAHIP_COB_DYN", None)
+        os.environ.pop("SPLAHIP_COB_DYN_WORKERS", None)
         r = torch.empty(n_rows, dtype=kernels.torch_dtype(t), device="cuda")
         for _ in range(calls):  # calls > 1: the later calls of a plan follow the hints its earlier calls left (mask probe, first-hit pass); the last result is checked
             if junk is not None:
@@ -64,7 +72,7 @@ def hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, op_mult, op_add, op_select, 
         assert np.all(np.abs(a[fin] - b[fin]) <= 1e-5 * np.maximum(np.abs(b[fin]), 1e-30) + 1e-30), "sliced-ELL kernel differs from the CSR kernels"
     else:
         assert np.array_equal(outs["sell"], outs["csr"]), "sliced-ELL kernel differs from the CSR kernels"
-    for form in ("cob", "cob-small"):
+    for form in ("cob", "cob-small", "cob-dyn", "cob-small-dyn"):
         if t == "FLOAT" and op_add in ("MIN", "MAX") and op_mult == "PLUS":  # the keyed fp32 MIN / MAX form is the reference's fold bit for bit
             assert np.array_equal(outs[form].view(np.uint32), outs["csr"].view(np.uint32)), f"{form} fp32 {op_add} differs from the CSR kernels"
         elif t == "FLOAT":
