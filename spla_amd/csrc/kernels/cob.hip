@@ -13,7 +13,9 @@
 //   2. a stable LSD radix sort of the keys on the (range, column) bits only, carrying the value word (rocprim, one-off per matrix):
 //      inside a (range, column) run the entries keep their order
 //   3. cob_group_kernel   first sorted entry of every (range, column window) group by binary search; chunks per group; scan
-//   4. cob_scatter_kernel one workgroup per chunk: pack cr / ax / hdr, pad a group's last chunk
+//   3b. cob_weight_kernel slots per entry: itself + one bridging slot per 255 columns of a gap of more than 255 to the entry before it (the column stream holds
+//                         8-bit deltas); their running sum places every entry
+//   4. cob_scatter_kernel one workgroup per chunk: pack sl / dl / ax / hdr (16-bit slot, 8-bit column delta, value word; column of the first slot), pad a group's last chunk
 //   5. the schedules      pieces (consecutive chunks of one range, at most one workgroup slot's share), largest first; shared accumulators
 //                         and tickets of the ranges cut into several pieces
 #include "block_utils.hpp"
@@ -24,6 +26,7 @@
 #include "plan.hpp"
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -214,51 +217,87 @@ namespace {
         }
         start[g] = lo;
     }
-    __global__ __launch_bounds__(256) void cob_chunk_count_kernel(uint32_t n_groups, const uint32_t* __restrict__ start, uint32_t* __restrict__ chunks) {
+    // Slots an entry takes in its group's chunks: itself, and — the column stream holds 8-bit DELTAS to the slot before — one bridging slot per 255 columns
+    // of a gap of more than 255 to the entry before it (same group).  A bridging slot is a padding slot (a spare LDS word, value 0) at a column of its own.
+    __global__ __launch_bounds__(256) void cob_weight_kernel(uint32_t nnz, const unsigned long long* __restrict__ key, uint32_t col_bits, uint32_t cbits, uint32_t* __restrict__ w) {
+        const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+        if (k > nnz) return;
+        if (k == nnz) {
+            w[k] = 0u;
+            return;
+        }
+        uint32_t x = 1u;
+        if (k > 0 && (key[k] >> (kSlotBits + col_bits)) == (key[k - 1] >> (kSlotBits + col_bits))) {
+            const uint32_t c = (uint32_t) (key[k] >> kSlotBits) & ((1u << cbits) - 1u), cp = (uint32_t) (key[k - 1] >> kSlotBits) & ((1u << cbits) - 1u);
+            const uint32_t gap = c - cp;
+            if (gap > 255u) x += (gap - 1u) / 255u;
+        }
+        w[k] = x;
+    }
+    __global__ __launch_bounds__(256) void cob_chunk_count_kernel(uint32_t n_groups, const uint32_t* __restrict__ start, const uint32_t* __restrict__ pos, uint32_t* __restrict__ chunks) {
         const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-        if (g < n_groups) chunks[g] = (start[g + 1] - start[g] + kCobChunk - 1) / kCobChunk;
+        if (g < n_groups) chunks[g] = (pos[start[g + 1]] - pos[start[g]] + kCobChunk - 1) / kCobChunk;
     }
 
-    // one workgroup (256 threads = 256 slots) per chunk
+    // one workgroup (256 threads = 256 slots) per chunk.  The chunk's three streams: sl (16-bit slot in range; a padding / bridging slot carries R + lane),
+    // dl (8-bit column delta to the slot before it in SORTED order; 0 for the chunk's first slot), ax (value word); hdr[chunk] = column of its first slot.
     __global__ __launch_bounds__(256) void cob_scatter_kernel(const unsigned long long* __restrict__ key, const uint32_t* __restrict__ val, const uint32_t* __restrict__ start,
-                                                              const uint32_t* __restrict__ chunk_first, uint32_t n_groups, uint32_t R_hub, uint32_t R_nat, uint32_t n_hub_ranges,
-                                                              uint32_t col_bits, uint32_t win_bits, uint32_t* __restrict__ cr, uint32_t* __restrict__ ax, uint32_t* __restrict__ hdr,
-                                                              uint32_t* __restrict__ chunk_lines) {
+                                                              const uint32_t* __restrict__ pos, const uint32_t* __restrict__ chunk_first, uint32_t n_groups, uint32_t R_hub, uint32_t R_nat,
+                                                              uint32_t n_hub_ranges, uint32_t cbits, uint32_t win_bits, uint16_t* __restrict__ sl, uint8_t* __restrict__ dl,
+                                                              uint32_t* __restrict__ ax, uint32_t* __restrict__ hdr, uint32_t* __restrict__ chunk_lines) {
+        __shared__ uint32_t s_col[kCobChunk];
         const uint32_t c = blockIdx.x;
         const uint32_t g = upper_bound_u32(chunk_first, n_groups + 1, c) - 1;// largest g with chunk_first[g] <= c (uniform)
         const uint32_t i = c - chunk_first[g];
         const uint32_t s0 = start[g], s1 = start[g + 1];
         const uint32_t R  = (g >> win_bits) < n_hub_ranges ? R_hub : R_nat;// the group's range decides which slot value marks padding
-        // memory position p = 4 * lane + j holds the chunk's sorted entry 64 * j + lane: a lane's 16-byte load brings its four slots, and the
-        // wave's j-th gather instruction covers 64 consecutive sorted entries (ascending, neighbouring columns)
-        const uint32_t src = s0 + i * kCobChunk + 64 * (threadIdx.x & 3) + (threadIdx.x >> 2);
-        uint32_t       w = (R + (threadIdx.x >> 2)) << col_bits, x = 0;// padding: slot field R + lane (the lane's spare LDS word: position 4 l + j belongs to lane l), column offset 0
-        if (src < s1) {
-            const unsigned long long k = key[src];
-            const uint32_t           rl = (uint32_t) k & ((1u << kSlotBits) - 1u);
-            const uint32_t           co = (uint32_t) (k >> kSlotBits) & ((1u << col_bits) - 1u);
-            w                           = (rl << col_bits) | co;
-            x                           = val[src];
+        // memory position p = 4 * lane + j holds the chunk's sorted slot 64 * j + lane: a lane's loads bring its four slots, and the wave's j-th gather
+        // instruction covers 64 consecutive sorted slots (ascending, neighbouring columns)
+        const uint32_t si    = 64 * (threadIdx.x & 3) + (threadIdx.x >> 2);
+        const uint32_t total = pos[s1] - pos[s0], S = i * kCobChunk + si, n_valid = min(kCobChunk, total - i * kCobChunk);
+        uint32_t       slot = R + (threadIdx.x >> 2), x = 0, col = 0;// padding: the lane's spare LDS word (position 4 l + j belongs to lane l)
+        if (S < total) {
+            // the entry k whose slots cover S: pos[k] - pos[s0] <= S < pos[k + 1] - pos[s0]
+            uint32_t lo = s0, hi = s1;
+            while (hi - lo > 1) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (pos[mid] - pos[s0] <= S) lo = mid;
+                else
+                    hi = mid;
+            }
+            const unsigned long long kk = key[lo];
+            const uint32_t           ck = (uint32_t) (kk >> kSlotBits) & ((1u << cbits) - 1u);
+            const uint32_t           t  = S - (pos[lo] - pos[s0]), wk = pos[lo + 1] - pos[lo];
+            if (t + 1 == wk) {// the entry itself (its bridging slots come first)
+                slot = (uint32_t) kk & ((1u << kSlotBits) - 1u);
+                x    = val[lo];
+                col  = ck;
+            } else
+                col = ((uint32_t) (key[lo - 1] >> kSlotBits) & ((1u << cbits) - 1u)) + 255u * (t + 1u);// bridging slot t of the gap before the entry
         }
-        cr[(size_t) c * kCobChunk + threadIdx.x] = w;
+        s_col[si] = col;
+        __syncthreads();
+        if (S >= total) col = s_col[n_valid - 1];// padding behind the group's last slot: no further column
+        __syncthreads();
+        s_col[si] = col;
+        __syncthreads();
+        const uint32_t prev = si ? s_col[si - 1] : col;
+        sl[(size_t) c * kCobChunk + threadIdx.x] = (uint16_t) slot;
+        dl[(size_t) c * kCobChunk + threadIdx.x] = (uint8_t) (col - prev);
         ax[(size_t) c * kCobChunk + threadIdx.x] = x;
-        // distinct 128-byte lines of v among the chunk's entries (they are sorted by column: count the changes): what the gathers of this chunk cost
-        bool fresh = false;
-        if (src < s1) {
-            const uint32_t line = (uint32_t) (key[src] >> (kSlotBits + 5)) & ((1u << (col_bits - 5)) - 1u);
-            fresh               = src == s0 + i * kCobChunk || line != ((uint32_t) (key[src - 1] >> (kSlotBits + 5)) & ((1u << (col_bits - 5)) - 1u));
-        }
-        const int lines = __syncthreads_count(fresh);
+        // distinct 128-byte lines of v among the chunk's slots (they are sorted by column: count the changes): what the gathers of this chunk cost
+        const bool fresh = si < n_valid && slot < R && (si == 0 || (col >> 5) != (prev >> 5));// (a padding / bridging slot gathers the chunk's base column: no line of its own)
+        const int  lines = __syncthreads_count(fresh);
         if (threadIdx.x == 0) {
-            const uint32_t window = win_bits ? (g & ((1u << win_bits) - 1u)) : 0u;
-            hdr[c]                = window << col_bits;
-            chunk_lines[c]        = (uint32_t) lines;
+            hdr[c]         = s_col[0];
+            chunk_lines[c] = (uint32_t) lines;
         }
     }
 
-    __global__ __launch_bounds__(256) void cob_padchunk_kernel(uint32_t c, uint32_t R, uint32_t col_bits, uint32_t* __restrict__ cr, uint32_t* __restrict__ ax,
+    __global__ __launch_bounds__(256) void cob_padchunk_kernel(uint32_t c, uint32_t R, uint16_t* __restrict__ sl, uint8_t* __restrict__ dl, uint32_t* __restrict__ ax,
                                                                uint32_t* __restrict__ hdr) {
-        cr[(size_t) c * kCobChunk + threadIdx.x] = (R + (threadIdx.x >> 2)) << col_bits;
+        sl[(size_t) c * kCobChunk + threadIdx.x] = (uint16_t) (R + (threadIdx.x >> 2));
+        dl[(size_t) c * kCobChunk + threadIdx.x] = 0;
         ax[(size_t) c * kCobChunk + threadIdx.x] = 0;
         if (threadIdx.x == 0) hdr[c] = 0;
     }
@@ -468,7 +507,8 @@ namespace {
         a.tiles      = reinterpret_cast<const CobTile*>(sc.d_tiles);
         a.ranges     = reinterpret_cast<const CobRange*>(sc.d_ranges);
         a.hdr        = g->d_hdr;
-        a.cr         = g->d_cr;
+        a.sl         = g->d_sl;
+        a.dl         = g->d_dl;
         a.ax         = g->d_ax;
         a.slot16     = g->d_slot16;
         a.hub_row    = g->d_hub_row;
@@ -671,7 +711,7 @@ namespace splahip {
     void cob_release(splahip_cob_s* g) {
         if (!g) return;
         if (g->h_probe) (void) hipHostFree(const_cast<uint32_t*>(g->h_probe));
-        for (void* p : {(void*) g->d_hdr, (void*) g->d_cr, (void*) g->d_ax, (void*) g->d_slot16, (void*) g->d_hub_row, (void*) g->d_acc, (void*) g->d_ticket, (void*) g->d_vbits, (void*) g->d_probe, (void*) g->d_hot_cols, (void*) g->d_vperm,
+        for (void* p : {(void*) g->d_hdr, (void*) g->d_sl, (void*) g->d_dl, (void*) g->d_ax, (void*) g->d_slot16, (void*) g->d_hub_row, (void*) g->d_acc, (void*) g->d_ticket, (void*) g->d_vbits, (void*) g->d_probe, (void*) g->d_hot_cols, (void*) g->d_vperm,
                         (void*) g->sched[0].d_tiles, (void*) g->sched[0].d_ranges, (void*) g->sched[1].d_tiles, (void*) g->sched[1].d_ranges, (void*) g->d_spans, (void*) g->d_dyn_words,
                         (void*) g->sched[0].d_jobs, (void*) g->d_fin_tasks, (void*) g->d_dyn_weight, (void*) g->d_dyn_ranges, (void*) g->sched[0].d_dyn_ctl, (void*) g->sched[1].d_jobs,
                         (void*) g->sched[1].d_dyn_ctl})
@@ -1114,7 +1154,24 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     if (e == hipSuccess) e = tmp.alloc(&chunk_first, (size_t) n_groups + 1);
     if (e != hipSuccess) return bail("scratch");
     hipLaunchKernelGGL(cob_group_kernel, dim3((n_groups + 256) / 256), dim3(256), 0, s, nnz, key_s, kSlotBits + col_bits, n_groups, start);
-    hipLaunchKernelGGL(cob_chunk_count_kernel, dim3((n_groups + 255) / 256), dim3(256), 0, s, n_groups, start, chunk_first);
+    // slots per entry (itself + the bridging slots of a column gap of more than 255), their running sum: where an entry's slots start
+    uint32_t *wgt = nullptr, *pos = nullptr;
+    e = tmp.alloc(&wgt, (size_t) nnz + 1);
+    if (e == hipSuccess) e = tmp.alloc(&pos, (size_t) nnz + 1);
+    if (e != hipSuccess) return bail("scratch");
+    hipLaunchKernelGGL(cob_weight_kernel, dim3((nnz + 256) / 256), dim3(256), 0, s, nnz, key_s, col_bits, cbits, wgt);
+    {
+        size_t bytes = 0;
+        e            = rocprim::exclusive_scan(nullptr, bytes, wgt, pos, 0u, (size_t) nnz + 1, rocprim::plus<uint32_t>(), s);
+        void* st_tmp = nullptr;
+        if (e == hipSuccess) e = device_malloc(&st_tmp, bytes ? bytes : 4);
+        if (e == hipSuccess) {
+            tmp.ptrs.push_back(st_tmp);
+            e = rocprim::exclusive_scan(st_tmp, bytes, wgt, pos, 0u, (size_t) nnz + 1, rocprim::plus<uint32_t>(), s);
+        }
+        if (e != hipSuccess) return bail("slot scan");
+    }
+    hipLaunchKernelGGL(cob_chunk_count_kernel, dim3((n_groups + 255) / 256), dim3(256), 0, s, n_groups, start, pos, chunk_first);
     hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk_first, n_groups);
     e = hipGetLastError();
     uint32_t n_chunks = 0;
@@ -1125,18 +1182,19 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
 
     stamp("groups -> chunks");
     // 4: the packed streams
-    own(&g->d_cr, ((size_t) n_chunks + 2) * kCobChunk);// + two all-padding chunks (the main loop's steps beyond a piece's end walk one: hub / natural slot values)
+    own(&g->d_sl, ((size_t) n_chunks + 2) * kCobChunk);// + two all-padding chunks (the main loop's steps beyond a piece's end walk one: hub / natural slot values)
+    own(&g->d_dl, ((size_t) n_chunks + 2) * kCobChunk);
     own(&g->d_ax, ((size_t) n_chunks + 2) * kCobChunk);
     own(&g->d_hdr, (size_t) n_chunks + 2);
     if (e != hipSuccess) return bail("hipMalloc");
-    hipLaunchKernelGGL(cob_padchunk_kernel, dim3(1), dim3(256), 0, s, n_chunks, R, col_bits, g->d_cr, g->d_ax, g->d_hdr);
-    hipLaunchKernelGGL(cob_padchunk_kernel, dim3(1), dim3(256), 0, s, n_chunks + 1, Rn, col_bits, g->d_cr, g->d_ax, g->d_hdr);
+    hipLaunchKernelGGL(cob_padchunk_kernel, dim3(1), dim3(256), 0, s, n_chunks, R, g->d_sl, g->d_dl, g->d_ax, g->d_hdr);
+    hipLaunchKernelGGL(cob_padchunk_kernel, dim3(1), dim3(256), 0, s, n_chunks + 1, Rn, g->d_sl, g->d_dl, g->d_ax, g->d_hdr);
     uint32_t* chunk_lines = nullptr;
     e                     = tmp.alloc(&chunk_lines, (size_t) n_chunks + 1);
     if (e != hipSuccess) return bail("scratch");
     if (n_chunks)
-        hipLaunchKernelGGL(cob_scatter_kernel, dim3(n_chunks), dim3(256), 0, s, key_s, val_s, start, chunk_first, n_groups, R, Rn, n_hub_ranges, col_bits, win_bits, g->d_cr, g->d_ax, g->d_hdr,
-                           chunk_lines);
+        hipLaunchKernelGGL(cob_scatter_kernel, dim3(n_chunks), dim3(256), 0, s, key_s, val_s, start, pos, chunk_first, n_groups, R, Rn, n_hub_ranges, cbits, win_bits, g->d_sl, g->d_dl,
+                           g->d_ax, g->d_hdr, chunk_lines);
     e = hipGetLastError();
     if (e != hipSuccess) return bail("scatter");
     uint32_t* negzero_word = nullptr;
@@ -1163,11 +1221,11 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     g->ax_negzero = h_negzero;
     std::vector<uint32_t> range_chunk((size_t) n_ranges + 1);
     for (uint32_t q = 0; q <= n_ranges; ++q) range_chunk[q] = h_first[(size_t) q << win_bits];
-    // cost of a chunk in units of one stream line's stay in the miss queue: 16 stream lines + its gather lines weighted SPLAHIP_COB_LINE_PCT % (default 40: measured, a cold chunk of ~230 lines walks in ~340 ns, a hub chunk in ~95;
+    // cost of a chunk in units of one stream line's stay in the miss queue: 14 stream lines + its gather lines weighted SPLAHIP_COB_LINE_PCT % (default 40: measured, a cold chunk of ~230 lines walks in ~340 ns, a hub chunk in ~85;
     // part of them hit the L2); cost_pre[c] = cost of the chunks before c
     const uint32_t        line_pct = env_u32("SPLAHIP_COB_LINE_PCT", 40);// (25 / 40 / 60 on one box, twice: R-MAT 22 151.5 / 145.2 / 147.9 us, R-MAT 23 307.5 / 304.1 / 308.7)
     std::vector<uint64_t> cost_pre((size_t) n_chunks + 1, 0);
-    for (uint32_t c = 0; c < n_chunks; ++c) cost_pre[c + 1] = cost_pre[c] + 1600 + (uint64_t) h_lines[c] * line_pct;
+    for (uint32_t c = 0; c < n_chunks; ++c) cost_pre[c + 1] = cost_pre[c] + 1400 + (uint64_t) h_lines[c] * line_pct;// (a chunk's three streams: 14 lines)
     own(&g->d_probe, 8);
     if (e == hipSuccess) e = hipMemsetAsync(g->d_probe, 0, sizeof(uint32_t) * 8, s);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(const_cast<uint32_t**>(&g->h_probe)), 4 * sizeof(uint32_t), hipHostMallocMapped);
@@ -1197,7 +1255,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         // and with pieces of similar cost the COUNT matters: 2.2 x slots pieces run in three rounds.  So the candidates are tried on a model of the launch
         // — dearest piece first onto the slot that frees first; a piece costs its chunks + ~4 us of zeroing and pipeline fill (+ ~3.5 us of merging
         // for a range in several pieces), a range's row pass goes to one of its pieces — and the share with the shortest modelled makespan is kept.
-        // (cost unit: 1600 = one chunk's streams ~ 95 ns.)  SPLAHIP_COB_SHARE_PCT fixes the share instead.
+        // (cost unit: 1400 = one chunk's streams, 14 lines ~ 83 ns.)  SPLAHIP_COB_SHARE_PCT fixes the share instead.
         std::vector<uint32_t> tiles, ranges((size_t) n_ranges * 4);
         std::vector<uint64_t> cost;
         uint32_t              n_multi = 0;
@@ -1346,8 +1404,8 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         if (knob_env("SPLAHIP_COB_TRACE"))
             std::fprintf(stderr, "[cob] schedule %d: R %u / %u, %u hub rows in %u hub ranges + %u natural ranges; slots %u, cost %.1f M (%.1f %% gathers), piece <= %u %% of a share in %u size levels, %u pieces, "
                                  "%u ranges in several pieces, modelled makespan %.1f us (even: %.1f)\n",
-                         w, R, Rn, H, n_hub_ranges, n_nat, slots, cost_pre[n_chunks] / 1e8, 100.0 - 100.0 * 1600.0 * n_chunks / std::max<uint64_t>(1, cost_pre[n_chunks]), share_pct, levels, n_tiles, n_multi,
-                         makespan() * 95e-3 / 1600, cost_pre[n_chunks] * 95e-3 / 1600 / slots);
+                         w, R, Rn, H, n_hub_ranges, n_nat, slots, cost_pre[n_chunks] / 1e8, 100.0 - 100.0 * 1400.0 * n_chunks / std::max<uint64_t>(1, cost_pre[n_chunks]), share_pct, levels, n_tiles, n_multi,
+                         makespan() * 83e-3 / 1400, cost_pre[n_chunks] * 83e-3 / 1400 / slots);
         sc.n_tiles = n_tiles;
         sc.n_multi = n_multi;
         max_multi  = std::max(max_multi, n_multi);

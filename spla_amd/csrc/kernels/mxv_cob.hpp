@@ -20,11 +20,15 @@
 //     (written by its hub range); a natural range's rows are written in order, 16 bytes per lane where no hub row intervenes
 //
 // Layout (all built on the device, cob.hip):
-//   chunk  = 256 entry slots = one wave iteration (a 16-byte load of 4 slots per lane for each of the two streams); the word at memory
-//            position 4 l + j is the chunk's sorted entry 64 j + l, so the wave's j-th gather instruction covers 64 CONSECUTIVE sorted entries
-//            cr[slot] = slot_in_range << col_bits | column - base_col      ax[slot] = value bits      hdr[chunk] = base_col
-//            a padding slot carries a slot value >= R, one of the spare words behind the LDS slice (kCobSpare: one per lane) — no count, no predicate in the loop
-//            a chunk never straddles a (range, column window of 2^col_bits columns) group; only a group's last chunk is padded
+//   chunk  = 256 entry slots = one wave iteration; THREE packed streams, 7 bytes per slot (round 5; 8 until then): sl (16-bit slot in range), dl (8-bit column
+//            DELTA to the slot before it in sorted order; 0 for the chunk's first slot), ax (value word), and hdr[chunk] = column of the first slot.  The
+//            element at memory position 4 l + j of a stream is the chunk's sorted slot 64 j + l: a lane's loads (8 + 4 + 16 bytes) bring its four slots, and the
+//            wave's j-th gather instruction covers 64 CONSECUTIVE sorted slots.  cob_decode turns a lane's packed words into the four words
+//            slot << 16 | column - hdr[chunk] the loop works on (two wave scans over the deltas: a chunk's columns span < 2^16).
+//            a gap of more than 255 columns between two entries is bridged by padding slots (one per 255 columns), built into the copy; a padding / bridging
+//            slot carries a slot value >= R, one of the spare words behind the LDS slice (kCobSpare: one per lane), value 0, and gathers the chunk's base
+//            column — no count, no predicate in the loop
+//            a chunk never straddles a (range, column window of 2^16 columns) group; only a group's last chunk is padded
 //   piece  = consecutive chunks of ONE range = one workgroup's work: zero the LDS slice, walk the chunks (wave w takes chunks
 //            w, w + waves, ...), then either finish the rows (a range that is a single piece) or add the slice into the range's shared
 //            accumulator in global memory (memory-side atomics of op_add) and take a ticket: the piece that arrives last reads the
@@ -280,11 +284,41 @@ namespace splahip {
             return from_bits<T>(acc);
     }
 
+    // The packed streams of a chunk -> the four words slot << 16 | column - hdr[chunk] of a lane's slots (the form the loop below works on).
+    // A chunk stores 2 + 1 + 4 bytes per slot: a 16-bit slot in range, an 8-bit column DELTA to the slot before it in sorted order (the chunk's first slot: 0;
+    // a gap of more than 255 columns is bridged by padding slots when the copy is built) and the value word.  The lane's slots are the sorted slots l, 64 + l,
+    // 128 + l, 192 + l: their columns are the chunk's running sums — two wave-wide inclusive scans over pairs of 16-bit partial sums (a group of 64 deltas
+    // sums to < 2^14, the whole chunk to < 2^16) by DPP row shifts and broadcasts, plus the three group totals from lane 63.
+    __device__ __forceinline__ uint32_t cob_scan16x2(uint32_t x) {
+        x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x111, 0xF, 0xF, false);// row_shr:1
+        x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x112, 0xF, 0xF, false);// row_shr:2
+        x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x114, 0xF, 0xF, false);// row_shr:4
+        x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x118, 0xF, 0xF, false);// row_shr:8
+        x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x142, 0xA, 0xF, false);// row_bcast:15 into rows 1 and 3
+        x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x143, 0xC, 0xF, false);// row_bcast:31 into rows 2 and 3
+        return x;
+    }
+    typedef uint32_t cob_u4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t cob_u2 __attribute__((ext_vector_type(2)));
+    __device__ __forceinline__ cob_u4 cob_decode(cob_u2 s, uint32_t d) {
+        const uint32_t a = cob_scan16x2((d & 0xFFu) | ((d & 0xFF00u) << 8));          // running sums of the deltas of groups 0 | 1
+        const uint32_t b = cob_scan16x2(((d >> 16) & 0xFFu) | ((d >> 24) << 16));      //                                   2 | 3
+        const uint32_t ta = (uint32_t) __builtin_amdgcn_readlane((int) a, 63), tb = (uint32_t) __builtin_amdgcn_readlane((int) b, 63);
+        const uint32_t t0 = ta & 0xFFFFu, t01 = t0 + (ta >> 16), t012 = t01 + (tb & 0xFFFFu);
+        cob_u4         e;
+        e.x = (s.x << 16) | (a & 0xFFFFu);
+        e.y = (s.x & 0xFFFF0000u) | (t0 + (a >> 16));
+        e.z = (s.y << 16) | (t01 + (b & 0xFFFFu));
+        e.w = (s.y & 0xFFFF0000u) | (t012 + (b >> 16));
+        return e;
+    }
+
     struct CobArgs {
         const CobTile*  tiles;
         const CobRange* ranges;
         const uint32_t* hdr;// per chunk: first column of its window
-        const uint32_t* cr;
+        const uint16_t* sl;// per slot: slot in range, 16 bits
+        const uint8_t*  dl;// per slot: column delta to the slot before it in sorted order, 8 bits
         const uint32_t* ax;
         const uint16_t* slot16; // per row: its slot in its natural range, kCobSlotEmpty, or kCobSlotHub (padded to a multiple of 8 rows)
         const uint32_t* hub_row;// per hub slot: its row, 0xFFFFFFFF for the padding behind the last hub row
@@ -319,7 +353,9 @@ namespace splahip {
 #ifdef SPLAHIP_COB_MIN_WAVES
         return SPLAHIP_COB_MIN_WAVES;
 #else
-        return (MODE != 0 && sizeof(typename CobSlice<T, ACC>::word) == 4) ? 8u : 4u;
+        // (the bit forms were cut for 64 registers — two workgroups per CU — until round 5; with one workgroup per CU and the packed streams' decode they spill
+        // 27 words at that cut and the min-plus calls ran 14 - 28 % slower: every form now gets the budget of 4 waves per SIMD)
+        return 4u;
 #endif
     }
 
@@ -643,7 +679,8 @@ namespace splahip {
         const unsigned lane  = lane_id();
         const uint32_t cmask = (1u << a.col_bits) - 1u;
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        const u4*       cr4 = reinterpret_cast<const u4*>(a.cr) + lane;
+        const cob_u2*   sl2 = reinterpret_cast<const cob_u2*>(a.sl) + lane;// a lane's four 16-bit slots of a chunk
+        const uint32_t* dl1 = reinterpret_cast<const uint32_t*>(a.dl) + lane;// its four 8-bit column deltas
         const u4*       ax4 = reinterpret_cast<const u4*>(a.ax) + lane;
         const uint32_t* hb  = a.hdr;
         // Software pipeline, four register sets deep, no data-dependent exit: every wave runs the same number of steps (a multiple of 4);
@@ -661,36 +698,43 @@ namespace splahip {
         const uint32_t pad_chunk = a.pad_chunk + (nat ? 1u : 0u);
         auto           chunk_of = [&](uint32_t ci) { return ci < t.n_chunks ? t.first_chunk + ci : pad_chunk; };
         u4             E[4], X[4];
+        cob_u2         S[4];   // the packed slot words and column deltas of a step, as loaded: decoded into E by the step's first user (cob_decode)
+        uint32_t       D[4];
         uint32_t       B[4];
         T              G[2][4];
         u4             W[2];   // MODE 1 / 2: the gathered bitmap words of a step
         uint32_t       M[2];   //             and, once they are in, the step's four bits
         auto load_set = [&](int q, uint32_t ci) {
             const uint32_t k = chunk_of(ci);
-            E[q]             = __builtin_nontemporal_load(cr4 + (size_t) k * (kCobChunk / 4));
+            S[q]             = __builtin_nontemporal_load(sl2 + (size_t) k * (kCobChunk / 4));
+            D[q]             = __builtin_nontemporal_load(dl1 + (size_t) k * (kCobChunk / 4));
             if constexpr (MODE != 2) X[q] = __builtin_nontemporal_load(ax4 + (size_t) k * (kCobChunk / 4));
             B[q] = hb[k];
         };
+        // column offset of a decoded word; a padding / bridging slot (slot field >= R) reads the chunk's base column instead of a line of its own — the bridging
+        // slots of the column gaps sit at columns nothing else refers to: 1.9 M extra lines of v per call at R-MAT 23 when they gathered there
+        auto coff = [&](uint32_t w) -> uint32_t { return (w >> 16) >= R ? 0u : (w & cmask); };
         auto gather_set = [&](int q, int gq) {
+            if constexpr (MODE == 0) E[q] = cob_decode(S[q], D[q]);
 #if defined(SPLAHIP_COB_EXP) && (SPLAHIP_COB_EXP == 2 || SPLAHIP_COB_EXP == 4)
-            G[gq][0] = from_bits<T>(B[q] + (E[q].x & cmask)), G[gq][1] = from_bits<T>(B[q] + (E[q].y & cmask)), G[gq][2] = from_bits<T>(B[q] + (E[q].z & cmask)),
-            G[gq][3] = from_bits<T>(B[q] + (E[q].w & cmask));// DIAGNOSTIC BUILD: no gathers
+            G[gq][0] = from_bits<T>(B[q] + coff(E[q].x)), G[gq][1] = from_bits<T>(B[q] + coff(E[q].y)), G[gq][2] = from_bits<T>(B[q] + coff(E[q].z)),
+            G[gq][3] = from_bits<T>(B[q] + coff(E[q].w));// DIAGNOSTIC BUILD: no gathers
 #else
             if constexpr (MODE == 0) {
 #if defined(SPLAHIP_COB_EXP) && SPLAHIP_COB_EXP >= 16// DIAGNOSTIC BUILD: every gather folded into the first 2^EXP words of v (same lines per instruction, all cache-resident)
                 constexpr uint32_t wm = (1u << SPLAHIP_COB_EXP) - 1u;
-                G[gq][0] = v[(B[q] + (E[q].x & cmask)) & wm];
-                G[gq][1] = v[(B[q] + (E[q].y & cmask)) & wm];
-                G[gq][2] = v[(B[q] + (E[q].z & cmask)) & wm];
-                G[gq][3] = v[(B[q] + (E[q].w & cmask)) & wm];
+                G[gq][0] = v[(B[q] + coff(E[q].x)) & wm];
+                G[gq][1] = v[(B[q] + coff(E[q].y)) & wm];
+                G[gq][2] = v[(B[q] + coff(E[q].z)) & wm];
+                G[gq][3] = v[(B[q] + coff(E[q].w)) & wm];
 #else
-                G[gq][0] = v[B[q] + (E[q].x & cmask)];
-                G[gq][1] = v[B[q] + (E[q].y & cmask)];
-                G[gq][2] = v[B[q] + (E[q].z & cmask)];
-                G[gq][3] = v[B[q] + (E[q].w & cmask)];
+                G[gq][0] = v[B[q] + coff(E[q].x)];
+                G[gq][1] = v[B[q] + coff(E[q].y)];
+                G[gq][2] = v[B[q] + coff(E[q].z)];
+                G[gq][3] = v[B[q] + coff(E[q].w)];
 #endif
             } else {// the bits of this step arrived one step ago: extract them, then gather v only where a bit is set (every other lane re-reads v[base]: one line)
-                const uint32_t c0 = B[q] + (E[q].x & cmask), c1 = B[q] + (E[q].y & cmask), c2 = B[q] + (E[q].z & cmask), c3 = B[q] + (E[q].w & cmask);
+                const uint32_t c0 = B[q] + coff(E[q].x), c1 = B[q] + coff(E[q].y), c2 = B[q] + coff(E[q].z), c3 = B[q] + coff(E[q].w);
                 const uint32_t m  = ((W[gq].x >> (c0 & 31)) & 1u) | (((W[gq].y >> (c1 & 31)) & 1u) << 1) | (((W[gq].z >> (c2 & 31)) & 1u) << 2) | (((W[gq].w >> (c3 & 31)) & 1u) << 3);
                 M[gq]    = m;
                 G[gq][0] = v[(m & 1u) ? c0 : B[q]];
@@ -701,10 +745,11 @@ namespace splahip {
 #endif
         };
         auto bits_set = [&](int q, int wq) {// MODE 1 / 2: one bitmap word per slot (a padding slot reads the word of the base column)
-            W[wq].x = a.vbits[(B[q] + (E[q].x & cmask)) >> 5];
-            W[wq].y = a.vbits[(B[q] + (E[q].y & cmask)) >> 5];
-            W[wq].z = a.vbits[(B[q] + (E[q].z & cmask)) >> 5];
-            W[wq].w = a.vbits[(B[q] + (E[q].w & cmask)) >> 5];
+            E[q]    = cob_decode(S[q], D[q]);
+            W[wq].x = a.vbits[(B[q] + coff(E[q].x)) >> 5];
+            W[wq].y = a.vbits[(B[q] + coff(E[q].y)) >> 5];
+            W[wq].z = a.vbits[(B[q] + coff(E[q].z)) >> 5];
+            W[wq].w = a.vbits[(B[q] + coff(E[q].w)) >> 5];
         };
 #if defined(SPLAHIP_COB_EXP) && SPLAHIP_COB_EXP == 1
         T dbg = T(0);

@@ -187,7 +187,8 @@ namespace splahip {
         const unsigned  lane    = lane_id();
         const uint32_t  cmask   = (1u << a.col_bits) - 1u;
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        const u4*       cr4 = reinterpret_cast<const u4*>(a.cr) + lane;
+        const cob_u2*   sl2 = reinterpret_cast<const cob_u2*>(a.sl) + lane;
+        const uint32_t* dl1 = reinterpret_cast<const uint32_t*>(a.dl) + lane;
         const u4*       ax4 = reinterpret_cast<const u4*>(a.ax) + lane;
         const uint32_t* hb  = a.hdr;
         uint32_t        job = blockIdx.x;
@@ -275,23 +276,28 @@ namespace splahip {
             uint32_t base_cur = ring_read(0);
             [[maybe_unused]] uint32_t walked = 0;
             u4       E[4], X[4];
+            cob_u2   S[4];
+            uint32_t D[4];
             uint32_t B[4];
             T        G[2][4];
             u4       W[2];
             uint32_t M[2];
             auto load_set = [&](int qs, uint32_t k) {
-                E[qs] = __builtin_nontemporal_load(cr4 + (size_t) k * (kCobChunk / 4));
+                S[qs] = __builtin_nontemporal_load(sl2 + (size_t) k * (kCobChunk / 4));
+                D[qs] = __builtin_nontemporal_load(dl1 + (size_t) k * (kCobChunk / 4));
                 if constexpr (MODE != 2) X[qs] = __builtin_nontemporal_load(ax4 + (size_t) k * (kCobChunk / 4));
                 B[qs] = hb[k];
             };
+            auto coff = [&](uint32_t w) -> uint32_t { return (w >> 16) >= R ? 0u : (w & cmask); };// (a padding / bridging slot reads the chunk's base column)
             auto gather_set = [&](int qs, int gq) {
+                if constexpr (MODE == 0) E[qs] = cob_decode(S[qs], D[qs]);
                 if constexpr (MODE == 0) {
-                    G[gq][0] = v[B[qs] + (E[qs].x & cmask)];
-                    G[gq][1] = v[B[qs] + (E[qs].y & cmask)];
-                    G[gq][2] = v[B[qs] + (E[qs].z & cmask)];
-                    G[gq][3] = v[B[qs] + (E[qs].w & cmask)];
+                    G[gq][0] = v[B[qs] + coff(E[qs].x)];
+                    G[gq][1] = v[B[qs] + coff(E[qs].y)];
+                    G[gq][2] = v[B[qs] + coff(E[qs].z)];
+                    G[gq][3] = v[B[qs] + coff(E[qs].w)];
                 } else {
-                    const uint32_t c0 = B[qs] + (E[qs].x & cmask), c1 = B[qs] + (E[qs].y & cmask), c2 = B[qs] + (E[qs].z & cmask), c3 = B[qs] + (E[qs].w & cmask);
+                    const uint32_t c0 = B[qs] + coff(E[qs].x), c1 = B[qs] + coff(E[qs].y), c2 = B[qs] + coff(E[qs].z), c3 = B[qs] + coff(E[qs].w);
                     const uint32_t m  = ((W[gq].x >> (c0 & 31)) & 1u) | (((W[gq].y >> (c1 & 31)) & 1u) << 1) | (((W[gq].z >> (c2 & 31)) & 1u) << 2) | (((W[gq].w >> (c3 & 31)) & 1u) << 3);
                     M[gq]    = m;
                     G[gq][0] = v[(m & 1u) ? c0 : B[qs]];
@@ -301,10 +307,11 @@ namespace splahip {
                 }
             };
             auto bits_set = [&](int qs, int wq) {
-                W[wq].x = a.vbits[(B[qs] + (E[qs].x & cmask)) >> 5];
-                W[wq].y = a.vbits[(B[qs] + (E[qs].y & cmask)) >> 5];
-                W[wq].z = a.vbits[(B[qs] + (E[qs].z & cmask)) >> 5];
-                W[wq].w = a.vbits[(B[qs] + (E[qs].w & cmask)) >> 5];
+                E[qs]   = cob_decode(S[qs], D[qs]);
+                W[wq].x = a.vbits[(B[qs] + coff(E[qs].x)) >> 5];
+                W[wq].y = a.vbits[(B[qs] + coff(E[qs].y)) >> 5];
+                W[wq].z = a.vbits[(B[qs] + coff(E[qs].z)) >> 5];
+                W[wq].w = a.vbits[(B[qs] + coff(E[qs].w)) >> 5];
             };
             auto add_set = [&](int qs, int gq) {
                 const u4 e = E[qs];

@@ -73,7 +73,7 @@ struct splahip_cob_s {
     uint32_t  hub_finish  = 0;// who finishes the hub ranges' rows: 0 the range's last piece, 1 a kernel of its own behind the main launch (SPLAHIP_COB_HUB_FINISH)
     uint32_t  ticket_words = 0;// words of d_ticket: arrival counters, then the finishers' counters
     bool      half_groups = false;// two double slices fit a CU's LDS: the fp32 PLUS forms run 8-wave workgroups, two per CU
-    uint32_t  col_bits = 0;// a chunk's columns are stored relative to its 2^col_bits-column window
+    uint32_t  col_bits = 0;// a chunk never straddles a window of 2^col_bits columns (so its columns span < 2^16: the decoded word is slot << 16 | column - hdr)
     uint32_t  n_chunks = 0;// 256-slot chunks
     uint32_t  n_ranges = 0;// hub ranges first, then the natural ranges in row order
     uint32_t  n_hub_ranges = 0;
@@ -82,8 +82,9 @@ struct splahip_cob_s {
     // [0]: 4-byte slice words (int / uint, LOR / LAND, fp32 MIN / MAX keys), [1]: 8-byte slice words (fp32 PLUS); they differ in the workgroups a CU
     // can hold.  n_tiles == 0: this slice width does not fit the LDS at this R
     splahip_cob_sched_s sched[2];
-    uint32_t* d_hdr    = nullptr;// n_chunks: first column of the chunk's window
-    uint32_t* d_cr     = nullptr;// n_chunks x 256: slot in range << col_bits | column - window base
+    uint32_t* d_hdr    = nullptr;// n_chunks: column of the chunk's first slot
+    uint16_t* d_sl     = nullptr;// n_chunks x 256: slot in range (padding / bridging slots: R + lane)
+    uint8_t*  d_dl     = nullptr;// n_chunks x 256: column delta to the slot before it in sorted order (0 for a chunk's first slot)
     uint32_t* d_ax     = nullptr;// n_chunks x 256 value words
     uint16_t* d_slot16 = nullptr;// n_rows (padded to 8): slot of the row in its natural range, 0xFFFF no entry, 0xFFFE hub row
     uint32_t* d_hub_row = nullptr;// n_hub_ranges x R: row of a hub slot, 0xFFFFFFFF padding
