@@ -711,30 +711,35 @@ namespace splahip {
             if constexpr (MODE != 2) X[q] = __builtin_nontemporal_load(ax4 + (size_t) k * (kCobChunk / 4));
             B[q] = hb[k];
         };
-        // column offset of a decoded word; a padding / bridging slot (slot field >= R) reads the chunk's base column instead of a line of its own — the bridging
+        // a step's packed words -> E; a padding / bridging slot (slot field >= R) gets column offset 0: it reads the chunk's base column instead of a line of its own — the bridging
         // slots of the column gaps sit at columns nothing else refers to: 1.9 M extra lines of v per call at R-MAT 23 when they gathered there
-        auto coff = [&](uint32_t w) -> uint32_t { return (w >> 16) >= R ? 0u : (w & cmask); };
+        auto decode_set = [&](int q) {
+            cob_u4 e = cob_decode(S[q], D[q]);
+            e.x = (e.x >> 16) >= R ? e.x & 0xFFFF0000u : e.x, e.y = (e.y >> 16) >= R ? e.y & 0xFFFF0000u : e.y;
+            e.z = (e.z >> 16) >= R ? e.z & 0xFFFF0000u : e.z, e.w = (e.w >> 16) >= R ? e.w & 0xFFFF0000u : e.w;
+            E[q] = e;
+        };
         auto gather_set = [&](int q, int gq) {
-            if constexpr (MODE == 0) E[q] = cob_decode(S[q], D[q]);
+            if constexpr (MODE == 0) decode_set(q);
 #if defined(SPLAHIP_COB_EXP) && (SPLAHIP_COB_EXP == 2 || SPLAHIP_COB_EXP == 4)
-            G[gq][0] = from_bits<T>(B[q] + coff(E[q].x)), G[gq][1] = from_bits<T>(B[q] + coff(E[q].y)), G[gq][2] = from_bits<T>(B[q] + coff(E[q].z)),
-            G[gq][3] = from_bits<T>(B[q] + coff(E[q].w));// DIAGNOSTIC BUILD: no gathers
+            G[gq][0] = from_bits<T>(B[q] + (E[q].x & cmask)), G[gq][1] = from_bits<T>(B[q] + (E[q].y & cmask)), G[gq][2] = from_bits<T>(B[q] + (E[q].z & cmask)),
+            G[gq][3] = from_bits<T>(B[q] + (E[q].w & cmask));// DIAGNOSTIC BUILD: no gathers
 #else
             if constexpr (MODE == 0) {
 #if defined(SPLAHIP_COB_EXP) && SPLAHIP_COB_EXP >= 16// DIAGNOSTIC BUILD: every gather folded into the first 2^EXP words of v (same lines per instruction, all cache-resident)
                 constexpr uint32_t wm = (1u << SPLAHIP_COB_EXP) - 1u;
-                G[gq][0] = v[(B[q] + coff(E[q].x)) & wm];
-                G[gq][1] = v[(B[q] + coff(E[q].y)) & wm];
-                G[gq][2] = v[(B[q] + coff(E[q].z)) & wm];
-                G[gq][3] = v[(B[q] + coff(E[q].w)) & wm];
+                G[gq][0] = v[(B[q] + (E[q].x & cmask)) & wm];
+                G[gq][1] = v[(B[q] + (E[q].y & cmask)) & wm];
+                G[gq][2] = v[(B[q] + (E[q].z & cmask)) & wm];
+                G[gq][3] = v[(B[q] + (E[q].w & cmask)) & wm];
 #else
-                G[gq][0] = v[B[q] + coff(E[q].x)];
-                G[gq][1] = v[B[q] + coff(E[q].y)];
-                G[gq][2] = v[B[q] + coff(E[q].z)];
-                G[gq][3] = v[B[q] + coff(E[q].w)];
+                G[gq][0] = v[B[q] + (E[q].x & cmask)];
+                G[gq][1] = v[B[q] + (E[q].y & cmask)];
+                G[gq][2] = v[B[q] + (E[q].z & cmask)];
+                G[gq][3] = v[B[q] + (E[q].w & cmask)];
 #endif
             } else {// the bits of this step arrived one step ago: extract them, then gather v only where a bit is set (every other lane re-reads v[base]: one line)
-                const uint32_t c0 = B[q] + coff(E[q].x), c1 = B[q] + coff(E[q].y), c2 = B[q] + coff(E[q].z), c3 = B[q] + coff(E[q].w);
+                const uint32_t c0 = B[q] + (E[q].x & cmask), c1 = B[q] + (E[q].y & cmask), c2 = B[q] + (E[q].z & cmask), c3 = B[q] + (E[q].w & cmask);
                 const uint32_t m  = ((W[gq].x >> (c0 & 31)) & 1u) | (((W[gq].y >> (c1 & 31)) & 1u) << 1) | (((W[gq].z >> (c2 & 31)) & 1u) << 2) | (((W[gq].w >> (c3 & 31)) & 1u) << 3);
                 M[gq]    = m;
                 G[gq][0] = v[(m & 1u) ? c0 : B[q]];
@@ -745,11 +750,11 @@ namespace splahip {
 #endif
         };
         auto bits_set = [&](int q, int wq) {// MODE 1 / 2: one bitmap word per slot (a padding slot reads the word of the base column)
-            E[q]    = cob_decode(S[q], D[q]);
-            W[wq].x = a.vbits[(B[q] + coff(E[q].x)) >> 5];
-            W[wq].y = a.vbits[(B[q] + coff(E[q].y)) >> 5];
-            W[wq].z = a.vbits[(B[q] + coff(E[q].z)) >> 5];
-            W[wq].w = a.vbits[(B[q] + coff(E[q].w)) >> 5];
+            decode_set(q);
+            W[wq].x = a.vbits[(B[q] + (E[q].x & cmask)) >> 5];
+            W[wq].y = a.vbits[(B[q] + (E[q].y & cmask)) >> 5];
+            W[wq].z = a.vbits[(B[q] + (E[q].z & cmask)) >> 5];
+            W[wq].w = a.vbits[(B[q] + (E[q].w & cmask)) >> 5];
         };
 #if defined(SPLAHIP_COB_EXP) && SPLAHIP_COB_EXP == 1
         T dbg = T(0);

@@ -288,16 +288,21 @@ namespace splahip {
                 if constexpr (MODE != 2) X[qs] = __builtin_nontemporal_load(ax4 + (size_t) k * (kCobChunk / 4));
                 B[qs] = hb[k];
             };
-            auto coff = [&](uint32_t w) -> uint32_t { return (w >> 16) >= R ? 0u : (w & cmask); };// (a padding / bridging slot reads the chunk's base column)
+            auto decode_set = [&](int qs) {// (a padding / bridging slot reads the chunk's base column: column offset 0)
+                cob_u4 e = cob_decode(S[qs], D[qs]);
+                e.x = (e.x >> 16) >= R ? e.x & 0xFFFF0000u : e.x, e.y = (e.y >> 16) >= R ? e.y & 0xFFFF0000u : e.y;
+                e.z = (e.z >> 16) >= R ? e.z & 0xFFFF0000u : e.z, e.w = (e.w >> 16) >= R ? e.w & 0xFFFF0000u : e.w;
+                E[qs] = e;
+            };
             auto gather_set = [&](int qs, int gq) {
-                if constexpr (MODE == 0) E[qs] = cob_decode(S[qs], D[qs]);
+                if constexpr (MODE == 0) decode_set(qs);
                 if constexpr (MODE == 0) {
-                    G[gq][0] = v[B[qs] + coff(E[qs].x)];
-                    G[gq][1] = v[B[qs] + coff(E[qs].y)];
-                    G[gq][2] = v[B[qs] + coff(E[qs].z)];
-                    G[gq][3] = v[B[qs] + coff(E[qs].w)];
+                    G[gq][0] = v[B[qs] + (E[qs].x & cmask)];
+                    G[gq][1] = v[B[qs] + (E[qs].y & cmask)];
+                    G[gq][2] = v[B[qs] + (E[qs].z & cmask)];
+                    G[gq][3] = v[B[qs] + (E[qs].w & cmask)];
                 } else {
-                    const uint32_t c0 = B[qs] + coff(E[qs].x), c1 = B[qs] + coff(E[qs].y), c2 = B[qs] + coff(E[qs].z), c3 = B[qs] + coff(E[qs].w);
+                    const uint32_t c0 = B[qs] + (E[qs].x & cmask), c1 = B[qs] + (E[qs].y & cmask), c2 = B[qs] + (E[qs].z & cmask), c3 = B[qs] + (E[qs].w & cmask);
                     const uint32_t m  = ((W[gq].x >> (c0 & 31)) & 1u) | (((W[gq].y >> (c1 & 31)) & 1u) << 1) | (((W[gq].z >> (c2 & 31)) & 1u) << 2) | (((W[gq].w >> (c3 & 31)) & 1u) << 3);
                     M[gq]    = m;
                     G[gq][0] = v[(m & 1u) ? c0 : B[qs]];
@@ -307,11 +312,11 @@ namespace splahip {
                 }
             };
             auto bits_set = [&](int qs, int wq) {
-                E[qs]   = cob_decode(S[qs], D[qs]);
-                W[wq].x = a.vbits[(B[qs] + coff(E[qs].x)) >> 5];
-                W[wq].y = a.vbits[(B[qs] + coff(E[qs].y)) >> 5];
-                W[wq].z = a.vbits[(B[qs] + coff(E[qs].z)) >> 5];
-                W[wq].w = a.vbits[(B[qs] + coff(E[qs].w)) >> 5];
+                decode_set(qs);
+                W[wq].x = a.vbits[(B[qs] + (E[qs].x & cmask)) >> 5];
+                W[wq].y = a.vbits[(B[qs] + (E[qs].y & cmask)) >> 5];
+                W[wq].z = a.vbits[(B[qs] + (E[qs].z & cmask)) >> 5];
+                W[wq].w = a.vbits[(B[qs] + (E[qs].w & cmask)) >> 5];
             };
             auto add_set = [&](int qs, int gq) {
                 const u4 e = E[qs];
