@@ -422,7 +422,9 @@ def bfs_step_line(args, rank, world):
 
     # HBM-side traffic of the same kernel from the rocprofv3 PMC passes (tools/gpu_round.sh -> tools/pmc_traffic.py):
     # collected by a separate profiler run of this command, so it is read from profiles/ when it matches this workload
-    tf = ROOT / "profiles" / "r04_pmc_traffic.json"
+    tf = ROOT / "profiles" / "r05_pmc_traffic.json"
+    if not tf.exists():
+        tf = ROOT / "profiles" / "r04_pmc_traffic.json"
     if not tf.exists():
         tf = ROOT / "profiles" / "pmc_traffic.json"  # (round 2's pass)
     if world == 1 and tf.exists():

@@ -163,7 +163,9 @@ def cpu_reference_sample(t, Ap, Aj, Ax, mask, v, r, mul, add, sel, init, sample_
 
 def pmc_traffic(key):
     """per-call fabric traffic of this workload from the committed counter pass (separate rocprofv3 --pmc runs; profiles/r03_pmc_<key>.json)"""
-    f = ROOT / "profiles" / f"r04_pmc_{key}.json"
+    f = ROOT / "profiles" / f"r05_pmc_{key}.json"
+    if not f.exists():
+        f = ROOT / "profiles" / f"r04_pmc_{key}.json"
     if not f.exists():  # (the kernels of this call did not change since round 3's pass)
         f = ROOT / "profiles" / f"r03_pmc_{key}.json"
     try:

@@ -63,7 +63,9 @@ def _roof(alg_bytes, ms, kernel, pmc=None):
     if pmc:
         import json
         from pathlib import Path
-        f = Path(__file__).resolve().parent / "profiles" / f"r04_pmc_{pmc}.json"
+        f = Path(__file__).resolve().parent / "profiles" / f"r05_pmc_{pmc}.json"
+        if not f.exists():
+            f = Path(__file__).resolve().parent / "profiles" / f"r04_pmc_{pmc}.json"
         if not f.exists():
             f = Path(__file__).resolve().parent / "profiles" / f"r03_pmc_{pmc}.json"
         if not f.exists():  # (a workload whose kernels did not change since round 2 keeps that round's pass; the file name is printed as traffic_source)
