@@ -54,7 +54,7 @@ namespace {
         return lo;
     }
 
-    constexpr uint32_t kSlotBits = 15;// slot field of a sort key and of a cr word: R <= 2^15 - 1 (the value R itself marks a padding slot)
+    constexpr uint32_t kSlotBits = 16;// slot field of a sort key, of the row map and of the slot stream: slots (and the 64 padding values R .. R + 63) below 0xFFFE
 
     __global__ __launch_bounds__(256) void cob_deg_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, uint32_t* __restrict__ deg, uint32_t* __restrict__ row_id) {
         const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -593,7 +593,7 @@ namespace {
             a.ranges        = reinterpret_cast<const CobRange*>(g->d_dyn_ranges);
             d.min_cost_hub   = g->dyn_min_hub;
             d.min_cost_nat   = g->dyn_min_nat;
-            COB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_dyn_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            COB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&cob_dyn_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 128));
             hipLaunchKernelGGL((cob_dyn_kernel<T, Mult, DynBin, ACC, VXM, kTpb, MODE>), dim3(sc.slots), dim3(kTpb), sc.lds_bytes, st, a, d, static_cast<const T*>(v),
                                static_cast<const T*>(mask), static_cast<T*>(r), Mult(op_mult), DynBin(op_add), op_select, init);
             COB_TRY(hipGetLastError());
@@ -814,7 +814,8 @@ namespace {
     // library default for the natural ranges' slot count (see splahip_csr_plan_attach_cob)
     uint32_t nat_slots_default(uint32_t R, bool explicit_bits) {
         if (explicit_bits || R != 20224u) return R;// a caller that sets the geometry gets one size
-        return 32704u;// (the library's own geometry: as large as a 4-byte slice can be, where the attach finds that it pays — see there)
+        return 32704u;// (the library's own geometry, where the attach finds that it pays — see there.  The slot field allows up to 40832 = 160 KB of float words
+                      // (SPLAHIP_COB_NAT_SLOTS); measured no better: R-MAT 23 278 against 271 us, R-MAT 24 611 against 609)
     }
 }// namespace
 
@@ -843,7 +844,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     const bool nat_auto = knob_env("SPLAHIP_COB_NAT_SLOTS") == nullptr;// the size is the library's proposal: the attach may take it back (below)
     uint32_t   Rn       = env_u32("SPLAHIP_COB_NAT_SLOTS", nat_slots_default(R, row_bits != 0));
     if (Rn < R) Rn = R;
-    SPLAHIP_REQUIRE(Rn % 64 == 0 && Rn <= 32704, "natural slots per range must be a multiple of 64, at most 32704");
+    SPLAHIP_REQUIRE(Rn % 64 == 0 && Rn <= 40832, "natural slots per range must be a multiple of 64, at most 40832");
     if (tile_chunks == 0) tile_chunks = env_u32("SPLAHIP_COB_TILE_CHUNKS", 0);// 0: pieces are cut at range and share boundaries only
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
@@ -851,7 +852,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     const uint32_t n_rows = plan->n_rows, nnz = plan->nnz;
     const uint32_t n_rows8 = (n_rows + 7) & ~7u;
 
-    const uint32_t col_bits = 31 - kSlotBits;                            // a cr word: slot field (15 bits used; the values R .. R + 63 mark padding) above 16 column bits
+    const uint32_t col_bits = 16;                                        // a chunk never straddles a window of 2^16 columns: its decoded words are slot << 16 | column offset
 
     // (SPLAHIP_COB_TRACE: wall time of the attach's phases on stderr; each stamp synchronises the stream)
     const bool trace_phases = knob_env("SPLAHIP_COB_TRACE") != nullptr;
@@ -1102,7 +1103,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
     const uint64_t n_groups64 = (uint64_t) n_ranges << win_bits;
     // every (range, window) group pads its last chunk: with more groups than nnz / 512 the copy would be mostly padding (a hypersparse
     // matrix) — the CSR kernels keep such a matrix
-    if (n_groups64 > (uint64_t) nnz / 512 + 64 || n_groups64 >= (1u << 30) || n_ranges >= (1u << 17)) {
+    if (n_groups64 > (uint64_t) nnz / 512 + 64 || n_groups64 >= (1u << 30) || n_ranges >= (1u << 16)) {
         cob_release(g);
         return SPLAHIP_OK;
     }
