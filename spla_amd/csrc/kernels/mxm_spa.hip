@@ -26,12 +26,14 @@
 #include "mxv_cob.hpp"
 #include "ops.hpp"
 
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include <unordered_map>
 #include <vector>
@@ -241,24 +243,41 @@ namespace splahip {
                         const bool any_long = __syncthreads_or(is_long ? 1 : 0) != 0;
                         block_products |= total | (any_long ? 1u : 0u);
                         SPA_T(tp1)
-                        for (uint32_t p = tid; p < total; p += kTpb) {
-                            SPA_WD(4, p, total)
-                            uint32_t lo = 0, hi = nk;// largest t with s_pref[t] <= p
-                            while (hi - lo > 1) {
-                                const uint32_t mid = (lo + hi) >> 1;
-                                if (s_pref[mid] <= p) lo = mid;
+                        // four products per thread in flight: the searches and the column / value loads of four products first (indices clamped, so the loads
+                        // stand outside every branch and the compiler waits once), then their LDS atomics.  One product per turn was one global round trip per
+                        // turn: a block step of ~4.5 K products walked in five dependent round trips (round 5: 28.9 ms of a 57 ms call at R-MAT 18)
+                        for (uint32_t p0 = tid; p0 < total; p0 += 4u * kTpb) {
+                            SPA_WD(4, p0, total)
+                            uint32_t lo4[4], col4[4], x4[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const uint32_t p = min(p0 + (uint32_t) u * kTpb, total - 1u);
+                                uint32_t       lo = 0, hi = nk;// largest t with s_pref[t] <= p
+                                while (hi - lo > 1) {
+                                    const uint32_t mid = (lo + hi) >> 1;
+                                    if (s_pref[mid] <= p) lo = mid;
+                                    else
+                                        hi = mid;
+                                }
+                                const uint32_t idx = s_seg[lo] + (p - s_pref[lo]);
+                                lo4[u]  = lo;
+                                col4[u] = a.Bj[idx];
+                                if constexpr (NUMERIC) x4[u] = a.Bx[idx];
                                 else
-                                    hi = mid;
+                                    x4[u] = 0;
                             }
-                            const uint32_t idx = s_seg[lo] + (p - s_pref[lo]);
-                            const uint32_t col = a.Bj[idx] - c0;
-                            if (dense_rows && (s_len[lo] >> 31) && col + c0 - a.d_j0 < a.d_hj) continue;// (in the dense tile)
-                            (void) __hip_atomic_fetch_or(s_bits + (col >> 5), 1u << (col & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if constexpr (NUMERIC) {
-                                const T prod = mult(from_bits<T>(s_av[lo]), from_bits<T>(a.Bx[idx]));
-                                if constexpr (sizeof(word) == 8) (void) __hip_atomic_fetch_add(s_acc + col, (double) prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                else
-                                    cob_accumulate<T, ACC>(s_acc + col, prod);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if (p0 + (uint32_t) u * kTpb >= total) break;
+                                const uint32_t lo = lo4[u], col = col4[u] - c0;
+                                if (dense_rows && (s_len[lo] >> 31) && col + c0 - a.d_j0 < a.d_hj) continue;// (in the dense tile)
+                                (void) __hip_atomic_fetch_or(s_bits + (col >> 5), 1u << (col & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if constexpr (NUMERIC) {
+                                    const T prod = mult(from_bits<T>(s_av[lo]), from_bits<T>(x4[u]));
+                                    if constexpr (sizeof(word) == 8) (void) __hip_atomic_fetch_add(s_acc + col, (double) prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    else
+                                        cob_accumulate<T, ACC>(s_acc + col, prod);
+                                }
                             }
                         }
                         if (any_long) {
@@ -269,26 +288,29 @@ namespace splahip {
                                 const uint32_t b0 = s_seg[t];
                                 T              av = T();
                                 if constexpr (NUMERIC) av = from_bits<T>(s_av[t]);
-                                for (uint32_t p = tid & 63u; p < n; p += 128u) {// two steps of 64 in flight per lane
-                                    const uint32_t p1 = p + 64u;
-                                    const uint32_t col0 = a.Bj[b0 + p] - c0, col1 = p1 < n ? a.Bj[b0 + p1] - c0 : 0u;
-                                    uint32_t       x0 = 0, x1 = 0;
-                                    if constexpr (NUMERIC) {
-                                        x0 = a.Bx[b0 + p];
-                                        if (p1 < n) x1 = a.Bx[b0 + p1];
+                                for (uint32_t p = tid & 63u; p < n; p += 256u) {// four steps of 64 in flight per lane (clamped loads, as above)
+                                    uint32_t col4[4], x4[4];
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) {
+                                        const uint32_t pp = min(p + 64u * (uint32_t) u, n - 1u);
+                                        col4[u]           = a.Bj[b0 + pp];
+                                        if constexpr (NUMERIC) x4[u] = a.Bx[b0 + pp];
+                                        else
+                                            x4[u] = 0;
                                     }
-                                    auto put = [&](uint32_t col, uint32_t xw) {
-                                        if (win && col + c0 - a.d_j0 < a.d_hj) return;// (in the dense tile)
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) {
+                                        if (p + 64u * (uint32_t) u >= n) break;
+                                        const uint32_t col = col4[u] - c0;
+                                        if (win && col + c0 - a.d_j0 < a.d_hj) continue;// (in the dense tile)
                                         (void) __hip_atomic_fetch_or(s_bits + (col >> 5), 1u << (col & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                         if constexpr (NUMERIC) {
-                                            const T prod = mult(av, from_bits<T>(xw));
+                                            const T prod = mult(av, from_bits<T>(x4[u]));
                                             if constexpr (sizeof(word) == 8) (void) __hip_atomic_fetch_add(s_acc + col, (double) prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                             else
                                                 cob_accumulate<T, ACC>(s_acc + col, prod);
                                         }
-                                    };
-                                    put(col0, x0);
-                                    if (p1 < n) put(col1, x1);
+                                    }
                                 }
                             }
                         }
@@ -754,21 +776,90 @@ namespace splahip {
             return e && *e ? (uint32_t) std::strtoul(e, nullptr, 10) : dflt;
         }
 
+        // scratch memory of a call, STREAM-ORDERED (hipMallocAsync / hipFreeAsync from the device's pool: ~25 buffers per call; hipMalloc / hipFree took a driver round
+        // trip each and the frees synchronised the device)
         struct Scratch {
+            hipStream_t        s = nullptr;
             std::vector<void*> ptrs;
+            explicit Scratch(hipStream_t stream) : s(stream) {}
+            Scratch(const Scratch&)            = delete;
+            Scratch& operator=(const Scratch&) = delete;
             ~Scratch() {
                 for (void* p : ptrs)
-                    if (p) (void) hipFree(p);
+                    if (p) (void) hipFreeAsync(p, s);
             }
             template<typename U>
             hipError_t alloc(U** out, size_t count) {
                 void*      p = nullptr;
-                hipError_t e = device_malloc(&p, sizeof(U) * (count ? count : 1));
+                hipError_t e = device_malloc_async(&p, sizeof(U) * (count ? count : 1), s);
                 if (e == hipSuccess) ptrs.push_back(p);
                 *out = static_cast<U*>(p);
                 return e;
             }
         };
+
+        // PINNED host memory for the few MB a call moves between host and device (row products and counts down, batch / item lists and row pointers up): a bump
+        // allocator per host thread, reset at the start of a call and kept for the life of the process (like runtime.hip's mailbox).  A copy from or to pageable
+        // memory is staged by the runtime and blocks the host: ~0.15 ms per small copy, 0.7 ms per MB (round-5 trace: 14 ms of a 54 ms call with the GPU idle)
+        struct PinnedArena {
+            struct Chunk {
+                unsigned char* p;
+                size_t         cap, used;
+            };
+            std::vector<Chunk> chunks;
+            void reset() {
+                for (Chunk& c : chunks) c.used = 0;
+            }
+            void* take(size_t bytes) {
+                bytes = (bytes + 255) & ~size_t(255);
+                for (Chunk& c : chunks)
+                    if (c.cap - c.used >= bytes) {
+                        void* r = c.p + c.used;
+                        c.used += bytes;
+                        return r;
+                    }
+                const size_t cap = std::max(bytes, size_t(8) << 20);
+                void*        p   = nullptr;
+                if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
+                    (void) hipGetLastError();
+                    return nullptr;
+                }
+                chunks.push_back({static_cast<unsigned char*>(p), cap, bytes});
+                return p;
+            }
+        };
+        PinnedArena& arena() {
+            static thread_local PinnedArena* a = new PinnedArena;
+            return *a;
+        }
+        // host -> device through the arena (the source may go out of scope at once); device -> host INTO the arena (valid after the next synchronisation of s,
+        // until the thread's next mxm call)
+        hipError_t h2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
+            if (bytes == 0) return hipSuccess;
+            void* st = arena().take(bytes);
+            if (!st) {
+                const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+                return e != hipSuccess ? e : hipStreamSynchronize(s);
+            }
+            std::memcpy(st, src, bytes);
+            return hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, s);
+        }
+        template<typename U>
+        hipError_t d2h(U** host, const U* src, size_t count, hipStream_t s) {
+            U* st = static_cast<U*>(arena().take(sizeof(U) * std::max<size_t>(1, count)));
+            *host = st;
+            if (!st) return hipErrorOutOfMemory;
+            return count ? hipMemcpyAsync(st, src, sizeof(U) * count, hipMemcpyDeviceToHost, s) : hipSuccess;
+        }
+        // SPLAHIP_MXM_HOSTTRACE=1: HOST time between the marks of a call, no synchronisation (what the host does while the GPU waits; diagnostic)
+        void host_mark(const char* what) {
+            static const bool on = knob_env("SPLAHIP_MXM_HOSTTRACE") != nullptr;
+            if (!on) return;
+            static thread_local auto t0 = std::chrono::steady_clock::now();
+            const auto               t1 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[mxm-host] %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+            t0 = t1;
+        }
 
         hipError_t scan_u32(uint32_t* in, uint32_t* out, size_t n, Scratch& tmp, hipStream_t s) {
             size_t     bytes = 0;
@@ -792,25 +883,24 @@ namespace splahip {
 
         template<typename T, class Mult, int ACC>
         int spa_run(uint32_t a_rows, uint32_t b_cols, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const uint32_t* Bp, const uint32_t* Bj, const void* Bx, uint32_t* Rp,
-                    uint32_t** Rj, void** Rx, uint32_t* h_nnz, const std::vector<u64>& hP, const u64* dP, const std::vector<uint32_t>& hAp, int op_mult, int op_add,
+                    uint32_t** Rj, void** Rx, uint32_t* h_nnz, const u64* hP, const u64* dP, const uint32_t* hAp, const uint32_t* h_order, int op_mult, int op_add,
                     uint32_t init_bits, uint32_t b_rows_hint, hipStream_t s) {
             using word      = typename CobSlice<T, ACC>::word;
             constexpr int t = TypeId<T>::value;
-            Scratch       tmp;
+            Scratch       tmp(s);
             hipError_t    e = hipSuccess;
             spa_trace("start", s);
-            // heavy rows, largest first
+            host_mark("call start");
+            // heavy rows, largest first: the front of h_order (rows by descending product count, sorted on the device)
             std::vector<uint32_t> heavy;
-            bool                  any_light = false;
-            uint32_t              max_deg   = 1;
-            for (uint32_t i = 0; i < a_rows; ++i) {
-                if (hP[i] > kLight) {
-                    heavy.push_back(i);
-                    max_deg = std::max(max_deg, hAp[i + 1] - hAp[i]);
-                } else if (hP[i] > 0)
-                    any_light = true;
+            uint32_t              max_deg = 1;
+            for (uint32_t k = 0; k < a_rows && hP[h_order[k]] > kLight; ++k) {
+                const uint32_t i = h_order[k];
+                heavy.push_back(i);
+                max_deg = std::max(max_deg, hAp[i + 1] - hAp[i]);
             }
-            std::stable_sort(heavy.begin(), heavy.end(), [&](uint32_t x, uint32_t y) { return hP[x] > hP[y]; });
+            const bool any_light = heavy.size() < a_rows && hP[h_order[heavy.size()]] > 0;
+            // (the work items are listed further down, while the light rows' kernel runs)
 
             // ---- light rows: expand - sort - compress inside a workgroup's LDS (light_batch_kernel); SPLAHIP_MXM_LIGHT_LDS=0: the global ESC form -------
             uint32_t *Lrj = nullptr, *Lrx = nullptr, l_nnz = 0;// (the ESC form's result arrays, when it ran)
@@ -833,6 +923,7 @@ namespace splahip {
                 // batches of consecutive light rows: at most kBatchCap products and kBatchRows rows each
                 std::vector<uint32_t> lrows, eoff(1, 0u), bfirst(1, 0u);
                 std::vector<u64>      poff(1, 0ull);
+                lrows.reserve(a_rows), eoff.reserve((size_t) a_rows + 1);
                 u64                   in_batch = 0;
                 for (uint32_t i = 0; i < a_rows; ++i) {
                     if (hP[i] == 0 || hP[i] > kLight) continue;
@@ -848,6 +939,7 @@ namespace splahip {
                 bfirst.push_back((uint32_t) lrows.size());
                 poff.push_back(poff.back() + in_batch);
                 const uint32_t n_batches = (uint32_t) bfirst.size() - 1;
+                host_mark("light batches listed");
                 uint32_t *d_lrows = nullptr, *d_eoff = nullptr, *d_bfirst = nullptr;
                 u64*      d_poff = nullptr;
                 e = tmp.alloc(&d_lrows, lrows.size());
@@ -858,15 +950,14 @@ namespace splahip {
                 if (e == hipSuccess) e = handoff_alloc(reinterpret_cast<void**>(&Sj), sizeof(uint32_t) * (size_t) std::max<u64>(1, poff.back()));
                 if (e == hipSuccess) stage_j = Sj, e = handoff_alloc(reinterpret_cast<void**>(&Sx), sizeof(uint32_t) * (size_t) std::max<u64>(1, poff.back()));
                 if (e == hipSuccess) stage_x = Sx;
-                if (e == hipSuccess) e = hipMemcpyAsync(d_lrows, lrows.data(), 4 * lrows.size(), hipMemcpyHostToDevice, s);
-                if (e == hipSuccess) e = hipMemcpyAsync(d_eoff, eoff.data(), 4 * eoff.size(), hipMemcpyHostToDevice, s);
-                if (e == hipSuccess) e = hipMemcpyAsync(d_bfirst, bfirst.data(), 4 * bfirst.size(), hipMemcpyHostToDevice, s);
-                if (e == hipSuccess) e = hipMemcpyAsync(d_poff, poff.data(), 8 * poff.size(), hipMemcpyHostToDevice, s);
+                if (e == hipSuccess) e = h2d(d_lrows, lrows.data(), 4 * lrows.size(), s);
+                if (e == hipSuccess) e = h2d(d_eoff, eoff.data(), 4 * eoff.size(), s);
+                if (e == hipSuccess) e = h2d(d_bfirst, bfirst.data(), 4 * bfirst.size(), s);
+                if (e == hipSuccess) e = h2d(d_poff, poff.data(), 8 * poff.size(), s);
                 if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm (light rows): %s", hipGetErrorString(e));
                 hipLaunchKernelGGL((light_batch_kernel<T, Mult, DynBin>), dim3(n_batches), dim3(kBatchTpb), 0, s, d_bfirst, d_lrows, d_eoff, d_poff, Ap, Aj, static_cast<const T*>(Ax), Bp, Bj,
                                    static_cast<const T*>(Bx), Sj, reinterpret_cast<T*>(Sx), d_lstart_lo, d_lstart_hi, d_lcnt, Mult(op_mult), DynBin(op_add), from_bits<T>(init_bits));
-                e = hipGetLastError();
-                if (e == hipSuccess) e = hipStreamSynchronize(s);// (the host vectors go out of scope)
+                e = hipGetLastError();// (no synchronisation: the lists went up through the pinned arena, and the host has the heavy rows to sort meanwhile)
                 if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm (light rows): %s", hipGetErrorString(e));
             } else if (any_light) {
                 uint32_t *len = nullptr, *Lp = nullptr, *Lj = nullptr, *Lx = nullptr, *Lrp = nullptr;
@@ -894,6 +985,7 @@ namespace splahip {
                 Sj = Lrj, Sx = Lrx;
                 hipLaunchKernelGGL(light_from_rowptr_kernel, dim3((a_rows + 255) / 256), dim3(256), 0, s, a_rows, Lrp, d_lstart_lo, d_lstart_hi, d_lcnt);
             }
+            host_mark("light rows enqueued");
             spa_trace("light rows", s);
             struct FreeLight {
                 uint32_t *&j, *&x;
@@ -902,6 +994,41 @@ namespace splahip {
                     if (x) (void) splahip_free(x);
                 }
             } free_light{Lrj, Lrx};
+
+            // ---- heavy rows: the work items (listed on the host while the light rows' kernel runs; nothing here depends on the dense window) ----------------
+            int dev = 0, cus = 256;
+            (void) hipGetDevice(&dev);
+            (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            const uint32_t extra = sizeof(uint32_t) * (4 * kTpb + 1 + kTpb / 64 + 4);
+            // numeric: accumulator block + bitmap; symbolic: bitmap only (a much wider block)
+            // columns per accumulator block of the blocked numeric form.  SPLAHIP_MXM_BLOCK_KB: its LDS footprint, default 128 KB = one workgroup
+            // per CU.  Every (row, block) step pays a scan of the row's part lengths, an emit scan and six barriers whatever it holds, and a
+            // hub row meets every block: R-MAT 18 per call 107 / 92 / 84 / 77 ms with 48 (two workgroups per CU, 43 blocks) / 64 / 96 / 128 KB (16 blocks)
+            const uint32_t blk_kb  = std::min(128u, std::max(16u, env_u32("SPLAHIP_MXM_BLOCK_KB", 128)));
+            const uint32_t blk_num = blk_kb * 1024u / (uint32_t) sizeof(word) / 2048u * 2048u;
+            const uint32_t blk_sym = std::max(blk_num, std::min<uint32_t>((1u << 20) - 32768u, b_cols + blk_num - 1) / blk_num * blk_num);// a multiple of blk_num; bitmap + chunk arrays < 160 KB
+            const uint32_t lds_num = blk_num * (uint32_t) sizeof(word) + blk_num / 8 + extra, lds_sym = blk_sym / 8 + extra;
+            // items: a heavy row; a row of more than kSplit products is cut into ranges of whole numeric blocks (its column blocks are independent), so that
+            // the few hub rows that carry most of the products are walked by many workgroups at once
+            const u64      kSplit = env_u32("SPLAHIP_MXM_SPLIT", 1u << 19);
+            const uint32_t nb_num = (b_cols + blk_num - 1) / blk_num;
+            struct Item {
+                uint32_t row, c0, c1;
+                u64      est;
+            };
+            std::vector<Item> items;
+            for (uint32_t i : heavy) {
+                const uint32_t pieces = (uint32_t) std::min<u64>(nb_num, std::max<u64>(1, (hP[i] + kSplit - 1) / kSplit));
+                for (uint32_t pc = 0; pc < pieces; ++pc) {
+                    const uint32_t b0 = (uint32_t) ((u64) nb_num * pc / pieces), b1 = (uint32_t) ((u64) nb_num * (pc + 1) / pieces);
+                    if (b1 > b0) items.push_back({i, b0 * blk_num, std::min(b_cols, b1 * blk_num), hP[i] / pieces});
+                }
+            }
+            std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.est > y.est; });
+            const uint32_t        n_items = (uint32_t) items.size();
+            host_mark("items listed");
+            std::vector<uint32_t> h_item(3 * (size_t) n_items);
+            for (uint32_t q = 0; q < n_items; ++q) h_item[q] = items[q].row, h_item[n_items + q] = items[q].c0, h_item[2 * (size_t) n_items + q] = items[q].c1;
 
             // ---- dense window (fp32 MULT / PLUS): a block A[i0 : i0 + hi, k0 : k0 + hk] x B[k0 : k0 + hk, j0 : j0 + hj] of tiles that are at least half full and
             // finite — ANYWHERE in the matrices (sides multiples of 32, at most SPLAHIP_MXM_DENSE_H = 1024) — goes through the matrix cores ---------------------
@@ -1015,38 +1142,6 @@ namespace splahip {
             const uint32_t dense_h = d_hi;// (non-zero: a dense window exists)
 
             // ---- heavy rows: work items, symbolic pass, row pointers + item offsets, numeric pass -----------------------------------------------
-            int dev = 0, cus = 256;
-            (void) hipGetDevice(&dev);
-            (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            const uint32_t extra = sizeof(uint32_t) * (4 * kTpb + 1 + kTpb / 64 + 4);
-            // numeric: accumulator block + bitmap; symbolic: bitmap only (a much wider block)
-            // columns per accumulator block of the blocked numeric form.  SPLAHIP_MXM_BLOCK_KB: its LDS footprint, default 128 KB = one workgroup
-            // per CU.  Every (row, block) step pays a scan of the row's part lengths, an emit scan and six barriers whatever it holds, and a
-            // hub row meets every block: R-MAT 18 per call 107 / 92 / 84 / 77 ms with 48 (two workgroups per CU, 43 blocks) / 64 / 96 / 128 KB (16 blocks)
-            const uint32_t blk_kb  = std::min(128u, std::max(16u, env_u32("SPLAHIP_MXM_BLOCK_KB", 128)));
-            const uint32_t blk_num = blk_kb * 1024u / (uint32_t) sizeof(word) / 2048u * 2048u;
-            const uint32_t blk_sym = std::max(blk_num, std::min<uint32_t>((1u << 20) - 32768u, b_cols + blk_num - 1) / blk_num * blk_num);// a multiple of blk_num; bitmap + chunk arrays < 160 KB
-            const uint32_t lds_num = blk_num * (uint32_t) sizeof(word) + blk_num / 8 + extra, lds_sym = blk_sym / 8 + extra;
-            // items: a heavy row; a row of more than kSplit products is cut into ranges of whole numeric blocks (its column blocks are independent), so that
-            // the few hub rows that carry most of the products are walked by many workgroups at once
-            const u64      kSplit = env_u32("SPLAHIP_MXM_SPLIT", 1u << 19);
-            const uint32_t nb_num = (b_cols + blk_num - 1) / blk_num;
-            struct Item {
-                uint32_t row, c0, c1;
-                u64      est;
-            };
-            std::vector<Item> items;
-            for (uint32_t i : heavy) {
-                const uint32_t pieces = (uint32_t) std::min<u64>(nb_num, std::max<u64>(1, (hP[i] + kSplit - 1) / kSplit));
-                for (uint32_t pc = 0; pc < pieces; ++pc) {
-                    const uint32_t b0 = (uint32_t) ((u64) nb_num * pc / pieces), b1 = (uint32_t) ((u64) nb_num * (pc + 1) / pieces);
-                    if (b1 > b0) items.push_back({i, b0 * blk_num, std::min(b_cols, b1 * blk_num), hP[i] / pieces});
-                }
-            }
-            std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.est > y.est; });
-            const uint32_t        n_items = (uint32_t) items.size();
-            std::vector<uint32_t> h_item(3 * (size_t) n_items);
-            for (uint32_t q = 0; q < n_items; ++q) h_item[q] = items[q].row, h_item[n_items + q] = items[q].c0, h_item[2 * (size_t) n_items + q] = items[q].c1;
             const uint32_t grid_sym = std::max(1u, std::min(n_items, (uint32_t) cus * std::max(1u, std::min(2u, (160u * 1024u - 256u) / lds_sym))));
             const uint32_t grid_num = std::max(1u, std::min(n_items, (uint32_t) cus * std::max(1u, std::min(2u, (160u * 1024u - 256u) / lds_num))));
             const uint32_t grid     = std::max(grid_sym, grid_num);
@@ -1056,7 +1151,7 @@ namespace splahip {
             if (e == hipSuccess) e = tmp.alloc(&d_counts, n_items);
             if (e == hipSuccess) e = tmp.alloc(&d_cursor, (size_t) grid * max_deg);
             if (e == hipSuccess) e = tmp.alloc(&d_dropped, 1);
-            if (e == hipSuccess && n_items) e = hipMemcpyAsync(d_item, h_item.data(), 4 * h_item.size(), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess && n_items) e = h2d(d_item, h_item.data(), 4 * h_item.size(), s);
             if (e == hipSuccess) e = hipMemsetAsync(d_dropped, 0, 4, s);
             if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm (row classes): %s", hipGetErrorString(e));
             // block boundaries of B's rows, once per call (up to 1 GiB; beyond that the kernels search and keep cursors)
@@ -1080,10 +1175,17 @@ namespace splahip {
             }
             // row pointers and item offsets on the host (a few hundred thousand counters): entries per row = the light rows' ESC result or the sum of the
             // row's items; an item's entries start at Rp[row] + the counts of the row's items to its left
-            std::vector<uint32_t> h_counts(n_items), h_cnt((size_t) a_rows + 1, 0u), h_Rp((size_t) a_rows + 1), h_out(n_items);
-            if (n_items) SPLAHIP_TRY(hipMemcpyAsync(h_counts.data(), d_counts, 4 * (size_t) n_items, hipMemcpyDeviceToHost, s));
-            if (d_lcnt) SPLAHIP_TRY(hipMemcpyAsync(h_cnt.data(), d_lcnt, 4 * (size_t) a_rows, hipMemcpyDeviceToHost, s));
+            host_mark("symbolic pass enqueued");
+            std::vector<uint32_t> h_Rp((size_t) a_rows + 1), h_out(n_items), h_cnt_own;
+            uint32_t *            h_counts = nullptr, *h_cnt = nullptr;
+            SPLAHIP_TRY(d2h(&h_counts, d_counts, n_items, s));
+            if (d_lcnt) SPLAHIP_TRY(d2h(&h_cnt, d_lcnt, a_rows, s));
+            else {
+                h_cnt_own.assign((size_t) a_rows + 1, 0u);
+                h_cnt = h_cnt_own.data();
+            }
             SPLAHIP_TRY(hipStreamSynchronize(s));
+            host_mark("counts on the host");
             if (d_lcnt) {
                 u64 ln = 0;
                 for (uint32_t i = 0; i < a_rows; ++i) ln += h_cnt[i];
@@ -1107,8 +1209,9 @@ namespace splahip {
             h_Rp[0] = 0;
             for (uint32_t i = 0; i < a_rows; ++i) h_Rp[i + 1] = h_Rp[i] + h_cnt[i];
             for (uint32_t q = 0; q < n_items; ++q) h_out[q] += h_Rp[items[q].row];
-            SPLAHIP_TRY(hipMemcpyAsync(Rp, h_Rp.data(), 4 * ((size_t) a_rows + 1), hipMemcpyHostToDevice, s));
-            if (n_items) SPLAHIP_TRY(hipMemcpyAsync(d_out, h_out.data(), 4 * (size_t) n_items, hipMemcpyHostToDevice, s));
+            SPLAHIP_TRY(h2d(Rp, h_Rp.data(), 4 * ((size_t) a_rows + 1), s));
+            if (n_items) SPLAHIP_TRY(h2d(d_out, h_out.data(), 4 * (size_t) n_items, s));
+            host_mark("row pointers");
             spa_trace("row pointers", s);
             uint32_t *oj = nullptr, *ox = nullptr;
             e = handoff_alloc(reinterpret_cast<void**>(&oj), sizeof(uint32_t) * (size_t) total);
@@ -1134,49 +1237,53 @@ namespace splahip {
                 // everything when B's boundary table was too large keep the blocked form
                 const uint32_t wr  = std::max(1u, 245760u / blk_num) * blk_num;
                 const uint32_t cap = ((160u * 1024u - 256u - 2u * (wr / 8) - (uint32_t) sizeof(uint32_t) * (3 * kTpb + 1 + kTpb / 64 + 4)) / (uint32_t) sizeof(word)) & ~63u;// what is left of the LDS
-                std::vector<uint32_t> rk[4], bl[4];
-                for (uint32_t q = 0; q < n_items; ++q) {
-                    const bool ranked = d_bblk && h_counts[q] <= cap && !(d_hi && items[q].row - d_i0 < d_hi) && env_u32("SPLAHIP_MXM_RANKED", 1) != 0;
-                    auto&      dst    = ranked ? rk : bl;
-                    dst[0].push_back(items[q].row), dst[1].push_back(items[q].c0), dst[2].push_back(items[q].c1), dst[3].push_back(h_out[q]);
+                const bool            ranked_on = d_bblk && env_u32("SPLAHIP_MXM_RANKED", 1) != 0;
+                auto                  is_ranked = [&](uint32_t q) { return ranked_on && h_counts[q] <= cap && !(d_hi && items[q].row - d_i0 < d_hi); };
+                uint32_t              n_rk = 0;
+                for (uint32_t q = 0; q < n_items; ++q) n_rk += is_ranked(q) ? 1u : 0u;
+                const uint32_t        n_bl = n_items - n_rk;
+                std::vector<uint32_t> rk(4 * (size_t) n_rk), bl(4 * (size_t) n_bl);// [rows | c0 | c1 | out], the items' order kept
+                for (uint32_t q = 0, ir = 0, ib = 0; q < n_items; ++q) {
+                    const bool     ranked = is_ranked(q);
+                    uint32_t*      dst    = ranked ? rk.data() : bl.data();
+                    const size_t   n = ranked ? n_rk : n_bl, at = ranked ? ir++ : ib++;
+                    dst[at] = items[q].row, dst[n + at] = items[q].c0, dst[2 * n + at] = items[q].c1, dst[3 * n + at] = h_out[q];
                 }
                 if (knob_env("SPLAHIP_MXM_TRACE")) {// class sizes (diagnostic)
                     u64 re = 0, be = 0, rp = 0, bp = 0, bsteps = 0;
                     for (uint32_t q = 0; q < n_items; ++q) {
-                        const bool ranked = d_bblk && h_counts[q] <= cap && !(d_hi && items[q].row - d_i0 < d_hi) && env_u32("SPLAHIP_MXM_RANKED", 1) != 0;
+                        const bool ranked = is_ranked(q);
                         (ranked ? re : be) += h_counts[q];
                         (ranked ? rp : bp) += items[q].est;
                         if (!ranked) bsteps += (items[q].c1 - items[q].c0 + blk_num - 1) / blk_num;
                     }
                     std::fprintf(stderr, "[mxm-spa] items: ranked %zu (entries %llu, products ~%llu), blocked %zu (entries %llu, products ~%llu, block steps %llu), cap %u\n",
-                                 rk[0].size(), (unsigned long long) re, (unsigned long long) rp, bl[0].size(), (unsigned long long) be, (unsigned long long) bp,
+                                 (size_t) n_rk, (unsigned long long) re, (unsigned long long) rp, (size_t) n_bl, (unsigned long long) be, (unsigned long long) bp,
                                  (unsigned long long) bsteps, cap);
                 }
-                auto upload = [&](std::vector<uint32_t>* v, uint32_t** d) -> hipError_t {
-                    const size_t n = v[0].size();
-                    hipError_t   er = tmp.alloc(d, 4 * n);
-                    for (int f = 0; f < 4 && er == hipSuccess && n; ++f) er = hipMemcpyAsync(*d + f * n, v[f].data(), 4 * n, hipMemcpyHostToDevice, s);
-                    return er;
-                };
                 uint32_t *d_rk = nullptr, *d_bl = nullptr;
-                e = upload(rk, &d_rk);
-                if (e == hipSuccess) e = upload(bl, &d_bl);
-                if (e == hipSuccess) e = hipStreamSynchronize(s);// (the vectors are locals of this block)
+                e = tmp.alloc(&d_rk, rk.size());
+                if (e == hipSuccess) e = tmp.alloc(&d_bl, bl.size());
+                if (e == hipSuccess) e = h2d(d_rk, rk.data(), 4 * rk.size(), s);
+                if (e == hipSuccess) e = h2d(d_bl, bl.data(), 4 * bl.size(), s);
                 if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm (row classes): %s", hipGetErrorString(e));
+                host_mark("item classes");
                 a.Rj = oj, a.Rx = ox;
-                if (const uint32_t n = (uint32_t) bl[0].size()) {
+                if (const uint32_t n = n_bl) {
                     a.block = blk_num, a.item_row = d_bl, a.item_c0 = d_bl + n, a.item_c1 = d_bl + 2 * (size_t) n, a.item_out = d_bl + 3 * (size_t) n, a.n_heavy = n;
                     hipLaunchKernelGGL((mxm_spa_kernel<T, Mult, ACC, true>), dim3(std::min(n, grid_num)), dim3(kTpb), lds_num, s, a, Mult(op_mult), DynBin(op_add), init);
                 }
-                if (const uint32_t n = (uint32_t) rk[0].size()) {
+                if (const uint32_t n = n_rk) {
                     SPLAHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mxm_spa_ranked_kernel<T, Mult, ACC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
                     const uint32_t lds_r = cap * (uint32_t) sizeof(word) + 2 * (wr / 8) + sizeof(uint32_t) * (3 * kTpb + 1 + kTpb / 64 + 4);
                     a.item_row = d_rk, a.item_c0 = d_rk + n, a.item_c1 = d_rk + 2 * (size_t) n, a.item_out = d_rk + 3 * (size_t) n, a.n_heavy = n;
                     hipLaunchKernelGGL((mxm_spa_ranked_kernel<T, Mult, ACC>), dim3(std::min(n, (uint32_t) cus)), dim3(kTpb), lds_r, s, a, cap, wr, Mult(op_mult), DynBin(op_add), init);
                 }
-                tl_last_ranked = (uint32_t) rk[0].size();
+                tl_last_ranked = n_rk;
             }
-            SPLAHIP_TRY(hipStreamSynchronize(s));// (h_Rp / h_out were read by the copies above)
+            host_mark("numeric pass enqueued");
+            SPLAHIP_TRY(hipStreamSynchronize(s));
+            host_mark("numeric pass done");
             spa_trace("numeric pass", s);
             uint32_t dropped = 0;
             e                = hipGetLastError();
@@ -1215,27 +1322,28 @@ namespace splahip {
 
         template<typename T, int ACC>
         int spa_by_mult(uint32_t a_rows, uint32_t b_cols, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const uint32_t* Bp, const uint32_t* Bj, const void* Bx, uint32_t* Rp,
-                        uint32_t** Rj, void** Rx, uint32_t* h_nnz, const std::vector<u64>& hP, const u64* dP, const std::vector<uint32_t>& hAp, int op_mult, int op_add,
+                        uint32_t** Rj, void** Rx, uint32_t* h_nnz, const u64* hP, const u64* dP, const uint32_t* hAp, const uint32_t* h_order, int op_mult, int op_add,
                         uint32_t init_bits, uint32_t b_rows_hint, hipStream_t s) {
-            if (op_mult == SPLAHIP_MULT) return spa_run<T, StaBin<SPLAHIP_MULT>, ACC>(a_rows, b_cols, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, hP, dP, hAp, op_mult, op_add, init_bits, b_rows_hint, s);
-            return spa_run<T, DynBin, ACC>(a_rows, b_cols, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, hP, dP, hAp, op_mult, op_add, init_bits, b_rows_hint, s);
+            if (op_mult == SPLAHIP_MULT) return spa_run<T, StaBin<SPLAHIP_MULT>, ACC>(a_rows, b_cols, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, hP, dP, hAp, h_order, op_mult, op_add, init_bits, b_rows_hint, s);
+            return spa_run<T, DynBin, ACC>(a_rows, b_cols, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, hP, dP, hAp, h_order, op_mult, op_add, init_bits, b_rows_hint, s);
         }
 
-        __global__ __launch_bounds__(256) void max_col_kernel(uint32_t nnz, const uint32_t* __restrict__ Aj, uint32_t* __restrict__ out) {
-            uint32_t m = 0;
+        __global__ __launch_bounds__(256) void max_col_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ Aj, uint32_t* __restrict__ out) {
+            const uint32_t nnz = Ap[n_rows];
+            uint32_t       m   = 0;
             for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nnz; k += gridDim.x * 256) m = max(m, Aj[k]);
             m = wave_max(m);
             if (lane_id() == 0) atomicMax(out, m);
         }
         __global__ __launch_bounds__(256) void rowprod_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ Aj, const uint32_t* __restrict__ Bp,
-                                                              u64* __restrict__ P) {
+                                                              u64* __restrict__ P, uint32_t* __restrict__ ids) {
             // a wavefront per row, lanes over its entries (a thread per row walked a hub's 10^5 entries alone: 3.3 ms of an R-MAT 18 call)
             const uint32_t i = blockIdx.x * (256 / 64) + threadIdx.x / 64;
             if (i >= n_rows) return;
             u64 sum = 0;
             for (uint32_t e = Ap[i] + (threadIdx.x & 63u); e < Ap[i + 1]; e += 64) sum += Bp[Aj[e] + 1] - Bp[Aj[e]];
             for (unsigned off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-            if ((threadIdx.x & 63u) == 0) P[i] = sum;
+            if ((threadIdx.x & 63u) == 0) P[i] = sum, ids[i] = i;
         }
 
     }// namespace
@@ -1250,30 +1358,41 @@ namespace splahip {
         if (tl_mxm_force_esc || env_u32("SPLAHIP_MXM_SPA", 1) == 0) return -1;
         const int acc = cob_acc_kind(op_add, type);
         if (acc == COB_NONE || b_cols == 0) return -1;
-        Scratch tmp;
-        u64*    dP = nullptr;
-        if (tmp.alloc(&dP, a_rows) != hipSuccess) return -1;
-        hipLaunchKernelGGL(rowprod_kernel, dim3((a_rows + 3) / 4), dim3(256), 0, s, a_rows, Ap, Aj, Bp, dP);
-        std::vector<u64>      hP(a_rows);
-        std::vector<uint32_t> hAp((size_t) a_rows + 1);
-        SPLAHIP_TRY(hipMemcpyAsync(hP.data(), dP, sizeof(u64) * (size_t) a_rows, hipMemcpyDeviceToHost, s));
-        SPLAHIP_TRY(hipMemcpyAsync(hAp.data(), Ap, 4 * ((size_t) a_rows + 1), hipMemcpyDeviceToHost, s));
+        arena().reset();
+        Scratch   tmp(s);
+        u64*      dP    = nullptr;
+        uint32_t* d_max = nullptr;
+        if (tmp.alloc(&dP, a_rows) != hipSuccess || tmp.alloc(&d_max, 1) != hipSuccess) return -1;
+        SPLAHIP_TRY(hipMemsetAsync(d_max, 0, 4, s));
+        // rows by descending product count, ties by row number (a stable device sort: the same order std::stable_sort gave, which cost the host 4 ms per R-MAT 18 call)
+        u64*      dPs   = nullptr;
+        uint32_t *d_ids = nullptr, *d_order = nullptr;
+        if (tmp.alloc(&dPs, a_rows) != hipSuccess || tmp.alloc(&d_ids, a_rows) != hipSuccess || tmp.alloc(&d_order, a_rows) != hipSuccess) return -1;
+        hipLaunchKernelGGL(rowprod_kernel, dim3((a_rows + 3) / 4), dim3(256), 0, s, a_rows, Ap, Aj, Bp, dP, d_ids);
+        {
+            size_t bytes = 0;
+            SPLAHIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, bytes, dP, dPs, d_ids, d_order, a_rows, 0, 64, s));
+            unsigned char* t = nullptr;
+            if (tmp.alloc(&t, bytes ? bytes : 4) != hipSuccess) return -1;
+            SPLAHIP_TRY(rocprim::radix_sort_pairs_desc(t, bytes, dP, dPs, d_ids, d_order, a_rows, 0, 64, s));
+        }
+        // the number of rows of B is not an argument of splahip_mxm: the largest inner index A refers to bounds what the dense corner may touch
+        hipLaunchKernelGGL(max_col_kernel, dim3(1024), dim3(256), 0, s, a_rows, Ap, Aj, d_max);
+        u64*      hP    = nullptr;
+        uint32_t *hAp = nullptr, *h_maxp = nullptr, *h_order = nullptr;
+        SPLAHIP_TRY(d2h(&hP, dP, a_rows, s));
+        SPLAHIP_TRY(d2h(&h_order, d_order, a_rows, s));
+        SPLAHIP_TRY(d2h(&hAp, Ap, (size_t) a_rows + 1, s));
+        SPLAHIP_TRY(d2h(&h_maxp, d_max, 1, s));
         SPLAHIP_TRY(hipStreamSynchronize(s));
         u64  total = 0;
         bool heavy = false;
-        for (u64 p : hP) total += p, heavy = heavy || p > kLight;
+        for (uint32_t i = 0; i < a_rows; ++i) total += hP[i], heavy = heavy || hP[i] > kLight;
         if (!heavy) return -1;
         if (h_products) *h_products = total;
-        // the number of rows of B is not an argument of splahip_mxm: the largest inner index A refers to bounds what the dense corner may touch
-        uint32_t* d_max = nullptr;
-        uint32_t  h_max = 0;
-        if (tmp.alloc(&d_max, 1) != hipSuccess) return -1;
-        SPLAHIP_TRY(hipMemsetAsync(d_max, 0, 4, s));
-        if (hAp[a_rows]) hipLaunchKernelGGL(max_col_kernel, dim3(1024), dim3(256), 0, s, hAp[a_rows], Aj, d_max);
-        SPLAHIP_TRY(hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, s));
-        SPLAHIP_TRY(hipStreamSynchronize(s));
+        const uint32_t h_max = *h_maxp;
         const uint32_t b_rows_hint = h_max + 1;
-#define SPLAHIP_SPA(TT, AA) return spa_by_mult<TT, AA>(a_rows, b_cols, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, hP, dP, hAp, op_mult, op_add, init_bits, b_rows_hint, s)
+#define SPLAHIP_SPA(TT, AA) return spa_by_mult<TT, AA>(a_rows, b_cols, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, hP, dP, hAp, h_order, op_mult, op_add, init_bits, b_rows_hint, s)
         switch (type) {
             case SPLAHIP_FLOAT:
                 if (acc == COB_ADD) SPLAHIP_SPA(float, COB_ADD);
