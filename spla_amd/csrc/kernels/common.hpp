@@ -61,6 +61,31 @@ namespace splahip {
     bool       handoff_release(void* p);// true: p was a hand-off allocation and has been taken back (cached or freed)
     void       handoff_trim();          // free the cached hand-off blocks
 
+    // SCRATCH ARENA of the blocking calls (mxm, mxmT): device blocks of the calling host thread, kept between calls and handed out by bumping an offset.  A call
+    // opens a ScratchScope, takes its ~20 workspaces with scratch_take and gives them all back when the scope ends (the offset returns to where the scope found
+    // it; scopes nest; the destructor synchronises the stream, so nothing queued still uses the memory).  Why: hipFreeAsync costs the host 25 us for a small buffer
+    // and 140 - 170 us for one of >= 16 MB (tools/exp/exp_r5_alloc_cost.py) — 1.5 - 3 ms per call with the GPU idle.  The arena grows by whole blocks and is
+    // melted into one block when the outermost scope ends; scratch_trim() (also run when any allocation of the library runs out of memory, and by
+    // splahip_mxm_trim) frees it.  SPLAHIP_SCRATCH_ARENA=0: scratch_active() stays false and the callers use the stream-ordered pool.
+    struct ScratchScope {
+        explicit ScratchScope(hipStream_t stream);
+        ~ScratchScope();
+        ScratchScope(const ScratchScope&)            = delete;
+        ScratchScope& operator=(const ScratchScope&) = delete;
+
+      private:
+        hipStream_t s_;
+        size_t      block_, off_, held_;
+        bool        on_;
+    };
+    bool       scratch_active();                    // inside a ScratchScope of this thread (and not paused)
+    hipError_t scratch_take(void** p, size_t bytes);// 256-byte aligned; valid until the innermost open scope ends
+    void       scratch_trim();                      // frees this thread's arena unless a scope is open
+    struct ScratchPause {                           // a nested call that allocates in a loop keeps to the pool
+        ScratchPause();
+        ~ScratchPause();
+    };
+
     // Scoped, STREAM-ORDERED scratch memory (hipMallocAsync / hipFreeAsync on the call's stream): taken from the device's
     // default memory pool, whose release threshold runtime.hip raises so that steady-state calls neither reach the driver
     // nor synchronise the device the way hipMalloc / hipFree do.  Everything that touches the buffer must run on `stream`.

@@ -43,20 +43,25 @@ namespace splahip {
         bool        pooled = false;
         ~DevBuf() { drop(); }
         void drop() {
-            if (p && !cached) {
+            if (p && !cached && !arena) {
                 if (handoff) (void) handoff_release(p);
                 else
                     (void) (pooled ? hipFreeAsync(p, s) : hipFree(p));
             }
             p      = nullptr;
-            cached = handoff = false;
+            cached = handoff = arena = false;
         }
         hipError_t alloc(size_t bytes) {
             drop();
             s      = tl_stream;
             pooled = true;
+            if (scratch_active()) {// the calling thread's scratch arena (common.hpp): given back when the call's ScratchScope ends
+                arena = true;
+                return scratch_take(&p, bytes ? bytes : 4);
+            }
             return device_malloc_async(&p, bytes ? bytes : 4, s);
         }
+        bool arena = false;
         hipError_t alloc_plain(size_t bytes) {// a result array: handed to the caller with release(), returned with splahip_free
             drop();
             pooled = false;
@@ -105,7 +110,7 @@ namespace splahip {
         void* release() {
             void* q = p;
             p       = nullptr;
-            cached = handoff = false;
+            cached = handoff = arena = false;
             return q;
         }
         template<typename U>
@@ -959,6 +964,7 @@ namespace splahip {
             Busy() { ++DevBuf::busy(); }
             ~Busy() { --DevBuf::busy(); }
         } busy_scope;// the cached workspaces are in use until this call returns
+        ScratchScope scratch_scope(s);// (before every DevBuf: the workspaces below come from the thread's scratch arena and go back when the call ends)
 
         *Rj = nullptr, *Rx = nullptr, *h_nnz = 0;
         if (n_entries == 0) {
@@ -1746,6 +1752,7 @@ int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols,
 
 int splahip_mxm_trim(void) {
     DevBuf::trim();
+    scratch_trim();
     handoff_trim();
     return SPLAHIP_OK;
 }

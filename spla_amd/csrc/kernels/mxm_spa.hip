@@ -776,23 +776,29 @@ namespace splahip {
             return e && *e ? (uint32_t) std::strtoul(e, nullptr, 10) : dflt;
         }
 
-        // scratch memory of a call, STREAM-ORDERED (hipMallocAsync / hipFreeAsync from the device's pool: ~25 buffers per call; hipMalloc / hipFree took a driver round
-        // trip each and the frees synchronised the device)
+        // scratch memory of a call: from the calling thread's scratch arena (common.hpp; mxm_spa opens the ScratchScope), or — with the arena switched off —
+        // stream-ordered from the device's pool.  (hipMalloc / hipFree took a driver round trip each and the frees synchronised the device; hipFreeAsync still costs
+        // the host 25 - 170 us per buffer: ~25 buffers per call)
         struct Scratch {
             hipStream_t        s = nullptr;
-            std::vector<void*> ptrs;
+            std::vector<void*> pooled;
             explicit Scratch(hipStream_t stream) : s(stream) {}
             Scratch(const Scratch&)            = delete;
             Scratch& operator=(const Scratch&) = delete;
             ~Scratch() {
-                for (void* p : ptrs)
+                for (void* p : pooled)
                     if (p) (void) hipFreeAsync(p, s);
             }
             template<typename U>
             hipError_t alloc(U** out, size_t count) {
-                void*      p = nullptr;
-                hipError_t e = device_malloc_async(&p, sizeof(U) * (count ? count : 1), s);
-                if (e == hipSuccess) ptrs.push_back(p);
+                void*        p     = nullptr;
+                const size_t bytes = sizeof(U) * (count ? count : 1);
+                hipError_t   e;
+                if (scratch_active()) e = scratch_take(&p, bytes);
+                else {
+                    e = device_malloc_async(&p, bytes, s);
+                    if (e == hipSuccess) pooled.push_back(p);
+                }
                 *out = static_cast<U*>(p);
                 return e;
             }
@@ -976,6 +982,7 @@ namespace splahip {
                 if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm (row classes): %s", hipGetErrorString(e));
                 hipLaunchKernelGGL(light_copy_kernel, dim3((a_rows + 255) / 256), dim3(256), 0, s, a_rows, Ap, Aj, static_cast<const uint32_t*>(Ax), dP, Lp, Lj, Lx, kLight);
                 tl_mxm_force_esc = true;
+                ScratchPause pause;// (the ESC form allocates per row block: it keeps to the stream-ordered pool)
                 void*     lrx    = nullptr;
                 uint32_t  esc_nnz = 0;
                 const int st     = splahip_mxm(t, a_rows, b_cols, Lp, Lj, Lx, Bp, Bj, Bx, Lrp, &Lrj, &lrx, &esc_nnz, nullptr, op_mult, op_add, init_bits, 0, s);
@@ -1359,7 +1366,8 @@ namespace splahip {
         const int acc = cob_acc_kind(op_add, type);
         if (acc == COB_NONE || b_cols == 0) return -1;
         arena().reset();
-        Scratch   tmp(s);
+        ScratchScope scratch_scope(s);
+        Scratch      tmp(s);
         u64*      dP    = nullptr;
         uint32_t* d_max = nullptr;
         if (tmp.alloc(&dP, a_rows) != hipSuccess || tmp.alloc(&d_max, 1) != hipSuccess) return -1;

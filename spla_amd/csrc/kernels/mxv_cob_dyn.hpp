@@ -67,7 +67,10 @@ namespace splahip {
         uint32_t* const gacc  = acc + (size_t) q * acc_stride;
         if (threadIdx.x == 0) {
             uint32_t expect = 1u;
-            s_ctl[3]        = __hip_atomic_compare_exchange_strong(state + q, &expect, 1u | (1u << 16), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+            // (bit 31: CLOSED for good.  "joined == done" alone does not say so: a worker that is turned back has already counted itself in, and the NEXT arrival then
+            // saw joined != done, joined the finished range, merged an empty slice and raised fin_flag — the kernel behind the launch overwrote the lone worker's
+            // rows with the identity: the intermittent mismatch of the three-workers-per-range test, tools/exp/exp_r5_dyn_flaky.py)
+            s_ctl[3] = __hip_atomic_compare_exchange_strong(state + q, &expect, 0x80000000u | 1u | (1u << 16), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
         }
         __syncthreads();
         const bool solo = s_ctl[3] != 0;
@@ -154,8 +157,8 @@ namespace splahip {
             const uint32_t st  = __hip_atomic_load(d.state + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t nc  = d.spans[q].n_chunks;
             if ((unsigned long long) cur * 128ull >= nc) continue;
-            const uint32_t joined = st & 0xFFFFu, done = st >> 16;
-            if (joined != 0u && joined == done) continue;// closed (a range without a chunk left is skipped above already)
+            const uint32_t joined = st & 0xFFFFu, done = (st >> 16) & 0x7FFFu;
+            if ((st >> 31) != 0u || (joined != 0u && joined == done)) continue;// closed (a range without a chunk left is skipped above already)
             const uint32_t active = joined > done ? joined - done : 0u;
             // the range that would finish last: unclaimed chunks x the modelled cost of one of its chunks (a cold range's chunk takes 2 - 3 x a hot one's:
             // its gathers), per worker, this workgroup included
@@ -228,7 +231,7 @@ namespace splahip {
                 const uint32_t old = __hip_atomic_fetch_add(d.state + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t rd0 = __hip_atomic_fetch_add(cur_pv, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t nxt = job < d.n_jobs ? __hip_atomic_fetch_add(d.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : d.n_jobs;
-                s_ctl[0]           = (old & 0xFFFFu) != 0u && (old & 0xFFFFu) == (old >> 16) ? 0u : 1u;// closed: its last worker has taken the row pass
+                s_ctl[0]           = (old >> 31) != 0u || ((old & 0xFFFFu) != 0u && (old & 0xFFFFu) == ((old >> 16) & 0x7FFFu)) ? 0u : 1u;// closed: its last worker has taken the row pass
                 s_ctl[1]           = nxt;
                 s_ring[0] = ring_word(0, rd0), s_ring[1] = ring_word(1, rd0 + 1u), s_ring[2] = 0u, s_ring[3] = 0u;
             }

@@ -186,6 +186,92 @@ namespace splahip {
         return e;
     }
 
+    // ---- scratch arena (common.hpp) ----------------------------------------------------------------------------------------------------------------------
+    namespace {
+        struct ArenaBlock {
+            unsigned char* p;
+            size_t         cap;
+        };
+        struct Arena {
+            std::vector<ArenaBlock> blocks;
+            size_t                  cur = 0, off = 0;// the next byte handed out: blocks[cur].p + off
+            int                     depth = 0, paused = 0;
+            size_t                  held = 0, peak = 0;// bytes handed out and not yet returned; the most ever held at once
+        };
+        Arena& scratch_arena() {
+            static thread_local Arena* a = new Arena;// (kept for the life of the process: a thread_local's destructor may run after the HIP runtime's)
+            return *a;
+        }
+        bool scratch_enabled() {
+            static const bool on = [] {
+                const char* e = knob_env("SPLAHIP_SCRATCH_ARENA");
+                return !(e && e[0] == '0');
+            }();
+            return on;
+        }
+    }// namespace
+    bool scratch_active() {
+        const Arena& a = scratch_arena();
+        return a.depth > 0 && a.paused == 0;
+    }
+    void scratch_trim() {
+        Arena& a = scratch_arena();
+        if (a.depth > 0) return;
+        for (ArenaBlock& b : a.blocks)
+            if (b.p) (void) hipFree(b.p);
+        a.blocks.clear();
+        a.cur = a.off = 0;
+    }
+    hipError_t scratch_take(void** p, size_t bytes) {
+        Arena& a = scratch_arena();
+        *p       = nullptr;
+        if (a.depth <= 0) return hipErrorInvalidValue;
+        bytes = (std::max<size_t>(bytes, 4) + 255) & ~size_t(255);
+        for (;;) {
+            if (a.cur < a.blocks.size() && a.blocks[a.cur].cap - a.off >= bytes) {
+                *p = a.blocks[a.cur].p + a.off;
+                a.off += bytes;
+                a.held += bytes;
+                a.peak = std::max(a.peak, a.held);
+                return hipSuccess;
+            }
+            if (a.cur + 1 < a.blocks.size()) {// the next block the arena already owns
+                ++a.cur;
+                a.off = 0;
+                continue;
+            }
+            // a new block: at least what the largest call so far held (so a steady-state call fits one block), at least 32 MB
+            const size_t cap = std::max({bytes, a.peak + a.peak / 8, size_t(32) << 20});
+            void*        q   = nullptr;
+            register_trim(&scratch_trim);// (idempotent)
+            size_t     got = cap;
+            hipError_t e   = device_malloc(&q, cap);
+            if (e != hipSuccess && cap > bytes) (void) hipGetLastError(), got = bytes, e = device_malloc(&q, bytes);
+            if (e != hipSuccess) return e;
+            a.blocks.push_back({static_cast<unsigned char*>(q), got});
+            a.cur = a.blocks.size() - 1;
+            a.off = 0;
+        }
+    }
+    ScratchScope::ScratchScope(hipStream_t stream) : s_(stream), block_(0), off_(0), held_(0), on_(scratch_enabled()) {
+        if (!on_) return;
+        Arena& a = scratch_arena();
+        block_ = a.cur, off_ = a.off, held_ = a.held;
+        ++a.depth;
+    }
+    ScratchScope::~ScratchScope() {
+        if (!on_) return;
+        Arena& a = scratch_arena();
+        (void) hipStreamSynchronize(s_);// nothing queued may still use what goes back
+        a.cur = block_, a.off = off_, a.held = held_;
+        if (--a.depth == 0) {
+            a.cur = a.off = a.held = 0;
+            if (a.blocks.size() > 1) scratch_trim();// melted into one block of `peak` bytes by the next call's first take
+        }
+    }
+    ScratchPause::ScratchPause() { ++scratch_arena().paused; }
+    ScratchPause::~ScratchPause() { --scratch_arena().paused; }
+
     namespace {
         // returned hand-off blocks kept for reuse: at most a quarter of the memory that was free when the device was selected, and at most 48 GiB
         size_t                            kHandoffCacheBytes = size_t(48) << 30;
