@@ -89,6 +89,12 @@ namespace splahip {
     // Scoped, STREAM-ORDERED scratch memory (hipMallocAsync / hipFreeAsync on the call's stream): taken from the device's
     // default memory pool, whose release threshold runtime.hip raises so that steady-state calls neither reach the driver
     // nor synchronise the device the way hipMalloc / hipFree do.  Everything that touches the buffer must run on `stream`.
+    // Between the pool and the caller sits a small per-thread cache of released blocks, keyed by stream (stream_block_alloc / stream_block_free, runtime.hip): a
+    // block released on stream s is handed to the next request of a similar size ON THE SAME STREAM — ordered behind its previous user exactly as the pool's own
+    // reuse is — without going through hipFreeAsync, which costs the host 25 us for a small block and 140 - 170 us for one of >= 16 MB
+    // (tools/exp/exp_r5_alloc_cost.py; a push step of 0.8 ms released 32 MB per call).  At most 24 blocks / 4 GiB per thread; SPLAHIP_STREAM_CACHE=0: off.
+    hipError_t stream_block_alloc(void** p, size_t bytes, hipStream_t stream);
+    void       stream_block_free(void* p, hipStream_t stream);
     struct DevMem {
         void*       p = nullptr;
         hipStream_t s = nullptr;
@@ -97,13 +103,13 @@ namespace splahip {
         DevMem& operator=(const DevMem&) = delete;
         ~DevMem() { release(); }
         void release() {
-            if (p) (void) hipFreeAsync(p, s);
+            if (p) stream_block_free(p, s);
             p = nullptr;
         }
         hipError_t alloc(hipStream_t stream, size_t bytes) {
             release();
             s = stream;
-            return device_malloc_async(&p, bytes ? bytes : 4, stream);
+            return stream_block_alloc(&p, bytes ? bytes : 4, stream);
         }
         template<typename U>
         U* as() { return static_cast<U*>(p); }

@@ -186,6 +186,82 @@ namespace splahip {
         return e;
     }
 
+    // ---- per-thread cache of released stream-ordered blocks (common.hpp: DevMem) ---------------------------------------------------------------------------
+    namespace {
+        struct StreamBlock {
+            void*       p;
+            size_t      cap;
+            hipStream_t s;
+        };
+        struct StreamCache {
+            std::vector<StreamBlock>          free;// oldest first
+            std::unordered_map<void*, size_t> live;// handed out: capacity
+            size_t                            free_bytes = 0;
+        };
+        StreamCache& stream_cache() {
+            static thread_local StreamCache* c = new StreamCache;// (kept for the life of the process, like the mailbox)
+            return *c;
+        }
+        constexpr size_t kStreamCacheBlocks = 24, kStreamCacheBytes = size_t(4) << 30, kStreamCacheBlockMax = size_t(1) << 30;
+        bool stream_cache_enabled() {
+            static const bool on = [] {
+                const char* e = knob_env("SPLAHIP_STREAM_CACHE");
+                return !(e && e[0] == '0');
+            }();
+            return on;
+        }
+        void stream_cache_trim() {// (run by release_idle_memory on the thread that ran out of memory, behind a device synchronisation)
+            StreamCache& c = stream_cache();
+            for (StreamBlock& b : c.free) (void) hipFreeAsync(b.p, b.s);
+            c.free.clear();
+            c.free_bytes = 0;
+        }
+    }// namespace
+    hipError_t stream_block_alloc(void** p, size_t bytes, hipStream_t stream) {
+        bytes = (std::max<size_t>(bytes, 4) + 255) & ~size_t(255);
+        if (!stream_cache_enabled()) return device_malloc_async(p, bytes, stream);
+        StreamCache& c    = stream_cache();
+        size_t       best = c.free.size();
+        for (size_t k = 0; k < c.free.size(); ++k) {
+            const StreamBlock& b = c.free[k];
+            if (b.s == stream && b.cap >= bytes && b.cap <= 4 * bytes + (size_t(1) << 20) && (best == c.free.size() || b.cap < c.free[best].cap)) best = k;
+        }
+        if (best != c.free.size()) {
+            *p = c.free[best].p;
+            c.live[*p] = c.free[best].cap;
+            c.free_bytes -= c.free[best].cap;
+            c.free.erase(c.free.begin() + (long) best);
+            return hipSuccess;
+        }
+        const hipError_t e = device_malloc_async(p, bytes, stream);
+        if (e == hipSuccess) c.live[*p] = bytes;
+        return e;
+    }
+    void stream_block_free(void* p, hipStream_t stream) {
+        if (!p) return;
+        if (!stream_cache_enabled()) {
+            (void) hipFreeAsync(p, stream);
+            return;
+        }
+        StreamCache& c  = stream_cache();
+        const auto   it = c.live.find(p);
+        if (it == c.live.end() || it->second > kStreamCacheBlockMax) {// (not ours, or too large to keep)
+            if (it != c.live.end()) c.live.erase(it);
+            (void) hipFreeAsync(p, stream);
+            return;
+        }
+        const size_t cap = it->second;
+        c.live.erase(it);
+        register_trim(&stream_cache_trim);// (idempotent)
+        c.free.push_back({p, cap, stream});
+        c.free_bytes += cap;
+        while (c.free.size() > kStreamCacheBlocks || c.free_bytes > kStreamCacheBytes) {// the oldest blocks go back to the pool
+            (void) hipFreeAsync(c.free.front().p, c.free.front().s);
+            c.free_bytes -= c.free.front().cap;
+            c.free.erase(c.free.begin());
+        }
+    }
+
     // ---- scratch arena (common.hpp) ----------------------------------------------------------------------------------------------------------------------
     namespace {
         struct ArenaBlock {

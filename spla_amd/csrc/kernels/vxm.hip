@@ -86,9 +86,7 @@ namespace splahip {
         hipLaunchKernelGGL(chunk_sum_kernel, dim3(n_chunks), dim3(256), 0, s, x, n, chunk.as<uint>());
         hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk.as<uint>(), n_chunks);
         hipLaunchKernelGGL(chunk_scan_apply_kernel, dim3(n_chunks), dim3(256), 0, s, x, n, chunk.as<uint>(), n_chunks, out);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(s);// chunk is freed on return
-        return e;
+        return hipGetLastError();// (no synchronisation: `chunk` is released in stream order)
     }
 
     // last i in [0, n) with a[i] <= k, for a[0] <= k < a[n]
