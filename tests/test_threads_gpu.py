@@ -1,0 +1,57 @@
+"""Host threads: the library keeps its per-call workspaces per thread (scratch arena of mxm / mxmT, pinned staging arena, cache of released stream-ordered
+blocks — runtime.hip, mxm_spa.hip), so calls of different host threads on streams of their own must not disturb one another."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(scale, seed):
+    from spla_amd import graphgen
+    n, Ap, Aj = graphgen.rmat_csr(scale, 8, seed=seed, device="cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    Ax = torch.randint(1, 5, (int(Ap[-1]),), generator=g, device="cuda", dtype=torch.int32)
+    return n, (Ap, Aj, Ax)
+
+
+def _work(scale, seed):
+    """mxm (row classes: pinned arena + scratch arena), mxmT (scratch arena), a push vxm (stream-ordered blocks) and an mxv of one small R-MAT matrix."""
+    from spla_amd import kernels
+    n, A = _inputs(scale, seed)
+    R, _ = kernels.mxm("INT", n, n, A, A, "MULT", "PLUS", 0)
+    T = kernels.mxmT_masked("INT", n, A, A, A, "MULT", "PLUS", "ALWAYS", 0)
+    v = torch.ones(n, dtype=torch.int32, device="cuda")
+    r = torch.empty(n, dtype=torch.int32, device="cuda")
+    plan = kernels.CsrPlan(n, int(A[0][-1]), A[0])
+    kernels.mxv_masked(plan, "INT", n, A[0], A[1], A[2], torch.zeros(n, dtype=torch.int32, device="cuda"), v, r, "MULT", "PLUS", "ALWAYS", 0, False)
+    torch.cuda.current_stream().synchronize()
+    plan.close()
+    return [t.cpu().numpy() for t in (*R, *T, r)]
+
+
+def test_calls_of_four_host_threads_on_their_own_streams_match_the_single_threaded_results():
+    keys = ((13, 1), (12, 2))
+    want = {k: _work(*k) for k in keys}
+    errors = []
+
+    def runner(key):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(6):
+                    for a, b in zip(_work(*key), want[key]):
+                        if a.shape != b.shape or not np.array_equal(a, b):
+                            errors.append(f"{key}: a result differs from the single-threaded one")
+                            return
+        except Exception as e:  # noqa: BLE001  (reported by the assert below)
+            errors.append(f"{key}: {type(e).__name__}: {e}")
+
+    threads = [threading.Thread(target=runner, args=(k,)) for k in keys + keys]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:4]
