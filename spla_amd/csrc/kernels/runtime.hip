@@ -212,7 +212,7 @@ namespace splahip {
         }
         void stream_cache_trim() {// (run by release_idle_memory on the thread that ran out of memory, behind a device synchronisation)
             StreamCache& c = stream_cache();
-            for (StreamBlock& b : c.free) (void) hipFreeAsync(b.p, b.s);
+            for (StreamBlock& b : c.free) (void) hipFree(b.p);// (hipFree, not hipFreeAsync(b.s): the stream a block was released on may be gone by now)
             c.free.clear();
             c.free_bytes = 0;
         }
@@ -255,8 +255,8 @@ namespace splahip {
         register_trim(&stream_cache_trim);// (idempotent)
         c.free.push_back({p, cap, stream});
         c.free_bytes += cap;
-        while (c.free.size() > kStreamCacheBlocks || c.free_bytes > kStreamCacheBytes) {// the oldest blocks go back to the pool
-            (void) hipFreeAsync(c.free.front().p, c.free.front().s);
+        while (c.free.size() > kStreamCacheBlocks || c.free_bytes > kStreamCacheBytes) {// the oldest blocks go back to the pool (rare in steady state; hipFree waits for the
+            (void) hipFree(c.free.front().p);                                            // device: the stream the block was released on may no longer exist)
             c.free_bytes -= c.free.front().cap;
             c.free.erase(c.free.begin());
         }
