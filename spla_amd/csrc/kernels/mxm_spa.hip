@@ -61,6 +61,9 @@ namespace splahip {
 
         struct SpaArgs {
             const uint32_t *Ap, *Aj, *Ax, *Bp, *Bj, *Bx;
+            // B's entries as (column, value word) PAIRS, written once per call (pairs_kernel): the numeric walks read 8 bytes per product from ONE line instead of a
+            // column word and a value word from two — a short part (the ~4 entries of a row of B inside one accumulator block) was two or three line requests
+            const uint2* Bjx;
             // work items, largest first: a heavy row, or — for a row of millions of products — one range of its column blocks (the blocks of a row are
             // independent: a hub's row is walked by many workgroups at once)
             const uint32_t* item_row;
@@ -119,6 +122,8 @@ namespace splahip {
             uint32_t* s_len  = s_seg + kTpb;// long parts: their length (0 for a short one)
             uint32_t* s_av   = s_len + kTpb;
             uint32_t* s_tmp  = s_av + kTpb;// kTpb / 64 + 2 words
+            uint32_t* s_lidx = s_tmp + kTpb / 64 + 4;// the long parts of a walk, in no particular order (kTpb words)
+            __shared__ uint32_t s_nlong[2];          // how many: one counter per parity of the walk's number (zeroed for the next walk while this one runs)
             const uint32_t      tid = threadIdx.x;
             uint32_t*           cur = a.cursor + (size_t) blockIdx.x * a.max_deg;
             uint32_t            n_dropped = 0;
@@ -137,7 +142,9 @@ namespace splahip {
 #endif
             // the accumulator block and the touched bitmap start clean and are left clean by every emit pass (it resets what it reads): a block in
             // which the row holds no product costs a scan of its part lengths and nothing else
+            uint32_t walk_no = 0;// (uniform) walks made so far: which of the two long-part counters this walk uses
             {
+                if (tid < 2) s_nlong[tid] = 0;
                 for (uint32_t w = tid; w < a.block / 32; w += kTpb) s_bits[w] = 0;
                 if constexpr (NUMERIC) {
                     const word id = [] {
@@ -237,10 +244,18 @@ namespace splahip {
                         // are one coalesced run of B's row
                         const bool is_long = len >= kLongPart;
                         s_len[tid]         = (is_long ? len : 0u) | (in_win ? 0x80000000u : 0u);// bit 31: leave out the products whose column lies in the dense window
+                        // the long parts are LISTED (an LDS counter, any order): a wave then visits the long parts only.  Every wave reading all nk part lengths in
+                        // turn to find the few long ones — 64 dependent LDS reads per wave and walk — was half of the walk phase (round 5)
+                        uint32_t* const n_long_p = &s_nlong[walk_no & 1u];
+                        if (is_long) s_lidx[__hip_atomic_fetch_add(n_long_p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = tid;
                         uint32_t       total;
                         const uint32_t ex = block_exclusive_sum<kTpb>(is_long ? 0u : len, s_tmp, total);
                         s_pref[tid]       = ex;// threads beyond nk hold `total`: a sentinel for the search
-                        const bool any_long = __syncthreads_or(is_long ? 1 : 0) != 0;
+                        __syncthreads();
+                        const uint32_t n_long   = *n_long_p;
+                        const bool     any_long = n_long != 0;
+                        if (tid == 0) s_nlong[(walk_no + 1u) & 1u] = 0;// (the next walk's counter: its appends come behind this walk's closing barrier)
+                        ++walk_no;
                         block_products |= total | (any_long ? 1u : 0u);
                         SPA_T(tp1)
                         // four products per thread in flight: the searches and the column / value loads of four products first (indices clamped, so the loads
@@ -261,10 +276,11 @@ namespace splahip {
                                 }
                                 const uint32_t idx = s_seg[lo] + (p - s_pref[lo]);
                                 lo4[u]  = lo;
-                                col4[u] = a.Bj[idx];
-                                if constexpr (NUMERIC) x4[u] = a.Bx[idx];
-                                else
-                                    x4[u] = 0;
+                                if constexpr (NUMERIC) {
+                                    const uint2 cx = a.Bjx[idx];
+                                    col4[u] = cx.x, x4[u] = cx.y;
+                                } else
+                                    col4[u] = a.Bj[idx], x4[u] = 0;
                             }
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
@@ -281,9 +297,9 @@ namespace splahip {
                             }
                         }
                         if (any_long) {
-                            for (uint32_t t = tid / 64; t < nk; t += kTpb / 64) {
+                            for (uint32_t lj = tid / 64; lj < n_long; lj += kTpb / 64) {
+                                const uint32_t t = s_lidx[lj];
                                 const uint32_t n = s_len[t] & 0x7FFFFFFFu;
-                                if (n == 0) continue;// (uniform per wavefront)
                                 const bool     win = dense_rows && (s_len[t] >> 31);
                                 const uint32_t b0 = s_seg[t];
                                 T              av = T();
@@ -293,10 +309,11 @@ namespace splahip {
 #pragma unroll
                                     for (int u = 0; u < 4; ++u) {
                                         const uint32_t pp = min(p + 64u * (uint32_t) u, n - 1u);
-                                        col4[u]           = a.Bj[b0 + pp];
-                                        if constexpr (NUMERIC) x4[u] = a.Bx[b0 + pp];
-                                        else
-                                            x4[u] = 0;
+                                        if constexpr (NUMERIC) {
+                                            const uint2 cx = a.Bjx[b0 + pp];
+                                            col4[u] = cx.x, x4[u] = cx.y;
+                                        } else
+                                            col4[u] = a.Bj[b0 + pp], x4[u] = 0;
                                     }
 #pragma unroll
                                     for (int u = 0; u < 4; ++u) {
@@ -414,8 +431,10 @@ namespace splahip {
                 for (uint32_t s0 = cb; s0 < ce; s0 += wr) {
                     const uint32_t s1 = min(ce, s0 + wr), words = (s1 - s0 + 31) / 32;
                     const bool     to_end = s1 >= a.b_cols;
-                    // one walk over the products of (row i, columns [s0, s1)): fn(value word of a_ik, index into B's arrays, column - s0)
-                    auto walk = [&](auto fn) {
+                    // one walk over the products of (row i, columns [s0, s1)): fn(value word of a_ik, column - s0, value word of b_kj — read, with the column, from the
+                    // pairs when `pairs` says so); four products per thread in flight, like the blocked form's walk
+                    auto walk = [&](auto pairs, auto fn) {
+                        constexpr bool kPairs = decltype(pairs)::value;
                         for (uint32_t kc = 0; kc < deg; kc += kTpb) {
                             const uint32_t nk  = min(kTpb, deg - kc);
                             uint32_t       len = 0;
@@ -431,23 +450,38 @@ namespace splahip {
                             const uint32_t ex = block_exclusive_sum<kTpb>(len, s_tmp, total);
                             s_pref[tid]       = ex;
                             __syncthreads();
-                            for (uint32_t p = tid; p < total; p += kTpb) {
-                                uint32_t lo = 0, hi = nk;
-                                while (hi - lo > 1) {
-                                    const uint32_t mid = (lo + hi) >> 1;
-                                    if (s_pref[mid] <= p) lo = mid;
-                                    else
-                                        hi = mid;
+                            for (uint32_t p0 = tid; p0 < total; p0 += 4u * kTpb) {
+                                uint32_t lo4[4], col4[4], x4[4];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const uint32_t p = min(p0 + (uint32_t) u * kTpb, total - 1u);
+                                    uint32_t       lo = 0, hi = nk;
+                                    while (hi - lo > 1) {
+                                        const uint32_t mid = (lo + hi) >> 1;
+                                        if (s_pref[mid] <= p) lo = mid;
+                                        else
+                                            hi = mid;
+                                    }
+                                    const uint32_t idx = s_seg[lo] + (p - s_pref[lo]);
+                                    lo4[u]             = lo;
+                                    if constexpr (kPairs) {
+                                        const uint2 cx = a.Bjx[idx];
+                                        col4[u] = cx.x, x4[u] = cx.y;
+                                    } else
+                                        col4[u] = a.Bj[idx], x4[u] = 0;
                                 }
-                                const uint32_t idx = s_seg[lo] + (p - s_pref[lo]);
-                                fn(s_av[lo], idx, a.Bj[idx] - s0);
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    if (p0 + (uint32_t) u * kTpb >= total) break;
+                                    fn(s_av[lo4[u]], col4[u] - s0, x4[u]);
+                                }
                             }
                             __syncthreads();
                         }
                     };
                     for (uint32_t w = tid; w < words; w += kTpb) s_bits[w] = 0;
                     __syncthreads();
-                    walk([&](uint32_t, uint32_t, uint32_t col) { (void) __hip_atomic_fetch_or(s_bits + (col >> 5), 1u << (col & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); });
+                    walk(std::false_type{}, [&](uint32_t, uint32_t col, uint32_t) { (void) __hip_atomic_fetch_or(s_bits + (col >> 5), 1u << (col & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); });
                     // ranks: exclusive popcount prefix over the bitmap words
                     uint32_t cnt = 0;
                     for (uint32_t w0 = 0; w0 < words; w0 += kTpb) {
@@ -459,9 +493,9 @@ namespace splahip {
                     }
                     for (uint32_t j = tid; j < cnt; j += kTpb) s_acc[j] = id;
                     __syncthreads();
-                    walk([&](uint32_t av, uint32_t idx, uint32_t col) {
+                    walk(std::true_type{}, [&](uint32_t av, uint32_t col, uint32_t xw) {
                         const uint32_t pos  = s_rank[col >> 5] + __popc(s_bits[col >> 5] & ((1u << (col & 31)) - 1u));
-                        const T        prod = mult(from_bits<T>(av), from_bits<T>(a.Bx[idx]));
+                        const T        prod = mult(from_bits<T>(av), from_bits<T>(xw));
                         if constexpr (sizeof(word) == 8) (void) __hip_atomic_fetch_add(s_acc + pos, (double) prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         else
                             cob_accumulate<T, ACC>(s_acc + pos, prod);
@@ -486,6 +520,16 @@ namespace splahip {
                 }
             }
             if (n_dropped) atomicAdd(a.dropped, n_dropped);
+        }
+
+        // (column, value word) pairs of B's first n entries (n read on the device: hint[1], left by max_col_tail_kernel)
+        __global__ __launch_bounds__(256) void pairs_kernel(const uint32_t* __restrict__ hint, const uint32_t* __restrict__ Bj, const uint32_t* __restrict__ Bx, uint2* __restrict__ out) {
+            const uint32_t n = hint[1];
+            for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) out[k] = make_uint2(Bj[k], Bx[k]);
+        }
+        // hint[0] = the largest inner index A refers to (max_col_kernel); hint[1] = entries of the rows of B up to it = what a call can read of B
+        __global__ void max_col_tail_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, uint32_t* __restrict__ hint, const uint32_t* __restrict__ Bp) {
+            hint[1] = Ap[n_rows] ? Bp[hint[0] + 1] : 0u;// (A without entries refers to no row of B)
         }
 
         // bblk[k][j]: a thread per (row of B, block edge)
@@ -890,13 +934,18 @@ namespace splahip {
         template<typename T, class Mult, int ACC>
         int spa_run(uint32_t a_rows, uint32_t b_cols, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const uint32_t* Bp, const uint32_t* Bj, const void* Bx, uint32_t* Rp,
                     uint32_t** Rj, void** Rx, uint32_t* h_nnz, const u64* hP, const u64* dP, const uint32_t* hAp, const uint32_t* h_order, int op_mult, int op_add,
-                    uint32_t init_bits, uint32_t b_rows_hint, hipStream_t s) {
+                    uint32_t init_bits, uint32_t b_rows_hint, const uint32_t* d_hint, uint32_t b_nnz_hint, hipStream_t s) {
             using word      = typename CobSlice<T, ACC>::word;
             constexpr int t = TypeId<T>::value;
             Scratch       tmp(s);
             hipError_t    e = hipSuccess;
             spa_trace("start", s);
             host_mark("call start");
+            // B as (column, value) pairs for the numeric walks (8 bytes per entry of scratch, one pass)
+            uint2* d_bjx = nullptr;
+            e            = tmp.alloc(&d_bjx, b_nnz_hint);
+            if (e != hipSuccess) return fail(SPLAHIP_ERROR, "mxm (row classes): %s", hipGetErrorString(e));
+            if (b_nnz_hint) hipLaunchKernelGGL(pairs_kernel, dim3(std::min<uint32_t>(4096u, (b_nnz_hint + 255) / 256)), dim3(256), 0, s, d_hint, Bj, static_cast<const uint32_t*>(Bx), d_bjx);
             // heavy rows, largest first: the front of h_order (rows by descending product count, sorted on the device)
             std::vector<uint32_t> heavy;
             uint32_t              max_deg = 1;
@@ -1006,7 +1055,7 @@ namespace splahip {
             int dev = 0, cus = 256;
             (void) hipGetDevice(&dev);
             (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            const uint32_t extra = sizeof(uint32_t) * (4 * kTpb + 1 + kTpb / 64 + 4);
+            const uint32_t extra = sizeof(uint32_t) * (5 * kTpb + 1 + kTpb / 64 + 4);
             // numeric: accumulator block + bitmap; symbolic: bitmap only (a much wider block)
             // columns per accumulator block of the blocked numeric form.  SPLAHIP_MXM_BLOCK_KB: its LDS footprint, default 128 KB = one workgroup
             // per CU.  Every (row, block) step pays a scan of the row's part lengths, an emit scan and six barriers whatever it holds, and a
@@ -1169,7 +1218,7 @@ namespace splahip {
                 const size_t cells = (size_t) b_rows_hint * (nb_num + 1);
                 hipLaunchKernelGGL(bblk_kernel, dim3((unsigned) ((cells + 255) / 256)), dim3(256), 0, s, b_rows_hint, nb_num, blk_num, Bp, Bj, d_bblk);
             }
-            SpaArgs a{Ap, Aj, static_cast<const uint32_t*>(Ax), Bp, Bj, static_cast<const uint32_t*>(Bx), d_item, d_item + n_items, d_item + 2 * (size_t) n_items, d_out, n_items, b_cols,
+            SpaArgs a{Ap, Aj, static_cast<const uint32_t*>(Ax), Bp, Bj, static_cast<const uint32_t*>(Bx), d_bjx, d_item, d_item + n_items, d_item + 2 * (size_t) n_items, d_out, n_items, b_cols,
                       blk_sym, d_bblk, blk_num, nb_num, d_cursor, max_deg, d_counts, nullptr, nullptr, d_dropped, d_i0, d_k0, d_j0, d_hi, d_hk, d_hj, dC, dN};
             const T init = from_bits<T>(init_bits);
             if (n_items) {
@@ -1330,9 +1379,9 @@ namespace splahip {
         template<typename T, int ACC>
         int spa_by_mult(uint32_t a_rows, uint32_t b_cols, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const uint32_t* Bp, const uint32_t* Bj, const void* Bx, uint32_t* Rp,
                         uint32_t** Rj, void** Rx, uint32_t* h_nnz, const u64* hP, const u64* dP, const uint32_t* hAp, const uint32_t* h_order, int op_mult, int op_add,
-                        uint32_t init_bits, uint32_t b_rows_hint, hipStream_t s) {
-            if (op_mult == SPLAHIP_MULT) return spa_run<T, StaBin<SPLAHIP_MULT>, ACC>(a_rows, b_cols, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, hP, dP, hAp, h_order, op_mult, op_add, init_bits, b_rows_hint, s);
-            return spa_run<T, DynBin, ACC>(a_rows, b_cols, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, hP, dP, hAp, h_order, op_mult, op_add, init_bits, b_rows_hint, s);
+                        uint32_t init_bits, uint32_t b_rows_hint, const uint32_t* d_hint, uint32_t b_nnz_hint, hipStream_t s) {
+            if (op_mult == SPLAHIP_MULT) return spa_run<T, StaBin<SPLAHIP_MULT>, ACC>(a_rows, b_cols, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, hP, dP, hAp, h_order, op_mult, op_add, init_bits, b_rows_hint, d_hint, b_nnz_hint, s);
+            return spa_run<T, DynBin, ACC>(a_rows, b_cols, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, hP, dP, hAp, h_order, op_mult, op_add, init_bits, b_rows_hint, d_hint, b_nnz_hint, s);
         }
 
         __global__ __launch_bounds__(256) void max_col_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ Aj, uint32_t* __restrict__ out) {
@@ -1370,8 +1419,8 @@ namespace splahip {
         Scratch      tmp(s);
         u64*      dP    = nullptr;
         uint32_t* d_max = nullptr;
-        if (tmp.alloc(&dP, a_rows) != hipSuccess || tmp.alloc(&d_max, 1) != hipSuccess) return -1;
-        SPLAHIP_TRY(hipMemsetAsync(d_max, 0, 4, s));
+        if (tmp.alloc(&dP, a_rows) != hipSuccess || tmp.alloc(&d_max, 2) != hipSuccess) return -1;
+        SPLAHIP_TRY(hipMemsetAsync(d_max, 0, 8, s));
         // rows by descending product count, ties by row number (a stable device sort: the same order std::stable_sort gave, which cost the host 4 ms per R-MAT 18 call)
         u64*      dPs   = nullptr;
         uint32_t *d_ids = nullptr, *d_order = nullptr;
@@ -1386,12 +1435,13 @@ namespace splahip {
         }
         // the number of rows of B is not an argument of splahip_mxm: the largest inner index A refers to bounds what the dense corner may touch
         hipLaunchKernelGGL(max_col_kernel, dim3(1024), dim3(256), 0, s, a_rows, Ap, Aj, d_max);
+        hipLaunchKernelGGL(max_col_tail_kernel, dim3(1), dim3(1), 0, s, a_rows, Ap, d_max, Bp);
         u64*      hP    = nullptr;
         uint32_t *hAp = nullptr, *h_maxp = nullptr, *h_order = nullptr;
         SPLAHIP_TRY(d2h(&hP, dP, a_rows, s));
         SPLAHIP_TRY(d2h(&h_order, d_order, a_rows, s));
         SPLAHIP_TRY(d2h(&hAp, Ap, (size_t) a_rows + 1, s));
-        SPLAHIP_TRY(d2h(&h_maxp, d_max, 1, s));
+        SPLAHIP_TRY(d2h(&h_maxp, d_max, 2, s));
         SPLAHIP_TRY(hipStreamSynchronize(s));
         u64  total = 0;
         bool heavy = false;
@@ -1400,7 +1450,7 @@ namespace splahip {
         if (h_products) *h_products = total;
         const uint32_t h_max = *h_maxp;
         const uint32_t b_rows_hint = h_max + 1;
-#define SPLAHIP_SPA(TT, AA) return spa_by_mult<TT, AA>(a_rows, b_cols, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, hP, dP, hAp, h_order, op_mult, op_add, init_bits, b_rows_hint, s)
+#define SPLAHIP_SPA(TT, AA) return spa_by_mult<TT, AA>(a_rows, b_cols, Ap, Aj, Ax, Bp, Bj, Bx, Rp, Rj, Rx, h_nnz, hP, dP, hAp, h_order, op_mult, op_add, init_bits, b_rows_hint, d_max, h_maxp[1], s)
         switch (type) {
             case SPLAHIP_FLOAT:
                 if (acc == COB_ADD) SPLAHIP_SPA(float, COB_ADD);
