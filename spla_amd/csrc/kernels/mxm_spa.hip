@@ -53,7 +53,10 @@ namespace splahip {
 
         using u64 = unsigned long long;
         constexpr unsigned kTpb   = 1024;
-        constexpr unsigned kLongPart = 128;// products of one (A entry, column block) part from which a wavefront walks the part on its own
+#ifndef SPLAHIP_MXM_LONG
+#define SPLAHIP_MXM_LONG 128
+#endif
+        constexpr unsigned kLongPart = SPLAHIP_MXM_LONG;// products of one (A entry, column block) part from which a wavefront walks the part on its own
         const u64 kLight = [] {// rows with at most this many products go to the ESC form
             const char* e = knob_env("SPLAHIP_MXM_LIGHT");
             return e && *e ? (u64) std::strtoull(e, nullptr, 10) : 4096ull;
