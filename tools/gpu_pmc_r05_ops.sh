@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 5: counter passes (separate rocprofv3 --pmc runs) of the SSSP step of configs[3] and of the PageRank pull step on the round-5 layout of the blocks
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp; export TMPDIR=/tmp; mkdir -p "$R/gpurun_out"
+want() { [ -z "$ONLY" ] || [[ " $ONLY " == *" $1 "* ]]; }   # ONLY="mxm tc_mxmT" tools/gpu_pmc_r05_ops.sh: just those passes
 run() { # name, reference kernel, other kernels (|-separated), command...
   name=$1; ref=$2; others=$3; shift 3
   rm -rf "$R/gpurun_out/pmc_r05/$name"
@@ -26,10 +27,11 @@ print(json.dumps(out["_per_call"]))
 PY
   find "$R/gpurun_out/pmc_r05/$name" -name "*.csv" -size +1M -delete
 }
-run sssp_step "cob_mxv_kernel<int" "cob_hub_finish_kernel<int|cob_vbits_kernel<int" python3 "$R/bench.py" --workload sssp-step --steps 5 --warmup 2 --no-cpu-baseline --no-verify
-run pagerank_vxm_orkut_like "cob_mxv_kernel<float" "cob_hub_finish_kernel<float|flag_write_kernel" python3 "$R/bench.py" --workload pagerank-vxm --steps 5 --warmup 2 --no-cpu-baseline --no-verify
+want sssp_step && run sssp_step "cob_mxv_kernel<int" "cob_hub_finish_kernel<int|cob_vbits_kernel<int" python3 "$R/bench.py" --workload sssp-step --steps 5 --warmup 2 --no-cpu-baseline --no-verify
+want pagerank_vxm_orkut_like && run pagerank_vxm_orkut_like "cob_mxv_kernel<float" "cob_hub_finish_kernel<float|flag_write_kernel" python3 "$R/bench.py" --workload pagerank-vxm --steps 5 --warmup 2 --no-cpu-baseline --no-verify
 # the BFS step of configs[1] (profiles/pmc_traffic.json was round 2's pass): the three kernels of the sliced-ELL bit form
 # (round 5: the step runs on the first-hit kernel; the sliced-ELL form of the same step with SPLAHIP_FIRST_HIT=0)
+if want bfs_step; then
 run bfs_step "mxv_first_hit_kernel<int" "vstat_kernel<int" python3 "$R/bench.py" --workload bfs-step --steps 10 --warmup 3 --no-cpu-baseline --no-verify --no-variants
 export SPLAHIP_FIRST_HIT=0
 run bfs_step_sell "sell_mxv_dual_kernel<int" "sell_vprep_kernel<int|sell_post_kernel<int" python3 "$R/bench.py" --workload bfs-step --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-variants
@@ -47,6 +49,7 @@ out = {"kernel": "vstat_kernel<int>|mxv_first_hit_kernel<int>", "traffic_bytes":
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("traffic_bytes", "algorithmic_bytes", "traffic_over_algorithmic")}))
 PY
+fi
 # round 5: the two SpGEMM workloads on this round's forms (owner form of mxmT; mxm with the light rows in LDS)
-run tc_mxmT "mxmT_owner_kernel<int" "mxmT_entry_kernel<int|mxmT_compact_kernel|mxmT_heavy_kernel<int|mxmT_merge_kernel<int|onesweep_iteration_kernel|onesweep_histograms_kernel" python3 "$R/bench.py" --workload tc-mxmT --steps 5 --warmup 2 --no-cpu-baseline --no-verify
-run mxm "mxm_spa_kernel<float, splahip::StaBin<2>, 0, true" "mxm_spa_kernel<float, splahip::StaBin<2>, 0, false|mxm_spa_ranked_kernel<float|light_batch_kernel<float|place_light_kernel|rowprod_kernel" python3 "$R/bench.py" --workload mxm --steps 3 --warmup 1 --no-cpu-baseline --no-verify
+want tc_mxmT && run tc_mxmT "mxmT_owner_kernel<int" "mxmT_entry_kernel<int|mxmT_compact_kernel|mxmT_heavy_kernel<int|mxmT_merge_kernel<int|onesweep_iteration_kernel|onesweep_histograms_kernel" python3 "$R/bench.py" --workload tc-mxmT --steps 5 --warmup 2 --no-cpu-baseline --no-verify
+want mxm && run mxm "mxm_spa_kernel<float, splahip::StaBin<2>, 0, true" "mxm_spa_kernel<float, splahip::StaBin<2>, 0, false|mxm_spa_ranked_kernel<float|light_batch_kernel<float|place_light_kernel|rowprod_kernel" python3 "$R/bench.py" --workload mxm --steps 3 --warmup 1 --no-cpu-baseline --no-verify
