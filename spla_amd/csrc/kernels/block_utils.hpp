@@ -12,13 +12,14 @@ namespace splahip {
     __device__ __forceinline__ unsigned wave_id() { return threadIdx.x / kWave; }
 
     // inclusive prefix sum across the 64 lanes of a wave
+    // (DPP row shifts and row broadcasts: six VALU adds — the ds_bpermute form, __shfl_up, was six LDS-crossbar round trips of ~60 cycles each)
     __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
-        const unsigned lane = lane_id();
-#pragma unroll
-        for (unsigned off = 1; off < kWave; off <<= 1) {
-            uint32_t y = __shfl_up(x, off, kWave);
-            if (lane >= off) x += y;
-        }
+        x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x111, 0xF, 0xF, false);// row_shr:1
+        x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x112, 0xF, 0xF, false);// row_shr:2
+        x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x114, 0xF, 0xF, false);// row_shr:4
+        x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x118, 0xF, 0xF, false);// row_shr:8
+        x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x142, 0xA, 0xF, false);// row_bcast:15 into rows 1 and 3
+        x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x143, 0xC, 0xF, false);// row_bcast:31 into rows 2 and 3
         return x;
     }
 
@@ -45,20 +46,14 @@ namespace splahip {
         const uint32_t     inc  = wave_inclusive_sum(x);
         if (lane == kWave - 1) s_tmp[wave] = inc;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t run = 0;
-            for (unsigned w = 0; w < NW; ++w) {
-                uint32_t t = s_tmp[w];
-                s_tmp[w]   = run;
-                run += t;
-            }
-            s_tmp[NW] = run;
-        }
-        __syncthreads();
-        const uint32_t res = s_tmp[wave] + inc - x;
-        total              = s_tmp[NW];
+        // every wave scans the NW wave totals itself (one LDS read, one wave scan): thread 0 walking them one by one — 16 dependent LDS round trips with a
+        // barrier on either side, 1023 threads waiting — was ~2.5 K cycles per call, 5 K of the 26 K cycles of a block step of mxm (round 5)
+        const uint32_t wt   = lane < NW ? s_tmp[lane] : 0u;
+        const uint32_t winc = wave_inclusive_sum(wt);
+        const uint32_t base = (uint32_t) __builtin_amdgcn_readlane((int) (winc - wt), __builtin_amdgcn_readfirstlane((int) wave));
+        total               = (uint32_t) __builtin_amdgcn_readlane((int) winc, (int) NW - 1);
         __syncthreads();// s_tmp may be reused by the caller
-        return res;
+        return base + inc - x;
     }
 
     // In-order wave reduction of (valid, value) pairs with an arbitrary associative op: after the call lane 0 holds
