@@ -24,16 +24,18 @@ namespace splahip {
     }
 
     // sum across the 64 lanes of a wave, result valid in every lane
-    __device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
-#pragma unroll
-        for (unsigned off = kWave / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
-        return x;
+    __device__ __forceinline__ uint32_t wave_sum(uint32_t x) {// (the scan's last lane, read back as a scalar: no LDS crossbar)
+        return (uint32_t) __builtin_amdgcn_readlane((int) wave_inclusive_sum(x), (int) kWave - 1);
     }
 
-    __device__ __forceinline__ uint32_t wave_max(uint32_t x) {
-#pragma unroll
-        for (unsigned off = kWave / 2; off > 0; off >>= 1) x = max(x, (uint32_t) __shfl_xor(x, off, kWave));
-        return x;
+    __device__ __forceinline__ uint32_t wave_max(uint32_t x) {// (an inclusive max-scan on the same DPP pattern; 0 is the identity of an unsigned max)
+        x = max(x, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x111, 0xF, 0xF, false));
+        x = max(x, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x112, 0xF, 0xF, false));
+        x = max(x, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x114, 0xF, 0xF, false));
+        x = max(x, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x118, 0xF, 0xF, false));
+        x = max(x, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x142, 0xA, 0xF, false));
+        x = max(x, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x143, 0xC, 0xF, false));
+        return (uint32_t) __builtin_amdgcn_readlane((int) x, (int) kWave - 1);
     }
 
     // Exclusive prefix sum of one value per thread across a workgroup of NT threads (NT multiple of 64, <= 1024).
