@@ -11,7 +11,8 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 tend = int(rows[-1]["End_Timestamp"])
-rows = [r for r in rows if int(r["Start_Timestamp"]) > tend - 60e6]
+import os
+rows = [r for r in rows if int(r["Start_Timestamp"]) > tend - float(os.environ.get("WINDOW_MS", "60")) * 1e6]
 t0 = int(rows[0]["Start_Timestamp"]); prev_end = t0
 for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
