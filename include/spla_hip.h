@@ -314,7 +314,9 @@ int splahip_mxm_last_info(uint32_t* n_heavy_rows, uint32_t* light_nnz, uint32_t*
  * half-full 32 x 32 tiles found ANYWHERE in the operands (fp32 MULT / PLUS), went through the matrix cores (LDS-staged v_mfma_f32_32x32x2_f32); rows == 0: none.
  * (reference: the accumulator row of Algo_mxm_cpu, src/cpu/cpu_mxm.hpp:93-113, restricted to the window's cells) */
 int splahip_mxm_last_dense(uint32_t* window6);
-/* mxm keeps its GB-sized workspaces between calls (per host thread, grow-only); this returns them to the driver */
+/* mxm / mxmT keep device memory between calls, per host thread: mxm's GB-sized ESC workspaces (grow-only), the scratch arena of the blocking calls and the cached
+ * result arrays that were handed back with splahip_free.  This returns the calling thread's share to the driver; any allocation of the library
+ * that runs out of memory does the same before it retries. */
 int splahip_mxm_trim(void);
 
 /* ---- vector operations between two hot-path calls of a traversal --------------------------------
