@@ -57,9 +57,12 @@ namespace splahip {
 #define SPLAHIP_MXM_LONG 128
 #endif
         constexpr unsigned kLongPart = SPLAHIP_MXM_LONG;// products of one (A entry, column block) part from which a wavefront walks the part on its own
+#ifndef SPLAHIP_MXM_LIGHT_DEFAULT
+#define SPLAHIP_MXM_LIGHT_DEFAULT 2048// (a light row has to fit one batch)
+#endif
         const u64 kLight = [] {// rows with at most this many products go to the ESC form
             const char* e = knob_env("SPLAHIP_MXM_LIGHT");
-            return e && *e ? (u64) std::strtoull(e, nullptr, 10) : 4096ull;
+            return e && *e ? (u64) std::strtoull(e, nullptr, 10) : (u64) SPLAHIP_MXM_LIGHT_DEFAULT;
         }();
 
         struct SpaArgs {
@@ -576,7 +579,13 @@ namespace splahip {
         //            how many there are.
         // No global sort, no expanded products in HBM (the ESC form wrote 12 bytes per product and radix-sorted them in five passes: 15 ms of a 61 ms R-MAT 18
         // call for 3 % of its products), exact for every op (fp32 PLUS included).  The rows' entries are copied to their place once the row pointers are known.
-        constexpr uint32_t kBatchCap = 4096, kBatchRows = 512, kBatchTpb = 512;
+#ifndef SPLAHIP_MXM_BATCH_CAP
+#define SPLAHIP_MXM_BATCH_CAP 2048// (round 5, whole call at R-MAT 18: 4096 products / 512 threads 40.75 ms, 2048 / 512 39.8, 2048 / 256 40.0, 1024 / 256 40.85: four workgroups per CU hide the batch's load chains)
+#endif
+#ifndef SPLAHIP_MXM_BATCH_TPB
+#define SPLAHIP_MXM_BATCH_TPB 512
+#endif
+        constexpr uint32_t kBatchCap = SPLAHIP_MXM_BATCH_CAP, kBatchRows = 512, kBatchTpb = SPLAHIP_MXM_BATCH_TPB;
         template<typename T, class Mult, class Add>
         __global__ __launch_bounds__(kBatchTpb) void light_batch_kernel(const uint32_t* __restrict__ batch_first, const uint32_t* __restrict__ light_rows, const uint32_t* __restrict__ light_eoff,
                                                                   const u64* __restrict__ batch_poff,
