@@ -256,6 +256,59 @@ namespace splahip {
             seen = prev;
         }
     }
+    // The same expansion with the product -> frontier-entry search taken off the critical chain.  part[b] = the frontier entry that holds product 256 b
+    // (push_part_kernel: one 20-step search per WORKGROUP of the expansion, all of them in one small launch); the workgroup then brings the offsets of its
+    // entries [part[b], part[b + 1]] into LDS with one coalesced load and every thread searches THERE.  A thread of push_atomic_kernel walked ~26 dependent
+    // memory operations (20 of them the search over `offs` in L2); here ~8.  Workgroups whose 256 products span more than kPushSpan entries (runs of empty rows)
+    // keep the global search.
+    constexpr uint kPushSpan = 768;
+    __global__ __launch_bounds__(256) void push_part_kernel(uint n_blocks, uint nvals, const uint* __restrict__ offs, uint* __restrict__ part) {
+        const uint b = blockIdx.x * 256 + threadIdx.x;
+        if (b < n_blocks) part[b] = upper_row(offs, nvals, b * 256u);
+        if (b == n_blocks) part[b] = nvals - 1u;
+    }
+    template<typename T, class Mult, class Add>
+    __global__ __launch_bounds__(256) void push_atomic_blocked_kernel(uint n_products, uint nvals, const uint* __restrict__ offs, const uint* __restrict__ part,
+                                                                      const uint* __restrict__ vi, const T* __restrict__ vx, const uint* __restrict__ Ap,
+                                                                      const uint* __restrict__ Aj, const uint* __restrict__ Ax, const T* __restrict__ mask, int op_select,
+                                                                      Mult mult, Add add, u64* __restrict__ acc, uint* __restrict__ nan_seen) {
+        __shared__ uint s_offs[kPushSpan];
+        const uint      r_lo = part[blockIdx.x], r_hi = part[blockIdx.x + 1], n_r = r_hi - r_lo + 1u;
+        const bool      local = n_r <= kPushSpan;// (uniform)
+        if (local)
+            for (uint i = threadIdx.x; i < n_r; i += 256) s_offs[i] = offs[r_lo + i];
+        __syncthreads();
+        const uint p = blockIdx.x * 256 + threadIdx.x;
+        if (p >= n_products) return;
+        uint idx;
+        if (local) {
+            uint lo = 0, hi = n_r;// largest i with s_offs[i] <= p (s_offs[0] <= 256 b <= p)
+            while (hi - lo > 1) {
+                const uint mid = lo + ((hi - lo) >> 1);
+                if (s_offs[mid] <= p) lo = mid;
+                else
+                    hi = mid;
+            }
+            idx = r_lo + lo;
+        } else
+            idx = upper_row(offs, nvals, p);
+        const uint k = Ap[vi[idx]] + (p - (local ? s_offs[idx - r_lo] : offs[idx]));
+        const uint j = Aj[k];
+        if (!eval_sel(op_select, mask[j])) return;
+        const T prod = mult(vx[idx], from_bits<T>(Ax[k]));
+        if (lead_nan_sticks(add, prod)) *nan_seen = 1u;// fp32 MIN / MAX: whether a NaN sticks depends on the fold order -> the host redoes the call in the sort form
+        u64*    slot = acc + j;
+        u64     seen = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (true) {
+            const bool touched = (seen >> 32) != 0;
+            const T    next    = touched ? add(from_bits<T>((uint) seen), prod) : prod;
+            const u64  want    = (1ull << 32) | (u64) to_bits(next);
+            if (want == seen) break;// nothing to change (e.g. OR-ing a bit that is set, MIN with a larger value)
+            const u64 prev = atomicCAS(slot, seen, want);
+            if (prev == seen) break;
+            seen = prev;
+        }
+    }
     __global__ __launch_bounds__(256) void acc_count_kernel(const u64* __restrict__ acc, uint n, uint* __restrict__ chunk) {
         __shared__ uint s_tmp[256 / kWave + 1];
         const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
@@ -701,15 +754,27 @@ namespace splahip {
         const uint  atomic_max = pm_env && *pm_env ? (uint) std::strtoul(pm_env, nullptr, 10) : kPushAtomicMax;
         if (n_products <= atomic_max && push_order_free(op_add, TypeId<T>::value) && !push_atomic_disabled()) {
             const uint n_chunks = (n_cols + 1023u) / 1024u;
-            DevMem     body;// acc[n_cols] (8 bytes each) | chunk[n_chunks + 1] | NaN-seen flag
-            SPLAHIP_TRY(body.alloc(s, sizeof(u64) * (size_t) n_cols + sizeof(uint) * ((size_t) n_chunks + 2)));
+            const uint n_blocks = (n_products + 255u) / 256u;
+            DevMem     body;// acc[n_cols] (8 bytes each) | chunk[n_chunks + 1] | NaN-seen flag | part[n_blocks + 1]
+            SPLAHIP_TRY(body.alloc(s, sizeof(u64) * (size_t) n_cols + sizeof(uint) * ((size_t) n_chunks + 2 + (size_t) n_blocks + 1)));
             u64*  acc   = body.as<u64>();
             uint* chunk = reinterpret_cast<uint*>(acc + n_cols);
+            uint* part  = chunk + n_chunks + 2;
             SPLAHIP_TRY(hipMemsetAsync(acc, 0, sizeof(u64) * (size_t) n_cols, s));
             SPLAHIP_TRY(hipMemsetAsync(chunk + n_chunks + 1, 0, sizeof(uint), s));
-            hipLaunchKernelGGL((push_atomic_kernel<T, DynBin, DynBin>), dim3((n_products + 255) / 256), dim3(256), 0, s, n_products, nvals, offs, vi,
-                               static_cast<const T*>(vx), Ap, Aj, static_cast<const uint*>(Ax), static_cast<const T*>(mask), op_select, DynBin(op_mult),
-                               DynBin(op_add), acc, chunk + n_chunks + 1);
+            static const bool blocked = [] {// SPLAHIP_PUSH_BLOCKED=0: every thread searches `offs` in global memory (the form of rounds 2 - 4)
+                const char* e = knob_env("SPLAHIP_PUSH_BLOCKED");
+                return !(e && e[0] == '0');
+            }();
+            if (blocked) {
+                hipLaunchKernelGGL(push_part_kernel, dim3((n_blocks + 1 + 255) / 256), dim3(256), 0, s, n_blocks, nvals, offs, part);
+                hipLaunchKernelGGL((push_atomic_blocked_kernel<T, DynBin, DynBin>), dim3(n_blocks), dim3(256), 0, s, n_products, nvals, offs, part, vi,
+                                   static_cast<const T*>(vx), Ap, Aj, static_cast<const uint*>(Ax), static_cast<const T*>(mask), op_select, DynBin(op_mult),
+                                   DynBin(op_add), acc, chunk + n_chunks + 1);
+            } else
+                hipLaunchKernelGGL((push_atomic_kernel<T, DynBin, DynBin>), dim3(n_blocks), dim3(256), 0, s, n_products, nvals, offs, vi,
+                                   static_cast<const T*>(vx), Ap, Aj, static_cast<const uint*>(Ax), static_cast<const T*>(mask), op_select, DynBin(op_mult),
+                                   DynBin(op_add), acc, chunk + n_chunks + 1);
             hipLaunchKernelGGL(acc_count_kernel, dim3(n_chunks), dim3(256), 0, s, acc, n_cols, chunk);
             hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk, n_chunks);
             hipLaunchKernelGGL(acc_write_kernel, dim3(n_chunks), dim3(256), 0, s, acc, n_cols, chunk, ri, static_cast<uint*>(rx));
