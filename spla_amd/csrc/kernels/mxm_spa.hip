@@ -57,6 +57,10 @@ namespace splahip {
 #define SPLAHIP_MXM_LONG 128
 #endif
         constexpr unsigned kLongPart = SPLAHIP_MXM_LONG;// products of one (A entry, column block) part from which a wavefront walks the part on its own
+#ifndef SPLAHIP_MXM_WALK_DEPTH
+#define SPLAHIP_MXM_WALK_DEPTH 2// (whole call at R-MAT 18: depth 1 / 2 38.3 - 38.5 ms, 3 39.3, 4 39.4 - 39.9, 6 41.9, 8 43.4 - 44.0: a step holds ~4.4 products per thread, deeper turns search and load for nothing)
+#endif
+        constexpr unsigned kWalkDepth = SPLAHIP_MXM_WALK_DEPTH;// products per thread in flight in the flat walk of a block step
 #ifndef SPLAHIP_MXM_LIGHT_DEFAULT
 #define SPLAHIP_MXM_LIGHT_DEFAULT 2048// (a light row has to fit one batch)
 #endif
@@ -264,14 +268,14 @@ namespace splahip {
                         ++walk_no;
                         block_products |= total | (any_long ? 1u : 0u);
                         SPA_T(tp1)
-                        // four products per thread in flight: the searches and the column / value loads of four products first (indices clamped, so the loads
+                        // kWalkDepth products per thread in flight: their searches and column / value loads first (indices clamped, so the loads
                         // stand outside every branch and the compiler waits once), then their LDS atomics.  One product per turn was one global round trip per
                         // turn: a block step of ~4.5 K products walked in five dependent round trips (round 5: 28.9 ms of a 57 ms call at R-MAT 18)
-                        for (uint32_t p0 = tid; p0 < total; p0 += 4u * kTpb) {
+                        for (uint32_t p0 = tid; p0 < total; p0 += kWalkDepth * kTpb) {
                             SPA_WD(4, p0, total)
-                            uint32_t lo4[4], col4[4], x4[4];
+                            uint32_t lo4[kWalkDepth], col4[kWalkDepth], x4[kWalkDepth];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
+                            for (int u = 0; u < (int) kWalkDepth; ++u) {
                                 const uint32_t p = min(p0 + (uint32_t) u * kTpb, total - 1u);
                                 uint32_t       lo = 0, hi = nk;// largest t with s_pref[t] <= p
                                 while (hi - lo > 1) {
@@ -289,7 +293,7 @@ namespace splahip {
                                     col4[u] = a.Bj[idx], x4[u] = 0;
                             }
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
+                            for (int u = 0; u < (int) kWalkDepth; ++u) {
                                 if (p0 + (uint32_t) u * kTpb >= total) break;
                                 const uint32_t lo = lo4[u], col = col4[u] - c0;
                                 if (dense_rows && (s_len[lo] >> 31) && col + c0 - a.d_j0 < a.d_hj) continue;// (in the dense tile)
