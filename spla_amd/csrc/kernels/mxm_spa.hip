@@ -60,6 +60,10 @@ namespace splahip {
 #ifndef SPLAHIP_MXM_WALK_DEPTH
 #define SPLAHIP_MXM_WALK_DEPTH 2// (whole call at R-MAT 18: depth 1 / 2 38.3 - 38.5 ms, 3 39.3, 4 39.4 - 39.9, 6 41.9, 8 43.4 - 44.0: a step holds ~4.4 products per thread, deeper turns search and load for nothing)
 #endif
+#ifndef SPLAHIP_MXM_RANKED_DEPTH
+#define SPLAHIP_MXM_RANKED_DEPTH 2// (whole call: 2 -> 38.2 - 38.5 ms, 4 -> 38.5 - 38.8, 8 -> 39.0 - 39.4)
+#endif
+        constexpr unsigned kRankedDepth = SPLAHIP_MXM_RANKED_DEPTH;// the same in the ranked form's two walks (whole rows: tens of products per thread)
         constexpr unsigned kWalkDepth = SPLAHIP_MXM_WALK_DEPTH;// products per thread in flight in the flat walk of a block step
 #ifndef SPLAHIP_MXM_LIGHT_DEFAULT
 #define SPLAHIP_MXM_LIGHT_DEFAULT 2048// (a light row has to fit one batch)
@@ -460,10 +464,10 @@ namespace splahip {
                             const uint32_t ex = block_exclusive_sum<kTpb>(len, s_tmp, total);
                             s_pref[tid]       = ex;
                             __syncthreads();
-                            for (uint32_t p0 = tid; p0 < total; p0 += 4u * kTpb) {
-                                uint32_t lo4[4], col4[4], x4[4];
+                            for (uint32_t p0 = tid; p0 < total; p0 += kRankedDepth * kTpb) {
+                                uint32_t lo4[kRankedDepth], col4[kRankedDepth], x4[kRankedDepth];
 #pragma unroll
-                                for (int u = 0; u < 4; ++u) {
+                                for (int u = 0; u < (int) kRankedDepth; ++u) {
                                     const uint32_t p = min(p0 + (uint32_t) u * kTpb, total - 1u);
                                     uint32_t       lo = 0, hi = nk;
                                     while (hi - lo > 1) {
@@ -481,7 +485,7 @@ namespace splahip {
                                         col4[u] = a.Bj[idx], x4[u] = 0;
                                 }
 #pragma unroll
-                                for (int u = 0; u < 4; ++u) {
+                                for (int u = 0; u < (int) kRankedDepth; ++u) {
                                     if (p0 + (uint32_t) u * kTpb >= total) break;
                                     fn(s_av[lo4[u]], col4[u] - s0, x4[u]);
                                 }
