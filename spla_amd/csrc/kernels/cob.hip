@@ -1381,12 +1381,17 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         };
         // (three size levels measured best at both bench scales whatever the model preferred — R-MAT 22: 154 us against 166 / 172 with two / one level, R-MAT 23: 308
         // against 336 / 327 — so the level count is fixed and the model picks the share; SPLAHIP_COB_LEVELS=0 lets it pick both)
-        uint32_t share_pct = env_u32("SPLAHIP_COB_SHARE_PCT", 0), levels = env_u32("SPLAHIP_COB_LEVELS", 3);
+        // (round 5: a FOURTH level for the schedule of the 4-byte slices where a slot has >= 3500 chunks to walk — the min-plus step at R-MAT 24: the smallest pieces are
+        // then still ~5 rounds of the loop.  R-MAT 24 min-plus 544 - 548 -> 522 - 529 us; the fp32 sums (double slices) gain nothing there (609 - 613 -> 604 - 613 us, the
+        // PageRank step level) and keep three; with fewer chunks per slot four levels lose: R-MAT 22 138 -> 162 us, R-MAT 23 271 -> 293 at the model's share —
+        // tools/gpu_r5_levels.sh)
+        const uint32_t levels_default = w == 0 && n_chunks / std::max(1u, slots) >= 3500u ? 4u : 3u;
+        uint32_t       share_pct = env_u32("SPLAHIP_COB_SHARE_PCT", 0), levels = env_u32("SPLAHIP_COB_LEVELS", levels_default);
         if (share_pct == 0 || levels == 0) {
             uint64_t       best = ~0ull;
             const uint32_t pct_fixed = share_pct, lev_fixed = levels;
-            for (uint32_t lv : {1u, 2u, 3u}) {
-                if (lev_fixed && lv != lev_fixed) continue;
+            for (uint32_t lv : {1u, 2u, 3u, 4u}) {
+                if (lev_fixed ? lv != lev_fixed : lv == 4u) continue;// (LEVELS=0: the model picks among 1 - 3)
                 for (uint32_t pct : {140u, 120u, 110u, 100u, 90u, 80u, 70u, 65u, 60u, 55u, 50u, 45u, 40u, 35u, 30u, 25u}) {
                     if (pct_fixed && pct != pct_fixed) continue;
                     cut(pct, lv);
