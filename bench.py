@@ -416,6 +416,10 @@ def bfs_step_line(args, rank, world):
 
     # measured streaming ceiling of this GPU in this run: a 1 GiB device-to-device copy, read + write bytes / time.
     # `frac` stays against the nominal 8 TB/s; `frac_of_measured_copy` is the same numerator against what a plain copy reaches here.
+    from bench_spmv import read_stream_gbs
+    rs_gbs = read_stream_gbs()
+    roofline["measured_read_stream_gbs"] = round(rs_gbs, 1)
+    roofline["frac_of_measured_read_stream"] = round(achieved / rs_gbs, 4)
     copy_gbs = copy_ceiling_gbs()
     roofline["measured_copy_gbs"] = round(copy_gbs, 1)
     roofline["frac_of_measured_copy"] = round(achieved / copy_gbs, 4)

@@ -81,6 +81,17 @@ def copy_ceiling_gbs(n_words=1 << 28, reps=10):
     return 2 * 4 * n_words / (float(np.median(ms)) * 1e-3) / 1e9
 
 
+def read_stream_gbs(n_bytes=1 << 30, reps=10):
+    """GB/s of this library's own read-only stream over 1 GiB (splahip_read_stream_gbs: 16 bytes per lane, non-temporal, a 1024-thread workgroup per CU): what
+    a kernel that only had to READ its bytes reaches on this GPU in this run — the honest measured denominator for a read-dominated kernel (VERDICT r5 item 7;
+    a device-to-device copy, 4.6 - 4.8 TB/s of read + write, is the lower of the two and flatters)."""
+    import ctypes as C
+    from spla_amd import _lib
+    g = C.c_double(0.0)
+    _lib.call("splahip_read_stream_gbs", C.c_size_t(n_bytes), reps, C.byref(g), None)
+    return float(g.value)
+
+
 def sample_rows(Ap, Aj, Ax, stride):
     """every stride-th row of a device CSR as host arrays (Ap_s, Aj_s, Ax_s) + the sampled row ids (device)"""
     n = Ap.numel() - 1
@@ -213,8 +224,11 @@ def run(args, rank, world):
             "kernel": kernels.mxv_variant("FLOAT", "MULT", "PLUS", False, plan), "kernel_avg_us": round(k_ms * 1e3, 2), "kernel_median_us": round(float(np.median(per)) * 1e3, 2),
             "algorithmic_bytes": alg, "bytes_per_entry": 8,
             "byte_model": "B = 8*nnz + 4*(n_rows+1) + 4*n_rows (mask) + 4*n_rows (r) + 4*n_cols (v once)   (SURVEY.md 8d; the reference's CSR is the yardstick)"}
+    rs = read_stream_gbs()
+    roof["measured_read_stream_gbs"], roof["frac_of_measured_read_stream"] = round(rs, 1), round(gbs / rs, 4)
     cg = copy_ceiling_gbs()
     roof["measured_copy_gbs"], roof["frac_of_measured_copy"] = round(cg, 1), round(gbs / cg, 4)
+    roof["measured_denominators"] = "read stream: this library's 16-B-per-lane non-temporal read of 1 GiB (the yardstick for a read-dominated kernel); copy: torch's device-to-device copy of 1 GiB, read + write bytes (lower: kept for continuity with rounds 3 - 5)"
     per_call, fname = pmc_traffic(f"spmv_fp32_scale{scale}")
     if per_call and per_call.get("nnz") == nnz:
         roof["traffic"] = per_call["traffic_bytes"]
@@ -387,6 +401,33 @@ def same_matrix_variants(args, n, nnz, Ap, Aj, Ax, v, mask, r_cob):
     csr = kernels.CsrPlan(n, nnz, Ap)
     run("fp32 MULT/PLUS, CSR wave-tile kernel (no layout copy; deterministic fold)", csr, "FLOAT", Ax, mask, v, r, "MULT", "PLUS", "ALWAYS", 0.0)
     res[-1]["max_rel_vs_cob"] = float(((r - r_cob).abs() / r_cob.abs().clamp_min(1e-30)).max())
+    # the reference-order mode (splahip_set_reference_order; Descriptor::set_reference_order): every row a strict left fold from init in entry order, the reference CPU
+    # backend's own loop (src/cpu/cpu_mxv.hpp:94-99) — checked BIT FOR BIT against the oracle on every 64th row and the 4096 longest rows
+    from oracle import pyoracle
+    from spla_amd import _lib
+    assert _lib.call("splahip_set_reference_order", 1) == 0
+    try:
+        rr = torch.empty_like(r_cob)
+        run("fp32 MULT/PLUS, reference-order mode (every row folded strictly left to right: bit-identical to the reference CPU backend)", csr, "FLOAT", Ax, mask, v, rr,
+            "MULT", "PLUS", "ALWAYS", 0.0)
+    finally:
+        assert _lib.call("splahip_set_reference_order", 0) == 1
+    deg = (Ap[1:] - Ap[:-1]).to(torch.int64)
+    rows = torch.unique(torch.cat([torch.arange(0, n, 64, device="cuda"), torch.topk(deg, 4096).indices]))
+    Ap64 = Ap.to(torch.int64)
+    dg = deg[rows]
+    Aps = torch.zeros(rows.numel() + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(dg, 0, out=Aps[1:])
+    rep = torch.repeat_interleave(torch.arange(rows.numel(), device="cuda"), dg)
+    src = Ap64[rows][rep] + (torch.arange(int(Aps[-1]), device="cuda") - Aps[:-1][rep])
+    want = pyoracle.Oracle().mxv_masked("FLOAT", int(rows.numel()), n, Aps.to(torch.int32).cpu().numpy().view(np.uint32), Aj[src].cpu().numpy().view(np.uint32),
+                                        Ax[src].cpu().numpy(), mask[rows].cpu().numpy(), v.cpu().numpy(), "MULT", "PLUS", "ALWAYS", 0.0)
+    same = bool(np.array_equal(rr[rows].cpu().numpy().view(np.uint32), want.view(np.uint32)))
+    res[-1]["verified_rows"], res[-1]["bit_identical_to_oracle"] = int(rows.numel()), same
+    res[-1]["max_rel_vs_cob"] = float(((rr - r_cob).abs() / r_cob.abs().clamp_min(1e-30)).max())
+    del rows, rep, src, Aps, dg, deg, Ap64, rr
+    if not same:
+        raise SystemExit("bench: the reference-order mode differs from the oracle")
     # the reference's own SSSP semiring: fp32 min-plus (src/algorithm.cpp:208-213), 1/8 of v finite, init = +inf
     gen = torch.Generator(device="cuda")
     gen.manual_seed(args.seed + 77)

@@ -210,6 +210,8 @@ SPLA_API spla_Status spla_Descriptor_set_early_exit(spla_Descriptor options, spl
 SPLA_API spla_Status spla_Descriptor_set_struct_only(spla_Descriptor options, spla_bool on);
 /* an addition of this build: fp32 sums of the call on the fixed-order kernels, bit-identical from run to run (spla_hip.h: splahip_set_deterministic) */
 SPLA_API spla_Status spla_Descriptor_set_deterministic(spla_Descriptor options, spla_bool on);
+/* an addition of this build: fp32 sums of the call folded in the reference CPU backend's order, bit-identical to it (spla_hip.h: splahip_set_reference_order) */
+SPLA_API spla_Status spla_Descriptor_set_reference_order(spla_Descriptor options, spla_bool on);
 SPLA_API spla_Status spla_Descriptor_set_traversal_mode(spla_Descriptor options, int mode); /* 0 push, 1 pull, 2 push-pull */
 SPLA_API spla_Status spla_Descriptor_set_front_factor(spla_Descriptor options, float fraction);
 

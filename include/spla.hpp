@@ -245,6 +245,10 @@ namespace spla {
         // (an addition of this build) fp32 sums of this call run on the fixed-order kernels: bit-identical from run to run (include/spla_hip.h: splahip_set_deterministic)
         void  set_deterministic(bool value) { m_deterministic = value; }
         bool  get_deterministic() const { return m_deterministic; }
+        // (an addition of this build) fp32 sums of this call are folded in the reference CPU backend's order — strictly left to right from init, src/cpu/cpu_mxv.hpp:94-99 —
+        // and equal its results bit for bit, at a few times the default call's time (include/spla_hip.h: splahip_set_reference_order)
+        void  set_reference_order(bool value) { m_reference_order = value; }
+        bool  get_reference_order() const { return m_reference_order; }
         bool  get_push_only() const { return m_mode == TraversalMode::Push; }
         bool  get_pull_only() const { return m_mode == TraversalMode::Pull; }
         bool  get_push_pull() const { return m_mode == TraversalMode::PushPull; }
@@ -264,6 +268,7 @@ namespace spla {
         bool          m_early_exit   = false;
         bool          m_struct_only  = false;
         bool          m_deterministic = false;
+        bool          m_reference_order = false;
     };
 
     // ---- operations -----------------------------------------------------------------------------------------------------

@@ -65,6 +65,17 @@ int         splahip_env_refresh(void);
  * fixed-order kernels (CSR wave-tile / row kernels, the sort form of mxm): two runs are bit-identical, at the CSR kernels' speed.  Integer and MIN / MAX
  * folds are exact in every form and unaffected.  The operator API sets it per call from Descriptor::set_deterministic (include/spla.hpp). */
 int         splahip_set_deterministic(int on);
+/* Measurement helper (bench.py's roofline.measured_read_stream_gbs): the rate of a read-only stream of `bytes` bytes read the way this library's kernels read their
+ * streams — 16 bytes per lane, non-temporal, one 1024-thread workgroup per CU on a contiguous span, four loads in flight per wavefront — best of `reps` launches,
+ * in GB/s.  Allocates and frees its own buffer; blocks until done. */
+int         splahip_read_stream_gbs(size_t bytes, int reps, double* gbs, void* stream);
+/* Reference fold order for the calls the CALLING HOST THREAD makes from now on (on != 0) / back to the default (0); returns the previous setting (not a
+ * status).  An fp32 PLUS fold of splahip_mxv_masked / splahip_vxm_pull then adds every row's products strictly left to right from `init` in entry order
+ * — the loop of the reference CPU backend, src/cpu/cpu_mxv.hpp:94-99, src/cpu/cpu_vxm.hpp:101-113 — so the result equals the reference's BIT FOR BIT
+ * (short rows: one lane per row out of LDS; rows beyond 508 entries: one wavefront per row, a chain of dependent additions — slow on purpose: a few
+ * times the default call).  Implies the deterministic setting for every other operator.  Every other fold (integers, MIN / MAX, ...) is exact in every
+ * form and unaffected.  The operator API sets it per call from Descriptor::set_reference_order (include/spla.hpp). */
+int         splahip_set_reference_order(int on);
 
 int splahip_malloc(void** d_ptr, size_t bytes);
 int splahip_free(void* d_ptr);

@@ -44,6 +44,8 @@ _SIGNATURES = {
     "splahip_csr_plan_hint_products": (C.c_int, [_vp, C.c_uint64]),
     "splahip_csr_plan_first_hit": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "splahip_set_deterministic": (C.c_int, [C.c_int]),
+    "splahip_set_reference_order": (C.c_int, [C.c_int]),
+    "splahip_read_stream_gbs": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(C.c_double), C.c_void_p]),
     "splahip_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "splahip_free": (C.c_int, [_vp]),
     "splahip_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
@@ -121,7 +123,7 @@ _SIGNATURES = {
     "splahip_m_transpose": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "splahip_map": (C.c_int, [C.c_int, C.c_uint32, _vp, _vp, C.c_int, _vp]),
 }
-_RAW = {"splahip_set_deterministic", "splahip_mxv_prefers_sell", "splahip_device_count", "splahip_last_error", "splahip_version", "splahip_mxv_variant", "splahip_mxv_variant_of", "splahip_dist_available",
+_RAW = {"splahip_set_deterministic", "splahip_set_reference_order", "splahip_mxv_prefers_sell", "splahip_device_count", "splahip_last_error", "splahip_version", "splahip_mxv_variant", "splahip_mxv_variant_of", "splahip_dist_available",
         "splahip_shard_split_serves", "splahip_shard_prefers_whole", "splahip_jit_available"}
 
 _lib = None

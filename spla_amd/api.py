@@ -55,7 +55,7 @@ def c_symbols():
              "spla_Exec_v_eadd", "spla_Exec_v_reduce", "spla_Exec_m_reduce", "spla_Exec_m_transpose", "spla_Exec_v_map",
              "spla_Algorithm_bfs", "spla_Algorithm_sssp", "spla_Algorithm_pr", "spla_Algorithm_tc",
              "spla_MtxLoader_load", "spla_MtxLoader_get", "spla_MtxLoader_delete",
-             "spla_Descriptor_make", "spla_Descriptor_set_early_exit", "spla_Descriptor_set_struct_only", "spla_Descriptor_set_deterministic",
+             "spla_Descriptor_make", "spla_Descriptor_set_early_exit", "spla_Descriptor_set_struct_only", "spla_Descriptor_set_deterministic", "spla_Descriptor_set_reference_order",
              "spla_Descriptor_set_traversal_mode", "spla_Descriptor_set_front_factor"]
     for op in BINARY_OPS:
         for t in ("INT", "UINT") + (() if op in BITWISE else ("FLOAT",)):
@@ -152,6 +152,7 @@ def _c():
         lib.spla_Descriptor_set_early_exit.argtypes = [_vp, C.c_int]
         lib.spla_Descriptor_set_struct_only.argtypes = [_vp, C.c_int]
         lib.spla_Descriptor_set_deterministic.argtypes = [_vp, C.c_int]
+        lib.spla_Descriptor_set_reference_order.argtypes = [_vp, C.c_int]
         _bound = True
     return lib
 
@@ -295,7 +296,7 @@ class Scalar(Object):
 class Descriptor(Object):
     PUSH, PULL, PUSH_PULL = 0, 1, 2
 
-    def __init__(self, early_exit=False, struct_only=False, traversal_mode=None, front_factor=None, deterministic=False):
+    def __init__(self, early_exit=False, struct_only=False, traversal_mode=None, front_factor=None, deterministic=False, reference_order=False):
         h = _vp()
         _check(_c().spla_Descriptor_make(C.byref(h)), "spla_Descriptor_make")
         super().__init__(h)
@@ -303,6 +304,8 @@ class Descriptor(Object):
         _c().spla_Descriptor_set_struct_only(h, 1 if struct_only else 0)
         if deterministic:  # fp32 sums on the fixed-order kernels: two runs of the call are bit-identical
             _check(_c().spla_Descriptor_set_deterministic(h, 1), "spla_Descriptor_set_deterministic")
+        if reference_order:  # fp32 sums folded as the reference CPU backend folds them: bit-identical to it
+            _check(_c().spla_Descriptor_set_reference_order(h, 1), "spla_Descriptor_set_reference_order")
         if traversal_mode is not None:
             _check(_c().spla_Descriptor_set_traversal_mode(h, int(traversal_mode)), "spla_Descriptor_set_traversal_mode")
         if front_factor is not None:

@@ -253,6 +253,11 @@ spla_Status spla_Descriptor_set_deterministic(spla_Descriptor desc, spla_bool va
     as_ptr<Descriptor>(desc)->set_deterministic(value != 0);
     return SPLA_STATUS_OK;
 }
+spla_Status spla_Descriptor_set_reference_order(spla_Descriptor desc, spla_bool value) {
+    if (!desc) return SPLA_STATUS_INVALID_ARGUMENT;
+    as_ptr<Descriptor>(desc)->set_reference_order(value != 0);
+    return SPLA_STATUS_OK;
+}
 spla_Status spla_Descriptor_set_traversal_mode(spla_Descriptor desc, int mode) {
     if (!desc || mode < 0 || mode > 2) return SPLA_STATUS_INVALID_ARGUMENT;
     as_ptr<Descriptor>(desc)->set_traversal_mode(static_cast<Descriptor::TraversalMode>(mode));

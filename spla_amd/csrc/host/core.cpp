@@ -434,6 +434,16 @@ namespace spla {
                 if (raised) (void) splahip_set_deterministic(0);
             }
         } scope(ctx.task->get_desc_or_default()->get_deterministic());
+        // the same for the reference-order setting (fp32 sums folded as the reference CPU backend folds them)
+        struct ReferenceOrderScope {
+            bool raised = false;
+            explicit ReferenceOrderScope(bool on) {
+                if (on) raised = splahip_set_reference_order(1) == 0;
+            }
+            ~ReferenceOrderScope() {
+                if (raised) (void) splahip_set_reference_order(0);
+            }
+        } order_scope(ctx.task->get_desc_or_default()->get_reference_order());
         try {
             return algo->execute(ctx);
         } catch (const std::exception& e) {

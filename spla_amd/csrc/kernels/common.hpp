@@ -40,6 +40,11 @@ namespace splahip {
     // fp32 PLUS merges partial sums in arrival order (column-ordered blocks, the LDS row classes of mxm) stand aside for the fixed-order kernels
     bool deterministic_calls();
     int  deterministic_exchange(int on);// returns the previous setting
+    // the calling host thread asked for the REFERENCE'S fold order (splahip_set_reference_order; the Descriptor's reference_order flag): an fp32 PLUS fold of
+    // mxv / vxm-pull then adds every row's products strictly left to right from `init` in entry order — the reference's own loop, src/cpu/cpu_mxv.hpp:94-99 —
+    // and the result is bit-identical to the reference CPU backend.  Implies deterministic_calls().
+    bool reference_order_calls();
+    int  reference_order_exchange(int on);// returns the previous setting
     void        knob_cache_clear();
 
     // make sure a device has been selected and is a gfx950; returns SPLAHIP_OK or an error status

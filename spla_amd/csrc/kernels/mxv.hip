@@ -97,6 +97,26 @@ namespace {
         return SPLAHIP_OK;
     }
 
+    // the reference-order mode (splahip_set_reference_order): run items with one lane per row, long rows with one wavefront per row — every selected row a
+    // strict left fold from init in entry order (mxv_kernels.hpp: ORDERED, spmv_longrow_ordered_kernel)
+    template<typename T>
+    int launch_ordered(splahip_plan plan, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const void* mask, const void* v, void* r, int op_mult, int op_add,
+                       int op_select, uint32_t init_bits, hipStream_t st) {
+        const uint grid = (plan->n_items + Cfg::kWaves - 1) / Cfg::kWaves;
+        hipLaunchKernelGGL((spmv_wavetile_kernel<Cfg, T, DynBin, StaBin<SPLAHIP_PLUS>, false, true>), dim3(grid), dim3(Cfg::kTpb), 0, st, plan->d_item_row, plan->d_item_k0, plan->n_items, Ap, Aj,
+                           static_cast<const uint32_t*>(Ax), static_cast<const T*>(mask), static_cast<const T*>(v), static_cast<const uint32_t*>(nullptr), static_cast<T*>(r),
+                           static_cast<uint32_t*>(nullptr), reinterpret_cast<T*>(plan->d_partial), static_cast<uint32_t*>(nullptr), DynBin(op_mult), StaBin<SPLAHIP_PLUS>(), op_select,
+                           from_bits<T>(init_bits), plan->nnz, static_cast<const uint32_t*>(nullptr));
+        SPLAHIP_TRY(hipGetLastError());
+        if (plan->n_long > 0) {
+            hipLaunchKernelGGL((spmv_longrow_ordered_kernel<Cfg, T, DynBin, StaBin<SPLAHIP_PLUS>, false>), dim3(grid), dim3(Cfg::kTpb), 0, st, plan->d_item_row, plan->d_item_k0, plan->n_items, Ap, Aj,
+                               static_cast<const uint32_t*>(Ax), static_cast<const T*>(mask), static_cast<const T*>(v), static_cast<const uint32_t*>(nullptr), static_cast<T*>(r),
+                               static_cast<uint32_t*>(nullptr), DynBin(op_mult), StaBin<SPLAHIP_PLUS>(), op_select, from_bits<T>(init_bits), plan->nnz);
+            SPLAHIP_TRY(hipGetLastError());
+        }
+        return SPLAHIP_OK;
+    }
+
     template<typename T, bool EARLY>
     int launch_rowseq(uint32_t n_rows, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const void* mask,
                       const void* v, void* r, int op_mult, int op_add, int op_select, uint32_t init_bits, hipStream_t st) {
@@ -258,6 +278,12 @@ namespace {
                        uint32_t init_bits, int early_exit, hipStream_t st) {
         constexpr int type = TypeId<T>::value;
         Variant variant = pick_variant(type, op_mult, op_add, early_exit);
+        // reference-order mode: an fp32 sum is folded exactly as the reference folds it (every other fold of the wave-tile kernels is exact as it is)
+        if (reference_order_calls() && type == SPLAHIP_FLOAT && op_add == SPLAHIP_PLUS && !early_exit) {
+            if (plan->n_items != 0 && ((reinterpret_cast<uintptr_t>(Aj) | reinterpret_cast<uintptr_t>(Ax)) & 15u) == 0)
+                return launch_ordered<T>(plan, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+            variant = Variant::RowSeq;// (an unaligned slice of a larger allocation: one lane per row straight from memory — the same fold)
+        }
         // the wave-tile kernels read Aj / Ax with 16-byte loads: an unaligned slice of a larger allocation takes the row kernel
         if (((reinterpret_cast<uintptr_t>(Aj) | reinterpret_cast<uintptr_t>(Ax)) & 15u) != 0 &&
             (variant == Variant::WaveTileStatic || variant == Variant::WaveTileDynamic))
@@ -444,7 +470,8 @@ const char* splahip_mxv_variant_of(splahip_plan plan, int type, int op_mult, int
         return type == SPLAHIP_FLOAT && op_add == SPLAHIP_PLUS ? "mxv_cob<column-ordered blocks, fp64 LDS accumulation>"
                : type == SPLAHIP_FLOAT && (op_add == SPLAHIP_MIN || op_add == SPLAHIP_MAX) ? "mxv_cob<column-ordered blocks, order-preserving integer keys in LDS>"
                                                                                             : "mxv_cob<column-ordered blocks, LDS accumulation>";
-    if (plan && plan->sell && !early_exit && fold_is_reorderable(op_add, type) && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add)) && !sell_disabled()) {
+    const bool ref_order = reference_order_calls() && type == SPLAHIP_FLOAT && op_add == SPLAHIP_PLUS;
+    if (plan && plan->sell && !early_exit && !ref_order && fold_is_reorderable(op_add, type) && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add)) && !sell_disabled()) {
         if (sell_skip_family(type, op_mult, op_add) != 0)// the device picks the bit form or the value form from the input vector's statistics
             return static_semiring(type, op_mult, op_add) ? "mxv_sell<static semiring; sparse-vector bit form | value form>" : "mxv_sell<runtime ops; sparse-vector bit form | value form>";
         return static_semiring(type, op_mult, op_add) ? "mxv_sell<static semiring>" : "mxv_sell<runtime ops>";
@@ -453,6 +480,7 @@ const char* splahip_mxv_variant_of(splahip_plan plan, int type, int op_mult, int
 }
 
 const char* splahip_mxv_variant(int type, int op_mult, int op_add, int early_exit) {
+    if (reference_order_calls() && type == SPLAHIP_FLOAT && op_add == SPLAHIP_PLUS && !early_exit) return "mxv_ordered<reference fold order: a lane per row, a wavefront per long row>";
     switch (pick_variant(type, op_mult, op_add, early_exit)) {
         case Variant::WaveTileStatic: return "mxv_wavetile<static semiring>";
         case Variant::WaveTileDynamic: return "mxv_wavetile<runtime ops>";
@@ -525,7 +553,8 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
     // the sliced-ELL copy (splahip_csr_plan_attach_sell) serves every associative op_add without early exit; its lanes fold in
     // entry order, so op_add need not be commutative.  SPLAHIP_SELL=0 keeps the CSR kernels (A/B runs, tests).
     // (rows with row-exclusive slices are folded lane-strided: then op_add must be commutative too — FIRST / SECOND keep the row kernel)
-    if (plan->sell && !early_exit && fold_is_reorderable(op_add, type) && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add)) &&
+    const bool ref_order = reference_order_calls() && type == SPLAHIP_FLOAT && op_add == SPLAHIP_PLUS;// (the CSR kernels' ordered forms serve it: dispatch_typed)
+    if (plan->sell && !early_exit && !ref_order && fold_is_reorderable(op_add, type) && (plan->sell->n_xslices == 0 || binop_is_commutative(op_add)) &&
         plan->sell->n_cols == n_cols && !sell_disabled() && d_r != d_mask && d_r != d_v &&// (its prep pass writes r before the kernel reads mask / v)
         ((reinterpret_cast<uintptr_t>(d_Ap) | reinterpret_cast<uintptr_t>(d_mask) | reinterpret_cast<uintptr_t>(d_v) | reinterpret_cast<uintptr_t>(d_r)) & 15u) == 0)// 16-byte accesses of Ap / mask / v / r
         return sell_mxv(plan, type, d_Ap, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, stream);

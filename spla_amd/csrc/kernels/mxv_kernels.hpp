@@ -219,7 +219,9 @@ namespace splahip {
     // VXM = true: the pull form of vxm on the transposed matrix: "rows" are output columns, entries whose v index is
     // not stored (`present` bitmap; nullptr = every index stored) are skipped, the fold starts at the first product (no
     // init) and touched[row] tells whether the output entry exists (reference src/cpu/cpu_vxm.hpp:101-107).
-    template<class C, typename T, class Mult, class Add, bool VXM>
+    // ORDERED (the reference-order mode, splahip_set_reference_order): every row of a run item is folded by ONE lane strictly left to right from `init`
+    // (the reference's own loop, src/cpu/cpu_mxv.hpp:94-99) whatever its length, and segment items are left to spmv_longrow_ordered_kernel below.
+    template<class C, typename T, class Mult, class Add, bool VXM, bool ORDERED = false>
     __global__ __launch_bounds__(C::kTpb) void spmv_wavetile_kernel(const uint* __restrict__ item_row,
                                                                     const uint* __restrict__ item_k0,
                                                                     uint n_items,
@@ -266,6 +268,7 @@ namespace splahip {
         SPLAHIP_STAMP(t_header)
 
         if (e0 & C::kSegFlag) {
+            if constexpr (ORDERED) return;// (the row is folded in order by spmv_longrow_ordered_kernel)
             // ---------------- segment item: a <= kSeg-entry piece of the long row `row`
             const uint rs   = Ap[row];
             const uint len  = Ap[row + 1] - rs;
@@ -442,7 +445,7 @@ namespace splahip {
                 bool has = !VXM;
                 if (sel.row(i)) {
                     const uint s = s_ap[i] - a0, e = s_ap[i + 1] - a0;
-                    if (e - s <= C::kShortMax) {
+                    if (ORDERED || e - s <= C::kShortMax) {
                         for (uint k = s; k < e; ++k) {
                             if constexpr (VXM) {
                                 if (s_ok[k]) {
@@ -504,6 +507,105 @@ namespace splahip {
             g_phase[3][slot] = (uint) (t_end - t_gather);
         }
 #endif
+    }
+
+    // The reference-order mode's kernel for the rows longer than kLongT (the plan's segment items): one wavefront per ROW — launched per item, the item that
+    // is its row's first segment acts — streams the row 64 entries a step (coalesced Aj / Ax, gathers of v, the next step's loads in flight) and adds the
+    // step's products ONE AFTER THE OTHER in entry order: lane l's product is read with v_readlane and added by every lane into the same running value, so
+    // the result is the reference's sequential fold (src/cpu/cpu_mxv.hpp:94-99; vxm: src/cpu/cpu_vxm.hpp:101-113, the fold starts at the first product)
+    // bit for bit.  Slow on purpose: a row of 10^5 entries is a chain of 10^5 dependent additions (~0.4 ms).
+    template<class C, typename T, class Mult, class Add, bool VXM>
+    __global__ __launch_bounds__(C::kTpb) void spmv_longrow_ordered_kernel(const uint* __restrict__ item_row, const uint* __restrict__ item_k0, uint n_items,
+                                                                           const uint* __restrict__ Ap, const uint* __restrict__ Aj, const uint* __restrict__ Ax,
+                                                                           const T* __restrict__ mask, const T* __restrict__ v, const uint* __restrict__ present,
+                                                                           T* __restrict__ r, uint* __restrict__ touched, Mult mult, Add add, int op_select, T init, uint nnz) {
+#pragma clang fp contract(off)
+        const uint lane = lane_id();
+        const uint item = blockIdx.x * C::kWaves + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+        if (item >= n_items) return;
+        const uint e0 = item_row[item];
+        if (!(e0 & C::kSegFlag)) return;
+        const uint row = e0 & ~C::kSegFlag;
+        const uint rs  = Ap[row];
+        if (item_k0[item] != rs) return;// not the first segment of its row
+        const uint re = Ap[row + 1];
+        if (!eval_sel(op_select, mask[row])) {
+            if (lane == 0) {
+                if constexpr (VXM) touched[row] = 0;
+                else
+                    r[row] = init;
+            }
+            return;
+        }
+        // a step = 256 entries: a lane owns the aligned quad 4 (lane) .. 4 (lane) + 3 of the step (16-byte loads of Aj / Ax, four gathers); the streams of step
+        // s + 2 and the gathers of step s + 1 are in flight while step s is added
+        const uint a0 = rs & ~3u;
+        struct Step {
+            uint4 j, x;
+            T     p[4];
+            uint  ok;// bit e: entry 4 lane + e of the step belongs to the row (and, vxm over a sparse v, its index of v is stored)
+        };
+        auto load_jx = [&](uint kb, Step& st) {// kb: the step's first (aligned) entry
+            const uint kq = kb + 4 * lane;
+            st.ok         = 0;
+            st.j = make_uint4(0, 0, 0, 0), st.x = make_uint4(0, 0, 0, 0);
+            if (kq < re) {
+                load_quad(Aj, Ax, kq, nnz, st.j, st.x);
+#pragma unroll
+                for (uint e = 0; e < 4; ++e) st.ok |= (kq + e >= rs && kq + e < re) ? (1u << e) : 0u;
+            }
+        };
+        auto gather = [&](Step& st) {
+            const uint jj[4] = {st.j.x, st.j.y, st.j.z, st.j.w};
+            const uint xx[4] = {st.x.x, st.x.y, st.x.z, st.x.w};
+#pragma unroll
+            for (uint e = 0; e < 4; ++e) {
+                const uint j = (st.ok >> e) & 1u ? jj[e] : jj[0];// (an entry of a neighbouring row rides along in the quad: its column is valid too, but need not be read)
+                if constexpr (VXM)
+                    if (present != nullptr && ((st.ok >> e) & 1u) && ((present[j >> 5] >> (j & 31u)) & 1u) == 0) st.ok &= ~(1u << e);
+                st.p[e] = entry_product<VXM>(mult, xx[e], gather_load(v + ((st.ok >> e) & 1u ? j : 0u)));
+            }
+        };
+        T    acc = init;
+        bool has = !VXM;
+        Step S0, S1, S2;
+        load_jx(a0, S0);
+        load_jx(a0 + 256, S1);
+        gather(S0);
+        for (uint kb = a0; kb < re; kb += 256) {
+            load_jx(kb + 512, S2);
+            gather(S1);
+            const u64 all = __ballot(S0.ok == 15u);
+            if (all == ~0ull && !VXM) {
+#pragma unroll 8
+                for (uint l = 0; l < kWave; ++l) {
+#pragma unroll
+                    for (uint e = 0; e < 4; ++e) acc = add(acc, from_bits<T>((uint) __builtin_amdgcn_readlane((int) to_bits(S0.p[e]), l)));
+                }
+            } else {
+                for (u64 m = __ballot(S0.ok != 0u); m; m &= m - 1) {
+                    const uint l  = __ffsll((long long) m) - 1;
+                    const uint ok = (uint) __builtin_amdgcn_readlane((int) S0.ok, l);
+#pragma unroll
+                    for (uint e = 0; e < 4; ++e) {
+                        const T pl = from_bits<T>((uint) __builtin_amdgcn_readlane((int) to_bits(S0.p[e]), l));
+                        if ((ok >> e) & 1u) {
+                            acc = has ? add(acc, pl) : pl;
+                            has = true;
+                        }
+                    }
+                }
+            }
+            S0 = S1;
+            S1 = S2;
+        }
+        if (lane == 0) {
+            if constexpr (VXM) {
+                touched[row] = has ? 1u : 0u;
+                if (has) r[row] = acc;
+            } else
+                r[row] = acc;
+        }
     }
 
     // finish rows made of several segment items: strict in-order fold of their partials

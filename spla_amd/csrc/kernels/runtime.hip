@@ -43,9 +43,16 @@ namespace splahip {
         return it->second;
     }
     namespace {
-        thread_local int tl_deterministic = 0;
+        thread_local int tl_deterministic   = 0;
+        thread_local int tl_reference_order = 0;
     }
-    bool deterministic_calls() { return tl_deterministic != 0; }
+    bool deterministic_calls() { return tl_deterministic != 0 || tl_reference_order != 0; }
+    bool reference_order_calls() { return tl_reference_order != 0; }
+    int  reference_order_exchange(int on) {
+        const int before   = tl_reference_order;
+        tl_reference_order = on ? 1 : 0;
+        return before;
+    }
     int  deterministic_exchange(int on) {
         const int before = tl_deterministic;
         tl_deterministic = on ? 1 : 0;
@@ -428,6 +435,62 @@ extern "C" {
 int splahip_version(void) { return 100; }
 
 int splahip_set_deterministic(int on) { return splahip::deterministic_exchange(on); }
+int splahip_set_reference_order(int on) { return splahip::reference_order_exchange(on); }
+
+namespace {
+    // a read-only stream the way the kernels of this library read theirs: 16 bytes per lane, non-temporal, a 1024-thread workgroup per CU walking a contiguous span,
+    // four loads in flight per wavefront (tools/exp/stream_bench.hip, form A; profiles/r03_stream_bench.txt)
+    typedef uint32_t stream_u4 __attribute__((ext_vector_type(4)));
+    __global__ __launch_bounds__(1024) void read_stream_kernel(const stream_u4* __restrict__ src, size_t words_per_wg, uint32_t* __restrict__ out) {
+        const unsigned   lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const stream_u4* base = src + (size_t) blockIdx.x * words_per_wg;
+        const size_t     steps = words_per_wg / 1024;// 1 KB pieces per wavefront
+        uint32_t         acc   = 0;
+        for (size_t s = 0; s + 4 <= steps; s += 4) {
+            stream_u4 r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = __builtin_nontemporal_load(base + ((s + u) * 16 + wave) * 64 + lane);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc ^= r[u].x ^ r[u].y ^ r[u].z ^ r[u].w;
+        }
+        if (acc == 0x9E3779B9u) out[blockIdx.x] = acc;// (keeps the loads; the buffer is zeroed, so nothing is stored)
+    }
+}// namespace
+
+int splahip_read_stream_gbs(size_t bytes, int reps, double* gbs, void* stream) {
+    SPLAHIP_REQUIRE(gbs != nullptr && reps > 0, "null argument");
+    *gbs   = 0.0;
+    int st = splahip::ensure_device();
+    if (st != SPLAHIP_OK) return st;
+    hipStream_t  s    = splahip::as_stream(stream);
+    const size_t wgs  = 256;
+    const size_t per  = std::max<size_t>(bytes / 16 / wgs / 4096, 1) * 4096;// 16-byte words per workgroup: whole rounds of 4 x 1 KB per wavefront
+    const size_t real = per * wgs * 16;
+    void *       buf = nullptr, *out = nullptr;
+    SPLAHIP_TRY(hipMalloc(&buf, real));
+    hipError_t e = hipMalloc(&out, wgs * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(buf, 0, real, s);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float best = 0.0f;
+    for (int k = 0; e == hipSuccess && k < reps + 2; ++k) {
+        (void) hipEventRecord(e0, s);
+        hipLaunchKernelGGL(read_stream_kernel, dim3((unsigned) wgs), dim3(1024), 0, s, static_cast<const stream_u4*>(buf), per, static_cast<uint32_t*>(out));
+        (void) hipEventRecord(e1, s);
+        e = hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (k >= 2 && ms > 0.0f && (best == 0.0f || ms < best)) best = ms;// (two warm-up launches; the fastest of the rest)
+    }
+    if (e0) (void) hipEventDestroy(e0);
+    if (e1) (void) hipEventDestroy(e1);
+    (void) hipFree(buf);
+    if (out) (void) hipFree(out);
+    if (e != hipSuccess) return splahip::fail(SPLAHIP_ERROR, "read stream: %s", hipGetErrorString(e));
+    if (best > 0.0f) *gbs = (double) real / ((double) best * 1e-3) / 1e9;
+    return SPLAHIP_OK;
+}
 
 int splahip_env_refresh(void) {
     splahip::knob_cache_clear();

@@ -593,7 +593,18 @@ namespace splahip {
         // every index of v stored + a sliced-ELL copy on the transposed matrix's plan: the value-form kernel in its vxm mode
         const char* sell_env = knob_env("SPLAHIP_SELL");
         // every index of v stored + a column-ordered-blocks copy on the transposed matrix's plan: its kernel in vxm mode
+        // reference-order mode (splahip_set_reference_order): an fp32 sum per output index is folded strictly in the order of v's indices from its first product —
+        // the reference's loop, src/cpu/cpu_vxm.hpp:101-113, over the rows of the transposed matrix (mxv_kernels.hpp: ORDERED, spmv_longrow_ordered_kernel)
+        const bool ref_order = reference_order_calls() && std::is_same<T, float>::value && op_add == SPLAHIP_PLUS;
         if (first_hit) {// (launched above)
+        } else if (ref_order && plan->n_items) {
+            hipLaunchKernelGGL((spmv_wavetile_kernel<Cfg, T, DynBin, StaBin<SPLAHIP_PLUS>, true, true>), dim3(grid), dim3(Cfg::kTpb), 0, s, plan->d_item_row, plan->d_item_k0, plan->n_items, Tp, Tj,
+                               static_cast<const uint*>(Tx), static_cast<const T*>(mask), d_v, d_present, reinterpret_cast<T*>(ws_outv), ws_touched, reinterpret_cast<T*>(plan->d_partial),
+                               plan->d_partial_ok, DynBin(op_mult), StaBin<SPLAHIP_PLUS>(), op_select, T(0), plan->nnz);
+            if (plan->n_long > 0)
+                hipLaunchKernelGGL((spmv_longrow_ordered_kernel<Cfg, T, DynBin, StaBin<SPLAHIP_PLUS>, true>), dim3(grid), dim3(Cfg::kTpb), 0, s, plan->d_item_row, plan->d_item_k0, plan->n_items, Tp,
+                                   Tj, static_cast<const uint*>(Tx), static_cast<const T*>(mask), d_v, d_present, reinterpret_cast<T*>(ws_outv), ws_touched, DynBin(op_mult),
+                                   StaBin<SPLAHIP_PLUS>(), op_select, T(0), plan->nnz);
         } else if (v_is_identity && cob_vxm_serves(plan, TypeId<T>::value, op_add, n_in) &&
             ((reinterpret_cast<uintptr_t>(ws_outv) | reinterpret_cast<uintptr_t>(ws_touched) | reinterpret_cast<uintptr_t>(mask)) & 15u) == 0) {
             int st = cob_vxm(plan, TypeId<T>::value, Tp, mask, d_v, ws_outv, ws_touched, op_mult, op_add, op_select, s);
@@ -820,7 +831,9 @@ namespace splahip {
                            chunk, ri, static_cast<T*>(rx), lcount, lpos, lrank, DynBin(op_add));
         // the long-run pass is launched for the worst case and sizes itself from the device-side counter (no read-back in between)
         const uint grid = (max_long + 3) / 4;
-        if (fold_is_reorderable(op_add, TypeId<T>::value))
+        // (reference-order mode: an fp32 sum's long runs are folded one product after the other too — the expand order is the reference's fold order)
+        const bool strict = reference_order_calls() && std::is_same<T, float>::value && op_add == SPLAHIP_PLUS;
+        if (fold_is_reorderable(op_add, TypeId<T>::value) && !strict)
             hipLaunchKernelGGL((long_run_kernel<T, DynBin, true>), dim3(grid), dim3(256), 0, s, key_b, reinterpret_cast<const T*>(val_b), n_products, lcount, lpos,
                                lrank, static_cast<T*>(rx), DynBin(op_add));
         else

@@ -160,3 +160,46 @@ def test_deterministic_descriptor_gives_bit_identical_fp32_sums(oracle):
         assert_same(got, want, "FLOAT", what="deterministic fp32 MULT/PLUS")
     assert_same(product(M, None), want, "FLOAT", what="default fp32 MULT/PLUS on the prepared matrix")
     assert_same(product(M, api.Descriptor()), want, "FLOAT", what="default descriptor after deterministic calls (the setting is per call)")
+
+
+def test_reference_order_descriptor_gives_the_reference_words(oracle):
+    """Descriptor(reference_order=True) (an addition of this build; include/spla.hpp, C: spla_Descriptor_set_reference_order): an fp32 PLUS product through the
+    operator API — spla_Exec_mxv_masked and spla_Exec_vxm_masked on a prepared matrix (blocks attached) — is folded as the reference CPU backend folds it
+    (src/cpu/cpu_mxv.hpp:94-99, cpu_vxm.hpp:101-113) and equals the oracle BIT FOR BIT; the setting is per call (the next default call is back on the blocks)."""
+    api = _api()
+    rng = np.random.default_rng(79)
+    n_rows, n_cols = 6000, 5000
+    Ap, Aj, _ = random_csr(rng, n_rows, n_cols, 14, "FLOAT", skew=True, long_rows=3, long_len=4000)
+    nnz = len(Aj)
+    Ax = ((rng.random(nnz) - 0.3) * np.exp(rng.normal(0, 3, nnz))).astype(np.float32)
+    Ax[Ax == 0] = 1.0
+    mask_np = random_mask(rng, n_rows, "FLOAT")
+    v_np = ((rng.random(n_cols) - 0.4) * np.exp(rng.normal(0, 2, n_cols))).astype(np.float32)
+    v_np[v_np == 0] = 0.5
+    T = api.FLOAT
+    M = api.Matrix.from_csr(Ap, Aj, Ax, (n_rows, n_cols), T)
+    M.set_format(6)
+    desc = api.Descriptor(reference_order=True)
+    want = oracle.mxv_masked("FLOAT", n_rows, n_cols, Ap, Aj, Ax, mask_np, v_np, "MULT", "PLUS", "NQZERO", 0.0)
+    mask = api.Vector.from_lists(np.arange(n_rows), mask_np, n_rows, T)
+    v = api.Vector.from_lists(np.arange(n_cols), v_np, n_cols, T)
+    for _ in range(2):
+        got = M.mxv(mask, v, T.MULT, T.PLUS, T.NQZERO, init=api.Scalar(T, 0.0), desc=desc).to_dense()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "reference-order mxv through the operator API differs from the oracle's words"
+    # the setting is per call: the next default call re-associates again (these sums cancel, so the bar is relative to the sum of the products' magnitudes)
+    dflt = M.mxv(mask, v, T.MULT, T.PLUS, T.NQZERO, init=api.Scalar(T, 0.0)).to_dense()
+    mag = oracle.mxv_masked("FLOAT", n_rows, n_cols, Ap, Aj, np.abs(Ax), mask_np, np.abs(v_np), "MULT", "PLUS", "NQZERO", 0.0)
+    assert np.all(np.abs(dflt.astype(np.float64) - want) <= 1e-5 * mag + 1e-30), "default call after reference-order calls"
+    # vxm: r = u^T M, u dense over the rows, mask over the columns
+    u_np = ((rng.random(n_rows) - 0.4) * np.exp(rng.normal(0, 2, n_rows))).astype(np.float32)
+    u_np[u_np == 0] = 0.5
+    cmask_np = random_mask(rng, n_cols, "FLOAT")
+    wi, wx = oracle.vxm_masked("FLOAT", n_rows, n_cols, Ap, Aj, Ax, cmask_np, np.arange(n_rows, dtype=np.uint32), u_np, "MULT", "PLUS", "NQZERO")
+    u = api.Vector.from_lists(np.arange(n_rows), u_np, n_rows, T)
+    cmask = api.Vector.from_lists(np.arange(n_cols), cmask_np, n_cols, T)
+    for mode in (api.Descriptor.PULL, api.Descriptor.PUSH):
+        d = api.Descriptor(reference_order=True, traversal_mode=mode)
+        ri, rx = u.vxm(cmask, M, T.MULT, T.PLUS, T.NQZERO, init=api.Scalar(T, 0.0), desc=d).read()
+        keep = wx != 0  # (entries equal to the fill value 0 are not stored)
+        assert np.array_equal(ri, wi[keep]), f"mode {mode}: structure"
+        assert np.array_equal(rx.view(np.uint32), wx[keep].view(np.uint32)), f"mode {mode}: reference-order vxm differs from the oracle's words"

@@ -510,6 +510,95 @@ def test_cfg3_full_size_pagerank_pull_column_ordered_blocks(oracle):
     plan_T.close()
 
 
+def _rows_sample_with_the_heaviest(Ap, step, n_heavy):
+    """every `step`-th row plus the `n_heavy` longest rows (the rows on which a re-associated fp32 fold strays furthest from the reference's)"""
+    n = Ap.numel() - 1
+    deg = (Ap[1:] - Ap[:-1]).to(torch.int64)
+    heavy = torch.topk(deg, n_heavy).indices
+    return torch.unique(torch.cat([torch.arange(0, n, step, device=Ap.device), heavy]))
+
+
+def test_north_star_full_size_reference_order_is_bit_identical_to_the_oracle(oracle):
+    """the north-star call — fp32 MULT / PLUS over all rows of R-MAT scale 23 (131 M nnz) — in REFERENCE-ORDER mode
+    (splahip_set_reference_order; Descriptor::set_reference_order): every row is folded strictly left to right from init in entry order, the loop of the
+    reference CPU backend (src/cpu/cpu_mxv.hpp:94-99), so there is no tolerance here: every 64th row and the 4096 longest rows (up to ~10^5 entries each) must
+    carry the oracle's WORD.  The plan holds the blocks (they stand aside for the call).  Masked once more (NQZERO, init 7.5).  The call's time is printed."""
+    import time
+    from spla_amd import _lib, kernels
+    n, Ap, Aj = _rmat(23, device="cuda")
+    nnz = int(Ap[-1])
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(401)
+    Ax = torch.rand(nnz, generator=gen, device="cuda", dtype=torch.float32)
+    v = torch.rand(n, generator=gen, device="cuda", dtype=torch.float32)
+    mask = (torch.rand(n, generator=gen, device="cuda") < 0.5).to(torch.float32)
+    plan = kernels.CsrPlan(n, nnz, Ap)
+    assert plan.attach_cob(n, Ap, Aj, Ax)
+    rows_idx = _rows_sample_with_the_heaviest(Ap, 64, 4096)
+    r = torch.full((n,), -1.0, dtype=torch.float32, device="cuda")
+    assert _lib.call("splahip_set_reference_order", 1) == 0
+    try:
+        assert "mxv_ordered" in kernels.mxv_variant("FLOAT", "MULT", "PLUS", False, plan)
+        for (sel, init) in (("ALWAYS", 0.0), ("NQZERO", 7.5)):
+            kernels.mxv_masked(plan, "FLOAT", n, Ap, Aj, Ax, mask, v, r, "MULT", "PLUS", sel, init)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            kernels.mxv_masked(plan, "FLOAT", n, Ap, Aj, Ax, mask, v, r, "MULT", "PLUS", sel, init)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3
+            want = _sampled_rows_oracle(oracle, "FLOAT", Ap, Aj, Ax, rows_idx, n, mask, v, "MULT", "PLUS", sel, init)
+            got = r[rows_idx].cpu().numpy()
+            bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+            print(f"[reference order] configs[1] R-MAT 23 fp32 plus-times {sel}: {len(got)} rows (the 4096 longest included) bit-identical to the oracle: {len(bad) == 0}; call {ms:.2f} ms")
+            PARITY_REPORT.append((f"configs[1] R-MAT 23, reference-order mode, {sel}: bit-identical rows", int(len(got)), float((len(got) - len(bad)) / len(got)), 0.0 if len(bad) == 0 else float("nan")))
+            assert len(bad) == 0, f"{sel}: {len(bad)} of {len(got)} rows differ from the oracle's word; first: row {int(rows_idx[bad[0]])}: {got[bad[0]]!r} vs {want[bad[0]]!r}"
+    finally:
+        assert _lib.call("splahip_set_reference_order", 0) == 1
+    plan.close()
+
+
+def test_cfg3_full_size_pagerank_pull_reference_order_is_bit_identical_to_the_oracle(oracle):
+    """VERDICT r5 item 2, configs[2]: the PageRank step — the pull form of exec_vxm_masked over M^T of the symmetrised R-MAT scale 22 stand-in (~220 M nnz),
+    values 0.85 / outdeg, v = 1/n — in reference-order mode: every output index adds its products in the order of v's indices (src/cpu/cpu_vxm.hpp:101-113).
+    Every 256th output and the 2048 longest columns against the oracle, bit for bit (the default mode holds 99.35 % of these outputs inside plain 1e-5)."""
+    import time
+    from spla_amd import _lib, kernels
+    n, Ap, Aj = _rmat(22, ef=28, device="cuda", symmetric=True)
+    nnz = int(Ap[-1])
+    deg = (Ap[1:] - Ap[:-1]).to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), deg)
+    Ax = (0.85 / deg.clamp(min=1).to(torch.float32))[rows].contiguous()
+    del rows
+    Tp, Tj, Tx = kernels.csr_transpose(n, n, Ap, Aj, Ax)
+    plan_T = kernels.CsrPlan(n, nnz, Tp)
+    assert plan_T.attach_cob(n, Tp, Tj, Tx) is not None
+    vi = torch.arange(n, dtype=torch.int32, device="cuda")
+    vx = torch.full((n,), 1.0 / n, dtype=torch.float32, device="cuda")
+    mask = torch.zeros(n, dtype=torch.float32, device="cuda")
+    assert _lib.call("splahip_set_reference_order", 1) == 0
+    try:
+        ri, rx = kernels.vxm_pull(plan_T, "FLOAT", n, n, Tp, Tj, Tx, mask, vi, vx, "MULT", "PLUS", "ALWAYS", identity=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ri, rx = kernels.vxm_pull(plan_T, "FLOAT", n, n, Tp, Tj, Tx, mask, vi, vx, "MULT", "PLUS", "ALWAYS", identity=True)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+    finally:
+        assert _lib.call("splahip_set_reference_order", 0) == 1
+    touched = torch.nonzero(Tp[1:] != Tp[:-1]).flatten().to(torch.int32)
+    assert torch.equal(ri.to(torch.int32), touched)
+    dense = torch.zeros(n, dtype=torch.float32, device="cuda")
+    dense[ri.to(torch.int64)] = rx
+    rows_idx = _rows_sample_with_the_heaviest(Tp, 256, 2048)
+    want = _sampled_rows_oracle(oracle, "FLOAT", Tp, Tj, Tx, rows_idx, n, mask, vx, "MULT", "PLUS", "ALWAYS", 0.0)  # x * v == v * x; 0 + p == p for p > 0
+    got = dense[rows_idx].cpu().numpy()
+    bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+    print(f"[reference order] configs[2] PageRank pull step: {len(got)} outputs (the 2048 longest columns included) bit-identical to the oracle: {len(bad) == 0}; call {ms:.2f} ms")
+    PARITY_REPORT.append(("configs[2] PageRank pull step, reference-order mode: bit-identical outputs", int(len(got)), float((len(got) - len(bad)) / len(got)), 0.0 if len(bad) == 0 else float("nan")))
+    assert len(bad) == 0, f"{len(bad)} of {len(got)} outputs differ from the oracle's word; first: {got[bad[0]]!r} vs {want[bad[0]]!r}"
+    plan_T.close()
+
+
 # ------------------------------------------------------------------------------------------ configs[4] and the N = 8 split of configs[3] at BASELINE's full sizes
 def test_cfg5_full_size_mxmT_rmat20_row_sample_and_triangle_count(oracle):
     """configs[4], triangle-count form at full size: L = strict lower triangle of symmetrised R-MAT scale 20 (15.7 M entries), exec_mxmT_masked(L, L, L) MULT / PLUS /

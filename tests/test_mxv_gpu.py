@@ -807,3 +807,88 @@ def test_first_hit_form_of_a_bfs_like_step(oracle, copy):
             assert plan.first_hit()["taken"]
             assert np.array_equal(host(early, NP[t]), oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, depth, vec, mul, add, "EQZERO", init, True)), (t, mul, add, init)
         plan.close()
+
+
+def test_reference_order_setting_gives_the_reference_fold_bit_for_bit(oracle):
+    """splahip_set_reference_order (include/spla_hip.h): an fp32 PLUS fold of mxv and of the pull form of vxm adds every row's products
+    strictly left to right from init in entry order — the reference's loop, src/cpu/cpu_mxv.hpp:94-99 / cpu_vxm.hpp:101-113 — so the result is the ORACLE'S
+    WORD on every row: rows folded by one lane out of LDS (up to 508 entries), rows of several segment items (one wavefront per row, a chain of dependent
+    additions; 509 ... 7000 entries here), unselected rows, empty rows; whatever copies the plan holds (blocks, sliced-ELL: both stand aside); random-magnitude
+    values so that every re-association would show.  The setting is per host thread and returns its previous value."""
+    import torch
+    from gpu_utils import dev, host
+    from spla_amd import _lib, kernels
+    rng = np.random.default_rng(606)
+    n_rows, n_cols = 12000, 9000
+    Ap, Aj, _ = random_csr(rng, n_rows, n_cols, 12, "FLOAT", skew=True, long_rows=6, long_len=7000)
+    deg = np.diff(Ap.astype(np.int64))
+    assert deg.max() >= 7000 and (deg > 1020).sum() >= 2
+    nnz = len(Aj)
+    Ax = ((rng.random(nnz) - 0.3) * np.exp(rng.normal(0, 3, nnz))).astype(np.float32)   # mixed signs and magnitudes: a different order is a different word
+    v = ((rng.random(n_cols) - 0.4) * np.exp(rng.normal(0, 2, n_cols))).astype(np.float32)
+    mask = random_mask(rng, n_rows, "FLOAT")
+    dAp, dAj, dAx, dm, dv = dev(Ap), dev(Aj), dev(Ax), dev(mask), dev(v)
+    plans = {"csr": kernels.CsrPlan(n_rows, nnz, dAp), "cob": kernels.CsrPlan(n_rows, nnz, dAp), "sell": kernels.CsrPlan(n_rows, nnz, dAp, n_cols, dAj, dAx)}
+    assert plans["cob"].attach_cob(n_cols, dAp, dAj, dAx) is not None
+    assert _lib.call("splahip_set_reference_order", 1) == 0
+    try:
+        assert "mxv_ordered" in kernels.mxv_variant("FLOAT", "MULT", "PLUS", False, plans["cob"])
+        assert "mxv_cob" in kernels.mxv_variant("FLOAT", "PLUS", "MIN", False, plans["cob"])      # exact in every form: stays
+        assert "mxv_cob" in kernels.mxv_variant("INT", "MULT", "PLUS", False, plans["cob"])
+        for (mul, sel, init) in [("MULT", "ALWAYS", 0.0), ("MULT", "NQZERO", 0.625), ("PLUS", "EQZERO", -3.5), ("MIN", "GTZERO", 1e-3), ("SECOND", "ALWAYS", 0.0)]:
+            want = oracle.mxv_masked("FLOAT", n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, "PLUS", sel, init)
+            for name, p in plans.items():
+                r = torch.full((n_rows,), -7.0, dtype=torch.float32, device="cuda")
+                kernels.mxv_masked(p, "FLOAT", n_cols, dAp, dAj, dAx, dm, dv, r, mul, "PLUS", sel, init)
+                torch.cuda.synchronize()
+                got = host(r, np.float32)
+                bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+                assert len(bad) == 0, f"{mul}/PLUS {sel} on the {name} plan: {len(bad)} rows differ from the oracle's word, first row {bad[0]} of {deg[bad[0]]} entries: {got[bad[0]]!r} vs {want[bad[0]]!r}"
+    finally:
+        assert _lib.call("splahip_set_reference_order", 0) == 1
+    # the default mode re-associates: on these values it must round differently somewhere (otherwise this test proves nothing)
+    want = oracle.mxv_masked("FLOAT", n_rows, n_cols, Ap, Aj, Ax, mask, v, "MULT", "PLUS", "ALWAYS", 0.0)
+    r = torch.empty(n_rows, dtype=torch.float32, device="cuda")
+    kernels.mxv_masked(plans["cob"], "FLOAT", n_cols, dAp, dAj, dAx, dm, dv, r, "MULT", "PLUS", "ALWAYS", 0.0)
+    torch.cuda.synchronize()
+    assert (host(r, np.float32).view(np.uint32) != want.view(np.uint32)).any(), "the default fold was expected to round differently somewhere on these values"
+    for p in plans.values():
+        p.close()
+
+
+def test_reference_order_setting_vxm_pull_bit_for_bit(oracle):
+    """The same setting for the pull form of exec_vxm_masked (the PageRank step of configs[2]): every output index's products are added in the order of v's
+    indices from the first product (src/cpu/cpu_vxm.hpp:101-113) — dense v (every index stored) and a sparse v (presence bitmap), a mask, long columns."""
+    from gpu_utils import dev, host
+    from spla_amd import _lib, kernels
+    rng = np.random.default_rng(607)
+    n_rows, n_cols = 7000, 8000
+    # long COLUMNS of M are long rows of M^T: build M^T with long rows, M = its transpose
+    Tp_h, Tj_h, _ = random_csr(rng, n_cols, n_rows, 9, "FLOAT", skew=True, long_rows=5, long_len=4000)
+    nnz = len(Tj_h)
+    Tx_h = ((rng.random(nnz) - 0.3) * np.exp(rng.normal(0, 3, nnz))).astype(np.float32)
+    dTp, dTj, dTx = dev(Tp_h), dev(Tj_h), dev(Tx_h)
+    Ap_d, Aj_d, Ax_d = kernels.csr_transpose(n_cols, n_rows, dTp, dTj, dTx)               # M: n_rows x n_cols
+    Ap, Aj, Ax = host(Ap_d, np.uint32), host(Aj_d, np.uint32), host(Ax_d, np.float32)
+    Tp2, Tj2, Tx2 = kernels.csr_transpose(n_rows, n_cols, Ap_d, Aj_d, Ax_d)               # M^T as the library builds it (stable: entries by ascending row of M)
+    mask = random_mask(rng, n_cols, "FLOAT")
+    for dense in (True, False):
+        if dense:
+            vi = np.arange(n_rows, dtype=np.uint32)
+        else:
+            vi = np.sort(rng.permutation(n_rows)[: n_rows // 3]).astype(np.uint32)
+        vx = ((rng.random(len(vi)) - 0.4) * np.exp(rng.normal(0, 2, len(vi)))).astype(np.float32)
+        for sel in ("ALWAYS", "NQZERO"):
+            wi, wx = oracle.vxm_masked("FLOAT", n_rows, n_cols, Ap, Aj, Ax, mask, vi, vx, "MULT", "PLUS", sel)
+            plan_T = kernels.CsrPlan(n_cols, nnz, Tp2)
+            assert plan_T.attach_cob(n_rows, Tp2, Tj2, Tx2) is not None
+            assert _lib.call("splahip_set_reference_order", 1) == 0
+            try:
+                ri, rx = kernels.vxm_pull(plan_T, "FLOAT", n_rows, n_cols, Tp2, Tj2, Tx2, dev(mask), dev(vi), dev(vx), "MULT", "PLUS", sel, identity=dense)
+            finally:
+                assert _lib.call("splahip_set_reference_order", 0) == 1
+            assert np.array_equal(host(ri, np.uint32), wi), f"dense={dense} {sel}: structure"
+            got = host(rx, np.float32)
+            bad = np.nonzero(got.view(np.uint32) != wx.view(np.uint32))[0]
+            assert len(bad) == 0, f"dense={dense} {sel}: {len(bad)} outputs differ from the oracle's word, first {got[bad[0]]!r} vs {wx[bad[0]]!r}"
+            plan_T.close()
