@@ -69,7 +69,7 @@ def parse():
     p.add_argument("--no-variants", action="store_true")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--no-scale23", action="store_true", help="skip the R-MAT scale-23 fp32 plus-times variant (the ~100 M-nnz north-star configuration)")
-    p.add_argument("--workload", default="spmv-fp32", choices=["spmv-fp32", "bfs-step", "pagerank-vxm", "vxm-push", "sssp-step", "tc-mxmT", "mxm", "algorithms", "transpose"],
+    p.add_argument("--workload", default="spmv-fp32", choices=["spmv-fp32", "bfs-step", "pagerank-vxm", "vxm-push", "sssp-step", "tc-mxmT", "mxm", "mxm-19", "mxm-dense", "algorithms", "transpose"],
                    help="spmv-fp32 (default, the contract line: the north-star configuration), bfs-step (BASELINE configs[1], the contract line of rounds 1-2) "
                         "or one of the other hot-path operators (bench_workloads.py; N = 1 only)")
     a = p.parse_args()
@@ -426,7 +426,9 @@ def bfs_step_line(args, rank, world):
 
     # HBM-side traffic of the same kernel from the rocprofv3 PMC passes (tools/gpu_round.sh -> tools/pmc_traffic.py):
     # collected by a separate profiler run of this command, so it is read from profiles/ when it matches this workload
-    tf = ROOT / "profiles" / "r05_pmc_traffic.json"
+    tf = ROOT / "profiles" / "r06_pmc_traffic.json"
+    if not tf.exists():
+        tf = ROOT / "profiles" / "r05_pmc_traffic.json"
     if not tf.exists():
         tf = ROOT / "profiles" / "r04_pmc_traffic.json"
     if not tf.exists():

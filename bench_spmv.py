@@ -174,7 +174,9 @@ def cpu_reference_sample(t, Ap, Aj, Ax, mask, v, r, mul, add, sel, init, sample_
 
 def pmc_traffic(key):
     """per-call fabric traffic of this workload from the committed counter pass (separate rocprofv3 --pmc runs; profiles/r03_pmc_<key>.json)"""
-    f = ROOT / "profiles" / f"r05_pmc_{key}.json"
+    f = ROOT / "profiles" / f"r06_pmc_{key}.json"
+    if not f.exists():
+        f = ROOT / "profiles" / f"r05_pmc_{key}.json"
     if not f.exists():
         f = ROOT / "profiles" / f"r04_pmc_{key}.json"
     if not f.exists():  # (the kernels of this call did not change since round 3's pass)
@@ -361,7 +363,8 @@ def config_variants(args, t_start):
     import bench_workloads
     res = []
     budget_s = float(os.environ.get("SPLA_BENCH_BUDGET_S", 420))
-    for key, label in (("pagerank-vxm", "configs[2]"), ("sssp-step", "configs[3] at N = 1"), ("tc-mxmT", "configs[4]: mxmT(L, L, L), R-MAT 20"), ("mxm", "configs[4]: mxm A x A, R-MAT 18")):
+    for key, label in (("pagerank-vxm", "configs[2]"), ("sssp-step", "configs[3] at N = 1"), ("tc-mxmT", "configs[4]: mxmT(L, L, L), R-MAT 20"), ("mxm", "configs[4]: mxm A x A, R-MAT 18"),
+                       ("mxm-19", "configs[4]: mxm A x A, R-MAT 19 (3.53 G result entries: the largest the reference's 32-bit row pointers index)")):
         if time.time() - t_start > budget_s:
             res.append({"name": f"{label} ({key})", "skipped": "time budget of the default run used up: python bench.py --workload " + key})
             continue

@@ -63,7 +63,9 @@ def _roof(alg_bytes, ms, kernel, pmc=None):
     if pmc:
         import json
         from pathlib import Path
-        f = Path(__file__).resolve().parent / "profiles" / f"r05_pmc_{pmc}.json"
+        f = Path(__file__).resolve().parent / "profiles" / f"r06_pmc_{pmc}.json"
+        if not f.exists():
+            f = Path(__file__).resolve().parent / "profiles" / f"r05_pmc_{pmc}.json"
         if not f.exists():
             f = Path(__file__).resolve().parent / "profiles" / f"r04_pmc_{pmc}.json"
         if not f.exists():
@@ -375,7 +377,7 @@ def tc_mxmT(args):
 def mxm(args):
     from oracle import pyoracle
     from spla_amd import graphgen, kernels
-    scale = 18 if args.scale == 22 else args.scale
+    scale = getattr(args, "mxm_scale", 0) or (18 if args.scale == 22 else args.scale)
     n, Ap, Aj = graphgen.rmat_csr(scale, args.edge_factor, seed=args.seed, device="cuda")
     nnz = int(Ap[-1])
     g = torch.Generator(device="cuda")
@@ -406,14 +408,18 @@ def mxm(args):
     args_steps = args.steps
     args.steps = steps
     line = _line("SpGEMM (mxm) G products/s", "Gproducts/s", P / (wall / steps) / 1e9, args, wall / steps * 1e3, "f32",
-                 {"workload": f"exec_mxm A x A, MULT/PLUS fp32, init 0; R-MAT scale {scale} ef {args.edge_factor} (scale 20 of BASELINE configs[4] expands to more "
-                              "products than one ESC pass should hold in round 1; stated fallback)", "n": n, "nnz_A": nnz, "products": P, "nnz_C": nnz_c,
+                 {"workload": f"exec_mxm A x A, MULT/PLUS fp32, init 0; R-MAT scale {scale} ef {args.edge_factor} (BASELINE configs[4] names scale 20: its result holds more than "
+                              "2^32 entries, which the reference's 32-bit row pointers (include/spla/config.hpp:56, `uint`) cannot index — the call refuses it, "
+                              "tests/test_mxm_gpu.py::test_mxm_refuses_a_result_beyond_32bit_row_pointers; scale 19, 3.53 G result entries, is the largest that fits)",
+                  "n": n, "nnz_A": nnz, "products": P, "nnz_C": nnz_c,
                   "form": "row classes (mxm_spa.hip): rows of > 4096 products keep the result row's accumulators in LDS (Gustavson; symbolic pass, then the ranked form "
                           "for rows whose entries fit one block and column blocks for the hubs), lighter rows through ESC; a dense leading corner would run on MFMA "
                           "(none in R-MAT: the 1 K x 1 K hub corner is ~23 % full); timed: the blocking C call", "row_classes": _mxm_info()},
-                 _roof(alg, ms, "mxm_spa (symbolic + numeric) + ESC for the light rows", pmc="mxm" if scale == 18 else None))
+                 _roof(alg, ms, "mxm_spa (symbolic + numeric) + ESC for the light rows", pmc="mxm" if scale == 18 else "mxm_scale19" if scale == 19 else None))
     args.steps = args_steps
     if not args.no_verify or not args.no_cpu_baseline:
+        del Rp, Rj, Rx  # (scale 19: 28 GB)
+        torch.cuda.empty_cache()
         srows = torch.arange(0, n, 256, device="cuda")
         Sp, Sj, Sx = _row_sample_csr(Ap, Aj, Ax, srows)
         (gp, gj, gx), sprod = kernels.mxm("FLOAT", n, n, (Sp, Sj, Sx), A, "MULT", "PLUS", 0.0)
@@ -647,4 +653,144 @@ def vxm_push(args):
     return line
 
 
-WORKLOADS = {"vxm-push": vxm_push, "pagerank-vxm": pagerank_vxm, "sssp-step": sssp_step, "tc-mxmT": tc_mxmT, "mxm": mxm, "algorithms": algorithms, "transpose": transpose}
+def mxm_dense(args):
+    """The MFMA sub-path of exec_mxm measured (north star: "MFMA used only ... where a row-bucket degenerates to a dense tile"): R-MAT scale 16 with a
+    planted fully dense H x H block on the diagonal, away from the origin (rows and columns [2H, 3H), H = 4096 unless --scale says otherwise), A x A fp32 MULT / PLUS.
+    Three runs of the same call: the window capped at the library's default side (1024), the window allowed the whole block (SPLAHIP_MXM_DENSE_H = H), and no window
+    (SPLAHIP_MXM_DENSE=0: every product through the sparse row classes).  Reported: the window found, the time of its MFMA GEMM (values; a second GEMM of the same shape
+    counts the products per cell) against the dense fp32 MFMA peak, end-to-end products/s of each run, parity against the oracle on a row sample (rows through the block
+    included) and agreement of the runs' structure."""
+    import ctypes as C
+    from oracle import pyoracle
+    from spla_amd import _lib, graphgen, kernels
+    scale, H = 16, 4096
+    n, Ap0, Aj0 = graphgen.rmat_csr(scale, args.edge_factor, seed=args.seed, device="cuda")
+    lo, hi_ = 2 * H, 3 * H
+    rows0 = torch.repeat_interleave(torch.arange(n, device="cuda"), (Ap0[1:] - Ap0[:-1]).to(torch.int64))
+    blk = torch.arange(lo, hi_, device="cuda", dtype=torch.int64)
+    keys = torch.unique(torch.cat([rows0 * n + Aj0.to(torch.int64), (blk[:, None] * n + blk[None, :]).reshape(-1)]), sorted=True)
+    del rows0
+    Ap, Aj = graphgen.keys_to_csr(keys, n, n)
+    del keys
+    nnz = int(Ap[-1])
+    g = torch.Generator(device="cuda")
+    g.manual_seed(args.seed + 19)
+    Ax = (torch.rand(nnz, generator=g, device="cuda") * 0.5 + 0.25).contiguous()
+    A = (Ap, Aj, Ax)
+
+    def one(env):
+        for k, v in env.items():
+            os.environ[k] = v
+        _lib.call("splahip_env_refresh")
+        try:
+            walls, P, win, gemm_ms, raw = [], 0, None, 0.0, None
+            for it in range(3):
+                if raw is not None:
+                    raw.free()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                raw, P = kernels.mxm("FLOAT", n, n, A, A, "MULT", "PLUS", 0.0, adopt=False)
+                dt = time.perf_counter() - t0
+                if it:
+                    walls.append(dt)
+                w = (C.c_uint32 * 6)()
+                _lib.call("splahip_mxm_last_dense", w)
+                win = [int(x) for x in w]
+                ms = C.c_float(0.0)
+                _lib.call("splahip_mxm_last_dense_ms", C.byref(ms))
+                gemm_ms = float(ms.value)
+            return float(np.mean(walls)) * 1e3, P, win, gemm_ms, raw
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+            _lib.call("splahip_env_refresh")
+
+    res = {}
+    runs = {"window <= 1024 (library default)": {"SPLAHIP_MXM_DENSE_TIME": "1"},
+            f"window <= {H} (the whole planted block)": {"SPLAHIP_MXM_DENSE_TIME": "1", "SPLAHIP_MXM_DENSE_H": str(H)},
+            "no window (all sparse)": {"SPLAHIP_MXM_DENSE": "0"}}
+    structure = None
+    for name, env in runs.items():
+        ms, P, win, gemm_ms, raw = one(env)
+        e = {"ms_per_call": round(ms, 2), "products": P, "gproducts_per_s": round(P / (ms * 1e-3) / 1e9, 2), "window_i0_k0_j0_hi_hk_hj": win}
+        if win[3]:
+            flops = 2.0 * win[3] * win[4] * win[5]
+            e["window_products"] = int(win[3]) * int(win[4]) * int(win[5])
+            if gemm_ms > 0:
+                # the event pair brackets TWO GEMMs of the same shape (values; product counts): the rate is quoted per GEMM
+                e["mfma_gemm_ms_each"] = round(gemm_ms / 2, 4)
+                e["mfma_gemm_tflops"] = round(flops / (gemm_ms / 2 * 1e-3) / 1e12, 2)
+                e["mfma_frac_of_fp32_peak"] = round(flops / (gemm_ms / 2 * 1e-3) / 1e12 / 157.3, 4)
+        Rp = raw.Rp.clone()
+        if structure is None:
+            structure = Rp
+            e["same_structure_as_first_run"] = True
+        else:
+            e["same_structure_as_first_run"] = bool(torch.equal(structure, Rp))
+        res[name] = e
+        _log(f"[bench] mxm-dense {name}: {e}")
+        if name.startswith(f"window <= {H}"):
+            best = raw  # (checked against the oracle below)
+        else:
+            raw.free()
+    # parity of the full-window run on a row sample: every 64th row plus 64 rows through the planted block
+    line_ok = None
+    if not args.no_verify:
+        Rp64 = best.Rp.to(torch.int64) & 0xFFFFFFFF
+        Rj, Rx = best.adopt("FLOAT")[1:]
+        srows = torch.unique(torch.cat([torch.arange(0, n, 64, device="cuda"), torch.arange(lo, hi_, 64, device="cuda") + 7]))
+        Sp, Sj, Sx = _row_sample_csr(Ap, Aj, Ax, srows)
+        Ah = tuple(t.cpu().numpy() for t in A)
+        wp, wj, wx = pyoracle.Oracle().mxm("FLOAT", n, n, (Sp.cpu().numpy(), Sj.cpu().numpy(), Sx.cpu().numpy()), Ah, "MULT", "PLUS", 0.0)  # (same shape, unsampled rows empty)
+        lens = (Rp64[1:] - Rp64[:-1])[srows]
+        Op = torch.zeros(srows.numel() + 1, dtype=torch.int64, device="cuda")
+        torch.cumsum(lens, 0, out=Op[1:])
+        orep = torch.repeat_interleave(torch.arange(srows.numel(), device="cuda"), lens)
+        pos = Rp64[srows][orep] + (torch.arange(int(Op[-1]), device="cuda") - Op[:-1][orep])
+        same_structure = bool(np.array_equal(lens.cpu().numpy(), np.diff(wp.astype(np.int64))[srows.cpu().numpy()]) and np.array_equal(Rj[pos].cpu().numpy().view(np.uint32), wj))
+        # values: an entry of the planted block is a sum of >= 4096 products — the reference's sequential fp32 fold is itself up to ~1e-4 away from the sum there, so,
+        # as for the long rows of the SpMV (tests/test_configs_gpu.py: _assert_fp32_sum_parity), every entry is held to 1e-5 relative PLUS the oracle's own distance
+        # from an fp64 evaluation of the same products, and the share inside plain 1e-5 is reported
+        import scipy.sparse as sp
+        S64 = sp.csr_matrix((Sx.cpu().numpy().astype(np.float64), Sj.cpu().numpy().astype(np.int64), Sp.cpu().numpy().astype(np.int64)), shape=(n, n))
+        A64 = sp.csr_matrix((Ah[2].astype(np.float64), Ah[1].astype(np.int64), Ah[0].astype(np.int64)), shape=(n, n))
+        E = (S64 @ A64).tocsr()
+        E.sort_indices()
+        got64, want64 = Rx[pos].cpu().numpy().astype(np.float64), wx.astype(np.float64)
+        exact_ok = same_structure and E.nnz == len(wj) and np.array_equal(E.indices.astype(np.uint32), wj)
+        ex = E.data if exact_ok else want64
+        diff = np.abs(got64 - want64) if same_structure else np.array([np.inf])
+        plain = diff <= 1e-5 * np.abs(want64) if same_structure else np.array([False])
+        line_ok = bool(same_structure and exact_ok and np.all(diff <= 1e-5 * np.abs(want64) + 1.01 * np.abs(want64 - ex) + 1e-30))
+        parity = {"rows": int(srows.numel()), "entries": int(len(wj)), "same_structure": same_structure, "within_plain_1e-5": float(plain.mean()),
+                  "max_rel_vs_oracle": float(np.max(diff / np.maximum(np.abs(want64), 1e-30))) if same_structure else None,
+                  "max_rel_vs_fp64": {"hip": float(np.max(np.abs(got64 - ex) / np.maximum(np.abs(ex), 1e-30))), "reference_sequential_fold": float(np.max(np.abs(want64 - ex) / np.maximum(np.abs(ex), 1e-30)))} if exact_ok else None}
+        _log(f"[bench] mxm-dense parity vs oracle: {parity}: {'OK' if line_ok else 'MISMATCH'}")
+        if not line_ok:
+            raise SystemExit("bench: mxm-dense result differs from the oracle")
+    else:
+        best.free()
+    full = res[f"window <= {H} (the whole planted block)"]
+    line = _line("SpGEMM (mxm) with a dense block on the matrix cores, G products/s", "Gproducts/s", full["gproducts_per_s"], args, full["ms_per_call"], "f32",
+                 {"workload": f"exec_mxm A x A, MULT/PLUS fp32: R-MAT scale {scale} ef {args.edge_factor} + a planted fully dense {H} x {H} block at rows / columns [{lo}, {hi_})",
+                  "n": n, "nnz_A": nnz, "products": full["products"], "runs": res,
+                  "mfma": "v_mfma_f32_32x32x2_f32, LDS-staged double-buffered K panels of 32, a 64 x 64 tile of C per four-wave workgroup (mxm_spa.hip: dense_gemm_mfma_kernel); "
+                          "dense fp32 MFMA peak 157.3 TFLOP/s"},
+                 {"bound": "mfma", "achieved": full.get("mfma_gemm_tflops"), "peak": 157.3, "unit": "TFLOP/s", "frac": full.get("mfma_frac_of_fp32_peak"), "traffic": None,
+                  "kernel": "dense_gemm_mfma_kernel (the window's values GEMM)"})
+    if line_ok is not None:
+        line["verified"], line["parity"] = line_ok, parity
+    return line
+
+
+def mxm_scale19(args):
+    """exec_mxm A x A at R-MAT scale 19: 3.53 G result entries, the largest result of this family the reference's 32-bit row pointers can index."""
+    import copy
+    b = copy.copy(args)
+    b.mxm_scale = 19
+    b.steps = min(b.steps, 3)
+    return mxm(b)
+
+
+WORKLOADS = {"vxm-push": vxm_push, "pagerank-vxm": pagerank_vxm, "sssp-step": sssp_step, "tc-mxmT": tc_mxmT, "mxm": mxm, "mxm-19": mxm_scale19, "mxm-dense": mxm_dense, "algorithms": algorithms,
+             "transpose": transpose}

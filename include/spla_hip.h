@@ -321,6 +321,9 @@ int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols,
 /* which row classes the last splahip_mxm of this host thread used (mxm_spa.hip): rows served by the LDS-accumulator form, entries the light rows'
  * ESC call produced, rows of the dense window computed on the matrix cores (0 = none; splahip_mxm_last_dense: where it lies).  All 0: the whole call ran the ESC form. */
 int splahip_mxm_last_info(uint32_t* n_heavy_rows, uint32_t* light_nnz, uint32_t* dense_h);
+/* Measurement helper (bench.py --workload mxm-dense): the time in ms of the two MFMA GEMMs (values and product counts) of the dense window of the calling thread's
+ * last splahip_mxm call, measured with events when SPLAHIP_MXM_DENSE_TIME=1 was set for that call (0: no window, or not timed). */
+int splahip_mxm_last_dense_ms(float* gemm_ms);
 /* the dense window of that call: six words i0, k0, j0, rows, inner, columns — A[i0 : i0 + rows, k0 : k0 + inner] x B[k0 : k0 + inner, j0 : j0 + columns], blocks of
  * half-full 32 x 32 tiles found ANYWHERE in the operands (fp32 MULT / PLUS), went through the matrix cores (LDS-staged v_mfma_f32_32x32x2_f32); rows == 0: none.
  * (reference: the accumulator row of Algo_mxm_cpu, src/cpu/cpu_mxm.hpp:93-113, restricted to the window's cells) */

@@ -114,6 +114,7 @@ _SIGNATURES = {
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, _vp]),
     "splahip_mxm_trim": (C.c_int, []),
     "splahip_mxm_last_info": (C.c_int, [_u32p, _u32p, _u32p]),
+    "splahip_mxm_last_dense_ms": (C.c_int, [C.POINTER(C.c_float)]),
     "splahip_mxm_last_dense": (C.c_int, [_u32p]),
     "splahip_mxmT_masked": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32] + [_vp] * 9 + [_vp, C.POINTER(_vp), C.POINTER(_vp), _u32p,
                                       C.c_int, C.c_int, C.c_int, C.c_uint32, _vp]),

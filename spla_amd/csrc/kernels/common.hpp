@@ -85,7 +85,9 @@ namespace splahip {
     };
     bool       scratch_active();                    // inside a ScratchScope of this thread (and not paused)
     hipError_t scratch_take(void** p, size_t bytes);// 256-byte aligned; valid until the innermost open scope ends
-    void       scratch_trim();                      // frees this thread's arena unless a scope is open
+    void       scratch_trim();                      // frees the arena of every host thread that has no scope open (and those of threads that have exited)
+    void       stream_caches_trim();                // frees every host thread's cache of released stream-ordered blocks (below)
+    void       pool_trim();                         // gives the stream-ordered pool's unused blocks back to the driver
     struct ScratchPause {                           // a nested call that allocates in a loop keeps to the pool
         ScratchPause();
         ~ScratchPause();

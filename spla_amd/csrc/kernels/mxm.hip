@@ -30,6 +30,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 namespace splahip {
@@ -73,13 +74,23 @@ namespace splahip {
         // pool's behaviour for buffers of this size is erratic (the same call: 0.2 ms or 2.6 s).  Released by splahip_mxm_trim().
         hipError_t alloc_cached(unsigned slot, size_t bytes) {
             drop();
-            auto& c = cache();
+            SlotCache& sc = cache();
+            std::lock_guard<std::mutex> g(sc.m);
+            auto& c = sc.slots;
             if (c.size() <= slot) c.resize(slot + 1);
             if (c[slot].bytes < bytes) {
                 if (c[slot].p) (void) hipFree(c[slot].p);
                 c[slot] = {nullptr, 0};
                 register_trim(&DevBuf::trim);// (idempotent) the cache goes back to the driver when any allocation of the library runs out of memory
-                hipError_t e = device_malloc(&c[slot].p, bytes);
+                hipError_t e = hipMalloc(&c[slot].p, bytes);
+                if (e == hipErrorOutOfMemory) {// (the release-everything retry outside this cache's lock: it trims every thread's cache, this one included)
+                    (void) hipGetLastError();
+                    sc.m.unlock();
+                    release_idle_memory();
+                    sc.m.lock();
+                    if (c.size() <= slot) c.resize(slot + 1);
+                    e = hipMalloc(&c[slot].p, bytes);
+                }
                 if (e != hipSuccess) return e;
                 c[slot].bytes = bytes;
             }
@@ -91,20 +102,64 @@ namespace splahip {
             void*  p;
             size_t bytes;
         };
-        static std::vector<Slot>& cache() {
-            static thread_local std::vector<Slot> c;
-            return c;
+        // (one per host thread, listed process-wide like the caches of runtime.hip: a trim frees the workspaces of every thread that is not inside a call, and
+        // deletes the caches of threads that have exited — the thread_local holder's destructor only marks its cache an orphan, it makes no HIP call)
+        struct SlotCache {
+            std::mutex        m;
+            std::vector<Slot> slots;
+            int               busy   = 0;// > 0 while an mxm / mxmT call of the owning thread is using the cached workspaces: a trim must not free them
+            bool              orphan = false;
+        };
+        struct SlotRegistry {
+            std::mutex              m;
+            std::vector<SlotCache*> all;
+        };
+        static SlotRegistry& registry() {
+            static SlotRegistry* r = new SlotRegistry;
+            return *r;
         }
-        // > 0 while an mxm / mxmT call of this thread is using the cached workspaces: an out-of-memory retry inside that call must not free them
-        static int& busy() {
-            static thread_local int b = 0;
-            return b;
+        struct SlotHolder {
+            SlotCache* c;
+            SlotHolder() : c(new SlotCache) {
+                auto& r = registry();
+                std::lock_guard<std::mutex> g(r.m);
+                r.all.push_back(c);
+            }
+            ~SlotHolder() {
+                std::lock_guard<std::mutex> g(c->m);
+                c->orphan = true;
+            }
+        };
+        static SlotCache& cache() {
+            static thread_local SlotHolder h;
+            return *h.c;
+        }
+        static void busy_add(int d) {
+            SlotCache& c = cache();
+            std::lock_guard<std::mutex> g(c.m);
+            c.busy += d;
         }
         static void trim() {
-            if (busy() > 0) return;
-            for (auto& sl : cache())
-                if (sl.p) (void) hipFree(sl.p);
-            cache().clear();
+            auto& r = registry();
+            std::lock_guard<std::mutex> rg(r.m);
+            for (size_t k = 0; k < r.all.size();) {
+                SlotCache* c    = r.all[k];
+                bool       drop = false;
+                {
+                    std::lock_guard<std::mutex> g(c->m);
+                    if (c->busy <= 0) {
+                        for (auto& sl : c->slots)
+                            if (sl.p) (void) hipFree(sl.p);
+                        c->slots.clear();
+                        drop = c->orphan;
+                    }
+                }
+                if (drop) {
+                    delete c;
+                    r.all.erase(r.all.begin() + (long) k);
+                } else
+                    ++k;
+            }
         }
         bool cached = false;
         void* release() {
@@ -976,8 +1031,8 @@ namespace splahip {
                    const uint* Bp, const uint* Bj, const void* Bx, uint* Rp, uint** Rj, void** Rx, uint* h_nnz,
                    int op_mult, int op_add, int op_select, uint32_t init_bits, hipStream_t s, hipFunction_t jit_entry = nullptr) {
         struct Busy {
-            Busy() { ++DevBuf::busy(); }
-            ~Busy() { --DevBuf::busy(); }
+            Busy() { DevBuf::busy_add(1); }
+            ~Busy() { DevBuf::busy_add(-1); }
         } busy_scope;// the cached workspaces are in use until this call returns
         ScratchScope scratch_scope(s);// (before every DevBuf: the workspaces below come from the thread's scratch arena and go back when the call ends)
 
@@ -1417,8 +1472,8 @@ namespace splahip {
                   uint* Rp, uint** Rj, void** Rx, uint* h_nnz, u64* h_products, int op_mult, int op_add, uint32_t init_bits,
                   u64 block_products, hipStream_t s, hipFunction_t jit_expand = nullptr, hipFunction_t jit_run = nullptr) {
         struct Busy {
-            Busy() { ++DevBuf::busy(); }
-            ~Busy() { --DevBuf::busy(); }
+            Busy() { DevBuf::busy_add(1); }
+            ~Busy() { DevBuf::busy_add(-1); }
         } busy_scope;// the cached workspaces are in use until this call returns
 
         *Rj = nullptr, *Rx = nullptr, *h_nnz = 0;
@@ -1667,6 +1722,7 @@ namespace splahip {
 }// namespace splahip
 
 namespace splahip {
+    void mxm_pinned_trim();// mxm_spa.hip: the pinned staging chunks of every host thread that is not inside a call
     int mxm_spa(int type, uint32_t a_rows, uint32_t b_cols, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const uint32_t* Bp, const uint32_t* Bj, const void* Bx, uint32_t* Rp,
                 uint32_t** Rj, void** Rx, uint32_t* h_nnz, unsigned long long* h_products, int op_mult, int op_add, uint32_t init_bits, hipStream_t s);
 }
@@ -1765,7 +1821,11 @@ int splahip_mxm(int type, uint32_t a_rows, uint32_t b_cols,
 int splahip_mxm_trim(void) {
     DevBuf::trim();
     scratch_trim();
+    stream_caches_trim();
+    mxm_pinned_trim();
     handoff_trim();
+    (void) hipDeviceSynchronize();// (what the pool still holds for queued work stays; everything else goes back)
+    pool_trim();
     return SPLAHIP_OK;
 }
 }

@@ -34,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <unordered_map>
 #include <vector>
@@ -48,6 +49,7 @@ namespace splahip {
     thread_local bool tl_mxm_force_esc = false;// set around the light rows' call into the ESC form
     thread_local uint32_t tl_last_dense[6] = {0, 0, 0, 0, 0, 0};// the dense window of the last mxm of this thread: i0, k0, j0, rows, inner, columns (splahip_mxm_last_dense)
     thread_local uint32_t tl_last_dense_h = 0, tl_last_heavy = 0, tl_last_light_nnz = 0, tl_last_ranked = 0;// what the last mxm of this thread did (splahip_mxm_last_info)
+    thread_local float    tl_last_gemm_ms = 0.0f;// the two MFMA GEMMs (values, product counts) of the last call's dense window, timed with events when SPLAHIP_MXM_DENSE_TIME=1
 
     namespace {
 
@@ -871,17 +873,24 @@ namespace splahip {
         // PINNED host memory for the few MB a call moves between host and device (row products and counts down, batch / item lists and row pointers up): a bump
         // allocator per host thread, reset at the start of a call and kept for the life of the process (like runtime.hip's mailbox).  A copy from or to pageable
         // memory is staged by the runtime and blocks the host: ~0.15 ms per small copy, 0.7 ms per MB (round-5 trace: 14 ms of a 54 ms call with the GPU idle)
+        // (one per host thread, listed in a process-wide registry like the device-side caches of runtime.hip: splahip_mxm_trim frees the chunks of every thread that is
+        // not inside a call and deletes the arenas of threads that have exited — the thread_local holder's destructor only marks its arena an orphan)
         struct PinnedArena {
             struct Chunk {
                 unsigned char* p;
                 size_t         cap, used;
             };
+            std::mutex         m;
             std::vector<Chunk> chunks;
+            int                in_call = 0;
+            bool               orphan  = false;
             void reset() {
+                std::lock_guard<std::mutex> g(m);
                 for (Chunk& c : chunks) c.used = 0;
             }
             void* take(size_t bytes) {
                 bytes = (bytes + 255) & ~size_t(255);
+                std::lock_guard<std::mutex> g(m);
                 for (Chunk& c : chunks)
                     if (c.cap - c.used >= bytes) {
                         void* r = c.p + c.used;
@@ -898,10 +907,42 @@ namespace splahip {
                 return p;
             }
         };
-        PinnedArena& arena() {
-            static thread_local PinnedArena* a = new PinnedArena;
-            return *a;
+        struct PinnedRegistry {
+            std::mutex                m;
+            std::vector<PinnedArena*> all;
+        };
+        PinnedRegistry& pinned_registry() {
+            static PinnedRegistry* r = new PinnedRegistry;
+            return *r;
         }
+        struct PinnedHolder {
+            PinnedArena* a;
+            PinnedHolder() : a(new PinnedArena) {
+                auto& r = pinned_registry();
+                std::lock_guard<std::mutex> g(r.m);
+                r.all.push_back(a);
+            }
+            ~PinnedHolder() {
+                std::lock_guard<std::mutex> g(a->m);
+                a->orphan = true;
+            }
+        };
+        PinnedArena& arena() {
+            static thread_local PinnedHolder h;
+            return *h.a;
+        }
+        struct PinnedCall {// the calling thread's arena is in use for the length of a call (a trim from another thread leaves it alone)
+            PinnedCall() {
+                PinnedArena& a = arena();
+                std::lock_guard<std::mutex> g(a.m);
+                ++a.in_call;
+            }
+            ~PinnedCall() {
+                PinnedArena& a = arena();
+                std::lock_guard<std::mutex> g(a.m);
+                --a.in_call;
+            }
+        };
         // host -> device through the arena (the source may go out of scope at once); device -> host INTO the arena (valid after the next synchronisation of s,
         // until the thread's next mxm call)
         hipError_t h2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
@@ -1196,8 +1237,18 @@ namespace splahip {
                                 if (e != hipSuccess) break;
                                 if (!hs[0] && hs[1] >= 0.5 * hi * hk && hs[2] >= 0.5 * hk * hj) {
                                     const dim3 grid((hj + 63) / 64, (hi + 63) / 64);
+                                    const bool timed = env_u32("SPLAHIP_MXM_DENSE_TIME", 0) != 0;// (measurement runs: bench.py --workload mxm-dense)
+                                    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+                                    if (timed && hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess) (void) hipEventRecord(ev0, s);
                                     hipLaunchKernelGGL(dense_gemm_mfma_kernel, grid, dim3(256), 0, s, hi, hj, hk, dA, dB, dC);
                                     hipLaunchKernelGGL(dense_gemm_mfma_kernel, grid, dim3(256), 0, s, hi, hj, hk, sA, sB, dN);
+                                    tl_last_gemm_ms = 0.0f;
+                                    if (ev0 && ev1) {
+                                        (void) hipEventRecord(ev1, s);
+                                        if (hipEventSynchronize(ev1) == hipSuccess) (void) hipEventElapsedTime(&tl_last_gemm_ms, ev0, ev1);
+                                    }
+                                    if (ev0) (void) hipEventDestroy(ev0);
+                                    if (ev1) (void) hipEventDestroy(ev1);
                                     d_i0 = i0, d_k0 = k0, d_j0 = j0, d_hi = hi, d_hk = hk, d_hj = hj;
                                 } else {// halve the longest side, keeping the seed's tile inside
                                     uint32_t &lo = (i_hi - i_lo >= k_hi - k_lo && i_hi - i_lo >= j_hi - j_lo) ? i_lo : (k_hi - k_lo >= j_hi - j_lo ? k_lo : j_lo);
@@ -1435,6 +1486,7 @@ namespace splahip {
         const int acc = cob_acc_kind(op_add, type);
         if (acc == COB_NONE || b_cols == 0) return -1;
         arena().reset();
+        PinnedCall   pinned_call;
         ScratchScope scratch_scope(s);
         Scratch      tmp(s);
         u64*      dP    = nullptr;
@@ -1506,6 +1558,36 @@ namespace splahip {
 
 // which row classes the last splahip_mxm of this thread used: heavy rows (LDS accumulator form), entries produced by the light rows' ESC call,
 // side of the dense corner that ran on the matrix cores (0 = none)
+namespace splahip {
+    // the pinned staging chunks of every host thread that is not inside an mxm call go back to the driver; arenas of threads that have exited are deleted
+    void mxm_pinned_trim() {
+        auto& r = pinned_registry();
+        std::lock_guard<std::mutex> rg(r.m);
+        for (size_t k = 0; k < r.all.size();) {
+            PinnedArena* a    = r.all[k];
+            bool         drop = false;
+            {
+                std::lock_guard<std::mutex> g(a->m);
+                if (a->in_call == 0) {
+                    for (auto& c : a->chunks) (void) hipHostFree(c.p);
+                    a->chunks.clear();
+                    drop = a->orphan;
+                }
+            }
+            if (drop) {
+                delete a;
+                r.all.erase(r.all.begin() + (long) k);
+            } else
+                ++k;
+        }
+    }
+}// namespace splahip
+
+extern "C" int splahip_mxm_last_dense_ms(float* gemm_ms) {
+    if (gemm_ms) *gemm_ms = splahip::tl_last_dense_h ? splahip::tl_last_gemm_ms : 0.0f;
+    return SPLAHIP_OK;
+}
+
 extern "C" int splahip_mxm_last_info(uint32_t* n_heavy_rows, uint32_t* light_nnz, uint32_t* dense_h) {
     if (n_heavy_rows) *n_heavy_rows = splahip::tl_last_heavy;
     if (light_nnz) *light_nnz = splahip::tl_last_light_nnz;

@@ -160,6 +160,12 @@ namespace splahip {
             if (f == fn) return;
         g_trim_fns.push_back(fn);
     }
+    void pool_trim() {// the stream-ordered pool's unused blocks (its release threshold is raised at start-up: it gives nothing back on its own)
+        int          dev  = 0;
+        hipMemPool_t pool = nullptr;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) (void) hipMemPoolTrimTo(pool, 0);
+        (void) hipGetLastError();
+    }
     void release_idle_memory() {
         (void) hipDeviceSynchronize();// nothing queued may still use a block that goes back to the driver
         handoff_trim();
@@ -169,10 +175,7 @@ namespace splahip {
             fns = g_trim_fns;
         }
         for (auto f : fns) f();
-        int          dev  = 0;
-        hipMemPool_t pool = nullptr;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) (void) hipMemPoolTrimTo(pool, 0);
-        (void) hipGetLastError();
+        pool_trim();
     }
     hipError_t device_malloc(void** p, size_t bytes) {
         hipError_t e = hipMalloc(p, bytes);
@@ -200,48 +203,98 @@ namespace splahip {
             size_t      cap;
             hipStream_t s;
         };
+        // Every host thread owns one cache; all of them are listed in a process-wide registry so that an out-of-memory retry (release_idle_memory) and
+        // splahip_mxm_trim can give back the blocks of EVERY thread, and so that the blocks of a thread that has exited are not lost: the thread_local holder's
+        // destructor only marks its cache an orphan (no HIP call from a TLS destructor: it may run after the runtime's), the next trim frees and deletes it.
+        // (the caches were thread_locals created with `new`, trimmed only by their own thread and never destroyed.)
         struct StreamCache {
+            std::mutex                        m;// the owner's calls and another thread's trim
             std::vector<StreamBlock>          free;// oldest first
             std::unordered_map<void*, size_t> live;// handed out: capacity
             size_t                            free_bytes = 0;
+            bool                              orphan     = false;
+        };
+        template<class C>
+        struct CacheRegistry {
+            std::mutex      m;
+            std::vector<C*> all;
+        };
+        CacheRegistry<StreamCache>& stream_registry() {
+            static CacheRegistry<StreamCache>* r = new CacheRegistry<StreamCache>;// (never destroyed: a late thread may still register)
+            return *r;
+        }
+        struct StreamCacheHolder {
+            StreamCache* c;
+            StreamCacheHolder() : c(new StreamCache) {
+                auto& r = stream_registry();
+                std::lock_guard<std::mutex> g(r.m);
+                r.all.push_back(c);
+            }
+            ~StreamCacheHolder() {
+                std::lock_guard<std::mutex> g(c->m);
+                c->orphan = true;
+            }
         };
         StreamCache& stream_cache() {
-            static thread_local StreamCache* c = new StreamCache;// (kept for the life of the process, like the mailbox)
-            return *c;
+            static thread_local StreamCacheHolder h;
+            return *h.c;
         }
         constexpr size_t kStreamCacheBlocks = 24, kStreamCacheBytes = size_t(4) << 30, kStreamCacheBlockMax = size_t(1) << 30;
-        bool stream_cache_enabled() {
+        bool stream_cache_enabled() {// (process-start-only knob: INTEGRATION.md)
             static const bool on = [] {
                 const char* e = knob_env("SPLAHIP_STREAM_CACHE");
                 return !(e && e[0] == '0');
             }();
             return on;
         }
-        void stream_cache_trim() {// (run by release_idle_memory on the thread that ran out of memory, behind a device synchronisation)
-            StreamCache& c = stream_cache();
-            for (StreamBlock& b : c.free) (void) hipFree(b.p);// (hipFree, not hipFreeAsync(b.s): the stream a block was released on may be gone by now)
-            c.free.clear();
-            c.free_bytes = 0;
+        // every thread's released blocks go back to the driver (run by release_idle_memory behind a device synchronisation, and by splahip_mxm_trim); the caches
+        // of threads that have exited are deleted
+        void stream_cache_trim() {
+            auto& r = stream_registry();
+            std::lock_guard<std::mutex> rg(r.m);
+            for (size_t k = 0; k < r.all.size();) {
+                StreamCache* c    = r.all[k];
+                bool         drop = false;
+                {
+                    std::lock_guard<std::mutex> g(c->m);
+                    for (StreamBlock& b : c->free) (void) hipFree(b.p);// (hipFree, not hipFreeAsync(b.s): the stream a block was released on may be gone by now)
+                    c->free.clear();
+                    c->free_bytes = 0;
+                    drop          = c->orphan && c->live.empty();
+                }
+                if (drop) {
+                    delete c;
+                    r.all.erase(r.all.begin() + (long) k);
+                } else
+                    ++k;
+            }
         }
     }// namespace
+    void stream_caches_trim() { stream_cache_trim(); }
     hipError_t stream_block_alloc(void** p, size_t bytes, hipStream_t stream) {
         bytes = (std::max<size_t>(bytes, 4) + 255) & ~size_t(255);
         if (!stream_cache_enabled()) return device_malloc_async(p, bytes, stream);
-        StreamCache& c    = stream_cache();
-        size_t       best = c.free.size();
-        for (size_t k = 0; k < c.free.size(); ++k) {
-            const StreamBlock& b = c.free[k];
-            if (b.s == stream && b.cap >= bytes && b.cap <= 4 * bytes + (size_t(1) << 20) && (best == c.free.size() || b.cap < c.free[best].cap)) best = k;
+        StreamCache& c = stream_cache();
+        {
+            std::lock_guard<std::mutex> g(c.m);
+            size_t                      best = c.free.size();
+            for (size_t k = 0; k < c.free.size(); ++k) {
+                const StreamBlock& b = c.free[k];
+                if (b.s == stream && b.cap >= bytes && b.cap <= 4 * bytes + (size_t(1) << 20) && (best == c.free.size() || b.cap < c.free[best].cap)) best = k;
+            }
+            if (best != c.free.size()) {
+                *p = c.free[best].p;
+                c.live[*p] = c.free[best].cap;
+                c.free_bytes -= c.free[best].cap;
+                c.free.erase(c.free.begin() + (long) best);
+                return hipSuccess;
+            }
         }
-        if (best != c.free.size()) {
-            *p = c.free[best].p;
-            c.live[*p] = c.free[best].cap;
-            c.free_bytes -= c.free[best].cap;
-            c.free.erase(c.free.begin() + (long) best);
-            return hipSuccess;
+        const hipError_t e = device_malloc_async(p, bytes, stream);// (outside the cache's lock: an out-of-memory retry trims every cache, this one included)
+        if (e == hipSuccess) {
+            std::lock_guard<std::mutex> g(c.m);
+            c.live[*p] = bytes;
         }
-        const hipError_t e = device_malloc_async(p, bytes, stream);
-        if (e == hipSuccess) c.live[*p] = bytes;
         return e;
     }
     void stream_block_free(void* p, hipStream_t stream) {
@@ -250,8 +303,10 @@ namespace splahip {
             (void) hipFreeAsync(p, stream);
             return;
         }
-        StreamCache& c  = stream_cache();
-        const auto   it = c.live.find(p);
+        StreamCache& c = stream_cache();
+        register_trim(&stream_cache_trim);// (idempotent)
+        std::lock_guard<std::mutex> g(c.m);
+        const auto                  it = c.live.find(p);
         if (it == c.live.end() || it->second > kStreamCacheBlockMax) {// (not ours, or too large to keep)
             if (it != c.live.end()) c.live.erase(it);
             (void) hipFreeAsync(p, stream);
@@ -259,7 +314,6 @@ namespace splahip {
         }
         const size_t cap = it->second;
         c.live.erase(it);
-        register_trim(&stream_cache_trim);// (idempotent)
         c.free.push_back({p, cap, stream});
         c.free_bytes += cap;
         while (c.free.size() > kStreamCacheBlocks || c.free_bytes > kStreamCacheBytes) {// the oldest blocks go back to the pool (rare in steady state; hipFree waits for the
@@ -276,34 +330,74 @@ namespace splahip {
             size_t         cap;
         };
         struct Arena {
+            std::mutex              m;// the owner's takes and another thread's trim (the owner's scope bookkeeping — depth, cur, off — is its own)
             std::vector<ArenaBlock> blocks;
             size_t                  cur = 0, off = 0;// the next byte handed out: blocks[cur].p + off
             int                     depth = 0, paused = 0;
-            size_t                  held = 0, peak = 0;// bytes handed out and not yet returned; the most ever held at once
+            size_t                  held = 0, peak = 0;// bytes handed out and not yet returned; the most held at once since the last trim
+            bool                    orphan = false;
+        };
+        CacheRegistry<Arena>& arena_registry() {
+            static CacheRegistry<Arena>* r = new CacheRegistry<Arena>;
+            return *r;
+        }
+        struct ArenaHolder {
+            Arena* a;
+            ArenaHolder() : a(new Arena) {
+                auto& r = arena_registry();
+                std::lock_guard<std::mutex> g(r.m);
+                r.all.push_back(a);
+            }
+            ~ArenaHolder() {
+                std::lock_guard<std::mutex> g(a->m);
+                a->orphan = true;
+            }
         };
         Arena& scratch_arena() {
-            static thread_local Arena* a = new Arena;// (kept for the life of the process: a thread_local's destructor may run after the HIP runtime's)
-            return *a;
+            static thread_local ArenaHolder h;// (the holder's destructor makes no HIP call; the arena of a thread that has exited is freed by the next trim)
+            return *h.a;
         }
-        bool scratch_enabled() {
+        bool scratch_enabled() {// (process-start-only knob: INTEGRATION.md)
             static const bool on = [] {
                 const char* e = knob_env("SPLAHIP_SCRATCH_ARENA");
                 return !(e && e[0] == '0');
             }();
             return on;
         }
+        void arena_free_blocks(Arena& a) {// (a.m held; no scope open)
+            for (ArenaBlock& b : a.blocks)
+                if (b.p) (void) hipFree(b.p);
+            a.blocks.clear();
+            a.cur = a.off = 0;
+        }
     }// namespace
     bool scratch_active() {
         const Arena& a = scratch_arena();
         return a.depth > 0 && a.paused == 0;
     }
+    // Every thread's arena that has no scope open goes back to the driver — the caller's own, other threads' (an out-of-memory retry on one thread must be able to
+    // reclaim what idle threads hold) and those of threads that have exited (deleted).  The remembered peak is forgotten too: the call after a trim sizes its first
+    // block from what IT needs, not from the largest call the thread ever made.
     void scratch_trim() {
-        Arena& a = scratch_arena();
-        if (a.depth > 0) return;
-        for (ArenaBlock& b : a.blocks)
-            if (b.p) (void) hipFree(b.p);
-        a.blocks.clear();
-        a.cur = a.off = 0;
+        auto& r = arena_registry();
+        std::lock_guard<std::mutex> rg(r.m);
+        for (size_t k = 0; k < r.all.size();) {
+            Arena* a    = r.all[k];
+            bool   drop = false;
+            {
+                std::lock_guard<std::mutex> g(a->m);
+                if (a->depth <= 0) {
+                    arena_free_blocks(*a);
+                    a->peak = 0;
+                    drop    = a->orphan;
+                }
+            }
+            if (drop) {
+                delete a;
+                r.all.erase(r.all.begin() + (long) k);
+            } else
+                ++k;
+        }
     }
     hipError_t scratch_take(void** p, size_t bytes) {
         Arena& a = scratch_arena();
@@ -311,26 +405,35 @@ namespace splahip {
         if (a.depth <= 0) return hipErrorInvalidValue;
         bytes = (std::max<size_t>(bytes, 4) + 255) & ~size_t(255);
         for (;;) {
-            if (a.cur < a.blocks.size() && a.blocks[a.cur].cap - a.off >= bytes) {
-                *p = a.blocks[a.cur].p + a.off;
-                a.off += bytes;
-                a.held += bytes;
-                a.peak = std::max(a.peak, a.held);
-                return hipSuccess;
+            size_t cap = 0;
+            {
+                std::lock_guard<std::mutex> g(a.m);
+                if (a.cur < a.blocks.size() && a.blocks[a.cur].cap - a.off >= bytes) {
+                    *p = a.blocks[a.cur].p + a.off;
+                    a.off += bytes;
+                    a.held += bytes;
+                    a.peak = std::max(a.peak, a.held);
+                    return hipSuccess;
+                }
+                if (a.cur + 1 < a.blocks.size()) {// the next block the arena already owns
+                    ++a.cur;
+                    a.off = 0;
+                    continue;
+                }
+                // a new block: at least what the largest call since the last trim held (so a steady-state call fits one block), at least 32 MB
+                cap = std::max({bytes, a.peak + a.peak / 8, size_t(32) << 20});
             }
-            if (a.cur + 1 < a.blocks.size()) {// the next block the arena already owns
-                ++a.cur;
-                a.off = 0;
-                continue;
-            }
-            // a new block: at least what the largest call so far held (so a steady-state call fits one block), at least 32 MB
-            const size_t cap = std::max({bytes, a.peak + a.peak / 8, size_t(32) << 20});
-            void*        q   = nullptr;
+            // (allocated outside the arena's lock: an out-of-memory retry trims every idle arena.)  The generous size first, plainly; then just what is asked for,
+            // plainly; only then the release-everything retry — a failed `peak`-sized request must not cost a device synchronisation and every cache of the
+            // library when `bytes` would have fit
+            void* q = nullptr;
             register_trim(&scratch_trim);// (idempotent)
             size_t     got = cap;
-            hipError_t e   = device_malloc(&q, cap);
-            if (e != hipSuccess && cap > bytes) (void) hipGetLastError(), got = bytes, e = device_malloc(&q, bytes);
+            hipError_t e   = hipMalloc(&q, cap);
+            if (e != hipSuccess && cap > bytes) (void) hipGetLastError(), got = bytes, e = hipMalloc(&q, bytes);
+            if (e != hipSuccess) (void) hipGetLastError(), got = bytes, e = device_malloc(&q, bytes);
             if (e != hipSuccess) return e;
+            std::lock_guard<std::mutex> g(a.m);
             a.blocks.push_back({static_cast<unsigned char*>(q), got});
             a.cur = a.blocks.size() - 1;
             a.off = 0;
@@ -339,6 +442,7 @@ namespace splahip {
     ScratchScope::ScratchScope(hipStream_t stream) : s_(stream), block_(0), off_(0), held_(0), on_(scratch_enabled()) {
         if (!on_) return;
         Arena& a = scratch_arena();
+        std::lock_guard<std::mutex> g(a.m);
         block_ = a.cur, off_ = a.off, held_ = a.held;
         ++a.depth;
     }
@@ -346,10 +450,11 @@ namespace splahip {
         if (!on_) return;
         Arena& a = scratch_arena();
         (void) hipStreamSynchronize(s_);// nothing queued may still use what goes back
+        std::lock_guard<std::mutex> g(a.m);
         a.cur = block_, a.off = off_, a.held = held_;
         if (--a.depth == 0) {
             a.cur = a.off = a.held = 0;
-            if (a.blocks.size() > 1) scratch_trim();// melted into one block of `peak` bytes by the next call's first take
+            if (a.blocks.size() > 1) arena_free_blocks(a);// melted into one block of `peak` bytes by the next call's first take
         }
     }
     ScratchPause::ScratchPause() { ++scratch_arena().paused; }

@@ -637,11 +637,14 @@ def test_cfg5_full_size_mxmT_rmat20_row_sample_and_triangle_count(oracle):
     assert torch.equal(Rj[full_ent], Sj) and torch.equal(Rx[full_ent], Sx)
 
 
-def test_cfg5_full_size_mxm_rmat18_row_sample(oracle):
-    """configs[4], A x A at the bench's size (R-MAT scale 18, 3.9 M entries, 2.9 G products, 1.28 G result entries), fp32 MULT / PLUS: the product count, the row
-    pointers' total, and every 1024th row of A against the oracle (a row of the result depends on that row of A and on B only): structure identical, values within 1e-5."""
+@pytest.mark.parametrize("scale", [18, 19])
+def test_cfg5_full_size_mxm_rmat_row_sample(oracle, scale):
+    """configs[4], A x A, fp32 MULT / PLUS, at the bench's two sizes: R-MAT scale 18 (3.9 M entries, 2.9 G products, 1.28 G result entries) and scale 19 — 3.53 G result
+    entries, the LARGEST result of this family the reference's 32-bit row pointers (include/spla/config.hpp:56) can index (scale 20 of BASELINE configs[4] exceeds 2^32: the
+    call refuses it, tests/test_mxm_gpu.py).  The product count, the row pointers' total, and every 1024th row of A against the oracle (a row of the result depends on that
+    row of A and on B only): structure identical, values within 1e-5."""
     from spla_amd import kernels
-    n, Ap, Aj = _rmat(18, device="cuda")
+    n, Ap, Aj = _rmat(scale, device="cuda")
     nnz = int(Ap[-1])
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1809)
@@ -650,8 +653,9 @@ def test_cfg5_full_size_mxm_rmat18_row_sample(oracle):
     raw, products = kernels.mxm("FLOAT", n, n, A, A, "MULT", "PLUS", 0.0, adopt=False)
     deg = (Ap[1:] - Ap[:-1]).to(torch.int64)
     assert products == int(deg[Aj.to(torch.int64)].sum())
-    Rp = raw.Rp.to(torch.int64)
-    assert int(Rp[-1]) == raw.nnz and raw.nnz > 1_000_000_000
+    Rp = raw.Rp.to(torch.int64) & 0xFFFFFFFF  # (row pointers are 32-bit unsigned words: past 2^31 at scale 19)
+    assert int(Rp[-1]) == raw.nnz and raw.nnz > (1_000_000_000 if scale == 18 else 3_000_000_000)
+    assert bool(torch.all(Rp[1:] >= Rp[:-1]))
     rows_idx = torch.arange(0, n, 1024, device="cuda")
     Ap64 = Ap.to(torch.int64)
     d = deg[rows_idx]
@@ -664,10 +668,15 @@ def test_cfg5_full_size_mxm_rmat18_row_sample(oracle):
     Rj, Rx = raw.adopt("FLOAT")[1:]
     lens = (Rp[1:] - Rp[:-1])[rows_idx]
     np.testing.assert_array_equal(lens.cpu().numpy(), np.diff(wp.astype(np.int64)))
-    take = torch.repeat_interleave(torch.zeros(n, dtype=torch.bool, device="cuda").index_fill_(0, rows_idx, True), Rp[1:] - Rp[:-1])
-    np.testing.assert_array_equal(_np_u32(Rj[take]), wj)
-    np.testing.assert_allclose(Rx[take].cpu().numpy(), wx, rtol=FP32_RTOL, atol=0)
-    del Rj, Rx, take
+    # the sampled rows' entries by explicit positions (the result has more than 2^31 entries at scale 19: no boolean mask over it)
+    Op = torch.zeros(rows_idx.numel() + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(lens, 0, out=Op[1:])
+    orep = torch.repeat_interleave(torch.arange(rows_idx.numel(), device="cuda"), lens)
+    pos = Rp[rows_idx][orep] + (torch.arange(int(Op[-1]), device="cuda") - Op[:-1][orep])
+    np.testing.assert_array_equal(_np_u32(Rj[pos]), wj)
+    np.testing.assert_allclose(Rx[pos].cpu().numpy(), wx, rtol=FP32_RTOL, atol=0)
+    del Rj, Rx, pos, raw
+    torch.cuda.empty_cache()
     from spla_amd import _lib
     _lib.call("splahip_mxm_trim")
 

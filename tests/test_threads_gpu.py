@@ -55,3 +55,41 @@ def test_calls_of_four_host_threads_on_their_own_streams_match_the_single_thread
     for t in threads:
         t.join()
     assert not errors, errors[:4]
+
+
+def test_caches_of_a_thread_that_has_exited_are_given_back_by_trim():
+    """the per-thread caches (scratch arena, released stream-ordered blocks, pinned staging chunks) are listed process-wide; a host thread that did mxm /
+    mxmT / push work and then exited leaves its caches as orphans, and splahip_mxm_trim — called from ANOTHER thread — gives their device memory back to the driver
+    (hipMemGetInfo recovers), as an out-of-memory retry of any thread would.  Before: thread_locals created with `new`, trimmed only by their own thread, never freed."""
+    from spla_amd import _lib
+    _work(13, 3)  # (warm: kernels loaded, this thread's own caches in steady state)
+    _lib.call("splahip_mxm_trim")
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    held = []
+
+    def runner():
+        with torch.cuda.stream(torch.cuda.Stream()):
+            _work(14, 4)
+            _work(14, 4)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        held.append(free0 - torch.cuda.mem_get_info()[0])
+
+    t = threading.Thread(target=runner)
+    t.start()
+    t.join()
+    assert held and held[0] > (8 << 20), f"the worker thread was expected to leave cached device memory behind (held {held})"
+    _lib.call("splahip_mxm_trim")  # from the main thread: the exited thread's caches are orphans in the registry
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (4 << 20), f"device memory not recovered after the trim: {held[0] >> 20} MiB held by the exited thread, {(free0 - free1) >> 20} MiB still missing"
+    # and the library keeps working on both kinds of thread afterwards
+    a = _work(12, 2)
+    out = []
+    t2 = threading.Thread(target=lambda: out.append(_work(12, 2)))
+    t2.start()
+    t2.join()
+    assert all(np.array_equal(x, y) for x, y in zip(a, out[0]))
