@@ -70,10 +70,10 @@ namespace splahip {
 #ifndef SPLAHIP_MXM_LIGHT_DEFAULT
 #define SPLAHIP_MXM_LIGHT_DEFAULT 2048// (a light row has to fit one batch)
 #endif
-        const u64 kLight = [] {// rows with at most this many products go to the ESC form
+        u64 light_threshold() {// rows with at most this many products go to the ESC form (read per call: splahip_env_refresh() takes effect)
             const char* e = knob_env("SPLAHIP_MXM_LIGHT");
             return e && *e ? (u64) std::strtoull(e, nullptr, 10) : (u64) SPLAHIP_MXM_LIGHT_DEFAULT;
-        }();
+        }
 
         struct SpaArgs {
             const uint32_t *Ap, *Aj, *Ax, *Bp, *Bj, *Bx;
@@ -596,6 +596,8 @@ namespace splahip {
 #define SPLAHIP_MXM_BATCH_TPB 512
 #endif
         constexpr uint32_t kBatchCap = SPLAHIP_MXM_BATCH_CAP, kBatchRows = 512, kBatchTpb = SPLAHIP_MXM_BATCH_TPB;
+        // the batch's sort key gives the product number 12 bits and the batch row 9 bits (below): a build with a larger batch would corrupt the column field silently
+        static_assert(kBatchCap <= 4096 && kBatchRows <= 512 && kBatchCap % 2 == 0, "light_batch_kernel: the key layout holds 12 bits of product number and 9 bits of batch row");
         template<typename T, class Mult, class Add>
         __global__ __launch_bounds__(kBatchTpb) void light_batch_kernel(const uint32_t* __restrict__ batch_first, const uint32_t* __restrict__ light_rows, const uint32_t* __restrict__ light_eoff,
                                                                   const u64* __restrict__ batch_poff,
@@ -964,8 +966,7 @@ namespace splahip {
         }
         // SPLAHIP_MXM_HOSTTRACE=1: HOST time between the marks of a call, no synchronisation (what the host does while the GPU waits; diagnostic)
         void host_mark(const char* what) {
-            static const bool on = knob_env("SPLAHIP_MXM_HOSTTRACE") != nullptr;
-            if (!on) return;
+            if (knob_env("SPLAHIP_MXM_HOSTTRACE") == nullptr) return;// (read per call: a cached hash lookup)
             static thread_local auto t0 = std::chrono::steady_clock::now();
             const auto               t1 = std::chrono::steady_clock::now();
             std::fprintf(stderr, "[mxm-host] %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
@@ -998,6 +999,7 @@ namespace splahip {
                     uint32_t init_bits, uint32_t b_rows_hint, const uint32_t* d_hint, uint32_t b_nnz_hint, hipStream_t s) {
             using word      = typename CobSlice<T, ACC>::word;
             constexpr int t = TypeId<T>::value;
+            const u64     kLight = light_threshold();
             Scratch       tmp(s);
             hipError_t    e = hipSuccess;
             spa_trace("start", s);
@@ -1515,8 +1517,9 @@ namespace splahip {
         SPLAHIP_TRY(d2h(&hAp, Ap, (size_t) a_rows + 1, s));
         SPLAHIP_TRY(d2h(&h_maxp, d_max, 2, s));
         SPLAHIP_TRY(hipStreamSynchronize(s));
-        u64  total = 0;
-        bool heavy = false;
+        u64       total  = 0;
+        bool      heavy  = false;
+        const u64 kLight = light_threshold();
         for (uint32_t i = 0; i < a_rows; ++i) total += hP[i], heavy = heavy || hP[i] > kLight;
         if (!heavy) return -1;
         if (h_products) *h_products = total;

@@ -773,10 +773,8 @@ namespace splahip {
             uint* part  = chunk + n_chunks + 2;
             SPLAHIP_TRY(hipMemsetAsync(acc, 0, sizeof(u64) * (size_t) n_cols, s));
             SPLAHIP_TRY(hipMemsetAsync(chunk + n_chunks + 1, 0, sizeof(uint), s));
-            static const bool blocked = [] {// SPLAHIP_PUSH_BLOCKED=0: every thread searches `offs` in global memory (the form of rounds 2 - 4)
-                const char* e = knob_env("SPLAHIP_PUSH_BLOCKED");
-                return !(e && e[0] == '0');
-            }();
+            const char* pb_env  = knob_env("SPLAHIP_PUSH_BLOCKED");// =0: every thread searches `offs` in global memory (the form of rounds 2 - 4); read per call
+            const bool  blocked = !(pb_env && pb_env[0] == '0');
             if (blocked) {
                 hipLaunchKernelGGL(push_part_kernel, dim3((n_blocks + 1 + 255) / 256), dim3(256), 0, s, n_blocks, nvals, offs, part);
                 hipLaunchKernelGGL((push_atomic_blocked_kernel<T, DynBin, DynBin>), dim3(n_blocks), dim3(256), 0, s, n_products, nvals, offs, part, vi,
