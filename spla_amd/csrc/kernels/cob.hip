@@ -446,7 +446,7 @@ namespace {
                 __hip_atomic_store(reinterpret_cast<unsigned long long*>(probe), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&probe[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(reinterpret_cast<unsigned long long*>(probe + 4), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (rows_ctl != nullptr) rows_ctl[0] = 0u, rows_ctl[1] = 0u;// the row kernels' list lengths (mxv_rows.hpp) start every call at zero: no memset to enqueue
+                if (rows_ctl != nullptr) rows_ctl[0] = 0u, rows_ctl[1] = 0u, rows_ctl[3] = 0u;// the row kernels' list lengths (mxv_rows.hpp) start every call at zero: no memset to enqueue
             }
         }
     }
@@ -759,10 +759,11 @@ namespace splahip {
         const int      rows     = g->h_probe[3] != 0u && g->h_probe[2] != 0u ? 1 : 0;
         hipStream_t    st       = as_stream(stream);
         const uint32_t stride   = std::max(1u, std::min(64u, g->n_rows >> 16));// a 1-in-64 sample once there are millions of rows; every row of a small matrix
-        // a selected entry costs the row kernels ~9 x what an entry costs the blocks (19 ns against 2.2 at R-MAT 23: a selected short row is ~16 line requests of its
-        // own, and that kernel runs at the chip's request ceiling); a selection that reaches into the heaviest rows is dearer still (their segments go through the
-        // wave-tile kernel and its combine pass: random 10 % of all rows measured 361 us on the row kernels against 300 on the blocks) — weighted so that it stays there
-        const uint32_t rows_x10 = env_u32("SPLAHIP_MASK_ROWS_X10", 90), long_x10 = env_u32("SPLAHIP_MASK_LONG_X10", 300);
+        // a selected entry costs the row kernels ~4.2 x what an entry costs the blocks, whatever its row's length (round 6, R-MAT 23: 9.5 us per million selected
+        // entries — the chip's ceiling of ~110 G four-byte gathers a second — on top of ~70 us of passes over mask / Ap / r, against 2.25 ns per stored entry on the
+        // blocks: the row kernels win below ~18 % of the entries.  Until round 6 a medium row was one lane's and the heaviest rows went through the wave-tile kernel:
+        // 9 x and 30 x, and a random 10 % of all rows stayed on the blocks at 1.09 x the all-rows call; now 0.69 x)
+        const uint32_t rows_x10 = env_u32("SPLAHIP_MASK_ROWS_X10", 45), long_x10 = env_u32("SPLAHIP_MASK_LONG_X10", 45);
         const uint32_t groups   = (g->n_rows + stride * 2048u - 1) / (stride * 2048u);
         g->probe_seq            = g->probe_seq + 1 ? g->probe_seq + 1 : 1;
 #define SPLAHIP_PROBE(T)                                                                                                                                          \

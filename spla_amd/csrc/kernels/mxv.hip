@@ -209,24 +209,31 @@ namespace {
         return SPLAHIP_OK;
     }
 
-    // workspaces of the selected-rows path, allocated on a plan's first masked call that may take it
-    int rows_prepare(splahip_plan plan, hipStream_t st) {
-        (void) st;
+    // workspaces of the selected-rows path, allocated on a plan's first masked call that may take it; the plan's long rows are listed here, once
+    int rows_prepare(splahip_plan plan, const uint32_t* Ap, hipStream_t st) {
         if (plan->rows_ready) return SPLAHIP_OK;
         // (nothing half-built stays with the plan when a step fails: the next call starts over)
-        uint32_t *list = nullptr, *ctl = nullptr, *items = nullptr;
-        hipError_t e = device_malloc(reinterpret_cast<void**>(&list), sizeof(uint32_t) * (size_t) plan->n_rows);
-        if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(&ctl), sizeof(uint32_t) * 8);// [0] short rows listed, [1] segment items listed, [4..7] the row kernels' gate: open
+        uint32_t *list = nullptr, *ctl = nullptr, *items = nullptr, *lrow = nullptr, *lfirst = nullptr;
+        // the call's selected short rows from the front, its selected medium rows from the end
+        hipError_t e = device_malloc(reinterpret_cast<void**>(&list), sizeof(uint32_t) * ((size_t) plan->n_rows + 1));
+        if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(&ctl), sizeof(uint32_t) * 8);// [0] short rows, [1] segment items, [3] medium rows listed by the running call (zeroed by its mask probe), [2] long rows of the plan, [4..7] the row kernels' gate: open
         const uint32_t open_gate[4] = {0, 0, 0, 1};
         if (e == hipSuccess) e = hipMemcpy(ctl + 4, open_gate, sizeof(open_gate), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemset(ctl, 0, 4 * sizeof(uint32_t));
         if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(&items), sizeof(uint32_t) * ((size_t) plan->n_items + 1));
+        if (e == hipSuccess && plan->n_long) e = device_malloc(reinterpret_cast<void**>(&lrow), sizeof(uint32_t) * (size_t) plan->n_long);
+        if (e == hipSuccess && plan->n_long) e = device_malloc(reinterpret_cast<void**>(&lfirst), sizeof(uint32_t) * (size_t) plan->n_long);
+        if (e == hipSuccess && plan->n_long && plan->n_items) {
+            hipLaunchKernelGGL(rows_long_list_kernel, dim3((plan->n_items + 255) / 256), dim3(256), 0, st, plan->d_item_row, plan->d_item_k0, plan->n_items, Ap, Cfg::kSegFlag, ctl + 2,
+                               lrow, lfirst);
+            e = hipGetLastError();
+        }
         if (e != hipSuccess) {
-            for (void* p : {(void*) list, (void*) ctl, (void*) items})
+            for (void* p : {(void*) list, (void*) ctl, (void*) items, (void*) lrow, (void*) lfirst})
                 if (p) (void) hipFree(p);
             return fail(SPLAHIP_ERROR, "selected-rows workspace: %s", hipGetErrorString(e));
         }
-        plan->d_rows_list = list, plan->d_rows_ctl = ctl, plan->d_long_items = items;
+        plan->d_rows_list = list, plan->d_rows_ctl = ctl, plan->d_long_items = items, plan->d_long_rows = lrow, plan->d_long_first = lfirst;
         plan->rows_ready = true;
         return SPLAHIP_OK;
     }
@@ -237,26 +244,26 @@ namespace {
                     int op_select, uint32_t init_bits, const uint32_t* gate, hipStream_t st) {
         const T        init = from_bits<T>(init_bits);
         const uint32_t n    = plan->n_rows;
-        // (d_rows_ctl[0] short rows listed, [1] segment items listed: returned to zero by the call's mask probe, enqueued just before — a probe whose launch
-        // failed makes cob_mask_probe answer "the blocks", so this path never runs behind a probe that did not)
+        // (d_rows_ctl[0] short rows, [1] segment items, [3] medium rows listed: returned to zero by the call's mask probe, enqueued just before — a probe whose
+        // launch failed makes cob_mask_probe answer "the blocks", so this path never runs behind a probe that did not)
         // (workgroups: every flush of a workgroup's list is a same-address atomic — 256 / 512 / 1024 / 2048 / 4096 workgroups at R-MAT 23, 10 % of the light rows: 103 / 87 /
         // 86 / 99 / 113 us per call)
-        hipLaunchKernelGGL((rows_compact_kernel<T>), dim3(knob_u32("SPLAHIP_ROWS_COMPACT_BLOCKS", 1024)), dim3(256), 0, st, n, Ap, static_cast<const T*>(mask), op_select, init, static_cast<T*>(r), plan->d_rows_list,
-                           plan->d_rows_ctl, plan->d_item_row, plan->n_items, Cfg::kSegFlag, Cfg::kSeg, plan->d_long_items, gate);
-        hipLaunchKernelGGL((rows_short_kernel<T, Mult, Add>), dim3(knob_u32("SPLAHIP_ROWS_SHORT_BLOCKS", 4096)), dim3(256), 0, st, plan->d_rows_list, plan->d_rows_ctl, Ap, Aj, static_cast<const uint32_t*>(Ax),
-                           static_cast<const T*>(v), static_cast<T*>(r), Mult(op_mult), Add(op_add), init, plan->nnz, gate);
+        hipLaunchKernelGGL((rows_compact_kernel<T>), dim3(knob_u32("SPLAHIP_ROWS_COMPACT_BLOCKS", 1024)), dim3(256), 0, st, n, Ap, static_cast<const T*>(mask), op_select, init,
+                           static_cast<T*>(r), plan->d_rows_list, plan->d_rows_ctl, gate);
+        if (plan->n_items && plan->n_long > 0)// the selected long rows' segment items (a plan without long rows lists none)
+            hipLaunchKernelGGL((rows_long_select_kernel<T>), dim3((plan->n_long + 255) / 256), dim3(256), 0, st, plan->n_long, plan->d_long_rows, plan->d_long_first, Ap,
+                               static_cast<const T*>(mask), op_select, Cfg::kSeg, plan->d_long_items, plan->d_rows_ctl + 1, gate);
+        hipLaunchKernelGGL((rows_short_kernel<T, Mult, Add>), dim3(knob_u32("SPLAHIP_ROWS_SHORT_BLOCKS", 4096)), dim3(256), 0, st, plan->d_rows_list, plan->d_rows_ctl, Ap, Aj,
+                           static_cast<const uint32_t*>(Ax), static_cast<const T*>(v), static_cast<T*>(r), Mult(op_mult), Add(op_add), init, plan->nnz, gate);
+        hipLaunchKernelGGL((rows_task_kernel<T, Mult, Add>), dim3(knob_u32("SPLAHIP_ROWS_LONG_BLOCKS", 4096)), dim3(256), 0, st, plan->d_long_items, plan->d_rows_ctl,
+                           plan->d_rows_list, n, plan->d_item_row, plan->d_item_k0, Ap, Aj, static_cast<const uint32_t*>(Ax), static_cast<const T*>(v), static_cast<T*>(r),
+                           reinterpret_cast<T*>(plan->d_partial), Mult(op_mult), Add(op_add), init, Cfg::kSegFlag, Cfg::kSeg, plan->nnz, gate);
         SPLAHIP_TRY(hipGetLastError());
-        if (plan->n_items && plan->n_long > 0) {// the selected long rows' segment items (mxv_rows.hpp: rows_long_kernel; a plan without long rows lists none)
-            hipLaunchKernelGGL((rows_long_kernel<T, Mult, Add>), dim3(512), dim3(256), 0, st, plan->d_long_items, plan->d_rows_ctl + 1, plan->d_item_row, plan->d_item_k0, Ap, Aj,
-                               static_cast<const uint32_t*>(Ax), static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(plan->d_partial), Mult(op_mult), Add(op_add), init,
-                               Cfg::kSegFlag, Cfg::kSeg, gate);
+        if (plan->n_items && plan->n_long > 0) {
+            hipLaunchKernelGGL((spmv_combine_kernel<Cfg, T, Add, false>), dim3((plan->n_items + 255) / 256), dim3(256), 0, st, plan->d_item_row, plan->d_item_k0, plan->n_items, Ap,
+                               static_cast<const T*>(mask), static_cast<T*>(r), static_cast<uint32_t*>(nullptr), reinterpret_cast<const T*>(plan->d_partial),
+                               static_cast<const uint32_t*>(nullptr), Add(op_add), op_select, init, gate);
             SPLAHIP_TRY(hipGetLastError());
-            if (plan->n_long > 0) {
-                hipLaunchKernelGGL((spmv_combine_kernel<Cfg, T, Add, false>), dim3((plan->n_items + 255) / 256), dim3(256), 0, st, plan->d_item_row, plan->d_item_k0, plan->n_items,
-                                   Ap, static_cast<const T*>(mask), static_cast<T*>(r), static_cast<uint32_t*>(nullptr), reinterpret_cast<const T*>(plan->d_partial),
-                                   static_cast<const uint32_t*>(nullptr), Add(op_add), op_select, init, gate);
-                SPLAHIP_TRY(hipGetLastError());
-            }
         }
         return SPLAHIP_OK;
     }
@@ -316,6 +323,8 @@ namespace {
         if (plan->d_rows_list) (void) hipFree(plan->d_rows_list);
         if (plan->d_rows_ctl) (void) hipFree(plan->d_rows_ctl);
         if (plan->d_long_items) (void) hipFree(plan->d_long_items);
+        if (plan->d_long_rows) (void) hipFree(plan->d_long_rows);
+        if (plan->d_long_first) (void) hipFree(plan->d_long_first);
         if (plan->d_item_row) (void) hipFree(plan->d_item_row);
         if (plan->d_item_k0) (void) hipFree(plan->d_item_k0);
         if (plan->d_partial) (void) hipFree(plan->d_partial);
@@ -539,7 +548,7 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
             const Variant wv = pick_variant(type, op_mult, op_add, 0);
             const bool    wt = (wv == Variant::WaveTileStatic || wv == Variant::WaveTileDynamic) && plan->n_items != 0 &&
                             ((reinterpret_cast<uintptr_t>(d_Aj) | reinterpret_cast<uintptr_t>(d_Ax) | reinterpret_cast<uintptr_t>(d_Ap)) & 15u) == 0;
-            if (wt && op_select != SPLAHIP_ALWAYS && rows_prepare(plan, s) != SPLAHIP_OK) return SPLAHIP_ERROR;// (the probe zeroes the row kernels' list lengths)
+            if (wt && op_select != SPLAHIP_ALWAYS && rows_prepare(plan, d_Ap, s) != SPLAHIP_OK) return SPLAHIP_ERROR;// (the probe zeroes the row kernels' list lengths)
             if (wt && cob_mask_probe(plan, type, d_Ap, d_mask, op_select, stream) != 0) {
                 switch (type) {
                     case SPLAHIP_INT: return rows_typed<int32_t>(plan, d_Ap, d_Aj, d_Ax, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, plan->d_rows_ctl + 4, s);

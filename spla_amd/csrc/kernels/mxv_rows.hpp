@@ -1,14 +1,21 @@
-// mxv_rows.hpp — masked SpMV over the SELECTED rows only (round 4): what a mask that selects few entries runs instead of streaming the whole matrix.
+// mxv_rows.hpp — masked SpMV over the SELECTED rows only (round 4; reworked in round 6): what a mask that selects few entries runs instead of streaming the whole matrix.
 //
 // Semantics: reference Algo_mxv_masked_cpu<T>::execute, src/cpu/cpu_mxv.hpp:88-103 — an unselected row costs the reference nothing (:89-92) and its own perf
 // test selects every 10th row (tests/test_mxv.cpp:91-130).  The column-ordered blocks (mxv_cob.hpp) stream every entry of a range whatever the mask, and the
-// wave-tile CSR kernel still visits every work item (~170 us at R-MAT 23 before the first selected entry).  Here:
-//   rows_compact_kernel  one streaming pass over mask and Ap: r = init everywhere, and the selected rows of 1 .. kRowsShortMax entries are appended to a list, a
-//                        few thousand at a time (an LDS buffer per workgroup, one global atomic per flush)
-//   rows_short_kernel    8 lanes per listed row: coalesced Aj / Ax, gathers of v, lane partials joined in lane order, r[row] = add(init, fold)
-//   longer rows          the segment items (rows > 508 entries) of the SELECTED long rows, listed by rows_compact_kernel, through the wave-tile kernel (mxv_kernels.hpp);
-//                        rows made of several segments are finished by its combine kernel
-// op_add must be associative and commutative (the lanes of a row take its entries strided) — the same calls the wave-tile kernel serves.  Every kernel takes the
+// wave-tile CSR kernel still visits every work item.  Here, by row length:
+//   rows_compact_kernel  one streaming pass over mask and Ap: r = init everywhere; the selected rows of 1 .. 32 entries are appended to a list (an LDS buffer per
+//                        workgroup, one global atomic per flush), the selected MEDIUM rows (33 .. 508 entries) to a second list (from the end of the same array)
+//   rows_short_kernel    the listed short rows, 64 per wave: coalesced Aj / Ax quads, gathers of v, products staged in LDS, a lane folds its row strictly left to
+//                        right from init (the reference's order: bit-exact, fp32 sums included)
+//   rows_task_kernel     a wave per task: a selected medium row, or a segment item (<= 1020 entries) of a selected long row — the whole task requested at once
+//   long rows            the plan's rows of more than 508 entries are listed once per plan (rows_long_list_kernel); per call rows_long_select_kernel appends the
+//                        segment items of the SELECTED ones; rows of several segments are finished by the wave-tile plan's combine kernel
+// Round 6 (profiles/r06_notes.md): until then a medium row was folded by ONE lane of a 64-row batch — a batch of 64 neighbouring medium rows was a pole of ~300 us —
+// and the list pass searched the plan (17 dependent loads) once per selected long row: a random 10 % of R-MAT 23's rows took 416 us against 300 on the blocks.
+// A version that cut the work by selected ENTRIES (tiles of a virtual stream of selected 16-byte quads, rows re-derived from mask / Ap per tile) was built, is
+// correct and was slower on every mask (177 us for the tiles of that call, 134 against 86 us on light rows): a 256-thread tile is a chain of barriers, the waves of
+// this form overlap their phases freely.
+// op_add must be associative and commutative (a task's lanes take its entries strided) — the same calls the wave-tile kernel serves.  Every kernel takes the
 // mask probe's words as its gate and returns at once unless word 3 says the row kernels serve the call (cob.hip: cob_mask_probe_kernel).
 #pragma once
 
@@ -16,26 +23,28 @@
 #include <stdint.h>
 
 #include "block_utils.hpp"
+#include "mxv_kernels.hpp"
 #include "ops.hpp"
 
 namespace splahip {
 
     constexpr uint32_t kRowsShortMax = 508;// = MxvCfg's longest row of a run item: longer rows are segment items of the wave-tile plan
-    constexpr uint32_t kRowsGroup    = 8;  // lanes per row (an R-MAT's selected short rows hold ~15 entries: two steps)
+    constexpr uint32_t kRowsLaneMax  = 32; // rows up to this length are folded by one lane of a 64-row batch (rows_short_kernel); up to kRowsShortMax: a wave each
 
     // One streaming pass over mask and Ap, 8 rows per thread and step (16-byte loads): r = init for every row (the row kernels overwrite the selected ones
-    // behind this launch), and list[0 .. *count) = the selected rows with 1 .. kRowsShortMax entries, in no particular order (clusters of neighbouring rows:
-    // an LDS buffer per workgroup, one global atomic per flush).
+    // behind this launch); list[0 .. count[0]) = the selected rows with 1 .. kRowsLaneMax entries, in no particular order (clusters of neighbouring rows: an LDS
+    // buffer per workgroup, one global atomic per flush); list[n_rows - 1 - i], i < count[3] = the selected MEDIUM rows (kRowsLaneMax + 1 .. kRowsShortMax entries:
+    // a wavefront each, rows_task_kernel), one atomic per wave.  Longer rows are the plan's business (rows_long_select_kernel).
     template<typename T>
     __global__ __launch_bounds__(256) void rows_compact_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, T init,
-                                                               T* __restrict__ r, uint32_t* __restrict__ list, uint32_t* __restrict__ count, const uint32_t* __restrict__ item_row,
-                                                               uint32_t n_items, uint32_t seg_flag, uint32_t seg_len, uint32_t* __restrict__ long_items,
-                                                               const uint32_t* __restrict__ gate) {
+                                                               T* __restrict__ r, uint32_t* __restrict__ list, uint32_t* __restrict__ count, const uint32_t* __restrict__ gate) {
         if (gate[3] == 0u) return;
         constexpr uint32_t kBuf = 4096;
         __shared__ uint32_t s_buf[kBuf + 2048];
-        __shared__ uint32_t s_n, s_base;
-        if (threadIdx.x == 0) s_n = 0;
+        constexpr uint32_t  kBufM = 1024;
+        __shared__ uint32_t s_med[kBufM + 2048];// the medium rows, buffered the same way (a global atomic per wave and step was ~5 K same-address atomics of ~15 ns each)
+        __shared__ uint32_t s_n, s_base, s_nm, s_basem;
+        if (threadIdx.x == 0) s_n = 0, s_nm = 0;
         __syncthreads();
         const uint32_t per = ((n_rows + gridDim.x - 1) / gridDim.x + 2047u) & ~2047u;// a contiguous share of the rows per workgroup, whole steps of 2048 rows
         const uint32_t b0 = blockIdx.x * per, b1 = min(n_rows, b0 + per);
@@ -63,26 +72,27 @@ namespace splahip {
                 for (uint32_t j = 0; j < 8; ++j)
                     if (row0 + j >= b1) ap[j] = ap[8];// (rows behind the share: length 0)
             }
-            uint32_t take = 0, cnt = 0;
+            uint32_t take = 0, cnt = 0, med = 0, n_med = 0;
 #pragma unroll
             for (uint32_t j = 0; j < 8; ++j) {
                 const uint32_t d = ap[j + 1] - ap[j];
-                if (row0 + j < b1 && d != 0 && eval_sel<T>(op_select, from_bits<T>(mk[j]))) {
-                    if (d <= kRowsShortMax) take |= 1u << j, ++cnt;
-                    else {
-                        // a selected LONG row (rare: the plan cuts it into segment items of seg_len entries): its items go to the wave-tile kernel's list.  The row's first
-                        // item is the first one whose item_row is (row | seg_flag): item_row ascends in the row bits
-                        const uint32_t row = row0 + j, nseg = (d + seg_len - 1) / seg_len;
-                        uint32_t       lo = 0, hi = n_items;
-                        while (lo < hi) {
-                            const uint32_t mid = (lo + hi) >> 1;
-                            if ((item_row[mid] & ~seg_flag) < row) lo = mid + 1;
-                            else
-                                hi = mid;
-                        }
-                        const uint32_t at = atomicAdd(count + 1, nseg);
-                        for (uint32_t g = 0; g < nseg; ++g) long_items[at + g] = lo + g;
-                    }
+                if (row0 + j < b1 && d != 0 && d <= kRowsShortMax && eval_sel<T>(op_select, from_bits<T>(mk[j]))) {
+                    if (d <= kRowsLaneMax) take |= 1u << j, ++cnt;
+                    else
+                        med |= 1u << j, ++n_med;
+                }
+            }
+            {// the medium rows: positions in the workgroup's second buffer (one LDS atomic per wave)
+                const uint32_t inc_m = wave_inclusive_sum(n_med);
+                const uint32_t tot_m = (uint32_t) __builtin_amdgcn_readlane((int) inc_m, (int) kWave - 1);
+                if (tot_m) {
+                    uint32_t base_m = 0;
+                    if (lane_id() == 0) base_m = atomicAdd(&s_nm, tot_m);
+                    base_m      = (uint32_t) __builtin_amdgcn_readfirstlane((int) base_m);
+                    uint32_t at = base_m + inc_m - n_med;
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j)
+                        if (med & (1u << j)) s_med[at++] = row0 + j;
                 }
             }
             // positions: the wave's counts scanned, one LDS atomic per wave
@@ -100,6 +110,15 @@ namespace splahip {
             for (uint32_t j = 0; j < 8; ++j)
                 if (take & (1u << j)) s_buf[pos++] = row0 + j;
             __syncthreads();
+            if (s_nm >= kBufM || base + 2048 >= b1) {// flush the medium rows: stored from the END of the list downwards (uniform: s_nm is read behind the barrier)
+                const uint32_t n = s_nm;
+                if (threadIdx.x == 0 && n) s_basem = atomicAdd(count + 3, n);
+                __syncthreads();
+                for (uint32_t i = threadIdx.x; i < n; i += 256) list[n_rows - 1u - (s_basem + i)] = s_med[i];
+                __syncthreads();
+                if (threadIdx.x == 0) s_nm = 0;
+                __syncthreads();
+            }
             if (s_n >= kBuf || base + 2048 >= b1) {// flush (uniform: s_n is read behind the barrier)
                 const uint32_t n = s_n;
                 if (threadIdx.x == 0 && n) s_base = atomicAdd(count, n);
@@ -113,7 +132,7 @@ namespace splahip {
     }
 
     // The listed rows, a wave at a time: 64 listed rows' bounds arrive in one round trip (lane l = row l); the wave then takes as many of them as fit its LDS stage
-    // (kRowsStage entries, rows padded to 16-byte quads), requests ALL their Aj / Ax quads at once (a lane's quads belong to whichever rows the scan of the quad
+    // (kRowsStage entries, rows padded to 16-byte quads; a listed row holds at most kRowsLaneMax entries: two rounds at most), requests ALL their Aj / Ax quads at once (a lane's quads belong to whichever rows the scan of the quad
     // counts says), gathers v for all of them, stages the products, and lane l folds row l's products out of LDS — strictly left to right from init, the
     // reference's own order (cpu_mxv.hpp:94-99): bit-exact for every op_add, fp32 sums included.  Three round trips per ~1000 entries instead of two per row.
     constexpr uint32_t kRowsStage = 1024;// entries of a wave's product stage (256 quads: 4 per lane)
@@ -139,7 +158,7 @@ namespace splahip {
                 k1     = Ap[my_row + 1];
             }
             const uint32_t a0 = k0 & ~3u;                            // 16-byte aligned origin of the row's quads
-            const uint32_t nq = k1 > k0 ? (k1 - a0 + 3) >> 2 : 0;   // quads of the row (<= 128)
+            const uint32_t nq = k1 > k0 ? (k1 - a0 + 3) >> 2 : 0;   // quads of the row (<= 9)
             uint32_t       done = 0;                                 // rows of this batch already folded
             const uint32_t here = min(kWave, n - i0);
             while (done < here) {
@@ -217,34 +236,90 @@ namespace splahip {
         }
     }
 
-    // The selected LONG rows (more than kRowsShortMax entries: the plan cuts them into segment items of seg_len entries; rows_compact_kernel listed the items of the
-    // selected ones): a fixed grid whose waves take listed items in turn — the list's length is only known on the device, and launching a wave per item of the PLAN
-    // (128 K at R-MAT 23, nearly all of which return at once) cost 17 us per call.  A wave folds its segment lane-strided (op_add is associative and commutative on
-    // this path), joins the lanes in order and leaves the partial for the combine kernel; a row of one segment is finished here (r = add(init, fold)).
+    // The plan's long rows, listed once per plan: long_row[i] = a row of more than kRowsShortMax entries, long_first[i] = its first segment item (in no particular order).
+    __global__ __launch_bounds__(256) void rows_long_list_kernel(const uint32_t* __restrict__ item_row, const uint32_t* __restrict__ item_k0, uint32_t n_items,
+                                                                 const uint32_t* __restrict__ Ap, uint32_t seg_flag, uint32_t* __restrict__ count, uint32_t* __restrict__ long_row,
+                                                                 uint32_t* __restrict__ long_first) {
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= n_items) return;
+        const uint32_t e0 = item_row[i];
+        if (!(e0 & seg_flag)) return;
+        const uint32_t row = e0 & ~seg_flag;
+        if (item_k0[i] != Ap[row]) return;// not the first segment of its row
+        const uint32_t at = atomicAdd(count, 1u);
+        long_row[at] = row, long_first[at] = i;
+    }
+
+    // per call: the segment items of the SELECTED long rows -> long_items[0 .. *n_listed)
+    template<typename T>
+    __global__ __launch_bounds__(256) void rows_long_select_kernel(uint32_t n_long, const uint32_t* __restrict__ long_row, const uint32_t* __restrict__ long_first,
+                                                                   const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, uint32_t seg_len,
+                                                                   uint32_t* __restrict__ long_items, uint32_t* __restrict__ n_listed, const uint32_t* __restrict__ gate) {
+        if (gate[3] == 0u) return;
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= n_long) return;
+        const uint32_t row = long_row[i];
+        if (!eval_sel<T>(op_select, mask[row])) return;
+        const uint32_t nseg = (Ap[row + 1] - Ap[row] + seg_len - 1) / seg_len, first = long_first[i];
+        const uint32_t at   = atomicAdd(n_listed, nseg);
+        for (uint32_t g = 0; g < nseg; ++g) long_items[at + g] = first + g;
+    }
+
+    // The wave tasks of a call, a wave per task in turn (a fixed grid: the lists' lengths are only known on the device): first the listed segment items of the
+    // selected long rows, then the selected medium rows (from the end of `list` downwards).  The whole task — at most 1020 entries, 256 aligned quads — is requested
+    // at once (4 quads per lane, then their 16 gathers); a lane folds its quads in entry order, the lanes are joined in order (op_add is associative and commutative
+    // on this path); a segment's partial goes to the combine kernel, a medium row or a row of one segment is finished here (r = add(init, fold)).
     template<typename T, class Mult, class Add>
-    __global__ __launch_bounds__(256) void rows_long_kernel(const uint32_t* __restrict__ long_items, const uint32_t* __restrict__ n_listed, const uint32_t* __restrict__ item_row,
+    __global__ __launch_bounds__(256) void rows_task_kernel(const uint32_t* __restrict__ long_items, const uint32_t* __restrict__ ctl, const uint32_t* __restrict__ list, uint32_t n_rows,
+                                                            const uint32_t* __restrict__ item_row,
                                                             const uint32_t* __restrict__ item_k0, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ Aj,
                                                             const uint32_t* __restrict__ Ax, const T* __restrict__ v, T* __restrict__ r, T* __restrict__ partial, Mult mult,
-                                                            Add add_raw, T init, uint32_t seg_flag, uint32_t seg_len, const uint32_t* __restrict__ gate) {
+                                                            Add add_raw, T init, uint32_t seg_flag, uint32_t seg_len, uint32_t nnz, const uint32_t* __restrict__ gate) {
         if (gate[3] == 0u) return;
         const Reassoc<Add> add(add_raw);
-        const uint32_t     n    = *n_listed;
+        const uint32_t     n_items = ctl[1], n = n_items + ctl[3];
         const uint32_t     lane = lane_id();
         for (uint32_t w = blockIdx.x * (256 / kWave) + threadIdx.x / kWave; w < n; w += gridDim.x * (256 / kWave)) {
-            const uint32_t item = long_items[w];
-            const uint32_t row  = item_row[item] & ~seg_flag;
-            const uint32_t k0 = item_k0[item], k1 = item_k0[item + 1];
+            const bool medium = w >= n_items;
+            uint32_t   item = 0, row, k0, k1;
+            if (medium) {
+                row = list[n_rows - 1u - (w - n_items)];
+                k0 = Ap[row], k1 = Ap[row + 1];
+            } else {
+                item = long_items[w];
+                row  = item_row[item] & ~seg_flag;
+                k0 = item_k0[item], k1 = item_k0[item + 1];
+            }
+            const uint32_t a0 = k0 & ~3u, nq = k1 > a0 ? (k1 - a0 + 3) >> 2 : 0;// <= 256
+            uint4          jq[4], xq[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u)
+                if (lane + u * kWave < nq) load_quad(Aj, Ax, a0 + 4 * (lane + u * kWave), nnz, jq[u], xq[u]);
             T    part  = init;
             bool valid = false;
-            for (uint32_t k = k0 + lane; k < k1; k += kWave) {
-                const T p = mult(from_bits<T>(Ax[k]), v[Aj[k]]);
-                part      = valid ? add(part, p) : p;
-                valid     = true;
-            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u)
+                if (lane + u * kWave < nq) {
+                    const uint32_t kq    = a0 + 4 * (lane + u * kWave);
+                    const uint32_t jj[4] = {jq[u].x, jq[u].y, jq[u].z, jq[u].w};
+                    const uint32_t xx[4] = {xq[u].x, xq[u].y, xq[u].z, xq[u].w};
+                    T              vv[4];
+#pragma unroll
+                    for (uint32_t e = 0; e < 4; ++e) vv[e] = v[jj[e]];
+#pragma unroll
+                    for (uint32_t e = 0; e < 4; ++e) {
+                        const bool take = kq + e >= k0 && kq + e < k1;// only the first / last quad of a segment are partial
+                        const T    p    = mult(from_bits<T>(xx[e]), vv[e]);
+                        const T    both = add(part, p);
+                        part            = take ? (valid ? both : p) : part;
+                        valid           = valid || take;
+                    }
+                }
+            // (a lane holds the quads lane, lane + 64, ...: joined in lane order the fold is a re-association, as everywhere on this path)
             wave_reduce_ordered(part, valid, add);
             if (lane == 0) {
-                const uint32_t len = Ap[row + 1] - Ap[row];
-                if (len <= seg_len) r[row] = valid ? add(init, part) : init;// a row of one segment: finished here (the combine kernel skips it)
+                const uint32_t len = medium ? 0u : Ap[row + 1] - Ap[row];
+                if (len <= seg_len) r[row] = valid ? add(init, part) : init;// a medium row, or a row of one segment: finished here (the combine kernel skips it)
                 else
                     partial[item] = part;
             }

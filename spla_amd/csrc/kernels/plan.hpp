@@ -139,9 +139,11 @@ struct splahip_plan_s {
     void*     d_ws         = nullptr;
     size_t    ws_bytes     = 0;
     // masked calls that select few entries (mxv_rows.hpp): the list of selected short rows of the running call, and the plan's segment items
-    uint32_t* d_rows_list  = nullptr;// n_rows words, built on the first such call
-    uint32_t* d_rows_ctl   = nullptr;// [0] rows listed by the running call, [1] segment items of the plan
-    uint32_t* d_long_items = nullptr;// the plan's segment items (rows longer than a run item's)
+    uint32_t* d_rows_list  = nullptr;// per block of 2048 rows: quads of its selected short rows -> offsets in the call's virtual quad stream (+ the total), built on the first such call
+    uint32_t* d_rows_ctl   = nullptr;// [1] segment items listed by the running call, [2] the plan's long rows (listed once), [4..7] the open gate
+    uint32_t* d_long_items = nullptr;// the segment items of the running call's selected long rows
+    uint32_t* d_long_rows  = nullptr;// the plan's long rows (more than 508 entries), in no particular order
+    uint32_t* d_long_first = nullptr;// ... and the first segment item of each
     uint32_t  n_long_items = 0;
     bool      rows_ready   = false;
     // BFS-like calls over a structure-only matrix (mxv_first_hit.hpp): per-call bitmap and statistics of the input vector, the verdict in pinned host memory

@@ -892,3 +892,65 @@ def test_reference_order_setting_vxm_pull_bit_for_bit(oracle):
             bad = np.nonzero(got.view(np.uint32) != wx.view(np.uint32))[0]
             assert len(bad) == 0, f"dense={dense} {sel}: {len(bad)} outputs differ from the oracle's word, first {got[bad[0]]!r} vs {wx[bad[0]]!r}"
             plan_T.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", ["INT", "UINT", "FLOAT"])
+def test_selected_rows_kernels_forced_on_every_mask_shape(oracle, t, monkeypatch):
+    """The selected-rows path (mxv_rows.hpp, round 6: short rows in 64-row batches with a lane per row, medium rows and the long rows' segment items a wavefront each,
+    the long rows listed from the plan) forced on whatever the mask (the probe's weights lowered): random 10 % / 90 % of the rows, every 10th row (the reference's
+    own perf test, tests/test_mxv.cpp:91-130), long blocks of consecutive rows, only the long rows, only empty rows, one row, everything — on a matrix of 70 003 rows
+    (not a multiple of 8 or of 2048) with rows of every length class: empty, short (<= 32), medium (33 .. 508), rows of one segment item (509 .. 1020) and of
+    several.  int / uint bit-identical to the oracle, fp32 sums too (the values are small multiples of 1/8: every order gives the same word)."""
+    import torch
+    from gpu_utils import dev, host
+    from spla_amd import kernels
+    monkeypatch.setenv("SPLAHIP_MASK_ROWS_X10", "1")
+    monkeypatch.setenv("SPLAHIP_MASK_LONG_X10", "1")
+    rng = np.random.default_rng(9091)
+    n_rows, n_cols = 70003, 50000
+    Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 9, t, skew=True, long_rows=0, long_len=0)
+    deg = np.diff(Ap.astype(np.int64))
+    # plant rows of the other length classes: rebuild with chosen degrees
+    want_deg = deg.copy()
+    for d, cnt in ((33, 40), (200, 40), (508, 20), (509, 10), (1020, 10), (1021, 6), (3000, 6), (9000, 3)):
+        want_deg[rng.choice(n_rows, cnt, replace=False)] = d
+    want_deg[-1] = 700  # (the matrix's last row is a long one; the row before it is empty)
+    want_deg[-2] = 0
+    Ap = np.zeros(n_rows + 1, np.uint32)
+    Ap[1:] = np.cumsum(want_deg)
+    nnz = int(Ap[-1])
+    Aj = np.empty(nnz, np.uint32)
+    for i in np.nonzero(want_deg)[0]:
+        Aj[Ap[i]:Ap[i + 1]] = np.sort(rng.choice(n_cols, int(want_deg[i]), replace=False))
+    Ax = random_values(rng, nnz, t)
+    if t == "FLOAT":
+        Ax = (rng.integers(1, 64, nnz) / 8.0).astype(np.float32)
+        v = (rng.integers(0, 32, n_cols) / 4.0).astype(np.float32)  # (sums of these are exact in fp32 in any order up to ~2^24 / (8 * 8 * 4) terms: thousands)
+    else:
+        v = random_values(rng, n_cols, t, zeros=0.2)
+    deg = want_deg
+    dAp, dAj, dAx, dv = dev(Ap), dev(Aj), dev(np.asarray(Ax, NP[t])), dev(np.asarray(v, NP[t]))
+    plan = kernels.CsrPlan(n_rows, nnz, dAp)
+    assert plan.attach_cob(n_cols, dAp, dAj, dAx) is not None
+    blocks = np.zeros(n_rows, bool)
+    for s0 in rng.integers(0, n_rows - 5000, 4):
+        blocks[s0:s0 + 4500] = True
+    one = np.zeros(n_rows, bool)
+    one[12345] = True
+    masks = {"random 10 %": rng.random(n_rows) < 0.1, "random 90 %": rng.random(n_rows) < 0.9, "every 10th row": np.arange(n_rows) % 10 == 0, "blocks of rows": blocks,
+             "only long rows": deg > 508, "only empty rows": deg == 0, "one row": one, "everything": np.ones(n_rows, bool), "the last rows": np.arange(n_rows) >= n_rows - 3}
+    for name, selrows in masks.items():
+        mask = np.where(selrows, 2, 0).astype(NP[t])
+        for mul, add, init in (("MULT", "PLUS", 3), ("PLUS", "MIN", 1000)):
+            want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, "NQZERO", init)
+            for attempt in (0, 1):
+                r = torch.full((n_rows,), 77, dtype=kernels.torch_dtype(t), device="cuda")
+                kernels.mxv_masked(plan, t, n_cols, dAp, dAj, dAx, dev(mask), dv, r, mul, add, "NQZERO", init)
+                torch.cuda.synchronize()
+            probe = plan.mask_probe()
+            assert probe["served_by_rows"], (name, probe)
+            got = host(r, NP[t])
+            bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+            assert len(bad) == 0, (t, name, mul, add, len(bad), int(bad[0]), int(deg[bad[0]]), got[bad[0]], want[bad[0]])
+    plan.close()
