@@ -404,17 +404,10 @@ def same_matrix_variants(args, n, nnz, Ap, Aj, Ax, v, mask, r_cob):
     csr = kernels.CsrPlan(n, nnz, Ap)
     run("fp32 MULT/PLUS, CSR wave-tile kernel (no layout copy; deterministic fold)", csr, "FLOAT", Ax, mask, v, r, "MULT", "PLUS", "ALWAYS", 0.0)
     res[-1]["max_rel_vs_cob"] = float(((r - r_cob).abs() / r_cob.abs().clamp_min(1e-30)).max())
-    # the reference-order mode (splahip_set_reference_order; Descriptor::set_reference_order): every row a strict left fold from init in entry order, the reference CPU
-    # backend's own loop (src/cpu/cpu_mxv.hpp:94-99) — checked BIT FOR BIT against the oracle on every 64th row and the 4096 longest rows
+    # ---- the exact-order paths: every row a strict left fold from init in entry order, the reference CPU backend's own loop (src/cpu/cpu_mxv.hpp:94-99), each checked BIT
+    # FOR BIT against the oracle on every 64th row and the 4096 longest rows
     from oracle import pyoracle
     from spla_amd import _lib
-    assert _lib.call("splahip_set_reference_order", 1) == 0
-    try:
-        rr = torch.empty_like(r_cob)
-        run("fp32 MULT/PLUS, reference-order mode (every row folded strictly left to right: bit-identical to the reference CPU backend)", csr, "FLOAT", Ax, mask, v, rr,
-            "MULT", "PLUS", "ALWAYS", 0.0)
-    finally:
-        assert _lib.call("splahip_set_reference_order", 0) == 1
     deg = (Ap[1:] - Ap[:-1]).to(torch.int64)
     rows = torch.unique(torch.cat([torch.arange(0, n, 64, device="cuda"), torch.topk(deg, 4096).indices]))
     Ap64 = Ap.to(torch.int64)
@@ -423,14 +416,49 @@ def same_matrix_variants(args, n, nnz, Ap, Aj, Ax, v, mask, r_cob):
     torch.cumsum(dg, 0, out=Aps[1:])
     rep = torch.repeat_interleave(torch.arange(rows.numel(), device="cuda"), dg)
     src = Ap64[rows][rep] + (torch.arange(int(Aps[-1]), device="cuda") - Aps[:-1][rep])
-    want = pyoracle.Oracle().mxv_masked("FLOAT", int(rows.numel()), n, Aps.to(torch.int32).cpu().numpy().view(np.uint32), Aj[src].cpu().numpy().view(np.uint32),
-                                        Ax[src].cpu().numpy(), mask[rows].cpu().numpy(), v.cpu().numpy(), "MULT", "PLUS", "ALWAYS", 0.0)
-    same = bool(np.array_equal(rr[rows].cpu().numpy().view(np.uint32), want.view(np.uint32)))
-    res[-1]["verified_rows"], res[-1]["bit_identical_to_oracle"] = int(rows.numel()), same
+    sample = (int(rows.numel()), n, Aps.to(torch.int32).cpu().numpy().view(np.uint32), Aj[src].cpu().numpy().view(np.uint32), Ax[src].cpu().numpy(), mask[rows].cpu().numpy(), v.cpu().numpy())
+    del rep, src, Aps, dg, deg, Ap64
+    orc = pyoracle.Oracle()
+
+    def check_exact(got, mul, add, init):
+        want = orc.mxv_masked("FLOAT", *sample, mul, add, "ALWAYS", init)
+        g = got[rows].cpu().numpy()
+        same = bool(np.all((g.view(np.uint32) == want.view(np.uint32)) | (np.isnan(g) & np.isnan(want))))
+        res[-1]["verified_rows"], res[-1]["bit_identical_to_oracle"] = int(rows.numel()), same
+        if not same:
+            raise SystemExit(f"bench: {res[-1]['name']} differs from the oracle")
+
+    # (1) the reference-order mode (splahip_set_reference_order; Descriptor::set_reference_order): an fp32 PLUS folded like the reference, the blocks standing aside
+    assert _lib.call("splahip_set_reference_order", 1) == 0
+    try:
+        rr = torch.empty_like(r_cob)
+        run("fp32 MULT/PLUS, reference-order mode (every row folded strictly left to right: bit-identical to the reference CPU backend)", csr, "FLOAT", Ax, mask, v, rr,
+            "MULT", "PLUS", "ALWAYS", 0.0)
+    finally:
+        assert _lib.call("splahip_set_reference_order", 0) == 1
+    check_exact(rr, "MULT", "PLUS", 0.0)
     res[-1]["max_rel_vs_cob"] = float(((rr - r_cob).abs() / r_cob.abs().clamp_min(1e-30)).max())
-    del rows, rep, src, Aps, dg, deg, Ap64, rr
-    if not same:
-        raise SystemExit("bench: the reference-order mode differs from the oracle")
+    # (2) an op_add that must not be re-ordered (MINUS: neither associative nor commutative): the same ordered kernels with the runtime-switched functor (round 6; a
+    # lane per row straight from memory until then: a hub row of 10^5 entries was one lane's)
+    run("fp32 MULT/MINUS (an op_add that must not be re-ordered), ordered kernels", csr, "FLOAT", Ax, mask, v, rr, "MULT", "MINUS", "ALWAYS", 0.0)
+    check_exact(rr, "MULT", "MINUS", 0.0)
+    # (3) a user-defined op_add (the reference's OpBinary::make_float text, compiled with hiprtc): a lane per row up to 508 entries, a wavefront per longer row
+    if _lib.call("splahip_jit_available"):
+        import ctypes as C
+        from spla_amd.ops import BINOP, SELOP
+        body = b"(float a, float b) { return a + b; }"  # (PLUS written by the user: the oracle's PLUS is its known answer)
+        P_ = lambda t: C.c_void_p(t.data_ptr())
+        call = lambda: _lib.call("splahip_mxv_masked_jit", 2, n, P_(Ap), P_(Aj), P_(Ax), P_(mask), P_(v), P_(rr), BINOP["MULT"], None, BINOP["PLUS"], body, SELOP["ALWAYS"], None,
+                                 C.c_uint32(0), 0, kernels.current_stream_ptr())
+        call()
+        torch.cuda.synchronize()
+        _, per = time_calls(call, max(3, steps // 4), 1)
+        ms = float(np.mean(per))
+        res.append({"name": "fp32 MULT / user-defined op_add \"(float a, float b) { return a + b; }\" (hiprtc), exact order for any op", "kernel": "splahip_mxv_jit + splahip_mxv_long_jit",
+                    "kernel_avg_us": round(ms * 1e3, 2), "gteps": round(nnz / (ms * 1e-3) / 1e9, 2), "hbm_gbs": round(alg / (ms * 1e-3) / 1e9, 1),
+                    "roofline_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        check_exact(rr, "MULT", "PLUS", 0.0)
+    del rows, rr
     # the reference's own SSSP semiring: fp32 min-plus (src/algorithm.cpp:208-213), 1/8 of v finite, init = +inf
     gen = torch.Generator(device="cuda")
     gen.manual_seed(args.seed + 77)

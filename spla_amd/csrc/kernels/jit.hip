@@ -239,20 +239,64 @@ namespace {
     std::string mxv_source(int type, int op_mult, const char* mult_src, int op_add, const char* add_src, int op_select, const char* select_src) {
         std::string s = prologue(type, op_mult, mult_src, op_add, add_src, op_select, select_src);
         // reference src/cpu/cpu_mxv.hpp:88-103: every row is written; a selected row folds its products left to right from init and, with
-        // early exit, stops after the product that makes the sum differ from init
+        // early exit, stops after the product that makes the sum differ from init.  Rows of more than `long_from` entries are left to splahip_mxv_long_jit below
+        // (0xFFFFFFFF: none — the early-exit calls, whose rows mostly stop after a few entries).
         s += "extern \"C\" __global__ void __launch_bounds__(256) splahip_mxv_jit(uint n_rows, const uint* __restrict__ Ap, const uint* __restrict__ Aj,\n"
-             "        const T* __restrict__ Ax, const T* __restrict__ mask, const T* __restrict__ v, T* __restrict__ r, T init, int early_exit) {\n"
+             "        const T* __restrict__ Ax, const T* __restrict__ mask, const T* __restrict__ v, T* __restrict__ r, T init, int early_exit, uint long_from) {\n"
              "    const uint i = blockIdx.x * 256u + threadIdx.x;\n"
              "    if (i >= n_rows) return;\n"
+             "    const uint k0 = Ap[i], k1 = Ap[i + 1];\n"
+             "    if (k1 - k0 > long_from) return;\n"
              "    T sum = init;\n"
              "    if (op_select(mask[i])) {\n"
-             "        const uint k1 = Ap[i + 1];\n"
-             "        for (uint k = Ap[i]; k < k1; ++k) {\n"
+             "        for (uint k = k0; k < k1; ++k) {\n"
              "            sum = op_add(sum, op_mult(Ax[k], v[Aj[k]]));\n"
              "            if (early_exit && sum != init) break;\n"
              "        }\n"
              "    }\n"
              "    r[i] = sum;\n"
+             "}\n";
+        return s;
+    }
+
+    // The long rows of a call with user-defined ops (round 6): one wavefront per listed row, 64 entries a step (coalesced Aj / Ax, gathers of v, the next step's loads
+    // in flight); the step's products are added ONE AFTER THE OTHER in entry order — the running value travels down the lanes (DPP wave_shr:1: in round t lane t takes
+    // lane t - 1's value and applies op_add to it and its own product; lane t's value is final after round t) — so the result is the reference's sequential fold for
+    // ANY op_add, associative or not (src/cpu/cpu_mxv.hpp:94-99).  Until round 6 such a row was one LANE's: a hub row of 10^5 entries, 10^5 dependent gathers.
+    std::string mxv_long_source(int type, int op_mult, const char* mult_src, int op_add, const char* add_src, int op_select, const char* select_src) {
+        std::string s = prologue(type, op_mult, mult_src, op_add, add_src, op_select, select_src);
+        s += type == SPLAHIP_FLOAT ? "#define TO_I(x) __float_as_int(x)\n#define FROM_I(x) __int_as_float(x)\n" : "#define TO_I(x) ((int) (x))\n#define FROM_I(x) ((T) (x))\n";
+        s += "extern \"C\" __global__ void __launch_bounds__(256) splahip_mxv_long_jit(const uint* __restrict__ rows, const uint* __restrict__ n_listed, const uint* __restrict__ Ap,\n"
+             "        const uint* __restrict__ Aj, const T* __restrict__ Ax, const T* __restrict__ mask, const T* __restrict__ v, T* __restrict__ r, T init) {\n"
+             "    const uint lane = threadIdx.x & 63u;\n"
+             "    const uint n = *n_listed;\n"
+             "    for (uint w = blockIdx.x * 4u + (threadIdx.x >> 6); w < n; w += gridDim.x * 4u) {\n"
+             "        const uint row = rows[w];\n"
+             "        if (!op_select(mask[row])) { if (lane == 0) r[row] = init; continue; }\n"
+             "        const uint rs = Ap[row], re = Ap[row + 1];\n"
+             "        T acc = init;\n"
+             "        uint k = rs + lane;\n"
+             "        T p = init;\n"
+             "        if (k < re) p = op_mult(Ax[k], v[Aj[k]]);\n"
+             "        for (uint k0 = rs; k0 < re; k0 += 64u) {\n"
+             "            const T pc = p;\n"
+             "            k = k0 + 64u + lane;\n"
+             "            if (k < re) p = op_mult(Ax[k], v[Aj[k]]);\n"
+             "            const uint cnt = re - k0 < 64u ? re - k0 : 64u;\n"
+             "            if (cnt == 64u) {\n"
+             "                T a = acc;\n"
+             "#pragma unroll 16\n"
+             "                for (int t = 0; t < 64; ++t) {\n"
+             "                    const T prev = FROM_I(__builtin_amdgcn_update_dpp(TO_I(acc), TO_I(a), 0x138, 0xF, 0xF, false));\n"
+             "                    a = op_add(prev, pc);\n"
+             "                }\n"
+             "                acc = FROM_I(__builtin_amdgcn_readlane(TO_I(a), 63));\n"
+             "            } else {\n"
+             "                for (uint l = 0; l < cnt; ++l) acc = op_add(acc, FROM_I(__builtin_amdgcn_readlane(TO_I(pc), l)));\n"
+             "            }\n"
+             "        }\n"
+             "        if (lane == 0) r[row] = acc;\n"
+             "    }\n"
              "}\n";
         return s;
     }
@@ -377,6 +421,15 @@ namespace {
 
 }// namespace
 
+namespace {
+    constexpr uint32_t kJitLongFrom = 508;// rows longer than this go to splahip_mxv_long_jit (the wave-tile plan's long-row threshold)
+    // list[1 + i], i < list[0]: the rows of more than long_from entries, in no particular order
+    __global__ __launch_bounds__(256) void jit_long_rows_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, uint32_t long_from, uint32_t* __restrict__ list) {
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        if (i < n_rows && Ap[i + 1] - Ap[i] > long_from) list[1 + atomicAdd(list, 1u)] = i;
+    }
+}// namespace
+
 extern "C" {
 
 int splahip_jit_available(void) { return rtc().ok ? 1 : 0; }
@@ -398,8 +451,24 @@ int splahip_mxv_masked_jit(int type, uint32_t n_rows, const uint32_t* d_Ap, cons
     if (st != SPLAHIP_OK) return st;
     uint32_t init = init_bits;
     int      ee   = early_exit ? 1 : 0;
-    void*    args[] = {&n_rows, &d_Ap, &d_Aj, &d_Ax, &d_mask, &d_v, &d_r, &init, &ee};
+    uint32_t long_from = early_exit ? 0xFFFFFFFFu : kJitLongFrom;
+    void*    args[] = {&n_rows, &d_Ap, &d_Aj, &d_Ax, &d_mask, &d_v, &d_r, &init, &ee, &long_from};
     SPLAHIP_TRY(hipModuleLaunchKernel(fn, (n_rows + 255u) / 256u, 1, 1, 256, 1, 1, 0, as_stream(stream), args, nullptr));
+    if (!early_exit) {// the long rows: listed on the device, a wavefront each (mxv_long_source)
+        hipFunction_t fl = nullptr;
+        st               = compile(mxv_long_source(type, op_mult, mult_src, op_add, add_src, op_select, select_src), "splahip_mxv_long_jit", &fl);
+        if (st != SPLAHIP_OK) return st;
+        hipStream_t s = as_stream(stream);
+        DevMem      list;
+        SPLAHIP_TRY(list.alloc(s, sizeof(uint32_t) * ((size_t) n_rows + 1)));
+        SPLAHIP_TRY(hipMemsetAsync(list.p, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(jit_long_rows_kernel, dim3((n_rows + 255u) / 256u), dim3(256), 0, s, n_rows, d_Ap, kJitLongFrom, list.as<uint32_t>());
+        SPLAHIP_TRY(hipGetLastError());
+        const uint32_t* rows  = list.as<uint32_t>() + 1;
+        const uint32_t* count = list.as<uint32_t>();
+        void*           la[]  = {&rows, &count, &d_Ap, &d_Aj, &d_Ax, &d_mask, &d_v, &d_r, &init};
+        SPLAHIP_TRY(hipModuleLaunchKernel(fl, 2048, 1, 1, 256, 1, 1, 0, s, la, nullptr));
+    }
     return SPLAHIP_OK;
 }
 

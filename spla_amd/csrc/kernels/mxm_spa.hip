@@ -1150,11 +1150,11 @@ namespace splahip {
             for (uint32_t q = 0; q < n_items; ++q) h_item[q] = items[q].row, h_item[n_items + q] = items[q].c0, h_item[2 * (size_t) n_items + q] = items[q].c1;
 
             // ---- dense window (fp32 MULT / PLUS): a block A[i0 : i0 + hi, k0 : k0 + hk] x B[k0 : k0 + hk, j0 : j0 + hj] of tiles that are at least half full and
-            // finite — ANYWHERE in the matrices (sides multiples of 32, at most SPLAHIP_MXM_DENSE_H = 1024) — goes through the matrix cores ---------------------
+            // finite — ANYWHERE in the matrices (sides multiples of 32, at most SPLAHIP_MXM_DENSE_H = 4096: six window-sized fp32 scratch arrays, 384 MB at most) — goes through the matrix cores ---------------------
             uint32_t d_i0 = 0, d_k0 = 0, d_j0 = 0, d_hi = 0, d_hk = 0, d_hj = 0;
             float *  dA = nullptr, *dB = nullptr, *dC = nullptr, *dN = nullptr, *sA = nullptr, *sB = nullptr;
             if constexpr (std::is_same<T, float>::value && ACC == COB_ADD) {
-                const uint32_t b_rows = b_rows_hint, h_max = std::max(32u, env_u32("SPLAHIP_MXM_DENSE_H", 1024u)) & ~31u;
+                const uint32_t b_rows = b_rows_hint, h_max = std::max(32u, env_u32("SPLAHIP_MXM_DENSE_H", 4096u)) & ~31u;
                 if (op_mult == SPLAHIP_MULT && env_u32("SPLAHIP_MXM_DENSE", 1) != 0 && a_rows >= 32 && b_cols >= 32 && b_rows >= 32) {
                     // 1. the half-full 32 x 32 tiles of A (row panels x inner tiles) and of B (inner panels x column tiles)
                     constexpr uint32_t kCap = 1u << 16;// listed tiles per matrix (more: the densest region is still among them in practice; the window is verified below anyway)

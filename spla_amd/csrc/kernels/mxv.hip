@@ -97,21 +97,23 @@ namespace {
         return SPLAHIP_OK;
     }
 
-    // the reference-order mode (splahip_set_reference_order): run items with one lane per row, long rows with one wavefront per row — every selected row a
-    // strict left fold from init in entry order (mxv_kernels.hpp: ORDERED, spmv_longrow_ordered_kernel)
-    template<typename T>
+    // the ORDERED kernels (mxv_kernels.hpp: ORDERED, spmv_longrow_ordered_kernel): run items with one lane per row, long rows with one wavefront per row — every
+    // selected row a strict left fold from init in entry order, the reference's own loop.  They serve the reference-order mode (an fp32 PLUS; AddF = the static
+    // functor: the chain of a long row is one dependent addition per entry) and, since round 6, every op_add that must not be re-ordered (MINUS, DIV, FIRST, SECOND,
+    // MINUS_POW2, fp32 MULT ...: AddF = the runtime-switched functor) — until then a lane per row straight from memory, a hub row of 10^5 entries one lane's.
+    template<typename T, class AddF>
     int launch_ordered(splahip_plan plan, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const void* mask, const void* v, void* r, int op_mult, int op_add,
                        int op_select, uint32_t init_bits, hipStream_t st) {
         const uint grid = (plan->n_items + Cfg::kWaves - 1) / Cfg::kWaves;
-        hipLaunchKernelGGL((spmv_wavetile_kernel<Cfg, T, DynBin, StaBin<SPLAHIP_PLUS>, false, true>), dim3(grid), dim3(Cfg::kTpb), 0, st, plan->d_item_row, plan->d_item_k0, plan->n_items, Ap, Aj,
+        hipLaunchKernelGGL((spmv_wavetile_kernel<Cfg, T, DynBin, AddF, false, true>), dim3(grid), dim3(Cfg::kTpb), 0, st, plan->d_item_row, plan->d_item_k0, plan->n_items, Ap, Aj,
                            static_cast<const uint32_t*>(Ax), static_cast<const T*>(mask), static_cast<const T*>(v), static_cast<const uint32_t*>(nullptr), static_cast<T*>(r),
-                           static_cast<uint32_t*>(nullptr), reinterpret_cast<T*>(plan->d_partial), static_cast<uint32_t*>(nullptr), DynBin(op_mult), StaBin<SPLAHIP_PLUS>(), op_select,
+                           static_cast<uint32_t*>(nullptr), reinterpret_cast<T*>(plan->d_partial), static_cast<uint32_t*>(nullptr), DynBin(op_mult), AddF(op_add), op_select,
                            from_bits<T>(init_bits), plan->nnz, static_cast<const uint32_t*>(nullptr));
         SPLAHIP_TRY(hipGetLastError());
         if (plan->n_long > 0) {
-            hipLaunchKernelGGL((spmv_longrow_ordered_kernel<Cfg, T, DynBin, StaBin<SPLAHIP_PLUS>, false>), dim3(grid), dim3(Cfg::kTpb), 0, st, plan->d_item_row, plan->d_item_k0, plan->n_items, Ap, Aj,
+            hipLaunchKernelGGL((spmv_longrow_ordered_kernel<Cfg, T, DynBin, AddF, false>), dim3(grid), dim3(Cfg::kTpb), 0, st, plan->d_item_row, plan->d_item_k0, plan->n_items, Ap, Aj,
                                static_cast<const uint32_t*>(Ax), static_cast<const T*>(mask), static_cast<const T*>(v), static_cast<const uint32_t*>(nullptr), static_cast<T*>(r),
-                               static_cast<uint32_t*>(nullptr), DynBin(op_mult), StaBin<SPLAHIP_PLUS>(), op_select, from_bits<T>(init_bits), plan->nnz);
+                               static_cast<uint32_t*>(nullptr), DynBin(op_mult), AddF(op_add), op_select, from_bits<T>(init_bits), plan->nnz);
             SPLAHIP_TRY(hipGetLastError());
         }
         return SPLAHIP_OK;
@@ -288,7 +290,7 @@ namespace {
         // reference-order mode: an fp32 sum is folded exactly as the reference folds it (every other fold of the wave-tile kernels is exact as it is)
         if (reference_order_calls() && type == SPLAHIP_FLOAT && op_add == SPLAHIP_PLUS && !early_exit) {
             if (plan->n_items != 0 && ((reinterpret_cast<uintptr_t>(Aj) | reinterpret_cast<uintptr_t>(Ax)) & 15u) == 0)
-                return launch_ordered<T>(plan, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, st);
+                return launch_ordered<T, StaBin<SPLAHIP_PLUS>>(plan, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, st);
             variant = Variant::RowSeq;// (an unaligned slice of a larger allocation: one lane per row straight from memory — the same fold)
         }
         // the wave-tile kernels read Aj / Ax with 16-byte loads: an unaligned slice of a larger allocation takes the row kernel
@@ -299,6 +301,10 @@ namespace {
             case Variant::RowSeqEarly:
                 return launch_rowseq<T, true>(n_rows, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, st);
             case Variant::RowSeq:
+                // an op_add that must not be re-ordered: the ordered kernels (the same fold, a hub row no longer one lane's); a plan without items (an empty
+                // matrix) or an unaligned slice of a larger allocation keeps the lane-per-row kernel
+                if (plan->n_items != 0 && ((reinterpret_cast<uintptr_t>(Aj) | reinterpret_cast<uintptr_t>(Ax)) & 15u) == 0 && !knob_env("SPLAHIP_FORCE_ROWSEQ"))
+                    return launch_ordered<T, DynBin>(plan, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, st);
                 return launch_rowseq<T, false>(n_rows, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, st);
             case Variant::WaveTileDynamic:
                 return launch_wavetile<T, DynBin, DynBin>(plan, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, st);
@@ -493,7 +499,7 @@ const char* splahip_mxv_variant(int type, int op_mult, int op_add, int early_exi
     switch (pick_variant(type, op_mult, op_add, early_exit)) {
         case Variant::WaveTileStatic: return "mxv_wavetile<static semiring>";
         case Variant::WaveTileDynamic: return "mxv_wavetile<runtime ops>";
-        case Variant::RowSeq: return "mxv_rowseq";
+        case Variant::RowSeq: return "mxv_ordered<an op_add that must not be re-ordered: a lane per row, a wavefront per long row>";
         case Variant::RowSeqEarly: return "mxv_rowseq<early_exit>";
     }
     return "?";

@@ -445,7 +445,11 @@ namespace splahip {
                 bool has = !VXM;
                 if (sel.row(i)) {
                     const uint s = s_ap[i] - a0, e = s_ap[i + 1] - a0;
-                    if (ORDERED || e - s <= C::kShortMax) {
+                    if constexpr (ORDERED && !VXM) {
+                        with_static_op(add_raw, [&](auto op) {// (ordered folds start at init: the op itself, its switch outside the loop)
+                            for (uint k = s; k < e; ++k) out = op(out, s_prod[k]);
+                        });
+                    } else if (ORDERED || e - s <= C::kShortMax) {
                         for (uint k = s; k < e; ++k) {
                             if constexpr (VXM) {
                                 if (s_ok[k]) {
@@ -577,11 +581,19 @@ namespace splahip {
             gather(S1);
             const u64 all = __ballot(S0.ok == 15u);
             if (all == ~0ull && !VXM) {
-#pragma unroll 8
-                for (uint l = 0; l < kWave; ++l) {
-#pragma unroll
-                    for (uint e = 0; e < 4; ++e) acc = add(acc, from_bits<T>((uint) __builtin_amdgcn_readlane((int) to_bits(S0.p[e]), l)));
-                }
+                // a full step: the running value travels DOWN the lanes — in round t lane t takes lane t - 1's value (DPP wave_shr:1; lane 0: the value carried in)
+                // and adds its own four products in order; every lane runs every round, lane t's value is final after round t (its left neighbour's was final a
+                // round earlier) and recomputing it later gives the same word.  One DPP move and four dependent adds per four entries (the v_readlane form:
+                // eight instructions and the SGPR hazards: the R-MAT 23 call 2.9 ms, bound by its longest row's chain).
+                T a = acc;
+                with_static_op(add, [&](auto op) {// (the op's switch once per step, not once per addition)
+#pragma unroll 16
+                    for (uint t = 0; t < kWave; ++t) {
+                        const T prev = from_bits<T>((uint) __builtin_amdgcn_update_dpp((int) to_bits(acc), (int) to_bits(a), 0x138, 0xF, 0xF, false));
+                        a            = op(op(op(op(prev, S0.p[0]), S0.p[1]), S0.p[2]), S0.p[3]);
+                    }
+                });
+                acc = from_bits<T>((uint) __builtin_amdgcn_readlane((int) to_bits(a), (int) kWave - 1));
             } else {
                 for (u64 m = __ballot(S0.ok != 0u); m; m &= m - 1) {
                     const uint l  = __ffsll((long long) m) - 1;

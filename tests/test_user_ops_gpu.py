@@ -73,3 +73,47 @@ def test_user_text_beside_builtin_ops(oracle):
     with pytest.raises(_lib.SplaHipError) as err:
         _jit("INT", n_rows, Ap, Aj, Ax, mask, v, "PLUS", "MIN", "EQZERO", 50, False, srcs=(None, "(int a, int b) { return a +* b; }", None))
     assert err.value.status == 8
+
+
+def test_user_defined_op_on_long_rows_keeps_the_reference_fold_order():
+    """Round 6: a call with user-defined ops folds rows of more than 508 entries with one WAVEFRONT per row (jit.hip: splahip_mxv_long_jit — the running value travels
+    down the lanes, one op_add per entry in entry order) instead of one lane: still the reference's sequential fold (src/cpu/cpu_mxv.hpp:94-99) for ANY op, associative
+    or not.  A non-associative, non-commutative fp32 op_add (0.25 a + 0.75 b) over rows of 509 ... 20 000 entries (whole steps of 64, ragged ends), masked, against the
+    same fold evaluated on the host in fp32, bit for bit; and early_exit = true (every row one lane's, as before) against the host's early-exit fold."""
+    rng = np.random.default_rng(31)
+    n_rows, n_cols = 3000, 30000
+    Ap, Aj, _ = random_csr(rng, n_rows, n_cols, 6, "FLOAT", skew=True, long_rows=0, long_len=0)
+    deg = np.diff(Ap.astype(np.int64))
+    for d in (509, 512, 575, 576, 1024, 4097, 20000):
+        deg[rng.integers(0, n_rows)] = d
+    Ap = np.zeros(n_rows + 1, np.uint32)
+    Ap[1:] = np.cumsum(deg)
+    nnz = int(Ap[-1])
+    Aj = np.empty(nnz, np.uint32)
+    for i in np.nonzero(deg)[0]:
+        Aj[Ap[i]:Ap[i + 1]] = np.sort(rng.choice(n_cols, int(deg[i]), replace=False))
+    Ax = (rng.random(nnz) * 2 - 0.7).astype(np.float32)
+    v = (rng.random(n_cols) * 2 - 0.6).astype(np.float32)
+    mask = random_mask(rng, n_rows, "FLOAT")
+    add_src = "(float a, float b) { return 0.25f * a + 0.75f * b; }"
+    init = np.float32(0.125)
+
+    def host_fold(early):
+        out = np.full(n_rows, init, np.float32)
+        q, t = np.float32(0.25), np.float32(0.75)
+        for i in range(n_rows):
+            if mask[i] == 0:
+                continue
+            s = init
+            for k in range(Ap[i], Ap[i + 1]):
+                s = np.float32(np.float32(q * s) + np.float32(t * np.float32(Ax[k] * v[Aj[k]])))
+                if early and s != init:
+                    break
+            out[i] = s
+        return out
+
+    for early in (False, True):
+        want = host_fold(early)
+        got = _jit("FLOAT", n_rows, Ap, Aj, Ax, mask, v, "MULT", "PLUS", "NQZERO", init, early, srcs=(None, add_src, None))
+        bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+        assert len(bad) == 0, (early, len(bad), int(bad[0]), int(deg[bad[0]]), got[bad[0]], want[bad[0]])

@@ -2,7 +2,8 @@
 calls per plan, so that the selected-rows kernels and the first-hit kernel — which follow the hint of an earlier call — are reached) against the oracle:
 random shapes, degree skews, long rows, semirings, select ops, init values and input-vector densities for a given time budget.
     python tools/exp/fuzz_mxv.py [seconds] [seed]"""
-import sys, time
+import os, sys, time
+os.environ["SPLA_ENV_AUTOSYNC"] = "1"  # knob changes made by the test helpers mid-process take effect (spla_amd/_lib.py: _sync_env)
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
@@ -36,6 +37,11 @@ while time.time() - t0 < budget:
         v = np.where(rng.random(n_cols) < dens, v if rng.integers(0, 2) else np.ones_like(v), 0).astype(NP[t])
     mask = random_mask(rng, n_rows, t)
     want = orc.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init)
+    # every third case: the selected-rows kernels forced on whatever the mask (round 6: short rows in batches, medium rows and long rows' segments a wave each)
+    if rng.random() < 0.34:
+        os.environ["SPLAHIP_MASK_ROWS_X10"], os.environ["SPLAHIP_MASK_LONG_X10"] = "1", "1"
+    else:
+        os.environ.pop("SPLAHIP_MASK_ROWS_X10", None), os.environ.pop("SPLAHIP_MASK_LONG_X10", None)
     try:
         got = hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, sel, init, junk=-3, calls=int(rng.integers(1, 4)))
     except AssertionError as e:

@@ -1,6 +1,7 @@
 """Randomised soak of vxm (push, small-frontier push, pull, pull over the sliced-ELL copy), mxm and mxmT against the oracle.
     python tools/exp/fuzz_ops.py [seconds] [seed]"""
-import sys, time
+import os, sys, time
+os.environ["SPLA_ENV_AUTOSYNC"] = "1"  # knob changes made by the test helpers mid-process take effect (spla_amd/_lib.py: _sync_env)
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
