@@ -580,7 +580,7 @@ namespace splahip {
             load_jx(kb + 512, S2);
             gather(S1);
             const u64 all = __ballot(S0.ok == 15u);
-            if (all == ~0ull && !VXM) {
+            if (all == ~0ull && has) {// (vxm: the fold starts at the FIRST product — its step takes the slow loop below, every later full step this one)
                 // a full step: the running value travels DOWN the lanes — in round t lane t takes lane t - 1's value (DPP wave_shr:1; lane 0: the value carried in)
                 // and adds its own four products in order; every lane runs every round, lane t's value is final after round t (its left neighbour's was final a
                 // round earlier) and recomputing it later gives the same word.  One DPP move and four dependent adds per four entries (the v_readlane form:
