@@ -241,20 +241,58 @@ namespace {
         // reference src/cpu/cpu_mxv.hpp:88-103: every row is written; a selected row folds its products left to right from init and, with
         // early exit, stops after the product that makes the sum differ from init.  Rows of more than `long_from` entries are left to splahip_mxv_long_jit below
         // (0xFFFFFFFF: none — the early-exit calls, whose rows mostly stop after a few entries).
+        s += type == SPLAHIP_FLOAT ? "#define TO_I(x) __float_as_int(x)\n#define FROM_I(x) __int_as_float(x)\n" : "#define TO_I(x) ((int) (x))\n#define FROM_I(x) ((T) (x))\n";
         s += "extern \"C\" __global__ void __launch_bounds__(256) splahip_mxv_jit(uint n_rows, const uint* __restrict__ Ap, const uint* __restrict__ Aj,\n"
              "        const T* __restrict__ Ax, const T* __restrict__ mask, const T* __restrict__ v, T* __restrict__ r, T init, int early_exit, uint long_from) {\n"
              "    const uint i = blockIdx.x * 256u + threadIdx.x;\n"
-             "    if (i >= n_rows) return;\n"
-             "    const uint k0 = Ap[i], k1 = Ap[i + 1];\n"
-             "    if (k1 - k0 > long_from) return;\n"
+             "    const uint lane = threadIdx.x & 63u;\n"
+             "    const bool in = i < n_rows;\n"
+             "    const uint k0 = in ? Ap[i] : 0u, k1 = in ? Ap[i + 1] : 0u;\n"
+             "    const bool sel = in && op_select(mask[i]);\n"
              "    T sum = init;\n"
-             "    if (op_select(mask[i])) {\n"
-             "        for (uint k = k0; k < k1; ++k) {\n"
-             "            sum = op_add(sum, op_mult(Ax[k], v[Aj[k]]));\n"
-             "            if (early_exit && sum != init) break;\n"
-             "        }\n"
+             "    if (!early_exit) {\n"
+             "        if (!in || k1 - k0 > long_from) return;\n"
+             "        if (sel) for (uint k = k0; k < k1; ++k) sum = op_add(sum, op_mult(Ax[k], v[Aj[k]]));\n"
+             "        r[i] = sum;\n"
+             "        return;\n"
              "    }\n"
-             "    r[i] = sum;\n"
+             // early exit: a lane walks the first 64 entries of its row; what is left of a longer row is searched by the wave, 64 entries a step (mxv_kernels.hpp:
+             // mxv_rowseq_kernel<EARLY> — the same rule, the same handling of a sum whose bits change without it moving off init)
+             "    uint k = sel ? k0 : 0u;\n"
+             "    const uint kend = sel ? k1 : 0u, ke = kend < k + 64u ? kend : k + 64u;\n"
+             "    bool done = false;\n"
+             "    for (; k < ke; ++k) { sum = op_add(sum, op_mult(Ax[k], v[Aj[k]])); if (sum != init) { done = true; break; } }\n"
+             "    u64 todo = __builtin_amdgcn_ballot_w64(sel && !done && ke < kend);\n"
+             "    while (todo != 0ull) {\n"
+             "        const int src = __builtin_ctzll(todo);\n"
+             "        const uint a = (uint) __builtin_amdgcn_readlane((int) ke, src), b = (uint) __builtin_amdgcn_readlane((int) kend, src);\n"
+             "        T S = FROM_I(__builtin_amdgcn_readlane(TO_I(sum), src));\n"
+             "        bool stopped = false;\n"
+             "        for (uint q = a; q < b && !stopped; q += 64u) {\n"
+             "            const uint kk = q + lane;\n"
+             "            const bool valid = kk < b;\n"
+             "            T p = init;\n"
+             "            if (valid) p = op_mult(Ax[kk], v[Aj[kk]]);\n"
+             "            const T c = valid ? op_add(S, p) : S;\n"
+             "            const bool off = valid && c != init;\n"
+             "            const bool flip = valid && !off && TO_I(c) != TO_I(S);\n"
+             "            const u64 m = __builtin_amdgcn_ballot_w64(off), f = __builtin_amdgcn_ballot_w64(flip);\n"
+             "            const u64 before = m != 0ull ? ((m & (0ull - m)) - 1ull) : ~0ull;\n"
+             "            if ((f & before) != 0ull) {\n"
+             "                T x = S;\n"
+             "                for (int t = 0; t < 64; ++t) {\n"
+             "                    const T prev = FROM_I(__builtin_amdgcn_update_dpp(TO_I(S), TO_I(x), 0x138, 0xF, 0xF, false));\n"
+             "                    x = valid ? op_add(prev, p) : prev;\n"
+             "                }\n"
+             "                const u64 m2 = __builtin_amdgcn_ballot_w64(valid && x != init);\n"
+             "                if (m2 != 0ull) { S = FROM_I(__builtin_amdgcn_readlane(TO_I(x), __builtin_ctzll(m2))); stopped = true; }\n"
+             "                else S = FROM_I(__builtin_amdgcn_readlane(TO_I(x), 63));\n"
+             "            } else if (m != 0ull) { S = FROM_I(__builtin_amdgcn_readlane(TO_I(c), __builtin_ctzll(m))); stopped = true; }\n"
+             "        }\n"
+             "        if ((int) lane == src) sum = S;\n"
+             "        todo &= todo - 1ull;\n"
+             "    }\n"
+             "    if (in) r[i] = sum;\n"
              "}\n";
         return s;
     }

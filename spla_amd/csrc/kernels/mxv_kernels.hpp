@@ -669,17 +669,74 @@ namespace splahip {
                                                              const T* __restrict__ v,
                                                              T* __restrict__ r,
                                                              Mult mult, Add add, int op_select, T init) {
-        const uint i = blockIdx.x * 256 + threadIdx.x;
-        if (i >= n_rows) return;
-        T sum = init;
-        if (eval_sel(op_select, mask[i])) {
-            const uint e = Ap[i + 1];
-            for (uint k = Ap[i]; k < e; ++k) {
-                sum = add(sum, mult(from_bits<T>(Ax[k]), v[Aj[k]]));
-                if (EARLY && sum != init) break;
+        const uint i  = blockIdx.x * 256 + threadIdx.x;
+        const bool in = i < n_rows;
+        T          sum = init;
+        if constexpr (!EARLY) {
+            if (in && eval_sel(op_select, mask[i])) {
+                const uint e = Ap[i + 1];
+                for (uint k = Ap[i]; k < e; ++k) sum = add(sum, mult(from_bits<T>(Ax[k]), v[Aj[k]]));
             }
+            if (in) r[i] = sum;
+        } else {
+            // early exit (src/cpu/cpu_mxv.hpp:96-98: the row stops behind the first product that moves the sum off init).  A lane walks the first kEarlyLane entries
+            // of its own row (most rows stop within a few); what is left of a longer row is searched by the whole WAVE, 64 entries a step (round 6: until then a
+            // hub row without an early hit was 10^5 dependent gathers on one lane).  Why the wave may look at 64 entries at once: until the row stops its sum
+            // compares equal to init, so with S the sum the step starts from, entry l's candidate add(S, p_l) is what the sequential fold would hold behind entry l
+            // — exactly, unless an earlier entry of the step changed the sum's BITS without moving it off init (a zero whose sign flips: MULT, DIV or SECOND as
+            // op_add over zero products).  Such a step (rare) is folded one entry after the other down the lanes (DPP wave_shr:1), like the ordered kernels.
+            constexpr uint kEarlyLane = 64;
+            const bool     sel = in && eval_sel(op_select, mask[i]);
+            uint           k   = sel ? Ap[i] : 0u;
+            const uint     k1  = sel ? Ap[i + 1] : 0u;
+            const uint     ke  = min(k1, k + kEarlyLane);
+            bool           done = false;
+            for (; k < ke; ++k) {
+                sum = add(sum, mult(from_bits<T>(Ax[k]), v[Aj[k]]));
+                if (sum != init) {
+                    done = true;
+                    break;
+                }
+            }
+            u64 todo = __ballot(sel && !done && ke < k1);
+            while (todo != 0ull) {
+                const int  src = __ffsll((long long) todo) - 1;
+                const uint a = __shfl(ke, src, kWave), b = __shfl(k1, src, kWave);
+                T          S = from_bits<T>((uint) __shfl((int) to_bits(sum), src, kWave));// the sum the next step starts from (compares equal to init)
+                bool       stopped = false;
+                for (uint q = a; q < b && !stopped; q += kWave) {
+                    const uint kk    = q + lane_id();
+                    const bool valid = kk < b;
+                    T          p     = init;
+                    if (valid) p = mult(from_bits<T>(Ax[kk]), v[Aj[kk]]);
+                    const T    c    = valid ? add(S, p) : S;
+                    const bool off  = valid && c != init;
+                    const bool flip = valid && !off && to_bits(c) != to_bits(S);
+                    const u64  m = __ballot(off), f = __ballot(flip);
+                    const u64  before = m != 0ull ? ((m & (0ull - m)) - 1ull) : ~0ull;// the lanes in front of the first entry that moves the sum
+                    if ((f & before) != 0ull) {
+                        // the sum's bits change inside the step before it stops: one entry after the other
+                        T x = S;
+                        for (uint t = 0; t < kWave; ++t) {
+                            const T prev = from_bits<T>((uint) __builtin_amdgcn_update_dpp((int) to_bits(S), (int) to_bits(x), 0x138, 0xF, 0xF, false));
+                            x            = valid ? add(prev, p) : prev;
+                        }
+                        const u64 m2 = __ballot(valid && x != init);
+                        if (m2 != 0ull) {
+                            S       = from_bits<T>((uint) __shfl((int) to_bits(x), __ffsll((long long) m2) - 1, kWave));
+                            stopped = true;
+                        } else
+                            S = from_bits<T>((uint) __builtin_amdgcn_readlane((int) to_bits(x), (int) kWave - 1));
+                    } else if (m != 0ull) {// the first entry that moves the sum: its lane's value is the row's result
+                        S       = from_bits<T>((uint) __shfl((int) to_bits(c), __ffsll((long long) m) - 1, kWave));
+                        stopped = true;
+                    }
+                }
+                if ((int) lane_id() == src) sum = S;
+                todo &= todo - 1ull;
+            }
+            if (in) r[i] = sum;
         }
-        r[i] = sum;
     }
 
 }// namespace splahip

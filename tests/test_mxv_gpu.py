@@ -954,3 +954,43 @@ def test_selected_rows_kernels_forced_on_every_mask_shape(oracle, t, monkeypatch
             bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
             assert len(bad) == 0, (t, name, mul, add, len(bad), int(bad[0]), int(deg[bad[0]]), got[bad[0]], want[bad[0]])
     plan.close()
+
+
+@pytest.mark.gpu
+def test_early_exit_over_long_rows_is_the_sequential_fold_signs_of_zeros_included(oracle):
+    """early_exit = true (src/cpu/cpu_mxv.hpp:96-98: a row stops behind the first product that moves its sum off init) over rows of up to 20 000 entries: since round 6
+    the wavefront searches a long row 64 entries a step instead of one lane walking it.  The search is the sequential fold exactly — also where the sum's BITS change
+    without the sum moving off init (a zero whose sign flips: SECOND, MULT or DIV as op_add over products that are +0 / -0): rows whose products are zeros of either
+    sign with the first non-zero product early, late or never.  fp32 and int32, several ops, init +0 and -0; every form against the oracle bit for bit."""
+    from gpu_utils import hip_mxv
+    rng = np.random.default_rng(4711)
+    n_cols = 30000
+    lens = [0, 1, 10, 63, 64, 65, 128, 129, 300, 1000, 1025, 5000, 20000, 7, 640]
+    n_rows = len(lens)
+    Ap = np.zeros(n_rows + 1, np.uint32)
+    Ap[1:] = np.cumsum(lens)
+    nnz = int(Ap[-1])
+    Aj = np.empty(nnz, np.uint32)
+    for i, d in enumerate(lens):
+        Aj[Ap[i]:Ap[i + 1]] = np.sort(rng.choice(n_cols, d, replace=False))
+    for t in ("FLOAT", "INT"):
+        if t == "FLOAT":
+            Ax = rng.choice(np.array([1.0, -1.0, 2.0, -0.5], np.float32), nnz)
+            v = rng.choice(np.array([0.0, -0.0], np.float32), n_cols)  # every product a zero of either sign ...
+        else:
+            Ax = rng.integers(-3, 4, nnz).astype(np.int32)
+            v = np.zeros(n_cols, np.int32)
+        for where in ("never", "late", "early"):
+            vv = v.copy()
+            if where != "never":
+                for i, d in enumerate(lens):  # ... except one column per row: the row's last entry ("late") or its third ("early")
+                    if d >= 3:
+                        vv[Aj[Ap[i] + (d - 1 if where == "late" else 2)]] = 3
+            mask = np.zeros(n_rows, NP[t])
+            for (mul, add) in (("MULT", "SECOND"), ("MULT", "MULT"), ("MULT", "PLUS"), ("MULT", "MIN"), ("MULT", "MINUS")):
+                for init in ((0.0, -0.0) if t == "FLOAT" else (0,)):
+                    init = NP[t](init)
+                    want = oracle.mxv_masked(t, n_rows, n_cols, Ap, Aj, Ax, mask, vv, mul, add, "EQZERO", init, True)
+                    got = hip_mxv(t, n_rows, n_cols, Ap, Aj, Ax, mask, vv, mul, add, "EQZERO", init, early_exit=True, junk=9)
+                    bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+                    assert len(bad) == 0, (t, where, mul, add, init, [(int(b), lens[b], got[b], want[b]) for b in bad[:4]])

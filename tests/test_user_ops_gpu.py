@@ -117,3 +117,32 @@ def test_user_defined_op_on_long_rows_keeps_the_reference_fold_order():
         got = _jit("FLOAT", n_rows, Ap, Aj, Ax, mask, v, "MULT", "PLUS", "NQZERO", init, early, srcs=(None, add_src, None))
         bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
         assert len(bad) == 0, (early, len(bad), int(bad[0]), int(deg[bad[0]]), got[bad[0]], want[bad[0]])
+
+
+def test_jit_early_exit_over_long_rows_signs_of_zeros_included(oracle):
+    """The run-time-compiled mxv kernel with early_exit = true searches a long row with the whole wavefront (round 6) — the sequential fold exactly, also where the sum's
+    bits change without it moving off init (zero products of either sign under SECOND / MULT as op_add): built-in ops emitted as text against the oracle, bit for bit."""
+    rng = np.random.default_rng(4712)
+    n_cols = 20000
+    lens = [0, 2, 64, 65, 130, 700, 4096, 9000]
+    n_rows = len(lens)
+    Ap = np.zeros(n_rows + 1, np.uint32)
+    Ap[1:] = np.cumsum(lens)
+    nnz = int(Ap[-1])
+    Aj = np.empty(nnz, np.uint32)
+    for i, d in enumerate(lens):
+        Aj[Ap[i]:Ap[i + 1]] = np.sort(rng.choice(n_cols, d, replace=False))
+    Ax = rng.choice(np.array([1.0, -1.0, 2.0, -0.5], np.float32), nnz)
+    mask = np.zeros(n_rows, np.float32)
+    for where in ("never", "late", "early"):
+        v = rng.choice(np.array([0.0, -0.0], np.float32), n_cols)
+        if where != "never":
+            for i, d in enumerate(lens):
+                if d >= 3:
+                    v[Aj[Ap[i] + (d - 1 if where == "late" else 2)]] = 3
+        for (mul, add) in (("MULT", "SECOND"), ("MULT", "MULT"), ("MULT", "PLUS"), ("MULT", "MINUS")):
+            for init in (np.float32(0.0), np.float32(-0.0)):
+                want = oracle.mxv_masked("FLOAT", n_rows, n_cols, Ap, Aj, Ax, mask, v, mul, add, "EQZERO", init, True)
+                got = _jit("FLOAT", n_rows, Ap, Aj, Ax, mask, v, mul, add, "EQZERO", init, True)
+                bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+                assert len(bad) == 0, (where, mul, add, init, [(int(b), lens[b], got[b], want[b]) for b in bad[:4]])
