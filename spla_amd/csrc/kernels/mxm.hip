@@ -1722,6 +1722,7 @@ namespace splahip {
 }// namespace splahip
 
 namespace splahip {
+    void vxm_workspaces_trim();// vxm.hip: the small-frontier push form's per-thread accumulators
     void mxm_pinned_trim();// mxm_spa.hip: the pinned staging chunks of every host thread that is not inside a call
     int mxm_spa(int type, uint32_t a_rows, uint32_t b_cols, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const uint32_t* Bp, const uint32_t* Bj, const void* Bx, uint32_t* Rp,
                 uint32_t** Rj, void** Rx, uint32_t* h_nnz, unsigned long long* h_products, int op_mult, int op_add, uint32_t init_bits, hipStream_t s);
@@ -1823,6 +1824,7 @@ int splahip_mxm_trim(void) {
     scratch_trim();
     stream_caches_trim();
     mxm_pinned_trim();
+    vxm_workspaces_trim();
     handoff_trim();
     (void) hipDeviceSynchronize();// (what the pool still holds for queued work stays; everything else goes back)
     pool_trim();

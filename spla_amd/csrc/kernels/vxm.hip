@@ -23,6 +23,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <rocprim/device/device_radix_sort.hpp>
 
 namespace splahip {
@@ -681,24 +682,83 @@ namespace splahip {
         return SPLAHIP_OK;
     }
 
-    // all-zero accumulator words kept between calls (grow-only, per host thread like the other cached workspaces)
+    // all-zero accumulator words kept between calls (grow-only, per host thread like the other cached workspaces; listed process-wide like them — runtime.hip: a
+    // trim from any thread frees the workspaces of threads that are not inside a call and deletes those of threads that have exited)
     struct SmallPushWs {
-        u64*   acc   = nullptr;
-        size_t words = 0;
-        uint*  misc  = nullptr;// gate[4] | chunk[...]
-        size_t misc_words = 0;
+        std::mutex m;
+        u64*       acc   = nullptr;
+        size_t     words = 0;
+        uint*      misc  = nullptr;// gate[4] | chunk[...]
+        size_t     misc_words = 0;
+        int        busy   = 0;
+        bool       orphan = false;
+    };
+    struct SmallPushRegistry {
+        std::mutex                m;
+        std::vector<SmallPushWs*> all;
+    };
+    inline SmallPushRegistry& small_push_registry() {
+        static SmallPushRegistry* r = new SmallPushRegistry;
+        return *r;
+    }
+    struct SmallPushHolder {
+        SmallPushWs* w;
+        SmallPushHolder() : w(new SmallPushWs) {
+            auto& r = small_push_registry();
+            std::lock_guard<std::mutex> g(r.m);
+            r.all.push_back(w);
+        }
+        ~SmallPushHolder() {
+            std::lock_guard<std::mutex> g(w->m);
+            w->orphan = true;
+        }
     };
     inline SmallPushWs& small_push_ws() {
-        static thread_local SmallPushWs ws;
-        return ws;
+        static thread_local SmallPushHolder h;
+        return *h.w;
     }
+    void small_push_trim() {
+        auto& r = small_push_registry();
+        std::lock_guard<std::mutex> rg(r.m);
+        for (size_t k = 0; k < r.all.size();) {
+            SmallPushWs* w    = r.all[k];
+            bool         drop = false;
+            {
+                std::lock_guard<std::mutex> g(w->m);
+                if (w->busy == 0) {
+                    if (w->acc) (void) hipFree(w->acc);
+                    if (w->misc) (void) hipFree(w->misc);
+                    w->acc = nullptr, w->misc = nullptr, w->words = w->misc_words = 0;
+                    drop = w->orphan;
+                }
+            }
+            if (drop) {
+                delete w;
+                r.all.erase(r.all.begin() + (long) k);
+            } else
+                ++k;
+        }
+    }
+    struct SmallPushBusy {// (the workspace is in use for the length of a call: the call ends with a host synchronisation)
+        SmallPushWs& w;
+        explicit SmallPushBusy(SmallPushWs& ws) : w(ws) {
+            std::lock_guard<std::mutex> g(w.m);
+            ++w.busy;
+        }
+        ~SmallPushBusy() {
+            std::lock_guard<std::mutex> g(w.m);
+            --w.busy;
+        }
+    };
 
     template<typename T>
     int push_small_typed(uint n_cols, const uint* Ap, const uint* Aj, const void* Ax, const void* mask, uint nvals, const uint* vi, const void* vx, uint* ri,
                          void* rx, uint max_products, uint* h_out /* count, products lo, products hi, unsorted, NaN seen */, int op_mult, int op_add, int op_select,
                          hipStream_t s) {
-        SmallPushWs& ws       = small_push_ws();
-        const uint   n_chunks = (n_cols + 1023u) / 1024u;
+        SmallPushWs&  ws = small_push_ws();
+        SmallPushBusy in_use(ws);
+        register_trim(&small_push_trim);// (idempotent)
+        const uint    n_chunks = (n_cols + 1023u) / 1024u;
         if (ws.words < n_cols) {
             if (ws.acc) (void) hipFree(ws.acc);
             ws.acc = nullptr, ws.words = 0;
@@ -859,6 +919,10 @@ namespace splahip {
 }// namespace splahip
 
 using namespace splahip;
+
+namespace splahip {
+    void vxm_workspaces_trim() { small_push_trim(); }// the small-frontier push form's per-thread accumulators (splahip_mxm_trim, out-of-memory retries)
+}// namespace splahip
 
 extern "C" {
 

@@ -28,9 +28,12 @@ def _work(scale, seed):
     r = torch.empty(n, dtype=torch.int32, device="cuda")
     plan = kernels.CsrPlan(n, int(A[0][-1]), A[0])
     kernels.mxv_masked(plan, "INT", n, A[0], A[1], A[2], torch.zeros(n, dtype=torch.int32, device="cuda"), v, r, "MULT", "PLUS", "ALWAYS", 0, False)
+    vi = torch.arange(0, n, 97, dtype=torch.int32, device="cuda")  # a small frontier: the single-pass push form (its per-thread all-zero accumulators)
+    P = kernels.vxm_push_small("INT", n, n, A[0], A[1], A[2], torch.zeros(n, dtype=torch.int32, device="cuda"), vi, torch.ones_like(vi), "MULT", "MAX", "ALWAYS", 1 << 22)
     torch.cuda.current_stream().synchronize()
     plan.close()
-    return [t.cpu().numpy() for t in (*R, *T, r)]
+    assert P[0], "the small-frontier push form was expected to run"
+    return [t.cpu().numpy() for t in (*R, *T, r, P[3], P[4])]
 
 
 def test_calls_of_four_host_threads_on_their_own_streams_match_the_single_threaded_results():
