@@ -68,6 +68,8 @@ _SIGNATURES = {
     "splahip_jit_available": (C.c_int, []),
     "splahip_mxv_masked_jit": (C.c_int, [C.c_int, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p,
                                          C.c_uint32, C.c_int, _vp]),
+    "splahip_vxm_masked_jit": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_int, _vp, _vp, C.POINTER(C.c_uint32), C.c_int, C.c_char_p,
+                                         C.c_int, C.c_char_p, C.c_int, C.c_char_p, _vp]),
     "splahip_dist_available": (C.c_int, []),
     "splahip_dist_get_unique_id": (C.c_int, [_vp]),
     "splahip_dist_comm_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _vp]),

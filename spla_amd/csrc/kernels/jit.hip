@@ -202,9 +202,10 @@ namespace {
         std::string s = prologue(type, op_mult, mult_src, op_add, add_src, op_select, select_src);
         s += "extern \"C\" __global__ void __launch_bounds__(256) splahip_vxm_jit(uint n_out, const uint* __restrict__ Tp, const uint* __restrict__ Tj, const T* __restrict__ Tx,\n"
              "        const T* __restrict__ mask, const T* __restrict__ v, const uint* __restrict__ present, const uint* __restrict__ vpos, int sorted,\n"
-             "        T* __restrict__ outv, uint* __restrict__ touched) {\n"
+             "        T* __restrict__ outv, uint* __restrict__ touched, uint long_from) {\n"
              "    const uint j = blockIdx.x * 256u + threadIdx.x;\n"
              "    if (j >= n_out) return;\n"
+             "    if (sorted && Tp[j + 1] - Tp[j] > long_from) return;\n"// (a long column of an index-sorted v: splahip_vxm_long_jit)
              "    T acc = (T) 0;\n"
              "    uint t = 0;\n"
              "    if (op_select(mask[j])) {\n"
@@ -232,6 +233,46 @@ namespace {
              "    }\n"
              "    outv[j] = acc;\n"
              "    touched[j] = t;\n"
+             "}\n";
+        return s;
+    }
+
+    // The long columns of an index-sorted vxm call with user-defined ops (round 6): one wavefront per listed output index, 64 entries of the transposed matrix's row a
+    // step; the running (value, "a product has been seen") pair travels down the lanes (DPP wave_shr:1) — lane t applies op_add to its left neighbour's value and its
+    // own product if its index of v is stored, initialises with its product if nothing was seen so far, passes the pair on otherwise — the reference's fold in the
+    // stored order of v (src/cpu/cpu_vxm.hpp:101-113) for ANY op.  Until round 6 such a column was one lane's.
+    std::string vxm_long_source(int type, int op_mult, const char* mult_src, int op_add, const char* add_src, int op_select, const char* select_src) {
+        std::string s = prologue(type, op_mult, mult_src, op_add, add_src, op_select, select_src);
+        s += type == SPLAHIP_FLOAT ? "#define TO_I(x) __float_as_int(x)\n#define FROM_I(x) __int_as_float(x)\n" : "#define TO_I(x) ((int) (x))\n#define FROM_I(x) ((T) (x))\n";
+        s += "extern \"C\" __global__ void __launch_bounds__(256) splahip_vxm_long_jit(const uint* __restrict__ rows, const uint* __restrict__ n_listed, const uint* __restrict__ Tp,\n"
+             "        const uint* __restrict__ Tj, const T* __restrict__ Tx, const T* __restrict__ mask, const T* __restrict__ v, const uint* __restrict__ present,\n"
+             "        T* __restrict__ outv, uint* __restrict__ touched) {\n"
+             "    const uint lane = threadIdx.x & 63u;\n"
+             "    const uint n = *n_listed;\n"
+             "    for (uint w = blockIdx.x * 4u + (threadIdx.x >> 6); w < n; w += gridDim.x * 4u) {\n"
+             "        const uint j = rows[w];\n"
+             "        if (!op_select(mask[j])) { if (lane == 0) { outv[j] = (T) 0; touched[j] = 0; } continue; }\n"
+             "        const uint rs = Tp[j], re = Tp[j + 1];\n"
+             "        T acc = (T) 0;\n"
+             "        int has = 0;\n"
+             "        for (uint k0 = rs; k0 < re; k0 += 64u) {\n"
+             "            const uint k = k0 + lane;\n"
+             "            bool ok = false;\n"
+             "            T p = (T) 0;\n"
+             "            if (k < re) { const uint i = Tj[k]; ok = ((present[i >> 5] >> (i & 31u)) & 1u) != 0u; if (ok) p = op_mult(v[i], Tx[k]); }\n"
+             "            if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;\n"
+             "            T a = acc;\n"
+             "            int h = has;\n"
+             "            for (int t = 0; t < 64; ++t) {\n"
+             "                const T pa = FROM_I(__builtin_amdgcn_update_dpp(TO_I(acc), TO_I(a), 0x138, 0xF, 0xF, false));\n"
+             "                const int ph = __builtin_amdgcn_update_dpp(has, h, 0x138, 0xF, 0xF, false);\n"
+             "                if (ok) { a = ph ? op_add(pa, p) : p; h = 1; } else { a = pa; h = ph; }\n"
+             "            }\n"
+             "            acc = FROM_I(__builtin_amdgcn_readlane(TO_I(a), 63));\n"
+             "            has = __builtin_amdgcn_readlane(h, 63);\n"
+             "        }\n"
+             "        if (lane == 0) { outv[j] = acc; touched[j] = (uint) has; }\n"
+             "    }\n"
              "}\n";
         return s;
     }
@@ -527,7 +568,12 @@ int splahip_vxm_masked_jit(splahip_plan plan_T, int type, uint32_t n_in, uint32_
     hipFunction_t fn = nullptr;
     st               = compile(vxm_source(type, op_mult, mult_src, op_add, add_src, op_select, select_src), "splahip_vxm_jit", &fn);
     if (st != SPLAHIP_OK) return st;
-    return vxm_pull_jit(plan_T, n_out, n_in, d_Tp, d_Tj, d_Tx, d_mask, nvals, d_vi, d_vx, sorted, d_ri, d_rx, h_count, fn, as_stream(stream));
+    hipFunction_t fl = nullptr;// the long columns of an index-sorted v: a wavefront each (vxm_long_source)
+    if (sorted) {
+        st = compile(vxm_long_source(type, op_mult, mult_src, op_add, add_src, op_select, select_src), "splahip_vxm_long_jit", &fl);
+        if (st != SPLAHIP_OK) return st;
+    }
+    return vxm_pull_jit(plan_T, n_out, n_in, d_Tp, d_Tj, d_Tx, d_mask, nvals, d_vi, d_vx, sorted, d_ri, d_rx, h_count, fn, fl, as_stream(stream));
 }
 
 // exec_mxmT_masked with user-defined ops (arguments as splahip_mxmT_masked)

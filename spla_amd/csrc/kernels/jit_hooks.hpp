@@ -22,9 +22,11 @@ namespace splahip {
     int mxm_jit(uint32_t a_rows, uint32_t b_cols, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const uint32_t* Bp, const uint32_t* Bj, const void* Bx, uint32_t* Rp,
                 uint32_t** Rj, void** Rx, uint32_t* h_nnz, uint32_t init_bits, hipFunction_t expand, hipFunction_t run, hipStream_t s);
     // vxm.hip — exec_vxm_masked, pull form over the transposed matrix (reference cpu_vxm.hpp:92-125): `column` folds one output index,
-    //   (uint n_out, Tp, Tj, Tx, mask, const T* v_dense, const uint* present, const uint* vpos, int sorted, T* outv, uint* touched)
+    //   (uint n_out, Tp, Tj, Tx, mask, const T* v_dense, const uint* present, const uint* vpos, int sorted, T* outv, uint* touched, uint long_from)
+    // `column_long` (may be null; index-sorted v only) folds the listed output indices of more than long_from entries, a wavefront each,
+    //   (const uint* rows, const uint* n_listed, Tp, Tj, Tx, mask, const T* v_dense, const uint* present, T* outv, uint* touched)
     int vxm_pull_jit(splahip_plan plan_T, uint32_t n_out, uint32_t n_in, const uint32_t* Tp, const uint32_t* Tj, const void* Tx, const void* mask, uint32_t nvals,
-                     const uint32_t* vi, const void* vx, int sorted, uint32_t* ri, void* rx, uint32_t* h_count, hipFunction_t column, hipStream_t s);
+                     const uint32_t* vi, const void* vx, int sorted, uint32_t* ri, void* rx, uint32_t* h_count, hipFunction_t column, hipFunction_t column_long, hipStream_t s);
 
     // vector_ops.hip — v_eadd_fdb, sparse operand (reference cpu_v_eadd_fdb.hpp:71-139): `apply` is the pass that applies the op and flags the changed entries,
     //   (uint nvals, T* r, const uint* vi, const T* vx, uint* changed, T* newval); the order-preserving compaction of the feedback is the built-in drivers'

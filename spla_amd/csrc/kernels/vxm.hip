@@ -643,12 +643,17 @@ namespace splahip {
 
     // jit_hooks.hpp: the pull form with the per-column fold replaced by a run-time-compiled kernel (user-defined ops, jit.hip): dense image of v + presence
     // bitmap (+ the position of every index in v's stored order when v is not index-sorted) in the plan's workspace, then the same compaction
+    // list[1 + i], i < list[0]: the rows of the transposed matrix (output indices) of more than long_from entries, in no particular order
+    __global__ __launch_bounds__(256) void vxm_long_rows_kernel(uint n_out, const uint* __restrict__ Tp, uint long_from, uint* __restrict__ list) {
+        const uint j = blockIdx.x * 256 + threadIdx.x;
+        if (j < n_out && Tp[j + 1] - Tp[j] > long_from) list[1 + atomicAdd(list, 1u)] = j;
+    }
     __global__ __launch_bounds__(256) void scatter_vpos_kernel(uint nvals, const uint* __restrict__ vi, uint* __restrict__ vpos) {
         const uint idx = blockIdx.x * 256 + threadIdx.x;
         if (idx < nvals) vpos[vi[idx]] = idx;
     }
     int vxm_pull_jit(splahip_plan plan, uint32_t n_out, uint32_t n_in, const uint32_t* Tp, const uint32_t* Tj, const void* Tx, const void* mask, uint32_t nvals,
-                     const uint32_t* vi, const void* vx, int sorted, uint32_t* ri, void* rx, uint32_t* h_count, hipFunction_t column, hipStream_t s) {
+                     const uint32_t* vi, const void* vx, int sorted, uint32_t* ri, void* rx, uint32_t* h_count, hipFunction_t column, hipFunction_t column_long, hipStream_t s) {
         const uint   words    = (n_in + 31u) / 32u;
         const uint   n_chunks = (n_out + 1023u) / 1024u;
         const uint   n_in4    = (n_in + 3u) & ~3u, words4 = (words + 3u) & ~3u, n_out4 = (n_out + 3u) & ~3u;
@@ -672,8 +677,21 @@ namespace splahip {
         uint  no = n_out;
         int   so = sorted ? 1 : 0;
         void *pd = ws_dense, *pp = ws_present, *pq = ws_vpos, *po = ws_outv, *pt = ws_touched;
-        void* args[] = {&no, &Tp, &Tj, &Tx, &mask, &pd, &pp, &pq, &so, &po, &pt};
+        constexpr uint kLongFrom = 508;// output indices of more entries (index-sorted v): a wavefront each (column_long) instead of one lane
+        uint           long_from = sorted && column_long ? kLongFrom : 0xFFFFFFFFu;
+        void* args[] = {&no, &Tp, &Tj, &Tx, &mask, &pd, &pp, &pq, &so, &po, &pt, &long_from};
         SPLAHIP_TRY(hipModuleLaunchKernel(column, (n_out + 255u) / 256u, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+        DevMem list;// [0] the count, then the listed output indices (kept until the stream has run the kernels below: released stream-ordered)
+        if (long_from != 0xFFFFFFFFu) {
+            SPLAHIP_TRY(list.alloc(s, sizeof(uint) * ((size_t) n_out + 1)));
+            SPLAHIP_TRY(hipMemsetAsync(list.p, 0, sizeof(uint), s));
+            hipLaunchKernelGGL(vxm_long_rows_kernel, dim3((n_out + 255u) / 256u), dim3(256), 0, s, n_out, Tp, kLongFrom, list.as<uint>());
+            SPLAHIP_TRY(hipGetLastError());
+            const uint* rows  = list.as<uint>() + 1;
+            const uint* count = list.as<uint>();
+            void*       la[]  = {&rows, &count, &Tp, &Tj, &Tx, &mask, &pd, &pp, &po, &pt};
+            SPLAHIP_TRY(hipModuleLaunchKernel(column_long, 2048, 1, 1, 256, 1, 1, 0, s, la, nullptr));
+        }
         hipLaunchKernelGGL(flag_count_kernel, dim3(n_chunks), dim3(256), 0, s, ws_touched, n_out, ws_chunk);
         hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, ws_chunk, n_chunks);
         hipLaunchKernelGGL(flag_write_kernel, dim3(n_chunks), dim3(256), 0, s, ws_touched, ws_outv, n_out, ws_chunk, ri, static_cast<uint*>(rx));

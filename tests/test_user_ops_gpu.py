@@ -146,3 +146,64 @@ def test_jit_early_exit_over_long_rows_signs_of_zeros_included(oracle):
                 got = _jit("FLOAT", n_rows, Ap, Aj, Ax, mask, v, mul, add, "EQZERO", init, True)
                 bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
                 assert len(bad) == 0, (where, mul, add, init, [(int(b), lens[b], got[b], want[b]) for b in bad[:4]])
+
+
+def test_user_defined_op_vxm_on_long_columns_keeps_the_reference_fold_order():
+    """Round 6: exec_vxm_masked with user-defined ops folds a column of more than 508 entries (index-sorted v) with one WAVEFRONT (jit.hip: splahip_vxm_long_jit — the
+    (value, seen) pair travels down the lanes) instead of one lane: the reference's fold in the stored order of v from the FIRST product (src/cpu/cpu_vxm.hpp:101-113), for
+    any op.  A non-associative fp32 op_add over columns of 509 ... 12 000 entries, a sparse v (a third of the indices stored), a mask; against the host's fold, bit for bit."""
+    import ctypes as C
+    import torch
+    from gpu_utils import dev, host
+    from spla_amd import _lib, kernels
+    from spla_amd.kernels import _ptr, current_stream_ptr
+    from spla_amd.ops import binop_id, selop_id
+    rng = np.random.default_rng(33)
+    n_rows, n_cols = 15000, 2500  # M: n_rows x n_cols; T = M^T: n_cols rows
+    Tp, Tj, _ = random_csr(rng, n_cols, n_rows, 8, "FLOAT", skew=True, long_rows=0, long_len=0)
+    deg = np.diff(Tp.astype(np.int64))
+    for d in (509, 640, 641, 2000, 12000):
+        deg[rng.integers(0, n_cols)] = d
+    Tp = np.zeros(n_cols + 1, np.uint32)
+    Tp[1:] = np.cumsum(deg)
+    nnz = int(Tp[-1])
+    Tj = np.empty(nnz, np.uint32)
+    for j in np.nonzero(deg)[0]:
+        Tj[Tp[j]:Tp[j + 1]] = np.sort(rng.choice(n_rows, int(deg[j]), replace=False))
+    Tx = (rng.random(nnz) * 2 - 0.7).astype(np.float32)
+    vi = np.sort(rng.permutation(n_rows)[: n_rows // 3]).astype(np.uint32)
+    vx = (rng.random(len(vi)) * 2 - 0.6).astype(np.float32)
+    mask = random_mask(rng, n_cols, "FLOAT")
+    add_src = b"(float a, float b) { return 0.25f * a + 0.75f * b; }"
+    # host: the fold of every selected column over the stored indices of v, ascending, from the first product
+    dense = np.zeros(n_rows, np.float32)
+    pres = np.zeros(n_rows, bool)
+    dense[vi], pres[vi] = vx, True
+    q, t = np.float32(0.25), np.float32(0.75)
+    wi, wx = [], []
+    for j in range(n_cols):
+        if mask[j] == 0:
+            continue
+        s, seen = np.float32(0), False
+        for k in range(Tp[j], Tp[j + 1]):
+            i = Tj[k]
+            if pres[i]:
+                p = np.float32(dense[i] * Tx[k])
+                s = np.float32(np.float32(q * s) + np.float32(t * p)) if seen else p
+                seen = True
+        if seen:
+            wi.append(j), wx.append(s)
+    dTp, dTj, dTx, dm, dvi, dvx = dev(Tp), dev(Tj), dev(Tx), dev(mask), dev(vi), dev(vx)
+    plan_T = kernels.CsrPlan(n_cols, nnz, dTp)
+    ri = torch.empty(n_cols, dtype=torch.int32, device="cuda")
+    rx = torch.empty(n_cols, dtype=torch.float32, device="cuda")
+    cnt = C.c_uint32(0)
+    _lib.call("splahip_vxm_masked_jit", plan_T.handle, 2, n_rows, n_cols, _ptr(dTp), _ptr(dTj), _ptr(dTx), _ptr(dm), len(vi), _ptr(dvi), _ptr(dvx), 1, _ptr(ri), _ptr(rx),
+              C.byref(cnt), binop_id("MULT"), None, binop_id("PLUS"), add_src, selop_id("NQZERO"), None, current_stream_ptr())
+    torch.cuda.synchronize()
+    gi, gx = host(ri[: cnt.value], np.uint32), host(rx[: cnt.value], np.float32)
+    assert np.array_equal(gi, np.array(wi, np.uint32)), "structure"
+    wxa = np.array(wx, np.float32)
+    bad = np.nonzero(gx.view(np.uint32) != wxa.view(np.uint32))[0]
+    assert len(bad) == 0, (len(bad), int(gi[bad[0]]), int(deg[gi[bad[0]]]), gx[bad[0]], wxa[bad[0]])
+    plan_T.close()
