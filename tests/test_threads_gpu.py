@@ -88,7 +88,7 @@ def test_caches_of_a_thread_that_has_exited_are_given_back_by_trim():
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     free1 = torch.cuda.mem_get_info()[0]
-    assert free0 - free1 < (4 << 20), f"device memory not recovered after the trim: {held[0] >> 20} MiB held by the exited thread, {(free0 - free1) >> 20} MiB still missing"
+    assert free0 - free1 < (16 << 20), f"device memory not recovered after the trim: {held[0] >> 20} MiB held by the exited thread, {(free0 - free1) >> 20} MiB still missing"
     # and the library keeps working on both kinds of thread afterwards
     a = _work(12, 2)
     out = []
