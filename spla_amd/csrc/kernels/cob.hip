@@ -539,7 +539,7 @@ namespace {
         const T init = from_bits<T>(init_bits);
         if (!sc.n_tiles) return fail(SPLAHIP_NOT_IMPLEMENTED, "the column-ordered blocks hold no schedule for this slice width");// (cob_serves says so beforehand)
         // the shared accumulators rest at the identity of the op_add that used them last: re-arm them when this call's differs
-        const uint32_t n_multi_max = std::max(std::max(g->sched[0].n_multi, g->sched[1].n_multi), g->n_ranges);
+        const uint32_t n_multi_max = std::max(std::max(g->sched[0].n_multi, g->sched[1].n_multi), g->dyn ? g->n_ranges : 0u);
         if (n_multi_max && (!g->acc_armed || g->acc_identity != cob_identity<T, ACC>())) {
             hipLaunchKernelGGL(cob_fill32_kernel, dim3(256), dim3(256), 0, st, (size_t) n_multi_max * g->acc_stride, g->d_acc, cob_identity<T, ACC>());
             hipLaunchKernelGGL(cob_fill32_kernel, dim3(1), dim3(256), 0, st, (size_t) g->ticket_words, g->d_ticket, 0u);
@@ -1519,7 +1519,7 @@ extern "C" int splahip_csr_plan_attach_cob(splahip_plan plan, uint32_t n_cols, c
         if (e == hipSuccess && !tasks.empty()) e = hipMemcpyAsync(g->d_fin_tasks, tasks.data(), 4 * tasks.size(), hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
     }
-    max_multi = std::max(max_multi, n_ranges);// the run-time schedule: any range may be shared, accumulator q belongs to range q
+    if (g->dyn) max_multi = std::max(max_multi, n_ranges);// the run-time schedule (opt-in): any range may be shared, accumulator q belongs to range q (not sized for it otherwise)
     own(&g->d_acc, (size_t) max_multi * g->acc_stride);
     g->ticket_words = max_multi + 4 + 32;
     own(&g->d_ticket, (size_t) g->ticket_words);

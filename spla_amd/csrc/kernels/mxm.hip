@@ -1085,7 +1085,11 @@ namespace splahip {
             const char* cenv = knob_env("SPLAHIP_MXMT_COUNT");
             const char* oenv = knob_env("SPLAHIP_MXMT_OWNER");
             const bool  b_is_a = Bp == Ap && Bx == Ax, b_is_m = Bp == Mp && Bx == Mx;
-            if (!jit_entry && !row_form && merge_form && merge_counts(op_add, TypeId<T>::value) && (b_is_a || b_is_m) && !(cenv && cenv[0] == '0')) {
+            // (the probe is two passes over the operands' values and a host synchronisation — not for a mask of a few thousand entries, whose merges
+            // cost less than that whatever their form: count mode only changes HOW the equal products are folded, never the result)
+            const char* fenv       = knob_env("SPLAHIP_MXMT_COUNT_FROM");
+            const uint  count_from = fenv && *fenv ? (uint) std::strtoul(fenv, nullptr, 10) : 16384u;
+            if (!jit_entry && !row_form && merge_form && merge_counts(op_add, TypeId<T>::value) && (b_is_a || b_is_m) && !(cenv && cenv[0] == '0') && n_entries >= count_from) {
                 DevBuf rng;
                 SPLAHIP_TRY(rng.alloc(5 * sizeof(uint)));
                 const uint init_rng[5] = {0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u, 0u};
