@@ -391,6 +391,10 @@ int splahip_map_jit(int type, uint32_t n, const void* d_x, void* d_out, const ch
  * returns the count on the host (blocks).  coo_to_dense fills with `fill` then scatters (last write wins).      */
 int splahip_vec_dense_to_coo(int type, uint32_t n, const void* d_dense, uint32_t fill_bits,
                              uint32_t* d_idx, void* d_val, uint32_t* h_count, void* stream);
+/* the same with the entries written only if there are at most `limit` of them (the count is returned either way: the caller of a v_count_mf that hands the vector
+ * to a push step next — reference src/algorithm.cpp:88-99 — gets the sparse form for the price of the count when the frontier is small, the count alone when it is not) */
+int splahip_vec_dense_to_coo_limited(int type, uint32_t n, const void* d_dense, uint32_t fill_bits,
+                                     uint32_t* d_idx, void* d_val, uint32_t limit, uint32_t* h_count, void* stream);
 int splahip_vec_coo_to_dense(uint32_t n, uint32_t nvals, const uint32_t* d_idx, const void* d_val, uint32_t fill_bits,
                              void* d_dense, void* stream);
 

@@ -104,6 +104,7 @@ _SIGNATURES = {
     "splahip_v_eadd_fdb_dense": (C.c_int, [C.c_int, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.c_int, _vp]),
     "splahip_v_eadd_fdb_sparse": (C.c_int, [C.c_int, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _u32p, C.c_int, _vp]),
     "splahip_vec_dense_to_coo": (C.c_int, [C.c_int, C.c_uint32, _vp, C.c_uint32, _vp, _vp, _u32p, _vp]),
+    "splahip_vec_dense_to_coo_limited": (C.c_int, [C.c_int, C.c_uint32, _vp, C.c_uint32, _vp, _vp, C.c_uint32, _u32p, _vp]),
     "splahip_vec_coo_to_dense": (C.c_int, [C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint32, _vp, _vp]),
     "splahip_vxm_probe": (C.c_int, [C.c_uint32, _vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int), _vp]),
     "splahip_vxm_pull": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_int,

@@ -527,6 +527,33 @@ namespace spla {
                 if (v->is_valid(FormatVector::CpuCoo)) return t->r->set_uint(v->coo()->values);
                 if (v->is_valid(FormatVector::AccCoo)) return t->r->set_uint(v->acc_coo()->values);
                 v->validate_rw(FormatVector::AccDense);
+                // count by COMPACTING: the dense -> sparse conversion counts the same entries (`!= fill`) on its way, costs no more kernel time than the counting kernel
+                // (two streaming passes of 4 B per row + 8 B per stored entry) and the same single host round trip — and the traversal loops that ask for this count (bfs:
+                // the next frontier, sssp: the changed entries) then hand the vector to a push step, which would convert it anyway and wait for the count a second time.
+                // SPLA_HIP_COUNT_BY_COMPACTION=0: the counting kernel
+                static const bool by_compaction = [] {
+                    const char* e = std::getenv("SPLA_HIP_COUNT_BY_COMPACTION");
+                    return !(e && e[0] == '0');
+                }();
+                if (by_compaction) {
+                    // ... the entries are written only if at most a quarter of the rows hold one (a push step is chosen for sparser vectors than that; a denser one
+                    // stays dense-only and costs the two counting passes)
+                    v->validate_ctor(FormatVector::AccCoo);
+                    auto&          st  = v->storage();
+                    auto*          out = st.template get<HipCooVec<T>>(static_cast<int>(FormatVector::AccCoo));
+                    const uint32_t n   = v->get_n_rows();
+                    out->Ai.reserve(n);
+                    out->Ax.reserve(n);
+                    uint32_t count = 0;
+                    hip_check(splahip_vec_dense_to_coo_limited(TypeTraits<T>::id, n, v->acc_dense()->Ax.ptr(), word_of(v->get_fill_value()), out->Ai.template as<uint32_t>(),
+                                                               out->Ax.ptr(), n / 4u, &count, nullptr),
+                              "splahip_vec_dense_to_coo_limited");
+                    if (count <= n / 4u) {
+                        out->values = count;
+                        st.valid.set(static_cast<int>(FormatVector::AccCoo));
+                    }
+                    return t->r->set_uint(count);
+                }
                 uint32_t count = 0;
                 hip_check(splahip_v_count_mf_dense(TypeTraits<T>::id, v->get_n_rows(), v->acc_dense()->Ax.ptr(), word_of(v->get_fill_value()), &count, nullptr),
                           "splahip_v_count_mf_dense");

@@ -31,10 +31,23 @@ namespace splahip {
 
     // An environment knob (SPLAHIP_...: A/B switches and tuning values for tests and experiments), read from the process environment ONCE and cached
     // (runtime.hip): a call's dispatch costs a hash lookup, not a scan of the environment.  splahip_env_refresh() drops the cache (tests change knobs mid-process).
-    // A few result words of a call brought to the host: a one-wave kernel writes them into pinned (mapped) memory of the calling host thread, the stream is
-    // synchronised, the words are copied out.  hipMemcpyAsync to a pageable destination costs a staged blit (~15 us per call in the kernel trace of
-    // spla_Algorithm_bfs, two per level); this is one small launch.  n <= 16 words; h_dst any host memory.  Returns a hipError_t.
+    // A few result words of a call brought to the host: a one-wave kernel writes them into pinned (mapped) memory of the calling host thread and the host POLLS
+    // for them (runtime.hip: at most SPLAHIP_MAILBOX_POLL_US, then it synchronises the stream).  hipMemcpyAsync to a pageable destination costs a staged blit (~15 us
+    // per call in the kernel trace of spla_Algorithm_bfs, two per level), and hipStreamSynchronize returns ~10 us after the last kernel; this is one small launch
+    // and a spin on host memory.  n <= 16 words; h_dst any host memory.  Returns a hipError_t.
     hipError_t fetch_words(void* h_dst, const void* d_src, uint32_t n_words, hipStream_t stream);
+    // The mailbox itself, for a kernel that posts its words on its own: slot k = sequence number << 32 | word, ONE 8-byte store per word — the host takes a slot as
+    // valid when it carries the number it waits for, so no fence orders the slots (a system-scope release in the middle of a kernel would first write the L2's dirty
+    // lines back).  mailbox_begin: the calling thread's mailbox and the number to post with; mailbox_end: wait for n words (poll, then synchronise) and copy them out.
+    struct MailboxTicket {
+        unsigned long long* dev = nullptr;// device view of the calling thread's 16 slots
+        uint32_t            seq = 0;
+    };
+    hipError_t mailbox_begin(MailboxTicket* t);
+    hipError_t mailbox_end(void* h_dst, uint32_t n_words, const MailboxTicket& t, hipStream_t stream);
+    __device__ __forceinline__ void mailbox_store(unsigned long long* mailbox, uint32_t slot, uint32_t mail_seq, uint32_t word) {
+        __hip_atomic_store(mailbox + slot, ((unsigned long long) mail_seq << 32) | word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const char* knob_env(const char* name);
     // the calling host thread asked for run-to-run identical fp32 sums (splahip_set_deterministic; the Descriptor's deterministic flag): the forms whose
     // fp32 PLUS merges partial sums in arrival order (column-ordered blocks, the LDS row classes of mxm) stand aside for the fixed-order kernels

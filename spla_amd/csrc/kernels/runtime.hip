@@ -4,6 +4,9 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -59,31 +62,87 @@ namespace splahip {
         return before;
     }
     namespace {
-        __global__ __launch_bounds__(64) void mailbox_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n) {
-            if (threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+        struct PokeWords {
+            uint32_t w[16];
+        };
+        // up to 16 words handed over as kernel ARGUMENTS: no staging copy, no wait — the launch has read them when it returns
+        __global__ __launch_bounds__(64) void poke_kernel(uint32_t* __restrict__ dst, PokeWords p, uint32_t n) {
+            uint32_t x = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 16; ++k) x = threadIdx.x == k ? p.w[k] : x;
+            if (threadIdx.x < n) dst[threadIdx.x] = x;
         }
-        struct Mailbox {// (64 bytes of pinned memory per host thread, kept for the life of the process: a thread_local's destructor may run after the HIP runtime's)
-            uint32_t* host = nullptr;
-            uint32_t* dev  = nullptr;
+        // words [0, n) of src into the host's mailbox slots, each with the call's sequence number (common.hpp: mailbox_store)
+        __global__ __launch_bounds__(64) void mailbox_kernel(const uint32_t* __restrict__ src, unsigned long long* __restrict__ dst, uint32_t n, uint32_t seq) {
+            if (threadIdx.x < n) mailbox_store(dst, threadIdx.x, seq, src[threadIdx.x]);
+        }
+        struct Mailbox {// (128 bytes of pinned memory per host thread, kept for the life of the process: a thread_local's destructor may run after the HIP runtime's)
+            unsigned long long* host = nullptr;
+            unsigned long long* dev  = nullptr;
+            uint32_t            seq  = 0;
         };
     }// namespace
-    hipError_t fetch_words(void* h_dst, const void* d_src, uint32_t n_words, hipStream_t stream) {
-        static thread_local Mailbox box;
-        if (n_words == 0) return hipStreamSynchronize(stream);
-        if (n_words > 16) return hipErrorInvalidValue;
+    // A few words of device memory for a host decision (a frontier's size, a result's entry count): a one-wave kernel copies them into mapped host memory.  The host
+    // does not wait for the STREAM (hipStreamSynchronize returns ~10 us after the last kernel: a barrier packet, its completion signal, the runtime's bookkeeping) but
+    // for the WORDS: it polls the sequence number the kernel writes behind them, for at most SPLAHIP_MAILBOX_POLL_US (default 100; 0 = always synchronise) — the case of a
+    // traversal level's few short kernels — and synchronises the stream if they have not arrived by then (a long product: no point in burning a core).
+    namespace {
+        Mailbox& thread_mailbox() {
+            static thread_local Mailbox box;
+            return box;
+        }
+    }// namespace
+    hipError_t mailbox_begin(MailboxTicket* t) {
+        Mailbox& box = thread_mailbox();
         if (!box.host) {
-            hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&box.host), 16 * sizeof(uint32_t), hipHostMallocMapped);
+            hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&box.host), 16 * sizeof(unsigned long long), hipHostMallocMapped);
             if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&box.dev), box.host, 0);
             if (e != hipSuccess) {
                 box.host = nullptr;
                 return e;
             }
+            for (int k = 0; k < 16; ++k) box.host[k] = 0;
         }
-        hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(64), 0, stream, static_cast<const uint32_t*>(d_src), box.dev, n_words);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e == hipSuccess) std::memcpy(h_dst, box.host, sizeof(uint32_t) * n_words);
-        return e;
+        t->seq = ++box.seq ? box.seq : ++box.seq;
+        t->dev = box.dev;
+        return hipSuccess;
+    }
+    hipError_t mailbox_end(void* h_dst, uint32_t n_words, const MailboxTicket& t, hipStream_t stream) {
+        Mailbox&       box     = thread_mailbox();
+        const char*    pe      = knob_env("SPLAHIP_MAILBOX_POLL_US");
+        const unsigned poll_us = pe ? (unsigned) std::strtoul(pe, nullptr, 10) : 100u;
+        uint32_t*      out     = static_cast<uint32_t*>(h_dst);
+        // slot k is there when it carries this call's number; the slots arrive in any order
+        auto arrived = [&]() {
+            for (uint32_t k = 0; k < n_words; ++k) {
+                const unsigned long long w = __atomic_load_n(box.host + k, __ATOMIC_ACQUIRE);
+                if ((uint32_t) (w >> 32) != t.seq) return false;
+                out[k] = (uint32_t) w;
+            }
+            return true;
+        };
+        if (poll_us) {
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(poll_us);
+            for (;;) {
+                for (int k = 0; k < 64; ++k)
+                    if (arrived()) return hipSuccess;
+                if (std::chrono::steady_clock::now() >= t_end) break;
+            }
+        }
+        const hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        return arrived() ? hipSuccess : hipErrorUnknown;// (not there after the stream has drained: the launch that was to post them did not run)
+    }
+    hipError_t fetch_words(void* h_dst, const void* d_src, uint32_t n_words, hipStream_t stream) {
+        if (n_words == 0) return hipStreamSynchronize(stream);
+        if (n_words > 16) return hipErrorInvalidValue;
+        MailboxTicket t;
+        hipError_t    e = mailbox_begin(&t);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(64), 0, stream, static_cast<const uint32_t*>(d_src), t.dev, n_words, t.seq);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        return mailbox_end(h_dst, n_words, t, stream);
     }
     void knob_cache_clear() {
         std::lock_guard<std::mutex> lock(knob_mutex());
@@ -650,6 +709,16 @@ int splahip_free(void* d_ptr) {
 int splahip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream) {
     if (bytes == 0) return SPLAHIP_OK;
     SPLAHIP_REQUIRE(d_dst && h_src, "null pointer");
+    // a few words (a traversal's source vertex, a scalar): a copy from pageable memory is a staging copy + a stream synchronisation, ~18 us; as kernel arguments ~5 us of
+    // the host and nothing to wait for
+    if (bytes <= sizeof(PokeWords) && bytes % 4 == 0 && reinterpret_cast<uintptr_t>(d_dst) % 4 == 0) {
+        PokeWords p;
+        std::memset(&p, 0, sizeof(p));
+        std::memcpy(&p, h_src, bytes);
+        hipLaunchKernelGGL(poke_kernel, dim3(1), dim3(64), 0, as_stream(stream), static_cast<uint32_t*>(d_dst), p, (uint32_t) (bytes / 4));
+        SPLAHIP_TRY(hipGetLastError());
+        return SPLAHIP_OK;
+    }
     SPLAHIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
     // pageable host memory may be reused by the caller right after return
     SPLAHIP_TRY(hipStreamSynchronize(as_stream(stream)));

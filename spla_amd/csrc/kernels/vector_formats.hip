@@ -29,8 +29,9 @@ namespace splahip {
 
     template<typename T>
     __global__ __launch_bounds__(256) void d2c_write_kernel(const T* __restrict__ dense, uint n, T fill, const uint* __restrict__ chunk,
-                                                            uint* __restrict__ out_i, T* __restrict__ out_x) {
+                                                            uint* __restrict__ out_i, T* __restrict__ out_x, uint limit) {
         __shared__ uint s_tmp[256 / kWave + 1];
+        if (chunk[gridDim.x] > limit) return;// (the caller wants the entries only if they are few: it reads the same count and knows)
         const uint      first = blockIdx.x * 1024u + threadIdx.x * 4u;
         T               x[4];
         bool            keep[4];
@@ -61,16 +62,16 @@ namespace splahip {
     }
 
     template<typename T>
-    int dense_to_coo(uint n, const void* d_dense, uint32_t fill_bits, void* d_idx, void* d_val, uint32_t* h_count, hipStream_t s) {
+    int dense_to_coo(uint n, const void* d_dense, uint32_t fill_bits, void* d_idx, void* d_val, uint32_t* h_count, hipStream_t s, uint limit = 0xFFFFFFFFu) {
         const uint n_chunks = (n + 1023u) / 1024u;
+        const T    fill = from_bits<T>(fill_bits);
         DevMem     mem;
         SPLAHIP_TRY(mem.alloc(s, sizeof(uint) * (size_t) (n_chunks + 1)));
         uint*      d_chunk = mem.as<uint>();
-        const T    fill = from_bits<T>(fill_bits);
         hipLaunchKernelGGL(d2c_count_kernel<T>, dim3(n_chunks), dim3(256), 0, s, static_cast<const T*>(d_dense), n, fill, d_chunk);
         hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, d_chunk, n_chunks);
         hipLaunchKernelGGL(d2c_write_kernel<T>, dim3(n_chunks), dim3(256), 0, s, static_cast<const T*>(d_dense), n, fill, d_chunk,
-                           static_cast<uint*>(d_idx), static_cast<T*>(d_val));
+                           static_cast<uint*>(d_idx), static_cast<T*>(d_val), limit);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = fetch_words(h_count, d_chunk + n_chunks, 1, s);
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "dense_to_coo failed: %s", hipGetErrorString(e));
@@ -83,8 +84,8 @@ using namespace splahip;
 
 extern "C" {
 
-int splahip_vec_dense_to_coo(int type, uint32_t n, const void* d_dense, uint32_t fill_bits,
-                             uint32_t* d_idx, void* d_val, uint32_t* h_count, void* stream) {
+int splahip_vec_dense_to_coo_limited(int type, uint32_t n, const void* d_dense, uint32_t fill_bits,
+                                     uint32_t* d_idx, void* d_val, uint32_t limit, uint32_t* h_count, void* stream) {
     SPLAHIP_REQUIRE(h_count != nullptr, "h_count is null");
     *h_count = 0;
     if (n == 0) return SPLAHIP_OK;
@@ -92,11 +93,16 @@ int splahip_vec_dense_to_coo(int type, uint32_t n, const void* d_dense, uint32_t
     int st = ensure_device();
     if (st != SPLAHIP_OK) return st;
     switch (type) {
-        case SPLAHIP_INT: return dense_to_coo<int32_t>(n, d_dense, fill_bits, d_idx, d_val, h_count, as_stream(stream));
-        case SPLAHIP_UINT: return dense_to_coo<uint32_t>(n, d_dense, fill_bits, d_idx, d_val, h_count, as_stream(stream));
-        case SPLAHIP_FLOAT: return dense_to_coo<float>(n, d_dense, fill_bits, d_idx, d_val, h_count, as_stream(stream));
+        case SPLAHIP_INT: return dense_to_coo<int32_t>(n, d_dense, fill_bits, d_idx, d_val, h_count, as_stream(stream), limit);
+        case SPLAHIP_UINT: return dense_to_coo<uint32_t>(n, d_dense, fill_bits, d_idx, d_val, h_count, as_stream(stream), limit);
+        case SPLAHIP_FLOAT: return dense_to_coo<float>(n, d_dense, fill_bits, d_idx, d_val, h_count, as_stream(stream), limit);
     }
     return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
+}
+
+int splahip_vec_dense_to_coo(int type, uint32_t n, const void* d_dense, uint32_t fill_bits,
+                             uint32_t* d_idx, void* d_val, uint32_t* h_count, void* stream) {
+    return splahip_vec_dense_to_coo_limited(type, n, d_dense, fill_bits, d_idx, d_val, 0xFFFFFFFFu, h_count, stream);
 }
 
 int splahip_vec_coo_to_dense(uint32_t n, uint32_t nvals, const uint32_t* d_idx, const void* d_val, uint32_t fill_bits,

@@ -304,3 +304,47 @@ def test_hip_eadd_reduce_edge_sizes(oracle):
                   binop_id("MINUS"), current_stream_ptr())
         wi, wx = oracle.v_eadd(t, ux, vx, "MINUS", u_idx=ui, v_idx=vi, u_fill=2, v_fill=3)
         assert cnt.value == len(wi) and np.array_equal(host(ri, np.uint32)[:cnt.value], wi) and np.array_equal(host(rx, np.int32)[:cnt.value], wx)
+
+
+@pytest.mark.gpu
+def test_host_round_trips_of_the_traversal_loops(oracle, monkeypatch):
+    """What a traversal level asks the host for, and how: (a) splahip_vec_dense_to_coo_limited returns the count always and the entries only when there are at most
+    `limit` (v_count_mf goes through it: reference src/cpu/cpu_v_count_mf.hpp:99-108 counts `!= fill`, the same entries the conversion keeps); (b) uploads of
+    <= 16 words travel as kernel arguments and larger ones by copy — same bytes either way; (c) the few words of a host decision arrive the same whether the host
+    polls for them or synchronises the stream (SPLAHIP_MAILBOX_POLL_US)."""
+    import ctypes as C
+    import torch
+    from gpu_utils import dev, host
+    from spla_amd import _lib
+    from spla_amd.kernels import _ptr, current_stream_ptr
+    from spla_amd.ops import scalar_bits, type_id
+    rng = np.random.default_rng(77)
+    for poll in ("100", "0"):
+        monkeypatch.setenv("SPLAHIP_MAILBOX_POLL_US", poll)
+        for t in ("INT", "FLOAT"):
+            tid = type_id(t)
+            for n in (1, 5, 1023, 1024, 1025, 70001, 300007):
+                x = vals(rng, n, t, 0, 3)
+                if n > 100000:                                   # long stretches without a stored entry, and without a gap
+                    x[n // 3: n // 2] = 2
+                    x[n // 2: n // 2 + 70000] = 1
+                keep = np.flatnonzero(x != NP[t](2)).astype(np.uint32)
+                dx = dev(x)
+                for limit in (0, len(keep) - 1 if len(keep) else 0, len(keep), n):
+                    di = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+                    dv = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+                    cnt = C.c_uint32()
+                    _lib.call("splahip_vec_dense_to_coo_limited", tid, n, _ptr(dx), scalar_bits(2, tid), _ptr(di), _ptr(dv), limit, C.byref(cnt), current_stream_ptr())
+                    assert cnt.value == len(keep) == oracle.v_count_mf(t, x, 2), (t, n, limit)
+                    if len(keep) <= limit:
+                        assert np.array_equal(host(di, np.uint32)[:len(keep)], keep) and np.array_equal(host(dv, NP[t])[:len(keep)], x[keep]), (t, n, limit)
+                    else:
+                        assert bool((di == -1).all()) and bool((dv == -1).all()), (t, n, limit)
+    for words in (1, 2, 3, 15, 16, 17, 64):
+        src = rng.integers(0, 2**32, size=words, dtype=np.uint64).astype(np.uint32)
+        dst = torch.zeros(words + 2, dtype=torch.int32, device="cuda")
+        _lib.call("splahip_memcpy_h2d", dst.data_ptr() + 4, src.ctypes.data_as(C.c_void_p), 4 * words, current_stream_ptr())
+        src_copy = src.copy()
+        src[:] = 0                                      # the caller's memory is its own again on return
+        got = host(dst, np.uint32)
+        assert got[0] == 0 and got[-1] == 0 and np.array_equal(got[1:-1], src_copy), words
