@@ -250,16 +250,25 @@ namespace {
         // launch failed makes cob_mask_probe answer "the blocks", so this path never runs behind a probe that did not)
         // (workgroups: every flush of a workgroup's list is a same-address atomic — 256 / 512 / 1024 / 2048 / 4096 workgroups at R-MAT 23, 10 % of the light rows: 103 / 87 /
         // 86 / 99 / 113 us per call)
-        hipLaunchKernelGGL((rows_compact_kernel<T>), dim3(knob_u32("SPLAHIP_ROWS_COMPACT_BLOCKS", 1024)), dim3(256), 0, st, n, Ap, static_cast<const T*>(mask), op_select, init,
-                           static_cast<T*>(r), plan->d_rows_list, plan->d_rows_ctl, gate);
-        if (plan->n_items && plan->n_long > 0)// the selected long rows' segment items (a plan without long rows lists none)
-            hipLaunchKernelGGL((rows_long_select_kernel<T>), dim3((plan->n_long + 255) / 256), dim3(256), 0, st, plan->n_long, plan->d_long_rows, plan->d_long_first, Ap,
-                               static_cast<const T*>(mask), op_select, Cfg::kSeg, plan->d_long_items, plan->d_rows_ctl + 1, gate);
-        hipLaunchKernelGGL((rows_short_kernel<T, Mult, Add>), dim3(knob_u32("SPLAHIP_ROWS_SHORT_BLOCKS", 4096)), dim3(256), 0, st, plan->d_rows_list, plan->d_rows_ctl, Ap, Aj,
+        const uint32_t compact_blocks = knob_u32("SPLAHIP_ROWS_COMPACT_BLOCKS", 1024), short_blocks = knob_u32("SPLAHIP_ROWS_SHORT_BLOCKS", 4096),
+                       task_blocks = knob_u32("SPLAHIP_ROWS_LONG_BLOCKS", 4096);
+        const bool     has_long = plan->n_items && plan->n_long > 0;// the selected long rows' segment items (a plan without long rows lists none)
+        if (knob_u32("SPLAHIP_ROWS_FUSED", 1)) {// the two mask passes share a launch (mxv_rows.hpp)
+            const uint32_t select_blocks = has_long ? (plan->n_long + 255) / 256 : 0u;
+            hipLaunchKernelGGL((rows_select_kernel<T>), dim3(select_blocks + compact_blocks), dim3(256), 0, st, select_blocks, n, Ap, static_cast<const T*>(mask), op_select, init,
+                               static_cast<T*>(r), plan->d_rows_list, plan->d_rows_ctl, plan->n_long, plan->d_long_rows, plan->d_long_first, Cfg::kSeg, plan->d_long_items, gate);
+        } else {
+            hipLaunchKernelGGL((rows_compact_kernel<T>), dim3(compact_blocks), dim3(256), 0, st, n, Ap, static_cast<const T*>(mask), op_select, init, static_cast<T*>(r),
+                               plan->d_rows_list, plan->d_rows_ctl, gate);
+            if (has_long)
+                hipLaunchKernelGGL((rows_long_select_kernel<T>), dim3((plan->n_long + 255) / 256), dim3(256), 0, st, plan->n_long, plan->d_long_rows, plan->d_long_first, Ap,
+                                   static_cast<const T*>(mask), op_select, Cfg::kSeg, plan->d_long_items, plan->d_rows_ctl + 1, gate);
+        }
+        hipLaunchKernelGGL((rows_short_kernel<T, Mult, Add>), dim3(short_blocks), dim3(256), 0, st, plan->d_rows_list, plan->d_rows_ctl, Ap, Aj,
                            static_cast<const uint32_t*>(Ax), static_cast<const T*>(v), static_cast<T*>(r), Mult(op_mult), Add(op_add), init, plan->nnz, gate);
-        hipLaunchKernelGGL((rows_task_kernel<T, Mult, Add>), dim3(knob_u32("SPLAHIP_ROWS_LONG_BLOCKS", 4096)), dim3(256), 0, st, plan->d_long_items, plan->d_rows_ctl,
-                           plan->d_rows_list, n, plan->d_item_row, plan->d_item_k0, Ap, Aj, static_cast<const uint32_t*>(Ax), static_cast<const T*>(v), static_cast<T*>(r),
-                           reinterpret_cast<T*>(plan->d_partial), Mult(op_mult), Add(op_add), init, Cfg::kSegFlag, Cfg::kSeg, plan->nnz, gate);
+        hipLaunchKernelGGL((rows_task_kernel<T, Mult, Add>), dim3(task_blocks), dim3(256), 0, st, plan->d_long_items, plan->d_rows_ctl, plan->d_rows_list, n, plan->d_item_row,
+                           plan->d_item_k0, Ap, Aj, static_cast<const uint32_t*>(Ax), static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(plan->d_partial),
+                           Mult(op_mult), Add(op_add), init, Cfg::kSegFlag, Cfg::kSeg, plan->nnz, gate);
         SPLAHIP_TRY(hipGetLastError());
         if (plan->n_items && plan->n_long > 0) {
             hipLaunchKernelGGL((spmv_combine_kernel<Cfg, T, Add, false>), dim3((plan->n_items + 255) / 256), dim3(256), 0, st, plan->d_item_row, plan->d_item_k0, plan->n_items, Ap,

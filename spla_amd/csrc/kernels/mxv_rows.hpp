@@ -36,7 +36,7 @@ namespace splahip {
     // buffer per workgroup, one global atomic per flush); list[n_rows - 1 - i], i < count[3] = the selected MEDIUM rows (kRowsLaneMax + 1 .. kRowsShortMax entries:
     // a wavefront each, rows_task_kernel), one atomic per wave.  Longer rows are the plan's business (rows_long_select_kernel).
     template<typename T>
-    __global__ __launch_bounds__(256) void rows_compact_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, T init,
+    __device__ __forceinline__ void rows_compact_body(const uint32_t vb, const uint32_t vg, uint32_t n_rows, const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, T init,
                                                                T* __restrict__ r, uint32_t* __restrict__ list, uint32_t* __restrict__ count, const uint32_t* __restrict__ gate) {
         if (gate[3] == 0u) return;
         constexpr uint32_t kBuf = 4096;
@@ -46,8 +46,8 @@ namespace splahip {
         __shared__ uint32_t s_n, s_base, s_nm, s_basem;
         if (threadIdx.x == 0) s_n = 0, s_nm = 0;
         __syncthreads();
-        const uint32_t per = ((n_rows + gridDim.x - 1) / gridDim.x + 2047u) & ~2047u;// a contiguous share of the rows per workgroup, whole steps of 2048 rows
-        const uint32_t b0 = blockIdx.x * per, b1 = min(n_rows, b0 + per);
+        const uint32_t per = ((n_rows + vg - 1) / vg + 2047u) & ~2047u;// a contiguous share of the rows per workgroup, whole steps of 2048 rows
+        const uint32_t b0 = vb * per, b1 = min(n_rows, b0 + per);
         const uint4    iv = make_uint4(to_bits(init), to_bits(init), to_bits(init), to_bits(init));
         for (uint32_t base = b0; base < b1; base += 2048) {
             const uint32_t row0 = base + threadIdx.x * 8;
@@ -137,7 +137,7 @@ namespace splahip {
     // reference's own order (cpu_mxv.hpp:94-99): bit-exact for every op_add, fp32 sums included.  Three round trips per ~1000 entries instead of two per row.
     constexpr uint32_t kRowsStage = 1024;// entries of a wave's product stage (256 quads: 4 per lane)
     template<typename T, class Mult, class Add>
-    __global__ __launch_bounds__(256) void rows_short_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, const uint32_t* __restrict__ Ap,
+    __device__ __forceinline__ void rows_short_body(const uint32_t vb, const uint32_t vg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, const uint32_t* __restrict__ Ap,
                                                              const uint32_t* __restrict__ Aj, const uint32_t* __restrict__ Ax, const T* __restrict__ v, T* __restrict__ r, Mult mult,
                                                              Add add, T init, uint32_t nnz, const uint32_t* __restrict__ gate) {
         if (gate[3] == 0u) return;
@@ -149,7 +149,7 @@ namespace splahip {
         T* const        s_prod = s_prod_all[wv];
         uint32_t* const s_q    = s_q_all[wv];
         uint32_t* const s_a    = s_a_all[wv];
-        const uint32_t  wave = blockIdx.x * (256 / kWave) + wv, n_waves = gridDim.x * (256 / kWave);
+        const uint32_t  wave = vb * (256 / kWave) + wv, n_waves = vg * (256 / kWave);
         for (uint32_t i0 = wave * kWave; i0 < n; i0 += n_waves * kWave) {
             uint32_t my_row = 0, k0 = 0, k1 = 0;
             if (i0 + lane < n) {
@@ -252,11 +252,11 @@ namespace splahip {
 
     // per call: the segment items of the SELECTED long rows -> long_items[0 .. *n_listed)
     template<typename T>
-    __global__ __launch_bounds__(256) void rows_long_select_kernel(uint32_t n_long, const uint32_t* __restrict__ long_row, const uint32_t* __restrict__ long_first,
+    __device__ __forceinline__ void rows_long_select_body(const uint32_t vb, const uint32_t vg, uint32_t n_long, const uint32_t* __restrict__ long_row, const uint32_t* __restrict__ long_first,
                                                                    const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, uint32_t seg_len,
                                                                    uint32_t* __restrict__ long_items, uint32_t* __restrict__ n_listed, const uint32_t* __restrict__ gate) {
         if (gate[3] == 0u) return;
-        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        const uint32_t i = vb * 256 + threadIdx.x;
         if (i >= n_long) return;
         const uint32_t row = long_row[i];
         if (!eval_sel<T>(op_select, mask[row])) return;
@@ -270,7 +270,7 @@ namespace splahip {
     // at once (4 quads per lane, then their 16 gathers); a lane folds its quads in entry order, the lanes are joined in order (op_add is associative and commutative
     // on this path); a segment's partial goes to the combine kernel, a medium row or a row of one segment is finished here (r = add(init, fold)).
     template<typename T, class Mult, class Add>
-    __global__ __launch_bounds__(256) void rows_task_kernel(const uint32_t* __restrict__ long_items, const uint32_t* __restrict__ ctl, const uint32_t* __restrict__ list, uint32_t n_rows,
+    __device__ __forceinline__ void rows_task_body(const uint32_t vb, const uint32_t vg, const uint32_t* __restrict__ long_items, const uint32_t* __restrict__ ctl, const uint32_t* __restrict__ list, uint32_t n_rows,
                                                             const uint32_t* __restrict__ item_row,
                                                             const uint32_t* __restrict__ item_k0, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ Aj,
                                                             const uint32_t* __restrict__ Ax, const T* __restrict__ v, T* __restrict__ r, T* __restrict__ partial, Mult mult,
@@ -279,7 +279,7 @@ namespace splahip {
         const Reassoc<Add> add(add_raw);
         const uint32_t     n_items = ctl[1], n = n_items + ctl[3];
         const uint32_t     lane = lane_id();
-        for (uint32_t w = blockIdx.x * (256 / kWave) + threadIdx.x / kWave; w < n; w += gridDim.x * (256 / kWave)) {
+        for (uint32_t w = vb * (256 / kWave) + threadIdx.x / kWave; w < n; w += vg * (256 / kWave)) {
             const bool medium = w >= n_items;
             uint32_t   item = 0, row, k0, k1;
             if (medium) {
@@ -324,6 +324,47 @@ namespace splahip {
                     partial[item] = part;
             }
         }
+    }
+
+    // ---- the launches of a call (mxv.hip: launch_rows).  The two passes that read the mask and do not depend on one another share a launch — the first workgroups
+    // list the segment items of the selected long rows, the others compact the selected short / medium rows (+ r = init): 41.5 us against 36 + 11 (R-MAT 23, a random
+    // 10 % of the rows).  Measured and NOT done: the short rows' batches and the wave tasks in one launch (even / odd workgroups): 143.6 us against 42 + 83 — both are
+    // bound by the same line requests, and each kind of workgroup then carries the other's registers and LDS ("50 %, no hub row", where there are no tasks: 234 against
+    // 170 us) — tools/gpu_r6_rows3.sh.
+    template<typename T>
+    __global__ __launch_bounds__(256) void rows_select_kernel(uint32_t select_blocks, uint32_t n_rows, const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, T init,
+                                                              T* __restrict__ r, uint32_t* __restrict__ list, uint32_t* __restrict__ ctl, uint32_t n_long,
+                                                              const uint32_t* __restrict__ long_row, const uint32_t* __restrict__ long_first, uint32_t seg_len,
+                                                              uint32_t* __restrict__ long_items, const uint32_t* __restrict__ gate) {
+        if (blockIdx.x < select_blocks) rows_long_select_body<T>(blockIdx.x, select_blocks, n_long, long_row, long_first, Ap, mask, op_select, seg_len, long_items, ctl + 1, gate);
+        else
+            rows_compact_body<T>(blockIdx.x - select_blocks, gridDim.x - select_blocks, n_rows, Ap, mask, op_select, init, r, list, ctl, gate);
+    }
+    // (the passes as launches of their own; compaction and selection apart: SPLAHIP_ROWS_FUSED=0, A/B runs)
+    template<typename T>
+    __global__ __launch_bounds__(256) void rows_compact_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, T init, T* __restrict__ r,
+                                                               uint32_t* __restrict__ list, uint32_t* __restrict__ count, const uint32_t* __restrict__ gate) {
+        rows_compact_body<T>(blockIdx.x, gridDim.x, n_rows, Ap, mask, op_select, init, r, list, count, gate);
+    }
+    template<typename T>
+    __global__ __launch_bounds__(256) void rows_long_select_kernel(uint32_t n_long, const uint32_t* __restrict__ long_row, const uint32_t* __restrict__ long_first,
+                                                                   const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, uint32_t seg_len,
+                                                                   uint32_t* __restrict__ long_items, uint32_t* __restrict__ n_listed, const uint32_t* __restrict__ gate) {
+        rows_long_select_body<T>(blockIdx.x, gridDim.x, n_long, long_row, long_first, Ap, mask, op_select, seg_len, long_items, n_listed, gate);
+    }
+    template<typename T, class Mult, class Add>
+    __global__ __launch_bounds__(256) void rows_short_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, const uint32_t* __restrict__ Ap,
+                                                             const uint32_t* __restrict__ Aj, const uint32_t* __restrict__ Ax, const T* __restrict__ v, T* __restrict__ r, Mult mult,
+                                                             Add add, T init, uint32_t nnz, const uint32_t* __restrict__ gate) {
+        rows_short_body<T, Mult, Add>(blockIdx.x, gridDim.x, list, count, Ap, Aj, Ax, v, r, mult, add, init, nnz, gate);
+    }
+    template<typename T, class Mult, class Add>
+    __global__ __launch_bounds__(256) void rows_task_kernel(const uint32_t* __restrict__ long_items, const uint32_t* __restrict__ ctl, const uint32_t* __restrict__ list, uint32_t n_rows,
+                                                            const uint32_t* __restrict__ item_row, const uint32_t* __restrict__ item_k0, const uint32_t* __restrict__ Ap,
+                                                            const uint32_t* __restrict__ Aj, const uint32_t* __restrict__ Ax, const T* __restrict__ v, T* __restrict__ r,
+                                                            T* __restrict__ partial, Mult mult, Add add, T init, uint32_t seg_flag, uint32_t seg_len, uint32_t nnz,
+                                                            const uint32_t* __restrict__ gate) {
+        rows_task_body<T, Mult, Add>(blockIdx.x, gridDim.x, long_items, ctl, list, n_rows, item_row, item_k0, Ap, Aj, Ax, v, r, partial, mult, add, init, seg_flag, seg_len, nnz, gate);
     }
 
 }// namespace splahip
