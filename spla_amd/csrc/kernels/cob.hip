@@ -20,6 +20,7 @@
 //                         and tickets of the ranges cut into several pieces
 #include "block_utils.hpp"
 #include "common.hpp"
+#include "mask_probe.hpp"
 #include "mxv_cob.hpp"
 #include "mxv_cob_dyn.hpp"
 #include "ops.hpp"
@@ -380,75 +381,10 @@ namespace {
     // set by cob_mxv_accumulate around its call (per host thread): the launch below then folds onto the values r already holds
     thread_local uint32_t tl_accumulate = 0;
 
-    // The mask probe of a masked call (op_select other than ALWAYS): how many ENTRIES does the selection cover?  A 1-in-`stride` sample of the rows (2048-row
-    // groups, every row of a group: coalesced loads of mask and Ap), scaled — a few MB, ~4 us at R-MAT 23; visiting every hub row instead cost 65 us of scattered
-    // 4-byte gathers (profiles/r04_notes.md 3).  The last workgroup to finish compares what the selected-rows kernels would cost — every selected row is
-    // ~20 line requests of its own: ~rows_x10 / 10 blocks-entries per selected entry, plus their passes over mask / Ap / r — with the blocks' stream of the whole
-    // matrix, and leaves the estimate and the verdict (1: the row kernels) in pinned HOST memory.  Both sides compute the reference's result for any mask, so the
-    // verdict is only a hint: the host reads the latest one that has arrived before it enqueues its NEXT masked call over the plan (no synchronisation, no gated
-    // launches: enqueueing both sides behind a device-side decision cost a dense masked call 4 - 5 us per launch that returned at once, 45 us in all).
+    // the mask probe as a launch of its own (mask_probe.hpp; a call served by the blocks)
     template<typename T>
-    __global__ __launch_bounds__(256) void cob_mask_probe_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, uint32_t stride,
-                                                                 uint32_t rows_x10, uint32_t nnz, uint32_t* __restrict__ probe, volatile uint32_t* __restrict__ host_words,
-                                                                 uint32_t seq, const uint32_t* __restrict__ hub_row, uint32_t heavy_slots, uint32_t heavy_deg, uint32_t long_x10,
-                                                                 uint32_t* __restrict__ rows_ctl) {
-        __shared__ unsigned long long s_sum[2][256 / kWave];
-        unsigned long long sel_entries = 0, sel_cost = 0;// entries of the selected rows; what they cost the row kernels, in tenths of a blocks-entry
-        const uint32_t n_groups = (n_rows + stride * 2048u - 1) / (stride * 2048u);
-        for (uint32_t gi = blockIdx.x; gi < n_groups; gi += gridDim.x) {
-            // (which of the stride's groups is sampled varies pseudo-randomly: a generator's labels put its hubs at regular strides)
-            const uint32_t row0 = (gi * stride + ((gi * 2654435761u) >> 9) % stride) * 2048u + threadIdx.x * 8u;
-            if (row0 < n_rows) {// (every load issued before the first use; a row behind the matrix's end re-reads the last one)
-                T        mk[8];
-                uint32_t ap[9];
-#pragma unroll
-                for (uint32_t j = 0; j < 8; ++j) mk[j] = mask[min(row0 + j, n_rows - 1)];
-#pragma unroll
-                for (uint32_t j = 0; j < 9; ++j) ap[j] = Ap[min(row0 + j, n_rows)];
-#pragma unroll
-                for (uint32_t j = 0; j < 8; ++j)
-                    if (row0 + j < n_rows && ap[j + 1] - ap[j] < heavy_deg && eval_sel<T>(op_select, mk[j])) {
-                        sel_entries += (unsigned long long) (ap[j + 1] - ap[j]) * stride;
-                        sel_cost += (unsigned long long) (ap[j + 1] - ap[j]) * stride * rows_x10;
-                    }
-            }
-        }
-        // the heaviest rows are no matter for a sample (a generator's first rows hold a quarter of a scale-free matrix: one sampled group of them would say anything):
-        // the first two hub ranges' rows — the heavy_slots rows of degree >= heavy_deg — are visited one by one
-        for (uint32_t s0 = blockIdx.x * 256 + threadIdx.x; s0 < heavy_slots; s0 += gridDim.x * 256) {
-            const uint32_t row = hub_row[s0];
-            if (row != 0xFFFFFFFFu) {
-                const uint32_t d = Ap[row + 1] - Ap[row];
-                if (d >= heavy_deg && eval_sel<T>(op_select, mask[row])) sel_entries += d, sel_cost += (unsigned long long) d * long_x10;
-            }
-        }
-        for (unsigned off = kWave / 2; off > 0; off >>= 1) sel_entries += __shfl_xor(sel_entries, off, kWave), sel_cost += __shfl_xor(sel_cost, off, kWave);
-        if (lane_id() == 0) s_sum[0][threadIdx.x / kWave] = sel_entries, s_sum[1][threadIdx.x / kWave] = sel_cost;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long tot = 0, cost = 0;
-            for (uint32_t w = 0; w < 256 / kWave; ++w) tot += s_sum[0][w], cost += s_sum[1][w];
-            if (tot) {
-                atomicAdd(reinterpret_cast<unsigned long long*>(probe), tot);
-                atomicAdd(reinterpret_cast<unsigned long long*>(probe + 4), cost);
-            }
-            __threadfence();
-            if (atomicAdd(&probe[2], 1u) == gridDim.x - 1) {// the last workgroup: every other one's sum is behind its fence
-                __threadfence();
-                const unsigned long long sel_nnz = __hip_atomic_load(reinterpret_cast<unsigned long long*>(probe), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // what the HOST reads before its next masked call over this plan (pinned memory, no synchronisation: a hint that lags by a call)
-                host_words[0] = (uint32_t) sel_nnz, host_words[1] = (uint32_t) (sel_nnz >> 32);
-                const unsigned long long sel_cost_all = __hip_atomic_load(reinterpret_cast<unsigned long long*>(probe + 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                host_words[2] = sel_cost_all / 10ull + nnz / 6ull < nnz ? 1u : 0u;
-                __threadfence_system();
-                host_words[3] = seq;
-                // the accumulators return to zero for the next probe (nobody else touches them in this launch)
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(probe), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&probe[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(probe + 4), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (rows_ctl != nullptr) rows_ctl[0] = 0u, rows_ctl[1] = 0u, rows_ctl[3] = 0u;// the row kernels' list lengths (mxv_rows.hpp) start every call at zero: no memset to enqueue
-            }
-        }
+    __global__ __launch_bounds__(256) void cob_mask_probe_kernel(MaskProbeArgs a, const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select) {
+        mask_probe_body<T>(blockIdx.x, gridDim.x, a, Ap, mask, op_select);
     }
 
     static thread_local uint32_t tl_skip_bits = 0;// the v value whose entries the sparse-vector form skips in the running call (0; init for min-plus)
@@ -752,36 +688,37 @@ namespace splahip {
         return fail(SPLAHIP_INVALID_ARGUMENT, "unknown element type");
     }
 
-    int cob_mask_probe(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, int op_select, void* stream) {
+    // A masked call over a plan that holds the blocks: which side serves it (1: the selected-rows kernels) — the verdict of the latest probe that has FINISHED, of an
+    // earlier call: the masks of consecutive calls usually select alike — and the probe of THIS call's mask (out->blocks == 0: none).  The side that serves the call
+    // launches it: cob_mask_probe_launch in front of the blocks, or the first workgroups of the row kernels' first launch (mxv.hip: launch_rows).
+    int cob_mask_probe_prepare(const splahip_plan_s* plan, int op_select, MaskProbeArgs* out) {
+        *out                   = MaskProbeArgs();
         const splahip_cob_s* g = plan ? plan->cob : nullptr;
         if (!g || !g->d_probe || !g->h_probe || op_select == SPLAHIP_ALWAYS || env_u32("SPLAHIP_MASK_PROBE", 1) == 0) return 0;
-        // the verdict of the latest probe that has finished (of an earlier call: the masks of consecutive calls usually select alike)
-        const int      rows     = g->h_probe[3] != 0u && g->h_probe[2] != 0u ? 1 : 0;
-        hipStream_t    st       = as_stream(stream);
-        const uint32_t stride   = std::max(1u, std::min(64u, g->n_rows >> 16));// a 1-in-64 sample once there are millions of rows; every row of a small matrix
+        const int      rows   = g->h_probe[3] != 0u && g->h_probe[2] != 0u ? 1 : 0;
+        const uint32_t stride = std::max(1u, std::min(64u, g->n_rows >> 16));// a 1-in-64 sample once there are millions of rows; every row of a small matrix
         // a selected entry costs the row kernels ~4.2 x what an entry costs the blocks, whatever its row's length (round 6, R-MAT 23: 9.5 us per million selected
-        // entries — the chip's ceiling of ~110 G four-byte gathers a second — on top of ~70 us of passes over mask / Ap / r, against 2.25 ns per stored entry on the
+        // entries — the chip's ceiling of ~110 G four-byte gathers a second — on top of ~60 us of passes over mask / Ap / r, against 2.25 ns per stored entry on the
         // blocks: the row kernels win below ~18 % of the entries.  Until round 6 a medium row was one lane's and the heaviest rows went through the wave-tile kernel:
-        // 9 x and 30 x, and a random 10 % of all rows stayed on the blocks at 1.09 x the all-rows call; now 0.69 x)
-        const uint32_t rows_x10 = env_u32("SPLAHIP_MASK_ROWS_X10", 45), long_x10 = env_u32("SPLAHIP_MASK_LONG_X10", 45);
-        const uint32_t groups   = (g->n_rows + stride * 2048u - 1) / (stride * 2048u);
-        g->probe_seq            = g->probe_seq + 1 ? g->probe_seq + 1 : 1;
-#define SPLAHIP_PROBE(T)                                                                                                                                          \
-    hipLaunchKernelGGL((cob_mask_probe_kernel<T>), dim3(std::min(groups, 1024u)), dim3(256), 0, st, g->n_rows, Ap, static_cast<const T*>(mask), op_select, stride, \
-                       rows_x10, plan->nnz, g->d_probe, g->d_h_probe, g->probe_seq, g->d_hub_row, stride > 1 ? g->heavy_slots : 0u, stride > 1 ? g->heavy_deg : 0xFFFFFFFFu, \
-                       long_x10, plan->d_rows_ctl)
-        switch (type) {
-            case SPLAHIP_INT: SPLAHIP_PROBE(int32_t); break;
-            case SPLAHIP_UINT: SPLAHIP_PROBE(uint32_t); break;
-            default: SPLAHIP_PROBE(float); break;
-        }
-#undef SPLAHIP_PROBE
-        if (hipGetLastError() != hipSuccess) {// the probe did not launch: its last workgroup will not zero the row kernels' list lengths — this call stays on the blocks
-            g->last_rows = 0;
-            return 0;
-        }
+        // 9 x and 30 x, and a random 10 % of all rows stayed on the blocks at 1.09 x the all-rows call; now 0.6 x)
+        const uint32_t groups = (g->n_rows + stride * 2048u - 1) / (stride * 2048u);
+        g->probe_seq          = g->probe_seq + 1 ? g->probe_seq + 1 : 1;
+        out->blocks           = std::min(groups, 1024u);
+        out->n_rows = g->n_rows, out->stride = stride, out->rows_x10 = env_u32("SPLAHIP_MASK_ROWS_X10", 45), out->long_x10 = env_u32("SPLAHIP_MASK_LONG_X10", 45);
+        out->nnz = plan->nnz, out->seq = g->probe_seq, out->probe = g->d_probe, out->host_words = g->d_h_probe, out->hub_row = g->d_hub_row;
+        out->heavy_slots = stride > 1 ? g->heavy_slots : 0u, out->heavy_deg = stride > 1 ? g->heavy_deg : 0xFFFFFFFFu;
         g->last_rows = rows;
         return rows;
+    }
+    void cob_mask_probe_launch(const MaskProbeArgs& a, int type, const uint32_t* Ap, const void* mask, int op_select, void* stream) {
+        if (a.blocks == 0) return;
+        hipStream_t st = as_stream(stream);
+        switch (type) {
+            case SPLAHIP_INT: hipLaunchKernelGGL((cob_mask_probe_kernel<int32_t>), dim3(a.blocks), dim3(256), 0, st, a, Ap, static_cast<const int32_t*>(mask), op_select); break;
+            case SPLAHIP_UINT: hipLaunchKernelGGL((cob_mask_probe_kernel<uint32_t>), dim3(a.blocks), dim3(256), 0, st, a, Ap, static_cast<const uint32_t*>(mask), op_select); break;
+            default: hipLaunchKernelGGL((cob_mask_probe_kernel<float>), dim3(a.blocks), dim3(256), 0, st, a, Ap, static_cast<const float*>(mask), op_select); break;
+        }
+        (void) hipGetLastError();// (a probe that did not launch leaves the hint as it was)
     }
 
     // second column part of a row block (dist.hip): r[row] = add(r[row], fold of this part's products) for the selected rows that hold an entry here

@@ -218,10 +218,11 @@ namespace {
         uint32_t *list = nullptr, *ctl = nullptr, *items = nullptr, *lrow = nullptr, *lfirst = nullptr;
         // the call's selected short rows from the front, its selected medium rows from the end
         hipError_t e = device_malloc(reinterpret_cast<void**>(&list), sizeof(uint32_t) * ((size_t) plan->n_rows + 1));
-        if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(&ctl), sizeof(uint32_t) * 8);// [0] short rows, [1] segment items, [3] medium rows listed by the running call (zeroed by its mask probe), [2] long rows of the plan, [4..7] the row kernels' gate: open
+        if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(&ctl), sizeof(uint32_t) * 16);// + [8..11]: the second set of list lengths (the calls use the two sets in turn)// [0] short rows, [1] medium rows (one 8-byte pair), [3] segment items listed by the running call (zeroed by its mask probe), [2] long rows of the plan, [4..7] the row kernels' gate: open
         const uint32_t open_gate[4] = {0, 0, 0, 1};
         if (e == hipSuccess) e = hipMemcpy(ctl + 4, open_gate, sizeof(open_gate), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemset(ctl, 0, 4 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(ctl + 8, 0, 8 * sizeof(uint32_t));
         if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(&items), sizeof(uint32_t) * ((size_t) plan->n_items + 1));
         if (e == hipSuccess && plan->n_long) e = device_malloc(reinterpret_cast<void**>(&lrow), sizeof(uint32_t) * (size_t) plan->n_long);
         if (e == hipSuccess && plan->n_long) e = device_malloc(reinterpret_cast<void**>(&lfirst), sizeof(uint32_t) * (size_t) plan->n_long);
@@ -243,33 +244,54 @@ namespace {
     // the selected-rows path (mxv_rows.hpp), every launch gated on the mask probe's decision
     template<typename T, class Mult, class Add>
     int launch_rows(splahip_plan plan, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const void* mask, const void* v, void* r, int op_mult, int op_add,
-                    int op_select, uint32_t init_bits, const uint32_t* gate, hipStream_t st) {
+                    int op_select, uint32_t init_bits, const uint32_t* gate, const MaskProbeArgs& probe, hipStream_t st) {
         const T        init = from_bits<T>(init_bits);
         const uint32_t n    = plan->n_rows;
-        // (d_rows_ctl[0] short rows, [1] segment items, [3] medium rows listed: returned to zero by the call's mask probe, enqueued just before — a probe whose
-        // launch failed makes cob_mask_probe answer "the blocks", so this path never runs behind a probe that did not)
+        // the list lengths: two sets of counters used in turn — a call's first launch returns the OTHER set to zero for the call after it
+        if (plan->rows_dirty) {// (a call whose launches failed may have left either set behind: both start over)
+            SPLAHIP_TRY(hipMemsetAsync(plan->d_rows_ctl, 0, 2 * sizeof(uint32_t), st));
+            SPLAHIP_TRY(hipMemsetAsync(plan->d_rows_ctl + 3, 0, sizeof(uint32_t), st));
+            SPLAHIP_TRY(hipMemsetAsync(plan->d_rows_ctl + 8, 0, 4 * sizeof(uint32_t), st));
+            plan->rows_dirty = false;
+        }
+        uint32_t* const ctl      = plan->d_rows_ctl + (plan->rows_parity ? 8 : 0);
+        uint32_t* const ctl_next = plan->d_rows_ctl + (plan->rows_parity ? 0 : 8);
+        plan->rows_parity ^= 1u;
+        // (ctl[0] short rows, [1] medium rows, [3] segment items listed: returned to zero by the first launch of the PREVIOUS rows-side call over the plan)
         // (workgroups: every flush of a workgroup's list is a same-address atomic — 256 / 512 / 1024 / 2048 / 4096 workgroups at R-MAT 23, 10 % of the light rows: 103 / 87 /
         // 86 / 99 / 113 us per call)
         const uint32_t compact_blocks = knob_u32("SPLAHIP_ROWS_COMPACT_BLOCKS", 1024), short_blocks = knob_u32("SPLAHIP_ROWS_SHORT_BLOCKS", 4096),
                        task_blocks = knob_u32("SPLAHIP_ROWS_LONG_BLOCKS", 4096);
         const bool     has_long = plan->n_items && plan->n_long > 0;// the selected long rows' segment items (a plan without long rows lists none)
-        if (knob_u32("SPLAHIP_ROWS_FUSED", 1)) {// the two mask passes share a launch (mxv_rows.hpp)
+        if (knob_u32("SPLAHIP_ROWS_FUSED", 1)) {// the call's mask probe and the two mask passes share a launch (mxv_rows.hpp)
             const uint32_t select_blocks = has_long ? (plan->n_long + 255) / 256 : 0u;
-            hipLaunchKernelGGL((rows_select_kernel<T>), dim3(select_blocks + compact_blocks), dim3(256), 0, st, select_blocks, n, Ap, static_cast<const T*>(mask), op_select, init,
-                               static_cast<T*>(r), plan->d_rows_list, plan->d_rows_ctl, plan->n_long, plan->d_long_rows, plan->d_long_first, Cfg::kSeg, plan->d_long_items, gate);
+            const dim3     grid(probe.blocks + select_blocks + compact_blocks);
+            if (knob_u32("SPLAHIP_ROWS_SMALL_LDS", 1))
+                hipLaunchKernelGGL((rows_select_kernel<T, true>), grid, dim3(256), 0, st, probe, select_blocks, n, Ap, static_cast<const T*>(mask), op_select, init, static_cast<T*>(r),
+                                   plan->d_rows_list, ctl, ctl_next, plan->n_long, plan->d_long_rows, plan->d_long_first, Cfg::kSeg, plan->d_long_items, gate);
+            else
+                hipLaunchKernelGGL((rows_select_kernel<T, false>), grid, dim3(256), 0, st, probe, select_blocks, n, Ap, static_cast<const T*>(mask), op_select, init, static_cast<T*>(r),
+                                   plan->d_rows_list, ctl, ctl_next, plan->n_long, plan->d_long_rows, plan->d_long_first, Cfg::kSeg, plan->d_long_items, gate);
         } else {
+            cob_mask_probe_launch(probe, TypeId<T>::value, Ap, mask, op_select, st);
             hipLaunchKernelGGL((rows_compact_kernel<T>), dim3(compact_blocks), dim3(256), 0, st, n, Ap, static_cast<const T*>(mask), op_select, init, static_cast<T*>(r),
-                               plan->d_rows_list, plan->d_rows_ctl, gate);
+                               plan->d_rows_list, ctl, ctl_next, gate);
             if (has_long)
                 hipLaunchKernelGGL((rows_long_select_kernel<T>), dim3((plan->n_long + 255) / 256), dim3(256), 0, st, plan->n_long, plan->d_long_rows, plan->d_long_first, Ap,
-                                   static_cast<const T*>(mask), op_select, Cfg::kSeg, plan->d_long_items, plan->d_rows_ctl + 1, gate);
+                                   static_cast<const T*>(mask), op_select, Cfg::kSeg, plan->d_long_items, ctl + 3, gate);
         }
-        hipLaunchKernelGGL((rows_short_kernel<T, Mult, Add>), dim3(short_blocks), dim3(256), 0, st, plan->d_rows_list, plan->d_rows_ctl, Ap, Aj,
+        hipLaunchKernelGGL((rows_short_kernel<T, Mult, Add>), dim3(short_blocks), dim3(256), 0, st, plan->d_rows_list, ctl, Ap, Aj,
                            static_cast<const uint32_t*>(Ax), static_cast<const T*>(v), static_cast<T*>(r), Mult(op_mult), Add(op_add), init, plan->nnz, gate);
-        hipLaunchKernelGGL((rows_task_kernel<T, Mult, Add>), dim3(task_blocks), dim3(256), 0, st, plan->d_long_items, plan->d_rows_ctl, plan->d_rows_list, n, plan->d_item_row,
+        hipLaunchKernelGGL((rows_task_kernel<T, Mult, Add>), dim3(task_blocks), dim3(256), 0, st, plan->d_long_items, ctl, plan->d_rows_list, n, plan->d_item_row,
                            plan->d_item_k0, Ap, Aj, static_cast<const uint32_t*>(Ax), static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(plan->d_partial),
                            Mult(op_mult), Add(op_add), init, Cfg::kSegFlag, Cfg::kSeg, plan->nnz, gate);
-        SPLAHIP_TRY(hipGetLastError());
+        {
+            const hipError_t le = hipGetLastError();
+            if (le != hipSuccess) {
+                plan->rows_dirty = true;
+                return fail(SPLAHIP_ERROR, "selected-rows kernels: %s", hipGetErrorString(le));
+            }
+        }
         if (plan->n_items && plan->n_long > 0) {
             hipLaunchKernelGGL((spmv_combine_kernel<Cfg, T, Add, false>), dim3((plan->n_items + 255) / 256), dim3(256), 0, st, plan->d_item_row, plan->d_item_k0, plan->n_items, Ap,
                                static_cast<const T*>(mask), static_cast<T*>(r), static_cast<uint32_t*>(nullptr), reinterpret_cast<const T*>(plan->d_partial),
@@ -280,12 +302,12 @@ namespace {
     }
     template<typename T>
     int rows_typed(splahip_plan plan, const uint32_t* Ap, const uint32_t* Aj, const void* Ax, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
-                   uint32_t init_bits, const uint32_t* gate, hipStream_t st) {
+                   uint32_t init_bits, const uint32_t* gate, const MaskProbeArgs& probe, hipStream_t st) {
         if (op_mult == SPLAHIP_MULT && op_add == SPLAHIP_PLUS)
-            return launch_rows<T, StaBin<SPLAHIP_MULT>, StaBin<SPLAHIP_PLUS>>(plan, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, gate, st);
+            return launch_rows<T, StaBin<SPLAHIP_MULT>, StaBin<SPLAHIP_PLUS>>(plan, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, gate, probe, st);
         if (op_mult == SPLAHIP_PLUS && op_add == SPLAHIP_MIN)
-            return launch_rows<T, StaBin<SPLAHIP_PLUS>, StaBin<SPLAHIP_MIN>>(plan, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, gate, st);
-        return launch_rows<T, DynBin, DynBin>(plan, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, gate, st);
+            return launch_rows<T, StaBin<SPLAHIP_PLUS>, StaBin<SPLAHIP_MIN>>(plan, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, gate, probe, st);
+        return launch_rows<T, DynBin, DynBin>(plan, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, gate, probe, st);
     }
 
 #define SPLAHIP_WT(MUL, ADD) launch_wavetile<T, StaBin<MUL>, StaBin<ADD>>(plan, Ap, Aj, Ax, mask, v, r, op_mult, op_add, op_select, init_bits, st)
@@ -563,14 +585,16 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
             const Variant wv = pick_variant(type, op_mult, op_add, 0);
             const bool    wt = (wv == Variant::WaveTileStatic || wv == Variant::WaveTileDynamic) && plan->n_items != 0 &&
                             ((reinterpret_cast<uintptr_t>(d_Aj) | reinterpret_cast<uintptr_t>(d_Ax) | reinterpret_cast<uintptr_t>(d_Ap)) & 15u) == 0;
-            if (wt && op_select != SPLAHIP_ALWAYS && rows_prepare(plan, d_Ap, s) != SPLAHIP_OK) return SPLAHIP_ERROR;// (the probe zeroes the row kernels' list lengths)
-            if (wt && cob_mask_probe(plan, type, d_Ap, d_mask, op_select, stream) != 0) {
+            if (wt && op_select != SPLAHIP_ALWAYS && rows_prepare(plan, d_Ap, s) != SPLAHIP_OK) return SPLAHIP_ERROR;
+            MaskProbeArgs probe;// this call's probe (a hint for the NEXT call): the first workgroups of the row kernels' first launch, or a launch of its own in front of the blocks
+            if (wt && cob_mask_probe_prepare(plan, op_select, &probe) != 0) {
                 switch (type) {
-                    case SPLAHIP_INT: return rows_typed<int32_t>(plan, d_Ap, d_Aj, d_Ax, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, plan->d_rows_ctl + 4, s);
-                    case SPLAHIP_UINT: return rows_typed<uint32_t>(plan, d_Ap, d_Aj, d_Ax, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, plan->d_rows_ctl + 4, s);
-                    default: return rows_typed<float>(plan, d_Ap, d_Aj, d_Ax, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, plan->d_rows_ctl + 4, s);
+                    case SPLAHIP_INT: return rows_typed<int32_t>(plan, d_Ap, d_Aj, d_Ax, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, plan->d_rows_ctl + 4, probe, s);
+                    case SPLAHIP_UINT: return rows_typed<uint32_t>(plan, d_Ap, d_Aj, d_Ax, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, plan->d_rows_ctl + 4, probe, s);
+                    default: return rows_typed<float>(plan, d_Ap, d_Aj, d_Ax, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, plan->d_rows_ctl + 4, probe, s);
                 }
             }
+            cob_mask_probe_launch(probe, type, d_Ap, d_mask, op_select, stream);
             return cob_mxv(plan, type, d_Ap, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, stream);
         }
     }

@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "block_utils.hpp"
+#include "mask_probe.hpp"
 #include "mxv_kernels.hpp"
 #include "ops.hpp"
 
@@ -33,15 +34,15 @@ namespace splahip {
 
     // One streaming pass over mask and Ap, 8 rows per thread and step (16-byte loads): r = init for every row (the row kernels overwrite the selected ones
     // behind this launch); list[0 .. count[0]) = the selected rows with 1 .. kRowsLaneMax entries, in no particular order (clusters of neighbouring rows: an LDS
-    // buffer per workgroup, one global atomic per flush); list[n_rows - 1 - i], i < count[3] = the selected MEDIUM rows (kRowsLaneMax + 1 .. kRowsShortMax entries:
+    // buffer per workgroup, one global atomic per flush); list[n_rows - 1 - i], i < count[1] = the selected MEDIUM rows (count[0 .. 1] are one 8-byte word for the last flush) (kRowsLaneMax + 1 .. kRowsShortMax entries:
     // a wavefront each, rows_task_kernel), one atomic per wave.  Longer rows are the plan's business (rows_long_select_kernel).
-    template<typename T>
+    template<typename T, bool SMALL = false>
     __device__ __forceinline__ void rows_compact_body(const uint32_t vb, const uint32_t vg, uint32_t n_rows, const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, T init,
                                                                T* __restrict__ r, uint32_t* __restrict__ list, uint32_t* __restrict__ count, const uint32_t* __restrict__ gate) {
         if (gate[3] == 0u) return;
-        constexpr uint32_t kBuf = 4096;
+        constexpr uint32_t kBuf = SMALL ? 2048 : 4096;// (SMALL: 26 KB of LDS per workgroup instead of 37 — six workgroups per CU instead of four)
         __shared__ uint32_t s_buf[kBuf + 2048];
-        constexpr uint32_t  kBufM = 1024;
+        constexpr uint32_t  kBufM = SMALL ? 512 : 1024;
         __shared__ uint32_t s_med[kBufM + 2048];// the medium rows, buffered the same way (a global atomic per wave and step was ~5 K same-address atomics of ~15 ns each)
         __shared__ uint32_t s_n, s_base, s_nm, s_basem;
         if (threadIdx.x == 0) s_n = 0, s_nm = 0;
@@ -49,18 +50,33 @@ namespace splahip {
         const uint32_t per = ((n_rows + vg - 1) / vg + 2047u) & ~2047u;// a contiguous share of the rows per workgroup, whole steps of 2048 rows
         const uint32_t b0 = vb * per, b1 = min(n_rows, b0 + per);
         const uint4    iv = make_uint4(to_bits(init), to_bits(init), to_bits(init), to_bits(init));
+        // the NEXT step's words are requested before this step's are looked at (a step is loads -> scans -> LDS -> barriers: without this the workgroup's
+        // memory requests and its barriers take turns); a thread whose 8 rows are not all inside the share and the matrix loads them one by one when their step comes
+        auto whole = [&](uint32_t base) { return base < b1 && base + threadIdx.x * 8 + 8 <= b1 && base + threadIdx.x * 8 + 8 < n_rows; };
+        uint4 na0 = make_uint4(0, 0, 0, 0), na1 = na0, nm0 = na0, nm1 = na0;
+        uint32_t na8 = 0;
+        auto request = [&](uint32_t base) {
+            if (whole(base)) {// (Ap and mask are 16-byte aligned arrays)
+                const uint32_t row0 = base + threadIdx.x * 8;
+                na0 = *reinterpret_cast<const uint4*>(Ap + row0), na1 = *reinterpret_cast<const uint4*>(Ap + row0 + 4);
+                nm0 = *reinterpret_cast<const uint4*>(mask + row0), nm1 = *reinterpret_cast<const uint4*>(mask + row0 + 4);
+                na8 = Ap[row0 + 8];
+            }
+        };
+        request(b0);
         for (uint32_t base = b0; base < b1; base += 2048) {
             const uint32_t row0 = base + threadIdx.x * 8;
             uint32_t       ap[9];
             uint32_t       mk[8];
-            if (row0 + 8 <= b1 && row0 + 8 < n_rows) {// (Ap and mask are 16-byte aligned arrays; the last rows of the matrix go one by one)
-                const uint4 a0 = *reinterpret_cast<const uint4*>(Ap + row0), a1 = *reinterpret_cast<const uint4*>(Ap + row0 + 4);
-                const uint4 m0 = *reinterpret_cast<const uint4*>(mask + row0), m1 = *reinterpret_cast<const uint4*>(mask + row0 + 4);
-                ap[0] = a0.x, ap[1] = a0.y, ap[2] = a0.z, ap[3] = a0.w, ap[4] = a1.x, ap[5] = a1.y, ap[6] = a1.z, ap[7] = a1.w, ap[8] = Ap[row0 + 8];
+            if (whole(base)) {
+                const uint4 a0 = na0, a1 = na1, m0 = nm0, m1 = nm1;
+                ap[0] = a0.x, ap[1] = a0.y, ap[2] = a0.z, ap[3] = a0.w, ap[4] = a1.x, ap[5] = a1.y, ap[6] = a1.z, ap[7] = a1.w, ap[8] = na8;
                 mk[0] = m0.x, mk[1] = m0.y, mk[2] = m0.z, mk[3] = m0.w, mk[4] = m1.x, mk[5] = m1.y, mk[6] = m1.z, mk[7] = m1.w;
+                request(base + 2048);
                 *reinterpret_cast<uint4*>(r + row0)     = iv;
                 *reinterpret_cast<uint4*>(r + row0 + 4) = iv;
             } else {
+                request(base + 2048);
 #pragma unroll
                 for (uint32_t j = 0; j < 8; ++j) {
                     const bool in = row0 + j < b1;
@@ -110,23 +126,35 @@ namespace splahip {
             for (uint32_t j = 0; j < 8; ++j)
                 if (take & (1u << j)) s_buf[pos++] = row0 + j;
             __syncthreads();
-            if (s_nm >= kBufM || base + 2048 >= b1) {// flush the medium rows: stored from the END of the list downwards (uniform: s_nm is read behind the barrier)
-                const uint32_t n = s_nm;
-                if (threadIdx.x == 0 && n) s_basem = atomicAdd(count + 3, n);
-                __syncthreads();
-                for (uint32_t i = threadIdx.x; i < n; i += 256) list[n_rows - 1u - (s_basem + i)] = s_med[i];
-                __syncthreads();
-                if (threadIdx.x == 0) s_nm = 0;
-                __syncthreads();
-            }
-            if (s_n >= kBuf || base + 2048 >= b1) {// flush (uniform: s_n is read behind the barrier)
-                const uint32_t n = s_n;
-                if (threadIdx.x == 0 && n) s_base = atomicAdd(count, n);
+            if (base + 2048 >= b1) {// the share's last step: both buffers go out behind ONE global atomic on the pair (short rows | medium rows) — the workgroups
+                                    // all get here at about the same time, and same-address atomics are served one by one (~6 ns each)
+                const uint32_t n = s_n, nm = s_nm;
+                if (threadIdx.x == 0 && (n | nm)) {
+                    const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(count), (unsigned long long) n | ((unsigned long long) nm << 32));
+                    s_base = (uint32_t) old, s_basem = (uint32_t) (old >> 32);
+                }
                 __syncthreads();
                 for (uint32_t i = threadIdx.x; i < n; i += 256) list[s_base + i] = s_buf[i];
-                __syncthreads();
-                if (threadIdx.x == 0) s_n = 0;
-                __syncthreads();
+                for (uint32_t i = threadIdx.x; i < nm; i += 256) list[n_rows - 1u - (s_basem + i)] = s_med[i];
+            } else {
+                if (s_nm >= kBufM) {// flush the medium rows: stored from the END of the list downwards (uniform: s_nm is read behind the barrier)
+                    const uint32_t n = s_nm;
+                    if (threadIdx.x == 0) s_basem = atomicAdd(count + 1, n);
+                    __syncthreads();
+                    for (uint32_t i = threadIdx.x; i < n; i += 256) list[n_rows - 1u - (s_basem + i)] = s_med[i];
+                    __syncthreads();
+                    if (threadIdx.x == 0) s_nm = 0;
+                    __syncthreads();
+                }
+                if (s_n >= kBuf) {// flush (uniform: s_n is read behind the barrier)
+                    const uint32_t n = s_n;
+                    if (threadIdx.x == 0) s_base = atomicAdd(count, n);
+                    __syncthreads();
+                    for (uint32_t i = threadIdx.x; i < n; i += 256) list[s_base + i] = s_buf[i];
+                    __syncthreads();
+                    if (threadIdx.x == 0) s_n = 0;
+                    __syncthreads();
+                }
             }
         }
     }
@@ -256,13 +284,17 @@ namespace splahip {
                                                                    const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, uint32_t seg_len,
                                                                    uint32_t* __restrict__ long_items, uint32_t* __restrict__ n_listed, const uint32_t* __restrict__ gate) {
         if (gate[3] == 0u) return;
-        const uint32_t i = vb * 256 + threadIdx.x;
-        if (i >= n_long) return;
-        const uint32_t row = long_row[i];
-        if (!eval_sel<T>(op_select, mask[row])) return;
-        const uint32_t nseg = (Ap[row + 1] - Ap[row] + seg_len - 1) / seg_len, first = long_first[i];
-        const uint32_t at   = atomicAdd(n_listed, nseg);
-        for (uint32_t g = 0; g < nseg; ++g) long_items[at + g] = first + g;
+        const uint32_t i   = vb * 256 + threadIdx.x;
+        const uint32_t row = i < n_long ? long_row[i] : 0u;
+        const bool     sel = i < n_long && eval_sel<T>(op_select, mask[row]);
+        const uint32_t nseg = sel ? (Ap[row + 1] - Ap[row] + seg_len - 1) / seg_len : 0u, first = sel ? long_first[i] : 0u;
+        // one global atomic per WAVE (the counts scanned across its lanes): same-address atomics are served one by one, ~6 ns each
+        const uint32_t inc = wave_inclusive_sum(nseg), total = (uint32_t) __builtin_amdgcn_readlane((int) inc, (int) kWave - 1);
+        if (total == 0u) return;
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(n_listed, total);
+        const uint32_t at = (uint32_t) __builtin_amdgcn_readfirstlane((int) base) + inc - nseg;
+        for (uint32_t g = 0; g < nseg; ++g) long_items[at + g] = (first + g) | (nseg == 1u ? 0x80000000u : 0u);// (bit 31: the row's only segment — rows_task_body finishes the row)
     }
 
     // The wave tasks of a call, a wave per task in turn (a fixed grid: the lists' lengths are only known on the device): first the listed segment items of the
@@ -277,24 +309,40 @@ namespace splahip {
                                                             Add add_raw, T init, uint32_t seg_flag, uint32_t seg_len, uint32_t nnz, const uint32_t* __restrict__ gate) {
         if (gate[3] == 0u) return;
         const Reassoc<Add> add(add_raw);
-        const uint32_t     n_items = ctl[1], n = n_items + ctl[3];
-        const uint32_t     lane = lane_id();
-        for (uint32_t w = vb * (256 / kWave) + threadIdx.x / kWave; w < n; w += vg * (256 / kWave)) {
-            const bool medium = w >= n_items;
-            uint32_t   item = 0, row, k0, k1;
-            if (medium) {
-                row = list[n_rows - 1u - (w - n_items)];
-                k0 = Ap[row], k1 = Ap[row + 1];
-            } else {
-                item = long_items[w];
-                row  = item_row[item] & ~seg_flag;
-                k0 = item_k0[item], k1 = item_k0[item + 1];
+        const uint32_t     n_items = ctl[3], n = n_items + ctl[1];
+        const uint32_t     lane = lane_id(), stride = vg * (256 / kWave);
+        uint32_t           w = vb * (256 / kWave) + threadIdx.x / kWave;
+        if (w >= n) return;
+        // A task's header is two dependent round trips (its list word, then its bounds) in front of the two of its entries (quads, gathers): the NEXT task's header
+        // is requested under this task's entries — its list word before the quads, its bounds before the gathers (loads return in order: they are there when the
+        // quads / gathers are).  A segment item that is its row's only segment carries bit 31 (rows_long_select_body): no look at Ap to tell.
+        auto list_word = [&](uint32_t t) { return t >= n_items ? list[n_rows - 1u - (t - n_items)] : long_items[t]; };
+        struct Head {
+            uint32_t row, k0, k1, item;
+            bool     whole;// the task is the whole row: finished here
+        };
+        auto bounds = [&](uint32_t t, uint32_t word) {
+            Head h;
+            if (t >= n_items) h.row = word, h.k0 = Ap[word], h.k1 = Ap[word + 1], h.item = 0u, h.whole = true;
+            else {
+                h.item = word & 0x7FFFFFFFu, h.whole = (word >> 31) != 0u;
+                h.row = item_row[h.item] & ~seg_flag, h.k0 = item_k0[h.item], h.k1 = item_k0[h.item + 1];
             }
+            return h;
+        };
+        Head cur = bounds(w, list_word(w));
+        for (;;) {
+            const uint32_t wn   = w + stride;
+            const bool     more = wn < n;
+            const uint32_t next_word = more ? list_word(wn) : 0u;
+            const uint32_t k0 = cur.k0, k1 = cur.k1;
             const uint32_t a0 = k0 & ~3u, nq = k1 > a0 ? (k1 - a0 + 3) >> 2 : 0;// <= 256
             uint4          jq[4], xq[4];
 #pragma unroll
             for (uint32_t u = 0; u < 4; ++u)
                 if (lane + u * kWave < nq) load_quad(Aj, Ax, a0 + 4 * (lane + u * kWave), nnz, jq[u], xq[u]);
+            Head nxt = cur;
+            if (more) nxt = bounds(wn, next_word);
             T    part  = init;
             bool valid = false;
 #pragma unroll
@@ -318,11 +366,12 @@ namespace splahip {
             // (a lane holds the quads lane, lane + 64, ...: joined in lane order the fold is a re-association, as everywhere on this path)
             wave_reduce_ordered(part, valid, add);
             if (lane == 0) {
-                const uint32_t len = medium ? 0u : Ap[row + 1] - Ap[row];
-                if (len <= seg_len) r[row] = valid ? add(init, part) : init;// a medium row, or a row of one segment: finished here (the combine kernel skips it)
+                if (cur.whole) r[cur.row] = valid ? add(init, part) : init;// a medium row, or a row of one segment: finished here (the combine kernel skips it)
                 else
-                    partial[item] = part;
+                    partial[cur.item] = part;
             }
+            if (!more) break;
+            w = wn, cur = nxt;
         }
     }
 
@@ -331,19 +380,29 @@ namespace splahip {
     // 10 % of the rows).  Measured and NOT done: the short rows' batches and the wave tasks in one launch (even / odd workgroups): 143.6 us against 42 + 83 — both are
     // bound by the same line requests, and each kind of workgroup then carries the other's registers and LDS ("50 %, no hub row", where there are no tasks: 234 against
     // 170 us) — tools/gpu_r6_rows3.sh.
-    template<typename T>
-    __global__ __launch_bounds__(256) void rows_select_kernel(uint32_t select_blocks, uint32_t n_rows, const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, T init,
-                                                              T* __restrict__ r, uint32_t* __restrict__ list, uint32_t* __restrict__ ctl, uint32_t n_long,
-                                                              const uint32_t* __restrict__ long_row, const uint32_t* __restrict__ long_first, uint32_t seg_len,
-                                                              uint32_t* __restrict__ long_items, const uint32_t* __restrict__ gate) {
-        if (blockIdx.x < select_blocks) rows_long_select_body<T>(blockIdx.x, select_blocks, n_long, long_row, long_first, Ap, mask, op_select, seg_len, long_items, ctl + 1, gate);
+    template<typename T, bool SMALL = false>
+    __global__ __launch_bounds__(256) void rows_select_kernel(MaskProbeArgs probe, uint32_t select_blocks, uint32_t n_rows, const uint32_t* __restrict__ Ap, const T* __restrict__ mask,
+                                                              int op_select, T init, T* __restrict__ r, uint32_t* __restrict__ list, uint32_t* __restrict__ ctl,
+                                                              uint32_t* __restrict__ ctl_next, uint32_t n_long, const uint32_t* __restrict__ long_row,
+                                                              const uint32_t* __restrict__ long_first, uint32_t seg_len, uint32_t* __restrict__ long_items,
+                                                              const uint32_t* __restrict__ gate) {
+        // the list lengths of the NEXT call over the plan start at zero (two sets of counters, used in turn: nobody else touches the other set during this launch)
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) ctl_next[0] = 0u, ctl_next[1] = 0u, ctl_next[3] = 0u;
+        if (blockIdx.x < probe.blocks) {// this call's mask probe (mask_probe.hpp): a hint for the next call, no part of this one
+            mask_probe_body<T>(blockIdx.x, probe.blocks, probe, Ap, mask, op_select);
+            return;
+        }
+        const uint32_t b = blockIdx.x - probe.blocks, g = gridDim.x - probe.blocks;
+        if (b < select_blocks) rows_long_select_body<T>(b, select_blocks, n_long, long_row, long_first, Ap, mask, op_select, seg_len, long_items, ctl + 3, gate);
         else
-            rows_compact_body<T>(blockIdx.x - select_blocks, gridDim.x - select_blocks, n_rows, Ap, mask, op_select, init, r, list, ctl, gate);
+            rows_compact_body<T, SMALL>(b - select_blocks, g - select_blocks, n_rows, Ap, mask, op_select, init, r, list, ctl, gate);
     }
     // (the passes as launches of their own; compaction and selection apart: SPLAHIP_ROWS_FUSED=0, A/B runs)
     template<typename T>
     __global__ __launch_bounds__(256) void rows_compact_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, T init, T* __restrict__ r,
-                                                               uint32_t* __restrict__ list, uint32_t* __restrict__ count, const uint32_t* __restrict__ gate) {
+                                                               uint32_t* __restrict__ list, uint32_t* __restrict__ count, uint32_t* __restrict__ ctl_next,
+                                                               const uint32_t* __restrict__ gate) {
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) ctl_next[0] = 0u, ctl_next[1] = 0u, ctl_next[3] = 0u;
         rows_compact_body<T>(blockIdx.x, gridDim.x, n_rows, Ap, mask, op_select, init, r, list, count, gate);
     }
     template<typename T>

@@ -140,7 +140,9 @@ struct splahip_plan_s {
     size_t    ws_bytes     = 0;
     // masked calls that select few entries (mxv_rows.hpp): the list of selected short rows of the running call, and the plan's segment items
     uint32_t* d_rows_list  = nullptr;// per block of 2048 rows: quads of its selected short rows -> offsets in the call's virtual quad stream (+ the total), built on the first such call
-    uint32_t* d_rows_ctl   = nullptr;// [1] segment items listed by the running call, [2] the plan's long rows (listed once), [4..7] the open gate
+    bool      rows_dirty   = false;  // a selected-rows call failed to launch: both sets of list lengths are cleared before the next one
+    uint32_t  rows_parity  = 0;      // which of the two sets of list lengths in d_rows_ctl ([0..3] / [8..11]) the next selected-rows call uses
+    uint32_t* d_rows_ctl   = nullptr;// [0] short rows, [1] medium rows, [3] segment items listed by the running call, [2] the plan's long rows (listed once), [4..7] the open gate
     uint32_t* d_long_items = nullptr;// the segment items of the running call's selected long rows
     uint32_t* d_long_rows  = nullptr;// the plan's long rows (more than 508 entries), in no particular order
     uint32_t* d_long_first = nullptr;// ... and the first segment item of each
@@ -180,7 +182,9 @@ namespace splahip {
     // masked calls (op_select other than ALWAYS): enqueue a probe of the mask (how many entries does the selection cover) whose verdict lands in pinned host memory,
     // and return the verdict of the latest probe that has FINISHED — 1: the selected-rows kernels (mxv_rows.hpp) serve such a mask faster than the blocks, which
     // stream the whole matrix whatever the mask.  Both compute the reference's result for any mask: the verdict is a hint that lags by a call.
-    int cob_mask_probe(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, int op_select, void* stream);
+    struct MaskProbeArgs;// (mask_probe.hpp)
+    int  cob_mask_probe_prepare(const splahip_plan_s* plan, int op_select, MaskProbeArgs* out);
+    void cob_mask_probe_launch(const MaskProbeArgs& a, int type, const uint32_t* Ap, const void* mask, int op_select, void* stream);
     // the same over a second column part of the same rows: r[row] = add(r[row], this part's fold) where the row is selected and holds an entry here
     int cob_mxv_accumulate(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add,
                            int op_select, void* stream);
