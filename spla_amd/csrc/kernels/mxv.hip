@@ -218,11 +218,11 @@ namespace {
         uint32_t *list = nullptr, *ctl = nullptr, *items = nullptr, *lrow = nullptr, *lfirst = nullptr;
         // the call's selected short rows from the front, its selected medium rows from the end
         hipError_t e = device_malloc(reinterpret_cast<void**>(&list), sizeof(uint32_t) * ((size_t) plan->n_rows + 1));
-        if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(&ctl), sizeof(uint32_t) * 16);// + [8..11]: the second set of list lengths (the calls use the two sets in turn)// [0] short rows, [1] medium rows (one 8-byte pair), [3] segment items listed by the running call (zeroed by its mask probe), [2] long rows of the plan, [4..7] the row kernels' gate: open
+        if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(&ctl), sizeof(uint32_t) * 2 * kRowsCtlSet);// two sets of list lengths (the calls use them in turn), kRowsRegions count pairs each on lines of their own (mxv_rows.hpp)// [0] short rows, [1] medium rows (one 8-byte pair), [3] segment items listed by the running call (zeroed by its mask probe), [2] long rows of the plan, [4..7] the row kernels' gate: open
         const uint32_t open_gate[4] = {0, 0, 0, 1};
         if (e == hipSuccess) e = hipMemcpy(ctl + 4, open_gate, sizeof(open_gate), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemset(ctl, 0, 4 * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemset(ctl + 8, 0, 8 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(ctl + 8, 0, (2 * kRowsCtlSet - 8) * sizeof(uint32_t));
         if (e == hipSuccess) e = device_malloc(reinterpret_cast<void**>(&items), sizeof(uint32_t) * ((size_t) plan->n_items + 1));
         if (e == hipSuccess && plan->n_long) e = device_malloc(reinterpret_cast<void**>(&lrow), sizeof(uint32_t) * (size_t) plan->n_long);
         if (e == hipSuccess && plan->n_long) e = device_malloc(reinterpret_cast<void**>(&lfirst), sizeof(uint32_t) * (size_t) plan->n_long);
@@ -248,41 +248,43 @@ namespace {
         const T        init = from_bits<T>(init_bits);
         const uint32_t n    = plan->n_rows;
         // the list lengths: two sets of counters used in turn — a call's first launch returns the OTHER set to zero for the call after it
-        if (plan->rows_dirty) {// (a call whose launches failed may have left either set behind: both start over)
+        if (plan->rows_dirty) {// (a call whose launches failed may have left either set behind: both start over; [2] the plan's long-row count and [4..7] the gate stay)
             SPLAHIP_TRY(hipMemsetAsync(plan->d_rows_ctl, 0, 2 * sizeof(uint32_t), st));
             SPLAHIP_TRY(hipMemsetAsync(plan->d_rows_ctl + 3, 0, sizeof(uint32_t), st));
-            SPLAHIP_TRY(hipMemsetAsync(plan->d_rows_ctl + 8, 0, 4 * sizeof(uint32_t), st));
+            SPLAHIP_TRY(hipMemsetAsync(plan->d_rows_ctl + 8, 0, (2 * kRowsCtlSet - 8) * sizeof(uint32_t), st));
             plan->rows_dirty = false;
         }
-        uint32_t* const ctl      = plan->d_rows_ctl + (plan->rows_parity ? 8 : 0);
-        uint32_t* const ctl_next = plan->d_rows_ctl + (plan->rows_parity ? 0 : 8);
+        uint32_t* const ctl      = plan->d_rows_ctl + (plan->rows_parity ? kRowsCtlSet : 0);
+        uint32_t* const ctl_next = plan->d_rows_ctl + (plan->rows_parity ? 0 : kRowsCtlSet);
         plan->rows_parity ^= 1u;
         // (ctl[0] short rows, [1] medium rows, [3] segment items listed: returned to zero by the first launch of the PREVIOUS rows-side call over the plan)
         // (workgroups: every flush of a workgroup's list is a same-address atomic — 256 / 512 / 1024 / 2048 / 4096 workgroups at R-MAT 23, 10 % of the light rows: 103 / 87 /
         // 86 / 99 / 113 us per call)
-        const uint32_t compact_blocks = knob_u32("SPLAHIP_ROWS_COMPACT_BLOCKS", 1024), short_blocks = knob_u32("SPLAHIP_ROWS_SHORT_BLOCKS", 4096),
-                       task_blocks = knob_u32("SPLAHIP_ROWS_LONG_BLOCKS", 4096);
+        const uint32_t compact_blocks = std::max(kRowsRegions, knob_u32("SPLAHIP_ROWS_COMPACT_BLOCKS", 1024) / kRowsRegions * kRowsRegions),// whole workgroups per list area
+                       short_blocks = knob_u32("SPLAHIP_ROWS_SHORT_BLOCKS", 4096), task_blocks = knob_u32("SPLAHIP_ROWS_LONG_BLOCKS", 4096);
+        // rows per list area = the rows of its compaction workgroups (rows_compact_body: a workgroup's share is whole steps of 2048 rows)
+        const uint32_t per_block = ((n + compact_blocks - 1) / compact_blocks + 2047u) & ~2047u, area = per_block * (compact_blocks / kRowsRegions);
         const bool     has_long = plan->n_items && plan->n_long > 0;// the selected long rows' segment items (a plan without long rows lists none)
         if (knob_u32("SPLAHIP_ROWS_FUSED", 1)) {// the call's mask probe and the two mask passes share a launch (mxv_rows.hpp)
             const uint32_t select_blocks = has_long ? (plan->n_long + 255) / 256 : 0u;
             const dim3     grid(probe.blocks + select_blocks + compact_blocks);
             if (knob_u32("SPLAHIP_ROWS_SMALL_LDS", 1))
                 hipLaunchKernelGGL((rows_select_kernel<T, true>), grid, dim3(256), 0, st, probe, select_blocks, n, Ap, static_cast<const T*>(mask), op_select, init, static_cast<T*>(r),
-                                   plan->d_rows_list, ctl, ctl_next, plan->n_long, plan->d_long_rows, plan->d_long_first, Cfg::kSeg, plan->d_long_items, gate);
+                                   plan->d_rows_list, ctl, ctl_next, area, plan->n_long, plan->d_long_rows, plan->d_long_first, Cfg::kSeg, plan->d_long_items, gate);
             else
                 hipLaunchKernelGGL((rows_select_kernel<T, false>), grid, dim3(256), 0, st, probe, select_blocks, n, Ap, static_cast<const T*>(mask), op_select, init, static_cast<T*>(r),
-                                   plan->d_rows_list, ctl, ctl_next, plan->n_long, plan->d_long_rows, plan->d_long_first, Cfg::kSeg, plan->d_long_items, gate);
+                                   plan->d_rows_list, ctl, ctl_next, area, plan->n_long, plan->d_long_rows, plan->d_long_first, Cfg::kSeg, plan->d_long_items, gate);
         } else {
             cob_mask_probe_launch(probe, TypeId<T>::value, Ap, mask, op_select, st);
             hipLaunchKernelGGL((rows_compact_kernel<T>), dim3(compact_blocks), dim3(256), 0, st, n, Ap, static_cast<const T*>(mask), op_select, init, static_cast<T*>(r),
-                               plan->d_rows_list, ctl, ctl_next, gate);
+                               plan->d_rows_list, ctl, ctl_next, area, gate);
             if (has_long)
                 hipLaunchKernelGGL((rows_long_select_kernel<T>), dim3((plan->n_long + 255) / 256), dim3(256), 0, st, plan->n_long, plan->d_long_rows, plan->d_long_first, Ap,
                                    static_cast<const T*>(mask), op_select, Cfg::kSeg, plan->d_long_items, ctl + 3, gate);
         }
-        hipLaunchKernelGGL((rows_short_kernel<T, Mult, Add>), dim3(short_blocks), dim3(256), 0, st, plan->d_rows_list, ctl, Ap, Aj,
+        hipLaunchKernelGGL((rows_short_kernel<T, Mult, Add>), dim3(short_blocks), dim3(256), 0, st, plan->d_rows_list, ctl, area, Ap, Aj,
                            static_cast<const uint32_t*>(Ax), static_cast<const T*>(v), static_cast<T*>(r), Mult(op_mult), Add(op_add), init, plan->nnz, gate);
-        hipLaunchKernelGGL((rows_task_kernel<T, Mult, Add>), dim3(task_blocks), dim3(256), 0, st, plan->d_long_items, ctl, plan->d_rows_list, n, plan->d_item_row,
+        hipLaunchKernelGGL((rows_task_kernel<T, Mult, Add>), dim3(task_blocks), dim3(256), 0, st, plan->d_long_items, ctl, plan->d_rows_list, n, area, plan->d_item_row,
                            plan->d_item_k0, Ap, Aj, static_cast<const uint32_t*>(Ax), static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(plan->d_partial),
                            Mult(op_mult), Add(op_add), init, Cfg::kSegFlag, Cfg::kSeg, plan->nnz, gate);
         {

@@ -29,6 +29,37 @@
 
 namespace splahip {
 
+    // The lists of a call live in kRowsRegions areas of the row space (area g = the rows of the compaction workgroups [g, g + 1) * blocks / kRowsRegions): an area's short
+    // rows from its start upwards, its medium rows from its end downwards, its two counts one 8-byte word on a 128-byte line of its own (ctl[32 g], ctl[32 g + 1]) — the
+    // compaction workgroups all flush at about the same time, same-address atomics are served one by one (~6 ns), and one counter for the whole matrix was 1 K of them in
+    // a row.  The consumers turn a list index into (area, offset) with the eight running sums (rows_region_sums).
+    constexpr uint32_t kRowsRegions = 8, kRowsCntStride = 32, kRowsCtlSet = kRowsRegions * kRowsCntStride;// (words of one set: [3] the segment items listed, [4..7] of the first set the gate)
+    struct RowsSums {
+        uint32_t pre[kRowsRegions + 1];
+        __device__ __forceinline__ uint32_t region_of(uint32_t i) const {
+            uint32_t g = 0;
+#pragma unroll
+            for (uint32_t k = 1; k < kRowsRegions; ++k) g += i >= pre[k] ? 1u : 0u;
+            return g;
+        }
+        // (the running sum in front of region g: a select chain, the index is not a compile-time constant)
+        __device__ __forceinline__ uint32_t before(uint32_t g) const {
+            uint32_t b = 0;
+#pragma unroll
+            for (uint32_t k = 1; k < kRowsRegions; ++k) b = g >= k ? pre[k] : b;
+            return b;
+        }
+    };
+    __device__ __forceinline__ RowsSums rows_region_sums(const uint32_t* __restrict__ ctl, uint32_t which) {// which: 0 short rows, 1 medium rows
+        RowsSums s;
+        uint32_t c[kRowsRegions];
+#pragma unroll
+        for (uint32_t g = 0; g < kRowsRegions; ++g) c[g] = ctl[g * kRowsCntStride + which];
+        s.pre[0] = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < kRowsRegions; ++g) s.pre[g + 1] = s.pre[g] + c[g];
+        return s;
+    }
     constexpr uint32_t kRowsShortMax = 508;// = MxvCfg's longest row of a run item: longer rows are segment items of the wave-tile plan
     constexpr uint32_t kRowsLaneMax  = 32; // rows up to this length are folded by one lane of a 64-row batch (rows_short_kernel); up to kRowsShortMax: a wave each
 
@@ -38,8 +69,13 @@ namespace splahip {
     // a wavefront each, rows_task_kernel), one atomic per wave.  Longer rows are the plan's business (rows_long_select_kernel).
     template<typename T, bool SMALL = false>
     __device__ __forceinline__ void rows_compact_body(const uint32_t vb, const uint32_t vg, uint32_t n_rows, const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, T init,
-                                                               T* __restrict__ r, uint32_t* __restrict__ list, uint32_t* __restrict__ count, const uint32_t* __restrict__ gate) {
+                                                               T* __restrict__ r, uint32_t* __restrict__ list, uint32_t* __restrict__ ctl, uint32_t area,
+                                                               const uint32_t* __restrict__ gate) {
         if (gate[3] == 0u) return;
+        // this workgroup's area of the lists (vg is a multiple of kRowsRegions; area = its workgroups' rows): the area's count pair, first and last list slot
+        const uint32_t  region     = vb / (vg / kRowsRegions);
+        uint32_t* const count      = ctl + region * kRowsCntStride;
+        const uint32_t  area_first = region * area, area_last = min(n_rows, (region + 1u) * area) - 1u;
         constexpr uint32_t kBuf = SMALL ? 2048 : 4096;// (SMALL: 26 KB of LDS per workgroup instead of 37 — six workgroups per CU instead of four)
         __shared__ uint32_t s_buf[kBuf + 2048];
         constexpr uint32_t  kBufM = SMALL ? 512 : 1024;
@@ -134,14 +170,14 @@ namespace splahip {
                     s_base = (uint32_t) old, s_basem = (uint32_t) (old >> 32);
                 }
                 __syncthreads();
-                for (uint32_t i = threadIdx.x; i < n; i += 256) list[s_base + i] = s_buf[i];
-                for (uint32_t i = threadIdx.x; i < nm; i += 256) list[n_rows - 1u - (s_basem + i)] = s_med[i];
+                for (uint32_t i = threadIdx.x; i < n; i += 256) list[area_first + s_base + i] = s_buf[i];
+                for (uint32_t i = threadIdx.x; i < nm; i += 256) list[area_last - (s_basem + i)] = s_med[i];
             } else {
                 if (s_nm >= kBufM) {// flush the medium rows: stored from the END of the list downwards (uniform: s_nm is read behind the barrier)
                     const uint32_t n = s_nm;
                     if (threadIdx.x == 0) s_basem = atomicAdd(count + 1, n);
                     __syncthreads();
-                    for (uint32_t i = threadIdx.x; i < n; i += 256) list[n_rows - 1u - (s_basem + i)] = s_med[i];
+                    for (uint32_t i = threadIdx.x; i < n; i += 256) list[area_last - (s_basem + i)] = s_med[i];
                     __syncthreads();
                     if (threadIdx.x == 0) s_nm = 0;
                     __syncthreads();
@@ -150,7 +186,7 @@ namespace splahip {
                     const uint32_t n = s_n;
                     if (threadIdx.x == 0) s_base = atomicAdd(count, n);
                     __syncthreads();
-                    for (uint32_t i = threadIdx.x; i < n; i += 256) list[s_base + i] = s_buf[i];
+                    for (uint32_t i = threadIdx.x; i < n; i += 256) list[area_first + s_base + i] = s_buf[i];
                     __syncthreads();
                     if (threadIdx.x == 0) s_n = 0;
                     __syncthreads();
@@ -165,14 +201,16 @@ namespace splahip {
     // reference's own order (cpu_mxv.hpp:94-99): bit-exact for every op_add, fp32 sums included.  Three round trips per ~1000 entries instead of two per row.
     constexpr uint32_t kRowsStage = 1024;// entries of a wave's product stage (256 quads: 4 per lane)
     template<typename T, class Mult, class Add>
-    __device__ __forceinline__ void rows_short_body(const uint32_t vb, const uint32_t vg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, const uint32_t* __restrict__ Ap,
+    __device__ __forceinline__ void rows_short_body(const uint32_t vb, const uint32_t vg, const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, uint32_t area,
+                                                             const uint32_t* __restrict__ Ap,
                                                              const uint32_t* __restrict__ Aj, const uint32_t* __restrict__ Ax, const T* __restrict__ v, T* __restrict__ r, Mult mult,
                                                              Add add, T init, uint32_t nnz, const uint32_t* __restrict__ gate) {
         if (gate[3] == 0u) return;
         __shared__ T        s_prod_all[256 / kWave][kRowsStage];
         __shared__ uint32_t s_q_all[256 / kWave][kWave + 1];// exclusive scan of the rows' quad counts
         __shared__ uint32_t s_a_all[256 / kWave][kWave];    // first (16-byte aligned) entry of the rows' quads
-        const uint32_t n    = *count;
+        const RowsSums sums = rows_region_sums(count, 0);
+        const uint32_t n    = sums.pre[kRowsRegions];
         const uint32_t lane = lane_id(), wv = threadIdx.x / kWave;
         T* const        s_prod = s_prod_all[wv];
         uint32_t* const s_q    = s_q_all[wv];
@@ -181,7 +219,8 @@ namespace splahip {
         for (uint32_t i0 = wave * kWave; i0 < n; i0 += n_waves * kWave) {
             uint32_t my_row = 0, k0 = 0, k1 = 0;
             if (i0 + lane < n) {
-                my_row = list[i0 + lane];
+                const uint32_t g = sums.region_of(i0 + lane);
+                my_row = list[g * area + (i0 + lane - sums.before(g))];
                 k0     = Ap[my_row];
                 k1     = Ap[my_row + 1];
             }
@@ -302,21 +341,26 @@ namespace splahip {
     // at once (4 quads per lane, then their 16 gathers); a lane folds its quads in entry order, the lanes are joined in order (op_add is associative and commutative
     // on this path); a segment's partial goes to the combine kernel, a medium row or a row of one segment is finished here (r = add(init, fold)).
     template<typename T, class Mult, class Add>
-    __device__ __forceinline__ void rows_task_body(const uint32_t vb, const uint32_t vg, const uint32_t* __restrict__ long_items, const uint32_t* __restrict__ ctl, const uint32_t* __restrict__ list, uint32_t n_rows,
+    __device__ __forceinline__ void rows_task_body(const uint32_t vb, const uint32_t vg, const uint32_t* __restrict__ long_items, const uint32_t* __restrict__ ctl, const uint32_t* __restrict__ list, uint32_t n_rows, uint32_t area,
                                                             const uint32_t* __restrict__ item_row,
                                                             const uint32_t* __restrict__ item_k0, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ Aj,
                                                             const uint32_t* __restrict__ Ax, const T* __restrict__ v, T* __restrict__ r, T* __restrict__ partial, Mult mult,
                                                             Add add_raw, T init, uint32_t seg_flag, uint32_t seg_len, uint32_t nnz, const uint32_t* __restrict__ gate) {
         if (gate[3] == 0u) return;
         const Reassoc<Add> add(add_raw);
-        const uint32_t     n_items = ctl[3], n = n_items + ctl[1];
+        const RowsSums     sums    = rows_region_sums(ctl, 1);
+        const uint32_t     n_items = ctl[3], n = n_items + sums.pre[kRowsRegions];
         const uint32_t     lane = lane_id(), stride = vg * (256 / kWave);
         uint32_t           w = vb * (256 / kWave) + threadIdx.x / kWave;
         if (w >= n) return;
         // A task's header is two dependent round trips (its list word, then its bounds) in front of the two of its entries (quads, gathers): the NEXT task's header
         // is requested under this task's entries — its list word before the quads, its bounds before the gathers (loads return in order: they are there when the
         // quads / gathers are).  A segment item that is its row's only segment carries bit 31 (rows_long_select_body): no look at Ap to tell.
-        auto list_word = [&](uint32_t t) { return t >= n_items ? list[n_rows - 1u - (t - n_items)] : long_items[t]; };
+        auto list_word = [&](uint32_t t) {
+            if (t < n_items) return long_items[t];
+            const uint32_t m = t - n_items, g = sums.region_of(m);// the m-th medium row: area g, counted from the area's end
+            return list[min(n_rows, (g + 1u) * area) - 1u - (m - sums.before(g))];
+        };
         struct Head {
             uint32_t row, k0, k1, item;
             bool     whole;// the task is the whole row: finished here
@@ -383,11 +427,14 @@ namespace splahip {
     template<typename T, bool SMALL = false>
     __global__ __launch_bounds__(256) void rows_select_kernel(MaskProbeArgs probe, uint32_t select_blocks, uint32_t n_rows, const uint32_t* __restrict__ Ap, const T* __restrict__ mask,
                                                               int op_select, T init, T* __restrict__ r, uint32_t* __restrict__ list, uint32_t* __restrict__ ctl,
-                                                              uint32_t* __restrict__ ctl_next, uint32_t n_long, const uint32_t* __restrict__ long_row,
+                                                              uint32_t* __restrict__ ctl_next, uint32_t area, uint32_t n_long, const uint32_t* __restrict__ long_row,
                                                               const uint32_t* __restrict__ long_first, uint32_t seg_len, uint32_t* __restrict__ long_items,
                                                               const uint32_t* __restrict__ gate) {
         // the list lengths of the NEXT call over the plan start at zero (two sets of counters, used in turn: nobody else touches the other set during this launch)
-        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) ctl_next[0] = 0u, ctl_next[1] = 0u, ctl_next[3] = 0u;
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x < kRowsRegions) {
+            ctl_next[threadIdx.x * kRowsCntStride] = 0u, ctl_next[threadIdx.x * kRowsCntStride + 1u] = 0u;
+            if (threadIdx.x == 0) ctl_next[3] = 0u;
+        }
         if (blockIdx.x < probe.blocks) {// this call's mask probe (mask_probe.hpp): a hint for the next call, no part of this one
             mask_probe_body<T>(blockIdx.x, probe.blocks, probe, Ap, mask, op_select);
             return;
@@ -395,15 +442,18 @@ namespace splahip {
         const uint32_t b = blockIdx.x - probe.blocks, g = gridDim.x - probe.blocks;
         if (b < select_blocks) rows_long_select_body<T>(b, select_blocks, n_long, long_row, long_first, Ap, mask, op_select, seg_len, long_items, ctl + 3, gate);
         else
-            rows_compact_body<T, SMALL>(b - select_blocks, g - select_blocks, n_rows, Ap, mask, op_select, init, r, list, ctl, gate);
+            rows_compact_body<T, SMALL>(b - select_blocks, g - select_blocks, n_rows, Ap, mask, op_select, init, r, list, ctl, area, gate);
     }
     // (the passes as launches of their own; compaction and selection apart: SPLAHIP_ROWS_FUSED=0, A/B runs)
     template<typename T>
     __global__ __launch_bounds__(256) void rows_compact_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, T init, T* __restrict__ r,
-                                                               uint32_t* __restrict__ list, uint32_t* __restrict__ count, uint32_t* __restrict__ ctl_next,
+                                                               uint32_t* __restrict__ list, uint32_t* __restrict__ count, uint32_t* __restrict__ ctl_next, uint32_t area,
                                                                const uint32_t* __restrict__ gate) {
-        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) ctl_next[0] = 0u, ctl_next[1] = 0u, ctl_next[3] = 0u;
-        rows_compact_body<T>(blockIdx.x, gridDim.x, n_rows, Ap, mask, op_select, init, r, list, count, gate);
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x < kRowsRegions) {
+            ctl_next[threadIdx.x * kRowsCntStride] = 0u, ctl_next[threadIdx.x * kRowsCntStride + 1u] = 0u;
+            if (threadIdx.x == 0) ctl_next[3] = 0u;
+        }
+        rows_compact_body<T>(blockIdx.x, gridDim.x, n_rows, Ap, mask, op_select, init, r, list, count, area, gate);
     }
     template<typename T>
     __global__ __launch_bounds__(256) void rows_long_select_kernel(uint32_t n_long, const uint32_t* __restrict__ long_row, const uint32_t* __restrict__ long_first,
@@ -412,18 +462,18 @@ namespace splahip {
         rows_long_select_body<T>(blockIdx.x, gridDim.x, n_long, long_row, long_first, Ap, mask, op_select, seg_len, long_items, n_listed, gate);
     }
     template<typename T, class Mult, class Add>
-    __global__ __launch_bounds__(256) void rows_short_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, const uint32_t* __restrict__ Ap,
+    __global__ __launch_bounds__(256) void rows_short_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, uint32_t area, const uint32_t* __restrict__ Ap,
                                                              const uint32_t* __restrict__ Aj, const uint32_t* __restrict__ Ax, const T* __restrict__ v, T* __restrict__ r, Mult mult,
                                                              Add add, T init, uint32_t nnz, const uint32_t* __restrict__ gate) {
-        rows_short_body<T, Mult, Add>(blockIdx.x, gridDim.x, list, count, Ap, Aj, Ax, v, r, mult, add, init, nnz, gate);
+        rows_short_body<T, Mult, Add>(blockIdx.x, gridDim.x, list, count, area, Ap, Aj, Ax, v, r, mult, add, init, nnz, gate);
     }
     template<typename T, class Mult, class Add>
     __global__ __launch_bounds__(256) void rows_task_kernel(const uint32_t* __restrict__ long_items, const uint32_t* __restrict__ ctl, const uint32_t* __restrict__ list, uint32_t n_rows,
-                                                            const uint32_t* __restrict__ item_row, const uint32_t* __restrict__ item_k0, const uint32_t* __restrict__ Ap,
+                                                            uint32_t area, const uint32_t* __restrict__ item_row, const uint32_t* __restrict__ item_k0, const uint32_t* __restrict__ Ap,
                                                             const uint32_t* __restrict__ Aj, const uint32_t* __restrict__ Ax, const T* __restrict__ v, T* __restrict__ r,
                                                             T* __restrict__ partial, Mult mult, Add add, T init, uint32_t seg_flag, uint32_t seg_len, uint32_t nnz,
                                                             const uint32_t* __restrict__ gate) {
-        rows_task_body<T, Mult, Add>(blockIdx.x, gridDim.x, long_items, ctl, list, n_rows, item_row, item_k0, Ap, Aj, Ax, v, r, partial, mult, add, init, seg_flag, seg_len, nnz, gate);
+        rows_task_body<T, Mult, Add>(blockIdx.x, gridDim.x, long_items, ctl, list, n_rows, area, item_row, item_k0, Ap, Aj, Ax, v, r, partial, mult, add, init, seg_flag, seg_len, nnz, gate);
     }
 
 }// namespace splahip
