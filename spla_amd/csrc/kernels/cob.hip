@@ -380,11 +380,33 @@ namespace {
 
     // set by cob_mxv_accumulate around its call (per host thread): the launch below then folds onto the values r already holds
     thread_local uint32_t tl_accumulate = 0;
+    // the mask probe of the running call, waiting for a launch to ride on (cob_mxv_probed): the hub ranges' finishing kernel takes it as its first workgroups
+    thread_local const MaskProbeArgs* tl_pending_probe = nullptr;
 
     // the mask probe as a launch of its own (mask_probe.hpp; a call served by the blocks)
     template<typename T>
     __global__ __launch_bounds__(256) void cob_mask_probe_kernel(MaskProbeArgs a, const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select) {
         mask_probe_body<T>(blockIdx.x, gridDim.x, a, Ap, mask, op_select);
+    }
+
+    // cob_hub_finish_kernel (mxv_cob.hpp) with the call's mask probe as its first workgroups: the probe is a hint for the NEXT masked call, and as a launch of its own
+    // in front of the blocks it was 12 us of a ~290 us call
+    template<typename T, int ACC, bool VXM>
+    __global__ __launch_bounds__(256) void cob_hub_finish_probe_kernel(MaskProbeArgs probe, const uint32_t* __restrict__ Ap, uint32_t n_slots, uint32_t R, uint32_t acc_stride,
+                                                                       uint32_t* __restrict__ acc, const uint32_t* __restrict__ hub_row, const T* __restrict__ mask, T* __restrict__ r,
+                                                                       uint32_t* __restrict__ touched, uint32_t accumulate, DynBin add, int op_select, T init) {
+        if (blockIdx.x < probe.blocks) {
+            mask_probe_body<T>(blockIdx.x, probe.blocks, probe, Ap, mask, op_select);
+            return;
+        }
+        const uint32_t i = (blockIdx.x - probe.blocks) * 256 + threadIdx.x;
+        if (i >= n_slots) return;
+        const size_t   ia  = (size_t) (i / R) * acc_stride + i % R;// accumulator q belongs to hub range q
+        const uint32_t w   = acc[ia];
+        const uint32_t row = hub_row[i];
+        acc[ia]            = cob_identity<T, ACC>();
+        if (row == 0xFFFFFFFFu) return;
+        cob_hub_row<T, ACC, VXM>(w, row, mask, r, touched, accumulate, add, op_select, init);
     }
 
     static thread_local uint32_t tl_skip_bits = 0;// the v value whose entries the sparse-vector form skips in the running call (0; init for min-plus)
@@ -551,8 +573,14 @@ namespace {
         }
         if (g->hub_finish == 1 && g->n_hub_ranges) {
             const uint32_t n_slots = g->n_hub_ranges * g->R;
-            hipLaunchKernelGGL((cob_hub_finish_kernel<T, ACC, VXM>), dim3((n_slots + 255) / 256), dim3(256), 0, st, n_slots, g->R, g->acc_stride, g->d_acc, g->d_hub_row, static_cast<const T*>(mask),
-                               static_cast<T*>(r), touched, a.accumulate, DynBin(op_add), op_select, init);
+            const MaskProbeArgs* probe = tl_pending_probe;
+            if (probe && probe->blocks && mask != nullptr) {
+                tl_pending_probe = nullptr;// (taken)
+                hipLaunchKernelGGL((cob_hub_finish_probe_kernel<T, ACC, VXM>), dim3(probe->blocks + (n_slots + 255) / 256), dim3(256), 0, st, *probe, Ap, n_slots, g->R, g->acc_stride,
+                                   g->d_acc, g->d_hub_row, static_cast<const T*>(mask), static_cast<T*>(r), touched, a.accumulate, DynBin(op_add), op_select, init);
+            } else
+                hipLaunchKernelGGL((cob_hub_finish_kernel<T, ACC, VXM>), dim3((n_slots + 255) / 256), dim3(256), 0, st, n_slots, g->R, g->acc_stride, g->d_acc, g->d_hub_row,
+                                   static_cast<const T*>(mask), static_cast<T*>(r), touched, a.accumulate, DynBin(op_add), op_select, init);
             COB_TRY(hipGetLastError());
         }
 #undef COB_TRY
@@ -719,6 +747,21 @@ namespace splahip {
             default: hipLaunchKernelGGL((cob_mask_probe_kernel<float>), dim3(a.blocks), dim3(256), 0, st, a, Ap, static_cast<const float*>(mask), op_select); break;
         }
         (void) hipGetLastError();// (a probe that did not launch leaves the hint as it was)
+    }
+
+    // a masked call served by the blocks, with its probe: the probe rides on the hub ranges' finishing launch when there is one (SPLAHIP_MASK_PROBE_FUSED=0: never),
+    // else it is a launch of its own behind the product — either way its verdict is there long before the next call asks
+    int cob_mxv_probed(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
+                       uint32_t init_bits, const MaskProbeArgs& probe, void* stream) {
+        tl_pending_probe = probe.blocks && env_u32("SPLAHIP_MASK_PROBE_FUSED", 1) ? &probe : nullptr;
+        const bool rode  = tl_pending_probe != nullptr;
+        if (!rode) cob_mask_probe_launch(probe, type, Ap, mask, op_select, stream);
+        const int st = cob_mxv(plan, type, Ap, mask, v, r, op_mult, op_add, op_select, init_bits, stream);
+        if (tl_pending_probe) {// nobody took it
+            tl_pending_probe = nullptr;
+            cob_mask_probe_launch(probe, type, Ap, mask, op_select, stream);
+        }
+        return st;
     }
 
     // second column part of a row block (dist.hip): r[row] = add(r[row], fold of this part's products) for the selected rows that hold an entry here

@@ -596,8 +596,7 @@ int splahip_mxv_masked(splahip_plan plan, int type, uint32_t n_rows, uint32_t n_
                     default: return rows_typed<float>(plan, d_Ap, d_Aj, d_Ax, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, plan->d_rows_ctl + 4, probe, s);
                 }
             }
-            cob_mask_probe_launch(probe, type, d_Ap, d_mask, op_select, stream);
-            return cob_mxv(plan, type, d_Ap, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, stream);
+            return cob_mxv_probed(plan, type, d_Ap, d_mask, d_v, d_r, op_mult, op_add, op_select, init_bits, probe, stream);
         }
     }
     // the sliced-ELL copy (splahip_csr_plan_attach_sell) serves every associative op_add without early exit; its lanes fold in

@@ -185,6 +185,8 @@ namespace splahip {
     struct MaskProbeArgs;// (mask_probe.hpp)
     int  cob_mask_probe_prepare(const splahip_plan_s* plan, int op_select, MaskProbeArgs* out);
     void cob_mask_probe_launch(const MaskProbeArgs& a, int type, const uint32_t* Ap, const void* mask, int op_select, void* stream);
+    int  cob_mxv_probed(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add, int op_select,
+                        uint32_t init_bits, const MaskProbeArgs& probe, void* stream);
     // the same over a second column part of the same rows: r[row] = add(r[row], this part's fold) where the row is selected and holds an entry here
     int cob_mxv_accumulate(const splahip_plan_s* plan, int type, const uint32_t* Ap, const void* mask, const void* v, void* r, int op_mult, int op_add,
                            int op_select, void* stream);
