@@ -261,7 +261,10 @@ namespace {
         // (workgroups: every flush of a workgroup's list is a same-address atomic — 256 / 512 / 1024 / 2048 / 4096 workgroups at R-MAT 23, 10 % of the light rows: 103 / 87 /
         // 86 / 99 / 113 us per call)
         const uint32_t compact_blocks = std::max(kRowsRegions, knob_u32("SPLAHIP_ROWS_COMPACT_BLOCKS", 1024) / kRowsRegions * kRowsRegions),// whole workgroups per list area
-                       short_blocks = knob_u32("SPLAHIP_ROWS_SHORT_BLOCKS", 4096), task_blocks = knob_u32("SPLAHIP_ROWS_LONG_BLOCKS", 4096);
+                       // (short rows / wave tasks: a workgroup per 512 rows of the matrix, 1024 ... 8192 — R-MAT 23, 4096 / 8192 of each: random 10 % 161.4 / 159.2 us, "50 %, no
+                       // hub row" 155.7 / 152.9 us, three repeats each: tools/gpu_r6_rows8.sh)
+                       by_rows      = std::min(8192u, std::max(1024u, n / 512u)),// (R-MAT 21: 2048 / 4096 / 8192 of each: random 10 % 63.0 / 60.6 / 60.6 us; R-MAT 20: level)
+                       short_blocks = knob_u32("SPLAHIP_ROWS_SHORT_BLOCKS", by_rows), task_blocks = knob_u32("SPLAHIP_ROWS_LONG_BLOCKS", by_rows);
         // rows per list area = the rows of its compaction workgroups (rows_compact_body: a workgroup's share is whole steps of 2048 rows)
         const uint32_t per_block = ((n + compact_blocks - 1) / compact_blocks + 2047u) & ~2047u, area = per_block * (compact_blocks / kRowsRegions);
         const bool     has_long = plan->n_items && plan->n_long > 0;// the selected long rows' segment items (a plan without long rows lists none)
