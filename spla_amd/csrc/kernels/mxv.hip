@@ -285,11 +285,20 @@ namespace {
                 hipLaunchKernelGGL((rows_long_select_kernel<T>), dim3((plan->n_long + 255) / 256), dim3(256), 0, st, plan->n_long, plan->d_long_rows, plan->d_long_first, Ap,
                                    static_cast<const T*>(mask), op_select, Cfg::kSeg, plan->d_long_items, ctl + 3, gate);
         }
-        hipLaunchKernelGGL((rows_short_kernel<T, Mult, Add>), dim3(short_blocks), dim3(256), 0, st, plan->d_rows_list, ctl, area, Ap, Aj,
-                           static_cast<const uint32_t*>(Ax), static_cast<const T*>(v), static_cast<T*>(r), Mult(op_mult), Add(op_add), init, plan->nnz, gate);
+        const bool combine = plan->n_items && plan->n_long > 0;// (rows of several segments: their partials are folded behind the tasks)
+        const bool ride    = combine && knob_u32("SPLAHIP_ROWS_COMBINE_FUSED", 1) != 0;
+        if (!ride)
+            hipLaunchKernelGGL((rows_short_kernel<T, Mult, Add>), dim3(short_blocks), dim3(256), 0, st, plan->d_rows_list, ctl, area, Ap, Aj, static_cast<const uint32_t*>(Ax),
+                               static_cast<const T*>(v), static_cast<T*>(r), Mult(op_mult), Add(op_add), init, plan->nnz, gate);
         hipLaunchKernelGGL((rows_task_kernel<T, Mult, Add>), dim3(task_blocks), dim3(256), 0, st, plan->d_long_items, ctl, plan->d_rows_list, n, area, plan->d_item_row,
                            plan->d_item_k0, Ap, Aj, static_cast<const uint32_t*>(Ax), static_cast<const T*>(v), static_cast<T*>(r), reinterpret_cast<T*>(plan->d_partial),
                            Mult(op_mult), Add(op_add), init, Cfg::kSegFlag, Cfg::kSeg, plan->nnz, gate);
+        if (ride) {// the short rows behind the tasks, the combine pass as the same launch's first workgroups (mxv_rows.hpp)
+            const uint32_t combine_blocks = (plan->n_items + 255) / 256;
+            hipLaunchKernelGGL((rows_short_combine_kernel<Cfg, T, Mult, Add>), dim3(combine_blocks + short_blocks), dim3(256), 0, st, combine_blocks, plan->d_item_row, plan->d_item_k0,
+                               plan->n_items, static_cast<const T*>(mask), reinterpret_cast<const T*>(plan->d_partial), op_select, plan->d_rows_list, ctl, area, Ap, Aj,
+                               static_cast<const uint32_t*>(Ax), static_cast<const T*>(v), static_cast<T*>(r), Mult(op_mult), Add(op_add), init, plan->nnz, gate);
+        }
         {
             const hipError_t le = hipGetLastError();
             if (le != hipSuccess) {
@@ -297,7 +306,7 @@ namespace {
                 return fail(SPLAHIP_ERROR, "selected-rows kernels: %s", hipGetErrorString(le));
             }
         }
-        if (plan->n_items && plan->n_long > 0) {
+        if (combine && !ride) {
             hipLaunchKernelGGL((spmv_combine_kernel<Cfg, T, Add, false>), dim3((plan->n_items + 255) / 256), dim3(256), 0, st, plan->d_item_row, plan->d_item_k0, plan->n_items, Ap,
                                static_cast<const T*>(mask), static_cast<T*>(r), static_cast<uint32_t*>(nullptr), reinterpret_cast<const T*>(plan->d_partial),
                                static_cast<const uint32_t*>(nullptr), Add(op_add), op_select, init, gate);

@@ -620,16 +620,11 @@ namespace splahip {
         }
     }
 
-    // finish rows made of several segment items: strict in-order fold of their partials
+    // finish rows made of several segment items: strict in-order fold of their partials (item i: the first segment of its row does the row)
     template<class C, typename T, class Add, bool VXM>
-    __global__ __launch_bounds__(256) void spmv_combine_kernel(const uint* __restrict__ item_row, const uint* __restrict__ item_k0,
-                                                               uint n_items, const uint* __restrict__ Ap,
-                                                               const T* __restrict__ mask, T* __restrict__ r, uint* __restrict__ touched,
-                                                               const T* __restrict__ partial, const uint* __restrict__ partial_ok,
-                                                               Add add_raw, int op_select, T init, const uint* __restrict__ gate = nullptr) {
-        if (gate != nullptr && gate[3] == 0u) return;
-        const Reassoc<Add> add(add_raw);
-        const uint i = blockIdx.x * 256 + threadIdx.x;
+    __device__ __forceinline__ void spmv_combine_item(uint i, const uint* __restrict__ item_row, const uint* __restrict__ item_k0, uint n_items, const uint* __restrict__ Ap,
+                                                      const T* __restrict__ mask, T* __restrict__ r, uint* __restrict__ touched, const T* __restrict__ partial,
+                                                      const uint* __restrict__ partial_ok, const Reassoc<Add>& add, int op_select, T init) {
         if (i >= n_items) return;
         const uint e0 = item_row[i];
         if (!(e0 & C::kSegFlag)) return;
@@ -655,6 +650,16 @@ namespace splahip {
         } else {
             r[row] = out;
         }
+    }
+    template<class C, typename T, class Add, bool VXM>
+    __global__ __launch_bounds__(256) void spmv_combine_kernel(const uint* __restrict__ item_row, const uint* __restrict__ item_k0,
+                                                               uint n_items, const uint* __restrict__ Ap,
+                                                               const T* __restrict__ mask, T* __restrict__ r, uint* __restrict__ touched,
+                                                               const T* __restrict__ partial, const uint* __restrict__ partial_ok,
+                                                               Add add_raw, int op_select, T init, const uint* __restrict__ gate = nullptr) {
+        if (gate != nullptr && gate[3] == 0u) return;
+        const Reassoc<Add> add(add_raw);
+        spmv_combine_item<C, T, Add, VXM>(blockIdx.x * 256 + threadIdx.x, item_row, item_k0, n_items, Ap, mask, r, touched, partial, partial_ok, add, op_select, init);
     }
 
     // ------------------------------------------------------------------------------------------------------------

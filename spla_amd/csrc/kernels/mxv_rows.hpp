@@ -444,6 +444,22 @@ namespace splahip {
         else
             rows_compact_body<T, SMALL>(b - select_blocks, g - select_blocks, n_rows, Ap, mask, op_select, init, r, list, ctl, area, gate);
     }
+    // the short rows' batches with the combine pass (mxv_kernels.hpp: the rows of several segments, from their partials) as the launch's first workgroups: launched BEHIND
+    // the wave tasks, whose partials it folds — the combine pass as a launch of its own was 5 us at the end of every call with a selected long row
+    template<class C, typename T, class Mult, class Add>
+    __global__ __launch_bounds__(256) void rows_short_combine_kernel(uint32_t combine_blocks, const uint32_t* __restrict__ item_row, const uint32_t* __restrict__ item_k0, uint32_t n_items,
+                                                                     const T* __restrict__ mask, const T* __restrict__ partial, int op_select, const uint32_t* __restrict__ list,
+                                                                     const uint32_t* __restrict__ count, uint32_t area, const uint32_t* __restrict__ Ap, const uint32_t* __restrict__ Aj,
+                                                                     const uint32_t* __restrict__ Ax, const T* __restrict__ v, T* __restrict__ r, Mult mult, Add add, T init, uint32_t nnz,
+                                                                     const uint32_t* __restrict__ gate) {
+        if (blockIdx.x < combine_blocks) {
+            if (gate[3] == 0u) return;
+            const Reassoc<Add> radd(add);
+            spmv_combine_item<C, T, Add, false>(blockIdx.x * 256 + threadIdx.x, item_row, item_k0, n_items, Ap, mask, r, nullptr, partial, nullptr, radd, op_select, init);
+            return;
+        }
+        rows_short_body<T, Mult, Add>(blockIdx.x - combine_blocks, gridDim.x - combine_blocks, list, count, area, Ap, Aj, Ax, v, r, mult, add, init, nnz, gate);
+    }
     // (the passes as launches of their own; compaction and selection apart: SPLAHIP_ROWS_FUSED=0, A/B runs)
     template<typename T>
     __global__ __launch_bounds__(256) void rows_compact_kernel(uint32_t n_rows, const uint32_t* __restrict__ Ap, const T* __restrict__ mask, int op_select, T init, T* __restrict__ r,
