@@ -895,8 +895,8 @@ def test_reference_order_setting_vxm_pull_bit_for_bit(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("t", ["INT", "UINT", "FLOAT"])
-def test_selected_rows_kernels_forced_on_every_mask_shape(oracle, t, monkeypatch):
+@pytest.mark.parametrize("t,compact_blocks", [("INT", None), ("UINT", None), ("FLOAT", None), ("FLOAT", "8"), ("INT", "24")])
+def test_selected_rows_kernels_forced_on_every_mask_shape(oracle, t, compact_blocks, monkeypatch):
     """The selected-rows path (mxv_rows.hpp, round 6: short rows in 64-row batches with a lane per row, medium rows and the long rows' segment items a wavefront each,
     the long rows listed from the plan) forced on whatever the mask (the probe's weights lowered): random 10 % / 90 % of the rows, every 10th row (the reference's
     own perf test, tests/test_mxv.cpp:91-130), long blocks of consecutive rows, only the long rows, only empty rows, one row, everything — on a matrix of 70 003 rows
@@ -907,6 +907,8 @@ def test_selected_rows_kernels_forced_on_every_mask_shape(oracle, t, monkeypatch
     from spla_amd import kernels
     monkeypatch.setenv("SPLAHIP_MASK_ROWS_X10", "1")
     monkeypatch.setenv("SPLAHIP_MASK_LONG_X10", "1")
+    if compact_blocks:  # few compaction workgroups: the lists' eight areas of the row space are all in use on this small matrix (by default: the first one only)
+        monkeypatch.setenv("SPLAHIP_ROWS_COMPACT_BLOCKS", compact_blocks)
     rng = np.random.default_rng(9091)
     n_rows, n_cols = 70003, 50000
     Ap, Aj, Ax = random_csr(rng, n_rows, n_cols, 9, t, skew=True, long_rows=0, long_len=0)
