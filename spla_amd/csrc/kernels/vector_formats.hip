@@ -7,6 +7,7 @@
 // Pure HBM-bound streaming: 4*n bytes read (+ 8*nvals written).
 #include "block_utils.hpp"
 #include "common.hpp"
+#include "scan_post.hpp"
 #include "ops.hpp"
 
 namespace splahip {
@@ -69,11 +70,12 @@ namespace splahip {
         SPLAHIP_TRY(mem.alloc(s, sizeof(uint) * (size_t) (n_chunks + 1)));
         uint*      d_chunk = mem.as<uint>();
         hipLaunchKernelGGL(d2c_count_kernel<T>, dim3(n_chunks), dim3(256), 0, s, static_cast<const T*>(d_dense), n, fill, d_chunk);
-        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, d_chunk, n_chunks);
+        ScanPost sp;
+        (void) scan_launch(d_chunk, n_chunks, s, &sp);// (the count reaches the host from the scan: scan_post.hpp)
         hipLaunchKernelGGL(d2c_write_kernel<T>, dim3(n_chunks), dim3(256), 0, s, static_cast<const T*>(d_dense), n, fill, d_chunk,
                            static_cast<uint*>(d_idx), static_cast<T*>(d_val), limit);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = fetch_words(h_count, d_chunk + n_chunks, 1, s);
+        if (e == hipSuccess) e = scan_total(h_count, d_chunk + n_chunks, sp, s);
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "dense_to_coo failed: %s", hipGetErrorString(e));
         return SPLAHIP_OK;
     }

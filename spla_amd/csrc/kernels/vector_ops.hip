@@ -20,6 +20,7 @@
 // compacted order-preservingly, so it lists the changed entries in the operand's stored order like the reference.
 #include "block_utils.hpp"
 #include "common.hpp"
+#include "scan_post.hpp"
 #include "jit_hooks.hpp"
 #include "ops.hpp"
 
@@ -122,10 +123,11 @@ namespace splahip {
         hipLaunchKernelGGL(eadd_fdb_sparse_apply_kernel<T>, dim3((nvals + 255) / 256), dim3(256), 0, s, nvals, static_cast<T*>(r), vi,
                            static_cast<const T*>(vx), changed, reinterpret_cast<T*>(newval), DynBin(op));
         hipLaunchKernelGGL(changed_count_kernel, dim3(n_chunks), dim3(256), 0, s, changed, nvals, chunk);
-        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk, n_chunks);
+        ScanPost sp;
+        (void) scan_launch(chunk, n_chunks, s, &sp);// (the count reaches the host from the scan: scan_post.hpp)
         hipLaunchKernelGGL(changed_write_kernel, dim3(n_chunks), dim3(256), 0, s, changed, vi, newval, nvals, chunk, fi, static_cast<uint*>(fx));
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = fetch_words(h_count, chunk + n_chunks, 1, s);
+        if (e == hipSuccess) e = scan_total(h_count, chunk + n_chunks, sp, s);
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "v_eadd_fdb (sparse) failed: %s", hipGetErrorString(e));
         return SPLAHIP_OK;
     }
@@ -374,10 +376,11 @@ namespace splahip {
         void* args[]  = {&n, &r, &vi, &vx, &changed, &newval};
         SPLAHIP_TRY(hipModuleLaunchKernel(apply, (nvals + 255u) / 256u, 1, 1, 256, 1, 1, 0, s, args, nullptr));
         hipLaunchKernelGGL(changed_count_kernel, dim3(n_chunks), dim3(256), 0, s, changed, nvals, chunk);
-        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk, n_chunks);
+        ScanPost sp;
+        (void) scan_launch(chunk, n_chunks, s, &sp);// (the count reaches the host from the scan: scan_post.hpp)
         hipLaunchKernelGGL(changed_write_kernel, dim3(n_chunks), dim3(256), 0, s, changed, vi, newval, nvals, chunk, fi, static_cast<uint*>(fx));
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = fetch_words(h_count, chunk + n_chunks, 1, s);
+        if (e == hipSuccess) e = scan_total(h_count, chunk + n_chunks, sp, s);
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "v_eadd_fdb (sparse, user-defined op) failed: %s", hipGetErrorString(e));
         return SPLAHIP_OK;
     }

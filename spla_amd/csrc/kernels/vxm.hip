@@ -15,6 +15,7 @@
 //         non-commutative op_add, because the run order is the reference's fold order.
 #include "block_utils.hpp"
 #include "common.hpp"
+#include "scan_post.hpp"
 #include "jit_hooks.hpp"
 #include "mxv_first_hit.hpp"
 #include "mxv_kernels.hpp"
@@ -634,10 +635,11 @@ namespace splahip {
         }
         // compaction of the touched columns, ascending
         hipLaunchKernelGGL(flag_count_kernel, dim3(n_chunks), dim3(256), 0, s, ws_touched, n_out, ws_chunk);
-        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, ws_chunk, n_chunks);
+        ScanPost sp;
+        (void) scan_launch(ws_chunk, n_chunks, s, &sp);// (the count reaches the host from the scan: scan_post.hpp)
         hipLaunchKernelGGL(flag_write_kernel, dim3(n_chunks), dim3(256), 0, s, ws_touched, ws_outv, n_out, ws_chunk, ri, static_cast<uint*>(rx));
         SPLAHIP_TRY(hipGetLastError());
-        SPLAHIP_TRY(fetch_words(h_count, ws_chunk + n_chunks, 1, s));
+        SPLAHIP_TRY(scan_total(h_count, ws_chunk + n_chunks, sp, s));
         return SPLAHIP_OK;
     }
 
@@ -693,10 +695,11 @@ namespace splahip {
             SPLAHIP_TRY(hipModuleLaunchKernel(column_long, 2048, 1, 1, 256, 1, 1, 0, s, la, nullptr));
         }
         hipLaunchKernelGGL(flag_count_kernel, dim3(n_chunks), dim3(256), 0, s, ws_touched, n_out, ws_chunk);
-        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, ws_chunk, n_chunks);
+        ScanPost sp;
+        (void) scan_launch(ws_chunk, n_chunks, s, &sp);// (the count reaches the host from the scan: scan_post.hpp)
         hipLaunchKernelGGL(flag_write_kernel, dim3(n_chunks), dim3(256), 0, s, ws_touched, ws_outv, n_out, ws_chunk, ri, static_cast<uint*>(rx));
         SPLAHIP_TRY(hipGetLastError());
-        SPLAHIP_TRY(fetch_words(h_count, ws_chunk + n_chunks, 1, s));
+        SPLAHIP_TRY(scan_total(h_count, ws_chunk + n_chunks, sp, s));
         return SPLAHIP_OK;
     }
 
@@ -798,11 +801,18 @@ namespace splahip {
         hipLaunchKernelGGL((push_direct_kernel<T, DynBin, DynBin>), dim3(nvals, share), dim3(256), 0, s, gate, max_products, vi, static_cast<const T*>(vx), Ap, Aj,
                            static_cast<const uint*>(Ax), static_cast<const T*>(mask), op_select, DynBin(op_mult), DynBin(op_add), ws.acc);
         hipLaunchKernelGGL(acc_count_gated_kernel, dim3(n_chunks), dim3(256), 0, s, gate, max_products, ws.acc, n_cols, chunk);
-        hipLaunchKernelGGL(chunk_scan_kernel<1024>, dim3(1), dim3(1024), 0, s, chunk, n_chunks);
+        // the count and the gate words reach the host from the scan (scan_post.hpp: slot 0 the count, slots 1 .. 5 gate[0 .. 4] — gate[3] itself is written by the pass behind)
+        ScanPost sp;
+        (void) scan_launch(chunk, n_chunks, s, &sp, gate, 5);
         hipLaunchKernelGGL(acc_write_reset_kernel, dim3(n_chunks), dim3(256), 0, s, gate, max_products, ws.acc, n_cols, chunk, ri, static_cast<uint*>(rx));
         SPLAHIP_TRY(hipGetLastError());
         uint h[5] = {0, 0, 0, 0, 0};// products lo, hi, unsorted, count, NaN seen
-        SPLAHIP_TRY(fetch_words(h, gate, 5, s));
+        if (sp.posted) {
+            uint w[6] = {0, 0, 0, 0, 0, 0};
+            SPLAHIP_TRY(mailbox_end(w, 6, sp.mt, s));
+            h[0] = w[1], h[1] = w[2], h[2] = w[3], h[3] = w[0], h[4] = w[5];
+        } else
+            SPLAHIP_TRY(fetch_words(h, gate, 5, s));
         h_out[0] = h[3], h_out[1] = h[0], h_out[2] = h[1], h_out[3] = h[2], h_out[4] = h[4];
         return SPLAHIP_OK;
     }
