@@ -478,7 +478,8 @@ def algorithms(args):
     res = {}
 
     def timed(name, fn, reps):
-        fn()  # first call: host COO -> CSR conversion, upload and plans
+        for _ in range(3):  # first calls: host COO -> CSR conversion, upload, plans; the matrix's layout copies arrive with its second / third product
+            fn()
         torch.cuda.synchronize()
         ts = []
         for _ in range(reps):
@@ -493,17 +494,17 @@ def algorithms(args):
     want = oracle.bfs(n, Ap_h, Aj_h, src)
     reached_edges = int(deg[want > 0].sum())
     for label, desc in (("push-pull (default)", None), ("pull only", api.Descriptor(traversal_mode=api.Descriptor.PULL)), ("push only", api.Descriptor(traversal_mode=api.Descriptor.PUSH))):
-        lv, dt = timed(f"bfs {label}", lambda d=desc: api.bfs(A, src, d), 5)
+        lv, dt = timed(f"bfs {label}", lambda d=desc: api.bfs(A, src, d), 21)
         ok = bool(np.array_equal(lv.to_dense() if n <= (1 << 16) else _dense_i(lv, n), want))
         res[f"bfs {label}"] = {"ms": round(dt * 1e3, 3), "gteps": round(reached_edges / dt / 1e9, 3), "levels": int(want.max()), "verified": ok}
     del A
     Wm = api.Matrix.from_lists(I_h, Aj_h, W_h, (n, n), api.FLOAT)
     want = oracle.sssp(n, Ap_h, Aj_h, W_h, src)
-    dv, dt = timed("sssp push-pull", lambda: api.sssp(Wm, src), 3)
+    dv, dt = timed("sssp push-pull", lambda: api.sssp(Wm, src), 11)
     res["sssp push-pull (default)"] = {"ms": round(dt * 1e3, 3), "verified": bool(np.array_equal(_dense_f(dv, n).view(np.uint32), want.view(np.uint32)))}
     del Wm
     Pm = api.Matrix.from_lists(I_h, Aj_h, P_h, (n, n), api.FLOAT)
-    pv, dt = timed("pr alpha 0.85 eps 1e-5", lambda: api.pr(Pm, 0.85, 1e-5), 3)
+    pv, dt = timed("pr alpha 0.85 eps 1e-5", lambda: api.pr(Pm, 0.85, 1e-5), 11)
     want = oracle.pr(n, Ap_h, Aj_h, P_h, 0.85, 1e-5)
     got = _dense_f(pv, n, fill=0.0)
     res["pr alpha 0.85 eps 1e-5"] = {"ms": round(dt * 1e3, 3), "max_abs_vs_oracle": float(np.abs(got - want).max()), "verified": bool(np.allclose(got, want, rtol=1e-3, atol=1e-8))}
