@@ -309,7 +309,8 @@ namespace splahip {
         }
     }
     template<typename T>
-    __global__ __launch_bounds__(256) void reduce_final_kernel(uint n_partial, const T* __restrict__ partial, const uint* __restrict__ partial_ok, T s, T* __restrict__ out, DynBin op_raw) {
+    __global__ __launch_bounds__(256) void reduce_final_kernel(uint n_partial, const T* __restrict__ partial, const uint* __restrict__ partial_ok, T s, T* __restrict__ out, DynBin op_raw,
+                                                               unsigned long long* __restrict__ mailbox, uint mail_seq) {
         const Reassoc<DynBin> op(op_raw);
         __shared__ T   s_val[256 / kWave];
         __shared__ int s_ok[256 / kWave];
@@ -323,7 +324,11 @@ namespace splahip {
                 valid = true;
             }
         block_fold(acc, valid, op, s_val, s_ok);
-        if (threadIdx.x == 0) out[0] = valid ? op(s, acc) : s;
+        if (threadIdx.x == 0) {
+            const T res = valid ? op(s, acc) : s;
+            out[0]      = res;
+            if (mailbox) mailbox_store(mailbox, 0, mail_seq, to_bits(res));// the host waits for this word: posted here, no mailbox launch behind (common.hpp)
+        }
     }
     // one wave: 64 lanes fetch a 1024-element chunk (coalesced), lane 0 folds it in order out of LDS
     template<typename T>
@@ -350,14 +355,18 @@ namespace splahip {
         T*    out     = mem.as<T>();
         T*    partial = out + 1;
         uint* ok      = reinterpret_cast<uint*>(partial + blocks);
+        MailboxTicket mt;
+        bool          posted = false;
         if (fold_is_reorderable(op, TypeId<T>::value) && binop_is_commutative(op)) {
+            const char* pe = knob_env("SPLAHIP_SCAN_POST");// (the knob of the compactions' posted counts: scan_post.hpp)
+            posted         = !(pe && pe[0] == '0') && mailbox_begin(&mt) == hipSuccess;
             hipLaunchKernelGGL(reduce_partial_kernel<T>, dim3(blocks), dim3(256), 0, s, n, static_cast<const T*>(x), partial, ok, DynBin(op));
-            hipLaunchKernelGGL(reduce_final_kernel<T>, dim3(1), dim3(256), 0, s, blocks, partial, ok, from_bits<T>(s_bits), out, DynBin(op));
+            hipLaunchKernelGGL(reduce_final_kernel<T>, dim3(1), dim3(256), 0, s, blocks, partial, ok, from_bits<T>(s_bits), out, DynBin(op), posted ? mt.dev : nullptr, mt.seq);
         } else {
             hipLaunchKernelGGL(reduce_sequential_kernel<T>, dim3(1), dim3(64), 0, s, n, static_cast<const T*>(x), from_bits<T>(s_bits), out, DynBin(op));
         }
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = fetch_words(h_result, out, 1, s);
+        if (e == hipSuccess) e = posted ? mailbox_end(h_result, 1, mt, s) : fetch_words(h_result, out, 1, s);
         if (e != hipSuccess) return fail(SPLAHIP_ERROR, "reduce failed: %s", hipGetErrorString(e));
         return SPLAHIP_OK;
     }
